@@ -1,0 +1,216 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the MI355X-native MockingBird hot path.
+
+Metric (BASELINE.json): audio samples/s (16 kHz) and xRT.  Workload at N=1 = BASELINE
+configs[1]: WaveRNN 9-bit mu-law, batch 1, (80, 1000) mel, batched generation (target 8000 /
+overlap 800 -> 23 folds x 9600 steps).  One "step" = one full infer_waveform-equivalent pass
+(conditioning networks + sample loop + device->host + float64 post-processing) over one
+utterance per GPU, mel already resident in HBM.  N>1: every rank vocodes its own utterance
+(weak scaling, no data-path collective) and finished waveforms are gathered to all ranks with
+RCCL (lengths + padded waveforms), inside the timed region.
+
+Also reports (same JSON line): roofline of the dominant loop kernel (HBM bound on the fp32
+weights), the CPU baseline (oracle = the reference's ATen-CPU arithmetic) on a bounded sample,
+and a secondary HiFi-GAN line (batch 32 x (80,200), MFMA bound).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA dense peak
+HIFIGAN_MFLOP_PER_FRAME = 352.1
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=1000, help="mel frames per utterance (BASELINE configs[1]: 1000)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hifigan", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    import torch.distributed as dist
+    use_dist = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mockingbird_amd import build, _lib
+    if rank == 0:
+        build.build(verbose=False)
+    if use_dist:
+        dist.barrier()
+    import synth
+    from mockingbird_amd.vocoder.wavernn.inference import WaveRNNDevice
+    from mockingbird_amd.vocoder.wavernn import dsp
+    from mockingbird_amd import sharding
+
+    state = synth.wavernn_state(seed=5)["model_state"]
+    model = WaveRNNDevice(state)
+    F = args.frames
+    target, overlap = 8000, 800
+    # each rank owns one utterance (seed differs per rank), already resident in HBM
+    mel = torch.from_numpy(synth.wavernn_mel(F, seed=1 + rank) / 4.0).to(dev)
+    wave_len = (F - 1) * model.hop_length
+
+    def one_pass(seed):
+        samples = model.generate_samples(mel, True, target, overlap, seed=seed)
+        wav = dsp.finish(samples.cpu().numpy(), True, overlap, model.n_classes, True, True, 0.97, wave_len,
+                         model.hop_length)
+        if use_dist:
+            wavs = sharding.gather_waveforms([wav.astype(np.float32)], dev)
+            return wav, sum(len(w) for w in wavs)
+        return wav, len(wav)
+
+    for i in range(args.warmup):
+        one_pass(1000 + i)
+    loop_ms = []
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    total_samples = 0
+    for i in range(args.steps):
+        wav, n = one_pass(i)
+        total_samples += n
+        loop_ms.append(model.last_loop_ms)
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    else:
+        total_samples = total_samples  # single rank: its own utterance
+    plan = model.last_plan
+    value = total_samples / elapsed
+    result = {
+        "metric": "audio samples/sec (16 kHz), WaveRNN vocoder.infer_waveform",
+        "value": value, "unit": "samples/s", "x_realtime": value / 16000.0,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1000.0, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: WaveRNN 9-bit mu-law RAW, batch=1 utterance/GPU, "
+                               f"mel 80x{F}, batched target=8000 overlap=800 -> {plan.n_folds} folds x "
+                               f"{plan.seq_len} steps, Philox sampling, fp32 weights (synthetic, seeded)",
+                   "samples_per_utterance": int(len(wav)), "utterances": world,
+                   "sample_loop_ms": float(np.median(loop_ms)),
+                   "us_per_time_step": float(np.median(loop_ms)) * 1000.0 / plan.seq_len},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant loop kernel: rnn_rowtile_kernel<GRU> (rnn1), HBM/L2-bound on weights
+        L = _lib.lib()
+        ws = model._ws
+        smp = torch.empty(plan.n_folds, plan.seq_len, device=dev)
+        per_kernel = {}
+        for which, name in enumerate(["rnn1_gru", "rnn2_gru", "fc1", "fc2", "fc3"]):
+            us, ab = C.c_float(), C.c_double()
+            _lib.check(L.mb_wavernn_bench_kernel(model._h, C.byref(plan), _lib.ptr(mel), _lib.ptr(smp),
+                                                 _lib.ptr(ws), ws.numel(), which, 2000, C.byref(us), C.byref(ab),
+                                                 _lib.stream_ptr()), "mb_wavernn_bench_kernel")
+            torch.cuda.synchronize()
+            per_kernel[name] = {"avg_us": us.value, "algorithmic_bytes": ab.value,
+                                "GBps": ab.value / (us.value * 1e-6) / 1e9}
+        dom = per_kernel["rnn1_gru"]
+        result["roofline"] = {
+            "kernel": "mb::rnn_rowtile_kernel<EPI_GRU> (WaveRNN rnn1 step)",
+            "bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_launch": dom["algorithmic_bytes"], "avg_launch_us": dom["avg_us"],
+            "whole_step": {"algorithmic_bytes": 16.3e6 + 452.0 * plan.n_folds,
+                           "us": result["config"]["us_per_time_step"],
+                           "GBps": (16.3e6 + 452.0 * plan.n_folds) / (result["config"]["us_per_time_step"] * 1e-6) / 1e9},
+            "per_kernel": per_kernel,
+        }
+        # ---- secondary: HiFi-GAN generator, batch 32 x (80, 200)
+        if not args.no_hifigan:
+            from mockingbird_amd.vocoder.gan import GanGenerator
+            h = synth.HIFIGAN_16K
+            gen = GanGenerator(h, synth.gan_state(h, "hifigan", seed=3)["generator"], 0)
+            gm = torch.from_numpy(synth.mel_input(200, 32, seed=0)).to(dev)
+            for _ in range(2):
+                gen(gm)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 5
+            e0.record()
+            for _ in range(reps):
+                y = gen(gm)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            flops = HIFIGAN_MFLOP_PER_FRAME * 1e6 * 200 * 32
+            result["hifigan"] = {
+                "workload": "HiFi-GAN V1 16k generator forward, batch 32 x mel (80,200), fp32 MFMA",
+                "value": 32 * 200 * 200 / (ms * 1e-3), "unit": "samples/s",
+                "x_realtime": 32 * 200 * 200 / (ms * 1e-3) / 16000.0, "ms_per_batch": ms,
+                "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
+                             "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                             "traffic": None},
+            }
+        # ---- CPU baseline: the oracle (reference's ATen CPU arithmetic) on a bounded sample
+        if not args.no_cpu_baseline:
+            from oracle import wavernn as ow
+            ncores = os.cpu_count() or 1
+            torch.set_num_threads(ncores)
+            w = dict(state)
+            cf = 100  # conditioning for a 100-frame prefix is enough for the bounded sample
+            with torch.no_grad():
+                mels, aux = ow.conditioning(w, ow.HP, torch.from_numpy(synth.wavernn_mel(F, seed=1)[None, :, :] / 4.0),
+                                            True, target, overlap)
+                nf = mels.shape[0]
+                t0c = time.perf_counter()
+                steps_done = 0
+                chunk = 50
+                while time.perf_counter() - t0c < args.cpu_seconds and steps_done < mels.shape[1]:
+                    # fresh state per chunk is irrelevant for timing; same arithmetic per step
+                    ow.sample_loop(w, ow.HP, mels[:, steps_done:steps_done + chunk], aux[:, steps_done:steps_done + chunk])
+                    steps_done += chunk
+                tc = time.perf_counter() - t0c
+            raw_rate = nf * steps_done / tc
+            useful = len(wav) / float(plan.n_folds * plan.seq_len)
+            result["cpu_baseline"] = {
+                "value": raw_rate * useful, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"oracle sample loop (reference ATen-CPU ops), {nf} folds x {steps_done} steps of the same "
+                          f"workload in {tc:.1f} s; raw {raw_rate:.0f} fold-steps/s scaled by the useful-sample "
+                          f"fraction {useful:.3f}",
+            }
+        print(json.dumps(result))
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

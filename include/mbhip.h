@@ -1,0 +1,253 @@
+/*
+ * mbhip.h -- C ABI of libmbhip.so: the MI355X (gfx950) native hot path of
+ * babysor/MockingBird (mel synthesis + waveform vocoding + monotonic_align).
+ *
+ * The reference has no FFI layer of its own: its boundary is a
+ * set of Python callables.  Every entry point below is what a binding for
+ * that boundary would call; the reference interface each one replaces is
+ * cited as file:line relative to the MockingBird repository.
+ *
+ * Conventions
+ *  - All `d_*` pointers are DEVICE pointers (HBM, fp32 unless stated); all
+ *    `h_*` pointers are HOST pointers.  No torch types cross this boundary.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  All
+ *    work is enqueued asynchronously on it; nothing here synchronises the
+ *    device except the *_create functions (weight upload) and where stated.
+ *  - Functions return 0 on success, a negative MB_E* code on failure;
+ *    mb_last_error() returns a thread-local description.
+ *  - Handles own their device weights (hipMalloc); workspaces are caller
+ *    owned so the caller's allocator (e.g. torch's caching allocator) decides
+ *    placement.  Query the size first.
+ */
+#ifndef MBHIP_H
+#define MBHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MB_OK 0
+#define MB_EINVAL (-1)   /* bad argument / shape */
+#define MB_EHIP (-2)     /* HIP runtime error (see mb_last_error) */
+#define MB_ENOMEM (-3)   /* workspace too small / allocation failed */
+#define MB_ESTATE (-4)   /* handle not usable */
+
+typedef void* mb_stream_t;
+
+const char* mb_last_error(void);
+int mb_abi_version(void);
+
+/* ------------------------------------------------------------------------
+ * 1. Conv1d / ConvTranspose1d primitive (fp32 MFMA implicit GEMM).
+ *    Building block of every conv stack on the path; exported so the parity
+ *    tests can exercise it per layer.
+ *    Replaces: torch.nn.Conv1d / ConvTranspose1d as used in
+ *      models/vocoder/hifigan/models.py:11-48,120-123,134-150
+ *      models/vocoder/fregan/generator.py:11-52,98-120,137-166
+ *      models/synthesizer/models/sublayer/common/batch_norm_conv.py:4-14
+ *      models/vocoder/wavernn/models/fatchord_version.py:9-44
+ * ---------------------------------------------------------------------- */
+
+/* Number of floats of the packed (MFMA A-fragment ordered) weight image. */
+size_t mb_conv1d_packed_floats(int c_out, int c_in, int ksize, int up);
+
+/* Pack torch-layout weights on the host.
+ *  transposed == 0: h_w is Conv1d weight   [c_out][c_in][ksize], up must be 1
+ *  transposed == 1: h_w is ConvTranspose1d [c_in][c_out][ksize], stride = up,
+ *                   padding = pad (ksize must be a multiple of up). */
+int mb_conv1d_pack(const float* h_w, int c_out, int c_in, int ksize, int up,
+                   int transposed, int pad, float* h_packed);
+
+typedef struct mb_conv1d_args {
+  const float* d_x;       /* [B][c_in][t_in] (batch stride x_bstride floats)     */
+  const float* d_wpacked; /* image from mb_conv1d_pack                            */
+  const float* d_bias;    /* [c_out] or NULL                                      */
+  const float* d_res;     /* residual, same layout as y, or NULL                  */
+  const float* d_post_scale; /* [c_out] or NULL: y = act(.)*scale + shift (BN)   */
+  const float* d_post_shift;
+  float* d_y;             /* [B][c_out][t_out], or [B][t_out][c_out] if transpose_out */
+  long long x_bstride, y_bstride, res_bstride;
+  int batch, c_in, c_out, t_in, t_out;
+  int ksize, dilation, pad; /* conv: padding; transposed conv: torch `padding`   */
+  int up;                 /* 1 = Conv1d, >1 = ConvTranspose1d with stride up      */
+  int in_act;             /* 0 none, 1 leaky_relu(in_slope) applied to x on load  */
+  float in_slope;
+  float in_scale;         /* x is multiplied by this before in_act (0 or 1.0 = none) */
+  int out_act;            /* 0 none, 1 relu, 2 tanh, 3 sigmoid                    */
+  float out_scale;        /* result *= out_scale after the residual add (0 or 1.0 = none) */
+  int accumulate;         /* y += result instead of y = result                    */
+  int in_repeat;          /* >1: x is read through nearest-neighbour upsampling,
+                             source index = t / in_repeat (t_in counts upsampled
+                             positions); fregan/generator.py:104-110            */
+  int transpose_out;      /* store y[b][t][c_out] (time-major)                    */
+} mb_conv1d_args;
+
+int mb_conv1d(const mb_conv1d_args* a, mb_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * 2. GAN vocoders: HiFi-GAN and Fre-GAN generator forward.
+ *    Replaces: Generator.forward  models/vocoder/hifigan/models.py:134-150
+ *              FreGAN.forward     models/vocoder/fregan/generator.py:137-166
+ *    behind infer_waveform        models/vocoder/{hifigan,fregan}/inference.py:60-74
+ * ---------------------------------------------------------------------- */
+#define MB_GAN_HIFIGAN 0
+#define MB_GAN_FREGAN 1
+#define MB_GAN_MAX_UPS 8
+#define MB_GAN_MAX_KERNELS 4
+#define MB_GAN_MAX_DIL 4
+
+typedef struct mb_gan_config {
+  int kind;                 /* MB_GAN_HIFIGAN | MB_GAN_FREGAN                    */
+  int num_mels;             /* 80                                                */
+  int upsample_initial_channel;
+  int num_upsamples;
+  int upsample_rates[MB_GAN_MAX_UPS];
+  int upsample_kernel_sizes[MB_GAN_MAX_UPS];
+  int num_kernels;          /* resblocks per stage                               */
+  int resblock_kernel_sizes[MB_GAN_MAX_KERNELS];
+  int num_dilations;        /* convs1/convs2 pairs per resblock (3 or 4)         */
+  int resblock_dilations[MB_GAN_MAX_KERNELS][MB_GAN_MAX_DIL];
+  int top_k;                /* Fre-GAN only (generator.py:80), default 4         */
+} mb_gan_config;
+
+typedef struct mb_gan mb_gan;
+
+/* Number of weight tensors mb_gan_create expects and, for tensor i, its
+ * element count.  Tensors are the reference module's parameters with
+ * weight_g/weight_v folded to `weight` (what remove_weight_norm() leaves,
+ * hifigan/models.py:152-162), each conv as (weight, bias), in this order:
+ *   conv_pre, ups[0..], [fregan: cond_up[0..], res_output[0..].1],
+ *   resblocks[0..]: convs1[0..] then convs2[0..], conv_post.
+ * See mockingbird_amd/weights.py:gan_weight_list. */
+int mb_gan_num_weights(const mb_gan_config* cfg);
+size_t mb_gan_weight_numel(const mb_gan_config* cfg, int index);
+
+int mb_gan_create(const mb_gan_config* cfg, const float* const* h_weights,
+                  int n_weights, mb_gan** out);
+void mb_gan_destroy(mb_gan* g);
+int mb_gan_hop(const mb_gan* g);                 /* product of upsample rates   */
+size_t mb_gan_workspace_bytes(const mb_gan* g, int batch, int frames);
+/* d_mel [batch][num_mels][frames] -> d_wav [batch][frames*hop] */
+int mb_gan_forward(const mb_gan* g, const float* d_mel, int batch, int frames,
+                   float* d_wav, void* d_workspace, size_t workspace_bytes,
+                   mb_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * 3. WaveRNN (fatchord) vocoder.
+ *    Replaces: WaveRNN.generate  models/vocoder/wavernn/models/fatchord_version.py:153-257
+ *    (UpsampleNetwork :60-85, fold_with_overlap :288-338, sample loop :190-234)
+ *    behind infer_waveform       models/vocoder/wavernn/inference.py:45-64
+ * ---------------------------------------------------------------------- */
+typedef struct mb_wavernn_config {
+  int rnn_dims, fc_dims, bits, pad;
+  int n_upsample; int upsample_factors[4];
+  int feat_dims, compute_dims, res_out_dims, res_blocks;
+  int mode;  /* 0 = RAW (softmax over 2^bits classes); MOL is not on the hot path */
+} mb_wavernn_config;
+
+typedef struct mb_wavernn mb_wavernn;
+
+/* Weight tensors in state_dict() order of the reference WaveRNN module
+ * (fatchord_version.py:88-122), BatchNorm as (weight,bias,running_mean,
+ * running_var); see mockingbird_amd/weights.py:wavernn_weight_list. */
+int mb_wavernn_num_weights(const mb_wavernn_config* cfg);
+size_t mb_wavernn_weight_numel(const mb_wavernn_config* cfg, int index);
+int mb_wavernn_create(const mb_wavernn_config* cfg, const float* const* h_weights,
+                      int n_weights, mb_wavernn** out);
+void mb_wavernn_destroy(mb_wavernn* w);
+
+/* Geometry of one generate() call: `frames` mel frames (unpadded) produce
+ * total_len = frames*prod(upsample_factors) conditioning positions, cut into
+ * n_folds windows of seq_len steps (batched) or 1 x total_len (unbatched). */
+typedef struct mb_wavernn_plan {
+  int frames, total_len, n_folds, seq_len, fold_stride; /* fold_stride = target+overlap */
+  size_t workspace_bytes;
+} mb_wavernn_plan;
+int mb_wavernn_plan_generate(const mb_wavernn* w, int frames, int batched, int target,
+                             int overlap, mb_wavernn_plan* plan);
+
+/* d_mel: [feat_dims][frames] (already divided by max_abs_value if the caller
+ *        normalises, inference.py:60-61).
+ * d_noise: NULL -> on-device counter RNG (seed); else Exp(1) draws
+ *        [seq_len][n_folds][n_classes] consumed exactly like
+ *        torch.multinomial(p,1) == argmax(p / noise).
+ * d_samples: [n_folds][seq_len] float32 in [-1,1] (2*k/(C-1)-1), the tensor the
+ *        reference stacks at fatchord_version.py:236.
+ * d_logits_out: optional [seq_len][n_folds][n_classes] dump of fc3 outputs (tests).
+ * d_forced: optional teacher forcing: [n_folds][seq_len] samples fed back
+ *        instead of the drawn ones (tests).
+ * h_progress: optional host-visible (pinned/host-coherent) int32 the kernels
+ *        update with the number of completed steps (progress_callback support). */
+int mb_wavernn_generate(const mb_wavernn* w, const mb_wavernn_plan* plan,
+                        const float* d_mel, const float* d_noise, uint64_t seed,
+                        float* d_samples, float* d_logits_out, const float* d_forced,
+                        int* h_progress, void* d_workspace, size_t workspace_bytes,
+                        mb_stream_t stream);
+/* time (ms) the sample-loop kernels of the LAST generate call took, measured
+ * with hipEvents on `stream` (valid after the stream is synchronised), and the
+ * number of kernel launches in it. */
+int mb_wavernn_last_loop_ms(const mb_wavernn* w, float* ms, int* launches);
+/* Measurement hook (bench.py roofline leg): runs the conditioning + init of a
+ * generate call, then re-launches ONE kernel of the sample loop `iters` times
+ * between two hipEvents on the stream it is launched on.  which: 0 rnn1 GRU,
+ * 1 rnn2 GRU, 2 fc1, 3 fc2, 4 fc3.  Reports the average duration
+ * and that launch's algorithmic bytes (weights once + vectors in/out, fp32). */
+int mb_wavernn_bench_kernel(mb_wavernn* w, const mb_wavernn_plan* plan, const float* d_mel,
+                            float* d_samples, void* d_workspace, size_t workspace_bytes,
+                            int which, int iters, float* avg_us, double* algorithmic_bytes,
+                            mb_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * 4. Tacotron decoder loop + CBHG postnet.
+ *    Replaces: Decoder.forward loop  models/synthesizer/models/tacotron.py:71-138,264-275
+ *              CBHG + post_proj      models/synthesizer/models/sublayer/cbhg.py:40-84,
+ *                                    tacotron.py:281-283
+ *    behind Synthesizer.synthesize_spectrograms models/synthesizer/inference.py:75-142
+ * ---------------------------------------------------------------------- */
+typedef struct mb_taco_config {
+  int n_mels, project_dims, decoder_dims, lstm_dims, max_r, r;
+  int postnet_dims, postnet_K, num_highways;
+  int lsa_kernel, lsa_filters;
+} mb_taco_config;
+typedef struct mb_taco mb_taco;
+int mb_taco_num_weights(const mb_taco_config* cfg);
+size_t mb_taco_weight_numel(const mb_taco_config* cfg, int index);
+int mb_taco_create(const mb_taco_config* cfg, const float* const* h_weights,
+                   int n_weights, mb_taco** out);
+void mb_taco_destroy(mb_taco* t);
+size_t mb_taco_workspace_bytes(const mb_taco* t, int batch, int t_text, int max_steps);
+/* Runs the autoregressive decoder until the reference's batch-wide stop rule
+ * fires (tacotron.py:275) or max_steps frames are produced, then the postnet.
+ *  d_memory      [B][T][project_dims]  encoder_seq after speaker/GST concat
+ *  d_memory_proj [B][T][decoder_dims]  encoder_proj(encoder_seq)
+ *  d_chars       [B][T] int32 token ids (0 = padding, lsa.py:34)
+ *  d_dropout     NULL -> on-device RNG(seed); else Bernoulli(0.5) keep masks
+ *                [n_iter][2][B][2*decoder_dims] (1.0 keep / 0.0 drop) drawn in
+ *                the reference's program order (pre_net.py:23,26)
+ *  d_mel         [B][n_mels][max_steps] decoder mel_outputs (cat of frames)
+ *  d_linear      [B][n_mels][max_steps] postnet output (what generate returns)
+ *  d_attn        [B][max_steps/r][T]
+ *  h_n_frames    host int: frames actually produced (synchronises the stream) */
+int mb_taco_decode(const mb_taco* t, const float* d_memory, const float* d_memory_proj,
+                   const int32_t* d_chars, int batch, int t_text, int max_steps,
+                   float min_stop_token, const float* d_dropout, uint64_t seed,
+                   float* d_mel, float* d_linear, float* d_attn, int* h_n_frames,
+                   void* d_workspace, size_t workspace_bytes, mb_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * 5. monotonic_align.maximum_path
+ *    Replaces: maximum_path_c  monotonic_align/core.pyx:38-42 (and :7-33)
+ *    d_values float32 [b][t_t][t_s] is mutated in place exactly like the
+ *    Cython code mutates `value`; d_paths int32 [b][t_t][t_s] must be zeroed
+ *    by the caller (monotonic_align/__init__.py:13 allocates zeros).
+ * ---------------------------------------------------------------------- */
+int mb_maximum_path(int32_t* d_paths, float* d_values, const int32_t* d_t_ys,
+                    const int32_t* d_t_xs, int b, int t_t, int t_s, mb_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MBHIP_H */

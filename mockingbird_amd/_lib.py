@@ -1,0 +1,161 @@
+"""ctypes binding of libmbhip.so (the C ABI declared in include/mbhip.h).
+
+There is NO fallback: if the shared object is missing or fails to load the
+import raises, and every call that returns a negative code raises
+``MbHipError`` with the library's message.  The oracle under ``oracle/`` is
+test infrastructure only and is never imported from here.
+"""
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("MBHIP_LIB", _HERE / "libmbhip.so"))
+
+
+class MbHipError(RuntimeError):
+    pass
+
+
+MB_GAN_MAX_UPS, MB_GAN_MAX_KERNELS, MB_GAN_MAX_DIL = 8, 4, 4
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [
+        ("d_x", C.c_void_p), ("d_wpacked", C.c_void_p), ("d_bias", C.c_void_p),
+        ("d_res", C.c_void_p), ("d_post_scale", C.c_void_p), ("d_post_shift", C.c_void_p),
+        ("d_y", C.c_void_p),
+        ("x_bstride", C.c_longlong), ("y_bstride", C.c_longlong), ("res_bstride", C.c_longlong),
+        ("batch", C.c_int), ("c_in", C.c_int), ("c_out", C.c_int), ("t_in", C.c_int),
+        ("t_out", C.c_int),
+        ("ksize", C.c_int), ("dilation", C.c_int), ("pad", C.c_int), ("up", C.c_int),
+        ("in_act", C.c_int), ("in_slope", C.c_float), ("in_scale", C.c_float),
+        ("out_act", C.c_int), ("out_scale", C.c_float), ("accumulate", C.c_int),
+        ("in_repeat", C.c_int), ("transpose_out", C.c_int),
+    ]
+
+
+class GanConfig(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int), ("num_mels", C.c_int), ("upsample_initial_channel", C.c_int),
+        ("num_upsamples", C.c_int),
+        ("upsample_rates", C.c_int * MB_GAN_MAX_UPS),
+        ("upsample_kernel_sizes", C.c_int * MB_GAN_MAX_UPS),
+        ("num_kernels", C.c_int),
+        ("resblock_kernel_sizes", C.c_int * MB_GAN_MAX_KERNELS),
+        ("num_dilations", C.c_int),
+        ("resblock_dilations", (C.c_int * MB_GAN_MAX_DIL) * MB_GAN_MAX_KERNELS),
+        ("top_k", C.c_int),
+    ]
+
+
+class WaveRNNConfig(C.Structure):
+    _fields_ = [
+        ("rnn_dims", C.c_int), ("fc_dims", C.c_int), ("bits", C.c_int), ("pad", C.c_int),
+        ("n_upsample", C.c_int), ("upsample_factors", C.c_int * 4),
+        ("feat_dims", C.c_int), ("compute_dims", C.c_int), ("res_out_dims", C.c_int),
+        ("res_blocks", C.c_int), ("mode", C.c_int),
+    ]
+
+
+class WaveRNNPlan(C.Structure):
+    _fields_ = [
+        ("frames", C.c_int), ("total_len", C.c_int), ("n_folds", C.c_int), ("seq_len", C.c_int),
+        ("fold_stride", C.c_int), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+class TacoConfig(C.Structure):
+    _fields_ = [
+        ("n_mels", C.c_int), ("project_dims", C.c_int), ("decoder_dims", C.c_int),
+        ("lstm_dims", C.c_int), ("max_r", C.c_int), ("r", C.c_int),
+        ("postnet_dims", C.c_int), ("postnet_K", C.c_int), ("num_highways", C.c_int),
+        ("lsa_kernel", C.c_int), ("lsa_filters", C.c_int),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol include/mbhip.h declares
+# (tests/test_abi.py checks this table against the header and the .so).
+_PP = C.POINTER(C.c_void_p)
+SIGNATURES = {
+    "mb_last_error": (C.c_char_p, []),
+    "mb_abi_version": (C.c_int, []),
+    "mb_conv1d_packed_floats": (C.c_size_t, [C.c_int] * 4),
+    "mb_conv1d_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_void_p]),
+    "mb_conv1d": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "mb_gan_num_weights": (C.c_int, [C.POINTER(GanConfig)]),
+    "mb_gan_weight_numel": (C.c_size_t, [C.POINTER(GanConfig), C.c_int]),
+    "mb_gan_create": (C.c_int, [C.POINTER(GanConfig), _PP, C.c_int, _PP]),
+    "mb_gan_destroy": (None, [C.c_void_p]),
+    "mb_gan_hop": (C.c_int, [C.c_void_p]),
+    "mb_gan_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    "mb_gan_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                 C.c_size_t, C.c_void_p]),
+    "mb_wavernn_num_weights": (C.c_int, [C.POINTER(WaveRNNConfig)]),
+    "mb_wavernn_weight_numel": (C.c_size_t, [C.POINTER(WaveRNNConfig), C.c_int]),
+    "mb_wavernn_create": (C.c_int, [C.POINTER(WaveRNNConfig), _PP, C.c_int, _PP]),
+    "mb_wavernn_destroy": (None, [C.c_void_p]),
+    "mb_wavernn_plan_generate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.POINTER(WaveRNNPlan)]),
+    "mb_wavernn_generate": (C.c_int, [C.c_void_p, C.POINTER(WaveRNNPlan), C.c_void_p, C.c_void_p,
+                                      C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mb_wavernn_last_loop_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "mb_wavernn_bench_kernel": (C.c_int, [C.c_void_p, C.POINTER(WaveRNNPlan), C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_float),
+                                          C.POINTER(C.c_double), C.c_void_p]),
+    "mb_taco_num_weights": (C.c_int, [C.POINTER(TacoConfig)]),
+    "mb_taco_weight_numel": (C.c_size_t, [C.POINTER(TacoConfig), C.c_int]),
+    "mb_taco_create": (C.c_int, [C.POINTER(TacoConfig), _PP, C.c_int, _PP]),
+    "mb_taco_destroy": (None, [C.c_void_p]),
+    "mb_taco_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "mb_taco_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                 C.c_int, C.c_float, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mb_maximum_path": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                  C.c_int, C.c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes library; raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise MbHipError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or python -m mockingbird_amd.build). "
+                "There is no CPU fallback.")
+        l = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what=""):
+    if rc is not None and rc < 0:
+        msg = lib().mb_last_error()
+        raise MbHipError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+    return rc
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def host_ptr_array(tensors):
+    """(void*[]) over contiguous float32 CPU tensors; keeps them alive via the return."""
+    arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr

@@ -1,0 +1,95 @@
+// Shared host/device helpers for libmbhip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/mbhip.h"
+
+namespace mb {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define MB_HIP(expr)                                                     \
+  do {                                                                   \
+    hipError_t _e = (expr);                                              \
+    if (_e != hipSuccess) return ::mb::hip_fail(_e, #expr, __FILE__, __LINE__); \
+  } while (0)
+
+#define MB_REQUIRE(cond, ...)            \
+  do {                                   \
+    if (!(cond)) {                       \
+      ::mb::set_error(__VA_ARGS__);      \
+      return MB_EINVAL;                  \
+    }                                    \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Simple bump allocator over a caller-provided workspace.
+struct Arena {
+  char* base;
+  size_t cap, off;
+  Arena(void* p, size_t c) : base((char*)p), cap(c), off(0) {}
+  template <typename T>
+  T* take(size_t n) {
+    size_t o = align_up(off, 256);
+    off = o + n * sizeof(T);
+    return (T*)(base ? base + o : nullptr);
+  }
+  bool ok() const { return off <= cap; }
+};
+
+// Device buffer owned by a handle.
+struct DevBuf {
+  float* p = nullptr;
+  size_t n = 0;
+  int upload(const float* h, size_t count);
+  int alloc(size_t count);
+  void release();
+};
+
+// wave-level reductions (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Philox4x32-10 counter RNG (Salmon et al. 2011), used for the on-device
+// sampling / dropout streams when no noise tensor is injected.
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                           uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// uniform in (0,1]
+__device__ __forceinline__ float u32_to_unit(uint32_t x) {
+  return ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f);
+}
+
+}  // namespace mb

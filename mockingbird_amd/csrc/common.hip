@@ -1,0 +1,44 @@
+// Error reporting, device buffers and ABI version for libmbhip.
+#include "common.h"
+
+namespace mb {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  set_error("HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+  return MB_EHIP;
+}
+
+int DevBuf::alloc(size_t count) {
+  release();
+  n = count;
+  if (count == 0) return MB_OK;
+  MB_HIP(hipMalloc((void**)&p, count * sizeof(float)));
+  return MB_OK;
+}
+
+int DevBuf::upload(const float* h, size_t count) {
+  int rc = alloc(count);
+  if (rc) return rc;
+  if (count) MB_HIP(hipMemcpy(p, h, count * sizeof(float), hipMemcpyHostToDevice));
+  return MB_OK;
+}
+
+void DevBuf::release() {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  n = 0;
+}
+
+}  // namespace mb
+
+extern "C" const char* mb_last_error(void) { return mb::g_err; }
+extern "C" int mb_abi_version(void) { return 1; }

@@ -1,0 +1,290 @@
+// HiFi-GAN / Fre-GAN generator forward as a chain of fused MFMA conv launches.
+//
+// Reference semantics:
+//   HiFi-GAN  Generator.forward  models/vocoder/hifigan/models.py:134-150
+//   Fre-GAN   FreGAN.forward     models/vocoder/fregan/generator.py:137-166
+//
+// Every leaky-relu, bias, residual add, the "sum of resblocks / num_kernels"
+// average and the final tanh are folded into the producing / consuming conv
+// kernel (conv1d.hip), so activations make exactly one HBM round trip per
+// conv.  Activation layout is the reference's [B][C][T] (time contiguous).
+#include "common.h"
+
+namespace mb {
+
+struct ConvSpec {
+  int c_out, c_in, k, stride, pad, dil, transposed;
+};
+
+struct ConvW {
+  ConvSpec s;
+  DevBuf w, b;
+};
+
+static int get_padding(int k, int d) { return (k * d - d) / 2; }  // utils/util.py:60-61
+
+// Conv list in ABI weight order (see mbhip.h).
+static int gan_specs(const mb_gan_config* c, std::vector<ConvSpec>* out) {
+  MB_REQUIRE(c, "gan: null config");
+  MB_REQUIRE(c->num_upsamples >= 1 && c->num_upsamples <= MB_GAN_MAX_UPS, "gan: num_upsamples");
+  MB_REQUIRE(c->num_kernels >= 1 && c->num_kernels <= MB_GAN_MAX_KERNELS, "gan: num_kernels");
+  MB_REQUIRE(c->num_dilations >= 1 && c->num_dilations <= MB_GAN_MAX_DIL, "gan: num_dilations");
+  const int uic = c->upsample_initial_channel;
+  out->clear();
+  out->push_back({uic, c->num_mels, 7, 1, 3, 1, 0});  // conv_pre
+  for (int i = 0; i < c->num_upsamples; ++i) {
+    const int u = c->upsample_rates[i], k = c->upsample_kernel_sizes[i];
+    MB_REQUIRE(u >= 1 && u <= 8 && k % u == 0, "gan: upsample %d: rate %d kernel %d", i, u, k);
+    MB_REQUIRE(k - 2 * (u / 2 + u % 2) + u % 2 == u, "gan: upsample %d is not an exact x%d", i, u);
+    out->push_back({uic >> (i + 1), uic >> i, k, u, u / 2 + u % 2, 1, 1});
+  }
+  if (c->kind == MB_GAN_FREGAN) {
+    const int lvl = c->num_upsamples - c->top_k;  // cond_level (generator.py:89)
+    MB_REQUIRE(lvl >= 1, "fregan: top_k must be < num_upsamples");
+    int kr = c->num_mels;
+    for (int i = lvl; i < c->num_upsamples; ++i) {  // cond_up (generator.py:111-118)
+      const int u = c->upsample_rates[i - 1], k = c->upsample_kernel_sizes[i - 1];
+      out->push_back({uic >> i, kr, k, u, u / 2 + u % 2, 1, 1});
+      kr = uic >> i;
+    }
+    for (int i = lvl + 1; i < c->num_upsamples; ++i)  // res_output (generator.py:103-110)
+      out->push_back({uic >> (i + 1), uic >> i, 1, 1, 0, 1, 0});
+  }
+  for (int i = 0; i < c->num_upsamples; ++i) {
+    const int ch = uic >> (i + 1);
+    for (int j = 0; j < c->num_kernels; ++j) {
+      const int k = c->resblock_kernel_sizes[j];
+      for (int d = 0; d < c->num_dilations; ++d) {
+        const int dil = c->resblock_dilations[j][d];
+        out->push_back({ch, ch, k, 1, get_padding(k, dil), dil, 0});
+      }
+      for (int d = 0; d < c->num_dilations; ++d) out->push_back({ch, ch, k, 1, get_padding(k, 1), 1, 0});
+    }
+  }
+  out->push_back({1, uic >> c->num_upsamples, 7, 1, 3, 1, 0});  // conv_post
+  return MB_OK;
+}
+
+__global__ void add_inplace_kernel(float* __restrict__ y, const float* __restrict__ x, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t n4 = n >> 2;
+  float4* y4 = reinterpret_cast<float4*>(y);
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (size_t k = i; k < n4; k += stride) {
+    float4 a = y4[k], b = x4[k];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    y4[k] = a;
+  }
+  for (size_t k = (n4 << 2) + i; k < n; k += stride) y[k] += x[k];
+}
+
+static int add_inplace(float* y, const float* x, size_t n, hipStream_t s) {
+  if (!n) return MB_OK;
+  int blocks = (int)std::min<size_t>((n / 4 + 255) / 256 + 1, 2048);
+  hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks), dim3(256), 0, s, y, x, n);
+  MB_HIP(hipGetLastError());
+  return MB_OK;
+}
+
+}  // namespace mb
+
+using namespace mb;
+
+struct mb_gan {
+  mb_gan_config cfg;
+  std::vector<ConvW> convs;  // ABI order
+  int hop;
+  // indices into convs
+  int i_pre, i_ups, i_cond, i_resout, i_rb, i_post;
+};
+
+extern "C" int mb_gan_num_weights(const mb_gan_config* cfg) {
+  std::vector<ConvSpec> v;
+  if (gan_specs(cfg, &v)) return MB_EINVAL;
+  return (int)v.size() * 2;
+}
+
+extern "C" size_t mb_gan_weight_numel(const mb_gan_config* cfg, int index) {
+  std::vector<ConvSpec> v;
+  if (gan_specs(cfg, &v) || index < 0 || index >= (int)v.size() * 2) return 0;
+  const ConvSpec& s = v[index / 2];
+  return (index & 1) ? (size_t)s.c_out : (size_t)s.c_out * s.c_in * s.k;
+}
+
+extern "C" int mb_gan_create(const mb_gan_config* cfg, const float* const* h_weights, int n_weights,
+                             mb_gan** out) {
+  MB_REQUIRE(out && h_weights, "gan_create: null pointer");
+  std::vector<ConvSpec> v;
+  int rc = gan_specs(cfg, &v);
+  if (rc) return rc;
+  MB_REQUIRE(n_weights == (int)v.size() * 2, "gan_create: expected %d weight tensors, got %d",
+             (int)v.size() * 2, n_weights);
+  mb_gan* g = new mb_gan();
+  g->cfg = *cfg;
+  g->convs.resize(v.size());
+  std::vector<float> packed;
+  for (size_t i = 0; i < v.size(); ++i) {
+    const ConvSpec& s = v[i];
+    g->convs[i].s = s;
+    packed.assign(mb_conv1d_packed_floats(s.c_out, s.c_in, s.k, s.stride), 0.f);
+    rc = mb_conv1d_pack(h_weights[2 * i], s.c_out, s.c_in, s.k, s.stride, s.transposed, s.pad,
+                        packed.data());
+    if (!rc) rc = g->convs[i].w.upload(packed.data(), packed.size());
+    if (!rc) rc = g->convs[i].b.upload(h_weights[2 * i + 1], s.c_out);
+    if (rc) { mb_gan_destroy(g); return rc; }
+  }
+  g->hop = 1;
+  for (int i = 0; i < cfg->num_upsamples; ++i) g->hop *= cfg->upsample_rates[i];
+  int idx = 0;
+  g->i_pre = idx++;
+  g->i_ups = idx; idx += cfg->num_upsamples;
+  g->i_cond = g->i_resout = -1;
+  if (cfg->kind == MB_GAN_FREGAN) {
+    const int lvl = cfg->num_upsamples - cfg->top_k;
+    g->i_cond = idx; idx += cfg->num_upsamples - lvl;
+    g->i_resout = idx; idx += cfg->num_upsamples - lvl - 1;
+  }
+  g->i_rb = idx; idx += cfg->num_upsamples * cfg->num_kernels * cfg->num_dilations * 2;
+  g->i_post = idx;
+  *out = g;
+  return MB_OK;
+}
+
+extern "C" void mb_gan_destroy(mb_gan* g) {
+  if (!g) return;
+  for (auto& c : g->convs) { c.w.release(); c.b.release(); }
+  delete g;
+}
+
+extern "C" int mb_gan_hop(const mb_gan* g) { return g ? g->hop : 0; }
+
+// Largest [C][T] activation of any stage, per batch item, in floats.
+static size_t gan_max_act(const mb_gan* g, int frames) {
+  const mb_gan_config& c = g->cfg;
+  size_t m = (size_t)c.upsample_initial_channel * frames;
+  size_t t = frames;
+  for (int i = 0; i < c.num_upsamples; ++i) {
+    t *= c.upsample_rates[i];
+    m = std::max(m, (size_t)(c.upsample_initial_channel >> (i + 1)) * t);
+    m = std::max(m, (size_t)(c.upsample_initial_channel >> i) * t);  // fregan res_output / cond
+  }
+  return m;
+}
+
+extern "C" size_t mb_gan_workspace_bytes(const mb_gan* g, int batch, int frames) {
+  if (!g || batch <= 0 || frames <= 0) return 0;
+  const size_t per = align_up(gan_max_act(g, frames) * batch * sizeof(float), 256);
+  const int nbuf = g->cfg.kind == MB_GAN_FREGAN ? 8 : 4;
+  return per * nbuf + 256;
+}
+
+namespace {
+struct Launcher {
+  hipStream_t s;
+  int batch;
+  int rc = MB_OK;
+  // y = conv(x) with fused pro/epilogue; lengths are per batch item.
+  void conv(const ConvW& c, const float* x, int t_in, float* y, int in_act, float in_slope,
+            const float* res, float out_scale, int accumulate, int out_act, int in_repeat = 1) {
+    if (rc) return;
+    mb_conv1d_args a;
+    memset(&a, 0, sizeof(a));
+    const int t_eff = t_in * in_repeat;
+    const int t_out = c.s.transposed ? t_eff * c.s.stride : t_eff;
+    a.d_x = x; a.d_wpacked = c.w.p; a.d_bias = c.b.p; a.d_res = res; a.d_y = y;
+    a.x_bstride = (long long)c.s.c_in * t_in;
+    a.y_bstride = (long long)c.s.c_out * t_out;
+    a.res_bstride = a.y_bstride;
+    a.batch = batch; a.c_in = c.s.c_in; a.c_out = c.s.c_out; a.t_in = t_eff; a.t_out = t_out;
+    a.ksize = c.s.k; a.dilation = c.s.dil; a.pad = c.s.pad; a.up = c.s.transposed ? c.s.stride : 1;
+    a.in_act = in_act; a.in_slope = in_slope; a.in_scale = 1.f;
+    a.out_act = out_act; a.out_scale = out_scale; a.accumulate = accumulate;
+    a.in_repeat = in_repeat;
+    rc = mb_conv1d(&a, (mb_stream_t)s);
+  }
+};
+}  // namespace
+
+extern "C" int mb_gan_forward(const mb_gan* g, const float* d_mel, int batch, int frames, float* d_wav,
+                              void* d_workspace, size_t workspace_bytes, mb_stream_t stream) {
+  MB_REQUIRE(g && d_mel && d_wav, "gan_forward: null pointer");
+  MB_REQUIRE(batch > 0 && frames > 0, "gan_forward: empty input (batch=%d frames=%d)", batch, frames);
+  const size_t need = mb_gan_workspace_bytes(g, batch, frames);
+  if (!d_workspace || workspace_bytes < need) {
+    set_error("gan_forward: workspace %zu B < required %zu B", workspace_bytes, need);
+    return MB_ENOMEM;
+  }
+  const mb_gan_config& c = g->cfg;
+  const bool fre = c.kind == MB_GAN_FREGAN;
+  const size_t per = gan_max_act(g, frames) * batch;
+  Arena ar(d_workspace, workspace_bytes);
+  float* X = ar.take<float>(per);   // ups output = resblock input
+  float* XS = ar.take<float>(per);  // stage output (mean of resblocks)
+  float* XR = ar.take<float>(per);  // running x inside a resblock
+  float* T = ar.take<float>(per);   // convs1 output
+  float *MELA = nullptr, *MELB = nullptr, *OUTA = nullptr, *OUTB = nullptr;
+  if (fre) {
+    MELA = ar.take<float>(per); MELB = ar.take<float>(per);
+    OUTA = ar.take<float>(per); OUTB = ar.take<float>(per);
+  }
+  Launcher L{(hipStream_t)stream, batch};
+  const float LRELU = 0.1f;  // LRELU_SLOPE models.py:8
+  const int lvl = fre ? c.num_upsamples - c.top_k : 1 << 30;
+  const float inv_nk = 1.0f / (float)c.num_kernels;
+
+  // conv_pre (models.py:135 / generator.py:139)
+  L.conv(g->convs[g->i_pre], d_mel, frames, XS, 0, 0.f, nullptr, 1.f, 0, 0);
+  int t = frames;                 // current length of XS
+  const float* mel_cur = d_mel;   // fregan conditioning chain
+  int mel_t = frames;
+  float* out_cur = nullptr;       // fregan `output`
+  int out_t = 0;
+  for (int i = 0; i < c.num_upsamples && !L.rc; ++i) {
+    const int ch = c.upsample_initial_channel >> (i + 1);
+    float* pending_out = nullptr;  // res_output result waiting for "+ x"
+    if (fre && i >= lvl) {
+      // mel = cond_up[i-lvl](mel); x += mel (generator.py:142-144)
+      float* mel_next = (mel_cur == MELA) ? MELB : MELA;
+      const ConvW& cu = g->convs[g->i_cond + (i - lvl)];
+      L.conv(cu, mel_cur, mel_t, mel_next, 0, 0.f, nullptr, 1.f, 0, 0);
+      mel_cur = mel_next; mel_t *= cu.s.stride;
+      if (!L.rc) L.rc = add_inplace(XS, mel_cur, (size_t)batch * cu.s.c_out * mel_t, L.s);
+    }
+    if (fre && i > lvl) {
+      // output = res_output[i-lvl-1](x or output): nearest x u then 1x1 conv (generator.py:145-149)
+      const ConvW& ro = g->convs[g->i_resout + (i - lvl - 1)];
+      const int u = c.upsample_rates[i];
+      const float* src = out_cur ? out_cur : XS;
+      const int src_t = out_cur ? out_t : t;
+      float* dst = (out_cur == OUTA) ? OUTB : OUTA;
+      L.conv(ro, src, src_t, dst, 0, 0.f, nullptr, 1.f, 0, 0, u);
+      pending_out = dst; out_t = src_t * u;
+    }
+    // x = ups[i](leaky_relu(x))
+    const ConvW& up = g->convs[g->i_ups + i];
+    L.conv(up, XS, t, X, 1, LRELU, nullptr, 1.f, 0, 0);
+    t *= up.s.stride;
+    // xs = mean_j resblock_j(x)
+    for (int j = 0; j < c.num_kernels; ++j) {
+      const int base = g->i_rb + ((i * c.num_kernels + j) * c.num_dilations) * 2;
+      const float* xr = X;
+      for (int d = 0; d < c.num_dilations; ++d) {
+        const ConvW& c1 = g->convs[base + d];
+        const ConvW& c2 = g->convs[base + c.num_dilations + d];
+        L.conv(c1, xr, t, T, 1, LRELU, nullptr, 1.f, 0, 0);
+        const bool last = d == c.num_dilations - 1;
+        if (last) L.conv(c2, T, t, XS, 1, LRELU, xr, inv_nk, j > 0, 0);
+        else { L.conv(c2, T, t, XR, 1, LRELU, xr, 1.f, 0, 0); xr = XR; }
+      }
+    }
+    if (pending_out) {  // output = output + x (generator.py:158-159)
+      if (!L.rc) L.rc = add_inplace(pending_out, XS, (size_t)batch * ch * t, L.s);
+      out_cur = pending_out;
+    }
+  }
+  // x = leaky_relu(x) [default slope 0.01, models.py:146]; conv_post; tanh
+  const float* fin = (fre && out_cur) ? out_cur : XS;
+  L.conv(g->convs[g->i_post], fin, t, d_wav, 1, 0.01f, nullptr, 1.f, 0, 2);
+  return L.rc;
+}

@@ -1,0 +1,62 @@
+// Skinny recurrent GEMM  Y[N][rows] = epilogue( W[rows][K] . X[N][K]^T )  for
+// the two autoregressive loops (WaveRNN sample loop, Tacotron decoder loop).
+//
+// Shape regime: N = folds / batch (1..32+), K = 512..2048, rows = 512..4096,
+// re-launched every time step with the same weights -> bound by streaming W
+// from L2 / Infinity Cache / HBM and by launch latency, not by FLOPs.
+//
+// Mapping (one workgroup = NW waves, one 16-row MFMA tile, 16 columns):
+//   * rows are permuted on the host so that MFMA row i = unit*4 + gate: the
+//     v_mfma_f32_16x16x4_f32 D fragment then gives every lane all gates of ONE
+//     (hidden unit, column) pair -> the GRU / LSTM cell update is lane-local.
+//   * the NW waves split K (16-wide blocks); each wave issues one coalesced
+//     float4 weight load (A fragment) and one float4 activation load (B
+//     fragment, activations are [N][K] so 4 consecutive k are contiguous) per
+//     block and 4 MFMAs; partials meet in LDS (one ds_write_b128 per part).
+//   * K is a concatenation of up to 4 activation segments, each tagged as the
+//     cell's input part (X) or hidden part (H); GRU keeps X/H sums apart
+//     because n = tanh(i_n + r*h_n) needs them separately.
+//   * GRU rows carry 3 live gates per unit; the 4th MFMA row is never loaded.
+#pragma once
+#include "common.h"
+
+namespace mb {
+
+enum { EPI_LINEAR = 0, EPI_GRU = 1, EPI_LSTM = 2 };
+
+struct RnnSeg {
+  const float* p;  // [N][ld]
+  int ld;
+  int nkb;   // 16-wide k blocks in this segment
+  int part;  // 0 = X (input), 1 = H (hidden)
+};
+
+struct RnnK {
+  const float* w;  // packed by pack_rowtile
+  RnnSeg seg[4];
+  int nseg, nkb_total;
+  int N;      // live columns
+  int units;  // hidden units (GRU/LSTM) or output rows (LINEAR)
+  const float* biasX;  // GRU/LSTM: [gates*units] torch gate-major order; LINEAR: [rows] (may be null)
+  const float* biasH;  // GRU/LSTM hidden bias (may be null)
+  const float* pre_table;  // optional additive X-part rows: pre_table[pre_idx[n]*pre_stride + gate*units + unit]
+  const int* pre_idx;      // null -> row 0
+  int pre_stride;
+  const float* h_prev; const float* c_prev; const float* x_res;  // [N][units]
+  float* h_out; float* c_out; float* x_out;                      // [N][units]
+  float* y; int ldy; int act;  // LINEAR: y[n*ldy + row]; act 0 none, 1 relu, 2 sigmoid, 3 tanh
+  const float* mask; float mask_scale;  // LINEAR: optional y *= mask[n*ldy+row]*mask_scale (dropout)
+  int* step_counter;  // block (0,0) increments it (loop step bookkeeping), may be null
+};
+
+// rows: live rows x K (K multiple of 16), tile-ordered: rows of tile mt are
+// [mt*4*RL, (mt+1)*4*RL) in (unit, gate) order.  RL = live gates per unit (3 GRU, 4 else).
+void pack_rowtile(const float* rows, int n_live_rows, int K, int RL, std::vector<float>* out);
+
+// Build tile-ordered rows for a GRU/LSTM cell from torch weight_ih [G*H][Kx], weight_hh [G*H][H].
+void cell_rows(const float* w_ih, int kx, int ldx, const float* w_hh, int kh, int H, int G,
+               std::vector<float>* rows);
+
+int rnn_launch(int epi, const RnnK& k, hipStream_t s);
+
+}  // namespace mb

@@ -1,0 +1,616 @@
+// WaveRNN (fatchord) generate(): conditioning networks + autoregressive sample loop.
+//
+// Reference: models/vocoder/wavernn/models/fatchord_version.py
+//   MelResNet/UpsampleNetwork :27-85, WaveRNN.generate :153-257 (loop body :190-234),
+//   fold_with_overlap :288-338 (done here by index arithmetic, never materialised).
+//
+// Loop restructuring (all exact algebra, fp32 throughout):
+//   * I([x_prev, m_t, a1_t]) = W_I[:,0]*x_prev + (W_I[:,1:].[m_t;a1_t] + b_I): the
+//     second term does not depend on the recurrence, so it is one MFMA GEMM
+//     over all conditioning positions before the loop (table Ipre, time-major).
+//   * the aux columns of rnn2 / fc1 / fc2 (a2,a3,a4 are constant over the 200
+//     samples of a mel frame) become per-FRAME tables G2pre/F1pre/F2pre with
+//     the biases folded in.  One extra all-zero conditioning row stands for
+//     the zero padding fold_with_overlap appends (:325-327).
+//   * what remains per step is 5 dependent skinny GEMMs (rnn.hip) + the
+//     sampler; the steps are captured in a hipGraph and replayed, the step
+//     index lives in device memory so the graph is parameter free.
+#include "rnn.h"
+
+namespace mb {
+
+// ---- conditioning helpers -------------------------------------------------
+
+// One UpsampleNetwork stage: Stretch2d(s,1) then Conv2d(1,1,(1,2s+1),padding=(0,s)) :47-57,69-74
+__global__ void upsample_stage_kernel(const float* __restrict__ in, int t_stored, int in_pad,
+                                      float* __restrict__ out, int s, const float* __restrict__ w,
+                                      int out_off, int t_out) {
+  const int c = blockIdx.y;
+  const int tv = (t_stored + 2 * in_pad) * s;  // stretched virtual length
+  const float* ic = in + (size_t)c * t_stored;
+  float* oc = out + (size_t)c * t_out;
+  for (int tp = blockIdx.x * blockDim.x + threadIdx.x; tp < t_out; tp += gridDim.x * blockDim.x) {
+    const int t = tp + out_off;
+    float acc = 0.f;
+    for (int j = 0; j <= 2 * s; ++j) {
+      const int uu = t + j - s;
+      if (uu >= 0 && uu < tv) {
+        const int f = uu / s - in_pad;
+        if (f >= 0 && f < t_stored) acc += w[j] * ic[f];
+      }
+    }
+    oc[tp] = acc;
+  }
+}
+
+// out[c][t] = in[c][t / rep]  (Stretch2d of the aux features :82-83)
+__global__ void repeat_rows_kernel(const float* __restrict__ in, int t_in, float* __restrict__ out,
+                                   int rep) {
+  const int c = blockIdx.y;
+  const int t_out = t_in * rep;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < t_out; t += gridDim.x * blockDim.x)
+    out[(size_t)c * t_out + t] = in[(size_t)c * t_in + t / rep];
+}
+
+// ---- sampler ----------------------------------------------------------------
+struct SampK {
+  const float* logits;  // [N][C]
+  const float* noise;   // [S][N][C] Exp(1) draws or null
+  unsigned long long seed;
+  const float* forced;  // [N][S] or null
+  float* samples;       // [N][S]
+  float* logits_out;    // [S][N][C] or null
+  const int* step;      // counter already incremented by this step's first kernel
+  int N, C, S, R;
+  int fold_stride, total_len, hop, frames;
+  const float* Ipre;    // [(total_len+1)][R]
+  const float* wI0;     // [R]
+  float* x0;            // [N][R]
+  int* idx_frame;       // [N]
+  volatile int* progress;
+};
+
+// x0 / table row for fold n at step s1 with fed-back sample xfb (:192-195 + fold indexing :334-336)
+__device__ __forceinline__ void prep_step(const SampK& a, int n, int s1, float xfb, int lane) {
+  const long long pos = (long long)n * a.fold_stride + s1;
+  const bool livep = pos < a.total_len;
+  const long long ipos = livep ? pos : a.total_len;
+  if (lane == 0) a.idx_frame[n] = livep ? (int)(pos / a.hop) : a.frames;
+  const float* ip = a.Ipre + ipos * a.R;
+  for (int j = lane; j < a.R; j += 64) a.x0[(size_t)n * a.R + j] = ip[j] + xfb * a.wI0[j];
+}
+
+__global__ __launch_bounds__(64) void wavernn_init_kernel(SampK a) {
+  prep_step(a, blockIdx.x, 0, 0.f, threadIdx.x);
+}
+
+// softmax -> Categorical.sample() -> 2k/(C-1)-1   (:222-228).  torch.multinomial(p, 1) on the
+// CPU path is argmax(p / Exp(1) noise) (verified bit-exact), restated here with
+// the noise either injected (parity) or drawn from Philox (production).
+__global__ __launch_bounds__(64) void wavernn_sample_kernel(SampK a) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  const int s = *a.step - 1;
+  const float* lg = a.logits + (size_t)n * a.C;
+  float m = -INFINITY;
+  for (int c = lane; c < a.C; c += 64) m = fmaxf(m, lg[c]);
+  m = wave_max(m);
+  float sum = 0.f;
+  for (int c = lane; c < a.C; c += 64) sum += expf(lg[c] - m);
+  sum = wave_sum(sum);
+  float best = -1.f;
+  int bidx = 0x7fffffff;
+  const size_t nb = ((size_t)s * a.N + n) * a.C;
+  for (int c = lane; c < a.C; c += 64) {
+    const float l = lg[c];
+    if (a.logits_out) a.logits_out[nb + c] = l;
+    const float p = expf(l - m) / sum;
+    float e;
+    if (a.noise) e = a.noise[nb + c];
+    else {
+      uint32_t r[4];
+      philox4x32((uint32_t)s, (uint32_t)n, (uint32_t)(c >> 2), 0x57415645u, (uint32_t)a.seed,
+                 (uint32_t)(a.seed >> 32), r);
+      e = -logf(u32_to_unit(r[c & 3]));
+    }
+    const float q = p / e;
+    if (q > best) { best = q; bidx = c; }  // c ascending per lane: first max kept
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bidx, o, 64);
+    if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+  }
+  const float x = 2.f * (float)bidx / ((float)a.C - 1.f) - 1.f;
+  if (lane == 0) {
+    a.samples[(size_t)n * a.S + s] = x;
+    if (a.progress && n == 0 && (s % 100 == 0 || s == a.S - 1)) *a.progress = s + 1;
+  }
+  const float xfb = a.forced ? a.forced[(size_t)n * a.S + s] : x;
+  if (s + 1 < a.S) prep_step(a, n, s + 1, xfb, lane);
+}
+
+}  // namespace mb
+
+using namespace mb;
+
+namespace {
+struct CondConv {  // conv with BN folded, packed for conv1d.hip
+  int c_out, c_in, k, pad;
+  DevBuf w, b;
+};
+}  // namespace
+
+struct mb_wavernn {
+  mb_wavernn_config cfg;
+  int hop, aux_dims, n_classes;
+  // conditioning
+  CondConv conv_in, conv_out;
+  std::vector<CondConv> res1, res2;
+  std::vector<DevBuf> up_w;
+  // tables
+  CondConv t_I, t_g2, t_f1, t_f2;  // 1x1 convs producing Ipre / G2pre / F1pre / F2pre
+  // loop weights
+  DevBuf wI0, w_rnn1, w_rnn2, w_fc1, w_fc2, w_fc3;
+  DevBuf b_ih1, b_hh1, b_hh2, b_fc3;
+  hipStream_t loop_stream = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+  hipGraph_t graph = nullptr;        // kept until the next call / destroy so generate stays async
+  hipGraphExec_t graph_exec = nullptr;
+  int last_launches = 0;
+  bool timed = false;
+  int bench_which = 0, bench_iters = 0;  // set by mb_wavernn_bench_kernel
+  void drop_graph() {
+    if (graph_exec) { (void)hipStreamSynchronize(loop_stream); (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+    if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
+  }
+};
+
+static int wavernn_shapes(const mb_wavernn_config* c, std::vector<size_t>* numel) {
+  MB_REQUIRE(c, "wavernn: null config");
+  MB_REQUIRE(c->mode == 0, "wavernn: only RAW mode is on the hot path (hparams.py voc_mode='RAW')");
+  MB_REQUIRE(c->n_upsample >= 1 && c->n_upsample <= 4, "wavernn: n_upsample");
+  MB_REQUIRE(c->rnn_dims % 16 == 0 && c->fc_dims % 16 == 0, "wavernn: rnn_dims/fc_dims must be multiples of 16");
+  MB_REQUIRE(c->res_out_dims % 4 == 0, "wavernn: res_out_dims %% 4");
+  const size_t R = c->rnn_dims, FC = c->fc_dims, A = c->res_out_dims / 4, CD = c->compute_dims;
+  const size_t C = (size_t)1 << c->bits;
+  numel->clear();
+  auto bn = [&](size_t n) { for (int i = 0; i < 4; ++i) numel->push_back(n); };
+  numel->push_back(CD * c->feat_dims * (2 * c->pad + 1));  // conv_in
+  bn(CD);
+  for (int i = 0; i < c->res_blocks; ++i) {
+    numel->push_back(CD * CD); bn(CD);  // conv1, batch_norm1
+    numel->push_back(CD * CD); bn(CD);  // conv2, batch_norm2
+  }
+  numel->push_back((size_t)c->res_out_dims * CD);  // conv_out.weight
+  numel->push_back(c->res_out_dims);               // conv_out.bias
+  for (int i = 0; i < c->n_upsample; ++i) numel->push_back(2 * c->upsample_factors[i] + 1);
+  numel->push_back(R * (c->feat_dims + A + 1)); numel->push_back(R);                    // I
+  numel->push_back(3 * R * R); numel->push_back(3 * R * R); numel->push_back(3 * R); numel->push_back(3 * R);  // rnn1
+  numel->push_back(3 * R * (R + A)); numel->push_back(3 * R * R); numel->push_back(3 * R); numel->push_back(3 * R);  // rnn2
+  numel->push_back(FC * (R + A)); numel->push_back(FC);   // fc1
+  numel->push_back(FC * (FC + A)); numel->push_back(FC);  // fc2
+  numel->push_back(C * FC); numel->push_back(C);          // fc3
+  return MB_OK;
+}
+
+extern "C" int mb_wavernn_num_weights(const mb_wavernn_config* cfg) {
+  std::vector<size_t> v;
+  if (wavernn_shapes(cfg, &v)) return MB_EINVAL;
+  return (int)v.size();
+}
+extern "C" size_t mb_wavernn_weight_numel(const mb_wavernn_config* cfg, int index) {
+  std::vector<size_t> v;
+  if (wavernn_shapes(cfg, &v) || index < 0 || index >= (int)v.size()) return 0;
+  return v[index];
+}
+
+// conv weight [c_out][c_in][k] (+ optional eval BatchNorm folded in) -> packed + bias
+static int make_cond_conv(CondConv* cc, const float* w, int c_out, int c_in, int k, int pad,
+                          const float* bias, const float* const* bn /* w,b,mean,var or null */) {
+  cc->c_out = c_out; cc->c_in = c_in; cc->k = k; cc->pad = pad;
+  std::vector<float> wf((size_t)c_out * c_in * k), bf(c_out, 0.f);
+  for (int co = 0; co < c_out; ++co) {
+    double scale = 1.0, shift = bias ? bias[co] : 0.0;
+    if (bn) {  // y = (conv - mean)/sqrt(var+eps)*w + b ; eps = 1e-5 (nn.BatchNorm1d default)
+      scale = (double)bn[0][co] / std::sqrt((double)bn[3][co] + 1e-5);
+      shift = (double)bn[1][co] + (shift - (double)bn[2][co]) * scale;
+    }
+    for (size_t i = 0; i < (size_t)c_in * k; ++i)
+      wf[(size_t)co * c_in * k + i] = (float)((double)w[(size_t)co * c_in * k + i] * scale);
+    bf[co] = (float)shift;
+  }
+  std::vector<float> packed(mb_conv1d_packed_floats(c_out, c_in, k, 1));
+  int rc = mb_conv1d_pack(wf.data(), c_out, c_in, k, 1, 0, pad, packed.data());
+  if (!rc) rc = cc->w.upload(packed.data(), packed.size());
+  if (!rc) rc = cc->b.upload(bf.data(), bf.size());
+  return rc;
+}
+
+// sub-matrix columns [c0, c0+nc) of a row-major [rows][ld] matrix
+static std::vector<float> col_slice(const float* w, int rows, int ld, int c0, int nc) {
+  std::vector<float> o((size_t)rows * nc);
+  for (int r = 0; r < rows; ++r) memcpy(&o[(size_t)r * nc], w + (size_t)r * ld + c0, sizeof(float) * nc);
+  return o;
+}
+
+extern "C" int mb_wavernn_create(const mb_wavernn_config* cfg, const float* const* hw, int n_weights,
+                                 mb_wavernn** out) {
+  MB_REQUIRE(out && hw, "wavernn_create: null pointer");
+  std::vector<size_t> shapes;
+  int rc = wavernn_shapes(cfg, &shapes);
+  if (rc) return rc;
+  MB_REQUIRE(n_weights == (int)shapes.size(), "wavernn_create: expected %d weight tensors, got %d",
+             (int)shapes.size(), n_weights);
+  mb_wavernn* w = new mb_wavernn();
+  w->cfg = *cfg;
+  const int R = cfg->rnn_dims, FC = cfg->fc_dims, A = cfg->res_out_dims / 4, CD = cfg->compute_dims;
+  const int C = 1 << cfg->bits, FEAT = cfg->feat_dims;
+  w->aux_dims = A; w->n_classes = C;
+  w->hop = 1;
+  for (int i = 0; i < cfg->n_upsample; ++i) w->hop *= cfg->upsample_factors[i];
+  int ix = 0;
+#define RC(x) do { if (!rc) rc = (x); } while (0)
+  // MelResNet :27-44
+  RC(make_cond_conv(&w->conv_in, hw[ix], CD, FEAT, 2 * cfg->pad + 1, cfg->pad, nullptr, hw + ix + 1));
+  ix += 5;
+  w->res1.resize(cfg->res_blocks); w->res2.resize(cfg->res_blocks);
+  for (int i = 0; i < cfg->res_blocks; ++i) {
+    RC(make_cond_conv(&w->res1[i], hw[ix], CD, CD, 1, 0, nullptr, hw + ix + 1)); ix += 5;
+    RC(make_cond_conv(&w->res2[i], hw[ix], CD, CD, 1, 0, nullptr, hw + ix + 1)); ix += 5;
+  }
+  RC(make_cond_conv(&w->conv_out, hw[ix], cfg->res_out_dims, CD, 1, 0, hw[ix + 1], nullptr)); ix += 2;
+  w->up_w.resize(cfg->n_upsample);
+  for (int i = 0; i < cfg->n_upsample; ++i) RC(w->up_w[i].upload(hw[ix++], 2 * cfg->upsample_factors[i] + 1));
+  // I :108,195
+  const float* WI = hw[ix]; const float* bI = hw[ix + 1]; ix += 2;
+  const int KI = FEAT + A + 1;
+  {
+    std::vector<float> c0 = col_slice(WI, R, KI, 0, 1);
+    RC(w->wI0.upload(c0.data(), c0.size()));
+    std::vector<float> wc = col_slice(WI, R, KI, 1, FEAT + A);
+    RC(make_cond_conv(&w->t_I, wc.data(), R, FEAT + A, 1, 0, bI, nullptr));
+  }
+  std::vector<float> rows, packed;
+  // rnn1 :109
+  {
+    const float *wih = hw[ix], *whh = hw[ix + 1], *bih = hw[ix + 2], *bhh = hw[ix + 3]; ix += 4;
+    cell_rows(wih, R, R, whh, R, R, 3, &rows);
+    pack_rowtile(rows.data(), 3 * R, 2 * R, 3, &packed);
+    RC(w->w_rnn1.upload(packed.data(), packed.size()));
+    RC(w->b_ih1.upload(bih, 3 * R)); RC(w->b_hh1.upload(bhh, 3 * R));
+  }
+  // rnn2 :110 (input = [x, a2])
+  {
+    const float *wih = hw[ix], *whh = hw[ix + 1], *bih = hw[ix + 2], *bhh = hw[ix + 3]; ix += 4;
+    cell_rows(wih, R, R + A, whh, R, R, 3, &rows);
+    pack_rowtile(rows.data(), 3 * R, 2 * R, 3, &packed);
+    RC(w->w_rnn2.upload(packed.data(), packed.size()));
+    RC(w->b_hh2.upload(bhh, 3 * R));
+    std::vector<float> wa = col_slice(wih, 3 * R, R + A, R, A);
+    RC(make_cond_conv(&w->t_g2, wa.data(), 3 * R, A, 1, 0, bih, nullptr));
+  }
+  // fc1 / fc2 / fc3 :111-113
+  {
+    const float *w1 = hw[ix], *b1 = hw[ix + 1], *w2 = hw[ix + 2], *b2 = hw[ix + 3], *w3 = hw[ix + 4], *b3 = hw[ix + 5];
+    ix += 6;
+    std::vector<float> m = col_slice(w1, FC, R + A, 0, R);
+    pack_rowtile(m.data(), FC, R, 4, &packed); RC(w->w_fc1.upload(packed.data(), packed.size()));
+    std::vector<float> a1 = col_slice(w1, FC, R + A, R, A);
+    RC(make_cond_conv(&w->t_f1, a1.data(), FC, A, 1, 0, b1, nullptr));
+    m = col_slice(w2, FC, FC + A, 0, FC);
+    pack_rowtile(m.data(), FC, FC, 4, &packed); RC(w->w_fc2.upload(packed.data(), packed.size()));
+    std::vector<float> a2 = col_slice(w2, FC, FC + A, FC, A);
+    RC(make_cond_conv(&w->t_f2, a2.data(), FC, A, 1, 0, b2, nullptr));
+    pack_rowtile(w3, C, FC, 4, &packed); RC(w->w_fc3.upload(packed.data(), packed.size()));
+    RC(w->b_fc3.upload(b3, C));
+  }
+#undef RC
+  if (!rc && hipStreamCreateWithFlags(&w->loop_stream, hipStreamNonBlocking) != hipSuccess) rc = MB_EHIP;
+  if (!rc) {
+    if (hipEventCreateWithFlags(&w->ev_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&w->ev_out, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreate(&w->ev_t0) != hipSuccess || hipEventCreate(&w->ev_t1) != hipSuccess)
+      rc = MB_EHIP;
+  }
+  if (rc) { if (rc == MB_EHIP) set_error("wavernn_create: stream/event creation failed"); mb_wavernn_destroy(w); return rc; }
+  *out = w;
+  return MB_OK;
+}
+
+extern "C" void mb_wavernn_destroy(mb_wavernn* w) {
+  if (!w) return;
+  auto rel = [](CondConv& c) { c.w.release(); c.b.release(); };
+  rel(w->conv_in); rel(w->conv_out); rel(w->t_I); rel(w->t_g2); rel(w->t_f1); rel(w->t_f2);
+  for (auto& c : w->res1) rel(c);
+  for (auto& c : w->res2) rel(c);
+  for (auto& b : w->up_w) b.release();
+  DevBuf* bs[] = {&w->wI0, &w->w_rnn1, &w->w_rnn2, &w->w_fc1, &w->w_fc2, &w->w_fc3,
+                  &w->b_ih1, &w->b_hh1, &w->b_hh2, &w->b_fc3};
+  for (DevBuf* b : bs) b->release();
+  w->drop_graph();
+  if (w->ev_in) (void)hipEventDestroy(w->ev_in);
+  if (w->ev_out) (void)hipEventDestroy(w->ev_out);
+  if (w->ev_t0) (void)hipEventDestroy(w->ev_t0);
+  if (w->ev_t1) (void)hipEventDestroy(w->ev_t1);
+  if (w->loop_stream) (void)hipStreamDestroy(w->loop_stream);
+  delete w;
+}
+
+namespace {
+struct WrnLayout {
+  float *r0, *r1, *r2, *aux, *m1, *m2, *cond, *Ipre, *G2, *F1, *F2;
+  float *x0, *x1, *x2, *y1, *y2, *logits, *h1, *h2;
+  int* idx_frame; int* step;
+  size_t bytes;
+};
+// python-style floor division
+inline long long floordiv(long long a, long long b) { long long q = a / b; if ((a % b != 0) && ((a < 0) != (b < 0))) --q; return q; }
+}  // namespace
+
+static void wavernn_layout(const mb_wavernn* w, const mb_wavernn_plan* p, void* base, WrnLayout* L) {
+  const mb_wavernn_config& c = w->cfg;
+  const size_t F = p->frames, T = p->total_len, N = p->n_folds, R = c.rnn_dims, FC = c.fc_dims;
+  const size_t CD = c.compute_dims, A = w->aux_dims;
+  Arena ar(base, (size_t)-1);
+  L->r0 = ar.take<float>(CD * F); L->r1 = ar.take<float>(CD * F); L->r2 = ar.take<float>(CD * F);
+  L->aux = ar.take<float>((size_t)c.res_out_dims * F);
+  // intermediate mel upsampling stages (the last stage writes straight into cond)
+  const size_t s1 = (F + 2 * c.pad) * c.upsample_factors[0];
+  const size_t s2 = s1 * (c.n_upsample > 1 ? c.upsample_factors[1] : 1);
+  L->m1 = ar.take<float>(c.n_upsample >= 2 ? (size_t)c.feat_dims * s1 : 1);
+  L->m2 = ar.take<float>(c.n_upsample >= 3 ? (size_t)c.feat_dims * s2 : 1);
+  L->cond = ar.take<float>((c.feat_dims + A) * T);
+  L->Ipre = ar.take<float>((T + 1) * R);
+  L->G2 = ar.take<float>((F + 1) * 3 * R);
+  L->F1 = ar.take<float>((F + 1) * FC);
+  L->F2 = ar.take<float>((F + 1) * FC);
+  L->x0 = ar.take<float>(N * R); L->x1 = ar.take<float>(N * R); L->x2 = ar.take<float>(N * R);
+  L->y1 = ar.take<float>(N * FC); L->y2 = ar.take<float>(N * FC);
+  L->logits = ar.take<float>(N * w->n_classes);
+  L->h1 = ar.take<float>(2 * N * R); L->h2 = ar.take<float>(2 * N * R);
+  L->idx_frame = ar.take<int>(N);
+  L->step = ar.take<int>(4);
+  L->bytes = ar.off + 256;
+}
+
+extern "C" int mb_wavernn_plan_generate(const mb_wavernn* w, int frames, int batched, int target,
+                                        int overlap, mb_wavernn_plan* plan) {
+  MB_REQUIRE(w && plan, "wavernn_plan: null pointer");
+  MB_REQUIRE(frames >= 1, "wavernn_plan: empty mel (frames=%d)", frames);
+  MB_REQUIRE(w->cfg.n_upsample <= 3, "wavernn_plan: >3 upsample stages not supported");
+  plan->frames = frames;
+  const long long total = (long long)frames * w->hop;
+  MB_REQUIRE(total < (1ll << 31) - 1, "wavernn_plan: mel too long");
+  plan->total_len = (int)total;
+  if (batched) {
+    MB_REQUIRE(target > 0 && overlap >= 0, "wavernn_plan: target/overlap");
+    // fold_with_overlap :313-322
+    long long nf = floordiv(total - overlap, target + overlap);
+    const long long ext = nf * (overlap + target) + overlap;
+    if (total - ext != 0) nf += 1;
+    MB_REQUIRE(nf >= 1, "wavernn_plan: mel too short for batched generation (target=%d overlap=%d)", target, overlap);
+    plan->n_folds = (int)nf;
+    plan->seq_len = target + 2 * overlap;
+    plan->fold_stride = target + overlap;
+  } else {
+    plan->n_folds = 1; plan->seq_len = plan->total_len; plan->fold_stride = 0;
+  }
+  WrnLayout L;
+  wavernn_layout(w, plan, nullptr, &L);
+  plan->workspace_bytes = L.bytes;
+  return MB_OK;
+}
+
+static int run_cond_conv(const CondConv& cc, const float* x, int t, float* y, const float* res,
+                         int out_act, int transpose_out, hipStream_t s) {
+  mb_conv1d_args a;
+  memset(&a, 0, sizeof(a));
+  a.d_x = x; a.d_wpacked = cc.w.p; a.d_bias = cc.b.p; a.d_res = res; a.d_y = y;
+  a.batch = 1; a.c_in = cc.c_in; a.c_out = cc.c_out; a.t_in = t; a.t_out = t;
+  a.ksize = cc.k; a.dilation = 1; a.pad = cc.pad; a.up = 1;
+  a.out_act = out_act; a.transpose_out = transpose_out;
+  return mb_conv1d(&a, (mb_stream_t)s);
+}
+
+extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* plan, const float* d_mel,
+                                   const float* d_noise, uint64_t seed, float* d_samples,
+                                   float* d_logits_out, const float* d_forced, int* h_progress,
+                                   void* d_workspace, size_t workspace_bytes, mb_stream_t stream) {
+  mb_wavernn* w = const_cast<mb_wavernn*>(wc);
+  MB_REQUIRE(w && plan && d_mel && d_samples, "wavernn_generate: null pointer");
+  WrnLayout L;
+  wavernn_layout(w, plan, d_workspace, &L);
+  if (!d_workspace || workspace_bytes < L.bytes) {
+    set_error("wavernn_generate: workspace %zu B < required %zu B", workspace_bytes, L.bytes);
+    return MB_ENOMEM;
+  }
+  const mb_wavernn_config& c = w->cfg;
+  const int F = plan->frames, T = plan->total_len, N = plan->n_folds, S = plan->seq_len;
+  const int R = c.rnn_dims, FC = c.fc_dims, A = w->aux_dims, C = w->n_classes, FEAT = c.feat_dims;
+  hipStream_t cs = (hipStream_t)stream, s = w->loop_stream;
+  MB_HIP(hipEventRecord(w->ev_in, cs));
+  MB_HIP(hipStreamWaitEvent(s, w->ev_in, 0));
+  int rc = MB_OK;
+#define RC(x) do { if (!rc) rc = (x); } while (0)
+  // ---- aux = MelResNet(pad(mel)) :37-44 (zero padding == conv padding) ----
+  RC(run_cond_conv(w->conv_in, d_mel, F, L.r0, nullptr, 1, 0, s));
+  float* cur = L.r0; float* oth = L.r1;
+  for (int i = 0; i < c.res_blocks; ++i) {  // ResBlock :17-24
+    RC(run_cond_conv(w->res1[i], cur, F, L.r2, nullptr, 1, 0, s));
+    RC(run_cond_conv(w->res2[i], L.r2, F, oth, cur, 0, 0, s));
+    std::swap(cur, oth);
+  }
+  RC(run_cond_conv(w->conv_out, cur, F, L.aux, nullptr, 0, 0, s));
+  // ---- mel upsampling :78-85 -> cond rows [0, FEAT) ----
+  if (!rc) {
+    const float* in = d_mel; int t_stored = F, in_pad = c.pad;
+    float* bufs[2] = {L.m1, L.m2};
+    for (int i = 0; i < c.n_upsample; ++i) {
+      const int sc = c.upsample_factors[i];
+      const bool last = i == c.n_upsample - 1;
+      const int t_full = (t_stored + 2 * in_pad) * sc;
+      const int off = last ? c.pad * w->hop : 0;  // indent crop :66,84
+      const int t_out = last ? T : t_full;
+      float* o = last ? L.cond : bufs[i & 1];
+      dim3 grid(std::min(cdiv(t_out, 256), 4096), FEAT);
+      hipLaunchKernelGGL(upsample_stage_kernel, grid, dim3(256), 0, s, in, t_stored, in_pad, o, sc,
+                         w->up_w[i].p, off, t_out);
+      in = o; t_stored = t_out; in_pad = 0;
+    }
+    // a1 rows: cond[FEAT + c][t] = aux[c][t / hop]
+    dim3 grid(std::min(cdiv(T, 256), 4096), A);
+    hipLaunchKernelGGL(repeat_rows_kernel, grid, dim3(256), 0, s, L.aux, F, L.cond + (size_t)FEAT * T, w->hop);
+    if (hipGetLastError() != hipSuccess) { set_error("wavernn: conditioning launch failed"); rc = MB_EHIP; }
+  }
+  // ---- tables (time-major) + the zero-conditioning row = bias ----
+  RC(run_cond_conv(w->t_I, L.cond, T, L.Ipre, nullptr, 0, 1, s));
+  RC(run_cond_conv(w->t_g2, L.aux + (size_t)1 * A * F, F, L.G2, nullptr, 0, 1, s));
+  RC(run_cond_conv(w->t_f1, L.aux + (size_t)2 * A * F, F, L.F1, nullptr, 0, 1, s));
+  RC(run_cond_conv(w->t_f2, L.aux + (size_t)3 * A * F, F, L.F2, nullptr, 0, 1, s));
+  if (!rc) {
+    MB_HIP(hipMemcpyAsync(L.Ipre + (size_t)T * R, w->t_I.b.p, sizeof(float) * R, hipMemcpyDeviceToDevice, s));
+    MB_HIP(hipMemcpyAsync(L.G2 + (size_t)F * 3 * R, w->t_g2.b.p, sizeof(float) * 3 * R, hipMemcpyDeviceToDevice, s));
+    MB_HIP(hipMemcpyAsync(L.F1 + (size_t)F * FC, w->t_f1.b.p, sizeof(float) * FC, hipMemcpyDeviceToDevice, s));
+    MB_HIP(hipMemcpyAsync(L.F2 + (size_t)F * FC, w->t_f2.b.p, sizeof(float) * FC, hipMemcpyDeviceToDevice, s));
+    MB_HIP(hipMemsetAsync(L.h1, 0, sizeof(float) * 2 * N * R, s));
+    MB_HIP(hipMemsetAsync(L.h2, 0, sizeof(float) * 2 * N * R, s));
+    MB_HIP(hipMemsetAsync(L.step, 0, sizeof(int) * 4, s));
+  }
+  if (rc) return rc;
+
+  SampK sk;
+  sk.logits = L.logits; sk.noise = d_noise; sk.seed = seed; sk.forced = d_forced; sk.samples = d_samples;
+  sk.logits_out = d_logits_out; sk.step = L.step; sk.N = N; sk.C = C; sk.S = S; sk.R = R;
+  sk.fold_stride = plan->fold_stride; sk.total_len = T; sk.hop = w->hop; sk.frames = F;
+  sk.Ipre = L.Ipre; sk.wI0 = w->wI0.p; sk.x0 = L.x0; sk.idx_frame = L.idx_frame; sk.progress = h_progress;
+  hipLaunchKernelGGL(wavernn_init_kernel, dim3(N), dim3(64), 0, s, sk);
+  MB_HIP(hipGetLastError());
+
+  // one time step = 5 GEMM launches + sampler; pp = parity of the step (state ping-pong)
+  auto step = [&](int pp, int which = 0x3f) -> int {
+    float* h1p = L.h1 + (size_t)pp * N * R; float* h1n = L.h1 + (size_t)(pp ^ 1) * N * R;
+    float* h2p = L.h2 + (size_t)pp * N * R; float* h2n = L.h2 + (size_t)(pp ^ 1) * N * R;
+    RnnK k;
+    int r = MB_OK;
+    // h1 = rnn1(x, h1); x = x + h1   :196-198
+    memset(&k, 0, sizeof(k));
+    k.w = w->w_rnn1.p; k.nseg = 2; k.nkb_total = 2 * R / 16;
+    k.seg[0] = {L.x0, R, R / 16, 0}; k.seg[1] = {h1p, R, R / 16, 1};
+    k.N = N; k.units = R; k.biasX = w->b_ih1.p; k.biasH = w->b_hh1.p;
+    k.h_prev = h1p; k.x_res = L.x0; k.h_out = h1n; k.x_out = L.x1; k.step_counter = L.step;
+    if ((which & 1) && (r = rnn_launch(EPI_GRU, k, s))) return r;
+    // h2 = rnn2([x, a2], h2); x = x + h2   :199-202
+    memset(&k, 0, sizeof(k));
+    k.w = w->w_rnn2.p; k.nseg = 2; k.nkb_total = 2 * R / 16;
+    k.seg[0] = {L.x1, R, R / 16, 0}; k.seg[1] = {h2p, R, R / 16, 1};
+    k.N = N; k.units = R; k.biasH = w->b_hh2.p;
+    k.pre_table = L.G2; k.pre_idx = L.idx_frame; k.pre_stride = 3 * R;
+    k.h_prev = h2p; k.x_res = L.x1; k.h_out = h2n; k.x_out = L.x2;
+    if ((which & 2) && (r = rnn_launch(EPI_GRU, k, s))) return r;
+    // x = relu(fc1([x, a3]))   :203-204
+    memset(&k, 0, sizeof(k));
+    k.w = w->w_fc1.p; k.nseg = 1; k.nkb_total = R / 16; k.seg[0] = {L.x2, R, R / 16, 0};
+    k.N = N; k.units = FC; k.pre_table = L.F1; k.pre_idx = L.idx_frame; k.pre_stride = FC;
+    k.y = L.y1; k.ldy = FC; k.act = 1;
+    if ((which & 4) && (r = rnn_launch(EPI_LINEAR, k, s))) return r;
+    // x = relu(fc2([x, a4]))   :206-207
+    memset(&k, 0, sizeof(k));
+    k.w = w->w_fc2.p; k.nseg = 1; k.nkb_total = FC / 16; k.seg[0] = {L.y1, FC, FC / 16, 0};
+    k.N = N; k.units = FC; k.pre_table = L.F2; k.pre_idx = L.idx_frame; k.pre_stride = FC;
+    k.y = L.y2; k.ldy = FC; k.act = 1;
+    if ((which & 8) && (r = rnn_launch(EPI_LINEAR, k, s))) return r;
+    // logits = fc3(x)   :209
+    memset(&k, 0, sizeof(k));
+    k.w = w->w_fc3.p; k.nseg = 1; k.nkb_total = FC / 16; k.seg[0] = {L.y2, FC, FC / 16, 0};
+    k.N = N; k.units = C; k.biasX = w->b_fc3.p; k.y = L.logits; k.ldy = C;
+    if ((which & 16) && (r = rnn_launch(EPI_LINEAR, k, s))) return r;
+    if (which & 32) {
+      hipLaunchKernelGGL(wavernn_sample_kernel, dim3(N), dim3(64), 0, s, sk);
+      MB_HIP(hipGetLastError());
+    }
+    return MB_OK;
+  };
+
+  if (w->bench_which) {  // micro-benchmark: relaunch ONE loop kernel on the initialised workspace
+    for (int i = 0; i < 20 && !rc; ++i) rc = step(0, w->bench_which);  // warm-up
+    MB_HIP(hipEventRecord(w->ev_t0, s));
+    for (int i = 0; i < w->bench_iters && !rc; ++i) rc = step(0, w->bench_which);
+    MB_HIP(hipEventRecord(w->ev_t1, s));
+    w->last_launches = w->bench_iters; w->timed = true;
+    MB_HIP(hipEventRecord(w->ev_out, s));
+    MB_HIP(hipStreamWaitEvent(cs, w->ev_out, 0));
+    return rc;
+  }
+  MB_HIP(hipEventRecord(w->ev_t0, s));
+  const bool use_graph = getenv("MBHIP_NO_GRAPH") == nullptr && S >= 64;
+  int done = 0;
+  if (use_graph) {
+    int G = 128;  // steps per graph (even: state parity returns to 0)
+    const char* ge = getenv("MBHIP_GRAPH_STEPS");
+    if (ge && atoi(ge) >= 2) G = atoi(ge) & ~1;
+    while (G > S) G >>= 1;
+    G &= ~1;
+    if (G >= 2) {
+      w->drop_graph();
+      MB_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+      for (int i = 0; i < G && !rc; ++i) rc = step(i & 1);
+      hipError_t e = hipStreamEndCapture(s, &w->graph);
+      if (rc) { w->drop_graph(); return rc; }
+      if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture", __FILE__, __LINE__);
+      e = hipGraphInstantiate(&w->graph_exec, w->graph, nullptr, nullptr, 0);
+      if (e != hipSuccess) { w->drop_graph(); return hip_fail(e, "hipGraphInstantiate", __FILE__, __LINE__); }
+      const int reps = S / G;
+      for (int r = 0; r < reps; ++r) MB_HIP(hipGraphLaunch(w->graph_exec, s));
+      done = reps * G;
+    }
+  }
+  for (int i = done; i < S && !rc; ++i) rc = step(i & 1);
+  if (rc) return rc;
+  MB_HIP(hipEventRecord(w->ev_t1, s));
+  w->last_launches = 6 * S;
+  w->timed = true;
+  MB_HIP(hipEventRecord(w->ev_out, s));
+  MB_HIP(hipStreamWaitEvent(cs, w->ev_out, 0));
+#undef RC
+  return MB_OK;
+}
+
+extern "C" int mb_wavernn_last_loop_ms(const mb_wavernn* w, float* ms, int* launches) {
+  MB_REQUIRE(w && ms, "wavernn_last_loop_ms: null pointer");
+  if (!w->timed) { set_error("wavernn_last_loop_ms: no generate call yet"); return MB_ESTATE; }
+  MB_HIP(hipEventSynchronize(w->ev_t1));
+  MB_HIP(hipEventElapsedTime(ms, w->ev_t0, w->ev_t1));
+  if (launches) *launches = w->last_launches;
+  return MB_OK;
+}
+
+extern "C" int mb_wavernn_bench_kernel(mb_wavernn* w, const mb_wavernn_plan* plan, const float* d_mel,
+                                       float* d_samples, void* d_workspace, size_t workspace_bytes,
+                                       int which, int iters, float* avg_us, double* algorithmic_bytes,
+                                       mb_stream_t stream) {
+  MB_REQUIRE(w && plan && avg_us && which >= 0 && which < 5 && iters > 0, "wavernn_bench_kernel: bad argument (which in 0..4)");
+  w->bench_which = 1 << which; w->bench_iters = iters;
+  int rc = mb_wavernn_generate(w, plan, d_mel, nullptr, 0, d_samples, nullptr, nullptr, nullptr, d_workspace,
+                               workspace_bytes, stream);
+  w->bench_which = 0; w->bench_iters = 0;
+  if (rc) return rc;
+  float ms = 0.f;
+  rc = mb_wavernn_last_loop_ms(w, &ms, nullptr);
+  if (rc) return rc;
+  *avg_us = ms * 1000.f / iters;
+  if (algorithmic_bytes) {
+    const double R = w->cfg.rnn_dims, FC = w->cfg.fc_dims, C = w->n_classes, N = plan->n_folds;
+    double b = 0;
+    switch (which) {  // weights once + activation vectors in/out + table rows, fp32
+      case 0: b = 3 * R * 2 * R + 2 * N * R + 2 * N * R + 6 * R; break;
+      case 1: b = 3 * R * 2 * R + 2 * N * R + 2 * N * R + 3 * R + N * 3 * R; break;
+      case 2: b = FC * R + N * R + N * FC + N * FC; break;
+      case 3: b = FC * FC + N * FC + N * FC + N * FC; break;
+      case 4: b = C * FC + N * FC + N * C + C; break;
+      default: b = N * C + N * R * 2 + R; break;
+    }
+    *algorithmic_bytes = b * 4.0;
+  }
+  return MB_OK;
+}

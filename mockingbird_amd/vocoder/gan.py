@@ -1,0 +1,129 @@
+"""Device-side HiFi-GAN / Fre-GAN generator behind the C ABI (mb_gan_*).
+
+Shared by ``vocoder.hifigan.inference`` and ``vocoder.fregan.inference`` --
+the two reference facades are line-for-line identical glue around different
+generators (models/vocoder/hifigan/inference.py:22-74,
+models/vocoder/fregan/inference.py:22-74).
+"""
+import ctypes as C
+import json
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from .. import _lib, weights
+
+KIND_HIFIGAN, KIND_FREGAN = 0, 1
+
+
+class GanGenerator:
+    """Owns an ``mb_gan`` handle; ``forward`` mirrors ``Generator.forward`` /
+    ``FreGAN.forward`` for a [B, 80, F] float32 device tensor."""
+
+    def __init__(self, config: dict, state_dict: dict, kind: int, top_k: int = 4):
+        self.cfg = weights.gan_config(config, kind, top_k)
+        self.kind = kind
+        L = _lib.lib()
+        ws = weights.gan_weight_list(state_dict, self.cfg)
+        n = L.mb_gan_num_weights(C.byref(self.cfg))
+        if n != len(ws):
+            raise _lib.MbHipError(f"weight list has {len(ws)} tensors, ABI expects {n}")
+        for i, w in enumerate(ws):
+            want = L.mb_gan_weight_numel(C.byref(self.cfg), i)
+            if w.numel() != want:
+                raise _lib.MbHipError(f"weight {i}: {tuple(w.shape)} has {w.numel()} elements, expected {want}")
+        arr = _lib.host_ptr_array(ws)
+        h = C.c_void_p()
+        _lib.check(L.mb_gan_create(C.byref(self.cfg), arr, len(ws), C.byref(h)), "mb_gan_create")
+        self._h = h
+        self.hop = L.mb_gan_hop(h)
+        self._ws = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.lib().mb_gan_destroy(h)
+            self._h = None
+
+    def forward(self, mel: torch.Tensor) -> torch.Tensor:
+        if not mel.is_cuda:
+            raise _lib.MbHipError("GanGenerator.forward needs a CUDA(HIP) tensor; there is no CPU path")
+        if mel.dim() == 2:
+            mel = mel.unsqueeze(0)
+        mel = mel.to(torch.float32).contiguous()
+        B, M, F = mel.shape
+        if M != self.cfg.num_mels:
+            raise _lib.MbHipError(f"mel has {M} channels, model expects {self.cfg.num_mels}")
+        if F == 0:
+            return torch.empty(B, 1, 0, device=mel.device)
+        L = _lib.lib()
+        need = L.mb_gan_workspace_bytes(self._h, B, F)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != mel.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=mel.device)
+        wav = torch.empty(B, 1, F * self.hop, dtype=torch.float32, device=mel.device)
+        _lib.check(L.mb_gan_forward(self._h, _lib.ptr(mel), B, F, _lib.ptr(wav), _lib.ptr(self._ws),
+                                    self._ws.numel(), _lib.stream_ptr()), "mb_gan_forward")
+        return wav
+
+    __call__ = forward
+
+
+class GanFacade:
+    """Module-global-singleton semantics of the reference inference modules."""
+
+    def __init__(self, kind: int, default_config: str, name: str):
+        self.kind, self.default_config, self.name = kind, default_config, name
+        self.generator = None
+        self.output_sample_rate = None
+        self._device = None
+
+    def load_model(self, weights_fpath, config_fpath=None, verbose=True):
+        weights_fpath = Path(weights_fpath)
+        if verbose:
+            print(f"Building {self.name}")
+        if config_fpath is None:  # inference.py:28-33
+            found = list(weights_fpath.parent.rglob("*.json"))
+            config_fpath = found[0] if found else self.default_config
+        with open(config_fpath) as f:
+            h = json.loads(f.read())
+        self.output_sample_rate = h["sampling_rate"]
+        torch.manual_seed(h["seed"])  # inference.py:39
+        if not torch.cuda.is_available():
+            raise _lib.MbHipError(f"{self.name}: no MI355X visible; this build has no CPU path")
+        self._device = torch.device("cuda")
+        if verbose:
+            print(f"Loading '{weights_fpath}'")
+        ckpt = torch.load(str(weights_fpath), map_location="cpu")
+        self.generator = GanGenerator(h, ckpt["generator"], self.kind)
+        if verbose:
+            print("Complete.")
+
+    def is_loaded(self):
+        return self.generator is not None
+
+    def infer_waveform(self, mel, progress_callback=None):
+        if self.generator is None:
+            raise Exception(f"Please load {self.name} in memory before using it")
+        mel = torch.FloatTensor(mel).to(self._device)  # numpy or CPU tensor (run.py:90)
+        y = self.generator(mel.unsqueeze(0))
+        audio = y.squeeze().cpu().numpy()
+        return audio, self.output_sample_rate
+
+    def infer_waveform_batch(self, mels, progress_callback=None):
+        """Additive API: a list of (80, Fi) mels -> list of
+        waveforms, run as ONE zero-padded batch (conv stacks are causal-free, so
+        each item is bit-identical to its own first Fi*hop samples only away from
+        the padded tail; items are therefore grouped by equal length)."""
+        if self.generator is None:
+            raise Exception(f"Please load {self.name} in memory before using it")
+        out = [None] * len(mels)
+        by_len = {}
+        for i, m in enumerate(mels):
+            by_len.setdefault(int(np.shape(m)[1]), []).append(i)
+        for _, idx in by_len.items():
+            batch = torch.stack([torch.FloatTensor(mels[i]) for i in idx]).to(self._device)
+            y = self.generator(batch).squeeze(1).cpu().numpy()
+            for k, i in enumerate(idx):
+                out[i] = y[k]
+        return out, self.output_sample_rate

@@ -1,0 +1,138 @@
+"""Drop-in for models/vocoder/wavernn/inference.py:8-64: same ``load_model /
+is_loaded / infer_waveform`` and globals; ``WaveRNN.generate``
+(fatchord_version.py:153-257) runs on the MI355X through libmbhip.so."""
+import ctypes as C
+import time
+
+import numpy as np
+import torch
+
+from ... import _lib, weights
+from . import dsp
+from . import hparams as hp
+
+_model = None   # type: WaveRNNDevice
+_device = None
+
+
+class WaveRNNDevice:
+    """Owns an ``mb_wavernn`` handle (weights resident in HBM)."""
+
+    def __init__(self, state_dict, hparams=hp):
+        self.hp = hparams
+        self.cfg = weights.wavernn_config(hparams)
+        L = _lib.lib()
+        ws = weights.wavernn_weight_list(state_dict, self.cfg)
+        n = L.mb_wavernn_num_weights(C.byref(self.cfg))
+        if n != len(ws):
+            raise _lib.MbHipError(f"weight list has {len(ws)} tensors, ABI expects {n}")
+        for i, w in enumerate(ws):
+            want = L.mb_wavernn_weight_numel(C.byref(self.cfg), i)
+            if w.numel() != want:
+                raise _lib.MbHipError(f"weight {i}: {tuple(w.shape)} has {w.numel()} elements, expected {want}")
+        h = C.c_void_p()
+        _lib.check(L.mb_wavernn_create(C.byref(self.cfg), _lib.host_ptr_array(ws), len(ws), C.byref(h)),
+                   "mb_wavernn_create")
+        self._h = h
+        self.n_classes = 2 ** self.cfg.bits
+        self.hop_length = hparams.hop_length
+        self.sample_rate = hparams.sample_rate
+        self._ws = None
+        self._progress = torch.zeros(4, dtype=torch.int32).pin_memory() if torch.cuda.is_available() else None
+        self.last_loop_ms = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.lib().mb_wavernn_destroy(h)
+            self._h = None
+
+    def plan(self, frames, batched, target, overlap):
+        p = _lib.WaveRNNPlan()
+        _lib.check(_lib.lib().mb_wavernn_plan_generate(self._h, frames, int(bool(batched)), target, overlap,
+                                                       C.byref(p)), "mb_wavernn_plan_generate")
+        return p
+
+    def generate_samples(self, mel: torch.Tensor, batched, target, overlap, noise=None, seed=0,
+                         forced=None, want_logits=False, progress_callback=None):
+        """mel [80, F] float32 CUDA (already normalised) -> samples [n_folds, seq_len] CUDA float32
+        (the tensor stacked at fatchord_version.py:236), optionally the fc3 logits [S, N, C]."""
+        if not mel.is_cuda:
+            raise _lib.MbHipError("WaveRNN needs a CUDA(HIP) tensor; there is no CPU path")
+        mel = mel.to(torch.float32).contiguous()
+        F = mel.shape[1]
+        p = self.plan(F, batched, target, overlap)
+        dev = mel.device
+        if self._ws is None or self._ws.numel() < p.workspace_bytes or self._ws.device != dev:
+            self._ws = torch.empty(p.workspace_bytes, dtype=torch.uint8, device=dev)
+        samples = torch.empty(p.n_folds, p.seq_len, dtype=torch.float32, device=dev)
+        logits = (torch.empty(p.seq_len, p.n_folds, self.n_classes, dtype=torch.float32, device=dev)
+                  if want_logits else None)
+        if noise is not None:
+            noise = noise.to(dev, torch.float32).contiguous()
+            if tuple(noise.shape) != (p.seq_len, p.n_folds, self.n_classes):
+                raise _lib.MbHipError(f"noise must be {(p.seq_len, p.n_folds, self.n_classes)}, got {tuple(noise.shape)}")
+        if forced is not None:
+            forced = forced.to(dev, torch.float32).contiguous()
+        self._progress.zero_()
+        L = _lib.lib()
+        start = time.time()
+        _lib.check(L.mb_wavernn_generate(self._h, C.byref(p), _lib.ptr(mel), _lib.ptr(noise), int(seed),
+                                         _lib.ptr(samples), _lib.ptr(logits), _lib.ptr(forced),
+                                         _lib.ptr(self._progress), _lib.ptr(self._ws), self._ws.numel(),
+                                         _lib.stream_ptr()), "mb_wavernn_generate")
+        if progress_callback is not None:
+            # the kernels publish the completed step count every 100 steps (fatchord_version.py:232-234)
+            done_ev = torch.cuda.Event()
+            done_ev.record()
+            last = -1
+            while not done_ev.query():
+                i = int(self._progress[0]) - 1
+                if i >= 0 and i != last:
+                    last = i
+                    gen_rate = (i + 1) / max(time.time() - start, 1e-9) * p.n_folds / 1000
+                    progress_callback(i, p.seq_len, p.n_folds, gen_rate)
+                time.sleep(0.002)
+        torch.cuda.current_stream().synchronize()
+        ms, nl = C.c_float(), C.c_int()
+        _lib.check(L.mb_wavernn_last_loop_ms(self._h, C.byref(ms), C.byref(nl)), "mb_wavernn_last_loop_ms")
+        self.last_loop_ms, self.last_loop_launches, self.last_plan = ms.value, nl.value, p
+        return (samples, logits) if want_logits else samples
+
+    def generate(self, mels, batched, target, overlap, mu_law, progress_callback=None, noise=None, seed=0):
+        """Signature of WaveRNN.generate (fatchord_version.py:153): mels [1, 80, F] tensor -> float64 wav."""
+        mel = mels[0] if mels.dim() == 3 else mels
+        wave_len = (mel.shape[-1] - 1) * self.hop_length
+        samples = self.generate_samples(mel.cuda(), batched, target, overlap, noise=noise, seed=seed,
+                                        progress_callback=progress_callback)
+        return dsp.finish(samples.cpu().numpy(), batched, overlap, self.n_classes, mu_law,
+                          self.hp.apply_preemphasis, self.hp.preemphasis, wave_len, self.hop_length)
+
+
+def load_model(weights_fpath, verbose=True):
+    # NB: the toolbox passes a 2nd positional config path that lands in `verbose`
+    # (control/toolbox/__init__.py:471); any truthy/falsy value is tolerated.
+    global _model, _device
+    if verbose:
+        print("Building Wave-RNN")
+    if not torch.cuda.is_available():
+        raise _lib.MbHipError("Wave-RNN: no MI355X visible; this build has no CPU path")
+    _device = torch.device('cuda')
+    if verbose:
+        print("Loading model weights at %s" % weights_fpath)
+    checkpoint = torch.load(str(weights_fpath), map_location="cpu")
+    _model = WaveRNNDevice(checkpoint['model_state'])
+
+
+def is_loaded():
+    return _model is not None
+
+
+def infer_waveform(mel, normalize=True, batched=True, target=8000, overlap=800, progress_callback=None):
+    if _model is None:
+        raise Exception("Please load Wave-RNN in memory before using it")
+    if normalize:
+        mel = mel / hp.mel_max_abs_value
+    mel = torch.from_numpy(mel[None, ...])
+    wav = _model.generate(mel, batched, target, overlap, hp.mu_law, progress_callback)
+    return wav, hp.sample_rate

@@ -1,0 +1,126 @@
+"""Checkpoint -> ABI weight lists.
+
+Accepts the reference's exact state-dict layouts (SURVEY.md section 5 "Checkpoint /
+resume") and produces, for each model, the ordered list of contiguous float32
+CPU tensors that the matching ``mb_*_create`` entry point documents in
+include/mbhip.h.  All folding (weight-norm, eval BatchNorm) is done here or in
+the C library at load time, never per call.
+"""
+from typing import Dict, List
+
+import torch
+
+from . import _lib
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to("cpu", torch.float32).contiguous()
+
+
+def fold_weight_norm(state: Dict[str, torch.Tensor], prefix: str) -> torch.Tensor:
+    """`weight` of a (possibly weight-normed) conv: w = g * v / ||v||, norm over
+    every dim but 0 -- what torch's remove_weight_norm() leaves behind
+    (models/vocoder/hifigan/models.py:152-162), for Conv1d and ConvTranspose1d alike."""
+    if prefix + ".weight" in state:
+        return _f32(state[prefix + ".weight"])
+    for g_key, v_key in ((".weight_g", ".weight_v"),
+                         (".parametrizations.weight.original0", ".parametrizations.weight.original1")):
+        if prefix + g_key in state:
+            g = state[prefix + g_key].detach().to("cpu", torch.float32)
+            v = state[prefix + v_key].detach().to("cpu", torch.float32)
+            # torch._weight_norm: v * (g / norm_except_dim(v, 2, 0))
+            norm = v.reshape(v.shape[0], -1).norm(dim=1).reshape(-1, *([1] * (v.dim() - 1)))
+            return (v * (g / norm)).contiguous()
+    raise KeyError(f"no weight for '{prefix}' in checkpoint")
+
+
+# ---------------------------------------------------------------- GAN vocoders
+def gan_config(h: dict, kind: int, top_k: int = 4) -> "_lib.GanConfig":
+    """AttrDict/json config (hifigan/config_16k_.json, fregan/config.json) -> mb_gan_config."""
+    if str(h.get("resblock", "1")) != "1":
+        raise _lib.MbHipError("only resblock type '1' is implemented (the shipped configs)")
+    if kind == 0 and int(h.get("sampling_rate", 16000)) == 24000:
+        raise _lib.MbHipError("24 kHz Interpolate+Conv1d HiFi-GAN variant (models.py:107-118) not implemented")
+    c = _lib.GanConfig()
+    c.kind = kind
+    c.num_mels = int(h.get("num_mels", 80))
+    c.upsample_initial_channel = int(h["upsample_initial_channel"])
+    ur, uk = list(h["upsample_rates"]), list(h["upsample_kernel_sizes"])
+    c.num_upsamples = len(ur)
+    for i, (u, k) in enumerate(zip(ur, uk)):
+        c.upsample_rates[i] = int(u)
+        c.upsample_kernel_sizes[i] = int(k)
+    rk, rd = list(h["resblock_kernel_sizes"]), list(h["resblock_dilation_sizes"])
+    c.num_kernels = len(rk)
+    c.num_dilations = len(rd[0])
+    for j, k in enumerate(rk):
+        c.resblock_kernel_sizes[j] = int(k)
+        for d, dil in enumerate(rd[j]):
+            c.resblock_dilations[j][d] = int(dil)
+    c.top_k = top_k
+    return c
+
+
+def gan_weight_list(state: Dict[str, torch.Tensor], cfg: "_lib.GanConfig") -> List[torch.Tensor]:
+    names = ["conv_pre"] + [f"ups.{i}" for i in range(cfg.num_upsamples)]
+    if cfg.kind == 1:
+        lvl = cfg.num_upsamples - cfg.top_k
+        names += [f"cond_up.{i}" for i in range(cfg.num_upsamples - lvl)]
+        names += [f"res_output.{i}.1" for i in range(cfg.num_upsamples - lvl - 1)]
+    for i in range(cfg.num_upsamples * cfg.num_kernels):
+        names += [f"resblocks.{i}.convs1.{d}" for d in range(cfg.num_dilations)]
+        names += [f"resblocks.{i}.convs2.{d}" for d in range(cfg.num_dilations)]
+    names.append("conv_post")
+    out = []
+    for n in names:
+        out.append(fold_weight_norm(state, n))
+        out.append(_f32(state[n + ".bias"]))
+    return out
+
+
+def fold_batchnorm(state, prefix: str, eps: float = 1e-5):
+    """Eval-mode BatchNorm1d as y = x*scale + shift."""
+    w = state[prefix + ".weight"].detach().double().cpu()
+    b = state[prefix + ".bias"].detach().double().cpu()
+    m = state[prefix + ".running_mean"].detach().double().cpu()
+    v = state[prefix + ".running_var"].detach().double().cpu()
+    scale = w / torch.sqrt(v + eps)
+    shift = b - m * scale
+    return scale.float().contiguous(), shift.float().contiguous()
+
+
+# --------------------------------------------------------------------- WaveRNN
+def wavernn_config(hp) -> "_lib.WaveRNNConfig":
+    """hp: module/dict with the reference's wavernn/hparams.py names."""
+    g = (lambda k: hp[k]) if isinstance(hp, dict) else (lambda k: getattr(hp, k))
+    c = _lib.WaveRNNConfig()
+    c.rnn_dims, c.fc_dims, c.bits, c.pad = int(g("voc_rnn_dims")), int(g("voc_fc_dims")), int(g("bits")), int(g("voc_pad"))
+    f = tuple(g("voc_upsample_factors"))
+    c.n_upsample = len(f)
+    for i, s in enumerate(f):
+        c.upsample_factors[i] = int(s)
+    c.feat_dims, c.compute_dims = int(g("num_mels")), int(g("voc_compute_dims"))
+    c.res_out_dims, c.res_blocks = int(g("voc_res_out_dims")), int(g("voc_res_blocks"))
+    mode = g("voc_mode")
+    if mode != "RAW":
+        raise _lib.MbHipError("only voc_mode='RAW' (the reference default, wavernn/hparams.py:23) is implemented")
+    c.mode = 0
+    return c
+
+
+def wavernn_weight_list(state: Dict[str, torch.Tensor], cfg: "_lib.WaveRNNConfig") -> List[torch.Tensor]:
+    """ABI order of mb_wavernn_create (include/mbhip.h section 3)."""
+    def bn(p):
+        return [p + ".weight", p + ".bias", p + ".running_mean", p + ".running_var"]
+    r = "upsample.resnet."
+    names = [r + "conv_in.weight"] + bn(r + "batch_norm")
+    for i in range(cfg.res_blocks):
+        q = f"{r}layers.{i}."
+        names += [q + "conv1.weight"] + bn(q + "batch_norm1") + [q + "conv2.weight"] + bn(q + "batch_norm2")
+    names += [r + "conv_out.weight", r + "conv_out.bias"]
+    names += [f"upsample.up_layers.{2 * i + 1}.weight" for i in range(cfg.n_upsample)]
+    names += ["I.weight", "I.bias"]
+    for n in ("rnn1", "rnn2"):
+        names += [f"{n}.weight_ih_l0", f"{n}.weight_hh_l0", f"{n}.bias_ih_l0", f"{n}.bias_hh_l0"]
+    names += ["fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias"]
+    return [_f32(state[n]) for n in names]

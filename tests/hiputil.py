@@ -1,0 +1,67 @@
+"""Thin helpers to call the C ABI primitives from tests."""
+import ctypes as C
+
+import torch
+
+from mockingbird_amd import _lib
+
+
+def pack_conv(w: torch.Tensor, transposed=False, up=1, pad=0):
+    """torch-layout conv weight -> packed device tensor."""
+    L = _lib.lib()
+    w = w.detach().float().contiguous().cpu()
+    if transposed:
+        c_in, c_out, k = w.shape
+    else:
+        c_out, c_in, k = w.shape
+    n = L.mb_conv1d_packed_floats(c_out, c_in, k, up)
+    out = torch.empty(n, dtype=torch.float32)
+    _lib.check(L.mb_conv1d_pack(w.data_ptr(), c_out, c_in, k, up, int(transposed), pad, out.data_ptr()),
+               "mb_conv1d_pack")
+    return out, (c_out, c_in, k)
+
+
+def conv1d_hip(x, w, bias=None, *, dilation=1, pad=0, transposed=False, up=1, in_act=0, in_slope=0.0,
+               in_scale=1.0, out_act=0, out_scale=1.0, res=None, accumulate_into=None, post=None,
+               transpose_out=False, in_repeat=1, device="cuda"):
+    """x [B, Cin, T] CPU/GPU tensor -> y (new tensor, or accumulate_into updated in place)."""
+    L = _lib.lib()
+    packed, (c_out, c_in, k) = pack_conv(w, transposed, up, pad)
+    dev = torch.device(device)
+    x = x.float().contiguous().to(dev)
+    B, _, t_src = x.shape
+    t_in = t_src * in_repeat
+    t_out = t_in * up if transposed else t_in + 2 * pad - dilation * (k - 1)
+    a = _lib.ConvArgs()
+    pw = packed.to(dev)
+    pb = bias.float().contiguous().to(dev) if bias is not None else None
+    pres = res.float().contiguous().to(dev) if res is not None else None
+    if accumulate_into is not None:
+        y = accumulate_into.float().contiguous().to(dev)
+    elif transpose_out:
+        y = torch.full((B, t_out, c_out), float("nan"), device=dev)
+    else:
+        y = torch.full((B, c_out, t_out), float("nan"), device=dev)
+    ps = pt = None
+    if post is not None:
+        ps, pt = post[0].float().contiguous().to(dev), post[1].float().contiguous().to(dev)
+    a.d_x, a.d_wpacked, a.d_bias, a.d_res = x.data_ptr(), pw.data_ptr(), (pb.data_ptr() if pb is not None else None), (pres.data_ptr() if pres is not None else None)
+    a.d_post_scale, a.d_post_shift = (ps.data_ptr() if ps is not None else None), (pt.data_ptr() if pt is not None else None)
+    a.d_y = y.data_ptr()
+    a.x_bstride, a.y_bstride, a.res_bstride = c_in * t_src, c_out * t_out, c_out * t_out
+    a.batch, a.c_in, a.c_out, a.t_in, a.t_out = B, c_in, c_out, t_in, t_out
+    a.ksize, a.dilation, a.pad, a.up = k, dilation, pad, (up if transposed else 1)
+    a.in_act, a.in_slope, a.in_scale = in_act, in_slope, in_scale
+    a.out_act, a.out_scale, a.accumulate = out_act, out_scale, int(accumulate_into is not None)
+    a.in_repeat, a.transpose_out = in_repeat, int(transpose_out)
+    _lib.check(L.mb_conv1d(C.byref(a), _lib.stream_ptr()), "mb_conv1d")
+    torch.cuda.synchronize()
+    return y
+
+
+def relerr(a: torch.Tensor, b: torch.Tensor):
+    a, b = a.double().cpu(), b.double().cpu()
+    d = (a - b).abs()
+    return dict(max_abs=float(d.max()), rms=float(d.pow(2).mean().sqrt()),
+                rel_rms=float(d.pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-30)),
+                ref_rms=float(b.pow(2).mean().sqrt()), nan=int(torch.isnan(a).sum()))

@@ -1,0 +1,28 @@
+"""Import the real reference (/root/reference) with the shims SURVEY.md section 8c lists.
+Only usable in the build container; the GPU box has no /root/reference."""
+import os
+import sys
+import types
+
+REF = os.environ.get("MOCKINGBIRD_REF", "/root/reference")
+
+
+def available() -> bool:
+    return os.path.isdir(os.path.join(REF, "models", "vocoder"))
+
+
+def setup():
+    if not available():
+        raise RuntimeError("reference checkout not present")
+    sys.dont_write_bytecode = True
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import numpy as np
+    if not hasattr(np, "cumproduct"):
+        np.cumproduct = np.cumprod  # fatchord_version.py:64 (NumPy 2 removed it)
+    for name in ("librosa", "librosa.filters", "soundfile"):  # wavernn/audio.py:3,6 (unused by generate)
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                sys.modules[name] = types.ModuleType(name)

@@ -1,0 +1,151 @@
+"""Seeded synthetic checkpoints in the reference's state-dict layouts (there
+are no pretrained checkpoints anywhere).  No reference import
+needed: shapes come from the configs.  Scales are chosen so activations stay
+O(1) (the reference's N(0,0.01) GAN init gives ~1e-6 outputs, making absolute
+tolerances vacuous, SURVEY.md section 7 hard part 5)."""
+import math
+
+import numpy as np
+import torch
+
+HIFIGAN_16K = {
+    "resblock": "1", "upsample_rates": [5, 5, 4, 2], "upsample_kernel_sizes": [10, 10, 8, 4],
+    "upsample_initial_channel": 512, "resblock_kernel_sizes": [3, 7, 11],
+    "resblock_dilation_sizes": [[1, 3, 5], [1, 3, 5], [1, 3, 5]], "num_mels": 80,
+    "sampling_rate": 16000, "seed": 1234,
+}
+FREGAN_16K = {
+    "resblock": "1", "upsample_rates": [5, 5, 2, 2, 2], "upsample_kernel_sizes": [10, 10, 4, 4, 4],
+    "upsample_initial_channel": 512, "resblock_kernel_sizes": [3, 7, 11],
+    "resblock_dilation_sizes": [[1, 3, 5, 7], [1, 3, 5, 7], [1, 3, 5, 7]], "num_mels": 80,
+    "sampling_rate": 16000, "seed": 1234,
+}
+
+
+def small(cfg, uic=64):
+    c = dict(cfg)
+    c["upsample_initial_channel"] = uic
+    return c
+
+
+def _wn(rng, shape, row_norm):
+    """weight_g / weight_v pair whose folded weight has per-dim0-row L2 norm `row_norm`."""
+    v = rng.standard_normal(shape).astype(np.float32)
+    g = np.full((shape[0],) + (1,) * (len(shape) - 1), row_norm, np.float32)
+    g *= (1.0 + 0.1 * rng.standard_normal(g.shape)).astype(np.float32)
+    return torch.from_numpy(g), torch.from_numpy(v)
+
+
+def gan_state(h, kind="hifigan", seed=0, top_k=4):
+    """{'generator': state_dict} with weight_g/weight_v/bias per conv, as
+    hifigan/inference.py:47-52 expects before remove_weight_norm()."""
+    rng = np.random.default_rng(seed)
+    uic = h["upsample_initial_channel"]
+    rates, ks = h["upsample_rates"], h["upsample_kernel_sizes"]
+    sd = {}
+
+    def conv(name, cout, cin, k, gain=1.0):  # Conv1d weight [cout][cin][k]
+        g, v = _wn(rng, (cout, cin, k), gain)
+        sd[name + ".weight_g"], sd[name + ".weight_v"] = g, v
+        sd[name + ".bias"] = torch.from_numpy((0.05 * rng.standard_normal(cout)).astype(np.float32))
+
+    def convT(name, cin, cout, k, u, gain=1.0):  # ConvTranspose1d weight [cin][cout][k]; norm per cin row
+        # each output sums cin*(k/u) taps of variance row_norm^2/(cout*k) -> var = cin*row_norm^2/(cout*u)
+        rn = gain * math.sqrt(cout * u / cin)
+        g, v = _wn(rng, (cin, cout, k), rn)
+        sd[name + ".weight_g"], sd[name + ".weight_v"] = g, v
+        sd[name + ".bias"] = torch.from_numpy((0.05 * rng.standard_normal(cout)).astype(np.float32))
+
+    conv("conv_pre", uic, h["num_mels"], 7, 1.0 / 1.5)
+    for i, (u, k) in enumerate(zip(rates, ks)):
+        convT(f"ups.{i}", uic >> i, uic >> (i + 1), k, u, 1.3)
+    if kind == "fregan":
+        lvl = len(rates) - top_k
+        kr = h["num_mels"]
+        for i in range(lvl, len(rates)):
+            convT(f"cond_up.{i - lvl}", kr, uic >> i, ks[i - 1], rates[i - 1], 0.7)
+            kr = uic >> i
+        for i in range(lvl + 1, len(rates)):
+            conv(f"res_output.{i - lvl - 1}.1", uic >> (i + 1), uic >> i, 1, 0.7)
+    nk = len(h["resblock_kernel_sizes"])
+    for i in range(len(rates)):
+        ch = uic >> (i + 1)
+        for j, k in enumerate(h["resblock_kernel_sizes"]):
+            nd = len(h["resblock_dilation_sizes"][j])
+            for d in range(nd):
+                conv(f"resblocks.{i * nk + j}.convs1.{d}", ch, ch, k, 1.2)
+            for d in range(nd):
+                conv(f"resblocks.{i * nk + j}.convs2.{d}", ch, ch, k, 0.6)
+    conv("conv_post", 1, uic >> len(rates), 7, 0.25)
+    return {"generator": sd}
+
+
+def mel_input(frames, batch=1, seed=0, n_mels=80):
+    """clip(N(0,1.5), -4, 4) float32."""
+    rng = np.random.default_rng(seed)
+    m = np.clip(rng.normal(0, 1.5, (batch, n_mels, frames)), -4, 4).astype(np.float32)
+    return m
+
+
+WAVERNN_HP = dict(rnn_dims=512, fc_dims=512, bits=9, pad=2, upsample_factors=(5, 5, 8), feat_dims=80,
+                  compute_dims=128, res_out_dims=128, res_blocks=10, hop_length=256, sample_rate=16000,
+                  mode="RAW", mu_law=True, apply_preemphasis=True, preemphasis=0.97,
+                  mel_max_abs_value=4.0)
+
+
+def wavernn_state(hp=WAVERNN_HP, seed=0):
+    """{'model_state': state_dict} in the reference WaveRNN layout (fatchord_version.py:88-122)."""
+    rng = np.random.default_rng(seed)
+    R, FC, A = hp["rnn_dims"], hp["fc_dims"], hp["res_out_dims"] // 4
+    CD, FEAT, C = hp["compute_dims"], hp["feat_dims"], 2 ** hp["bits"]
+    sd = {}
+
+    def t(shape, scale):
+        return torch.from_numpy((scale * rng.standard_normal(shape)).astype(np.float32))
+
+    def bn(p, n):
+        sd[p + ".weight"] = torch.from_numpy((1.0 + 0.1 * rng.standard_normal(n)).astype(np.float32))
+        sd[p + ".bias"] = t((n,), 0.1)
+        sd[p + ".running_mean"] = t((n,), 0.1)
+        sd[p + ".running_var"] = torch.from_numpy(rng.uniform(0.5, 1.5, n).astype(np.float32))
+        sd[p + ".num_batches_tracked"] = torch.tensor(1, dtype=torch.long)
+
+    k = 2 * hp["pad"] + 1
+    sd["upsample.resnet.conv_in.weight"] = t((CD, FEAT, k), 1.0 / math.sqrt(FEAT * k))
+    bn("upsample.resnet.batch_norm", CD)
+    for i in range(hp["res_blocks"]):
+        p = f"upsample.resnet.layers.{i}."
+        sd[p + "conv1.weight"] = t((CD, CD, 1), 1.0 / math.sqrt(CD))
+        sd[p + "conv2.weight"] = t((CD, CD, 1), 0.5 / math.sqrt(CD))
+        bn(p + "batch_norm1", CD)
+        bn(p + "batch_norm2", CD)
+    sd["upsample.resnet.conv_out.weight"] = t((hp["res_out_dims"], CD, 1), 0.3 / math.sqrt(CD))
+    sd["upsample.resnet.conv_out.bias"] = t((hp["res_out_dims"],), 0.1)
+    for i, s in enumerate(hp["upsample_factors"]):
+        wk = np.full((1, 1, 1, 2 * s + 1), 1.0 / (2 * s + 1), np.float32)
+        wk *= (1.0 + 0.05 * rng.standard_normal(wk.shape)).astype(np.float32)  # "trained" box filter
+        sd[f"upsample.up_layers.{2 * i + 1}.weight"] = torch.from_numpy(wk)
+    sd["I.weight"] = t((R, FEAT + A + 1), 1.0 / math.sqrt(FEAT + A + 1))
+    sd["I.bias"] = t((R,), 0.1)
+    for n, kin in (("rnn1", R), ("rnn2", R + A)):
+        sd[f"{n}.weight_ih_l0"] = t((3 * R, kin), 1.0 / math.sqrt(kin))
+        sd[f"{n}.weight_hh_l0"] = t((3 * R, R), 1.0 / math.sqrt(R))
+        sd[f"{n}.bias_ih_l0"] = t((3 * R,), 0.1)
+        sd[f"{n}.bias_hh_l0"] = t((3 * R,), 0.1)
+    sd["fc1.weight"] = t((FC, R + A), 1.0 / math.sqrt(R + A)); sd["fc1.bias"] = t((FC,), 0.1)
+    sd["fc2.weight"] = t((FC, FC + A), 1.4 / math.sqrt(FC + A)); sd["fc2.bias"] = t((FC,), 0.1)
+    sd["fc3.weight"] = t((C, FC), 2.0 / math.sqrt(FC)); sd["fc3.bias"] = t((C,), 0.1)
+    sd["step"] = torch.zeros(1, dtype=torch.long)
+    return {"model_state": sd}
+
+
+def wavernn_mel(frames, seed=1, n_mels=80):
+    """U(0,4) float32; infer_waveform divides by 4."""
+    rng = np.random.default_rng(seed)
+    return rng.uniform(0, 4, (n_mels, frames)).astype(np.float32)
+
+
+def exp_noise(seed, steps, folds, classes):
+    """Exp(1) draws in the order torch.multinomial consumes them: one (folds, classes) tensor per step."""
+    g = torch.Generator().manual_seed(seed)
+    return torch.stack([torch.empty(folds, classes).exponential_(1, generator=g) for _ in range(steps)])

@@ -1,0 +1,126 @@
+"""Parity of the MFMA conv primitive (mb_conv1d) against ATen CPU conv ops, layer shapes of the path."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import hiputil
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5  # fp32 MFMA is an exact fmaf chain; only summation order differs from ATen
+
+
+def _rand(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g)
+
+
+CONV_CASES = [
+    # (B, Cin, Cout, T, k, dil)  -- HiFi-GAN / Fre-GAN / CBHG / WaveRNN layer shapes
+    (1, 80, 512, 40, 7, 1),      # conv_pre
+    (2, 256, 256, 200, 3, 1),
+    (1, 256, 256, 130, 11, 5),   # widest HiFi-GAN halo
+    (1, 128, 128, 333, 7, 3),
+    (1, 64, 64, 700, 11, 7),     # Fre-GAN dilation 7
+    (3, 32, 32, 1000, 3, 5),
+    (1, 32, 1, 800, 7, 1),       # conv_post (Cout=1)
+    (1, 16, 1, 513, 7, 1),       # Fre-GAN conv_post
+    (2, 80, 512, 57, 5, 1),      # CBHG bank k=5
+    (1, 2560, 512, 64, 3, 1),    # CBHG proj1
+    (1, 512, 80, 64, 3, 1),      # CBHG proj2 (Cout not multiple of 32)
+    (1, 128, 128, 37, 1, 1),     # MelResNet 1x1
+    (1, 112, 512, 77, 1, 1),     # WaveRNN I table
+    (1, 32, 1536, 9, 1, 1),      # WaveRNN G2 table (tiny T, many rows -> WM=4 path)
+    (1, 20, 24, 50, 3, 1),       # odd channel counts (padding paths)
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T,k,dil", CONV_CASES)
+def test_conv1d_same(cuda, lib, B, Cin, Cout, T, k, dil):
+    x = _rand(B, Cin, T, seed=1)
+    w = _rand(Cout, Cin, k, seed=2) / (Cin * k) ** 0.5
+    b = _rand(Cout, seed=3)
+    pad = (k * dil - dil) // 2
+    ref = F.conv1d(x, w, b, dilation=dil, padding=pad)
+    y = hiputil.conv1d_hip(x, w, b, dilation=dil, pad=pad)
+    e = hiputil.relerr(y, ref)
+    assert e["nan"] == 0 and e["max_abs"] < TOL * max(1.0, e["ref_rms"]) * 10, e
+
+
+def test_conv1d_even_kernel_crop(cuda, lib):
+    # CBHG bank with even k: padding k//2 gives T+1 outputs, reference keeps [:T] (cbhg.py:55-56)
+    x = _rand(2, 80, 50, seed=4)
+    w = _rand(128, 80, 4, seed=5) / 18.0
+    ref = F.conv1d(x, w, None, padding=2)
+    y = hiputil.conv1d_hip(x, w, None, pad=2)
+    assert y.shape[-1] == 51
+    e = hiputil.relerr(y, ref)
+    assert e["nan"] == 0 and e["max_abs"] < 1e-4, e
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T,k,u", [
+    (1, 512, 256, 40, 10, 5), (2, 256, 128, 100, 10, 5), (1, 128, 64, 300, 8, 4), (1, 64, 32, 777, 4, 2),
+    (1, 80, 256, 33, 10, 5),   # Fre-GAN cond_up[0]
+])
+def test_conv_transpose1d(cuda, lib, B, Cin, Cout, T, k, u):
+    x = _rand(B, Cin, T, seed=6)
+    w = _rand(Cin, Cout, k, seed=7) / (Cin * k / u) ** 0.5
+    b = _rand(Cout, seed=8)
+    pad = u // 2 + u % 2
+    ref = F.conv_transpose1d(x, w, b, stride=u, padding=pad, output_padding=u % 2)
+    y = hiputil.conv1d_hip(x, w, b, transposed=True, up=u, pad=pad)
+    assert y.shape == ref.shape
+    e = hiputil.relerr(y, ref)
+    assert e["nan"] == 0 and e["max_abs"] < 1e-4, e
+
+
+def test_fused_prologue_epilogue(cuda, lib):
+    # y_old + ((conv(lrelu(x*s)) + b) + res) * out_scale   -- the resblock tail (models.py:38-43,140-145)
+    x, res, yold = _rand(2, 64, 300, seed=9), _rand(2, 64, 300, seed=10), _rand(2, 64, 300, seed=11)
+    w, b = _rand(64, 64, 7, seed=12) / 21.0, _rand(64, seed=13)
+    ref = yold + (F.conv1d(F.leaky_relu(x * 0.5, 0.1), w, b, padding=3) + res) * (1.0 / 3.0)
+    y = hiputil.conv1d_hip(x, w, b, pad=3, in_act=1, in_slope=0.1, in_scale=0.5, res=res, out_scale=1.0 / 3.0,
+                           accumulate_into=yold)
+    e = hiputil.relerr(y, ref)
+    assert e["nan"] == 0 and e["max_abs"] < 1e-4, e
+
+
+def test_relu_bn_and_tanh(cuda, lib):
+    x = _rand(1, 80, 90, seed=14)
+    w = _rand(96, 80, 3, seed=15) / 15.0
+    sc, sh = _rand(96, seed=16).abs() + 0.5, _rand(96, seed=17)
+    ref = F.relu(F.conv1d(x, w, None, padding=1)) * sc[None, :, None] + sh[None, :, None]
+    y = hiputil.conv1d_hip(x, w, None, pad=1, out_act=1, post=(sc, sh))
+    e = hiputil.relerr(y, ref)
+    assert e["max_abs"] < 1e-4, e
+    ref = torch.tanh(F.conv1d(F.leaky_relu(x, 0.01), w, None, padding=1))
+    y = hiputil.conv1d_hip(x, w, None, pad=1, in_act=1, in_slope=0.01, out_act=2)
+    e = hiputil.relerr(y, ref)
+    assert e["max_abs"] < 1e-5, e
+
+
+def test_maxpool_prologue(cuda, lib):
+    # MaxPool1d(2,1,1)[:T] fused into the consumer conv (cbhg.py:20,61-64)
+    x = _rand(2, 40, 61, seed=18)
+    w = _rand(64, 40, 3, seed=19) / 11.0
+    pooled = F.max_pool1d(x, kernel_size=2, stride=1, padding=1)[:, :, :61]
+    ref = F.conv1d(pooled, w, None, padding=1)
+    y = hiputil.conv1d_hip(x, w, None, pad=1, in_act=2)
+    e = hiputil.relerr(y, ref)
+    assert e["max_abs"] < 1e-4, e
+
+
+def test_transpose_out_and_repeat(cuda, lib):
+    x = _rand(1, 112, 300, seed=20)
+    w, b = _rand(512, 112, 1, seed=21) / 10.6, _rand(512, seed=22)
+    ref = F.conv1d(x, w, b).transpose(1, 2)
+    y = hiputil.conv1d_hip(x, w, b, transpose_out=True)
+    e = hiputil.relerr(y, ref)
+    assert y.shape == ref.shape and e["nan"] == 0 and e["max_abs"] < 1e-4, e
+    # nearest-neighbour upsample x2 folded into a 1x1 conv (fregan/generator.py:104-110)
+    x = _rand(2, 128, 75, seed=23)
+    w, b = _rand(64, 128, 1, seed=24) / 11.3, _rand(64, seed=25)
+    ref = F.conv1d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b)
+    y = hiputil.conv1d_hip(x, w, b, in_repeat=2)
+    e = hiputil.relerr(y, ref)
+    assert y.shape == ref.shape and e["max_abs"] < 1e-4, e

@@ -1,0 +1,83 @@
+"""HiFi-GAN / Fre-GAN generator forward: HIP (mb_gan_forward via the facade classes) vs the oracle.
+Gate (north_star / SURVEY.md section 8d): audio RMS(delta) <= 1e-4, relative RMS <= 1e-3 on O(1) fixtures."""
+import numpy as np
+import pytest
+import torch
+
+import hiputil
+import synth
+from oracle import gan as og
+
+pytestmark = pytest.mark.gpu
+
+RMS_TOL, REL_TOL = 1e-4, 1e-3
+
+
+def _run(kind, h, frames, batch, seed):
+    from mockingbird_amd.vocoder.gan import GanGenerator
+    st = synth.gan_state(h, kind, seed=seed)
+    gen = GanGenerator(h, st["generator"], 0 if kind == "hifigan" else 1)
+    mel = torch.from_numpy(synth.mel_input(frames, batch, seed=seed + 1))
+    with torch.no_grad():
+        w = og.fold_weight_norm_state(st["generator"])
+        ref = (og.hifigan_forward if kind == "hifigan" else og.fregan_forward)(w, h, mel)
+    y = gen(mel.cuda())
+    torch.cuda.synchronize()
+    return y.cpu(), ref
+
+
+@pytest.mark.parametrize("kind,cfg", [("hifigan", synth.HIFIGAN_16K), ("fregan", synth.FREGAN_16K)])
+@pytest.mark.parametrize("uic,frames,batch", [(64, 16, 2), (64, 37, 1), (512, 12, 1)])
+def test_gan_forward_matches_oracle(cuda, lib, kind, cfg, uic, frames, batch):
+    h = synth.small(cfg, uic)
+    y, ref = _run(kind, h, frames, batch, seed=3)
+    assert y.shape == ref.shape == (batch, 1, frames * 200)
+    e = hiputil.relerr(y, ref)
+    assert e["nan"] == 0 and e["rms"] <= RMS_TOL and e["rel_rms"] <= REL_TOL, e
+
+
+@pytest.mark.parametrize("kind,cfg", [("hifigan", synth.HIFIGAN_16K), ("fregan", synth.FREGAN_16K)])
+def test_gan_time_translation_property(cuda, lib, kind, cfg):
+    """Size-independent property at full length (BASELINE config 0: 80x200): the generator is
+    fully convolutional, so the interior of the output for a mel equals the output for the
+    same mel embedded in a longer zero-padded one, away from the receptive-field border."""
+    from mockingbird_amd.vocoder.gan import GanGenerator
+    h = cfg
+    st = synth.gan_state(h, kind, seed=5)
+    gen = GanGenerator(h, st["generator"], 0 if kind == "hifigan" else 1)
+    mel = torch.from_numpy(synth.mel_input(200, 1, seed=0)).cuda()
+    y = gen(mel)
+    # same content shifted by 8 frames inside a longer input
+    longer = torch.zeros(1, 80, 232, device="cuda")
+    longer[:, :, 8:208] = mel
+    y2 = gen(longer)
+    torch.cuda.synchronize()
+    a = y[0, 0, 40 * 200:160 * 200].cpu()
+    b = y2[0, 0, 48 * 200:168 * 200].cpu()
+    e = hiputil.relerr(a, b)
+    assert e["nan"] == 0 and e["rms"] <= 1e-5, e
+    assert float(y.abs().max()) <= 1.0 and float(y.pow(2).mean()) > 1e-4
+
+
+def test_facade_signature_and_errors(cuda, lib, tmp_path):
+    """models/vocoder/hifigan/inference.py:22-74 semantics: json lookup beside the checkpoint,
+    exception text when unloaded, numpy in -> (float32 numpy, sample_rate) out."""
+    import importlib, json
+    import mockingbird_amd.vocoder.hifigan.inference as inf
+    inf = importlib.reload(inf)
+    assert not inf.is_loaded()
+    with pytest.raises(Exception, match="Please load hifi"):
+        inf.infer_waveform(np.zeros((80, 10), np.float32))
+    h = synth.small(synth.HIFIGAN_16K, 32)
+    torch.save(synth.gan_state(h, "hifigan", seed=1), tmp_path / "g_test.pt")
+    (tmp_path / "config.json").write_text(json.dumps(h))
+    inf.load_model(tmp_path / "g_test.pt", verbose=False)
+    assert inf.is_loaded() and inf.output_sample_rate == 16000
+    mel = synth.mel_input(9, 1, seed=2)[0]
+    wav, sr = inf.infer_waveform(mel)
+    assert sr == 16000 and wav.dtype == np.float32 and wav.shape == (1800,)
+    wav2, _ = inf.infer_waveform(torch.from_numpy(mel))  # CPU tensor input (run.py:90)
+    assert np.array_equal(wav, wav2)
+    outs, _ = inf.infer_waveform_batch([mel, mel[:, :5], mel])
+    assert outs[0].shape == (1800,) and outs[1].shape == (1000,)
+    assert np.allclose(outs[0], wav, atol=1e-6) and np.array_equal(outs[0], outs[2])
