@@ -182,19 +182,31 @@ def main():
         # ---- CPU baseline: the oracle (reference's ATen CPU arithmetic) on a bounded sample
         if not args.no_cpu_baseline:
             from oracle import wavernn as ow
-            ncores = os.cpu_count() or 1
-            torch.set_num_threads(ncores)
             w = dict(state)
-            cf = 100  # conditioning for a 100-frame prefix is enough for the bounded sample
             with torch.no_grad():
                 mels, aux = ow.conditioning(w, ow.HP, torch.from_numpy(synth.wavernn_mel(F, seed=1)[None, :, :] / 4.0),
                                             True, target, overlap)
                 nf = mels.shape[0]
+                # The reference would run with torch's default thread count (= all host cores); on a
+                # many-core host that oversubscribes these tiny GEMVs, so probe a few settings and
+                # time the bounded sample with the fastest one (reported in `cores`).
+                ncores = os.cpu_count() or 1
+                best_t, best_rate = 1, 0.0
+                for nt in sorted({1, 4, 8, 16, min(32, ncores)}):
+                    if nt > ncores:
+                        continue
+                    torch.set_num_threads(nt)
+                    ow.sample_loop(w, ow.HP, mels[:, :2], aux[:, :2])
+                    tp = time.perf_counter()
+                    ow.sample_loop(w, ow.HP, mels[:, :8], aux[:, :8])
+                    rate = 8 / (time.perf_counter() - tp)
+                    if rate > best_rate:
+                        best_t, best_rate = nt, rate
+                torch.set_num_threads(best_t)
                 t0c = time.perf_counter()
                 steps_done = 0
-                chunk = 50
-                while time.perf_counter() - t0c < args.cpu_seconds and steps_done < mels.shape[1]:
-                    # fresh state per chunk is irrelevant for timing; same arithmetic per step
+                chunk = 10
+                while time.perf_counter() - t0c < args.cpu_seconds and steps_done + chunk <= mels.shape[1]:
                     ow.sample_loop(w, ow.HP, mels[:, steps_done:steps_done + chunk], aux[:, steps_done:steps_done + chunk])
                     steps_done += chunk
                 tc = time.perf_counter() - t0c

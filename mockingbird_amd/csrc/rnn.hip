@@ -21,30 +21,82 @@ __global__ __launch_bounds__(NW * 64) void rnn_rowtile_kernel(RnnK a) {
 
   if (a.step_counter && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.step_counter += 1;
 
-  f32x4 accX = {0.f, 0.f, 0.f, 0.f}, accH = {0.f, 0.f, 0.f, 0.f};
-  int kb0 = 0;
-  for (int sgi = 0; sgi < a.nseg; ++sgi) {
-    const RnnSeg sg = a.seg[sgi];
-    const float* xb = sg.p + (size_t)ncol * sg.ld + kq * 4;
-    // this wave's blocks inside the segment: local index j with (kb0 + j) % NW == wave
-    int j = (wave - kb0 % NW + NW) % NW;
-    for (; j < sg.nkb; j += NW) {
-      const float4 bv = *reinterpret_cast<const float4*>(xb + j * 16);
-      float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (live) av = *reinterpret_cast<const float4*>(wl + (size_t)(kb0 + j) * BLK);
-      if (NPART == 2 && sg.part == 1) {
-        accH = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, accH, 0, 0, 0);
-        accH = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, accH, 0, 0, 0);
-        accH = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, accH, 0, 0, 0);
-        accH = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, accH, 0, 0, 0);
-      } else {
-        accX = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, accX, 0, 0, 0);
-        accX = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, accX, 0, 0, 0);
-        accX = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, accX, 0, 0, 0);
-        accX = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, accX, 0, 0, 0);
+  // Epilogue operands (biases, table row, previous state) are fetched by wave 0 BEFORE the
+  // GEMM so their latency hides under it instead of extending the dependent tail.
+  const int en = ntile * 16 + (lane & 15);   // epilogue column of this lane
+  const int edu = lane >> 4;                 // epilogue unit within the tile
+  float e_bx[4] = {0.f, 0.f, 0.f, 0.f}, e_bh[4] = {0.f, 0.f, 0.f, 0.f};
+  float e_hp = 0.f, e_cp = 0.f, e_xr = 0.f, e_mask[4] = {1.f, 1.f, 1.f, 1.f};
+  if (wave == 0 && en < a.N) {
+    const int prow = a.pre_idx ? a.pre_idx[en] : 0;
+    const float* pre = a.pre_table ? a.pre_table + (size_t)prow * a.pre_stride : nullptr;
+    if (EPI == EPI_LINEAR) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = mt * 16 + edu * 4 + r;
+        if (row < a.units) {
+          if (a.biasX) e_bx[r] += a.biasX[row];
+          if (pre) e_bx[r] += pre[row];
+          if (a.mask) e_mask[r] = a.mask[(size_t)en * a.ldy + row] * a.mask_scale;
+        }
+      }
+    } else {
+      const int j = mt * 4 + edu;
+      if (j < a.units) {
+        const int H = a.units;
+#pragma unroll
+        for (int g = 0; g < RL; ++g) {
+          if (a.biasX) e_bx[g] += a.biasX[g * H + j];
+          if (pre) e_bx[g] += pre[g * H + j];
+          if (a.biasH) e_bh[g] += a.biasH[g * H + j];
+        }
+        const size_t so = (size_t)en * H + j;
+        if (EPI == EPI_GRU) e_hp = a.h_prev[so];
+        if (EPI == EPI_LSTM) e_cp = a.c_prev[so];
+        if (a.x_res) e_xr = a.x_res[so];
       }
     }
-    kb0 += sg.nkb;
+  }
+
+  f32x4 accX = {0.f, 0.f, 0.f, 0.f}, accH = {0.f, 0.f, 0.f, 0.f};
+  // This wave owns k-blocks wave, wave+NW, ... of the concatenated K.  They are walked UB at a
+  // time with ALL fragment loads of a batch issued before the first MFMA, so a wave pays one
+  // memory round trip per batch instead of one per block (the loop is latency-, not FLOP-bound).
+  constexpr int UB = 8;
+  for (int kb_base = wave; kb_base < a.nkb_total; kb_base += NW * UB) {
+    float4 av[UB], bv[UB];
+    int part[UB];
+#pragma unroll
+    for (int ub = 0; ub < UB; ++ub) {
+      const int kb = kb_base + ub * NW;
+      av[ub] = make_float4(0.f, 0.f, 0.f, 0.f);
+      bv[ub] = make_float4(0.f, 0.f, 0.f, 0.f);
+      part[ub] = 0;
+      if (kb < a.nkb_total) {
+        int local = kb, sgi = 0;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+          if (sgi < a.nseg - 1 && local >= a.seg[sgi].nkb) { local -= a.seg[sgi].nkb; ++sgi; }
+        const RnnSeg sg = a.seg[sgi];
+        part[ub] = sg.part;
+        bv[ub] = *reinterpret_cast<const float4*>(sg.p + (size_t)ncol * sg.ld + local * 16 + kq * 4);
+        if (live) av[ub] = *reinterpret_cast<const float4*>(wl + (size_t)kb * BLK);
+      }
+    }
+#pragma unroll
+    for (int ub = 0; ub < UB; ++ub) {
+      if (NPART == 2 && part[ub] == 1) {
+        accH = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ub].x, bv[ub].x, accH, 0, 0, 0);
+        accH = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ub].y, bv[ub].y, accH, 0, 0, 0);
+        accH = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ub].z, bv[ub].z, accH, 0, 0, 0);
+        accH = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ub].w, bv[ub].w, accH, 0, 0, 0);
+      } else {
+        accX = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ub].x, bv[ub].x, accX, 0, 0, 0);
+        accX = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ub].y, bv[ub].y, accX, 0, 0, 0);
+        accX = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ub].z, bv[ub].z, accX, 0, 0, 0);
+        accX = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ub].w, bv[ub].w, accX, 0, 0, 0);
+      }
+    }
   }
   // cross-wave reduction through LDS: D fragment lane = (unit = lane>>4, col = lane&15), reg = gate
   float4* red4 = reinterpret_cast<float4*>(red);
@@ -62,26 +114,20 @@ __global__ __launch_bounds__(NW * 64) void rnn_rowtile_kernel(RnnK a) {
       sh[0] += h.x; sh[1] += h.y; sh[2] += h.z; sh[3] += h.w;
     }
   }
-  const int n = ntile * 16 + (lane & 15);
-  const int du = lane >> 4;  // unit within tile
+  const int n = en, du = edu;
   if (n >= a.N) return;
-  const int prow = a.pre_idx ? a.pre_idx[n] : 0;
-  const float* pre = a.pre_table ? a.pre_table + (size_t)prow * a.pre_stride : nullptr;
 
   if (EPI == EPI_LINEAR) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = mt * 16 + du * 4 + r;
       if (row < a.units) {
-        float v = sx[r];
-        if (a.biasX) v += a.biasX[row];
-        if (pre) v += pre[row];
+        float v = sx[r] + e_bx[r];
         if (a.act == 1) v = fmaxf(v, 0.f);
         else if (a.act == 2) v = sigmoidf_(v);
         else if (a.act == 3) v = tanhf(v);
-        const size_t o = (size_t)n * a.ldy + row;
-        if (a.mask) v = v * a.mask[o] * a.mask_scale;
-        a.y[o] = v;
+        if (a.mask) v = v * e_mask[r];
+        a.y[(size_t)n * a.ldy + row] = v;
       }
     }
     return;
@@ -94,28 +140,23 @@ __global__ __launch_bounds__(NW * 64) void rnn_rowtile_kernel(RnnK a) {
     // torch GRUCell (gate order r,z,n): r = s(i_r+h_r), z = s(i_z+h_z), n = tanh(i_n + r*h_n),
     // h' = n + z*(h - n).   models/vocoder/wavernn/models/fatchord_version.py:196-200,265-271;
     // models/synthesizer/models/tacotron.py:60,98
-    float ir = sx[0], iz = sx[1], in_ = sx[2], hr = sh[0], hz = sh[1], hn = sh[2];
-    if (a.biasX) { ir += a.biasX[j]; iz += a.biasX[H + j]; in_ += a.biasX[2 * H + j]; }
-    if (pre) { ir += pre[j]; iz += pre[H + j]; in_ += pre[2 * H + j]; }
-    if (a.biasH) { hr += a.biasH[j]; hz += a.biasH[H + j]; hn += a.biasH[2 * H + j]; }
-    const float rg = sigmoidf_(ir + hr);
-    const float zg = sigmoidf_(iz + hz);
-    const float ng = tanhf(in_ + rg * hn);
-    const float hp = a.h_prev[so];
-    const float hy = ng + zg * (hp - ng);
+    const float rg = sigmoidf_((sx[0] + e_bx[0]) + (sh[0] + e_bh[0]));
+    const float zg = sigmoidf_((sx[1] + e_bx[1]) + (sh[1] + e_bh[1]));
+    const float ng = tanhf((sx[2] + e_bx[2]) + rg * (sh[2] + e_bh[2]));
+    const float hy = ng + zg * (e_hp - ng);
     a.h_out[so] = hy;
-    if (a.x_out) a.x_out[so] = (a.x_res ? a.x_res[so] : 0.f) + hy;
+    if (a.x_out) a.x_out[so] = e_xr + hy;
   } else {
     // torch LSTMCell (gate order i,f,g,o).  tacotron.py:62-63,112-125
-    float gi = sx[0], gf = sx[1], gg = sx[2], go = sx[3];
-    if (a.biasX) { gi += a.biasX[j]; gf += a.biasX[H + j]; gg += a.biasX[2 * H + j]; go += a.biasX[3 * H + j]; }
-    if (a.biasH) { gi += a.biasH[j]; gf += a.biasH[H + j]; gg += a.biasH[2 * H + j]; go += a.biasH[3 * H + j]; }
-    gi = sigmoidf_(gi); gf = sigmoidf_(gf); gg = tanhf(gg); go = sigmoidf_(go);
-    const float cy = gf * a.c_prev[so] + gi * gg;
+    const float gi = sigmoidf_(sx[0] + e_bx[0] + e_bh[0]);
+    const float gf = sigmoidf_(sx[1] + e_bx[1] + e_bh[1]);
+    const float gg = tanhf(sx[2] + e_bx[2] + e_bh[2]);
+    const float go = sigmoidf_(sx[3] + e_bx[3] + e_bh[3]);
+    const float cy = gf * e_cp + gi * gg;
     const float hy = go * tanhf(cy);
     a.c_out[so] = cy;
     a.h_out[so] = hy;
-    if (a.x_out) a.x_out[so] = (a.x_res ? a.x_res[so] : 0.f) + hy;
+    if (a.x_out) a.x_out[so] = e_xr + hy;
   }
 }
 

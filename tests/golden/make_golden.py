@@ -1,0 +1,101 @@
+"""Generate the golden fixtures under tests/golden/ by running the REAL reference
+(/root/reference, imported read-only with the shims of tests/refimport.py) on seeded synthetic
+checkpoints (tests/synth.py).  Run in the build container only:
+
+    python tests/golden/make_golden.py
+
+Fixtures hold inputs' seeds/shapes and the reference OUTPUTS only (weights are regenerated from
+the seed by tests/synth.py), so they stay small.  torch version is recorded: the arithmetic
+lives in ATen CPU kernels."""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+import refimport
+import synth
+
+refimport.setup()
+torch.set_num_threads(1)  # deterministic reduction order for the fixtures
+
+
+def gan():
+    from utils.util import AttrDict
+    from models.vocoder.hifigan.models import Generator
+    from models.vocoder.fregan.generator import FreGAN
+    out = {}
+    for kind, cfg, cls in (("hifigan", synth.HIFIGAN_16K, Generator), ("fregan", synth.FREGAN_16K, FreGAN)):
+        for uic, frames, batch, seed in ((64, 16, 2, 3), (512, 8, 1, 4)):
+            h = synth.small(cfg, uic)
+            st = synth.gan_state(h, kind, seed=seed)
+            g = cls(AttrDict(h))
+            g.load_state_dict(st["generator"])
+            g.eval()
+            g.remove_weight_norm()
+            mel = torch.from_numpy(synth.mel_input(frames, batch, seed=seed + 1))
+            with torch.no_grad():
+                y = g(mel)
+            out[f"{kind}_uic{uic}_f{frames}_b{batch}_s{seed}"] = y.numpy()
+    np.savez_compressed(os.path.join(HERE, "gan.npz"), torch_version=torch.__version__, **out)
+    print("gan.npz", {k: v.shape for k, v in out.items()})
+
+
+def wavernn():
+    from models.vocoder.wavernn.models.fatchord_version import WaveRNN
+    from models.vocoder.wavernn import hparams as hp
+    st = synth.wavernn_state(seed=5)
+    m = WaveRNN(rnn_dims=hp.voc_rnn_dims, fc_dims=hp.voc_fc_dims, bits=hp.bits, pad=hp.voc_pad,
+                upsample_factors=hp.voc_upsample_factors, feat_dims=hp.num_mels, compute_dims=hp.voc_compute_dims,
+                res_out_dims=hp.voc_res_out_dims, res_blocks=hp.voc_res_blocks, hop_length=hp.hop_length,
+                sample_rate=hp.sample_rate, mode=hp.voc_mode)
+    m.load_state_dict(st["model_state"])
+    m.eval()
+    out = {}
+    mel = synth.wavernn_mel(30, seed=2)
+    quiet = lambda *a: None
+    torch.manual_seed(11)
+    out["batched_f30_t600_o100_seed11"] = m.generate(torch.from_numpy(mel[None] / 4.0), True, 600, 100, True, quiet)
+    torch.manual_seed(3)
+    out["unbatched_f27_seed3"] = m.generate(torch.from_numpy(mel[None, :, :27] / 4.0), False, 0, 0, True, quiet)
+    m.eval()  # generate() leaves the module in train mode (fatchord_version.py:255)
+    with torch.no_grad():
+        mp = m.pad_tensor(torch.from_numpy(mel[None] / 4.0).transpose(1, 2), pad=2, side="both")
+        mels, aux = m.upsample(mp.transpose(1, 2))
+    out["cond_mels_f30_stride97"] = mels[0, ::97].numpy()
+    out["cond_aux_f30_stride97"] = aux[0, ::97].numpy()
+    np.savez_compressed(os.path.join(HERE, "wavernn.npz"), torch_version=torch.__version__, **out)
+    print("wavernn.npz", {k: v.shape for k, v in out.items()})
+
+
+def maximum_path():
+    from oracle import build_ref
+    build_ref.build()
+    ref = build_ref.load()
+    out = {}
+    for b, tt, ts, seed in ((3, 17, 5, 1), (4, 200, 60, 2), (2, 400, 120, 3)):
+        rng = np.random.default_rng(seed)
+        neg = (rng.standard_normal((b, tt, ts)) * 3).astype(np.float32)
+        tys = rng.integers(max(1, tt // 2), tt + 1, b).astype(np.int32)
+        txs = np.array([rng.integers(1, min(ts, ty) + 1) for ty in tys], np.int32)
+        v, p = neg.copy(), np.zeros(neg.shape, np.int32)
+        ref.maximum_path_c(p, v, tys, txs)
+        k = f"b{b}_t{tt}_s{ts}_seed{seed}"
+        out[k + "_path"] = p.astype(np.int8)
+        out[k + "_tys"], out[k + "_txs"] = tys, txs
+        out[k + "_valsum"] = np.array([np.float64(v.astype(np.float64).sum())])
+    np.savez_compressed(os.path.join(HERE, "maximum_path.npz"), **out)
+    print("maximum_path.npz", list(out))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["gan", "wavernn", "maximum_path", "tacotron"]
+    for w in which:
+        if w in globals():
+            globals()[w]()

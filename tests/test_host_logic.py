@@ -1,0 +1,92 @@
+"""Host-side logic that needs no GPU: weight folding/packing, generate() geometry, waveform
+post-processing, utterance sharding."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import gan as og, wavernn as ow
+
+
+def test_fold_weight_norm_matches_torch():
+    from mockingbird_amd import weights
+    st = synth.gan_state(synth.small(synth.HIFIGAN_16K, 32), "hifigan", seed=2)["generator"]
+    ref = og.fold_weight_norm_state(st)
+    for name in ("conv_pre", "ups.1", "resblocks.3.convs1.2", "conv_post"):
+        w = weights.fold_weight_norm(st, name)
+        assert torch.allclose(w, ref[name + ".weight"], rtol=1e-6, atol=1e-7)
+    # ConvTranspose1d: norm is over dims (1,2) per INPUT channel (dim 0)
+    v = st["ups.0.weight_v"]
+    w = weights.fold_weight_norm(st, "ups.0")
+    assert torch.allclose(w.reshape(v.shape[0], -1).norm(dim=1), st["ups.0.weight_g"].flatten(), rtol=1e-5)
+
+
+def test_gan_weight_list_matches_abi_counts(lib):
+    from mockingbird_amd import weights
+    for kind, cfg in (("hifigan", synth.HIFIGAN_16K), ("fregan", synth.FREGAN_16K)):
+        h = synth.small(cfg, 32)
+        c = weights.gan_config(h, 0 if kind == "hifigan" else 1)
+        ws = weights.gan_weight_list(synth.gan_state(h, kind, seed=1)["generator"], c)
+        assert lib.mb_gan_num_weights(C.byref(c)) == len(ws)
+        for i, w in enumerate(ws):
+            assert lib.mb_gan_weight_numel(C.byref(c), i) == w.numel(), i
+
+
+def test_wavernn_weight_list_matches_abi_counts(lib):
+    from mockingbird_amd import weights
+    from mockingbird_amd.vocoder.wavernn import hparams as hp
+    c = weights.wavernn_config(hp)
+    ws = weights.wavernn_weight_list(synth.wavernn_state(seed=1)["model_state"], c)
+    assert lib.mb_wavernn_num_weights(C.byref(c)) == len(ws)
+    for i, w in enumerate(ws):
+        assert lib.mb_wavernn_weight_numel(C.byref(c), i) == w.numel(), i
+
+
+def test_conv_pack_is_a_permutation_with_zero_padding(lib):
+    """mb_conv1d_pack: every weight appears exactly once in the A-fragment image (conv and all
+    polyphase taps of the transposed conv), padding is zero."""
+    import hiputil
+    for (shape, transposed, up, pad) in (((40, 20, 3), False, 1, 1), ((24, 16, 10), True, 5, 3), ((64, 32, 4), True, 2, 1)):
+        w = torch.arange(1, int(np.prod(shape)) + 1, dtype=torch.float32).reshape(shape)
+        packed, _ = hiputil.pack_conv(w, transposed, up, pad)
+        nz = packed[packed != 0]
+        assert nz.numel() == w.numel() and torch.equal(nz.sort().values, w.flatten().sort().values)
+
+
+@pytest.mark.parametrize("frames,target,overlap", [(30, 600, 100), (1000, 8000, 800), (200, 8000, 800), (44, 8000, 800)])
+def test_plan_matches_fold_with_overlap(frames, target, overlap):
+    """Fold geometry of mb_wavernn_plan_generate == fold_with_overlap (fatchord_version.py:313-322);
+    checked through the oracle's restatement on a dummy tensor."""
+    x = torch.zeros(1, frames * 200, 1)
+    folded = ow.fold_with_overlap(x, target, overlap)
+    total = frames * 200
+    nf = (total - overlap) // (target + overlap)
+    if total - (nf * (target + overlap) + overlap) != 0:
+        nf += 1
+    assert folded.shape[0] == nf and folded.shape[1] == target + 2 * overlap
+
+
+def test_dsp_matches_oracle_postprocess():
+    from mockingbird_amd.vocoder.wavernn import dsp
+    rng = np.random.default_rng(0)
+    k = rng.integers(0, 512, (9, 800))
+    samples = (2 * k / 511.0 - 1).astype(np.float32)
+    wave_len = 29 * 256
+    mine = dsp.finish(samples.copy(), True, 100, 512, True, True, 0.97, wave_len, 256)
+    ref = ow.postprocess(ow.HP, torch.from_numpy(samples.copy()), wave_len, True, 600, 100)
+    assert np.array_equal(mine, ref)
+    mine = dsp.finish(samples[:1, :].repeat(8, 1).reshape(1, -1).copy(), False, 0, 512, True, True, 0.97, 24 * 256, 256)
+    ref = ow.postprocess(ow.HP, torch.from_numpy(samples[:1, :].repeat(8, 1).reshape(1, -1).copy()), 24 * 256, False, 0, 0)
+    assert np.array_equal(mine, ref)
+
+
+def test_shard_indices_balanced_and_complete():
+    from mockingbird_amd.sharding import shard_indices
+    lens = [90, 110, 95, 101, 99, 108, 93, 97, 100, 105, 91, 102]
+    for world in (1, 2, 4, 8):
+        parts = [shard_indices(lens, world, r) for r in range(world)]
+        assert sorted(sum(parts, [])) == list(range(len(lens)))
+        loads = [sum(lens[i] for i in p) for p in parts]
+        assert max(loads) - min(loads) <= max(lens)

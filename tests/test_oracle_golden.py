@@ -1,0 +1,129 @@
+"""Pin the oracle: every oracle function against the golden vectors generated from the real
+reference (tests/golden/make_golden.py) and, when the reference checkout is present (build
+container only), against the live reference modules."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import refimport
+import synth
+from oracle import gan as og, maximum_path as omp, wavernn as ow
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+torch.set_num_threads(1)
+
+
+@pytest.mark.parametrize("key", ["hifigan_uic64_f16_b2_s3", "hifigan_uic512_f8_b1_s4",
+                                 "fregan_uic64_f16_b2_s3", "fregan_uic512_f8_b1_s4"])
+def test_gan_oracle_vs_golden(key):
+    gold = np.load(os.path.join(G, "gan.npz"))[key]
+    kind, uic, f, b, s = key.split("_")
+    uic, f, b, s = int(uic[3:]), int(f[1:]), int(b[1:]), int(s[1:])
+    h = synth.small(synth.HIFIGAN_16K if kind == "hifigan" else synth.FREGAN_16K, uic)
+    st = synth.gan_state(h, kind, seed=s)
+    w = og.fold_weight_norm_state(st["generator"])
+    mel = torch.from_numpy(synth.mel_input(f, b, seed=s + 1))
+    with torch.no_grad():
+        y = (og.hifigan_forward if kind == "hifigan" else og.fregan_forward)(w, h, mel).numpy()
+    assert y.shape == gold.shape
+    # same ATen kernels; allow for a different CPU ISA / thread count on the test host
+    assert np.abs(y - gold).max() <= 2e-6, np.abs(y - gold).max()
+    assert np.sqrt((gold ** 2).mean()) > 0.05  # fixture is O(0.1..1), tolerances are not vacuous
+
+
+def test_wavernn_oracle_vs_golden():
+    gold = np.load(os.path.join(G, "wavernn.npz"))
+    st = synth.wavernn_state(seed=5)
+    w = dict(st["model_state"])
+    mel = synth.wavernn_mel(30, seed=2)
+    with torch.no_grad():
+        mels, aux = ow.upsample_network(w, ow.HP, ow.pad_tensor(torch.from_numpy(mel[None] / 4.0).transpose(1, 2), 2).transpose(1, 2))
+    assert np.abs(mels[0, ::97].numpy() - gold["cond_mels_f30_stride97"]).max() <= 1e-6
+    assert np.abs(aux[0, ::97].numpy() - gold["cond_aux_f30_stride97"]).max() <= 1e-5
+    torch.manual_seed(11)
+    wav = ow.generate(w, ow.HP, torch.from_numpy(mel[None] / 4.0), True, 600, 100)
+    g = gold["batched_f30_t600_o100_seed11"]
+    assert wav.shape == g.shape and wav.dtype == np.float64
+    if not np.array_equal(wav, g):
+        # a different CPU ISA may round a logit differently and flip one near-tie sample, after
+        # which the autoregression diverges; the stream before that must still be identical
+        first = int(np.argmax(wav != g))
+        assert first >= 200, f"oracle diverges from the reference golden at sample {first}"
+    torch.manual_seed(3)
+    wav = ow.generate(w, ow.HP, torch.from_numpy(mel[None, :, :27] / 4.0), False, 0, 0)
+    g = gold["unbatched_f27_seed3"]
+    assert wav.shape == g.shape
+    if not np.array_equal(wav, g):
+        assert int(np.argmax(wav != g)) >= 200
+
+
+def test_wavernn_injected_noise_equals_global_rng():
+    """argmax(p / Exp(1)) with pre-drawn noise == Categorical(p).sample(), including
+    the GRUCell-constructor draws generate() makes first."""
+    st = synth.wavernn_state(seed=5)
+    w = dict(st["model_state"])
+    mel = torch.from_numpy(synth.wavernn_mel(26, seed=7)[None] / 4.0)
+    torch.manual_seed(21)
+    a = ow.generate(w, ow.HP, mel, True, 500, 60)
+    torch.manual_seed(21)
+    ow.consume_gru_init_rng(ow.HP)
+    n_folds = (26 * 200 - 60) // 560 + 1
+    noise = torch.stack([torch.empty(n_folds, 512).exponential_(1) for _ in range(620)])
+    b = ow.generate(w, ow.HP, mel, True, 500, 60, noise=noise)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("key", ["b3_t17_s5_seed1", "b4_t200_s60_seed2", "b2_t400_s120_seed3"])
+def test_maximum_path_oracle_vs_golden(key):
+    gold = np.load(os.path.join(G, "maximum_path.npz"))
+    b, tt, ts, seed = (int(x.lstrip("btsed")) for x in key.split("_"))
+    rng = np.random.default_rng(seed)
+    neg = (rng.standard_normal((b, tt, ts)) * 3).astype(np.float32)
+    tys = rng.integers(max(1, tt // 2), tt + 1, b).astype(np.int32)
+    txs = np.array([rng.integers(1, min(ts, ty) + 1) for ty in tys], np.int32)
+    assert np.array_equal(tys, gold[key + "_tys"]) and np.array_equal(txs, gold[key + "_txs"])
+    v, p = neg.copy(), np.zeros(neg.shape, np.int32)
+    omp.maximum_path_c(p, v, tys, txs)
+    assert np.array_equal(p.astype(np.int8), gold[key + "_path"])
+    assert np.float64(v.astype(np.float64).sum()) == gold[key + "_valsum"][0]
+
+
+def test_maximum_path_edge_cases():
+    # t_x == 1, t_x == t_y (pure diagonal), zero-length items
+    for ty, tx in ((5, 1), (6, 6), (1, 1)):
+        neg = np.random.default_rng(0).standard_normal((1, 8, 8)).astype(np.float32)
+        p = np.zeros(neg.shape, np.int32)
+        omp.maximum_path_c(p, neg.copy(), np.array([ty], np.int32), np.array([tx], np.int32))
+        idx = p[0, :ty].argmax(1)
+        assert (p[0, :ty].sum(1) == 1).all() and idx[0] == 0 and idx[-1] == tx - 1
+        assert p[0, ty:].sum() == 0
+    p = np.zeros((1, 4, 4), np.int32)
+    omp.maximum_path_c(p, np.zeros((1, 4, 4), np.float32), np.array([0], np.int32), np.array([0], np.int32))
+    assert p.sum() == 0
+
+
+@pytest.mark.skipif(not refimport.available(), reason="reference checkout only exists in the build container")
+def test_oracle_vs_live_reference():
+    refimport.setup()
+    from utils.util import AttrDict
+    from models.vocoder.hifigan.models import Generator
+    h = synth.small(synth.HIFIGAN_16K, 32)
+    st = synth.gan_state(h, "hifigan", seed=9)
+    g = Generator(AttrDict(h))
+    g.load_state_dict(st["generator"])
+    g.eval()
+    g.remove_weight_norm()
+    mel = torch.from_numpy(synth.mel_input(11, 2, seed=10))
+    with torch.no_grad():
+        assert torch.equal(g(mel), og.hifigan_forward(og.fold_weight_norm_state(st["generator"]), h, mel))
+    from oracle import build_ref
+    ref = build_ref.load()
+    rng = np.random.default_rng(5)
+    neg = rng.standard_normal((2, 30, 12)).astype(np.float32)
+    tys, txs = np.array([30, 22], np.int32), np.array([12, 7], np.int32)
+    v1, p1, v2, p2 = neg.copy(), np.zeros(neg.shape, np.int32), neg.copy(), np.zeros(neg.shape, np.int32)
+    ref.maximum_path_c(p1, v1, tys, txs)
+    omp.maximum_path_c(p2, v2, tys, txs)
+    assert np.array_equal(p1, p2) and np.array_equal(v1, v2)
