@@ -76,13 +76,16 @@ typedef struct mb_conv1d_args {
   int in_act;             /* 0 none, 1 leaky_relu(in_slope) applied to x on load  */
   float in_slope;
   float in_scale;         /* x is multiplied by this before in_act (0 or 1.0 = none) */
-  int out_act;            /* 0 none, 1 relu, 2 tanh, 3 sigmoid                    */
+  int out_act;            /* 0 none, 1 relu, 2 tanh, 3 sigmoid, 4 highway:
+                             y = g*relu(conv+b) + (1-g)*res with g = d_gate
+                             (common/highway_network.py:12-17)                  */
   float out_scale;        /* result *= out_scale after the residual add (0 or 1.0 = none) */
   int accumulate;         /* y += result instead of y = result                    */
   int in_repeat;          /* >1: x is read through nearest-neighbour upsampling,
                              source index = t / in_repeat (t_in counts upsampled
                              positions); fregan/generator.py:104-110            */
   int transpose_out;      /* store y[b][t][c_out] (time-major)                    */
+  const float* d_gate;    /* out_act 4 only: sigmoid gate, same layout as y       */
 } mb_conv1d_args;
 
 int mb_conv1d(const mb_conv1d_args* a, mb_stream_t stream);

@@ -31,7 +31,7 @@ class ConvArgs(C.Structure):
         ("ksize", C.c_int), ("dilation", C.c_int), ("pad", C.c_int), ("up", C.c_int),
         ("in_act", C.c_int), ("in_slope", C.c_float), ("in_scale", C.c_float),
         ("out_act", C.c_int), ("out_scale", C.c_float), ("accumulate", C.c_int),
-        ("in_repeat", C.c_int), ("transpose_out", C.c_int),
+        ("in_repeat", C.c_int), ("transpose_out", C.c_int), ("d_gate", C.c_void_p),
     ]
 
 

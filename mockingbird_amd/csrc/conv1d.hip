@@ -29,7 +29,7 @@ static constexpr int CK = 16;  // input channels staged per LDS chunk
 
 struct ConvK {
   const float* x; const float* w; const float* bias; const float* res;
-  const float* post_scale; const float* post_shift; float* y;
+  const float* post_scale; const float* post_shift; const float* gate; float* y;
   long long x_bstride, y_bstride, res_bstride;
   int c_in, cin_pad, c_out, t_in, t_out;
   int ntaps, up, step, min_off, span;
@@ -154,7 +154,10 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvK a) {
         else if (a.out_act == 3) v = 1.0f / (1.0f + expf(-v));
         if (a.post_scale) v = v * a.post_scale[co] + a.post_shift[co];
         const long long o = TR ? ((long long)t * a.c_out + co) : ((long long)co * a.t_out + t);
-        if (rb) v += rb[o];
+        if (a.out_act == 4) {
+          const float g = a.gate[(long long)b * a.y_bstride + o];
+          v = g * fmaxf(v, 0.f) + (1.f - g) * rb[o];
+        } else if (rb) v += rb[o];
         v *= a.out_scale;
         if (a.accumulate) v += yb[o];
         yb[o] = v;
@@ -233,7 +236,8 @@ extern "C" int mb_conv1d(const mb_conv1d_args* a, mb_stream_t stream) {
   int rc = conv_geometry(a, &k);
   if (rc) return rc;
   k.x = a->d_x; k.w = a->d_wpacked; k.bias = a->d_bias; k.res = a->d_res;
-  k.post_scale = a->d_post_scale; k.post_shift = a->d_post_shift; k.y = a->d_y;
+  k.post_scale = a->d_post_scale; k.post_shift = a->d_post_shift; k.y = a->d_y; k.gate = a->d_gate;
+  MB_REQUIRE(a->out_act != 4 || (a->d_gate && a->d_res), "conv1d: highway epilogue needs d_gate and d_res");
   k.x_bstride = a->x_bstride; k.y_bstride = a->y_bstride; k.res_bstride = a->res_bstride;
   k.c_in = a->c_in; k.cin_pad = (a->c_in + 7) / 8 * 8; k.c_out = a->c_out;
   k.t_in = a->t_in; k.t_out = a->t_out;

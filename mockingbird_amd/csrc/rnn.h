@@ -40,13 +40,19 @@ struct RnnK {
   const float* biasX;  // GRU/LSTM: [gates*units] torch gate-major order; LINEAR: [rows] (may be null)
   const float* biasH;  // GRU/LSTM hidden bias (may be null)
   const float* pre_table;  // optional additive X-part rows: pre_table[pre_idx[n]*pre_stride + gate*units + unit]
-  const int* pre_idx;      // null -> row 0
+  const int* pre_idx;      // null -> row pre_base_row + n*pre_n_stride
   int pre_stride;
+  int pre_base_row, pre_n_stride;
   const float* h_prev; const float* c_prev; const float* x_res;  // [N][units]
   float* h_out; float* c_out; float* x_out;                      // [N][units]
   float* y; int ldy; int act;  // LINEAR: y[n*ldy + row]; act 0 none, 1 relu, 2 sigmoid, 3 tanh
   const float* mask; float mask_scale;  // LINEAR: optional y *= mask[n*ldy+row]*mask_scale (dropout)
   int* step_counter;  // block (0,0) increments it (loop step bookkeeping), may be null
+  const int* skip_flag;  // if non-null and *skip_flag != 0 the launch is a no-op (decoder stop rule)
+  // optional strided copy of h_out into a sequence tensor: seq_out[n*seq_n_stride + j*seq_j_stride + seq_off]
+  float* seq_out; long long seq_n_stride, seq_j_stride, seq_off;
+  // LINEAR dropout when mask == null and drop_seed_on: keep = philox(seed, drop_iter, drop_layer; n,row) < 0.5
+  int drop_on; unsigned long long drop_seed; int drop_iter, drop_layer;
 };
 
 // rows: live rows x K (K multiple of 16), tile-ordered: rows of tile mt are

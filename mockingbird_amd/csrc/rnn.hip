@@ -19,6 +19,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_rowtile_kernel(RnnK a) {
   int ncol = ntile * 16 + i;
   if (ncol >= a.N) ncol = a.N - 1;  // duplicate a live column; its result is never stored
 
+  if (a.skip_flag && *a.skip_flag) return;
   if (a.step_counter && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.step_counter += 1;
 
   // Epilogue operands (biases, table row, previous state) are fetched by wave 0 BEFORE the
@@ -28,7 +29,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_rowtile_kernel(RnnK a) {
   float e_bx[4] = {0.f, 0.f, 0.f, 0.f}, e_bh[4] = {0.f, 0.f, 0.f, 0.f};
   float e_hp = 0.f, e_cp = 0.f, e_xr = 0.f, e_mask[4] = {1.f, 1.f, 1.f, 1.f};
   if (wave == 0 && en < a.N) {
-    const int prow = a.pre_idx ? a.pre_idx[en] : 0;
+    const int prow = a.pre_idx ? a.pre_idx[en] : a.pre_base_row + en * a.pre_n_stride;
     const float* pre = a.pre_table ? a.pre_table + (size_t)prow * a.pre_stride : nullptr;
     if (EPI == EPI_LINEAR) {
 #pragma unroll
@@ -38,6 +39,12 @@ __global__ __launch_bounds__(NW * 64) void rnn_rowtile_kernel(RnnK a) {
           if (a.biasX) e_bx[r] += a.biasX[row];
           if (pre) e_bx[r] += pre[row];
           if (a.mask) e_mask[r] = a.mask[(size_t)en * a.ldy + row] * a.mask_scale;
+          else if (a.drop_on) {
+            uint32_t rr[4];
+            philox4x32((uint32_t)a.drop_iter, (uint32_t)a.drop_layer, (uint32_t)en, (uint32_t)(row >> 2),
+                       (uint32_t)a.drop_seed, (uint32_t)(a.drop_seed >> 32), rr);
+            e_mask[r] = (rr[row & 3] & 0x80000000u) ? a.mask_scale : 0.f;
+          }
         }
       }
     } else {
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_rowtile_kernel(RnnK a) {
         if (a.act == 1) v = fmaxf(v, 0.f);
         else if (a.act == 2) v = sigmoidf_(v);
         else if (a.act == 3) v = tanhf(v);
-        if (a.mask) v = v * e_mask[r];
+        if (a.mask || a.drop_on) v = v * e_mask[r];
         a.y[(size_t)n * a.ldy + row] = v;
       }
     }
@@ -146,6 +153,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_rowtile_kernel(RnnK a) {
     const float hy = ng + zg * (e_hp - ng);
     a.h_out[so] = hy;
     if (a.x_out) a.x_out[so] = e_xr + hy;
+    if (a.seq_out) a.seq_out[(long long)n * a.seq_n_stride + (long long)j * a.seq_j_stride + a.seq_off] = hy;
   } else {
     // torch LSTMCell (gate order i,f,g,o).  tacotron.py:62-63,112-125
     const float gi = sigmoidf_(sx[0] + e_bx[0] + e_bh[0]);

@@ -1,0 +1,151 @@
+"""Drop-in for models/synthesizer/inference.py:15-185: same ``Synthesizer`` class and
+``synthesize_spectrograms`` signature/returns; the Tacotron decoder loop and CBHG postnet
+(tacotron.py:264-283) run as HIP kernels through libmbhip.so (mb_taco_decode)."""
+import ctypes as C
+from pathlib import Path
+from typing import List, Union
+
+import numpy as np
+import torch
+
+from .. import _lib, weights
+from . import frontend
+from .hparams import hparams
+from .text import symbols, text_to_sequence, to_pinyin
+
+
+class TacotronDevice:
+    """Weights resident in HBM: decoder + postnet inside an ``mb_taco`` handle, the
+    once-per-chunk encoder/GST weights as device tensors for the torch-op front-end."""
+
+    def __init__(self, state_dict, device, r=None):
+        self.device = device
+        self.cfg = weights.taco_config(state_dict, r=r)
+        self.r = self.cfg.r
+        L = _lib.lib()
+        ws = weights.taco_weight_list(state_dict, self.cfg)
+        n = L.mb_taco_num_weights(C.byref(self.cfg))
+        if n != len(ws):
+            raise _lib.MbHipError(f"weight list has {len(ws)} tensors, ABI expects {n}")
+        for i, w in enumerate(ws):
+            want = L.mb_taco_weight_numel(C.byref(self.cfg), i)
+            if w.numel() != want:
+                raise _lib.MbHipError(f"weight {i}: {tuple(w.shape)} has {w.numel()} elements, expected {want}")
+        h = C.c_void_p()
+        _lib.check(L.mb_taco_create(C.byref(self.cfg), _lib.host_ptr_array(ws), len(ws), C.byref(h)), "mb_taco_create")
+        self._h = h
+        self.front = {k: v.detach().to(device, torch.float32) for k, v in state_dict.items()
+                      if k.startswith(("encoder.", "gst.", "encoder_proj.")) and v.is_floating_point()}
+        self._ws = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _lib.lib().mb_taco_destroy(h)
+            self._h = None
+
+    def decode(self, memory, memory_proj, chars, steps, min_stop_token, dropout=None, seed=0):
+        """HIP decoder loop + postnet.  Returns (mel_outputs, linear, attn) trimmed to the frames produced."""
+        B, T, _ = memory.shape
+        r = self.r
+        max_steps = (steps + r - 1) // r * r  # range(0, steps, r) emits r frames per iteration (tacotron.py:264)
+        dev = memory.device
+        L = _lib.lib()
+        need = L.mb_taco_workspace_bytes(self._h, B, T, max_steps)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        mel = torch.empty(B, self.cfg.n_mels, max_steps, device=dev)
+        lin = torch.empty(B, self.cfg.n_mels, max_steps, device=dev)
+        attn = torch.empty(B, max_steps // r, T, device=dev)
+        chars32 = chars.to(torch.int32).contiguous()
+        if dropout is not None:
+            dropout = dropout.to(dev, torch.float32).contiguous()
+            if tuple(dropout.shape[1:]) != (2, B, 2 * self.cfg.decoder_dims) or dropout.shape[0] < max_steps // r:
+                raise _lib.MbHipError(f"dropout masks must be [>= {max_steps // r}, 2, {B}, {2 * self.cfg.decoder_dims}]")
+        nf = C.c_int(0)
+        _lib.check(L.mb_taco_decode(self._h, _lib.ptr(memory), _lib.ptr(memory_proj), _lib.ptr(chars32), B, T, max_steps,
+                                    float(min_stop_token), _lib.ptr(dropout), int(seed), _lib.ptr(mel), _lib.ptr(lin),
+                                    _lib.ptr(attn), C.byref(nf), _lib.ptr(self._ws), self._ws.numel(), _lib.stream_ptr()),
+                   "mb_taco_decode")
+        F = nf.value
+        return mel[:, :, :F], lin[:, :, :F], attn[:, :F // r]
+
+    def generate(self, chars, speaker_embedding, steps=2000, style_idx=0, min_stop_token=5, enc_masks=None,
+                 dropout=None, seed=0):
+        """Tacotron.generate (tacotron.py:295-298) -> (mel_outputs, linear, attn_scores)."""
+        memory, memory_proj = frontend.encoder_memory(self.front, hparams, chars, speaker_embedding, style_idx, enc_masks)
+        return self.decode(memory, memory_proj, chars, steps, min_stop_token, dropout, seed)
+
+
+class Synthesizer:
+    sample_rate = hparams.sample_rate
+    hparams = hparams
+
+    def __init__(self, model_fpath: Path, verbose=True):
+        self.model_fpath = Path(model_fpath)
+        self.verbose = verbose
+        if not torch.cuda.is_available():
+            raise _lib.MbHipError("Synthesizer: no MI355X visible; this build has no CPU path")
+        self.device = torch.device("cuda")
+        if self.verbose:
+            print("Synthesizer using device:", self.device)
+        self._model = None
+
+    def is_loaded(self):
+        return self._model is not None
+
+    def load(self):
+        found = list(self.model_fpath.parent.rglob("*.json"))  # inference.py:47-50
+        if len(found) > 0 and found[0].exists():
+            hparams.loadJson(found[0])
+        checkpoint = torch.load(str(self.model_fpath), map_location="cpu")
+        state = checkpoint["model_state"] if "model_state" in checkpoint else checkpoint["model"]  # base.py:51-54
+        self._model = TacotronDevice(state, self.device)
+        self._step = int(state["step"].item()) if "step" in state else 0
+        if self.verbose:
+            print("Loaded synthesizer \"%s\" trained to step %d" % (self.model_fpath.name, self._step))
+
+    def synthesize_spectrograms(self, texts: List[str], embeddings: Union[np.ndarray, List[np.ndarray]],
+                                return_alignments=False, style_idx=0, min_stop_token=5, steps=2000):
+        if not self.is_loaded():
+            self.load()
+        print("Read " + str(texts))
+        texts = to_pinyin(texts)
+        print("Synthesizing " + str(texts))
+        inputs = [text_to_sequence(text, hparams.tts_cleaner_names) for text in texts]
+        specs, alignments = self.synthesize_from_tokens(inputs, embeddings, style_idx, min_stop_token, steps)
+        if self.verbose:
+            print("\n\nDone.\n")
+        return (specs, alignments) if return_alignments else specs
+
+    def synthesize_from_tokens(self, inputs, embeddings, style_idx=0, min_stop_token=5, steps=2000, enc_masks=None,
+                               dropout=None, seed=0):
+        """inference.py:104-139 from token id sequences (benchmarks feed these directly)."""
+        if not self.is_loaded():
+            self.load()
+        if not isinstance(embeddings, list):
+            embeddings = [embeddings]
+        bs = hparams.synthesis_batch_size
+        specs, alignments = [], None
+        for i in range(0, len(inputs), bs):
+            batch = inputs[i:i + bs]
+            if self.verbose:
+                print(f"\n| Generating {i // bs + 1}/{(len(inputs) + bs - 1) // bs}")
+            max_text_len = max(len(t) for t in batch)
+            chars = np.stack([pad1d(t, max_text_len) for t in batch])
+            speaker_embeds = np.stack(embeddings[i:i + bs])
+            chars = torch.tensor(chars).long().to(self.device)
+            speaker_embeddings = torch.tensor(speaker_embeds).float().to(self.device)
+            _, mels, alignments = self._model.generate(chars, speaker_embeddings, style_idx=style_idx,
+                                                       min_stop_token=min_stop_token, steps=steps,
+                                                       enc_masks=enc_masks, dropout=dropout, seed=seed)
+            mels = mels.detach().cpu().numpy()
+            for m in mels:
+                while np.max(m[:, -1]) < hparams.tts_stop_threshold:  # trim silence (inference.py:136-137)
+                    m = m[:, :-1]
+                specs.append(m)
+        return specs, alignments
+
+
+def pad1d(x, max_len, pad_value=0):
+    return np.pad(x, (0, max_len - len(x)), mode="constant", constant_values=pad_value)

@@ -124,3 +124,50 @@ def wavernn_weight_list(state: Dict[str, torch.Tensor], cfg: "_lib.WaveRNNConfig
         names += [f"{n}.weight_ih_l0", f"{n}.weight_hh_l0", f"{n}.bias_ih_l0", f"{n}.bias_hh_l0"]
     names += ["fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias"]
     return [_f32(state[n]) for n in names]
+
+
+# -------------------------------------------------------------------- Tacotron
+def taco_config(state: Dict[str, torch.Tensor], r: int = None, max_r: int = 20) -> "_lib.TacoConfig":
+    """Shapes are read from the checkpoint (config must come from the loaded
+    objects, not be hard-coded)."""
+    c = _lib.TacoConfig()
+    fc1 = state["decoder.prenet.fc1.weight"]
+    c.n_mels = fc1.shape[1]
+    c.decoder_dims = fc1.shape[0] // 2
+    c.lstm_dims = state["decoder.res_rnn1.weight_hh"].shape[1]
+    c.project_dims = state["decoder.rnn_input.weight"].shape[1] - c.decoder_dims
+    c.max_r = state["decoder.mel_proj.weight"].shape[0] // c.n_mels if max_r is None else max_r
+    c.r = int(state["decoder.r"].item()) if r is None else int(r)
+    c.postnet_dims = state["postnet.conv_project1.conv.weight"].shape[0]
+    c.postnet_K = sum(1 for k in state if k.startswith("postnet.conv1d_bank.") and k.endswith(".conv.weight"))
+    c.num_highways = sum(1 for k in state if k.startswith("postnet.highways.") and k.endswith(".W1.weight"))
+    cw = state["decoder.attn_net.conv.weight"]
+    c.lsa_filters, c.lsa_kernel = cw.shape[0], cw.shape[2]
+    return c
+
+
+def taco_weight_list(state: Dict[str, torch.Tensor], cfg: "_lib.TacoConfig") -> List[torch.Tensor]:
+    """ABI order of mb_taco_create (decoder + postnet + post_proj)."""
+    def bn(p):
+        return [p + ".weight", p + ".bias", p + ".running_mean", p + ".running_var"]
+    d = "decoder."
+    names = [d + "prenet.fc1.weight", d + "prenet.fc1.bias", d + "prenet.fc2.weight", d + "prenet.fc2.bias",
+             d + "attn_net.conv.weight", d + "attn_net.conv.bias", d + "attn_net.L.weight", d + "attn_net.W.weight",
+             d + "attn_net.W.bias", d + "attn_net.v.weight",
+             d + "attn_rnn.weight_ih", d + "attn_rnn.weight_hh", d + "attn_rnn.bias_ih", d + "attn_rnn.bias_hh",
+             d + "rnn_input.weight", d + "rnn_input.bias"]
+    for n in ("res_rnn1", "res_rnn2"):
+        names += [f"{d}{n}.weight_ih", f"{d}{n}.weight_hh", f"{d}{n}.bias_ih", f"{d}{n}.bias_hh"]
+    names += [d + "mel_proj.weight", d + "stop_proj.weight", d + "stop_proj.bias"]
+    p = "postnet."
+    for k in range(cfg.postnet_K):
+        names += [f"{p}conv1d_bank.{k}.conv.weight"] + bn(f"{p}conv1d_bank.{k}.bnorm")
+    names += [p + "conv_project1.conv.weight"] + bn(p + "conv_project1.bnorm")
+    names += [p + "conv_project2.conv.weight"] + bn(p + "conv_project2.bnorm")
+    names += [p + "pre_highway.weight"]
+    for i in range(cfg.num_highways):
+        names += [f"{p}highways.{i}.W1.weight", f"{p}highways.{i}.W1.bias", f"{p}highways.{i}.W2.weight", f"{p}highways.{i}.W2.bias"]
+    for sfx in ("", "_reverse"):
+        names += [f"{p}rnn.weight_ih_l0{sfx}", f"{p}rnn.weight_hh_l0{sfx}", f"{p}rnn.bias_ih_l0{sfx}", f"{p}rnn.bias_hh_l0{sfx}"]
+    names += ["post_proj.weight"]
+    return [_f32(state[n]) for n in names]

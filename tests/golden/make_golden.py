@@ -94,6 +94,32 @@ def maximum_path():
     print("maximum_path.npz", list(out))
 
 
+def tacotron():
+    from models.synthesizer.models.tacotron import Tacotron
+    from models.synthesizer.hparams import hparams
+    from models.synthesizer.utils.symbols import symbols
+    m = Tacotron(embed_dims=hparams.tts_embed_dims, num_chars=len(symbols), encoder_dims=hparams.tts_encoder_dims,
+                 decoder_dims=hparams.tts_decoder_dims, n_mels=hparams.num_mels, fft_bins=hparams.num_mels,
+                 postnet_dims=hparams.tts_postnet_dims, encoder_K=hparams.tts_encoder_K, lstm_dims=hparams.tts_lstm_dims,
+                 postnet_K=hparams.tts_postnet_K, num_highways=hparams.tts_num_highways, dropout=hparams.tts_dropout,
+                 stop_threshold=hparams.tts_stop_threshold, speaker_embedding_size=hparams.speaker_embedding_size)
+    m.load_state_dict(synth.tacotron_state(seed=3)["model_state"])
+    m.eval()
+    out = {}
+    for name, (B, tmin, tmax, steps, style, mst, seed) in {"b3_style-1": (3, 20, 30, 40, -1, 11, 5),
+                                                           "b2_style0_stop": (2, 14, 18, 60, 0, 4.0, 6)}.items():
+        seqs, emb = synth.tacotron_inputs(B, tmin, tmax, seed=seed)
+        T = max(len(s) for s in seqs)
+        chars = torch.tensor(np.stack([np.pad(s, (0, T - len(s))) for s in seqs])).long()
+        spk = torch.tensor(np.stack(emb))
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            mel, lin, att = m.generate(chars, spk, steps=steps, style_idx=style, min_stop_token=mst)
+        out[name + "_mel"], out[name + "_linear"], out[name + "_attn"] = mel.numpy(), lin.numpy(), att.numpy()
+    np.savez_compressed(os.path.join(HERE, "tacotron.npz"), torch_version=torch.__version__, **out)
+    print("tacotron.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gan", "wavernn", "maximum_path", "tacotron"]
     for w in which:

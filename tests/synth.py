@@ -149,3 +149,95 @@ def exp_noise(seed, steps, folds, classes):
     """Exp(1) draws in the order torch.multinomial consumes them: one (folds, classes) tensor per step."""
     g = torch.Generator().manual_seed(seed)
     return torch.stack([torch.empty(folds, classes).exponential_(1, generator=g) for _ in range(steps)])
+
+
+def tacotron_state(seed=0, r=2, num_chars=75, n_mels=80, P_enc=256, spk=256, gst_E=512, D=128, H=1024, C=512, K=5, nh=4):
+    """{'model_state': state_dict} in the reference Tacotron layout (tacotron.py:140-162 with use_gst)."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+
+    def t(shape, scale):
+        return torch.from_numpy((scale * rng.standard_normal(shape)).astype(np.float32))
+
+    def lin(name, out, inp, gain=1.0, bias=True):
+        sd[name + ".weight"] = t((out, inp), gain / math.sqrt(inp))
+        if bias:
+            sd[name + ".bias"] = t((out,), 0.1)
+
+    def bn(p, n):
+        sd[p + ".weight"] = torch.from_numpy((1.0 + 0.1 * rng.standard_normal(n)).astype(np.float32))
+        sd[p + ".bias"] = t((n,), 0.1)
+        sd[p + ".running_mean"] = t((n,), 0.1)
+        sd[p + ".running_var"] = torch.from_numpy(rng.uniform(0.5, 1.5, n).astype(np.float32))
+        sd[p + ".num_batches_tracked"] = torch.tensor(1, dtype=torch.long)
+
+    def cbhg(p, cin, ch, proj):
+        for k in range(1, K + 1):
+            sd[f"{p}.conv1d_bank.{k - 1}.conv.weight"] = t((ch, cin, k), 1.4 / math.sqrt(cin * k))
+            bn(f"{p}.conv1d_bank.{k - 1}.bnorm", ch)
+        sd[f"{p}.conv_project1.conv.weight"] = t((proj[0], K * ch, 3), 1.4 / math.sqrt(K * ch * 3)); bn(f"{p}.conv_project1.bnorm", proj[0])
+        sd[f"{p}.conv_project2.conv.weight"] = t((proj[1], proj[0], 3), 1.0 / math.sqrt(proj[0] * 3)); bn(f"{p}.conv_project2.bnorm", proj[1])
+        if proj[1] != ch:
+            lin(f"{p}.pre_highway", ch, proj[1], 1.0, bias=False)
+        for i in range(nh):
+            lin(f"{p}.highways.{i}.W1", ch, ch, 1.4)
+            lin(f"{p}.highways.{i}.W2", ch, ch, 1.0)
+        for sfx in ("", "_reverse"):
+            sd[f"{p}.rnn.weight_ih_l0{sfx}"] = t((3 * ch // 2, ch), 1.0 / math.sqrt(ch))
+            sd[f"{p}.rnn.weight_hh_l0{sfx}"] = t((3 * ch // 2, ch // 2), 1.0 / math.sqrt(ch // 2))
+            sd[f"{p}.rnn.bias_ih_l0{sfx}"] = t((3 * ch // 2,), 0.1)
+            sd[f"{p}.rnn.bias_hh_l0{sfx}"] = t((3 * ch // 2,), 0.1)
+
+    P = P_enc + spk + gst_E
+    sd["encoder.embedding.weight"] = t((num_chars, 512), 1.0)
+    lin("encoder.pre_net.fc1", P_enc, 512, 1.4); lin("encoder.pre_net.fc2", P_enc, P_enc, 1.4)
+    cbhg("encoder.cbhg", P_enc, P_enc, [P_enc, P_enc])
+    lin("encoder_proj", D, P, 1.0, bias=False)
+    filt = [1, 32, 32, 64, 64, 128, 128]
+    for i in range(6):
+        sd[f"gst.encoder.convs.{i}.weight"] = t((filt[i + 1], filt[i], 3, 3), 1.4 / math.sqrt(filt[i] * 9))
+        sd[f"gst.encoder.convs.{i}.bias"] = t((filt[i + 1],), 0.1)
+        bn(f"gst.encoder.bns.{i}", filt[i + 1])
+    sd["gst.encoder.gru.weight_ih_l0"] = t((3 * gst_E // 2, 128 * 4), 1.0 / math.sqrt(512))
+    sd["gst.encoder.gru.weight_hh_l0"] = t((3 * gst_E // 2, gst_E // 2), 1.0 / math.sqrt(gst_E // 2))
+    sd["gst.encoder.gru.bias_ih_l0"] = t((3 * gst_E // 2,), 0.1); sd["gst.encoder.gru.bias_hh_l0"] = t((3 * gst_E // 2,), 0.1)
+    sd["gst.stl.embed"] = t((10, gst_E // 8), 0.5)
+    lin("gst.stl.attention.W_query", gst_E, gst_E // 2 + spk, 1.0, bias=False)
+    lin("gst.stl.attention.W_key", gst_E, gst_E // 8, 1.0, bias=False)
+    lin("gst.stl.attention.W_value", gst_E, gst_E // 8, 1.0, bias=False)
+    sd["decoder.r"] = torch.tensor(r, dtype=torch.int)
+    lin("decoder.prenet.fc1", 2 * D, n_mels, 1.4); lin("decoder.prenet.fc2", 2 * D, 2 * D, 1.4)
+    sd["decoder.attn_net.conv.weight"] = t((32, 1, 31), 1.0 / math.sqrt(31)); sd["decoder.attn_net.conv.bias"] = t((32,), 0.1)
+    lin("decoder.attn_net.L", D, 32, 1.0, bias=False); lin("decoder.attn_net.W", D, D, 1.0)
+    lin("decoder.attn_net.v", 1, D, 4.0, bias=False)  # sharper attention than a unit-gain init
+    sd["decoder.attn_rnn.weight_ih"] = t((3 * D, P + 2 * D), 1.0 / math.sqrt(P + 2 * D)); sd["decoder.attn_rnn.weight_hh"] = t((3 * D, D), 1.0 / math.sqrt(D))
+    sd["decoder.attn_rnn.bias_ih"] = t((3 * D,), 0.1); sd["decoder.attn_rnn.bias_hh"] = t((3 * D,), 0.1)
+    lin("decoder.rnn_input", H, P + D, 1.0)
+    for n in ("res_rnn1", "res_rnn2"):
+        sd[f"decoder.{n}.weight_ih"] = t((4 * H, H), 1.0 / math.sqrt(H)); sd[f"decoder.{n}.weight_hh"] = t((4 * H, H), 1.0 / math.sqrt(H))
+        sd[f"decoder.{n}.bias_ih"] = t((4 * H,), 0.1); sd[f"decoder.{n}.bias_hh"] = t((4 * H,), 0.1)
+    lin("decoder.mel_proj", n_mels * 20, H, 1.5, bias=False)
+    lin("decoder.stop_proj", 1, H + P, 1.0)
+    cbhg("postnet", n_mels, C, [C, n_mels])
+    lin("post_proj", n_mels, C, 1.0, bias=False)
+    sd["step"] = torch.zeros(1, dtype=torch.long)
+    sd["stop_threshold"] = torch.tensor(-3.4, dtype=torch.float32)
+    return {"model_state": sd}
+
+
+def tacotron_inputs(batch, t_min=90, t_max=110, seed=2):
+    """ids U{2..74}, length U{t_min..t_max}, EOS=1 appended; L2-normalised N(0,1) speaker embeds."""
+    rng = np.random.default_rng(seed)
+    seqs, embeds = [], []
+    for _ in range(batch):
+        n = int(rng.integers(t_min, t_max + 1))
+        seqs.append(np.concatenate([rng.integers(2, 75, n), [1]]).astype(np.int64))
+        e = rng.standard_normal(256).astype(np.float32)
+        embeds.append(e / np.linalg.norm(e))
+    return seqs, embeds
+
+
+def decoder_dropout_masks(seed, n_iter, batch, width=256):
+    """Bernoulli(0.5) keep masks [n_iter, 2, batch, width] (pre_net.py:23,26 order within an iteration)."""
+    g = torch.Generator().manual_seed(seed)
+    return torch.empty(n_iter, 2, batch, width).bernoulli_(0.5, generator=g)

@@ -9,7 +9,7 @@ import torch
 
 import refimport
 import synth
-from oracle import gan as og, maximum_path as omp, wavernn as ow
+from oracle import gan as og, maximum_path as omp, tacotron as ot, wavernn as ow
 
 G = os.path.join(os.path.dirname(__file__), "golden")
 torch.set_num_threads(1)
@@ -127,3 +127,37 @@ def test_oracle_vs_live_reference():
     ref.maximum_path_c(p1, v1, tys, txs)
     omp.maximum_path_c(p2, v2, tys, txs)
     assert np.array_equal(p1, p2) and np.array_equal(v1, v2)
+
+
+@pytest.mark.parametrize("name,B,tmin,tmax,steps,style,mst,seed", [("b3_style-1", 3, 20, 30, 40, -1, 11, 5),
+                                                                   ("b2_style0_stop", 2, 14, 18, 60, 0, 4.0, 6)])
+def test_tacotron_oracle_vs_golden(name, B, tmin, tmax, steps, style, mst, seed):
+    """Tacotron.generate of the real reference (same torch.manual_seed -> same dropout draws)."""
+    gold = np.load(os.path.join(G, "tacotron.npz"))
+    w = synth.tacotron_state(seed=3)["model_state"]
+    seqs, emb = synth.tacotron_inputs(B, tmin, tmax, seed=seed)
+    T = max(len(s) for s in seqs)
+    chars = torch.tensor(np.stack([np.pad(s, (0, T - len(s))) for s in seqs])).long()
+    spk = torch.tensor(np.stack(emb))
+    torch.manual_seed(seed)
+    mel, lin, att = ot.generate(w, ot.HP, 2, chars, spk, steps=steps, style_idx=style, min_stop_token=mst)
+    assert mel.shape == gold[name + "_mel"].shape  # includes the stop-rule frame count
+    assert np.abs(mel.numpy() - gold[name + "_mel"]).max() <= 2e-5
+    assert np.abs(lin.numpy() - gold[name + "_linear"]).max() <= 2e-5
+    assert np.abs(att.numpy() - gold[name + "_attn"]).max() <= 1e-5
+
+
+def test_tacotron_injected_masks_equal_global_rng():
+    """x * mask * 2 with masks pre-drawn by bernoulli_ in program order == F.dropout(training=True)."""
+    w = synth.tacotron_state(seed=3)["model_state"]
+    seqs, emb = synth.tacotron_inputs(2, 10, 14, seed=8)
+    T = max(len(s) for s in seqs)
+    chars = torch.tensor(np.stack([np.pad(s, (0, T - len(s))) for s in seqs])).long()
+    spk = torch.tensor(np.stack(emb))
+    torch.manual_seed(4)
+    a = ot.generate(w, ot.HP, 2, chars, spk, steps=16, style_idx=0, min_stop_token=11)
+    torch.manual_seed(4)
+    masks = [torch.empty(2, T, 256).bernoulli_(0.5) for _ in range(2)]
+    masks += [torch.empty(2, 256).bernoulli_(0.5) for _ in range(16)]
+    b = ot.generate(w, ot.HP, 2, chars, spk, steps=16, style_idx=0, min_stop_token=11, masks=ot.MaskSource(masks))
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
