@@ -54,66 +54,91 @@ __global__ void repeat_rows_kernel(const float* __restrict__ in, int t_in, float
 
 // ---- sampler ----------------------------------------------------------------
 struct SampK {
-  const float* logits;  // [N][C]
-  const float* noise;   // [S][N][C] Exp(1) draws or null
+  const float* logits;  // [n][C] (lane-local)
+  const float* noise;   // [S][N_total][C] Exp(1) draws or null
   unsigned long long seed;
-  const float* forced;  // [N][S] or null
-  float* samples;       // [N][S]
-  float* logits_out;    // [S][N][C] or null
-  const int* step;      // counter already incremented by this step's first kernel
-  int N, C, S, R;
+  const float* forced;  // [N_total][S] or null
+  float* samples;       // [N_total][S]
+  float* logits_out;    // [S][N_total][C] or null
+  const int* step;      // lane counter, already incremented by this step's first kernel
+  int n_off, N_total;   // this lane covers folds [n_off, n_off + gridDim.x)
+  int C, S, R;
   int fold_stride, total_len, hop, frames;
   const float* Ipre;    // [(total_len+1)][R]
   const float* wI0;     // [R]
-  float* x0;            // [N][R]
-  int* idx_frame;       // [N]
+  float* x0;            // [n][R] (lane-local)
+  int* idx_frame;       // [n]   (lane-local)
   volatile int* progress;
 };
 
-// x0 / table row for fold n at step s1 with fed-back sample xfb (:192-195 + fold indexing :334-336)
-__device__ __forceinline__ void prep_step(const SampK& a, int n, int s1, float xfb, int lane) {
-  const long long pos = (long long)n * a.fold_stride + s1;
+// x0 / table row for lane-local fold n at step s1 with fed-back sample xfb (:192-195 + fold indexing :334-336)
+__device__ __forceinline__ void prep_step(const SampK& a, int n, int s1, float xfb, int tid, int nthreads) {
+  const long long pos = (long long)(a.n_off + n) * a.fold_stride + s1;
   const bool livep = pos < a.total_len;
   const long long ipos = livep ? pos : a.total_len;
-  if (lane == 0) a.idx_frame[n] = livep ? (int)(pos / a.hop) : a.frames;
+  if (tid == 0) a.idx_frame[n] = livep ? (int)(pos / a.hop) : a.frames;
   const float* ip = a.Ipre + ipos * a.R;
-  for (int j = lane; j < a.R; j += 64) a.x0[(size_t)n * a.R + j] = ip[j] + xfb * a.wI0[j];
+  for (int j = tid; j < a.R; j += nthreads) a.x0[(size_t)n * a.R + j] = ip[j] + xfb * a.wI0[j];
 }
 
-__global__ __launch_bounds__(64) void wavernn_init_kernel(SampK a) {
-  prep_step(a, blockIdx.x, 0, 0.f, threadIdx.x);
+__global__ __launch_bounds__(128) void wavernn_init_kernel(SampK a) {
+  prep_step(a, blockIdx.x, 0, 0.f, threadIdx.x, blockDim.x);
 }
 
 // softmax -> Categorical.sample() -> 2k/(C-1)-1   (:222-228).  torch.multinomial(p, 1) on the
 // CPU path is argmax(p / Exp(1) noise) (verified bit-exact), restated here with
-// the noise either injected (parity) or drawn from Philox (production).
-__global__ __launch_bounds__(64) void wavernn_sample_kernel(SampK a) {
-  const int n = blockIdx.x, lane = threadIdx.x;
+// the noise either injected (parity) or drawn from Philox (production; one call per 4 classes).
+// One workgroup (2 waves) per fold, 4 classes per thread per pass, wave-shuffle + LDS reductions.
+__global__ __launch_bounds__(128) void wavernn_sample_kernel(SampK a) {
+  __shared__ float redf[2];
+  __shared__ int redi[2];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int s = *a.step - 1;
+  const int gn = a.n_off + n;
   const float* lg = a.logits + (size_t)n * a.C;
   float m = -INFINITY;
-  for (int c = lane; c < a.C; c += 64) m = fmaxf(m, lg[c]);
+  for (int c = tid * 4; c < a.C; c += 512) {
+    const float4 v = *reinterpret_cast<const float4*>(lg + c);
+    m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+  }
   m = wave_max(m);
+  if (lane == 0) redf[wave] = m;
+  __syncthreads();
+  m = fmaxf(redf[0], redf[1]);
+  __syncthreads();
   float sum = 0.f;
-  for (int c = lane; c < a.C; c += 64) sum += expf(lg[c] - m);
+  for (int c = tid * 4; c < a.C; c += 512) {
+    const float4 v = *reinterpret_cast<const float4*>(lg + c);
+    sum += (expf(v.x - m) + expf(v.y - m)) + (expf(v.z - m) + expf(v.w - m));
+  }
   sum = wave_sum(sum);
+  if (lane == 0) redf[wave] = sum;
+  __syncthreads();
+  sum = redf[0] + redf[1];
+  __syncthreads();
   float best = -1.f;
   int bidx = 0x7fffffff;
-  const size_t nb = ((size_t)s * a.N + n) * a.C;
-  for (int c = lane; c < a.C; c += 64) {
-    const float l = lg[c];
-    if (a.logits_out) a.logits_out[nb + c] = l;
-    const float p = expf(l - m) / sum;
-    float e;
-    if (a.noise) e = a.noise[nb + c];
-    else {
+  const size_t nb = ((size_t)s * a.N_total + gn) * a.C;
+  for (int c = tid * 4; c < a.C; c += 512) {
+    const float4 v = *reinterpret_cast<const float4*>(lg + c);
+    const float l4[4] = {v.x, v.y, v.z, v.w};
+    float e4[4];
+    if (a.noise) {
+      const float4 e = *reinterpret_cast<const float4*>(a.noise + nb + c);
+      e4[0] = e.x; e4[1] = e.y; e4[2] = e.z; e4[3] = e.w;
+    } else {
       uint32_t r[4];
-      philox4x32((uint32_t)s, (uint32_t)n, (uint32_t)(c >> 2), 0x57415645u, (uint32_t)a.seed,
+      philox4x32((uint32_t)s, (uint32_t)gn, (uint32_t)(c >> 2), 0x57415645u, (uint32_t)a.seed,
                  (uint32_t)(a.seed >> 32), r);
-      e = -logf(u32_to_unit(r[c & 3]));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) e4[i] = -logf(u32_to_unit(r[i]));
     }
-    const float q = p / e;
-    if (q > best) { best = q; bidx = c; }  // c ascending per lane: first max kept
+    if (a.logits_out) *reinterpret_cast<float4*>(a.logits_out + nb + c) = v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float q = (expf(l4[i] - m) / sum) / e4[i];
+      if (q > best) { best = q; bidx = c + i; }  // ascending c per thread: first max kept
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -121,13 +146,16 @@ __global__ __launch_bounds__(64) void wavernn_sample_kernel(SampK a) {
     const int oi = __shfl_xor(bidx, o, 64);
     if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
   }
+  if (lane == 0) { redf[wave] = best; redi[wave] = bidx; }
+  __syncthreads();
+  if (redf[1] > redf[0] || (redf[1] == redf[0] && redi[1] < redi[0])) bidx = redi[1]; else bidx = redi[0];
   const float x = 2.f * (float)bidx / ((float)a.C - 1.f) - 1.f;
-  if (lane == 0) {
-    a.samples[(size_t)n * a.S + s] = x;
-    if (a.progress && n == 0 && (s % 100 == 0 || s == a.S - 1)) *a.progress = s + 1;
+  if (tid == 0) {
+    a.samples[(size_t)gn * a.S + s] = x;
+    if (a.progress && gn == 0 && (s % 100 == 0 || s == a.S - 1)) *a.progress = s + 1;
   }
-  const float xfb = a.forced ? a.forced[(size_t)n * a.S + s] : x;
-  if (s + 1 < a.S) prep_step(a, n, s + 1, xfb, lane);
+  const float xfb = a.forced ? a.forced[(size_t)gn * a.S + s] : x;
+  if (s + 1 < a.S) prep_step(a, n, s + 1, xfb, tid, 128);
 }
 
 }  // namespace mb
@@ -153,16 +181,23 @@ struct mb_wavernn {
   // loop weights
   DevBuf wI0, w_rnn1, w_rnn2, w_fc1, w_fc2, w_fc3;
   DevBuf b_ih1, b_hh1, b_hh2, b_fc3;
-  hipStream_t loop_stream = nullptr;
-  hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
-  hipGraph_t graph = nullptr;        // kept until the next call / destroy so generate stays async
-  hipGraphExec_t graph_exec = nullptr;
-  int last_launches = 0;
+  // Folds are independent sequences: they are dealt to up to MAX_LANES "lanes", each with its own
+  // stream + graph, so the per-kernel dependency latency of one lane overlaps with the others.
+  static constexpr int MAX_LANES = 8;
+  hipStream_t loop_stream = nullptr;          // lane 0 (also runs the conditioning networks)
+  hipStream_t lane_stream[MAX_LANES] = {};
+  hipEvent_t lane_ev[MAX_LANES] = {};
+  hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_cond = nullptr;
+  hipGraph_t graph[MAX_LANES] = {};           // kept until the next call / destroy so generate stays async
+  hipGraphExec_t graph_exec[MAX_LANES] = {};
+  int last_launches = 0, last_lanes = 1;
   bool timed = false;
   int bench_which = 0, bench_iters = 0;  // set by mb_wavernn_bench_kernel
   void drop_graph() {
-    if (graph_exec) { (void)hipStreamSynchronize(loop_stream); (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
-    if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
+    for (int l = 0; l < MAX_LANES; ++l) {
+      if (graph_exec[l]) { (void)hipStreamSynchronize(lane_stream[l]); (void)hipGraphExecDestroy(graph_exec[l]); graph_exec[l] = nullptr; }
+      if (graph[l]) { (void)hipGraphDestroy(graph[l]); graph[l] = nullptr; }
+    }
   }
 };
 
@@ -306,7 +341,12 @@ extern "C" int mb_wavernn_create(const mb_wavernn_config* cfg, const float* cons
     RC(w->b_fc3.upload(b3, C));
   }
 #undef RC
-  if (!rc && hipStreamCreateWithFlags(&w->loop_stream, hipStreamNonBlocking) != hipSuccess) rc = MB_EHIP;
+  for (int l = 0; l < mb_wavernn::MAX_LANES && !rc; ++l) {
+    if (hipStreamCreateWithFlags(&w->lane_stream[l], hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&w->lane_ev[l], hipEventDisableTiming) != hipSuccess) rc = MB_EHIP;
+  }
+  w->loop_stream = w->lane_stream[0];
+  if (!rc && hipEventCreateWithFlags(&w->ev_cond, hipEventDisableTiming) != hipSuccess) rc = MB_EHIP;
   if (!rc) {
     if (hipEventCreateWithFlags(&w->ev_in, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&w->ev_out, hipEventDisableTiming) != hipSuccess ||
@@ -333,7 +373,11 @@ extern "C" void mb_wavernn_destroy(mb_wavernn* w) {
   if (w->ev_out) (void)hipEventDestroy(w->ev_out);
   if (w->ev_t0) (void)hipEventDestroy(w->ev_t0);
   if (w->ev_t1) (void)hipEventDestroy(w->ev_t1);
-  if (w->loop_stream) (void)hipStreamDestroy(w->loop_stream);
+  if (w->ev_cond) (void)hipEventDestroy(w->ev_cond);
+  for (int l = 0; l < mb_wavernn::MAX_LANES; ++l) {
+    if (w->lane_ev[l]) (void)hipEventDestroy(w->lane_ev[l]);
+    if (w->lane_stream[l]) (void)hipStreamDestroy(w->lane_stream[l]);
+  }
   delete w;
 }
 
@@ -370,7 +414,7 @@ static void wavernn_layout(const mb_wavernn* w, const mb_wavernn_plan* p, void* 
   L->logits = ar.take<float>(N * w->n_classes);
   L->h1 = ar.take<float>(2 * N * R); L->h2 = ar.take<float>(2 * N * R);
   L->idx_frame = ar.take<int>(N);
-  L->step = ar.take<int>(4);
+  L->step = ar.take<int>(16);
   L->bytes = ar.off + 256;
 }
 
@@ -475,73 +519,87 @@ extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* 
     MB_HIP(hipMemcpyAsync(L.F2 + (size_t)F * FC, w->t_f2.b.p, sizeof(float) * FC, hipMemcpyDeviceToDevice, s));
     MB_HIP(hipMemsetAsync(L.h1, 0, sizeof(float) * 2 * N * R, s));
     MB_HIP(hipMemsetAsync(L.h2, 0, sizeof(float) * 2 * N * R, s));
-    MB_HIP(hipMemsetAsync(L.step, 0, sizeof(int) * 4, s));
+    MB_HIP(hipMemsetAsync(L.step, 0, sizeof(int) * 16, s));
   }
   if (rc) return rc;
 
-  SampK sk;
-  sk.logits = L.logits; sk.noise = d_noise; sk.seed = seed; sk.forced = d_forced; sk.samples = d_samples;
-  sk.logits_out = d_logits_out; sk.step = L.step; sk.N = N; sk.C = C; sk.S = S; sk.R = R;
-  sk.fold_stride = plan->fold_stride; sk.total_len = T; sk.hop = w->hop; sk.frames = F;
-  sk.Ipre = L.Ipre; sk.wI0 = w->wI0.p; sk.x0 = L.x0; sk.idx_frame = L.idx_frame; sk.progress = h_progress;
-  hipLaunchKernelGGL(wavernn_init_kernel, dim3(N), dim3(64), 0, s, sk);
-  MB_HIP(hipGetLastError());
+  // ---- lanes: contiguous fold ranges, one stream each ----
+  // Measured on MI355X (profiles/r01_wavernn_lane_sweep.json): extra lanes do NOT overlap -- kernel
+  // submission serialises on the host/CP at ~3-4 us per launch -- so the default is one lane.
+  int lanes = 1;
+  if (const char* le = getenv("MBHIP_WAVERNN_LANES")) { if (atoi(le) >= 1) lanes = atoi(le); }
+  lanes = std::max(1, std::min(std::min(lanes, (int)mb_wavernn::MAX_LANES), N));
+  int lane_n0[mb_wavernn::MAX_LANES + 1];
+  for (int l = 0; l <= lanes; ++l) lane_n0[l] = (int)((long long)N * l / lanes);
+  MB_HIP(hipEventRecord(w->ev_cond, s));  // conditioning tables + zeroed state are ready
 
-  // one time step = 5 GEMM launches + sampler; pp = parity of the step (state ping-pong)
-  auto step = [&](int pp, int which = 0x3f) -> int {
-    float* h1p = L.h1 + (size_t)pp * N * R; float* h1n = L.h1 + (size_t)(pp ^ 1) * N * R;
-    float* h2p = L.h2 + (size_t)pp * N * R; float* h2n = L.h2 + (size_t)(pp ^ 1) * N * R;
+  auto make_sk = [&](int l) {
+    const int n0 = lane_n0[l];
+    SampK sk;
+    sk.logits = L.logits + (size_t)n0 * C; sk.noise = d_noise; sk.seed = seed; sk.forced = d_forced;
+    sk.samples = d_samples; sk.logits_out = d_logits_out; sk.step = L.step + l; sk.n_off = n0; sk.N_total = N;
+    sk.C = C; sk.S = S; sk.R = R; sk.fold_stride = plan->fold_stride; sk.total_len = T; sk.hop = w->hop; sk.frames = F;
+    sk.Ipre = L.Ipre; sk.wI0 = w->wI0.p; sk.x0 = L.x0 + (size_t)n0 * R; sk.idx_frame = L.idx_frame + n0;
+    sk.progress = h_progress;
+    return sk;
+  };
+
+  // one time step of lane l = 5 GEMM launches + sampler; pp = parity of the step (state ping-pong)
+  auto step = [&](int l, int pp, int which = 0x3f) -> int {
+    const int n0 = lane_n0[l], nl = lane_n0[l + 1] - n0;
+    hipStream_t ls = w->lane_stream[l];
+    float* x0 = L.x0 + (size_t)n0 * R; float* x1 = L.x1 + (size_t)n0 * R; float* x2 = L.x2 + (size_t)n0 * R;
+    float* y1 = L.y1 + (size_t)n0 * FC; float* y2 = L.y2 + (size_t)n0 * FC; float* lgt = L.logits + (size_t)n0 * C;
+    float* h1p = L.h1 + ((size_t)pp * N + n0) * R; float* h1n = L.h1 + ((size_t)(pp ^ 1) * N + n0) * R;
+    float* h2p = L.h2 + ((size_t)pp * N + n0) * R; float* h2n = L.h2 + ((size_t)(pp ^ 1) * N + n0) * R;
+    const int* idxf = L.idx_frame + n0;
     RnnK k;
     int r = MB_OK;
     // h1 = rnn1(x, h1); x = x + h1   :196-198
     memset(&k, 0, sizeof(k));
     k.w = w->w_rnn1.p; k.nseg = 2; k.nkb_total = 2 * R / 16;
-    k.seg[0] = {L.x0, R, R / 16, 0}; k.seg[1] = {h1p, R, R / 16, 1};
-    k.N = N; k.units = R; k.biasX = w->b_ih1.p; k.biasH = w->b_hh1.p;
-    k.h_prev = h1p; k.x_res = L.x0; k.h_out = h1n; k.x_out = L.x1; k.step_counter = L.step;
-    if ((which & 1) && (r = rnn_launch(EPI_GRU, k, s))) return r;
+    k.seg[0] = {x0, R, R / 16, 0}; k.seg[1] = {h1p, R, R / 16, 1};
+    k.N = nl; k.units = R; k.biasX = w->b_ih1.p; k.biasH = w->b_hh1.p;
+    k.h_prev = h1p; k.x_res = x0; k.h_out = h1n; k.x_out = x1; k.step_counter = L.step + l;
+    if ((which & 1) && (r = rnn_launch(EPI_GRU, k, ls))) return r;
     // h2 = rnn2([x, a2], h2); x = x + h2   :199-202
     memset(&k, 0, sizeof(k));
     k.w = w->w_rnn2.p; k.nseg = 2; k.nkb_total = 2 * R / 16;
-    k.seg[0] = {L.x1, R, R / 16, 0}; k.seg[1] = {h2p, R, R / 16, 1};
-    k.N = N; k.units = R; k.biasH = w->b_hh2.p;
-    k.pre_table = L.G2; k.pre_idx = L.idx_frame; k.pre_stride = 3 * R;
-    k.h_prev = h2p; k.x_res = L.x1; k.h_out = h2n; k.x_out = L.x2;
-    if ((which & 2) && (r = rnn_launch(EPI_GRU, k, s))) return r;
+    k.seg[0] = {x1, R, R / 16, 0}; k.seg[1] = {h2p, R, R / 16, 1};
+    k.N = nl; k.units = R; k.biasH = w->b_hh2.p;
+    k.pre_table = L.G2; k.pre_idx = idxf; k.pre_stride = 3 * R;
+    k.h_prev = h2p; k.x_res = x1; k.h_out = h2n; k.x_out = x2;
+    if ((which & 2) && (r = rnn_launch(EPI_GRU, k, ls))) return r;
     // x = relu(fc1([x, a3]))   :203-204
     memset(&k, 0, sizeof(k));
-    k.w = w->w_fc1.p; k.nseg = 1; k.nkb_total = R / 16; k.seg[0] = {L.x2, R, R / 16, 0};
-    k.N = N; k.units = FC; k.pre_table = L.F1; k.pre_idx = L.idx_frame; k.pre_stride = FC;
-    k.y = L.y1; k.ldy = FC; k.act = 1;
-    if ((which & 4) && (r = rnn_launch(EPI_LINEAR, k, s))) return r;
+    k.w = w->w_fc1.p; k.nseg = 1; k.nkb_total = R / 16; k.seg[0] = {x2, R, R / 16, 0};
+    k.N = nl; k.units = FC; k.pre_table = L.F1; k.pre_idx = idxf; k.pre_stride = FC;
+    k.y = y1; k.ldy = FC; k.act = 1;
+    if ((which & 4) && (r = rnn_launch(EPI_LINEAR, k, ls))) return r;
     // x = relu(fc2([x, a4]))   :206-207
     memset(&k, 0, sizeof(k));
-    k.w = w->w_fc2.p; k.nseg = 1; k.nkb_total = FC / 16; k.seg[0] = {L.y1, FC, FC / 16, 0};
-    k.N = N; k.units = FC; k.pre_table = L.F2; k.pre_idx = L.idx_frame; k.pre_stride = FC;
-    k.y = L.y2; k.ldy = FC; k.act = 1;
-    if ((which & 8) && (r = rnn_launch(EPI_LINEAR, k, s))) return r;
+    k.w = w->w_fc2.p; k.nseg = 1; k.nkb_total = FC / 16; k.seg[0] = {y1, FC, FC / 16, 0};
+    k.N = nl; k.units = FC; k.pre_table = L.F2; k.pre_idx = idxf; k.pre_stride = FC;
+    k.y = y2; k.ldy = FC; k.act = 1;
+    if ((which & 8) && (r = rnn_launch(EPI_LINEAR, k, ls))) return r;
     // logits = fc3(x)   :209
     memset(&k, 0, sizeof(k));
-    k.w = w->w_fc3.p; k.nseg = 1; k.nkb_total = FC / 16; k.seg[0] = {L.y2, FC, FC / 16, 0};
-    k.N = N; k.units = C; k.biasX = w->b_fc3.p; k.y = L.logits; k.ldy = C;
-    if ((which & 16) && (r = rnn_launch(EPI_LINEAR, k, s))) return r;
+    k.w = w->w_fc3.p; k.nseg = 1; k.nkb_total = FC / 16; k.seg[0] = {y2, FC, FC / 16, 0};
+    k.N = nl; k.units = C; k.biasX = w->b_fc3.p; k.y = lgt; k.ldy = C;
+    if ((which & 16) && (r = rnn_launch(EPI_LINEAR, k, ls))) return r;
     if (which & 32) {
-      hipLaunchKernelGGL(wavernn_sample_kernel, dim3(N), dim3(64), 0, s, sk);
+      hipLaunchKernelGGL(wavernn_sample_kernel, dim3(nl), dim3(128), 0, ls, make_sk(l));
       MB_HIP(hipGetLastError());
     }
     return MB_OK;
   };
 
-  if (w->bench_which) {  // micro-benchmark: relaunch ONE loop kernel on the initialised workspace
-    for (int i = 0; i < 20 && !rc; ++i) rc = step(0, w->bench_which);  // warm-up
-    MB_HIP(hipEventRecord(w->ev_t0, s));
-    for (int i = 0; i < w->bench_iters && !rc; ++i) rc = step(0, w->bench_which);
-    MB_HIP(hipEventRecord(w->ev_t1, s));
-    w->last_launches = w->bench_iters; w->timed = true;
-    MB_HIP(hipEventRecord(w->ev_out, s));
-    MB_HIP(hipStreamWaitEvent(cs, w->ev_out, 0));
-    return rc;
+  for (int l = 0; l < lanes; ++l) {
+    if (l > 0) MB_HIP(hipStreamWaitEvent(w->lane_stream[l], w->ev_cond, 0));
+    hipLaunchKernelGGL(wavernn_init_kernel, dim3(lane_n0[l + 1] - lane_n0[l]), dim3(128), 0, w->lane_stream[l], make_sk(l));
+    MB_HIP(hipGetLastError());
   }
+
   MB_HIP(hipEventRecord(w->ev_t0, s));
   const bool use_graph = getenv("MBHIP_NO_GRAPH") == nullptr && S >= 64;
   int done = 0;
@@ -553,22 +611,32 @@ extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* 
     G &= ~1;
     if (G >= 2) {
       w->drop_graph();
-      MB_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
-      for (int i = 0; i < G && !rc; ++i) rc = step(i & 1);
-      hipError_t e = hipStreamEndCapture(s, &w->graph);
-      if (rc) { w->drop_graph(); return rc; }
-      if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture", __FILE__, __LINE__);
-      e = hipGraphInstantiate(&w->graph_exec, w->graph, nullptr, nullptr, 0);
-      if (e != hipSuccess) { w->drop_graph(); return hip_fail(e, "hipGraphInstantiate", __FILE__, __LINE__); }
+      for (int l = 0; l < lanes; ++l) {
+        hipStream_t ls = w->lane_stream[l];
+        MB_HIP(hipStreamBeginCapture(ls, hipStreamCaptureModeRelaxed));
+        for (int i = 0; i < G && !rc; ++i) rc = step(l, i & 1, 0x3f & ~w->bench_which);
+        hipError_t e = hipStreamEndCapture(ls, &w->graph[l]);
+        if (rc) { w->drop_graph(); return rc; }
+        if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture", __FILE__, __LINE__);
+        e = hipGraphInstantiate(&w->graph_exec[l], w->graph[l], nullptr, nullptr, 0);
+        if (e != hipSuccess) { w->drop_graph(); return hip_fail(e, "hipGraphInstantiate", __FILE__, __LINE__); }
+      }
       const int reps = S / G;
-      for (int r = 0; r < reps; ++r) MB_HIP(hipGraphLaunch(w->graph_exec, s));
+      for (int r = 0; r < reps; ++r)
+        for (int l = 0; l < lanes; ++l) MB_HIP(hipGraphLaunch(w->graph_exec[l], w->lane_stream[l]));
       done = reps * G;
     }
   }
-  for (int i = done; i < S && !rc; ++i) rc = step(i & 1);
+  for (int i = done; i < S && !rc; ++i)
+    for (int l = 0; l < lanes && !rc; ++l) rc = step(l, i & 1, 0x3f & ~w->bench_which);
   if (rc) return rc;
+  for (int l = 1; l < lanes; ++l) {  // join the lanes on lane 0
+    MB_HIP(hipEventRecord(w->lane_ev[l], w->lane_stream[l]));
+    MB_HIP(hipStreamWaitEvent(s, w->lane_ev[l], 0));
+  }
   MB_HIP(hipEventRecord(w->ev_t1, s));
-  w->last_launches = 6 * S;
+  w->last_launches = 6 * S * lanes;
+  w->last_lanes = lanes;
   w->timed = true;
   MB_HIP(hipEventRecord(w->ev_out, s));
   MB_HIP(hipStreamWaitEvent(cs, w->ev_out, 0));
@@ -589,15 +657,23 @@ extern "C" int mb_wavernn_bench_kernel(mb_wavernn* w, const mb_wavernn_plan* pla
                                        float* d_samples, void* d_workspace, size_t workspace_bytes,
                                        int which, int iters, float* avg_us, double* algorithmic_bytes,
                                        mb_stream_t stream) {
-  MB_REQUIRE(w && plan && avg_us && which >= 0 && which < 5 && iters > 0, "wavernn_bench_kernel: bad argument (which in 0..4)");
-  w->bench_which = 1 << which; w->bench_iters = iters;
-  int rc = mb_wavernn_generate(w, plan, d_mel, nullptr, 0, d_samples, nullptr, nullptr, nullptr, d_workspace,
-                               workspace_bytes, stream);
-  w->bench_which = 0; w->bench_iters = 0;
+  // In-situ marginal duration: time the real (graph-replayed) sample loop with HIP events on its
+  // stream, with and without kernel `which`; kernels of the chain run back to back, so the
+  // difference per step is that kernel's launch-to-launch duration (what rocprofv3 reports).
+  MB_REQUIRE(w && plan && avg_us && which >= 1 && which < 5, "wavernn_bench_kernel: which must be 1..4");
+  (void)iters;
+  float ms_full = 0.f, ms_wo = 0.f;
+  int rc = MB_OK;
+  for (int pass = 0; pass < 2 && !rc; ++pass) {
+    w->bench_which = pass ? (1 << which) : 0;
+    rc = mb_wavernn_generate(w, plan, d_mel, nullptr, 0, d_samples, nullptr, nullptr, nullptr, d_workspace,
+                             workspace_bytes, stream);
+    if (!rc) rc = mb_wavernn_last_loop_ms(w, pass ? &ms_wo : &ms_full, nullptr);
+  }
+  w->bench_which = 0;
   if (rc) return rc;
-  float ms = 0.f;
-  rc = mb_wavernn_last_loop_ms(w, &ms, nullptr);
-  if (rc) return rc;
+  const float ms = ms_full - ms_wo;
+  iters = plan->seq_len;
   *avg_us = ms * 1000.f / iters;
   if (algorithmic_bytes) {
     const double R = w->cfg.rnn_dims, FC = w->cfg.fc_dims, C = w->n_classes, N = plan->n_folds;

@@ -43,8 +43,8 @@ class WaveRNNDevice:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
-            _lib.lib().mb_wavernn_destroy(h)
+        if h and _lib is not None and getattr(_lib, "_lib", None) is not None:
+            _lib._lib.mb_wavernn_destroy(h)
             self._h = None
 
     def plan(self, frames, batched, target, overlap):
