@@ -3,32 +3,35 @@
 
 namespace mb {
 
-template <int EPI, int NW>
+template <int EPI, int NW, int NT>
 __global__ __launch_bounds__(NW * 64) void rnn_rowtile_kernel(RnnK a) {
   constexpr int RL = (EPI == EPI_GRU) ? 3 : 4;
   constexpr int BLK = 4 * RL * 16;  // floats per (tile, k-block)
   constexpr int NPART = (EPI == EPI_GRU) ? 2 : 1;
-  __shared__ __attribute__((aligned(16))) float red[NW * NPART * 256];
+  __shared__ __attribute__((aligned(16))) float red[NW * NPART * NT * 256];
 
+  if (a.skip_flag && *a.skip_flag) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int mt = blockIdx.x, ntile = blockIdx.y;
-  const int i = lane & 15, kq = lane >> 4;  // A: row i, k-quad kq;  B: column i, k-quad kq
+  const int mt = blockIdx.x, ntile0 = blockIdx.y * NT;  // this workgroup covers NT column tiles: the
+  const int i = lane & 15, kq = lane >> 4;              // weight fragment is fetched once for all of them
   const int u = i >> 2, tau = i & 3;
   const bool live = tau < RL;
   const float* wl = a.w + (size_t)mt * a.nkb_total * BLK + ((u * RL + tau) * 4 + kq) * 4;
-  int ncol = ntile * 16 + i;
-  if (ncol >= a.N) ncol = a.N - 1;  // duplicate a live column; its result is never stored
-
-  if (a.skip_flag && *a.skip_flag) return;
+  int ncol[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    ncol[nt] = (ntile0 + nt) * 16 + i;
+    if (ncol[nt] >= a.N) ncol[nt] = a.N - 1;  // duplicate a live column; its result is never stored
+  }
   if (a.step_counter && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.step_counter += 1;
 
-  // Epilogue operands (biases, table row, previous state) are fetched by wave 0 BEFORE the
-  // GEMM so their latency hides under it instead of extending the dependent tail.
-  const int en = ntile * 16 + (lane & 15);   // epilogue column of this lane
-  const int edu = lane >> 4;                 // epilogue unit within the tile
+  // Epilogue operands (biases, table row, previous state) are fetched by the epilogue waves
+  // (wave w < NT owns column tile w) BEFORE the GEMM so their latency hides under it.
+  const int en = (ntile0 + (wave < NT ? wave : 0)) * 16 + (lane & 15);  // epilogue column of this lane
+  const int edu = lane >> 4;                                            // epilogue unit within the tile
   float e_bx[4] = {0.f, 0.f, 0.f, 0.f}, e_bh[4] = {0.f, 0.f, 0.f, 0.f};
   float e_hp = 0.f, e_cp = 0.f, e_xr = 0.f, e_mask[4] = {1.f, 1.f, 1.f, 1.f};
-  if (wave == 0 && en < a.N) {
+  if (wave < NT && en < a.N) {
     const int prow = a.pre_idx ? a.pre_idx[en] : a.pre_base_row + en * a.pre_n_stride;
     const float* pre = a.pre_table ? a.pre_table + (size_t)prow * a.pre_stride : nullptr;
     if (EPI == EPI_LINEAR) {
@@ -65,19 +68,22 @@ __global__ __launch_bounds__(NW * 64) void rnn_rowtile_kernel(RnnK a) {
     }
   }
 
-  f32x4 accX = {0.f, 0.f, 0.f, 0.f}, accH = {0.f, 0.f, 0.f, 0.f};
+  f32x4 accX[NT], accH[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) { accX[nt] = {0.f, 0.f, 0.f, 0.f}; accH[nt] = {0.f, 0.f, 0.f, 0.f}; }
   // This wave owns k-blocks wave, wave+NW, ... of the concatenated K.  They are walked UB at a
   // time with ALL fragment loads of a batch issued before the first MFMA, so a wave pays one
   // memory round trip per batch instead of one per block (the loop is latency-, not FLOP-bound).
-  constexpr int UB = 8;
+  constexpr int UB = (NT == 1) ? 8 : 4;
   for (int kb_base = wave; kb_base < a.nkb_total; kb_base += NW * UB) {
-    float4 av[UB], bv[UB];
+    float4 av[UB], bv[UB][NT];
     int part[UB];
 #pragma unroll
     for (int ub = 0; ub < UB; ++ub) {
       const int kb = kb_base + ub * NW;
       av[ub] = make_float4(0.f, 0.f, 0.f, 0.f);
-      bv[ub] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bv[ub][nt] = make_float4(0.f, 0.f, 0.f, 0.f);
       part[ub] = 0;
       if (kb < a.nkb_total) {
         int local = kb, sgi = 0;
@@ -86,38 +92,47 @@ __global__ __launch_bounds__(NW * 64) void rnn_rowtile_kernel(RnnK a) {
           if (sgi < a.nseg - 1 && local >= a.seg[sgi].nkb) { local -= a.seg[sgi].nkb; ++sgi; }
         const RnnSeg sg = a.seg[sgi];
         part[ub] = sg.part;
-        bv[ub] = *reinterpret_cast<const float4*>(sg.p + (size_t)ncol * sg.ld + local * 16 + kq * 4);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          bv[ub][nt] = *reinterpret_cast<const float4*>(sg.p + (size_t)ncol[nt] * sg.ld + local * 16 + kq * 4);
         if (live) av[ub] = *reinterpret_cast<const float4*>(wl + (size_t)kb * BLK);
       }
     }
 #pragma unroll
     for (int ub = 0; ub < UB; ++ub) {
-      if (NPART == 2 && part[ub] == 1) {
-        accH = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ub].x, bv[ub].x, accH, 0, 0, 0);
-        accH = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ub].y, bv[ub].y, accH, 0, 0, 0);
-        accH = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ub].z, bv[ub].z, accH, 0, 0, 0);
-        accH = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ub].w, bv[ub].w, accH, 0, 0, 0);
-      } else {
-        accX = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ub].x, bv[ub].x, accX, 0, 0, 0);
-        accX = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ub].y, bv[ub].y, accX, 0, 0, 0);
-        accX = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ub].z, bv[ub].z, accX, 0, 0, 0);
-        accX = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ub].w, bv[ub].w, accX, 0, 0, 0);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        if (NPART == 2 && part[ub] == 1) {
+          accH[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ub].x, bv[ub][nt].x, accH[nt], 0, 0, 0);
+          accH[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ub].y, bv[ub][nt].y, accH[nt], 0, 0, 0);
+          accH[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ub].z, bv[ub][nt].z, accH[nt], 0, 0, 0);
+          accH[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ub].w, bv[ub][nt].w, accH[nt], 0, 0, 0);
+        } else {
+          accX[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ub].x, bv[ub][nt].x, accX[nt], 0, 0, 0);
+          accX[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ub].y, bv[ub][nt].y, accX[nt], 0, 0, 0);
+          accX[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ub].z, bv[ub][nt].z, accX[nt], 0, 0, 0);
+          accX[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ub].w, bv[ub][nt].w, accX[nt], 0, 0, 0);
+        }
       }
     }
   }
   // cross-wave reduction through LDS: D fragment lane = (unit = lane>>4, col = lane&15), reg = gate
   float4* red4 = reinterpret_cast<float4*>(red);
-  red4[(wave * NPART + 0) * 64 + lane] = make_float4(accX[0], accX[1], accX[2], accX[3]);
-  if (NPART == 2) red4[(wave * NPART + 1) * 64 + lane] = make_float4(accH[0], accH[1], accH[2], accH[3]);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    red4[((wave * NT + nt) * NPART + 0) * 64 + lane] = make_float4(accX[nt][0], accX[nt][1], accX[nt][2], accX[nt][3]);
+    if (NPART == 2)
+      red4[((wave * NT + nt) * NPART + 1) * 64 + lane] = make_float4(accH[nt][0], accH[nt][1], accH[nt][2], accH[nt][3]);
+  }
   __syncthreads();
-  if (wave != 0) return;
+  if (wave >= NT) return;
   float sx[4] = {0.f, 0.f, 0.f, 0.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int w = 0; w < NW; ++w) {
-    const float4 v = red4[(w * NPART + 0) * 64 + lane];
+    const float4 v = red4[((w * NT + wave) * NPART + 0) * 64 + lane];
     sx[0] += v.x; sx[1] += v.y; sx[2] += v.z; sx[3] += v.w;
     if (NPART == 2) {
-      const float4 h = red4[(w * NPART + 1) * 64 + lane];
+      const float4 h = red4[((w * NT + wave) * NPART + 1) * 64 + lane];
       sh[0] += h.x; sh[1] += h.y; sh[2] += h.z; sh[3] += h.w;
     }
   }
@@ -200,10 +215,19 @@ int rnn_launch(int epi, const RnnK& k, hipStream_t s) {
   MB_REQUIRE(k.N >= 1 && k.units >= 1 && k.nseg >= 1 && k.nseg <= 4, "rnn_launch: bad shape");
   constexpr int NW = 8;
   const int n_mt = (epi == EPI_LINEAR) ? cdiv(k.units, 16) : cdiv(k.units, 4);
-  dim3 grid(n_mt, cdiv(k.N, 16));
-  if (epi == EPI_LINEAR) hipLaunchKernelGGL((rnn_rowtile_kernel<EPI_LINEAR, NW>), grid, dim3(NW * 64), 0, s, k);
-  else if (epi == EPI_GRU) hipLaunchKernelGGL((rnn_rowtile_kernel<EPI_GRU, NW>), grid, dim3(NW * 64), 0, s, k);
-  else hipLaunchKernelGGL((rnn_rowtile_kernel<EPI_LSTM, NW>), grid, dim3(NW * 64), 0, s, k);
+  // More than 16 columns AND a weight matrix big enough to be bandwidth-bound (the batch-32
+  // Tacotron LSTMs, 33.5 MB): one workgroup covers two 16-column tiles so the weights are
+  // streamed once per 32 columns.  Small matrices (WaveRNN, <= 6.6 MB) are latency-bound and run
+  // faster with twice the workgroups (measured: 45 vs 51 us per WaveRNN step).
+  const int rl = (epi == EPI_GRU) ? 3 : 4;
+  const size_t wbytes = (size_t)n_mt * k.nkb_total * 4 * rl * 16 * sizeof(float);
+  const int nt = (k.N > 16 && wbytes >= ((size_t)12 << 20)) ? 2 : 1;
+  dim3 grid(n_mt, cdiv(k.N, 16 * nt));
+#define MB_RNN(EPI_, NT_) hipLaunchKernelGGL((rnn_rowtile_kernel<EPI_, NW, NT_>), grid, dim3(NW * 64), 0, s, k)
+  if (epi == EPI_LINEAR) { if (nt == 2) MB_RNN(EPI_LINEAR, 2); else MB_RNN(EPI_LINEAR, 1); }
+  else if (epi == EPI_GRU) { if (nt == 2) MB_RNN(EPI_GRU, 2); else MB_RNN(EPI_GRU, 1); }
+  else { if (nt == 2) MB_RNN(EPI_LSTM, 2); else MB_RNN(EPI_LSTM, 1); }
+#undef MB_RNN
   MB_HIP(hipGetLastError());
   return MB_OK;
 }

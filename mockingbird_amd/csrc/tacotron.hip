@@ -27,7 +27,8 @@ struct LsaK {
   const float* mem_proj;  // [B][T][D]
   const float* memory;    // [B][T][P]
   const int* chars;       // [B][T]
-  float* cumulative;      // [B][T] state (in/out)
+  const float* cum_in;    // [B][T] cumulative attention (read)
+  float* cum_out;         // [B][T] cumulative attention (written; ping-pong, no intra-launch race)
   const float* conv_w;    // [Fl][Kl]
   const float* conv_b;    // [Fl]
   const float* Lw;        // [D][Fl]
@@ -36,89 +37,136 @@ struct LsaK {
   const float* vw;        // [D]
   float* context;         // [B][P] out
   float* attn_out;        // [B][n_iter_max][T] (row `iter`)
-  int T, D, P, Fl, Kl, iter, n_iter_max;
+  int T, D, P, Fl, Kl, iter, n_iter_max, psplit;
   const int* skip_flag;
 };
 
-// dynamic LDS: cum[T + Kl - 1] | pq[D] | loc[T][Fl] | u[T] | red[32]
+// One workgroup (8 waves) per (utterance, quarter of the context columns).  The attention
+// window -- cumulative alignment (zero padded), location features, energies, scores -- lives in
+// LDS; the scores are recomputed by each of the `psplit` column groups (cheap) so the T x P
+// context product, the only part that streams real data (T*P*4 B per utterance from L2),
+// is spread over psplit CUs with 16 B/lane loads, 8 rows in flight per wave.
+// dynamic LDS: cum[T+Kl-1] | pq[D] | LwT[Fl][D] | cw[Fl*Kl] | loc[T][Fl] | u[T] | red[64] | part[8][64*4]
 __global__ __launch_bounds__(512) void lsa_kernel(LsaK a) {
   if (a.skip_flag && *a.skip_flag) return;
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int b = blockIdx.x, pg = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = a.T, D = a.D, Fl = a.Fl, Kl = a.Kl, half = (Kl - 1) / 2;
-  float* cum = sm;                    // zero padded by `half` on both sides
-  float* pq = cum + (T + Kl - 1);
-  float* loc = pq + D;
+  float* cum = sm;  // zero padded by `half` on both sides
+  float* pq = cum + ((T + Kl - 1 + 3) & ~3);
+  float* LwT = pq + D;
+  float* cw = LwT + (size_t)Fl * D;
+  float* loc = cw + ((Fl * Kl + 3) & ~3);
   float* u = loc + (size_t)T * Fl;
-  float* red = u + T;
-  float* cg = a.cumulative + (size_t)b * T;
-  for (int i = tid; i < T + Kl - 1; i += blockDim.x) {
+  float* red = u + ((T + 3) & ~3);
+  float* part = red + 64;
+  const float* cg = a.cum_in + (size_t)b * T;
+  for (int i = tid; i < T + Kl - 1; i += 512) {
     const int t = i - half;
     cum[i] = (t >= 0 && t < T) ? cg[t] : 0.f;
   }
-  // processed_query = W(query)  (lsa.py:25)
-  for (int d = tid; d < D; d += blockDim.x) {
-    const float* wr = a.Ww + (size_t)d * D;
-    const float* q = a.query + (size_t)b * D;
+  for (int i = tid; i < Fl * D; i += 512) { const int d = i / Fl, f = i - d * Fl; LwT[f * D + d] = a.Lw[i]; }
+  for (int i = tid; i < Fl * Kl; i += 512) cw[i] = a.conv_w[i];
+  // processed_query = W(query) (lsa.py:25): thread (d, quarter of k), partials through LDS
+  {
+    const int nq = 512 / D > 0 ? 512 / D : 1;  // k-parts per output (4 for D=128)
+    const int d = tid % D, kp = tid / D;
     float acc = 0.f;
-    for (int k = 0; k < D; ++k) acc += wr[k] * q[k];
-    pq[d] = acc + a.Wb[d];
+    if (kp < nq) {
+      const float* wr = a.Ww + (size_t)d * D;
+      const float* q = a.query + (size_t)b * D;
+      const int k0 = kp * (D / nq), k1 = (kp == nq - 1) ? D : k0 + D / nq;
+      for (int k = k0; k < k1; ++k) acc += wr[k] * q[k];
+      part[kp * D + d] = acc;
+    }
+    __syncthreads();
+    if (tid < D) {
+      float sacc = 0.f;
+      for (int j = 0; j < nq; ++j) sacc += part[j * D + tid];
+      pq[tid] = sacc + a.Wb[tid];
+    }
   }
   __syncthreads();
   // location features: conv1d(1 -> Fl, k = Kl, same padding) over the cumulative attention (lsa.py:27-28)
-  for (int i = tid; i < T * Fl; i += blockDim.x) {
+  for (int i = tid; i < T * Fl; i += 512) {
     const int t = i / Fl, f = i - t * Fl;
-    const float* wf = a.conv_w + (size_t)f * Kl;
+    const float* wf = cw + f * Kl;
     float acc = 0.f;
     for (int j = 0; j < Kl; ++j) acc += wf[j] * cum[t + j];
     loc[i] = acc + a.conv_b[f];
   }
   __syncthreads();
-  // u[t] = v . tanh(pq + mem_proj[t] + L(loc[t]))   (lsa.py:28-31); one wave per t, lanes over d
+  // u[t] = v . tanh(pq + mem_proj[t] + L(loc[t])) (lsa.py:28-31): one wave per t, lanes over d
   const float* mp = a.mem_proj + (size_t)b * T * D;
-  for (int t = wave; t < T; t += nw) {
-    float part = 0.f;
+  for (int t = wave; t < T; t += 8) {
+    float pacc = 0.f;
+    const float* lt = loc + (size_t)t * Fl;
     for (int d = lane; d < D; d += 64) {
-      const float* lw = a.Lw + (size_t)d * Fl;
-      const float* lt = loc + (size_t)t * Fl;
       float pl = 0.f;
-      for (int f = 0; f < Fl; ++f) pl += lw[f] * lt[f];
-      part += a.vw[d] * tanhf((pq[d] + mp[(size_t)t * D + d]) + pl);
+      for (int f = 0; f < Fl; ++f) pl += LwT[f * D + d] * lt[f];
+      pacc += a.vw[d] * tanhf((pq[d] + mp[(size_t)t * D + d]) + pl);
     }
-    part = wave_sum(part);
-    if (lane == 0) u[t] = a.chars[(size_t)b * T + t] != 0 ? part : part * 0.f;  // u * (chars != 0) (lsa.py:34)
+    pacc = wave_sum(pacc);
+    if (lane == 0) u[t] = a.chars[(size_t)b * T + t] != 0 ? pacc : pacc * 0.f;  // u * (chars != 0) (lsa.py:34)
   }
   __syncthreads();
   // softmax over T (lsa.py:38)
   float m = -INFINITY;
-  for (int t = tid; t < T; t += blockDim.x) m = fmaxf(m, u[t]);
+  for (int t = tid; t < T; t += 512) m = fmaxf(m, u[t]);
   m = wave_max(m);
   if (lane == 0) red[wave] = m;
   __syncthreads();
   m = red[0];
-  for (int w = 1; w < nw; ++w) m = fmaxf(m, red[w]);
+  for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w]);
   __syncthreads();
-  float s = 0.f;
-  for (int t = tid; t < T; t += blockDim.x) { const float e = expf(u[t] - m); u[t] = e; s += e; }
-  s = wave_sum(s);
-  if (lane == 0) red[wave] = s;
+  float ssum = 0.f;
+  for (int t = tid; t < T; t += 512) { const float e = expf(u[t] - m); u[t] = e; ssum += e; }
+  ssum = wave_sum(ssum);
+  if (lane == 0) red[wave] = ssum;
   __syncthreads();
-  s = 0.f;
-  for (int w = 0; w < nw; ++w) s += red[w];
-  float* ao = a.attn_out ? a.attn_out + ((size_t)b * a.n_iter_max + a.iter) * T : nullptr;
-  for (int t = tid; t < T; t += blockDim.x) {
-    const float sc = u[t] / s;
+  ssum = 0.f;
+  for (int w = 0; w < 8; ++w) ssum += red[w];
+  float* ao = (a.attn_out && pg == 0) ? a.attn_out + ((size_t)b * a.n_iter_max + a.iter) * T : nullptr;
+  for (int t = tid; t < T; t += 512) {
+    const float sc = u[t] / ssum;
     u[t] = sc;
-    cg[t] = cum[t + half] + sc;  // cumulative += attention (lsa.py:40)
+    if (pg == 0) a.cum_out[(size_t)b * T + t] = cum[t + half] + sc;  // cumulative += attention (lsa.py:40)
     if (ao) ao[t] = sc;
   }
   __syncthreads();
-  // context = scores @ encoder_seq (tacotron.py:104)
-  const float* mem = a.memory + (size_t)b * T * a.P;
-  for (int p = tid; p < a.P; p += blockDim.x) {
-    float acc = 0.f;
-    for (int t = 0; t < T; ++t) acc += u[t] * mem[(size_t)t * a.P + p];
-    a.context[(size_t)b * a.P + p] = acc;
+  // context = scores @ encoder_seq (tacotron.py:104) for this group's columns [p0, p0 + pw)
+  const int pw = a.P / a.psplit, p0 = pg * pw;
+  const float* mem = a.memory + (size_t)b * T * a.P + p0;
+  for (int c4 = lane * 4; c4 < pw; c4 += 256) {  // 64 lanes x float4 = 256 columns per sweep
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int t = wave;
+    for (; t + 56 < T; t += 64) {  // 8 independent rows in flight
+      float4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(mem + (size_t)(t + 8 * j) * a.P + c4);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float sc = u[t + 8 * j];
+        acc.x += sc * v[j].x; acc.y += sc * v[j].y; acc.z += sc * v[j].z; acc.w += sc * v[j].w;
+      }
+    }
+    for (; t < T; t += 8) {
+      const float4 v = *reinterpret_cast<const float4*>(mem + (size_t)t * a.P + c4);
+      const float sc = u[t];
+      acc.x += sc * v.x; acc.y += sc * v.y; acc.z += sc * v.z; acc.w += sc * v.w;
+    }
+    reinterpret_cast<float4*>(part)[wave * 64 + lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+      float4 r = reinterpret_cast<float4*>(part)[lane];
+#pragma unroll
+      for (int w = 1; w < 8; ++w) {
+        const float4 o = reinterpret_cast<float4*>(part)[w * 64 + lane];
+        r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+      }
+      *reinterpret_cast<float4*>(a.context + (size_t)b * a.P + p0 + c4) = r;
+    }
+    __syncthreads();
   }
 }
 
@@ -395,7 +443,7 @@ static void taco_layout(const mb_taco* t, int B, int T, int max_steps, void* bas
   L->h1 = ar.take<float>(2 * B * H); L->c1 = ar.take<float>(2 * B * H);
   L->h2 = ar.take<float>(2 * B * H); L->c2 = ar.take<float>(2 * B * H);
   L->melstep = ar.take<float>((size_t)B * c.r * M);
-  L->cumulative = ar.take<float>((size_t)B * T);
+  L->cumulative = ar.take<float>((size_t)2 * B * T);
   L->stop = ar.take<float>(B);
   L->flags = ar.take<int>(8);
   L->melc = ar.take<float>(B * M * F);
@@ -448,7 +496,10 @@ extern "C" int mb_taco_decode(const mb_taco* t, const float* d_memory, const flo
   const int C = c.postnet_dims, Hg = C / 2;
   hipStream_t s = (hipStream_t)stream;
   const int n_iter_max = cdiv(max_steps, r);
-  const size_t lds_lsa = sizeof(float) * ((size_t)(T + c.lsa_kernel - 1) + D + (size_t)T * c.lsa_filters + T + 32);
+  const int psplit = (P % 1024 == 0) ? 4 : 1;  // context column groups per utterance (pw must be a multiple of 256)
+  MB_REQUIRE((P / psplit) % 256 == 0 && D <= 512 && 512 % D == 0, "taco_decode: unsupported project_dims/decoder_dims for the LSA kernel");
+  const size_t lds_lsa = sizeof(float) * ((size_t)((T + c.lsa_kernel - 1 + 3) & ~3) + D + (size_t)c.lsa_filters * D +
+                                          ((c.lsa_filters * c.lsa_kernel + 3) & ~3) + (size_t)T * c.lsa_filters + ((T + 3) & ~3) + 64 + 8 * 64 * 4);
   MB_REQUIRE(lds_lsa <= 64 * 1024, "taco_decode: text too long for the LSA window in LDS (T=%d)", T);
 
   // zero initial states (tacotron.py:219-230,261; lsa.py:15-19)
@@ -457,7 +508,7 @@ extern "C" int mb_taco_decode(const mb_taco* t, const float* d_memory, const flo
   MB_HIP(hipMemsetAsync(L.h1, 0, sizeof(float) * 2 * B * H, s)); MB_HIP(hipMemsetAsync(L.c1, 0, sizeof(float) * 2 * B * H, s));
   MB_HIP(hipMemsetAsync(L.h2, 0, sizeof(float) * 2 * B * H, s)); MB_HIP(hipMemsetAsync(L.c2, 0, sizeof(float) * 2 * B * H, s));
   MB_HIP(hipMemsetAsync(L.melstep, 0, sizeof(float) * B * r * M, s));  // <GO> frame
-  MB_HIP(hipMemsetAsync(L.cumulative, 0, sizeof(float) * B * T, s));
+  MB_HIP(hipMemsetAsync(L.cumulative, 0, sizeof(float) * 2 * B * T, s));
   MB_HIP(hipMemsetAsync(L.flags, 0, sizeof(int) * 8, s));
   MB_HIP(hipMemsetAsync(d_mel, 0, sizeof(float) * (size_t)B * M * max_steps, s));
   if (d_attn) MB_HIP(hipMemsetAsync(d_attn, 0, sizeof(float) * (size_t)B * n_iter_max * T, s));
@@ -497,11 +548,12 @@ extern "C" int mb_taco_decode(const mb_taco* t, const float* d_memory, const flo
     if ((rc = rnn_launch(EPI_GRU, k, s))) return rc;
     // scores = attn_net(...); context = scores @ encoder_seq  (tacotron.py:101-105)
     LsaK lk;
-    lk.query = ah_n; lk.mem_proj = d_memory_proj; lk.memory = d_memory; lk.chars = d_chars; lk.cumulative = L.cumulative;
+    lk.query = ah_n; lk.mem_proj = d_memory_proj; lk.memory = d_memory; lk.chars = d_chars;
+    lk.cum_in = L.cumulative + (size_t)pp * B * T; lk.cum_out = L.cumulative + (size_t)(pp ^ 1) * B * T; lk.psplit = psplit;
     lk.conv_w = t->lsa_conv_w.p; lk.conv_b = t->lsa_conv_b.p; lk.Lw = t->lsa_L.p; lk.Ww = t->lsa_W.p; lk.Wb = t->lsa_Wb.p;
     lk.vw = t->lsa_v.p; lk.context = cx_n; lk.attn_out = d_attn; lk.T = T; lk.D = D; lk.P = P; lk.Fl = c.lsa_filters;
     lk.Kl = c.lsa_kernel; lk.iter = it; lk.n_iter_max = n_iter_max; lk.skip_flag = done;
-    hipLaunchKernelGGL(lsa_kernel, dim3(B), dim3(512), lds_lsa, s, lk);
+    hipLaunchKernelGGL(lsa_kernel, dim3(B, psplit), dim3(512), lds_lsa, s, lk);
     MB_HIP(hipGetLastError());
     // x = rnn_input([context, attn_hidden])  (tacotron.py:108-109)
     memset(&k, 0, sizeof(k));
