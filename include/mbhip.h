@@ -214,6 +214,8 @@ typedef struct mb_taco_config {
   int n_mels, project_dims, decoder_dims, lstm_dims, max_r, r;
   int postnet_dims, postnet_K, num_highways;
   int lsa_kernel, lsa_filters;
+  /* optional text encoder (tacotron.py:11-44,255): present when has_encoder != 0 */
+  int has_encoder, num_chars, embed_dims, encoder_dims, encoder_K, speaker_dims, style_dims;
 } mb_taco_config;
 typedef struct mb_taco mb_taco;
 int mb_taco_num_weights(const mb_taco_config* cfg);
@@ -239,6 +241,23 @@ int mb_taco_decode(const mb_taco* t, const float* d_memory, const float* d_memor
                    float min_stop_token, const float* d_dropout, uint64_t seed,
                    float* d_mel, float* d_linear, float* d_attn, int* h_n_frames,
                    void* d_workspace, size_t workspace_bytes, mb_stream_t stream);
+
+/* Text encoder + attention-memory assembly (the once-per-chunk front half of
+ * Tacotron.forward, tacotron.py:234-255, minus the tiny GST style network whose
+ * output the caller passes in):
+ *  d_chars   [B][T] int32, d_speaker [B][speaker_dims],
+ *  d_style   [style_batch][style_dims] (style_batch 1 = broadcast, tacotron.py:243-249),
+ *  d_dropout NULL -> on-device RNG(seed); else keep masks [2][B][T][encoder_dims]
+ *            (encoder PreNet, pre_net.py:23,26)
+ *  -> d_memory [B][T][project_dims], d_memory_proj [B][T][decoder_dims].
+ * Encoder weights follow the decoder/postnet list of mb_taco_create:
+ *   encoder.embedding, encoder.pre_net.fc1/fc2 (w,b), encoder.cbhg (bank K x (conv,BN4),
+ *   proj1, proj2, highways, rnn fwd/rev), encoder_proj.weight. */
+size_t mb_taco_encode_workspace_bytes(const mb_taco* t, int batch, int t_text);
+int mb_taco_encode(const mb_taco* t, const int32_t* d_chars, const float* d_speaker, const float* d_style,
+                   int style_batch, int batch, int t_text, const float* d_dropout, uint64_t seed,
+                   float* d_memory, float* d_memory_proj, void* d_workspace, size_t workspace_bytes,
+                   mb_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * 5. monotonic_align.maximum_path

@@ -71,6 +71,8 @@ class TacoConfig(C.Structure):
         ("lstm_dims", C.c_int), ("max_r", C.c_int), ("r", C.c_int),
         ("postnet_dims", C.c_int), ("postnet_K", C.c_int), ("num_highways", C.c_int),
         ("lsa_kernel", C.c_int), ("lsa_filters", C.c_int),
+        ("has_encoder", C.c_int), ("num_chars", C.c_int), ("embed_dims", C.c_int), ("encoder_dims", C.c_int),
+        ("encoder_K", C.c_int), ("speaker_dims", C.c_int), ("style_dims", C.c_int),
     ]
 
 
@@ -113,6 +115,9 @@ SIGNATURES = {
     "mb_taco_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                  C.c_int, C.c_float, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mb_taco_encode_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    "mb_taco_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                 C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mb_maximum_path": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                   C.c_int, C.c_void_p]),
 }

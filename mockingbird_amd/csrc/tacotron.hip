@@ -270,6 +270,191 @@ int make_linear_conv(ConvL* c, const float* w, int c_out, int c_in, const float*
   if (!rc && bias) rc = c->b.upload(bias, c_out);
   return rc;
 }
+
+// CBHG (sublayer/cbhg.py:6-84): conv bank K -> maxpool -> 2 projections -> +residual -> [pre_highway]
+// -> highways -> bidirectional GRU.  Shared by the postnet (in 80, ch 512) and the text encoder
+// (in 256, ch 256).  Activations stay channel-major [B][C][T] end to end.
+struct Cbhg {
+  int cin = 0, ch = 0, K = 0, nh = 0, proj_out = 0;
+  std::vector<ConvL> bank, hw1, hw2;
+  ConvL proj1, proj2, pre_highway, gru_ih_f, gru_ih_b;
+  DevBuf gru_hh_f, gru_hh_b, gru_bhh_f, gru_bhh_b;
+  bool has_pre = false;
+  void release() {
+    for (auto& c : bank) c.release();
+    for (auto& c : hw1) c.release();
+    for (auto& c : hw2) c.release();
+    proj1.release(); proj2.release(); pre_highway.release(); gru_ih_f.release(); gru_ih_b.release();
+    gru_hh_f.release(); gru_hh_b.release(); gru_bhh_f.release(); gru_bhh_b.release();
+  }
+};
+
+void cbhg_shapes(std::vector<size_t>* n, size_t cin, size_t ch, size_t p0, size_t p1, int K, int nh) {
+  auto bn = [&](size_t k) { for (int i = 0; i < 4; ++i) n->push_back(k); };
+  for (int k = 1; k <= K; ++k) { n->push_back(ch * cin * k); bn(ch); }
+  n->push_back(p0 * (ch * K) * 3); bn(p0);
+  n->push_back(p1 * p0 * 3); bn(p1);
+  if (p1 != ch) n->push_back(ch * p1);  // pre_highway (cbhg.py:26-30)
+  for (int i = 0; i < nh; ++i) { n->push_back(ch * ch); n->push_back(ch); n->push_back(ch * ch); n->push_back(ch); }
+  for (int d = 0; d < 2; ++d) { n->push_back(3 * (ch / 2) * ch); n->push_back(3 * (ch / 2) * (ch / 2)); n->push_back(3 * (ch / 2)); n->push_back(3 * (ch / 2)); }
+}
+
+int make_cbhg(Cbhg* c, const float* const* hw, int* pix, int cin, int ch, int p0, int p1, int K, int nh) {
+  int ix = *pix, rc = MB_OK;
+  c->cin = cin; c->ch = ch; c->K = K; c->nh = nh; c->proj_out = p1;
+#define RC(x) do { if (!rc) rc = (x); } while (0)
+  c->bank.resize(K);
+  for (int k = 1; k <= K; ++k) { RC(make_bnconv(&c->bank[k - 1], hw[ix], ch, cin, k, hw + ix + 1, true)); ix += 5; }
+  RC(make_bnconv(&c->proj1, hw[ix], p0, ch * K, 3, hw + ix + 1, true)); ix += 5;
+  RC(make_bnconv(&c->proj2, hw[ix], p1, p0, 3, hw + ix + 1, false)); ix += 5;
+  c->has_pre = p1 != ch;
+  if (c->has_pre) { RC(make_linear_conv(&c->pre_highway, hw[ix], ch, p1, nullptr)); ix += 1; }
+  c->hw1.resize(nh); c->hw2.resize(nh);
+  for (int i = 0; i < nh; ++i) {
+    RC(make_linear_conv(&c->hw1[i], hw[ix], ch, ch, hw[ix + 1]));
+    RC(make_linear_conv(&c->hw2[i], hw[ix + 2], ch, ch, hw[ix + 3]));
+    ix += 4;
+  }
+  const int Hg = ch / 2;
+  std::vector<float> rows, packed;
+  for (int d = 0; d < 2; ++d) {
+    RC(make_linear_conv(d ? &c->gru_ih_b : &c->gru_ih_f, hw[ix], 3 * Hg, ch, hw[ix + 2]));  // W_ih.x + b_ih for all t
+    cell_rows(hw[ix + 1], 0, 0, hw[ix + 1], Hg, Hg, 3, &rows);                                // hidden part only
+    pack_rowtile(rows.data(), 3 * Hg, Hg, 3, &packed);
+    RC((d ? c->gru_hh_b : c->gru_hh_f).upload(packed.data(), packed.size()));
+    RC((d ? c->gru_bhh_b : c->gru_bhh_f).upload(hw[ix + 3], 3 * Hg));
+    ix += 4;
+  }
+#undef RC
+  *pix = ix;
+  return rc;
+}
+
+struct CbhgWs { float *bank, *pj1, *pj2, *hwa, *hwb, *gate, *ihf, *ihb, *gh, *seq; };
+
+void cbhg_take(Arena& ar, const Cbhg& c, size_t B, size_t F, CbhgWs* w) {
+  const size_t ch = c.ch;
+  w->bank = ar.take<float>(B * ch * c.K * F);
+  w->pj1 = ar.take<float>(B * std::max<size_t>(ch, c.proj1.c_out) * F);
+  w->pj2 = ar.take<float>(B * std::max<size_t>(c.proj_out, 1) * F);
+  w->hwa = ar.take<float>(B * ch * F); w->hwb = ar.take<float>(B * ch * F); w->gate = ar.take<float>(B * ch * F);
+  w->ihf = ar.take<float>(B * F * 3 * (ch / 2)); w->ihb = ar.take<float>(B * F * 3 * (ch / 2));
+  w->gh = ar.take<float>(4 * B * (ch / 2));
+  w->seq = ar.take<float>(B * ch * F);
+}
+
+int run_conv(const ConvL& c, const float* x, int batch, int t, float* y, long long y_bstride, int in_act,
+             int out_act, const float* res, const float* gate, int transpose_out, hipStream_t s);
+
+// x [B][cin][F] -> ws.seq [B][ch][F] (forward half in channels [0, ch/2), backward in [ch/2, ch))
+int cbhg_forward(const Cbhg& c, const float* x, int B, int F, const CbhgWs& L, hipStream_t s) {
+  int rc = MB_OK;
+  const int C = c.ch, Hg = C / 2;
+#define RC(x) do { if (!rc) rc = (x); } while (0)
+  const long long bank_bs = (long long)C * c.K * F;
+  for (int k = 0; k < c.K; ++k)  // conv -> ReLU -> BN, concatenated on the channel axis (cbhg.py:53-59)
+    RC(run_conv(c.bank[k], x, B, F, L.bank + (size_t)k * C * F, bank_bs, 0, 1, nullptr, nullptr, 0, s));
+  {  // maxpool(2,1,1)[:F] (cbhg.py:61-62) fused into conv_project1's input staging
+    mb_conv1d_args a;
+    memset(&a, 0, sizeof(a));
+    const ConvL& cv = c.proj1;
+    a.d_x = L.bank; a.d_wpacked = cv.w.p; a.d_y = L.pj1; a.d_post_scale = cv.ps.p; a.d_post_shift = cv.pt.p;
+    a.x_bstride = bank_bs; a.y_bstride = (long long)cv.c_out * F; a.batch = B; a.c_in = cv.c_in; a.c_out = cv.c_out;
+    a.t_in = F; a.t_out = F; a.ksize = 3; a.dilation = 1; a.pad = 1; a.up = 1; a.in_act = 2; a.out_act = 1;
+    RC(mb_conv1d(&a, (mb_stream_t)s));
+  }
+  RC(run_conv(c.proj2, L.pj1, B, F, L.pj2, 0, 0, 0, x, nullptr, 0, s));  // BN folded, + residual (cbhg.py:66-69)
+  float* hx = L.hwa; float* hy = L.hwb;
+  const float* hin = L.pj2;
+  if (c.has_pre) { RC(run_conv(c.pre_highway, L.pj2, B, F, L.hwa, 0, 0, 0, nullptr, nullptr, 0, s)); hin = L.hwa; hx = L.hwa; hy = L.hwb; }
+  for (int i = 0; i < c.nh; ++i) {  // highway_network.py:12-17
+    float* dst = (hin == L.hwa) ? L.hwb : L.hwa;
+    RC(run_conv(c.hw2[i], hin, B, F, L.gate, 0, 0, 3, nullptr, nullptr, 0, s));   // g = sigmoid(W2 x)
+    RC(run_conv(c.hw1[i], hin, B, F, dst, 0, 0, 4, hin, L.gate, 0, s));           // g*relu(W1 x) + (1-g)*x
+    hin = dst;
+  }
+  (void)hx; (void)hy;
+  // bidirectional GRU (cbhg.py:76-77): W_ih.x + b_ih for every t as one GEMM per direction (time-major table)
+  RC(run_conv(c.gru_ih_f, hin, B, F, L.ihf, (long long)F * 3 * Hg, 0, 0, nullptr, nullptr, 1, s));
+  RC(run_conv(c.gru_ih_b, hin, B, F, L.ihb, (long long)F * 3 * Hg, 0, 0, nullptr, nullptr, 1, s));
+  if (!rc) {
+    MB_HIP(hipMemsetAsync(L.gh, 0, sizeof(float) * 4 * B * Hg, s));
+    for (int st = 0; st < F && !rc; ++st) {
+      for (int d = 0; d < 2 && !rc; ++d) {
+        const int tt = d ? F - 1 - st : st;
+        float* hp = L.gh + ((size_t)d * 2 + (st & 1)) * B * Hg;
+        float* hn = L.gh + ((size_t)d * 2 + ((st & 1) ^ 1)) * B * Hg;
+        RnnK k;
+        memset(&k, 0, sizeof(k));
+        k.w = d ? c.gru_hh_b.p : c.gru_hh_f.p; k.nseg = 1; k.nkb_total = Hg / 16; k.seg[0] = {hp, Hg, Hg / 16, 1};
+        k.N = B; k.units = Hg; k.biasH = d ? c.gru_bhh_b.p : c.gru_bhh_f.p;
+        k.pre_table = d ? L.ihb : L.ihf; k.pre_stride = 3 * Hg; k.pre_base_row = tt; k.pre_n_stride = F;
+        k.h_prev = hp; k.h_out = hn;
+        k.seq_out = L.seq; k.seq_n_stride = (long long)C * F; k.seq_j_stride = F; k.seq_off = (long long)d * Hg * F + tt;
+        rc = rnn_launch(EPI_GRU, k, s);
+      }
+    }
+  }
+#undef RC
+  return rc;
+}
+
+// ---- text-encoder helpers (tacotron.py:31-44, 171-197, 255) ----
+// xe[b][c][t] = embedding[chars[b][t]][c]   (channel-major for the conv kernel)
+__global__ void embed_gather_kernel(const int* __restrict__ chars, const float* __restrict__ emb, float* __restrict__ xe,
+                                    int T, int E, int num_chars) {
+  const int b = blockIdx.y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < E * T; i += gridDim.x * blockDim.x) {
+    const int c = i / T, t = i - c * T;
+    int id = chars[(size_t)b * T + t];
+    id = id < 0 ? 0 : (id >= num_chars ? num_chars - 1 : id);
+    xe[(size_t)b * E * T + i] = emb[(size_t)id * E + c];
+  }
+}
+
+// always-on PreNet dropout (pre_net.py:23,26) on y [B][C][T]; masks (if injected) are [B][T][C]
+__global__ void dropout_cm_kernel(float* __restrict__ y, const float* __restrict__ mask, int C, int T,
+                                  unsigned long long seed, int layer) {
+  const int b = blockIdx.y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < C * T; i += gridDim.x * blockDim.x) {
+    const int c = i / T, t = i - c * T;
+    float keep;
+    if (mask) keep = mask[((size_t)b * T + t) * C + c];
+    else {
+      uint32_t r[4];
+      philox4x32((uint32_t)(b * T + t), (uint32_t)(c >> 2), (uint32_t)layer, 0x454e4344u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+      keep = (r[c & 3] & 0x80000000u) ? 1.f : 0.f;
+    }
+    y[(size_t)b * C * T + i] *= keep * 2.f;
+  }
+}
+
+// memory[b][t] = [enc_seq[b][:, t] | speaker[b] | style[b]]; projres[b][t][d] = Wp[d][Ce:] . [speaker; style]
+__global__ __launch_bounds__(256) void assemble_memory_kernel(const float* __restrict__ seq, const float* __restrict__ spk,
+                                                              const float* __restrict__ style, int style_batch,
+                                                              const float* __restrict__ Wp, float* __restrict__ memory,
+                                                              float* __restrict__ projres, int T, int Ce, int S, int E, int D) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // tail[S+E] | pb[D]
+  const int b = blockIdx.x, tid = threadIdx.x, P = Ce + S + E;
+  float* tail = sm;
+  float* pb = sm + S + E;
+  const float* st = style + (size_t)(style_batch > 1 ? b : 0) * E;
+  for (int i = tid; i < S; i += 256) tail[i] = spk[(size_t)b * S + i];
+  for (int i = tid; i < E; i += 256) tail[S + i] = st[i];
+  __syncthreads();
+  for (int d = tid; d < D; d += 256) {
+    const float* wr = Wp + (size_t)d * P + Ce;
+    float acc = 0.f;
+    for (int k = 0; k < S + E; ++k) acc += wr[k] * tail[k];
+    pb[d] = acc;
+  }
+  __syncthreads();
+  for (int i = tid; i < T * P; i += 256) {
+    const int t = i / P, p = i - t * P;
+    memory[((size_t)b * T + t) * P + p] = p < Ce ? seq[((size_t)b * Ce + p) * T + t] : tail[p - Ce];
+  }
+  for (int i = tid; i < T * D; i += 256) projres[(size_t)b * T * D + i] = pb[i % D];
+}
 }  // namespace
 
 struct mb_taco {
@@ -282,12 +467,13 @@ struct mb_taco {
   DevBuf l1_w, l1_bih, l1_bhh, l2_w, l2_bih, l2_bhh;
   DevBuf mel_w, stop_w, stop_b;
   // postnet
-  std::vector<ConvL> bank;
-  ConvL proj1, proj2, pre_highway, post_proj;
-  std::vector<ConvL> hw1, hw2;
-  ConvL gru_ih_f, gru_ih_b;
-  DevBuf gru_hh_f, gru_hh_b, gru_bhh_f, gru_bhh_b;
-  bool has_pre_highway = false;
+  Cbhg post;
+  ConvL post_proj;
+  // text encoder (optional: cfg.has_encoder)
+  DevBuf emb;
+  ConvL enc_fc1, enc_fc2, enc_proj;
+  DevBuf enc_proj_full;  // encoder_proj.weight [D][P] (speaker/style columns used by assemble_memory)
+  Cbhg enc;
 };
 
 static int taco_shapes(const mb_taco_config* c, std::vector<size_t>* n) {
@@ -298,7 +484,6 @@ static int taco_shapes(const mb_taco_config* c, std::vector<size_t>* n) {
   MB_REQUIRE(c->postnet_dims % 32 == 0 && c->postnet_K >= 1 && c->postnet_K <= 16, "taco: postnet dims");
   const size_t M = c->n_mels, P = c->project_dims, D = c->decoder_dims, H = c->lstm_dims, C = c->postnet_dims;
   n->clear();
-  auto bn = [&](size_t k) { for (int i = 0; i < 4; ++i) n->push_back(k); };
   n->push_back(2 * D * M); n->push_back(2 * D); n->push_back(2 * D * 2 * D); n->push_back(2 * D);  // prenet
   n->push_back((size_t)c->lsa_filters * c->lsa_kernel); n->push_back(c->lsa_filters);               // attn_net.conv
   n->push_back(D * c->lsa_filters); n->push_back(D * D); n->push_back(D); n->push_back(D);          // L, W.w, W.b, v
@@ -307,13 +492,18 @@ static int taco_shapes(const mb_taco_config* c, std::vector<size_t>* n) {
   for (int i = 0; i < 2; ++i) { n->push_back(4 * H * H); n->push_back(4 * H * H); n->push_back(4 * H); n->push_back(4 * H); }
   n->push_back(M * c->max_r * H);                                                                    // mel_proj
   n->push_back(H + P); n->push_back(1);                                                              // stop_proj
-  for (int k = 1; k <= c->postnet_K; ++k) { n->push_back(C * M * k); bn(C); }                        // conv bank
-  n->push_back(C * (C * c->postnet_K) * 3); bn(C);                                                   // conv_project1
-  n->push_back(M * C * 3); bn(M);                                                                    // conv_project2
-  n->push_back(C * M);                                                                               // pre_highway
-  for (int i = 0; i < c->num_highways; ++i) { n->push_back(C * C); n->push_back(C); n->push_back(C * C); n->push_back(C); }
-  for (int d = 0; d < 2; ++d) { n->push_back(3 * (C / 2) * C); n->push_back(3 * (C / 2) * (C / 2)); n->push_back(3 * (C / 2)); n->push_back(3 * (C / 2)); }
+  cbhg_shapes(n, M, C, C, M, c->postnet_K, c->num_highways);                                         // postnet
   n->push_back(M * C);                                                                               // post_proj
+  if (c->has_encoder) {
+    MB_REQUIRE(c->encoder_dims + c->speaker_dims + c->style_dims == c->project_dims,
+               "taco: encoder_dims + speaker_dims + style_dims != project_dims");
+    MB_REQUIRE(c->encoder_dims % 32 == 0 && c->embed_dims % 8 == 0 && c->num_chars > 0, "taco: encoder dims");
+    const size_t Ce = c->encoder_dims, Em = c->embed_dims;
+    n->push_back((size_t)c->num_chars * Em);
+    n->push_back(Ce * Em); n->push_back(Ce); n->push_back(Ce * Ce); n->push_back(Ce);               // encoder.pre_net
+    cbhg_shapes(n, Ce, Ce, Ce, Ce, c->encoder_K, c->num_highways);                                   // encoder.cbhg
+    n->push_back(D * P);                                                                             // encoder_proj
+  }
   return MB_OK;
 }
 
@@ -376,31 +566,24 @@ extern "C" int mb_taco_create(const mb_taco_config* cfg, const float* const* hw,
   }
   RC(t->stop_w.upload(hw[ix], H + P)); RC(t->stop_b.upload(hw[ix + 1], 1));
   ix += 2;
-  // postnet CBHG
-  t->bank.resize(cfg->postnet_K);
-  for (int k = 1; k <= cfg->postnet_K; ++k) { RC(make_bnconv(&t->bank[k - 1], hw[ix], C, M, k, hw + ix + 1, true)); ix += 5; }
-  RC(make_bnconv(&t->proj1, hw[ix], C, C * cfg->postnet_K, 3, hw + ix + 1, true)); ix += 5;
-  RC(make_bnconv(&t->proj2, hw[ix], M, C, 3, hw + ix + 1, false)); ix += 5;
-  RC(make_linear_conv(&t->pre_highway, hw[ix], C, M, nullptr)); ix += 1;
-  t->has_pre_highway = true;
-  t->hw1.resize(cfg->num_highways); t->hw2.resize(cfg->num_highways);
-  for (int i = 0; i < cfg->num_highways; ++i) {
-    RC(make_linear_conv(&t->hw1[i], hw[ix], C, C, hw[ix + 1]));
-    RC(make_linear_conv(&t->hw2[i], hw[ix + 2], C, C, hw[ix + 3]));
-    ix += 4;
-  }
-  const int Hg = C / 2;
-  for (int d = 0; d < 2; ++d) {
-    ConvL& ih = d ? t->gru_ih_b : t->gru_ih_f;
-    RC(make_linear_conv(&ih, hw[ix], 3 * Hg, C, hw[ix + 2]));  // W_ih.x + b_ih for all t
-    std::vector<float> none;
-    cell_rows(hw[ix + 1], 0, 0, hw[ix + 1], Hg, Hg, 3, &rows);  // hidden part only
-    pack_rowtile(rows.data(), 3 * Hg, Hg, 3, &packed);
-    RC((d ? t->gru_hh_b : t->gru_hh_f).upload(packed.data(), packed.size()));
-    RC((d ? t->gru_bhh_b : t->gru_bhh_f).upload(hw[ix + 3], 3 * Hg));
-    ix += 4;
-  }
+  // postnet CBHG + post_proj
+  RC(make_cbhg(&t->post, hw, &ix, M, C, C, M, cfg->postnet_K, cfg->num_highways));
   RC(make_linear_conv(&t->post_proj, hw[ix], M, C, nullptr)); ix += 1;
+  if (cfg->has_encoder && !rc) {
+    const int Ce = cfg->encoder_dims, Em = cfg->embed_dims;
+    RC(t->emb.upload(hw[ix], (size_t)cfg->num_chars * Em)); ix += 1;
+    RC(make_linear_conv(&t->enc_fc1, hw[ix], Ce, Em, hw[ix + 1]));
+    RC(make_linear_conv(&t->enc_fc2, hw[ix + 2], Ce, Ce, hw[ix + 3]));
+    ix += 4;
+    RC(make_cbhg(&t->enc, hw, &ix, Ce, Ce, Ce, Ce, cfg->encoder_K, cfg->num_highways));
+    {  // encoder_proj: columns [0, Ce) as a 1x1 conv over the encoder sequence; the rest per utterance
+      std::vector<float> we((size_t)D * Ce);
+      for (int d = 0; d < D; ++d) memcpy(&we[(size_t)d * Ce], hw[ix] + (size_t)d * P, sizeof(float) * Ce);
+      RC(make_linear_conv(&t->enc_proj, we.data(), D, Ce, nullptr));
+      RC(t->enc_proj_full.upload(hw[ix], (size_t)D * P));
+      ix += 1;
+    }
+  }
 #undef RC
   if (rc) { mb_taco_destroy(t); return rc; }
   *out = t;
@@ -412,13 +595,10 @@ extern "C" void mb_taco_destroy(mb_taco* t) {
   DevBuf* bs[] = {&t->pre1_w, &t->pre1_b, &t->pre2_w, &t->pre2_b, &t->lsa_conv_w, &t->lsa_conv_b, &t->lsa_L, &t->lsa_W,
                   &t->lsa_Wb, &t->lsa_v, &t->attn_w, &t->attn_bih, &t->attn_bhh, &t->rin_w, &t->rin_b, &t->l1_w,
                   &t->l1_bih, &t->l1_bhh, &t->l2_w, &t->l2_bih, &t->l2_bhh, &t->mel_w, &t->stop_w, &t->stop_b,
-                  &t->gru_hh_f, &t->gru_hh_b, &t->gru_bhh_f, &t->gru_bhh_b};
+                  &t->emb, &t->enc_proj_full};
   for (DevBuf* b : bs) b->release();
-  for (auto& c : t->bank) c.release();
-  for (auto& c : t->hw1) c.release();
-  for (auto& c : t->hw2) c.release();
-  t->proj1.release(); t->proj2.release(); t->pre_highway.release(); t->post_proj.release();
-  t->gru_ih_f.release(); t->gru_ih_b.release();
+  t->post.release(); t->post_proj.release(); t->enc.release();
+  t->enc_fc1.release(); t->enc_fc2.release(); t->enc_proj.release();
   delete t;
 }
 
@@ -427,7 +607,8 @@ struct TacoLayout {
   float *p1, *p2, *attn_h, *context, *x, *x1, *x2, *h1, *c1, *h2, *c2, *melstep, *cumulative, *stop;
   int* flags;  // [0] done, [1] n_frames, [2] arrive
   // postnet
-  float *melc, *bank, *pj1, *pj2, *hwa, *hwb, *gate, *ihf, *ihb, *gh, *seq, *linc;
+  float *melc, *linc;
+  CbhgWs cb;
   size_t bytes;
 };
 }  // namespace
@@ -447,14 +628,9 @@ static void taco_layout(const mb_taco* t, int B, int T, int max_steps, void* bas
   L->stop = ar.take<float>(B);
   L->flags = ar.take<int>(8);
   L->melc = ar.take<float>(B * M * F);
-  L->bank = ar.take<float>(B * C * c.postnet_K * F);
-  L->pj1 = ar.take<float>(B * C * F);
-  L->pj2 = ar.take<float>(B * M * F);
-  L->hwa = ar.take<float>(B * C * F); L->hwb = ar.take<float>(B * C * F); L->gate = ar.take<float>(B * C * F);
-  L->ihf = ar.take<float>(B * F * 3 * (C / 2)); L->ihb = ar.take<float>(B * F * 3 * (C / 2));
-  L->gh = ar.take<float>(4 * B * (C / 2));
-  L->seq = ar.take<float>(B * C * F);
   L->linc = ar.take<float>(B * M * F);
+  cbhg_take(ar, t->post, B, F, &L->cb);
+  (void)C;
   L->bytes = ar.off + 256;
 }
 
@@ -465,8 +641,9 @@ extern "C" size_t mb_taco_workspace_bytes(const mb_taco* t, int batch, int t_tex
   return L.bytes;
 }
 
-static int run_conv(const ConvL& c, const float* x, int batch, int t, float* y, long long y_bstride, int in_act,
-                    int out_act, const float* res, const float* gate, int transpose_out, hipStream_t s) {
+namespace {
+int run_conv(const ConvL& c, const float* x, int batch, int t, float* y, long long y_bstride, int in_act,
+             int out_act, const float* res, const float* gate, int transpose_out, hipStream_t s) {
   mb_conv1d_args a;
   memset(&a, 0, sizeof(a));
   a.d_x = x; a.d_wpacked = c.w.p; a.d_bias = c.b.p; a.d_res = res; a.d_y = y; a.d_gate = gate;
@@ -478,6 +655,7 @@ static int run_conv(const ConvL& c, const float* x, int batch, int t, float* y, 
   a.in_act = in_act; a.out_act = out_act; a.transpose_out = transpose_out;
   return mb_conv1d(&a, (mb_stream_t)s);
 }
+}  // namespace
 
 extern "C" int mb_taco_decode(const mb_taco* t, const float* d_memory, const float* d_memory_proj,
                               const int32_t* d_chars, int batch, int t_text, int max_steps, float min_stop_token,
@@ -493,7 +671,6 @@ extern "C" int mb_taco_decode(const mb_taco* t, const float* d_memory, const flo
   }
   const mb_taco_config& c = t->cfg;
   const int B = batch, T = t_text, D = c.decoder_dims, P = c.project_dims, H = c.lstm_dims, M = c.n_mels, r = c.r;
-  const int C = c.postnet_dims, Hg = C / 2;
   hipStream_t s = (hipStream_t)stream;
   const int n_iter_max = cdiv(max_steps, r);
   const int psplit = (P % 1024 == 0) ? 4 : 1;  // context column groups per utterance (pw must be a multiple of 256)
@@ -601,53 +778,75 @@ extern "C" int mb_taco_decode(const mb_taco* t, const float* d_memory, const flo
                           hipMemcpyDeviceToDevice, s));
   int rc = MB_OK;
 #define RC(x) do { if (!rc) rc = (x); } while (0)
-  const long long bank_bs = (long long)C * c.postnet_K * F;
-  for (int k = 0; k < c.postnet_K; ++k)  // conv -> ReLU -> BN, concatenated on the channel axis
-    RC(run_conv(t->bank[k], L.melc, B, F, L.bank + (size_t)k * C * F, bank_bs, 0, 1, nullptr, nullptr, 0, s));
-  {  // maxpool(2,1,1)[:F] fused into conv_project1's input staging
-    mb_conv1d_args a;
-    memset(&a, 0, sizeof(a));
-    const ConvL& cv = t->proj1;
-    a.d_x = L.bank; a.d_wpacked = cv.w.p; a.d_y = L.pj1; a.d_post_scale = cv.ps.p; a.d_post_shift = cv.pt.p;
-    a.x_bstride = bank_bs; a.y_bstride = (long long)C * F; a.batch = B; a.c_in = cv.c_in; a.c_out = C; a.t_in = F; a.t_out = F;
-    a.ksize = 3; a.dilation = 1; a.pad = 1; a.up = 1; a.in_act = 2; a.out_act = 1;
-    RC(mb_conv1d(&a, (mb_stream_t)s));
-  }
-  RC(run_conv(t->proj2, L.pj1, B, F, L.pj2, 0, 0, 0, L.melc, nullptr, 0, s));       // BN folded, + residual
-  RC(run_conv(t->pre_highway, L.pj2, B, F, L.hwa, 0, 0, 0, nullptr, nullptr, 0, s));
-  float* hx = L.hwa; float* hy = L.hwb;
-  for (int i = 0; i < c.num_highways; ++i) {
-    RC(run_conv(t->hw2[i], hx, B, F, L.gate, 0, 0, 3, nullptr, nullptr, 0, s));       // g = sigmoid(W2 x)
-    RC(run_conv(t->hw1[i], hx, B, F, hy, 0, 0, 4, hx, L.gate, 0, s));                  // g*relu(W1 x) + (1-g)*x
-    std::swap(hx, hy);
-  }
-  // bidirectional GRU: W_ih.x + b_ih for every t as one GEMM per direction (time-major table)
-  RC(run_conv(t->gru_ih_f, hx, B, F, L.ihf, (long long)F * 3 * Hg, 0, 0, nullptr, nullptr, 1, s));
-  RC(run_conv(t->gru_ih_b, hx, B, F, L.ihb, (long long)F * 3 * Hg, 0, 0, nullptr, nullptr, 1, s));
-  if (!rc) {
-    MB_HIP(hipMemsetAsync(L.gh, 0, sizeof(float) * 4 * B * Hg, s));
-    for (int st = 0; st < F && !rc; ++st) {
-      for (int d = 0; d < 2 && !rc; ++d) {
-        const int tt = d ? F - 1 - st : st;
-        float* hp = L.gh + ((size_t)d * 2 + (st & 1)) * B * Hg;
-        float* hn = L.gh + ((size_t)d * 2 + ((st & 1) ^ 1)) * B * Hg;
-        RnnK k;
-        memset(&k, 0, sizeof(k));
-        k.w = d ? t->gru_hh_b.p : t->gru_hh_f.p; k.nseg = 1; k.nkb_total = Hg / 16; k.seg[0] = {hp, Hg, Hg / 16, 1};
-        k.N = B; k.units = Hg; k.biasH = d ? t->gru_bhh_b.p : t->gru_bhh_f.p;
-        k.pre_table = d ? L.ihb : L.ihf; k.pre_stride = 3 * Hg; k.pre_base_row = tt; k.pre_n_stride = F;
-        k.h_prev = hp; k.h_out = hn;
-        k.seq_out = L.seq; k.seq_n_stride = (long long)C * F; k.seq_j_stride = F; k.seq_off = (long long)d * Hg * F + tt;
-        rc = rnn_launch(EPI_GRU, k, s);
-      }
-    }
-  }
-  RC(run_conv(t->post_proj, L.seq, B, F, L.linc, 0, 0, 0, nullptr, nullptr, 0, s));
+  RC(cbhg_forward(t->post, L.melc, B, F, L.cb, s));
+  RC(run_conv(t->post_proj, L.cb.seq, B, F, L.linc, 0, 0, 0, nullptr, nullptr, 0, s));
   if (!rc) {
     MB_HIP(hipMemsetAsync(d_linear, 0, sizeof(float) * (size_t)B * M * max_steps, s));
     MB_HIP(hipMemcpy2DAsync(d_linear, sizeof(float) * max_steps, L.linc, sizeof(float) * F, sizeof(float) * F, (size_t)B * M,
                             hipMemcpyDeviceToDevice, s));
   }
+#undef RC
+  return rc;
+}
+
+namespace {
+struct EncLayout { float *xe, *p1, *p2, *projres; CbhgWs cb; size_t bytes; };
+void enc_layout(const mb_taco* t, int B, int T, void* base, EncLayout* L) {
+  const mb_taco_config& c = t->cfg;
+  Arena ar(base, (size_t)-1);
+  L->xe = ar.take<float>((size_t)B * c.embed_dims * T);
+  L->p1 = ar.take<float>((size_t)B * c.encoder_dims * T);
+  L->p2 = ar.take<float>((size_t)B * c.encoder_dims * T);
+  L->projres = ar.take<float>((size_t)B * T * c.decoder_dims);
+  cbhg_take(ar, t->enc, B, T, &L->cb);
+  L->bytes = ar.off + 256;
+}
+}  // namespace
+
+extern "C" size_t mb_taco_encode_workspace_bytes(const mb_taco* t, int batch, int t_text) {
+  if (!t || !t->cfg.has_encoder || batch <= 0 || t_text <= 0) return 0;
+  EncLayout L;
+  enc_layout(t, batch, t_text, nullptr, &L);
+  return L.bytes;
+}
+
+extern "C" int mb_taco_encode(const mb_taco* t, const int32_t* d_chars, const float* d_speaker, const float* d_style,
+                              int style_batch, int batch, int t_text, const float* d_dropout, uint64_t seed,
+                              float* d_memory, float* d_memory_proj, void* d_workspace, size_t workspace_bytes,
+                              mb_stream_t stream) {
+  MB_REQUIRE(t && d_chars && d_speaker && d_style && d_memory && d_memory_proj, "taco_encode: null pointer");
+  MB_REQUIRE(t->cfg.has_encoder, "taco_encode: handle was created without encoder weights");
+  MB_REQUIRE(batch > 0 && t_text > 0 && (style_batch == 1 || style_batch == batch), "taco_encode: bad shape");
+  EncLayout L;
+  enc_layout(t, batch, t_text, d_workspace, &L);
+  if (!d_workspace || workspace_bytes < L.bytes) {
+    set_error("taco_encode: workspace %zu B < required %zu B", workspace_bytes, L.bytes);
+    return MB_ENOMEM;
+  }
+  const mb_taco_config& c = t->cfg;
+  const int B = batch, T = t_text, Ce = c.encoder_dims, Em = c.embed_dims, D = c.decoder_dims;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = MB_OK;
+#define RC(x) do { if (!rc) rc = (x); } while (0)
+  // x = embedding(texts); x = pre_net(x)  (tacotron.py:41-42, pre_net.py:21-26)
+  hipLaunchKernelGGL(embed_gather_kernel, dim3(std::min(cdiv(Em * T, 256), 1024), B), dim3(256), 0, s, (const int*)d_chars,
+                     t->emb.p, L.xe, T, Em, c.num_chars);
+  RC(run_conv(t->enc_fc1, L.xe, B, T, L.p1, 0, 0, 1, nullptr, nullptr, 0, s));
+  hipLaunchKernelGGL(dropout_cm_kernel, dim3(std::min(cdiv(Ce * T, 256), 1024), B), dim3(256), 0, s, L.p1,
+                     d_dropout ? d_dropout : nullptr, Ce, T, (unsigned long long)seed, 0);
+  RC(run_conv(t->enc_fc2, L.p1, B, T, L.p2, 0, 0, 1, nullptr, nullptr, 0, s));
+  hipLaunchKernelGGL(dropout_cm_kernel, dim3(std::min(cdiv(Ce * T, 256), 1024), B), dim3(256), 0, s, L.p2,
+                     d_dropout ? d_dropout + (size_t)B * T * Ce : nullptr, Ce, T, (unsigned long long)seed, 1);
+  // x = cbhg(x)  (tacotron.py:43-44)
+  RC(cbhg_forward(t->enc, L.p2, B, T, L.cb, s));
+  // speaker + style concat (tacotron.py:171-197, 253) and encoder_proj (:255)
+  if (!rc) {
+    const size_t lds = sizeof(float) * (c.speaker_dims + c.style_dims + D);
+    hipLaunchKernelGGL(assemble_memory_kernel, dim3(B), dim3(256), lds, s, L.cb.seq, d_speaker, d_style, style_batch,
+                       t->enc_proj_full.p, d_memory, L.projres, T, Ce, c.speaker_dims, c.style_dims, D);
+    MB_HIP(hipGetLastError());
+  }
+  RC(run_conv(t->enc_proj, L.cb.seq, B, T, d_memory_proj, (long long)T * D, 0, 0, L.projres, nullptr, 1, s));
 #undef RC
   return rc;
 }

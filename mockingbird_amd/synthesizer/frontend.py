@@ -1,47 +1,9 @@
-"""Once-per-chunk front half of Tacotron.forward (tacotron.py:234-255): text encoder, speaker
-embedding tiling, GST style embedding, encoder_proj.  It runs once per batch, outside the
-autoregressive hot loop; SURVEY.md section 8(a) T3/T4 keep it on PyTorch-ROCm tensor ops for the first
-pass (section 8(f) rank 1 moves it onto the HIP conv/GRU kernels).  Produces the attention memory the
-HIP decoder (mb_taco_decode) consumes."""
+"""GST style embedding (tacotron.py:243-252, global_style_token.py): a [1|B, E] vector per chunk
+from ten 64-d tokens / a 1-step GRU -- a few kFLOP, computed with tensor ops on the device and
+handed to the HIP text encoder (mb_taco_encode), which does everything else of
+tacotron.py:234-255 (embedding, PreNet, encoder CBHG, speaker/style concat, encoder_proj)."""
 import torch
 import torch.nn.functional as F
-
-
-def _dropout(x, p, masks):
-    if masks is None:
-        return F.dropout(x, p, training=True)  # always on, pre_net.py:23,26
-    m = masks.pop(0).to(x.device)
-    return x * m * (1.0 / (1.0 - p))
-
-
-def _prenet(w, p, x, drop, masks):
-    x = _dropout(F.relu(F.linear(x, w[p + ".fc1.weight"], w[p + ".fc1.bias"])), drop, masks)
-    return _dropout(F.relu(F.linear(x, w[p + ".fc2.weight"], w[p + ".fc2.bias"])), drop, masks)
-
-
-def _bnconv(w, p, x, k, relu=True):
-    x = F.conv1d(x, w[p + ".conv.weight"], None, padding=k // 2)
-    x = F.relu(x) if relu else x
-    return F.batch_norm(x, w[p + ".bnorm.running_mean"], w[p + ".bnorm.running_var"], w[p + ".bnorm.weight"],
-                        w[p + ".bnorm.bias"], False, 0.0, 1e-5)
-
-
-def _cbhg(w, p, x, K, num_highways):
-    residual, T = x, x.size(-1)
-    x = torch.cat([_bnconv(w, f"{p}.conv1d_bank.{k - 1}", x, k)[:, :, :T] for k in range(1, K + 1)], dim=1)
-    x = F.max_pool1d(x, kernel_size=2, stride=1, padding=1)[:, :, :T]
-    x = _bnconv(w, p + ".conv_project2", _bnconv(w, p + ".conv_project1", x, 3), 3, relu=False)
-    x = (x + residual).transpose(1, 2)
-    if p + ".pre_highway.weight" in w:
-        x = F.linear(x, w[p + ".pre_highway.weight"])
-    for i in range(num_highways):
-        q = f"{p}.highways.{i}"
-        g = torch.sigmoid(F.linear(x, w[q + ".W2.weight"], w[q + ".W2.bias"]))
-        x = g * F.relu(F.linear(x, w[q + ".W1.weight"], w[q + ".W1.bias"])) + (1. - g) * x
-    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
-    flat = [w[f"{p}.rnn.{n}"] for n in names] + [w[f"{p}.rnn.{n}_reverse"] for n in names]
-    h0 = torch.zeros(2, x.size(0), flat[1].shape[1], device=x.device)
-    return torch.gru(x, h0, flat, True, 1, 0.0, False, True, True)[0]
 
 
 def _mha(w, p, query, key, key_dim, heads, units):
@@ -81,14 +43,9 @@ def _style_embed(w, hp, spk, style_idx):
 
 
 @torch.no_grad()
-def encoder_memory(w, hp, chars, spk, style_idx, masks=None):
-    """-> (encoder_seq [B,T,P], encoder_seq_proj [B,T,D]) on chars.device."""
-    x = F.embedding(chars, w["encoder.embedding.weight"])
-    x = _prenet(w, "encoder.pre_net", x, hp.tts_dropout, masks).transpose(1, 2)
-    x = _cbhg(w, "encoder.cbhg", x, hp.tts_encoder_K, hp.tts_num_highways)
-    B, T = x.size(0), x.size(1)
-    e = spk.repeat_interleave(T, dim=1).reshape(B, spk.size(1), T).transpose(1, 2)  # tacotron.py:187-193
-    x = torch.cat((x, e), 2)
-    if "gst.stl.embed" in w:
-        x = torch.cat([x, _style_embed(w, hp, spk, style_idx).expand(B, T, -1)], dim=-1)
-    return x.contiguous(), F.linear(x, w["encoder_proj.weight"]).contiguous()
+def style_embed(w, hp, spk, style_idx):
+    """-> [1 or B, E] style embedding (or None when the checkpoint has no GST)."""
+    if "gst.stl.embed" not in w:
+        return None
+    e = _style_embed(w, hp, spk, style_idx)
+    return e.reshape(e.shape[0], -1).contiguous()

@@ -35,8 +35,9 @@ class TacotronDevice:
         _lib.check(L.mb_taco_create(C.byref(self.cfg), _lib.host_ptr_array(ws), len(ws), C.byref(h)), "mb_taco_create")
         self._h = h
         self.front = {k: v.detach().to(device, torch.float32) for k, v in state_dict.items()
-                      if k.startswith(("encoder.", "gst.", "encoder_proj.")) and v.is_floating_point()}
+                      if k.startswith("gst.") and v.is_floating_point()}
         self._ws = None
+        self._ews = None
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -70,10 +71,37 @@ class TacotronDevice:
         F = nf.value
         return mel[:, :, :F], lin[:, :, :F], attn[:, :F // r]
 
+    def encode(self, chars, speaker_embedding, style_idx=0, enc_masks=None, seed=0):
+        """Front half of Tacotron.forward (tacotron.py:234-255) in HIP: -> (encoder_seq [B,T,P],
+        encoder_seq_proj [B,T,D]).  enc_masks: optional [2, B, T, encoder_dims] PreNet keep masks."""
+        if not self.cfg.has_encoder:
+            raise _lib.MbHipError("checkpoint has no encoder weights")
+        dev = chars.device
+        B, T = chars.shape
+        spk = speaker_embedding.to(dev, torch.float32).contiguous()
+        style = frontend.style_embed(self.front, hparams, spk, style_idx)
+        if style is None:
+            style = torch.zeros(1, max(self.cfg.style_dims, 1), device=dev)
+        L = _lib.lib()
+        need = L.mb_taco_encode_workspace_bytes(self._h, B, T)
+        if self._ews is None or self._ews.numel() < need or self._ews.device != dev:
+            self._ews = torch.empty(need, dtype=torch.uint8, device=dev)
+        memory = torch.empty(B, T, self.cfg.project_dims, device=dev)
+        memory_proj = torch.empty(B, T, self.cfg.decoder_dims, device=dev)
+        chars32 = chars.to(torch.int32).contiguous()
+        if enc_masks is not None:
+            enc_masks = torch.as_tensor(enc_masks).to(dev, torch.float32).contiguous()
+            if tuple(enc_masks.shape) != (2, B, T, self.cfg.encoder_dims):
+                raise _lib.MbHipError(f"encoder masks must be {(2, B, T, self.cfg.encoder_dims)}, got {tuple(enc_masks.shape)}")
+        _lib.check(L.mb_taco_encode(self._h, _lib.ptr(chars32), _lib.ptr(spk), _lib.ptr(style), style.shape[0], B, T,
+                                    _lib.ptr(enc_masks), int(seed) ^ 0x5EED, _lib.ptr(memory), _lib.ptr(memory_proj),
+                                    _lib.ptr(self._ews), self._ews.numel(), _lib.stream_ptr()), "mb_taco_encode")
+        return memory, memory_proj
+
     def generate(self, chars, speaker_embedding, steps=2000, style_idx=0, min_stop_token=5, enc_masks=None,
                  dropout=None, seed=0):
         """Tacotron.generate (tacotron.py:295-298) -> (mel_outputs, linear, attn_scores)."""
-        memory, memory_proj = frontend.encoder_memory(self.front, hparams, chars, speaker_embedding, style_idx, enc_masks)
+        memory, memory_proj = self.encode(chars, speaker_embedding, style_idx, enc_masks, seed)
         return self.decode(memory, memory_proj, chars, steps, min_stop_token, dropout, seed)
 
 

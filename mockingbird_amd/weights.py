@@ -143,6 +143,14 @@ def taco_config(state: Dict[str, torch.Tensor], r: int = None, max_r: int = 20) 
     c.num_highways = sum(1 for k in state if k.startswith("postnet.highways.") and k.endswith(".W1.weight"))
     cw = state["decoder.attn_net.conv.weight"]
     c.lsa_filters, c.lsa_kernel = cw.shape[0], cw.shape[2]
+    if "encoder.embedding.weight" in state:
+        emb = state["encoder.embedding.weight"]
+        c.has_encoder = 1
+        c.num_chars, c.embed_dims = emb.shape
+        c.encoder_dims = state["encoder.pre_net.fc1.weight"].shape[0]
+        c.encoder_K = sum(1 for k in state if k.startswith("encoder.cbhg.conv1d_bank.") and k.endswith(".conv.weight"))
+        c.style_dims = state["gst.stl.attention.W_value.weight"].shape[0] if "gst.stl.attention.W_value.weight" in state else 0
+        c.speaker_dims = c.project_dims - c.encoder_dims - c.style_dims
     return c
 
 
@@ -170,4 +178,20 @@ def taco_weight_list(state: Dict[str, torch.Tensor], cfg: "_lib.TacoConfig") -> 
     for sfx in ("", "_reverse"):
         names += [f"{p}rnn.weight_ih_l0{sfx}", f"{p}rnn.weight_hh_l0{sfx}", f"{p}rnn.bias_ih_l0{sfx}", f"{p}rnn.bias_hh_l0{sfx}"]
     names += ["post_proj.weight"]
+    if cfg.has_encoder:
+        e = "encoder."
+        names += [e + "embedding.weight", e + "pre_net.fc1.weight", e + "pre_net.fc1.bias", e + "pre_net.fc2.weight",
+                  e + "pre_net.fc2.bias"]
+        q = e + "cbhg."
+        for k in range(cfg.encoder_K):
+            names += [f"{q}conv1d_bank.{k}.conv.weight"] + bn(f"{q}conv1d_bank.{k}.bnorm")
+        names += [q + "conv_project1.conv.weight"] + bn(q + "conv_project1.bnorm")
+        names += [q + "conv_project2.conv.weight"] + bn(q + "conv_project2.bnorm")
+        if q + "pre_highway.weight" in state:
+            names += [q + "pre_highway.weight"]
+        for i in range(cfg.num_highways):
+            names += [f"{q}highways.{i}.W1.weight", f"{q}highways.{i}.W1.bias", f"{q}highways.{i}.W2.weight", f"{q}highways.{i}.W2.bias"]
+        for sfx in ("", "_reverse"):
+            names += [f"{q}rnn.weight_ih_l0{sfx}", f"{q}rnn.weight_hh_l0{sfx}", f"{q}rnn.bias_ih_l0{sfx}", f"{q}rnn.bias_hh_l0{sfx}"]
+        names += ["encoder_proj.weight"]
     return [_f32(state[n]) for n in names]

@@ -90,3 +90,15 @@ def test_shard_indices_balanced_and_complete():
         assert sorted(sum(parts, [])) == list(range(len(lens)))
         loads = [sum(lens[i] for i in p) for p in parts]
         assert max(loads) - min(loads) <= max(lens)
+
+
+def test_tacotron_weight_list_matches_abi_counts(lib):
+    from mockingbird_amd import weights
+    st = synth.tacotron_state(seed=1)["model_state"]
+    c = weights.taco_config(st)
+    assert (c.n_mels, c.project_dims, c.decoder_dims, c.lstm_dims, c.r, c.postnet_K, c.num_highways) == (80, 1024, 128, 1024, 2, 5, 4)
+    assert (c.has_encoder, c.num_chars, c.embed_dims, c.encoder_dims, c.encoder_K, c.speaker_dims, c.style_dims) == (1, 75, 512, 256, 5, 256, 512)
+    ws = weights.taco_weight_list(st, c)
+    assert lib.mb_taco_num_weights(C.byref(c)) == len(ws)
+    for i, w in enumerate(ws):
+        assert lib.mb_taco_weight_numel(C.byref(c), i) == w.numel(), i
