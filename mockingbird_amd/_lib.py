@@ -134,6 +134,9 @@ def lib():
                 f"{LIB_PATH} not found: the HIP extension is not built. Run "
                 "`python -c 'import __graft_entry__ as g; g.build()'` (or python -m mockingbird_amd.build). "
                 "There is no CPU fallback.")
+        # torch first: its bundled HIP runtime must be the one this process binds (libmbhip.so only
+        # borrows device memory / streams from it); loading ours first can leave two runtimes around.
+        import torch  # noqa: F401
         l = C.CDLL(str(LIB_PATH))
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the .so lacks a declared symbol

@@ -47,13 +47,47 @@ struct RnnK {
   float* h_out; float* c_out; float* x_out;                      // [N][units]
   float* y; int ldy; int act;  // LINEAR: y[n*ldy + row]; act 0 none, 1 relu, 2 sigmoid, 3 tanh
   const float* mask; float mask_scale;  // LINEAR: optional y *= mask[n*ldy+row]*mask_scale (dropout)
-  int* step_counter;  // block (0,0) increments it (loop step bookkeeping), may be null
+  // Table row computed in-kernel from a step index (WaveRNN fold geometry, fatchord_version.py:334-336):
+  //   s = *fr_base + fr_off;  pos = (fr_n_off + n)*fr_fold_stride + s;
+  //   row = pos < fr_total_len ? pos / fr_hop : fr_frames          (used when fr_base != null)
+  // *fr_base changes once per graph replay, fr_off is baked per launch: the loop kernels never read a
+  // word the previous launch has just written except the activations themselves.
+  const int* fr_base; int fr_off, fr_n_off, fr_fold_stride, fr_total_len, fr_hop, fr_frames;
   const int* skip_flag;  // if non-null and *skip_flag != 0 the launch is a no-op (decoder stop rule)
   // optional strided copy of h_out into a sequence tensor: seq_out[n*seq_n_stride + j*seq_j_stride + seq_off]
   float* seq_out; long long seq_n_stride, seq_j_stride, seq_off;
   // LINEAR dropout when mask == null and drop_seed_on: keep = philox(seed, drop_iter, drop_layer; n,row) < 0.5
   int drop_on; unsigned long long drop_seed; int drop_iter, drop_layer;
+  // diagnostics (MBHIP_TRACE_FILE): per-workgroup (start, end) wall_clock64 ticks, TRACE_SLOTS pairs
+  unsigned long long* trace;
 };
+
+static constexpr int TRACE_SLOTS = 512;  // workgroups recorded per launch
+#ifdef MB_TRACE_MARKS
+// diagnostics build only (tools/build_diag.sh): shader-clock marks inside workgroup 0 / wave 0
+#define MB_MARK(tr, k, waitall)                                                                     \
+  do {                                                                                              \
+    if (waitall) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                        \
+    if ((tr) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)                             \
+      (tr)[2 * 496 + (k)] = (unsigned long long)clock64();                                          \
+  } while (0)
+#else
+#define MB_MARK(tr, k, waitall) do { } while (0)
+#endif
+__device__ __forceinline__ void trace_begin(unsigned long long* tr) {
+  if (tr && threadIdx.x == 0) {
+    const unsigned b = blockIdx.x + blockIdx.y * gridDim.x;
+    if (b < TRACE_SLOTS) tr[2 * b] = (unsigned long long)wall_clock64();
+    if (b == 0) tr[2 * (TRACE_SLOTS - 1)] = (unsigned long long)clock64();  // shader-clock ticks (DVFS probe)
+  }
+}
+__device__ __forceinline__ void trace_end(unsigned long long* tr) {
+  if (tr && (threadIdx.x & 63) == 0) {
+    const unsigned b = blockIdx.x + blockIdx.y * gridDim.x;
+    if (b < TRACE_SLOTS) atomicMax(tr + 2 * b + 1, (unsigned long long)wall_clock64());
+    if (b == 0 && threadIdx.x == 0) tr[2 * (TRACE_SLOTS - 1) + 1] = (unsigned long long)clock64();
+  }
+}
 
 // rows: live rows x K (K multiple of 16), tile-ordered: rows of tile mt are
 // [mt*4*RL, (mt+1)*4*RL) in (unit, gate) order.  RL = live gates per unit (3 GRU, 4 else).

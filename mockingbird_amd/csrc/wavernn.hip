@@ -60,15 +60,16 @@ struct SampK {
   const float* forced;  // [N_total][S] or null
   float* samples;       // [N_total][S]
   float* logits_out;    // [S][N_total][C] or null
-  const int* step;      // lane counter, already incremented by this step's first kernel
+  const int* step_base; // step index of the first launch of the current graph replay (device word)
+  int step_off;         // + offset baked into this launch
   int n_off, N_total;   // this lane covers folds [n_off, n_off + gridDim.x)
   int C, S, R;
   int fold_stride, total_len, hop, frames;
   const float* Ipre;    // [(total_len+1)][R]
   const float* wI0;     // [R]
   float* x0;            // [n][R] (lane-local)
-  int* idx_frame;       // [n]   (lane-local)
   volatile int* progress;
+  unsigned long long* trace;
 };
 
 // x0 / table row for lane-local fold n at step s1 with fed-back sample xfb (:192-195 + fold indexing :334-336)
@@ -76,7 +77,6 @@ __device__ __forceinline__ void prep_step(const SampK& a, int n, int s1, float x
   const long long pos = (long long)(a.n_off + n) * a.fold_stride + s1;
   const bool livep = pos < a.total_len;
   const long long ipos = livep ? pos : a.total_len;
-  if (tid == 0) a.idx_frame[n] = livep ? (int)(pos / a.hop) : a.frames;
   const float* ip = a.Ipre + ipos * a.R;
   for (int j = tid; j < a.R; j += nthreads) a.x0[(size_t)n * a.R + j] = ip[j] + xfb * a.wI0[j];
 }
@@ -85,59 +85,80 @@ __global__ __launch_bounds__(128) void wavernn_init_kernel(SampK a) {
   prep_step(a, blockIdx.x, 0, 0.f, threadIdx.x, blockDim.x);
 }
 
+// step_base += n (last node of every graph replay / after every eager step)
+__global__ void wavernn_bump_kernel(int* step_base, int n) { *step_base += n; }
+
 // softmax -> Categorical.sample() -> 2k/(C-1)-1   (:222-228).  torch.multinomial(p, 1) on the
 // CPU path is argmax(p / Exp(1) noise) (verified bit-exact), restated here with
 // the noise either injected (parity) or drawn from Philox (production; one call per 4 classes).
-// One workgroup (2 waves) per fold, 4 classes per thread per pass, wave-shuffle + LDS reductions.
-__global__ __launch_bounds__(128) void wavernn_sample_kernel(SampK a) {
-  __shared__ float redf[2];
-  __shared__ int redi[2];
-  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int s = *a.step - 1;
+//
+// ONE wavefront per fold: C/64 classes per lane (C = 512 -> two float4), so max / sum / argmax are
+// pure wave-shuffle reductions -- no LDS, no barrier.  Latency-first like rnn.hip: the logits, the
+// step counter, the next step's Ipre row and W_I[:,0] are all requested before the first wait; the
+// fed-back sample only scales W_I[:,0] at the very end.
+template <int C4>  // float4 chunks of logits per lane (C = 256 * C4)
+__global__ __launch_bounds__(64) void wavernn_sample_kernel(SampK a) {
+  trace_begin(a.trace);
+  const int n = blockIdx.x, lane = threadIdx.x;
   const int gn = a.n_off + n;
   const float* lg = a.logits + (size_t)n * a.C;
-  float m = -INFINITY;
-  for (int c = tid * 4; c < a.C; c += 512) {
-    const float4 v = *reinterpret_cast<const float4*>(lg + c);
-    m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+  float4 v[C4];
+#pragma unroll
+  for (int q = 0; q < C4; ++q) v[q] = *reinterpret_cast<const float4*>(lg + (q * 64 + lane) * 4);
+  const int s = *a.step_base + a.step_off;
+  // next step's input row: position known from s alone (fold indexing :334-336)
+  const long long pos = (long long)gn * a.fold_stride + (s + 1);
+  const bool livep = pos < a.total_len;
+  const long long ipos = livep ? pos : a.total_len;
+  const float* ip = a.Ipre + ipos * a.R;
+  constexpr int R4MAX = 4;  // R <= 1024
+  float4 ipv[R4MAX], w0v[R4MAX];
+#pragma unroll
+  for (int q = 0; q < R4MAX; ++q) {
+    const int j = (q * 64 + lane) * 4;
+    const int jc = j < a.R ? j : 0;
+    ipv[q] = *reinterpret_cast<const float4*>(ip + jc);
+    w0v[q] = *reinterpret_cast<const float4*>(a.wI0 + jc);
   }
+  const size_t nb = ((size_t)s * a.N_total + gn) * a.C;
+  float4 ev[C4];
+  if (a.noise) {
+#pragma unroll
+    for (int q = 0; q < C4; ++q) ev[q] = *reinterpret_cast<const float4*>(a.noise + nb + (q * 64 + lane) * 4);
+  }
+  const float forced = a.forced ? a.forced[(size_t)gn * a.S + s] : 0.f;
+
+  float m = -INFINITY;
+#pragma unroll
+  for (int q = 0; q < C4; ++q) m = fmaxf(fmaxf(m, fmaxf(v[q].x, v[q].y)), fmaxf(v[q].z, v[q].w));
   m = wave_max(m);
-  if (lane == 0) redf[wave] = m;
-  __syncthreads();
-  m = fmaxf(redf[0], redf[1]);
-  __syncthreads();
+  float ex[C4][4];
   float sum = 0.f;
-  for (int c = tid * 4; c < a.C; c += 512) {
-    const float4 v = *reinterpret_cast<const float4*>(lg + c);
-    sum += (expf(v.x - m) + expf(v.y - m)) + (expf(v.z - m) + expf(v.w - m));
+#pragma unroll
+  for (int q = 0; q < C4; ++q) {
+    ex[q][0] = expf(v[q].x - m); ex[q][1] = expf(v[q].y - m); ex[q][2] = expf(v[q].z - m); ex[q][3] = expf(v[q].w - m);
+    sum += (ex[q][0] + ex[q][1]) + (ex[q][2] + ex[q][3]);
   }
   sum = wave_sum(sum);
-  if (lane == 0) redf[wave] = sum;
-  __syncthreads();
-  sum = redf[0] + redf[1];
-  __syncthreads();
   float best = -1.f;
   int bidx = 0x7fffffff;
-  const size_t nb = ((size_t)s * a.N_total + gn) * a.C;
-  for (int c = tid * 4; c < a.C; c += 512) {
-    const float4 v = *reinterpret_cast<const float4*>(lg + c);
-    const float l4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int q = 0; q < C4; ++q) {
+    const int c = (q * 64 + lane) * 4;
     float e4[4];
-    if (a.noise) {
-      const float4 e = *reinterpret_cast<const float4*>(a.noise + nb + c);
-      e4[0] = e.x; e4[1] = e.y; e4[2] = e.z; e4[3] = e.w;
-    } else {
+    if (a.noise) { e4[0] = ev[q].x; e4[1] = ev[q].y; e4[2] = ev[q].z; e4[3] = ev[q].w; }
+    else {
       uint32_t r[4];
       philox4x32((uint32_t)s, (uint32_t)gn, (uint32_t)(c >> 2), 0x57415645u, (uint32_t)a.seed,
                  (uint32_t)(a.seed >> 32), r);
 #pragma unroll
       for (int i = 0; i < 4; ++i) e4[i] = -logf(u32_to_unit(r[i]));
     }
-    if (a.logits_out) *reinterpret_cast<float4*>(a.logits_out + nb + c) = v;
+    if (a.logits_out) *reinterpret_cast<float4*>(a.logits_out + nb + c) = v[q];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float q = (expf(l4[i] - m) / sum) / e4[i];
-      if (q > best) { best = q; bidx = c + i; }  // ascending c per thread: first max kept
+      const float qv = (ex[q][i] / sum) / e4[i];
+      if (qv > best) { best = qv; bidx = c + i; }  // ascending c per lane: first max kept
     }
   }
 #pragma unroll
@@ -146,16 +167,25 @@ __global__ __launch_bounds__(128) void wavernn_sample_kernel(SampK a) {
     const int oi = __shfl_xor(bidx, o, 64);
     if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
   }
-  if (lane == 0) { redf[wave] = best; redi[wave] = bidx; }
-  __syncthreads();
-  if (redf[1] > redf[0] || (redf[1] == redf[0] && redi[1] < redi[0])) bidx = redi[1]; else bidx = redi[0];
   const float x = 2.f * (float)bidx / ((float)a.C - 1.f) - 1.f;
-  if (tid == 0) {
+  if (lane == 0) {
     a.samples[(size_t)gn * a.S + s] = x;
     if (a.progress && gn == 0 && (s % 100 == 0 || s == a.S - 1)) *a.progress = s + 1;
   }
-  const float xfb = a.forced ? a.forced[(size_t)gn * a.S + s] : x;
-  if (s + 1 < a.S) prep_step(a, n, s + 1, xfb, tid, 128);
+  const float xfb = a.forced ? forced : x;
+  if (s + 1 < a.S) {
+#pragma unroll
+    for (int q = 0; q < R4MAX; ++q) {
+      const int j = (q * 64 + lane) * 4;
+      if (j < a.R) {
+        float4 o;
+        o.x = ipv[q].x + xfb * w0v[q].x; o.y = ipv[q].y + xfb * w0v[q].y;
+        o.z = ipv[q].z + xfb * w0v[q].z; o.w = ipv[q].w + xfb * w0v[q].w;
+        *reinterpret_cast<float4*>(a.x0 + (size_t)n * a.R + j) = o;
+      }
+    }
+  }
+  trace_end(a.trace);
 }
 
 }  // namespace mb
@@ -207,6 +237,8 @@ static int wavernn_shapes(const mb_wavernn_config* c, std::vector<size_t>* numel
   MB_REQUIRE(c->n_upsample >= 1 && c->n_upsample <= 4, "wavernn: n_upsample");
   MB_REQUIRE(c->rnn_dims % 16 == 0 && c->fc_dims % 16 == 0, "wavernn: rnn_dims/fc_dims must be multiples of 16");
   MB_REQUIRE(c->res_out_dims % 4 == 0, "wavernn: res_out_dims %% 4");
+  MB_REQUIRE(c->bits >= 8 && c->bits <= 10, "wavernn: bits=%d unsupported by the one-wave sampler (8..10)", c->bits);
+  MB_REQUIRE(c->rnn_dims <= 1024, "wavernn: rnn_dims=%d > 1024", c->rnn_dims);
   const size_t R = c->rnn_dims, FC = c->fc_dims, A = c->res_out_dims / 4, CD = c->compute_dims;
   const size_t C = (size_t)1 << c->bits;
   numel->clear();
@@ -385,7 +417,7 @@ namespace {
 struct WrnLayout {
   float *r0, *r1, *r2, *aux, *m1, *m2, *cond, *Ipre, *G2, *F1, *F2;
   float *x0, *x1, *x2, *y1, *y2, *logits, *h1, *h2;
-  int* idx_frame; int* step;
+  int* step;
   size_t bytes;
 };
 // python-style floor division
@@ -413,7 +445,6 @@ static void wavernn_layout(const mb_wavernn* w, const mb_wavernn_plan* p, void* 
   L->y1 = ar.take<float>(N * FC); L->y2 = ar.take<float>(N * FC);
   L->logits = ar.take<float>(N * w->n_classes);
   L->h1 = ar.take<float>(2 * N * R); L->h2 = ar.take<float>(2 * N * R);
-  L->idx_frame = ar.take<int>(N);
   L->step = ar.take<int>(16);
   L->bytes = ar.off + 256;
 }
@@ -537,22 +568,25 @@ extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* 
     const int n0 = lane_n0[l];
     SampK sk;
     sk.logits = L.logits + (size_t)n0 * C; sk.noise = d_noise; sk.seed = seed; sk.forced = d_forced;
-    sk.samples = d_samples; sk.logits_out = d_logits_out; sk.step = L.step + l; sk.n_off = n0; sk.N_total = N;
+    sk.samples = d_samples; sk.logits_out = d_logits_out; sk.step_base = L.step + l; sk.step_off = 0; sk.n_off = n0; sk.N_total = N;
     sk.C = C; sk.S = S; sk.R = R; sk.fold_stride = plan->fold_stride; sk.total_len = T; sk.hop = w->hop; sk.frames = F;
-    sk.Ipre = L.Ipre; sk.wI0 = w->wI0.p; sk.x0 = L.x0 + (size_t)n0 * R; sk.idx_frame = L.idx_frame + n0;
-    sk.progress = h_progress;
+    sk.Ipre = L.Ipre; sk.wI0 = w->wI0.p; sk.x0 = L.x0 + (size_t)n0 * R;
+    sk.progress = h_progress; sk.trace = nullptr;
     return sk;
   };
 
   // one time step of lane l = 5 GEMM launches + sampler; pp = parity of the step (state ping-pong)
-  auto step = [&](int l, int pp, int which = 0x3f) -> int {
+  auto step = [&](int l, int pp, int soff, int which = 0x3f, unsigned long long* tr = nullptr) -> int {
     const int n0 = lane_n0[l], nl = lane_n0[l + 1] - n0;
     hipStream_t ls = w->lane_stream[l];
     float* x0 = L.x0 + (size_t)n0 * R; float* x1 = L.x1 + (size_t)n0 * R; float* x2 = L.x2 + (size_t)n0 * R;
     float* y1 = L.y1 + (size_t)n0 * FC; float* y2 = L.y2 + (size_t)n0 * FC; float* lgt = L.logits + (size_t)n0 * C;
     float* h1p = L.h1 + ((size_t)pp * N + n0) * R; float* h1n = L.h1 + ((size_t)(pp ^ 1) * N + n0) * R;
     float* h2p = L.h2 + ((size_t)pp * N + n0) * R; float* h2n = L.h2 + ((size_t)(pp ^ 1) * N + n0) * R;
-    const int* idxf = L.idx_frame + n0;
+    auto frame_rows = [&](RnnK& k) {  // per-frame table row of fold n at this step, computed in-kernel
+      k.fr_base = L.step + l; k.fr_off = soff; k.fr_n_off = n0; k.fr_fold_stride = plan->fold_stride;
+      k.fr_total_len = T; k.fr_hop = w->hop; k.fr_frames = F;
+    };
     RnnK k;
     int r = MB_OK;
     // h1 = rnn1(x, h1); x = x + h1   :196-198
@@ -560,35 +594,45 @@ extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* 
     k.w = w->w_rnn1.p; k.nseg = 2; k.nkb_total = 2 * R / 16;
     k.seg[0] = {x0, R, R / 16, 0}; k.seg[1] = {h1p, R, R / 16, 1};
     k.N = nl; k.units = R; k.biasX = w->b_ih1.p; k.biasH = w->b_hh1.p;
-    k.h_prev = h1p; k.x_res = x0; k.h_out = h1n; k.x_out = x1; k.step_counter = L.step + l;
+    k.h_prev = h1p; k.x_res = x0; k.h_out = h1n; k.x_out = x1;
+    k.trace = tr ? tr + 0 : nullptr;
     if ((which & 1) && (r = rnn_launch(EPI_GRU, k, ls))) return r;
     // h2 = rnn2([x, a2], h2); x = x + h2   :199-202
     memset(&k, 0, sizeof(k));
     k.w = w->w_rnn2.p; k.nseg = 2; k.nkb_total = 2 * R / 16;
     k.seg[0] = {x1, R, R / 16, 0}; k.seg[1] = {h2p, R, R / 16, 1};
     k.N = nl; k.units = R; k.biasH = w->b_hh2.p;
-    k.pre_table = L.G2; k.pre_idx = idxf; k.pre_stride = 3 * R;
+    k.pre_table = L.G2; frame_rows(k); k.pre_stride = 3 * R;
     k.h_prev = h2p; k.x_res = x1; k.h_out = h2n; k.x_out = x2;
+    k.trace = tr ? tr + 2 * TRACE_SLOTS : nullptr;
     if ((which & 2) && (r = rnn_launch(EPI_GRU, k, ls))) return r;
     // x = relu(fc1([x, a3]))   :203-204
     memset(&k, 0, sizeof(k));
     k.w = w->w_fc1.p; k.nseg = 1; k.nkb_total = R / 16; k.seg[0] = {x2, R, R / 16, 0};
-    k.N = nl; k.units = FC; k.pre_table = L.F1; k.pre_idx = idxf; k.pre_stride = FC;
+    k.N = nl; k.units = FC; k.pre_table = L.F1; frame_rows(k); k.pre_stride = FC;
     k.y = y1; k.ldy = FC; k.act = 1;
+    k.trace = tr ? tr + 4 * TRACE_SLOTS : nullptr;
     if ((which & 4) && (r = rnn_launch(EPI_LINEAR, k, ls))) return r;
     // x = relu(fc2([x, a4]))   :206-207
     memset(&k, 0, sizeof(k));
     k.w = w->w_fc2.p; k.nseg = 1; k.nkb_total = FC / 16; k.seg[0] = {y1, FC, FC / 16, 0};
-    k.N = nl; k.units = FC; k.pre_table = L.F2; k.pre_idx = idxf; k.pre_stride = FC;
+    k.N = nl; k.units = FC; k.pre_table = L.F2; frame_rows(k); k.pre_stride = FC;
     k.y = y2; k.ldy = FC; k.act = 1;
+    k.trace = tr ? tr + 6 * TRACE_SLOTS : nullptr;
     if ((which & 8) && (r = rnn_launch(EPI_LINEAR, k, ls))) return r;
     // logits = fc3(x)   :209
     memset(&k, 0, sizeof(k));
     k.w = w->w_fc3.p; k.nseg = 1; k.nkb_total = FC / 16; k.seg[0] = {y2, FC, FC / 16, 0};
     k.N = nl; k.units = C; k.biasX = w->b_fc3.p; k.y = lgt; k.ldy = C;
+    k.trace = tr ? tr + 8 * TRACE_SLOTS : nullptr;
     if ((which & 16) && (r = rnn_launch(EPI_LINEAR, k, ls))) return r;
     if (which & 32) {
-      hipLaunchKernelGGL(wavernn_sample_kernel, dim3(nl), dim3(128), 0, ls, make_sk(l));
+      SampK sk = make_sk(l);
+      sk.step_off = soff;
+      sk.trace = tr ? tr + 10 * TRACE_SLOTS : nullptr;
+      if (C == 512) hipLaunchKernelGGL(wavernn_sample_kernel<2>, dim3(nl), dim3(64), 0, ls, sk);
+      else if (C == 256) hipLaunchKernelGGL(wavernn_sample_kernel<1>, dim3(nl), dim3(64), 0, ls, sk);
+      else hipLaunchKernelGGL(wavernn_sample_kernel<4>, dim3(nl), dim3(64), 0, ls, sk);
       MB_HIP(hipGetLastError());
     }
     return MB_OK;
@@ -600,6 +644,11 @@ extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* 
     MB_HIP(hipGetLastError());
   }
 
+  // diagnostics: MBHIP_TRACE_FILE=<path> records per-kernel first-wave-start / last-store-end device
+  // timestamps (wall_clock64, 100 MHz) of the LAST graph replay and dumps them after a sync.
+  const char* trace_path = getenv("MBHIP_TRACE_FILE");
+  unsigned long long* d_trace = nullptr;
+  int trace_steps = 0;
   MB_HIP(hipEventRecord(w->ev_t0, s));
   const bool use_graph = getenv("MBHIP_NO_GRAPH") == nullptr && S >= 64;
   int done = 0;
@@ -613,8 +662,14 @@ extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* 
       w->drop_graph();
       for (int l = 0; l < lanes; ++l) {
         hipStream_t ls = w->lane_stream[l];
+        if (trace_path && l == 0 && lanes == 1) {
+          trace_steps = G;
+          if (hipMalloc((void**)&d_trace, sizeof(unsigned long long) * 12 * TRACE_SLOTS * G) != hipSuccess) { d_trace = nullptr; trace_steps = 0; }
+        }
         MB_HIP(hipStreamBeginCapture(ls, hipStreamCaptureModeRelaxed));
-        for (int i = 0; i < G && !rc; ++i) rc = step(l, i & 1, 0x3f & ~w->bench_which);
+        for (int i = 0; i < G && !rc; ++i)
+          rc = step(l, i & 1, i, 0x3f & ~w->bench_which, d_trace ? d_trace + (size_t)12 * TRACE_SLOTS * i : nullptr);
+        hipLaunchKernelGGL(wavernn_bump_kernel, dim3(1), dim3(1), 0, ls, L.step + l, G);  // step_base += G per replay
         hipError_t e = hipStreamEndCapture(ls, &w->graph[l]);
         if (rc) { w->drop_graph(); return rc; }
         if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture", __FILE__, __LINE__);
@@ -622,19 +677,33 @@ extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* 
         if (e != hipSuccess) { w->drop_graph(); return hip_fail(e, "hipGraphInstantiate", __FILE__, __LINE__); }
       }
       const int reps = S / G;
-      for (int r = 0; r < reps; ++r)
+      for (int r = 0; r < reps; ++r) {
+        if (d_trace && r == reps - 1) {  // (start, end) pairs: start = ~0 for atomicMin, end = 0 for atomicMax
+          std::vector<unsigned long long> init((size_t)12 * TRACE_SLOTS * trace_steps);
+          for (size_t i = 0; i < init.size(); ++i) init[i] = (i & 1) ? 0ull : ~0ull;
+          MB_HIP(hipStreamSynchronize(w->lane_stream[0]));
+          MB_HIP(hipMemcpy(d_trace, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+        }
         for (int l = 0; l < lanes; ++l) MB_HIP(hipGraphLaunch(w->graph_exec[l], w->lane_stream[l]));
+      }
       done = reps * G;
     }
   }
-  for (int i = done; i < S && !rc; ++i)
-    for (int l = 0; l < lanes && !rc; ++l) rc = step(l, i & 1, 0x3f & ~w->bench_which);
+  for (int i = done; i < S && !rc; ++i)  // eager tail: step_base stays at `done`, the offset carries the step
+    for (int l = 0; l < lanes && !rc; ++l) rc = step(l, i & 1, i - done, 0x3f & ~w->bench_which);
   if (rc) return rc;
   for (int l = 1; l < lanes; ++l) {  // join the lanes on lane 0
     MB_HIP(hipEventRecord(w->lane_ev[l], w->lane_stream[l]));
     MB_HIP(hipStreamWaitEvent(s, w->lane_ev[l], 0));
   }
   MB_HIP(hipEventRecord(w->ev_t1, s));
+  if (d_trace) {
+    std::vector<unsigned long long> host((size_t)12 * TRACE_SLOTS * trace_steps);
+    MB_HIP(hipStreamSynchronize(s));
+    MB_HIP(hipMemcpy(host.data(), d_trace, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    (void)hipFree(d_trace);
+    if (FILE* f = fopen(trace_path, "wb")) { fwrite(host.data(), sizeof(unsigned long long), host.size(), f); fclose(f); }
+  }
   w->last_launches = 6 * S * lanes;
   w->last_lanes = lanes;
   w->timed = true;
