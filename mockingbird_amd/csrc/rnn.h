@@ -58,9 +58,35 @@ struct RnnK {
   float* seq_out; long long seq_n_stride, seq_j_stride, seq_off;
   // LINEAR dropout when mask == null and drop_seed_on: keep = philox(seed, drop_iter, drop_layer; n,row) < 0.5
   int drop_on; unsigned long long drop_seed; int drop_iter, drop_layer;
+  // ---- WaveRNN fused sampling (production path, no injected noise) ----
+  // aff_slot != null (GRU): the cell input is x0[n] = aff_table[ipos_n] + x_n * aff_vec  (I(x) split,
+  // wavernn.hip header) with ipos_n from the fr_* geometry (row fr_total_len = zero-conditioning row) and
+  // x_n decoded from the argmax word aff_slot[n] the previous step's fc3 launch left (0 = no sample yet
+  // -> x = 0).  K segment 0 then reads table row ipos_n for column n and the epilogue adds
+  // x_n * aff_gate (aff_gate = W_ih . aff_vec, [3*units] gate-major); x_res is rebuilt the same way.
+  // Workgroups with blockIdx.x == 0 also store x_n to aff_samples[(fr_n_off+n)*aff_S + s-1].
+  const unsigned long long* aff_slot; const float* aff_table; const float* aff_vec; const float* aff_gate;
+  int aff_ld, aff_C, aff_S;
+  float* aff_samples; volatile int* aff_progress;
+  // gum_slot != null (LINEAR, rows = classes): instead of (only) storing logits, draw Exp(1) noise from
+  // Philox(gum_seed; s, fold, class/4) and atomicMax the packed (logit - log E, class) into gum_slot[n]:
+  // argmax_c p_c/E_c == argmax_c (l_c - log E_c)  (torch.multinomial's rule).
+  unsigned long long* gum_slot; unsigned long long gum_seed;
+  // zero_slot != null: workgroup (0,0) clears zero_slot[0..N) (the argmax words of the NEXT step)
+  unsigned long long* zero_slot;
   // diagnostics (MBHIP_TRACE_FILE): per-workgroup (start, end) wall_clock64 ticks, TRACE_SLOTS pairs
   unsigned long long* trace;
 };
+
+// order-preserving float -> uint key and the packed (key, lowest-class-wins) argmax word
+__host__ __device__ __forceinline__ unsigned int float_key(float f) {
+  const unsigned int b = __builtin_bit_cast(unsigned int, f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__host__ __device__ __forceinline__ unsigned long long pack_argmax(float score, int cls) {
+  return ((unsigned long long)float_key(score) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)cls);
+}
+__host__ __device__ __forceinline__ int argmax_class(unsigned long long w) { return (int)(0xFFFFFFFFu - (unsigned)w); }
 
 static constexpr int TRACE_SLOTS = 512;  // workgroups recorded per launch
 #ifdef MB_TRACE_MARKS

@@ -85,6 +85,12 @@ __global__ __launch_bounds__(128) void wavernn_init_kernel(SampK a) {
   prep_step(a, blockIdx.x, 0, 0.f, threadIdx.x, blockDim.x);
 }
 
+// fused-sampling path: the sample of the LAST step is still only an argmax word; decode it.
+__global__ void wavernn_flush_kernel(const unsigned long long* slot, float* samples, int N, int S, int C) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < N) samples[(size_t)n * S + (S - 1)] = slot[n] ? 2.f * (float)argmax_class(slot[n]) / ((float)C - 1.f) - 1.f : 0.f;
+}
+
 // step_base += n (last node of every graph replay / after every eager step)
 __global__ void wavernn_bump_kernel(int* step_base, int n) { *step_base += n; }
 
@@ -209,7 +215,7 @@ struct mb_wavernn {
   // tables
   CondConv t_I, t_g2, t_f1, t_f2;  // 1x1 convs producing Ipre / G2pre / F1pre / F2pre
   // loop weights
-  DevBuf wI0, w_rnn1, w_rnn2, w_fc1, w_fc2, w_fc3;
+  DevBuf wI0, g1I0, w_rnn1, w_rnn2, w_fc1, w_fc2, w_fc3;
   DevBuf b_ih1, b_hh1, b_hh2, b_fc3;
   // Folds are independent sequences: they are dealt to up to MAX_LANES "lanes", each with its own
   // stream + graph, so the per-kernel dependency latency of one lane overlaps with the others.
@@ -345,6 +351,15 @@ extern "C" int mb_wavernn_create(const mb_wavernn_config* cfg, const float* cons
     cell_rows(wih, R, R, whh, R, R, 3, &rows);
     pack_rowtile(rows.data(), 3 * R, 2 * R, 3, &packed);
     RC(w->w_rnn1.upload(packed.data(), packed.size()));
+    {  // W_ih1 . W_I[:,0] (fused-sampling path: the fed-back sample enters the gates through this vector)
+      std::vector<float> g(3 * R);
+      for (int r = 0; r < 3 * R; ++r) {
+        double acc = 0.0;
+        for (int k2 = 0; k2 < R; ++k2) acc += (double)wih[(size_t)r * R + k2] * (double)WI[(size_t)k2 * KI];
+        g[r] = (float)acc;
+      }
+      RC(w->g1I0.upload(g.data(), g.size()));
+    }
     RC(w->b_ih1.upload(bih, 3 * R)); RC(w->b_hh1.upload(bhh, 3 * R));
   }
   // rnn2 :110 (input = [x, a2])
@@ -397,7 +412,7 @@ extern "C" void mb_wavernn_destroy(mb_wavernn* w) {
   for (auto& c : w->res1) rel(c);
   for (auto& c : w->res2) rel(c);
   for (auto& b : w->up_w) b.release();
-  DevBuf* bs[] = {&w->wI0, &w->w_rnn1, &w->w_rnn2, &w->w_fc1, &w->w_fc2, &w->w_fc3,
+  DevBuf* bs[] = {&w->wI0, &w->g1I0, &w->w_rnn1, &w->w_rnn2, &w->w_fc1, &w->w_fc2, &w->w_fc3,
                   &w->b_ih1, &w->b_hh1, &w->b_hh2, &w->b_fc3};
   for (DevBuf* b : bs) b->release();
   w->drop_graph();
@@ -417,7 +432,7 @@ namespace {
 struct WrnLayout {
   float *r0, *r1, *r2, *aux, *m1, *m2, *cond, *Ipre, *G2, *F1, *F2;
   float *x0, *x1, *x2, *y1, *y2, *logits, *h1, *h2;
-  int* step;
+  int* step; unsigned long long* slots;
   size_t bytes;
 };
 // python-style floor division
@@ -446,6 +461,7 @@ static void wavernn_layout(const mb_wavernn* w, const mb_wavernn_plan* p, void* 
   L->logits = ar.take<float>(N * w->n_classes);
   L->h1 = ar.take<float>(2 * N * R); L->h2 = ar.take<float>(2 * N * R);
   L->step = ar.take<int>(16);
+  L->slots = ar.take<unsigned long long>(2 * N);
   L->bytes = ar.off + 256;
 }
 
@@ -551,6 +567,7 @@ extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* 
     MB_HIP(hipMemsetAsync(L.h1, 0, sizeof(float) * 2 * N * R, s));
     MB_HIP(hipMemsetAsync(L.h2, 0, sizeof(float) * 2 * N * R, s));
     MB_HIP(hipMemsetAsync(L.step, 0, sizeof(int) * 16, s));
+    MB_HIP(hipMemsetAsync(L.slots, 0, sizeof(unsigned long long) * 2 * N, s));
   }
   if (rc) return rc;
 
@@ -564,6 +581,9 @@ extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* 
   for (int l = 0; l <= lanes; ++l) lane_n0[l] = (int)((long long)N * l / lanes);
   MB_HIP(hipEventRecord(w->ev_cond, s));  // conditioning tables + zeroed state are ready
 
+  // Production path (no injected noise / teacher forcing / logits dump): the sampler is fused into the
+  // fc3 launch and the next step's input is rebuilt inside the rnn1 launch -> 5 launches per step.
+  const bool fused = !d_noise && !d_forced && !d_logits_out && getenv("MBHIP_WAVERNN_NOFUSE") == nullptr;
   auto make_sk = [&](int l) {
     const int n0 = lane_n0[l];
     SampK sk;
@@ -590,11 +610,19 @@ extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* 
     RnnK k;
     int r = MB_OK;
     // h1 = rnn1(x, h1); x = x + h1   :196-198
+    unsigned long long* slot_prev = L.slots + (size_t)(pp ^ 1) * N + n0;  // written by fc3 of step s-1
+    unsigned long long* slot_cur = L.slots + (size_t)pp * N + n0;         // written by fc3 of this step
     memset(&k, 0, sizeof(k));
     k.w = w->w_rnn1.p; k.nseg = 2; k.nkb_total = 2 * R / 16;
     k.seg[0] = {x0, R, R / 16, 0}; k.seg[1] = {h1p, R, R / 16, 1};
     k.N = nl; k.units = R; k.biasX = w->b_ih1.p; k.biasH = w->b_hh1.p;
     k.h_prev = h1p; k.x_res = x0; k.h_out = h1n; k.x_out = x1;
+    if (fused) {  // x0 = Ipre[pos] + x_{s-1} * W_I[:,0] rebuilt inside the launch from the argmax word
+      frame_rows(k);
+      k.x_res = nullptr;
+      k.aff_slot = slot_prev; k.aff_table = L.Ipre; k.aff_vec = w->wI0.p; k.aff_gate = w->g1I0.p; k.aff_ld = R; k.aff_C = C; k.aff_S = S;
+      k.aff_samples = d_samples; k.aff_progress = h_progress;
+    }
     k.trace = tr ? tr + 0 : nullptr;
     if ((which & 1) && (r = rnn_launch(EPI_GRU, k, ls))) return r;
     // h2 = rnn2([x, a2], h2); x = x + h2   :199-202
@@ -604,6 +632,7 @@ extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* 
     k.N = nl; k.units = R; k.biasH = w->b_hh2.p;
     k.pre_table = L.G2; frame_rows(k); k.pre_stride = 3 * R;
     k.h_prev = h2p; k.x_res = x1; k.h_out = h2n; k.x_out = x2;
+    if (fused) k.zero_slot = slot_prev;  // free for fc3 of step s+1 once rnn1 of this step has read it
     k.trace = tr ? tr + 2 * TRACE_SLOTS : nullptr;
     if ((which & 2) && (r = rnn_launch(EPI_GRU, k, ls))) return r;
     // x = relu(fc1([x, a3]))   :203-204
@@ -624,9 +653,13 @@ extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* 
     memset(&k, 0, sizeof(k));
     k.w = w->w_fc3.p; k.nseg = 1; k.nkb_total = FC / 16; k.seg[0] = {y2, FC, FC / 16, 0};
     k.N = nl; k.units = C; k.biasX = w->b_fc3.p; k.y = lgt; k.ldy = C;
+    if (fused) {  // Gumbel-argmax sampler in the epilogue: logits never leave the launch
+      frame_rows(k);
+      k.y = nullptr; k.gum_slot = slot_cur; k.gum_seed = seed;
+    }
     k.trace = tr ? tr + 8 * TRACE_SLOTS : nullptr;
     if ((which & 16) && (r = rnn_launch(EPI_LINEAR, k, ls))) return r;
-    if (which & 32) {
+    if ((which & 32) && !fused) {
       SampK sk = make_sk(l);
       sk.step_off = soff;
       sk.trace = tr ? tr + 10 * TRACE_SLOTS : nullptr;
@@ -640,7 +673,7 @@ extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* 
 
   for (int l = 0; l < lanes; ++l) {
     if (l > 0) MB_HIP(hipStreamWaitEvent(w->lane_stream[l], w->ev_cond, 0));
-    hipLaunchKernelGGL(wavernn_init_kernel, dim3(lane_n0[l + 1] - lane_n0[l]), dim3(128), 0, w->lane_stream[l], make_sk(l));
+    if (!fused) hipLaunchKernelGGL(wavernn_init_kernel, dim3(lane_n0[l + 1] - lane_n0[l]), dim3(128), 0, w->lane_stream[l], make_sk(l));
     MB_HIP(hipGetLastError());
   }
 
@@ -692,6 +725,14 @@ extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* 
   for (int i = done; i < S && !rc; ++i)  // eager tail: step_base stays at `done`, the offset carries the step
     for (int l = 0; l < lanes && !rc; ++l) rc = step(l, i & 1, i - done, 0x3f & ~w->bench_which);
   if (rc) return rc;
+  if (fused) {
+    for (int l = 0; l < lanes; ++l) {
+      const int n0 = lane_n0[l], nl = lane_n0[l + 1] - n0;
+      hipLaunchKernelGGL(wavernn_flush_kernel, dim3(cdiv(nl, 64)), dim3(64), 0, w->lane_stream[l],
+                         L.slots + (size_t)((S - 1) & 1) * N + n0, d_samples + (size_t)n0 * S, nl, S, C);
+    }
+    MB_HIP(hipGetLastError());
+  }
   for (int l = 1; l < lanes; ++l) {  // join the lanes on lane 0
     MB_HIP(hipEventRecord(w->lane_ev[l], w->lane_stream[l]));
     MB_HIP(hipStreamWaitEvent(s, w->lane_ev[l], 0));
@@ -704,7 +745,7 @@ extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* 
     (void)hipFree(d_trace);
     if (FILE* f = fopen(trace_path, "wb")) { fwrite(host.data(), sizeof(unsigned long long), host.size(), f); fclose(f); }
   }
-  w->last_launches = 6 * S * lanes;
+  w->last_launches = (fused ? 5 : 6) * S * lanes;
   w->last_lanes = lanes;
   w->timed = true;
   MB_HIP(hipEventRecord(w->ev_out, s));

@@ -52,7 +52,13 @@ gap_next[:-1, 5] = (st[1:, 0] - en[:-1, 5]) * tick
 gap_next[-1, 5] = np.nan
 sl = slice(8, -1)
 res = {}
+live = [k for k in range(6) if nblk[k] > 0]
 for k, n in enumerate(names):
+    if k not in live:
+        continue
+    if k == live[-1]:
+        gap_next[:-1, k] = (st[1:, 0] - en[:-1, k]) * tick
+        gap_next[-1, k] = np.nan
     res[n] = dict(body_us=float(np.median(body[sl, k])), gap_after_us=float(np.nanmedian(gap_next[sl, k])))
     print(f"{n:7s} body {res[n]['body_us']:6.2f} us   gap-after {res[n]['gap_after_us']:6.2f} us")
 step = (st[1:, 0] - st[:-1, 0]) * tick
