@@ -216,6 +216,10 @@ typedef struct mb_taco_config {
   int lsa_kernel, lsa_filters;
   /* optional text encoder (tacotron.py:11-44,255): present when has_encoder != 0 */
   int has_encoder, num_chars, embed_dims, encoder_dims, encoder_K, speaker_dims, style_dims;
+  /* optional global style tokens (global_style_token.py:9-145, gst_hyperparameters.py): present when
+   * has_gst != 0 (needs has_encoder); style_dims = E */
+  int has_gst, gst_tokens, gst_heads, gst_n_convs, gst_width;
+  int gst_filters[8];
 } mb_taco_config;
 typedef struct mb_taco mb_taco;
 int mb_taco_num_weights(const mb_taco_config* cfg);
@@ -242,20 +246,26 @@ int mb_taco_decode(const mb_taco* t, const float* d_memory, const float* d_memor
                    float* d_mel, float* d_linear, float* d_attn, int* h_n_frames,
                    void* d_workspace, size_t workspace_bytes, mb_stream_t stream);
 
-/* Text encoder + attention-memory assembly (the once-per-chunk front half of
- * Tacotron.forward, tacotron.py:234-255, minus the tiny GST style network whose
- * output the caller passes in):
+/* Text encoder + global style token + attention-memory assembly (the once-per-chunk front
+ * half of Tacotron.forward, tacotron.py:234-255):
  *  d_chars   [B][T] int32, d_speaker [B][speaker_dims],
- *  d_style   [style_batch][style_dims] (style_batch 1 = broadcast, tacotron.py:243-249),
+ *  style_idx 0..gst_tokens-1: that token's value vector, broadcast (tacotron.py:243-248);
+ *            anything else: ReferenceEncoder(zeros) (+) speaker embedding -> multi-head attention
+ *            over all tokens, per utterance (tacotron.py:249-251; gen_voice.py passes -1).
+ *            The ReferenceEncoder output on the all-zero input is a constant of the checkpoint
+ *            and is folded at mb_taco_create time.
  *  d_dropout NULL -> on-device RNG(seed); else keep masks [2][B][T][encoder_dims]
  *            (encoder PreNet, pre_net.py:23,26)
  *  -> d_memory [B][T][project_dims], d_memory_proj [B][T][decoder_dims].
  * Encoder weights follow the decoder/postnet list of mb_taco_create:
  *   encoder.embedding, encoder.pre_net.fc1/fc2 (w,b), encoder.cbhg (bank K x (conv,BN4),
- *   proj1, proj2, highways, rnn fwd/rev), encoder_proj.weight. */
+ *   proj1, proj2, highways, rnn fwd/rev), encoder_proj.weight, then (has_gst)
+ *   gst.encoder.convs[i] (weight,bias) + bns[i] (weight,bias,running_mean,running_var) per conv,
+ *   gst.encoder.gru (weight_ih,weight_hh,bias_ih,bias_hh), gst.stl.embed,
+ *   gst.stl.attention.W_query/W_key/W_value. */
 size_t mb_taco_encode_workspace_bytes(const mb_taco* t, int batch, int t_text);
-int mb_taco_encode(const mb_taco* t, const int32_t* d_chars, const float* d_speaker, const float* d_style,
-                   int style_batch, int batch, int t_text, const float* d_dropout, uint64_t seed,
+int mb_taco_encode(const mb_taco* t, const int32_t* d_chars, const float* d_speaker, int style_idx,
+                   int batch, int t_text, const float* d_dropout, uint64_t seed,
                    float* d_memory, float* d_memory_proj, void* d_workspace, size_t workspace_bytes,
                    mb_stream_t stream);
 

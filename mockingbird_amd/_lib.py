@@ -73,6 +73,8 @@ class TacoConfig(C.Structure):
         ("lsa_kernel", C.c_int), ("lsa_filters", C.c_int),
         ("has_encoder", C.c_int), ("num_chars", C.c_int), ("embed_dims", C.c_int), ("encoder_dims", C.c_int),
         ("encoder_K", C.c_int), ("speaker_dims", C.c_int), ("style_dims", C.c_int),
+        ("has_gst", C.c_int), ("gst_tokens", C.c_int), ("gst_heads", C.c_int), ("gst_n_convs", C.c_int),
+        ("gst_width", C.c_int), ("gst_filters", C.c_int * 8),
     ]
 
 
@@ -116,7 +118,7 @@ SIGNATURES = {
                                  C.c_int, C.c_float, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_size_t, C.c_void_p]),
     "mb_taco_encode_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
-    "mb_taco_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+    "mb_taco_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                  C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mb_maximum_path": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                   C.c_int, C.c_void_p]),

@@ -429,6 +429,55 @@ __global__ void dropout_cm_kernel(float* __restrict__ y, const float* __restrict
   }
 }
 
+// Global style token, inference branches of tacotron.py:243-251 + global_style_token.py:93-145.
+//  style_idx in [0, tokens): query = 0 -> one key -> softmax over a single score = 1 -> value row.
+//  otherwise: q = W_query [ref_h ; speaker] (ref_h = ReferenceEncoder(zeros), folded into qconst at
+//  load), scores_h = q_h . K_h^T / sqrt(d_k), softmax over the tokens, out_h = scores_h V_h.
+// K = W_key tanh(embed), V = W_value tanh(embed) are checkpoint constants, WqS = W_query[:, E/2:]^T.
+__global__ __launch_bounds__(256) void gst_style_kernel(const float* __restrict__ spk, const float* __restrict__ qconst,
+                                                        const float* __restrict__ WqS, const float* __restrict__ Kt,
+                                                        const float* __restrict__ Vt, float* __restrict__ out, int S, int E,
+                                                        int tokens, int heads, int style_idx) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // spk[S] | q[E] | sc[heads*tokens]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (style_idx >= 0 && style_idx < tokens) {
+    for (int d = tid; d < E; d += 256) out[(size_t)b * E + d] = Vt[(size_t)style_idx * E + d];
+    return;
+  }
+  float* sp = sm; float* q = sm + S; float* sc = q + E;
+  for (int k = tid; k < S; k += 256) sp[k] = spk[(size_t)b * S + k];
+  __syncthreads();
+  for (int d = tid; d < E; d += 256) {
+    float acc = 0.f;
+    for (int k = 0; k < S; ++k) acc += WqS[(size_t)k * E + d] * sp[k];
+    q[d] = qconst[d] + acc;
+  }
+  __syncthreads();
+  const int dk = E / heads;
+  const float inv = 1.0f / sqrtf((float)dk);
+  for (int t = tid; t < heads * tokens; t += 256) {
+    const int h = t / tokens, j = t - h * tokens;
+    float acc = 0.f;
+    for (int dd = 0; dd < dk; ++dd) acc += q[h * dk + dd] * Kt[(size_t)j * E + h * dk + dd];
+    sc[t] = acc * inv;
+  }
+  __syncthreads();
+  if (tid < heads) {
+    float m = -INFINITY;
+    for (int j = 0; j < tokens; ++j) m = fmaxf(m, sc[tid * tokens + j]);
+    float ssum = 0.f;
+    for (int j = 0; j < tokens; ++j) { const float e = expf(sc[tid * tokens + j] - m); sc[tid * tokens + j] = e; ssum += e; }
+    for (int j = 0; j < tokens; ++j) sc[tid * tokens + j] /= ssum;
+  }
+  __syncthreads();
+  for (int d = tid; d < E; d += 256) {
+    const int h = d / dk;
+    float acc = 0.f;
+    for (int j = 0; j < tokens; ++j) acc += sc[h * tokens + j] * Vt[(size_t)j * E + d];
+    out[(size_t)b * E + d] = acc;
+  }
+}
+
 // memory[b][t] = [enc_seq[b][:, t] | speaker[b] | style[b]]; projres[b][t][d] = Wp[d][Ce:] . [speaker; style]
 __global__ __launch_bounds__(256) void assemble_memory_kernel(const float* __restrict__ seq, const float* __restrict__ spk,
                                                               const float* __restrict__ style, int style_batch,
@@ -474,7 +523,94 @@ struct mb_taco {
   ConvL enc_fc1, enc_fc2, enc_proj;
   DevBuf enc_proj_full;  // encoder_proj.weight [D][P] (speaker/style columns used by assemble_memory)
   Cbhg enc;
+  // global style tokens: checkpoint constants folded at load (see gst_style_kernel)
+  DevBuf gst_qconst, gst_WqS, gst_K, gst_V;
 };
+
+// ReferenceEncoder(zeros) -> ref_h, then the style-token constants (double precision on the host:
+// this is weight preprocessing like BatchNorm folding, not part of the per-request path).
+// global_style_token.py:31-76 (6 x [Conv2d 3x3 s2 p1, BN, ReLU], GRU) on the all-zero input the
+// inference branch feeds (tacotron.py:250); :79-145 (STL + multi-head attention).
+static int fold_gst(mb_taco* t, const float* const* hw, int* pix) {
+  const mb_taco_config& c = t->cfg;
+  int ix = *pix;
+  const int E = c.style_dims, Eh = E / 2, S = c.speaker_dims, dk = E / c.gst_heads, NTK = c.gst_tokens;
+  int Hh = S / c.gst_width, Wd = c.gst_width, fin = 1;
+  std::vector<double> x((size_t)Hh * Wd, 0.0), y;
+  for (int l = 0; l < c.gst_n_convs; ++l) {
+    const int fo = c.gst_filters[l], Ho = (Hh - 1) / 2 + 1, Wo = (Wd - 1) / 2 + 1;
+    const float *cw = hw[ix], *cb = hw[ix + 1], *bw = hw[ix + 2], *bb = hw[ix + 3], *bm = hw[ix + 4], *bv = hw[ix + 5];
+    ix += 6;
+    y.assign((size_t)fo * Ho * Wo, 0.0);
+    for (int co = 0; co < fo; ++co) {
+      const double sc = (double)bw[co] / std::sqrt((double)bv[co] + 1e-5);
+      for (int oy = 0; oy < Ho; ++oy)
+        for (int ox = 0; ox < Wo; ++ox) {
+          double acc = cb[co];
+          for (int ci = 0; ci < fin; ++ci)
+            for (int ky = 0; ky < 3; ++ky) {
+              const int iy = oy * 2 - 1 + ky;
+              if (iy < 0 || iy >= Hh) continue;
+              for (int kx = 0; kx < 3; ++kx) {
+                const int jx = ox * 2 - 1 + kx;
+                if (jx < 0 || jx >= Wd) continue;
+                acc += (double)cw[(((size_t)co * fin + ci) * 3 + ky) * 3 + kx] * x[((size_t)ci * Hh + iy) * Wd + jx];
+              }
+            }
+          const double v = (acc - (double)bm[co]) * sc + (double)bb[co];
+          y[((size_t)co * Ho + oy) * Wo + ox] = v > 0.0 ? v : 0.0;
+        }
+    }
+    x.swap(y); fin = fo; Hh = Ho; Wd = Wo;
+  }
+  // [N, C, T', W'] -> [N, T', C*W'] -> GRU(h0 = 0), last hidden state
+  const float *wih = hw[ix], *whh = hw[ix + 1], *bih = hw[ix + 2], *bhh = hw[ix + 3];
+  ix += 4;
+  const int gin = fin * Wd;
+  std::vector<double> h(Eh, 0.0), hn(Eh), gi(3 * Eh), gh(3 * Eh);
+  for (int tt = 0; tt < Hh; ++tt) {
+    for (int r = 0; r < 3 * Eh; ++r) {
+      double a = bih[r], b = bhh[r];
+      for (int ch = 0; ch < fin; ++ch)
+        for (int xx = 0; xx < Wd; ++xx) a += (double)wih[(size_t)r * gin + ch * Wd + xx] * x[((size_t)ch * Hh + tt) * Wd + xx];
+      for (int k = 0; k < Eh; ++k) b += (double)whh[(size_t)r * Eh + k] * h[k];
+      gi[r] = a; gh[r] = b;
+    }
+    for (int j = 0; j < Eh; ++j) {
+      const double rg = 1.0 / (1.0 + std::exp(-(gi[j] + gh[j])));
+      const double zg = 1.0 / (1.0 + std::exp(-(gi[Eh + j] + gh[Eh + j])));
+      const double ng = std::tanh(gi[2 * Eh + j] + rg * gh[2 * Eh + j]);
+      hn[j] = (1.0 - zg) * ng + zg * h[j];
+    }
+    h = hn;
+  }
+  const float *emb = hw[ix], *Wq = hw[ix + 1], *Wk = hw[ix + 2], *Wv = hw[ix + 3];
+  ix += 4;
+  const int dq = Eh + S;
+  std::vector<float> qconst(E), WqS((size_t)S * E), Kt((size_t)NTK * E), Vt((size_t)NTK * E);
+  for (int d = 0; d < E; ++d) {
+    double a = 0.0;
+    for (int k = 0; k < Eh; ++k) a += (double)Wq[(size_t)d * dq + k] * h[k];
+    qconst[d] = (float)a;
+    for (int k = 0; k < S; ++k) WqS[(size_t)k * E + d] = Wq[(size_t)d * dq + Eh + k];
+    for (int j = 0; j < NTK; ++j) {
+      double ak = 0.0, av = 0.0;
+      for (int q = 0; q < dk; ++q) {
+        const double key = std::tanh((double)emb[(size_t)j * dk + q]);
+        ak += (double)Wk[(size_t)d * dk + q] * key;
+        av += (double)Wv[(size_t)d * dk + q] * key;
+      }
+      Kt[(size_t)j * E + d] = (float)ak;
+      Vt[(size_t)j * E + d] = (float)av;
+    }
+  }
+  int rc = t->gst_qconst.upload(qconst.data(), qconst.size());
+  if (!rc) rc = t->gst_WqS.upload(WqS.data(), WqS.size());
+  if (!rc) rc = t->gst_K.upload(Kt.data(), Kt.size());
+  if (!rc) rc = t->gst_V.upload(Vt.data(), Vt.size());
+  *pix = ix;
+  return rc;
+}
 
 static int taco_shapes(const mb_taco_config* c, std::vector<size_t>* n) {
   MB_REQUIRE(c, "taco: null config");
@@ -503,6 +639,21 @@ static int taco_shapes(const mb_taco_config* c, std::vector<size_t>* n) {
     n->push_back(Ce * Em); n->push_back(Ce); n->push_back(Ce * Ce); n->push_back(Ce);               // encoder.pre_net
     cbhg_shapes(n, Ce, Ce, Ce, Ce, c->encoder_K, c->num_highways);                                   // encoder.cbhg
     n->push_back(D * P);                                                                             // encoder_proj
+    if (c->has_gst) {
+      MB_REQUIRE(c->gst_tokens > 0 && c->gst_heads > 0 && c->style_dims % (2 * c->gst_heads) == 0 && c->gst_n_convs >= 1 &&
+                 c->gst_n_convs <= 8 && c->gst_width > 0 && c->speaker_dims % c->gst_width == 0, "taco: bad GST config");
+      const size_t E = c->style_dims, dk = E / c->gst_heads;
+      size_t fin = 1, wd = c->gst_width;
+      for (int i = 0; i < c->gst_n_convs; ++i) {
+        const size_t fo = c->gst_filters[i];
+        n->push_back(fo * fin * 9); n->push_back(fo);
+        for (int j = 0; j < 4; ++j) n->push_back(fo);
+        fin = fo; wd = (wd - 1) / 2 + 1;
+      }
+      n->push_back(3 * (E / 2) * fin * wd); n->push_back(3 * (E / 2) * (E / 2)); n->push_back(3 * (E / 2)); n->push_back(3 * (E / 2));
+      n->push_back((size_t)c->gst_tokens * dk);
+      n->push_back(E * (E / 2 + c->speaker_dims)); n->push_back(E * dk); n->push_back(E * dk);
+    }
   }
   return MB_OK;
 }
@@ -583,6 +734,7 @@ extern "C" int mb_taco_create(const mb_taco_config* cfg, const float* const* hw,
       RC(t->enc_proj_full.upload(hw[ix], (size_t)D * P));
       ix += 1;
     }
+    if (cfg->has_gst && !rc) rc = fold_gst(t, hw, &ix);
   }
 #undef RC
   if (rc) { mb_taco_destroy(t); return rc; }
@@ -595,7 +747,7 @@ extern "C" void mb_taco_destroy(mb_taco* t) {
   DevBuf* bs[] = {&t->pre1_w, &t->pre1_b, &t->pre2_w, &t->pre2_b, &t->lsa_conv_w, &t->lsa_conv_b, &t->lsa_L, &t->lsa_W,
                   &t->lsa_Wb, &t->lsa_v, &t->attn_w, &t->attn_bih, &t->attn_bhh, &t->rin_w, &t->rin_b, &t->l1_w,
                   &t->l1_bih, &t->l1_bhh, &t->l2_w, &t->l2_bih, &t->l2_bhh, &t->mel_w, &t->stop_w, &t->stop_b,
-                  &t->emb, &t->enc_proj_full};
+                  &t->emb, &t->enc_proj_full, &t->gst_qconst, &t->gst_WqS, &t->gst_K, &t->gst_V};
   for (DevBuf* b : bs) b->release();
   t->post.release(); t->post_proj.release(); t->enc.release();
   t->enc_fc1.release(); t->enc_fc2.release(); t->enc_proj.release();
@@ -790,7 +942,7 @@ extern "C" int mb_taco_decode(const mb_taco* t, const float* d_memory, const flo
 }
 
 namespace {
-struct EncLayout { float *xe, *p1, *p2, *projres; CbhgWs cb; size_t bytes; };
+struct EncLayout { float *xe, *p1, *p2, *projres, *style; CbhgWs cb; size_t bytes; };
 void enc_layout(const mb_taco* t, int B, int T, void* base, EncLayout* L) {
   const mb_taco_config& c = t->cfg;
   Arena ar(base, (size_t)-1);
@@ -798,6 +950,7 @@ void enc_layout(const mb_taco* t, int B, int T, void* base, EncLayout* L) {
   L->p1 = ar.take<float>((size_t)B * c.encoder_dims * T);
   L->p2 = ar.take<float>((size_t)B * c.encoder_dims * T);
   L->projres = ar.take<float>((size_t)B * T * c.decoder_dims);
+  L->style = ar.take<float>((size_t)B * std::max(c.style_dims, 1));
   cbhg_take(ar, t->enc, B, T, &L->cb);
   L->bytes = ar.off + 256;
 }
@@ -810,13 +963,14 @@ extern "C" size_t mb_taco_encode_workspace_bytes(const mb_taco* t, int batch, in
   return L.bytes;
 }
 
-extern "C" int mb_taco_encode(const mb_taco* t, const int32_t* d_chars, const float* d_speaker, const float* d_style,
-                              int style_batch, int batch, int t_text, const float* d_dropout, uint64_t seed,
+extern "C" int mb_taco_encode(const mb_taco* t, const int32_t* d_chars, const float* d_speaker, int style_idx,
+                              int batch, int t_text, const float* d_dropout, uint64_t seed,
                               float* d_memory, float* d_memory_proj, void* d_workspace, size_t workspace_bytes,
                               mb_stream_t stream) {
-  MB_REQUIRE(t && d_chars && d_speaker && d_style && d_memory && d_memory_proj, "taco_encode: null pointer");
+  MB_REQUIRE(t && d_chars && d_speaker && d_memory && d_memory_proj, "taco_encode: null pointer");
   MB_REQUIRE(t->cfg.has_encoder, "taco_encode: handle was created without encoder weights");
-  MB_REQUIRE(batch > 0 && t_text > 0 && (style_batch == 1 || style_batch == batch), "taco_encode: bad shape");
+  MB_REQUIRE(batch > 0 && t_text > 0, "taco_encode: bad shape");
+  MB_REQUIRE(t->cfg.style_dims == 0 || t->cfg.has_gst, "taco_encode: style_dims > 0 but the handle has no GST weights");
   EncLayout L;
   enc_layout(t, batch, t_text, d_workspace, &L);
   if (!d_workspace || workspace_bytes < L.bytes) {
@@ -842,7 +996,15 @@ extern "C" int mb_taco_encode(const mb_taco* t, const int32_t* d_chars, const fl
   // speaker + style concat (tacotron.py:171-197, 253) and encoder_proj (:255)
   if (!rc) {
     const size_t lds = sizeof(float) * (c.speaker_dims + c.style_dims + D);
-    hipLaunchKernelGGL(assemble_memory_kernel, dim3(B), dim3(256), lds, s, L.cb.seq, d_speaker, d_style, style_batch,
+    int style_batch = 1;
+    if (c.has_gst) {
+      const bool token = style_idx >= 0 && style_idx < c.gst_tokens;
+      style_batch = token ? 1 : B;
+      const size_t lg = sizeof(float) * (c.speaker_dims + c.style_dims + c.gst_heads * c.gst_tokens);
+      hipLaunchKernelGGL(gst_style_kernel, dim3(style_batch), dim3(256), lg, s, d_speaker, t->gst_qconst.p, t->gst_WqS.p,
+                         t->gst_K.p, t->gst_V.p, L.style, c.speaker_dims, c.style_dims, c.gst_tokens, c.gst_heads, style_idx);
+    }
+    hipLaunchKernelGGL(assemble_memory_kernel, dim3(B), dim3(256), lds, s, L.cb.seq, d_speaker, L.style, style_batch,
                        t->enc_proj_full.p, d_memory, L.projres, T, Ce, c.speaker_dims, c.style_dims, D);
     MB_HIP(hipGetLastError());
   }

@@ -9,14 +9,13 @@ import numpy as np
 import torch
 
 from .. import _lib, weights
-from . import frontend
 from .hparams import hparams
 from .text import symbols, text_to_sequence, to_pinyin
 
 
 class TacotronDevice:
-    """Weights resident in HBM: decoder + postnet inside an ``mb_taco`` handle, the
-    once-per-chunk encoder/GST weights as device tensors for the torch-op front-end."""
+    """Weights resident in HBM inside an ``mb_taco`` handle: text encoder, global style tokens,
+    decoder loop and postnet all run as HIP kernels (no torch op touches the data path)."""
 
     def __init__(self, state_dict, device, r=None):
         self.device = device
@@ -34,8 +33,6 @@ class TacotronDevice:
         h = C.c_void_p()
         _lib.check(L.mb_taco_create(C.byref(self.cfg), _lib.host_ptr_array(ws), len(ws), C.byref(h)), "mb_taco_create")
         self._h = h
-        self.front = {k: v.detach().to(device, torch.float32) for k, v in state_dict.items()
-                      if k.startswith("gst.") and v.is_floating_point()}
         self._ws = None
         self._ews = None
 
@@ -79,9 +76,6 @@ class TacotronDevice:
         dev = chars.device
         B, T = chars.shape
         spk = speaker_embedding.to(dev, torch.float32).contiguous()
-        style = frontend.style_embed(self.front, hparams, spk, style_idx)
-        if style is None:
-            style = torch.zeros(1, max(self.cfg.style_dims, 1), device=dev)
         L = _lib.lib()
         need = L.mb_taco_encode_workspace_bytes(self._h, B, T)
         if self._ews is None or self._ews.numel() < need or self._ews.device != dev:
@@ -93,7 +87,7 @@ class TacotronDevice:
             enc_masks = torch.as_tensor(enc_masks).to(dev, torch.float32).contiguous()
             if tuple(enc_masks.shape) != (2, B, T, self.cfg.encoder_dims):
                 raise _lib.MbHipError(f"encoder masks must be {(2, B, T, self.cfg.encoder_dims)}, got {tuple(enc_masks.shape)}")
-        _lib.check(L.mb_taco_encode(self._h, _lib.ptr(chars32), _lib.ptr(spk), _lib.ptr(style), style.shape[0], B, T,
+        _lib.check(L.mb_taco_encode(self._h, _lib.ptr(chars32), _lib.ptr(spk), int(style_idx), B, T,
                                     _lib.ptr(enc_masks), int(seed) ^ 0x5EED, _lib.ptr(memory), _lib.ptr(memory_proj),
                                     _lib.ptr(self._ews), self._ews.numel(), _lib.stream_ptr()), "mb_taco_encode")
         return memory, memory_proj

@@ -151,6 +151,19 @@ def taco_config(state: Dict[str, torch.Tensor], r: int = None, max_r: int = 20) 
         c.encoder_K = sum(1 for k in state if k.startswith("encoder.cbhg.conv1d_bank.") and k.endswith(".conv.weight"))
         c.style_dims = state["gst.stl.attention.W_value.weight"].shape[0] if "gst.stl.attention.W_value.weight" in state else 0
         c.speaker_dims = c.project_dims - c.encoder_dims - c.style_dims
+        if c.style_dims:
+            c.has_gst = 1
+            emb = state["gst.stl.embed"]
+            c.gst_tokens = emb.shape[0]
+            c.gst_heads = c.style_dims // emb.shape[1]
+            n = 0
+            while f"gst.encoder.convs.{n}.weight" in state:
+                c.gst_filters[n] = state[f"gst.encoder.convs.{n}.weight"].shape[0]
+                n += 1
+            c.gst_n_convs = n
+            # ReferenceEncoder views its (all-zero, [N,1,speaker_embedding_size]) input as [N,1,-1,n_mels]
+            # with GSTHyperparameters.n_mels = 256 (global_style_token.py:55, gst_hyperparameters.py:13)
+            c.gst_width = 256 if c.speaker_dims % 256 == 0 else c.speaker_dims
     return c
 
 
@@ -194,4 +207,11 @@ def taco_weight_list(state: Dict[str, torch.Tensor], cfg: "_lib.TacoConfig") -> 
         for sfx in ("", "_reverse"):
             names += [f"{q}rnn.weight_ih_l0{sfx}", f"{q}rnn.weight_hh_l0{sfx}", f"{q}rnn.bias_ih_l0{sfx}", f"{q}rnn.bias_hh_l0{sfx}"]
         names += ["encoder_proj.weight"]
+        if cfg.has_gst:
+            g = "gst.encoder."
+            for i in range(cfg.gst_n_convs):
+                names += [f"{g}convs.{i}.weight", f"{g}convs.{i}.bias"] + bn(f"{g}bns.{i}")
+            names += [g + "gru.weight_ih_l0", g + "gru.weight_hh_l0", g + "gru.bias_ih_l0", g + "gru.bias_hh_l0",
+                      "gst.stl.embed", "gst.stl.attention.W_query.weight", "gst.stl.attention.W_key.weight",
+                      "gst.stl.attention.W_value.weight"]
     return [_f32(state[n]) for n in names]

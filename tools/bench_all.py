@@ -54,7 +54,6 @@ for kind, cfg, mflop in (("hifigan", synth.HIFIGAN_16K, 352.1), ("fregan", synth
 
 # Tacotron configs[2]: B=32 (one batch) ~100 tokens, r=2, 400 steps forced
 from mockingbird_amd.synthesizer.inference import TacotronDevice
-from mockingbird_amd.synthesizer import frontend
 from mockingbird_amd.synthesizer.hparams import hparams
 st = synth.tacotron_state(seed=3)["model_state"]
 dev = TacotronDevice(st, torch.device("cuda"))
@@ -64,7 +63,7 @@ chars = torch.tensor(np.stack([np.pad(s, (0, T - len(s))) for s in seqs])).long(
 spk = torch.tensor(np.stack(emb))
 cg, sg = chars.cuda(), spk.cuda()
 tg_full = gpu_time(lambda: dev.generate(cg, sg, steps=400, style_idx=-1, min_stop_token=11, seed=1), reps=3)
-mem, memp = frontend.encoder_memory(dev.front, hparams, cg, sg, -1)
+mem, memp = dev.encode(cg, sg, -1, None, 1)
 tg_dec = gpu_time(lambda: dev.decode(mem, memp, cg, 400, 11, seed=1), reps=3)
 rec = {"gpu_generate_s": tg_full, "gpu_decode_postnet_s": tg_dec, "frames_per_s": 32 * 400 / tg_full,
        "xRT_at_200_samples_per_frame": 32 * 400 * 200 / tg_full / 16000, "decoder_us_per_iteration_incl_postnet": tg_dec / 200 * 1e6}
