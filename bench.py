@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=1000, help="mel frames per utterance (BASELINE configs[1]: 1000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hifigan", action="store_true")
+    ap.add_argument("--no-tacotron", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -134,7 +135,7 @@ def main():
         ws = model._ws
         smp = torch.empty(plan.n_folds, plan.seq_len, device=dev)
         per_kernel = {}
-        for which, name in ((1, "rnn2_gru"), (2, "fc1"), (3, "fc2"), (4, "fc3")):
+        for which, name in ((0, "rnn1_gru"), (1, "rnn2_gru"), (2, "fc1"), (3, "fc2"), (4, "fc3_sampler")):
             us, ab = C.c_float(), C.c_double()
             _lib.check(L.mb_wavernn_bench_kernel(model._h, C.byref(plan), _lib.ptr(mel), _lib.ptr(smp),
                                                  _lib.ptr(ws), ws.numel(), which, 0, C.byref(us), C.byref(ab),
@@ -143,10 +144,18 @@ def main():
             per_kernel[name] = {"avg_us": us.value, "algorithmic_bytes": ab.value,
                                 "GBps": ab.value / (us.value * 1e-6) / 1e9}
         dom = per_kernel["rnn2_gru"]
+        # HBM traffic of that kernel from the committed rocprofv3 PMC pass (FETCH_SIZE doubled per
+        # MI355X_MICROARCH.md's gfx950 correction + WRITE_SIZE); counters cannot be read in-process
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_wavernn.json")))
+            traffic = pm.get("rnn2_gru_hbm_bytes_per_launch")
+        except Exception:
+            pass
         result["roofline"] = {
-            "kernel": "mb::rnn_rowtile_kernel<1, 8> (EPI_GRU; WaveRNN rnn2 instance, in-situ marginal duration)",
+            "kernel": "mb::rnn_rowtile_kernel<EPI_GRU, 1, 8, ...> (WaveRNN rnn2 instance, in-situ marginal duration)",
             "bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": None,
+            "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes_per_launch": dom["algorithmic_bytes"], "avg_launch_us": dom["avg_us"],
             "whole_step": {"algorithmic_bytes": 16.3e6 + 452.0 * plan.n_folds,
                            "us": result["config"]["us_per_time_step"],
@@ -178,6 +187,40 @@ def main():
                 "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
                              "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
                              "traffic": None},
+            }
+        # ---- secondary: Tacotron synthesize (BASELINE configs[2]): B=32, ~100 tokens, r=2, 400 frames forced
+        if not args.no_tacotron:
+            from mockingbird_amd.synthesizer.inference import TacotronDevice
+            tst = synth.tacotron_state(seed=3)["model_state"]
+            tdev = TacotronDevice(tst, dev)
+            seqs, emb = synth.tacotron_inputs(32, 90, 110, seed=2)
+            Tt = max(len(q) for q in seqs)
+            chars = torch.tensor(np.stack([np.pad(q, (0, Tt - len(q))) for q in seqs])).long().to(dev)
+            spk = torch.tensor(np.stack(emb)).to(dev)
+            tdev.generate(chars, spk, steps=400, style_idx=-1, min_stop_token=11, seed=1)
+            torch.cuda.synchronize()
+            t0t = time.perf_counter()
+            reps = 3
+            for i in range(reps):
+                tdev.generate(chars, spk, steps=400, style_idx=-1, min_stop_token=11, seed=2 + i)
+            torch.cuda.synchronize()
+            tt = (time.perf_counter() - t0t) / reps
+            mem, memp = tdev.encode(chars, spk, -1, None, 1)
+            torch.cuda.synchronize()
+            t0t = time.perf_counter()
+            for i in range(reps):
+                tdev.decode(mem, memp, chars, 400, 11, seed=2 + i)
+            torch.cuda.synchronize()
+            td = (time.perf_counter() - t0t) / reps
+            result["tacotron"] = {
+                "workload": "Tacotron generate (text encoder + GST + 200 decoder iterations r=2 + CBHG postnet), "
+                            f"batch 32 x ~100 tokens (T={Tt}), 400 mel frames forced, fp32, on-device dropout RNG",
+                "value": 32 * 400 / tt, "unit": "mel frames/s", "x_realtime_at_200_samples_per_frame": 32 * 400 * 200 / tt / 16000.0,
+                "ms_per_batch": tt * 1e3, "decode_plus_postnet_ms": td * 1e3,
+                "roofline": {"bound": "hbm", "kernel": "decoder iteration (9 launches; 81.06 MB fp32 weights + attention memory)",
+                             "achieved": (81.06e6 + 32 * Tt * (1024 + 128) * 4) * 200 / td / 1e9, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": (81.06e6 + 32 * Tt * (1024 + 128) * 4) * 200 / td / 1e9 / HBM_PEAK_GBS,
+                             "traffic": None, "note": "upper bound on the loop's rate: the postnet time is inside decode_plus_postnet_ms"},
             }
         # ---- CPU baseline: the oracle (reference's ATen CPU arithmetic) on a bounded sample
         if not args.no_cpu_baseline:

@@ -194,8 +194,8 @@ int mb_wavernn_generate(const mb_wavernn* w, const mb_wavernn_plan* plan,
  * number of kernel launches in it. */
 int mb_wavernn_last_loop_ms(const mb_wavernn* w, float* ms, int* launches);
 /* Measurement hook (bench.py roofline leg): runs the real generate loop twice on its
- * stream, bracketed by hipEvents, with and without kernel `which` (1 rnn2 GRU, 2 fc1,
- * 3 fc2, 4 fc3); the loop's kernels run back to back, so the per-step difference is that
+ * stream, bracketed by hipEvents, with and without kernel `which` (0 rnn1 GRU, 1 rnn2 GRU,
+ * 2 fc1, 3 fc2, 4 fc3); the loop's kernels run back to back, so the per-step difference is that
  * kernel's launch-to-launch duration.  Also reports that launch's algorithmic bytes
  * (weights once + vectors in/out + table rows, fp32).  `iters` is ignored. */
 int mb_wavernn_bench_kernel(mb_wavernn* w, const mb_wavernn_plan* plan, const float* d_mel,

@@ -39,6 +39,10 @@ struct LsaK {
   float* attn_out;        // [B][n_iter_max][T] (row `iter`)
   int T, D, P, Fl, Kl, iter, n_iter_max, psplit;
   const int* skip_flag;
+  // fast path (lsa_fast_kernel): conv and L folded into one D x Kl tap matrix, W transposed
+  const float* Mt;   // [Kl][D]  M = L . conv_w   (location features -> processed location in one 31-tap conv)
+  const float* c0;   // [D]      L . conv_b
+  const float* Wt;   // [D(k)][D(d)] W^T
 };
 
 // One workgroup (8 waves) per (utterance, quarter of the context columns).  The attention
@@ -167,6 +171,166 @@ __global__ __launch_bounds__(512) void lsa_kernel(LsaK a) {
       *reinterpret_cast<float4*>(a.context + (size_t)b * a.P + p0 + c4) = r;
     }
     __syncthreads();
+  }
+}
+
+// Latency-first LSA for the production shape (D = 128, context column group of 256, Kl <= 32,
+// T <= 4*TJ).  The old kernel walked the text positions with a global load inside every loop
+// iteration (one L2/HBM round trip per position: 73 us per decoder iteration, rocprofv3
+// profiles/r01_bench_kernel_stats.csv); here
+//   * every global load -- query, cumulative attention, this thread's mem_proj column, its tap-matrix
+//     row, its W^T quarter, the context rows -- is issued before the first wait,
+//   * conv1d(1->32,k=31) followed by L (32->128) is one 31-tap conv with the folded matrix M = L.conv_w,
+//     evaluated from registers: thread (d, quarter q) owns positions [q*TQ, (q+1)*TQ) and slides a
+//     register window over the cumulative attention,
+//   * 5 workgroup barriers in total.
+// tanh is evaluated as 1 - 2/(exp(2x)+1) (absolute error ~1e-7, the parity bar on attention is 1e-4).
+template <int TJ>
+__global__ __launch_bounds__(512) void lsa_fast_kernel(LsaK a) {
+  constexpr int D = 128, KL = 31, TMAX = 4 * TJ, TM = TMAX / 8, PW = 256;
+  __shared__ __attribute__((aligned(16))) float s_cum[TMAX + 64];   // zero padded by `half` on both sides
+  __shared__ __attribute__((aligned(16))) float s_q[D];
+  __shared__ __attribute__((aligned(16))) float s_pq[4][D];
+  __shared__ __attribute__((aligned(16))) float s_up[TMAX][2];
+  __shared__ __attribute__((aligned(16))) float s_u[TMAX];
+  __shared__ __attribute__((aligned(16))) float4 s_part[8][64];
+  const int b = blockIdx.x, pg = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int d = tid & (D - 1), tq = __builtin_amdgcn_readfirstlane(tid >> 7);
+  const int T = a.T, P = a.P, half = (a.Kl - 1) / 2;
+  const int TQ = (T + 3) >> 2, t0 = tq * TQ;  // this thread's positions [t0, t0 + TQ)
+  int skip = 0;
+  if (a.skip_flag) skip = *a.skip_flag;
+
+  // ---- phase 0: every global load ----
+  const float qv = (tid < D) ? a.query[(size_t)b * D + tid] : 0.f;          // fresh (attention GRU output)
+  const float* cg = a.cum_in + (size_t)b * T;
+  float cpre[(TMAX + 64 + 511) / 512];
+#pragma unroll
+  for (int m = 0; m < (TMAX + 64 + 511) / 512; ++m) {
+    const int i2 = tid + 512 * m, t = i2 - half;
+    cpre[m] = (i2 < T + 2 * half && t >= 0 && t < T) ? cg[t] : 0.f;
+  }
+  float wq[32];   // W^T[k][d] for k in this thread's quarter: coalesced over d
+#pragma unroll
+  for (int k = 0; k < 32; ++k) wq[k] = a.Wt[(size_t)(tq * 32 + k) * D + d];
+  float mrow[KL];  // folded tap matrix column of this d
+#pragma unroll
+  for (int j = 0; j < KL; ++j) mrow[j] = (j < a.Kl) ? a.Mt[(size_t)j * D + d] : 0.f;
+  const float* mp = a.mem_proj + (size_t)b * T * D;
+  float mpv[TJ];
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    const int t = t0 + j;
+    mpv[j] = (j < TQ && t < T) ? mp[(size_t)t * D + d] : 0.f;
+  }
+  const float vd = a.vw[d], wb = a.Wb[d], c0d = a.c0[d];
+  // staging
+  if (tid < D) s_q[tid] = qv;
+#pragma unroll
+  for (int m = 0; m < (TMAX + 64 + 511) / 512; ++m) {
+    const int i2 = tid + 512 * m;
+    if (i2 < TMAX + 64) s_cum[i2] = cpre[m];
+  }
+  __syncthreads();  // B1
+  // ---- phase 1: processed query partials (lsa.py:25) ----
+  {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc += wq[k] * s_q[tq * 32 + k];
+    s_pq[tq][d] = acc;
+  }
+  // context rows (stable data): requested now, consumed after the softmax
+  const int p0 = pg * PW;
+  const float* mem = a.memory + (size_t)b * T * P + p0 + lane * 4;
+  float4 memv[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int t = wave + 8 * j;
+    memv[j] = (t < T) ? *reinterpret_cast<const float4*>(mem + (size_t)t * P) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // chars of this thread's softmax positions (mask), requested early as well
+  int chv[(TMAX + 63) / 64];
+#pragma unroll
+  for (int m = 0; m < (TMAX + 63) / 64; ++m) {
+    const int t = lane + 64 * m;
+    chv[m] = (t < T) ? a.chars[(size_t)b * T + t] : 0;
+  }
+  __syncthreads();  // B2
+  const float pqd = ((s_pq[0][d] + s_pq[1][d]) + (s_pq[2][d] + s_pq[3][d])) + wb;
+  // ---- phase 2+3: location term from a sliding register window, energies, reduction over d ----
+  {
+    float win[TJ + KL - 1];
+#pragma unroll
+    for (int m = 0; m < TJ + KL - 1; ++m) win[m] = s_cum[t0 + m < TMAX + 64 ? t0 + m : 0];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      float pl = c0d;
+#pragma unroll
+      for (int jj = 0; jj < KL; ++jj) pl += mrow[jj] * win[j + jj];
+      const float x = (pqd + mpv[j]) + pl;
+      const float th = 1.f - 2.f / (__expf(2.f * x) + 1.f);
+      const float e = wave_sum(vd * th);
+      if (lane == 0 && j < TQ && t0 + j < T) s_up[t0 + j][wave & 1] = e;
+    }
+  }
+  __syncthreads();  // B3
+  // ---- phase 4: mask, softmax over T (lsa.py:34-38) by wave 0, cumulative update ----
+  if (wave == 0) {
+    float uv[(TMAX + 63) / 64];
+    float m = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < (TMAX + 63) / 64; ++q) {
+      const int t = lane + 64 * q;
+      float u = -INFINITY;
+      if (t < T) { u = s_up[t][0] + s_up[t][1]; u = chv[q] != 0 ? u : u * 0.f; }  // u * (chars != 0)
+      uv[q] = u;
+      m = fmaxf(m, u);
+    }
+    m = wave_max(m);
+    float ssum = 0.f;
+#pragma unroll
+    for (int q = 0; q < (TMAX + 63) / 64; ++q) {
+      const int t = lane + 64 * q;
+      uv[q] = (t < T) ? expf(uv[q] - m) : 0.f;
+      ssum += uv[q];
+    }
+    ssum = wave_sum(ssum);
+    float* ao = (a.attn_out && pg == 0) ? a.attn_out + ((size_t)b * a.n_iter_max + a.iter) * T : nullptr;
+#pragma unroll
+    for (int q = 0; q < (TMAX + 63) / 64; ++q) {
+      const int t = lane + 64 * q;
+      if (t < T) {
+        const float sc = uv[q] / ssum;
+        s_u[t] = sc;
+        if (pg == 0 && !skip) {
+          a.cum_out[(size_t)b * T + t] = s_cum[t + half] + sc;  // cumulative += attention (lsa.py:40)
+          if (ao) ao[t] = sc;
+        }
+      }
+    }
+  }
+  __syncthreads();  // B4
+  // ---- phase 5: context = scores @ encoder_seq (tacotron.py:104), this group's 256 columns ----
+  {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int t = wave + 8 * j;
+      const float sc = (t < T) ? s_u[t] : 0.f;
+      acc.x += sc * memv[j].x; acc.y += sc * memv[j].y; acc.z += sc * memv[j].z; acc.w += sc * memv[j].w;
+    }
+    s_part[wave][lane] = acc;
+  }
+  __syncthreads();  // B5
+  if (wave == 0 && !skip) {
+    float4 r = s_part[0][lane];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) {
+      const float4 o = s_part[w][lane];
+      r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+    }
+    *reinterpret_cast<float4*>(a.context + (size_t)b * P + p0 + lane * 4) = r;
   }
 }
 
@@ -511,6 +675,7 @@ struct mb_taco {
   // decoder
   DevBuf pre1_w, pre1_b, pre2_w, pre2_b;
   DevBuf lsa_conv_w, lsa_conv_b, lsa_L, lsa_W, lsa_Wb, lsa_v;
+  DevBuf lsa_Mt, lsa_c0, lsa_Wt;  // folded / transposed copies for lsa_fast_kernel
   DevBuf attn_w, attn_bih, attn_bhh;
   DevBuf rin_w, rin_b;
   DevBuf l1_w, l1_bih, l1_bhh, l2_w, l2_bih, l2_bhh;
@@ -689,6 +854,23 @@ extern "C" int mb_taco_create(const mb_taco_config* cfg, const float* const* hw,
   RC(t->lsa_conv_w.upload(hw[ix], (size_t)cfg->lsa_filters * cfg->lsa_kernel)); RC(t->lsa_conv_b.upload(hw[ix + 1], cfg->lsa_filters));
   RC(t->lsa_L.upload(hw[ix + 2], (size_t)D * cfg->lsa_filters)); RC(t->lsa_W.upload(hw[ix + 3], (size_t)D * D));
   RC(t->lsa_Wb.upload(hw[ix + 4], D)); RC(t->lsa_v.upload(hw[ix + 5], D));
+  {  // M = L . conv_w ([D][Kl], stored [Kl][D]), c0 = L . conv_b, W^T
+    const int Fl = cfg->lsa_filters, Kl = cfg->lsa_kernel;
+    const float *cw = hw[ix], *cb = hw[ix + 1], *Lw = hw[ix + 2], *Ww = hw[ix + 3];
+    std::vector<float> Mt((size_t)Kl * D), c0(D), Wt((size_t)D * D);
+    for (int dd = 0; dd < D; ++dd) {
+      double acc0 = 0.0;
+      for (int f = 0; f < Fl; ++f) acc0 += (double)Lw[(size_t)dd * Fl + f] * (double)cb[f];
+      c0[dd] = (float)acc0;
+      for (int j = 0; j < Kl; ++j) {
+        double acc = 0.0;
+        for (int f = 0; f < Fl; ++f) acc += (double)Lw[(size_t)dd * Fl + f] * (double)cw[(size_t)f * Kl + j];
+        Mt[(size_t)j * D + dd] = (float)acc;
+      }
+      for (int k2 = 0; k2 < D; ++k2) Wt[(size_t)k2 * D + dd] = Ww[(size_t)dd * D + k2];
+    }
+    RC(t->lsa_Mt.upload(Mt.data(), Mt.size())); RC(t->lsa_c0.upload(c0.data(), c0.size())); RC(t->lsa_Wt.upload(Wt.data(), Wt.size()));
+  }
   ix += 6;
   // attn_rnn GRUCell(P + 2D -> D)
   cell_rows(hw[ix], P + 2 * D, P + 2 * D, hw[ix + 1], D, D, 3, &rows);
@@ -747,7 +929,7 @@ extern "C" void mb_taco_destroy(mb_taco* t) {
   DevBuf* bs[] = {&t->pre1_w, &t->pre1_b, &t->pre2_w, &t->pre2_b, &t->lsa_conv_w, &t->lsa_conv_b, &t->lsa_L, &t->lsa_W,
                   &t->lsa_Wb, &t->lsa_v, &t->attn_w, &t->attn_bih, &t->attn_bhh, &t->rin_w, &t->rin_b, &t->l1_w,
                   &t->l1_bih, &t->l1_bhh, &t->l2_w, &t->l2_bih, &t->l2_bhh, &t->mel_w, &t->stop_w, &t->stop_b,
-                  &t->emb, &t->enc_proj_full, &t->gst_qconst, &t->gst_WqS, &t->gst_K, &t->gst_V};
+                  &t->emb, &t->enc_proj_full, &t->lsa_Mt, &t->lsa_c0, &t->lsa_Wt, &t->gst_qconst, &t->gst_WqS, &t->gst_K, &t->gst_V};
   for (DevBuf* b : bs) b->release();
   t->post.release(); t->post_proj.release(); t->enc.release();
   t->enc_fc1.release(); t->enc_fc2.release(); t->enc_proj.release();
@@ -882,7 +1064,12 @@ extern "C" int mb_taco_decode(const mb_taco* t, const float* d_memory, const flo
     lk.conv_w = t->lsa_conv_w.p; lk.conv_b = t->lsa_conv_b.p; lk.Lw = t->lsa_L.p; lk.Ww = t->lsa_W.p; lk.Wb = t->lsa_Wb.p;
     lk.vw = t->lsa_v.p; lk.context = cx_n; lk.attn_out = d_attn; lk.T = T; lk.D = D; lk.P = P; lk.Fl = c.lsa_filters;
     lk.Kl = c.lsa_kernel; lk.iter = it; lk.n_iter_max = n_iter_max; lk.skip_flag = done;
-    hipLaunchKernelGGL(lsa_kernel, dim3(B, psplit), dim3(512), lds_lsa, s, lk);
+    lk.Mt = t->lsa_Mt.p; lk.c0 = t->lsa_c0.p; lk.Wt = t->lsa_Wt.p;
+    const bool lsa_fast = D == 128 && P / psplit == 256 && c.lsa_kernel <= 31 && (c.lsa_kernel & 1) && T <= 192 &&
+                          getenv("MBHIP_LSA_GENERIC") == nullptr;
+    if (lsa_fast && T <= 128) hipLaunchKernelGGL(lsa_fast_kernel<32>, dim3(B, psplit), dim3(512), 0, s, lk);
+    else if (lsa_fast) hipLaunchKernelGGL(lsa_fast_kernel<48>, dim3(B, psplit), dim3(512), 0, s, lk);
+    else hipLaunchKernelGGL(lsa_kernel, dim3(B, psplit), dim3(512), lds_lsa, s, lk);
     MB_HIP(hipGetLastError());
     // x = rnn_input([context, attn_hidden])  (tacotron.py:108-109)
     memset(&k, 0, sizeof(k));

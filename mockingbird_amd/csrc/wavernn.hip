@@ -770,7 +770,7 @@ extern "C" int mb_wavernn_bench_kernel(mb_wavernn* w, const mb_wavernn_plan* pla
   // In-situ marginal duration: time the real (graph-replayed) sample loop with HIP events on its
   // stream, with and without kernel `which`; kernels of the chain run back to back, so the
   // difference per step is that kernel's launch-to-launch duration (what rocprofv3 reports).
-  MB_REQUIRE(w && plan && avg_us && which >= 1 && which < 5, "wavernn_bench_kernel: which must be 1..4");
+  MB_REQUIRE(w && plan && avg_us && which >= 0 && which < 5, "wavernn_bench_kernel: which must be 0..4");
   (void)iters;
   float ms_full = 0.f, ms_wo = 0.f;
   int rc = MB_OK;
