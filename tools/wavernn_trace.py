@@ -20,7 +20,7 @@ p = model.last_plan
 print("folds", p.n_folds, "seq", p.seq_len, "us/step", model.last_loop_ms * 1e3 / p.seq_len)
 raw = np.fromfile(path, dtype=np.uint64).reshape(-1, 6, 512, 2)
 marks = raw[:, :, 496:500, :].reshape(raw.shape[0], 6, 8).astype(np.float64)
-if marks[8:, :5, 6].min() > 0:
+if marks[8:, :5, 6].min() > 0 and marks[8:, :5, :7].max() < 1e18:
     dm = (marks[:, :, 1:7] - marks[:, :, 0:6])  # shader cycles between consecutive marks
     print("marks (wave 0 of workgroup 0, us @2.4GHz): issue | loads-arrive | mfma | lds+barrier | epi-wait+reduce | math+store")
     for k in range(5):
