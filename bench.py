@@ -30,7 +30,9 @@ import torch
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA dense peak
+MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: fp16/bf16 MFMA dense peak
 HIFIGAN_MFLOP_PER_FRAME = 352.1
+FREGAN_MFLOP_PER_FRAME = 385.1
 
 
 def parse():
@@ -162,32 +164,62 @@ def main():
                            "GBps": (16.3e6 + 452.0 * plan.n_folds) / (result["config"]["us_per_time_step"] * 1e-6) / 1e9},
             "per_kernel": per_kernel,
         }
-        # ---- secondary: HiFi-GAN generator, batch 32 x (80, 200)
+        # ---- secondary: GAN vocoders.  HiFi-GAN batch 32 x (80,200) (north_star "batch-32 synthetic input"),
+        # fp32 MFMA (parity path) and fp16 MFMA (throughput path); Fre-GAN fp16 8 x (80,3000) = the per-GPU
+        # share of BASELINE configs[4] (batch 64 over 8 GPUs).
         if not args.no_hifigan:
             from mockingbird_amd.vocoder.gan import GanGenerator
+
+            def time_gan(gen, gm, reps):
+                for _ in range(2):
+                    gen(gm)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    y = gen(gm)
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / reps, y
+
             h = synth.HIFIGAN_16K
-            gen = GanGenerator(h, synth.gan_state(h, "hifigan", seed=3)["generator"], 0)
+            st = synth.gan_state(h, "hifigan", seed=3)["generator"]
             gm = torch.from_numpy(synth.mel_input(200, 32, seed=0)).to(dev)
-            for _ in range(2):
-                gen(gm)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = 5
-            e0.record()
-            for _ in range(reps):
-                y = gen(gm)
-            e1.record()
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / reps
             flops = HIFIGAN_MFLOP_PER_FRAME * 1e6 * 200 * 32
-            result["hifigan"] = {
-                "workload": "HiFi-GAN V1 16k generator forward, batch 32 x mel (80,200), fp32 MFMA",
-                "value": 32 * 200 * 200 / (ms * 1e-3), "unit": "samples/s",
-                "x_realtime": 32 * 200 * 200 / (ms * 1e-3) / 16000.0, "ms_per_batch": ms,
-                "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
-                             "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                             "traffic": None},
+            y32 = None
+            for dt, peak, key in (("f32", MFMA_F32_PEAK_TFLOPS, "hifigan"), ("f16", MFMA_F16_PEAK_TFLOPS, "hifigan_f16")):
+                gen = GanGenerator(h, st, 0, dtype=dt)
+                ms, y = time_gan(gen, gm, 5 if dt == "f32" else 20)
+                entry = {
+                    "workload": f"HiFi-GAN V1 16k generator forward, batch 32 x mel (80,200), {dt} MFMA"
+                                + (" (fp16 storage, fp32 accumulate)" if dt == "f16" else ""),
+                    "dtype": dt, "value": 32 * 200 * 200 / (ms * 1e-3), "unit": "samples/s",
+                    "x_realtime": 32 * 200 * 200 / (ms * 1e-3) / 16000.0, "ms_per_batch": ms,
+                    "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": peak,
+                                 "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / 1e12 / peak, "traffic": None},
+                }
+                if dt == "f32":
+                    y32 = y
+                else:
+                    d = (y.double() - y32.double())
+                    entry["vs_f32_path"] = {"rms": float(d.pow(2).mean().sqrt()),
+                                            "rel_rms": float(d.pow(2).mean().sqrt() / y32.double().pow(2).mean().sqrt())}
+                result[key] = entry
+                del gen
+            hf = synth.FREGAN_16K
+            stf = synth.gan_state(hf, "fregan", seed=4)["generator"]
+            gmf = torch.from_numpy(synth.mel_input(3000, 8, seed=1)).to(dev)
+            gen = GanGenerator(hf, stf, 1, dtype="f16")
+            ms, y = time_gan(gen, gmf, 5)
+            fl = FREGAN_MFLOP_PER_FRAME * 1e6 * 3000 * 8
+            result["fregan_f16"] = {
+                "workload": "BASELINE configs[4] per-GPU share: Fre-GAN generator forward fp16 MFMA, batch 8 x mel (80,3000)",
+                "dtype": "f16", "value": 8 * 3000 * 200 / (ms * 1e-3), "unit": "samples/s",
+                "x_realtime": 8 * 3000 * 200 / (ms * 1e-3) / 16000.0, "ms_per_batch": ms,
+                "roofline": {"bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12, "peak": MFMA_F16_PEAK_TFLOPS,
+                             "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, "traffic": None},
             }
+            del gen, y, gmf
         # ---- secondary: Tacotron synthesize (BASELINE configs[2]): B=32, ~100 tokens, r=2, 400 frames forced
         if not args.no_tacotron:
             from mockingbird_amd.synthesizer.inference import TacotronDevice

@@ -91,6 +91,46 @@ typedef struct mb_conv1d_args {
 int mb_conv1d(const mb_conv1d_args* a, mb_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * 1b. fp16 Conv1d / ConvTranspose1d primitive (fp16 storage, fp32 accumulate on
+ *     v_mfma_f32_32x32x16_f16) -- the throughput path of the GAN vocoders
+ *     (BASELINE configs[4]: "Fre-GAN vocoder fp16 with MFMA Conv1d").
+ *     Activations are TIME-MAJOR [B][T][C] fp16 (channel contiguous).
+ *     Replaces the same torch.nn.Conv1d / ConvTranspose1d call sites as
+ *     section 1, run under .half():
+ *      models/vocoder/hifigan/models.py:11-48,120-123,134-150
+ *      models/vocoder/fregan/generator.py:11-52,98-120,137-166
+ * ---------------------------------------------------------------------- */
+size_t mb_conv1d_f16_packed_halves(int c_out, int c_in, int ksize, int up);
+/* h_w: fp32 torch-layout weights (as mb_conv1d_pack) -> fp16 A-fragment image. */
+int mb_conv1d_f16_pack(const float* h_w, int c_out, int c_in, int ksize, int up,
+                       int transposed, int pad, uint16_t* h_packed);
+
+typedef struct mb_conv1d_f16_args {
+  const void* d_x;        /* fp16 [B][t_in/in_repeat][c_in], c_in % 8 == 0        */
+  const void* d_wpacked;  /* image from mb_conv1d_f16_pack                        */
+  const float* d_bias;    /* fp32 [c_out] or NULL                                 */
+  const void* d_res;      /* fp16 residual, same layout as y, or NULL             */
+  void* d_y;              /* fp16 [B][t_out][c_out] (fp32 if y_f32)               */
+  long long x_bstride, y_bstride, res_bstride; /* in elements                     */
+  int batch, c_in, c_out, t_in, t_out;
+  int ksize, dilation, pad, up;  /* as mb_conv1d_args                             */
+  int in_act;             /* 0 none, 1 leaky_relu(in_slope), 0 < slope < 1        */
+  float in_slope;
+  int out_act;            /* 0 none, 1 relu, 2 tanh                               */
+  float out_scale;        /* result *= out_scale after the residual add (0 = 1.0) */
+  int accumulate;         /* y += result                                          */
+  int in_repeat;          /* nearest-neighbour upsampled read, as mb_conv1d_args  */
+  int y_f32;              /* store y as fp32 (final conv_post -> waveform)        */
+} mb_conv1d_f16_args;
+
+int mb_conv1d_f16(const mb_conv1d_f16_args* a, mb_stream_t stream);
+
+/* Layout/precision converters between the reference's [B][C][T] fp32 tensors and the
+ * time-major fp16 activations above (mel upload; tests). */
+int mb_f32_to_f16_tm(const float* d_x, void* d_y, int batch, int channels, int t, mb_stream_t stream);
+int mb_f16_tm_to_f32(const void* d_x, float* d_y, int batch, int channels, int t, mb_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * 2. GAN vocoders: HiFi-GAN and Fre-GAN generator forward.
  *    Replaces: Generator.forward  models/vocoder/hifigan/models.py:134-150
  *              FreGAN.forward     models/vocoder/fregan/generator.py:137-166
@@ -130,6 +170,15 @@ size_t mb_gan_weight_numel(const mb_gan_config* cfg, int index);
 
 int mb_gan_create(const mb_gan_config* cfg, const float* const* h_weights,
                   int n_weights, mb_gan** out);
+/* Same, choosing the arithmetic of the conv stacks: MB_F32 = fp32 MFMA (the 1e-4 RMS parity
+ * path, what mb_gan_create builds), MB_F16 = fp16 storage / fp32 accumulate (section 1b; parity
+ * gate: relative RMS <= 5e-3).  mb_gan_forward's signature is the same for
+ * both: fp32 mel in, fp32 waveform out. */
+#define MB_F32 0
+#define MB_F16 1
+int mb_gan_create_ex(const mb_gan_config* cfg, const float* const* h_weights,
+                     int n_weights, int dtype, mb_gan** out);
+int mb_gan_dtype(const mb_gan* g);
 void mb_gan_destroy(mb_gan* g);
 int mb_gan_hop(const mb_gan* g);                 /* product of upsample rates   */
 size_t mb_gan_workspace_bytes(const mb_gan* g, int batch, int frames);

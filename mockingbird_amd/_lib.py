@@ -35,6 +35,22 @@ class ConvArgs(C.Structure):
     ]
 
 
+class ConvF16Args(C.Structure):
+    _fields_ = [
+        ("d_x", C.c_void_p), ("d_wpacked", C.c_void_p), ("d_bias", C.c_void_p), ("d_res", C.c_void_p),
+        ("d_y", C.c_void_p),
+        ("x_bstride", C.c_longlong), ("y_bstride", C.c_longlong), ("res_bstride", C.c_longlong),
+        ("batch", C.c_int), ("c_in", C.c_int), ("c_out", C.c_int), ("t_in", C.c_int), ("t_out", C.c_int),
+        ("ksize", C.c_int), ("dilation", C.c_int), ("pad", C.c_int), ("up", C.c_int),
+        ("in_act", C.c_int), ("in_slope", C.c_float),
+        ("out_act", C.c_int), ("out_scale", C.c_float),
+        ("accumulate", C.c_int), ("in_repeat", C.c_int), ("y_f32", C.c_int),
+    ]
+
+
+MB_F32, MB_F16 = 0, 1
+
+
 class GanConfig(C.Structure):
     _fields_ = [
         ("kind", C.c_int), ("num_mels", C.c_int), ("upsample_initial_channel", C.c_int),
@@ -88,9 +104,17 @@ SIGNATURES = {
     "mb_conv1d_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_void_p]),
     "mb_conv1d": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "mb_conv1d_f16_packed_halves": (C.c_size_t, [C.c_int] * 4),
+    "mb_conv1d_f16_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p]),
+    "mb_conv1d_f16": (C.c_int, [C.POINTER(ConvF16Args), C.c_void_p]),
+    "mb_f32_to_f16_tm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mb_f16_tm_to_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mb_gan_num_weights": (C.c_int, [C.POINTER(GanConfig)]),
     "mb_gan_weight_numel": (C.c_size_t, [C.POINTER(GanConfig), C.c_int]),
     "mb_gan_create": (C.c_int, [C.POINTER(GanConfig), _PP, C.c_int, _PP]),
+    "mb_gan_create_ex": (C.c_int, [C.POINTER(GanConfig), _PP, C.c_int, C.c_int, _PP]),
+    "mb_gan_dtype": (C.c_int, [C.c_void_p]),
     "mb_gan_destroy": (None, [C.c_void_p]),
     "mb_gan_hop": (C.c_int, [C.c_void_p]),
     "mb_gan_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),

@@ -87,12 +87,32 @@ static int add_inplace(float* y, const float* x, size_t n, hipStream_t s) {
   return MB_OK;
 }
 
+typedef _Float16 h16x8_t __attribute__((ext_vector_type(8)));
+// fp16 variant: n is a multiple of 8 (channel counts are multiples of 8 on the fp16 path)
+__global__ void add_inplace_f16_kernel(_Float16* __restrict__ y, const _Float16* __restrict__ x, size_t n8) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  h16x8_t* y8 = reinterpret_cast<h16x8_t*>(y);
+  const h16x8_t* x8 = reinterpret_cast<const h16x8_t*>(x);
+  for (size_t k = i; k < n8; k += stride) y8[k] = y8[k] + x8[k];
+}
+
+static int add_inplace_f16(void* y, const void* x, size_t n, hipStream_t s) {
+  if (!n) return MB_OK;
+  MB_REQUIRE(n % 8 == 0, "gan(f16): activation size %zu not a multiple of 8", n);
+  int blocks = (int)std::min<size_t>((n / 8 + 255) / 256, 4096);
+  hipLaunchKernelGGL(add_inplace_f16_kernel, dim3(blocks), dim3(256), 0, s, (_Float16*)y, (const _Float16*)x, n / 8);
+  MB_HIP(hipGetLastError());
+  return MB_OK;
+}
+
 }  // namespace mb
 
 using namespace mb;
 
 struct mb_gan {
   mb_gan_config cfg;
+  int dtype = MB_F32;
   std::vector<ConvW> convs;  // ABI order
   int hop;
   // indices into convs
@@ -114,7 +134,15 @@ extern "C" size_t mb_gan_weight_numel(const mb_gan_config* cfg, int index) {
 
 extern "C" int mb_gan_create(const mb_gan_config* cfg, const float* const* h_weights, int n_weights,
                              mb_gan** out) {
+  return mb_gan_create_ex(cfg, h_weights, n_weights, MB_F32, out);
+}
+
+extern "C" int mb_gan_dtype(const mb_gan* g) { return g ? g->dtype : MB_EINVAL; }
+
+extern "C" int mb_gan_create_ex(const mb_gan_config* cfg, const float* const* h_weights, int n_weights,
+                                int dtype, mb_gan** out) {
   MB_REQUIRE(out && h_weights, "gan_create: null pointer");
+  MB_REQUIRE(dtype == MB_F32 || dtype == MB_F16, "gan_create: dtype %d", dtype);
   std::vector<ConvSpec> v;
   int rc = gan_specs(cfg, &v);
   if (rc) return rc;
@@ -122,14 +150,27 @@ extern "C" int mb_gan_create(const mb_gan_config* cfg, const float* const* h_wei
              (int)v.size() * 2, n_weights);
   mb_gan* g = new mb_gan();
   g->cfg = *cfg;
+  g->dtype = dtype;
   g->convs.resize(v.size());
   std::vector<float> packed;
   for (size_t i = 0; i < v.size(); ++i) {
     const ConvSpec& s = v[i];
     g->convs[i].s = s;
-    packed.assign(mb_conv1d_packed_floats(s.c_out, s.c_in, s.k, s.stride), 0.f);
-    rc = mb_conv1d_pack(h_weights[2 * i], s.c_out, s.c_in, s.k, s.stride, s.transposed, s.pad,
-                        packed.data());
+    if (dtype == MB_F16) {
+      if (s.c_in % 8 != 0) {
+        set_error("gan_create(f16): conv %zu has c_in=%d, the fp16 path needs multiples of 8", i, s.c_in);
+        mb_gan_destroy(g);
+        return MB_EINVAL;
+      }
+      const size_t nh = mb_conv1d_f16_packed_halves(s.c_out, s.c_in, s.k, s.stride);  // multiple of 512
+      packed.assign(nh / 2, 0.f);
+      rc = mb_conv1d_f16_pack(h_weights[2 * i], s.c_out, s.c_in, s.k, s.stride, s.transposed, s.pad,
+                              reinterpret_cast<uint16_t*>(packed.data()));
+    } else {
+      packed.assign(mb_conv1d_packed_floats(s.c_out, s.c_in, s.k, s.stride), 0.f);
+      rc = mb_conv1d_pack(h_weights[2 * i], s.c_out, s.c_in, s.k, s.stride, s.transposed, s.pad,
+                          packed.data());
+    }
     if (!rc) rc = g->convs[i].w.upload(packed.data(), packed.size());
     if (!rc) rc = g->convs[i].b.upload(h_weights[2 * i + 1], s.c_out);
     if (rc) { mb_gan_destroy(g); return rc; }
@@ -174,20 +215,51 @@ static size_t gan_max_act(const mb_gan* g, int frames) {
 
 extern "C" size_t mb_gan_workspace_bytes(const mb_gan* g, int batch, int frames) {
   if (!g || batch <= 0 || frames <= 0) return 0;
-  const size_t per = align_up(gan_max_act(g, frames) * batch * sizeof(float), 256);
+  const size_t esz = g->dtype == MB_F16 ? 2 : sizeof(float);
+  const size_t per = align_up(gan_max_act(g, frames) * batch * esz, 256);
   const int nbuf = g->cfg.kind == MB_GAN_FREGAN ? 8 : 4;
-  return per * nbuf + 256;
+  // fp16: + the time-major fp16 copy of the mel
+  const size_t melh = g->dtype == MB_F16 ? align_up((size_t)batch * frames * g->cfg.num_mels * 2, 256) : 0;
+  return per * nbuf + melh + 256;
 }
 
 namespace {
 struct Launcher {
   hipStream_t s;
   int batch;
+  int dtype;
   int rc = MB_OK;
-  // y = conv(x) with fused pro/epilogue; lengths are per batch item.
-  void conv(const ConvW& c, const float* x, int t_in, float* y, int in_act, float in_slope,
-            const float* res, float out_scale, int accumulate, int out_act, int in_repeat = 1) {
+  void add(void* y, const void* x, size_t n) {
     if (rc) return;
+    rc = dtype == MB_F16 ? add_inplace_f16(y, x, n, s) : add_inplace((float*)y, (const float*)x, n, s);
+  }
+  void conv_f16(const ConvW& c, const void* x, int t_in, void* y, int in_act, float in_slope,
+                const void* res, float out_scale, int accumulate, int out_act, int in_repeat, int y_f32) {
+    mb_conv1d_f16_args a;
+    memset(&a, 0, sizeof(a));
+    const int t_eff = t_in * in_repeat;
+    const int t_out = c.s.transposed ? t_eff * c.s.stride : t_eff;
+    a.d_x = x; a.d_wpacked = c.w.p; a.d_bias = c.b.p; a.d_res = res; a.d_y = y;
+    a.x_bstride = (long long)c.s.c_in * t_in;
+    a.y_bstride = (long long)c.s.c_out * t_out;
+    a.res_bstride = a.y_bstride;
+    a.batch = batch; a.c_in = c.s.c_in; a.c_out = c.s.c_out; a.t_in = t_eff; a.t_out = t_out;
+    a.ksize = c.s.k; a.dilation = c.s.dil; a.pad = c.s.pad; a.up = c.s.transposed ? c.s.stride : 1;
+    a.in_act = in_act; a.in_slope = in_slope;
+    a.out_act = out_act; a.out_scale = out_scale; a.accumulate = accumulate;
+    a.in_repeat = in_repeat; a.y_f32 = y_f32;
+    rc = mb_conv1d_f16(&a, (mb_stream_t)s);
+  }
+  // y = conv(x) with fused pro/epilogue; lengths are per batch item.  `last` = conv_post (fp32 out).
+  void conv(const ConvW& c, const void* xv, int t_in, void* yv, int in_act, float in_slope,
+            const void* resv, float out_scale, int accumulate, int out_act, int in_repeat = 1,
+            bool last = false) {
+    if (rc) return;
+    if (dtype == MB_F16) {
+      conv_f16(c, xv, t_in, yv, in_act, in_slope, resv, out_scale, accumulate, out_act, in_repeat, last);
+      return;
+    }
+    const float* x = (const float*)xv; float* y = (float*)yv; const float* res = (const float*)resv;
     mb_conv1d_args a;
     memset(&a, 0, sizeof(a));
     const int t_eff = t_in * in_repeat;
@@ -217,47 +289,55 @@ extern "C" int mb_gan_forward(const mb_gan* g, const float* d_mel, int batch, in
   }
   const mb_gan_config& c = g->cfg;
   const bool fre = c.kind == MB_GAN_FREGAN;
-  const size_t per = gan_max_act(g, frames) * batch;
+  const bool f16 = g->dtype == MB_F16;
+  const size_t esz = f16 ? 2 : sizeof(float);
+  const size_t per = gan_max_act(g, frames) * batch * esz;  // bytes per activation buffer
   Arena ar(d_workspace, workspace_bytes);
-  float* X = ar.take<float>(per);   // ups output = resblock input
-  float* XS = ar.take<float>(per);  // stage output (mean of resblocks)
-  float* XR = ar.take<float>(per);  // running x inside a resblock
-  float* T = ar.take<float>(per);   // convs1 output
-  float *MELA = nullptr, *MELB = nullptr, *OUTA = nullptr, *OUTB = nullptr;
+  char* X = ar.take<char>(per);   // ups output = resblock input
+  char* XS = ar.take<char>(per);  // stage output (mean of resblocks)
+  char* XR = ar.take<char>(per);  // running x inside a resblock
+  char* T = ar.take<char>(per);   // convs1 output
+  char *MELA = nullptr, *MELB = nullptr, *OUTA = nullptr, *OUTB = nullptr;
   if (fre) {
-    MELA = ar.take<float>(per); MELB = ar.take<float>(per);
-    OUTA = ar.take<float>(per); OUTB = ar.take<float>(per);
+    MELA = ar.take<char>(per); MELB = ar.take<char>(per);
+    OUTA = ar.take<char>(per); OUTB = ar.take<char>(per);
   }
-  Launcher L{(hipStream_t)stream, batch};
+  Launcher L{(hipStream_t)stream, batch, g->dtype};
+  const void* mel_in = d_mel;
+  if (f16) {  // [B][80][F] fp32 -> time-major fp16
+    char* melh = ar.take<char>((size_t)batch * frames * c.num_mels * 2);
+    L.rc = mb_f32_to_f16_tm(d_mel, melh, batch, c.num_mels, frames, stream);
+    mel_in = melh;
+  }
   const float LRELU = 0.1f;  // LRELU_SLOPE models.py:8
   const int lvl = fre ? c.num_upsamples - c.top_k : 1 << 30;
   const float inv_nk = 1.0f / (float)c.num_kernels;
 
   // conv_pre (models.py:135 / generator.py:139)
-  L.conv(g->convs[g->i_pre], d_mel, frames, XS, 0, 0.f, nullptr, 1.f, 0, 0);
+  L.conv(g->convs[g->i_pre], mel_in, frames, XS, 0, 0.f, nullptr, 1.f, 0, 0);
   int t = frames;                 // current length of XS
-  const float* mel_cur = d_mel;   // fregan conditioning chain
+  const void* mel_cur = mel_in;   // fregan conditioning chain
   int mel_t = frames;
-  float* out_cur = nullptr;       // fregan `output`
+  char* out_cur = nullptr;        // fregan `output`
   int out_t = 0;
   for (int i = 0; i < c.num_upsamples && !L.rc; ++i) {
     const int ch = c.upsample_initial_channel >> (i + 1);
-    float* pending_out = nullptr;  // res_output result waiting for "+ x"
+    char* pending_out = nullptr;  // res_output result waiting for "+ x"
     if (fre && i >= lvl) {
       // mel = cond_up[i-lvl](mel); x += mel (generator.py:142-144)
-      float* mel_next = (mel_cur == MELA) ? MELB : MELA;
+      char* mel_next = (mel_cur == MELA) ? MELB : MELA;
       const ConvW& cu = g->convs[g->i_cond + (i - lvl)];
       L.conv(cu, mel_cur, mel_t, mel_next, 0, 0.f, nullptr, 1.f, 0, 0);
       mel_cur = mel_next; mel_t *= cu.s.stride;
-      if (!L.rc) L.rc = add_inplace(XS, mel_cur, (size_t)batch * cu.s.c_out * mel_t, L.s);
+      L.add(XS, mel_cur, (size_t)batch * cu.s.c_out * mel_t);
     }
     if (fre && i > lvl) {
       // output = res_output[i-lvl-1](x or output): nearest x u then 1x1 conv (generator.py:145-149)
       const ConvW& ro = g->convs[g->i_resout + (i - lvl - 1)];
       const int u = c.upsample_rates[i];
-      const float* src = out_cur ? out_cur : XS;
+      const char* src = out_cur ? out_cur : XS;
       const int src_t = out_cur ? out_t : t;
-      float* dst = (out_cur == OUTA) ? OUTB : OUTA;
+      char* dst = (out_cur == OUTA) ? OUTB : OUTA;
       L.conv(ro, src, src_t, dst, 0, 0.f, nullptr, 1.f, 0, 0, u);
       pending_out = dst; out_t = src_t * u;
     }
@@ -268,7 +348,7 @@ extern "C" int mb_gan_forward(const mb_gan* g, const float* d_mel, int batch, in
     // xs = mean_j resblock_j(x)
     for (int j = 0; j < c.num_kernels; ++j) {
       const int base = g->i_rb + ((i * c.num_kernels + j) * c.num_dilations) * 2;
-      const float* xr = X;
+      const char* xr = X;
       for (int d = 0; d < c.num_dilations; ++d) {
         const ConvW& c1 = g->convs[base + d];
         const ConvW& c2 = g->convs[base + c.num_dilations + d];
@@ -279,12 +359,12 @@ extern "C" int mb_gan_forward(const mb_gan* g, const float* d_mel, int batch, in
       }
     }
     if (pending_out) {  // output = output + x (generator.py:158-159)
-      if (!L.rc) L.rc = add_inplace(pending_out, XS, (size_t)batch * ch * t, L.s);
+      L.add(pending_out, XS, (size_t)batch * ch * t);
       out_cur = pending_out;
     }
   }
   // x = leaky_relu(x) [default slope 0.01, models.py:146]; conv_post; tanh
-  const float* fin = (fre && out_cur) ? out_cur : XS;
-  L.conv(g->convs[g->i_post], fin, t, d_wav, 1, 0.01f, nullptr, 1.f, 0, 2);
+  const char* fin = (fre && out_cur) ? out_cur : XS;
+  L.conv(g->convs[g->i_post], fin, t, d_wav, 1, 0.01f, nullptr, 1.f, 0, 2, 1, true);
   return L.rc;
 }

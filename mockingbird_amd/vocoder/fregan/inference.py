@@ -10,9 +10,11 @@ output_sample_rate = None
 _device = None
 
 
-def load_model(weights_fpath, config_fpath=None, verbose=True):
+def load_model(weights_fpath, config_fpath=None, verbose=True, dtype=None):
+    """Reference signature plus an additive keyword: dtype "f32" (parity path) | "f16"
+    (fp16 matrix cores); default from env MBHIP_GAN_DTYPE, else "f32"."""
     global generator, output_sample_rate, _device
-    _facade.load_model(weights_fpath, config_fpath, verbose)
+    _facade.load_model(weights_fpath, config_fpath, verbose, dtype=dtype)
     generator, output_sample_rate, _device = _facade.generator, _facade.output_sample_rate, _facade._device
 
 

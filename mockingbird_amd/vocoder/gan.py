@@ -21,9 +21,14 @@ class GanGenerator:
     """Owns an ``mb_gan`` handle; ``forward`` mirrors ``Generator.forward`` /
     ``FreGAN.forward`` for a [B, 80, F] float32 device tensor."""
 
-    def __init__(self, config: dict, state_dict: dict, kind: int, top_k: int = 4):
+    def __init__(self, config: dict, state_dict: dict, kind: int, top_k: int = 4, dtype: str = "f32"):
+        """dtype "f32": fp32 MFMA (1e-4 RMS parity path).  "f16": fp16 storage / fp32 accumulate on
+        the fp16 matrix cores (BASELINE configs[4]; relative-RMS gate 5e-3)."""
+        if dtype not in ("f32", "f16"):
+            raise _lib.MbHipError(f"GanGenerator: dtype {dtype!r} (use 'f32' or 'f16')")
         self.cfg = weights.gan_config(config, kind, top_k)
         self.kind = kind
+        self.dtype = dtype
         L = _lib.lib()
         ws = weights.gan_weight_list(state_dict, self.cfg)
         n = L.mb_gan_num_weights(C.byref(self.cfg))
@@ -35,7 +40,9 @@ class GanGenerator:
                 raise _lib.MbHipError(f"weight {i}: {tuple(w.shape)} has {w.numel()} elements, expected {want}")
         arr = _lib.host_ptr_array(ws)
         h = C.c_void_p()
-        _lib.check(L.mb_gan_create(C.byref(self.cfg), arr, len(ws), C.byref(h)), "mb_gan_create")
+        _lib.check(L.mb_gan_create_ex(C.byref(self.cfg), arr, len(ws),
+                                      _lib.MB_F16 if dtype == "f16" else _lib.MB_F32, C.byref(h)),
+                   "mb_gan_create_ex")
         self._h = h
         self.hop = L.mb_gan_hop(h)
         self._ws = None
@@ -78,7 +85,11 @@ class GanFacade:
         self.output_sample_rate = None
         self._device = None
 
-    def load_model(self, weights_fpath, config_fpath=None, verbose=True):
+    def load_model(self, weights_fpath, config_fpath=None, verbose=True, dtype=None):
+        """Reference signature (inference.py:22) plus an additive keyword: dtype "f32" | "f16"
+        (default: env MBHIP_GAN_DTYPE, else "f32")."""
+        import os
+        dtype = dtype or os.environ.get("MBHIP_GAN_DTYPE", "f32")
         weights_fpath = Path(weights_fpath)
         if verbose:
             print(f"Building {self.name}")
@@ -95,7 +106,7 @@ class GanFacade:
         if verbose:
             print(f"Loading '{weights_fpath}'")
         ckpt = torch.load(str(weights_fpath), map_location="cpu")
-        self.generator = GanGenerator(h, ckpt["generator"], self.kind)
+        self.generator = GanGenerator(h, ckpt["generator"], self.kind, dtype=dtype)
         if verbose:
             print("Complete.")
 

@@ -59,6 +59,65 @@ def conv1d_hip(x, w, bias=None, *, dilation=1, pad=0, transposed=False, up=1, in
     return y
 
 
+def conv1d_f16_hip(x, w, bias=None, *, dilation=1, pad=0, transposed=False, up=1, in_act=0, in_slope=0.0,
+                   out_act=0, out_scale=1.0, res=None, accumulate_into=None, in_repeat=1, y_f32=False,
+                   device="cuda"):
+    """fp16 primitive (mb_conv1d_f16).  x / res / accumulate_into are [B, C, T] float tensors in the
+    reference's layout; they are converted to time-major fp16 with the ABI's own converter and the
+    result comes back as [B, Cout, T_out] float32."""
+    L = _lib.lib()
+    dev = torch.device(device)
+    w = w.detach().float().contiguous().cpu()
+    if transposed:
+        c_in, c_out, k = w.shape
+    else:
+        c_out, c_in, k = w.shape
+    nh = L.mb_conv1d_f16_packed_halves(c_out, c_in, k, up)
+    packed = torch.empty(nh, dtype=torch.float16)
+    _lib.check(L.mb_conv1d_f16_pack(w.data_ptr(), c_out, c_in, k, up, int(transposed), pad, packed.data_ptr()),
+               "mb_conv1d_f16_pack")
+    pw = packed.to(dev)
+
+    def to_tm(t):
+        t = t.float().contiguous().to(dev)
+        B, Cc, Tt = t.shape
+        out = torch.empty(B, Tt, Cc, dtype=torch.float16, device=dev)
+        _lib.check(L.mb_f32_to_f16_tm(t.data_ptr(), out.data_ptr(), B, Cc, Tt, _lib.stream_ptr()), "mb_f32_to_f16_tm")
+        return out
+
+    xh = to_tm(x)
+    B, t_src, _ = xh.shape
+    t_in = t_src * in_repeat
+    t_out = t_in * up if transposed else t_in + 2 * pad - dilation * (k - 1)
+    pb = bias.float().contiguous().to(dev) if bias is not None else None
+    pres = to_tm(res) if res is not None else None
+    if accumulate_into is not None:
+        y = accumulate_into.float().contiguous().to(dev).transpose(1, 2).contiguous() if y_f32 else to_tm(accumulate_into)
+    elif y_f32:
+        y = torch.full((B, t_out, c_out), float("nan"), device=dev)
+    else:
+        y = torch.full((B, t_out, c_out), float("nan"), dtype=torch.float16, device=dev)
+    a = _lib.ConvF16Args()
+    a.d_x, a.d_wpacked = xh.data_ptr(), pw.data_ptr()
+    a.d_bias = pb.data_ptr() if pb is not None else None
+    a.d_res = pres.data_ptr() if pres is not None else None
+    a.d_y = y.data_ptr()
+    a.x_bstride, a.y_bstride, a.res_bstride = c_in * t_src, c_out * t_out, c_out * t_out
+    a.batch, a.c_in, a.c_out, a.t_in, a.t_out = B, c_in, c_out, t_in, t_out
+    a.ksize, a.dilation, a.pad, a.up = k, dilation, pad, (up if transposed else 1)
+    a.in_act, a.in_slope = in_act, in_slope
+    a.out_act, a.out_scale, a.accumulate = out_act, out_scale, int(accumulate_into is not None)
+    a.in_repeat, a.y_f32 = in_repeat, int(y_f32)
+    _lib.check(L.mb_conv1d_f16(C.byref(a), _lib.stream_ptr()), "mb_conv1d_f16")
+    torch.cuda.synchronize()
+    if y_f32:
+        return y.transpose(1, 2).contiguous()
+    out = torch.empty(B, c_out, t_out, device=dev)
+    _lib.check(L.mb_f16_tm_to_f32(y.data_ptr(), out.data_ptr(), B, c_out, t_out, _lib.stream_ptr()), "mb_f16_tm_to_f32")
+    torch.cuda.synchronize()
+    return out
+
+
 def relerr(a: torch.Tensor, b: torch.Tensor):
     a, b = a.double().cpu(), b.double().cpu()
     d = (a - b).abs()

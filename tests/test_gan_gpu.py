@@ -13,10 +13,10 @@ pytestmark = pytest.mark.gpu
 RMS_TOL, REL_TOL = 1e-4, 1e-3
 
 
-def _run(kind, h, frames, batch, seed):
+def _run(kind, h, frames, batch, seed, dtype="f32"):
     from mockingbird_amd.vocoder.gan import GanGenerator
     st = synth.gan_state(h, kind, seed=seed)
-    gen = GanGenerator(h, st["generator"], 0 if kind == "hifigan" else 1)
+    gen = GanGenerator(h, st["generator"], 0 if kind == "hifigan" else 1, dtype=dtype)
     mel = torch.from_numpy(synth.mel_input(frames, batch, seed=seed + 1))
     with torch.no_grad():
         w = og.fold_weight_norm_state(st["generator"])
@@ -34,6 +34,40 @@ def test_gan_forward_matches_oracle(cuda, lib, kind, cfg, uic, frames, batch):
     assert y.shape == ref.shape == (batch, 1, frames * 200)
     e = hiputil.relerr(y, ref)
     assert e["nan"] == 0 and e["rms"] <= RMS_TOL and e["rel_rms"] <= REL_TOL, e
+
+
+F16_REL_TOL = 5e-3  # fp16 gate, relative RMS, reported separately
+
+
+@pytest.mark.parametrize("kind,cfg", [("hifigan", synth.HIFIGAN_16K), ("fregan", synth.FREGAN_16K)])
+@pytest.mark.parametrize("uic,frames,batch", [(64, 16, 2), (128, 37, 1), (512, 12, 1)])
+def test_gan_forward_f16_matches_oracle(cuda, lib, kind, cfg, uic, frames, batch):
+    """fp16 MFMA path (BASELINE configs[4]) against the fp32 oracle."""
+    h = synth.small(cfg, uic)
+    y, ref = _run(kind, h, frames, batch, seed=3, dtype="f16")
+    assert y.shape == ref.shape == (batch, 1, frames * 200)
+    e = hiputil.relerr(y, ref)
+    print("f16 parity", kind, uic, frames, batch, e)
+    assert e["nan"] == 0 and e["rel_rms"] <= F16_REL_TOL, e
+
+
+def test_gan_f16_full_size_properties(cuda, lib):
+    """BASELINE-size run of the fp16 path (batch 4 x (80,200), full 512-channel model): bounded output,
+    batch items independent (item k alone == item k inside the batch, bit for bit), and close to the
+    fp32 MFMA path on the same input."""
+    from mockingbird_amd.vocoder.gan import GanGenerator
+    h = synth.HIFIGAN_16K
+    st = synth.gan_state(h, "hifigan", seed=5)["generator"]
+    g16, g32 = GanGenerator(h, st, 0, dtype="f16"), GanGenerator(h, st, 0, dtype="f32")
+    mel = torch.from_numpy(synth.mel_input(200, 4, seed=0)).cuda()
+    y16, y32 = g16(mel), g32(mel)
+    y1 = g16(mel[2:3])
+    torch.cuda.synchronize()
+    assert torch.equal(y1[0], y16[2])
+    assert float(y16.abs().max()) <= 1.0 and int(torch.isnan(y16).sum()) == 0
+    e = hiputil.relerr(y16, y32)
+    print("f16 vs f32 path, full size", e)
+    assert e["rel_rms"] <= F16_REL_TOL, e
 
 
 @pytest.mark.parametrize("kind,cfg", [("hifigan", synth.HIFIGAN_16K), ("fregan", synth.FREGAN_16K)])
