@@ -39,8 +39,12 @@ def test_gan_forward_matches_oracle(cuda, lib, kind, cfg, uic, frames, batch):
 F16_REL_TOL = 5e-3  # fp16 gate, relative RMS, reported separately
 
 
-@pytest.mark.parametrize("kind,cfg", [("hifigan", synth.HIFIGAN_16K), ("fregan", synth.FREGAN_16K)])
-@pytest.mark.parametrize("uic,frames,batch", [(64, 16, 2), (128, 37, 1), (512, 12, 1)])
+# the fp16 path stores activations as 16-byte rows of 8 channels: every conv needs c_in % 8 == 0,
+# i.e. upsample_initial_channel >= 128 (HiFi-GAN, 4 halvings) / 256 (Fre-GAN, 5 halvings)
+@pytest.mark.parametrize("kind,cfg,uic,frames,batch", [
+    ("hifigan", synth.HIFIGAN_16K, 128, 16, 2), ("hifigan", synth.HIFIGAN_16K, 256, 37, 1),
+    ("hifigan", synth.HIFIGAN_16K, 512, 12, 1), ("fregan", synth.FREGAN_16K, 256, 16, 2),
+    ("fregan", synth.FREGAN_16K, 256, 37, 1), ("fregan", synth.FREGAN_16K, 512, 12, 1)])
 def test_gan_forward_f16_matches_oracle(cuda, lib, kind, cfg, uic, frames, batch):
     """fp16 MFMA path (BASELINE configs[4]) against the fp32 oracle."""
     h = synth.small(cfg, uic)
@@ -49,6 +53,17 @@ def test_gan_forward_f16_matches_oracle(cuda, lib, kind, cfg, uic, frames, batch
     e = hiputil.relerr(y, ref)
     print("f16 parity", kind, uic, frames, batch, e)
     assert e["nan"] == 0 and e["rel_rms"] <= F16_REL_TOL, e
+
+
+def test_gan_f16_rejects_narrow_channels(cuda, lib):
+    """A model whose last stage is narrower than 8 channels cannot take the fp16 layout: creation
+    fails loudly (no silent fp32 fallback)."""
+    from mockingbird_amd.vocoder.gan import GanGenerator
+    from mockingbird_amd._lib import MbHipError
+    h = synth.small(synth.HIFIGAN_16K, 64)
+    st = synth.gan_state(h, "hifigan", seed=1)["generator"]
+    with pytest.raises(MbHipError, match="multiples of 8"):
+        GanGenerator(h, st, 0, dtype="f16")
 
 
 def test_gan_f16_full_size_properties(cuda, lib):
