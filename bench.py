@@ -137,7 +137,10 @@ def main():
         ws = model._ws
         smp = torch.empty(plan.n_folds, plan.seq_len, device=dev)
         per_kernel = {}
-        for which, name in ((0, "rnn1_gru"), (1, "rnn2_gru"), (2, "fc1"), (3, "fc2"), (4, "fc3_sampler")):
+        split = os.environ.get("MBHIP_WAVERNN_CHAIN", "") != "classic"
+        names = (("gru1_finish", "rnn2_input_half", "fc1+hh1", "fc2+hh2", "fc3_sampler") if split
+                 else ("rnn1_gru", "rnn2_gru", "fc1", "fc2", "fc3_sampler"))
+        for which, name in enumerate(names):
             us, ab = C.c_float(), C.c_double()
             _lib.check(L.mb_wavernn_bench_kernel(model._h, C.byref(plan), _lib.ptr(mel), _lib.ptr(smp),
                                                  _lib.ptr(ws), ws.numel(), which, 0, C.byref(us), C.byref(ab),
@@ -145,17 +148,21 @@ def main():
             torch.cuda.synchronize()
             per_kernel[name] = {"avg_us": us.value, "algorithmic_bytes": ab.value,
                                 "GBps": ab.value / (us.value * 1e-6) / 1e9}
-        dom = per_kernel["rnn2_gru"]
+        dom_name = "fc1+hh1" if split else "rnn2_gru"
+        dom = per_kernel[dom_name]
         # HBM traffic of that kernel from the committed rocprofv3 PMC pass (FETCH_SIZE doubled per
         # MI355X_MICROARCH.md's gfx950 correction + WRITE_SIZE); counters cannot be read in-process
         traffic = None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_wavernn.json")))
-            traffic = pm.get("rnn2_gru_hbm_bytes_per_launch")
+            traffic = pm.get(("fc1_hh1" if split else "rnn2_gru") + "_hbm_bytes_per_launch")
         except Exception:
             pass
         result["roofline"] = {
-            "kernel": "mb::rnn_rowtile_kernel<EPI_GRU, 1, 8, ...> (WaveRNN rnn2 instance, in-situ marginal duration)",
+            "kernel": ("mb::rnn_dual_linear_kernel<4, ..., 4, ...> (WaveRNN fc1 beside the hidden half of the next step's "
+                       "rnn1, in-situ marginal duration)" if split else
+                       "mb::rnn_rowtile_kernel<EPI_GRU, 1, 8, ...> (WaveRNN rnn2 instance, in-situ marginal duration)"),
+            "chain": "split-hidden" if split else "classic",
             "bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes_per_launch": dom["algorithmic_bytes"], "avg_launch_us": dom["avg_us"],

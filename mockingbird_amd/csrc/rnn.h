@@ -44,6 +44,8 @@ struct RnnK {
   int pre_stride;
   int pre_base_row, pre_n_stride;
   const float* h_prev; const float* c_prev; const float* x_res;  // [N][units]
+  const float* h_pre;  // GRU, optional: precomputed hidden-part pre-activations [N][3*units] gate-major (W_hh.h + b_hh);
+                       // the K segments then hold the input part only and biasH must be null
   float* h_out; float* c_out; float* x_out;                      // [N][units]
   float* y; int ldy; int act;  // LINEAR: y[n*ldy + row]; act 0 none, 1 relu, 2 sigmoid, 3 tanh
   const float* mask; float mask_scale;  // LINEAR: optional y *= mask[n*ldy+row]*mask_scale (dropout)
@@ -124,5 +126,7 @@ void cell_rows(const float* w_ih, int kx, int ldx, const float* w_hh, int kh, in
                std::vector<float>* rows);
 
 int rnn_launch(int epi, const RnnK& k, hipStream_t s);
+// Two LINEAR jobs in one launch (job 0 on the critical path gets the first workgroups); see rnn.hip.
+int rnn_launch_dual_linear(const RnnK& k0, const RnnK& k1, hipStream_t s);
 
 }  // namespace mb

@@ -20,6 +20,7 @@ enum : unsigned {
   RF_BIASX = 1u << 0, RF_BIASH = 1u << 1, RF_PRE = 1u << 2, RF_PREIDX = 1u << 3, RF_FRAME = 1u << 4,
   RF_XRES = 1u << 5, RF_SKIP = 1u << 6, RF_MASK = 1u << 7, RF_DROP = 1u << 8, RF_SEQ = 1u << 9,
   RF_XOUT = 1u << 10, RF_AFFINE = 1u << 11, RF_GUMBEL = 1u << 12, RF_ZERO = 1u << 13, RF_MULTISEG = 1u << 14,
+  RF_HPRE = 1u << 15,
   RF_ACT_SHIFT = 16,  // 2 bits
   RF_GENERIC = 1u << 31
 };
@@ -41,6 +42,7 @@ static unsigned rnn_features(int epi, const RnnK& k) {
   if (k.gum_slot) f |= RF_GUMBEL;
   if (k.zero_slot) f |= RF_ZERO;
   if (k.nseg > 1) f |= RF_MULTISEG;
+  if (k.h_pre) f |= RF_HPRE;
   if (epi == EPI_LINEAR) f |= (unsigned)(k.act & 3) << RF_ACT_SHIFT;
   return f;
 }
@@ -57,11 +59,13 @@ struct RnnDev {
 #define RHAS(bit, cond) ((F & RF_GENERIC) ? (cond) : ((F & (bit)) != 0))
 
 template <int EPI, int NT, int UB, unsigned F>
-__global__ __launch_bounds__(512) void rnn_rowtile_kernel(RnnDev d) {
+__device__ __forceinline__ void rnn_rowtile_body(const RnnDev& d, const int bx, const int by) {
   constexpr int NW = 8;
   constexpr int RL = (EPI == EPI_GRU) ? 3 : 4;
   constexpr int BLK = 4 * RL * 16;  // floats per (tile, k-block)
-  constexpr int NPART = (EPI == EPI_GRU) ? 2 : 1;
+  // GRU keeps the hidden-part sums apart (n = tanh(i_n + r*h_n)); an instance whose hidden part comes
+  // precomputed (RF_HPRE) has only input-part k-blocks and reduces one partial per wave
+  constexpr int NPART = (EPI == EPI_GRU && !(F & RF_HPRE)) ? 2 : 1;
   __shared__ __attribute__((aligned(16))) float red[NW * NPART * NT * 256];
   const RnnK& a = d.k;
   const bool f_biasx = RHAS(RF_BIASX, a.biasX != nullptr), f_biash = RHAS(RF_BIASH, a.biasH != nullptr);
@@ -72,13 +76,14 @@ __global__ __launch_bounds__(512) void rnn_rowtile_kernel(RnnDev d) {
   const bool f_xout = RHAS(RF_XOUT, a.x_out != nullptr), f_aff = RHAS(RF_AFFINE, a.aff_slot != nullptr);
   const bool f_gum = RHAS(RF_GUMBEL, a.gum_slot != nullptr), f_zero = RHAS(RF_ZERO, a.zero_slot != nullptr);
   const bool f_mseg = RHAS(RF_MULTISEG, a.nseg > 1);
+  const bool f_hpre = RHAS(RF_HPRE, a.h_pre != nullptr);
   const int act = (F & RF_GENERIC) ? a.act : (int)((F >> RF_ACT_SHIFT) & 3);
 
   MB_MARK(a.trace, 0, 0);
   trace_begin(a.trace);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int mt = blockIdx.x, ntile0 = blockIdx.y * NT;  // NT column tiles share one weight fetch
+  const int mt = bx, ntile0 = by * NT;  // NT column tiles share one weight fetch
   const int i = lane & 15, kq = lane >> 4;
   const int u = i >> 2, tau = (i & 3) < RL ? (i & 3) : RL - 1;  // dead 4th GRU row re-reads row 2
   const float* wl = a.w + (size_t)mt * a.nkb_total * BLK + ((u * RL + tau) * 4 + kq) * 4;
@@ -188,6 +193,7 @@ __global__ __launch_bounds__(512) void rnn_rowtile_kernel(RnnDev d) {
   float l_bx[4] = {0.f, 0.f, 0.f, 0.f}, l_pre[4] = {0.f, 0.f, 0.f, 0.f}, l_bh[4] = {0.f, 0.f, 0.f, 0.f};
   float l_mask[4] = {1.f, 1.f, 1.f, 1.f};
   float l_hp = 0.f, l_cp = 0.f, l_xr = 0.f, l_xw = 0.f, l_ag[4] = {0.f, 0.f, 0.f, 0.f};
+  float l_hs[4] = {0.f, 0.f, 0.f, 0.f};  // precomputed hidden-part pre-activations (W_hh.h + b_hh)
   {
     const float* prp = a.pre_table + (size_t)prow * a.pre_stride;
     const size_t so = (size_t)en * H + ej;
@@ -205,6 +211,7 @@ __global__ __launch_bounds__(512) void rnn_rowtile_kernel(RnnDev d) {
         if (f_biasx) l_bx[g] = a.biasX[g * H + ej];
         if (f_pre) l_pre[g] = prp[g * H + ej];
         if (f_biash) l_bh[g] = a.biasH[g * H + ej];
+        if (EPI == EPI_GRU && f_hpre) l_hs[g] = a.h_pre[(size_t)en * (RL * H) + g * H + ej];
       }
       if (EPI == EPI_GRU) l_hp = a.h_prev[so];
       if (EPI == EPI_LSTM) l_cp = a.c_prev[so];
@@ -256,6 +263,10 @@ __global__ __launch_bounds__(512) void rnn_rowtile_kernel(RnnDev d) {
     }
   }
   MB_MARK(a.trace, 5, 1);
+  if (EPI == EPI_GRU && f_hpre) {
+#pragma unroll
+    for (int g = 0; g < RL; ++g) sh[g] += l_hs[g];
+  }
   const int n = en_raw, du = edu;
   const float xsE = (f_aff && slotE) ? 2.f * (float)argmax_class(slotE) / ((float)a.aff_C - 1.f) - 1.f : 0.f;
   if (f_aff && mt == 0 && du == 0 && n < a.N && fr_s > 0) {  // previous step's sample -> output tensor
@@ -341,6 +352,21 @@ __global__ __launch_bounds__(512) void rnn_rowtile_kernel(RnnDev d) {
   trace_end(a.trace);
 }
 
+template <int EPI, int NT, int UB, unsigned F>
+__global__ __launch_bounds__(512) void rnn_rowtile_kernel(RnnDev d) {
+  rnn_rowtile_body<EPI, NT, UB, F>(d, blockIdx.x, blockIdx.y);
+}
+
+// Two independent LINEAR jobs in ONE launch: workgroups with blockIdx.x < nx0 run job 0 (the one on
+// the critical path: they are dispatched first), the rest run job 1 on the CUs job 0 leaves idle.
+// The WaveRNN loop uses it to compute the hidden halves W_hh.h + b_hh of the NEXT step's GRUs beside
+// fc1 / fc2 (wavernn.hip), which takes them off the dependent chain.
+template <int UB0, unsigned F0, int UB1, unsigned F1>
+__global__ __launch_bounds__(512) void rnn_dual_linear_kernel(RnnDev d0, RnnDev d1, int nx0) {
+  if ((int)blockIdx.x < nx0) rnn_rowtile_body<EPI_LINEAR, 1, UB0, F0>(d0, blockIdx.x, blockIdx.y);
+  else rnn_rowtile_body<EPI_LINEAR, 1, UB1, F1>(d1, blockIdx.x - nx0, blockIdx.y);
+}
+
 void pack_rowtile(const float* rows, int n_live_rows, int K, int RL, std::vector<float>* out) {
   const int per_tile = 4 * RL;
   const int n_mt = (n_live_rows + per_tile - 1) / per_tile;
@@ -381,6 +407,8 @@ void cell_rows(const float* w_ih, int kx, int ldx, const float* w_hh, int kh, in
   X(EPI_LINEAR, 1, 4, RF_PRE | RF_FRAME | ACT(1))                                                         \
   X(EPI_LINEAR, 1, 4, RF_BIASX)                                                                           \
   X(EPI_LINEAR, 1, 4, RF_BIASX | RF_FRAME | RF_GUMBEL)                                                    \
+  /* WaveRNN split-hidden chain: rnn2 on its input half only (hidden half precomputed) */                 \
+  X(EPI_GRU, 1, 4, RF_PRE | RF_FRAME | RF_HPRE | RF_XRES | RF_XOUT | RF_ZERO)                             \
   /* Tacotron decoder: prenet fc1/fc2 (mask / on-device dropout), attention GRU, rnn_input, LSTMs, mel */ \
   X(EPI_LINEAR, 1, 2, RF_BIASX | RF_SKIP | RF_MASK | ACT(1))                                              \
   X(EPI_LINEAR, 1, 2, RF_BIASX | RF_SKIP | RF_DROP | ACT(1))                                              \
@@ -392,10 +420,45 @@ void cell_rows(const float* w_ih, int kx, int ldx, const float* w_hh, int kh, in
   /* CBHG bidirectional GRU scan */                                                                       \
   X(EPI_GRU, 1, 2, RF_PRE | RF_BIASH | RF_SEQ)
 
+static int make_rnn_dev(const RnnK& k, RnnDev* d) {
+  d->k = k;
+  int start = 0;
+  for (int t = 0; t < 4; ++t) {
+    if (t < k.nseg) {
+      d->segp[t] = k.seg[t].p; d->segld[t] = k.seg[t].ld; d->segpart[t] = k.seg[t].part; d->segstart[t] = start;
+      start += k.seg[t].nkb;
+    } else {
+      d->segp[t] = k.seg[0].p; d->segld[t] = 0; d->segpart[t] = 0; d->segstart[t] = 0x7fffffff;
+    }
+  }
+  MB_REQUIRE(start == k.nkb_total, "rnn_launch: segments cover %d k-blocks, nkb_total=%d", start, k.nkb_total);
+  return MB_OK;
+}
+
+int rnn_launch_dual_linear(const RnnK& k0, const RnnK& k1, hipStream_t s) {
+  constexpr int NW = 8;
+  MB_REQUIRE(k0.N >= 1 && k0.N == k1.N && k0.nseg == 1 && k1.nseg == 1, "rnn_launch_dual: bad shape");
+  RnnDev d0, d1;
+  int rc = make_rnn_dev(k0, &d0);
+  if (!rc) rc = make_rnn_dev(k1, &d1);
+  if (rc) return rc;
+  const int nx0 = cdiv(k0.units, 16), nx1 = cdiv(k1.units, 16);
+  const unsigned f0 = rnn_features(EPI_LINEAR, k0), f1 = rnn_features(EPI_LINEAR, k1);
+  constexpr unsigned F0 = RF_PRE | RF_FRAME | (1u << RF_ACT_SHIFT), F1 = RF_BIASX;
+  const int pw0 = cdiv(k0.nkb_total, NW), pw1 = cdiv(k1.nkb_total, NW);
+  MB_REQUIRE(f0 == F0 && f1 == F1 && pw0 == 4 && pw1 == 4,
+             "rnn_launch_dual: only the (relu table linear, biased linear) K=512 pair is instantiated (features %x/%x)", f0, f1);
+  dim3 grid(nx0 + nx1, cdiv(k0.N, 16));
+  hipLaunchKernelGGL((rnn_dual_linear_kernel<4, F0, 4, F1>), grid, dim3(NW * 64), 0, s, d0, d1, nx0);
+  MB_HIP(hipGetLastError());
+  return MB_OK;
+}
+
 int rnn_launch(int epi, const RnnK& k, hipStream_t s) {
   MB_REQUIRE(k.N >= 1 && k.units >= 1 && k.nseg >= 1 && k.nseg <= 4, "rnn_launch: bad shape");
   MB_REQUIRE(!k.aff_slot || (k.fr_base && k.nseg >= 1 && epi == EPI_GRU), "rnn_launch: rebuilt segment needs the fold geometry");
   MB_REQUIRE(!k.gum_slot || (k.fr_base && epi == EPI_LINEAR && k.units % 4 == 0), "rnn_launch: fused sampler needs the step index");
+  MB_REQUIRE(!k.h_pre || (epi == EPI_GRU && !k.biasH), "rnn_launch: h_pre is a GRU feature and already holds b_hh");
   constexpr int NW = 8;
   const int n_mt = (epi == EPI_LINEAR) ? cdiv(k.units, 16) : cdiv(k.units, 4);
   // More than 16 columns AND a weight matrix big enough to be bandwidth-bound (the batch-32
@@ -406,17 +469,8 @@ int rnn_launch(int epi, const RnnK& k, hipStream_t s) {
   const size_t wbytes = (size_t)n_mt * k.nkb_total * 4 * rl * 16 * sizeof(float);
   const int nt = (k.N > 16 && wbytes >= ((size_t)12 << 20)) ? 2 : 1;
   RnnDev d;
-  d.k = k;
-  int start = 0;
-  for (int t = 0; t < 4; ++t) {
-    if (t < k.nseg) {
-      d.segp[t] = k.seg[t].p; d.segld[t] = k.seg[t].ld; d.segpart[t] = k.seg[t].part; d.segstart[t] = start;
-      start += k.seg[t].nkb;
-    } else {
-      d.segp[t] = k.seg[0].p; d.segld[t] = 0; d.segpart[t] = 0; d.segstart[t] = 0x7fffffff;
-    }
-  }
-  MB_REQUIRE(start == k.nkb_total, "rnn_launch: segments cover %d k-blocks, nkb_total=%d", start, k.nkb_total);
+  int rcd = make_rnn_dev(k, &d);
+  if (rcd) return rcd;
   const int per_wave = cdiv(k.nkb_total, NW);
   const int ub = nt == 2 ? (per_wave >= 4 ? 4 : 2) : (per_wave >= 8 ? 8 : (per_wave >= 4 ? 4 : 2));
   const unsigned feat = rnn_features(epi, k);

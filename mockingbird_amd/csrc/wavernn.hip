@@ -15,6 +15,13 @@
 //   * what remains per step is 5 dependent skinny GEMMs (rnn.hip) + the
 //     sampler; the steps are captured in a hipGraph and replayed, the step
 //     index lives in device memory so the graph is parameter free.
+//   * production ("split-hidden") chain: a GRU's hidden half W_hh.h + b_hh depends only on the
+//     PREVIOUS step's state, so it is computed beside fc1 / fc2 of the previous step in the same
+//     launches (rnn_dual_linear_kernel: extra workgroups on CUs the 64-workgroup fc launch leaves
+//     idle) and leaves the dependent chain.  rnn1's input half is W_ih1.(Ipre[pos] + x*W_I[:,0]) =
+//     T1[pos] + x*(W_ih1.W_I[:,0]) with T1 one more per-position table, so once the sample x is
+//     known rnn1 is ELEMENTWISE (wavernn_gru1_finish_kernel) and rnn2 only multiplies its input
+//     half (K = 512 instead of 1024).  Still 5 launches per step, about half the bytes on the chain.
 #include "rnn.h"
 
 namespace mb {
@@ -93,6 +100,51 @@ __global__ void wavernn_flush_kernel(const unsigned long long* slot, float* samp
 
 // step_base += n (last node of every graph replay / after every eager step)
 __global__ void wavernn_bump_kernel(int* step_base, int n) { *step_base += n; }
+
+// Split-hidden chain, first launch of a step: h1 = GRUCell(I([x, m_t, a1_t]), h1); x1 = I(..) + h1
+// (:195-198) with every matrix product already done:
+//   i_g = T1[pos][g] + x * g1[g]         T1 = W_ih1.(W_I[:,1:].[m;a1] + b_I) + b_ih1, g1 = W_ih1.W_I[:,0]
+//   h_g = P1[n][g]                       W_hh1.h1 + b_hh1, left by the previous step's fc1 launch
+// x is decoded from the argmax word the previous step's fc3 launch left (0 = no sample yet -> x = 0).
+// One thread per (fold, unit); all loads are issued before the first use.
+struct Fin1K {
+  const unsigned long long* slot;  // [nl]
+  const float* T1; const float* Ipre; const float* P1; const float* g1; const float* wI0; const float* h_prev;
+  float* h_out; float* x_out; float* samples; volatile int* progress;
+  const int* step_base; int step_off, n_off, nl, R, C, S, fold_stride, total_len;
+  unsigned long long* trace;
+};
+__global__ __launch_bounds__(256) void wavernn_gru1_finish_kernel(Fin1K a) {
+  trace_begin(a.trace);
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int n = idx / a.R, j = idx - n * a.R;
+  if (n >= a.nl) return;
+  const unsigned long long slot = a.slot[n];  // fresh data: requested first
+  const int s = *a.step_base + a.step_off;
+  const int H = a.R;
+  const float* p1 = a.P1 + (size_t)n * 3 * H + j;
+  const float hr = p1[0], hz = p1[H], hn = p1[2 * H];
+  const float hp = a.h_prev[(size_t)n * H + j];
+  unsigned pos = (unsigned)(a.n_off + n) * (unsigned)a.fold_stride + (unsigned)s;
+  if (pos > (unsigned)a.total_len) pos = (unsigned)a.total_len;  // zero-conditioning row
+  const float* t1 = a.T1 + (size_t)pos * 3 * H + j;
+  const float tr = t1[0], tz = t1[H], tn = t1[2 * H];
+  const float ip = a.Ipre[(size_t)pos * H + j];
+  const float gr = a.g1[j], gz = a.g1[H + j], gn = a.g1[2 * H + j], w0 = a.wI0[j];
+  const float x = slot ? 2.f * (float)argmax_class(slot) / ((float)a.C - 1.f) - 1.f : 0.f;
+  // torch GRUCell, gate order (r, z, n)
+  const float rg = sigmoidf_((tr + x * gr) + hr);
+  const float zg = sigmoidf_((tz + x * gz) + hz);
+  const float ng = tanhf((tn + x * gn) + rg * hn);
+  const float hy = ng + zg * (hp - ng);
+  a.h_out[(size_t)n * H + j] = hy;
+  a.x_out[(size_t)n * H + j] = (ip + x * w0) + hy;
+  if (j == 0 && s > 0) {  // previous step's sample -> output tensor
+    a.samples[(size_t)(a.n_off + n) * a.S + (s - 1)] = x;
+    if (a.progress && a.n_off + n == 0 && (s - 1) % 100 == 0) *a.progress = s;
+  }
+  trace_end(a.trace);
+}
 
 // softmax -> Categorical.sample() -> 2k/(C-1)-1   (:222-228).  torch.multinomial(p, 1) on the
 // CPU path is argmax(p / Exp(1) noise) (verified bit-exact), restated here with
@@ -217,6 +269,10 @@ struct mb_wavernn {
   // loop weights
   DevBuf wI0, g1I0, w_rnn1, w_rnn2, w_fc1, w_fc2, w_fc3;
   DevBuf b_ih1, b_hh1, b_hh2, b_fc3;
+  // split-hidden chain: T1 table conv, rnn2 input half (GRU tile order, K = R), hidden halves as plain
+  // row-tile linears (rows in torch gate-major order)
+  CondConv t_T1;
+  DevBuf w_rnn2x, w_hh1, w_hh2;
   // Folds are independent sequences: they are dealt to up to MAX_LANES "lanes", each with its own
   // stream + graph, so the per-kernel dependency latency of one lane overlaps with the others.
   static constexpr int MAX_LANES = 8;
@@ -361,6 +417,26 @@ extern "C" int mb_wavernn_create(const mb_wavernn_config* cfg, const float* cons
       RC(w->g1I0.upload(g.data(), g.size()));
     }
     RC(w->b_ih1.upload(bih, 3 * R)); RC(w->b_hh1.upload(bhh, 3 * R));
+    {  // T1 = (W_ih1 . W_I[:,1:]) . [m; a1] + (W_ih1 . b_I + b_ih1): one more 1x1 conv over the conditioning
+      const int KC = FEAT + A;
+      std::vector<float> m((size_t)3 * R * KC), mb(3 * R);
+      std::vector<double> acc(KC);
+      for (int r = 0; r < 3 * R; ++r) {
+        std::fill(acc.begin(), acc.end(), 0.0);
+        double ab = (double)bih[r];
+        for (int k2 = 0; k2 < R; ++k2) {
+          const double wv = (double)wih[(size_t)r * R + k2];
+          const float* wi = WI + (size_t)k2 * KI + 1;
+          for (int q = 0; q < KC; ++q) acc[q] += wv * (double)wi[q];
+          ab += wv * (double)bI[k2];
+        }
+        for (int q = 0; q < KC; ++q) m[(size_t)r * KC + q] = (float)acc[q];
+        mb[r] = (float)ab;
+      }
+      RC(make_cond_conv(&w->t_T1, m.data(), 3 * R, KC, 1, 0, mb.data(), nullptr));
+    }
+    pack_rowtile(whh, 3 * R, R, 4, &packed);
+    RC(w->w_hh1.upload(packed.data(), packed.size()));
   }
   // rnn2 :110 (input = [x, a2])
   {
@@ -369,6 +445,11 @@ extern "C" int mb_wavernn_create(const mb_wavernn_config* cfg, const float* cons
     pack_rowtile(rows.data(), 3 * R, 2 * R, 3, &packed);
     RC(w->w_rnn2.upload(packed.data(), packed.size()));
     RC(w->b_hh2.upload(bhh, 3 * R));
+    cell_rows(wih, R, R + A, whh, 0, R, 3, &rows);
+    pack_rowtile(rows.data(), 3 * R, R, 3, &packed);
+    RC(w->w_rnn2x.upload(packed.data(), packed.size()));
+    pack_rowtile(whh, 3 * R, R, 4, &packed);
+    RC(w->w_hh2.upload(packed.data(), packed.size()));
     std::vector<float> wa = col_slice(wih, 3 * R, R + A, R, A);
     RC(make_cond_conv(&w->t_g2, wa.data(), 3 * R, A, 1, 0, bih, nullptr));
   }
@@ -408,12 +489,12 @@ extern "C" int mb_wavernn_create(const mb_wavernn_config* cfg, const float* cons
 extern "C" void mb_wavernn_destroy(mb_wavernn* w) {
   if (!w) return;
   auto rel = [](CondConv& c) { c.w.release(); c.b.release(); };
-  rel(w->conv_in); rel(w->conv_out); rel(w->t_I); rel(w->t_g2); rel(w->t_f1); rel(w->t_f2);
+  rel(w->conv_in); rel(w->conv_out); rel(w->t_I); rel(w->t_g2); rel(w->t_f1); rel(w->t_f2); rel(w->t_T1);
   for (auto& c : w->res1) rel(c);
   for (auto& c : w->res2) rel(c);
   for (auto& b : w->up_w) b.release();
   DevBuf* bs[] = {&w->wI0, &w->g1I0, &w->w_rnn1, &w->w_rnn2, &w->w_fc1, &w->w_fc2, &w->w_fc3,
-                  &w->b_ih1, &w->b_hh1, &w->b_hh2, &w->b_fc3};
+                  &w->b_ih1, &w->b_hh1, &w->b_hh2, &w->b_fc3, &w->w_rnn2x, &w->w_hh1, &w->w_hh2};
   for (DevBuf* b : bs) b->release();
   w->drop_graph();
   if (w->ev_in) (void)hipEventDestroy(w->ev_in);
@@ -432,12 +513,20 @@ namespace {
 struct WrnLayout {
   float *r0, *r1, *r2, *aux, *m1, *m2, *cond, *Ipre, *G2, *F1, *F2;
   float *x0, *x1, *x2, *y1, *y2, *logits, *h1, *h2;
+  float *T1, *P1, *P2;  // split-hidden chain: per-position rnn1 input table, hidden-half pre-activations
   int* step; unsigned long long* slots;
   size_t bytes;
 };
 // python-style floor division
 inline long long floordiv(long long a, long long b) { long long q = a / b; if ((a % b != 0) && ((a < 0) != (b < 0))) --q; return q; }
 }  // namespace
+
+// MBHIP_WAVERNN_CHAIN=classic keeps the 5-launch chain with both GRU halves on the dependent path
+// (no T1 table: 6 KB less workspace per conditioning position)
+static bool wavernn_split_chain() {
+  const char* e = getenv("MBHIP_WAVERNN_CHAIN");
+  return !(e && strcmp(e, "classic") == 0);
+}
 
 static void wavernn_layout(const mb_wavernn* w, const mb_wavernn_plan* p, void* base, WrnLayout* L) {
   const mb_wavernn_config& c = w->cfg;
@@ -460,6 +549,8 @@ static void wavernn_layout(const mb_wavernn* w, const mb_wavernn_plan* p, void* 
   L->y1 = ar.take<float>(N * FC); L->y2 = ar.take<float>(N * FC);
   L->logits = ar.take<float>(N * w->n_classes);
   L->h1 = ar.take<float>(2 * N * R); L->h2 = ar.take<float>(2 * N * R);
+  L->P1 = ar.take<float>(N * 3 * R); L->P2 = ar.take<float>(N * 3 * R);
+  L->T1 = ar.take<float>(wavernn_split_chain() ? (T + 1) * 3 * R : 1);
   L->step = ar.take<int>(16);
   L->slots = ar.take<unsigned long long>(2 * N);
   L->bytes = ar.off + 256;
@@ -554,12 +645,19 @@ extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* 
     hipLaunchKernelGGL(repeat_rows_kernel, grid, dim3(256), 0, s, L.aux, F, L.cond + (size_t)FEAT * T, w->hop);
     if (hipGetLastError() != hipSuccess) { set_error("wavernn: conditioning launch failed"); rc = MB_EHIP; }
   }
+  // Production path (no injected noise / teacher forcing / logits dump): the sampler is fused into the
+  // fc3 launch and the next step's input is rebuilt from the argmax word -> 5 launches per step.
+  const bool fused = !d_noise && !d_forced && !d_logits_out && getenv("MBHIP_WAVERNN_NOFUSE") == nullptr;
+  const bool split = fused && wavernn_split_chain();
   // ---- tables (time-major) + the zero-conditioning row = bias ----
   RC(run_cond_conv(w->t_I, L.cond, T, L.Ipre, nullptr, 0, 1, s));
   RC(run_cond_conv(w->t_g2, L.aux + (size_t)1 * A * F, F, L.G2, nullptr, 0, 1, s));
   RC(run_cond_conv(w->t_f1, L.aux + (size_t)2 * A * F, F, L.F1, nullptr, 0, 1, s));
   RC(run_cond_conv(w->t_f2, L.aux + (size_t)3 * A * F, F, L.F2, nullptr, 0, 1, s));
+  if (split) RC(run_cond_conv(w->t_T1, L.cond, T, L.T1, nullptr, 0, 1, s));
   if (!rc) {
+    if (split)
+      MB_HIP(hipMemcpyAsync(L.T1 + (size_t)T * 3 * R, w->t_T1.b.p, sizeof(float) * 3 * R, hipMemcpyDeviceToDevice, s));
     MB_HIP(hipMemcpyAsync(L.Ipre + (size_t)T * R, w->t_I.b.p, sizeof(float) * R, hipMemcpyDeviceToDevice, s));
     MB_HIP(hipMemcpyAsync(L.G2 + (size_t)F * 3 * R, w->t_g2.b.p, sizeof(float) * 3 * R, hipMemcpyDeviceToDevice, s));
     MB_HIP(hipMemcpyAsync(L.F1 + (size_t)F * FC, w->t_f1.b.p, sizeof(float) * FC, hipMemcpyDeviceToDevice, s));
@@ -568,6 +666,16 @@ extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* 
     MB_HIP(hipMemsetAsync(L.h2, 0, sizeof(float) * 2 * N * R, s));
     MB_HIP(hipMemsetAsync(L.step, 0, sizeof(int) * 16, s));
     MB_HIP(hipMemsetAsync(L.slots, 0, sizeof(unsigned long long) * 2 * N, s));
+  }
+  if (split && !rc) {  // P = W_hh.0 + b_hh for the first step, by the same launch the loop uses
+    for (int g = 0; g < 2 && !rc; ++g) {
+      RnnK k;
+      memset(&k, 0, sizeof(k));
+      k.w = g ? w->w_hh2.p : w->w_hh1.p; k.nseg = 1; k.nkb_total = R / 16;
+      k.seg[0] = {g ? L.h2 : L.h1, R, R / 16, 0};
+      k.N = N; k.units = 3 * R; k.biasX = g ? w->b_hh2.p : w->b_hh1.p; k.y = g ? L.P2 : L.P1; k.ldy = 3 * R;
+      rc = rnn_launch(EPI_LINEAR, k, s);
+    }
   }
   if (rc) return rc;
 
@@ -581,9 +689,6 @@ extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* 
   for (int l = 0; l <= lanes; ++l) lane_n0[l] = (int)((long long)N * l / lanes);
   MB_HIP(hipEventRecord(w->ev_cond, s));  // conditioning tables + zeroed state are ready
 
-  // Production path (no injected noise / teacher forcing / logits dump): the sampler is fused into the
-  // fc3 launch and the next step's input is rebuilt inside the rnn1 launch -> 5 launches per step.
-  const bool fused = !d_noise && !d_forced && !d_logits_out && getenv("MBHIP_WAVERNN_NOFUSE") == nullptr;
   auto make_sk = [&](int l) {
     const int n0 = lane_n0[l];
     SampK sk;
@@ -612,6 +717,53 @@ extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* 
     // h1 = rnn1(x, h1); x = x + h1   :196-198
     unsigned long long* slot_prev = L.slots + (size_t)(pp ^ 1) * N + n0;  // written by fc3 of step s-1
     unsigned long long* slot_cur = L.slots + (size_t)pp * N + n0;         // written by fc3 of this step
+    if (split) {
+      float* P1 = L.P1 + (size_t)n0 * 3 * R; float* P2 = L.P2 + (size_t)n0 * 3 * R;
+      // (A) rnn1, elementwise: every product is precomputed (T1 table, P1 from the previous step)
+      if (which & 1) {
+        Fin1K f;
+        f.slot = slot_prev; f.T1 = L.T1; f.Ipre = L.Ipre; f.P1 = P1; f.g1 = w->g1I0.p; f.wI0 = w->wI0.p;
+        f.h_prev = h1p; f.h_out = h1n; f.x_out = x1; f.samples = d_samples; f.progress = h_progress;
+        f.step_base = L.step + l; f.step_off = soff; f.n_off = n0; f.nl = nl; f.R = R; f.C = C; f.S = S;
+        f.fold_stride = plan->fold_stride; f.total_len = T;
+        f.trace = tr ? tr + 0 : nullptr;
+        hipLaunchKernelGGL(wavernn_gru1_finish_kernel, dim3(cdiv(nl * R, 256)), dim3(256), 0, ls, f);
+        MB_HIP(hipGetLastError());
+      }
+      // (B) rnn2 on its input half; hidden half = P2 (left by the previous step's fc2 launch)
+      memset(&k, 0, sizeof(k));
+      k.w = w->w_rnn2x.p; k.nseg = 1; k.nkb_total = R / 16; k.seg[0] = {x1, R, R / 16, 0};
+      k.N = nl; k.units = R; k.h_pre = P2;
+      k.pre_table = L.G2; frame_rows(k); k.pre_stride = 3 * R;
+      k.h_prev = h2p; k.x_res = x1; k.h_out = h2n; k.x_out = x2;
+      k.zero_slot = slot_prev;  // free for fc3 of step s+1: its only reader (A) has run
+      k.trace = tr ? tr + 2 * TRACE_SLOTS : nullptr;
+      if ((which & 2) && (r = rnn_launch(EPI_GRU, k, ls))) return r;
+      // (C) fc1 || P1 = W_hh1.h1 + b_hh1 for the next step; (D) fc2 || P2 = W_hh2.h2 + b_hh2
+      for (int g = 0; g < 2; ++g) {
+        RnnK k1;
+        memset(&k, 0, sizeof(k)); memset(&k1, 0, sizeof(k1));
+        k.w = g ? w->w_fc2.p : w->w_fc1.p; k.nseg = 1; k.nkb_total = R / 16;
+        k.seg[0] = {g ? y1 : x2, g ? FC : R, (g ? FC : R) / 16, 0};
+        k.nkb_total = k.seg[0].nkb;
+        k.N = nl; k.units = FC; k.pre_table = g ? L.F2 : L.F1; frame_rows(k); k.pre_stride = FC;
+        k.y = g ? y2 : y1; k.ldy = FC; k.act = 1;
+        k.trace = tr ? tr + (4 + 2 * g) * TRACE_SLOTS : nullptr;
+        k1.w = g ? w->w_hh2.p : w->w_hh1.p; k1.nseg = 1; k1.nkb_total = R / 16;
+        k1.seg[0] = {g ? h2n : h1n, R, R / 16, 0};
+        k1.N = nl; k1.units = 3 * R; k1.biasX = g ? w->b_hh2.p : w->b_hh1.p; k1.y = g ? P2 : P1; k1.ldy = 3 * R;
+        if ((which & (4 << g)) && (r = rnn_launch_dual_linear(k, k1, ls))) return r;
+      }
+      // (E) logits = fc3(x) with the Gumbel-argmax sampler in the epilogue   :209,222-228
+      memset(&k, 0, sizeof(k));
+      k.w = w->w_fc3.p; k.nseg = 1; k.nkb_total = FC / 16; k.seg[0] = {y2, FC, FC / 16, 0};
+      k.N = nl; k.units = C; k.biasX = w->b_fc3.p; k.ldy = C;
+      frame_rows(k);
+      k.gum_slot = slot_cur; k.gum_seed = seed;
+      k.trace = tr ? tr + 8 * TRACE_SLOTS : nullptr;
+      if ((which & 16) && (r = rnn_launch(EPI_LINEAR, k, ls))) return r;
+      return MB_OK;
+    }
     memset(&k, 0, sizeof(k));
     k.w = w->w_rnn1.p; k.nseg = 2; k.nkb_total = 2 * R / 16;
     k.seg[0] = {x0, R, R / 16, 0}; k.seg[1] = {h1p, R, R / 16, 1};
@@ -788,6 +940,15 @@ extern "C" int mb_wavernn_bench_kernel(mb_wavernn* w, const mb_wavernn_plan* pla
   if (algorithmic_bytes) {
     const double R = w->cfg.rnn_dims, FC = w->cfg.fc_dims, C = w->n_classes, N = plan->n_folds;
     double b = 0;
+    if (wavernn_split_chain()) {
+      switch (which) {  // split-hidden chain (A..E of mb_wavernn_generate), fp32
+        case 0: b = N * 3 * R * 2 + N * R * 2 + 4 * R + 2 * N * R; break;                     // P1, T1 rows, Ipre rows, h1 | g1, wI0 | h1', x1
+        case 1: b = 3 * R * R + N * R + N * 3 * R + N * 3 * R + N * R + 2 * N * R; break;     // W_ih2 | x1, P2, G2 rows, h2 | h2', x2
+        case 2: b = FC * R + 3 * R * R + N * R + 2 * N * FC + N * R + 3 * R + N * 3 * R; break;   // fc1 + W_hh1 | x2, F1 rows, y1 | h1, b_hh1, P1
+        case 3: b = FC * FC + 3 * R * R + N * FC + 2 * N * FC + N * R + 3 * R + N * 3 * R; break; // fc2 + W_hh2
+        default: b = C * FC + N * FC + N * C + C; break;
+      }
+    } else
     switch (which) {  // weights once + activation vectors in/out + table rows, fp32
       case 0: b = 3 * R * 2 * R + 2 * N * R + 2 * N * R + 6 * R; break;
       case 1: b = 3 * R * 2 * R + 2 * N * R + 2 * N * R + 3 * R + N * 3 * R; break;
