@@ -76,6 +76,9 @@ struct RnnK {
   unsigned long long* gum_slot; unsigned long long gum_seed;
   // zero_slot != null: workgroup (0,0) clears zero_slot[0..N) (the argmax words of the NEXT step)
   unsigned long long* zero_slot;
+  // arrive != null (with gum_slot): once this workgroup's argmax atomics have been performed, one lane adds 1
+  // to *arrive (agent scope) -- the in-launch hand-off to the gru1-finish job of rnn_fc3_finish_kernel
+  unsigned int* arrive;
   // diagnostics (MBHIP_TRACE_FILE): per-workgroup (start, end) wall_clock64 ticks, TRACE_SLOTS pairs
   unsigned long long* trace;
 };
@@ -125,7 +128,26 @@ void pack_rowtile(const float* rows, int n_live_rows, int K, int RL, std::vector
 void cell_rows(const float* w_ih, int kx, int ldx, const float* w_hh, int kh, int H, int G,
                std::vector<float>* rows);
 
+// WaveRNN split-hidden chain, rnn1 of a step as an ELEMENTWISE job (wavernn.hip header):
+//   h1 = GRUCell(I([x, m_t, a1_t]), h1); x1 = I(..) + h1   (fatchord_version.py:195-198) with
+//   i_g = T1[pos][g] + x * g1[g]      T1 = W_ih1.(W_I[:,1:].[m;a1] + b_I) + b_ih1,  g1 = W_ih1.W_I[:,0]
+//   h_g = P1[n][g]                    W_hh1.h1 + b_hh1, left by the previous step's fc1 launch
+// x is decoded from the argmax word of the previous step's fc3 launch (0 = no sample yet -> x = 0).
+struct Fin1K {
+  const unsigned long long* slot;  // [nl]
+  const float* T1; const float* Ipre; const float* P1; const float* g1; const float* wI0; const float* h_prev;
+  float* h_out; float* x_out; float* samples; volatile int* progress;
+  const int* step_base; int step_off, n_off, nl, R, C, S, fold_stride, total_len;
+  // in-launch variant: wait until *arrive >= (step index) * arrive_per_step before reading the slots
+  const unsigned int* arrive; unsigned int arrive_per_step;
+  unsigned long long* trace;
+};
 int rnn_launch(int epi, const RnnK& k, hipStream_t s);
+// stand-alone gru1-finish launch (first step of a generate call, or MBHIP_WAVERNN_MERGE=0)
+int rnn_launch_finish(const Fin1K& f, hipStream_t s);
+// fc3 + Gumbel-argmax sampler AND the gru1-finish job of the NEXT step in one launch: the finish
+// workgroups prefetch their sample-independent operands, then wait on the arrival counter (rnn.hip)
+int rnn_launch_fc3_finish(const RnnK& k, const Fin1K& f, hipStream_t s);
 // Two LINEAR jobs in one launch (job 0 on the critical path gets the first workgroups); see rnn.hip.
 int rnn_launch_dual_linear(const RnnK& k0, const RnnK& k1, hipStream_t s);
 

@@ -20,7 +20,7 @@ enum : unsigned {
   RF_BIASX = 1u << 0, RF_BIASH = 1u << 1, RF_PRE = 1u << 2, RF_PREIDX = 1u << 3, RF_FRAME = 1u << 4,
   RF_XRES = 1u << 5, RF_SKIP = 1u << 6, RF_MASK = 1u << 7, RF_DROP = 1u << 8, RF_SEQ = 1u << 9,
   RF_XOUT = 1u << 10, RF_AFFINE = 1u << 11, RF_GUMBEL = 1u << 12, RF_ZERO = 1u << 13, RF_MULTISEG = 1u << 14,
-  RF_HPRE = 1u << 15,
+  RF_HPRE = 1u << 15, RF_ARRIVE = 1u << 20,
   RF_ACT_SHIFT = 16,  // 2 bits
   RF_GENERIC = 1u << 31
 };
@@ -43,6 +43,7 @@ static unsigned rnn_features(int epi, const RnnK& k) {
   if (k.zero_slot) f |= RF_ZERO;
   if (k.nseg > 1) f |= RF_MULTISEG;
   if (k.h_pre) f |= RF_HPRE;
+  if (k.arrive) f |= RF_ARRIVE;
   if (epi == EPI_LINEAR) f |= (unsigned)(k.act & 3) << RF_ACT_SHIFT;
   return f;
 }
@@ -77,6 +78,7 @@ __device__ __forceinline__ void rnn_rowtile_body(const RnnDev& d, const int bx, 
   const bool f_gum = RHAS(RF_GUMBEL, a.gum_slot != nullptr), f_zero = RHAS(RF_ZERO, a.zero_slot != nullptr);
   const bool f_mseg = RHAS(RF_MULTISEG, a.nseg > 1);
   const bool f_hpre = RHAS(RF_HPRE, a.h_pre != nullptr);
+  const bool f_arrive = RHAS(RF_ARRIVE, a.arrive != nullptr);
   const int act = (F & RF_GENERIC) ? a.act : (int)((F >> RF_ACT_SHIFT) & 3);
 
   MB_MARK(a.trace, 0, 0);
@@ -311,7 +313,14 @@ __device__ __forceinline__ void rnn_rowtile_body(const RnnDev& d, const int bx, 
       pk = o1 > pk ? o1 : pk;
       const unsigned long long o2 = __shfl_xor(pk, 32, 64);
       pk = o2 > pk ? o2 : pk;
-      if (du == 0) atomicMax(a.gum_slot + n, pk);
+      if (f_arrive) {
+        // the returned value proves the atomic was performed at the device coherence point; only then
+        // does this workgroup count as arrived (relaxed agent-scope add, nothing else to publish)
+        unsigned int lo = 0;
+        if (du == 0) lo = (unsigned int)atomicMax(a.gum_slot + n, pk);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(lo) : : "memory");
+        if (lane == 0) __hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else if (du == 0) atomicMax(a.gum_slot + n, pk);
     }
     MB_MARK(a.trace, 6, 0);
     trace_end(a.trace);
@@ -355,6 +364,71 @@ __device__ __forceinline__ void rnn_rowtile_body(const RnnDev& d, const int bx, 
 template <int EPI, int NT, int UB, unsigned F>
 __global__ __launch_bounds__(512) void rnn_rowtile_kernel(RnnDev d) {
   rnn_rowtile_body<EPI, NT, UB, F>(d, blockIdx.x, blockIdx.y);
+}
+
+// ---- gru1-finish job (Fin1K, rnn.h): one thread per (fold, unit), all loads issued before first use ----
+template <bool WAIT>
+__device__ __forceinline__ void gru1_finish_body(const Fin1K& a, const int block, const int nthreads) {
+  const int idx = block * nthreads + threadIdx.x;
+  const int H = a.R;
+  int n = idx / H;
+  const int j = idx - n * H;
+  const bool live = n < a.nl;
+  if (!live) n = a.nl - 1;  // clamped: loads legal, nothing stored (keeps every thread at the barrier below)
+  const int s = *a.step_base + a.step_off;
+  const float* p1 = a.P1 + (size_t)n * 3 * H + j;
+  const float hr = p1[0], hz = p1[H], hn = p1[2 * H];
+  const float hp = a.h_prev[(size_t)n * H + j];
+  unsigned pos = (unsigned)(a.n_off + n) * (unsigned)a.fold_stride + (unsigned)s;
+  if (pos > (unsigned)a.total_len) pos = (unsigned)a.total_len;  // zero-conditioning row
+  const float* t1 = a.T1 + (size_t)pos * 3 * H + j;
+  const float tr = t1[0], tz = t1[H], tn = t1[2 * H];
+  const float ip = a.Ipre[(size_t)pos * H + j];
+  const float gr = a.g1[j], gz = a.g1[H + j], gn = a.g1[2 * H + j], w0 = a.wI0[j];
+  unsigned long long slot;
+  if (WAIT) {
+    // every fc3 workgroup of this launch has added 1 to *arrive after its argmax atomics were performed
+    if (threadIdx.x == 0) {
+      const unsigned int target = (unsigned int)s * a.arrive_per_step;  // s = index of the step being prepared
+      int spins = 0;
+      while (__hip_atomic_load(a.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1 << 17))
+        __builtin_amdgcn_s_sleep(1);  // bounded: a lost arrival costs wrong samples, never a hung GPU
+    }
+    __syncthreads();
+    slot = __hip_atomic_load(a.slot + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    slot = a.slot[n];
+  }
+  if (!live) return;
+  const float x = slot ? 2.f * (float)argmax_class(slot) / ((float)a.C - 1.f) - 1.f : 0.f;
+  // torch GRUCell, gate order (r, z, n)
+  const float rg = sigmoidf_((tr + x * gr) + hr);
+  const float zg = sigmoidf_((tz + x * gz) + hz);
+  const float ng = tanhf((tn + x * gn) + rg * hn);
+  const float hy = ng + zg * (hp - ng);
+  a.h_out[(size_t)n * H + j] = hy;
+  a.x_out[(size_t)n * H + j] = (ip + x * w0) + hy;
+  if (j == 0 && s > 0) {  // previous step's sample -> output tensor
+    a.samples[(size_t)(a.n_off + n) * a.S + (s - 1)] = x;
+    if (a.progress && a.n_off + n == 0 && (s - 1) % 100 == 0) *a.progress = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void wavernn_gru1_finish_kernel(Fin1K a) {
+  trace_begin(a.trace);
+  gru1_finish_body<false>(a, blockIdx.x, 256);
+  trace_end(a.trace);
+}
+
+// fc3 + sampler (job 0, first workgroups) and the NEXT step's gru1-finish (job 1) in one launch.
+// Job 1 needs every job-0 workgroup's argmax: job 0 arrives on a device-scope counter (RF_ARRIVE),
+// job 1 prefetches everything that does not depend on the sample and then polls the counter.  All
+// nx0*gridDim.y + finish workgroups are co-resident (far fewer than CUs), job 0 is dispatched first.
+template <unsigned F0>
+__global__ __launch_bounds__(512) void rnn_fc3_finish_kernel(RnnDev d0, Fin1K f, int nx0) {
+  if ((int)blockIdx.x < nx0) { rnn_rowtile_body<EPI_LINEAR, 1, 4, F0>(d0, blockIdx.x, blockIdx.y); return; }
+  if (blockIdx.y != 0) return;
+  gru1_finish_body<true>(f, blockIdx.x - nx0, 512);
 }
 
 // Two independent LINEAR jobs in ONE launch: workgroups with blockIdx.x < nx0 run job 0 (the one on
@@ -450,6 +524,29 @@ int rnn_launch_dual_linear(const RnnK& k0, const RnnK& k1, hipStream_t s) {
              "rnn_launch_dual: only the (relu table linear, biased linear) K=512 pair is instantiated (features %x/%x)", f0, f1);
   dim3 grid(nx0 + nx1, cdiv(k0.N, 16));
   hipLaunchKernelGGL((rnn_dual_linear_kernel<4, F0, 4, F1>), grid, dim3(NW * 64), 0, s, d0, d1, nx0);
+  MB_HIP(hipGetLastError());
+  return MB_OK;
+}
+
+int rnn_launch_finish(const Fin1K& f, hipStream_t s) {
+  MB_REQUIRE(f.nl >= 1 && f.R >= 1, "rnn_launch_finish: bad shape");
+  hipLaunchKernelGGL(wavernn_gru1_finish_kernel, dim3(cdiv(f.nl * f.R, 256)), dim3(256), 0, s, f);
+  MB_HIP(hipGetLastError());
+  return MB_OK;
+}
+
+int rnn_launch_fc3_finish(const RnnK& k, const Fin1K& f, hipStream_t s) {
+  constexpr int NW = 8;
+  constexpr unsigned F0 = RF_BIASX | RF_FRAME | RF_GUMBEL | RF_ARRIVE;
+  RnnDev d0;
+  int rc = make_rnn_dev(k, &d0);
+  if (rc) return rc;
+  MB_REQUIRE(rnn_features(EPI_LINEAR, k) == F0 && cdiv(k.nkb_total, NW) == 4 && k.nseg == 1 && f.arrive == k.arrive,
+             "rnn_launch_fc3_finish: needs the fused-sampler fc3 instance with K = 512 (features %x)", rnn_features(EPI_LINEAR, k));
+  const int nx0 = cdiv(k.units, 16), ny = cdiv(k.N, 16);
+  MB_REQUIRE(f.arrive_per_step == (unsigned)(nx0 * ny), "rnn_launch_fc3_finish: arrive_per_step must be %d", nx0 * ny);
+  dim3 grid(nx0 + cdiv(f.nl * f.R, NW * 64), ny);
+  hipLaunchKernelGGL((rnn_fc3_finish_kernel<F0>), grid, dim3(NW * 64), 0, s, d0, f, nx0);
   MB_HIP(hipGetLastError());
   return MB_OK;
 }

@@ -101,51 +101,6 @@ __global__ void wavernn_flush_kernel(const unsigned long long* slot, float* samp
 // step_base += n (last node of every graph replay / after every eager step)
 __global__ void wavernn_bump_kernel(int* step_base, int n) { *step_base += n; }
 
-// Split-hidden chain, first launch of a step: h1 = GRUCell(I([x, m_t, a1_t]), h1); x1 = I(..) + h1
-// (:195-198) with every matrix product already done:
-//   i_g = T1[pos][g] + x * g1[g]         T1 = W_ih1.(W_I[:,1:].[m;a1] + b_I) + b_ih1, g1 = W_ih1.W_I[:,0]
-//   h_g = P1[n][g]                       W_hh1.h1 + b_hh1, left by the previous step's fc1 launch
-// x is decoded from the argmax word the previous step's fc3 launch left (0 = no sample yet -> x = 0).
-// One thread per (fold, unit); all loads are issued before the first use.
-struct Fin1K {
-  const unsigned long long* slot;  // [nl]
-  const float* T1; const float* Ipre; const float* P1; const float* g1; const float* wI0; const float* h_prev;
-  float* h_out; float* x_out; float* samples; volatile int* progress;
-  const int* step_base; int step_off, n_off, nl, R, C, S, fold_stride, total_len;
-  unsigned long long* trace;
-};
-__global__ __launch_bounds__(256) void wavernn_gru1_finish_kernel(Fin1K a) {
-  trace_begin(a.trace);
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  const int n = idx / a.R, j = idx - n * a.R;
-  if (n >= a.nl) return;
-  const unsigned long long slot = a.slot[n];  // fresh data: requested first
-  const int s = *a.step_base + a.step_off;
-  const int H = a.R;
-  const float* p1 = a.P1 + (size_t)n * 3 * H + j;
-  const float hr = p1[0], hz = p1[H], hn = p1[2 * H];
-  const float hp = a.h_prev[(size_t)n * H + j];
-  unsigned pos = (unsigned)(a.n_off + n) * (unsigned)a.fold_stride + (unsigned)s;
-  if (pos > (unsigned)a.total_len) pos = (unsigned)a.total_len;  // zero-conditioning row
-  const float* t1 = a.T1 + (size_t)pos * 3 * H + j;
-  const float tr = t1[0], tz = t1[H], tn = t1[2 * H];
-  const float ip = a.Ipre[(size_t)pos * H + j];
-  const float gr = a.g1[j], gz = a.g1[H + j], gn = a.g1[2 * H + j], w0 = a.wI0[j];
-  const float x = slot ? 2.f * (float)argmax_class(slot) / ((float)a.C - 1.f) - 1.f : 0.f;
-  // torch GRUCell, gate order (r, z, n)
-  const float rg = sigmoidf_((tr + x * gr) + hr);
-  const float zg = sigmoidf_((tz + x * gz) + hz);
-  const float ng = tanhf((tn + x * gn) + rg * hn);
-  const float hy = ng + zg * (hp - ng);
-  a.h_out[(size_t)n * H + j] = hy;
-  a.x_out[(size_t)n * H + j] = (ip + x * w0) + hy;
-  if (j == 0 && s > 0) {  // previous step's sample -> output tensor
-    a.samples[(size_t)(a.n_off + n) * a.S + (s - 1)] = x;
-    if (a.progress && a.n_off + n == 0 && (s - 1) % 100 == 0) *a.progress = s;
-  }
-  trace_end(a.trace);
-}
-
 // softmax -> Categorical.sample() -> 2k/(C-1)-1   (:222-228).  torch.multinomial(p, 1) on the
 // CPU path is argmax(p / Exp(1) noise) (verified bit-exact), restated here with
 // the noise either injected (parity) or drawn from Philox (production; one call per 4 classes).
@@ -649,6 +604,11 @@ extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* 
   // fc3 launch and the next step's input is rebuilt from the argmax word -> 5 launches per step.
   const bool fused = !d_noise && !d_forced && !d_logits_out && getenv("MBHIP_WAVERNN_NOFUSE") == nullptr;
   const bool split = fused && wavernn_split_chain();
+  // MBHIP_WAVERNN_MERGE=1 (experiment, off): fc3 + the next step's elementwise rnn1 in ONE launch (4 per
+  // step) through an in-launch arrival counter.  Measured on MI355X (profiles/r01_wavernn_chain_ab.json):
+  // 26.4 us/step against 25.7 with the kernel boundary -- the 64-arrival fan-in + poll + fresh slot
+  // read costs more than the 1.7 us boundary it removes, so the boundary stays.
+  const bool merged = split && getenv("MBHIP_WAVERNN_MERGE") && atoi(getenv("MBHIP_WAVERNN_MERGE")) == 1;
   // ---- tables (time-major) + the zero-conditioning row = bias ----
   RC(run_cond_conv(w->t_I, L.cond, T, L.Ipre, nullptr, 0, 1, s));
   RC(run_cond_conv(w->t_g2, L.aux + (size_t)1 * A * F, F, L.G2, nullptr, 0, 1, s));
@@ -719,16 +679,25 @@ extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* 
     unsigned long long* slot_cur = L.slots + (size_t)pp * N + n0;         // written by fc3 of this step
     if (split) {
       float* P1 = L.P1 + (size_t)n0 * 3 * R; float* P2 = L.P2 + (size_t)n0 * 3 * R;
-      // (A) rnn1, elementwise: every product is precomputed (T1 table, P1 from the previous step)
-      if (which & 1) {
+      // (A) rnn1, elementwise: every product is precomputed (T1 table, P1 from the previous step).
+      //     merged: A of step s+1 rides in the fc3 launch of step s (below); A of step 0 is launched
+      //     once before the loop.
+      auto fin = [&](int parity, int off) {
         Fin1K f;
-        f.slot = slot_prev; f.T1 = L.T1; f.Ipre = L.Ipre; f.P1 = P1; f.g1 = w->g1I0.p; f.wI0 = w->wI0.p;
-        f.h_prev = h1p; f.h_out = h1n; f.x_out = x1; f.samples = d_samples; f.progress = h_progress;
-        f.step_base = L.step + l; f.step_off = soff; f.n_off = n0; f.nl = nl; f.R = R; f.C = C; f.S = S;
+        memset(&f, 0, sizeof(f));
+        f.slot = L.slots + (size_t)(parity ^ 1) * N + n0;
+        f.T1 = L.T1; f.Ipre = L.Ipre; f.P1 = P1; f.g1 = w->g1I0.p; f.wI0 = w->wI0.p;
+        f.h_prev = L.h1 + ((size_t)parity * N + n0) * R; f.h_out = L.h1 + ((size_t)(parity ^ 1) * N + n0) * R;
+        f.x_out = x1; f.samples = d_samples; f.progress = h_progress;
+        f.step_base = L.step + l; f.step_off = off; f.n_off = n0; f.nl = nl; f.R = R; f.C = C; f.S = S;
         f.fold_stride = plan->fold_stride; f.total_len = T;
+        return f;
+      };
+      if (which == 0x100) return rnn_launch_finish(fin(pp, soff), ls);  // prologue: A of the first step only
+      if ((which & 1) && !merged) {
+        Fin1K f = fin(pp, soff);
         f.trace = tr ? tr + 0 : nullptr;
-        hipLaunchKernelGGL(wavernn_gru1_finish_kernel, dim3(cdiv(nl * R, 256)), dim3(256), 0, ls, f);
-        MB_HIP(hipGetLastError());
+        if ((r = rnn_launch_finish(f, ls))) return r;
       }
       // (B) rnn2 on its input half; hidden half = P2 (left by the previous step's fc2 launch)
       memset(&k, 0, sizeof(k));
@@ -761,7 +730,13 @@ extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* 
       frame_rows(k);
       k.gum_slot = slot_cur; k.gum_seed = seed;
       k.trace = tr ? tr + 8 * TRACE_SLOTS : nullptr;
-      if ((which & 16) && (r = rnn_launch(EPI_LINEAR, k, ls))) return r;
+      if (merged && (which & 1)) {  // + A of step s+1 in the same launch
+        Fin1K f = fin(pp ^ 1, soff + 1);
+        k.arrive = reinterpret_cast<unsigned int*>(L.step + 8 + l);
+        f.arrive = k.arrive;
+        f.arrive_per_step = (unsigned)(cdiv(C, 16) * cdiv(nl, 16));
+        if ((which & 16) && (r = rnn_launch_fc3_finish(k, f, ls))) return r;
+      } else if ((which & 16) && (r = rnn_launch(EPI_LINEAR, k, ls))) return r;
       return MB_OK;
     }
     memset(&k, 0, sizeof(k));
@@ -828,6 +803,10 @@ extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* 
     if (!fused) hipLaunchKernelGGL(wavernn_init_kernel, dim3(lane_n0[l + 1] - lane_n0[l]), dim3(128), 0, w->lane_stream[l], make_sk(l));
     MB_HIP(hipGetLastError());
   }
+
+  if (merged)
+    for (int l = 0; l < lanes && !rc; ++l) rc = step(l, 0, 0, 0x100);
+  if (rc) return rc;
 
   // diagnostics: MBHIP_TRACE_FILE=<path> records per-kernel first-wave-start / last-store-end device
   // timestamps (wall_clock64, 100 MHz) of the LAST graph replay and dumps them after a sync.
@@ -897,7 +876,7 @@ extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* 
     (void)hipFree(d_trace);
     if (FILE* f = fopen(trace_path, "wb")) { fwrite(host.data(), sizeof(unsigned long long), host.size(), f); fclose(f); }
   }
-  w->last_launches = (fused ? 5 : 6) * S * lanes;
+  w->last_launches = (merged ? 4 : fused ? 5 : 6) * S * lanes;
   w->last_lanes = lanes;
   w->timed = true;
   MB_HIP(hipEventRecord(w->ev_out, s));
