@@ -125,6 +125,33 @@ typedef struct mb_conv1d_f16_args {
 
 int mb_conv1d_f16(const mb_conv1d_f16_args* a, mb_stream_t stream);
 
+/* Fused ResBlock unit (fp16 path):  y = x + conv2(lrelu(conv1(lrelu(x)) + b1)) + b2  with conv1
+ * (k taps, dilation d, "same" padding) and conv2 (k taps, dilation 1), i.e. ONE iteration of
+ *   ResBlock1.forward  models/vocoder/hifigan/models.py:39-46
+ *                      models/vocoder/fregan/generator.py:43-50
+ * in a single launch, the intermediate activation kept in LDS (resblock_f16.hip).  Optionally the
+ * result is scaled and accumulated into y (the mean over the parallel ResBlocks, models.py:141-145):
+ *   y = (accumulate ? y : 0) + out_scale * (x + conv2(...)).
+ * Supported: channels in {32,64,128,256}, k odd >= 3 (mb_resblock_pair_f16_supported). */
+int mb_resblock_pair_f16_supported(int channels, int ksize, int dilation);
+size_t mb_resblock_pair_f16_packed_halves(int channels, int ksize);
+/* h_w1, h_w2: fp32 torch Conv1d weights [C][C][k], weight norm folded -> one fp16 A-fragment stream */
+int mb_resblock_pair_f16_pack(const float* h_w1, const float* h_w2, int channels, int ksize,
+                              uint16_t* h_packed);
+typedef struct mb_resblock_pair_f16_args {
+  const void* d_x;        /* fp16 [B][t][channels]                                */
+  void* d_y;              /* fp16 [B][t][channels], must not alias d_x            */
+  const void* d_wpacked;  /* image from mb_resblock_pair_f16_pack                 */
+  const float* d_b1;      /* fp32 [channels] bias of conv1                        */
+  const float* d_b2;      /* fp32 [channels] bias of conv2                        */
+  int batch, channels, t;
+  int ksize, dilation;    /* conv1 dilation; conv2 has dilation 1                 */
+  float slope;            /* leaky_relu slope in (0,1), applied before both convs */
+  float out_scale;        /* 0 = 1.0                                              */
+  int accumulate;
+} mb_resblock_pair_f16_args;
+int mb_resblock_pair_f16(const mb_resblock_pair_f16_args* a, mb_stream_t stream);
+
 /* Layout/precision converters between the reference's [B][C][T] fp32 tensors and the
  * time-major fp16 activations above (mel upload; tests). */
 int mb_f32_to_f16_tm(const float* d_x, void* d_y, int batch, int channels, int t, mb_stream_t stream);

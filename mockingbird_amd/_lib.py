@@ -48,6 +48,15 @@ class ConvF16Args(C.Structure):
     ]
 
 
+class ResPairF16Args(C.Structure):
+    _fields_ = [
+        ("d_x", C.c_void_p), ("d_y", C.c_void_p), ("d_wpacked", C.c_void_p), ("d_b1", C.c_void_p),
+        ("d_b2", C.c_void_p),
+        ("batch", C.c_int), ("channels", C.c_int), ("t", C.c_int), ("ksize", C.c_int), ("dilation", C.c_int),
+        ("slope", C.c_float), ("out_scale", C.c_float), ("accumulate", C.c_int),
+    ]
+
+
 MB_F32, MB_F16 = 0, 1
 
 
@@ -108,6 +117,10 @@ SIGNATURES = {
     "mb_conv1d_f16_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_void_p]),
     "mb_conv1d_f16": (C.c_int, [C.POINTER(ConvF16Args), C.c_void_p]),
+    "mb_resblock_pair_f16_supported": (C.c_int, [C.c_int] * 3),
+    "mb_resblock_pair_f16_packed_halves": (C.c_size_t, [C.c_int] * 2),
+    "mb_resblock_pair_f16_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "mb_resblock_pair_f16": (C.c_int, [C.POINTER(ResPairF16Args), C.c_void_p]),
     "mb_f32_to_f16_tm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mb_f16_tm_to_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mb_gan_num_weights": (C.c_int, [C.POINTER(GanConfig)]),

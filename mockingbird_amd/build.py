@@ -12,7 +12,7 @@ ROOT = Path(__file__).resolve().parent
 CSRC = ROOT / "csrc"
 LIB = ROOT / "libmbhip.so"
 ARCH = "gfx950"
-SOURCES = ["common.hip", "conv1d.hip", "conv1d_f16.hip", "gan.hip", "rnn.hip", "wavernn.hip", "tacotron.hip",
+SOURCES = ["common.hip", "conv1d.hip", "conv1d_f16.hip", "resblock_f16.hip", "gan.hip", "rnn.hip", "wavernn.hip", "tacotron.hip",
            "maximum_path.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
@@ -56,7 +56,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
             print(out.decode(errors="replace"))
     if failed:
         raise RuntimeError("hipcc compilation failed")
-    if force or procs or not LIB.exists():
+    if force or procs or not LIB.exists() or any(o.stat().st_mtime > LIB.stat().st_mtime for o in objs):
         cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB), *map(str, objs)]
         if verbose:
             print("[mbhip build]", " ".join(cmd), flush=True)

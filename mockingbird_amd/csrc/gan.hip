@@ -114,6 +114,9 @@ struct mb_gan {
   mb_gan_config cfg;
   int dtype = MB_F32;
   std::vector<ConvW> convs;  // ABI order
+  // fp16 path: fused (convs1[d], convs2[d]) weight streams of the ResBlocks (resblock_f16.hip), indexed
+  // ((stage * num_kernels + kernel) * num_dilations + d); empty buffer = pair not fusable -> two launches
+  std::vector<DevBuf> pairs;
   int hop;
   // indices into convs
   int i_pre, i_ups, i_cond, i_resout, i_rb, i_post;
@@ -188,6 +191,27 @@ extern "C" int mb_gan_create_ex(const mb_gan_config* cfg, const float* const* h_
   }
   g->i_rb = idx; idx += cfg->num_upsamples * cfg->num_kernels * cfg->num_dilations * 2;
   g->i_post = idx;
+  if (dtype == MB_F16 && !getenv("MBHIP_GAN_NOFUSE")) {
+    const int nd = cfg->num_dilations;
+    g->pairs.resize((size_t)cfg->num_upsamples * cfg->num_kernels * nd);
+    std::vector<float> img;
+    for (int i = 0; i < cfg->num_upsamples; ++i)
+      for (int j = 0; j < cfg->num_kernels; ++j)
+        for (int d = 0; d < nd; ++d) {
+          const int base = g->i_rb + ((i * cfg->num_kernels + j) * nd) * 2;
+          const ConvSpec& s1 = v[base + d];
+          const ConvSpec& s2 = v[base + nd + d];
+          if (s1.c_in != s1.c_out || s2.c_in != s1.c_in || s2.c_out != s1.c_in || s1.k != s2.k || s2.dil != 1 ||
+              s1.transposed || s2.transposed || s1.pad != s1.dil * (s1.k - 1) / 2 || s2.pad != (s2.k - 1) / 2 ||
+              !mb_resblock_pair_f16_supported(s1.c_in, s1.k, s1.dil))
+            continue;
+          img.assign(mb_resblock_pair_f16_packed_halves(s1.c_in, s1.k) / 2, 0.f);
+          rc = mb_resblock_pair_f16_pack(h_weights[2 * (base + d)], h_weights[2 * (base + nd + d)], s1.c_in, s1.k,
+                                         reinterpret_cast<uint16_t*>(img.data()));
+          if (!rc) rc = g->pairs[(size_t)(i * cfg->num_kernels + j) * nd + d].upload(img.data(), img.size());
+          if (rc) { mb_gan_destroy(g); return rc; }
+        }
+  }
   *out = g;
   return MB_OK;
 }
@@ -195,6 +219,7 @@ extern "C" int mb_gan_create_ex(const mb_gan_config* cfg, const float* const* h_
 extern "C" void mb_gan_destroy(mb_gan* g) {
   if (!g) return;
   for (auto& c : g->convs) { c.w.release(); c.b.release(); }
+  for (auto& p : g->pairs) p.release();
   delete g;
 }
 
@@ -249,6 +274,17 @@ struct Launcher {
     a.out_act = out_act; a.out_scale = out_scale; a.accumulate = accumulate;
     a.in_repeat = in_repeat; a.y_f32 = y_f32;
     rc = mb_conv1d_f16(&a, (mb_stream_t)s);
+  }
+  // fp16 fused ResBlock unit: y = (acc ? y : 0) + scale * (x + c2(lrelu(c1(lrelu(x)))))
+  void pair_f16(const DevBuf& w, const ConvW& c1, const ConvW& c2, const void* x, int t, void* y, float slope,
+                float out_scale, int accumulate) {
+    if (rc) return;
+    mb_resblock_pair_f16_args a;
+    memset(&a, 0, sizeof(a));
+    a.d_x = x; a.d_y = y; a.d_wpacked = w.p; a.d_b1 = c1.b.p; a.d_b2 = c2.b.p;
+    a.batch = batch; a.channels = c1.s.c_in; a.t = t; a.ksize = c1.s.k; a.dilation = c1.s.dil;
+    a.slope = slope; a.out_scale = out_scale; a.accumulate = accumulate;
+    rc = mb_resblock_pair_f16(&a, (mb_stream_t)s);
   }
   // y = conv(x) with fused pro/epilogue; lengths are per batch item.  `last` = conv_post (fp32 out).
   void conv(const ConvW& c, const void* xv, int t_in, void* yv, int in_act, float in_slope,
@@ -349,6 +385,19 @@ extern "C" int mb_gan_forward(const mb_gan* g, const float* d_mel, int batch, in
     for (int j = 0; j < c.num_kernels; ++j) {
       const int base = g->i_rb + ((i * c.num_kernels + j) * c.num_dilations) * 2;
       const char* xr = X;
+      bool all_fused = f16 && !g->pairs.empty();
+      for (int d = 0; d < c.num_dilations && all_fused; ++d)
+        all_fused = g->pairs[(size_t)(i * c.num_kernels + j) * c.num_dilations + d].p != nullptr;
+      if (all_fused) {  // one launch per (convs1[d], convs2[d]); never in place: X -> XR -> T -> XR ... -> XS
+        for (int d = 0; d < c.num_dilations; ++d) {
+          const bool last = d == c.num_dilations - 1;
+          char* dst = last ? XS : ((d & 1) ? T : XR);
+          L.pair_f16(g->pairs[(size_t)(i * c.num_kernels + j) * c.num_dilations + d], g->convs[base + d],
+                     g->convs[base + c.num_dilations + d], xr, t, dst, LRELU, last ? inv_nk : 1.f, last && j > 0);
+          xr = dst;
+        }
+        continue;
+      }
       for (int d = 0; d < c.num_dilations; ++d) {
         const ConvW& c1 = g->convs[base + d];
         const ConvW& c2 = g->convs[base + c.num_dilations + d];

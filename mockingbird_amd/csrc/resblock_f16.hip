@@ -1,0 +1,459 @@
+// Fused ResBlock unit of the GAN vocoders on the gfx950 fp16 matrix cores:
+//
+//   y = x + conv2( lrelu( conv1( lrelu(x) ) + b1 ) ) + b2        conv1: k taps, dilation d; conv2: k taps, dilation 1
+//
+// = one (convs1[i], convs2[i]) iteration of ResBlock1.forward
+//   models/vocoder/hifigan/models.py:39-46, models/vocoder/fregan/generator.py:43-50
+// with the intermediate activation kept in LDS: the unfused path (conv1d_f16.hip, one launch per
+// conv) moves 3 x C*T fp16 tensors through HBM per conv, this moves x in and y out once per PAIR
+// (3x less traffic; the C <= 64 stages were HBM-bound).  Optionally y is scaled and accumulated
+// into the stage output (the mean over the parallel ResBlocks, models.py:141-145).
+//
+// Layout: time-major [B][T][C] fp16 (conv1d_f16.hip).  C in {32, 64, 128, 256}, k odd.
+//
+// One PERSISTENT workgroup per CU walks over output tiles of NB = N1 - (k-1) positions:
+//   phase 1  h[N1 x C]  = lrelu(W1 * lrelu(x window) + b1)   -> LDS (fp16), zero outside [0, T)
+//   phase 2  y[NB x C]  = W2 * h + b2 + x                    -> HBM
+// 8 waves: waves 0-3 run the MFMA loops (v_mfma_f32_32x32x16_f16, each wave MT x NTW 32x32 tiles),
+// waves 4-7 are LOADERS that stage the next 64-channel chunk of the x window (leaky-relu applied)
+// into the other half of a double-buffered LDS tile while the MMA waves consume the current one.
+// Loading is a separate role because vector-memory returns are in order per wave: x loads issued
+// by an MMA wave would sit in front of its weight prefetches and stall the MFMA chain once per chunk.
+//
+// Weights never touch LDS: they are packed on the host as ONE circular stream per 32-channel output
+// tile in exactly the order the kernel consumes them ([conv1: chunk, tap, k-block][conv2: ...]), and
+// each MMA wave keeps a register ring of the next TWO taps' A fragments (8 k-steps ~ 0.9 us of MFMA
+// work ahead), which runs seamlessly across chunk, phase and tile boundaries.  k is odd, so the ring
+// slot of a chunk's first tap alternates 0,1,0,1,...: the chunk body exists in two statically
+// scheduled variants (the compiler's s_waitcnt placement stays exact, no dynamic ring indexing).
+#include "common.h"
+
+namespace mb {
+
+typedef _Float16 h16;
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+
+struct ResPairK {
+  const h16* x; h16* y; const h16* w; const float* b1; const float* b2;
+  long long bstride;  // elements per batch item (T*C)
+  int T, ntaps, dil;
+  int NB, tiles_per_item, n_tiles, x_rows;
+  int nbuf;  // LDS buffers of the x window (1 = single buffer, refilled while phase 2 runs; C <= 64 only)
+  float slope, out_scale;
+  int accumulate;
+};
+
+constexpr int PAIR_NL = 4;  // loader waves per workgroup (beside the 4 MMA waves)
+
+template <int C> struct PairGeom {
+  static constexpr int CK = C >= 64 ? 64 : 32;  // channels per x chunk
+  static constexpr int KB = CK / 16;            // k-steps per tap per chunk
+  static constexpr int NCH = C / CK;
+  static constexpr int MTT = C / 32;
+  static constexpr int WM = MTT >= 8 ? 4 : (MTT >= 4 ? 2 : 1);
+  static constexpr int MT = MTT / WM;
+  static constexpr int WN = 4 / WM;
+  static constexpr int CKP = CK + 8, CP = C + 8;  // LDS row strides (odd multiples of 16 B)
+};
+
+// TD = taps of weight prefetch kept in flight per wave (2: 64 VGPRs at MT = 2; 1 for the instances whose
+// accumulators leave no room -- the kernel must stay within 256 VGPRs because the loader wave shares
+// a SIMD with an MMA wave)
+template <int C, int NTW, int TD>
+__global__ __launch_bounds__(64 * (4 + PAIR_NL)) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void resblock_pair_f16_kernel(ResPairK a) {
+  using G = PairGeom<C>;
+  constexpr int CK = G::CK, KB = G::KB, NCH = G::NCH, MT = G::MT, WN = G::WN;
+  constexpr int CKP = G::CKP, CP = G::CP;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  h16* xs = reinterpret_cast<h16*>(lds_raw);           // [nbuf][x_rows][CKP]
+  h16* hs = xs + a.nbuf * a.x_rows * CKP;               // [N1 + ntaps - 1][CP]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntaps = a.ntaps;
+  const int p2 = (ntaps - 1) >> 1, p1 = p2 * a.dil;
+  const int my_tiles = (a.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int njobs = my_tiles * NCH;
+
+  if (wave >= 4) {
+    // ------------------------------ loader waves ------------------------------
+    // PAIR_NL waves split the 16-byte pieces of the window; every piece of a wave is in flight at once
+    // (one HBM round trip per chunk), then leaky-relu'd and written to LDS.
+    constexpr int PPR = CK / 8;  // 16-byte pieces per row
+    constexpr int LB = 20;       // loads in flight per lane per batch
+    const h16 slope = (h16)a.slope;
+    const int total = a.x_rows * PPR;
+    const int ltid = tid - 256;
+    h16x8 v[LB];
+    auto load_batch = [&](int q, int base) {
+      const int tile = (int)blockIdx.x + (q / NCH) * (int)gridDim.x, c = q % NCH;
+      const int b = tile / a.tiles_per_item, t0 = (tile - b * a.tiles_per_item) * a.NB;
+      const int tx0 = t0 - p2 - p1;
+      const h16* xb = a.x + (long long)b * a.bstride + c * CK;
+#pragma unroll
+      for (int i = 0; i < LB; ++i) {
+        const int idx = base + i * (64 * PAIR_NL) + ltid;
+        const int row = idx / PPR, pc = idx - row * PPR;
+        const int tx = tx0 + row;
+        v[i] = (h16x8)(h16)0.f;
+        if (idx < total && tx >= 0 && tx < a.T)
+          v[i] = *reinterpret_cast<const h16x8*>(xb + (long long)tx * C + pc * 8);
+      }
+    };
+    auto store_batch = [&](int q, int base) {
+      h16* buf = xs + (q % a.nbuf) * a.x_rows * CKP;
+#pragma unroll
+      for (int i = 0; i < LB; ++i) {
+        const int idx = base + i * (64 * PAIR_NL) + ltid;
+        const int row = idx / PPR, pc = idx - row * PPR;
+        const h16x8 s = __builtin_elementwise_max(v[i], v[i] * slope);  // leaky_relu, 0 < slope < 1
+        if (idx < total) *reinterpret_cast<h16x8*>(buf + row * CKP + pc * 8) = s;
+      }
+    };
+    auto fill = [&](int q) {
+      for (int base = 0; base < total; base += 64 * PAIR_NL * LB) { load_batch(q, base); store_batch(q, base); }
+    };
+    if (a.nbuf == 1) {
+      // single buffer (NCH == 1, window = one batch): the next tile's loads fly during phase 1 and are
+      // written to LDS while the MMA waves run phase 2, which reads only h
+      if (njobs > 0) fill(0);
+      for (int q = 0; q < njobs; ++q) {
+        __syncthreads();  // B_q
+        if (q + 1 < njobs) load_batch(q + 1, 0);
+        __syncthreads();  // E1_q: phase 1 has finished reading xs
+        if (q + 1 < njobs) store_batch(q + 1, 0);
+      }
+      return;
+    }
+    for (int q = 0; q < a.nbuf - 1 && q < njobs; ++q) fill(q);
+    for (int q = 0; q < njobs; ++q) {
+      __syncthreads();  // B_q: job q is staged, the buffer of job q-1 is free
+      if (q + a.nbuf - 1 < njobs) fill(q + a.nbuf - 1);
+      if (q % NCH == NCH - 1) __syncthreads();  // E1 of this tile (the MMA waves publish h)
+    }
+    return;
+  }
+
+  // ------------------------------ MMA waves ------------------------------
+  const int wm = wave / WN, wn = wave % WN;
+  const int mt0 = wm * MT;
+  const int NFT = 2 * NCH * ntaps;  // flat taps of the circular weight stream
+  const h16x8* wp[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+    wp[i] = reinterpret_cast<const h16x8*>(a.w) + (size_t)(mt0 + i) * NFT * KB * 64 + lane;
+
+  h16x8 ring[TD][KB][MT];
+#pragma unroll
+  for (int s = 0; s < TD; ++s)
+#pragma unroll
+    for (int u = 0; u < KB; ++u)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) ring[s][u][i] = wp[i][(size_t)(s * KB + u) * 64];
+  int ftn = TD;  // next flat tap to prefetch
+
+  f32x16 acc[MT][NTW];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int n = 0; n < NTW; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
+  };
+
+  // one tap: KB k-steps from ring slot S; refills the slot with flat tap ftn
+#define MB_TAP(S, BPTR, RS)                                                                        \
+  do {                                                                                             \
+    const h16* bp_ = (BPTR);                                                                       \
+    const size_t nf_ = (size_t)ftn * KB;                                                           \
+    _Pragma("unroll") for (int u = 0; u < KB; ++u) {                                               \
+      h16x8 af_[MT];                                                                               \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i) af_[i] = ring[S][u][i];                       \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i) ring[S][u][i] = wp[i][(nf_ + u) * 64];        \
+      __builtin_amdgcn_sched_barrier(0);                                                           \
+      h16x8 bf_[NTW];                                                                              \
+      _Pragma("unroll") for (int n = 0; n < NTW; ++n)                                              \
+        bf_[n] = *reinterpret_cast<const h16x8*>(bp_ + n * 32 * (RS) + u * 16);                    \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i)                                               \
+        _Pragma("unroll") for (int n = 0; n < NTW; ++n)                                            \
+          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[i], bf_[n], acc[i][n], 0, 0, 0);  \
+    }                                                                                              \
+    ftn = ftn + 1 == NFT ? 0 : ftn + 1;                                                            \
+  } while (0)
+
+  // a chunk = ntaps taps (ntaps odd); S0 = ring slot of its first tap
+#define MB_CHUNK(S0, BASE, RS, TAPSTEP)                                                            \
+  do {                                                                                             \
+    const h16* cb_ = (BASE);                                                                       \
+    int j_ = 0;                                                                                    \
+    if (TD == 1) {                                                                                 \
+      for (; j_ < ntaps; ++j_) MB_TAP(0, cb_ + (size_t)j_ * (TAPSTEP), RS);                        \
+      break;                                                                                       \
+    }                                                                                              \
+    if (S0 == 1) { MB_TAP(TD - 1, cb_, RS); j_ = 1; }                                              \
+    for (; j_ + 1 < ntaps; j_ += 2) {                                                              \
+      MB_TAP(0, cb_ + (size_t)j_ * (TAPSTEP), RS);                                                 \
+      MB_TAP(TD - 1, cb_ + (size_t)(j_ + 1) * (TAPSTEP), RS);                                      \
+    }                                                                                              \
+    if (S0 == 0) MB_TAP(0, cb_ + (size_t)(ntaps - 1) * (TAPSTEP), RS);                             \
+  } while (0)
+
+  const int lrow = wn * (NTW * 32) + (lane & 31);  // this lane's row inside an N tile group
+  const int lcol = (lane >> 5) * 8;
+  const int x_tapstep = a.dil * CKP;
+  for (int it = 0; it < my_tiles; ++it) {
+    const int tile = (int)blockIdx.x + it * (int)gridDim.x;
+    const int b = tile / a.tiles_per_item, t0 = (tile - b * a.tiles_per_item) * a.NB;
+    // ---------------- phase 1: h = lrelu(conv1(lrelu(x)) + b1) ----------------
+    zero_acc();
+    if (NCH == 1) {
+      __syncthreads();
+      MB_CHUNK(0, xs + ((it * NCH) % a.nbuf) * a.x_rows * CKP + lrow * CKP + lcol, CKP, x_tapstep);
+    } else {
+      for (int c = 0; c < NCH; c += 2) {
+        __syncthreads();
+        MB_CHUNK(0, xs + ((it * NCH + c) % a.nbuf) * a.x_rows * CKP + lrow * CKP + lcol, CKP, x_tapstep);
+        __syncthreads();
+        MB_CHUNK(1, xs + ((it * NCH + c + 1) % a.nbuf) * a.x_rows * CKP + lrow * CKP + lcol, CKP, x_tapstep);
+      }
+    }
+    {  // epilogue 1 -> hs (fp16); rows outside [0, T) are conv2's zero padding
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+          const int row = lrow + n * 32;
+          const int th = t0 - p2 + row;
+          const bool inside = th >= 0 && th < a.T;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int co0 = (mt0 + i) * 32 + 8 * g + 4 * (lane >> 5);
+            const float4 bv = *reinterpret_cast<const float4*>(a.b1 + co0);
+            float v[4] = {acc[i][n][4 * g] + bv.x, acc[i][n][4 * g + 1] + bv.y, acc[i][n][4 * g + 2] + bv.z,
+                          acc[i][n][4 * g + 3] + bv.w};
+            h16x4 hv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float l = v[e] > 0.f ? v[e] : v[e] * a.slope;
+              hv[e] = (h16)(inside ? l : 0.f);
+            }
+            *reinterpret_cast<h16x4*>(hs + row * CP + co0) = hv;
+          }
+        }
+    }
+    __syncthreads();  // E1
+    // ---------------- phase 2: y = conv2(h) + b2 + x ----------------
+    zero_acc();
+    if (NCH == 1) {
+      MB_CHUNK(1, hs + lrow * CP + lcol, CP, CP);
+    } else {
+      for (int c = 0; c < NCH; c += 2) {
+        MB_CHUNK(0, hs + lrow * CP + c * CK + lcol, CP, CP);
+        MB_CHUNK(1, hs + lrow * CP + (c + 1) * CK + lcol, CP, CP);
+      }
+    }
+    {  // epilogue 2: residual (and accumulate) operands of one channel tile are requested together
+      const h16* xb = a.x + (long long)b * a.bstride;
+      h16* yb = a.y + (long long)b * a.bstride;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        h16x4 rv[NTW][4];
+        float4 bv[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const float4*>(a.b2 + (mt0 + i) * 32 + 8 * g + 4 * (lane >> 5));
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+          const int q = lrow + n * 32;
+          int t = t0 + q;
+          t = t < a.T ? t : a.T - 1;  // clamped: loads legal, stores predicated below
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const long long o = (long long)t * C + (mt0 + i) * 32 + 8 * g + 4 * (lane >> 5);
+            rv[n][g] = *reinterpret_cast<const h16x4*>(xb + o);
+          }
+        }
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+          const int q = lrow + n * 32;
+          const int t = t0 + q;
+          if (q < a.NB && t < a.T) {
+            h16x4 ov[4];
+            if (a.accumulate) {
+#pragma unroll
+              for (int g = 0; g < 4; ++g)
+                ov[g] = *reinterpret_cast<const h16x4*>(yb + (long long)t * C + (mt0 + i) * 32 + 8 * g + 4 * (lane >> 5));
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const long long o = (long long)t * C + (mt0 + i) * 32 + 8 * g + 4 * (lane >> 5);
+              float v[4] = {acc[i][n][4 * g] + bv[g].x, acc[i][n][4 * g + 1] + bv[g].y, acc[i][n][4 * g + 2] + bv[g].z,
+                            acc[i][n][4 * g + 3] + bv[g].w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = (v[e] + (float)rv[n][g][e]) * a.out_scale;
+              if (a.accumulate) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (float)ov[g][e];
+              }
+              h16x4 hv;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) hv[e] = (h16)v[e];
+              *reinterpret_cast<h16x4*>(yb + o) = hv;
+            }
+          }
+        }
+        asm volatile("" ::: "memory");
+      }
+    }
+  }
+#undef MB_CHUNK
+#undef MB_TAP
+}
+
+// LDS bytes of a (C, NTW) instance for a given conv1 geometry and x-window buffer count
+template <int C>
+static size_t pair_lds_bytes(int ntw, int ntaps, int dil, int nbuf) {
+  using G = PairGeom<C>;
+  const int n1 = G::WN * ntw * 32;
+  const int x_rows = n1 + (ntaps - 1) * dil;
+  return ((size_t)nbuf * x_rows * G::CKP + (size_t)(n1 + ntaps - 1) * G::CP) * sizeof(h16);
+}
+constexpr size_t PAIR_LDS_CAP = 160 * 1024;
+// fewest buffers an instance can run with: 1 (single-buffer mode) when the window is one chunk and one
+// loader batch, else 2
+template <int C>
+static int pair_min_nbuf(int ntw, int ntaps, int dil) {
+  using G = PairGeom<C>;
+  const int x_rows = G::WN * ntw * 32 + (ntaps - 1) * dil;
+  const bool single_ok = G::NCH == 1 && x_rows * (G::CK / 8) <= 64 * PAIR_NL * 20;
+  return single_ok ? 1 : 2;
+}
+template <int C>
+static bool pair_fits(int ntw, int ntaps, int dil) {
+  return pair_lds_bytes<C>(ntw, ntaps, dil, pair_min_nbuf<C>(ntw, ntaps, dil)) <= PAIR_LDS_CAP;
+}
+
+template <int C, int NTW, int TD>
+static int launch_pair(ResPairK k, int batch, hipStream_t s) {
+  using G = PairGeom<C>;
+  const int n1 = G::WN * NTW * 32;
+  k.NB = n1 - (k.ntaps - 1);
+  k.x_rows = n1 + (k.ntaps - 1) * k.dil;
+  k.tiles_per_item = cdiv(k.T, k.NB);
+  k.n_tiles = k.tiles_per_item * batch;
+  // as many x-window buffers as fit (<= 4): the loaders run nbuf-1 chunks ahead of the MMA waves
+  int nbuf = pair_min_nbuf<C>(NTW, k.ntaps, k.dil);
+  while (nbuf < 4 && pair_lds_bytes<C>(NTW, k.ntaps, k.dil, nbuf + 1) <= PAIR_LDS_CAP) ++nbuf;
+  if (const char* e = getenv("MBHIP_PAIR_NBUF")) { const int f = atoi(e); if (f >= pair_min_nbuf<C>(NTW, k.ntaps, k.dil) && f <= nbuf) nbuf = f; }
+  k.nbuf = nbuf;
+  const size_t lds = pair_lds_bytes<C>(NTW, k.ntaps, k.dil, nbuf);
+  static bool attr_done = false;
+  if (!attr_done) {
+    MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_f16_kernel<C, NTW, TD>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  int n_cu = 256;
+  {
+    static int cached = 0;
+    if (!cached) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        cached = prop.multiProcessorCount;
+      else
+        cached = 256;
+    }
+    n_cu = cached;
+  }
+  const int grid = std::min(k.n_tiles, n_cu);
+  hipLaunchKernelGGL((resblock_pair_f16_kernel<C, NTW, TD>), dim3(grid), dim3(64 * (4 + PAIR_NL)), lds, s, k);
+  MB_HIP(hipGetLastError());
+  return MB_OK;
+}
+
+}  // namespace mb
+
+using namespace mb;
+
+extern "C" int mb_resblock_pair_f16_supported(int channels, int ksize, int dilation) {
+  if (!(channels == 32 || channels == 64 || channels == 128 || channels == 256)) return 0;
+  if (ksize < 3 || (ksize & 1) == 0 || dilation < 1) return 0;
+  switch (channels) {
+    case 256: return pair_fits<256>(3, ksize, dilation);
+    case 128: return pair_fits<128>(2, ksize, dilation);
+    case 64: return pair_fits<64>(2, ksize, dilation);
+    default: return pair_fits<32>(2, ksize, dilation);
+  }
+}
+
+extern "C" size_t mb_resblock_pair_f16_packed_halves(int channels, int ksize) {
+  return (size_t)2 * channels * channels * ksize;
+}
+
+// h_w1 / h_w2: fp32 torch Conv1d weights [C][C][k] (weight norm already folded).
+extern "C" int mb_resblock_pair_f16_pack(const float* h_w1, const float* h_w2, int channels, int ksize,
+                                         uint16_t* h_packed) {
+  MB_REQUIRE(h_w1 && h_w2 && h_packed, "resblock_pair_f16_pack: null pointer");
+  MB_REQUIRE(mb_resblock_pair_f16_supported(channels, ksize, 1), "resblock_pair_f16_pack: C=%d k=%d unsupported",
+             channels, ksize);
+  const int C = channels, CK = C >= 64 ? 64 : 32, KB = CK / 16, NCH = C / CK, MTT = C / 32;
+  h16* out = reinterpret_cast<h16*>(h_packed);
+  size_t o = 0;
+  for (int mt = 0; mt < MTT; ++mt)
+    for (int ph = 0; ph < 2; ++ph) {
+      const float* w = ph ? h_w2 : h_w1;
+      for (int c = 0; c < NCH; ++c)
+        for (int j = 0; j < ksize; ++j)
+          for (int u = 0; u < KB; ++u)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int e = 0; e < 8; ++e) {
+                // A fragment of v_mfma_f32_32x32x16_f16: lane l holds A[m = l&31][k = 8*(l>>5) + e]
+                const int co = mt * 32 + (lane & 31);
+                const int ci = c * CK + u * 16 + (lane >> 5) * 8 + e;
+                out[o++] = (h16)w[((size_t)co * C + ci) * ksize + j];
+              }
+    }
+  return MB_OK;
+}
+
+extern "C" int mb_resblock_pair_f16(const mb_resblock_pair_f16_args* a, mb_stream_t stream) {
+  MB_REQUIRE(a && a->d_x && a->d_y && a->d_wpacked && a->d_b1 && a->d_b2, "resblock_pair_f16: null pointer");
+  MB_REQUIRE(a->d_x != a->d_y, "resblock_pair_f16: in-place is not supported (tiles read their neighbours' halo)");
+  MB_REQUIRE(mb_resblock_pair_f16_supported(a->channels, a->ksize, a->dilation),
+             "resblock_pair_f16: C=%d k=%d d=%d unsupported", a->channels, a->ksize, a->dilation);
+  MB_REQUIRE(a->slope > 0.f && a->slope < 1.f, "resblock_pair_f16: leaky_relu slope must be in (0,1)");
+  if (a->batch <= 0 || a->t <= 0) return MB_OK;
+  ResPairK k;
+  memset(&k, 0, sizeof(k));
+  k.x = reinterpret_cast<const h16*>(a->d_x); k.y = reinterpret_cast<h16*>(a->d_y);
+  k.w = reinterpret_cast<const h16*>(a->d_wpacked); k.b1 = a->d_b1; k.b2 = a->d_b2;
+  k.bstride = (long long)a->t * a->channels;
+  k.T = a->t; k.ntaps = a->ksize; k.dil = a->dilation;
+  k.slope = a->slope; k.out_scale = a->out_scale == 0.f ? 1.f : a->out_scale; k.accumulate = a->accumulate;
+  hipStream_t s = (hipStream_t)stream;
+  // N-tile count per wave: the candidate with the smallest makespan (rounds of 256 persistent
+  // workgroups x positions per tile) that fits LDS; ties -> the larger tile (less halo recompute,
+  // more reuse of every weight fragment).
+  auto cost = [&](int n1) {
+    const int nb = n1 - (a->ksize - 1);
+    const long long tiles = (long long)cdiv(a->t, nb) * a->batch;
+    return ((tiles + 255) / 256) * (long long)n1;
+  };
+#define MB_PICK2(C_, WN_, NA, TDA, NB_, TDB)                                                        \
+  do {                                                                                              \
+    const bool fa = pair_fits<C_>(NA, a->ksize, a->dilation);                                       \
+    const bool fb = pair_fits<C_>(NB_, a->ksize, a->dilation);                                      \
+    if (fb && (!fa || cost(WN_ * NB_ * 32) <= cost(WN_ * NA * 32)))                                 \
+      return launch_pair<C_, NB_, TDB>(k, a->batch, s);                                             \
+    return launch_pair<C_, NA, TDA>(k, a->batch, s);                                                \
+  } while (0)
+  switch (a->channels) {
+    case 256: MB_PICK2(256, 1, 3, 2, 4, 1);
+    case 128: MB_PICK2(128, 2, 2, 2, 3, 1);
+    case 64: MB_PICK2(64, 4, 2, 2, 4, 1);
+    default: MB_PICK2(32, 4, 2, 2, 4, 2);
+  }
+#undef MB_PICK2
+}

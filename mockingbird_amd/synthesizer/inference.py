@@ -39,7 +39,10 @@ class TacotronDevice:
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
-            _lib.lib().mb_taco_destroy(h)
+            try:
+                _lib.lib().mb_taco_destroy(h)
+            except Exception:  # interpreter shutdown: module globals are already torn down
+                pass
             self._h = None
 
     def decode(self, memory, memory_proj, chars, steps, min_stop_token, dropout=None, seed=0):

@@ -50,7 +50,10 @@ class GanGenerator:
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
-            _lib.lib().mb_gan_destroy(h)
+            try:
+                _lib.lib().mb_gan_destroy(h)
+            except Exception:  # interpreter shutdown: module globals are already torn down
+                pass
             self._h = None
 
     def forward(self, mel: torch.Tensor) -> torch.Tensor:

@@ -124,3 +124,38 @@ def relerr(a: torch.Tensor, b: torch.Tensor):
     return dict(max_abs=float(d.max()), rms=float(d.pow(2).mean().sqrt()),
                 rel_rms=float(d.pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-30)),
                 ref_rms=float(b.pow(2).mean().sqrt()), nan=int(torch.isnan(a).sum()))
+
+
+def resblock_pair_f16_hip(x, w1, b1, w2, b2, *, dilation=1, slope=0.1, out_scale=1.0, accumulate_into=None,
+                          device="cuda"):
+    """Fused ResBlock unit (mb_resblock_pair_f16).  x / accumulate_into are [B, C, T] float tensors
+    (reference layout); returns [B, C, T] float32."""
+    L = _lib.lib()
+    dev = torch.device(device)
+    w1 = w1.detach().float().contiguous().cpu()
+    w2 = w2.detach().float().contiguous().cpu()
+    Cc, _, k = w1.shape
+    packed = torch.empty(L.mb_resblock_pair_f16_packed_halves(Cc, k), dtype=torch.float16)
+    _lib.check(L.mb_resblock_pair_f16_pack(w1.data_ptr(), w2.data_ptr(), Cc, k, packed.data_ptr()),
+               "mb_resblock_pair_f16_pack")
+    pw = packed.to(dev)
+
+    def to_tm(t):
+        t = t.float().contiguous().to(dev)
+        B, C_, Tt = t.shape
+        out = torch.empty(B, Tt, C_, dtype=torch.float16, device=dev)
+        _lib.check(L.mb_f32_to_f16_tm(t.data_ptr(), out.data_ptr(), B, C_, Tt, _lib.stream_ptr()), "mb_f32_to_f16_tm")
+        return out
+
+    xh = to_tm(x)
+    B, T, _ = xh.shape
+    y = to_tm(accumulate_into) if accumulate_into is not None else \
+        torch.full((B, T, Cc), float("nan"), dtype=torch.float16, device=dev)
+    pb1, pb2 = b1.float().contiguous().to(dev), b2.float().contiguous().to(dev)
+    a = _lib.ResPairF16Args()
+    a.d_x, a.d_y, a.d_wpacked, a.d_b1, a.d_b2 = xh.data_ptr(), y.data_ptr(), pw.data_ptr(), pb1.data_ptr(), pb2.data_ptr()
+    a.batch, a.channels, a.t, a.ksize, a.dilation = B, Cc, T, k, dilation
+    a.slope, a.out_scale, a.accumulate = slope, out_scale, int(accumulate_into is not None)
+    _lib.check(L.mb_resblock_pair_f16(C.byref(a), _lib.stream_ptr()), "mb_resblock_pair_f16")
+    torch.cuda.synchronize()
+    return y.float().transpose(1, 2).contiguous().cpu()
