@@ -39,12 +39,28 @@ struct ResPairK {
   long long bstride;  // elements per batch item (T*C)
   int T, ntaps, dil;
   int NB, tiles_per_item, n_tiles, x_rows;
+  unsigned long long* trace;  // diagnostics only (MBHIP_PAIR_TRACE): shader-clock marks of workgroup 0
+  int dbg;   // diagnostics only (MBHIP_PAIR_DBG): 1 = weight stream folded onto its first taps (L1-resident),
+             // 2 = no residual read, 4 = no output store -- results are wrong, timings isolate one cost each
   int nbuf;  // LDS buffers of the x window (1 = single buffer, refilled while phase 2 runs; C <= 64 only)
   float slope, out_scale;
   int accumulate;
 };
 
 constexpr int PAIR_NL = 4;  // loader waves per workgroup (beside the 4 MMA waves)
+// Activations stream through once per launch; the weights are re-read by every tile.  Non-temporal
+// activation loads/stores keep the 4 MiB per-XCD L2 for the weight stream.
+#ifndef MB_PAIR_NT
+#define MB_PAIR_NT 0
+#endif
+constexpr bool PAIR_NT = MB_PAIR_NT != 0;
+
+// diagnostics: mark k of tile `it`, role 0 = MMA wave 0, 1 = support wave 4 (workgroup 0, first 8 tiles)
+#define MB_PMARK(role, it, k)                                                                  \
+  do {                                                                                         \
+    if (a.trace && blockIdx.x == 0 && (it) < 8 && (tid & 63) == 0 && wave == ((role) ? 4 : 0)) \
+      a.trace[((role) * 8 + (it)) * 16 + (k)] = (unsigned long long)clock64();                 \
+  } while (0)
 
 template <int C> struct PairGeom {
   static constexpr int CK = C >= 64 ? 64 : 32;  // channels per x chunk
@@ -69,12 +85,16 @@ void resblock_pair_f16_kernel(ResPairK a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   h16* xs = reinterpret_cast<h16*>(lds_raw);           // [nbuf][x_rows][CKP]
   h16* hs = xs + a.nbuf * a.x_rows * CKP;               // [N1 + ntaps - 1][CP]
+  // biases live in LDS: a vector-memory read in the epilogues would queue behind the weight prefetches
+  float* bs = reinterpret_cast<float*>(hs + (WN * NTW * 32 + a.ntaps - 1) * CP);  // [2][C]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntaps = a.ntaps;
   const int p2 = (ntaps - 1) >> 1, p1 = p2 * a.dil;
   const int my_tiles = (a.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int njobs = my_tiles * NCH;
+
+  for (int i = tid; i < 2 * C; i += 64 * (4 + PAIR_NL)) bs[i] = i < C ? a.b1[i] : a.b2[i - C];  // visible after the first barrier
 
   if (wave >= 4) {
     // ------------------------------ loader waves ------------------------------
@@ -98,7 +118,8 @@ void resblock_pair_f16_kernel(ResPairK a) {
         const int tx = tx0 + row;
         v[i] = (h16x8)(h16)0.f;
         if (idx < total && tx >= 0 && tx < a.T)
-          v[i] = *reinterpret_cast<const h16x8*>(xb + (long long)tx * C + pc * 8);
+          v[i] = PAIR_NT ? __builtin_nontemporal_load(reinterpret_cast<const h16x8*>(xb + (long long)tx * C + pc * 8))
+                         : *reinterpret_cast<const h16x8*>(xb + (long long)tx * C + pc * 8);
       }
     };
     auto store_batch = [&](int q, int base) {
@@ -114,24 +135,88 @@ void resblock_pair_f16_kernel(ResPairK a) {
     auto fill = [&](int q) {
       for (int base = 0; base < total; base += 64 * PAIR_NL * LB) { load_batch(q, base); store_batch(q, base); }
     };
+    // y write-out of a finished tile: the MMA waves leave conv2(h) + b2 in hs (fp16); here the residual
+    // x (and the running sum when accumulating) is added and the rows leave as coalesced 16-byte stores.
+    // Runs while the MMA waves are already in phase 1 of the next tile -- they never wait on HBM.
+    constexpr int WB = 8;         // pieces per lane per batch
+    constexpr int YPR = C / 8;    // 16-byte pieces per output row
+    auto write_out = [&](int it) {
+      const int tile = (int)blockIdx.x + it * (int)gridDim.x;
+      const int b = tile / a.tiles_per_item, t0 = (tile - b * a.tiles_per_item) * a.NB;
+      const int rows = min(a.NB, a.T - t0);
+      const int ytotal = rows * YPR;
+      const h16* xb = a.x + (long long)b * a.bstride + (long long)t0 * C;
+      h16* yb = a.y + (long long)b * a.bstride + (long long)t0 * C;
+      for (int base = 0; base < ytotal; base += 64 * PAIR_NL * WB) {
+        h16x8 rx[WB], ry[WB];
+#pragma unroll
+        for (int i = 0; i < WB; ++i) {
+          int idx = base + i * (64 * PAIR_NL) + ltid;
+          idx = idx < ytotal ? idx : ytotal - 1;  // clamped: loads legal, store predicated
+          rx[i] = (a.dbg & 2) ? (h16x8)(h16)0.f : *reinterpret_cast<const h16x8*>(xb + (long long)idx * 8);
+          if (a.accumulate) ry[i] = *reinterpret_cast<const h16x8*>(yb + (long long)idx * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < WB; ++i) {
+          const int idx = base + i * (64 * PAIR_NL) + ltid;
+          const int idc = idx < ytotal ? idx : ytotal - 1;
+          const int row = idc / YPR, pc = idc - row * YPR;
+          const h16x8 hv = *reinterpret_cast<const h16x8*>(hs + row * CP + pc * 8);
+          h16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float f = ((float)hv[e] + (float)rx[i][e]) * a.out_scale;
+            if (a.accumulate) f += (float)ry[i][e];
+            o[e] = (h16)f;
+          }
+          if (idx < ytotal && !(a.dbg & 4)) *reinterpret_cast<h16x8*>(yb + (long long)idx * 8) = o;
+        }
+      }
+    };
+    // Barrier schedule per tile (must mirror the MMA waves'): B per chunk, W, E1, P, Y.
     if (a.nbuf == 1) {
       // single buffer (NCH == 1, window = one batch): the next tile's loads fly during phase 1 and are
       // written to LDS while the MMA waves run phase 2, which reads only h
-      if (njobs > 0) fill(0);
-      for (int q = 0; q < njobs; ++q) {
-        __syncthreads();  // B_q
-        if (q + 1 < njobs) load_batch(q + 1, 0);
-        __syncthreads();  // E1_q: phase 1 has finished reading xs
-        if (q + 1 < njobs) store_batch(q + 1, 0);
+      if (my_tiles > 0) fill(0);
+      for (int it = 0; it < my_tiles; ++it) {
+        MB_PMARK(1, it, 0);
+        __syncthreads();  // B
+        MB_PMARK(1, it, 1);
+        if (it + 1 < my_tiles) load_batch(it + 1, 0);
+        MB_PMARK(1, it, 2);
+        if (it > 0) write_out(it - 1);
+        MB_PMARK(1, it, 3);
+        __syncthreads();  // W: hs is free for h of this tile
+        __syncthreads();  // E1: phase 1 has finished reading xs
+        MB_PMARK(1, it, 4);
+        if (it + 1 < my_tiles) store_batch(it + 1, 0);
+        MB_PMARK(1, it, 5);
+        __syncthreads();  // P
+        __syncthreads();  // Y: y of this tile is staged in hs
+        MB_PMARK(1, it, 6);
       }
-      return;
+    } else {
+      for (int q = 0; q < a.nbuf - 1 && q < njobs; ++q) fill(q);
+      for (int it = 0; it < my_tiles; ++it) {
+        for (int c = 0; c < NCH; ++c) {
+          const int q = it * NCH + c;
+          if (c == 0) MB_PMARK(1, it, 0);
+          __syncthreads();  // B_q: job q is staged, the buffer of job q-1 is free
+          if (c == 0) MB_PMARK(1, it, 1);
+          if (q + a.nbuf - 1 < njobs) fill(q + a.nbuf - 1);
+          if (c == 0) MB_PMARK(1, it, 2);
+          if (c == 0 && it > 0) write_out(it - 1);
+          if (c == 0) MB_PMARK(1, it, 3);
+        }
+        __syncthreads();  // W
+        __syncthreads();  // E1
+        MB_PMARK(1, it, 4);
+        __syncthreads();  // P
+        __syncthreads();  // Y
+        MB_PMARK(1, it, 6);
+      }
     }
-    for (int q = 0; q < a.nbuf - 1 && q < njobs; ++q) fill(q);
-    for (int q = 0; q < njobs; ++q) {
-      __syncthreads();  // B_q: job q is staged, the buffer of job q-1 is free
-      if (q + a.nbuf - 1 < njobs) fill(q + a.nbuf - 1);
-      if (q % NCH == NCH - 1) __syncthreads();  // E1 of this tile (the MMA waves publish h)
-    }
+    if (my_tiles > 0) write_out(my_tiles - 1);
     return;
   }
 
@@ -163,41 +248,54 @@ void resblock_pair_f16_kernel(ResPairK a) {
         for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
   };
 
-  // one tap: KB k-steps from ring slot S; refills the slot with flat tap ftn
-#define MB_TAP(S, BPTR, RS)                                                                        \
+  // one tap: KB k-steps from ring slot S; refills the slot with flat tap ftn.  The B fragments (LDS) are
+  // software-pipelined one k-step ahead (bfc_ = current, loaded during the previous step's MFMAs): with
+  // one MMA wave per SIMD nothing else would hide the ds_read latency.  NEXT = first row of the next tap
+  // (or any valid row after the chunk's last tap: that read is discarded).
+#define MB_TAP(S, BPTR, NEXT, RS)                                                                  \
   do {                                                                                             \
     const h16* bp_ = (BPTR);                                                                       \
-    const size_t nf_ = (size_t)ftn * KB;                                                           \
+    const h16* np_ = (NEXT);                                                                       \
+    const size_t nf_ = (size_t)((a.dbg & 1) ? (ftn & 1) : ftn) * KB;                               \
     _Pragma("unroll") for (int u = 0; u < KB; ++u) {                                               \
       h16x8 af_[MT];                                                                               \
       _Pragma("unroll") for (int i = 0; i < MT; ++i) af_[i] = ring[S][u][i];                       \
-      _Pragma("unroll") for (int i = 0; i < MT; ++i) ring[S][u][i] = wp[i][(nf_ + u) * 64];        \
-      __builtin_amdgcn_sched_barrier(0);                                                           \
-      h16x8 bf_[NTW];                                                                              \
+      if (!(a.dbg & 8)) { _Pragma("unroll") for (int i = 0; i < MT; ++i) ring[S][u][i] = wp[i][(nf_ + u) * 64]; } \
+      h16x8 bfn_[NTW];                                                                             \
+      const h16* rp_ = u + 1 < KB ? bp_ + (u + 1) * 16 : np_;                                      \
       _Pragma("unroll") for (int n = 0; n < NTW; ++n)                                              \
-        bf_[n] = *reinterpret_cast<const h16x8*>(bp_ + n * 32 * (RS) + u * 16);                    \
+        bfn_[n] = *reinterpret_cast<const h16x8*>(rp_ + n * 32 * (RS));                            \
+      __builtin_amdgcn_sched_barrier(0);                                                           \
       _Pragma("unroll") for (int i = 0; i < MT; ++i)                                               \
         _Pragma("unroll") for (int n = 0; n < NTW; ++n)                                            \
-          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[i], bf_[n], acc[i][n], 0, 0, 0);  \
+          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[i], bfc_[n], acc[i][n], 0, 0, 0); \
+      _Pragma("unroll") for (int n = 0; n < NTW; ++n) bfc_[n] = bfn_[n];                           \
     }                                                                                              \
     ftn = ftn + 1 == NFT ? 0 : ftn + 1;                                                            \
   } while (0)
 
   // a chunk = ntaps taps (ntaps odd); S0 = ring slot of its first tap
+#define MB_TAPJ(S, J)                                                                              \
+  MB_TAP(S, cb_ + (size_t)(J) * ts_, cb_ + (size_t)((J) + 1 < ntaps ? (J) + 1 : 0) * ts_, rs_)
 #define MB_CHUNK(S0, BASE, RS, TAPSTEP)                                                            \
   do {                                                                                             \
     const h16* cb_ = (BASE);                                                                       \
+    const int rs_ = (RS);                                                                          \
+    const size_t ts_ = (size_t)(TAPSTEP);                                                          \
+    h16x8 bfc_[NTW];                                                                               \
+    _Pragma("unroll") for (int n = 0; n < NTW; ++n)                                                \
+      bfc_[n] = *reinterpret_cast<const h16x8*>(cb_ + n * 32 * rs_);                               \
     int j_ = 0;                                                                                    \
     if (TD == 1) {                                                                                 \
-      for (; j_ < ntaps; ++j_) MB_TAP(0, cb_ + (size_t)j_ * (TAPSTEP), RS);                        \
+      for (; j_ < ntaps; ++j_) MB_TAPJ(0, j_);                                                     \
       break;                                                                                       \
     }                                                                                              \
-    if (S0 == 1) { MB_TAP(TD - 1, cb_, RS); j_ = 1; }                                              \
+    if (S0 == 1) { MB_TAPJ(TD - 1, 0); j_ = 1; }                                                   \
     for (; j_ + 1 < ntaps; j_ += 2) {                                                              \
-      MB_TAP(0, cb_ + (size_t)j_ * (TAPSTEP), RS);                                                 \
-      MB_TAP(TD - 1, cb_ + (size_t)(j_ + 1) * (TAPSTEP), RS);                                      \
+      MB_TAPJ(0, j_);                                                                              \
+      MB_TAPJ(TD - 1, j_ + 1);                                                                     \
     }                                                                                              \
-    if (S0 == 0) MB_TAP(0, cb_ + (size_t)(ntaps - 1) * (TAPSTEP), RS);                             \
+    if (S0 == 0) MB_TAPJ(0, ntaps - 1);                                                            \
   } while (0)
 
   const int lrow = wn * (NTW * 32) + (lane & 31);  // this lane's row inside an N tile group
@@ -205,11 +303,13 @@ void resblock_pair_f16_kernel(ResPairK a) {
   const int x_tapstep = a.dil * CKP;
   for (int it = 0; it < my_tiles; ++it) {
     const int tile = (int)blockIdx.x + it * (int)gridDim.x;
-    const int b = tile / a.tiles_per_item, t0 = (tile - b * a.tiles_per_item) * a.NB;
+    const int t0 = (tile % a.tiles_per_item) * a.NB;
     // ---------------- phase 1: h = lrelu(conv1(lrelu(x)) + b1) ----------------
     zero_acc();
+    MB_PMARK(0, it, 0);
     if (NCH == 1) {
       __syncthreads();
+      MB_PMARK(0, it, 1);
       MB_CHUNK(0, xs + ((it * NCH) % a.nbuf) * a.x_rows * CKP + lrow * CKP + lcol, CKP, x_tapstep);
     } else {
       for (int c = 0; c < NCH; c += 2) {
@@ -219,7 +319,12 @@ void resblock_pair_f16_kernel(ResPairK a) {
         MB_CHUNK(1, xs + ((it * NCH + c + 1) % a.nbuf) * a.x_rows * CKP + lrow * CKP + lcol, CKP, x_tapstep);
       }
     }
-    {  // epilogue 1 -> hs (fp16); rows outside [0, T) are conv2's zero padding
+    MB_PMARK(0, it, 2);
+    __syncthreads();  // W: the support waves have written out the previous tile's y from hs
+    MB_PMARK(0, it, 3);
+    {  // epilogue 1 -> hs (fp16); rows outside [0, T) are conv2's zero padding.  Packed math: this runs
+       // on the MMA waves' critical path (one wave per SIMD, 128 values per lane)
+      const h16 hslope = (h16)a.slope;
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -230,20 +335,19 @@ void resblock_pair_f16_kernel(ResPairK a) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int co0 = (mt0 + i) * 32 + 8 * g + 4 * (lane >> 5);
-            const float4 bv = *reinterpret_cast<const float4*>(a.b1 + co0);
-            float v[4] = {acc[i][n][4 * g] + bv.x, acc[i][n][4 * g + 1] + bv.y, acc[i][n][4 * g + 2] + bv.z,
-                          acc[i][n][4 * g + 3] + bv.w};
-            h16x4 hv;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float l = v[e] > 0.f ? v[e] : v[e] * a.slope;
-              hv[e] = (h16)(inside ? l : 0.f);
-            }
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bs + co0);
+            f32x4 v = {acc[i][n][4 * g], acc[i][n][4 * g + 1], acc[i][n][4 * g + 2], acc[i][n][4 * g + 3]};
+            v += bv;
+            h16x4 hv = __builtin_convertvector(v, h16x4);
+            hv = __builtin_elementwise_max(hv, hv * hslope);  // leaky_relu in fp16, as the unfused path applies it
+            if (!inside) hv = (h16x4)(h16)0.f;
             *reinterpret_cast<h16x4*>(hs + row * CP + co0) = hv;
           }
         }
     }
+    MB_PMARK(0, it, 4);
     __syncthreads();  // E1
+    MB_PMARK(0, it, 5);
     // ---------------- phase 2: y = conv2(h) + b2 + x ----------------
     zero_acc();
     if (NCH == 1) {
@@ -254,60 +358,31 @@ void resblock_pair_f16_kernel(ResPairK a) {
         MB_CHUNK(1, hs + lrow * CP + (c + 1) * CK + lcol, CP, CP);
       }
     }
-    {  // epilogue 2: residual (and accumulate) operands of one channel tile are requested together
-      const h16* xb = a.x + (long long)b * a.bstride;
-      h16* yb = a.y + (long long)b * a.bstride;
+    MB_PMARK(0, it, 6);
+    __syncthreads();  // P: every MMA wave has finished reading h
+    MB_PMARK(0, it, 7);
+    {  // epilogue 2 -> hs: conv2 + b2 (fp16); the support waves add the residual and write y out
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        h16x4 rv[NTW][4];
-        float4 bv[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const float4*>(a.b2 + (mt0 + i) * 32 + 8 * g + 4 * (lane >> 5));
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int n = 0; n < NTW; ++n) {
-          const int q = lrow + n * 32;
-          int t = t0 + q;
-          t = t < a.T ? t : a.T - 1;  // clamped: loads legal, stores predicated below
+          const int row = lrow + n * 32;
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const long long o = (long long)t * C + (mt0 + i) * 32 + 8 * g + 4 * (lane >> 5);
-            rv[n][g] = *reinterpret_cast<const h16x4*>(xb + o);
+            const int co0 = (mt0 + i) * 32 + 8 * g + 4 * (lane >> 5);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bs + C + co0);
+            f32x4 v = {acc[i][n][4 * g], acc[i][n][4 * g + 1], acc[i][n][4 * g + 2], acc[i][n][4 * g + 3]};
+            v += bv;
+            *reinterpret_cast<h16x4*>(hs + row * CP + co0) = __builtin_convertvector(v, h16x4);
           }
         }
-#pragma unroll
-        for (int n = 0; n < NTW; ++n) {
-          const int q = lrow + n * 32;
-          const int t = t0 + q;
-          if (q < a.NB && t < a.T) {
-            h16x4 ov[4];
-            if (a.accumulate) {
-#pragma unroll
-              for (int g = 0; g < 4; ++g)
-                ov[g] = *reinterpret_cast<const h16x4*>(yb + (long long)t * C + (mt0 + i) * 32 + 8 * g + 4 * (lane >> 5));
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const long long o = (long long)t * C + (mt0 + i) * 32 + 8 * g + 4 * (lane >> 5);
-              float v[4] = {acc[i][n][4 * g] + bv[g].x, acc[i][n][4 * g + 1] + bv[g].y, acc[i][n][4 * g + 2] + bv[g].z,
-                            acc[i][n][4 * g + 3] + bv[g].w};
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = (v[e] + (float)rv[n][g][e]) * a.out_scale;
-              if (a.accumulate) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += (float)ov[g][e];
-              }
-              h16x4 hv;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) hv[e] = (h16)v[e];
-              *reinterpret_cast<h16x4*>(yb + o) = hv;
-            }
-          }
-        }
-        asm volatile("" ::: "memory");
-      }
     }
+    MB_PMARK(0, it, 8);
+    __syncthreads();  // Y
+    MB_PMARK(0, it, 9);
   }
 #undef MB_CHUNK
+#undef MB_TAPJ
 #undef MB_TAP
 }
 
@@ -317,7 +392,7 @@ static size_t pair_lds_bytes(int ntw, int ntaps, int dil, int nbuf) {
   using G = PairGeom<C>;
   const int n1 = G::WN * ntw * 32;
   const int x_rows = n1 + (ntaps - 1) * dil;
-  return ((size_t)nbuf * x_rows * G::CKP + (size_t)(n1 + ntaps - 1) * G::CP) * sizeof(h16);
+  return ((size_t)nbuf * x_rows * G::CKP + (size_t)(n1 + ntaps - 1) * G::CP) * sizeof(h16) + 2 * C * sizeof(float);
 }
 constexpr size_t PAIR_LDS_CAP = 160 * 1024;
 // fewest buffers an instance can run with: 1 (single-buffer mode) when the window is one chunk and one
@@ -347,6 +422,14 @@ static int launch_pair(ResPairK k, int batch, hipStream_t s) {
   while (nbuf < 4 && pair_lds_bytes<C>(NTW, k.ntaps, k.dil, nbuf + 1) <= PAIR_LDS_CAP) ++nbuf;
   if (const char* e = getenv("MBHIP_PAIR_NBUF")) { const int f = atoi(e); if (f >= pair_min_nbuf<C>(NTW, k.ntaps, k.dil) && f <= nbuf) nbuf = f; }
   k.nbuf = nbuf;
+  if (const char* e = getenv("MBHIP_PAIR_DBG")) k.dbg = atoi(e);
+  static unsigned long long* d_trace = nullptr;
+  const char* trace_path = getenv("MBHIP_PAIR_TRACE");
+  if (trace_path) {
+    if (!d_trace) MB_HIP(hipMalloc((void**)&d_trace, 256 * sizeof(unsigned long long)));
+    MB_HIP(hipMemsetAsync(d_trace, 0, 256 * sizeof(unsigned long long), s));
+    k.trace = d_trace;
+  }
   const size_t lds = pair_lds_bytes<C>(NTW, k.ntaps, k.dil, nbuf);
   static bool attr_done = false;
   if (!attr_done) {
@@ -370,6 +453,17 @@ static int launch_pair(ResPairK k, int batch, hipStream_t s) {
   const int grid = std::min(k.n_tiles, n_cu);
   hipLaunchKernelGGL((resblock_pair_f16_kernel<C, NTW, TD>), dim3(grid), dim3(64 * (4 + PAIR_NL)), lds, s, k);
   MB_HIP(hipGetLastError());
+  if (trace_path) {  // diagnostics: append "C NTW TD ntaps dil nbuf tiles : marks..." per launch
+    unsigned long long h[256];
+    MB_HIP(hipStreamSynchronize(s));
+    MB_HIP(hipMemcpy(h, d_trace, sizeof(h), hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(trace_path, "a")) {
+      fprintf(f, "%d %d %d %d %d %d %d :", C, NTW, TD, k.ntaps, k.dil, k.nbuf, k.n_tiles);
+      for (int i = 0; i < 256; ++i) fprintf(f, " %llu", h[i]);
+      fprintf(f, "\n");
+      fclose(f);
+    }
+  }
   return MB_OK;
 }
 
