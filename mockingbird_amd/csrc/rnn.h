@@ -143,6 +143,9 @@ struct Fin1K {
   unsigned long long* trace;
 };
 int rnn_launch(int epi, const RnnK& k, hipStream_t s);
+// Forward and backward step of a bidirectional GRU scan in one launch (falls back to two launches for
+// shapes outside the instantiated scan instance)
+int rnn_launch_dual_gru(const RnnK& k0, const RnnK& k1, hipStream_t s);
 // stand-alone gru1-finish launch (first step of a generate call, or MBHIP_WAVERNN_MERGE=0)
 int rnn_launch_finish(const Fin1K& f, hipStream_t s);
 // fc3 + Gumbel-argmax sampler AND the gru1-finish job of the NEXT step in one launch: the finish

@@ -17,7 +17,7 @@
 // a no-op (skip flag) and the host learns the frame count at its next poll.
 // CBHG runs on the MFMA conv kernel (conv1d.hip) with ReLU->BatchNorm, max-pool and highway
 // gates fused; the bidirectional GRU is a scan of EPI_GRU launches over precomputed W_ih.x.
-#include "rnn.h"
+#include "rnn_body.h"
 
 namespace mb {
 
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(512) void lsa_kernel(LsaK a) {
 //   * 5 workgroup barriers in total.
 // tanh is evaluated as 1 - 2/(exp(2x)+1) (absolute error ~1e-7, the parity bar on attention is 1e-4).
 template <int TJ>
-__global__ __launch_bounds__(512) void lsa_fast_kernel(LsaK a) {
+__device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const int pg) {
   constexpr int D = 128, KL = 31, TMAX = 4 * TJ, TM = TMAX / 8, PW = 256;
   __shared__ __attribute__((aligned(16))) float s_cum[TMAX + 64];   // zero padded by `half` on both sides
   __shared__ __attribute__((aligned(16))) float s_q[D];
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(512) void lsa_fast_kernel(LsaK a) {
   __shared__ __attribute__((aligned(16))) float s_up[TMAX][2];
   __shared__ __attribute__((aligned(16))) float s_u[TMAX];
   __shared__ __attribute__((aligned(16))) float4 s_part[8][64];
-  const int b = blockIdx.x, pg = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int d = tid & (D - 1), tq = __builtin_amdgcn_readfirstlane(tid >> 7);
   const int T = a.T, P = a.P, half = (a.Kl - 1) / 2;
@@ -334,6 +334,26 @@ __global__ __launch_bounds__(512) void lsa_fast_kernel(LsaK a) {
   }
 }
 
+template <int TJ>
+__global__ __launch_bounds__(512) void lsa_fast_kernel(LsaK a) {
+  lsa_fast_body<TJ>(a, blockIdx.x, blockIdx.y);
+}
+
+// The attention launch is latency-bound and occupies B*psplit of the 256 CUs.  The hidden halves of the
+// two decoder LSTMs, W_hh.h(t-1) + b_hh (2 x 16.8 MB of weights, bandwidth-bound), depend only on the
+// previous iteration's state, so they ride in the same launch as extra workgroups (the attention
+// workgroups come first in dispatch order) and leave the dependent chain: the LSTM launches then
+// stream only their input halves.
+constexpr unsigned HH_FEAT = RF_BIASX | RF_SKIP;
+template <int TJ>
+__global__ __launch_bounds__(512) void lsa_hh_kernel(LsaK a, RnnDev d1, RnnDev d2, int n_lsa, int B, int nx1) {
+  const int id = blockIdx.x;
+  if (id < n_lsa) { lsa_fast_body<TJ>(a, id % B, id / B); return; }
+  const int j = id - n_lsa;
+  if (j < nx1) rnn_rowtile_body<EPI_LINEAR, 2, 4, HH_FEAT>(d1, j, 0);
+  else rnn_rowtile_body<EPI_LINEAR, 2, 4, HH_FEAT>(d2, j - nx1, 0);
+}
+
 // ---------------------------------------------------------------- finalize
 struct FinK {
   const float* x2;       // [B][H]
@@ -350,11 +370,15 @@ struct FinK {
   float min_stop_token;
 };
 
+// One workgroup per utterance (a single CU cannot pull the whole batch's 256 KB of fresh state fast
+// enough: that variant measured 14.5 us).  The batch-wide stop rule is decided by the last workgroup to
+// arrive, through two device-scope atomics -- a count of utterances still below the threshold, then the
+// arrival ticket -- with no __threadfence(): nothing but those atomics is exchanged (the fenced
+// "last block" protocol this replaces spent ~7 of its 9.9 us in the fences).
 __global__ __launch_bounds__(256) void finalize_kernel(FinK a) {
   if (*a.done) return;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   __shared__ float red[4];
-  __shared__ int last;
   // stop = sigmoid(stop_proj([x, context]))  (tacotron.py:133-136)
   float acc = 0.f;
   for (int k = tid; k < a.H; k += 256) acc += a.stop_w[k] * a.x2[(size_t)b * a.H + k];
@@ -370,22 +394,17 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinK a) {
   if (tid == 0) {
     const float sgm = 1.0f / (1.0f + expf(-((red[0] + red[1]) + (red[2] + red[3]) + a.stop_b[0])));
     a.stop_out[b] = sgm;
-    __threadfence();
-    last = (atomicAdd(a.arrive, 1) == a.B - 1);
-  }
-  __syncthreads();
-  if (!last) return;
-  // last block: batch-wide stop rule  (stop*10 > min_stop_token).all() and t > 10  (tacotron.py:275)
-  if (tid == 0) {
-    __threadfence();
-    bool all = true;
-    for (int i = 0; i < a.B; ++i) {
-      const float sv = __hip_atomic_load(a.stop_out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      all = all && (sv * 10.f > a.min_stop_token);
+    // batch-wide stop rule  (stop*10 > min_stop_token).all() and t > 10  (tacotron.py:275)
+    if (!(sgm * 10.f > a.min_stop_token)) {
+      int old = atomicAdd(a.arrive + 1, 1);  // utterances not ready to stop; performed before the ticket below
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(old) : : "memory");
     }
-    *a.n_frames = min(a.t0 + a.r, a.max_steps);
-    if (all && a.t0 > 10) *a.done = 1;
-    *a.arrive = 0;
+    if (atomicAdd(a.arrive, 1) == a.B - 1) {  // last arrival
+      const int not_ready = __hip_atomic_load(a.arrive + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *a.n_frames = min(a.t0 + a.r, a.max_steps);
+      if (not_ready == 0 && a.t0 > 10) *a.done = 1;
+      a.arrive[0] = 0; a.arrive[1] = 0;  // visible to the next iteration's launch (kernel boundary)
+    }
   }
 }
 
@@ -544,19 +563,20 @@ int cbhg_forward(const Cbhg& c, const float* x, int B, int F, const CbhgWs& L, h
   if (!rc) {
     MB_HIP(hipMemsetAsync(L.gh, 0, sizeof(float) * 4 * B * Hg, s));
     for (int st = 0; st < F && !rc; ++st) {
-      for (int d = 0; d < 2 && !rc; ++d) {
+      RnnK kd[2];
+      for (int d = 0; d < 2; ++d) {
         const int tt = d ? F - 1 - st : st;
         float* hp = L.gh + ((size_t)d * 2 + (st & 1)) * B * Hg;
         float* hn = L.gh + ((size_t)d * 2 + ((st & 1) ^ 1)) * B * Hg;
-        RnnK k;
+        RnnK& k = kd[d];
         memset(&k, 0, sizeof(k));
         k.w = d ? c.gru_hh_b.p : c.gru_hh_f.p; k.nseg = 1; k.nkb_total = Hg / 16; k.seg[0] = {hp, Hg, Hg / 16, 1};
         k.N = B; k.units = Hg; k.biasH = d ? c.gru_bhh_b.p : c.gru_bhh_f.p;
         k.pre_table = d ? L.ihb : L.ihf; k.pre_stride = 3 * Hg; k.pre_base_row = tt; k.pre_n_stride = F;
         k.h_prev = hp; k.h_out = hn;
         k.seq_out = L.seq; k.seq_n_stride = (long long)C * F; k.seq_j_stride = F; k.seq_off = (long long)d * Hg * F + tt;
-        rc = rnn_launch(EPI_GRU, k, s);
       }
+      rc = rnn_launch_dual_gru(kd[0], kd[1], s);  // both directions of step st in one launch
     }
   }
 #undef RC
@@ -679,6 +699,7 @@ struct mb_taco {
   DevBuf attn_w, attn_bih, attn_bhh;
   DevBuf rin_w, rin_b;
   DevBuf l1_w, l1_bih, l1_bhh, l2_w, l2_bih, l2_bhh;
+  DevBuf l1_wx, l1_whh, l2_wx, l2_whh;  // split-hidden decoder: input halves (LSTM tile order), hidden halves (plain row tiles)
   DevBuf mel_w, stop_w, stop_b;
   // postnet
   Cbhg post;
@@ -883,9 +904,15 @@ extern "C" int mb_taco_create(const mb_taco_config* cfg, const float* const* hw,
   // res_rnn1 / res_rnn2 LSTMCell(H -> H)
   cell_rows(hw[ix], H, H, hw[ix + 1], H, H, 4, &rows); pack_rowtile(rows.data(), 4 * H, 2 * H, 4, &packed);
   RC(t->l1_w.upload(packed.data(), packed.size())); RC(t->l1_bih.upload(hw[ix + 2], 4 * H)); RC(t->l1_bhh.upload(hw[ix + 3], 4 * H));
+  cell_rows(hw[ix], H, H, hw[ix + 1], 0, H, 4, &rows); pack_rowtile(rows.data(), 4 * H, H, 4, &packed);
+  RC(t->l1_wx.upload(packed.data(), packed.size()));
+  pack_rowtile(hw[ix + 1], 4 * H, H, 4, &packed); RC(t->l1_whh.upload(packed.data(), packed.size()));
   ix += 4;
   cell_rows(hw[ix], H, H, hw[ix + 1], H, H, 4, &rows); pack_rowtile(rows.data(), 4 * H, 2 * H, 4, &packed);
   RC(t->l2_w.upload(packed.data(), packed.size())); RC(t->l2_bih.upload(hw[ix + 2], 4 * H)); RC(t->l2_bhh.upload(hw[ix + 3], 4 * H));
+  cell_rows(hw[ix], H, H, hw[ix + 1], 0, H, 4, &rows); pack_rowtile(rows.data(), 4 * H, H, 4, &packed);
+  RC(t->l2_wx.upload(packed.data(), packed.size()));
+  pack_rowtile(hw[ix + 1], 4 * H, H, 4, &packed); RC(t->l2_whh.upload(packed.data(), packed.size()));
   ix += 4;
   // mel_proj: keep rows m*max_r + j for j < r, ordered frame-major (j, m)  (tacotron.py:128-129)
   {
@@ -928,7 +955,7 @@ extern "C" void mb_taco_destroy(mb_taco* t) {
   if (!t) return;
   DevBuf* bs[] = {&t->pre1_w, &t->pre1_b, &t->pre2_w, &t->pre2_b, &t->lsa_conv_w, &t->lsa_conv_b, &t->lsa_L, &t->lsa_W,
                   &t->lsa_Wb, &t->lsa_v, &t->attn_w, &t->attn_bih, &t->attn_bhh, &t->rin_w, &t->rin_b, &t->l1_w,
-                  &t->l1_bih, &t->l1_bhh, &t->l2_w, &t->l2_bih, &t->l2_bhh, &t->mel_w, &t->stop_w, &t->stop_b,
+                  &t->l1_bih, &t->l1_bhh, &t->l2_w, &t->l2_bih, &t->l2_bhh, &t->l1_wx, &t->l1_whh, &t->l2_wx, &t->l2_whh, &t->mel_w, &t->stop_w, &t->stop_b,
                   &t->emb, &t->enc_proj_full, &t->lsa_Mt, &t->lsa_c0, &t->lsa_Wt, &t->gst_qconst, &t->gst_WqS, &t->gst_K, &t->gst_V};
   for (DevBuf* b : bs) b->release();
   t->post.release(); t->post_proj.release(); t->enc.release();
@@ -939,7 +966,8 @@ extern "C" void mb_taco_destroy(mb_taco* t) {
 namespace {
 struct TacoLayout {
   float *p1, *p2, *attn_h, *context, *x, *x1, *x2, *h1, *c1, *h2, *c2, *melstep, *cumulative, *stop;
-  int* flags;  // [0] done, [1] n_frames, [2] arrive
+  float *hp1, *hp2;  // hidden halves W_hh.h + b_hh of the two LSTMs, [B][4H] gate-major
+  int* flags;  // [0] done, [1] n_frames, [2] arrive, [3] utterances below the stop threshold
   // postnet
   float *melc, *linc;
   CbhgWs cb;
@@ -957,6 +985,7 @@ static void taco_layout(const mb_taco* t, int B, int T, int max_steps, void* bas
   L->x = ar.take<float>(B * H); L->x1 = ar.take<float>(B * H); L->x2 = ar.take<float>(B * H);
   L->h1 = ar.take<float>(2 * B * H); L->c1 = ar.take<float>(2 * B * H);
   L->h2 = ar.take<float>(2 * B * H); L->c2 = ar.take<float>(2 * B * H);
+  L->hp1 = ar.take<float>((size_t)B * 4 * H); L->hp2 = ar.take<float>((size_t)B * 4 * H);
   L->melstep = ar.take<float>((size_t)B * c.r * M);
   L->cumulative = ar.take<float>((size_t)2 * B * T);
   L->stop = ar.take<float>(B);
@@ -1067,7 +1096,28 @@ extern "C" int mb_taco_decode(const mb_taco* t, const float* d_memory, const flo
     lk.Mt = t->lsa_Mt.p; lk.c0 = t->lsa_c0.p; lk.Wt = t->lsa_Wt.p;
     const bool lsa_fast = D == 128 && P / psplit == 256 && c.lsa_kernel <= 31 && (c.lsa_kernel & 1) && T <= 192 &&
                           getenv("MBHIP_LSA_GENERIC") == nullptr;
-    if (lsa_fast && T <= 128) hipLaunchKernelGGL(lsa_fast_kernel<32>, dim3(B, psplit), dim3(512), 0, s, lk);
+    // split-hidden decoder (experiment): the LSTMs' hidden halves ride in the attention launch.
+    // Measured on MI355X (B = 32): attention+hidden 27.9 us + 2 x 10.6 us LSTM input halves = 49.0 us against
+    // 19.6 + 2 x 15.3 = 50.2 us on the classic chain -- the hidden halves are bandwidth-bound work that
+    // takes as long beside the attention kernel as on the chain, so the classic chain stays the default
+    // (MBHIP_TACO_SPLIT=1 selects this path; parity-tested either way).
+    const bool split = lsa_fast && B <= 32 && H % 64 == 0 && getenv("MBHIP_TACO_SPLIT") != nullptr &&
+                       atoi(getenv("MBHIP_TACO_SPLIT")) == 1;
+    if (split) {
+      RnnK kh[2];
+      RnnDev dh[2];
+      for (int g = 0; g < 2; ++g) {
+        memset(&kh[g], 0, sizeof(RnnK));
+        kh[g].w = g ? t->l2_whh.p : t->l1_whh.p; kh[g].nseg = 1; kh[g].nkb_total = H / 16;
+        kh[g].seg[0] = {g ? h2p : h1p, H, H / 16, 0};
+        kh[g].N = B; kh[g].units = 4 * H; kh[g].biasX = g ? t->l2_bhh.p : t->l1_bhh.p;
+        kh[g].y = g ? L.hp2 : L.hp1; kh[g].ldy = 4 * H; kh[g].skip_flag = done;
+        if ((rc = make_rnn_dev(kh[g], &dh[g]))) return rc;
+      }
+      const int nx = cdiv(4 * H, 16), n_lsa = B * psplit;
+      if (T <= 128) hipLaunchKernelGGL(lsa_hh_kernel<32>, dim3(n_lsa + 2 * nx), dim3(512), 0, s, lk, dh[0], dh[1], n_lsa, B, nx);
+      else hipLaunchKernelGGL(lsa_hh_kernel<48>, dim3(n_lsa + 2 * nx), dim3(512), 0, s, lk, dh[0], dh[1], n_lsa, B, nx);
+    } else if (lsa_fast && T <= 128) hipLaunchKernelGGL(lsa_fast_kernel<32>, dim3(B, psplit), dim3(512), 0, s, lk);
     else if (lsa_fast) hipLaunchKernelGGL(lsa_fast_kernel<48>, dim3(B, psplit), dim3(512), 0, s, lk);
     else hipLaunchKernelGGL(lsa_kernel, dim3(B, psplit), dim3(512), lds_lsa, s, lk);
     MB_HIP(hipGetLastError());
@@ -1080,11 +1130,13 @@ extern "C" int mb_taco_decode(const mb_taco* t, const float* d_memory, const flo
     memset(&k, 0, sizeof(k));
     k.w = t->l1_w.p; k.nseg = 2; k.nkb_total = 2 * H / 16; k.seg[0] = {L.x, H, H / 16, 0}; k.seg[1] = {h1p, H, H / 16, 1};
     k.N = B; k.units = H; k.biasX = t->l1_bih.p; k.biasH = t->l1_bhh.p; k.c_prev = c1p; k.x_res = L.x;
+    if (split) { k.w = t->l1_wx.p; k.nseg = 1; k.nkb_total = H / 16; k.biasH = nullptr; k.h_pre = L.hp1; }
     k.h_out = h1n; k.c_out = c1n; k.x_out = L.x1; k.skip_flag = done;
     if ((rc = rnn_launch(EPI_LSTM, k, s))) return rc;
     memset(&k, 0, sizeof(k));
     k.w = t->l2_w.p; k.nseg = 2; k.nkb_total = 2 * H / 16; k.seg[0] = {L.x1, H, H / 16, 0}; k.seg[1] = {h2p, H, H / 16, 1};
     k.N = B; k.units = H; k.biasX = t->l2_bih.p; k.biasH = t->l2_bhh.p; k.c_prev = c2p; k.x_res = L.x1;
+    if (split) { k.w = t->l2_wx.p; k.nseg = 1; k.nkb_total = H / 16; k.biasH = nullptr; k.h_pre = L.hp2; }
     k.h_out = h2n; k.c_out = c2n; k.x_out = L.x2; k.skip_flag = done;
     if ((rc = rnn_launch(EPI_LSTM, k, s))) return rc;
     // mels = mel_proj(x)[:, :, :r]  (tacotron.py:128-129)
