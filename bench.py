@@ -71,7 +71,6 @@ def main():
         dist.barrier()
     import synth
     from mockingbird_amd.vocoder.wavernn.inference import WaveRNNDevice
-    from mockingbird_amd.vocoder.wavernn import dsp
     from mockingbird_amd import sharding
 
     state = synth.wavernn_state(seed=5)["model_state"]
@@ -84,8 +83,7 @@ def main():
 
     def one_pass(seed):
         samples = model.generate_samples(mel, True, target, overlap, seed=seed)
-        wav = dsp.finish(samples.cpu().numpy(), True, overlap, model.n_classes, True, True, 0.97, wave_len,
-                         model.hop_length)
+        wav = model.finish(samples, True, overlap, True, wave_len)  # float64 tail on the device, D2H of the waveform
         if use_dist:
             wavs = sharding.gather_waveforms([wav.astype(np.float32)], dev)
             return wav, sum(len(w) for w in wavs)

@@ -268,6 +268,18 @@ int mb_wavernn_generate(const mb_wavernn* w, const mb_wavernn_plan* plan,
 /* time (ms) the sample-loop kernels of the LAST generate call took, measured
  * with hipEvents on `stream` (valid after the stream is synchronised), and the
  * number of kernel launches in it. */
+/* Device post-processing of the generated folds, float64 (wavernn_post.hip).
+ * Replaces the numpy tail of WaveRNN.generate  models/vocoder/wavernn/models/fatchord_version.py:236-257:
+ *   xfade_and_unfold :340-402 (if batched), decode_mu_law audio.py:102-107 (if mu_law),
+ *   de_emphasis audio.py:92-93 (if apply_preemphasis), output[:wave_len], linear fade over fade_len samples.
+ * d_samples: fp32 [n_folds][seq_len] as written by mb_wavernn_generate; d_wav: float64, capacity >=
+ * min(wave_len, unfolded length); *out_len receives that length.  Fails (MB_EINVAL) when the waveform is
+ * shorter than the fade window, where the reference raises (mels < 26 frames). */
+size_t mb_wavernn_finish_workspace_bytes(int n_folds, int seq_len, int batched, int overlap);
+int mb_wavernn_finish(const float* d_samples, int n_folds, int seq_len, int batched, int overlap,
+                      int n_classes, int mu_law, int apply_preemphasis, double preemphasis,
+                      int wave_len, int fade_len, double* d_wav, int* out_len, void* d_workspace,
+                      size_t workspace_bytes, mb_stream_t stream);
 int mb_wavernn_last_loop_ms(const mb_wavernn* w, float* ms, int* launches);
 /* Measurement hook (bench.py roofline leg): runs the real generate loop twice on its
  * stream, bracketed by hipEvents, with and without kernel `which` (0 rnn1 GRU, 1 rnn2 GRU,

@@ -135,6 +135,10 @@ SIGNATURES = {
                                  C.c_size_t, C.c_void_p]),
     "mb_wavernn_num_weights": (C.c_int, [C.POINTER(WaveRNNConfig)]),
     "mb_wavernn_weight_numel": (C.c_size_t, [C.POINTER(WaveRNNConfig), C.c_int]),
+    "mb_wavernn_finish_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
+    "mb_wavernn_finish": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_double, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_void_p,
+                                    C.c_size_t, C.c_void_p]),
     "mb_wavernn_create": (C.c_int, [C.POINTER(WaveRNNConfig), _PP, C.c_int, _PP]),
     "mb_wavernn_destroy": (None, [C.c_void_p]),
     "mb_wavernn_plan_generate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

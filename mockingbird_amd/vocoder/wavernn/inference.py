@@ -8,7 +8,6 @@ import numpy as np
 import torch
 
 from ... import _lib, weights
-from . import dsp
 from . import hparams as hp
 
 _model = None   # type: WaveRNNDevice
@@ -105,8 +104,31 @@ class WaveRNNDevice:
         wave_len = (mel.shape[-1] - 1) * self.hop_length
         samples = self.generate_samples(mel.cuda(), batched, target, overlap, noise=noise, seed=seed,
                                         progress_callback=progress_callback)
-        return dsp.finish(samples.cpu().numpy(), batched, overlap, self.n_classes, mu_law,
-                          self.hp.apply_preemphasis, self.hp.preemphasis, wave_len, self.hop_length)
+        return self.finish(samples, batched, overlap, mu_law, wave_len)
+
+    def finish(self, samples, batched, overlap, mu_law, wave_len):
+        """Float64 tail of WaveRNN.generate (fatchord_version.py:236-257) on the device: xfade_and_unfold,
+        decode_mu_law, de_emphasis, truncation to wave_len, linear fade-out over 20 hops.  Only the finished
+        waveform crosses PCIe.  Returns np.float64 like the reference."""
+        if not samples.is_cuda:
+            raise _lib.MbHipError("WaveRNN.finish needs a CUDA(HIP) tensor; there is no CPU path")
+        samples = samples.to(torch.float32).contiguous()
+        n_folds, seq_len = samples.shape
+        fade_n = 20 * self.hop_length
+        unfolded = n_folds * (seq_len - overlap) + overlap if batched else seq_len
+        n_out = min(wave_len, unfolded)
+        if n_out < fade_n:  # the reference dies here with numpy's broadcast error (SURVEY finding 5)
+            raise ValueError(f"operands could not be broadcast together with shapes ({n_out},) ({fade_n},)")
+        L = _lib.lib()
+        need = L.mb_wavernn_finish_workspace_bytes(n_folds, seq_len, int(bool(batched)), overlap)
+        ws = torch.empty(need, dtype=torch.uint8, device=samples.device)
+        wav = torch.empty(n_out, dtype=torch.float64, device=samples.device)
+        got = C.c_int()
+        _lib.check(L.mb_wavernn_finish(_lib.ptr(samples), n_folds, seq_len, int(bool(batched)), overlap,
+                                       self.n_classes, int(bool(mu_law)), int(bool(self.hp.apply_preemphasis)),
+                                       float(self.hp.preemphasis), wave_len, fade_n, _lib.ptr(wav), C.byref(got),
+                                       _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "mb_wavernn_finish")
+        return wav[:got.value].cpu().numpy()
 
 
 def load_model(weights_fpath, verbose=True):

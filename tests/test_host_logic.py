@@ -68,20 +68,6 @@ def test_plan_matches_fold_with_overlap(frames, target, overlap):
     assert folded.shape[0] == nf and folded.shape[1] == target + 2 * overlap
 
 
-def test_dsp_matches_oracle_postprocess():
-    from mockingbird_amd.vocoder.wavernn import dsp
-    rng = np.random.default_rng(0)
-    k = rng.integers(0, 512, (9, 800))
-    samples = (2 * k / 511.0 - 1).astype(np.float32)
-    wave_len = 29 * 256
-    mine = dsp.finish(samples.copy(), True, 100, 512, True, True, 0.97, wave_len, 256)
-    ref = ow.postprocess(ow.HP, torch.from_numpy(samples.copy()), wave_len, True, 600, 100)
-    assert np.array_equal(mine, ref)
-    mine = dsp.finish(samples[:1, :].repeat(8, 1).reshape(1, -1).copy(), False, 0, 512, True, True, 0.97, 24 * 256, 256)
-    ref = ow.postprocess(ow.HP, torch.from_numpy(samples[:1, :].repeat(8, 1).reshape(1, -1).copy()), 24 * 256, False, 0, 0)
-    assert np.array_equal(mine, ref)
-
-
 def test_shard_indices_balanced_and_complete():
     from mockingbird_amd.sharding import shard_indices
     lens = [90, 110, 95, 101, 99, 108, 93, 97, 100, 105, 91, 102]

@@ -80,12 +80,14 @@ def test_free_running_injected_noise_and_waveform(model):
     assert sum(fb == S for fb in first_bad) >= n - 2, first_bad
     good = [i for i in range(n) if first_bad[i] == S]
     assert torch.equal(s[good], o_samples[good])
-    # post-processing parity on identical samples
-    from mockingbird_amd.vocoder.wavernn import dsp
+    # post-processing parity on identical samples: device float64 tail (mb_wavernn_finish) vs the oracle's
+    # numpy restatement of fatchord_version.py:236-257.  Elementwise steps follow numpy's operation
+    # order; pow() and the chunked de-emphasis scan reorder roundings -> 1e-12 absolute gate.
     wave_len = (frames - 1) * 256
-    mine = dsp.finish(o_samples.numpy().copy(), True, overlap, 512, True, True, 0.97, wave_len, 256)
+    mine = dev.finish(o_samples.cuda(), True, overlap, True, wave_len)
     ref = ow.postprocess(ow.HP, o_samples.clone(), wave_len, True, target, overlap)
-    assert mine.dtype == np.float64 and np.array_equal(mine, ref)
+    assert mine.dtype == np.float64 and mine.shape == ref.shape
+    assert float(np.abs(mine - ref).max()) <= 1e-12, float(np.abs(mine - ref).max())
 
 
 def test_device_rng_statistics(model):
@@ -168,3 +170,41 @@ def test_infer_waveform_facade(model, tmp_path):
     assert calls and all(len(c) == 4 and c[1] == 2400 for c in calls)
     with pytest.raises(ValueError):  # reference crashes for mels < 26 frames (SURVEY finding 5)
         inf.infer_waveform(synth.wavernn_mel(20, seed=8), target=2000, overlap=200)
+
+
+@pytest.mark.parametrize("n_folds,target,overlap,batched,wave_len", [
+    (9, 600, 100, True, 29 * 256),     # wave_len > unfolded length: truncation to the shorter one
+    (23, 8000, 800, True, 200000),     # BASELINE configs[1] geometry
+    (4, 2000, 200, True, 6000),        # wave_len < unfolded length
+    (9, 700, 1, True, 6000),           # overlap 1: silence 0 / fade 1 (linspace of one point)
+    (1, 24 * 256, 0, False, 23 * 256),  # unbatched: one sequence, no cross-fade
+])
+def test_device_finish_matches_oracle(model, n_folds, target, overlap, batched, wave_len):
+    """mb_wavernn_finish (xfade_and_unfold, decode_mu_law, de_emphasis scan, truncate, fade-out in float64
+    on the device) against oracle.postprocess on random class samples."""
+    dev, w = model
+    rng = np.random.default_rng(n_folds * 131 + overlap)
+    S = target + 2 * overlap if batched else target
+    k = rng.integers(0, 512, (n_folds, S))
+    samples = torch.from_numpy((2 * k / 511.0 - 1).astype(np.float32))
+    mine = dev.finish(samples.cuda(), batched, overlap, True, wave_len)
+    ref = ow.postprocess(ow.HP, samples.clone(), wave_len, batched, target, overlap)
+    assert mine.dtype == np.float64 and mine.shape == ref.shape
+    err = float(np.abs(mine - ref).max())
+    assert err <= 1e-12, err
+    # without mu-law / de-emphasis every step is elementwise in numpy's operation order: bit-exact
+    hp2 = dict(ow.HP); hp2["mu_law"] = False; hp2["apply_preemphasis"] = False
+    pre = dev.hp.apply_preemphasis
+    dev.hp.apply_preemphasis = False
+    try:
+        mine2 = dev.finish(samples.cuda(), batched, overlap, False, wave_len)
+    finally:
+        dev.hp.apply_preemphasis = pre
+    ref2 = ow.postprocess(hp2, samples.clone(), wave_len, batched, target, overlap)
+    assert np.array_equal(mine2, ref2)
+
+
+def test_device_finish_short_mel_raises(model):
+    dev, w = model
+    with pytest.raises(ValueError):  # shorter than the 20-hop fade window (reference: numpy broadcast error)
+        dev.finish(torch.zeros(1, 3000).cuda(), False, 0, True, 19 * 256)
