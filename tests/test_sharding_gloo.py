@@ -44,3 +44,64 @@ def test_gather_waveforms_world2():
     for p in procs:
         p.join(30)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+class _StubSynth:
+    """Deterministic stand-in for the Synthesizer facade: sentence -> (80, 2*len(text)) spectrogram."""
+    sample_rate = 16000
+
+    class hparams:
+        hop_size = 200
+
+    def synthesize_spectrograms(self, texts, embeddings, style_idx=0, min_stop_token=5, steps=2000):
+        return [np.full((80, 2 * len(t)), float(len(t)) + float(e[0]), np.float32) for t, e in zip(texts, embeddings)]
+
+
+class _StubVocoder:
+    def infer_waveform_batch(self, mels):
+        return [np.repeat(m[0], 200).astype(np.float32) for m in mels], 16000
+
+
+def _requests():
+    rng = np.random.default_rng(0)
+    reqs = []
+    for i in range(5):
+        texts = ["x" * int(rng.integers(3, 30)) for _ in range(1 + i % 3)]
+        reqs.append((texts, np.full(256, float(i), np.float32)))
+    return reqs
+
+
+def _pipeline_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mockingbird_amd import pipeline
+    out = pipeline.gen_wavs(_StubSynth(), _StubVocoder(), _requests())
+    q.put((rank, [w.tolist() for w in out]))
+    dist.destroy_process_group()
+
+
+def test_pipeline_gen_wavs_world2_matches_single_process():
+    """configs[3] plumbing: requests sharded over 2 ranks come back complete and in request order, equal to
+    the single-process result, with gen_voice.py's 0.15 s breaks after every sentence."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from mockingbird_amd import pipeline
+    ref = pipeline.gen_wavs(_StubSynth(), _StubVocoder(), _requests())
+    reqs = _requests()
+    for w, (texts, emb) in zip(ref, reqs):
+        assert len(w) == sum(2 * len(t) * 200 for t in texts) + len(texts) * int(0.15 * 16000)
+        assert (w[-int(0.15 * 16000):] == 0).all()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(30)
+    for r in (0, 1):
+        assert len(res[r]) == len(ref)
+        for a, b in zip(res[r], ref):
+            assert np.array_equal(np.asarray(a, np.float32), b.astype(np.float32))
