@@ -76,7 +76,10 @@ template <int C> struct PairGeom {
 // TD = taps of weight prefetch kept in flight per wave (2: 64 VGPRs at MT = 2; 1 for the instances whose
 // accumulators leave no room -- the kernel must stay within 256 VGPRs because the loader wave shares
 // a SIMD with an MMA wave)
-template <int C, int NTW, int TD>
+// YS = y staged in its own LDS tile (C <= 64, where LDS has room): the support waves then have the whole
+// tile time -- not only phase 1 -- for the x prefetch and the y write-out, which is what bounds those
+// HBM-limited stages.  Without it y is staged in the h tile and must be written out before the next h.
+template <int C, int NTW, int TD, bool YS>
 __global__ __launch_bounds__(64 * (4 + PAIR_NL)) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void resblock_pair_f16_kernel(ResPairK a) {
   using G = PairGeom<C>;
@@ -86,7 +89,8 @@ void resblock_pair_f16_kernel(ResPairK a) {
   h16* xs = reinterpret_cast<h16*>(lds_raw);           // [nbuf][x_rows][CKP]
   h16* hs = xs + a.nbuf * a.x_rows * CKP;               // [N1 + ntaps - 1][CP]
   // biases live in LDS: a vector-memory read in the epilogues would queue behind the weight prefetches
-  float* bs = reinterpret_cast<float*>(hs + (WN * NTW * 32 + a.ntaps - 1) * CP);  // [2][C]
+  h16* ys = YS ? hs + (WN * NTW * 32 + a.ntaps - 1) * CP : hs;  // [N1][CP] staged conv2 + b2
+  float* bs = reinterpret_cast<float*>(ys + (YS ? WN * NTW * 32 * CP : (WN * NTW * 32 + a.ntaps - 1) * CP));  // [2][C]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntaps = a.ntaps;
@@ -140,14 +144,17 @@ void resblock_pair_f16_kernel(ResPairK a) {
     // Runs while the MMA waves are already in phase 1 of the next tile -- they never wait on HBM.
     constexpr int WB = 8;         // pieces per lane per batch
     constexpr int YPR = C / 8;    // 16-byte pieces per output row
-    auto write_out = [&](int it) {
+    auto write_out = [&](int it, int part) {  // part 0 = everything, 1 = first 3/8 of the batches, 2 = the rest
       const int tile = (int)blockIdx.x + it * (int)gridDim.x;
       const int b = tile / a.tiles_per_item, t0 = (tile - b * a.tiles_per_item) * a.NB;
       const int rows = min(a.NB, a.T - t0);
       const int ytotal = rows * YPR;
       const h16* xb = a.x + (long long)b * a.bstride + (long long)t0 * C;
       h16* yb = a.y + (long long)b * a.bstride + (long long)t0 * C;
-      for (int base = 0; base < ytotal; base += 64 * PAIR_NL * WB) {
+      constexpr int BSZ = 64 * PAIR_NL * WB;
+      const int nbt = (ytotal + BSZ - 1) / BSZ, ncut = (3 * nbt) / 8;
+      const int b_lo = part == 2 ? ncut : 0, b_hi = part == 1 ? ncut : nbt;
+      for (int base = b_lo * BSZ; base < b_hi * BSZ && base < ytotal; base += BSZ) {
         h16x8 rx[WB], ry[WB];
 #pragma unroll
         for (int i = 0; i < WB; ++i) {
@@ -161,7 +168,7 @@ void resblock_pair_f16_kernel(ResPairK a) {
           const int idx = base + i * (64 * PAIR_NL) + ltid;
           const int idc = idx < ytotal ? idx : ytotal - 1;
           const int row = idc / YPR, pc = idc - row * YPR;
-          const h16x8 hv = *reinterpret_cast<const h16x8*>(hs + row * CP + pc * 8);
+          const h16x8 hv = *reinterpret_cast<const h16x8*>(ys + row * CP + pc * 8);
           h16x8 o;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -173,7 +180,7 @@ void resblock_pair_f16_kernel(ResPairK a) {
         }
       }
     };
-    // Barrier schedule per tile (must mirror the MMA waves'): B per chunk, W, E1, P, Y.
+    // Barrier schedule per tile (must mirror the MMA waves'): B per chunk, [W], E1, P|YF, Y.
     if (a.nbuf == 1) {
       // single buffer (NCH == 1, window = one batch): the next tile's loads fly during phase 1 and are
       // written to LDS while the MMA waves run phase 2, which reads only h
@@ -184,15 +191,16 @@ void resblock_pair_f16_kernel(ResPairK a) {
         MB_PMARK(1, it, 1);
         if (it + 1 < my_tiles) load_batch(it + 1, 0);
         MB_PMARK(1, it, 2);
-        if (it > 0) write_out(it - 1);
+        if (it > 0) write_out(it - 1, YS ? 1 : 0);
         MB_PMARK(1, it, 3);
-        __syncthreads();  // W: hs is free for h of this tile
+        if (!YS) __syncthreads();  // W: hs is free for h of this tile
         __syncthreads();  // E1: phase 1 has finished reading xs
         MB_PMARK(1, it, 4);
         if (it + 1 < my_tiles) store_batch(it + 1, 0);
+        if (YS && it > 0) write_out(it - 1, 2);
         MB_PMARK(1, it, 5);
-        __syncthreads();  // P
-        __syncthreads();  // Y: y of this tile is staged in hs
+        __syncthreads();  // P (all MMA waves done with h) | YF (ys is free for y of this tile)
+        __syncthreads();  // Y: y of this tile is staged
         MB_PMARK(1, it, 6);
       }
     } else {
@@ -205,18 +213,19 @@ void resblock_pair_f16_kernel(ResPairK a) {
           if (c == 0) MB_PMARK(1, it, 1);
           if (q + a.nbuf - 1 < njobs) fill(q + a.nbuf - 1);
           if (c == 0) MB_PMARK(1, it, 2);
-          if (c == 0 && it > 0) write_out(it - 1);
+          if (!YS && c == 0 && it > 0) write_out(it - 1, 0);
           if (c == 0) MB_PMARK(1, it, 3);
         }
-        __syncthreads();  // W
+        if (!YS) __syncthreads();  // W
         __syncthreads();  // E1
         MB_PMARK(1, it, 4);
-        __syncthreads();  // P
+        if (YS && it > 0) write_out(it - 1, 0);
+        __syncthreads();  // P | YF
         __syncthreads();  // Y
         MB_PMARK(1, it, 6);
       }
     }
-    if (my_tiles > 0) write_out(my_tiles - 1);
+    if (my_tiles > 0) write_out(my_tiles - 1, 0);
     return;
   }
 
@@ -320,7 +329,7 @@ void resblock_pair_f16_kernel(ResPairK a) {
       }
     }
     MB_PMARK(0, it, 2);
-    __syncthreads();  // W: the support waves have written out the previous tile's y from hs
+    if (!YS) __syncthreads();  // W: the support waves have written out the previous tile's y from hs
     MB_PMARK(0, it, 3);
     {  // epilogue 1 -> hs (fp16); rows outside [0, T) are conv2's zero padding.  Packed math: this runs
        // on the MMA waves' critical path (one wave per SIMD, 128 values per lane)
@@ -359,9 +368,9 @@ void resblock_pair_f16_kernel(ResPairK a) {
       }
     }
     MB_PMARK(0, it, 6);
-    __syncthreads();  // P: every MMA wave has finished reading h
+    __syncthreads();  // P: every MMA wave has finished reading h | YF: the previous tile's y has left ys
     MB_PMARK(0, it, 7);
-    {  // epilogue 2 -> hs: conv2 + b2 (fp16); the support waves add the residual and write y out
+    {  // epilogue 2 -> ys: conv2 + b2 (fp16); the support waves add the residual and write y out
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -373,7 +382,7 @@ void resblock_pair_f16_kernel(ResPairK a) {
             const f32x4 bv = *reinterpret_cast<const f32x4*>(bs + C + co0);
             f32x4 v = {acc[i][n][4 * g], acc[i][n][4 * g + 1], acc[i][n][4 * g + 2], acc[i][n][4 * g + 3]};
             v += bv;
-            *reinterpret_cast<h16x4*>(hs + row * CP + co0) = __builtin_convertvector(v, h16x4);
+            *reinterpret_cast<h16x4*>(ys + row * CP + co0) = __builtin_convertvector(v, h16x4);
           }
         }
     }
@@ -388,11 +397,11 @@ void resblock_pair_f16_kernel(ResPairK a) {
 
 // LDS bytes of a (C, NTW) instance for a given conv1 geometry and x-window buffer count
 template <int C>
-static size_t pair_lds_bytes(int ntw, int ntaps, int dil, int nbuf) {
+static size_t pair_lds_bytes(int ntw, int ntaps, int dil, int nbuf, bool ys = false) {
   using G = PairGeom<C>;
   const int n1 = G::WN * ntw * 32;
   const int x_rows = n1 + (ntaps - 1) * dil;
-  return ((size_t)nbuf * x_rows * G::CKP + (size_t)(n1 + ntaps - 1) * G::CP) * sizeof(h16) + 2 * C * sizeof(float);
+  return ((size_t)nbuf * x_rows * G::CKP + (size_t)(n1 + ntaps - 1 + (ys ? n1 : 0)) * G::CP) * sizeof(h16) + 2 * C * sizeof(float);
 }
 constexpr size_t PAIR_LDS_CAP = 160 * 1024;
 // fewest buffers an instance can run with: 1 (single-buffer mode) when the window is one chunk and one
@@ -405,11 +414,11 @@ static int pair_min_nbuf(int ntw, int ntaps, int dil) {
   return single_ok ? 1 : 2;
 }
 template <int C>
-static bool pair_fits(int ntw, int ntaps, int dil) {
-  return pair_lds_bytes<C>(ntw, ntaps, dil, pair_min_nbuf<C>(ntw, ntaps, dil)) <= PAIR_LDS_CAP;
+static bool pair_fits(int ntw, int ntaps, int dil, bool ys = false) {
+  return pair_lds_bytes<C>(ntw, ntaps, dil, pair_min_nbuf<C>(ntw, ntaps, dil), ys) <= PAIR_LDS_CAP;
 }
 
-template <int C, int NTW, int TD>
+template <int C, int NTW, int TD, bool YS>
 static int launch_pair(ResPairK k, int batch, hipStream_t s) {
   using G = PairGeom<C>;
   const int n1 = G::WN * NTW * 32;
@@ -419,7 +428,7 @@ static int launch_pair(ResPairK k, int batch, hipStream_t s) {
   k.n_tiles = k.tiles_per_item * batch;
   // as many x-window buffers as fit (<= 4): the loaders run nbuf-1 chunks ahead of the MMA waves
   int nbuf = pair_min_nbuf<C>(NTW, k.ntaps, k.dil);
-  while (nbuf < 4 && pair_lds_bytes<C>(NTW, k.ntaps, k.dil, nbuf + 1) <= PAIR_LDS_CAP) ++nbuf;
+  while (nbuf < 4 && pair_lds_bytes<C>(NTW, k.ntaps, k.dil, nbuf + 1, YS) <= PAIR_LDS_CAP) ++nbuf;
   if (const char* e = getenv("MBHIP_PAIR_NBUF")) { const int f = atoi(e); if (f >= pair_min_nbuf<C>(NTW, k.ntaps, k.dil) && f <= nbuf) nbuf = f; }
   k.nbuf = nbuf;
   if (const char* e = getenv("MBHIP_PAIR_DBG")) k.dbg = atoi(e);
@@ -430,10 +439,10 @@ static int launch_pair(ResPairK k, int batch, hipStream_t s) {
     MB_HIP(hipMemsetAsync(d_trace, 0, 256 * sizeof(unsigned long long), s));
     k.trace = d_trace;
   }
-  const size_t lds = pair_lds_bytes<C>(NTW, k.ntaps, k.dil, nbuf);
+  const size_t lds = pair_lds_bytes<C>(NTW, k.ntaps, k.dil, nbuf, YS);
   static bool attr_done = false;
   if (!attr_done) {
-    MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_f16_kernel<C, NTW, TD>),
+    MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_f16_kernel<C, NTW, TD, YS>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
@@ -451,7 +460,7 @@ static int launch_pair(ResPairK k, int batch, hipStream_t s) {
     n_cu = cached;
   }
   const int grid = std::min(k.n_tiles, n_cu);
-  hipLaunchKernelGGL((resblock_pair_f16_kernel<C, NTW, TD>), dim3(grid), dim3(64 * (4 + PAIR_NL)), lds, s, k);
+  hipLaunchKernelGGL((resblock_pair_f16_kernel<C, NTW, TD, YS>), dim3(grid), dim3(64 * (4 + PAIR_NL)), lds, s, k);
   MB_HIP(hipGetLastError());
   if (trace_path) {  // diagnostics: append "C NTW TD ntaps dil nbuf tiles : marks..." per launch
     unsigned long long h[256];
@@ -474,11 +483,11 @@ using namespace mb;
 extern "C" int mb_resblock_pair_f16_supported(int channels, int ksize, int dilation) {
   if (!(channels == 32 || channels == 64 || channels == 128 || channels == 256)) return 0;
   if (ksize < 3 || (ksize & 1) == 0 || dilation < 1) return 0;
-  switch (channels) {
-    case 256: return pair_fits<256>(3, ksize, dilation);
-    case 128: return pair_fits<128>(2, ksize, dilation);
-    case 64: return pair_fits<64>(2, ksize, dilation);
-    default: return pair_fits<32>(2, ksize, dilation);
+  switch (channels) {  // the candidates of mb_resblock_pair_f16's instance choice
+    case 256: return pair_fits<256>(3, ksize, dilation) || pair_fits<256>(4, ksize, dilation);
+    case 128: return pair_fits<128>(2, ksize, dilation) || pair_fits<128>(3, ksize, dilation);
+    case 64: return pair_fits<64>(4, ksize, dilation) || pair_fits<64>(2, ksize, dilation, true);
+    default: return pair_fits<32>(2, ksize, dilation, true) || pair_fits<32>(4, ksize, dilation, true);
   }
 }
 
@@ -535,19 +544,25 @@ extern "C" int mb_resblock_pair_f16(const mb_resblock_pair_f16_args* a, mb_strea
     const long long tiles = (long long)cdiv(a->t, nb) * a->batch;
     return ((tiles + 255) / 256) * (long long)n1;
   };
-#define MB_PICK2(C_, WN_, NA, TDA, NB_, TDB)                                                        \
+#define MB_PICK2(C_, WN_, NA, TDA, YA, NB_, TDB, YB)                                                \
   do {                                                                                              \
-    const bool fa = pair_fits<C_>(NA, a->ksize, a->dilation);                                       \
-    const bool fb = pair_fits<C_>(NB_, a->ksize, a->dilation);                                      \
-    if (fb && (!fa || cost(WN_ * NB_ * 32) <= cost(WN_ * NA * 32)))                                 \
-      return launch_pair<C_, NB_, TDB>(k, a->batch, s);                                             \
-    return launch_pair<C_, NA, TDA>(k, a->batch, s);                                                \
+    const bool fa = pair_fits<C_>(NA, a->ksize, a->dilation, YA);                                   \
+    const bool fb = pair_fits<C_>(NB_, a->ksize, a->dilation, YB);                                  \
+    MB_REQUIRE(fa || fb, "resblock_pair_f16: no instance fits LDS");                                 \
+    if (fb && (!fa || prefer_b || cost(WN_ * NB_ * 32) <= cost(WN_ * NA * 32)))                     \
+      return launch_pair<C_, NB_, TDB, YB>(k, a->batch, s);                                         \
+    return launch_pair<C_, NA, TDA, YA>(k, a->batch, s);                                            \
   } while (0)
+  bool prefer_b = false;
   switch (a->channels) {
-    case 256: MB_PICK2(256, 1, 3, 2, 4, 1);
-    case 128: MB_PICK2(128, 2, 2, 2, 3, 1);
-    case 64: MB_PICK2(64, 4, 2, 2, 4, 1);
-    default: MB_PICK2(32, 4, 2, 2, 4, 2);
+    case 256: MB_PICK2(256, 1, 3, 2, false, 4, 1, false);
+    case 128: MB_PICK2(128, 2, 2, 2, false, 3, 1, false);
+    case 64:
+      // N1 = 256 with its own y tile (support waves overlap the whole tile) vs N1 = 512 sharing the h tile;
+      // MBHIP_PAIR_C64=big selects the latter
+      prefer_b = !(getenv("MBHIP_PAIR_C64") && strcmp(getenv("MBHIP_PAIR_C64"), "big") == 0);
+      MB_PICK2(64, 4, 4, 1, false, 2, 2, true);
+    default: prefer_b = true; MB_PICK2(32, 4, 2, 2, true, 4, 2, true);
   }
 #undef MB_PICK2
 }
