@@ -88,3 +88,45 @@ def test_tacotron_weight_list_matches_abi_counts(lib):
     assert lib.mb_taco_num_weights(C.byref(c)) == len(ws)
     for i, w in enumerate(ws):
         assert lib.mb_taco_weight_numel(C.byref(c), i) == w.numel(), i
+
+
+def test_resblock_pair_weight_stream_layout(lib):
+    """mb_resblock_pair_f16_pack (host code): the fp16 image is ONE circular stream per 32-channel output
+    tile in the kernel's consumption order [conv1: chunk, tap, k-block][conv2: ...][lane][8], with the
+    v_mfma_f32_32x32x16_f16 A-fragment lane map (lane l holds row l&31, k = 8*(l>>5) + e)."""
+    import ctypes as C_
+    from mockingbird_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(0)
+    for Cc, k in ((64, 3), (32, 7), (128, 3)):
+        w1 = rng.standard_normal((Cc, Cc, k)).astype(np.float32)
+        w2 = rng.standard_normal((Cc, Cc, k)).astype(np.float32)
+        n = L.mb_resblock_pair_f16_packed_halves(Cc, k)
+        assert n == 2 * Cc * Cc * k
+        img = np.empty(n, np.float16)
+        _lib.check(L.mb_resblock_pair_f16_pack(w1.ctypes.data, w2.ctypes.data, Cc, k, img.ctypes.data),
+                   "mb_resblock_pair_f16_pack")
+        CK = 64 if Cc >= 64 else 32
+        KB, NCH, MTT = CK // 16, Cc // CK, Cc // 32
+        img = img.reshape(MTT, 2, NCH, k, KB, 64, 8)
+        for mt, ph, c, j, u, lane in [(0, 0, 0, 0, 0, 0), (MTT - 1, 1, NCH - 1, k - 1, KB - 1, 63), (MTT // 2, 1, 0, 1, 1, 37)]:
+            w = (w1, w2)[ph]
+            co = mt * 32 + (lane & 31)
+            ci0 = c * CK + u * 16 + (lane >> 5) * 8
+            assert np.array_equal(img[mt, ph, c, j, u, lane], w[co, ci0:ci0 + 8, j].astype(np.float16))
+    assert L.mb_resblock_pair_f16_supported(64, 11, 5) == 1 and L.mb_resblock_pair_f16_supported(48, 3, 1) == 0
+    assert L.mb_resblock_pair_f16_supported(64, 4, 1) == 0  # even kernel sizes have no "same" padding
+
+
+def test_wavernn_finish_workspace_and_shape_errors(lib):
+    """Host-side checks of mb_wavernn_finish: workspace formula, argument validation before any launch."""
+    from mockingbird_amd import _lib
+    L = _lib.lib()
+    n_folds, S, ov = 23, 9600, 800
+    unfolded = n_folds * (S - ov) + ov
+    need = L.mb_wavernn_finish_workspace_bytes(n_folds, S, 1, ov)
+    assert need >= unfolded * 8 and need < unfolded * 8 + 64 * 1024
+    assert L.mb_wavernn_finish_workspace_bytes(1, 100, 1, 60) == 0  # seq_len <= 2*overlap
+    got = C.c_int()
+    rc = L.mb_wavernn_finish(None, 1, 100, 0, 0, 512, 1, 1, 0.97, 50, 10, None, C.byref(got), None, 0, None)
+    assert rc < 0 and b"null pointer" in L.mb_last_error()
