@@ -144,7 +144,7 @@ void resblock_pair_f16_kernel(ResPairK a) {
     // Runs while the MMA waves are already in phase 1 of the next tile -- they never wait on HBM.
     constexpr int WB = 8;         // pieces per lane per batch
     constexpr int YPR = C / 8;    // 16-byte pieces per output row
-    auto write_out = [&](int it, int part) {  // part 0 = everything, 1 = first 3/8 of the batches, 2 = the rest
+    auto write_out = [&](int it, int lo, int hi, int den) {  // batches [nbt*lo/den, nbt*hi/den) of tile `it`
       const int tile = (int)blockIdx.x + it * (int)gridDim.x;
       const int b = tile / a.tiles_per_item, t0 = (tile - b * a.tiles_per_item) * a.NB;
       const int rows = min(a.NB, a.T - t0);
@@ -152,8 +152,8 @@ void resblock_pair_f16_kernel(ResPairK a) {
       const h16* xb = a.x + (long long)b * a.bstride + (long long)t0 * C;
       h16* yb = a.y + (long long)b * a.bstride + (long long)t0 * C;
       constexpr int BSZ = 64 * PAIR_NL * WB;
-      const int nbt = (ytotal + BSZ - 1) / BSZ, ncut = (3 * nbt) / 8;
-      const int b_lo = part == 2 ? ncut : 0, b_hi = part == 1 ? ncut : nbt;
+      const int nbt = (ytotal + BSZ - 1) / BSZ;
+      const int b_lo = nbt * lo / den, b_hi = nbt * hi / den;
       for (int base = b_lo * BSZ; base < b_hi * BSZ && base < ytotal; base += BSZ) {
         h16x8 rx[WB], ry[WB];
 #pragma unroll
@@ -191,13 +191,13 @@ void resblock_pair_f16_kernel(ResPairK a) {
         MB_PMARK(1, it, 1);
         if (it + 1 < my_tiles) load_batch(it + 1, 0);
         MB_PMARK(1, it, 2);
-        if (it > 0) write_out(it - 1, YS ? 1 : 0);
+        if (it > 0) write_out(it - 1, 0, YS ? 3 : 8, 8);  // with its own y tile: 3/8 now, the rest during phase 2
         MB_PMARK(1, it, 3);
         if (!YS) __syncthreads();  // W: hs is free for h of this tile
         __syncthreads();  // E1: phase 1 has finished reading xs
         MB_PMARK(1, it, 4);
         if (it + 1 < my_tiles) store_batch(it + 1, 0);
-        if (YS && it > 0) write_out(it - 1, 2);
+        if (YS && it > 0) write_out(it - 1, 3, 8, 8);
         MB_PMARK(1, it, 5);
         __syncthreads();  // P (all MMA waves done with h) | YF (ys is free for y of this tile)
         __syncthreads();  // Y: y of this tile is staged
@@ -213,19 +213,19 @@ void resblock_pair_f16_kernel(ResPairK a) {
           if (c == 0) MB_PMARK(1, it, 1);
           if (q + a.nbuf - 1 < njobs) fill(q + a.nbuf - 1);
           if (c == 0) MB_PMARK(1, it, 2);
-          if (!YS && c == 0 && it > 0) write_out(it - 1, 0);
+          if (!YS && it > 0) write_out(it - 1, c, c + 1, NCH);  // spread over the chunks: no B barrier waits long
           if (c == 0) MB_PMARK(1, it, 3);
         }
         if (!YS) __syncthreads();  // W
         __syncthreads();  // E1
         MB_PMARK(1, it, 4);
-        if (YS && it > 0) write_out(it - 1, 0);
+        if (YS && it > 0) write_out(it - 1, 0, 1, 1);
         __syncthreads();  // P | YF
         __syncthreads();  // Y
         MB_PMARK(1, it, 6);
       }
     }
-    if (my_tiles > 0) write_out(my_tiles - 1, 0);
+    if (my_tiles > 0) write_out(my_tiles - 1, 0, 1, 1);
     return;
   }
 
@@ -556,7 +556,7 @@ extern "C" int mb_resblock_pair_f16(const mb_resblock_pair_f16_args* a, mb_strea
   bool prefer_b = false;
   switch (a->channels) {
     case 256: MB_PICK2(256, 1, 3, 2, false, 4, 1, false);
-    case 128: MB_PICK2(128, 2, 2, 2, false, 3, 1, false);
+    case 128: MB_PICK2(128, 2, 2, 2, false, 3, 2, false);
     case 64:
       // N1 = 256 with its own y tile (support waves overlap the whole tile) vs N1 = 512 sharing the h tile;
       // MBHIP_PAIR_C64=big selects the latter
