@@ -130,3 +130,25 @@ def test_facade_signature_and_errors(cuda, lib, tmp_path):
     outs, _ = inf.infer_waveform_batch([mel, mel[:, :5], mel])
     assert outs[0].shape == (1800,) and outs[1].shape == (1000,)
     assert np.allclose(outs[0], wav, atol=1e-6) and np.array_equal(outs[0], outs[2])
+
+
+def test_fregan_f16_config4_share_properties(cuda, lib):
+    """BASELINE configs[4] per-GPU share: Fre-GAN fp16, batch 8 x mel (80,3000) (64 utterances over 8 GPUs).
+    Size-independent properties at full size: bounded finite output of 8 x 600000 samples, batch items
+    independent (item k alone == item k inside the batch, bit for bit: tiles never straddle utterances), and
+    agreement with the fp32 MFMA path on one full-length item within the fp16 gate."""
+    from mockingbird_amd.vocoder.gan import GanGenerator
+    h = synth.FREGAN_16K
+    st = synth.gan_state(h, "fregan", seed=5)["generator"]
+    g16, g32 = GanGenerator(h, st, 1, dtype="f16"), GanGenerator(h, st, 1, dtype="f32")
+    mel = torch.from_numpy(synth.mel_input(3000, 8, seed=0)).cuda()
+    y16 = g16(mel)
+    y1 = g16(mel[5:6])
+    y32 = g32(mel[5:6])
+    torch.cuda.synchronize()
+    assert y16.shape == (8, 1, 600000)
+    assert float(y16.abs().max()) <= 1.0 and int(torch.isnan(y16).sum()) == 0
+    assert torch.equal(y1[0], y16[5])
+    e = hiputil.relerr(y1, y32)
+    print("fregan f16 vs f32, 3000 frames", e)
+    assert e["rel_rms"] <= F16_REL_TOL, e

@@ -208,3 +208,22 @@ def test_device_finish_short_mel_raises(model):
     dev, w = model
     with pytest.raises(ValueError):  # shorter than the 20-hop fade window (reference: numpy broadcast error)
         dev.finish(torch.zeros(1, 3000).cuda(), False, 0, True, 19 * 256)
+
+
+def test_baseline_config1_full_size_properties(model):
+    """BASELINE configs[1] at full size (mel 80x1000, batched target 8000 / overlap 800 -> 23 folds x 9600
+    steps, production chain): seed -> stream determinism, different seeds differ, samples are class
+    centres in [-1, 1], the float64 waveform is finite with the reference's length rule."""
+    dev, w = model
+    m = torch.from_numpy(synth.wavernn_mel(1000, seed=1) / 4.0).cuda()
+    a = dev.generate_samples(m, True, 8000, 800, seed=11)
+    p = dev.last_plan
+    assert (p.n_folds, p.seq_len) == (23, 9600) and dev.last_loop_launches == 5 * 9600
+    b = dev.generate_samples(m, True, 8000, 800, seed=11)
+    c = dev.generate_samples(m, True, 8000, 800, seed=12)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    k = (a + 1) * 511 / 2
+    assert float(a.min()) >= -1 and float(a.max()) <= 1 and float((k - k.round()).abs().max()) < 1e-3
+    wav = dev.finish(a, True, 800, True, (1000 - 1) * 256)
+    assert wav.dtype == np.float64 and wav.shape == (min(999 * 256, 23 * 8800 + 800),) and np.isfinite(wav).all()
+    assert abs(wav[-1]) == 0.0 and np.abs(wav).max() > 0  # linear fade reaches exactly zero
