@@ -120,8 +120,31 @@ def tacotron():
     print("tacotron.npz", {k: v.shape for k, v in out.items()})
 
 
+def ppg2mel():
+    """models/ppg2mel/rnn_decoder_mol.py Decoder.inference (B = 1) / inference_batched (B > 1) of the REAL
+    module on the synthetic state; the prenet dropout draws from torch's global RNG (seed recorded)."""
+    m = refimport.import_ppg2mel_decoder()
+    hp = synth.PPG2MEL_HP
+    out = {}
+    for name, B, T, wseed, sb, mseed, rseed in synth.PPG2MEL_CASES:
+        d = m.Decoder(enc_dim=hp["enc_dim"], num_mels=hp["num_mels"], frames_per_step=hp["frames_per_step"],
+                      attention_rnn_dim=hp["attention_rnn_dim"], decoder_rnn_dim=hp["decoder_rnn_dim"],
+                      prenet_dims=list(hp["prenet_dims"]), num_mixtures=hp["num_mixtures"],
+                      encoder_down_factor=hp["encoder_down_factor"], num_decoder_rnn_layer=hp["num_decoder_rnn_layer"],
+                      use_stop_tokens=True, concat_context_to_last=hp["concat_context_to_last"])
+        d.load_state_dict(synth.ppg2mel_decoder_state(hp, seed=wseed, stop_bias=sb))
+        d.eval()
+        mem = torch.from_numpy(synth.ppg2mel_memory(B, T, seed=mseed))
+        torch.manual_seed(rseed)
+        with torch.no_grad():
+            mel, al = d.inference(mem) if B == 1 else d.inference_batched(mem)
+        out[name + "_mel"], out[name + "_align"] = mel.numpy(), al.numpy()
+    np.savez_compressed(os.path.join(HERE, "ppg2mel.npz"), torch_version=torch.__version__, **out)
+    print("ppg2mel.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gan", "wavernn", "maximum_path", "tacotron"]
+    which = sys.argv[1:] or ["gan", "wavernn", "maximum_path", "tacotron", "ppg2mel"]
     for w in which:
         if w in globals():
             globals()[w]()

@@ -26,3 +26,16 @@ def setup():
                 __import__(name)
             except Exception:
                 sys.modules[name] = types.ModuleType(name)
+
+
+def import_ppg2mel_decoder():
+    """models/ppg2mel/rnn_decoder_mol.py without running the package __init__ (which imports the whole
+    voice-conversion stack: espnet-style encoders, preprocessing, ...)."""
+    import importlib
+    setup()
+    import models  # noqa: F401
+    if "models.ppg2mel" not in sys.modules:
+        pkg = types.ModuleType("models.ppg2mel")
+        pkg.__path__ = [os.path.join(REF, "models", "ppg2mel")]
+        sys.modules["models.ppg2mel"] = pkg
+    return importlib.import_module("models.ppg2mel.rnn_decoder_mol")

@@ -241,3 +241,65 @@ def decoder_dropout_masks(seed, n_iter, batch, width=256):
     """Bernoulli(0.5) keep masks [n_iter, 2, batch, width] (pre_net.py:23,26 order within an iteration)."""
     g = torch.Generator().manual_seed(seed)
     return torch.empty(n_iter, 2, batch, width).bernoulli_(0.5, generator=g)
+
+
+PPG2MEL_HP = dict(enc_dim=256, num_mels=80, frames_per_step=2, attention_rnn_dim=512, decoder_rnn_dim=512,
+                  prenet_dims=(256, 128), num_mixtures=5, encoder_down_factor=4, num_decoder_rnn_layer=1,
+                  concat_context_to_last=True)
+
+
+def ppg2mel_decoder_state(hp=PPG2MEL_HP, seed=0, stop_bias=-2.0):
+    """state_dict of models/ppg2mel/rnn_decoder_mol.py:Decoder (names and shapes as the reference module
+    registers them) with O(1) activations.  MoL biases as MOLAttention.initialize_bias sets them
+    (sigma 1.0; Delta -0.432 for r = frames_per_step / encoder_down_factor = 0.5)."""
+    rng = np.random.default_rng(seed)
+    E, nm, r = hp["enc_dim"], hp["num_mels"], hp["frames_per_step"]
+    A, D, M = hp["attention_rnn_dim"], hp["decoder_rnn_dim"], hp["num_mixtures"]
+
+    def mat(rows, cols, gain=1.0):
+        return torch.from_numpy((gain * rng.standard_normal((rows, cols)) / np.sqrt(cols)).astype(np.float32))
+
+    def vec(n, scale=0.05):
+        return torch.from_numpy((scale * rng.standard_normal(n)).astype(np.float32))
+
+    sd = {}
+    dims = [nm] + list(hp["prenet_dims"])
+    for name in ("prenet", "prenet_pitch"):  # prenet_pitch is registered but unused at inference
+        for i in range(len(dims) - 1):
+            sd[f"{name}.layers.{i}.linear_layer.weight"] = mat(dims[i + 1], dims[i], 1.4)
+    P = dims[-1]
+    sd["attention_rnn.weight_ih"] = mat(4 * A, P + E); sd["attention_rnn.weight_hh"] = mat(4 * A, A)
+    sd["attention_rnn.bias_ih"] = vec(4 * A); sd["attention_rnn.bias_hh"] = vec(4 * A)
+    sd["attention_layer.query_layer.0.weight"] = mat(256, A); sd["attention_layer.query_layer.0.bias"] = vec(256)
+    sd["attention_layer.query_layer.2.weight"] = mat(3 * M, 256, 0.5)
+    b = vec(3 * M)
+    b[M:2 * M] = 1.0
+    b[2 * M:] = -0.432
+    sd["attention_layer.query_layer.2.bias"] = b
+    for i in range(hp["num_decoder_rnn_layer"]):
+        kin = E + A if i == 0 else D
+        sd[f"decoder_rnn_layers.{i}.weight_ih"] = mat(4 * D, kin); sd[f"decoder_rnn_layers.{i}.weight_hh"] = mat(4 * D, D)
+        sd[f"decoder_rnn_layers.{i}.bias_ih"] = vec(4 * D); sd[f"decoder_rnn_layers.{i}.bias_hh"] = vec(4 * D)
+    kout = D + E if hp["concat_context_to_last"] else D
+    sd["linear_projection.linear_layer.weight"] = mat(nm * r, kout, 2.0); sd["linear_projection.linear_layer.bias"] = vec(nm * r, 0.2)
+    sd["stop_layer.linear_layer.weight"] = mat(1, kout, 2.0)
+    sd["stop_layer.linear_layer.bias"] = torch.tensor([stop_bias], dtype=torch.float32)
+    return sd
+
+
+def ppg2mel_memory(batch, t_enc, seed=0, enc_dim=256):
+    """Decoder memory [B, T_enc, enc_dim] (the reference feeds InstanceNorm'd features: O(1))."""
+    return np.random.default_rng(seed).standard_normal((batch, t_enc, enc_dim)).astype(np.float32)
+
+
+def ppg2mel_dropout_masks(seed, n_steps, batch, dims=(256, 128)):
+    """Bernoulli(0.5) keep masks of the two prenet layers per decoder step, program order (layer 0, layer 1)."""
+    g = torch.Generator().manual_seed(seed)
+    return [torch.empty(batch, d).bernoulli_(0.5, generator=g) for _ in range(n_steps) for d in dims]
+
+
+PPG2MEL_CASES = [  # golden cases: (name, batch, t_enc, weight seed, stop bias, memory seed, torch RNG seed)
+    ("b1_t30_runs_to_max", 1, 30, 3, -2.0, 1, 7),
+    ("b1_t26_stops", 1, 26, 4, 0.0, 2, 8),
+    ("b3_t24_batched", 3, 24, 3, 0.0, 3, 7),
+]

@@ -161,3 +161,47 @@ def test_tacotron_injected_masks_equal_global_rng():
     masks += [torch.empty(2, 256).bernoulli_(0.5) for _ in range(16)]
     b = ot.generate(w, ot.HP, 2, chars, spk, steps=16, style_idx=0, min_stop_token=11, masks=ot.MaskSource(masks))
     assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("case", synth.PPG2MEL_CASES, ids=lambda c: c[0])
+def test_ppg2mel_oracle_vs_golden(case):
+    """oracle/ppg2mel.py against the outputs of the reference's own Decoder module (ppg2mel.npz): same
+    global-RNG dropout stream, bit-exact alignments and mels (B > 1: the reference truncates each item at
+    its first above-threshold step and concatenates, rnn_decoder_mol.py:364-372)."""
+    from oracle import ppg2mel as op
+    name, B, T, wseed, sb, mseed, rseed = case
+    g = np.load(os.path.join(GOLD, "ppg2mel.npz"))
+    w = synth.ppg2mel_decoder_state(synth.PPG2MEL_HP, seed=wseed, stop_bias=sb)
+    mem = torch.from_numpy(synth.ppg2mel_memory(B, T, seed=mseed))
+    torch.set_num_threads(1)
+    torch.manual_seed(rseed)
+    with torch.no_grad():
+        mel, al, stop = op.inference_batched(w, dict(op.HP), mem)
+    assert np.array_equal(al.numpy(), g[name + "_align"])
+    if B == 1:
+        assert np.array_equal(mel.numpy(), g[name + "_mel"])
+        steps = al.shape[1]
+        assert (T * 4 // 2 - 5) <= steps <= T * 4 // 2
+    else:
+        parts = []
+        for b in range(B):
+            idx = int((torch.sigmoid(stop[b]) > 0.5).nonzero()[0])
+            parts.append(mel[b, :idx])
+        assert np.array_equal(torch.cat(parts, 0).unsqueeze(0).numpy(), g[name + "_mel"])
+
+
+def test_ppg2mel_injected_masks_equal_global_rng():
+    """The injected-mask mode (what the GPU parity tests use) reproduces the global-RNG mode when the masks
+    are drawn with the same generator calls in program order."""
+    from oracle import ppg2mel as op
+    w = synth.ppg2mel_decoder_state(synth.PPG2MEL_HP, seed=5, stop_bias=0.0)
+    mem = torch.from_numpy(synth.ppg2mel_memory(2, 12, seed=9))
+    torch.manual_seed(3)
+    with torch.no_grad():
+        mel, al, stop = op.inference_batched(w, dict(op.HP), mem)
+    steps = al.shape[1]
+    torch.manual_seed(3)
+    masks = [torch.empty(2, d).bernoulli_(0.5) for _ in range(steps) for d in (256, 128)]
+    with torch.no_grad():
+        mel2, al2, stop2 = op.inference_batched(w, dict(op.HP), mem, masks=op.MaskSource(masks))
+    assert torch.equal(mel, mel2) and torch.equal(al, al2) and torch.equal(stop, stop2)
