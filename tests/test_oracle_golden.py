@@ -170,7 +170,7 @@ def test_ppg2mel_oracle_vs_golden(case):
     its first above-threshold step and concatenates, rnn_decoder_mol.py:364-372)."""
     from oracle import ppg2mel as op
     name, B, T, wseed, sb, mseed, rseed = case
-    g = np.load(os.path.join(GOLD, "ppg2mel.npz"))
+    g = np.load(os.path.join(G, "ppg2mel.npz"))
     w = synth.ppg2mel_decoder_state(synth.PPG2MEL_HP, seed=wseed, stop_bias=sb)
     mem = torch.from_numpy(synth.ppg2mel_memory(B, T, seed=mseed))
     torch.set_num_threads(1)
