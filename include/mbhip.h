@@ -367,6 +367,38 @@ int mb_taco_encode(const mb_taco* t, const int32_t* d_chars, const float* d_spea
 int mb_maximum_path(int32_t* d_paths, float* d_values, const int32_t* d_t_ys,
                     const int32_t* d_t_xs, int b, int t_t, int t_s, mb_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * 6. ppg2mel voice-conversion decoder: the autoregressive loop of
+ *    Decoder.inference / inference_batched   models/ppg2mel/rnn_decoder_mol.py:267-374
+ *    (DecoderPrenet :10-22, attention LSTMCell + MOLAttention models/ppg2mel/utils/mol_attention.py:67-122,
+ *    decoder LSTMCell stack :200-209, linear_projection + stop_layer :281-288, stop rule :301-305/:349-354).
+ *    Weights (fp32, torch layout), in this order: prenet.layers[i].weight (n_prenet, bias-free);
+ *    attention_rnn weight_ih, weight_hh, bias_ih, bias_hh; attention_layer.query_layer.0 weight, bias;
+ *    query_layer.2 weight, bias; per decoder layer weight_ih, weight_hh, bias_ih, bias_hh;
+ *    linear_projection weight, bias; stop_layer weight, bias.
+ * ---------------------------------------------------------------------- */
+typedef struct mb_ppg2mel_config {
+  int enc_dim, num_mels, frames_per_step, attention_rnn_dim, decoder_rnn_dim;
+  int n_prenet, prenet_dims[4];
+  int num_mixtures, encoder_down_factor, num_decoder_rnn_layer, concat_context_to_last;
+} mb_ppg2mel_config;
+typedef struct mb_ppg2mel mb_ppg2mel;
+int mb_ppg2mel_num_weights(const mb_ppg2mel_config* cfg);
+size_t mb_ppg2mel_weight_numel(const mb_ppg2mel_config* cfg, int index);
+int mb_ppg2mel_create(const mb_ppg2mel_config* cfg, const float* const* h_weights, int n_weights, mb_ppg2mel** out);
+void mb_ppg2mel_destroy(mb_ppg2mel* p);
+size_t mb_ppg2mel_workspace_bytes(const mb_ppg2mel* p, int batch);
+/* d_memory: fp32 [batch][t_enc][enc_dim].  Runs until every utterance's sigmoid(stop) > stop_threshold with at
+ * least min_steps steps done, or max_steps (the reference: max = t_enc*down/r, min = max - 5).
+ * d_dropout: optional prenet keep masks (0/1), layer l at offset sum_{k<l} max_steps*batch*prenet_dims[k],
+ * [max_steps][batch][prenet_dims[l]] inside; NULL -> Philox(seed).  Outputs are per step, untruncated:
+ * d_mel [batch][max_steps][frames_per_step*num_mels], d_align [batch][max_steps][t_enc],
+ * d_stop [batch][max_steps] (logits); *h_n_steps = steps produced. */
+int mb_ppg2mel_decode(const mb_ppg2mel* p, const float* d_memory, int batch, int t_enc, int max_steps,
+                      int min_steps, float stop_threshold, const float* d_dropout, uint64_t seed,
+                      float* d_mel, float* d_align, float* d_stop, int* h_n_steps, void* d_workspace,
+                      size_t workspace_bytes, mb_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,15 @@ class ResPairF16Args(C.Structure):
     ]
 
 
+class Ppg2MelConfig(C.Structure):
+    _fields_ = [
+        ("enc_dim", C.c_int), ("num_mels", C.c_int), ("frames_per_step", C.c_int), ("attention_rnn_dim", C.c_int),
+        ("decoder_rnn_dim", C.c_int), ("n_prenet", C.c_int), ("prenet_dims", C.c_int * 4),
+        ("num_mixtures", C.c_int), ("encoder_down_factor", C.c_int), ("num_decoder_rnn_layer", C.c_int),
+        ("concat_context_to_last", C.c_int),
+    ]
+
+
 MB_F32, MB_F16 = 0, 1
 
 
@@ -150,6 +159,14 @@ SIGNATURES = {
     "mb_wavernn_bench_kernel": (C.c_int, [C.c_void_p, C.POINTER(WaveRNNPlan), C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_float),
                                           C.POINTER(C.c_double), C.c_void_p]),
+    "mb_ppg2mel_num_weights": (C.c_int, [C.POINTER(Ppg2MelConfig)]),
+    "mb_ppg2mel_weight_numel": (C.c_size_t, [C.POINTER(Ppg2MelConfig), C.c_int]),
+    "mb_ppg2mel_create": (C.c_int, [C.POINTER(Ppg2MelConfig), _PP, C.c_int, _PP]),
+    "mb_ppg2mel_destroy": (None, [C.c_void_p]),
+    "mb_ppg2mel_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "mb_ppg2mel_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                    C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p,
+                                    C.c_size_t, C.c_void_p]),
     "mb_taco_num_weights": (C.c_int, [C.POINTER(TacoConfig)]),
     "mb_taco_weight_numel": (C.c_size_t, [C.POINTER(TacoConfig), C.c_int]),
     "mb_taco_create": (C.c_int, [C.POINTER(TacoConfig), _PP, C.c_int, _PP]),

@@ -1,0 +1,398 @@
+// ppg2mel voice-conversion decoder, inference loop.
+//
+// Reference: models/ppg2mel/rnn_decoder_mol.py
+//   Decoder.inference :267-316, Decoder.inference_batched :318-374 (same loop body),
+//   DecoderPrenet :10-22 (bias-free linears, dropout ON at inference), attend :187-198, decode :200-209;
+// models/ppg2mel/utils/mol_attention.py  MOLAttention.forward :67-122 (discretised mixture of logistics).
+//
+// One decoder step = 8 dependent launches on the row-tile recurrent GEMM (rnn_body.h) plus two small
+// kernels:
+//   prenet fc0, fc1 (relu + dropout mask) -> attention LSTMCell [prenet, context, h] -> query layer 0 (relu)
+//   -> mol_attention_kernel (query layer 2, mixture parameters, alpha over T_enc, context = alpha . memory)
+//   -> decoder LSTMCell(s) [att_h, context, h] -> projection (+ stop row) -> ppg_finalize_kernel
+// (frames / stop logits to the outputs, batch-wide stop rule).  The next step's prenet reads the last
+// frame straight out of the projection buffer.  fp32 throughout.
+#include "rnn.h"
+
+namespace mb {
+
+struct MolK {
+  const float* q;        // [B][Q] relu(query_layer.0(att_h))
+  const float* w2;       // [3M][Q]
+  const float* b2;       // [3M]
+  const float* memory;   // [B][T][E]
+  float* mu;             // [B][M] in/out
+  float* context;        // [B][E]
+  float* align_out;      // [B][max_steps][T]
+  const int* skip_flag;
+  int T, E, Q, M, step, max_steps;
+  float eps;
+};
+
+__device__ __forceinline__ float softplusf_(float x) { return x > 20.f ? x : log1pf(expf(x)); }  // F.softplus(beta=1, threshold=20)
+
+// One workgroup per utterance.  dynamic LDS: q[Q] | par[3M] (w, sigma, mu) | af[T+1] | alpha[T]
+__global__ __launch_bounds__(256) void mol_attention_kernel(MolK a) {
+  if (*a.skip_flag) return;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* s_q = sm;
+  float* s_mp = s_q + a.Q;           // [3M] raw mixture parameters, then (w, sigma, mu_cur)
+  float* s_af = s_mp + 3 * a.M + 1;  // [T+1]
+  float* s_al = s_af + a.T + 1;      // [T]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < a.Q; i += 256) s_q[i] = a.q[(size_t)b * a.Q + i];
+  __syncthreads();
+  // mixture_params = query_layer.2(q)   :75  -- one wave-reduction per output
+  for (int o = wave; o < 3 * a.M; o += 4) {
+    float acc = 0.f;
+    for (int k = lane; k < a.Q; k += 64) acc += a.w2[(size_t)o * a.Q + k] * s_q[k];
+    acc = wave_sum(acc);
+    if (lane == 0) s_mp[o] = acc + a.b2[o];
+  }
+  __syncthreads();
+  if (tid == 0) {  // w = softmax(w_hat) + eps; sigma = softplus(sigma_hat) + eps; mu = mu_prev + softplus(Delta_hat)  :92-96
+    float mx = -INFINITY;
+    for (int m = 0; m < a.M; ++m) mx = fmaxf(mx, s_mp[m]);
+    float se = 0.f;
+    for (int m = 0; m < a.M; ++m) se += expf(s_mp[m] - mx);
+    for (int m = 0; m < a.M; ++m) {
+      const float w = expf(s_mp[m] - mx) / se + a.eps;
+      const float sg = softplusf_(s_mp[a.M + m]) + a.eps;
+      const float mu = a.mu[(size_t)b * a.M + m] + softplusf_(s_mp[2 * a.M + m]);
+      a.mu[(size_t)b * a.M + m] = mu;
+      s_mp[m] = w; s_mp[a.M + m] = sg; s_mp[2 * a.M + m] = mu;
+    }
+  }
+  __syncthreads();
+  // alpha_full[j] = sum_m w_m / (1 + sigmoid((mu_m - (j + 0.5)) / sigma_m)),  j = 0..T   :101-107
+  for (int j = tid; j <= a.T; j += 256) {
+    float s = 0.f;
+    const float pos = (float)j + 0.5f;
+    for (int m = 0; m < a.M; ++m) {
+      const float z = (s_mp[2 * a.M + m] - pos) / s_mp[a.M + m];
+      s += s_mp[m] * (1.f / (1.f + 1.f / (1.f + expf(-z))));
+    }
+    s_af[j] = s;
+  }
+  __syncthreads();
+  float* al = a.align_out + ((size_t)b * a.max_steps + a.step) * a.T;
+  for (int t = tid; t < a.T; t += 256) {  // alpha_t = diff; zeros -> eps   :108-109
+    float v = s_af[t + 1] - s_af[t];
+    if (v == 0.f) v = a.eps;
+    s_al[t] = v;
+    al[t] = v;
+  }
+  __syncthreads();
+  // context = alpha . memory   :115
+  const float* mem = a.memory + (size_t)b * a.T * a.E;
+  for (int e = tid; e < a.E; e += 256) {
+    float acc = 0.f;
+    for (int t = 0; t < a.T; ++t) acc += s_al[t] * mem[(size_t)t * a.E + e];
+    a.context[(size_t)b * a.E + e] = acc;
+  }
+}
+
+struct PpgFinK {
+  const float* y;   // [B][ldy]: r*num_mels frame values, then the stop logit
+  float* mel_out;   // [B][max_steps][r*num_mels]
+  float* stop_out;  // [B][max_steps] logits
+  int* done; int* n_steps;
+  int B, ldy, RM, step, max_steps, min_steps;
+  float thr;
+};
+
+// one workgroup: scatter this step's frames / stop logits, batch-wide stop rule (:301-305, :349-354)
+__global__ __launch_bounds__(256) void ppg_finalize_kernel(PpgFinK a) {
+  if (*a.done) return;
+  const int tid = threadIdx.x;
+  __shared__ int s_below;
+  if (tid == 0) s_below = 0;
+  __syncthreads();
+  for (int i = tid; i < a.B * a.RM; i += 256) {
+    const int b = i / a.RM, q = i - b * a.RM;
+    a.mel_out[((size_t)b * a.max_steps + a.step) * a.RM + q] = a.y[(size_t)b * a.ldy + q];
+  }
+  for (int b = tid; b < a.B; b += 256) {
+    const float lg = a.y[(size_t)b * a.ldy + a.RM];
+    a.stop_out[(size_t)b * a.max_steps + a.step] = lg;
+    if (!(1.f / (1.f + expf(-lg)) > a.thr)) atomicAdd(&s_below, 1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    *a.n_steps = a.step + 1;
+    if (s_below == 0 && a.step + 1 >= a.min_steps) *a.done = 1;
+  }
+}
+
+}  // namespace mb
+
+using namespace mb;
+
+struct mb_ppg2mel {
+  mb_ppg2mel_config cfg;
+  std::vector<DevBuf> pre_w;  // prenet layers (row-tile packed)
+  DevBuf zero_bias;           // the prenet linears are bias-free; a zero bias keeps the specialised instance
+  DevBuf att_w, att_bih, att_bhh;
+  DevBuf q0_w, q0_b, q2_w, q2_b;
+  std::vector<DevBuf> dec_w, dec_bih, dec_bhh;
+  DevBuf out_w, out_b;  // projection rows then the stop row
+};
+
+static int ppg_shapes(const mb_ppg2mel_config* c, std::vector<size_t>* numel) {
+  MB_REQUIRE(c, "ppg2mel: null config");
+  MB_REQUIRE(c->n_prenet >= 1 && c->n_prenet <= 4 && c->num_decoder_rnn_layer >= 1 && c->num_decoder_rnn_layer <= 4,
+             "ppg2mel: unsupported layer counts");
+  MB_REQUIRE(c->enc_dim % 16 == 0 && c->attention_rnn_dim % 16 == 0 && c->decoder_rnn_dim % 16 == 0 && c->num_mels % 16 == 0,
+             "ppg2mel: dims must be multiples of 16");
+  for (int i = 0; i < c->n_prenet; ++i) MB_REQUIRE(c->prenet_dims[i] % 16 == 0, "ppg2mel: prenet dims must be multiples of 16");
+  MB_REQUIRE(c->num_mixtures >= 1 && c->num_mixtures <= 16 && c->frames_per_step >= 1, "ppg2mel: bad mixture / frames_per_step");
+  const size_t E = c->enc_dim, A = c->attention_rnn_dim, D = c->decoder_rnn_dim, nm = c->num_mels, r = c->frames_per_step;
+  const size_t Q = 256, M = c->num_mixtures;
+  numel->clear();
+  size_t in = nm;
+  for (int i = 0; i < c->n_prenet; ++i) { numel->push_back((size_t)c->prenet_dims[i] * in); in = c->prenet_dims[i]; }
+  const size_t P = in;
+  numel->push_back(4 * A * (P + E)); numel->push_back(4 * A * A); numel->push_back(4 * A); numel->push_back(4 * A);
+  numel->push_back(Q * A); numel->push_back(Q); numel->push_back(3 * M * Q); numel->push_back(3 * M);
+  for (int i = 0; i < c->num_decoder_rnn_layer; ++i) {
+    const size_t kin = i == 0 ? E + A : D;
+    numel->push_back(4 * D * kin); numel->push_back(4 * D * D); numel->push_back(4 * D); numel->push_back(4 * D);
+  }
+  const size_t kout = c->concat_context_to_last ? D + E : D;
+  numel->push_back(nm * r * kout); numel->push_back(nm * r); numel->push_back(kout); numel->push_back(1);
+  return MB_OK;
+}
+
+extern "C" int mb_ppg2mel_num_weights(const mb_ppg2mel_config* cfg) {
+  std::vector<size_t> n;
+  return ppg_shapes(cfg, &n) ? MB_EINVAL : (int)n.size();
+}
+extern "C" size_t mb_ppg2mel_weight_numel(const mb_ppg2mel_config* cfg, int index) {
+  std::vector<size_t> n;
+  if (ppg_shapes(cfg, &n) || index < 0 || index >= (int)n.size()) return 0;
+  return n[index];
+}
+
+extern "C" void mb_ppg2mel_destroy(mb_ppg2mel* p) {
+  if (!p) return;
+  for (auto& b : p->pre_w) b.release();
+  for (auto& b : p->dec_w) b.release();
+  for (auto& b : p->dec_bih) b.release();
+  for (auto& b : p->dec_bhh) b.release();
+  DevBuf* bs[] = {&p->zero_bias, &p->att_w, &p->att_bih, &p->att_bhh, &p->q0_w, &p->q0_b, &p->q2_w, &p->q2_b, &p->out_w, &p->out_b};
+  for (DevBuf* b : bs) b->release();
+  delete p;
+}
+
+extern "C" int mb_ppg2mel_create(const mb_ppg2mel_config* cfg, const float* const* hw, int n_weights, mb_ppg2mel** out) {
+  MB_REQUIRE(out && hw, "ppg2mel_create: null pointer");
+  std::vector<size_t> shapes;
+  int rc = ppg_shapes(cfg, &shapes);
+  if (rc) return rc;
+  MB_REQUIRE(n_weights == (int)shapes.size(), "ppg2mel_create: expected %d weight tensors, got %d", (int)shapes.size(), n_weights);
+  mb_ppg2mel* p = new mb_ppg2mel();
+  p->cfg = *cfg;
+  const int E = cfg->enc_dim, A = cfg->attention_rnn_dim, D = cfg->decoder_rnn_dim, nm = cfg->num_mels, r = cfg->frames_per_step;
+  const int Q = 256, M = cfg->num_mixtures;
+  std::vector<float> rows, packed;
+  int ix = 0;
+#define RC(x) do { if (!rc) rc = (x); } while (0)
+  p->pre_w.resize(cfg->n_prenet);
+  int in = nm, maxp = 0;
+  for (int i = 0; i < cfg->n_prenet; ++i) {
+    pack_rowtile(hw[ix++], cfg->prenet_dims[i], in, 4, &packed);
+    RC(p->pre_w[i].upload(packed.data(), packed.size()));
+    in = cfg->prenet_dims[i];
+    maxp = std::max(maxp, in);
+  }
+  const int P = in;
+  {
+    std::vector<float> z(maxp, 0.f);
+    RC(p->zero_bias.upload(z.data(), z.size()));
+  }
+  // attention_rnn = LSTMCell(P + E, A): input order [prenet, context] (attend :188)
+  cell_rows(hw[ix], P + E, P + E, hw[ix + 1], A, A, 4, &rows);
+  pack_rowtile(rows.data(), 4 * A, P + E + A, 4, &packed);
+  RC(p->att_w.upload(packed.data(), packed.size())); RC(p->att_bih.upload(hw[ix + 2], 4 * A)); RC(p->att_bhh.upload(hw[ix + 3], 4 * A));
+  ix += 4;
+  pack_rowtile(hw[ix], Q, A, 4, &packed); RC(p->q0_w.upload(packed.data(), packed.size())); RC(p->q0_b.upload(hw[ix + 1], Q));
+  RC(p->q2_w.upload(hw[ix + 2], (size_t)3 * M * Q)); RC(p->q2_b.upload(hw[ix + 3], 3 * M));
+  ix += 4;
+  p->dec_w.resize(cfg->num_decoder_rnn_layer); p->dec_bih.resize(cfg->num_decoder_rnn_layer); p->dec_bhh.resize(cfg->num_decoder_rnn_layer);
+  for (int i = 0; i < cfg->num_decoder_rnn_layer; ++i) {
+    const int kin = i == 0 ? A + E : D;  // layer 0 input order [attention_hidden, context] (attend :194-195)
+    cell_rows(hw[ix], kin, kin, hw[ix + 1], D, D, 4, &rows);
+    pack_rowtile(rows.data(), 4 * D, kin + D, 4, &packed);
+    RC(p->dec_w[i].upload(packed.data(), packed.size())); RC(p->dec_bih[i].upload(hw[ix + 2], 4 * D)); RC(p->dec_bhh[i].upload(hw[ix + 3], 4 * D));
+    ix += 4;
+  }
+  {  // linear_projection rows then the stop_layer row: one launch produces both (:287-288)
+    const int kout = cfg->concat_context_to_last ? D + E : D;
+    std::vector<float> w((size_t)(nm * r + 1) * kout), b(nm * r + 1);
+    memcpy(w.data(), hw[ix], sizeof(float) * (size_t)nm * r * kout);
+    memcpy(b.data(), hw[ix + 1], sizeof(float) * nm * r);
+    memcpy(w.data() + (size_t)nm * r * kout, hw[ix + 2], sizeof(float) * kout);
+    b[nm * r] = hw[ix + 3][0];
+    pack_rowtile(w.data(), nm * r + 1, kout, 4, &packed);
+    RC(p->out_w.upload(packed.data(), packed.size())); RC(p->out_b.upload(b.data(), b.size()));
+    ix += 4;
+  }
+#undef RC
+  if (rc) { mb_ppg2mel_destroy(p); return rc; }
+  *out = p;
+  return MB_OK;
+}
+
+namespace {
+struct PpgLayout {
+  float *pbuf[4], *att_h, *att_c, *ctx, *q, *mu, *dec_h[4], *dec_c[4], *y, *zero;
+  int* flags;
+  size_t bytes;
+  int ldy;
+};
+void ppg_layout(const mb_ppg2mel* p, int B, void* base, PpgLayout* L) {
+  const mb_ppg2mel_config& c = p->cfg;
+  Arena ar(base, (size_t)-1);
+  for (int i = 0; i < c.n_prenet; ++i) L->pbuf[i] = ar.take<float>((size_t)B * c.prenet_dims[i]);
+  L->att_h = ar.take<float>((size_t)2 * B * c.attention_rnn_dim); L->att_c = ar.take<float>((size_t)2 * B * c.attention_rnn_dim);
+  L->ctx = ar.take<float>((size_t)B * c.enc_dim);
+  L->q = ar.take<float>((size_t)B * 256);
+  L->mu = ar.take<float>((size_t)B * c.num_mixtures);
+  for (int i = 0; i < c.num_decoder_rnn_layer; ++i) {
+    L->dec_h[i] = ar.take<float>((size_t)2 * B * c.decoder_rnn_dim); L->dec_c[i] = ar.take<float>((size_t)2 * B * c.decoder_rnn_dim);
+  }
+  L->ldy = (c.num_mels * c.frames_per_step + 1 + 3) & ~3;  // rows of 16-byte multiples: the next prenet reads frames in place
+  L->y = ar.take<float>((size_t)B * L->ldy);
+  L->zero = ar.take<float>((size_t)B * L->ldy);
+  L->flags = ar.take<int>(8);
+  L->bytes = ar.off + 256;
+}
+}  // namespace
+
+extern "C" size_t mb_ppg2mel_workspace_bytes(const mb_ppg2mel* p, int batch) {
+  if (!p || batch <= 0) return 0;
+  PpgLayout L;
+  ppg_layout(p, batch, nullptr, &L);
+  return L.bytes;
+}
+
+extern "C" int mb_ppg2mel_decode(const mb_ppg2mel* p, const float* d_memory, int batch, int t_enc, int max_steps,
+                                 int min_steps, float stop_threshold, const float* d_dropout, uint64_t seed,
+                                 float* d_mel, float* d_align, float* d_stop, int* h_n_steps, void* d_workspace,
+                                 size_t workspace_bytes, mb_stream_t stream) {
+  MB_REQUIRE(p && d_memory && d_mel && d_align && d_stop && h_n_steps, "ppg2mel_decode: null pointer");
+  MB_REQUIRE(batch > 0 && t_enc > 0 && max_steps > 0, "ppg2mel_decode: empty input");
+  MB_REQUIRE(batch <= 256, "ppg2mel_decode: batch %d > 256", batch);
+  PpgLayout L;
+  ppg_layout(p, batch, d_workspace, &L);
+  if (!d_workspace || workspace_bytes < L.bytes) {
+    set_error("ppg2mel_decode: workspace %zu B < required %zu B", workspace_bytes, L.bytes);
+    return MB_ENOMEM;
+  }
+  const mb_ppg2mel_config& c = p->cfg;
+  const int B = batch, T = t_enc, E = c.enc_dim, A = c.attention_rnn_dim, D = c.decoder_rnn_dim, nm = c.num_mels, r = c.frames_per_step;
+  const int RM = nm * r, Q = 256, M = c.num_mixtures, NL = c.num_decoder_rnn_layer;
+  const int P = c.prenet_dims[c.n_prenet - 1];
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds_mol = sizeof(float) * ((size_t)Q + 3 * M + 1 + (T + 1) + T + 8);
+  MB_REQUIRE(lds_mol <= 64 * 1024, "ppg2mel_decode: memory too long for the attention window in LDS (T=%d)", T);
+  // zero initial states (initialize_decoder_states :118-148, init_states :58-66, go frame :111-115)
+  MB_HIP(hipMemsetAsync(L.att_h, 0, sizeof(float) * 2 * B * A, s)); MB_HIP(hipMemsetAsync(L.att_c, 0, sizeof(float) * 2 * B * A, s));
+  for (int i = 0; i < NL; ++i) {
+    MB_HIP(hipMemsetAsync(L.dec_h[i], 0, sizeof(float) * 2 * B * D, s)); MB_HIP(hipMemsetAsync(L.dec_c[i], 0, sizeof(float) * 2 * B * D, s));
+  }
+  MB_HIP(hipMemsetAsync(L.ctx, 0, sizeof(float) * B * E, s));
+  MB_HIP(hipMemsetAsync(L.mu, 0, sizeof(float) * B * M, s));
+  MB_HIP(hipMemsetAsync(L.zero, 0, sizeof(float) * B * L.ldy, s));
+  MB_HIP(hipMemsetAsync(L.flags, 0, sizeof(int) * 8, s));
+  MB_HIP(hipMemsetAsync(d_mel, 0, sizeof(float) * (size_t)B * max_steps * RM, s));
+  MB_HIP(hipMemsetAsync(d_align, 0, sizeof(float) * (size_t)B * max_steps * T, s));
+  MB_HIP(hipMemsetAsync(d_stop, 0, sizeof(float) * (size_t)B * max_steps, s));
+  int* done = L.flags;
+  int* n_steps = L.flags + 1;
+  // dropout masks: layer l at d_dropout + sum_{k<l} max_steps*B*dims[k], step-major inside
+  size_t mask_base[4] = {0, 0, 0, 0};
+  for (int i = 1; i < c.n_prenet; ++i) mask_base[i] = mask_base[i - 1] + (size_t)max_steps * B * c.prenet_dims[i - 1];
+
+  int steps = 0;
+  for (int st = 0; st < max_steps; ++st) {
+    const int pp = st & 1;
+    float* ah_p = L.att_h + (size_t)pp * B * A; float* ah_n = L.att_h + (size_t)(pp ^ 1) * B * A;
+    float* ac_p = L.att_c + (size_t)pp * B * A; float* ac_n = L.att_c + (size_t)(pp ^ 1) * B * A;
+    RnnK k;
+    int rc;
+    // decoder_input = prenet(last frame of the previous step | go frame)   :283, :307
+    const float* xin = st == 0 ? L.zero : L.y + (size_t)(r - 1) * nm;
+    int kin = nm;
+    for (int i = 0; i < c.n_prenet; ++i) {
+      memset(&k, 0, sizeof(k));
+      k.w = p->pre_w[i].p; k.nseg = 1; k.nkb_total = kin / 16;
+      k.seg[0] = {i == 0 ? xin : L.pbuf[i - 1], i == 0 ? L.ldy : c.prenet_dims[i - 1], kin / 16, 0};
+      k.N = B; k.units = c.prenet_dims[i]; k.biasX = p->zero_bias.p; k.y = L.pbuf[i]; k.ldy = c.prenet_dims[i]; k.act = 1;
+      k.mask_scale = 2.f;
+      k.mask = d_dropout ? d_dropout + mask_base[i] + (size_t)st * B * c.prenet_dims[i] : nullptr;
+      k.drop_on = d_dropout ? 0 : 1; k.drop_seed = seed; k.drop_iter = st; k.drop_layer = i; k.skip_flag = done;
+      if ((rc = rnn_launch(EPI_LINEAR, k, s))) return rc;
+      kin = c.prenet_dims[i];
+    }
+    // attention_hidden, attention_cell = attention_rnn([decoder_input, attention_context], ...)   :188-190
+    memset(&k, 0, sizeof(k));
+    k.w = p->att_w.p; k.nseg = 3; k.nkb_total = (P + E + A) / 16;
+    k.seg[0] = {L.pbuf[c.n_prenet - 1], P, P / 16, 0}; k.seg[1] = {L.ctx, E, E / 16, 0}; k.seg[2] = {ah_p, A, A / 16, 1};
+    k.N = B; k.units = A; k.biasX = p->att_bih.p; k.biasH = p->att_bhh.p; k.c_prev = ac_p; k.h_out = ah_n; k.c_out = ac_n; k.skip_flag = done;
+    if ((rc = rnn_launch(EPI_LSTM, k, s))) return rc;
+    // MOLAttention: q = relu(query_layer.0(att_h)), then the attention kernel   mol_attention.py:75-122
+    memset(&k, 0, sizeof(k));
+    k.w = p->q0_w.p; k.nseg = 1; k.nkb_total = A / 16; k.seg[0] = {ah_n, A, A / 16, 0};
+    k.N = B; k.units = Q; k.biasX = p->q0_b.p; k.y = L.q; k.ldy = Q; k.act = 1; k.skip_flag = done;
+    if ((rc = rnn_launch(EPI_LINEAR, k, s))) return rc;
+    MolK mk;
+    mk.q = L.q; mk.w2 = p->q2_w.p; mk.b2 = p->q2_b.p; mk.memory = d_memory; mk.mu = L.mu; mk.context = L.ctx;
+    mk.align_out = d_align; mk.skip_flag = done; mk.T = T; mk.E = E; mk.Q = Q; mk.M = M; mk.step = st; mk.max_steps = max_steps;
+    mk.eps = 1e-5f;
+    hipLaunchKernelGGL(mol_attention_kernel, dim3(B), dim3(256), lds_mol, s, mk);
+    MB_HIP(hipGetLastError());
+    // decoder LSTM stack   :200-209
+    const float* dprev = nullptr;
+    for (int i = 0; i < NL; ++i) {
+      float* hp_ = L.dec_h[i] + (size_t)pp * B * D; float* hn_ = L.dec_h[i] + (size_t)(pp ^ 1) * B * D;
+      float* cp_ = L.dec_c[i] + (size_t)pp * B * D; float* cn_ = L.dec_c[i] + (size_t)(pp ^ 1) * B * D;
+      memset(&k, 0, sizeof(k));
+      k.w = p->dec_w[i].p;
+      if (i == 0) {
+        k.nseg = 3; k.nkb_total = (A + E + D) / 16;
+        k.seg[0] = {ah_n, A, A / 16, 0}; k.seg[1] = {L.ctx, E, E / 16, 0}; k.seg[2] = {hp_, D, D / 16, 1};
+      } else {
+        k.nseg = 2; k.nkb_total = 2 * D / 16;
+        k.seg[0] = {dprev, D, D / 16, 0}; k.seg[1] = {hp_, D, D / 16, 1};
+      }
+      k.N = B; k.units = D; k.biasX = p->dec_bih[i].p; k.biasH = p->dec_bhh[i].p; k.c_prev = cp_; k.h_out = hn_; k.c_out = cn_; k.skip_flag = done;
+      if ((rc = rnn_launch(EPI_LSTM, k, s))) return rc;
+      dprev = hn_;
+    }
+    // mel_output = linear_projection([h, context]); stop_output = stop_layer(...)   :281-288
+    memset(&k, 0, sizeof(k));
+    k.w = p->out_w.p;
+    if (c.concat_context_to_last) {
+      k.nseg = 2; k.nkb_total = (D + E) / 16; k.seg[0] = {dprev, D, D / 16, 0}; k.seg[1] = {L.ctx, E, E / 16, 0};
+    } else {
+      k.nseg = 1; k.nkb_total = D / 16; k.seg[0] = {dprev, D, D / 16, 0};
+    }
+    k.N = B; k.units = RM + 1; k.biasX = p->out_b.p; k.y = L.y; k.ldy = L.ldy; k.skip_flag = done;
+    if ((rc = rnn_launch(EPI_LINEAR, k, s))) return rc;
+    PpgFinK fk;
+    fk.y = L.y; fk.mel_out = d_mel; fk.stop_out = d_stop; fk.done = done; fk.n_steps = n_steps;
+    fk.B = B; fk.ldy = L.ldy; fk.RM = RM; fk.step = st; fk.max_steps = max_steps; fk.min_steps = min_steps; fk.thr = stop_threshold;
+    hipLaunchKernelGGL(ppg_finalize_kernel, dim3(1), dim3(256), 0, s, fk);
+    MB_HIP(hipGetLastError());
+    if ((st & 15) == 15 || st == max_steps - 1) {  // poll the stop flag (skipped launches in between are no-ops)
+      int hf[2] = {0, 0};
+      MB_HIP(hipMemcpyAsync(hf, L.flags, sizeof(hf), hipMemcpyDeviceToHost, s));
+      MB_HIP(hipStreamSynchronize(s));
+      steps = hf[1];
+      if (hf[0]) break;
+    }
+  }
+  *h_n_steps = steps;
+  return MB_OK;
+}

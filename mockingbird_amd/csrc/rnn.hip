@@ -156,6 +156,11 @@ void cell_rows(const float* w_ih, int kx, int ldx, const float* w_hh, int kh, in
   X(EPI_LSTM, 2, 4, RF_BIASX | RF_HPRE | RF_XRES | RF_XOUT | RF_SKIP)                                     \
   X(EPI_LSTM, 1, 8, RF_BIASX | RF_HPRE | RF_XRES | RF_XOUT | RF_SKIP)                                     \
   X(EPI_LINEAR, 1, 8, RF_SKIP)                                                                            \
+  /* ppg2mel decoder: attention / decoder LSTMCells (no residual), projection + stop rows, query layer */ \
+  X(EPI_LSTM, 1, 4, RF_BIASX | RF_BIASH | RF_SKIP | RF_MULTISEG)                                          \
+  X(EPI_LSTM, 1, 8, RF_BIASX | RF_BIASH | RF_SKIP | RF_MULTISEG)                                          \
+  X(EPI_LINEAR, 1, 4, RF_BIASX | RF_SKIP | RF_MULTISEG)                                                   \
+  X(EPI_LINEAR, 1, 4, RF_BIASX | RF_SKIP | ACT(1))                                                        \
   /* CBHG bidirectional GRU scan */                                                                       \
   X(EPI_GRU, 1, 2, RF_PRE | RF_BIASH | RF_SEQ)
 

@@ -1,0 +1,133 @@
+"""ppg2mel voice-conversion decoder: the autoregressive loop of
+models/ppg2mel/rnn_decoder_mol.py:Decoder.inference / inference_batched on HIP kernels
+(csrc/ppg2mel.hip, mb_ppg2mel_*).  `Ppg2MelDecoder` mirrors the reference Decoder's inference-time
+surface: `inference(memory, stop_threshold=0.5)` and `inference_batched(memory, stop_threshold=0.5)` with
+the reference's return values; it is built from the `decoder.*` entries of a MelDecoderMOLv2 checkpoint.
+The convolutional front end (bnf_prenet, pitch_convs), the speaker projection and the CNN postnet of
+MelDecoderMOLv2 (models/ppg2mel/__init__.py:50-118,166-192) are one-shot and stay with the caller.
+There is no CPU path."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+DEFAULT_HP = dict(enc_dim=256, num_mels=80, frames_per_step=2, attention_rnn_dim=512, decoder_rnn_dim=512,
+                  prenet_dims=(256, 128), num_mixtures=5, encoder_down_factor=4, num_decoder_rnn_layer=1,
+                  concat_context_to_last=True)
+
+
+def weight_list(state, hp):
+    """state_dict of the reference Decoder module -> tensors in the ABI order (include/mbhip.h section 6)."""
+    names = [f"prenet.layers.{i}.linear_layer.weight" for i in range(len(hp["prenet_dims"]))]
+    names += ["attention_rnn.weight_ih", "attention_rnn.weight_hh", "attention_rnn.bias_ih", "attention_rnn.bias_hh",
+              "attention_layer.query_layer.0.weight", "attention_layer.query_layer.0.bias",
+              "attention_layer.query_layer.2.weight", "attention_layer.query_layer.2.bias"]
+    for i in range(hp["num_decoder_rnn_layer"]):
+        names += [f"decoder_rnn_layers.{i}.{n}" for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    names += ["linear_projection.linear_layer.weight", "linear_projection.linear_layer.bias",
+              "stop_layer.linear_layer.weight", "stop_layer.linear_layer.bias"]
+    return [state[n].detach().to(torch.float32).contiguous().cpu() for n in names]
+
+
+class Ppg2MelDecoder:
+    def __init__(self, state_dict, hp=None):
+        if not torch.cuda.is_available():
+            raise _lib.MbHipError("ppg2mel decoder: no MI355X visible; this build has no CPU path")
+        self.hp = dict(DEFAULT_HP if hp is None else hp)
+        h = self.hp
+        cfg = _lib.Ppg2MelConfig()
+        cfg.enc_dim, cfg.num_mels, cfg.frames_per_step = h["enc_dim"], h["num_mels"], h["frames_per_step"]
+        cfg.attention_rnn_dim, cfg.decoder_rnn_dim = h["attention_rnn_dim"], h["decoder_rnn_dim"]
+        cfg.n_prenet = len(h["prenet_dims"])
+        for i, d in enumerate(h["prenet_dims"]):
+            cfg.prenet_dims[i] = d
+        cfg.num_mixtures, cfg.encoder_down_factor = h["num_mixtures"], h["encoder_down_factor"]
+        cfg.num_decoder_rnn_layer, cfg.concat_context_to_last = h["num_decoder_rnn_layer"], int(h["concat_context_to_last"])
+        self.cfg = cfg
+        L = _lib.lib()
+        ws = weight_list(state_dict, h)
+        n = L.mb_ppg2mel_num_weights(C.byref(cfg))
+        if n != len(ws):
+            raise _lib.MbHipError(f"ppg2mel: ABI expects {n} weight tensors, checkpoint mapping gives {len(ws)}")
+        for i, w in enumerate(ws):
+            want = L.mb_ppg2mel_weight_numel(C.byref(cfg), i)
+            if w.numel() != want:
+                raise _lib.MbHipError(f"ppg2mel weight {i}: {tuple(w.shape)} has {w.numel()} elements, expected {want}")
+        arr = _lib.host_ptr_array(ws)
+        hnd = C.c_void_p()
+        _lib.check(L.mb_ppg2mel_create(C.byref(cfg), arr, len(ws), C.byref(hnd)), "mb_ppg2mel_create")
+        self._h = hnd
+        self._ws = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _lib.lib().mb_ppg2mel_destroy(h)
+            except Exception:  # interpreter shutdown
+                pass
+            self._h = None
+
+    def decode(self, memory, stop_threshold=0.5, dropout=None, seed=0, max_steps=None):
+        """Raw loop: memory [B, T_enc, enc_dim] (CUDA) -> (mel [B, steps, r*num_mels], alignments [B, steps, T_enc],
+        stop logits [B, steps]), untruncated.  dropout: optional list of keep masks in program order
+        (step-major, prenet layer inside) as produced for the oracle."""
+        if not memory.is_cuda:
+            raise _lib.MbHipError("ppg2mel decoder needs a CUDA(HIP) tensor; there is no CPU path")
+        memory = memory.to(torch.float32).contiguous()
+        B, T, E = memory.shape
+        h = self.hp
+        if E != h["enc_dim"]:
+            raise _lib.MbHipError(f"memory has enc_dim {E}, model expects {h['enc_dim']}")
+        r, nm = h["frames_per_step"], h["num_mels"]
+        lim = T * h["encoder_down_factor"] // r  # rnn_decoder_mol.py:281-282
+        max_step = lim if max_steps is None else max_steps
+        min_step = lim - 5
+        dev = memory.device
+        L = _lib.lib()
+        need = L.mb_ppg2mel_workspace_bytes(self._h, B)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        mel = torch.empty(B, max_step, r * nm, device=dev)
+        align = torch.empty(B, max_step, T, device=dev)
+        stop = torch.empty(B, max_step, device=dev)
+        dmask = None
+        if dropout is not None:
+            dims = list(h["prenet_dims"])
+            n_steps = len(dropout) // len(dims)
+            if n_steps < max_step:
+                raise _lib.MbHipError(f"dropout masks cover {n_steps} steps, need {max_step}")
+            per_layer = [torch.stack([dropout[s * len(dims) + l] for s in range(max_step)]) for l in range(len(dims))]
+            dmask = torch.cat([p.reshape(-1) for p in per_layer]).to(dev, torch.float32).contiguous()
+        n = C.c_int(0)
+        _lib.check(L.mb_ppg2mel_decode(self._h, _lib.ptr(memory), B, T, max_step, min_step, float(stop_threshold),
+                                       _lib.ptr(dmask), int(seed), _lib.ptr(mel), _lib.ptr(align), _lib.ptr(stop),
+                                       C.byref(n), _lib.ptr(self._ws), self._ws.numel(), _lib.stream_ptr()),
+                   "mb_ppg2mel_decode")
+        s = n.value
+        return mel[:, :s], align[:, :s], stop[:, :s]
+
+    def inference(self, memory, stop_threshold=0.5, dropout=None, seed=0):
+        """Decoder.inference (rnn_decoder_mol.py:267-316): memory [1, T_enc, enc_dim] ->
+        (mel_outputs [1, steps*r, num_mels], alignments [1, steps, T_enc])."""
+        if memory.shape[0] != 1:
+            raise _lib.MbHipError("Decoder.inference takes one utterance; use inference_batched")
+        mel, al, _ = self.decode(memory, stop_threshold, dropout, seed)
+        return mel.reshape(1, -1, self.hp["num_mels"]), al
+
+    def inference_batched(self, memory, stop_threshold=0.5, dropout=None, seed=0):
+        """Decoder.inference_batched (rnn_decoder_mol.py:318-374): every utterance is cut at its first step whose
+        sigmoid(stop) exceeds the threshold and the pieces are concatenated -> (mel [1, sum, num_mels],
+        alignments [B, steps, T_enc]).  Like the reference this raises IndexError for an utterance that never
+        crosses the threshold."""
+        mel, al, stop = self.decode(memory, stop_threshold, dropout, seed)
+        B = mel.shape[0]
+        melf = mel.reshape(B, -1, self.hp["num_mels"])
+        parts = []
+        sg = torch.sigmoid(stop).cpu()
+        for b in range(B):
+            idx = np.argwhere(sg[b] > stop_threshold)[0][0].item()
+            parts.append(melf[b, :idx, :])
+        return torch.cat(parts, dim=0).unsqueeze(0), al

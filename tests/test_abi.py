@@ -41,16 +41,16 @@ def test_struct_layouts_match_header_sizes(lib, tmp_path):
     """ctypes mirrors of the ABI structs have the same size as the C structs."""
     from mockingbird_amd import _lib
     src = tmp_path / "sz.c"
-    src.write_text('#include "mbhip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include "mbhip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(mb_conv1d_args),sizeof(mb_gan_config),sizeof(mb_wavernn_config),'
                    'sizeof(mb_wavernn_plan),sizeof(mb_taco_config),sizeof(mb_conv1d_f16_args),'
-                   'sizeof(mb_resblock_pair_f16_args));return 0;}\n')
+                   'sizeof(mb_resblock_pair_f16_args),sizeof(mb_ppg2mel_config));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", f"-I{ROOT / 'include'}", str(src), "-o", str(exe)])
     sizes = list(map(int, subprocess.check_output([str(exe)], text=True).split()))
     mine = [C.sizeof(_lib.ConvArgs), C.sizeof(_lib.GanConfig), C.sizeof(_lib.WaveRNNConfig),
             C.sizeof(_lib.WaveRNNPlan), C.sizeof(_lib.TacoConfig), C.sizeof(_lib.ConvF16Args),
-            C.sizeof(_lib.ResPairF16Args)]
+            C.sizeof(_lib.ResPairF16Args), C.sizeof(_lib.Ppg2MelConfig)]
     assert sizes == mine
 
 

@@ -1,0 +1,82 @@
+"""Parity of the ppg2mel decoder loop (mb_ppg2mel_decode: prenet, attention LSTMCell, MoL attention, decoder
+LSTMCell, projection + stop, stop rule) against the oracle restatement of
+models/ppg2mel/rnn_decoder_mol.py:267-374 (pinned bit-exactly to the reference module by
+tests/golden/ppg2mel.npz), with the prenet dropout masks injected on both sides.
+Gates: mel max|delta| <= 1e-3 (north_star's mel gate), alignments <= 1e-4, same number of steps."""
+import numpy as np
+import pytest
+import torch
+
+import hiputil
+import synth
+from oracle import ppg2mel as op
+
+pytestmark = pytest.mark.gpu
+MEL_TOL, ALIGN_TOL = 1e-3, 1e-4
+
+
+def _run(B, T, wseed, sb, mseed, dseed):
+    from mockingbird_amd.ppg2mel import Ppg2MelDecoder
+    w = synth.ppg2mel_decoder_state(synth.PPG2MEL_HP, seed=wseed, stop_bias=sb)
+    dec = Ppg2MelDecoder(w, synth.PPG2MEL_HP)
+    mem = torch.from_numpy(synth.ppg2mel_memory(B, T, seed=mseed))
+    max_step = T * 4 // 2
+    masks = synth.ppg2mel_dropout_masks(dseed, max_step, B)
+    with torch.no_grad():
+        omel, oal, ostop = op.inference_batched(w, dict(op.HP), mem, masks=op.MaskSource(list(masks)))
+    mel, al, stop = dec.decode(mem.cuda(), dropout=masks)
+    return dec, mem, (mel.cpu(), al.cpu(), stop.cpu()), (omel, oal, ostop)
+
+
+@pytest.mark.parametrize("B,T,wseed,sb,mseed", [(1, 30, 3, -2.0, 1), (1, 26, 4, 0.0, 2), (3, 24, 3, 0.0, 3), (17, 40, 5, 0.0, 4)])
+def test_decode_matches_oracle(cuda, lib, B, T, wseed, sb, mseed):
+    dec, mem, (mel, al, stop), (omel, oal, ostop) = _run(B, T, wseed, sb, mseed, dseed=11)
+    steps = oal.shape[1]
+    assert al.shape == oal.shape and stop.shape == ostop.shape, (al.shape, oal.shape)
+    assert T * 2 - 5 <= steps <= T * 2
+    e = hiputil.relerr(mel.reshape(B, -1, 80), omel)
+    assert e["nan"] == 0 and e["max_abs"] <= MEL_TOL, e
+    assert float((al - oal).abs().max()) <= ALIGN_TOL
+    assert float((stop - ostop).abs().max()) <= 1e-2
+    assert float(omel.abs().mean()) > 0.05  # O(1) fixture: the tolerance is not vacuous
+    assert torch.allclose(oal.sum(2), al.sum(2), atol=1e-4)
+
+
+def test_reference_surface_and_golden(cuda, lib):
+    """inference / inference_batched return what the reference returns (shapes, per-item truncation,
+    concatenation) -- checked against the golden outputs of the reference module itself.  The golden was
+    produced with the reference's global-RNG dropout, so the masks are re-drawn with the same generator
+    calls (F.dropout(x, .5, True) == x * bernoulli_(.5) * 2 for the same draws)."""
+    import os
+    from mockingbird_amd.ppg2mel import Ppg2MelDecoder
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ppg2mel.npz"))
+    for name, B, T, wseed, sb, mseed, rseed in synth.PPG2MEL_CASES:
+        w = synth.ppg2mel_decoder_state(synth.PPG2MEL_HP, seed=wseed, stop_bias=sb)
+        dec = Ppg2MelDecoder(w, synth.PPG2MEL_HP)
+        mem = torch.from_numpy(synth.ppg2mel_memory(B, T, seed=mseed))
+        torch.manual_seed(rseed)
+        masks = [torch.empty(B, d).bernoulli_(0.5) for _ in range(T * 2) for d in (256, 128)]
+        if B == 1:
+            mel, al = dec.inference(mem.cuda(), dropout=masks)
+        else:
+            mel, al = dec.inference_batched(mem.cuda(), dropout=masks)
+        assert tuple(mel.shape) == g[name + "_mel"].shape and tuple(al.shape) == g[name + "_align"].shape
+        assert float(np.abs(mel.cpu().numpy() - g[name + "_mel"]).max()) <= MEL_TOL
+        assert float(np.abs(al.cpu().numpy() - g[name + "_align"]).max()) <= ALIGN_TOL
+
+
+def test_device_rng_and_errors(cuda, lib):
+    from mockingbird_amd.ppg2mel import Ppg2MelDecoder
+    from mockingbird_amd._lib import MbHipError
+    w = synth.ppg2mel_decoder_state(synth.PPG2MEL_HP, seed=3, stop_bias=-2.0)
+    dec = Ppg2MelDecoder(w, synth.PPG2MEL_HP)
+    mem = torch.from_numpy(synth.ppg2mel_memory(2, 20, seed=1)).cuda()
+    a = dec.decode(mem, seed=5)
+    b = dec.decode(mem, seed=5)
+    c = dec.decode(mem, seed=6)
+    assert torch.equal(a[0], b[0]) and not torch.equal(a[0], c[0])  # counter RNG: seed -> dropout stream
+    assert a[0].shape == (2, 40, 160) and torch.isfinite(a[0]).all()
+    with pytest.raises(MbHipError, match="no CPU path"):
+        dec.decode(mem.cpu())
+    with pytest.raises(MbHipError, match="enc_dim"):
+        dec.decode(torch.zeros(1, 8, 128).cuda())
