@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hifigan", action="store_true")
     ap.add_argument("--no-tacotron", action="store_true")
+    ap.add_argument("--no-ppg2mel", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -259,6 +260,33 @@ def main():
                              "unit": "GB/s", "frac": (81.06e6 + 32 * Tt * (1024 + 128) * 4) * 200 / td / 1e9 / HBM_PEAK_GBS,
                              "traffic": None, "note": "upper bound on the loop's rate: the postnet time is inside decode_plus_postnet_ms"},
             }
+        # ---- secondary: ppg2mel voice-conversion decoder: one utterance of 200 encoder
+        # frames (800 ppg frames, 8 s) -> 400 forced decoder steps of 2 mel frames; and a batch of 32
+        if not args.no_ppg2mel:
+            from mockingbird_amd.ppg2mel import Ppg2MelDecoder
+            pdec = Ppg2MelDecoder(synth.ppg2mel_decoder_state(synth.PPG2MEL_HP, seed=3, stop_bias=-6.0), synth.PPG2MEL_HP)
+            entry = {}
+            for pb in (1, 32):
+                pmem = torch.from_numpy(synth.ppg2mel_memory(pb, 200, seed=1)).to(dev)
+                pdec.decode(pmem, seed=1)
+                torch.cuda.synchronize()
+                t0p = time.perf_counter()
+                for i in range(3):
+                    pm, _, _ = pdec.decode(pmem, seed=2 + i)
+                torch.cuda.synchronize()
+                tp = (time.perf_counter() - t0p) / 3
+                steps_p = pm.shape[1]
+                entry[f"batch{pb}"] = {"ms": tp * 1e3, "steps": int(steps_p), "us_per_step": tp * 1e6 / steps_p,
+                                       "mel_frames_per_s": pb * steps_p * 2 / tp}
+            # 19.1 MB of fp32 weights are touched once per step (attention LSTM 7.3 MB, decoder LSTM 10.5 MB, rest 1.3 MB)
+            wbytes = 4.0 * (256 * 80 + 128 * 256 + 2048 * (384 + 512) + 256 * 512 + 15 * 256 + 2048 * (768 + 512) + 161 * 768)
+            entry["workload"] = ("ppg2mel Decoder.inference loop (prenet, attention LSTMCell, MoL attention, decoder LSTMCell, "
+                                 "projection + stop), T_enc = 200, 400 steps forced, fp32, on-device dropout RNG")
+            entry["roofline"] = {"bound": "hbm", "kernel": "decoder step (9 launches), weights streamed once per step",
+                                 "achieved": wbytes / (entry["batch1"]["us_per_step"] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": wbytes / (entry["batch1"]["us_per_step"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                 "traffic": None, "algorithmic_bytes_per_step": wbytes}
+            result["ppg2mel"] = entry
         # ---- CPU baseline: the oracle (reference's ATen CPU arithmetic) on a bounded sample
         if not args.no_cpu_baseline:
             from oracle import wavernn as ow
