@@ -213,6 +213,12 @@ size_t mb_gan_workspace_bytes(const mb_gan* g, int batch, int frames);
 int mb_gan_forward(const mb_gan* g, const float* d_mel, int batch, int frames,
                    float* d_wav, void* d_workspace, size_t workspace_bytes,
                    mb_stream_t stream);
+/* As mb_gan_forward, plus an optional per-utterance channel bias added to conv_pre's output:
+ * d_chan_bias fp32 [batch][upsample_initial_channel] or NULL.  With kind = MB_GAN_HIFIGAN and num_mels =
+ * the latent width this is the VITS decoder, Generator.forward models/synthesizer/models/vits.py:273-291
+ * (x = conv_pre(x) + cond(g); cond(g) is constant over time), conv_post's missing bias passed as zeros. */
+int mb_gan_forward_ex(const mb_gan* g, const float* d_mel, int batch, int frames, float* d_wav,
+                      const float* d_chan_bias, void* d_workspace, size_t workspace_bytes, mb_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * 3. WaveRNN (fatchord) vocoder.

@@ -142,6 +142,8 @@ SIGNATURES = {
     "mb_gan_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "mb_gan_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_size_t, C.c_void_p]),
+    "mb_gan_forward_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_size_t, C.c_void_p]),
     "mb_wavernn_num_weights": (C.c_int, [C.POINTER(WaveRNNConfig)]),
     "mb_wavernn_weight_numel": (C.c_size_t, [C.POINTER(WaveRNNConfig), C.c_int]),
     "mb_wavernn_finish_workspace_bytes": (C.c_size_t, [C.c_int] * 4),

@@ -106,6 +106,23 @@ static int add_inplace_f16(void* y, const void* x, size_t n, hipStream_t s) {
   return MB_OK;
 }
 
+// x[b][c][t] += bias[b][c]  (fp32 channel-major)  /  x[b][t][c] += bias[b][c]  (fp16 time-major):
+// the VITS decoder's `x + cond(g)` after conv_pre (vits.py:274-276), cond(g) being constant over time
+__global__ void add_chan_bias_f32_kernel(float* __restrict__ x, const float* __restrict__ bias, int C, int T) {
+  const int b = blockIdx.z, c = blockIdx.y;
+  const float v = bias[(size_t)b * C + c];
+  float* xr = x + ((size_t)b * C + c) * T;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x) xr[t] += v;
+}
+__global__ void add_chan_bias_f16_kernel(_Float16* __restrict__ x, const float* __restrict__ bias, int C, int T) {
+  const int b = blockIdx.y;
+  const size_t n = (size_t)C * T;
+  _Float16* xb = x + (size_t)b * n;
+  const float* bb = bias + (size_t)b * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    xb[i] = (_Float16)((float)xb[i] + bb[i % C]);
+}
+
 }  // namespace mb
 
 using namespace mb;
@@ -316,6 +333,12 @@ struct Launcher {
 
 extern "C" int mb_gan_forward(const mb_gan* g, const float* d_mel, int batch, int frames, float* d_wav,
                               void* d_workspace, size_t workspace_bytes, mb_stream_t stream) {
+  return mb_gan_forward_ex(g, d_mel, batch, frames, d_wav, nullptr, d_workspace, workspace_bytes, stream);
+}
+
+extern "C" int mb_gan_forward_ex(const mb_gan* g, const float* d_mel, int batch, int frames, float* d_wav,
+                                 const float* d_chan_bias, void* d_workspace, size_t workspace_bytes,
+                                 mb_stream_t stream) {
   MB_REQUIRE(g && d_mel && d_wav, "gan_forward: null pointer");
   MB_REQUIRE(batch > 0 && frames > 0, "gan_forward: empty input (batch=%d frames=%d)", batch, frames);
   const size_t need = mb_gan_workspace_bytes(g, batch, frames);
@@ -351,6 +374,14 @@ extern "C" int mb_gan_forward(const mb_gan* g, const float* d_mel, int batch, in
 
   // conv_pre (models.py:135 / generator.py:139)
   L.conv(g->convs[g->i_pre], mel_in, frames, XS, 0, 0.f, nullptr, 1.f, 0, 0);
+  if (d_chan_bias && !L.rc) {  // VITS decoder: x = conv_pre(x) + cond(g)   vits.py:274-276
+    const int C0 = c.upsample_initial_channel;
+    if (f16) hipLaunchKernelGGL(add_chan_bias_f16_kernel, dim3(std::min(cdiv(C0 * frames, 256), 1024), batch), dim3(256), 0,
+                                (hipStream_t)stream, reinterpret_cast<_Float16*>(XS), d_chan_bias, C0, frames);
+    else hipLaunchKernelGGL(add_chan_bias_f32_kernel, dim3(std::min(cdiv(frames, 256), 64), C0, batch), dim3(256), 0,
+                            (hipStream_t)stream, reinterpret_cast<float*>(XS), d_chan_bias, C0, frames);
+    MB_HIP(hipGetLastError());
+  }
   int t = frames;                 // current length of XS
   const void* mel_cur = mel_in;   // fregan conditioning chain
   int mel_t = frames;

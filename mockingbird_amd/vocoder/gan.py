@@ -56,7 +56,7 @@ class GanGenerator:
                 pass
             self._h = None
 
-    def forward(self, mel: torch.Tensor) -> torch.Tensor:
+    def forward(self, mel: torch.Tensor, chan_bias: torch.Tensor = None) -> torch.Tensor:
         if not mel.is_cuda:
             raise _lib.MbHipError("GanGenerator.forward needs a CUDA(HIP) tensor; there is no CPU path")
         if mel.dim() == 2:
@@ -72,8 +72,12 @@ class GanGenerator:
         if self._ws is None or self._ws.numel() < need or self._ws.device != mel.device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=mel.device)
         wav = torch.empty(B, 1, F * self.hop, dtype=torch.float32, device=mel.device)
-        _lib.check(L.mb_gan_forward(self._h, _lib.ptr(mel), B, F, _lib.ptr(wav), _lib.ptr(self._ws),
-                                    self._ws.numel(), _lib.stream_ptr()), "mb_gan_forward")
+        if chan_bias is not None:  # [B, upsample_initial_channel] added to conv_pre's output (VITS cond)
+            chan_bias = chan_bias.to(mel.device, torch.float32).contiguous()
+            if tuple(chan_bias.shape) != (B, self.cfg.upsample_initial_channel):
+                raise _lib.MbHipError(f"chan_bias must be {(B, self.cfg.upsample_initial_channel)}, got {tuple(chan_bias.shape)}")
+        _lib.check(L.mb_gan_forward_ex(self._h, _lib.ptr(mel), B, F, _lib.ptr(wav), _lib.ptr(chan_bias), _lib.ptr(self._ws),
+                                       self._ws.numel(), _lib.stream_ptr()), "mb_gan_forward_ex")
         return wav
 
     __call__ = forward

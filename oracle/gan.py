@@ -96,3 +96,26 @@ def fregan_forward(w, h, mel, top_k=4):
     x = F.leaky_relu(output)
     x = F.conv1d(x, w["conv_post.weight"], w["conv_post.bias"], padding=3)
     return torch.tanh(x)
+
+
+def vits_generator_forward(w, h, x, g=None):
+    """VITS decoder: Generator.forward, models/synthesizer/models/vits.py:273-291 (ResBlock1,
+    sublayer/vits_modules.py:180-216 with x_mask=None).  x [B, initial_channel, T] latent, g [B, gin, 1]
+    speaker embedding or None -> [B, 1, T*hop].  Differences from the HiFi-GAN generator: conv_pre is not
+    weight-normed, optional `x + cond(g)` after it, ConvTranspose1d padding (k-u)//2 (:255-257), conv_post
+    has no bias."""
+    nk = len(h["resblock_kernel_sizes"])
+    x = F.conv1d(x, w["conv_pre.weight"], w["conv_pre.bias"], padding=3)
+    if g is not None:
+        x = x + F.conv1d(g, w["cond.weight"], w["cond.bias"])
+    for i, (u, k) in enumerate(zip(h["upsample_rates"], h["upsample_kernel_sizes"])):
+        x = F.leaky_relu(x, LRELU_SLOPE)
+        x = F.conv_transpose1d(x, w[f"ups.{i}.weight"], w[f"ups.{i}.bias"], stride=u, padding=(k - u) // 2)
+        xs = None
+        for j in range(nk):
+            r = _resblock1(w, f"resblocks.{i * nk + j}", x, h["resblock_kernel_sizes"][j], h["resblock_dilation_sizes"][j])
+            xs = r if xs is None else xs + r
+        x = xs / nk
+    x = F.leaky_relu(x)
+    x = F.conv1d(x, w["conv_post.weight"], None, padding=3)
+    return torch.tanh(x)

@@ -143,8 +143,36 @@ def ppg2mel():
     print("ppg2mel.npz", {k: v.shape for k, v in out.items()})
 
 
+def vits():
+    """models/synthesizer/models/vits.py Generator (the VITS decoder) of the REAL reference on the synthetic
+    state (loguru / monotonic_align are stubbed: the module imports them at file scope, the decoder does not
+    use them)."""
+    import types
+    for name in ("loguru", "monotonic_align"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            if name == "loguru":
+                m.logger = types.SimpleNamespace(info=print, debug=print, warning=print, error=print)
+            sys.modules[name] = m
+    from models.synthesizer.models.vits import Generator
+    out = {}
+    for name, uic, frames, batch, use_g, seed in synth.VITS_CASES:
+        h = dict(synth.VITS_DEC)
+        h["upsample_initial_channel"] = uic
+        g = Generator(h["initial_channel"], h["resblock"], h["resblock_kernel_sizes"], h["resblock_dilation_sizes"],
+                      h["upsample_rates"], uic, h["upsample_kernel_sizes"], gin_channels=h["gin_channels"])
+        g.load_state_dict(synth.vits_dec_state(h, seed=seed))
+        g.eval()
+        z, spk = synth.vits_latent(frames, batch, seed=seed + 1)
+        with torch.no_grad():
+            y = g(torch.from_numpy(z), g=torch.from_numpy(spk) if use_g else None)
+        out[name] = y.numpy()
+    np.savez_compressed(os.path.join(HERE, "vits.npz"), torch_version=torch.__version__, **out)
+    print("vits.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gan", "wavernn", "maximum_path", "tacotron", "ppg2mel"]
+    which = sys.argv[1:] or ["gan", "wavernn", "maximum_path", "tacotron", "ppg2mel", "vits"]
     for w in which:
         if w in globals():
             globals()[w]()

@@ -303,3 +303,42 @@ PPG2MEL_CASES = [  # golden cases: (name, batch, t_enc, weight seed, stop bias, 
     ("b1_t26_stops", 1, 26, 4, 0.0, 2, 8),
     ("b3_t24_batched", 3, 24, 3, 0.0, 3, 7),
 ]
+
+
+VITS_DEC = dict(initial_channel=192, resblock="1", resblock_kernel_sizes=[3, 7, 11],
+                resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]], upsample_rates=[8, 8, 2, 2],
+                upsample_initial_channel=512, upsample_kernel_sizes=[16, 16, 4, 4], gin_channels=256)
+
+
+def vits_dec_state(h=VITS_DEC, seed=0):
+    """state_dict of models/synthesizer/models/vits.py:Generator (names as the reference registers them):
+    the HiFi-GAN-style stack of gan_state() with a plain conv_pre, a bias-free conv_post and cond."""
+    hh = dict(h)
+    hh["num_mels"] = h["initial_channel"]
+    sd = dict(gan_state(hh, "hifigan", seed=seed)["generator"])
+    import oracle.gan as og
+    folded = og.fold_weight_norm_state({k: v for k, v in sd.items() if k.startswith("conv_pre.")})
+    for k in [k for k in sd if k.startswith("conv_pre.")]:
+        del sd[k]
+    sd["conv_pre.weight"], sd["conv_pre.bias"] = folded["conv_pre.weight"], folded["conv_pre.bias"]
+    post = og.fold_weight_norm_state({k: v for k, v in sd.items() if k.startswith("conv_post.")})
+    for k in [k for k in sd if k.startswith("conv_post.")]:
+        del sd[k]
+    sd["conv_post.weight"] = post["conv_post.weight"]
+    rng = np.random.default_rng(seed + 1000)
+    gin, c0 = h["gin_channels"], h["upsample_initial_channel"]
+    if gin:
+        sd["cond.weight"] = torch.from_numpy((rng.standard_normal((c0, gin, 1)) / np.sqrt(gin)).astype(np.float32))
+        sd["cond.bias"] = torch.from_numpy((0.05 * rng.standard_normal(c0)).astype(np.float32))
+    return sd
+
+
+def vits_latent(frames, batch=1, seed=0, channels=192, gin=256):
+    rng = np.random.default_rng(seed)
+    z = rng.standard_normal((batch, channels, frames)).astype(np.float32)
+    g = rng.standard_normal((batch, gin, 1)).astype(np.float32)
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    return z, g
+
+
+VITS_CASES = [("uic64_t9_b2_g", 64, 9, 2, True, 3), ("uic512_t6_b1_nog", 512, 6, 1, False, 4)]

@@ -205,3 +205,19 @@ def test_ppg2mel_injected_masks_equal_global_rng():
     with torch.no_grad():
         mel2, al2, stop2 = op.inference_batched(w, dict(op.HP), mem, masks=op.MaskSource(masks))
     assert torch.equal(mel, mel2) and torch.equal(al, al2) and torch.equal(stop, stop2)
+
+
+@pytest.mark.parametrize("case", synth.VITS_CASES, ids=lambda c: c[0])
+def test_vits_generator_oracle_vs_golden(case):
+    """oracle.gan.vits_generator_forward against the reference's own vits.Generator outputs (vits.npz)."""
+    name, uic, frames, batch, use_g, seed = case
+    gold = np.load(os.path.join(G, "vits.npz"))[name]
+    h = dict(synth.VITS_DEC)
+    h["upsample_initial_channel"] = uic
+    w = og.fold_weight_norm_state(synth.vits_dec_state(h, seed=seed))
+    z, spk = synth.vits_latent(frames, batch, seed=seed + 1)
+    torch.set_num_threads(1)
+    with torch.no_grad():
+        y = og.vits_generator_forward(w, h, torch.from_numpy(z), torch.from_numpy(spk) if use_g else None)
+    assert y.shape == gold.shape == (batch, 1, frames * 256)
+    assert float(np.abs(y.numpy() - gold).max()) <= 1e-6
