@@ -59,6 +59,10 @@ def main():
             print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
     import torch.distributed as dist
     use_dist = world > 1
+    if use_dist:
+        # N > 1: the line is the sharded headline workload + its roofline; the secondary single-GPU objects and
+        # the CPU baseline are N = 1 material (rank 0 would otherwise keep the other ranks waiting ~1 min)
+        args.no_hifigan = args.no_tacotron = args.no_ppg2mel = args.no_cpu_baseline = True
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if use_dist:
