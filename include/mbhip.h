@@ -274,6 +274,23 @@ int mb_wavernn_generate(const mb_wavernn* w, const mb_wavernn_plan* plan,
 /* time (ms) the sample-loop kernels of the LAST generate call took, measured
  * with hipEvents on `stream` (valid after the stream is synchronised), and the
  * number of kernel launches in it. */
+/* Several utterances in ONE sample loop (additive; the reference vocodes one utterance per call): the folds
+ * of all utterances are the columns of the same 5 launches per step, amortising the launch latency that
+ * bounds a single utterance.  Production chain only (Philox sampling); batched fold geometry
+ * (fold_with_overlap, fatchord_version.py:288-338) per utterance; utterance u draws exactly the noise it
+ * would draw alone with seed h_seeds[u], so its samples equal those of mb_wavernn_generate(seed = h_seeds[u]).
+ * h_fold_offsets [n_utt+1] (out of the plan call): utterance u owns rows [off[u], off[u+1]) of
+ * d_samples [n_folds][seq_len].  h_d_mels: HOST array of n_utt DEVICE pointers, mel u = fp32 [feat][frames[u]]. */
+typedef struct mb_wavernn_batch_plan {
+  int n_utt, n_folds, seq_len, fold_stride;
+  size_t workspace_bytes;
+} mb_wavernn_batch_plan;
+int mb_wavernn_plan_generate_batch(const mb_wavernn* w, int n_utt, const int* h_frames, int target, int overlap,
+                                   mb_wavernn_batch_plan* plan, int* h_fold_offsets);
+int mb_wavernn_generate_batch(const mb_wavernn* w, const mb_wavernn_batch_plan* plan, const int* h_frames,
+                              const float* const* h_d_mels, const uint64_t* h_seeds, float* d_samples,
+                              void* d_workspace, size_t workspace_bytes, mb_stream_t stream);
+
 /* Device post-processing of the generated folds, float64 (wavernn_post.hip).
  * Replaces the numpy tail of WaveRNN.generate  models/vocoder/wavernn/models/fatchord_version.py:236-257:
  *   xfade_and_unfold :340-402 (if batched), decode_mu_law audio.py:102-107 (if mu_law),

@@ -92,6 +92,11 @@ class WaveRNNConfig(C.Structure):
     ]
 
 
+class WaveRNNBatchPlan(C.Structure):
+    _fields_ = [("n_utt", C.c_int), ("n_folds", C.c_int), ("seq_len", C.c_int), ("fold_stride", C.c_int),
+                ("workspace_bytes", C.c_size_t)]
+
+
 class WaveRNNPlan(C.Structure):
     _fields_ = [
         ("frames", C.c_int), ("total_len", C.c_int), ("n_folds", C.c_int), ("seq_len", C.c_int),
@@ -146,6 +151,10 @@ SIGNATURES = {
                                     C.c_size_t, C.c_void_p]),
     "mb_wavernn_num_weights": (C.c_int, [C.POINTER(WaveRNNConfig)]),
     "mb_wavernn_weight_numel": (C.c_size_t, [C.POINTER(WaveRNNConfig), C.c_int]),
+    "mb_wavernn_plan_generate_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int,
+                                                 C.POINTER(WaveRNNBatchPlan), C.POINTER(C.c_int)]),
+    "mb_wavernn_generate_batch": (C.c_int, [C.c_void_p, C.POINTER(WaveRNNBatchPlan), C.POINTER(C.c_int), _PP,
+                                            C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mb_wavernn_finish_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "mb_wavernn_finish": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_double, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_void_p,

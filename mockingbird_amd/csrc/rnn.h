@@ -55,6 +55,12 @@ struct RnnK {
   // *fr_base changes once per graph replay, fr_off is baked per launch: the loop kernels never read a
   // word the previous launch has just written except the activations themselves.
   const int* fr_base; int fr_off, fr_n_off, fr_fold_stride, fr_total_len, fr_hop, fr_frames;
+  // Several utterances in one loop (mb_wavernn_generate_batch): per-fold descriptors replace the arithmetic
+  // above.  fr_desc[(fr_n_off + n) * 8 + ..] = {pos0, total_len_u, pos_row_base, frame_row_base, frames_u,
+  // local fold index, seed lo, seed hi}:  pos = pos0 + s; position-table row = pos_row_base + min(pos, total_len_u);
+  // frame-table row = frame_row_base + (pos < total_len_u ? pos / fr_hop : frames_u); the Gumbel noise of fold n
+  // is Philox(seed_u; s, local fold, class/4) -- exactly what utterance u alone with seed_u would draw.
+  const int* fr_desc;
   const int* skip_flag;  // if non-null and *skip_flag != 0 the launch is a no-op (decoder stop rule)
   // optional strided copy of h_out into a sequence tensor: seq_out[n*seq_n_stride + j*seq_j_stride + seq_off]
   float* seq_out; long long seq_n_stride, seq_j_stride, seq_off;
@@ -138,6 +144,7 @@ struct Fin1K {
   const float* T1; const float* Ipre; const float* P1; const float* g1; const float* wI0; const float* h_prev;
   float* h_out; float* x_out; float* samples; volatile int* progress;
   const int* step_base; int step_off, n_off, nl, R, C, S, fold_stride, total_len;
+  const int* desc;  // optional per-fold descriptors (RnnK::fr_desc layout)
   // in-launch variant: wait until *arrive >= (step index) * arrive_per_step before reading the slots
   const unsigned int* arrive; unsigned int arrive_per_step;
   unsigned long long* trace;

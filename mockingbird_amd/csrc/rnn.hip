@@ -33,8 +33,16 @@ __device__ __forceinline__ void gru1_finish_body(const Fin1K& a, const int block
   const float* p1 = a.P1 + (size_t)n * 3 * H + j;
   const float hr = p1[0], hz = p1[H], hn = p1[2 * H];
   const float hp = a.h_prev[(size_t)n * H + j];
-  unsigned pos = (unsigned)(a.n_off + n) * (unsigned)a.fold_stride + (unsigned)s;
-  if (pos > (unsigned)a.total_len) pos = (unsigned)a.total_len;  // zero-conditioning row
+  unsigned pos;
+  if (a.desc) {  // several utterances: row = pos_row_base + min(pos0 + s, total_len_u)
+    const int4 d0 = *reinterpret_cast<const int4*>(a.desc + (size_t)(a.n_off + n) * 8);
+    pos = (unsigned)(d0.x + s);
+    if (pos > (unsigned)d0.y) pos = (unsigned)d0.y;
+    pos += (unsigned)d0.z;
+  } else {
+    pos = (unsigned)(a.n_off + n) * (unsigned)a.fold_stride + (unsigned)s;
+    if (pos > (unsigned)a.total_len) pos = (unsigned)a.total_len;  // zero-conditioning row
+  }
   const float* t1 = a.T1 + (size_t)pos * 3 * H + j;
   const float tr = t1[0], tz = t1[H], tn = t1[2 * H];
   const float ip = a.Ipre[(size_t)pos * H + j];
@@ -145,6 +153,9 @@ void cell_rows(const float* w_ih, int kx, int ldx, const float* w_hh, int kh, in
   X(EPI_LINEAR, 1, 4, RF_BIASX | RF_FRAME | RF_GUMBEL)                                                    \
   /* WaveRNN split-hidden chain: rnn2 on its input half only (hidden half precomputed) */                 \
   X(EPI_GRU, 1, 4, RF_PRE | RF_FRAME | RF_HPRE | RF_XRES | RF_XOUT | RF_ZERO)                             \
+  /* ... and with per-fold descriptors (several utterances per loop) */                                   \
+  X(EPI_GRU, 1, 4, RF_PRE | RF_FRAME | RF_HPRE | RF_XRES | RF_XOUT | RF_ZERO | RF_FOLDTAB)                \
+  X(EPI_LINEAR, 1, 4, RF_BIASX | RF_FRAME | RF_GUMBEL | RF_FOLDTAB)                                       \
   /* Tacotron decoder: prenet fc1/fc2 (mask / on-device dropout), attention GRU, rnn_input, LSTMs, mel */ \
   X(EPI_LINEAR, 1, 2, RF_BIASX | RF_SKIP | RF_MASK | ACT(1))                                              \
   X(EPI_LINEAR, 1, 2, RF_BIASX | RF_SKIP | RF_DROP | ACT(1))                                              \
@@ -175,10 +186,11 @@ int rnn_launch_dual_linear(const RnnK& k0, const RnnK& k1, hipStream_t s) {
   const unsigned f0 = rnn_features(EPI_LINEAR, k0), f1 = rnn_features(EPI_LINEAR, k1);
   constexpr unsigned F0 = RF_PRE | RF_FRAME | (1u << RF_ACT_SHIFT), F1 = RF_BIASX;
   const int pw0 = cdiv(k0.nkb_total, NW), pw1 = cdiv(k1.nkb_total, NW);
-  MB_REQUIRE(f0 == F0 && f1 == F1 && pw0 == 4 && pw1 == 4,
+  MB_REQUIRE((f0 == F0 || f0 == (F0 | RF_FOLDTAB)) && f1 == F1 && pw0 == 4 && pw1 == 4,
              "rnn_launch_dual: only the (relu table linear, biased linear) K=512 pair is instantiated (features %x/%x)", f0, f1);
   dim3 grid(nx0 + nx1, cdiv(k0.N, 16));
-  hipLaunchKernelGGL((rnn_dual_linear_kernel<4, F0, 4, F1>), grid, dim3(NW * 64), 0, s, d0, d1, nx0);
+  if (f0 == F0) hipLaunchKernelGGL((rnn_dual_linear_kernel<4, F0, 4, F1>), grid, dim3(NW * 64), 0, s, d0, d1, nx0);
+  else hipLaunchKernelGGL((rnn_dual_linear_kernel<4, F0 | RF_FOLDTAB, 4, F1>), grid, dim3(NW * 64), 0, s, d0, d1, nx0);
   MB_HIP(hipGetLastError());
   return MB_OK;
 }

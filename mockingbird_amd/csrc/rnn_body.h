@@ -10,7 +10,7 @@ enum : unsigned {
   RF_BIASX = 1u << 0, RF_BIASH = 1u << 1, RF_PRE = 1u << 2, RF_PREIDX = 1u << 3, RF_FRAME = 1u << 4,
   RF_XRES = 1u << 5, RF_SKIP = 1u << 6, RF_MASK = 1u << 7, RF_DROP = 1u << 8, RF_SEQ = 1u << 9,
   RF_XOUT = 1u << 10, RF_AFFINE = 1u << 11, RF_GUMBEL = 1u << 12, RF_ZERO = 1u << 13, RF_MULTISEG = 1u << 14,
-  RF_HPRE = 1u << 15, RF_ARRIVE = 1u << 20,
+  RF_HPRE = 1u << 15, RF_ARRIVE = 1u << 20, RF_FOLDTAB = 1u << 21,
   RF_ACT_SHIFT = 16,  // 2 bits
   RF_GENERIC = 1u << 31
 };
@@ -34,6 +34,7 @@ static inline unsigned rnn_features(int epi, const RnnK& k) {
   if (k.nseg > 1) f |= RF_MULTISEG;
   if (k.h_pre) f |= RF_HPRE;
   if (k.arrive) f |= RF_ARRIVE;
+  if (k.fr_desc) f |= RF_FOLDTAB;
   if (epi == EPI_LINEAR) f |= (unsigned)(k.act & 3) << RF_ACT_SHIFT;
   return f;
 }
@@ -69,6 +70,7 @@ __device__ __forceinline__ void rnn_rowtile_body(const RnnDev& d, const int bx, 
   const bool f_mseg = RHAS(RF_MULTISEG, a.nseg > 1);
   const bool f_hpre = RHAS(RF_HPRE, a.h_pre != nullptr);
   const bool f_arrive = RHAS(RF_ARRIVE, a.arrive != nullptr);
+  const bool f_ftab = RHAS(RF_FOLDTAB, a.fr_desc != nullptr);
   const int act = (F & RF_GENERIC) ? a.act : (int)((F >> RF_ACT_SHIFT) & 3);
 
   MB_MARK(a.trace, 0, 0);
@@ -178,7 +180,15 @@ __device__ __forceinline__ void rnn_rowtile_body(const RnnDev& d, const int bx, 
   int prow = a.pre_base_row + en * a.pre_n_stride;
   if (f_preidx) prow = idx_raw;
   unsigned posE = 0;
-  if (f_frame) {
+  int dsc_fold = 0;
+  unsigned dsc_slo = 0, dsc_shi = 0;
+  if (f_frame && f_ftab) {  // several utterances: per-fold descriptor (stable data) instead of the fold arithmetic
+    const int4 d0 = *reinterpret_cast<const int4*>(a.fr_desc + (size_t)(a.fr_n_off + en) * 8);
+    const int4 d1 = *reinterpret_cast<const int4*>(a.fr_desc + (size_t)(a.fr_n_off + en) * 8 + 4);
+    posE = (unsigned)(d0.x + fr_s);
+    prow = d0.w + (posE < (unsigned)d0.y ? (int)(posE / (unsigned)a.fr_hop) : d1.x);
+    dsc_fold = d1.y; dsc_slo = (unsigned)d1.z; dsc_shi = (unsigned)d1.w;
+  } else if (f_frame) {
     posE = cond_pos(en);
     prow = posE < (unsigned)a.fr_total_len ? (int)(posE / (unsigned)a.fr_hop) : a.fr_frames;
   }
@@ -276,8 +286,10 @@ __device__ __forceinline__ void rnn_rowtile_body(const RnnDev& d, const int bx, 
     float best = -INFINITY;
     int bcls = 0;
     uint32_t gr[4] = {0u, 0u, 0u, 0u};
-    if (f_gum) philox4x32((uint32_t)fr_s, (uint32_t)(a.fr_n_off + n), (uint32_t)((mt * 16 + du * 4) >> 2), 0x57415645u,
-                          (uint32_t)a.gum_seed, (uint32_t)(a.gum_seed >> 32), gr);
+    if (f_gum && f_ftab) philox4x32((uint32_t)fr_s, (uint32_t)dsc_fold, (uint32_t)((mt * 16 + du * 4) >> 2), 0x57415645u,
+                                    dsc_slo, dsc_shi, gr);
+    else if (f_gum) philox4x32((uint32_t)fr_s, (uint32_t)(a.fr_n_off + n), (uint32_t)((mt * 16 + du * 4) >> 2), 0x57415645u,
+                               (uint32_t)a.gum_seed, (uint32_t)(a.gum_seed >> 32), gr);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = mt * 16 + du * 4 + r;

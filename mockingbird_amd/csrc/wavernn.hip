@@ -885,6 +885,252 @@ extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* 
   return MB_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Several utterances in ONE sample loop (additive API; the reference vocodes one utterance per call).
+// The folds of all utterances become the columns of the same 5 launches per step, so the launch
+// latency that bounds a single utterance (23 columns) is amortised over n_utt x folds columns.
+// Production chain only (split-hidden, fused Philox sampler).  Fold n carries a descriptor
+// (RnnK::fr_desc) with its utterance's table offsets, so utterances may have different lengths;
+// utterance u draws exactly the noise it would draw alone with seed h_seeds[u].
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct WrnBatchLayout {
+  float *r0, *r1, *r2, *aux, *m1, *m2, *cond;           // per-utterance conditioning scratch (max frames)
+  float *Ipre, *T1, *G2, *F1, *F2;                       // concatenated tables, one zero-conditioning row per utterance
+  float *x1, *x2, *y1, *y2, *h1, *h2, *P1, *P2;
+  int* step; unsigned long long* slots; int* desc;
+  size_t bytes;
+};
+void wavernn_batch_layout(const mb_wavernn* w, int n_utt, const int* frames, int n_folds, void* base, WrnBatchLayout* L) {
+  const mb_wavernn_config& c = w->cfg;
+  const size_t R = c.rnn_dims, FC = c.fc_dims, CD = c.compute_dims, A = w->aux_dims, N = n_folds;
+  size_t fmax = 0, pos_rows = 0, frame_rows = 0;
+  for (int u = 0; u < n_utt; ++u) {
+    fmax = std::max(fmax, (size_t)frames[u]);
+    pos_rows += (size_t)frames[u] * w->hop + 1;
+    frame_rows += (size_t)frames[u] + 1;
+  }
+  const size_t Tmax = fmax * w->hop;
+  Arena ar(base, (size_t)-1);
+  L->r0 = ar.take<float>(CD * fmax); L->r1 = ar.take<float>(CD * fmax); L->r2 = ar.take<float>(CD * fmax);
+  L->aux = ar.take<float>((size_t)c.res_out_dims * fmax);
+  const size_t s1 = (fmax + 2 * c.pad) * c.upsample_factors[0];
+  const size_t s2 = s1 * (c.n_upsample > 1 ? c.upsample_factors[1] : 1);
+  L->m1 = ar.take<float>(c.n_upsample >= 2 ? (size_t)c.feat_dims * s1 : 1);
+  L->m2 = ar.take<float>(c.n_upsample >= 3 ? (size_t)c.feat_dims * s2 : 1);
+  L->cond = ar.take<float>((c.feat_dims + A) * Tmax);
+  L->Ipre = ar.take<float>(pos_rows * R); L->T1 = ar.take<float>(pos_rows * 3 * R);
+  L->G2 = ar.take<float>(frame_rows * 3 * R); L->F1 = ar.take<float>(frame_rows * FC); L->F2 = ar.take<float>(frame_rows * FC);
+  L->x1 = ar.take<float>(N * R); L->x2 = ar.take<float>(N * R); L->y1 = ar.take<float>(N * FC); L->y2 = ar.take<float>(N * FC);
+  L->h1 = ar.take<float>(2 * N * R); L->h2 = ar.take<float>(2 * N * R);
+  L->P1 = ar.take<float>(N * 3 * R); L->P2 = ar.take<float>(N * 3 * R);
+  L->step = ar.take<int>(16);
+  L->slots = ar.take<unsigned long long>(2 * N);
+  L->desc = ar.take<int>(N * 8);
+  L->bytes = ar.off + 256;
+}
+int batch_folds(const mb_wavernn* w, int frames, int target, int overlap, int* nf) {
+  const long long total = (long long)frames * w->hop;
+  long long n = floordiv(total - overlap, target + overlap);  // fold_with_overlap :313-322
+  if (total - (n * (overlap + target) + overlap) != 0) n += 1;
+  MB_REQUIRE(n >= 1, "wavernn_batch: mel of %d frames too short for batched generation", frames);
+  *nf = (int)n;
+  return MB_OK;
+}
+}  // namespace
+
+extern "C" int mb_wavernn_plan_generate_batch(const mb_wavernn* w, int n_utt, const int* h_frames, int target, int overlap,
+                                              mb_wavernn_batch_plan* plan, int* h_fold_offsets) {
+  MB_REQUIRE(w && h_frames && plan && h_fold_offsets && n_utt >= 1, "wavernn_plan_batch: bad arguments");
+  MB_REQUIRE(target > 0 && overlap >= 0 && w->cfg.n_upsample <= 3, "wavernn_plan_batch: target/overlap");
+  int n = 0;
+  for (int u = 0; u < n_utt; ++u) {
+    MB_REQUIRE(h_frames[u] >= 1, "wavernn_plan_batch: utterance %d is empty", u);
+    int nf = 0;
+    int rc = batch_folds(w, h_frames[u], target, overlap, &nf);
+    if (rc) return rc;
+    h_fold_offsets[u] = n;
+    n += nf;
+  }
+  h_fold_offsets[n_utt] = n;
+  plan->n_utt = n_utt; plan->n_folds = n; plan->seq_len = target + 2 * overlap; plan->fold_stride = target + overlap;
+  WrnBatchLayout L;
+  wavernn_batch_layout(w, n_utt, h_frames, n, nullptr, &L);
+  plan->workspace_bytes = L.bytes;
+  return MB_OK;
+}
+
+extern "C" int mb_wavernn_generate_batch(const mb_wavernn* wc, const mb_wavernn_batch_plan* plan, const int* h_frames,
+                                         const float* const* h_d_mels, const uint64_t* h_seeds, float* d_samples,
+                                         void* d_workspace, size_t workspace_bytes, mb_stream_t stream) {
+  mb_wavernn* w = const_cast<mb_wavernn*>(wc);
+  MB_REQUIRE(w && plan && h_frames && h_d_mels && h_seeds && d_samples, "wavernn_generate_batch: null pointer");
+  const int n_utt = plan->n_utt, N = plan->n_folds, S = plan->seq_len;
+  WrnBatchLayout L;
+  wavernn_batch_layout(w, n_utt, h_frames, N, d_workspace, &L);
+  if (!d_workspace || workspace_bytes < L.bytes) {
+    set_error("wavernn_generate_batch: workspace %zu B < required %zu B", workspace_bytes, L.bytes);
+    return MB_ENOMEM;
+  }
+  const mb_wavernn_config& c = w->cfg;
+  const int R = c.rnn_dims, FC = c.fc_dims, A = w->aux_dims, C = w->n_classes, FEAT = c.feat_dims;
+  hipStream_t cs = (hipStream_t)stream, s = w->loop_stream;
+  MB_HIP(hipEventRecord(w->ev_in, cs));
+  MB_HIP(hipStreamWaitEvent(s, w->ev_in, 0));
+  int rc = MB_OK;
+#define RC(x) do { if (!rc) rc = (x); } while (0)
+  // ---- conditioning networks + tables, one utterance after the other into the concatenated tables ----
+  std::vector<int> desc((size_t)N * 8);
+  size_t pos_row = 0, frame_row = 0;
+  int fold = 0;
+  for (int u = 0; u < n_utt && !rc; ++u) {
+    const int F = h_frames[u], T = F * w->hop;
+    const float* d_mel = h_d_mels[u];
+    MB_REQUIRE(d_mel, "wavernn_generate_batch: mel %d is null", u);
+    MB_REQUIRE(pos_row + T + 1 < ((size_t)1 << 31) / 2, "wavernn_generate_batch: batch too long for 32-bit table rows");
+    RC(run_cond_conv(w->conv_in, d_mel, F, L.r0, nullptr, 1, 0, s));  // MelResNet :37-44
+    float* cur = L.r0; float* oth = L.r1;
+    for (int i = 0; i < c.res_blocks; ++i) {
+      RC(run_cond_conv(w->res1[i], cur, F, L.r2, nullptr, 1, 0, s));
+      RC(run_cond_conv(w->res2[i], L.r2, F, oth, cur, 0, 0, s));
+      std::swap(cur, oth);
+    }
+    RC(run_cond_conv(w->conv_out, cur, F, L.aux, nullptr, 0, 0, s));
+    if (!rc) {  // mel upsampling :78-85
+      const float* in = d_mel; int t_stored = F, in_pad = c.pad;
+      float* bufs[2] = {L.m1, L.m2};
+      for (int i = 0; i < c.n_upsample; ++i) {
+        const int sc = c.upsample_factors[i];
+        const bool last = i == c.n_upsample - 1;
+        const int t_full = (t_stored + 2 * in_pad) * sc;
+        const int off = last ? c.pad * w->hop : 0;
+        const int t_out = last ? T : t_full;
+        float* o = last ? L.cond : bufs[i & 1];
+        dim3 grid(std::min(cdiv(t_out, 256), 4096), FEAT);
+        hipLaunchKernelGGL(upsample_stage_kernel, grid, dim3(256), 0, s, in, t_stored, in_pad, o, sc, w->up_w[i].p, off, t_out);
+        in = o; t_stored = t_out; in_pad = 0;
+      }
+      dim3 grid(std::min(cdiv(T, 256), 4096), A);
+      hipLaunchKernelGGL(repeat_rows_kernel, grid, dim3(256), 0, s, L.aux, F, L.cond + (size_t)FEAT * T, w->hop);
+      if (hipGetLastError() != hipSuccess) { set_error("wavernn_batch: conditioning launch failed"); rc = MB_EHIP; }
+    }
+    float* Ipre = L.Ipre + pos_row * R; float* T1 = L.T1 + pos_row * 3 * R;
+    float* G2 = L.G2 + frame_row * 3 * R; float* F1 = L.F1 + frame_row * FC; float* F2 = L.F2 + frame_row * FC;
+    RC(run_cond_conv(w->t_I, L.cond, T, Ipre, nullptr, 0, 1, s));
+    RC(run_cond_conv(w->t_T1, L.cond, T, T1, nullptr, 0, 1, s));
+    RC(run_cond_conv(w->t_g2, L.aux + (size_t)1 * A * F, F, G2, nullptr, 0, 1, s));
+    RC(run_cond_conv(w->t_f1, L.aux + (size_t)2 * A * F, F, F1, nullptr, 0, 1, s));
+    RC(run_cond_conv(w->t_f2, L.aux + (size_t)3 * A * F, F, F2, nullptr, 0, 1, s));
+    if (!rc) {  // zero-conditioning rows = the biases
+      MB_HIP(hipMemcpyAsync(Ipre + (size_t)T * R, w->t_I.b.p, sizeof(float) * R, hipMemcpyDeviceToDevice, s));
+      MB_HIP(hipMemcpyAsync(T1 + (size_t)T * 3 * R, w->t_T1.b.p, sizeof(float) * 3 * R, hipMemcpyDeviceToDevice, s));
+      MB_HIP(hipMemcpyAsync(G2 + (size_t)F * 3 * R, w->t_g2.b.p, sizeof(float) * 3 * R, hipMemcpyDeviceToDevice, s));
+      MB_HIP(hipMemcpyAsync(F1 + (size_t)F * FC, w->t_f1.b.p, sizeof(float) * FC, hipMemcpyDeviceToDevice, s));
+      MB_HIP(hipMemcpyAsync(F2 + (size_t)F * FC, w->t_f2.b.p, sizeof(float) * FC, hipMemcpyDeviceToDevice, s));
+    }
+    int nf = 0;
+    RC(batch_folds(w, F, plan->fold_stride - (S - plan->fold_stride), S - plan->fold_stride, &nf));
+    for (int f = 0; f < nf && !rc; ++f, ++fold) {
+      MB_REQUIRE(fold < N, "wavernn_generate_batch: plan does not match the frame counts");
+      int* d = &desc[(size_t)fold * 8];
+      d[0] = f * plan->fold_stride; d[1] = T; d[2] = (int)pos_row; d[3] = (int)frame_row; d[4] = F; d[5] = f;
+      d[6] = (int)(uint32_t)h_seeds[u]; d[7] = (int)(uint32_t)(h_seeds[u] >> 32);
+    }
+    pos_row += (size_t)T + 1; frame_row += (size_t)F + 1;
+  }
+  if (!rc && fold != N) { set_error("wavernn_generate_batch: plan has %d folds, frames give %d", N, fold); rc = MB_EINVAL; }
+  if (rc) return rc;
+  MB_HIP(hipMemcpyAsync(L.desc, desc.data(), sizeof(int) * desc.size(), hipMemcpyHostToDevice, s));
+  MB_HIP(hipStreamSynchronize(s));  // `desc` is a host temporary
+  MB_HIP(hipMemsetAsync(L.h1, 0, sizeof(float) * 2 * N * R, s));
+  MB_HIP(hipMemsetAsync(L.h2, 0, sizeof(float) * 2 * N * R, s));
+  MB_HIP(hipMemsetAsync(L.step, 0, sizeof(int) * 16, s));
+  MB_HIP(hipMemsetAsync(L.slots, 0, sizeof(unsigned long long) * 2 * N, s));
+  for (int g = 0; g < 2 && !rc; ++g) {  // P = W_hh.0 + b_hh for the first step
+    RnnK k;
+    memset(&k, 0, sizeof(k));
+    k.w = g ? w->w_hh2.p : w->w_hh1.p; k.nseg = 1; k.nkb_total = R / 16; k.seg[0] = {g ? L.h2 : L.h1, R, R / 16, 0};
+    k.N = N; k.units = 3 * R; k.biasX = g ? w->b_hh2.p : w->b_hh1.p; k.y = g ? L.P2 : L.P1; k.ldy = 3 * R;
+    rc = rnn_launch(EPI_LINEAR, k, s);
+  }
+  if (rc) return rc;
+
+  // one time step = the split-hidden chain of mb_wavernn_generate with per-fold descriptors
+  auto step = [&](int pp, int soff) -> int {
+    float* h1p = L.h1 + (size_t)pp * N * R; float* h1n = L.h1 + (size_t)(pp ^ 1) * N * R;
+    float* h2p = L.h2 + (size_t)pp * N * R; float* h2n = L.h2 + (size_t)(pp ^ 1) * N * R;
+    unsigned long long* slot_prev = L.slots + (size_t)(pp ^ 1) * N;
+    unsigned long long* slot_cur = L.slots + (size_t)pp * N;
+    auto frame_rows = [&](RnnK& k) {
+      k.fr_base = L.step; k.fr_off = soff; k.fr_n_off = 0; k.fr_fold_stride = plan->fold_stride;
+      k.fr_total_len = 0; k.fr_hop = w->hop; k.fr_frames = 0; k.fr_desc = L.desc;
+    };
+    int r;
+    Fin1K f;
+    memset(&f, 0, sizeof(f));
+    f.slot = slot_prev; f.T1 = L.T1; f.Ipre = L.Ipre; f.P1 = L.P1; f.g1 = w->g1I0.p; f.wI0 = w->wI0.p;
+    f.h_prev = h1p; f.h_out = h1n; f.x_out = L.x1; f.samples = d_samples; f.progress = nullptr;
+    f.step_base = L.step; f.step_off = soff; f.n_off = 0; f.nl = N; f.R = R; f.C = C; f.S = S;
+    f.fold_stride = plan->fold_stride; f.total_len = 0; f.desc = L.desc;
+    if ((r = rnn_launch_finish(f, s))) return r;
+    RnnK k;
+    memset(&k, 0, sizeof(k));
+    k.w = w->w_rnn2x.p; k.nseg = 1; k.nkb_total = R / 16; k.seg[0] = {L.x1, R, R / 16, 0};
+    k.N = N; k.units = R; k.h_pre = L.P2; k.pre_table = L.G2; frame_rows(k); k.pre_stride = 3 * R;
+    k.h_prev = h2p; k.x_res = L.x1; k.h_out = h2n; k.x_out = L.x2; k.zero_slot = slot_prev;
+    if ((r = rnn_launch(EPI_GRU, k, s))) return r;
+    for (int g = 0; g < 2; ++g) {
+      RnnK k1;
+      memset(&k, 0, sizeof(k)); memset(&k1, 0, sizeof(k1));
+      k.w = g ? w->w_fc2.p : w->w_fc1.p; k.nseg = 1;
+      k.seg[0] = {g ? L.y1 : L.x2, g ? FC : R, (g ? FC : R) / 16, 0};
+      k.nkb_total = k.seg[0].nkb;
+      k.N = N; k.units = FC; k.pre_table = g ? L.F2 : L.F1; frame_rows(k); k.pre_stride = FC;
+      k.y = g ? L.y2 : L.y1; k.ldy = FC; k.act = 1;
+      k1.w = g ? w->w_hh2.p : w->w_hh1.p; k1.nseg = 1; k1.nkb_total = R / 16; k1.seg[0] = {g ? h2n : h1n, R, R / 16, 0};
+      k1.N = N; k1.units = 3 * R; k1.biasX = g ? w->b_hh2.p : w->b_hh1.p; k1.y = g ? L.P2 : L.P1; k1.ldy = 3 * R;
+      if ((r = rnn_launch_dual_linear(k, k1, s))) return r;
+    }
+    memset(&k, 0, sizeof(k));
+    k.w = w->w_fc3.p; k.nseg = 1; k.nkb_total = FC / 16; k.seg[0] = {L.y2, FC, FC / 16, 0};
+    k.N = N; k.units = C; k.biasX = w->b_fc3.p; k.ldy = C; frame_rows(k);
+    k.gum_slot = slot_cur; k.gum_seed = 0;
+    return rnn_launch(EPI_LINEAR, k, s);
+  };
+  MB_HIP(hipEventRecord(w->ev_t0, s));
+  const bool use_graph = getenv("MBHIP_NO_GRAPH") == nullptr && S >= 64;
+  int done = 0;
+  if (use_graph) {
+    int G = 128;
+    while (G > S) G >>= 1;
+    G &= ~1;
+    if (G >= 2) {
+      w->drop_graph();
+      MB_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+      for (int i = 0; i < G && !rc; ++i) rc = step(i & 1, i);
+      hipLaunchKernelGGL(wavernn_bump_kernel, dim3(1), dim3(1), 0, s, L.step, G);
+      hipError_t e = hipStreamEndCapture(s, &w->graph[0]);
+      if (rc) { w->drop_graph(); return rc; }
+      if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture", __FILE__, __LINE__);
+      e = hipGraphInstantiate(&w->graph_exec[0], w->graph[0], nullptr, nullptr, 0);
+      if (e != hipSuccess) { w->drop_graph(); return hip_fail(e, "hipGraphInstantiate", __FILE__, __LINE__); }
+      const int reps = S / G;
+      for (int r2 = 0; r2 < reps; ++r2) MB_HIP(hipGraphLaunch(w->graph_exec[0], s));
+      done = reps * G;
+    }
+  }
+  for (int i = done; i < S && !rc; ++i) rc = step(i & 1, i - done);
+  if (rc) return rc;
+  hipLaunchKernelGGL(wavernn_flush_kernel, dim3(cdiv(N, 64)), dim3(64), 0, s, L.slots + (size_t)((S - 1) & 1) * N, d_samples, N, S, C);
+  MB_HIP(hipGetLastError());
+  MB_HIP(hipEventRecord(w->ev_t1, s));
+  w->last_launches = 5 * S; w->last_lanes = 1; w->timed = true;
+  MB_HIP(hipEventRecord(w->ev_out, s));
+  MB_HIP(hipStreamWaitEvent(cs, w->ev_out, 0));
+#undef RC
+  return MB_OK;
+}
+
 extern "C" int mb_wavernn_last_loop_ms(const mb_wavernn* w, float* ms, int* launches) {
   MB_REQUIRE(w && ms, "wavernn_last_loop_ms: null pointer");
   if (!w->timed) { set_error("wavernn_last_loop_ms: no generate call yet"); return MB_ESTATE; }

@@ -98,6 +98,45 @@ class WaveRNNDevice:
         self.last_loop_ms, self.last_loop_launches, self.last_plan = ms.value, nl.value, p
         return (samples, logits) if want_logits else samples
 
+    def generate_samples_batch(self, mels, target, overlap, seeds=None):
+        """Several utterances in ONE sample loop (mb_wavernn_generate_batch; additive API).  mels: list of
+        [80, F_u] CUDA tensors (already divided by mel_max_abs_value); seeds: one per utterance (default u).
+        Returns the list of per-utterance sample tensors [folds_u, seq_len]; utterance u equals
+        generate_samples(mels[u], True, target, overlap, seed=seeds[u])."""
+        if not mels:
+            return []
+        if any(not m.is_cuda for m in mels):
+            raise _lib.MbHipError("WaveRNN needs CUDA(HIP) tensors; there is no CPU path")
+        mels = [m.to(torch.float32).contiguous() for m in mels]
+        n = len(mels)
+        seeds = list(range(n)) if seeds is None else [int(x) for x in seeds]
+        frames = (C.c_int * n)(*[int(m.shape[1]) for m in mels])
+        offs = (C.c_int * (n + 1))()
+        plan = _lib.WaveRNNBatchPlan()
+        L = _lib.lib()
+        _lib.check(L.mb_wavernn_plan_generate_batch(self._h, n, frames, int(target), int(overlap), C.byref(plan), offs),
+                   "mb_wavernn_plan_generate_batch")
+        dev = mels[0].device
+        if self._ws is None or self._ws.numel() < plan.workspace_bytes or self._ws.device != dev:
+            self._ws = None
+            self._ws = torch.empty(plan.workspace_bytes, dtype=torch.uint8, device=dev)
+        samples = torch.empty(plan.n_folds, plan.seq_len, dtype=torch.float32, device=dev)
+        ptrs = (C.c_void_p * n)(*[m.data_ptr() for m in mels])
+        cseeds = (C.c_uint64 * n)(*seeds)
+        _lib.check(L.mb_wavernn_generate_batch(self._h, C.byref(plan), frames, ptrs, cseeds, _lib.ptr(samples),
+                                               _lib.ptr(self._ws), self._ws.numel(), _lib.stream_ptr()),
+                   "mb_wavernn_generate_batch")
+        torch.cuda.current_stream().synchronize()
+        ms, nl = C.c_float(), C.c_int()
+        _lib.check(L.mb_wavernn_last_loop_ms(self._h, C.byref(ms), C.byref(nl)), "mb_wavernn_last_loop_ms")
+        self.last_loop_ms, self.last_loop_launches, self.last_batch_plan = ms.value, nl.value, plan
+        return [samples[offs[u]:offs[u + 1]] for u in range(n)]
+
+    def generate_batch(self, mels, target, overlap, mu_law, seeds=None):
+        """Batch counterpart of generate(): list of [80, F_u] mels -> list of float64 waveforms."""
+        outs = self.generate_samples_batch([m.cuda() for m in mels], target, overlap, seeds)
+        return [self.finish(smp, True, overlap, mu_law, (m.shape[-1] - 1) * self.hop_length) for smp, m in zip(outs, mels)]
+
     def generate(self, mels, batched, target, overlap, mu_law, progress_callback=None, noise=None, seed=0):
         """Signature of WaveRNN.generate (fatchord_version.py:153): mels [1, 80, F] tensor -> float64 wav."""
         mel = mels[0] if mels.dim() == 3 else mels
@@ -158,3 +197,12 @@ def infer_waveform(mel, normalize=True, batched=True, target=8000, overlap=800, 
     mel = torch.from_numpy(mel[None, ...])
     wav = _model.generate(mel, batched, target, overlap, hp.mu_law, progress_callback)
     return wav, hp.sample_rate
+
+
+def infer_waveform_batch(mels, normalize=True, target=8000, overlap=800, seeds=None):
+    """Additive API: a list of (80, F_u) numpy mels -> (list of float64 waveforms, sample
+    rate), all utterances sharing ONE batched sample loop."""
+    if _model is None:
+        raise Exception("Please load Wave-RNN in memory before using it")
+    ms = [torch.from_numpy(np.asarray(m, np.float32) / (hp.mel_max_abs_value if normalize else 1.0)) for m in mels]
+    return _model.generate_batch(ms, target, overlap, hp.mu_law, seeds), hp.sample_rate

@@ -227,3 +227,24 @@ def test_baseline_config1_full_size_properties(model):
     wav = dev.finish(a, True, 800, True, (1000 - 1) * 256)
     assert wav.dtype == np.float64 and wav.shape == (min(999 * 256, 23 * 8800 + 800),) and np.isfinite(wav).all()
     assert abs(wav[-1]) == 0.0 and np.abs(wav).max() > 0  # linear fade reaches exactly zero
+
+
+def test_batch_loop_equals_single_utterance_runs(model):
+    """mb_wavernn_generate_batch: three utterances of different lengths in ONE sample loop.  Fold n carries a
+    descriptor with its utterance's table offsets and noise identity, so utterance u must reproduce
+    generate_samples(mel_u, seed=seeds[u]) sample for sample (columns of the MFMA GEMMs are independent and the
+    Philox counter is (step, local fold, class) under the utterance's own seed)."""
+    dev, w = model
+    frames = [41, 30, 57]
+    mels = [torch.from_numpy(synth.wavernn_mel(f, seed=20 + i) / 4.0).cuda() for i, f in enumerate(frames)]
+    seeds = [101, 7, 55]
+    outs = dev.generate_samples_batch(mels, 2000, 200, seeds)
+    assert dev.last_loop_launches == 5 * 2400
+    assert [o.shape[1] for o in outs] == [2400] * 3
+    for u, m in enumerate(mels):
+        single = dev.generate_samples(m, True, 2000, 200, seed=seeds[u])
+        assert outs[u].shape == single.shape, (outs[u].shape, single.shape)
+        assert torch.equal(outs[u], single), (u, int((outs[u] != single).sum()))
+    wavs = dev.generate_batch([m.cpu() for m in mels], 2000, 200, True, seeds)
+    for wv, f in zip(wavs, frames):
+        assert wv.dtype == np.float64 and np.isfinite(wv).all() and len(wv) <= (f - 1) * 256
