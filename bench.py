@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-hifigan", action="store_true")
     ap.add_argument("--no-tacotron", action="store_true")
     ap.add_argument("--no-ppg2mel", action="store_true")
+    ap.add_argument("--no-wavernn-batch", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -62,7 +63,7 @@ def main():
     if use_dist:
         # N > 1: the line is the sharded headline workload + its roofline; the secondary single-GPU objects and
         # the CPU baseline are N = 1 material (rank 0 would otherwise keep the other ranks waiting ~1 min)
-        args.no_hifigan = args.no_tacotron = args.no_ppg2mel = args.no_cpu_baseline = True
+        args.no_hifigan = args.no_tacotron = args.no_ppg2mel = args.no_cpu_baseline = args.no_wavernn_batch = True
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if use_dist:
@@ -174,6 +175,31 @@ def main():
                            "GBps": (16.3e6 + 452.0 * plan.n_folds) / (result["config"]["us_per_time_step"] * 1e-6) / 1e9},
             "per_kernel": per_kernel,
         }
+        # ---- secondary: WaveRNN throughput mode -- north_star's "batch-32 synthetic input": 32 utterances of
+        # mel 80x{F} share ONE sample loop (736 fold columns instead of 23 per launch)
+        if not args.no_wavernn_batch:
+            nb = 32
+            bm = [torch.from_numpy(synth.wavernn_mel(F, seed=100 + u) / 4.0).to(dev) for u in range(nb)]
+            model.generate_samples_batch(bm[:2], target, overlap, [1, 2])  # warm the code path
+            torch.cuda.synchronize()
+            t0b = time.perf_counter()
+            outs = model.generate_samples_batch(bm, target, overlap, list(range(nb)))
+            bw = [model.finish(o, True, overlap, True, wave_len) for o in outs]
+            torch.cuda.synchronize()
+            tb = time.perf_counter() - t0b
+            bp = model.last_batch_plan
+            nsmp = sum(len(x) for x in bw)
+            result["wavernn_batch32"] = {
+                "workload": f"{nb} utterances x mel 80x{F} in one sample loop: {bp.n_folds} folds x {bp.seq_len} steps, "
+                            "conditioning + loop + float64 tail + D2H, Philox sampling, fp32",
+                "value": nsmp / tb, "unit": "samples/s", "x_realtime": nsmp / tb / 16000.0, "s_total": tb,
+                "sample_loop_ms": model.last_loop_ms, "us_per_time_step": model.last_loop_ms * 1e3 / bp.seq_len,
+                "us_per_fold_step": model.last_loop_ms * 1e3 / bp.seq_len / bp.n_folds,
+                "workspace_GB": bp.workspace_bytes / 1e9,
+            }
+            del outs, bw, bm
+            model._ws = None
+            torch.cuda.empty_cache()
         # ---- secondary: GAN vocoders.  HiFi-GAN batch 32 x (80,200) (north_star "batch-32 synthetic input"),
         # fp32 MFMA (parity path) and fp16 MFMA (throughput path); Fre-GAN fp16 8 x (80,3000) = the per-GPU
         # share of BASELINE configs[4] (batch 64 over 8 GPUs).
