@@ -103,6 +103,21 @@ __global__ __launch_bounds__(512) void rnn_dual_linear_kernel(RnnDev d0, RnnDev 
   else rnn_rowtile_body<EPI_LINEAR, 1, UB1, F1>(d1, blockIdx.x - nx0, blockIdx.y);
 }
 
+// Tile-split launches (rnn_body.h, TS): wide batches (several utterances per WaveRNN loop)
+template <int EPI, unsigned F>
+__global__ __launch_bounds__(512) void rnn_ts_kernel(RnnDev d) {
+  rnn_rowtile_body<EPI, 1, 8, F, true>(d, blockIdx.x, blockIdx.y);
+}
+template <unsigned F0, unsigned F1>
+__global__ __launch_bounds__(512) void rnn_dual_linear_ts_kernel(RnnDev d0, RnnDev d1, int nx0) {
+  if ((int)blockIdx.x < nx0) rnn_rowtile_body<EPI_LINEAR, 1, 8, F0, true>(d0, blockIdx.x, blockIdx.y);
+  else rnn_rowtile_body<EPI_LINEAR, 1, 8, F1, true>(d1, blockIdx.x - nx0, blockIdx.y);
+}
+static bool rnn_ts_enabled(int N) {
+  const char* e = getenv("MBHIP_RNN_TS");
+  return N > 64 && !(e && atoi(e) == 0);
+}
+
 // Two independent GRU steps in ONE launch (the forward and backward directions of a bidirectional scan,
 // cbhg.py:76-77): blockIdx.x < nx0 -> job 0, else job 1.  Halves the launch count of the CBHG scans.
 template <int UB, unsigned F>
@@ -188,6 +203,13 @@ int rnn_launch_dual_linear(const RnnK& k0, const RnnK& k1, hipStream_t s) {
   const int pw0 = cdiv(k0.nkb_total, NW), pw1 = cdiv(k1.nkb_total, NW);
   MB_REQUIRE((f0 == F0 || f0 == (F0 | RF_FOLDTAB)) && f1 == F1 && pw0 == 4 && pw1 == 4,
              "rnn_launch_dual: only the (relu table linear, biased linear) K=512 pair is instantiated (features %x/%x)", f0, f1);
+  if (f0 == (F0 | RF_FOLDTAB) && rnn_ts_enabled(k0.N)) {  // wide batch: tile-split form, 2 row tiles x 4 column tiles per workgroup
+    dim3 gts(cdiv(nx0, 2) + cdiv(nx1, 2), cdiv(cdiv(k0.N, 16), 4));
+    MB_REQUIRE(k0.nkb_total == k1.nkb_total, "rnn_launch_dual(ts): jobs must share K");
+    hipLaunchKernelGGL((rnn_dual_linear_ts_kernel<F0 | RF_FOLDTAB, F1>), gts, dim3(NW * 64), 0, s, d0, d1, cdiv(nx0, 2));
+    MB_HIP(hipGetLastError());
+    return MB_OK;
+  }
   dim3 grid(nx0 + nx1, cdiv(k0.N, 16));
   if (f0 == F0) hipLaunchKernelGGL((rnn_dual_linear_kernel<4, F0, 4, F1>), grid, dim3(NW * 64), 0, s, d0, d1, nx0);
   else hipLaunchKernelGGL((rnn_dual_linear_kernel<4, F0 | RF_FOLDTAB, 4, F1>), grid, dim3(NW * 64), 0, s, d0, d1, nx0);
@@ -261,6 +283,13 @@ int rnn_launch(int epi, const RnnK& k, hipStream_t s) {
   const unsigned feat = rnn_features(epi, k);
   dim3 grid(n_mt, cdiv(k.N, 16 * nt));
   bool done = false;
+  if (rnn_ts_enabled(k.N) && k.nseg == 1) {  // wide batch: tile-split instances
+    constexpr unsigned FG = RF_PRE | RF_FRAME | RF_HPRE | RF_XRES | RF_XOUT | RF_ZERO | RF_FOLDTAB;
+    constexpr unsigned FL = RF_BIASX | RF_FRAME | RF_GUMBEL | RF_FOLDTAB;
+    dim3 gts(cdiv(n_mt, 2), cdiv(cdiv(k.N, 16), 4));
+    if (epi == EPI_GRU && feat == FG) { hipLaunchKernelGGL((rnn_ts_kernel<EPI_GRU, FG>), gts, dim3(NW * 64), 0, s, d); done = true; }
+    else if (epi == EPI_LINEAR && feat == FL) { hipLaunchKernelGGL((rnn_ts_kernel<EPI_LINEAR, FL>), gts, dim3(NW * 64), 0, s, d); done = true; }
+  }
 #define MB_TRY(EPI_, NT_, UB_, F_)                                                                         \
   if (!done && epi == (EPI_) && nt == (NT_) && ub == (UB_) && feat == (unsigned)(F_)) {                    \
     hipLaunchKernelGGL((rnn_rowtile_kernel<EPI_, NT_, UB_, (unsigned)(F_)>), grid, dim3(NW * 64), 0, s, d); \

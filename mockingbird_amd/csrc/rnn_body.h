@@ -50,15 +50,23 @@ struct RnnDev {
 
 #define RHAS(bit, cond) ((F & RF_GENERIC) ? (cond) : ((F & (bit)) != 0))
 
-template <int EPI, int NT, int UB, unsigned F>
+// TS ("tile split", wide batches: hundreds of columns): the 8 waves of a workgroup own 2 row tiles x 4
+// column tiles and each runs the WHOLE K, instead of splitting K for one row tile -- the operands of a
+// workgroup tile of 32 rows x 64 columns are fetched from L2 once and re-used through L1, which is what
+// bounds wide launches.  The arithmetic is kept bit-identical to the K-split form: k-block kb still
+// accumulates in chain (kb mod 8) and the eight chains are added in the same order as the LDS reduction,
+// so a column's result does not depend on how many other columns share the launch.
+template <int EPI, int NT, int UB, unsigned F, bool TS = false>
 __device__ __forceinline__ void rnn_rowtile_body(const RnnDev& d, const int bx, const int by) {
   constexpr int NW = 8;
+  constexpr int KS = TS ? 1 : NW;  // k-block stride between the UB blocks of a batch
   constexpr int RL = (EPI == EPI_GRU) ? 3 : 4;
   constexpr int BLK = 4 * RL * 16;  // floats per (tile, k-block)
   // GRU keeps the hidden-part sums apart (n = tanh(i_n + r*h_n)); an instance whose hidden part comes
   // precomputed (RF_HPRE) has only input-part k-blocks and reduces one partial per wave
   constexpr int NPART = (EPI == EPI_GRU && !(F & RF_HPRE)) ? 2 : 1;
-  __shared__ __attribute__((aligned(16))) float red[NW * NPART * NT * 256];
+  static_assert(!TS || (UB == 8 && NT == 1 && NPART == 1), "tile-split instances: one column tile per wave, 8 accumulation chains");
+  __shared__ __attribute__((aligned(16))) float red[TS ? 4 : NW * NPART * NT * 256];
   const RnnK& a = d.k;
   const bool f_biasx = RHAS(RF_BIASX, a.biasX != nullptr), f_biash = RHAS(RF_BIASH, a.biasH != nullptr);
   const bool f_pre = RHAS(RF_PRE, a.pre_table != nullptr), f_preidx = RHAS(RF_PREIDX, a.pre_idx != nullptr);
@@ -77,7 +85,10 @@ __device__ __forceinline__ void rnn_rowtile_body(const RnnDev& d, const int bx, 
   trace_begin(a.trace);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int mt = bx, ntile0 = by * NT;  // NT column tiles share one weight fetch
+  const int n_mt_all = (EPI == EPI_LINEAR) ? (a.units + 15) / 16 : (a.units + 3) / 4;
+  const int mt_raw = TS ? bx * 2 + (wave >> 2) : bx;
+  const int mt = mt_raw < n_mt_all ? mt_raw : n_mt_all - 1;  // TS: an odd tile count leaves one wave row idle (loads legal, no stores)
+  const int ntile0 = TS ? by * 4 + (wave & 3) : by * NT;  // NT column tiles share one weight fetch
   const int i = lane & 15, kq = lane >> 4;
   const int u = i >> 2, tau = (i & 3) < RL ? (i & 3) : RL - 1;  // dead 4th GRU row re-reads row 2
   const float* wl = a.w + (size_t)mt * a.nkb_total * BLK + ((u * RL + tau) * 4 + kq) * 4;
@@ -87,8 +98,8 @@ __device__ __forceinline__ void rnn_rowtile_body(const RnnDev& d, const int bx, 
     ncol[nt] = (ntile0 + nt) * 16 + i;
     if (ncol[nt] >= a.N) ncol[nt] = a.N - 1;  // duplicate a live column; its result is never stored
   }
-  const bool epi_wave = wave < NT;
-  const int en_raw = (ntile0 + (epi_wave ? wave : 0)) * 16 + (lane & 15);
+  const bool epi_wave = TS ? true : wave < NT;
+  const int en_raw = TS ? ntile0 * 16 + (lane & 15) : (ntile0 + (epi_wave ? wave : 0)) * 16 + (lane & 15);
   const int en = en_raw < a.N ? en_raw : a.N - 1;  // clamped: loads always legal
   const int edu = lane >> 4;                      // epilogue unit (or row quad) within the tile
 
@@ -117,7 +128,7 @@ __device__ __forceinline__ void rnn_rowtile_body(const RnnDev& d, const int bx, 
   auto issue = [&](Frag& f, int kb_base) {
 #pragma unroll
     for (int ub = 0; ub < UB; ++ub) {
-      int kb = kb_base + ub * NW;
+      int kb = kb_base + ub * KS;
       const bool valid = kb < a.nkb_total;
       if (!valid) kb = a.nkb_total - 1;
       const float* sp = d.segp[0];
@@ -145,12 +156,23 @@ __device__ __forceinline__ void rnn_rowtile_body(const RnnDev& d, const int bx, 
     }
   };
   f32x4 accX[NT], accH[NT];
+  f32x4 accT[TS ? 8 : 1];  // TS: chain c accumulates the k-blocks kb = c (mod 8), as wave c does in the K-split form
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) { accX[nt] = {0.f, 0.f, 0.f, 0.f}; accH[nt] = {0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int c = 0; c < (TS ? 8 : 1); ++c) accT[c] = {0.f, 0.f, 0.f, 0.f};
   auto consume = [&](const Frag& f) {
 #pragma unroll
     for (int ub = 0; ub < UB; ++ub) {
       if (f.part[ub] == 2) continue;  // wave-uniform
+      if (TS) {  // batches start at multiples of 8: block ub of a batch belongs to chain ub
+        const float4 b = f.b[ub][0];
+        accT[ub & 7] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[ub].x, b.x, accT[ub & 7], 0, 0, 0);
+        accT[ub & 7] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[ub].y, b.y, accT[ub & 7], 0, 0, 0);
+        accT[ub & 7] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[ub].z, b.z, accT[ub & 7], 0, 0, 0);
+        accT[ub & 7] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[ub].w, b.w, accT[ub & 7], 0, 0, 0);
+        continue;
+      }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const float4 b = f.b[ub][nt];
@@ -169,7 +191,7 @@ __device__ __forceinline__ void rnn_rowtile_body(const RnnDev& d, const int bx, 
     }
   };
   Frag f0, f1;
-  issue(f0, wave);
+  issue(f0, TS ? 0 : wave);
 
   // ---- epilogue operands: issued by every wave right behind the first batch and consumed only
   //      after the reduction barrier, so the MFMA chain never waits on them ----
@@ -233,8 +255,8 @@ __device__ __forceinline__ void rnn_rowtile_body(const RnnDev& d, const int bx, 
 
   // This wave owns k-blocks wave, wave+NW, ... of the concatenated K, UB per batch; the next
   // batch's loads are in flight while the current batch feeds the MFMA chain.
-  for (int kb_base = wave; kb_base < a.nkb_total; kb_base += 2 * NW * UB) {
-    const int kb1 = kb_base + NW * UB, kb2 = kb_base + 2 * NW * UB;
+  for (int kb_base = TS ? 0 : wave; kb_base < a.nkb_total; kb_base += 2 * KS * UB) {
+    const int kb1 = kb_base + KS * UB, kb2 = kb_base + 2 * KS * UB;
     if (kb1 < a.nkb_total) issue(f1, kb1);
     consume(f0);
     if (kb1 < a.nkb_total) {
@@ -245,18 +267,25 @@ __device__ __forceinline__ void rnn_rowtile_body(const RnnDev& d, const int bx, 
   MB_MARK(a.trace, 3, 0);
   // cross-wave reduction through LDS: D fragment lane = (unit = lane>>4, col = lane&15), reg = gate
   float4* red4 = reinterpret_cast<float4*>(red);
+  if (!TS) {
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    red4[((wave * NT + nt) * NPART + 0) * 64 + lane] = make_float4(accX[nt][0], accX[nt][1], accX[nt][2], accX[nt][3]);
-    if (NPART == 2)
-      red4[((wave * NT + nt) * NPART + 1) * 64 + lane] = make_float4(accH[nt][0], accH[nt][1], accH[nt][2], accH[nt][3]);
+    for (int nt = 0; nt < NT; ++nt) {
+      red4[((wave * NT + nt) * NPART + 0) * 64 + lane] = make_float4(accX[nt][0], accX[nt][1], accX[nt][2], accX[nt][3]);
+      if (NPART == 2)
+        red4[((wave * NT + nt) * NPART + 1) * 64 + lane] = make_float4(accH[nt][0], accH[nt][1], accH[nt][2], accH[nt][3]);
+    }
+    __syncthreads();
   }
-  __syncthreads();
   MB_MARK(a.trace, 4, 0);
   if (!epi_wave || skip) return;
+  if (TS && mt_raw >= n_mt_all) return;
   float sx[4] = {0.f, 0.f, 0.f, 0.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+  if (TS) {  // the eight chains, added in the order the K-split form adds its eight waves
 #pragma unroll
-  for (int w = 0; w < NW; ++w) {
+    for (int c = 0; c < 8; ++c) { sx[0] += accT[c & (TS ? 7 : 0)][0]; sx[1] += accT[c & (TS ? 7 : 0)][1]; sx[2] += accT[c & (TS ? 7 : 0)][2]; sx[3] += accT[c & (TS ? 7 : 0)][3]; }
+  }
+#pragma unroll
+  for (int w = 0; w < (TS ? 0 : NW); ++w) {
     const float4 v = red4[((w * NT + wave) * NPART + 0) * 64 + lane];
     sx[0] += v.x; sx[1] += v.y; sx[2] += v.z; sx[3] += v.w;
     if (NPART == 2) {

@@ -1,0 +1,38 @@
+"""Derive per-kernel MFMA utilisation of the HiFi-GAN fp16 pass from the counter passes of tools/pmc_gan.sh
+(gpurun_out/pmc_gan_*.json) -> profiles/r01_hifigan_f16_mfma_util.json.
+
+MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs * active cycles), SIMDs = 256 CUs * 4, active cycles =
+GRBM_GUI_ACTIVE / 8 (the counter is summed over the 8 XCDs).  SQ_VALU_MFMA_BUSY_CYCLES counts matrix-pipe
+cycles per SIMD (32 per v_mfma_f32_32x32x16_f16, MI355X_MICROARCH.md).  Wave-state counters are quad-cycles and
+include the four support waves of the fused kernel, which sit at barriers most of the time."""
+import glob, json, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+acc = {}
+for f in glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_gan_*.json")):
+    for k, cs in json.load(open(f)).items():
+        if "resblock_pair" in k or "conv1d_f16" in k:
+            acc.setdefault(k, {}).update({c: v["mean_per_dispatch"] for c, v in cs.items()})
+            acc[k]["dispatches"] = max(acc[k].get("dispatches", 0), max(v["dispatches"] for v in cs.values()))
+out = {"source": "rocprofv3 --kernel-trace --pmc <group> (4 separate passes), python tools/gan_run.py hifigan f16 32 200 3; "
+                 "means per dispatch", "kernels": {}}
+tot_busy = tot_cyc = 0.0
+for k, c in sorted(acc.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0) * kv[1].get("dispatches", 0)):
+    if "GRBM_GUI_ACTIVE" not in c or "SQ_VALU_MFMA_BUSY_CYCLES" not in c:
+        continue
+    active = c["GRBM_GUI_ACTIVE"] / 8.0
+    util = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * active)
+    wc = c.get("SQ_WAVE_CYCLES", 0.0)
+    out["kernels"][k] = {
+        "dispatches": c["dispatches"], "active_cycles": active, "mfma_util": util,
+        "wave_wait_any_frac": c.get("SQ_WAIT_ANY", 0.0) / wc if wc else None,
+        "wave_issue_stall_frac": c.get("SQ_WAIT_INST_ANY", 0.0) / wc if wc else None,
+        "wave_active_frac": c.get("SQ_ACTIVE_INST_ANY", 0.0) / wc if wc else None,
+        "raw": {n: v for n, v in c.items() if n != "dispatches"},
+    }
+    tot_busy += c["SQ_VALU_MFMA_BUSY_CYCLES"] * c["dispatches"]
+    tot_cyc += 1024.0 * active * c["dispatches"]
+out["whole_pass_mfma_util"] = tot_busy / tot_cyc if tot_cyc else None
+json.dump(out, open(os.path.join(ROOT, "profiles", "r01_hifigan_f16_mfma_util.json"), "w"), indent=1)
+for k, v in out["kernels"].items():
+    print(f"{k[9:60]:52s} x{v['dispatches']:3d}  MfmaUtil {100 * v['mfma_util']:5.1f}%  wait {100 * (v['wave_wait_any_frac'] or 0):4.0f}%  issue-stall {100 * (v['wave_issue_stall_frac'] or 0):4.0f}%")
+print("whole pass MfmaUtil %.1f%%" % (100 * out["whole_pass_mfma_util"]))
