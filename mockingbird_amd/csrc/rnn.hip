@@ -203,7 +203,7 @@ int rnn_launch_dual_linear(const RnnK& k0, const RnnK& k1, hipStream_t s) {
   const int pw0 = cdiv(k0.nkb_total, NW), pw1 = cdiv(k1.nkb_total, NW);
   MB_REQUIRE((f0 == F0 || f0 == (F0 | RF_FOLDTAB)) && f1 == F1 && pw0 == 4 && pw1 == 4,
              "rnn_launch_dual: only the (relu table linear, biased linear) K=512 pair is instantiated (features %x/%x)", f0, f1);
-  if (f0 == (F0 | RF_FOLDTAB) && rnn_ts_enabled(k0.N)) {  // wide batch: tile-split form, 2 row tiles x 4 column tiles per workgroup
+  if (f0 == (F0 | RF_FOLDTAB) && rnn_ts_enabled(k0.N) && k0.nkb_total % 8 == 0 && k1.nkb_total % 8 == 0) {  // wide batch: tile-split form, 2 row tiles x 4 column tiles per workgroup
     dim3 gts(cdiv(nx0, 2) + cdiv(nx1, 2), cdiv(cdiv(k0.N, 16), 4));
     MB_REQUIRE(k0.nkb_total == k1.nkb_total, "rnn_launch_dual(ts): jobs must share K");
     hipLaunchKernelGGL((rnn_dual_linear_ts_kernel<F0 | RF_FOLDTAB, F1>), gts, dim3(NW * 64), 0, s, d0, d1, cdiv(nx0, 2));
@@ -283,7 +283,7 @@ int rnn_launch(int epi, const RnnK& k, hipStream_t s) {
   const unsigned feat = rnn_features(epi, k);
   dim3 grid(n_mt, cdiv(k.N, 16 * nt));
   bool done = false;
-  if (rnn_ts_enabled(k.N) && k.nseg == 1) {  // wide batch: tile-split instances
+  if (rnn_ts_enabled(k.N) && k.nseg == 1 && k.nkb_total % 8 == 0) {  // wide batch: tile-split instances (whole batches of 8 k-blocks)
     constexpr unsigned FG = RF_PRE | RF_FRAME | RF_HPRE | RF_XRES | RF_XOUT | RF_ZERO | RF_FOLDTAB;
     constexpr unsigned FL = RF_BIASX | RF_FRAME | RF_GUMBEL | RF_FOLDTAB;
     dim3 gts(cdiv(n_mt, 2), cdiv(cdiv(k.N, 16), 4));

@@ -162,17 +162,23 @@ __device__ __forceinline__ void rnn_rowtile_body(const RnnDev& d, const int bx, 
 #pragma unroll
   for (int c = 0; c < (TS ? 8 : 1); ++c) accT[c] = {0.f, 0.f, 0.f, 0.f};
   auto consume = [&](const Frag& f) {
+    if (TS) {
+      // batches start at multiples of 8: block ub of a batch belongs to chain ub.  The four MFMAs of a
+      // k-block depend on each other; walking the eight chains inside each component keeps consecutive
+      // MFMAs independent (the counters showed 54 % issue stalls with the chains walked one after the other)
+#pragma unroll
+      for (int cmp = 0; cmp < 4; ++cmp)
+#pragma unroll
+        for (int ub = 0; ub < UB; ++ub) {  // no padding blocks: tile-split launches require nkb_total % 8 == 0
+          const float av = cmp == 0 ? f.a[ub].x : cmp == 1 ? f.a[ub].y : cmp == 2 ? f.a[ub].z : f.a[ub].w;
+          const float bv = cmp == 0 ? f.b[ub][0].x : cmp == 1 ? f.b[ub][0].y : cmp == 2 ? f.b[ub][0].z : f.b[ub][0].w;
+          accT[ub & 7] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, accT[ub & 7], 0, 0, 0);
+        }
+      return;
+    }
 #pragma unroll
     for (int ub = 0; ub < UB; ++ub) {
       if (f.part[ub] == 2) continue;  // wave-uniform
-      if (TS) {  // batches start at multiples of 8: block ub of a batch belongs to chain ub
-        const float4 b = f.b[ub][0];
-        accT[ub & 7] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[ub].x, b.x, accT[ub & 7], 0, 0, 0);
-        accT[ub & 7] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[ub].y, b.y, accT[ub & 7], 0, 0, 0);
-        accT[ub & 7] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[ub].z, b.z, accT[ub & 7], 0, 0, 0);
-        accT[ub & 7] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[ub].w, b.w, accT[ub & 7], 0, 0, 0);
-        continue;
-      }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const float4 b = f.b[ub][nt];
