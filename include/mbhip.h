@@ -132,7 +132,7 @@ int mb_conv1d_f16(const mb_conv1d_f16_args* a, mb_stream_t stream);
  * in a single launch, the intermediate activation kept in LDS (resblock_f16.hip).  Optionally the
  * result is scaled and accumulated into y (the mean over the parallel ResBlocks, models.py:141-145):
  *   y = (accumulate ? y : 0) + out_scale * (x + conv2(...)).
- * Supported: channels in {32,64,128,256}, k odd >= 3 (mb_resblock_pair_f16_supported). */
+ * Supported: channels in {16,32,64,128,256}, k odd >= 3 (mb_resblock_pair_f16_supported). */
 int mb_resblock_pair_f16_supported(int channels, int ksize, int dilation);
 size_t mb_resblock_pair_f16_packed_halves(int channels, int ksize);
 /* h_w1, h_w2: fp32 torch Conv1d weights [C][C][k], weight norm folded -> one fp16 A-fragment stream */

@@ -9,7 +9,7 @@
 // (3x less traffic; the C <= 64 stages were HBM-bound).  Optionally y is scaled and accumulated
 // into the stage output (the mean over the parallel ResBlocks, models.py:141-145).
 //
-// Layout: time-major [B][T][C] fp16 (conv1d_f16.hip).  C in {32, 64, 128, 256}, k odd.
+// Layout: time-major [B][T][C] fp16 (conv1d_f16.hip).  C in {16, 32, 64, 128, 256}, k odd.
 //
 // One PERSISTENT workgroup per CU walks over output tiles of NB = N1 - (k-1) positions:
 //   phase 1  h[N1 x C]  = lrelu(W1 * lrelu(x window) + b1)   -> LDS (fp16), zero outside [0, T)
@@ -63,10 +63,10 @@ constexpr bool PAIR_NT = MB_PAIR_NT != 0;
   } while (0)
 
 template <int C> struct PairGeom {
-  static constexpr int CK = C >= 64 ? 64 : 32;  // channels per x chunk
+  static constexpr int CK = C >= 64 ? 64 : (C >= 32 ? 32 : 16);  // channels per x chunk
   static constexpr int KB = CK / 16;            // k-steps per tap per chunk
   static constexpr int NCH = C / CK;
-  static constexpr int MTT = C / 32;
+  static constexpr int MTT = (C + 31) / 32;  // C = 16: one 32-row tile whose upper half has zero weights
   static constexpr int WM = MTT >= 8 ? 4 : (MTT >= 4 ? 2 : 1);
   static constexpr int MT = MTT / WM;
   static constexpr int WN = 4 / WM;
@@ -344,6 +344,7 @@ void resblock_pair_f16_kernel(ResPairK a) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int co0 = (mt0 + i) * 32 + 8 * g + 4 * (lane >> 5);
+            if (co0 >= C) continue;  // only C = 16: rows 16..31 of the tile are padding
             const f32x4 bv = *reinterpret_cast<const f32x4*>(bs + co0);
             f32x4 v = {acc[i][n][4 * g], acc[i][n][4 * g + 1], acc[i][n][4 * g + 2], acc[i][n][4 * g + 3]};
             v += bv;
@@ -379,6 +380,7 @@ void resblock_pair_f16_kernel(ResPairK a) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int co0 = (mt0 + i) * 32 + 8 * g + 4 * (lane >> 5);
+            if (co0 >= C) continue;
             const f32x4 bv = *reinterpret_cast<const f32x4*>(bs + C + co0);
             f32x4 v = {acc[i][n][4 * g], acc[i][n][4 * g + 1], acc[i][n][4 * g + 2], acc[i][n][4 * g + 3]};
             v += bv;
@@ -481,18 +483,21 @@ static int launch_pair(ResPairK k, int batch, hipStream_t s) {
 using namespace mb;
 
 extern "C" int mb_resblock_pair_f16_supported(int channels, int ksize, int dilation) {
-  if (!(channels == 32 || channels == 64 || channels == 128 || channels == 256)) return 0;
+  if (!(channels == 16 || channels == 32 || channels == 64 || channels == 128 || channels == 256)) return 0;
   if (ksize < 3 || (ksize & 1) == 0 || dilation < 1) return 0;
   switch (channels) {  // the candidates of mb_resblock_pair_f16's instance choice
     case 256: return pair_fits<256>(3, ksize, dilation) || pair_fits<256>(4, ksize, dilation);
     case 128: return pair_fits<128>(2, ksize, dilation) || pair_fits<128>(3, ksize, dilation);
     case 64: return pair_fits<64>(4, ksize, dilation) || pair_fits<64>(2, ksize, dilation, true);
+    case 16: return pair_fits<16>(4, ksize, dilation, true) || pair_fits<16>(8, ksize, dilation, true);
     default: return pair_fits<32>(2, ksize, dilation, true) || pair_fits<32>(4, ksize, dilation, true);
   }
 }
 
 extern "C" size_t mb_resblock_pair_f16_packed_halves(int channels, int ksize) {
-  return (size_t)2 * channels * channels * ksize;
+  // per 32-row output tile: 2 convs x (channels / 16) k-blocks x ksize taps, 512 halves per fragment
+  const int mtt = (channels + 31) / 32;
+  return (size_t)mtt * 2 * (channels / 16) * ksize * 512;
 }
 
 // h_w1 / h_w2: fp32 torch Conv1d weights [C][C][k] (weight norm already folded).
@@ -501,7 +506,7 @@ extern "C" int mb_resblock_pair_f16_pack(const float* h_w1, const float* h_w2, i
   MB_REQUIRE(h_w1 && h_w2 && h_packed, "resblock_pair_f16_pack: null pointer");
   MB_REQUIRE(mb_resblock_pair_f16_supported(channels, ksize, 1), "resblock_pair_f16_pack: C=%d k=%d unsupported",
              channels, ksize);
-  const int C = channels, CK = C >= 64 ? 64 : 32, KB = CK / 16, NCH = C / CK, MTT = C / 32;
+  const int C = channels, CK = C >= 64 ? 64 : (C >= 32 ? 32 : 16), KB = CK / 16, NCH = C / CK, MTT = (C + 31) / 32;
   h16* out = reinterpret_cast<h16*>(h_packed);
   size_t o = 0;
   for (int mt = 0; mt < MTT; ++mt)
@@ -515,7 +520,7 @@ extern "C" int mb_resblock_pair_f16_pack(const float* h_w1, const float* h_w2, i
                 // A fragment of v_mfma_f32_32x32x16_f16: lane l holds A[m = l&31][k = 8*(l>>5) + e]
                 const int co = mt * 32 + (lane & 31);
                 const int ci = c * CK + u * 16 + (lane >> 5) * 8 + e;
-                out[o++] = (h16)w[((size_t)co * C + ci) * ksize + j];
+                out[o++] = co < C ? (h16)w[((size_t)co * C + ci) * ksize + j] : (h16)0.f;
               }
     }
   return MB_OK;
@@ -562,6 +567,7 @@ extern "C" int mb_resblock_pair_f16(const mb_resblock_pair_f16_args* a, mb_strea
       // MBHIP_PAIR_C64=big selects the latter
       prefer_b = !(getenv("MBHIP_PAIR_C64") && strcmp(getenv("MBHIP_PAIR_C64"), "big") == 0);
       MB_PICK2(64, 4, 4, 1, false, 2, 2, true);
+    case 16: prefer_b = true; MB_PICK2(16, 4, 4, 2, true, 8, 2, true);  // 1024-position tiles: per-tile overheads amortise
     default: prefer_b = true; MB_PICK2(32, 4, 2, 2, true, 4, 2, true);
   }
 #undef MB_PICK2

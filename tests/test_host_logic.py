@@ -98,22 +98,23 @@ def test_resblock_pair_weight_stream_layout(lib):
     from mockingbird_amd import _lib
     L = _lib.lib()
     rng = np.random.default_rng(0)
-    for Cc, k in ((64, 3), (32, 7), (128, 3)):
+    for Cc, k in ((64, 3), (32, 7), (128, 3), (16, 3)):
         w1 = rng.standard_normal((Cc, Cc, k)).astype(np.float32)
         w2 = rng.standard_normal((Cc, Cc, k)).astype(np.float32)
         n = L.mb_resblock_pair_f16_packed_halves(Cc, k)
-        assert n == 2 * Cc * Cc * k
+        assert n == max(1, Cc // 32) * 2 * (Cc // 16) * k * 512
         img = np.empty(n, np.float16)
         _lib.check(L.mb_resblock_pair_f16_pack(w1.ctypes.data, w2.ctypes.data, Cc, k, img.ctypes.data),
                    "mb_resblock_pair_f16_pack")
-        CK = 64 if Cc >= 64 else 32
-        KB, NCH, MTT = CK // 16, Cc // CK, Cc // 32
+        CK = 64 if Cc >= 64 else (32 if Cc >= 32 else 16)
+        KB, NCH, MTT = CK // 16, Cc // CK, max(1, Cc // 32)
         img = img.reshape(MTT, 2, NCH, k, KB, 64, 8)
-        for mt, ph, c, j, u, lane in [(0, 0, 0, 0, 0, 0), (MTT - 1, 1, NCH - 1, k - 1, KB - 1, 63), (MTT // 2, 1, 0, 1, 1, 37)]:
+        for mt, ph, c, j, u, lane in [(0, 0, 0, 0, 0, 0), (MTT - 1, 1, NCH - 1, k - 1, KB - 1, 63), (MTT // 2, 1, 0, 1, min(1, KB - 1), 37)]:
             w = (w1, w2)[ph]
             co = mt * 32 + (lane & 31)
             ci0 = c * CK + u * 16 + (lane >> 5) * 8
-            assert np.array_equal(img[mt, ph, c, j, u, lane], w[co, ci0:ci0 + 8, j].astype(np.float16))
+            want = w[co, ci0:ci0 + 8, j].astype(np.float16) if co < Cc else np.zeros(8, np.float16)
+            assert np.array_equal(img[mt, ph, c, j, u, lane], want)
     assert L.mb_resblock_pair_f16_supported(64, 11, 5) == 1 and L.mb_resblock_pair_f16_supported(48, 3, 1) == 0
     assert L.mb_resblock_pair_f16_supported(64, 4, 1) == 0  # even kernel sizes have no "same" padding
 

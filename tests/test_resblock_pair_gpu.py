@@ -35,6 +35,7 @@ CASES = [
     (2, 128, 333, 7, 3), (1, 128, 5000, 11, 5), (1, 128, 64, 3, 1),
     (1, 64, 700, 11, 7), (3, 64, 2000, 3, 5), (1, 64, 37, 7, 1),
     (3, 32, 1000, 3, 5), (1, 32, 4100, 11, 1), (1, 32, 9, 7, 3),
+    (2, 16, 3000, 11, 7), (1, 16, 777, 3, 1), (1, 16, 5, 7, 5),  # Fre-GAN last stage: half an MFMA tile of channels
 ]
 
 
