@@ -13,12 +13,15 @@
 //
 // One PERSISTENT workgroup per CU walks over output tiles of NB = N1 - (k-1) positions:
 //   phase 1  h[N1 x C]  = lrelu(W1 * lrelu(x window) + b1)   -> LDS (fp16), zero outside [0, T)
-//   phase 2  y[NB x C]  = W2 * h + b2 + x                    -> HBM
-// 8 waves: waves 0-3 run the MFMA loops (v_mfma_f32_32x32x16_f16, each wave MT x NTW 32x32 tiles),
-// waves 4-7 are LOADERS that stage the next 64-channel chunk of the x window (leaky-relu applied)
-// into the other half of a double-buffered LDS tile while the MMA waves consume the current one.
-// Loading is a separate role because vector-memory returns are in order per wave: x loads issued
-// by an MMA wave would sit in front of its weight prefetches and stall the MFMA chain once per chunk.
+//   phase 2  conv2(h) + b2 (fp16)                            -> LDS (the h tile, or its own y tile for C <= 64)
+//   write-out y = (acc ? y : 0) + scale * (x + conv2(h) + b2) -> HBM, coalesced 16-byte rows
+// 8 waves, two roles.  Waves 0-3 ("MMA") run the MFMA loops (v_mfma_f32_32x32x16_f16, each wave MT x NTW
+// 32x32 tiles) and touch only LDS and their weight prefetch.  Waves 4-7 ("support") own all HBM traffic:
+// they stage the next 64-channel chunk of the x window (leaky-relu applied) into a ring of LDS buffers
+// while the MMA waves consume the current one, and write the previous tile's y out (adding the residual)
+// while the MMA waves are already in the next tile.  The roles are separate waves because vector-memory
+// returns are in order per wave: loads issued by an MMA wave would sit in front of its own weight
+// prefetches and stall the MFMA chain.  The waves meet at s_barriers only (B per chunk, [W], E1, P|YF, Y).
 //
 // Weights never touch LDS: they are packed on the host as ONE circular stream per 32-channel output
 // tile in exactly the order the kernel consumes them ([conv1: chunk, tap, k-block][conv2: ...]), and
