@@ -50,7 +50,11 @@ struct ResPairK {
   int accumulate;
 };
 
-constexpr int PAIR_NL = 4;  // loader waves per workgroup (beside the 4 MMA waves)
+#ifndef MB_PAIR_NL
+#define MB_PAIR_NL 4
+#endif
+constexpr int PAIR_NL = MB_PAIR_NL;  // support waves per workgroup (beside the 4 MMA waves)
+constexpr int PAIR_LB = 80 / PAIR_NL;  // x-window loads in flight per support lane per batch
 // Activations stream through once per launch; the weights are re-read by every tile.  Non-temporal
 // activation loads/stores keep the 4 MiB per-XCD L2 for the weight stream.
 #ifndef MB_PAIR_NT
@@ -108,7 +112,7 @@ void resblock_pair_f16_kernel(ResPairK a) {
     // PAIR_NL waves split the 16-byte pieces of the window; every piece of a wave is in flight at once
     // (one HBM round trip per chunk), then leaky-relu'd and written to LDS.
     constexpr int PPR = CK / 8;  // 16-byte pieces per row
-    constexpr int LB = 20;       // loads in flight per lane per batch
+    constexpr int LB = PAIR_LB;  // loads in flight per lane per batch
     const h16 slope = (h16)a.slope;
     const int total = a.x_rows * PPR;
     const int ltid = tid - 256;
@@ -415,7 +419,7 @@ template <int C>
 static int pair_min_nbuf(int ntw, int ntaps, int dil) {
   using G = PairGeom<C>;
   const int x_rows = G::WN * ntw * 32 + (ntaps - 1) * dil;
-  const bool single_ok = G::NCH == 1 && x_rows * (G::CK / 8) <= 64 * PAIR_NL * 20;
+  const bool single_ok = G::NCH == 1 && x_rows * (G::CK / 8) <= 64 * PAIR_NL * PAIR_LB;
   return single_ok ? 1 : 2;
 }
 template <int C>
