@@ -181,6 +181,13 @@ typedef struct mb_gan_config {
   int num_dilations;        /* convs1/convs2 pairs per resblock (3 or 4)         */
   int resblock_dilations[MB_GAN_MAX_KERNELS][MB_GAN_MAX_DIL];
   int top_k;                /* Fre-GAN only (generator.py:80), default 4         */
+  int interp_ups;           /* HiFi-GAN h.sampling_rate == 24000 (models.py:107-118): each
+                               ups[i] is nearest-interpolate x u (InterpolationBlock,
+                               models.py:74-91) + Conv1d(k, padding (k-1)//2) instead of a
+                               ConvTranspose1d; weight i+1 is then a Conv1d weight
+                               [C_out][C_in][k] (state name ups.i.1).  An even k makes the
+                               stage one sample short (T*u - 1), as the reference's does:
+                               size d_wav with mb_gan_out_samples.                       */
 } mb_gan_config;
 
 typedef struct mb_gan mb_gan;
@@ -208,8 +215,11 @@ int mb_gan_create_ex(const mb_gan_config* cfg, const float* const* h_weights,
 int mb_gan_dtype(const mb_gan* g);
 void mb_gan_destroy(mb_gan* g);
 int mb_gan_hop(const mb_gan* g);                 /* product of upsample rates   */
+/* Samples per utterance mb_gan_forward writes for `frames` mel frames: frames*hop, except
+ * for interp_ups configs with even upsample kernels (see mb_gan_config.interp_ups). */
+long long mb_gan_out_samples(const mb_gan* g, int frames);
 size_t mb_gan_workspace_bytes(const mb_gan* g, int batch, int frames);
-/* d_mel [batch][num_mels][frames] -> d_wav [batch][frames*hop] */
+/* d_mel [batch][num_mels][frames] -> d_wav [batch][mb_gan_out_samples(g, frames)] */
 int mb_gan_forward(const mb_gan* g, const float* d_mel, int batch, int frames,
                    float* d_wav, void* d_workspace, size_t workspace_bytes,
                    mb_stream_t stream);
@@ -421,6 +431,32 @@ int mb_ppg2mel_decode(const mb_ppg2mel* p, const float* d_memory, int batch, int
                       int min_steps, float stop_threshold, const float* d_dropout, uint64_t seed,
                       float* d_mel, float* d_align, float* d_stop, int* h_n_steps, void* d_workspace,
                       size_t workspace_bytes, mb_stream_t stream);
+
+/* ----------------------------------------------------------------------
+ * 7. Waveform wire format on device: the elementwise tail between the
+ *    vocoder and the file / the rank-0 gather.  d_wav is fp32 (HiFi-GAN / Fre-GAN output) or float64
+ *    (mb_wavernn_finish output); arithmetic is done in THAT type, as numpy does on the array it is given.
+ * ---------------------------------------------------------------------- */
+#define MB_F64 2
+/* wav = wav / max|wav| * target, in place            gen_voice.py:41, control/toolbox/__init__.py:313
+ * (target 0.97).  An all-zero waveform gives NaNs, as the reference's 0/0 does. */
+int mb_wave_peak_normalize(void* d_wav, int dtype, long long n, double target, void* d_workspace,
+                           size_t workspace_bytes, mb_stream_t stream);
+/* float -> int16 PCM.  mode:
+ *   MB_PCM16_SNDFILE   x*32768, clipped to [-32768, 32767], round-half-even: what libsndfile's
+ *                      f2s_clip_array / d2s_clip_array (src/pcm.c) do for sf.write(.., "PCM_16") with
+ *                      python-soundfile's SFC_SET_CLIPPING on (run.py:91, gen_voice.py:47).  libsndfile is
+ *                      not vendored by the reference nor installed here: restated, parity unpinned.
+ *   MB_PCM16_ENCODE16  np.clip(x * 2**15, -2**15, 2**15 - 1).astype(np.int16)  (truncation)
+ *                      models/vocoder/wavernn/audio.py:38-39
+ *   MB_PCM16_SAVE_WAV  x * (32767 / max(0.01, max|x|)), .astype(np.int16)      (truncation)
+ *                      models/synthesizer/audio.py:12-15 */
+#define MB_PCM16_SNDFILE 0
+#define MB_PCM16_ENCODE16 1
+#define MB_PCM16_SAVE_WAV 2
+size_t mb_wave_workspace_bytes(void);
+int mb_wave_pack_pcm16(const void* d_wav, int dtype, long long n, int mode, int16_t* d_pcm,
+                       void* d_workspace, size_t workspace_bytes, mb_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -66,7 +66,8 @@ class Ppg2MelConfig(C.Structure):
     ]
 
 
-MB_F32, MB_F16 = 0, 1
+MB_F32, MB_F16, MB_F64 = 0, 1, 2
+MB_PCM16_SNDFILE, MB_PCM16_ENCODE16, MB_PCM16_SAVE_WAV = 0, 1, 2
 
 
 class GanConfig(C.Structure):
@@ -80,6 +81,7 @@ class GanConfig(C.Structure):
         ("num_dilations", C.c_int),
         ("resblock_dilations", (C.c_int * MB_GAN_MAX_DIL) * MB_GAN_MAX_KERNELS),
         ("top_k", C.c_int),
+        ("interp_ups", C.c_int),
     ]
 
 
@@ -144,6 +146,7 @@ SIGNATURES = {
     "mb_gan_dtype": (C.c_int, [C.c_void_p]),
     "mb_gan_destroy": (None, [C.c_void_p]),
     "mb_gan_hop": (C.c_int, [C.c_void_p]),
+    "mb_gan_out_samples": (C.c_longlong, [C.c_void_p, C.c_int]),
     "mb_gan_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "mb_gan_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_size_t, C.c_void_p]),
@@ -159,6 +162,11 @@ SIGNATURES = {
     "mb_wavernn_finish": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_double, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_void_p,
                                     C.c_size_t, C.c_void_p]),
+    "mb_wave_workspace_bytes": (C.c_size_t, []),
+    "mb_wave_peak_normalize": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_double, C.c_void_p, C.c_size_t,
+                                         C.c_void_p]),
+    "mb_wave_pack_pcm16": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_size_t, C.c_void_p]),
     "mb_wavernn_create": (C.c_int, [C.POINTER(WaveRNNConfig), _PP, C.c_int, _PP]),
     "mb_wavernn_destroy": (None, [C.c_void_p]),
     "mb_wavernn_plan_generate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

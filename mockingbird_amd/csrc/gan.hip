@@ -34,6 +34,12 @@ static int gan_specs(const mb_gan_config* c, std::vector<ConvSpec>* out) {
   out->push_back({uic, c->num_mels, 7, 1, 3, 1, 0});  // conv_pre
   for (int i = 0; i < c->num_upsamples; ++i) {
     const int u = c->upsample_rates[i], k = c->upsample_kernel_sizes[i];
+    if (c->interp_ups) {  // InterpolationBlock(u) + Conv1d(k, padding=(k-1)//2)  models.py:107-112
+      MB_REQUIRE(c->kind == MB_GAN_HIFIGAN, "gan: interp_ups is a HiFi-GAN option");
+      MB_REQUIRE(u >= 1 && u <= 16 && k >= 1, "gan: upsample %d: rate %d kernel %d", i, u, k);
+      out->push_back({uic >> (i + 1), uic >> i, k, 1, (k - 1) / 2, 1, 0});
+      continue;
+    }
     MB_REQUIRE(u >= 1 && u <= 8 && k % u == 0, "gan: upsample %d: rate %d kernel %d", i, u, k);
     MB_REQUIRE(k - 2 * (u / 2 + u % 2) + u % 2 == u, "gan: upsample %d is not an exact x%d", i, u);
     out->push_back({uic >> (i + 1), uic >> i, k, u, u / 2 + u % 2, 1, 1});
@@ -242,6 +248,19 @@ extern "C" void mb_gan_destroy(mb_gan* g) {
 
 extern "C" int mb_gan_hop(const mb_gan* g) { return g ? g->hop : 0; }
 
+// length after ups[i] for an input of t samples
+static long long gan_up_len(const mb_gan_config& c, int i, long long t) {
+  const int u = c.upsample_rates[i], k = c.upsample_kernel_sizes[i];
+  return c.interp_ups ? t * u + 2 * ((k - 1) / 2) - (k - 1) : t * u;
+}
+
+extern "C" long long mb_gan_out_samples(const mb_gan* g, int frames) {
+  if (!g || frames <= 0) return 0;
+  long long t = frames;
+  for (int i = 0; i < g->cfg.num_upsamples; ++i) t = gan_up_len(g->cfg, i, t);
+  return t > 0 ? t : 0;
+}
+
 // Largest [C][T] activation of any stage, per batch item, in floats.
 static size_t gan_max_act(const mb_gan* g, int frames) {
   const mb_gan_config& c = g->cfg;
@@ -280,7 +299,7 @@ struct Launcher {
     mb_conv1d_f16_args a;
     memset(&a, 0, sizeof(a));
     const int t_eff = t_in * in_repeat;
-    const int t_out = c.s.transposed ? t_eff * c.s.stride : t_eff;
+    const int t_out = c.s.transposed ? t_eff * c.s.stride : t_eff + 2 * c.s.pad - c.s.dil * (c.s.k - 1);
     a.d_x = x; a.d_wpacked = c.w.p; a.d_bias = c.b.p; a.d_res = res; a.d_y = y;
     a.x_bstride = (long long)c.s.c_in * t_in;
     a.y_bstride = (long long)c.s.c_out * t_out;
@@ -316,7 +335,7 @@ struct Launcher {
     mb_conv1d_args a;
     memset(&a, 0, sizeof(a));
     const int t_eff = t_in * in_repeat;
-    const int t_out = c.s.transposed ? t_eff * c.s.stride : t_eff;
+    const int t_out = c.s.transposed ? t_eff * c.s.stride : t_eff + 2 * c.s.pad - c.s.dil * (c.s.k - 1);
     a.d_x = x; a.d_wpacked = c.w.p; a.d_bias = c.b.p; a.d_res = res; a.d_y = y;
     a.x_bstride = (long long)c.s.c_in * t_in;
     a.y_bstride = (long long)c.s.c_out * t_out;
@@ -410,8 +429,10 @@ extern "C" int mb_gan_forward_ex(const mb_gan* g, const float* d_mel, int batch,
     }
     // x = ups[i](leaky_relu(x))
     const ConvW& up = g->convs[g->i_ups + i];
-    L.conv(up, XS, t, X, 1, LRELU, nullptr, 1.f, 0, 0);
-    t *= up.s.stride;
+    // (24 kHz variant: interpolate(nearest, x u) is folded into the conv's read -- lrelu commutes with it)
+    L.conv(up, XS, t, X, 1, LRELU, nullptr, 1.f, 0, 0, c.interp_ups ? c.upsample_rates[i] : 1);
+    t = (int)gan_up_len(c, i, t);
+    MB_REQUIRE(t > 0, "gan_forward: %d frames vanish in upsample stage %d", frames, i);
     // xs = mean_j resblock_j(x)
     for (int j = 0; j < c.num_kernels; ++j) {
       const int base = g->i_rb + ((i * c.num_kernels + j) * c.num_dilations) * 2;

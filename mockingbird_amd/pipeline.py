@@ -28,13 +28,20 @@ def insert_breaks(wav: np.ndarray, frames_per_sentence: Sequence[int], hop_size:
     b_ends = np.cumsum(np.array(frames_per_sentence) * hop_size)
     b_starts = np.concatenate(([0], b_ends[:-1]))
     wavs = [wav[start:end] for start, end in zip(b_starts, b_ends)]
-    gap = np.zeros(int(BREAK_SECONDS * sample_rate))
+    # (float waveforms: float64 zeros, so the result is float64 as in the reference; int16 PCM stays int16)
+    gap = np.zeros(int(BREAK_SECONDS * sample_rate), dtype=np.int16 if wav.dtype == np.int16 else np.float64)
     return np.concatenate([piece for w in wavs for piece in (w, gap)])
 
 
 def gen_wavs(synthesizer, vocoder, requests: List[Tuple[List[str], np.ndarray]], *, style_idx=-1, min_stop_token=4,
-             steps=400, group=None) -> List[np.ndarray]:
+             steps=400, group=None, normalize=None, pcm16=None) -> List[np.ndarray]:
     """requests: [(texts, embed)] -> one float waveform per request, in request order, on every rank.
+
+    normalize / pcm16 (optional): run gen_voice.py:41's peak normalisation and the
+    PCM_16 conversion of the file writer on the device (vocoder/wave.py) before the waveform leaves the GPU; the
+    result is int16 and the gather moves half the bytes.  The reference normalises AFTER inserting the breaks
+    and trimming silence (gen_voice.py:40-41); zeros do not move the peak, so only a trim that removed the
+    loudest sample would differ.
 
     synthesizer: object with synthesize_spectrograms / hparams.hop_size / sample_rate (the Synthesizer facade);
     vocoder: module or object with infer_waveform_batch(mels) -> (wavs, sample_rate) (hifigan / fregan facade)."""
@@ -54,10 +61,14 @@ def gen_wavs(synthesizer, vocoder, requests: List[Tuple[List[str], np.ndarray]],
                                                     min_stop_token=min_stop_token, steps=steps)
         per_req = {i: [s for s, o in zip(specs, owner) if o == i] for i in mine}
         mels = [np.concatenate(per_req[i], axis=1) for i in mine]
-        wavs, _sr = vocoder.infer_waveform_batch(mels)
+        if normalize is not None or pcm16 is not None:
+            wavs, _sr = vocoder.infer_waveform_batch(mels, normalize=normalize, pcm16=pcm16)
+        else:
+            wavs, _sr = vocoder.infer_waveform_batch(mels)
         hop, sr = synthesizer.hparams.hop_size, synthesizer.sample_rate
         local = [insert_breaks(w, [s.shape[1] for s in per_req[i]], hop, sr) for w, i in zip(wavs, mine)]
-    gathered = sharding.gather_waveforms([np.asarray(w, np.float32) for w in local], group=group)
+    wire = np.int16 if pcm16 is not None else np.float32
+    gathered = sharding.gather_waveforms([np.asarray(w, wire) for w in local], group=group)
     # gather_waveforms returns rank-major order; put the requests back in their own order
     order = [i for r in range(world) for i in sharding.shard_indices(lengths, world, r)]
     out: List[np.ndarray] = [None] * len(requests)

@@ -26,5 +26,5 @@ def infer_waveform(mel, progress_callback=None):
     return _facade.infer_waveform(mel, progress_callback)
 
 
-def infer_waveform_batch(mels, progress_callback=None):
-    return _facade.infer_waveform_batch(mels, progress_callback)
+def infer_waveform_batch(mels, progress_callback=None, normalize=None, pcm16=None):
+    return _facade.infer_waveform_batch(mels, progress_callback, normalize=normalize, pcm16=pcm16)

@@ -71,7 +71,10 @@ class GanGenerator:
         need = L.mb_gan_workspace_bytes(self._h, B, F)
         if self._ws is None or self._ws.numel() < need or self._ws.device != mel.device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=mel.device)
-        wav = torch.empty(B, 1, F * self.hop, dtype=torch.float32, device=mel.device)
+        n_out = int(L.mb_gan_out_samples(self._h, F))  # F*hop, minus one per even-kernel stage of the 24 kHz variant
+        if n_out <= 0:
+            raise _lib.MbHipError(f"{F} mel frames are too few for this configuration")
+        wav = torch.empty(B, 1, n_out, dtype=torch.float32, device=mel.device)
         if chan_bias is not None:  # [B, upsample_initial_channel] added to conv_pre's output (VITS cond)
             chan_bias = chan_bias.to(mel.device, torch.float32).contiguous()
             if tuple(chan_bias.shape) != (B, self.cfg.upsample_initial_channel):
@@ -128,11 +131,13 @@ class GanFacade:
         audio = y.squeeze().cpu().numpy()
         return audio, self.output_sample_rate
 
-    def infer_waveform_batch(self, mels, progress_callback=None):
+    def infer_waveform_batch(self, mels, progress_callback=None, normalize=None, pcm16=None):
         """Additive API: a list of (80, Fi) mels -> list of
         waveforms, run as ONE zero-padded batch (conv stacks are causal-free, so
         each item is bit-identical to its own first Fi*hop samples only away from
-        the padded tail; items are therefore grouped by equal length)."""
+        the padded tail; items are therefore grouped by equal length).
+        normalize=0.97 / pcm16='sndfile'|'encode_16bits'|'save_wav' apply the reference's host-side tail
+        (gen_voice.py:41, run.py:91) on the device and return int16 arrays."""
         if self.generator is None:
             raise Exception(f"Please load {self.name} in memory before using it")
         out = [None] * len(mels)
@@ -141,7 +146,19 @@ class GanFacade:
             by_len.setdefault(int(np.shape(m)[1]), []).append(i)
         for _, idx in by_len.items():
             batch = torch.stack([torch.FloatTensor(mels[i]) for i in idx]).to(self._device)
-            y = self.generator(batch).squeeze(1).cpu().numpy()
+            y = self.generator(batch).squeeze(1)
+            if normalize is not None or pcm16 is not None:
+                # wire format on device (vocoder/wave.py): per-utterance peak normalisation (gen_voice.py:41)
+                # and int16 PCM (run.py:91) before the copy to the host
+                from . import wave
+                rows = []
+                for k in range(y.shape[0]):
+                    r = y[k]
+                    if normalize is not None:
+                        wave.peak_normalize_(r, normalize)
+                    rows.append(wave.pack_pcm16(r, pcm16) if pcm16 is not None else r)
+                y = torch.stack(rows)
+            y = y.cpu().numpy()
             for k, i in enumerate(idx):
                 out[i] = y[k]
         return out, self.output_sample_rate

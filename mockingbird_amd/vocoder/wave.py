@@ -1,0 +1,61 @@
+"""Waveform wire format on device (include/mbhip.h section 7).
+
+The reference finishes a generated waveform in numpy on the host: peak-normalise to 0.97
+(gen_voice.py:41, control/toolbox/__init__.py:313) and convert to 16-bit PCM when writing
+(run.py:91 sf.write(.., "PCM_16"); models/synthesizer/audio.py:12-15 save_wav;
+models/vocoder/wavernn/audio.py:38-39 encode_16bits).  Here both run on the vocoder's output
+while it is still in HBM, so the D2H copy (and the multi-GPU gather, pipeline.gen_wavs) moves
+2 bytes per sample instead of 4 or 8.  fp32 and float64 tensors are processed in their own type,
+like the numpy arrays they replace.  There is no CPU path."""
+import torch
+
+from .. import _lib
+
+_MODES = {"sndfile": _lib.MB_PCM16_SNDFILE, "encode_16bits": _lib.MB_PCM16_ENCODE16, "save_wav": _lib.MB_PCM16_SAVE_WAV}
+
+
+def _dtype(wav: torch.Tensor) -> int:
+    if not wav.is_cuda:
+        raise _lib.MbHipError("waveform post-processing needs a CUDA(HIP) tensor; there is no CPU path")
+    if wav.dtype == torch.float32:
+        return _lib.MB_F32
+    if wav.dtype == torch.float64:
+        return _lib.MB_F64
+    raise _lib.MbHipError(f"waveform must be float32 or float64, got {wav.dtype}")
+
+
+def _workspace(dev) -> torch.Tensor:
+    return torch.empty(_lib.lib().mb_wave_workspace_bytes(), dtype=torch.uint8, device=dev)
+
+
+def peak_normalize_(wav: torch.Tensor, target: float = 0.97) -> torch.Tensor:
+    """In place: wav = wav / abs(wav).max() * target (gen_voice.py:41).  One waveform per call
+    (the maximum is taken over the whole tensor)."""
+    dt = _dtype(wav)
+    if not wav.is_contiguous():
+        raise _lib.MbHipError("peak_normalize_ needs a contiguous tensor")
+    if wav.numel() == 0:
+        raise ValueError("zero-size array to reduction operation maximum which has no identity")  # np.abs(wav).max()
+    ws = _workspace(wav.device)
+    _lib.check(_lib.lib().mb_wave_peak_normalize(_lib.ptr(wav), dt, wav.numel(), float(target), _lib.ptr(ws), ws.numel(),
+                                                 _lib.stream_ptr()), "mb_wave_peak_normalize")
+    return wav
+
+
+def pack_pcm16(wav: torch.Tensor, mode: str = "sndfile") -> torch.Tensor:
+    """float waveform -> int16 tensor of the same shape.  mode: 'sndfile' (PCM_16 as libsndfile writes it,
+    run.py:91), 'encode_16bits' (wavernn/audio.py:38-39), 'save_wav' (synthesizer/audio.py:12-15, rescales
+    the peak to 32767)."""
+    if mode not in _MODES:
+        raise ValueError(f"mode must be one of {sorted(_MODES)}, got {mode!r}")
+    dt = _dtype(wav)
+    wav = wav.contiguous()
+    out = torch.empty(wav.shape, dtype=torch.int16, device=wav.device)
+    if wav.numel() == 0:
+        if mode == "save_wav":
+            raise ValueError("zero-size array to reduction operation maximum which has no identity")
+        return out
+    ws = _workspace(wav.device)
+    _lib.check(_lib.lib().mb_wave_pack_pcm16(_lib.ptr(wav), dt, wav.numel(), _MODES[mode], _lib.ptr(out), _lib.ptr(ws),
+                                             ws.numel(), _lib.stream_ptr()), "mb_wave_pack_pcm16")
+    return out

@@ -39,10 +39,10 @@ def gan_config(h: dict, kind: int, top_k: int = 4) -> "_lib.GanConfig":
     """AttrDict/json config (hifigan/config_16k_.json, fregan/config.json) -> mb_gan_config."""
     if str(h.get("resblock", "1")) != "1":
         raise _lib.MbHipError("only resblock type '1' is implemented (the shipped configs)")
-    if kind == 0 and int(h.get("sampling_rate", 16000)) == 24000:
-        raise _lib.MbHipError("24 kHz Interpolate+Conv1d HiFi-GAN variant (models.py:107-118) not implemented")
     c = _lib.GanConfig()
     c.kind = kind
+    # h.sampling_rate == 24000 swaps every ConvTranspose1d for Interpolate(nearest)+Conv1d (models.py:107-118)
+    c.interp_ups = int(kind == 0 and int(h.get("sampling_rate", 16000)) == 24000)
     c.num_mels = int(h.get("num_mels", 80))
     c.upsample_initial_channel = int(h["upsample_initial_channel"])
     ur, uk = list(h["upsample_rates"]), list(h["upsample_kernel_sizes"])
@@ -62,7 +62,8 @@ def gan_config(h: dict, kind: int, top_k: int = 4) -> "_lib.GanConfig":
 
 
 def gan_weight_list(state: Dict[str, torch.Tensor], cfg: "_lib.GanConfig") -> List[torch.Tensor]:
-    names = ["conv_pre"] + [f"ups.{i}" for i in range(cfg.num_upsamples)]
+    up = "ups.{}.1" if cfg.interp_ups else "ups.{}"  # Sequential(InterpolationBlock, Conv1d)  models.py:108-112
+    names = ["conv_pre"] + [up.format(i) for i in range(cfg.num_upsamples)]
     if cfg.kind == 1:
         lvl = cfg.num_upsamples - cfg.top_k
         names += [f"cond_up.{i}" for i in range(cfg.num_upsamples - lvl)]

@@ -48,13 +48,22 @@ def _up(w, name, x, u):
                               padding=u // 2 + u % 2, output_padding=u % 2)
 
 
+def _up_interp(w, name, x, u, k):
+    # h.sampling_rate == 24000: Sequential(InterpolationBlock(u), Conv1d(k, padding=(k-1)//2))
+    # models.py:74-91,107-118.  interpolate(size=T*u, mode='nearest') repeats every sample u times.
+    x = F.interpolate(x, size=x.shape[-1] * u, mode="nearest")
+    return F.conv1d(x, w[name + ".1.weight"], w[name + ".1.bias"], padding=(k - 1) // 2)
+
+
 def hifigan_forward(w, h, mel):
-    """Generator.forward, models/vocoder/hifigan/models.py:134-150.  mel [B,80,F] -> [B,1,F*hop]."""
+    """Generator.forward, models/vocoder/hifigan/models.py:134-150.  mel [B,80,F] -> [B,1,F*hop]
+    (24 kHz variant: one sample less per even-kernel upsampling stage)."""
     nk = len(h["resblock_kernel_sizes"])
+    interp = int(h.get("sampling_rate", 16000)) == 24000
     x = F.conv1d(mel, w["conv_pre.weight"], w["conv_pre.bias"], padding=3)
     for i, u in enumerate(h["upsample_rates"]):
         x = F.leaky_relu(x, LRELU_SLOPE)
-        x = _up(w, f"ups.{i}", x, u)
+        x = _up_interp(w, f"ups.{i}", x, u, h["upsample_kernel_sizes"][i]) if interp else _up(w, f"ups.{i}", x, u)
         xs = None
         for j in range(nk):
             r = _resblock1(w, f"resblocks.{i * nk + j}", x, h["resblock_kernel_sizes"][j],

@@ -47,6 +47,26 @@ def gan():
     print("gan.npz", {k: v.shape for k, v in out.items()})
 
 
+def gan24k():
+    """HiFi-GAN with h.sampling_rate == 24000: Interpolate+Conv1d upsampler (models.py:107-118)."""
+    from utils.util import AttrDict
+    from models.vocoder.hifigan.models import Generator
+    out = {}
+    for uic, frames, batch, seed in synth.GAN24K_CASES:
+        h = synth.small(synth.HIFIGAN_24K, uic)
+        st = synth.gan_state(h, "hifigan", seed=seed)
+        g = Generator(AttrDict(h))
+        g.load_state_dict(st["generator"])
+        g.eval()
+        g.remove_weight_norm()
+        mel = torch.from_numpy(synth.mel_input(frames, batch, seed=seed + 1))
+        with torch.no_grad():
+            y = g(mel)
+        out[f"hifigan24k_uic{uic}_f{frames}_b{batch}_s{seed}"] = y.numpy()
+    np.savez_compressed(os.path.join(HERE, "gan24k.npz"), torch_version=torch.__version__, **out)
+    print("gan24k.npz", {k: (v.shape, float(np.abs(v).mean())) for k, v in out.items()})
+
+
 def wavernn():
     from models.vocoder.wavernn.models.fatchord_version import WaveRNN
     from models.vocoder.wavernn import hparams as hp
@@ -171,8 +191,30 @@ def vits():
     print("vits.npz", {k: v.shape for k, v in out.items()})
 
 
+def wave():
+    """encode_16bits (wavernn/audio.py:38-39) and save_wav (synthesizer/audio.py:12-15, through
+    scipy.io.wavfile and back) run on seeded waveforms."""
+    import tempfile
+    from scipy.io import wavfile
+    import models.vocoder.wavernn.audio as wa
+    import models.synthesizer.audio as sa
+    out = {}
+    for dtype, n, peak, seed in synth.WAVE_CASES:
+        x = synth.wave_input(dtype, n, peak, seed)
+        key = f"{dtype}_n{n}_s{seed}"
+        out["encode16_" + key] = wa.encode_16bits(x.copy())
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "x.wav")
+            sa.save_wav(x.copy(), path, 16000)
+            sr, pcm = wavfile.read(path)
+        assert sr == 16000 and pcm.dtype == np.int16
+        out["savewav_" + key] = pcm
+    np.savez_compressed(os.path.join(HERE, "wave.npz"), numpy_version=np.__version__, **out)
+    print("wave.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gan", "wavernn", "maximum_path", "tacotron", "ppg2mel", "vits"]
+    which = sys.argv[1:] or ["gan", "gan24k", "wavernn", "maximum_path", "tacotron", "ppg2mel", "vits", "wave"]
     for w in which:
         if w in globals():
             globals()[w]()

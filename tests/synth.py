@@ -14,6 +14,16 @@ HIFIGAN_16K = {
     "resblock_dilation_sizes": [[1, 3, 5], [1, 3, 5], [1, 3, 5]], "num_mels": 80,
     "sampling_rate": 16000, "seed": 1234,
 }
+# The reference ships no 24 kHz json; h.sampling_rate == 24000 switches Generator to the
+# Interpolate(nearest)+Conv1d upsampler (hifigan/models.py:107-118).  Rates for hop 300 (12.5 ms @ 24 kHz);
+# kernels mix odd ("same" length) and even (the stage comes out one sample short).
+HIFIGAN_24K = {
+    "resblock": "1", "upsample_rates": [5, 5, 4, 3], "upsample_kernel_sizes": [11, 10, 8, 7],
+    "upsample_initial_channel": 512, "resblock_kernel_sizes": [3, 7, 11],
+    "resblock_dilation_sizes": [[1, 3, 5], [1, 3, 5], [1, 3, 5]], "num_mels": 80,
+    "sampling_rate": 24000, "seed": 1234,
+}
+GAN24K_CASES = ((64, 16, 2, 5), (256, 9, 1, 6))  # (upsample_initial_channel, frames, batch, seed)
 FREGAN_16K = {
     "resblock": "1", "upsample_rates": [5, 5, 2, 2, 2], "upsample_kernel_sizes": [10, 10, 4, 4, 4],
     "upsample_initial_channel": 512, "resblock_kernel_sizes": [3, 7, 11],
@@ -58,7 +68,10 @@ def gan_state(h, kind="hifigan", seed=0, top_k=4):
 
     conv("conv_pre", uic, h["num_mels"], 7, 1.0 / 1.5)
     for i, (u, k) in enumerate(zip(rates, ks)):
-        convT(f"ups.{i}", uic >> i, uic >> (i + 1), k, u, 1.3)
+        if kind == "hifigan" and int(h.get("sampling_rate", 16000)) == 24000:
+            conv(f"ups.{i}.1", uic >> (i + 1), uic >> i, k, 1.6)  # Sequential(Interpolate, Conv1d) models.py:107-118
+        else:
+            convT(f"ups.{i}", uic >> i, uic >> (i + 1), k, u, 1.3)
     if kind == "fregan":
         lvl = len(rates) - top_k
         kr = h["num_mels"]
@@ -342,3 +355,22 @@ def vits_latent(frames, batch=1, seed=0, channels=192, gin=256):
 
 
 VITS_CASES = [("uic64_t9_b2_g", 64, 9, 2, True, 3), ("uic512_t6_b1_nog", 512, 6, 1, False, 4)]
+
+
+# ---------------------------------------------------------------------------- waveform wire format
+WAVE_CASES = (("f32", 5000, 1.3, 21), ("f64", 4097, 1.1, 22), ("f32", 777, 0.004, 23), ("f64", 1, 0.7, 24))  # dtype, n, peak, seed
+
+
+def wave_input(dtype, n, peak, seed):
+    """A waveform with clipping excursions (peak > 1), exact +-1, and exact half-way points k + 0.5 of the
+    x*32768 grid (round-half-even vs truncation vs round-half-up all differ there)."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n)
+    x = peak * np.sin(0.031 * t + 0.5) * (0.6 + 0.4 * np.sin(0.0017 * t)) + 0.015 * peak * rng.standard_normal(n)
+    if n > 64 and peak >= 0.5:  # (the quiet case keeps max|x| < 0.01: save_wav's floor)
+        x[3], x[4] = 1.0, -1.0
+        ks = np.array([0, 1, 2, 3, -1, -2, -3, 100, 101, -100, -101, 32766, -32767])
+        x[10:10 + len(ks)] = (ks + 0.5) / 32768.0
+        x[30] = 32767.0 / 32768.0
+        x[31] = 0.0
+    return x.astype(np.float32 if dtype == "f32" else np.float64)

@@ -55,6 +55,35 @@ def test_gan_forward_f16_matches_oracle(cuda, lib, kind, cfg, uic, frames, batch
     assert e["nan"] == 0 and e["rel_rms"] <= F16_REL_TOL, e
 
 
+def _len24k(h, frames):
+    t = frames
+    for u, k in zip(h["upsample_rates"], h["upsample_kernel_sizes"]):
+        t = t * u + 2 * ((k - 1) // 2) - (k - 1)
+    return t
+
+
+@pytest.mark.parametrize("uic,frames,batch,seed", list(synth.GAN24K_CASES) + [(128, 31, 3, 9)])
+def test_hifigan_24k_interp_upsampler_matches_oracle(cuda, lib, uic, frames, batch, seed):
+    """h.sampling_rate == 24000 (hifigan/models.py:107-118): nearest-interpolate + Conv1d upsampler, folded
+    into the conv's read.  Even upsample kernels leave each stage one sample short, as the reference's does."""
+    h = synth.small(synth.HIFIGAN_24K, uic)
+    y, ref = _run("hifigan", h, frames, batch, seed=seed)
+    assert y.shape == ref.shape == (batch, 1, _len24k(h, frames))
+    assert y.shape[-1] < frames * 300
+    e = hiputil.relerr(y, ref)
+    assert e["nan"] == 0 and e["rms"] <= RMS_TOL and e["rel_rms"] <= REL_TOL, e
+
+
+@pytest.mark.parametrize("uic,frames,batch", [(128, 16, 2), (512, 23, 1)])
+def test_hifigan_24k_f16_matches_oracle(cuda, lib, uic, frames, batch):
+    h = synth.small(synth.HIFIGAN_24K, uic)
+    y, ref = _run("hifigan", h, frames, batch, seed=4, dtype="f16")
+    assert y.shape == ref.shape == (batch, 1, _len24k(h, frames))
+    e = hiputil.relerr(y, ref)
+    print("f16 24k parity", uic, frames, batch, e)
+    assert e["nan"] == 0 and e["rel_rms"] <= F16_REL_TOL, e
+
+
 def test_gan_f16_rejects_narrow_channels(cuda, lib):
     """A model whose last stage is narrower than 8 channels cannot take the fp16 layout: creation
     fails loudly (no silent fp32 fallback)."""

@@ -25,9 +25,10 @@ def test_fold_weight_norm_matches_torch():
 
 def test_gan_weight_list_matches_abi_counts(lib):
     from mockingbird_amd import weights
-    for kind, cfg in (("hifigan", synth.HIFIGAN_16K), ("fregan", synth.FREGAN_16K)):
+    for kind, cfg in (("hifigan", synth.HIFIGAN_16K), ("fregan", synth.FREGAN_16K), ("hifigan", synth.HIFIGAN_24K)):
         h = synth.small(cfg, 32)
         c = weights.gan_config(h, 0 if kind == "hifigan" else 1)
+        assert c.interp_ups == int(cfg is synth.HIFIGAN_24K)  # models.py:107: only h.sampling_rate == 24000
         ws = weights.gan_weight_list(synth.gan_state(h, kind, seed=1)["generator"], c)
         assert lib.mb_gan_num_weights(C.byref(c)) == len(ws)
         for i, w in enumerate(ws):

@@ -33,6 +33,22 @@ def test_gan_oracle_vs_golden(key):
     assert np.sqrt((gold ** 2).mean()) > 0.05  # fixture is O(0.1..1), tolerances are not vacuous
 
 
+@pytest.mark.parametrize("case", synth.GAN24K_CASES)
+def test_hifigan_24k_oracle_vs_golden(case):
+    """h.sampling_rate == 24000 -> Interpolate+Conv1d upsampler (hifigan/models.py:107-118)."""
+    uic, f, b, s = case
+    gold = np.load(os.path.join(G, "gan24k.npz"))[f"hifigan24k_uic{uic}_f{f}_b{b}_s{s}"]
+    h = synth.small(synth.HIFIGAN_24K, uic)
+    st = synth.gan_state(h, "hifigan", seed=s)
+    w = og.fold_weight_norm_state(st["generator"])
+    mel = torch.from_numpy(synth.mel_input(f, b, seed=s + 1))
+    with torch.no_grad():
+        y = og.hifigan_forward(w, h, mel).numpy()
+    assert y.shape == gold.shape and y.shape[-1] < f * 300  # even kernels: one sample short per stage
+    assert np.abs(y - gold).max() <= 2e-6, np.abs(y - gold).max()
+    assert np.sqrt((gold ** 2).mean()) > 0.05
+
+
 def test_wavernn_oracle_vs_golden():
     gold = np.load(os.path.join(G, "wavernn.npz"))
     st = synth.wavernn_state(seed=5)
@@ -221,3 +237,27 @@ def test_vits_generator_oracle_vs_golden(case):
         y = og.vits_generator_forward(w, h, torch.from_numpy(z), torch.from_numpy(spk) if use_g else None)
     assert y.shape == gold.shape == (batch, 1, frames * 256)
     assert float(np.abs(y.numpy() - gold).max()) <= 1e-6
+
+
+@pytest.mark.parametrize("case", synth.WAVE_CASES)
+def test_wave_oracle_vs_golden(case):
+    """encode_16bits / save_wav restatements against the reference functions' own int16 output."""
+    from oracle import wave as owv
+    dtype, n, peak, seed = case
+    gold = np.load(os.path.join(G, "wave.npz"))
+    x = synth.wave_input(dtype, n, peak, seed)
+    key = f"{dtype}_n{n}_s{seed}"
+    assert np.array_equal(owv.encode_16bits(x), gold["encode16_" + key])
+    assert np.array_equal(owv.save_wav_pcm(x), gold["savewav_" + key])
+    if peak < 0.01:
+        assert np.abs(gold["savewav_" + key]).max() < 32767  # the 0.01 floor was the divisor
+
+
+def test_sndfile_pcm16_known_answers():
+    """libsndfile's clip path (unpinned restatement, oracle/wave.py): hand-computed cases."""
+    from oracle import wave as owv
+    for dt in (np.float32, np.float64):
+        x = np.array([0.0, 1.0, -1.0, 2.0, -2.0, 0.5 / 32768, 1.5 / 32768, 2.5 / 32768, -0.5 / 32768, -1.5 / 32768,
+                      32766.5 / 32768, 32767.0 / 32768, 0.25, -0.25], dt)
+        want = np.array([0, 32767, -32768, 32767, -32768, 0, 2, 2, 0, -2, 32766, 32767, 8192, -8192], np.int16)
+        assert np.array_equal(owv.sndfile_pcm16(x), want)

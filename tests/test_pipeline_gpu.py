@@ -50,3 +50,10 @@ def test_gen_wavs_single_rank(cuda, lib, tmp_path):
     assert sr == 16000
     hand = pipeline.insert_breaks(wav, [specs[0].shape[1]], hop, 16000).astype(np.float32)
     assert hand.shape == wavs[1].shape
+    # wire format on device: the same requests as peak-normalised int16 PCM equal the
+    # numpy tail applied to the float waveforms above (normalise per request before the zero gaps, then PCM_16)
+    from oracle import wave as owv
+    pcm = pipeline.gen_wavs(syn, voc, requests, steps=24, min_stop_token=11, normalize=0.97, pcm16="sndfile")
+    for p, w in zip(pcm, wavs):
+        assert p.dtype == np.int16 and p.shape == w.shape
+        assert np.array_equal(p, owv.sndfile_pcm16(owv.peak_normalize(w, np.float32(0.97))))

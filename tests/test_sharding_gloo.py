@@ -3,6 +3,7 @@ import os
 import socket
 import sys
 
+import pytest
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -58,8 +59,15 @@ class _StubSynth:
 
 
 class _StubVocoder:
-    def infer_waveform_batch(self, mels):
-        return [np.repeat(m[0], 200).astype(np.float32) for m in mels], 16000
+    def infer_waveform_batch(self, mels, normalize=None, pcm16=None):
+        wavs = [np.sin(np.arange(m.shape[1] * 200) * 0.01 * m[0, 0]).astype(np.float32) * 0.5 for m in mels]
+        if normalize is not None:  # CPU stand-in for vocoder/wave.py (the oracle is the checker here)
+            from oracle import wave as owv
+            wavs = [owv.peak_normalize(w, normalize) for w in wavs]
+        if pcm16 is not None:
+            from oracle import wave as owv
+            wavs = [owv.sndfile_pcm16(w) for w in wavs]
+        return wavs, 16000
 
 
 def _requests():
@@ -71,23 +79,26 @@ def _requests():
     return reqs
 
 
-def _pipeline_worker(rank, world, port, q):
+def _pipeline_worker(rank, world, port, q, kw):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from mockingbird_amd import pipeline
-    out = pipeline.gen_wavs(_StubSynth(), _StubVocoder(), _requests())
-    q.put((rank, [w.tolist() for w in out]))
+    out = pipeline.gen_wavs(_StubSynth(), _StubVocoder(), _requests(), **kw)
+    q.put((rank, [(str(w.dtype), w.tolist()) for w in out]))
     dist.destroy_process_group()
 
 
-def test_pipeline_gen_wavs_world2_matches_single_process():
+@pytest.mark.parametrize("kw", [{}, {"normalize": 0.97, "pcm16": "sndfile"}], ids=["float32", "pcm16"])
+def test_pipeline_gen_wavs_world2_matches_single_process(kw):
     """configs[3] plumbing: requests sharded over 2 ranks come back complete and in request order, equal to
-    the single-process result, with gen_voice.py's 0.15 s breaks after every sentence."""
+    the single-process result, with gen_voice.py's 0.15 s breaks after every sentence -- as float32, and as
+    int16 PCM on the wire (half the gather bytes)."""
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from mockingbird_amd import pipeline
-    ref = pipeline.gen_wavs(_StubSynth(), _StubVocoder(), _requests())
+    ref = pipeline.gen_wavs(_StubSynth(), _StubVocoder(), _requests(), **kw)
+    want_dtype = np.int16 if kw else np.float32
     reqs = _requests()
     for w, (texts, emb) in zip(ref, reqs):
         assert len(w) == sum(2 * len(t) * 200 for t in texts) + len(texts) * int(0.15 * 16000)
@@ -95,7 +106,7 @@ def test_pipeline_gen_wavs_world2_matches_single_process():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, q, kw)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=120) for _ in procs)
@@ -103,5 +114,8 @@ def test_pipeline_gen_wavs_world2_matches_single_process():
         p.join(30)
     for r in (0, 1):
         assert len(res[r]) == len(ref)
-        for a, b in zip(res[r], ref):
-            assert np.array_equal(np.asarray(a, np.float32), b.astype(np.float32))
+        for (dt, a), b in zip(res[r], ref):
+            assert dt == np.dtype(want_dtype).name and b.dtype == want_dtype
+            assert np.array_equal(np.asarray(a, want_dtype), b)
+    if kw:
+        assert max(int(np.abs(b).max()) for b in ref) == round(0.97 * 32768)
