@@ -60,7 +60,8 @@ def test_full_size_properties(cuda, lib):
         assert torch.equal(p, -q)
         order = torch.argsort(y)
         assert bool((p[order][1:] >= p[order][:-1]).all())
-    assert int(wave.pack_pcm16(y, "save_wav").abs().max()) == 32767
+    # peak * fl(32767 / peak) may round just below 32767 and truncate: numpy does the same
+    assert int(wave.pack_pcm16(y, "save_wav").abs().max()) in (32766, 32767)
 
 
 def test_errors(cuda, lib):
