@@ -11,7 +11,7 @@
 // Hence: (1) the kernel is specialised at compile time on the feature set the caller uses (F), so a
 // launch executes straight-line code with no dead branches; (2) every load is issued before the
 // first wait; (3) nothing the previous launch wrote is read except the activations themselves.
-#include "rnn_body.h"
+#include "rnn_ts2_body.h"
 
 namespace mb {
 
@@ -113,6 +113,24 @@ __global__ __launch_bounds__(512) void rnn_dual_linear_ts_kernel(RnnDev d0, RnnD
   if ((int)blockIdx.x < nx0) rnn_rowtile_body<EPI_LINEAR, 1, 8, F0, true>(d0, blockIdx.x, blockIdx.y);
   else rnn_rowtile_body<EPI_LINEAR, 1, 8, F1, true>(d1, blockIdx.x - nx0, blockIdx.y);
 }
+// Register-tiled wide form (rnn_ts2_body.h): 4 waves, each MT row tiles x NT column tiles, one workgroup per CU
+template <int EPI, unsigned F, int MT, int NT>
+__global__ __launch_bounds__(256) void rnn_ts2_kernel(RnnDev d) {
+  rnn_ts2_body<EPI, F, MT, NT>(d, blockIdx.x, blockIdx.y);
+}
+template <unsigned F0, unsigned F1, int MT, int NT>
+__global__ __launch_bounds__(256) void rnn_dual_linear_ts2_kernel(RnnDev d0, RnnDev d1, int nx0) {
+  if ((int)blockIdx.x < nx0) rnn_ts2_body<EPI_LINEAR, F0, MT, NT>(d0, blockIdx.x, blockIdx.y);
+  else rnn_ts2_body<EPI_LINEAR, F1, MT, NT>(d1, blockIdx.x - nx0, blockIdx.y);
+}
+static unsigned rnn_ts2_lds() {  // diagnostics: dynamic LDS per workgroup (limits workgroups per CU)
+  const char* e = getenv("MBHIP_TS2_LDS");
+  return e ? (unsigned)atoi(e) : 0u;
+}
+static bool rnn_ts2_enabled() {  // default; MBHIP_RNN_TS2=0 selects the first wide form (rnn_body.h TS) for A/B runs
+  const char* e = getenv("MBHIP_RNN_TS2");
+  return !(e && atoi(e) == 0);
+}
 static bool rnn_ts_enabled(int N) {
   const char* e = getenv("MBHIP_RNN_TS");
   return N > 64 && !(e && atoi(e) == 0);
@@ -203,6 +221,14 @@ int rnn_launch_dual_linear(const RnnK& k0, const RnnK& k1, hipStream_t s) {
   const int pw0 = cdiv(k0.nkb_total, NW), pw1 = cdiv(k1.nkb_total, NW);
   MB_REQUIRE((f0 == F0 || f0 == (F0 | RF_FOLDTAB)) && f1 == F1 && pw0 == 4 && pw1 == 4,
              "rnn_launch_dual: only the (relu table linear, biased linear) K=512 pair is instantiated (features %x/%x)", f0, f1);
+  if (f0 == (F0 | RF_FOLDTAB) && rnn_ts_enabled(k0.N) && rnn_ts2_enabled() && k0.nkb_total % 8 == 0 && k1.nkb_total % 8 == 0) {
+    constexpr int MT = 2, NT = 3;  // 8 row tiles x 3 column tiles per workgroup (rnn_ts2_body.h)
+    dim3 g2(cdiv(nx0, MT * TS2_WAVES) + cdiv(nx1, MT * TS2_WAVES), cdiv(cdiv(k0.N, 16), NT));
+    MB_REQUIRE(k0.nkb_total == k1.nkb_total, "rnn_launch_dual(ts2): jobs must share K");
+    hipLaunchKernelGGL((rnn_dual_linear_ts2_kernel<F0 | RF_FOLDTAB, F1, MT, NT>), g2, dim3(256), rnn_ts2_lds(), s, d0, d1, cdiv(nx0, MT * TS2_WAVES));
+    MB_HIP(hipGetLastError());
+    return MB_OK;
+  }
   if (f0 == (F0 | RF_FOLDTAB) && rnn_ts_enabled(k0.N) && k0.nkb_total % 8 == 0 && k1.nkb_total % 8 == 0) {  // wide batch: tile-split form, 2 row tiles x 4 column tiles per workgroup
     dim3 gts(cdiv(nx0, 2) + cdiv(nx1, 2), cdiv(cdiv(k0.N, 16), 4));
     MB_REQUIRE(k0.nkb_total == k1.nkb_total, "rnn_launch_dual(ts): jobs must share K");
@@ -287,7 +313,17 @@ int rnn_launch(int epi, const RnnK& k, hipStream_t s) {
     constexpr unsigned FG = RF_PRE | RF_FRAME | RF_HPRE | RF_XRES | RF_XOUT | RF_ZERO | RF_FOLDTAB;
     constexpr unsigned FL = RF_BIASX | RF_FRAME | RF_GUMBEL | RF_FOLDTAB;
     dim3 gts(cdiv(n_mt, 2), cdiv(cdiv(k.N, 16), 4));
-    if (epi == EPI_GRU && feat == FG) { hipLaunchKernelGGL((rnn_ts_kernel<EPI_GRU, FG>), gts, dim3(NW * 64), 0, s, d); done = true; }
+    if (rnn_ts2_enabled()) {
+      if (epi == EPI_GRU && feat == FG) {  // rnn2: 128 row tiles -> 2 x 3 tiles per wave
+        dim3 g2(cdiv(n_mt, 2 * TS2_WAVES), cdiv(cdiv(k.N, 16), 3));
+        hipLaunchKernelGGL((rnn_ts2_kernel<EPI_GRU, FG, 2, 3>), g2, dim3(256), rnn_ts2_lds(), s, d); done = true;
+      } else if (epi == EPI_LINEAR && feat == FL) {  // fc3 + sampler: 32 row tiles only -> 1 x 2 tiles per wave
+        dim3 g2(cdiv(n_mt, 1 * TS2_WAVES), cdiv(cdiv(k.N, 16), 2));
+        hipLaunchKernelGGL((rnn_ts2_kernel<EPI_LINEAR, FL, 1, 2>), g2, dim3(256), rnn_ts2_lds(), s, d); done = true;
+      }
+    }
+    if (done) {}
+    else if (epi == EPI_GRU && feat == FG) { hipLaunchKernelGGL((rnn_ts_kernel<EPI_GRU, FG>), gts, dim3(NW * 64), 0, s, d); done = true; }
     else if (epi == EPI_LINEAR && feat == FL) { hipLaunchKernelGGL((rnn_ts_kernel<EPI_LINEAR, FL>), gts, dim3(NW * 64), 0, s, d); done = true; }
   }
 #define MB_TRY(EPI_, NT_, UB_, F_)                                                                         \

@@ -13,6 +13,8 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p
 find gpurun_out/prof -name '*kernel_stats*' | head
 find gpurun_out/prof -type f ! -name '*stats*' -delete
 # HBM traffic counters: tools/pmc_run.sh (counter mode segfaults on hipGraph replays -> MBHIP_NO_GRAPH=1 there)
+if [ -z "${SKIP_PMC:-}" ]; then
 bash tools/pmc_run.sh
 python tools/pmc_wavernn_json.py
+fi
 tail -3 gpurun_out/pytest_gpu.log
