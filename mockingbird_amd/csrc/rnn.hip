@@ -113,6 +113,10 @@ __global__ __launch_bounds__(512) void rnn_dual_linear_ts_kernel(RnnDev d0, RnnD
   if ((int)blockIdx.x < nx0) rnn_rowtile_body<EPI_LINEAR, 1, 8, F0, true>(d0, blockIdx.x, blockIdx.y);
   else rnn_rowtile_body<EPI_LINEAR, 1, 8, F1, true>(d1, blockIdx.x - nx0, blockIdx.y);
 }
+#ifndef MB_TS2_FC3_MT
+#define MB_TS2_FC3_MT 2  // wave tile of the fc3 + sampler launch (32 row tiles only; 1x1, 1x2, 1x3 measured no better)
+#define MB_TS2_FC3_NT 1
+#endif
 // Register-tiled wide form (rnn_ts2_body.h): 4 waves, each MT row tiles x NT column tiles, one workgroup per CU
 template <int EPI, unsigned F, int MT, int NT>
 __global__ __launch_bounds__(256) void rnn_ts2_kernel(RnnDev d) {
@@ -318,8 +322,8 @@ int rnn_launch(int epi, const RnnK& k, hipStream_t s) {
         dim3 g2(cdiv(n_mt, 2 * TS2_WAVES), cdiv(cdiv(k.N, 16), 3));
         hipLaunchKernelGGL((rnn_ts2_kernel<EPI_GRU, FG, 2, 3>), g2, dim3(256), rnn_ts2_lds(), s, d); done = true;
       } else if (epi == EPI_LINEAR && feat == FL) {  // fc3 + sampler: 32 row tiles only -> 1 x 2 tiles per wave
-        dim3 g2(cdiv(n_mt, 1 * TS2_WAVES), cdiv(cdiv(k.N, 16), 2));
-        hipLaunchKernelGGL((rnn_ts2_kernel<EPI_LINEAR, FL, 1, 2>), g2, dim3(256), rnn_ts2_lds(), s, d); done = true;
+        dim3 g2(cdiv(n_mt, MB_TS2_FC3_MT * TS2_WAVES), cdiv(cdiv(k.N, 16), MB_TS2_FC3_NT));
+        hipLaunchKernelGGL((rnn_ts2_kernel<EPI_LINEAR, FL, MB_TS2_FC3_MT, MB_TS2_FC3_NT>), g2, dim3(256), rnn_ts2_lds(), s, d); done = true;
       }
     }
     if (done) {}

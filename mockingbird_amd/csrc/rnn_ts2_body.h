@@ -33,6 +33,9 @@
 namespace mb {
 
 constexpr int TS2_WAVES = 4;  // waves per workgroup, stacked along the rows
+#ifndef MB_TS2_TAIL
+#define MB_TS2_TAIL 2  // 4 (all four tail fragments in flight under the operand loads) measured 3 % slower
+#endif
 
 template <int EPI, unsigned F, int MT, int NT>
 __device__ __forceinline__ void rnn_ts2_body(const RnnDev& d, const int bx, const int by) {
@@ -47,6 +50,7 @@ __device__ __forceinline__ void rnn_ts2_body(const RnnDev& d, const int bx, cons
   constexpr bool f_xres = (F & RF_XRES) != 0, f_xout = (F & RF_XOUT) != 0, f_gum = (F & RF_GUMBEL) != 0;
   constexpr bool f_zero = (F & RF_ZERO) != 0, f_hpre = (F & RF_HPRE) != 0, f_ftab = (F & RF_FOLDTAB) != 0;
   constexpr int act = (int)((F >> RF_ACT_SHIFT) & 3);
+  constexpr int TAIL = MB_TS2_TAIL;  // k-steps (2 or 4) left to run when the epilogue operands are requested
   const RnnK& a = d.k;
 
   trace_begin(a.trace);
@@ -100,8 +104,14 @@ __device__ __forceinline__ void rnn_ts2_body(const RnnDev& d, const int bx, cons
     const int kb0 = 8 * r + 2 * p;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
+#ifdef MB_TS2_DIAG_NOLOAD_A
+      if (it < 2)
+#endif
 #pragma unroll
       for (int m = 0; m < MT; ++m) f.a[m][c] = *reinterpret_cast<const float4*>(wA[m] + (size_t)(kb0 + c) * BLK);
+#ifdef MB_TS2_DIAG_NOLOAD_B
+      if (it < 2)
+#endif
 #pragma unroll
       for (int n = 0; n < NT; ++n) f.b[n][c] = *reinterpret_cast<const float4*>(pB[n] + (kb0 + c) * 16);
     }
@@ -149,9 +159,9 @@ __device__ __forceinline__ void rnn_ts2_body(const RnnDev& d, const int bx, cons
   // not latency-bound).  The scheduling barriers keep each step's loads in front of the MFMAs they overlap; left
   // alone, the scheduler sinks them to the end of the MFMA block.  No branches around loads: they make the
   // waitcnt pass assume the worst and drain the new loads too.
-  Frag f0, f1;
+  Frag f0, f1, f2, f3;
   if (NIT) issue(f0, 0);
-  for (int it = 0; it + 2 < NIT; it += 2) {  // NIT = 4R is even; the last two steps follow the operand loads
+  for (int it = 0; it + TAIL < NIT; it += 2) {  // NIT = 4R; the last TAIL steps follow the operand loads
     issue(f1, it + 1);
     __builtin_amdgcn_sched_barrier(0);
     consume(f0, it);
@@ -161,7 +171,11 @@ __device__ __forceinline__ void rnn_ts2_body(const RnnDev& d, const int bx, cons
     consume(f1, it + 1);
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (NIT) issue(f1, NIT - 1);
+  // the fragments of the last TAIL steps are all requested here, so that the operand loads can queue behind them
+  if (NIT) {
+    issue(f1, NIT - TAIL + 1);
+    if (TAIL == 4) { issue(f2, NIT - 2); issue(f3, NIT - 1); }
+  }
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- epilogue operands of the MT x NT tiles: requested behind the LAST fragment loads (vector memory
@@ -220,8 +234,9 @@ __device__ __forceinline__ void rnn_ts2_body(const RnnDev& d, const int bx, cons
 #endif
   __builtin_amdgcn_sched_barrier(0);
   if (NIT) {
-    consume(f0, NIT - 2);
-    consume(f1, NIT - 1);
+    consume(f0, NIT - TAIL);
+    consume(f1, NIT - TAIL + 1);
+    if (TAIL == 4) { consume(f2, NIT - 2); consume(f3, NIT - 1); }
   }
 
 #ifdef MB_TS2_DIAG_NOEPI
