@@ -2,7 +2,7 @@
 // utterances in one WaveRNN loop, mb_wavernn_generate_batch).  Same packed weights, same epilogues and --
 // bit for bit -- the same sums as rnn_rowtile_body (rnn_body.h); only the walk over the work differs.
 //
-// Why (measured at 736 columns, tools/_diag.sh variants, profiles/r01_wavernn_batch_ts2.md): the first wide
+// Why (measured at 736 columns, tools/variant_bench.sh variants, profiles/r01_wavernn_batch_ts2.md): the first wide
 // form (rnn_body.h TS: one 16x16 MFMA tile per wave, whole K) ran at 15-23 % of the fp32 MFMA peak.  Taking it
 // apart: (1) 8 fragment loads feed only 32 MFMAs and nothing is reused from registers; (2) 768 workgroups on
 // 256 CUs packed 2-3 per CU thrash each other's L1 (one workgroup per CU alone: -18 %); (3) the work came in

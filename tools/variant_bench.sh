@@ -1,3 +1,6 @@
+#!/bin/bash
+# Batch-32 WaveRNN step time for variant libraries built by tools/build_variant.sh.
+# usage: tools/variant_bench.sh "<variant> [ENV=value ...]" ...
 # usage: _diag.sh "<variant> [ENV=..]" ...
 for spec in "$@"; do
 set -- $spec; v=$1; shift
