@@ -132,3 +132,26 @@ def test_wavernn_finish_workspace_and_shape_errors(lib):
     got = C.c_int()
     rc = L.mb_wavernn_finish(None, 1, 100, 0, 0, 512, 1, 1, 0.97, 50, 10, None, C.byref(got), None, 0, None)
     assert rc < 0 and b"null pointer" in L.mb_last_error()
+
+
+def test_wave_wire_format_has_no_cpu_path(lib):
+    """vocoder/wave.py refuses host tensors and unknown encodings loudly (no numpy fallback in the product)."""
+    from mockingbird_amd.vocoder import wave
+    from mockingbird_amd._lib import MbHipError
+    with pytest.raises(MbHipError, match="no CPU path"):
+        wave.pack_pcm16(torch.zeros(8))
+    with pytest.raises(MbHipError, match="no CPU path"):
+        wave.peak_normalize_(torch.zeros(8, dtype=torch.float64))
+    with pytest.raises(ValueError, match="mode must be one of"):
+        wave.pack_pcm16(torch.zeros(8), "pcm24")
+    assert lib.mb_wave_workspace_bytes() >= 8
+
+
+def test_gan_out_samples_rule_24k():
+    """Length rule of the 24 kHz upsampler (models.py:107-112): T*u + 2*((k-1)//2) - (k-1) per stage."""
+    t = 16
+    for u, k in zip(synth.HIFIGAN_24K["upsample_rates"], synth.HIFIGAN_24K["upsample_kernel_sizes"]):
+        t = t * u + 2 * ((k - 1) // 2) - (k - 1)
+    import numpy as np, os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "gan24k.npz"))
+    assert g["hifigan24k_uic64_f16_b2_s5"].shape[-1] == t == 4785
