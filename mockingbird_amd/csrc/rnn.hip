@@ -131,9 +131,18 @@ static unsigned rnn_ts2_lds() {  // diagnostics: dynamic LDS per workgroup (limi
   const char* e = getenv("MBHIP_TS2_LDS");
   return e ? (unsigned)atoi(e) : 0u;
 }
-static bool rnn_ts2_enabled() {  // default; MBHIP_RNN_TS2=0 selects the first wide form (rnn_body.h TS) for A/B runs
+// Column tiles per wave of the register-tiled wide form, 0 = use the first wide form (rnn_body.h TS).
+// 128 row tiles in pieces of 2 make 16 workgroup rows, so the piece must be narrow enough for >= 256 workgroups:
+// 3 column tiles from 44 column tiles up (736 columns: exactly one piece per SIMD), 2 from 28, 1 from 14; narrower
+// batches keep the 8-wave one-tile-per-wave form, which cuts the same work into four times as many workgroups.
+// MBHIP_RNN_TS2=0 forces that form, MBHIP_TS2_NT=1|2|3 forces a piece width (parity tests, A/B runs).
+static int rnn_ts2_nt(int N) {
   const char* e = getenv("MBHIP_RNN_TS2");
-  return !(e && atoi(e) == 0);
+  if (e && atoi(e) == 0) return 0;
+  const char* f = getenv("MBHIP_TS2_NT");
+  if (f && atoi(f) >= 1 && atoi(f) <= 3) return atoi(f);
+  const int ct = cdiv(N, 16);
+  return ct >= 44 ? 3 : ct >= 28 ? 2 : ct >= 14 ? 1 : 0;
 }
 static bool rnn_ts_enabled(int N) {
   const char* e = getenv("MBHIP_RNN_TS");
@@ -225,11 +234,15 @@ int rnn_launch_dual_linear(const RnnK& k0, const RnnK& k1, hipStream_t s) {
   const int pw0 = cdiv(k0.nkb_total, NW), pw1 = cdiv(k1.nkb_total, NW);
   MB_REQUIRE((f0 == F0 || f0 == (F0 | RF_FOLDTAB)) && f1 == F1 && pw0 == 4 && pw1 == 4,
              "rnn_launch_dual: only the (relu table linear, biased linear) K=512 pair is instantiated (features %x/%x)", f0, f1);
-  if (f0 == (F0 | RF_FOLDTAB) && rnn_ts_enabled(k0.N) && rnn_ts2_enabled() && k0.nkb_total % 8 == 0 && k1.nkb_total % 8 == 0) {
-    constexpr int MT = 2, NT = 3;  // 8 row tiles x 3 column tiles per workgroup (rnn_ts2_body.h)
-    dim3 g2(cdiv(nx0, MT * TS2_WAVES) + cdiv(nx1, MT * TS2_WAVES), cdiv(cdiv(k0.N, 16), NT));
+  const int nt2 = rnn_ts_enabled(k0.N) ? rnn_ts2_nt(k0.N) : 0;
+  if (f0 == (F0 | RF_FOLDTAB) && nt2 && k0.nkb_total % 8 == 0 && k1.nkb_total % 8 == 0) {
+    constexpr int MT = 2;  // workgroup = 8 row tiles x nt2 column tiles (rnn_ts2_body.h)
+    dim3 g2(cdiv(nx0, MT * TS2_WAVES) + cdiv(nx1, MT * TS2_WAVES), cdiv(cdiv(k0.N, 16), nt2));
     MB_REQUIRE(k0.nkb_total == k1.nkb_total, "rnn_launch_dual(ts2): jobs must share K");
-    hipLaunchKernelGGL((rnn_dual_linear_ts2_kernel<F0 | RF_FOLDTAB, F1, MT, NT>), g2, dim3(256), rnn_ts2_lds(), s, d0, d1, cdiv(nx0, MT * TS2_WAVES));
+    const int nxw = cdiv(nx0, MT * TS2_WAVES);
+    if (nt2 == 3) hipLaunchKernelGGL((rnn_dual_linear_ts2_kernel<F0 | RF_FOLDTAB, F1, MT, 3>), g2, dim3(256), rnn_ts2_lds(), s, d0, d1, nxw);
+    else if (nt2 == 2) hipLaunchKernelGGL((rnn_dual_linear_ts2_kernel<F0 | RF_FOLDTAB, F1, MT, 2>), g2, dim3(256), rnn_ts2_lds(), s, d0, d1, nxw);
+    else hipLaunchKernelGGL((rnn_dual_linear_ts2_kernel<F0 | RF_FOLDTAB, F1, MT, 1>), g2, dim3(256), rnn_ts2_lds(), s, d0, d1, nxw);
     MB_HIP(hipGetLastError());
     return MB_OK;
   }
@@ -317,11 +330,14 @@ int rnn_launch(int epi, const RnnK& k, hipStream_t s) {
     constexpr unsigned FG = RF_PRE | RF_FRAME | RF_HPRE | RF_XRES | RF_XOUT | RF_ZERO | RF_FOLDTAB;
     constexpr unsigned FL = RF_BIASX | RF_FRAME | RF_GUMBEL | RF_FOLDTAB;
     dim3 gts(cdiv(n_mt, 2), cdiv(cdiv(k.N, 16), 4));
-    if (rnn_ts2_enabled()) {
-      if (epi == EPI_GRU && feat == FG) {  // rnn2: 128 row tiles -> 2 x 3 tiles per wave
-        dim3 g2(cdiv(n_mt, 2 * TS2_WAVES), cdiv(cdiv(k.N, 16), 3));
-        hipLaunchKernelGGL((rnn_ts2_kernel<EPI_GRU, FG, 2, 3>), g2, dim3(256), rnn_ts2_lds(), s, d); done = true;
-      } else if (epi == EPI_LINEAR && feat == FL) {  // fc3 + sampler: 32 row tiles only -> 1 x 2 tiles per wave
+    if (const int nt2 = rnn_ts2_nt(k.N)) {
+      if (epi == EPI_GRU && feat == FG) {  // rnn2: 128 row tiles -> 2 x nt2 tiles per wave
+        dim3 g2(cdiv(n_mt, 2 * TS2_WAVES), cdiv(cdiv(k.N, 16), nt2));
+        if (nt2 == 3) hipLaunchKernelGGL((rnn_ts2_kernel<EPI_GRU, FG, 2, 3>), g2, dim3(256), rnn_ts2_lds(), s, d);
+        else if (nt2 == 2) hipLaunchKernelGGL((rnn_ts2_kernel<EPI_GRU, FG, 2, 2>), g2, dim3(256), rnn_ts2_lds(), s, d);
+        else hipLaunchKernelGGL((rnn_ts2_kernel<EPI_GRU, FG, 2, 1>), g2, dim3(256), rnn_ts2_lds(), s, d);
+        done = true;
+      } else if (epi == EPI_LINEAR && feat == FL) {  // fc3 + sampler: 32 row tiles only -> 2 x 1 tiles per wave at every width
         dim3 g2(cdiv(n_mt, MB_TS2_FC3_MT * TS2_WAVES), cdiv(cdiv(k.N, 16), MB_TS2_FC3_NT));
         hipLaunchKernelGGL((rnn_ts2_kernel<EPI_LINEAR, FL, MB_TS2_FC3_MT, MB_TS2_FC3_NT>), g2, dim3(256), rnn_ts2_lds(), s, d); done = true;
       }

@@ -250,18 +250,26 @@ def test_batch_loop_equals_single_utterance_runs(model):
         assert wv.dtype == np.float64 and np.isfinite(wv).all() and len(wv) <= (f - 1) * 256
 
 
-def test_wide_batch_tile_split_equals_single_runs(model):
-    """More than 64 columns: the loop switches to the tile-split launches (2 row tiles x 4 column tiles per
-    workgroup, every wave runs the whole K in the same 8 accumulation chains as the K-split form), so each
-    utterance must still equal its own single-utterance run bit for bit."""
+@pytest.mark.parametrize("form", ["auto", "ts", "ts2_nt1", "ts2_nt2", "ts2_nt3"])
+def test_wide_batch_tile_split_equals_single_runs(model, monkeypatch, form):
+    """More than 64 columns: the loop switches to the wide forms of the recurrent GEMM -- rnn_body.h TS (one tile
+    per wave) or rnn_ts2_body.h (2 x NT tiles per wave, NT chosen by the width; forced here so that every
+    instantiated piece width is exercised at 76 columns).  All of them walk the same 8 accumulation chains as
+    the K-split form, so each utterance must still equal its own single-utterance run bit for bit."""
     dev, w = model
+    if form == "ts":
+        monkeypatch.setenv("MBHIP_RNN_TS2", "0")
+    elif form.startswith("ts2_nt"):
+        monkeypatch.setenv("MBHIP_TS2_NT", form[-1])
     frames = [100, 93, 100, 77]
     mels = [torch.from_numpy(synth.wavernn_mel(f, seed=40 + i) / 4.0).cuda() for i, f in enumerate(frames)]
     seeds = [3, 1, 4, 1]
     outs = dev.generate_samples_batch(mels, 1000, 100, seeds)
     assert dev.last_batch_plan.n_folds > 64
+    monkeypatch.delenv("MBHIP_RNN_TS2", raising=False)
+    monkeypatch.delenv("MBHIP_TS2_NT", raising=False)
     for u in (0, 1, 3):
         single = dev.generate_samples(mels[u], True, 1000, 100, seed=seeds[u])
-        assert torch.equal(outs[u], single), (u, int((outs[u] != single).sum()))
+        assert torch.equal(outs[u], single), (form, u, int((outs[u] != single).sum()))
     # utterances 0 and 2 have different mels but equal length; 1 and 3 share a seed but not a mel
     assert not torch.equal(outs[0], outs[2])
