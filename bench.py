@@ -197,6 +197,17 @@ def main():
                 "us_per_fold_step": model.last_loop_ms * 1e3 / bp.seq_len / bp.n_folds,
                 "workspace_GB": bp.workspace_bytes / 1e9,
             }
+            # at this width the loop is MFMA-bound, not latency-bound: price it against the fp32 matrix peak.
+            # Algorithmic flops per fold and step = the six products of the split chain (table-folded inputs and
+            # the GRU tiles' dead fourth row not counted): rnn2 input half, hh1, hh2 (3R x R each), fc1, fc2, fc3
+            R_, FC_, C_ = model.cfg.rnn_dims, model.cfg.fc_dims, model.n_classes
+            fl = 2.0 * (3 * (3 * R_ * R_) + FC_ * R_ + FC_ * FC_ + C_ * FC_) * bp.n_folds
+            tf = fl / (result["wavernn_batch32"]["us_per_time_step"] * 1e-6) / 1e12
+            result["wavernn_batch32"]["roofline"] = {
+                "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                "kernel": "mb::rnn_ts2_kernel / rnn_dual_linear_ts2_kernel (whole step: 4 GEMM launches + finish)",
+                "algorithmic_flops_per_step": fl}
             del outs, bw, bm
             model._ws = None
             torch.cuda.empty_cache()
