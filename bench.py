@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-tacotron", action="store_true")
     ap.add_argument("--no-ppg2mel", action="store_true")
     ap.add_argument("--no-wavernn-batch", action="store_true")
+    ap.add_argument("--no-wavernn-unbatched", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -64,6 +65,7 @@ def main():
         # N > 1: the line is the sharded headline workload + its roofline; the secondary single-GPU objects and
         # the CPU baseline are N = 1 material (rank 0 would otherwise keep the other ranks waiting ~1 min)
         args.no_hifigan = args.no_tacotron = args.no_ppg2mel = args.no_cpu_baseline = args.no_wavernn_batch = True
+        args.no_wavernn_unbatched = True
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if use_dist:
@@ -175,6 +177,23 @@ def main():
                            "GBps": (16.3e6 + 452.0 * plan.n_folds) / (result["config"]["us_per_time_step"] * 1e-6) / 1e9},
             "per_kernel": per_kernel,
         }
+        # ---- secondary: the same utterance with batched=False (SURVEY.md section 8d config 1 "also report"): ONE
+        # fold, one column per launch, every sample a dependent step -- the pure latency floor of the chain
+        if not args.no_wavernn_unbatched:
+            model.generate_samples(mel[:, :40], False, target, overlap, seed=3)  # untimed: graph capture / first touch
+            torch.cuda.synchronize()
+            t0u = time.perf_counter()
+            su = model.generate_samples(mel, False, target, overlap, seed=3)
+            wu = model.finish(su, False, overlap, True, wave_len)
+            torch.cuda.synchronize()
+            tu = time.perf_counter() - t0u
+            pu = model.last_plan
+            result["wavernn_unbatched"] = {
+                "workload": f"mel 80x{F}, batched=False: {pu.n_folds} fold x {pu.seq_len} dependent steps, Philox sampling, fp32",
+                "value": len(wu) / tu, "unit": "samples/s", "x_realtime": len(wu) / tu / 16000.0, "s_total": tu,
+                "sample_loop_ms": model.last_loop_ms, "us_per_time_step": model.last_loop_ms * 1e3 / pu.seq_len,
+            }
+            del su, wu
         # ---- secondary: WaveRNN throughput mode -- north_star's "batch-32 synthetic input": 32 utterances of
         # mel 80x{F} share ONE sample loop (736 fold columns instead of 23 per launch)
         if not args.no_wavernn_batch:
