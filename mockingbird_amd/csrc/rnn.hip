@@ -97,10 +97,19 @@ __global__ __launch_bounds__(512) void rnn_fc3_finish_kernel(RnnDev d0, Fin1K f,
 // the critical path: they are dispatched first), the rest run job 1 on the CUs job 0 leaves idle.
 // The WaveRNN loop uses it to compute the hidden halves W_hh.h + b_hh of the NEXT step's GRUs beside
 // fc1 / fc2 (wavernn.hip), which takes them off the dependent chain.
-template <int UB0, unsigned F0, int UB1, unsigned F1>
+template <int UB0, unsigned F0, int UB1, unsigned F1, int NT = 1>
 __global__ __launch_bounds__(512) void rnn_dual_linear_kernel(RnnDev d0, RnnDev d1, int nx0) {
-  if ((int)blockIdx.x < nx0) rnn_rowtile_body<EPI_LINEAR, 1, UB0, F0>(d0, blockIdx.x, blockIdx.y);
-  else rnn_rowtile_body<EPI_LINEAR, 1, UB1, F1>(d1, blockIdx.x - nx0, blockIdx.y);
+  if ((int)blockIdx.x < nx0) rnn_rowtile_body<EPI_LINEAR, NT, UB0, F0>(d0, blockIdx.x, blockIdx.y);
+  else rnn_rowtile_body<EPI_LINEAR, NT, UB1, F1>(d1, blockIdx.x - nx0, blockIdx.y);
+}
+// 17..64 fold columns (BASELINE configs[1]: 23): two 16-column tiles per workgroup share one weight fetch, half the
+// workgroups per launch.  Measured and NOT adopted: 29.1 us per step against 26.0 with one tile per workgroup (each
+// launch +0.2..1.0 us: the second tile's loads, MFMAs and reduction are serial inside the workgroup, while a second
+// workgroup runs beside the first) -- the loop is latency-bound, not bound by the weight stream.  Kept behind
+// MBHIP_WAVERNN_NT2=1, bit-identical sample stream (tests/test_wavernn_gpu.py).
+static bool rnn_wavernn_nt2(int N) {
+  const char* e = getenv("MBHIP_WAVERNN_NT2");
+  return e && atoi(e) != 0 && N > 16 && N <= 64;
 }
 
 // Tile-split launches (rnn_body.h, TS): wide batches (several utterances per WaveRNN loop)
@@ -202,6 +211,11 @@ void cell_rows(const float* w_ih, int kx, int ldx, const float* w_hh, int kh, in
   /* ... and with per-fold descriptors (several utterances per loop) */                                   \
   X(EPI_GRU, 1, 4, RF_PRE | RF_FRAME | RF_HPRE | RF_XRES | RF_XOUT | RF_ZERO | RF_FOLDTAB)                \
   X(EPI_LINEAR, 1, 4, RF_BIASX | RF_FRAME | RF_GUMBEL | RF_FOLDTAB)                                       \
+  /* ... with two column tiles per workgroup (MBHIP_WAVERNN_NT2) */                                        \
+  X(EPI_GRU, 2, 4, RF_PRE | RF_FRAME | RF_HPRE | RF_XRES | RF_XOUT | RF_ZERO)                             \
+  X(EPI_GRU, 2, 4, RF_PRE | RF_FRAME | RF_HPRE | RF_XRES | RF_XOUT | RF_ZERO | RF_FOLDTAB)                \
+  X(EPI_LINEAR, 2, 4, RF_BIASX | RF_FRAME | RF_GUMBEL)                                                    \
+  X(EPI_LINEAR, 2, 4, RF_BIASX | RF_FRAME | RF_GUMBEL | RF_FOLDTAB)                                       \
   /* Tacotron decoder: prenet fc1/fc2 (mask / on-device dropout), attention GRU, rnn_input, LSTMs, mel */ \
   X(EPI_LINEAR, 1, 2, RF_BIASX | RF_SKIP | RF_MASK | ACT(1))                                              \
   X(EPI_LINEAR, 1, 2, RF_BIASX | RF_SKIP | RF_DROP | ACT(1))                                              \
@@ -250,6 +264,13 @@ int rnn_launch_dual_linear(const RnnK& k0, const RnnK& k1, hipStream_t s) {
     dim3 gts(cdiv(nx0, 2) + cdiv(nx1, 2), cdiv(cdiv(k0.N, 16), 4));
     MB_REQUIRE(k0.nkb_total == k1.nkb_total, "rnn_launch_dual(ts): jobs must share K");
     hipLaunchKernelGGL((rnn_dual_linear_ts_kernel<F0 | RF_FOLDTAB, F1>), gts, dim3(NW * 64), 0, s, d0, d1, cdiv(nx0, 2));
+    MB_HIP(hipGetLastError());
+    return MB_OK;
+  }
+  if (rnn_wavernn_nt2(k0.N)) {
+    dim3 grid2(nx0 + nx1, cdiv(k0.N, 32));
+    if (f0 == F0) hipLaunchKernelGGL((rnn_dual_linear_kernel<4, F0, 4, F1, 2>), grid2, dim3(NW * 64), 0, s, d0, d1, nx0);
+    else hipLaunchKernelGGL((rnn_dual_linear_kernel<4, F0 | RF_FOLDTAB, 4, F1, 2>), grid2, dim3(NW * 64), 0, s, d0, d1, nx0);
     MB_HIP(hipGetLastError());
     return MB_OK;
   }
@@ -317,13 +338,16 @@ int rnn_launch(int epi, const RnnK& k, hipStream_t s) {
   // faster with twice the workgroups.
   const int rl = (epi == EPI_GRU) ? 3 : 4;
   const size_t wbytes = (size_t)n_mt * k.nkb_total * 4 * rl * 16 * sizeof(float);
-  const int nt = (k.N > 16 && wbytes >= ((size_t)12 << 20)) ? 2 : 1;
+  const unsigned feat = rnn_features(epi, k);
+  constexpr unsigned FW_G = RF_PRE | RF_FRAME | RF_HPRE | RF_XRES | RF_XOUT | RF_ZERO, FW_L = RF_BIASX | RF_FRAME | RF_GUMBEL;
+  const bool wavernn_nt2 = rnn_wavernn_nt2(k.N) && ((epi == EPI_GRU && (feat & ~RF_FOLDTAB) == FW_G) ||
+                                                    (epi == EPI_LINEAR && (feat & ~RF_FOLDTAB) == FW_L));
+  const int nt = ((k.N > 16 && wbytes >= ((size_t)12 << 20)) || wavernn_nt2) ? 2 : 1;
   RnnDev d;
   int rcd = make_rnn_dev(k, &d);
   if (rcd) return rcd;
   const int per_wave = cdiv(k.nkb_total, NW);
   const int ub = nt == 2 ? (per_wave >= 4 ? 4 : 2) : (per_wave >= 8 ? 8 : (per_wave >= 4 ? 4 : 2));
-  const unsigned feat = rnn_features(epi, k);
   dim3 grid(n_mt, cdiv(k.N, 16 * nt));
   bool done = false;
   if (rnn_ts_enabled(k.N) && k.nseg == 1 && k.nkb_total % 8 == 0) {  // wide batch: tile-split instances (whole batches of 8 k-blocks)

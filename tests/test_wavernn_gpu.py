@@ -25,10 +25,15 @@ def _oracle_cond(w, mel, batched, target, overlap):
         return ow.conditioning(w, ow.HP, torch.from_numpy(mel[None] / 4.0), batched, target, overlap)
 
 
-@pytest.mark.parametrize("frames,batched,target,overlap", [(30, True, 600, 100), (27, False, 0, 0),
-                                                           (40, True, 1100, 50)])
-def test_teacher_forced_logits(model, frames, batched, target, overlap):
+@pytest.mark.parametrize("frames,batched,target,overlap,nt2", [(30, True, 600, 100, 0), (27, False, 0, 0, 0),
+                                                               (40, True, 1100, 50, 0), (70, True, 600, 100, 0),
+                                                               (70, True, 600, 100, 1)])
+def test_teacher_forced_logits(model, monkeypatch, frames, batched, target, overlap, nt2):
+    """(70, 600, 100) gives 26 folds: two 16-column MFMA tiles, as BASELINE configs[1]'s 23; nt2 = the launch form
+    with both tiles in one workgroup (MBHIP_WAVERNN_NT2)."""
     dev, w = model
+    if nt2:
+        monkeypatch.setenv("MBHIP_WAVERNN_NT2", "1")
     mel = synth.wavernn_mel(frames, seed=2)
     mels, aux = _oracle_cond(w, mel, batched, target, overlap)
     steps = 96
@@ -227,6 +232,18 @@ def test_baseline_config1_full_size_properties(model):
     wav = dev.finish(a, True, 800, True, (1000 - 1) * 256)
     assert wav.dtype == np.float64 and wav.shape == (min(999 * 256, 23 * 8800 + 800),) and np.isfinite(wav).all()
     assert abs(wav[-1]) == 0.0 and np.abs(wav).max() > 0  # linear fade reaches exactly zero
+
+
+def test_two_column_tiles_per_workgroup_is_bit_identical(model, monkeypatch):
+    """MBHIP_WAVERNN_NT2: 17..64 folds with two column tiles per workgroup (one weight fetch for both) must give
+    the sample stream of the one-tile-per-workgroup launches bit for bit (same K split, same reduction order)."""
+    dev, w = model
+    mel = torch.from_numpy(synth.wavernn_mel(90, seed=12) / 4.0).cuda()
+    a = dev.generate_samples(mel, True, 800, 80, seed=9)
+    assert 16 < dev.last_plan.n_folds <= 32
+    monkeypatch.setenv("MBHIP_WAVERNN_NT2", "1")
+    b = dev.generate_samples(mel, True, 800, 80, seed=9)
+    assert torch.equal(a, b), int((a != b).sum())
 
 
 def test_batch_loop_equals_single_utterance_runs(model):
