@@ -341,6 +341,9 @@ typedef struct mb_taco_config {
    * has_gst != 0 (needs has_encoder); style_dims = E */
   int has_gst, gst_tokens, gst_heads, gst_n_convs, gst_width;
   int gst_filters[8];
+  /* PreNet dropout probability (hparams.tts_dropout, pre_net.py:23,26: applied at inference too); kept values are
+   * scaled by 1/(1-p).  0 disables dropout. */
+  float dropout;
 } mb_taco_config;
 typedef struct mb_taco mb_taco;
 int mb_taco_num_weights(const mb_taco_config* cfg);

@@ -115,7 +115,7 @@ class TacoConfig(C.Structure):
         ("has_encoder", C.c_int), ("num_chars", C.c_int), ("embed_dims", C.c_int), ("encoder_dims", C.c_int),
         ("encoder_K", C.c_int), ("speaker_dims", C.c_int), ("style_dims", C.c_int),
         ("has_gst", C.c_int), ("gst_tokens", C.c_int), ("gst_heads", C.c_int), ("gst_n_convs", C.c_int),
-        ("gst_width", C.c_int), ("gst_filters", C.c_int * 8),
+        ("gst_width", C.c_int), ("gst_filters", C.c_int * 8), ("dropout", C.c_float),
     ]
 
 
@@ -240,6 +240,16 @@ def ptr(t):
 def stream_ptr():
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def fresh_seed() -> int:
+    """A 62-bit key for the on-device counter RNGs drawn from torch's GLOBAL (CPU) generator: unseeded calls
+    vary, and torch.manual_seed(...) -- the toolbox's "random seed" box, hifigan.load_model's manual_seed
+    (control/toolbox/__init__.py:240-243, hifigan/inference.py:39) -- makes a run reproducible, as it does for the
+    reference, whose F.dropout (pre_net.py:23,26) / Categorical.sample (fatchord_version.py:224-226) consume
+    that generator."""
+    import torch
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
 
 def host_ptr_array(tensors):

@@ -331,7 +331,7 @@ extern "C" int mb_ppg2mel_decode(const mb_ppg2mel* p, const float* d_memory, int
       k.N = B; k.units = c.prenet_dims[i]; k.biasX = p->zero_bias.p; k.y = L.pbuf[i]; k.ldy = c.prenet_dims[i]; k.act = 1;
       k.mask_scale = 2.f;
       k.mask = d_dropout ? d_dropout + mask_base[i] + (size_t)st * B * c.prenet_dims[i] : nullptr;
-      k.drop_on = d_dropout ? 0 : 1; k.drop_seed = seed; k.drop_iter = st; k.drop_layer = i; k.skip_flag = done;
+      k.drop_on = d_dropout ? 0 : 1; k.drop_thresh = 0x80000000u; k.drop_seed = seed; k.drop_iter = st; k.drop_layer = i; k.skip_flag = done;
       if ((rc = rnn_launch(EPI_LINEAR, k, s))) return rc;
       kin = c.prenet_dims[i];
     }

@@ -65,7 +65,8 @@ struct RnnK {
   // optional strided copy of h_out into a sequence tensor: seq_out[n*seq_n_stride + j*seq_j_stride + seq_off]
   float* seq_out; long long seq_n_stride, seq_j_stride, seq_off;
   // LINEAR dropout when mask == null and drop_seed_on: keep = philox(seed, drop_iter, drop_layer; n,row) < 0.5
-  int drop_on; unsigned long long drop_seed; int drop_iter, drop_layer;
+  // (keep iff the 32-bit draw >= drop_thresh = p * 2^32; the kept value is scaled by mask_scale = 1/(1-p))
+  int drop_on; unsigned long long drop_seed; int drop_iter, drop_layer; unsigned int drop_thresh;
   // ---- WaveRNN fused sampling (production path, no injected noise) ----
   // aff_slot != null (GRU): the cell input is x0[n] = aff_table[ipos_n] + x_n * aff_vec  (I(x) split,
   // wavernn.hip header) with ipos_n from the fr_* geometry (row fr_total_len = zero-conditioning row) and

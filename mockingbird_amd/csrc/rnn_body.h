@@ -338,7 +338,7 @@ __device__ __forceinline__ void rnn_rowtile_body(const RnnDev& d, const int bx, 
           uint32_t rr[4];
           philox4x32((uint32_t)a.drop_iter, (uint32_t)a.drop_layer, (uint32_t)n, (uint32_t)(row >> 2),
                      (uint32_t)a.drop_seed, (uint32_t)(a.drop_seed >> 32), rr);
-          v = v * ((rr[row & 3] & 0x80000000u) ? a.mask_scale : 0.f);
+          v = v * ((rr[row & 3] >= a.drop_thresh) ? a.mask_scale : 0.f);
         }
         if (a.y) a.y[(size_t)n * a.ldy + row] = v;
         if (f_gum) {

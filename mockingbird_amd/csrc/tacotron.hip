@@ -339,21 +339,6 @@ __global__ __launch_bounds__(512) void lsa_fast_kernel(LsaK a) {
   lsa_fast_body<TJ>(a, blockIdx.x, blockIdx.y);
 }
 
-// The attention launch is latency-bound and occupies B*psplit of the 256 CUs.  The hidden halves of the
-// two decoder LSTMs, W_hh.h(t-1) + b_hh (2 x 16.8 MB of weights, bandwidth-bound), depend only on the
-// previous iteration's state, so they ride in the same launch as extra workgroups (the attention
-// workgroups come first in dispatch order) and leave the dependent chain: the LSTM launches then
-// stream only their input halves.
-constexpr unsigned HH_FEAT = RF_BIASX | RF_SKIP;
-template <int TJ>
-__global__ __launch_bounds__(512) void lsa_hh_kernel(LsaK a, RnnDev d1, RnnDev d2, int n_lsa, int B, int nx1) {
-  const int id = blockIdx.x;
-  if (id < n_lsa) { lsa_fast_body<TJ>(a, id % B, id / B); return; }
-  const int j = id - n_lsa;
-  if (j < nx1) rnn_rowtile_body<EPI_LINEAR, 2, 4, HH_FEAT>(d1, j, 0);
-  else rnn_rowtile_body<EPI_LINEAR, 2, 4, HH_FEAT>(d2, j - nx1, 0);
-}
-
 // ---------------------------------------------------------------- finalize
 struct FinK {
   const float* x2;       // [B][H]
@@ -598,7 +583,7 @@ __global__ void embed_gather_kernel(const int* __restrict__ chars, const float* 
 
 // always-on PreNet dropout (pre_net.py:23,26) on y [B][C][T]; masks (if injected) are [B][T][C]
 __global__ void dropout_cm_kernel(float* __restrict__ y, const float* __restrict__ mask, int C, int T,
-                                  unsigned long long seed, int layer) {
+                                  unsigned long long seed, int layer, unsigned thresh, float scale) {
   const int b = blockIdx.y;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < C * T; i += gridDim.x * blockDim.x) {
     const int c = i / T, t = i - c * T;
@@ -607,9 +592,9 @@ __global__ void dropout_cm_kernel(float* __restrict__ y, const float* __restrict
     else {
       uint32_t r[4];
       philox4x32((uint32_t)(b * T + t), (uint32_t)(c >> 2), (uint32_t)layer, 0x454e4344u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-      keep = (r[c & 3] & 0x80000000u) ? 1.f : 0.f;
+      keep = (r[c & 3] >= thresh) ? 1.f : 0.f;
     }
-    y[(size_t)b * C * T + i] *= keep * 2.f;
+    y[(size_t)b * C * T + i] *= keep * scale;
   }
 }
 
@@ -803,6 +788,7 @@ static int taco_shapes(const mb_taco_config* c, std::vector<size_t>* n) {
   MB_REQUIRE(c->n_mels % 16 == 0 && c->project_dims % 16 == 0 && c->decoder_dims % 16 == 0 && c->lstm_dims % 16 == 0,
              "taco: n_mels/project_dims/decoder_dims/lstm_dims must be multiples of 16");
   MB_REQUIRE(c->r >= 1 && c->r <= c->max_r, "taco: r=%d out of range", c->r);
+  MB_REQUIRE(c->dropout >= 0.f && c->dropout < 1.f, "taco: dropout probability %g outside [0, 1)", (double)c->dropout);
   MB_REQUIRE(c->postnet_dims % 32 == 0 && c->postnet_K >= 1 && c->postnet_K <= 16, "taco: postnet dims");
   const size_t M = c->n_mels, P = c->project_dims, D = c->decoder_dims, H = c->lstm_dims, C = c->postnet_dims;
   n->clear();
@@ -1040,7 +1026,13 @@ extern "C" int mb_taco_decode(const mb_taco* t, const float* d_memory, const flo
   MB_REQUIRE((P / psplit) % 256 == 0 && D <= 512 && 512 % D == 0, "taco_decode: unsupported project_dims/decoder_dims for the LSA kernel");
   const size_t lds_lsa = sizeof(float) * ((size_t)((T + c.lsa_kernel - 1 + 3) & ~3) + D + (size_t)c.lsa_filters * D +
                                           ((c.lsa_filters * c.lsa_kernel + 3) & ~3) + (size_t)T * c.lsa_filters + ((T + 3) & ~3) + 64 + 8 * 64 * 4);
-  MB_REQUIRE(lds_lsa <= 64 * 1024, "taco_decode: text too long for the LSA window in LDS (T=%d)", T);
+  const bool lsa_fast = D == 128 && P / psplit == 256 && c.lsa_kernel <= 31 && (c.lsa_kernel & 1) && T <= 192 &&
+                        getenv("MBHIP_LSA_GENERIC") == nullptr;
+  if (!lsa_fast) {  // the general kernel keeps its location window in dynamic LDS: up to the 160 KB a gfx950 CU has
+    MB_REQUIRE(lds_lsa <= 160 * 1024, "taco_decode: text too long for the LSA window in LDS (T=%d needs %zu B of 163840)", T, lds_lsa);
+    if (lds_lsa > 48 * 1024)
+      MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lsa_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lsa));
+  }
 
   // zero initial states (tacotron.py:219-230,261; lsa.py:15-19)
   MB_HIP(hipMemsetAsync(L.attn_h, 0, sizeof(float) * 2 * B * D, s));
@@ -1056,6 +1048,10 @@ extern "C" int mb_taco_decode(const mb_taco* t, const float* d_memory, const flo
   int* n_frames = L.flags + 1;
   int* arrive = L.flags + 2;
 
+  // always-on PreNet dropout (pre_net.py:23,26) with the checkpoint's probability p: keep iff draw >= p * 2^32
+  const bool drop_enabled = c.dropout > 0.f;
+  const float drop_scale = drop_enabled ? 1.f / (1.f - c.dropout) : 1.f;
+  const unsigned drop_thresh = drop_enabled ? (unsigned)std::min(4294967295.0, (double)c.dropout * 4294967296.0) : 0u;
   int frames = 0;
   for (int it = 0; it < n_iter_max; ++it) {
     const int pp = it & 1;
@@ -1070,15 +1066,15 @@ extern "C" int mb_taco_decode(const mb_taco* t, const float* d_memory, const flo
     // prenet (pre_net.py:21-26): input = last frame of the previous iteration (tacotron.py:268)
     memset(&k, 0, sizeof(k));
     k.w = t->pre1_w.p; k.nseg = 1; k.nkb_total = M / 16; k.seg[0] = {L.melstep + (size_t)(r - 1) * M, r * M, M / 16, 0};
-    k.N = B; k.units = 2 * D; k.biasX = t->pre1_b.p; k.y = L.p1; k.ldy = 2 * D; k.act = 1; k.mask_scale = 2.f;
-    k.mask = d_dropout ? d_dropout + ((size_t)it * 2 + 0) * B * 2 * D : nullptr;
-    k.drop_on = d_dropout ? 0 : 1; k.drop_seed = seed; k.drop_iter = it; k.drop_layer = 0; k.skip_flag = done;
+    k.N = B; k.units = 2 * D; k.biasX = t->pre1_b.p; k.y = L.p1; k.ldy = 2 * D; k.act = 1; k.mask_scale = drop_scale; k.drop_thresh = drop_thresh;
+    k.mask = (d_dropout && drop_enabled) ? d_dropout + ((size_t)it * 2 + 0) * B * 2 * D : nullptr;
+    k.drop_on = (d_dropout || !drop_enabled) ? 0 : 1; k.drop_seed = seed; k.drop_iter = it; k.drop_layer = 0; k.skip_flag = done;
     if ((rc = rnn_launch(EPI_LINEAR, k, s))) return rc;
     memset(&k, 0, sizeof(k));
     k.w = t->pre2_w.p; k.nseg = 1; k.nkb_total = 2 * D / 16; k.seg[0] = {L.p1, 2 * D, 2 * D / 16, 0};
-    k.N = B; k.units = 2 * D; k.biasX = t->pre2_b.p; k.y = L.p2; k.ldy = 2 * D; k.act = 1; k.mask_scale = 2.f;
-    k.mask = d_dropout ? d_dropout + ((size_t)it * 2 + 1) * B * 2 * D : nullptr;
-    k.drop_on = d_dropout ? 0 : 1; k.drop_seed = seed; k.drop_iter = it; k.drop_layer = 1; k.skip_flag = done;
+    k.N = B; k.units = 2 * D; k.biasX = t->pre2_b.p; k.y = L.p2; k.ldy = 2 * D; k.act = 1; k.mask_scale = drop_scale; k.drop_thresh = drop_thresh;
+    k.mask = (d_dropout && drop_enabled) ? d_dropout + ((size_t)it * 2 + 1) * B * 2 * D : nullptr;
+    k.drop_on = (d_dropout || !drop_enabled) ? 0 : 1; k.drop_seed = seed; k.drop_iter = it; k.drop_layer = 1; k.skip_flag = done;
     if ((rc = rnn_launch(EPI_LINEAR, k, s))) return rc;
     // attn_hidden = attn_rnn([context, prenet_out], attn_hidden)  (tacotron.py:97-98)
     memset(&k, 0, sizeof(k));
@@ -1094,30 +1090,7 @@ extern "C" int mb_taco_decode(const mb_taco* t, const float* d_memory, const flo
     lk.vw = t->lsa_v.p; lk.context = cx_n; lk.attn_out = d_attn; lk.T = T; lk.D = D; lk.P = P; lk.Fl = c.lsa_filters;
     lk.Kl = c.lsa_kernel; lk.iter = it; lk.n_iter_max = n_iter_max; lk.skip_flag = done;
     lk.Mt = t->lsa_Mt.p; lk.c0 = t->lsa_c0.p; lk.Wt = t->lsa_Wt.p;
-    const bool lsa_fast = D == 128 && P / psplit == 256 && c.lsa_kernel <= 31 && (c.lsa_kernel & 1) && T <= 192 &&
-                          getenv("MBHIP_LSA_GENERIC") == nullptr;
-    // split-hidden decoder (experiment): the LSTMs' hidden halves ride in the attention launch.
-    // Measured on MI355X (B = 32): attention+hidden 27.9 us + 2 x 10.6 us LSTM input halves = 49.0 us against
-    // 19.6 + 2 x 15.3 = 50.2 us on the classic chain -- the hidden halves are bandwidth-bound work that
-    // takes as long beside the attention kernel as on the chain, so the classic chain stays the default
-    // (MBHIP_TACO_SPLIT=1 selects this path; parity-tested either way).
-    const bool split = lsa_fast && B <= 32 && H % 64 == 0 && getenv("MBHIP_TACO_SPLIT") != nullptr &&
-                       atoi(getenv("MBHIP_TACO_SPLIT")) == 1;
-    if (split) {
-      RnnK kh[2];
-      RnnDev dh[2];
-      for (int g = 0; g < 2; ++g) {
-        memset(&kh[g], 0, sizeof(RnnK));
-        kh[g].w = g ? t->l2_whh.p : t->l1_whh.p; kh[g].nseg = 1; kh[g].nkb_total = H / 16;
-        kh[g].seg[0] = {g ? h2p : h1p, H, H / 16, 0};
-        kh[g].N = B; kh[g].units = 4 * H; kh[g].biasX = g ? t->l2_bhh.p : t->l1_bhh.p;
-        kh[g].y = g ? L.hp2 : L.hp1; kh[g].ldy = 4 * H; kh[g].skip_flag = done;
-        if ((rc = make_rnn_dev(kh[g], &dh[g]))) return rc;
-      }
-      const int nx = cdiv(4 * H, 16), n_lsa = B * psplit;
-      if (T <= 128) hipLaunchKernelGGL(lsa_hh_kernel<32>, dim3(n_lsa + 2 * nx), dim3(512), 0, s, lk, dh[0], dh[1], n_lsa, B, nx);
-      else hipLaunchKernelGGL(lsa_hh_kernel<48>, dim3(n_lsa + 2 * nx), dim3(512), 0, s, lk, dh[0], dh[1], n_lsa, B, nx);
-    } else if (lsa_fast && T <= 128) hipLaunchKernelGGL(lsa_fast_kernel<32>, dim3(B, psplit), dim3(512), 0, s, lk);
+    if (lsa_fast && T <= 128) hipLaunchKernelGGL(lsa_fast_kernel<32>, dim3(B, psplit), dim3(512), 0, s, lk);
     else if (lsa_fast) hipLaunchKernelGGL(lsa_fast_kernel<48>, dim3(B, psplit), dim3(512), 0, s, lk);
     else hipLaunchKernelGGL(lsa_kernel, dim3(B, psplit), dim3(512), lds_lsa, s, lk);
     MB_HIP(hipGetLastError());
@@ -1130,13 +1103,11 @@ extern "C" int mb_taco_decode(const mb_taco* t, const float* d_memory, const flo
     memset(&k, 0, sizeof(k));
     k.w = t->l1_w.p; k.nseg = 2; k.nkb_total = 2 * H / 16; k.seg[0] = {L.x, H, H / 16, 0}; k.seg[1] = {h1p, H, H / 16, 1};
     k.N = B; k.units = H; k.biasX = t->l1_bih.p; k.biasH = t->l1_bhh.p; k.c_prev = c1p; k.x_res = L.x;
-    if (split) { k.w = t->l1_wx.p; k.nseg = 1; k.nkb_total = H / 16; k.biasH = nullptr; k.h_pre = L.hp1; }
     k.h_out = h1n; k.c_out = c1n; k.x_out = L.x1; k.skip_flag = done;
     if ((rc = rnn_launch(EPI_LSTM, k, s))) return rc;
     memset(&k, 0, sizeof(k));
     k.w = t->l2_w.p; k.nseg = 2; k.nkb_total = 2 * H / 16; k.seg[0] = {L.x1, H, H / 16, 0}; k.seg[1] = {h2p, H, H / 16, 1};
     k.N = B; k.units = H; k.biasX = t->l2_bih.p; k.biasH = t->l2_bhh.p; k.c_prev = c2p; k.x_res = L.x1;
-    if (split) { k.w = t->l2_wx.p; k.nseg = 1; k.nkb_total = H / 16; k.biasH = nullptr; k.h_pre = L.hp2; }
     k.h_out = h2n; k.c_out = c2n; k.x_out = L.x2; k.skip_flag = done;
     if ((rc = rnn_launch(EPI_LSTM, k, s))) return rc;
     // mels = mel_proj(x)[:, :, :r]  (tacotron.py:128-129)
@@ -1221,15 +1192,18 @@ extern "C" int mb_taco_encode(const mb_taco* t, const int32_t* d_chars, const fl
   hipStream_t s = (hipStream_t)stream;
   int rc = MB_OK;
 #define RC(x) do { if (!rc) rc = (x); } while (0)
+  const bool e_drop = c.dropout > 0.f;
+  const float e_scale = e_drop ? 1.f / (1.f - c.dropout) : 1.f;
+  const unsigned e_thresh = e_drop ? (unsigned)std::min(4294967295.0, (double)c.dropout * 4294967296.0) : 0u;
   // x = embedding(texts); x = pre_net(x)  (tacotron.py:41-42, pre_net.py:21-26)
   hipLaunchKernelGGL(embed_gather_kernel, dim3(std::min(cdiv(Em * T, 256), 1024), B), dim3(256), 0, s, (const int*)d_chars,
                      t->emb.p, L.xe, T, Em, c.num_chars);
   RC(run_conv(t->enc_fc1, L.xe, B, T, L.p1, 0, 0, 1, nullptr, nullptr, 0, s));
   hipLaunchKernelGGL(dropout_cm_kernel, dim3(std::min(cdiv(Ce * T, 256), 1024), B), dim3(256), 0, s, L.p1,
-                     d_dropout ? d_dropout : nullptr, Ce, T, (unsigned long long)seed, 0);
+                     d_dropout ? d_dropout : nullptr, Ce, T, (unsigned long long)seed, 0, e_thresh, e_scale);
   RC(run_conv(t->enc_fc2, L.p1, B, T, L.p2, 0, 0, 1, nullptr, nullptr, 0, s));
   hipLaunchKernelGGL(dropout_cm_kernel, dim3(std::min(cdiv(Ce * T, 256), 1024), B), dim3(256), 0, s, L.p2,
-                     d_dropout ? d_dropout + (size_t)B * T * Ce : nullptr, Ce, T, (unsigned long long)seed, 1);
+                     d_dropout ? d_dropout + (size_t)B * T * Ce : nullptr, Ce, T, (unsigned long long)seed, 1, e_thresh, e_scale);
   // x = cbhg(x)  (tacotron.py:43-44)
   RC(cbhg_forward(t->enc, L.p2, B, T, L.cb, s));
   // speaker + style concat (tacotron.py:171-197, 253) and encoder_proj (:255)

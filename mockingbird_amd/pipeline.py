@@ -11,7 +11,7 @@ package and soundfile and stay on the reference's CPU path (north_star).
 
 Sharding: requests are dealt to ranks by sharding.shard_indices (length-sorted
 round robin), each rank runs ITS requests through both models on its GPU, and the finished waveforms are
-exchanged once (sharding.gather_waveforms).  There is no collective inside a request."""
+gathered once to rank 0 (sharding.gather_waveforms).  There is no collective inside a request."""
 from typing import List, Sequence, Tuple
 
 import numpy as np
@@ -34,22 +34,25 @@ def insert_breaks(wav: np.ndarray, frames_per_sentence: Sequence[int], hop_size:
 
 
 def gen_wavs(synthesizer, vocoder, requests: List[Tuple[List[str], np.ndarray]], *, style_idx=-1, min_stop_token=4,
-             steps=400, group=None, normalize=None, pcm16=None) -> List[np.ndarray]:
-    """requests: [(texts, embed)] -> one float waveform per request, in request order, on every rank.
+             steps=400, group=None, normalize=None, pcm16=None, dst=0) -> List[np.ndarray]:
+    """requests: [(texts, embed)] -> one waveform per request, in request order, on rank `dst` (every other rank
+    returns []; dst=None: on every rank).
 
-    normalize / pcm16 (optional): run gen_voice.py:41's peak normalisation and the
-    PCM_16 conversion of the file writer on the device (vocoder/wave.py) before the waveform leaves the GPU; the
-    result is int16 and the gather moves half the bytes.  The reference normalises AFTER inserting the breaks
-    and trimming silence (gen_voice.py:40-41); zeros do not move the peak, so only a trim that removed the
-    loudest sample would differ.
+    The whole tail of gen_voice.py:30-41 that does not need the speaker-encoder package runs on the device inside
+    the vocoder facade (vocoder/wave.py): the 0.15 s sentence breaks, then -- optionally -- normalize (gen_voice.py:41's
+    peak normalisation) and pcm16 (the PCM_16 conversion of the file writer, run.py:91).  The finished waveforms
+    stay in HBM until the gather, which moves them device-to-device to rank `dst` (int16: half the bytes).  The
+    reference trims silence between break insertion and normalisation (gen_voice.py:40, webrtcvad on the CPU); zeros
+    do not move the peak, so only a trim that removed the loudest sample would change the normalised result.
 
     synthesizer: object with synthesize_spectrograms / hparams.hop_size / sample_rate (the Synthesizer facade);
-    vocoder: module or object with infer_waveform_batch(mels) -> (wavs, sample_rate) (hifigan / fregan facade)."""
+    vocoder: module or object with infer_waveform_batch(mels, normalize=, pcm16=, breaks=, break_hop=, device_out=)
+    -> (wavs, sample_rate) (hifigan / fregan facade)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     lengths = [sum(len(t) for t in texts) for texts, _ in requests]
     mine = sharding.shard_indices(lengths, world, rank)
-    local: List[np.ndarray] = []
+    local = []
     if mine:
         flat_texts, flat_embeds, owner = [], [], []
         for i in mine:
@@ -61,14 +64,12 @@ def gen_wavs(synthesizer, vocoder, requests: List[Tuple[List[str], np.ndarray]],
                                                     min_stop_token=min_stop_token, steps=steps)
         per_req = {i: [s for s, o in zip(specs, owner) if o == i] for i in mine}
         mels = [np.concatenate(per_req[i], axis=1) for i in mine]
-        if normalize is not None or pcm16 is not None:
-            wavs, _sr = vocoder.infer_waveform_batch(mels, normalize=normalize, pcm16=pcm16)
-        else:
-            wavs, _sr = vocoder.infer_waveform_batch(mels)
-        hop, sr = synthesizer.hparams.hop_size, synthesizer.sample_rate
-        local = [insert_breaks(w, [s.shape[1] for s in per_req[i]], hop, sr) for w, i in zip(wavs, mine)]
-    wire = np.int16 if pcm16 is not None else np.float32
-    gathered = sharding.gather_waveforms([np.asarray(w, wire) for w in local], group=group)
+        local, _sr = vocoder.infer_waveform_batch(mels, normalize=normalize, pcm16=pcm16,
+                                                  breaks=[[s.shape[1] for s in per_req[i]] for i in mine],
+                                                  break_hop=synthesizer.hparams.hop_size, device_out=True)
+    gathered = sharding.gather_waveforms(local, group=group, dst=dst)
+    if dst is not None and rank != dst:
+        return []
     # gather_waveforms returns rank-major order; put the requests back in their own order
     order = [i for r in range(world) for i in sharding.shard_indices(lengths, world, r)]
     out: List[np.ndarray] = [None] * len(requests)

@@ -70,12 +70,14 @@ class Ppg2MelDecoder:
                 pass
             self._h = None
 
-    def decode(self, memory, stop_threshold=0.5, dropout=None, seed=0, max_steps=None):
+    def decode(self, memory, stop_threshold=0.5, dropout=None, seed=None, max_steps=None):
         """Raw loop: memory [B, T_enc, enc_dim] (CUDA) -> (mel [B, steps, r*num_mels], alignments [B, steps, T_enc],
         stop logits [B, steps]), untruncated.  dropout: optional list of keep masks in program order
         (step-major, prenet layer inside) as produced for the oracle."""
         if not memory.is_cuda:
             raise _lib.MbHipError("ppg2mel decoder needs a CUDA(HIP) tensor; there is no CPU path")
+        if seed is None:  # the reference's prenet dropout draws from torch's global generator
+            seed = _lib.fresh_seed()
         memory = memory.to(torch.float32).contiguous()
         B, T, E = memory.shape
         h = self.hp
@@ -99,6 +101,11 @@ class Ppg2MelDecoder:
             n_steps = len(dropout) // len(dims)
             if n_steps < max_step:
                 raise _lib.MbHipError(f"dropout masks cover {n_steps} steps, need {max_step}")
+            for s_ in range(max_step):
+                for l, d_ in enumerate(dims):
+                    if tuple(dropout[s_ * len(dims) + l].shape) != (B, d_):
+                        raise _lib.MbHipError(f"dropout mask {s_ * len(dims) + l} must be {(B, d_)}, got "
+                                              f"{tuple(dropout[s_ * len(dims) + l].shape)}")
             per_layer = [torch.stack([dropout[s * len(dims) + l] for s in range(max_step)]) for l in range(len(dims))]
             dmask = torch.cat([p.reshape(-1) for p in per_layer]).to(dev, torch.float32).contiguous()
         n = C.c_int(0)
@@ -109,7 +116,7 @@ class Ppg2MelDecoder:
         s = n.value
         return mel[:, :s], align[:, :s], stop[:, :s]
 
-    def inference(self, memory, stop_threshold=0.5, dropout=None, seed=0):
+    def inference(self, memory, stop_threshold=0.5, dropout=None, seed=None):
         """Decoder.inference (rnn_decoder_mol.py:267-316): memory [1, T_enc, enc_dim] ->
         (mel_outputs [1, steps*r, num_mels], alignments [1, steps, T_enc])."""
         if memory.shape[0] != 1:
@@ -117,7 +124,7 @@ class Ppg2MelDecoder:
         mel, al, _ = self.decode(memory, stop_threshold, dropout, seed)
         return mel.reshape(1, -1, self.hp["num_mels"]), al
 
-    def inference_batched(self, memory, stop_threshold=0.5, dropout=None, seed=0):
+    def inference_batched(self, memory, stop_threshold=0.5, dropout=None, seed=None):
         """Decoder.inference_batched (rnn_decoder_mol.py:318-374): every utterance is cut at its first step whose
         sigmoid(stop) exceeds the threshold and the pieces are concatenated -> (mel [1, sum, num_mels],
         alignments [B, steps, T_enc]).  Like the reference this raises IndexError for an utterance that never

@@ -1,7 +1,7 @@
 """Utterance-level data parallelism: one process per GPU, units =
 utterances, no intra-utterance collective.  The only exchange is the gather of finished
-waveforms (lengths first, then zero-padded float32 waveforms) over RCCL/xGMI -- tens of MB,
-latency bound, so one all_gather each (a ring buys nothing at this size).
+waveforms to rank 0 (a small header all_gather, then ONE flat buffer per rank gathered device-to-device) over
+RCCL/xGMI -- tens of MB, latency bound: every peer sends its slice to rank 0 over its own point-to-point link.
 
 Reference precedent: data_parallel_workaround, models/synthesizer/utils/__init__.py:7-21
 (batch-dim scatter/gather in one process); the reference has no multi-GPU inference."""
@@ -20,44 +20,79 @@ def shard_indices(lengths: Sequence[int], world_size: int, rank: int) -> List[in
     return order[rank::world_size]
 
 
-def gather_waveforms(local: List[np.ndarray], device=None, group=None) -> List[np.ndarray]:
-    """All ranks contribute a list of waveforms (float32, or int16 PCM: half the bytes on the wire);
-    every rank returns the concatenated list in rank order.  Works with nccl(=RCCL) on GPUs and gloo on
-    CPU.  The sample type is that of the first local waveform (int16 stays int16, anything else -> float32)
-    and must be the same on every rank."""
+def _as_tensor(w, dev, np_dt, t_dt):
+    if isinstance(w, torch.Tensor):
+        return w.detach().reshape(-1).to(dev, t_dt)
+    return torch.from_numpy(np.ascontiguousarray(w, dtype=np_dt).reshape(-1)).to(dev)
+
+
+def gather_waveforms(local, device=None, group=None, dst=0) -> List[np.ndarray]:
+    """Every rank contributes a list of finished waveforms; rank `dst` returns the concatenated list in rank
+    order (as numpy arrays), every other rank returns [] -- north_star: "RCCL over xGMI only to gather finished
+    waveforms".  dst=None returns the full list on every rank (all_gather instead of gather).
+
+    The items may be numpy arrays or torch tensors that already live on the GPU: they are packed into ONE flat
+    device buffer per rank and travel device-to-device (nccl = RCCL on GPUs, gloo on CPU); only rank `dst` copies
+    the result to the host, once.  Sample type = that of the first local waveform (int16 PCM stays int16 -- half
+    the bytes on the wire -- anything else travels as float32) and must agree across ranks."""
+    def kind(w):
+        return (w.dtype == torch.int16) if isinstance(w, torch.Tensor) else (np.asarray(w).dtype == np.int16)
+
+    def host(w, np_dt):
+        return w.detach().cpu().numpy().astype(np_dt, copy=False) if isinstance(w, torch.Tensor) else np.asarray(w, np_dt)
+
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return list(local)
-    world = dist.get_world_size(group)
+        return [host(w, np.int16 if kind(w) else np.float32) for w in local]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
     backend = dist.get_backend(group)
-    dev = torch.device(device) if device is not None else torch.device("cuda" if backend == "nccl" else "cpu")
-    n_local = torch.tensor([len(local)], dtype=torch.int64, device=dev)
-    counts = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(counts, n_local, group=group)
-    max_items = int(max(int(c.item()) for c in counts))
-    lens = torch.zeros(max_items, dtype=torch.int64, device=dev)
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device()) \
+        if backend == "nccl" else torch.device("cpu")
+    # ---- header: item count, sample type, per-item lengths (one small all_gather: every rank sizes its buffer) ----
+    MAXI = 1 + max(int(x) for x in _all_gather_ints([len(local)], dev, group))
+    head = torch.zeros(2 + MAXI, dtype=torch.int64, device=dev)
+    head[0] = len(local)
+    head[1] = (1 if kind(local[0]) else 0) if local else -1
     for i, w in enumerate(local):
-        lens[i] = len(w)
-    all_lens = [torch.zeros_like(lens) for _ in range(world)]
-    dist.all_gather(all_lens, lens, group=group)
-    max_len = int(max(int(l.max().item()) if l.numel() else 0 for l in all_lens))
-    is_pcm = torch.tensor([int(bool(local) and np.asarray(local[0]).dtype == np.int16), int(bool(local))],
-                          dtype=torch.int64, device=dev)
-    kinds = [torch.zeros_like(is_pcm) for _ in range(world)]
-    dist.all_gather(kinds, is_pcm, group=group)
-    votes = {int(k[0].item()) for k in kinds if int(k[1].item())}  # ranks with no waveform do not vote
+        head[2 + i] = int(w.numel() if isinstance(w, torch.Tensor) else np.asarray(w).size)
+    heads = [torch.zeros_like(head) for _ in range(world)]
+    dist.all_gather(heads, head, group=group)
+    heads = [h.cpu() for h in heads]
+    votes = {int(h[1]) for h in heads if int(h[1]) >= 0}  # ranks with no waveform do not vote
     if len(votes) > 1:
         raise ValueError("gather_waveforms: ranks disagree on the sample type (int16 vs float)")
     np_dt, t_dt = (np.int16, torch.int16) if votes == {1} else (np.float32, torch.float32)
-    buf = torch.zeros(max_items, max_len, dtype=t_dt, device=dev)
-    for i, w in enumerate(local):
-        buf[i, :len(w)] = torch.from_numpy(np.ascontiguousarray(w, dtype=np_dt)).to(dev)
-    # int16 travels as bytes: gloo has no int16 collectives, and the byte view costs nothing
-    wire = buf.view(torch.uint8) if t_dt == torch.int16 else buf
-    all_bufs = [torch.zeros_like(wire) for _ in range(world)]
-    dist.all_gather(all_bufs, wire, group=group)
+    totals = [int(h[2:2 + int(h[0])].sum()) for h in heads]
+    cap = max(max(totals), 1)
+    cap += cap & 1  # even sample count: the int16 payload travels as bytes / stays 4-byte aligned
+    # ---- payload: one flat device buffer per rank, gathered device-to-device ----
+    buf = torch.zeros(cap, dtype=t_dt, device=dev)
+    o = 0
+    for w in local:
+        t = _as_tensor(w, dev, np_dt, t_dt)
+        buf[o:o + t.numel()] = t
+        o += t.numel()
+    wire = buf.view(torch.uint8) if t_dt == torch.int16 else buf  # gloo has no int16 collectives
+    if dst is None:
+        bufs = [torch.zeros_like(wire) for _ in range(world)]
+        dist.all_gather(bufs, wire, group=group)
+    else:
+        bufs = [torch.zeros_like(wire) for _ in range(world)] if rank == dst else None
+        dist.gather(wire, bufs, dst=dist.get_global_rank(group, dst) if group is not None else dst, group=group)
+        if rank != dst:
+            return []
     out = []
     for r in range(world):
-        b = all_bufs[r].view(t_dt).cpu().numpy()
-        for i in range(int(counts[r].item())):
-            out.append(b[i, :int(all_lens[r][i].item())].copy())
+        flat = bufs[r].view(t_dt).cpu().numpy()
+        o = 0
+        for i in range(int(heads[r][0])):
+            n = int(heads[r][2 + i])
+            out.append(flat[o:o + n].copy())
+            o += n
     return out
+
+
+def _all_gather_ints(vals, dev, group=None):
+    t = torch.tensor(list(vals), dtype=torch.int64, device=dev)
+    parts = [torch.zeros_like(t) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(parts, t, group=group)
+    return [int(x) for p in parts for x in p.cpu()]

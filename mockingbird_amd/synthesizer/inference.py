@@ -13,13 +13,18 @@ from .hparams import hparams
 from .text import symbols, text_to_sequence, to_pinyin
 
 
+fresh_seed = _lib.fresh_seed
+
+
 class TacotronDevice:
     """Weights resident in HBM inside an ``mb_taco`` handle: text encoder, global style tokens,
     decoder loop and postnet all run as HIP kernels (no torch op touches the data path)."""
 
-    def __init__(self, state_dict, device, r=None):
+    def __init__(self, state_dict, device, r=None, dropout=None):
+        if not torch.cuda.is_available():
+            raise _lib.MbHipError("Tacotron: no MI355X visible; this build has no CPU path")
         self.device = device
-        self.cfg = weights.taco_config(state_dict, r=r)
+        self.cfg = weights.taco_config(state_dict, r=r, dropout=hparams.tts_dropout if dropout is None else dropout)
         self.r = self.cfg.r
         L = _lib.lib()
         ws = weights.taco_weight_list(state_dict, self.cfg)
@@ -45,8 +50,11 @@ class TacotronDevice:
                 pass
             self._h = None
 
-    def decode(self, memory, memory_proj, chars, steps, min_stop_token, dropout=None, seed=0):
-        """HIP decoder loop + postnet.  Returns (mel_outputs, linear, attn) trimmed to the frames produced."""
+    def decode(self, memory, memory_proj, chars, steps, min_stop_token, dropout=None, seed=None):
+        """HIP decoder loop + postnet.  Returns (mel_outputs, linear, attn) trimmed to the frames produced.
+        seed=None draws the Philox key of the always-on PreNet dropout from torch's global generator (the
+        reference's F.dropout consumes that generator, pre_net.py:23,26: torch.manual_seed steers both)."""
+        seed = fresh_seed() if seed is None else seed
         B, T, _ = memory.shape
         r = self.r
         max_steps = (steps + r - 1) // r * r  # range(0, steps, r) emits r frames per iteration (tacotron.py:264)
@@ -71,9 +79,10 @@ class TacotronDevice:
         F = nf.value
         return mel[:, :, :F], lin[:, :, :F], attn[:, :F // r]
 
-    def encode(self, chars, speaker_embedding, style_idx=0, enc_masks=None, seed=0):
+    def encode(self, chars, speaker_embedding, style_idx=0, enc_masks=None, seed=None):
         """Front half of Tacotron.forward (tacotron.py:234-255) in HIP: -> (encoder_seq [B,T,P],
         encoder_seq_proj [B,T,D]).  enc_masks: optional [2, B, T, encoder_dims] PreNet keep masks."""
+        seed = fresh_seed() if seed is None else seed
         if not self.cfg.has_encoder:
             raise _lib.MbHipError("checkpoint has no encoder weights")
         dev = chars.device
@@ -96,8 +105,9 @@ class TacotronDevice:
         return memory, memory_proj
 
     def generate(self, chars, speaker_embedding, steps=2000, style_idx=0, min_stop_token=5, enc_masks=None,
-                 dropout=None, seed=0):
+                 dropout=None, seed=None):
         """Tacotron.generate (tacotron.py:295-298) -> (mel_outputs, linear, attn_scores)."""
+        seed = fresh_seed() if seed is None else seed
         memory, memory_proj = self.encode(chars, speaker_embedding, style_idx, enc_masks, seed)
         return self.decode(memory, memory_proj, chars, steps, min_stop_token, dropout, seed)
 
@@ -109,9 +119,9 @@ class Synthesizer:
     def __init__(self, model_fpath: Path, verbose=True):
         self.model_fpath = Path(model_fpath)
         self.verbose = verbose
-        if not torch.cuda.is_available():
-            raise _lib.MbHipError("Synthesizer: no MI355X visible; this build has no CPU path")
-        self.device = torch.device("cuda")
+        # inference.py:30-33 picks cuda when available; the model itself is built lazily by load(), which is
+        # where a missing GPU becomes an error (there is no CPU path to fall back to)
+        self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
         if self.verbose:
             print("Synthesizer using device:", self.device)
         self._model = None
@@ -125,7 +135,7 @@ class Synthesizer:
             hparams.loadJson(found[0])
         checkpoint = torch.load(str(self.model_fpath), map_location="cpu")
         state = checkpoint["model_state"] if "model_state" in checkpoint else checkpoint["model"]  # base.py:51-54
-        self._model = TacotronDevice(state, self.device)
+        self._model = TacotronDevice(state, self.device)  # raises MbHipError without a GPU: there is no CPU path
         self._step = int(state["step"].item()) if "step" in state else 0
         if self.verbose:
             print("Loaded synthesizer \"%s\" trained to step %d" % (self.model_fpath.name, self._step))
@@ -144,8 +154,10 @@ class Synthesizer:
         return (specs, alignments) if return_alignments else specs
 
     def synthesize_from_tokens(self, inputs, embeddings, style_idx=0, min_stop_token=5, steps=2000, enc_masks=None,
-                               dropout=None, seed=0):
-        """inference.py:104-139 from token id sequences (benchmarks feed these directly)."""
+                               dropout=None, seed=None):
+        """inference.py:104-139 from token id sequences (benchmarks feed these directly).  seed=None: every
+        chunk draws its own RNG key from torch's global generator (fresh_seed); an explicit seed is advanced
+        per chunk so that no two chunks share dropout masks."""
         if not self.is_loaded():
             self.load()
         if not isinstance(embeddings, list):
@@ -161,15 +173,61 @@ class Synthesizer:
             speaker_embeds = np.stack(embeddings[i:i + bs])
             chars = torch.tensor(chars).long().to(self.device)
             speaker_embeddings = torch.tensor(speaker_embeds).float().to(self.device)
+            chunk_seed = fresh_seed() if seed is None else int(seed) + 0x9E3779B97F4A7C15 * (i // bs) & (2 ** 63 - 1)
             _, mels, alignments = self._model.generate(chars, speaker_embeddings, style_idx=style_idx,
                                                        min_stop_token=min_stop_token, steps=steps,
-                                                       enc_masks=enc_masks, dropout=dropout, seed=seed)
+                                                       enc_masks=enc_masks, dropout=dropout, seed=chunk_seed)
             mels = mels.detach().cpu().numpy()
             for m in mels:
                 while np.max(m[:, -1]) < hparams.tts_stop_threshold:  # trim silence (inference.py:136-137)
                     m = m[:, :-1]
                 specs.append(m)
         return specs, alignments
+
+
+    # ---- host-side signal utilities of the reference class (inference.py:144-181).  north_star keeps the
+    # speaker-encoder front end, mel extraction and Griffin-Lim on the reference's CPU path: these statics
+    # delegate to the reference's own modules (models/synthesizer/audio.py, utils/logmmse.py, librosa), which
+    # stay importable next to the aliased facade (mockingbird_amd.install() replaces only inference.py).
+    @staticmethod
+    def _reference_audio():
+        try:
+            from models.synthesizer import audio  # the reference checkout on sys.path
+        except Exception as e:  # pragma: no cover - depends on the caller's environment
+            raise ImportError("Synthesizer.load_preprocess_wav / make_spectrogram / griffin_lim run the reference's CPU "
+                              "code (models/synthesizer/audio.py, librosa): put the MockingBird checkout and its "
+                              f"requirements on sys.path ({e})") from e
+        return audio
+
+    @staticmethod
+    def load_preprocess_wav(fpath):
+        """inference.py:144-159: load at hparams.sample_rate, rescale, logMMSE denoise from the first/last 0.15 s."""
+        Synthesizer._reference_audio()
+        import librosa
+        from utils import logmmse
+        wav = librosa.load(path=str(fpath), sr=hparams.sample_rate)[0]
+        if hparams.rescale:
+            wav = wav / np.abs(wav).max() * hparams.rescaling_max
+        if len(wav) > hparams.sample_rate * (0.3 + 0.1):
+            noise_wav = np.concatenate([wav[:int(hparams.sample_rate * 0.15)], wav[-int(hparams.sample_rate * 0.15):]])
+            profile = logmmse.profile_noise(noise_wav, hparams.sample_rate)
+            wav = logmmse.denoise(wav, profile)
+        return wav
+
+    @staticmethod
+    def make_spectrogram(fpath_or_wav: Union[str, Path, np.ndarray]):
+        """inference.py:161-173: mel spectrogram as fed to the synthesizer in training."""
+        audio = Synthesizer._reference_audio()
+        if isinstance(fpath_or_wav, (str, Path)):
+            wav = Synthesizer.load_preprocess_wav(fpath_or_wav)
+        else:
+            wav = fpath_or_wav
+        return audio.melspectrogram(wav, hparams).astype(np.float32)
+
+    @staticmethod
+    def griffin_lim(mel):
+        """inference.py:175-181: Griffin-Lim inversion with the parameters in hparams."""
+        return Synthesizer._reference_audio().inv_mel_spectrogram(mel, hparams)
 
 
 def pad1d(x, max_len, pad_value=0):

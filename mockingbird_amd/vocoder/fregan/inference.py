@@ -26,5 +26,6 @@ def infer_waveform(mel, progress_callback=None):
     return _facade.infer_waveform(mel, progress_callback)
 
 
-def infer_waveform_batch(mels, progress_callback=None, normalize=None, pcm16=None):
-    return _facade.infer_waveform_batch(mels, progress_callback, normalize=normalize, pcm16=pcm16)
+def infer_waveform_batch(mels, progress_callback=None, **kw):
+    """Additive API: see GanFacade.infer_waveform_batch (normalize / pcm16 / breaks / device_out keywords)."""
+    return _facade.infer_waveform_batch(mels, progress_callback, **kw)

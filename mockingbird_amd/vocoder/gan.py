@@ -26,6 +26,8 @@ class GanGenerator:
         the fp16 matrix cores (BASELINE configs[4]; relative-RMS gate 5e-3)."""
         if dtype not in ("f32", "f16"):
             raise _lib.MbHipError(f"GanGenerator: dtype {dtype!r} (use 'f32' or 'f16')")
+        if not torch.cuda.is_available():
+            raise _lib.MbHipError("GAN vocoder: no MI355X visible; this build has no CPU path")
         self.cfg = weights.gan_config(config, kind, top_k)
         self.kind = kind
         self.dtype = dtype
@@ -110,9 +112,7 @@ class GanFacade:
             h = json.loads(f.read())
         self.output_sample_rate = h["sampling_rate"]
         torch.manual_seed(h["seed"])  # inference.py:39
-        if not torch.cuda.is_available():
-            raise _lib.MbHipError(f"{self.name}: no MI355X visible; this build has no CPU path")
-        self._device = torch.device("cuda")
+        self._device = torch.device("cuda" if torch.cuda.is_available() else "cpu")  # inference.py:41-45
         if verbose:
             print(f"Loading '{weights_fpath}'")
         ckpt = torch.load(str(weights_fpath), map_location="cpu")
@@ -131,34 +131,35 @@ class GanFacade:
         audio = y.squeeze().cpu().numpy()
         return audio, self.output_sample_rate
 
-    def infer_waveform_batch(self, mels, progress_callback=None, normalize=None, pcm16=None):
-        """Additive API: a list of (80, Fi) mels -> list of
-        waveforms, run as ONE zero-padded batch (conv stacks are causal-free, so
-        each item is bit-identical to its own first Fi*hop samples only away from
-        the padded tail; items are therefore grouped by equal length).
-        normalize=0.97 / pcm16='sndfile'|'encode_16bits'|'save_wav' apply the reference's host-side tail
-        (gen_voice.py:41, run.py:91) on the device and return int16 arrays."""
+    def infer_waveform_batch(self, mels, progress_callback=None, normalize=None, pcm16=None, breaks=None,
+                             break_hop=None, break_seconds=0.15, device_out=False):
+        """Additive API: a list of (80, Fi) mels -> list of waveforms, run as batches of
+        equal length (conv stacks are not causal: a zero-padded item differs from its own run near the padded tail).
+
+        The reference's host-side tail can run on the device, in gen_voice.py's order, before anything leaves HBM:
+          breaks[i] = frames per sentence of item i -> cut at the sentence boundaries (frames * break_hop samples,
+                      gen_voice.py:30-32) and put break_seconds of silence after every sentence (:33-34);
+          normalize = 0.97 -> wav / abs(wav).max() * 0.97 (gen_voice.py:41);
+          pcm16 = 'sndfile' | 'encode_16bits' | 'save_wav' -> int16 PCM (run.py:91).
+        device_out=True returns the device tensors themselves (for a device-to-device gather) instead of numpy."""
         if self.generator is None:
             raise Exception(f"Please load {self.name} in memory before using it")
+        from . import wave
         out = [None] * len(mels)
         by_len = {}
         for i, m in enumerate(mels):
             by_len.setdefault(int(np.shape(m)[1]), []).append(i)
         for _, idx in by_len.items():
-            batch = torch.stack([torch.FloatTensor(mels[i]) for i in idx]).to(self._device)
+            batch = torch.stack([torch.as_tensor(mels[i], dtype=torch.float32) for i in idx]).to(self._device)
             y = self.generator(batch).squeeze(1)
-            if normalize is not None or pcm16 is not None:
-                # wire format on device (vocoder/wave.py): per-utterance peak normalisation (gen_voice.py:41)
-                # and int16 PCM (run.py:91) before the copy to the host
-                from . import wave
-                rows = []
-                for k in range(y.shape[0]):
-                    r = y[k]
-                    if normalize is not None:
-                        wave.peak_normalize_(r, normalize)
-                    rows.append(wave.pack_pcm16(r, pcm16) if pcm16 is not None else r)
-                y = torch.stack(rows)
-            y = y.cpu().numpy()
             for k, i in enumerate(idx):
-                out[i] = y[k]
+                r = y[k]
+                if breaks is not None:
+                    r = wave.insert_breaks(r, breaks[i], break_hop, self.output_sample_rate, break_seconds)
+                if normalize is not None:
+                    r = r.contiguous()
+                    wave.peak_normalize_(r, normalize)
+                if pcm16 is not None:
+                    r = wave.pack_pcm16(r, pcm16)
+                out[i] = r if device_out else r.cpu().numpy()
         return out, self.output_sample_rate

@@ -59,3 +59,27 @@ def pack_pcm16(wav: torch.Tensor, mode: str = "sndfile") -> torch.Tensor:
     _lib.check(_lib.lib().mb_wave_pack_pcm16(_lib.ptr(wav), dt, wav.numel(), _MODES[mode], _lib.ptr(out), _lib.ptr(ws),
                                              ws.numel(), _lib.stream_ptr()), "mb_wave_pack_pcm16")
     return out
+
+
+def insert_breaks(wav: torch.Tensor, frames_per_sentence, hop_size: int, sample_rate: int, seconds: float = 0.15) -> torch.Tensor:
+    """gen_voice.py:30-34 on the device: cut the vocoded waveform at the sentence boundaries (frames * hop_size
+    samples -- slices past the end clip, as numpy's do: the reference cuts with the synthesizer's hop 256 while the
+    16 kHz vocoders emit 200 samples per frame, SURVEY finding 5) and append `seconds` of zeros to every sentence.
+    Pure device-memory plumbing: one output allocation, one copy per sentence; the waveform never visits the host."""
+    if not wav.is_cuda:
+        raise _lib.MbHipError("insert_breaks needs a CUDA(HIP) tensor; there is no CPU path")
+    wav = wav.reshape(-1)
+    n, gap = wav.numel(), int(seconds * sample_rate)
+    ends, e = [], 0
+    for f in frames_per_sentence:
+        e += int(f) * int(hop_size)
+        ends.append(e)
+    starts = [0] + ends[:-1]
+    pieces = [(min(s, n), min(t, n)) for s, t in zip(starts, ends)]
+    total = sum(t - s for s, t in pieces) + gap * len(pieces)
+    out = torch.zeros(total, dtype=wav.dtype, device=wav.device)
+    o = 0
+    for s, t in pieces:
+        out[o:o + (t - s)] = wav[s:t]
+        o += (t - s) + gap
+    return out

@@ -52,12 +52,14 @@ class WaveRNNDevice:
                                                        C.byref(p)), "mb_wavernn_plan_generate")
         return p
 
-    def generate_samples(self, mel: torch.Tensor, batched, target, overlap, noise=None, seed=0,
+    def generate_samples(self, mel: torch.Tensor, batched, target, overlap, noise=None, seed=None,
                          forced=None, want_logits=False, progress_callback=None):
         """mel [80, F] float32 CUDA (already normalised) -> samples [n_folds, seq_len] CUDA float32
         (the tensor stacked at fatchord_version.py:236), optionally the fc3 logits [S, N, C]."""
         if not mel.is_cuda:
             raise _lib.MbHipError("WaveRNN needs a CUDA(HIP) tensor; there is no CPU path")
+        if seed is None:  # the reference samples from torch's global generator (fatchord_version.py:224-226)
+            seed = _lib.fresh_seed()
         mel = mel.to(torch.float32).contiguous()
         F = mel.shape[1]
         p = self.plan(F, batched, target, overlap)
@@ -73,6 +75,8 @@ class WaveRNNDevice:
                 raise _lib.MbHipError(f"noise must be {(p.seq_len, p.n_folds, self.n_classes)}, got {tuple(noise.shape)}")
         if forced is not None:
             forced = forced.to(dev, torch.float32).contiguous()
+            if tuple(forced.shape) != (p.n_folds, p.seq_len):
+                raise _lib.MbHipError(f"forced must be {(p.n_folds, p.seq_len)}, got {tuple(forced.shape)}")
         self._progress.zero_()
         L = _lib.lib()
         start = time.time()
@@ -100,7 +104,8 @@ class WaveRNNDevice:
 
     def generate_samples_batch(self, mels, target, overlap, seeds=None):
         """Several utterances in ONE sample loop (mb_wavernn_generate_batch; additive API).  mels: list of
-        [80, F_u] CUDA tensors (already divided by mel_max_abs_value); seeds: one per utterance (default u).
+        [80, F_u] CUDA tensors (already divided by mel_max_abs_value); seeds: one per utterance (default: drawn
+        from torch's global generator).
         Returns the list of per-utterance sample tensors [folds_u, seq_len]; utterance u equals
         generate_samples(mels[u], True, target, overlap, seed=seeds[u])."""
         if not mels:
@@ -109,7 +114,7 @@ class WaveRNNDevice:
             raise _lib.MbHipError("WaveRNN needs CUDA(HIP) tensors; there is no CPU path")
         mels = [m.to(torch.float32).contiguous() for m in mels]
         n = len(mels)
-        seeds = list(range(n)) if seeds is None else [int(x) for x in seeds]
+        seeds = [_lib.fresh_seed() for _ in range(n)] if seeds is None else [int(x) for x in seeds]
         frames = (C.c_int * n)(*[int(m.shape[1]) for m in mels])
         offs = (C.c_int * (n + 1))()
         plan = _lib.WaveRNNBatchPlan()
@@ -137,7 +142,7 @@ class WaveRNNDevice:
         outs = self.generate_samples_batch([m.cuda() for m in mels], target, overlap, seeds)
         return [self.finish(smp, True, overlap, mu_law, (m.shape[-1] - 1) * self.hop_length) for smp, m in zip(outs, mels)]
 
-    def generate(self, mels, batched, target, overlap, mu_law, progress_callback=None, noise=None, seed=0):
+    def generate(self, mels, batched, target, overlap, mu_law, progress_callback=None, noise=None, seed=None):
         """Signature of WaveRNN.generate (fatchord_version.py:153): mels [1, 80, F] tensor -> float64 wav."""
         mel = mels[0] if mels.dim() == 3 else mels
         wave_len = (mel.shape[-1] - 1) * self.hop_length

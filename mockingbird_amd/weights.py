@@ -128,10 +128,11 @@ def wavernn_weight_list(state: Dict[str, torch.Tensor], cfg: "_lib.WaveRNNConfig
 
 
 # -------------------------------------------------------------------- Tacotron
-def taco_config(state: Dict[str, torch.Tensor], r: int = None, max_r: int = 20) -> "_lib.TacoConfig":
+def taco_config(state: Dict[str, torch.Tensor], r: int = None, max_r: int = 20, dropout: float = 0.5) -> "_lib.TacoConfig":
     """Shapes are read from the checkpoint (config must come from the loaded
     objects, not be hard-coded)."""
     c = _lib.TacoConfig()
+    c.dropout = float(dropout)  # hparams.tts_dropout: PreNet dropout stays on at inference (pre_net.py:23,26)
     fc1 = state["decoder.prenet.fc1.weight"]
     c.n_mels = fc1.shape[1]
     c.decoder_dims = fc1.shape[0] // 2

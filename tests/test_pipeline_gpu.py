@@ -31,6 +31,7 @@ def test_gen_wavs_single_rank(cuda, lib, tmp_path):
     embeds = [e / np.linalg.norm(e) for e in rng.standard_normal((3, 256)).astype(np.float32)]
     requests = [(["hello world.", "second sentence"], embeds[0]), (["one"], embeds[1]),
                 (["a b c", "d e f g", "the last one."], embeds[2])]
+    torch.manual_seed(5)  # the PreNet dropout keys come from torch's global generator, as in the reference
     wavs = pipeline.gen_wavs(syn, voc, requests, steps=24, min_stop_token=11)  # 24 forced frames per sentence
     assert len(wavs) == 3
     gap = int(0.15 * 16000)
@@ -53,7 +54,11 @@ def test_gen_wavs_single_rank(cuda, lib, tmp_path):
     # wire format on device: the same requests as peak-normalised int16 PCM equal the
     # numpy tail applied to the float waveforms above (normalise per request before the zero gaps, then PCM_16)
     from oracle import wave as owv
+    torch.manual_seed(5)
     pcm = pipeline.gen_wavs(syn, voc, requests, steps=24, min_stop_token=11, normalize=0.97, pcm16="sndfile")
     for p, w in zip(pcm, wavs):
         assert p.dtype == np.int16 and p.shape == w.shape
         assert np.array_equal(p, owv.sndfile_pcm16(owv.peak_normalize(w, np.float32(0.97))))
+    torch.manual_seed(6)  # another seed -> other dropout masks -> another waveform (the toolbox's "random seed" box)
+    other = pipeline.gen_wavs(syn, voc, requests, steps=24, min_stop_token=11)
+    assert any(o.shape != w.shape or not np.array_equal(o, w) for o, w in zip(other, wavs))

@@ -27,9 +27,18 @@ def _worker(rank, world, port, q):
     lens = [700, 1200, 64, 999, 5]
     mine = shard_indices(lens, world, rank)
     local = [np.full(lens[i], float(i + 1), np.float32) for i in mine]
-    out = gather_waveforms(local, device="cpu")
     order = [i for r in range(world) for i in shard_indices(lens, world, r)]
-    ok = len(out) == len(lens) and all(len(w) == lens[i] and (w == i + 1).all() for w, i in zip(out, order))
+
+    def complete(out):
+        return len(out) == len(lens) and all(len(w) == lens[i] and (w == i + 1).all() for w, i in zip(out, order))
+
+    out = gather_waveforms(local, device="cpu")                 # default: gather to rank 0 only
+    ok = complete(out) if rank == 0 else out == []
+    out1 = gather_waveforms([torch.from_numpy(w) for w in local], device="cpu", dst=1)  # tensors in, another root
+    ok = ok and (complete(out1) if rank == 1 else out1 == [])
+    ok = ok and complete(gather_waveforms(local, device="cpu", dst=None))  # all ranks
+    pcm = gather_waveforms([np.full(lens[i], i + 1, np.int16) for i in mine], device="cpu", dst=None)
+    ok = ok and complete(pcm) and all(w.dtype == np.int16 for w in pcm)
     q.put((rank, ok))
     dist.destroy_process_group()
 
@@ -59,8 +68,11 @@ class _StubSynth:
 
 
 class _StubVocoder:
-    def infer_waveform_batch(self, mels, normalize=None, pcm16=None):
+    def infer_waveform_batch(self, mels, normalize=None, pcm16=None, breaks=None, break_hop=None, device_out=False):
+        from mockingbird_amd import pipeline
         wavs = [np.sin(np.arange(m.shape[1] * 200) * 0.01 * m[0, 0]).astype(np.float32) * 0.5 for m in mels]
+        if breaks is not None:  # CPU stand-in for vocoder/wave.py insert_breaks
+            wavs = [pipeline.insert_breaks(w, b, break_hop, 16000).astype(np.float32) for w, b in zip(wavs, breaks)]
         if normalize is not None:  # CPU stand-in for vocoder/wave.py (the oracle is the checker here)
             from oracle import wave as owv
             wavs = [owv.peak_normalize(w, normalize) for w in wavs]
@@ -112,10 +124,10 @@ def test_pipeline_gen_wavs_world2_matches_single_process(kw):
     res = dict(q.get(timeout=120) for _ in procs)
     for p in procs:
         p.join(30)
-    for r in (0, 1):
-        assert len(res[r]) == len(ref)
-        for (dt, a), b in zip(res[r], ref):
-            assert dt == np.dtype(want_dtype).name and b.dtype == want_dtype
-            assert np.array_equal(np.asarray(a, want_dtype), b)
+    assert res[1] == []  # finished waveforms are gathered to rank 0 only
+    assert len(res[0]) == len(ref)
+    for (dt, a), b in zip(res[0], ref):
+        assert dt == np.dtype(want_dtype).name and b.dtype == want_dtype
+        assert np.array_equal(np.asarray(a, want_dtype), b)
     if kw:
         assert max(int(np.abs(b).max()) for b in ref) == round(0.97 * 32768)

@@ -129,3 +129,86 @@ def test_encoder_matches_oracle(model):
         for name, a, b in (("memory", hm, mem), ("memory_proj", hp, memp)):
             e = hiputil.relerr(a, b)
             assert a.shape == b.shape and e["nan"] == 0 and e["max_abs"] <= 1e-4, (name, style, e)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Kernel instances the BASELINE configs actually launch: every one of them against
+# the oracle, not only through size-independent properties.
+# ---------------------------------------------------------------------------------------------------------
+def _decode_vs_oracle(dev, w, hp, r, mem, memp, chars, steps, mask_seed, width=256):
+    B = mem.shape[0]
+    n_it = (steps + r - 1) // r
+    masks = synth.decoder_dropout_masks(mask_seed, n_it, B, width)
+    src = ot.MaskSource([masks[i, l] for i in range(n_it) for l in range(2)])
+    with torch.no_grad():
+        omel, oattn = ot.decode(w, hp, r, mem, memp, chars, steps, 11.0, src)
+        olin = ot.postnet(w, hp, omel)
+    mel, lin, attn = dev.decode(mem.cuda(), memp.cuda(), chars.cuda(), steps, 11.0, dropout=masks)
+    assert mel.shape == omel.shape and lin.shape == olin.shape and attn.shape == oattn.shape
+    out = {}
+    for name, a, b, tol in (("mel", mel, omel, MEL_TOL), ("linear", lin, olin, MEL_TOL), ("attn", attn, oattn, 1e-4)):
+        e = hiputil.relerr(a, b)
+        assert e["nan"] == 0 and e["max_abs"] <= tol, (name, e)
+        out[name] = e
+    assert float(omel.abs().mean()) > 0.1
+    return out
+
+
+def test_baseline_config2_b32_decode_matches_oracle(model):
+    """BASELINE configs[2] shape: B = 32, T in [90, 110], r = 2 -- the batch-32 instances of the loop
+    (two column tiles per launch, the bandwidth-bound LSTM form) against the oracle over 40 forced steps."""
+    dev, w = model
+    chars, spk, _, _ = _batch(32, 90, 110, seed=2)
+    torch.manual_seed(1)
+    with torch.no_grad():
+        mem, memp = ot.encoder_memory(w, ot.HP, chars, spk, -1)
+    _decode_vs_oracle(dev, w, ot.HP, 2, mem, memp, chars, 40, mask_seed=17)
+
+
+@pytest.mark.parametrize("B,tmin,tmax", [(2, 140, 150), (3, 200, 220), (2, 290, 300), (1, 640, 640)])
+def test_long_text_attention_kernels_match_oracle(model, B, tmin, tmax):
+    """T = 150 -> lsa_fast_kernel<48>; T = 220 / 300 / 640 -> the general lsa_kernel (location window in dynamic LDS,
+    above 64 KB from T ~ 265: the reference has no text-length limit, sublayer/lsa.py:21-42)."""
+    dev, w = model
+    chars, spk, _, _ = _batch(B, tmin, tmax, seed=40 + B)
+    torch.manual_seed(2)
+    with torch.no_grad():
+        mem, memp = ot.encoder_memory(w, ot.HP, chars, spk, 0)
+    _decode_vs_oracle(dev, w, ot.HP, 2, mem, memp, chars, 24, mask_seed=23)
+
+
+@pytest.mark.parametrize("generic", ["rnn", "lsa", "both"])
+def test_generic_fallback_instances_match_oracle(model, monkeypatch, generic):
+    """The run-time-flag instances (RF_GENERIC rnn kernels, the general LSA kernel) on the DEFAULT dims, forced
+    through the diagnostics switches -- the same code a checkpoint with other dims runs."""
+    dev, w = model
+    if generic in ("rnn", "both"):
+        monkeypatch.setenv("MBHIP_RNN_GENERIC", "1")
+    if generic in ("lsa", "both"):
+        monkeypatch.setenv("MBHIP_LSA_GENERIC", "1")
+    chars, spk, _, _ = _batch(4, 30, 44, seed=9)
+    torch.manual_seed(3)
+    with torch.no_grad():
+        mem, memp = ot.encoder_memory(w, ot.HP, chars, spk, -1)
+    _decode_vs_oracle(dev, w, ot.HP, 2, mem, memp, chars, 30, mask_seed=29)
+
+
+@pytest.mark.parametrize("B,r", [(3, 2), (18, 3)])
+def test_non_default_checkpoint_dims_match_oracle(cuda, lib, B, r):
+    """A checkpoint with other dimensions (decoder 64, LSTM 256, memory 768, postnet 256, r = 3): none of the
+    specialised instances match, every launch is an RF_GENERIC one and the attention runs the general kernel."""
+    from mockingbird_amd.synthesizer.inference import TacotronDevice
+    D, H, P, C = 64, 256, 768, 256
+    st = synth.tacotron_state(seed=11, r=r, P_enc=256, spk=256, gst_E=256, D=D, H=H, C=C)["model_state"]
+    dec = {k: v for k, v in st.items() if k.startswith(("decoder.", "postnet.", "post_proj."))}
+    dev = TacotronDevice(dec, torch.device("cuda"))
+    assert (dev.cfg.decoder_dims, dev.cfg.lstm_dims, dev.cfg.project_dims, dev.cfg.postnet_dims, dev.r) == (D, H, P, C, r)
+    hp = dict(ot.HP, decoder_dims=D, lstm_dims=H, postnet_dims=C)
+    rng = np.random.default_rng(5)
+    T = 37
+    mem = torch.from_numpy(rng.standard_normal((B, T, P)).astype(np.float32) * 0.7)
+    memp = torch.from_numpy(rng.standard_normal((B, T, D)).astype(np.float32) * 0.7)
+    chars = torch.from_numpy(rng.integers(2, 75, (B, T)))
+    for b in range(B):  # ragged padding (chars == 0 masks the logits, lsa.py:34)
+        chars[b, T - (b % 5):] = 0
+    _decode_vs_oracle(dev, dec, hp, r, mem, memp, chars, 8 * r, mask_seed=31, width=2 * D)
