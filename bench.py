@@ -6,8 +6,9 @@ configs[1]: WaveRNN 9-bit mu-law, batch 1, (80, 1000) mel, batched generation (t
 overlap 800 -> 23 folds x 9600 steps).  One "step" = one full infer_waveform-equivalent pass
 (conditioning networks + sample loop + device->host + float64 post-processing) over one
 utterance per GPU, mel already resident in HBM.  N>1: every rank vocodes its own utterance
-(weak scaling, no data-path collective) and finished waveforms are gathered to all ranks with
-RCCL (lengths + padded waveforms), inside the timed region.
+(weak scaling, no data-path collective) and the finished waveforms are gathered device-to-device to
+rank 0 with RCCL, inside the timed region.  `python bench.py --gpus N` without a launcher starts its
+own N ranks (torch.distributed.run); the line carries ranks_seen = dist.get_world_size().
 
 Also reports (same JSON line): roofline of the dominant loop kernel (HBM bound on the fp32
 weights), the CPU baseline (oracle = the reference's ATen-CPU arithmetic) on a bounded sample,
@@ -47,42 +48,332 @@ def parse():
     ap.add_argument("--no-ppg2mel", action="store_true")
     ap.add_argument("--no-wavernn-batch", action="store_true")
     ap.add_argument("--no-wavernn-unbatched", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the configs[3] / configs[4] sharded objects")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks_if_needed(args):
+    """`python bench.py --gpus N` with no launcher around it starts its own N ranks (one process per GPU) by
+    re-executing itself under torch.distributed.run -- the same command line the driver uses.  Under a launcher
+    (WORLD_SIZE set) this is a no-op; a WORLD_SIZE that disagrees with --gpus is an error, not a silent fallback."""
+    if "WORLD_SIZE" in os.environ:
+        world = int(os.environ["WORLD_SIZE"])
+        if world != args.gpus:
+            raise SystemExit(f"[bench] launched with WORLD_SIZE={world} but --gpus {args.gpus}: refusing to report a "
+                             f"line whose n_gpus is not the number of ranks that ran")
+        return
+    if args.gpus <= 1:
+        return
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.stdout.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
+class _StubModel:
+    """MBHIP_BENCH_STUB=1 (tests/test_bench_spawn.py, CPU + gloo): stands in for the WaveRNN handle so that the
+    launcher / barrier / max-over-ranks / gather / JSON plumbing can be exercised without a GPU.  The line it
+    produces says data = "stub"; it is never a measurement."""
+    hop_length, last_loop_ms = 256, 1.0
+
+    class _P:
+        n_folds, seq_len = 23, 9600
+    last_plan = _P()
+
+    def generate_samples(self, mel, batched, target, overlap, seed=0):
+        time.sleep(0.01)
+        return torch.zeros(23, 16)
+
+    def finish(self, samples, batched, overlap, mu_law, wave_len):
+        return np.zeros(4096, np.float64)
+
+
+def _median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
+
+
+def _reference_available():
+    try:
+        import refimport
+        return refimport.available()
+    except Exception:
+        return False
+
+
+def cpu_baseline_wavernn(state, F, target, overlap, n_useful, plan, cpu_seconds):
+    """The reference's WaveRNN.generate (fatchord_version.py:153-257) on the host cores, same weights and mel.
+    kind "reference": the real nn.Module from /root/reference, ONE full generate (it cannot be bounded: 23 folds x
+    9600 steps).  kind "port": oracle/wavernn.py (the same ATen-CPU ops in the same order) for ~cpu_seconds of the
+    same workload.  Threads: torch's default (all host cores), as the reference would run; no best-of probing."""
+    import synth
+    threads = torch.get_num_threads()
+    mel = synth.wavernn_mel(F, seed=1)
+    if _reference_available():
+        try:
+            import refimport
+            refimport.setup()
+            from models.vocoder.wavernn.models.fatchord_version import WaveRNN
+            from oracle import wavernn as ow
+            hp = ow.HP
+            m = WaveRNN(rnn_dims=hp["rnn_dims"], fc_dims=hp["fc_dims"], bits=hp["bits"], pad=hp["pad"],
+                        upsample_factors=hp["upsample_factors"], feat_dims=hp["feat_dims"], compute_dims=hp["compute_dims"],
+                        res_out_dims=hp["res_out_dims"], res_blocks=hp["res_blocks"], hop_length=hp["hop_length"],
+                        sample_rate=hp["sample_rate"], mode=hp["mode"])
+            m.load_state_dict(state, strict=False)
+            m.eval()
+            import contextlib
+            import io
+            t0 = time.perf_counter()
+            with contextlib.redirect_stdout(io.StringIO()):  # the reference draws a progress bar on stdout
+                out = m.generate(torch.from_numpy(mel[None] / 4.0), True, target, overlap, hp["mu_law"], None)
+            tc = time.perf_counter() - t0
+            return {"value": len(out) / tc, "unit": "samples/s", "cores": threads, "kind": "reference",
+                    "sample": f"the reference's WaveRNN.generate (imported from the checkout) on the same mel 80x{F}, one "
+                              f"full pass: {len(out)} samples in {tc:.1f} s"}
+        except Exception as e:  # fall through to the port, and say why
+            note = f" (reference import failed: {type(e).__name__}: {e})"
+    else:
+        note = " (no reference checkout on this host)"
+    from oracle import wavernn as ow
+    w = dict(state)
+    with torch.no_grad():
+        mels, aux = ow.conditioning(w, ow.HP, torch.from_numpy(mel[None, :, :] / 4.0), True, target, overlap)
+        nf = mels.shape[0]
+        ow.sample_loop(w, ow.HP, mels[:, :2], aux[:, :2])  # warm-up
+        t0c = time.perf_counter()
+        steps_done, chunk = 0, 10
+        while time.perf_counter() - t0c < cpu_seconds and steps_done + chunk <= mels.shape[1]:
+            ow.sample_loop(w, ow.HP, mels[:, steps_done:steps_done + chunk], aux[:, steps_done:steps_done + chunk])
+            steps_done += chunk
+        tc = time.perf_counter() - t0c
+    raw_rate = nf * steps_done / tc
+    useful = n_useful / float(plan.n_folds * plan.seq_len)
+    return {"value": raw_rate * useful, "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"oracle sample loop (the reference's ATen-CPU ops, oracle/wavernn.py){note}: {nf} folds x {steps_done} "
+                      f"steps of the same workload in {tc:.1f} s with torch's default {threads} threads; raw "
+                      f"{raw_rate:.0f} fold-steps/s scaled by the useful-sample fraction {useful:.3f}"}
+
+
+def cpu_baseline_hifigan():
+    """BASELINE configs[0]: HiFi-GAN infer_waveform on 1 x (80, 200), CPU, median of 3."""
+    import synth
+    from oracle import gan as og
+    h = synth.HIFIGAN_16K
+    st = synth.gan_state(h, "hifigan", seed=3)["generator"]
+    mel = torch.from_numpy(synth.mel_input(200, 1, seed=0))
+    kind, fwd = "port", None
+    if _reference_available():
+        try:
+            import refimport
+            refimport.setup()
+            from models.vocoder.hifigan.models import Generator
+            from utils.util import AttrDict
+            import contextlib
+            import io
+            with contextlib.redirect_stdout(io.StringIO()):
+                g = Generator(AttrDict(h))
+                g.load_state_dict(st)
+                g.eval()
+                g.remove_weight_norm()
+            kind, fwd = "reference", (lambda: g(mel))
+        except Exception:
+            fwd = None
+    if fwd is None:
+        w = og.fold_weight_norm_state(st)
+        fwd = lambda: og.hifigan_forward(w, h, mel)  # noqa: E731
+    ts = []
+    with torch.no_grad():
+        fwd()
+        for _ in range(3):
+            t0 = time.perf_counter()
+            y = fwd()
+            ts.append(time.perf_counter() - t0)
+    t = _median(ts)
+    return {"value": y.numel() / t, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": kind,
+            "sample": f"BASELINE configs[0]: generator forward on 1 x (80,200), median of 3 = {t * 1e3:.1f} ms "
+                      f"({'the reference Generator' if kind == 'reference' else 'oracle/gan.py, the same ATen-CPU ops'})"}
+
+
+def _ref_tacotron(Tacotron, rhp, symbols):
+    # models/synthesizer/inference.py:54-67
+    return Tacotron(embed_dims=rhp.tts_embed_dims, num_chars=len(symbols), encoder_dims=rhp.tts_encoder_dims,
+                    decoder_dims=rhp.tts_decoder_dims, n_mels=rhp.num_mels, fft_bins=rhp.num_mels,
+                    postnet_dims=rhp.tts_postnet_dims, encoder_K=rhp.tts_encoder_K, lstm_dims=rhp.tts_lstm_dims,
+                    postnet_K=rhp.tts_postnet_K, num_highways=rhp.tts_num_highways, dropout=rhp.tts_dropout,
+                    stop_threshold=rhp.tts_stop_threshold, speaker_embedding_size=rhp.speaker_embedding_size)
+
+
+def cpu_baseline_tacotron():
+    """BASELINE configs[2]: Tacotron.generate, B = 32, ~100 tokens, 400 frames forced, CPU, median of 3."""
+    import synth
+    from oracle import tacotron as ot
+    tst = synth.tacotron_state(seed=3)["model_state"]
+    seqs, emb = synth.tacotron_inputs(32, 90, 110, seed=2)
+    Tt = max(len(q) for q in seqs)
+    chars = torch.tensor(np.stack([np.pad(q, (0, Tt - len(q))) for q in seqs])).long()
+    spk = torch.tensor(np.stack(emb))
+    kind, fwd = "port", None
+    if _reference_available():
+        try:
+            import refimport
+            refimport.setup()
+            from models.synthesizer.models.tacotron import Tacotron
+            from models.synthesizer.hparams import hparams as rhp
+            from models.synthesizer.utils.symbols import symbols
+            import contextlib
+            import io
+            with contextlib.redirect_stdout(io.StringIO()):
+                m = _ref_tacotron(Tacotron, rhp, symbols)
+            m.load_state_dict(tst, strict=False)
+            m.eval()
+            kind, fwd = "reference", (lambda: m.generate(chars, spk, steps=400, style_idx=-1, min_stop_token=11))
+        except Exception:
+            fwd = None
+    if fwd is None:
+        fwd = lambda: ot.generate(tst, ot.HP, 2, chars, spk, steps=400, style_idx=-1, min_stop_token=11)  # noqa: E731
+    ts = []
+    with torch.no_grad():
+        for _ in range(3):
+            t0 = time.perf_counter()
+            out = fwd()
+            ts.append(time.perf_counter() - t0)
+    t = _median(ts)
+    frames = int(out[1].shape[-1]) * 32
+    return {"value": frames / t, "unit": "mel frames/s", "cores": torch.get_num_threads(), "kind": kind,
+            "sample": f"BASELINE configs[2]: generate, B=32, T={Tt}, {frames // 32} frames forced, median of 3 = {t:.2f} s "
+                      f"({'the reference Tacotron' if kind == 'reference' else 'oracle/tacotron.py, the same ATen-CPU ops'})"}
+
+
+def sharded_objects(args, rank, world, dev, use_dist, timed, total_over_ranks):
+    """The two BASELINE configs that are DEFINED on 8 GPUs, as weak-scaling objects (every rank runs its per-GPU share,
+    finished waveforms gathered device-to-device to rank 0 inside the timed region):
+      configs[3]: end-to-end gen_voice.py shape, Tacotron2 + HiFi-GAN, 256 requests / 8 GPUs = 32 per rank
+      configs[4]: Fre-GAN fp16, batch 64 x (80,3000) / 8 GPUs = 8 per rank."""
+    import tempfile
+    import synth
+    from mockingbird_amd import pipeline
+    from mockingbird_amd.synthesizer.inference import Synthesizer
+    from mockingbird_amd.vocoder import gan as gan_mod
+    out = {}
+    tmp = tempfile.mkdtemp(prefix=f"mbhip_bench_r{rank}_")
+    # ---- configs[3] ----
+    torch.save(synth.tacotron_state(seed=3), os.path.join(tmp, "taco.pt"))
+    syn = Synthesizer(os.path.join(tmp, "taco.pt"), verbose=False)
+    voc = gan_mod.GanFacade(gan_mod.KIND_HIFIGAN, "", "hifigan")
+    os.makedirs(os.path.join(tmp, "voc"))
+    torch.save(synth.gan_state(synth.HIFIGAN_16K, "hifigan", seed=3), os.path.join(tmp, "voc", "g.pt"))
+    json.dump(synth.HIFIGAN_16K, open(os.path.join(tmp, "voc", "config.json"), "w"))
+    voc.load_model(os.path.join(tmp, "voc", "g.pt"), verbose=False)
+    rng = np.random.default_rng(7)  # every rank draws the same request list: ~100-character ASCII prompts
+    n_req = 32 * world
+    alphabet = np.array(list("abcdefghijklmnopqrstuvwxyz     "))
+    requests = []
+    for i in range(n_req):
+        text = "".join(rng.choice(alphabet, int(rng.integers(90, 111)))).strip() or "a"
+        e = rng.standard_normal(256).astype(np.float32)
+        requests.append(([text], e / np.linalg.norm(e)))
+    import contextlib
+    import io
+
+    def e2e(_):
+        with contextlib.redirect_stdout(io.StringIO()):  # the facade prints the prompts, like the reference
+            wavs = pipeline.gen_wavs(syn, voc, requests, steps=400, min_stop_token=11, normalize=0.97, pcm16="sndfile")
+        return sum(len(w) for w in wavs)  # rank 0 holds everything after the gather; other ranks 0
+
+    el, res = timed(e2e, 1, 1)
+    n_samples = total_over_ranks(res[0])
+    out["e2e_configs3"] = {
+        "workload": f"BASELINE configs[3]: {n_req} cloned-voice requests (~100 tokens, one sentence) sharded over {world} GPU(s) "
+                    "= 32 per rank: Synthesizer.synthesize_spectrograms (chunks of 16, 400 frames forced) -> HiFi-GAN V1 fp32 -> "
+                    "0.15 s breaks, peak normalise, int16 PCM on the device -> device-to-device gather to rank 0",
+        "value": n_samples / el, "unit": "samples/s", "x_realtime": n_samples / el / 16000.0, "s_total": el,
+        "requests": n_req, "n_gpus": world, "scaling": "weak"}
+    del syn, voc
+    # ---- configs[4] ----
+    hf = synth.FREGAN_16K
+    gen = gan_mod.GanFacade(gan_mod.KIND_FREGAN, "", "fregan")
+    os.makedirs(os.path.join(tmp, "fre"))
+    torch.save(synth.gan_state(hf, "fregan", seed=4), os.path.join(tmp, "fre", "g.pt"))
+    json.dump(hf, open(os.path.join(tmp, "fre", "config.json"), "w"))
+    gen.load_model(os.path.join(tmp, "fre", "g.pt"), verbose=False, dtype="f16")
+    mels = [m for m in synth.mel_input(3000, 8, seed=1 + rank)]
+    from mockingbird_amd import sharding
+
+    def fre(_):
+        wavs, _sr = gen.infer_waveform_batch(mels, pcm16="sndfile", device_out=True)
+        got = sharding.gather_waveforms(wavs, dev, dst=0)
+        return sum(len(w) for w in got)
+
+    el, res = timed(fre, 2, 1)
+    n_samples = total_over_ranks(sum(res))
+    fl = FREGAN_MFLOP_PER_FRAME * 1e6 * 3000 * 8 * world * 2
+    out["fregan_configs4"] = {
+        "workload": f"BASELINE configs[4]: Fre-GAN fp16 MFMA, batch {8 * world} x mel (80,3000) = 8 per rank over {world} GPU(s): "
+                    "H2D of the mels, generator forward, int16 PCM on the device, gather to rank 0 (2 timed passes)",
+        "value": n_samples / el, "unit": "samples/s", "x_realtime": n_samples / el / 16000.0, "s_total": el,
+        "n_gpus": world, "scaling": "weak", "aggregate_TFLOPs": fl / el / 1e12}
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
+    spawn_ranks_if_needed(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    stub = os.environ.get("MBHIP_BENCH_STUB") == "1"
     import torch.distributed as dist
     use_dist = world > 1
     if use_dist:
-        # N > 1: the line is the sharded headline workload + its roofline; the secondary single-GPU objects and
-        # the CPU baseline are N = 1 material (rank 0 would otherwise keep the other ranks waiting ~1 min)
+        # N > 1: the line is the sharded headline workload + its roofline and the sharded configs[3]/[4] objects; the
+        # single-GPU secondary objects and the CPU baseline are N = 1 material (rank 0 would keep the others waiting)
         args.no_hifigan = args.no_tacotron = args.no_ppg2mel = args.no_cpu_baseline = args.no_wavernn_batch = True
         args.no_wavernn_unbatched = True
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if stub:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if stub:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    ranks_seen = dist.get_world_size() if use_dist else 1
 
-    from mockingbird_amd import build, _lib
-    if rank == 0:
-        build.build(verbose=False)
-    if use_dist:
-        dist.barrier()
+    def sync():
+        if not stub:
+            torch.cuda.synchronize()
+
     import synth
-    from mockingbird_amd.vocoder.wavernn.inference import WaveRNNDevice
     from mockingbird_amd import sharding
-
-    state = synth.wavernn_state(seed=5)["model_state"]
-    model = WaveRNNDevice(state)
+    if stub:
+        model, state, _lib = _StubModel(), None, None
+    else:
+        from mockingbird_amd import build, _lib
+        if rank == 0:
+            build.build(verbose=False)
+        if use_dist:
+            dist.barrier()
+        from mockingbird_amd.vocoder.wavernn.inference import WaveRNNDevice
+        state = synth.wavernn_state(seed=5)["model_state"]
+        model = WaveRNNDevice(state)
     F = args.frames
     target, overlap = 8000, 800
     # each rank owns one utterance (seed differs per rank), already resident in HBM
@@ -91,44 +382,65 @@ def main():
 
     def one_pass(seed):
         samples = model.generate_samples(mel, True, target, overlap, seed=seed)
-        wav = model.finish(samples, True, overlap, True, wave_len)  # float64 tail on the device, D2H of the waveform
-        if use_dist:
-            wavs = sharding.gather_waveforms([wav.astype(np.float32)], dev)
-            return wav, sum(len(w) for w in wavs)
+        if use_dist and not stub:
+            # float64 tail on the device; the finished waveform goes device-to-device to rank 0 (the only exchange
+            # of the whole path), which copies the gathered set to the host once
+            wav = model.finish(samples, True, overlap, True, wave_len, device_out=True)
+            sharding.gather_waveforms([wav.to(torch.float32)], dev, dst=0)
+        else:
+            wav = model.finish(samples, True, overlap, True, wave_len)  # float64 tail on the device, D2H of the waveform
+            if use_dist:
+                sharding.gather_waveforms([wav.astype(np.float32)], dev, dst=0)
         return wav, len(wav)
 
-    for i in range(args.warmup):
-        one_pass(1000 + i)
+    def timed(fn, steps, warmup):
+        """warmup untimed calls, then exactly `steps` calls bracketed by barrier + synchronize on both sides;
+        returns (max-over-ranks seconds, per-rank results of the timed calls)."""
+        for i in range(warmup):
+            fn(1000 + i)
+        sync()
+        if use_dist:
+            dist.barrier()
+        sync()
+        t0_ = time.perf_counter()
+        res = [fn(i) for i in range(steps)]
+        sync()
+        if use_dist:
+            dist.barrier()
+        sync()
+        el = time.perf_counter() - t0_
+        if use_dist:
+            te = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            el = float(te.item())
+        return el, res
+
+    def total_over_ranks(n):
+        if not use_dist:
+            return n
+        t = torch.tensor([n], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+
     loop_ms = []
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    total_samples = 0
-    for i in range(args.steps):
-        wav, n = one_pass(i)
-        total_samples += n
+
+    def headline(i):
+        wav_, n_ = one_pass(i)
         loop_ms.append(model.last_loop_ms)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
-    else:
-        total_samples = total_samples  # single rank: its own utterance
+        return wav_, n_
+
+    elapsed, res = timed(headline, args.steps, args.warmup)
+    loop_ms = loop_ms[args.warmup:]
+    wav = res[-1][0]
+    total_samples = total_over_ranks(sum(n for _, n in res))  # every rank vocoded its own utterance
     plan = model.last_plan
     value = total_samples / elapsed
     result = {
         "metric": "audio samples/sec (16 kHz), WaveRNN vocoder.infer_waveform",
         "value": value, "unit": "samples/s", "x_realtime": value / 16000.0,
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1000.0, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32", "data": "stub" if stub else "synthetic",
         "config": {"workload": "BASELINE configs[1]: WaveRNN 9-bit mu-law RAW, batch=1 utterance/GPU, "
                                f"mel 80x{F}, batched target=8000 overlap=800 -> {plan.n_folds} folds x "
                                f"{plan.seq_len} steps, Philox sampling, fp32 weights (synthetic, seeded)",
@@ -137,6 +449,15 @@ def main():
                    "us_per_time_step": float(np.median(loop_ms)) * 1000.0 / plan.seq_len},
     }
 
+    if stub:
+        if rank == 0:
+            print(json.dumps(result))
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    if not args.no_e2e:
+        result.update(sharded_objects(args, rank, world, dev, use_dist, timed, total_over_ranks))
     if rank == 0:
         # ---- roofline of the dominant loop kernel: rnn_rowtile_kernel<GRU> (rnn1), HBM/L2-bound on weights
         L = _lib.lib()
@@ -158,19 +479,23 @@ def main():
         dom = per_kernel[dom_name]
         # HBM traffic of that kernel from the committed rocprofv3 PMC pass (FETCH_SIZE doubled per
         # MI355X_MICROARCH.md's gfx950 correction + WRITE_SIZE); counters cannot be read in-process
-        traffic = None
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_wavernn.json")))
-            traffic = pm.get(("fc1_hh1" if split else "rnn2_gru") + "_hbm_bytes_per_launch")
-        except Exception:
-            pass
+        traffic, traffic_src = None, None
+        for cand in ("r02_pmc_wavernn.json", "r01_pmc_wavernn.json"):
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", cand)))
+                traffic = pm.get(("fc1_hh1" if split else "rnn2_gru") + "_hbm_bytes_per_launch")
+                traffic_src = f"profiles/{cand}: {pm.get('source', '')[:160]}"
+                if traffic is not None:
+                    break
+            except Exception:
+                pass
         result["roofline"] = {
             "kernel": ("mb::rnn_dual_linear_kernel<4, ..., 4, ...> (WaveRNN fc1 beside the hidden half of the next step's "
                        "rnn1, in-situ marginal duration)" if split else
                        "mb::rnn_rowtile_kernel<EPI_GRU, 1, 8, ...> (WaveRNN rnn2 instance, in-situ marginal duration)"),
             "chain": "split-hidden" if split else "classic",
             "bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
+            "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": dom["algorithmic_bytes"], "avg_launch_us": dom["avg_us"],
             "whole_step": {"algorithmic_bytes": 16.3e6 + 452.0 * plan.n_folds,
                            "us": result["config"]["us_per_time_step"],
@@ -347,45 +672,14 @@ def main():
                                  "unit": "GB/s", "frac": wbytes / (entry["batch1"]["us_per_step"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                  "traffic": None, "algorithmic_bytes_per_step": wbytes}
             result["ppg2mel"] = entry
-        # ---- CPU baseline: the oracle (reference's ATen CPU arithmetic) on a bounded sample
+        # ---- CPU baselines: the reference itself when its checkout is importable (this container), else the oracle
+        # port (the GPU box has no /root/reference); torch's default thread count = what the reference would use
         if not args.no_cpu_baseline:
-            from oracle import wavernn as ow
-            w = dict(state)
-            with torch.no_grad():
-                mels, aux = ow.conditioning(w, ow.HP, torch.from_numpy(synth.wavernn_mel(F, seed=1)[None, :, :] / 4.0),
-                                            True, target, overlap)
-                nf = mels.shape[0]
-                # The reference would run with torch's default thread count (= all host cores); on a
-                # many-core host that oversubscribes these tiny GEMVs, so probe a few settings and
-                # time the bounded sample with the fastest one (reported in `cores`).
-                ncores = os.cpu_count() or 1
-                best_t, best_rate = 1, 0.0
-                for nt in sorted({1, 4, 8, 16, min(32, ncores)}):
-                    if nt > ncores:
-                        continue
-                    torch.set_num_threads(nt)
-                    ow.sample_loop(w, ow.HP, mels[:, :2], aux[:, :2])
-                    tp = time.perf_counter()
-                    ow.sample_loop(w, ow.HP, mels[:, :8], aux[:, :8])
-                    rate = 8 / (time.perf_counter() - tp)
-                    if rate > best_rate:
-                        best_t, best_rate = nt, rate
-                torch.set_num_threads(best_t)
-                t0c = time.perf_counter()
-                steps_done = 0
-                chunk = 10
-                while time.perf_counter() - t0c < args.cpu_seconds and steps_done + chunk <= mels.shape[1]:
-                    ow.sample_loop(w, ow.HP, mels[:, steps_done:steps_done + chunk], aux[:, steps_done:steps_done + chunk])
-                    steps_done += chunk
-                tc = time.perf_counter() - t0c
-            raw_rate = nf * steps_done / tc
-            useful = len(wav) / float(plan.n_folds * plan.seq_len)
-            result["cpu_baseline"] = {
-                "value": raw_rate * useful, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-                "sample": f"oracle sample loop (reference ATen-CPU ops), {nf} folds x {steps_done} steps of the same "
-                          f"workload in {tc:.1f} s; raw {raw_rate:.0f} fold-steps/s scaled by the useful-sample "
-                          f"fraction {useful:.3f}",
-            }
+            result["cpu_baseline"] = cpu_baseline_wavernn(state, F, target, overlap, len(wav), plan, args.cpu_seconds)
+            if "hifigan" in result:
+                result["hifigan"]["cpu_baseline"] = cpu_baseline_hifigan()
+            if "tacotron" in result:
+                result["tacotron"]["cpu_baseline"] = cpu_baseline_tacotron()
         print(json.dumps(result))
     if use_dist:
         dist.barrier()

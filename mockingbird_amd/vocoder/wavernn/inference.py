@@ -150,7 +150,7 @@ class WaveRNNDevice:
                                         progress_callback=progress_callback)
         return self.finish(samples, batched, overlap, mu_law, wave_len)
 
-    def finish(self, samples, batched, overlap, mu_law, wave_len):
+    def finish(self, samples, batched, overlap, mu_law, wave_len, device_out=False):
         """Float64 tail of WaveRNN.generate (fatchord_version.py:236-257) on the device: xfade_and_unfold,
         decode_mu_law, de_emphasis, truncation to wave_len, linear fade-out over 20 hops.  Only the finished
         waveform crosses PCIe.  Returns np.float64 like the reference."""
@@ -172,7 +172,8 @@ class WaveRNNDevice:
                                        self.n_classes, int(bool(mu_law)), int(bool(self.hp.apply_preemphasis)),
                                        float(self.hp.preemphasis), wave_len, fade_n, _lib.ptr(wav), C.byref(got),
                                        _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "mb_wavernn_finish")
-        return wav[:got.value].cpu().numpy()
+        # device_out: keep the float64 waveform in HBM (multi-GPU gather, further device-side post-processing)
+        return wav[:got.value] if device_out else wav[:got.value].cpu().numpy()
 
 
 def load_model(weights_fpath, verbose=True):

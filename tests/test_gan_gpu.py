@@ -27,8 +27,9 @@ def _run(kind, h, frames, batch, seed, dtype="f32"):
 
 
 @pytest.mark.parametrize("kind,cfg", [("hifigan", synth.HIFIGAN_16K), ("fregan", synth.FREGAN_16K)])
-@pytest.mark.parametrize("uic,frames,batch", [(64, 16, 2), (64, 37, 1), (512, 12, 1)])
+@pytest.mark.parametrize("uic,frames,batch", [(64, 16, 2), (64, 37, 1), (512, 12, 1), (512, 200, 1)])
 def test_gan_forward_matches_oracle(cuda, lib, kind, cfg, uic, frames, batch):
+    """(512, 200, 1) is BASELINE configs[0] at full size: the shipped config, one (80, 200) mel."""
     h = synth.small(cfg, uic)
     y, ref = _run(kind, h, frames, batch, seed=3)
     assert y.shape == ref.shape == (batch, 1, frames * 200)
@@ -44,7 +45,8 @@ F16_REL_TOL = 5e-3  # fp16 gate, relative RMS, reported se
 @pytest.mark.parametrize("kind,cfg,uic,frames,batch", [
     ("hifigan", synth.HIFIGAN_16K, 128, 16, 2), ("hifigan", synth.HIFIGAN_16K, 256, 37, 1),
     ("hifigan", synth.HIFIGAN_16K, 512, 12, 1), ("fregan", synth.FREGAN_16K, 256, 16, 2),
-    ("fregan", synth.FREGAN_16K, 256, 37, 1), ("fregan", synth.FREGAN_16K, 512, 12, 1)])
+    ("fregan", synth.FREGAN_16K, 256, 37, 1), ("fregan", synth.FREGAN_16K, 512, 12, 1),
+    ("hifigan", synth.HIFIGAN_16K, 512, 200, 1), ("fregan", synth.FREGAN_16K, 512, 200, 2)])
 def test_gan_forward_f16_matches_oracle(cuda, lib, kind, cfg, uic, frames, batch):
     """fp16 MFMA path (BASELINE configs[4]) against the fp32 oracle."""
     h = synth.small(cfg, uic)
@@ -181,3 +183,18 @@ def test_fregan_f16_config4_share_properties(cuda, lib):
     e = hiputil.relerr(y1, y32)
     print("fregan f16 vs f32, 3000 frames", e)
     assert e["rel_rms"] <= F16_REL_TOL, e
+
+
+@pytest.mark.parametrize("kind,cfg,uic,frames,batch", [("hifigan", synth.HIFIGAN_16K, 256, 23, 2),
+                                                       ("fregan", synth.FREGAN_16K, 512, 12, 1)])
+def test_gan_f16_unfused_path_matches_oracle(cuda, lib, monkeypatch, kind, cfg, uic, frames, batch):
+    """MBHIP_GAN_NOFUSE=1 (read at create time): every ResBlock conv as its own conv1d_f16 launch -- the path
+    shapes without a fused ResBlock-unit instance take -- against the fp32 oracle, and against the fused path."""
+    h = synth.small(cfg, uic)
+    fused, ref = _run(kind, h, frames, batch, seed=5, dtype="f16")
+    monkeypatch.setenv("MBHIP_GAN_NOFUSE", "1")
+    unfused, _ = _run(kind, h, frames, batch, seed=5, dtype="f16")
+    e = hiputil.relerr(unfused, ref)
+    assert e["nan"] == 0 and e["rel_rms"] <= F16_REL_TOL, e
+    d = hiputil.relerr(unfused, fused)
+    assert d["rel_rms"] <= F16_REL_TOL, d

@@ -63,6 +63,39 @@ def test_teacher_forced_logits(model, monkeypatch, frames, batched, target, over
         assert not bad.any(), f"{int(bad.sum())} non-tie sample mismatches"
 
 
+def test_baseline_config1_teacher_forced_logits_23_folds(model):
+    """BASELINE configs[1] geometry against the oracle directly: mel 80 x 1000, target 8000 / overlap 800 -> 23 folds
+    (two column tiles, the second one ragged: 7 live columns), 200 teacher-forced steps: fc3 logits <= 1e-3 and the
+    same class indices except provable near-ties."""
+    dev, w = model
+    frames, target, overlap, steps = 1000, 8000, 800, 200
+    mel = synth.wavernn_mel(frames, seed=1)
+    mels, aux = _oracle_cond(w, mel, True, target, overlap)
+    n, S = mels.shape[0], mels.shape[1]
+    assert (n, S) == (23, 9600)
+    g = torch.Generator().manual_seed(21)
+    noise_head = torch.stack([torch.empty(n, 512).exponential_(1, generator=g) for _ in range(steps)])
+    with torch.no_grad():
+        o_samples, o_logits = ow.sample_loop(w, ow.HP, mels, aux, noise=noise_head, return_logits=True, max_steps=steps)
+    # the ABI takes noise for the whole sequence; only the first `steps` draws matter for the compared prefix
+    noise = torch.ones(S, n, 512)
+    noise[:steps] = noise_head
+    forced = torch.zeros(n, S)
+    forced[:, :steps] = o_samples
+    s, lg = dev.generate_samples(torch.from_numpy(mel / 4.0).cuda(), True, target, overlap, noise=noise, forced=forced,
+                                 want_logits=True)
+    e = hiputil.relerr(lg[:steps], o_logits)
+    assert e["nan"] == 0 and e["max_abs"] <= 1e-3, e
+    k_hip = torch.round((s[:, :steps].cpu() + 1) * 511 / 2).long()
+    k_or = torch.round((o_samples + 1) * 511 / 2).long()
+    mism = (k_hip != k_or)
+    if mism.any():
+        post = torch.softmax(o_logits, dim=2) / noise_head
+        top2 = post.topk(2, dim=2).values
+        ratio = (top2[..., 0] - top2[..., 1]) / top2[..., 0]
+        assert not (mism.t() & (ratio > 1e-4)).any()
+
+
 def test_free_running_injected_noise_and_waveform(model):
     """Free-running generation with injected noise reproduces the oracle's sample stream and the
     facade's post-processing (xfade, mu-law, de-emphasis, fade) its float64 waveform."""
