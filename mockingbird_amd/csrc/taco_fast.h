@@ -1,0 +1,356 @@
+// Tacotron decoder iteration, production shape (decoder 128, memory 1024, LSTM 1024): the seven launches of
+// one iteration (tacotron.py:71-138) on activations kept in MFMA-fragment order.
+//
+// What the first-generation loop (rnn_rowtile_body, 9 launches per iteration) paid for, per
+// profiles/r01_tacotron_generate_kernel_stats.csv and r01_pmc_tacotron.json:
+//   * every B-operand load was a 16-byte piece of a [column][K] row: 16 half-used cache lines per wave
+//     instruction, the activations re-read by every row tile through that path (2 x the weight bytes for the
+//     batch-32 LSTMs: 33.5 MB in 15.3 us = 2.2 TB/s, 47 % of the wave cycles stalled on issue);
+//   * cell outputs were written back as 4-byte stores 4 KB apart;
+//   * two launches (prenet fc1, finalize) and the context / hidden-state parts of the attention GRU sat on the
+//     dependent chain although their inputs are known a launch (or an iteration) earlier.
+// Here:
+//   * FM ("fragment-major") activations: element (column n, feature k) of a K-vector set lives at
+//       ((k/16 * NTA + n/16) * 64 + (k/4 % 4) * 16 + n % 16) * 4 + k % 4          (NTA = column tiles)
+//     so the B fragment of a (k-block, column tile) is ONE contiguous 1 KB read -- the same shape as the packed A
+//     fragments -- and the LINEAR / GRU / LSTM epilogues, whose lanes own (row quad | unit, column), store
+//     contiguous 1 KB / 256 B pieces of the next launch's operand.
+//   * CM4 / CM1 ("cell-major") per-(unit, column) quads / scalars at (unit/4 * NTA + n/16) * 64 + lane: what one
+//     epilogue lane writes is what the consuming epilogue lane reads (gate pre-activations, LSTM cell state).
+//   * every weight and activation fragment of a wave (K/128 k-blocks) is requested before the first MFMA; the two
+//     column tiles of a workgroup alternate on the matrix pipe, so consecutive MFMAs are independent.
+//   * chain: fc2 | attention GRU on its prenet columns only | LSA + context | rnn_input beside the NEXT iteration's
+//     GRU context/hidden pre-activations | LSTM1 | LSTM2 | mel_proj beside the next iteration's prenet fc1 (folded
+//     through mel_proj: fc1 . mel_proj[last frame], exact algebra) and the stop token + batch-wide stop rule.
+//     7 launches, captured in a hipGraph (iteration index, seed and flags live in device memory).
+// Reference arithmetic: models/synthesizer/models/tacotron.py:71-138, sublayer/pre_net.py:21-26, torch GRUCell /
+// LSTMCell gate orders as in rnn_body.h.
+#pragma once
+#include "rnn_body.h"
+
+namespace mb {
+
+// flags block in the workspace (ints): [0] done, [1] n_frames, [2] arrival ticket, [3] utterances below the stop
+// threshold, [4] iteration index of the first launch of the current graph replay, [6..7] 64-bit dropout seed
+enum { TF_DONE = 0, TF_NFRAMES = 1, TF_ARRIVE = 2, TF_NOTREADY = 3, TF_ITER = 4, TF_SEED = 6 };
+
+__host__ __device__ __forceinline__ size_t fm_floats(int K, int nta) { return (size_t)(K / 16) * nta * 256; }
+__host__ __device__ __forceinline__ size_t cm_items(int units, int nta) { return (size_t)((units + 3) / 4) * nta * 64; }
+// float index of element (column n, feature k) in an FM buffer
+__host__ __device__ __forceinline__ size_t fm_index(int nta, int n, int k) {
+  return ((size_t)(k >> 4) * nta + (n >> 4)) * 256 + ((k >> 2) & 3) * 64 + (n & 15) * 4 + (k & 3);
+}
+
+// row sum over the 16 lanes of a DPP row (every lane of the row receives it): 4 VALU ops, no LDS crossbar
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror
+  return v;
+}
+
+// Skinny GEMM core: one 16-row weight tile (mt) x NT column tiles, K = 8 * PW k-blocks split over the 8 waves
+// (wave w owns k-blocks w, w+8, ...), first PS steps from seg0, the rest from seg1 (both FM).  NPART = 2 keeps the
+// seg1 sums apart (GRU hidden part).  All loads are issued before the first MFMA.  Returns true for the NT
+// epilogue waves (wave w finishes column tile nt0 + w) with the reduced sums in sx / sh (k order: waves 0..7).
+template <int NT, int PW, int PS, int RL, int NPART>
+__device__ __forceinline__ bool fm_gemm(const float* __restrict__ w, const int mt, const float* __restrict__ seg0,
+                                        const float* __restrict__ seg1, const int nta, const int nt0, float* red,
+                                        float (&sx)[4], float (&sh)[4]) {
+  constexpr int BLK = 4 * RL * 16, NKB = 8 * PW;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, kq = lane >> 4;
+  const int u = i >> 2, tau = (i & 3) < RL ? (i & 3) : RL - 1;  // dead 4th GRU row re-reads row 2 (never used)
+  const float* wl = w + (size_t)mt * NKB * BLK + ((u * RL + tau) * 4 + kq) * 4;
+  int ntc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) ntc[nt] = (nt0 + nt < nta) ? nt0 + nt : nta - 1;  // odd tile count: duplicate, never stored
+  float4 a[PW], b[PW][NT];
+#pragma unroll
+  for (int p = 0; p < PW; ++p) {
+    const int kb = wave + 8 * p;
+    a[p] = *reinterpret_cast<const float4*>(wl + (size_t)kb * BLK);
+    const float4* sp = reinterpret_cast<const float4*>(p < PS ? seg0 : seg1);
+    const int kl = p < PS ? kb : kb - 8 * PS;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[p][nt] = sp[((size_t)kl * nta + ntc[nt]) * 64 + lane];
+  }
+  // the machine scheduler would otherwise sink the loads next to their MFMAs to save registers (50 VGPRs, two or
+  // three k-blocks in flight per wave); the whole point is to have every fragment of the wave in flight at once
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 accX[NT], accH[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) { accX[nt] = {0.f, 0.f, 0.f, 0.f}; accH[nt] = {0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int p = 0; p < PW; ++p) {
+    const bool hpart = NPART == 2 && p >= PS;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float av = c == 0 ? a[p].x : c == 1 ? a[p].y : c == 2 ? a[p].z : a[p].w;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float bv = c == 0 ? b[p][nt].x : c == 1 ? b[p][nt].y : c == 2 ? b[p][nt].z : b[p][nt].w;
+        if (hpart) accH[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, accH[nt], 0, 0, 0);
+        else accX[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, accX[nt], 0, 0, 0);
+      }
+    }
+  }
+  float4* red4 = reinterpret_cast<float4*>(red);  // [8][NT][NPART][64]
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    red4[((wave * NT + nt) * NPART + 0) * 64 + lane] = make_float4(accX[nt][0], accX[nt][1], accX[nt][2], accX[nt][3]);
+    if (NPART == 2) red4[((wave * NT + nt) * NPART + 1) * 64 + lane] = make_float4(accH[nt][0], accH[nt][1], accH[nt][2], accH[nt][3]);
+  }
+  __syncthreads();
+  if (wave >= NT) return false;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) { sx[g] = 0.f; sh[g] = 0.f; }
+#pragma unroll
+  for (int w8 = 0; w8 < 8; ++w8) {
+    const float4 v = red4[((w8 * NT + wave) * NPART + 0) * 64 + lane];
+    sx[0] += v.x; sx[1] += v.y; sx[2] += v.z; sx[3] += v.w;
+    if (NPART == 2) {
+      const float4 h = red4[((w8 * NT + wave) * NPART + 1) * 64 + lane];
+      sh[0] += h.x; sh[1] += h.y; sh[2] += h.z; sh[3] += h.w;
+    }
+  }
+  return true;
+}
+
+template <int NT, int NPART> struct FmRed { static constexpr int floats = 8 * NT * NPART * 256; };
+
+// ---- always-on PreNet dropout (pre_net.py:23,26) of a relu'd row quad; same masks / same Philox stream as the
+//      general path (rnn_body.h): mask [n_iter][2][B][ld], Philox(iter, layer, n, row/4) ----
+struct DropK {
+  const float* mask;  // injected keep masks or null
+  int ld;             // 2 * decoder_dims
+  int layer, it_add;  // prenet layer (0/1); iteration offset (the fc1 job of launch `it` prepares iteration it + 1)
+  unsigned thresh; float scale; int enabled;
+};
+__device__ __forceinline__ void relu_drop_quad(const DropK& d, const int* flags, int it, int B, int n, int row0, float (&v)[4]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+  if (!d.enabled) return;
+  const int iter = it + d.it_add;
+  if (d.mask) {
+    const float4 m = *reinterpret_cast<const float4*>(d.mask + ((size_t)iter * 2 + d.layer) * B * d.ld + (size_t)n * d.ld + row0);
+    v[0] *= m.x * d.scale; v[1] *= m.y * d.scale; v[2] *= m.z * d.scale; v[3] *= m.w * d.scale;
+  } else {
+    const unsigned long long seed = *reinterpret_cast<const unsigned long long*>(flags + TF_SEED);
+    uint32_t rr[4];
+    philox4x32((uint32_t)iter, (uint32_t)d.layer, (uint32_t)n, (uint32_t)(row0 >> 2), (uint32_t)seed, (uint32_t)(seed >> 32), rr);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] *= (rr[r] >= d.thresh) ? d.scale : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ fc2
+// p2 = dropout(relu(fc2 . p1 + b2))   (pre_net.py:24-26).  K = 2D = 256 -> PW = 2.
+struct TfFcK {
+  const float* w; const float* bias; const float* xin; float* yout;
+  int nta, B, it_off; const int* flags; DropK drop;
+};
+template <int NT>
+__global__ __launch_bounds__(512) void taco_fc2_kernel(TfFcK a) {
+  __shared__ __attribute__((aligned(16))) float red[FmRed<NT, 1>::floats];
+  const int mt = blockIdx.x, nt0 = blockIdx.y * NT;
+  const int done = a.flags[TF_DONE], it = a.flags[TF_ITER] + a.it_off;
+  float sx[4], sh[4];
+  if (!fm_gemm<NT, 2, 2, 4, 1>(a.w, mt, a.xin, a.xin, a.nta, nt0, red, sx, sh)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nt = nt0 + wave, du = lane >> 4, n = nt * 16 + (lane & 15), row0 = mt * 16 + du * 4;
+  if (nt >= a.nta || done) return;
+  const float4 bq = *reinterpret_cast<const float4*>(a.bias + row0);
+  float v[4] = {sx[0] + bq.x, sx[1] + bq.y, sx[2] + bq.z, sx[3] + bq.w};
+  relu_drop_quad(a.drop, a.flags, it, a.B, n < a.B ? n : a.B - 1, row0, v);
+  reinterpret_cast<float4*>(a.yout)[((size_t)mt * a.nta + nt) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// ------------------------------------------------------------------------------------------------ attention GRU
+// attn_hidden = GRUCell([context, prenet_out], attn_hidden)  (tacotron.py:97-98) on its prenet columns only:
+// W_ih[:, :P] . context + b_ih and W_hh . attn_hidden + b_hh were left as CM4 quads by the previous rnn_input launch.
+struct TfGruK {
+  const float* w; const float* xin; const float4* xpre; const float4* hpre; float* ah;  // ah FM [D], updated in place
+  int nta, B; const int* flags;
+};
+template <int NT>
+__global__ __launch_bounds__(512) void taco_gru_kernel(TfGruK a) {
+  __shared__ __attribute__((aligned(16))) float red[FmRed<NT, 1>::floats];
+  const int mt = blockIdx.x, nt0 = blockIdx.y * NT;
+  const int done = a.flags[TF_DONE];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ntE = (nt0 + (wv < NT ? wv : 0) < a.nta) ? nt0 + (wv < NT ? wv : 0) : a.nta - 1;
+  const size_t cm = ((size_t)mt * a.nta + ntE) * 64 + lane;
+  const float4 xp = a.xpre[cm], hp = a.hpre[cm];  // requested before the fragments are waited for
+  const int du = lane >> 4, i = lane & 15;
+  float* hpt = a.ah + ((size_t)(mt >> 2) * a.nta + ntE) * 256 + (mt & 3) * 64 + i * 4 + du;
+  const float hprev = *hpt;
+  float sx[4], sh[4];
+  if (!fm_gemm<NT, 2, 2, 3, 1>(a.w, mt, a.xin, a.xin, a.nta, nt0, red, sx, sh)) return;
+  if (nt0 + wv >= a.nta || done) return;
+  // torch GRUCell, gate order (r, z, n)
+  const float rg = sigmoidf_((sx[0] + xp.x) + hp.x);
+  const float zg = sigmoidf_((sx[1] + xp.y) + hp.y);
+  const float ng = tanhf((sx[2] + xp.z) + rg * hp.z);
+  *hpt = ng + zg * (hprev - ng);
+}
+
+// ------------------------------------------------------------------------------------------------ rnn_input (+ GRU pre)
+// job 0 (blockIdx.x < n_rin): x = rnn_input([context, attn_hidden])  (tacotron.py:108-109) -> FM
+// job 1: the NEXT iteration's attention-GRU pre-activations from the same operands:
+//        xpre = W_ih[:, :P] . context + b_ih,  hpre = W_hh . attn_hidden + b_hh   (CM4: r, z, n, -)
+struct TfRinK {
+  const float* w_rin; const float* b_rin; const float* w_pre; const float4* bih4; const float4* bhh4;
+  const float* ctx; const float* ah; float* x; float4* xpre; float4* hpre;
+  int nta, n_rin; const int* flags;
+};
+template <int NT>
+__global__ __launch_bounds__(512) void taco_rin_kernel(TfRinK a) {
+  __shared__ __attribute__((aligned(16))) float red[FmRed<NT, 2>::floats];
+  const int nt0 = blockIdx.y * NT;
+  const int done = a.flags[TF_DONE];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, du = lane >> 4;
+  float sx[4], sh[4];
+  if ((int)blockIdx.x < a.n_rin) {
+    const int mt = blockIdx.x;
+    if (!fm_gemm<NT, 9, 8, 4, 1>(a.w_rin, mt, a.ctx, a.ah, a.nta, nt0, red, sx, sh)) return;
+    const int nt = nt0 + wv;
+    if (nt >= a.nta || done) return;
+    const float4 bq = *reinterpret_cast<const float4*>(a.b_rin + mt * 16 + du * 4);
+    reinterpret_cast<float4*>(a.x)[((size_t)mt * a.nta + nt) * 64 + lane] =
+        make_float4(sx[0] + bq.x, sx[1] + bq.y, sx[2] + bq.z, sx[3] + bq.w);
+    return;
+  }
+  const int mt = blockIdx.x - a.n_rin;
+  if (!fm_gemm<NT, 9, 8, 3, 2>(a.w_pre, mt, a.ctx, a.ah, a.nta, nt0, red, sx, sh)) return;
+  const int nt = nt0 + wv;
+  if (nt >= a.nta || done) return;
+  const float4 bi = a.bih4[mt * 4 + du], bh = a.bhh4[mt * 4 + du];
+  const size_t cm = ((size_t)mt * a.nta + nt) * 64 + lane;
+  a.xpre[cm] = make_float4(sx[0] + bi.x, sx[1] + bi.y, sx[2] + bi.z, 0.f);
+  a.hpre[cm] = make_float4(sh[0] + bh.x, sh[1] + bh.y, sh[2] + bh.z, 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------ residual LSTM
+// h, c = LSTMCell(x, (h, c)); x = x + h   (tacotron.py:112-125, eval branch).  K = [x | h_prev] = 128 k-blocks.
+struct TfLstmK {
+  const float* w; const float4* b4;  // b_ih + b_hh per unit: (i, f, g, o)
+  const float* x; const float* h_prev; float* h_out; float* c; float* x_out;  // FM, FM, FM, CM1 (in place), FM
+  int nta; const int* flags;
+};
+template <int NT>
+__global__ __launch_bounds__(512) void taco_lstm_kernel(TfLstmK a) {
+  __shared__ __attribute__((aligned(16))) float red[FmRed<NT, 1>::floats];
+  const int mt = blockIdx.x, nt0 = blockIdx.y * NT;
+  const int done = a.flags[TF_DONE];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, du = lane >> 4, i = lane & 15;
+  const int ntE = (nt0 + (wv < NT ? wv : 0) < a.nta) ? nt0 + (wv < NT ? wv : 0) : a.nta - 1;
+  const float4 bq = a.b4[mt * 4 + du];
+  float* cp = a.c + ((size_t)mt * a.nta + ntE) * 64 + lane;
+  const float cprev = *cp;
+  const size_t fo = ((size_t)(mt >> 2) * a.nta + ntE) * 256 + (mt & 3) * 64 + i * 4 + du;
+  const float xr = a.x[fo];
+  float sx[4], sh[4];
+  if (!fm_gemm<NT, 16, 8, 4, 1>(a.w, mt, a.x, a.h_prev, a.nta, nt0, red, sx, sh)) return;
+  if (nt0 + wv >= a.nta || done) return;
+  // torch LSTMCell, gate order (i, f, g, o)
+  const float gi = sigmoidf_(sx[0] + bq.x);
+  const float gf = sigmoidf_(sx[1] + bq.y);
+  const float gg = tanhf(sx[2] + bq.z);
+  const float go = sigmoidf_(sx[3] + bq.w);
+  const float cy = gf * cprev + gi * gg;
+  const float hy = go * tanhf(cy);
+  *cp = cy;
+  a.h_out[fo] = hy;
+  a.x_out[fo] = xr + hy;
+}
+
+// ------------------------------------------------------------------------------------------------ mel_proj (+ fc1' + stop)
+// job 0 (n_mel tiles): mels = mel_proj(x)[:, :, :r] (tacotron.py:128-129: only the r live frames' rows are kept,
+//        frame-major) scattered straight into mel_out[b][m][t0 + j]
+// job 1 (16 tiles):    the NEXT iteration's prenet layer 1: relu(fc1 . mel[last frame] + b1) with fc1 folded through
+//        mel_proj (W' = fc1 . mel_proj[last frame rows]), dropout of iteration it + 1
+// job 2 (1 tile):      stop = sigmoid(stop_proj([x, context])) (:133-136) and the batch-wide stop rule (:275)
+struct TfMelK {
+  const float* w_mel; const float* w_fc1; const float* b_fc1; const float* w_stop; const float* b_stop;
+  const float* x2; const float* ctx; float* p1; float* mel_out; float* stop_out;
+  int nta, B, n_mel, M, r, max_steps, it_off; float min_stop_token; int* flags; DropK drop;
+};
+template <int NT>
+__global__ __launch_bounds__(512) void taco_mel_kernel(TfMelK a) {
+  __shared__ __attribute__((aligned(16))) float red[FmRed<NT, 1>::floats];
+  const int nt0 = blockIdx.y * NT;
+  const int done = a.flags[TF_DONE], it = a.flags[TF_ITER] + a.it_off;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, du = lane >> 4, i = lane & 15;
+  const int bx = blockIdx.x;
+  float sx[4], sh[4];
+  if (bx < a.n_mel) {
+    if (!fm_gemm<NT, 8, 8, 4, 1>(a.w_mel, bx, a.x2, a.x2, a.nta, nt0, red, sx, sh)) return;
+    const int nt = nt0 + wv, n = nt * 16 + i, t0 = it * a.r;
+    if (nt >= a.nta || n >= a.B || done) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = bx * 16 + du * 4 + q;
+      if (row < a.r * a.M) {
+        const int j = row / a.M, m = row - j * a.M;
+        if (t0 + j < a.max_steps) a.mel_out[((size_t)n * a.M + m) * a.max_steps + t0 + j] = sx[q];
+      }
+    }
+    return;
+  }
+  if (bx < a.n_mel + 16) {
+    const int mt = bx - a.n_mel;
+    if (!fm_gemm<NT, 8, 8, 4, 1>(a.w_fc1, mt, a.x2, a.x2, a.nta, nt0, red, sx, sh)) return;
+    const int nt = nt0 + wv, n = nt * 16 + i, row0 = mt * 16 + du * 4;
+    if (nt >= a.nta || done) return;
+    const float4 bq = *reinterpret_cast<const float4*>(a.b_fc1 + row0);
+    float v[4] = {sx[0] + bq.x, sx[1] + bq.y, sx[2] + bq.z, sx[3] + bq.w};
+    relu_drop_quad(a.drop, a.flags, it, a.B, n < a.B ? n : a.B - 1, row0, v);
+    reinterpret_cast<float4*>(a.p1)[((size_t)mt * a.nta + nt) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+    return;
+  }
+  // stop tile: one live row (row 0) over K = [x2 | context]
+  if (!fm_gemm<NT, 16, 8, 4, 1>(a.w_stop, 0, a.x2, a.ctx, a.nta, nt0, red, sx, sh)) return;
+  const int nt = nt0 + wv, n = nt * 16 + i;
+  if (nt >= a.nta || done) return;
+  int below = 0;
+  if (du == 0 && n < a.B) {
+    const float sgm = 1.0f / (1.0f + expf(-(sx[0] + a.b_stop[0])));
+    a.stop_out[n] = sgm;
+    below = !(sgm * 10.f > a.min_stop_token);  // (stop * 10 > min_stop_token).all()
+  }
+  const unsigned long long vote = __ballot(below);
+  if (lane == 0) {
+    if (vote) {  // utterances not ready to stop: performed before this tile's arrival ticket
+      int old = atomicAdd(a.flags + TF_NOTREADY, __popcll(vote));
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(old) : : "memory");
+    }
+    if (atomicAdd(a.flags + TF_ARRIVE, 1) == a.nta - 1) {  // last column tile to arrive decides for the batch
+      const int not_ready = __hip_atomic_load(a.flags + TF_NOTREADY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int t0 = it * a.r;
+      a.flags[TF_NFRAMES] = min(t0 + a.r, a.max_steps);
+      if (not_ready == 0 && t0 > 10) a.flags[TF_DONE] = 1;  // ... and t > 10
+      a.flags[TF_ARRIVE] = 0; a.flags[TF_NOTREADY] = 0;       // visible to the next iteration (kernel boundary)
+    }
+  }
+}
+
+// p1 of iteration 0: the <GO> frame is all zeros (tacotron.py:261), so fc1's output is relu(b1), then dropout(it = 0)
+struct TfP1K { const float* b_fc1; float* p1; int nta, B, rows; const int* flags; DropK drop; };
+__global__ __launch_bounds__(64) void taco_p1_init_kernel(TfP1K a) {
+  const int mt = blockIdx.x, nt = blockIdx.y, lane = threadIdx.x, du = lane >> 4, n = nt * 16 + (lane & 15), row0 = mt * 16 + du * 4;
+  const float4 bq = *reinterpret_cast<const float4*>(a.b_fc1 + row0);
+  float v[4] = {bq.x, bq.y, bq.z, bq.w};
+  relu_drop_quad(a.drop, a.flags, a.flags[TF_ITER], a.B, n < a.B ? n : a.B - 1, row0, v);
+  reinterpret_cast<float4*>(a.p1)[((size_t)mt * a.nta + nt) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+__global__ void taco_bump_kernel(int* flags, int n) { flags[TF_ITER] += n; }
+
+}  // namespace mb

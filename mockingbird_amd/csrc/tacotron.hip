@@ -17,7 +17,7 @@
 // a no-op (skip flag) and the host learns the frame count at its next poll.
 // CBHG runs on the MFMA conv kernel (conv1d.hip) with ReLU->BatchNorm, max-pool and highway
 // gates fused; the bidirectional GRU is a scan of EPI_GRU launches over precomputed W_ih.x.
-#include "rnn_body.h"
+#include "taco_fast.h"
 
 namespace mb {
 
@@ -43,7 +43,16 @@ struct LsaK {
   const float* Mt;   // [Kl][D]  M = L . conv_w   (location features -> processed location in one 31-tap conv)
   const float* c0;   // [D]      L . conv_b
   const float* Wt;   // [D(k)][D(d)] W^T
+  // fast decoder loop (taco_fast.h): query / context are FM buffers with fm_nta column tiles (0: plain [B][D] / [B][P]),
+  // and the iteration index is iter + *iter_base (device word, bumped once per graph replay)
+  int fm_nta; const int* iter_base;
 };
+__device__ __forceinline__ size_t lsa_qidx(const LsaK& a, int b, int k) { return a.fm_nta ? fm_index(a.fm_nta, b, k) : (size_t)b * a.D + k; }
+// float4 slot of context columns [p, p+4) of utterance b (p % 4 == 0)
+__device__ __forceinline__ float4* lsa_ctx4(const LsaK& a, int b, int p) {
+  return a.fm_nta ? reinterpret_cast<float4*>(a.context) + ((size_t)(p >> 4) * a.fm_nta + (b >> 4)) * 64 + ((p >> 2) & 3) * 16 + (b & 15)
+                  : reinterpret_cast<float4*>(a.context + (size_t)b * a.P + p);
+}
 
 // One workgroup (8 waves) per (utterance, quarter of the context columns).  The attention
 // window -- cumulative alignment (zero padded), location features, energies, scores -- lives in
@@ -78,9 +87,8 @@ __global__ __launch_bounds__(512) void lsa_kernel(LsaK a) {
     float acc = 0.f;
     if (kp < nq) {
       const float* wr = a.Ww + (size_t)d * D;
-      const float* q = a.query + (size_t)b * D;
       const int k0 = kp * (D / nq), k1 = (kp == nq - 1) ? D : k0 + D / nq;
-      for (int k = k0; k < k1; ++k) acc += wr[k] * q[k];
+      for (int k = k0; k < k1; ++k) acc += wr[k] * a.query[lsa_qidx(a, b, k)];
       part[kp * D + d] = acc;
     }
     __syncthreads();
@@ -130,7 +138,8 @@ __global__ __launch_bounds__(512) void lsa_kernel(LsaK a) {
   __syncthreads();
   ssum = 0.f;
   for (int w = 0; w < 8; ++w) ssum += red[w];
-  float* ao = (a.attn_out && pg == 0) ? a.attn_out + ((size_t)b * a.n_iter_max + a.iter) * T : nullptr;
+  const int iter = a.iter + (a.iter_base ? *a.iter_base : 0);
+  float* ao = (a.attn_out && pg == 0) ? a.attn_out + ((size_t)b * a.n_iter_max + iter) * T : nullptr;
   for (int t = tid; t < T; t += 512) {
     const float sc = u[t] / ssum;
     u[t] = sc;
@@ -168,7 +177,7 @@ __global__ __launch_bounds__(512) void lsa_kernel(LsaK a) {
         const float4 o = reinterpret_cast<float4*>(part)[w * 64 + lane];
         r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
       }
-      *reinterpret_cast<float4*>(a.context + (size_t)b * a.P + p0 + c4) = r;
+      *lsa_ctx4(a, b, p0 + c4) = r;
     }
     __syncthreads();
   }
@@ -191,7 +200,7 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
   __shared__ __attribute__((aligned(16))) float s_cum[TMAX + 64];   // zero padded by `half` on both sides
   __shared__ __attribute__((aligned(16))) float s_q[D];
   __shared__ __attribute__((aligned(16))) float s_pq[4][D];
-  __shared__ __attribute__((aligned(16))) float s_up[TMAX][2];
+  __shared__ __attribute__((aligned(16))) float s_up[TMAX][8];
   __shared__ __attribute__((aligned(16))) float s_u[TMAX];
   __shared__ __attribute__((aligned(16))) float4 s_part[8][64];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -203,7 +212,8 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
   if (a.skip_flag) skip = *a.skip_flag;
 
   // ---- phase 0: every global load ----
-  const float qv = (tid < D) ? a.query[(size_t)b * D + tid] : 0.f;          // fresh (attention GRU output)
+  const float qv = (tid < D) ? a.query[lsa_qidx(a, b, tid)] : 0.f;          // fresh (attention GRU output)
+  const int iter = a.iter + (a.iter_base ? *a.iter_base : 0);
   const float* cg = a.cum_in + (size_t)b * T;
   float cpre[(TMAX + 64 + 511) / 512];
 #pragma unroll
@@ -270,8 +280,9 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
       for (int jj = 0; jj < KL; ++jj) pl += mrow[jj] * win[j + jj];
       const float x = (pqd + mpv[j]) + pl;
       const float th = 1.f - 2.f / (__expf(2.f * x) + 1.f);
-      const float e = wave_sum(vd * th);
-      if (lane == 0 && j < TQ && t0 + j < T) s_up[t0 + j][wave & 1] = e;
+      // reduction over d: 16-lane DPP row sums (4 VALU ops), the 8 row partials of a position meet in the softmax
+      const float e = row16_sum(vd * th);
+      if ((lane & 15) == 0 && j < TQ && t0 + j < T) s_up[t0 + j][(wave & 1) * 4 + (lane >> 4)] = e;
     }
   }
   __syncthreads();  // B3
@@ -283,7 +294,11 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
     for (int q = 0; q < (TMAX + 63) / 64; ++q) {
       const int t = lane + 64 * q;
       float u = -INFINITY;
-      if (t < T) { u = s_up[t][0] + s_up[t][1]; u = chv[q] != 0 ? u : u * 0.f; }  // u * (chars != 0)
+      if (t < T) {
+        const float4 ua = *reinterpret_cast<const float4*>(&s_up[t][0]), ub = *reinterpret_cast<const float4*>(&s_up[t][4]);
+        u = ((ua.x + ua.y) + (ua.z + ua.w)) + ((ub.x + ub.y) + (ub.z + ub.w));
+        u = chv[q] != 0 ? u : u * 0.f;  // u * (chars != 0)
+      }
       uv[q] = u;
       m = fmaxf(m, u);
     }
@@ -296,7 +311,7 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
       ssum += uv[q];
     }
     ssum = wave_sum(ssum);
-    float* ao = (a.attn_out && pg == 0) ? a.attn_out + ((size_t)b * a.n_iter_max + a.iter) * T : nullptr;
+    float* ao = (a.attn_out && pg == 0) ? a.attn_out + ((size_t)b * a.n_iter_max + iter) * T : nullptr;
 #pragma unroll
     for (int q = 0; q < (TMAX + 63) / 64; ++q) {
       const int t = lane + 64 * q;
@@ -330,7 +345,7 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
       const float4 o = s_part[w][lane];
       r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
     }
-    *reinterpret_cast<float4*>(a.context + (size_t)b * P + p0 + lane * 4) = r;
+    *lsa_ctx4(a, b, p0 + lane * 4) = r;
   }
 }
 
@@ -696,6 +711,21 @@ struct mb_taco {
   Cbhg enc;
   // global style tokens: checkpoint constants folded at load (see gst_style_kernel)
   DevBuf gst_qconst, gst_WqS, gst_K, gst_V;
+  // fast decoder loop (taco_fast.h), packed when the checkpoint has the production dims
+  bool fast = false;
+  DevBuf f_gru_w, f_pre_w, f_bih4, f_bhh4, f_l1_b4, f_l2_b4, f_fc1_w, f_stop_w;
+  // captured iterations of the fast loop: reused while the call arguments do not change (handle is single-threaded)
+  struct GraphKey { const void *mem, *memp, *chars, *drop, *mel, *attn, *ws; int B, T, max_steps, G; float mst; } gkey = {};
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  int* h_flags = nullptr;  // pinned: [2][8] flag snapshots
+  hipEvent_t ev_flags[2] = {nullptr, nullptr};
+  hipStream_t loop_stream = nullptr;  // the loop runs (and is captured) on its own stream: the caller's may be the
+  hipEvent_t ev_in = nullptr;         // legacy default stream, which cannot be captured
+  void drop_graph() {
+    if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+    if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
+  }
 };
 
 // ReferenceEncoder(zeros) -> ref_h, then the style-token constants (double precision on the host:
@@ -912,6 +942,56 @@ extern "C" int mb_taco_create(const mb_taco_config* cfg, const float* const* hw,
   }
   RC(t->stop_w.upload(hw[ix], H + P)); RC(t->stop_b.upload(hw[ix + 1], 1));
   ix += 2;
+  // ---- fast decoder loop (taco_fast.h): production dims only; every k extent a multiple of 128 ----
+  t->fast = D == 128 && P == 1024 && H == 1024 && M % 16 == 0 && (cfg->r * M) % 16 == 0 && cfg->lsa_kernel <= 31 && (cfg->lsa_kernel & 1);
+  if (t->fast && !rc) {
+    // weight list offsets (taco_shapes order): 0-3 prenet, 4-9 LSA, 10-13 attn_rnn, 14-15 rnn_input, 16-19 / 20-23 LSTMs, 24 mel_proj, 25-26 stop
+    const float *fc1_w = hw[0], *a_wih = hw[10], *a_whh = hw[11], *a_bih = hw[12], *a_bhh = hw[13];
+    const float *mel_w = hw[24], *stop_w = hw[25];
+    // attention GRU on its prenet columns W_ih[:, P:P+2D] (GRU tile order, K = 2D)
+    cell_rows(a_wih + P, 2 * D, P + 2 * D, a_whh, 0, D, 3, &rows);
+    pack_rowtile(rows.data(), 3 * D, 2 * D, 3, &packed); RC(t->f_gru_w.upload(packed.data(), packed.size()));
+    // ... and its context / hidden parts over K = [context | attn_hidden], two accumulators
+    cell_rows(a_wih, P, P + 2 * D, a_whh, D, D, 3, &rows);
+    pack_rowtile(rows.data(), 3 * D, P + D, 3, &packed); RC(t->f_pre_w.upload(packed.data(), packed.size()));
+    std::vector<float> q4((size_t)D * 4), h4((size_t)D * 4);
+    for (int j = 0; j < D; ++j)
+      for (int g = 0; g < 4; ++g) {
+        q4[(size_t)j * 4 + g] = g < 3 ? a_bih[g * D + j] : 0.f;
+        h4[(size_t)j * 4 + g] = g < 3 ? a_bhh[g * D + j] : 0.f;
+      }
+    RC(t->f_bih4.upload(q4.data(), q4.size())); RC(t->f_bhh4.upload(h4.data(), h4.size()));
+    for (int l = 0; l < 2; ++l) {  // LSTM biases b_ih + b_hh per unit (i, f, g, o)
+      const float *bi = hw[16 + 4 * l + 2], *bh = hw[16 + 4 * l + 3];
+      std::vector<float> b4((size_t)H * 4);
+      for (int j = 0; j < H; ++j)
+        for (int g = 0; g < 4; ++g) b4[(size_t)j * 4 + g] = bi[g * H + j] + bh[g * H + j];
+      RC((l ? t->f_l2_b4 : t->f_l1_b4).upload(b4.data(), b4.size()));
+    }
+    {  // prenet fc1 folded through mel_proj's last live frame: W' = fc1 . mel_proj[rows m*max_r + (r-1)]  ([2D][H])
+      std::vector<double> acc(H);
+      std::vector<float> wf((size_t)2 * D * H);
+      for (int o = 0; o < 2 * D; ++o) {
+        std::fill(acc.begin(), acc.end(), 0.0);
+        for (int m = 0; m < M; ++m) {
+          const double f = fc1_w[(size_t)o * M + m];
+          const float* mr = mel_w + ((size_t)m * cfg->max_r + (cfg->r - 1)) * H;
+          for (int k = 0; k < H; ++k) acc[k] += f * (double)mr[k];
+        }
+        for (int k = 0; k < H; ++k) wf[(size_t)o * H + k] = (float)acc[k];
+      }
+      pack_rowtile(wf.data(), 2 * D, H, 4, &packed); RC(t->f_fc1_w.upload(packed.data(), packed.size()));
+    }
+    pack_rowtile(stop_w, 1, H + P, 4, &packed); RC(t->f_stop_w.upload(packed.data(), packed.size()));  // one live row
+    if (!rc && (hipHostMalloc((void**)&t->h_flags, sizeof(int) * 16) != hipSuccess ||
+                hipStreamCreateWithFlags(&t->loop_stream, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&t->ev_in, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&t->ev_flags[0], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&t->ev_flags[1], hipEventDisableTiming) != hipSuccess)) {
+      set_error("taco_create: pinned flag buffer / events");
+      rc = MB_EHIP;
+    }
+  }
   // postnet CBHG + post_proj
   RC(make_cbhg(&t->post, hw, &ix, M, C, C, M, cfg->postnet_K, cfg->num_highways));
   RC(make_linear_conv(&t->post_proj, hw[ix], M, C, nullptr)); ix += 1;
@@ -942,8 +1022,14 @@ extern "C" void mb_taco_destroy(mb_taco* t) {
   DevBuf* bs[] = {&t->pre1_w, &t->pre1_b, &t->pre2_w, &t->pre2_b, &t->lsa_conv_w, &t->lsa_conv_b, &t->lsa_L, &t->lsa_W,
                   &t->lsa_Wb, &t->lsa_v, &t->attn_w, &t->attn_bih, &t->attn_bhh, &t->rin_w, &t->rin_b, &t->l1_w,
                   &t->l1_bih, &t->l1_bhh, &t->l2_w, &t->l2_bih, &t->l2_bhh, &t->l1_wx, &t->l1_whh, &t->l2_wx, &t->l2_whh, &t->mel_w, &t->stop_w, &t->stop_b,
-                  &t->emb, &t->enc_proj_full, &t->lsa_Mt, &t->lsa_c0, &t->lsa_Wt, &t->gst_qconst, &t->gst_WqS, &t->gst_K, &t->gst_V};
+                  &t->emb, &t->enc_proj_full, &t->lsa_Mt, &t->lsa_c0, &t->lsa_Wt, &t->gst_qconst, &t->gst_WqS, &t->gst_K, &t->gst_V,
+                  &t->f_gru_w, &t->f_pre_w, &t->f_bih4, &t->f_bhh4, &t->f_l1_b4, &t->f_l2_b4, &t->f_fc1_w, &t->f_stop_w};
   for (DevBuf* b : bs) b->release();
+  t->drop_graph();
+  if (t->h_flags) (void)hipHostFree(t->h_flags);
+  for (int e = 0; e < 2; ++e) if (t->ev_flags[e]) (void)hipEventDestroy(t->ev_flags[e]);
+  if (t->ev_in) (void)hipEventDestroy(t->ev_in);
+  if (t->loop_stream) (void)hipStreamDestroy(t->loop_stream);
   t->post.release(); t->post_proj.release(); t->enc.release();
   t->enc_fc1.release(); t->enc_fc2.release(); t->enc_proj.release();
   delete t;
@@ -952,8 +1038,10 @@ extern "C" void mb_taco_destroy(mb_taco* t) {
 namespace {
 struct TacoLayout {
   float *p1, *p2, *attn_h, *context, *x, *x1, *x2, *h1, *c1, *h2, *c2, *melstep, *cumulative, *stop;
-  float *hp1, *hp2;  // hidden halves W_hh.h + b_hh of the two LSTMs, [B][4H] gate-major
-  int* flags;  // [0] done, [1] n_frames, [2] arrive, [3] utterances below the stop threshold
+  // fast loop (taco_fast.h): FM activations, CM cell state / gate pre-activations
+  float *f_p1, *f_p2, *f_ah, *f_ctx, *f_x, *f_x1, *f_x2, *f_h1, *f_h2, *f_c1, *f_c2, *f_xpre, *f_hpre;
+  size_t f_state_bytes;  // the region above, zeroed per call
+  int* flags;  // [0] done, [1] n_frames, [2] arrive, [3] utterances below the stop threshold, [4] iteration base, [6..7] seed
   // postnet
   float *melc, *linc;
   CbhgWs cb;
@@ -971,11 +1059,22 @@ static void taco_layout(const mb_taco* t, int B, int T, int max_steps, void* bas
   L->x = ar.take<float>(B * H); L->x1 = ar.take<float>(B * H); L->x2 = ar.take<float>(B * H);
   L->h1 = ar.take<float>(2 * B * H); L->c1 = ar.take<float>(2 * B * H);
   L->h2 = ar.take<float>(2 * B * H); L->c2 = ar.take<float>(2 * B * H);
-  L->hp1 = ar.take<float>((size_t)B * 4 * H); L->hp2 = ar.take<float>((size_t)B * 4 * H);
+  {
+    const int nta = (B + 15) / 16;
+    L->f_p1 = ar.take<float>(fm_floats(2 * D, nta));
+    const size_t start = ar.off - fm_floats(2 * D, nta) * sizeof(float);
+    L->f_p2 = ar.take<float>(fm_floats(2 * D, nta)); L->f_ah = ar.take<float>(fm_floats(D, nta));
+    L->f_ctx = ar.take<float>(fm_floats(P, nta));
+    L->f_x = ar.take<float>(fm_floats(H, nta)); L->f_x1 = ar.take<float>(fm_floats(H, nta)); L->f_x2 = ar.take<float>(fm_floats(H, nta));
+    L->f_h1 = ar.take<float>(2 * fm_floats(H, nta)); L->f_h2 = ar.take<float>(2 * fm_floats(H, nta));
+    L->f_c1 = ar.take<float>(cm_items(H, nta)); L->f_c2 = ar.take<float>(cm_items(H, nta));
+    L->f_xpre = ar.take<float>(4 * cm_items(D, nta)); L->f_hpre = ar.take<float>(4 * cm_items(D, nta));
+    L->f_state_bytes = ar.off - start;
+  }
   L->melstep = ar.take<float>((size_t)B * c.r * M);
   L->cumulative = ar.take<float>((size_t)2 * B * T);
   L->stop = ar.take<float>(B);
-  L->flags = ar.take<int>(8);
+  L->flags = ar.take<int>(16);
   L->melc = ar.take<float>(B * M * F);
   L->linc = ar.take<float>(B * M * F);
   cbhg_take(ar, t->post, B, F, &L->cb);
@@ -1005,6 +1104,157 @@ int run_conv(const ConvL& c, const float* x, int batch, int t, float* y, long lo
   return mb_conv1d(&a, (mb_stream_t)s);
 }
 }  // namespace
+
+// ---- fast decoder loop (taco_fast.h): 7 launches per iteration, hipGraph-captured, stop flag polled one replay behind ----
+static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_memory, const float* d_memory_proj, const int32_t* d_chars,
+                               int B, int T, int max_steps, float min_stop_token, const float* d_dropout, uint64_t seed, float* d_mel,
+                               float* d_attn, bool lsa_fast, size_t lds_lsa, int psplit, void* d_workspace, hipStream_t s, int* frames_out) {
+  const mb_taco_config& c = t->cfg;
+  const int D = c.decoder_dims, P = c.project_dims, H = c.lstm_dims, M = c.n_mels, r = c.r;
+  const int nta = cdiv(B, 16), n_iter_max = cdiv(max_steps, r);
+  const bool drop_enabled = c.dropout > 0.f;
+  DropK dk;
+  dk.mask = drop_enabled ? d_dropout : nullptr; dk.ld = 2 * D; dk.layer = 0; dk.it_add = 0;
+  dk.thresh = drop_enabled ? (unsigned)std::min(4294967295.0, (double)c.dropout * 4294967296.0) : 0u;
+  dk.scale = drop_enabled ? 1.f / (1.f - c.dropout) : 1.f; dk.enabled = drop_enabled ? 1 : 0;
+  int* flags = L.flags;
+  MB_HIP(hipMemsetAsync(L.f_p1, 0, L.f_state_bytes, s));
+  MB_HIP(hipMemcpyAsync(flags + TF_SEED, &seed, sizeof(seed), hipMemcpyHostToDevice, s));  // pageable source: staged before return
+  {
+    TfP1K pk;
+    pk.b_fc1 = t->pre1_b.p; pk.p1 = L.f_p1; pk.nta = nta; pk.B = B; pk.rows = 2 * D; pk.flags = flags; pk.drop = dk;
+    hipLaunchKernelGGL(taco_p1_init_kernel, dim3(2 * D / 16, nta), dim3(64), 0, s, pk);
+  }
+  // attention-GRU pre-activations of iteration 0: context = 0, attn_hidden = 0 -> the biases
+  {
+    TfRinK rk;
+    rk.w_rin = t->rin_w.p; rk.b_rin = t->rin_b.p; rk.w_pre = t->f_pre_w.p;
+    rk.bih4 = reinterpret_cast<const float4*>(t->f_bih4.p); rk.bhh4 = reinterpret_cast<const float4*>(t->f_bhh4.p);
+    rk.ctx = L.f_ctx; rk.ah = L.f_ah; rk.x = L.f_x; rk.xpre = reinterpret_cast<float4*>(L.f_xpre); rk.hpre = reinterpret_cast<float4*>(L.f_hpre);
+    rk.nta = nta; rk.n_rin = H / 16; rk.flags = flags;
+    if (nta >= 2) hipLaunchKernelGGL(taco_rin_kernel<2>, dim3(H / 16 + D / 4, cdiv(nta, 2)), dim3(512), 0, s, rk);
+    else hipLaunchKernelGGL(taco_rin_kernel<1>, dim3(H / 16 + D / 4, nta), dim3(512), 0, s, rk);
+  }
+  MB_HIP(hipGetLastError());
+
+  auto iteration = [&](int pp, int it_off) -> int {
+    const size_t hsz = fm_floats(H, nta);
+    float* h1p = L.f_h1 + (size_t)pp * hsz; float* h1n = L.f_h1 + (size_t)(pp ^ 1) * hsz;
+    float* h2p = L.f_h2 + (size_t)pp * hsz; float* h2n = L.f_h2 + (size_t)(pp ^ 1) * hsz;
+    const dim3 blk(512);
+    const int gy = nta >= 2 ? cdiv(nta, 2) : nta;
+#define TF_LAUNCH(KERNEL, GX, ARG)                                                     \
+    do {                                                                               \
+      if (nta >= 2) hipLaunchKernelGGL(KERNEL<2>, dim3(GX, gy), blk, 0, s, ARG);       \
+      else hipLaunchKernelGGL(KERNEL<1>, dim3(GX, gy), blk, 0, s, ARG);                \
+    } while (0)
+    // 1. prenet layer 2 (layer 1 was left by the previous iteration's mel launch / the prologue)
+    TfFcK fk;
+    fk.w = t->pre2_w.p; fk.bias = t->pre2_b.p; fk.xin = L.f_p1; fk.yout = L.f_p2; fk.nta = nta; fk.B = B; fk.it_off = it_off;
+    fk.flags = flags; fk.drop = dk; fk.drop.layer = 1;
+    TF_LAUNCH(taco_fc2_kernel, 2 * D / 16, fk);
+    // 2. attention GRU on the prenet columns
+    TfGruK gk;
+    gk.w = t->f_gru_w.p; gk.xin = L.f_p2; gk.xpre = reinterpret_cast<const float4*>(L.f_xpre);
+    gk.hpre = reinterpret_cast<const float4*>(L.f_hpre); gk.ah = L.f_ah; gk.nta = nta; gk.B = B; gk.flags = flags;
+    TF_LAUNCH(taco_gru_kernel, D / 4, gk);
+    // 3. location-sensitive attention + context
+    LsaK lk;
+    lk.query = L.f_ah; lk.mem_proj = d_memory_proj; lk.memory = d_memory; lk.chars = d_chars;
+    lk.cum_in = L.cumulative + (size_t)pp * B * T; lk.cum_out = L.cumulative + (size_t)(pp ^ 1) * B * T; lk.psplit = psplit;
+    lk.conv_w = t->lsa_conv_w.p; lk.conv_b = t->lsa_conv_b.p; lk.Lw = t->lsa_L.p; lk.Ww = t->lsa_W.p; lk.Wb = t->lsa_Wb.p;
+    lk.vw = t->lsa_v.p; lk.context = L.f_ctx; lk.attn_out = d_attn; lk.T = T; lk.D = D; lk.P = P; lk.Fl = c.lsa_filters;
+    lk.Kl = c.lsa_kernel; lk.iter = it_off; lk.n_iter_max = n_iter_max; lk.skip_flag = flags + TF_DONE;
+    lk.Mt = t->lsa_Mt.p; lk.c0 = t->lsa_c0.p; lk.Wt = t->lsa_Wt.p; lk.fm_nta = nta; lk.iter_base = flags + TF_ITER;
+    if (lsa_fast && T <= 128) hipLaunchKernelGGL(lsa_fast_kernel<32>, dim3(B, psplit), dim3(512), 0, s, lk);
+    else if (lsa_fast) hipLaunchKernelGGL(lsa_fast_kernel<48>, dim3(B, psplit), dim3(512), 0, s, lk);
+    else hipLaunchKernelGGL(lsa_kernel, dim3(B, psplit), dim3(512), lds_lsa, s, lk);
+    // 4. rnn_input beside the next iteration's attention-GRU pre-activations
+    TfRinK rk;
+    rk.w_rin = t->rin_w.p; rk.b_rin = t->rin_b.p; rk.w_pre = t->f_pre_w.p;
+    rk.bih4 = reinterpret_cast<const float4*>(t->f_bih4.p); rk.bhh4 = reinterpret_cast<const float4*>(t->f_bhh4.p);
+    rk.ctx = L.f_ctx; rk.ah = L.f_ah; rk.x = L.f_x; rk.xpre = reinterpret_cast<float4*>(L.f_xpre); rk.hpre = reinterpret_cast<float4*>(L.f_hpre);
+    rk.nta = nta; rk.n_rin = H / 16; rk.flags = flags;
+    TF_LAUNCH(taco_rin_kernel, H / 16 + D / 4, rk);
+    // 5./6. residual LSTMs
+    TfLstmK lk1;
+    lk1.w = t->l1_w.p; lk1.b4 = reinterpret_cast<const float4*>(t->f_l1_b4.p); lk1.x = L.f_x; lk1.h_prev = h1p; lk1.h_out = h1n;
+    lk1.c = L.f_c1; lk1.x_out = L.f_x1; lk1.nta = nta; lk1.flags = flags;
+    TF_LAUNCH(taco_lstm_kernel, H / 4, lk1);
+    TfLstmK lk2 = lk1;
+    lk2.w = t->l2_w.p; lk2.b4 = reinterpret_cast<const float4*>(t->f_l2_b4.p); lk2.x = L.f_x1; lk2.h_prev = h2p; lk2.h_out = h2n;
+    lk2.c = L.f_c2; lk2.x_out = L.f_x2;
+    TF_LAUNCH(taco_lstm_kernel, H / 4, lk2);
+    // 7. mel frames, next prenet layer 1, stop token + stop rule
+    TfMelK mk;
+    mk.w_mel = t->mel_w.p; mk.w_fc1 = t->f_fc1_w.p; mk.b_fc1 = t->pre1_b.p; mk.w_stop = t->f_stop_w.p; mk.b_stop = t->stop_b.p;
+    mk.x2 = L.f_x2; mk.ctx = L.f_ctx; mk.p1 = L.f_p1; mk.mel_out = d_mel; mk.stop_out = L.stop;
+    mk.nta = nta; mk.B = B; mk.n_mel = r * M / 16; mk.M = M; mk.r = r; mk.max_steps = max_steps; mk.it_off = it_off;
+    mk.min_stop_token = min_stop_token; mk.flags = flags; mk.drop = dk; mk.drop.layer = 0; mk.drop.it_add = 1;
+    TF_LAUNCH(taco_mel_kernel, r * M / 16 + 2 * D / 16 + 1, mk);
+#undef TF_LAUNCH
+    MB_HIP(hipGetLastError());
+    return MB_OK;
+  };
+
+  int G = 16;  // iterations per graph replay (even: the LSTM state / cumulative-attention parity returns to 0)
+  if (const char* ge = getenv("MBHIP_TACO_GRAPH_ITERS")) G = atoi(ge) & ~1;
+  const bool use_graph = getenv("MBHIP_NO_GRAPH") == nullptr && G >= 2 && n_iter_max >= G;
+  int it_done = 0, rc = MB_OK;
+  bool stopped = false;
+  if (use_graph) {
+    mb_taco::GraphKey key = {d_memory, d_memory_proj, d_chars, d_dropout, d_mel, d_attn, d_workspace, B, T, max_steps, G, min_stop_token};
+    if (!t->graph_exec || memcmp(&key, &t->gkey, sizeof(key)) != 0) {
+      t->drop_graph();
+      MB_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+      for (int i = 0; i < G && !rc; ++i) rc = iteration(i & 1, i);
+      hipLaunchKernelGGL(taco_bump_kernel, dim3(1), dim3(1), 0, s, flags, G);
+      hipError_t e = hipStreamEndCapture(s, &t->graph);
+      if (rc) { t->drop_graph(); return rc; }
+      if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture", __FILE__, __LINE__);
+      e = hipGraphInstantiate(&t->graph_exec, t->graph, nullptr, nullptr, 0);
+      if (e != hipSuccess) { t->drop_graph(); return hip_fail(e, "hipGraphInstantiate", __FILE__, __LINE__); }
+      t->gkey = key;
+    }
+    const int reps = n_iter_max / G;
+    for (int rep = 0; rep < reps; ++rep) {
+      MB_HIP(hipGraphLaunch(t->graph_exec, s));
+      MB_HIP(hipMemcpyAsync(t->h_flags + 8 * (rep & 1), flags, sizeof(int) * 8, hipMemcpyDeviceToHost, s));
+      MB_HIP(hipEventRecord(t->ev_flags[rep & 1], s));
+      it_done += G;
+      if (rep > 0) {  // look at the flags of the replay before: the device never waits for the host
+        MB_HIP(hipEventSynchronize(t->ev_flags[(rep - 1) & 1]));
+        if (t->h_flags[8 * ((rep - 1) & 1) + TF_DONE]) { stopped = true; break; }
+      }
+    }
+  }
+  for (int it = it_done; it < n_iter_max && !stopped; ++it) {  // eager tail (and short runs): the offset carries the iteration
+    if ((rc = iteration(it & 1, it - it_done))) return rc;
+    if (((it - it_done) & 15) == 15) {
+      MB_HIP(hipMemcpyAsync(t->h_flags, flags, sizeof(int) * 8, hipMemcpyDeviceToHost, s));
+      MB_HIP(hipStreamSynchronize(s));
+      if (t->h_flags[TF_DONE]) stopped = true;
+    }
+  }
+  MB_HIP(hipMemcpyAsync(t->h_flags, flags, sizeof(int) * 8, hipMemcpyDeviceToHost, s));
+  MB_HIP(hipStreamSynchronize(s));
+  *frames_out = t->h_flags[TF_NFRAMES];
+  return MB_OK;
+}
+
+static int taco_fast_loop(mb_taco* t, const TacoLayout& L, const float* d_memory, const float* d_memory_proj, const int32_t* d_chars,
+                          int B, int T, int max_steps, float min_stop_token, const float* d_dropout, uint64_t seed, float* d_mel,
+                          float* d_attn, bool lsa_fast, size_t lds_lsa, int psplit, void* d_workspace, hipStream_t caller, int* frames_out) {
+  hipStream_t ls = t->loop_stream;
+  MB_HIP(hipEventRecord(t->ev_in, caller));  // the caller's memsets / producers of memory first
+  MB_HIP(hipStreamWaitEvent(ls, t->ev_in, 0));
+  const int rc = taco_fast_loop_body(t, L, d_memory, d_memory_proj, d_chars, B, T, max_steps, min_stop_token, d_dropout, seed, d_mel,
+                                     d_attn, lsa_fast, lds_lsa, psplit, d_workspace, ls, frames_out);
+  // success: the body ended with a host synchronisation of the loop stream (frame count), so whatever the caller
+  // enqueues next is ordered behind the loop.  Failure: drain what was enqueued before handing the buffers back.
+  if (rc) (void)hipStreamSynchronize(ls);
+  return rc;
+}
 
 extern "C" int mb_taco_decode(const mb_taco* t, const float* d_memory, const float* d_memory_proj,
                               const int32_t* d_chars, int batch, int t_text, int max_steps, float min_stop_token,
@@ -1053,6 +1303,15 @@ extern "C" int mb_taco_decode(const mb_taco* t, const float* d_memory, const flo
   const float drop_scale = drop_enabled ? 1.f / (1.f - c.dropout) : 1.f;
   const unsigned drop_thresh = drop_enabled ? (unsigned)std::min(4294967295.0, (double)c.dropout * 4294967296.0) : 0u;
   int frames = 0;
+  // production dims: the FM-layout loop of taco_fast.h (MBHIP_TACO_FAST=0 forces the general loop below, which also
+  // serves every other checkpoint shape)
+  const char* fenv = getenv("MBHIP_TACO_FAST");
+  const bool use_fast = t->fast && !(fenv && atoi(fenv) == 0);
+  if (use_fast) {
+    const int rcf = taco_fast_loop(const_cast<mb_taco*>(t), L, d_memory, d_memory_proj, d_chars, B, T, max_steps, min_stop_token,
+                                   d_dropout, seed, d_mel, d_attn, lsa_fast, lds_lsa, psplit, d_workspace, s, &frames);
+    if (rcf) return rcf;
+  } else
   for (int it = 0; it < n_iter_max; ++it) {
     const int pp = it & 1;
     float* ah_p = L.attn_h + (size_t)pp * B * D; float* ah_n = L.attn_h + (size_t)(pp ^ 1) * B * D;
@@ -1089,7 +1348,7 @@ extern "C" int mb_taco_decode(const mb_taco* t, const float* d_memory, const flo
     lk.conv_w = t->lsa_conv_w.p; lk.conv_b = t->lsa_conv_b.p; lk.Lw = t->lsa_L.p; lk.Ww = t->lsa_W.p; lk.Wb = t->lsa_Wb.p;
     lk.vw = t->lsa_v.p; lk.context = cx_n; lk.attn_out = d_attn; lk.T = T; lk.D = D; lk.P = P; lk.Fl = c.lsa_filters;
     lk.Kl = c.lsa_kernel; lk.iter = it; lk.n_iter_max = n_iter_max; lk.skip_flag = done;
-    lk.Mt = t->lsa_Mt.p; lk.c0 = t->lsa_c0.p; lk.Wt = t->lsa_Wt.p;
+    lk.Mt = t->lsa_Mt.p; lk.c0 = t->lsa_c0.p; lk.Wt = t->lsa_Wt.p; lk.fm_nta = 0; lk.iter_base = nullptr;
     if (lsa_fast && T <= 128) hipLaunchKernelGGL(lsa_fast_kernel<32>, dim3(B, psplit), dim3(512), 0, s, lk);
     else if (lsa_fast) hipLaunchKernelGGL(lsa_fast_kernel<48>, dim3(B, psplit), dim3(512), 0, s, lk);
     else hipLaunchKernelGGL(lsa_kernel, dim3(B, psplit), dim3(512), lds_lsa, s, lk);

@@ -27,7 +27,8 @@ def _batch(n, tmin, tmax, seed):
     return chars, torch.tensor(np.stack(emb)), seqs, emb
 
 
-@pytest.mark.parametrize("B,tmin,tmax,steps,style", [(3, 20, 30, 40, -1), (5, 33, 47, 60, 0), (1, 12, 12, 24, 3)])
+@pytest.mark.parametrize("B,tmin,tmax,steps,style", [(3, 20, 30, 40, -1), (5, 33, 47, 60, 0), (1, 12, 12, 24, 3),
+                                                     (20, 20, 30, 36, -1), (40, 15, 25, 24, 0)])
 def test_decode_and_postnet_match_oracle(model, B, tmin, tmax, steps, style):
     dev, w = model
     chars, spk, _, _ = _batch(B, tmin, tmax, seed=B)
@@ -46,6 +47,32 @@ def test_decode_and_postnet_match_oracle(model, B, tmin, tmax, steps, style):
         assert e["nan"] == 0 and e["max_abs"] <= tol, (name, e)
     assert float(omel.abs().mean()) > 0.1  # O(1) fixture, tolerance not vacuous
     assert torch.allclose(attn.sum(2).cpu(), torch.ones(B, steps // 2), atol=1e-5)
+
+
+def test_fast_loop_equals_general_loop(model, monkeypatch):
+    """The production-dims loop (taco_fast.h: FM activations, 7 launches, hipGraph replays + eager tail) against the
+    general loop (MBHIP_TACO_FAST=0) on the same masks: same frames, mels within 1e-4 (different summation orders),
+    and with on-device dropout both draw the same Philox stream for a seed."""
+    dev, w = model
+    chars, spk, _, _ = _batch(19, 25, 40, seed=4)
+    with torch.no_grad():
+        mem, memp = ot.encoder_memory(w, ot.HP, chars, spk, 0)
+    steps = 70  # 35 iterations: two graph replays of 16 + 3 eager
+    masks = synth.decoder_dropout_masks(3, steps // 2, 19)
+    monkeypatch.delenv("MBHIP_TACO_FAST", raising=False)
+    f = dev.decode(mem.cuda(), memp.cuda(), chars.cuda(), steps, 11.0, dropout=masks)
+    fr = dev.decode(mem.cuda(), memp.cuda(), chars.cuda(), steps, 11.0, seed=77)
+    monkeypatch.setenv("MBHIP_NO_GRAPH", "1")
+    fe = dev.decode(mem.cuda(), memp.cuda(), chars.cuda(), steps, 11.0, dropout=masks)
+    monkeypatch.delenv("MBHIP_NO_GRAPH")
+    monkeypatch.setenv("MBHIP_TACO_FAST", "0")
+    g = dev.decode(mem.cuda(), memp.cuda(), chars.cuda(), steps, 11.0, dropout=masks)
+    gr = dev.decode(mem.cuda(), memp.cuda(), chars.cuda(), steps, 11.0, seed=77)
+    for a, b in zip(f, fe):
+        assert torch.equal(a, b)  # graph replays == eager launches of the same kernels
+    for name, a, b in (("mel", f[0], g[0]), ("linear", f[1], g[1]), ("attn", f[2], g[2]), ("mel_rng", fr[0], gr[0])):
+        e = hiputil.relerr(a, b)
+        assert a.shape == b.shape and e["nan"] == 0 and e["max_abs"] <= 2e-4, (name, e)
 
 
 def test_stop_rule_matches_oracle(model):
