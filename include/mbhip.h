@@ -370,6 +370,11 @@ int mb_taco_decode(const mb_taco* t, const float* d_memory, const float* d_memor
                    float* d_mel, float* d_linear, float* d_attn, int* h_n_frames,
                    void* d_workspace, size_t workspace_bytes, mb_stream_t stream);
 
+/* Duration of the decoder loop of the last mb_taco_decode call (HIP events on the loop's own stream: iterations
+ * only, without the state initialisation in front of it and the postnet behind it) and the number of decoder
+ * iterations it ran.  Production-dims handles only (the hipGraph-replayed loop); MB_ESTATE otherwise. */
+int mb_taco_last_loop_ms(const mb_taco* t, float* ms, int* iterations);
+
 /* Text encoder + global style token + attention-memory assembly (the once-per-chunk front
  * half of Tacotron.forward, tacotron.py:234-255):
  *  d_chars   [B][T] int32, d_speaker [B][speaker_dims],

@@ -41,6 +41,22 @@ __host__ __device__ __forceinline__ size_t fm_index(int nta, int n, int k) {
   return ((size_t)(k >> 4) * nta + (n >> 4)) * 256 + ((k >> 2) & 3) * 64 + (n & 15) * 4 + (k & 3);
 }
 
+// diagnostics (MBHIP_TACO_TRACE=<file>): shader-clock stamps of one workgroup per kernel, 16 marks per kernel slot;
+// mark 14 / 15 = 100 MHz wall clock at kernel start / end (aligns the kernels of an iteration with each other)
+enum { TS_FC2 = 0, TS_GRU = 1, TS_LSA = 2, TS_RIN = 3, TS_LSTM1 = 4, TS_LSTM2 = 5, TS_MEL = 6, TS_MEL_FC1 = 7, TS_MEL_STOP = 8, TS_SLOTS = 9 };
+__device__ __forceinline__ void tf_mark(unsigned long long* tr, int slot, int k, bool pick) {
+  if (tr && pick && threadIdx.x == 0) {
+    tr[slot * 16 + k] = (unsigned long long)clock64();
+    if (k == 0) tr[slot * 16 + 14] = (unsigned long long)wall_clock64();
+  }
+}
+__device__ __forceinline__ void tf_mark_end(unsigned long long* tr, int slot, int k, bool pick) {
+  if (tr && pick && (threadIdx.x & 63) == 0 && threadIdx.x < 128) {  // epilogue waves: the later one wins
+    atomicMax(tr + slot * 16 + k, (unsigned long long)clock64());
+    atomicMax(tr + slot * 16 + 15, (unsigned long long)wall_clock64());
+  }
+}
+
 // row sum over the 16 lanes of a DPP row (every lane of the row receives it): 4 VALU ops, no LDS crossbar
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
@@ -61,7 +77,8 @@ __device__ __forceinline__ float row16_sum(float v) {
 template <int NT, int PW, int PS, int RL, int NPART>
 __device__ __forceinline__ bool fm_gemm(const float* __restrict__ w, const int mt, const float* __restrict__ seg0,
                                         const float* __restrict__ seg1, const int nta, const int nt0, float* red,
-                                        float (&sx)[4], float (&sh)[4]) {
+                                        float (&sx)[4], float (&sh)[4], unsigned long long* tr = nullptr, int slot = 0,
+                                        bool pick = false) {
   constexpr int BLK = 4 * RL * 16, NKB = 8 * PW;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -84,6 +101,7 @@ __device__ __forceinline__ bool fm_gemm(const float* __restrict__ w, const int m
   // the machine scheduler would otherwise sink the loads next to their MFMAs to save registers (50 VGPRs, two or
   // three k-blocks in flight per wave); the whole point is to have every fragment of the wave in flight at once
   __builtin_amdgcn_sched_barrier(0);
+  tf_mark(tr, slot, 1, pick);  // every load issued
   f32x4 accX[NT], accH[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) { accX[nt] = {0.f, 0.f, 0.f, 0.f}; accH[nt] = {0.f, 0.f, 0.f, 0.f}; }
@@ -102,12 +120,14 @@ __device__ __forceinline__ bool fm_gemm(const float* __restrict__ w, const int m
     }
   }
   float4* red4 = reinterpret_cast<float4*>(red);  // [8][NT][NPART][64]
+  tf_mark(tr, slot, 2, pick);  // MFMAs of wave 0 issued (its last fragment has arrived)
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     red4[((wave * NT + nt) * NPART + 0) * 64 + lane] = make_float4(accX[nt][0], accX[nt][1], accX[nt][2], accX[nt][3]);
     if (NPART == 2) red4[((wave * NT + nt) * NPART + 1) * 64 + lane] = make_float4(accH[nt][0], accH[nt][1], accH[nt][2], accH[nt][3]);
   }
   __syncthreads();
+  tf_mark(tr, slot, 3, pick);  // all eight waves done
   if (wave >= NT) return false;
 #pragma unroll
   for (int g = 0; g < 4; ++g) { sx[g] = 0.f; sh[g] = 0.f; }
@@ -154,7 +174,7 @@ __device__ __forceinline__ void relu_drop_quad(const DropK& d, const int* flags,
 // p2 = dropout(relu(fc2 . p1 + b2))   (pre_net.py:24-26).  K = 2D = 256 -> PW = 2.
 struct TfFcK {
   const float* w; const float* bias; const float* xin; float* yout;
-  int nta, B, it_off; const int* flags; DropK drop;
+  int nta, B, it_off; const int* flags; DropK drop; unsigned long long* trace;
 };
 template <int NT>
 __global__ __launch_bounds__(512) void taco_fc2_kernel(TfFcK a) {
@@ -162,7 +182,9 @@ __global__ __launch_bounds__(512) void taco_fc2_kernel(TfFcK a) {
   const int mt = blockIdx.x, nt0 = blockIdx.y * NT;
   const int done = a.flags[TF_DONE], it = a.flags[TF_ITER] + a.it_off;
   float sx[4], sh[4];
-  if (!fm_gemm<NT, 2, 2, 4, 1>(a.w, mt, a.xin, a.xin, a.nta, nt0, red, sx, sh)) return;
+  const bool pick = blockIdx.x == 3 && blockIdx.y == 0;
+  tf_mark(a.trace, TS_FC2, 0, pick);
+  if (!fm_gemm<NT, 2, 2, 4, 1>(a.w, mt, a.xin, a.xin, a.nta, nt0, red, sx, sh, a.trace, TS_FC2, pick)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nt = nt0 + wave, du = lane >> 4, n = nt * 16 + (lane & 15), row0 = mt * 16 + du * 4;
   if (nt >= a.nta || done) return;
@@ -170,6 +192,7 @@ __global__ __launch_bounds__(512) void taco_fc2_kernel(TfFcK a) {
   float v[4] = {sx[0] + bq.x, sx[1] + bq.y, sx[2] + bq.z, sx[3] + bq.w};
   relu_drop_quad(a.drop, a.flags, it, a.B, n < a.B ? n : a.B - 1, row0, v);
   reinterpret_cast<float4*>(a.yout)[((size_t)mt * a.nta + nt) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+  tf_mark_end(a.trace, TS_FC2, 4, pick);
 }
 
 // ------------------------------------------------------------------------------------------------ attention GRU
@@ -177,7 +200,7 @@ __global__ __launch_bounds__(512) void taco_fc2_kernel(TfFcK a) {
 // W_ih[:, :P] . context + b_ih and W_hh . attn_hidden + b_hh were left as CM4 quads by the previous rnn_input launch.
 struct TfGruK {
   const float* w; const float* xin; const float4* xpre; const float4* hpre; float* ah;  // ah FM [D], updated in place
-  int nta, B; const int* flags;
+  int nta, B; const int* flags; unsigned long long* trace;
 };
 template <int NT>
 __global__ __launch_bounds__(512) void taco_gru_kernel(TfGruK a) {
@@ -192,23 +215,29 @@ __global__ __launch_bounds__(512) void taco_gru_kernel(TfGruK a) {
   float* hpt = a.ah + ((size_t)(mt >> 2) * a.nta + ntE) * 256 + (mt & 3) * 64 + i * 4 + du;
   const float hprev = *hpt;
   float sx[4], sh[4];
-  if (!fm_gemm<NT, 2, 2, 3, 1>(a.w, mt, a.xin, a.xin, a.nta, nt0, red, sx, sh)) return;
+  const bool pick = blockIdx.x == 3 && blockIdx.y == 0;
+  tf_mark(a.trace, TS_GRU, 0, pick);
+  if (!fm_gemm<NT, 2, 2, 3, 1>(a.w, mt, a.xin, a.xin, a.nta, nt0, red, sx, sh, a.trace, TS_GRU, pick)) return;
   if (nt0 + wv >= a.nta || done) return;
   // torch GRUCell, gate order (r, z, n)
   const float rg = sigmoidf_((sx[0] + xp.x) + hp.x);
   const float zg = sigmoidf_((sx[1] + xp.y) + hp.y);
   const float ng = tanhf((sx[2] + xp.z) + rg * hp.z);
   *hpt = ng + zg * (hprev - ng);
+  tf_mark_end(a.trace, TS_GRU, 4, pick);
 }
 
 // ------------------------------------------------------------------------------------------------ rnn_input (+ GRU pre)
 // job 0 (blockIdx.x < n_rin): x = rnn_input([context, attn_hidden])  (tacotron.py:108-109) -> FM
 // job 1: the NEXT iteration's attention-GRU pre-activations from the same operands:
 //        xpre = W_ih[:, :P] . context + b_ih,  hpre = W_hh . attn_hidden + b_hh   (CM4: r, z, n, -)
+// job 2 (one tile, one live row): the context half of the stop token's logit, stop_proj[:, H:] . context
+//        (tacotron.py:133-135); the mel launch adds the x half once the LSTMs are through
 struct TfRinK {
   const float* w_rin; const float* b_rin; const float* w_pre; const float4* bih4; const float4* bhh4;
+  const float* w_stopc; float* stop_part;  // job 2: stop_proj's context columns . context -> [nta*16] partial logits
   const float* ctx; const float* ah; float* x; float4* xpre; float4* hpre;
-  int nta, n_rin; const int* flags;
+  int nta, n_rin; const int* flags; unsigned long long* trace;
 };
 template <int NT>
 __global__ __launch_bounds__(512) void taco_rin_kernel(TfRinK a) {
@@ -219,15 +248,25 @@ __global__ __launch_bounds__(512) void taco_rin_kernel(TfRinK a) {
   float sx[4], sh[4];
   if ((int)blockIdx.x < a.n_rin) {
     const int mt = blockIdx.x;
-    if (!fm_gemm<NT, 9, 8, 4, 1>(a.w_rin, mt, a.ctx, a.ah, a.nta, nt0, red, sx, sh)) return;
+    const bool pick = blockIdx.x == 3 && blockIdx.y == 0;
+    tf_mark(a.trace, TS_RIN, 0, pick);
+    if (!fm_gemm<NT, 9, 8, 4, 1>(a.w_rin, mt, a.ctx, a.ah, a.nta, nt0, red, sx, sh, a.trace, TS_RIN, pick)) return;
     const int nt = nt0 + wv;
     if (nt >= a.nta || done) return;
     const float4 bq = *reinterpret_cast<const float4*>(a.b_rin + mt * 16 + du * 4);
     reinterpret_cast<float4*>(a.x)[((size_t)mt * a.nta + nt) * 64 + lane] =
         make_float4(sx[0] + bq.x, sx[1] + bq.y, sx[2] + bq.z, sx[3] + bq.w);
+    tf_mark_end(a.trace, TS_RIN, 4, pick);
     return;
   }
   const int mt = blockIdx.x - a.n_rin;
+  if (mt >= 32) {  // stop token, context half
+    if (!fm_gemm<NT, 9, 8, 4, 1>(a.w_stopc, 0, a.ctx, a.ah, a.nta, nt0, red, sx, sh)) return;
+    const int nt = nt0 + wv;
+    if (nt >= a.nta || done || du != 0) return;
+    a.stop_part[nt * 16 + (lane & 15)] = sx[0];
+    return;
+  }
   if (!fm_gemm<NT, 9, 8, 3, 2>(a.w_pre, mt, a.ctx, a.ah, a.nta, nt0, red, sx, sh)) return;
   const int nt = nt0 + wv;
   if (nt >= a.nta || done) return;
@@ -237,12 +276,34 @@ __global__ __launch_bounds__(512) void taco_rin_kernel(TfRinK a) {
   a.hpre[cm] = make_float4(sh[0] + bh.x, sh[1] + bh.y, sh[2] + bh.z, 0.f);
 }
 
+// ------------------------------------------------------------------------------------------------ LSTM hidden halves
+// hh job: hpre = W_hh . h (LSTM tile order: the 16 rows of tile mt are the 4 gates of units 4 mt .. 4 mt + 3), one
+// CM4 quad per (unit, column).  Rides as extra workgroups behind the jobs of a latency-bound launch.
+struct TfHhK { const float* w; const float* h; float4* hpre; int n_tiles; };
+template <int NT>
+__device__ __forceinline__ void fm_hh_job(const TfHhK& a, const int mt, const int nt0, const int nta, const int done, float* red) {
+  float sx[4], sh[4];
+  if (!fm_gemm<NT, 8, 8, 4, 1>(a.w, mt, a.h, a.h, nta, nt0, red, sx, sh)) return;
+  const int lane = threadIdx.x & 63, nt = nt0 + (threadIdx.x >> 6);
+  if (nt >= nta || done) return;
+  a.hpre[((size_t)mt * nta + nt) * 64 + lane] = make_float4(sx[0], sx[1], sx[2], sx[3]);
+}
+// stand-alone form (general LSA kernel in use, or diagnostics)
+template <int NT>
+__global__ __launch_bounds__(512) void taco_hh_kernel(TfHhK a, int nta, const int* flags) {
+  __shared__ __attribute__((aligned(16))) float red[FmRed<NT, 1>::floats];
+  fm_hh_job<NT>(a, blockIdx.x, blockIdx.y * NT, nta, flags[TF_DONE], red);
+}
+
 // ------------------------------------------------------------------------------------------------ residual LSTM
-// h, c = LSTMCell(x, (h, c)); x = x + h   (tacotron.py:112-125, eval branch).  K = [x | h_prev] = 128 k-blocks.
+// h, c = LSTMCell(x, (h, c)); x = x + h   (tacotron.py:112-125, eval branch).  Only the input half W_ih . x (64
+// k-blocks) is multiplied on the dependent chain: the hidden half W_hh . h depends on the PREVIOUS iteration's state
+// alone and was left as CM4 gate quads by an hh job (fm_hh_job) riding in an earlier, latency-bound launch.
 struct TfLstmK {
-  const float* w; const float4* b4;  // b_ih + b_hh per unit: (i, f, g, o)
-  const float* x; const float* h_prev; float* h_out; float* c; float* x_out;  // FM, FM, FM, CM1 (in place), FM
-  int nta; const int* flags;
+  const float* w; const float4* b4;  // W_ih tiles; b_ih + b_hh per unit: (i, f, g, o)
+  const float4* hpre;                // W_hh . h_prev (CM4)
+  const float* x; float* h_out; float* c; float* x_out;  // FM, FM, CM1 (in place), FM
+  int nta; const int* flags; unsigned long long* trace; int trace_slot;
 };
 template <int NT>
 __global__ __launch_bounds__(512) void taco_lstm_kernel(TfLstmK a) {
@@ -252,23 +313,27 @@ __global__ __launch_bounds__(512) void taco_lstm_kernel(TfLstmK a) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, du = lane >> 4, i = lane & 15;
   const int ntE = (nt0 + (wv < NT ? wv : 0) < a.nta) ? nt0 + (wv < NT ? wv : 0) : a.nta - 1;
   const float4 bq = a.b4[mt * 4 + du];
+  const float4 hq = a.hpre[((size_t)mt * a.nta + ntE) * 64 + lane];
   float* cp = a.c + ((size_t)mt * a.nta + ntE) * 64 + lane;
   const float cprev = *cp;
   const size_t fo = ((size_t)(mt >> 2) * a.nta + ntE) * 256 + (mt & 3) * 64 + i * 4 + du;
   const float xr = a.x[fo];
   float sx[4], sh[4];
-  if (!fm_gemm<NT, 16, 8, 4, 1>(a.w, mt, a.x, a.h_prev, a.nta, nt0, red, sx, sh)) return;
+  const bool pick = blockIdx.x == 100 && blockIdx.y == 0;
+  tf_mark(a.trace, a.trace_slot, 0, pick);
+  if (!fm_gemm<NT, 8, 8, 4, 1>(a.w, mt, a.x, a.x, a.nta, nt0, red, sx, sh, a.trace, a.trace_slot, pick)) return;
   if (nt0 + wv >= a.nta || done) return;
   // torch LSTMCell, gate order (i, f, g, o)
-  const float gi = sigmoidf_(sx[0] + bq.x);
-  const float gf = sigmoidf_(sx[1] + bq.y);
-  const float gg = tanhf(sx[2] + bq.z);
-  const float go = sigmoidf_(sx[3] + bq.w);
+  const float gi = sigmoidf_((sx[0] + hq.x) + bq.x);
+  const float gf = sigmoidf_((sx[1] + hq.y) + bq.y);
+  const float gg = tanhf((sx[2] + hq.z) + bq.z);
+  const float go = sigmoidf_((sx[3] + hq.w) + bq.w);
   const float cy = gf * cprev + gi * gg;
   const float hy = go * tanhf(cy);
   *cp = cy;
   a.h_out[fo] = hy;
   a.x_out[fo] = xr + hy;
+  tf_mark_end(a.trace, a.trace_slot, 4, pick);
 }
 
 // ------------------------------------------------------------------------------------------------ mel_proj (+ fc1' + stop)
@@ -276,11 +341,14 @@ __global__ __launch_bounds__(512) void taco_lstm_kernel(TfLstmK a) {
 //        frame-major) scattered straight into mel_out[b][m][t0 + j]
 // job 1 (16 tiles):    the NEXT iteration's prenet layer 1: relu(fc1 . mel[last frame] + b1) with fc1 folded through
 //        mel_proj (W' = fc1 . mel_proj[last frame rows]), dropout of iteration it + 1
-// job 2 (1 tile):      stop = sigmoid(stop_proj([x, context])) (:133-136) and the batch-wide stop rule (:275)
+// job 2 (1 tile):      stop = sigmoid(stop_proj([x, context])) (:133-136) -- x half here, context half from the rnn_input
+//        launch -- and the batch-wide stop rule (:275)
+// job 3 (hh.n_tiles row tiles): W_hh1 . h1 for the next iteration (fm_hh_job)
 struct TfMelK {
   const float* w_mel; const float* w_fc1; const float* b_fc1; const float* w_stop; const float* b_stop;
-  const float* x2; const float* ctx; float* p1; float* mel_out; float* stop_out;
-  int nta, B, n_mel, M, r, max_steps, it_off; float min_stop_token; int* flags; DropK drop;
+  const float* x2; const float* stop_part; float* p1; float* mel_out; float* stop_out;
+  TfHhK hh;  // job 3: hidden half of the NEXT iteration's first LSTM (h1 of this iteration is final)
+  int nta, B, n_mel, M, r, max_steps, it_off; float min_stop_token; int* flags; DropK drop; unsigned long long* trace;
 };
 template <int NT>
 __global__ __launch_bounds__(512) void taco_mel_kernel(TfMelK a) {
@@ -291,7 +359,9 @@ __global__ __launch_bounds__(512) void taco_mel_kernel(TfMelK a) {
   const int bx = blockIdx.x;
   float sx[4], sh[4];
   if (bx < a.n_mel) {
-    if (!fm_gemm<NT, 8, 8, 4, 1>(a.w_mel, bx, a.x2, a.x2, a.nta, nt0, red, sx, sh)) return;
+    const bool pick = bx == 3 && blockIdx.y == 0;
+    tf_mark(a.trace, TS_MEL, 0, pick);
+    if (!fm_gemm<NT, 8, 8, 4, 1>(a.w_mel, bx, a.x2, a.x2, a.nta, nt0, red, sx, sh, a.trace, TS_MEL, pick)) return;
     const int nt = nt0 + wv, n = nt * 16 + i, t0 = it * a.r;
     if (nt >= a.nta || n >= a.B || done) return;
 #pragma unroll
@@ -302,26 +372,38 @@ __global__ __launch_bounds__(512) void taco_mel_kernel(TfMelK a) {
         if (t0 + j < a.max_steps) a.mel_out[((size_t)n * a.M + m) * a.max_steps + t0 + j] = sx[q];
       }
     }
+    tf_mark_end(a.trace, TS_MEL, 4, pick);
     return;
   }
   if (bx < a.n_mel + 16) {
     const int mt = bx - a.n_mel;
-    if (!fm_gemm<NT, 8, 8, 4, 1>(a.w_fc1, mt, a.x2, a.x2, a.nta, nt0, red, sx, sh)) return;
+    const bool pick = mt == 3 && blockIdx.y == 0;
+    tf_mark(a.trace, TS_MEL_FC1, 0, pick);
+    if (!fm_gemm<NT, 8, 8, 4, 1>(a.w_fc1, mt, a.x2, a.x2, a.nta, nt0, red, sx, sh, a.trace, TS_MEL_FC1, pick)) return;
     const int nt = nt0 + wv, n = nt * 16 + i, row0 = mt * 16 + du * 4;
     if (nt >= a.nta || done) return;
     const float4 bq = *reinterpret_cast<const float4*>(a.b_fc1 + row0);
     float v[4] = {sx[0] + bq.x, sx[1] + bq.y, sx[2] + bq.z, sx[3] + bq.w};
     relu_drop_quad(a.drop, a.flags, it, a.B, n < a.B ? n : a.B - 1, row0, v);
     reinterpret_cast<float4*>(a.p1)[((size_t)mt * a.nta + nt) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+    tf_mark_end(a.trace, TS_MEL_FC1, 4, pick);
     return;
   }
-  // stop tile: one live row (row 0) over K = [x2 | context]
-  if (!fm_gemm<NT, 16, 8, 4, 1>(a.w_stop, 0, a.x2, a.ctx, a.nta, nt0, red, sx, sh)) return;
+  if (bx > a.n_mel + 16) {
+    fm_hh_job<NT>(a.hh, bx - (a.n_mel + 17), nt0, a.nta, done, red);
+    return;
+  }
+  // stop tile: one live row (row 0) over K = x2; the context half of the logit comes from the rnn_input launch
+  const bool pickS = blockIdx.y == 0;
+  tf_mark(a.trace, TS_MEL_STOP, 0, pickS);
+  const int ntS = (nt0 + (wv < NT ? wv : 0) < a.nta) ? nt0 + (wv < NT ? wv : 0) : a.nta - 1;
+  const float spart = a.stop_part[ntS * 16 + i];
+  if (!fm_gemm<NT, 8, 8, 4, 1>(a.w_stop, 0, a.x2, a.x2, a.nta, nt0, red, sx, sh, a.trace, TS_MEL_STOP, pickS)) return;
   const int nt = nt0 + wv, n = nt * 16 + i;
   if (nt >= a.nta || done) return;
   int below = 0;
   if (du == 0 && n < a.B) {
-    const float sgm = 1.0f / (1.0f + expf(-(sx[0] + a.b_stop[0])));
+    const float sgm = 1.0f / (1.0f + expf(-((sx[0] + spart) + a.b_stop[0])));
     a.stop_out[n] = sgm;
     below = !(sgm * 10.f > a.min_stop_token);  // (stop * 10 > min_stop_token).all()
   }
@@ -339,6 +421,7 @@ __global__ __launch_bounds__(512) void taco_mel_kernel(TfMelK a) {
       a.flags[TF_ARRIVE] = 0; a.flags[TF_NOTREADY] = 0;       // visible to the next iteration (kernel boundary)
     }
   }
+  tf_mark_end(a.trace, TS_MEL_STOP, 4, pickS);
 }
 
 // p1 of iteration 0: the <GO> frame is all zeros (tacotron.py:261), so fc1's output is relu(b1), then dropout(it = 0)

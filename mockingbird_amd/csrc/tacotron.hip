@@ -43,9 +43,15 @@ struct LsaK {
   const float* Mt;   // [Kl][D]  M = L . conv_w   (location features -> processed location in one 31-tap conv)
   const float* c0;   // [D]      L . conv_b
   const float* Wt;   // [D(k)][D(d)] W^T
+  // the same operands as 16-byte rows per thread (one dwordx4 load where the first generation issued four dword loads:
+  // the attention launch was bound by the vector-memory INSTRUCTION count, 118 per lane, profiles/r02_taco_trace_v1.json):
+  const float4* Wq4;   // [4 quarters][8][D]: W[d][32 q + 4 k4 .. +3]
+  const float4* Mq4;   // [8][D]: M[d][4 j4 .. +3] (taps padded to 32 with zeros)
+  const float4* mpq4;  // [B][4 quarters][TJ/4][D]: mem_proj[b][q TQ + 4 j4 .. +3][d], built per decode call (lsa_pack_memproj_kernel)
   // fast decoder loop (taco_fast.h): query / context are FM buffers with fm_nta column tiles (0: plain [B][D] / [B][P]),
   // and the iteration index is iter + *iter_base (device word, bumped once per graph replay)
   int fm_nta; const int* iter_base;
+  unsigned long long* trace;  // diagnostics (taco_fast.h tf_mark)
 };
 __device__ __forceinline__ size_t lsa_qidx(const LsaK& a, int b, int k) { return a.fm_nta ? fm_index(a.fm_nta, b, k) : (size_t)b * a.D + k; }
 // float4 slot of context columns [p, p+4) of utterance b (p % 4 == 0)
@@ -210,6 +216,8 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
   const int TQ = (T + 3) >> 2, t0 = tq * TQ;  // this thread's positions [t0, t0 + TQ)
   int skip = 0;
   if (a.skip_flag) skip = *a.skip_flag;
+  const bool pick = b == 5 && pg == 1;
+  tf_mark(a.trace, TS_LSA, 0, pick);
 
   // ---- phase 0: every global load ----
   const float qv = (tid < D) ? a.query[lsa_qidx(a, b, tid)] : 0.f;          // fresh (attention GRU output)
@@ -221,19 +229,16 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
     const int i2 = tid + 512 * m, t = i2 - half;
     cpre[m] = (i2 < T + 2 * half && t >= 0 && t < T) ? cg[t] : 0.f;
   }
-  float wq[32];   // W^T[k][d] for k in this thread's quarter: coalesced over d
+  constexpr int J4 = TJ / 4;
+  float4 wq4[8];  // W[d][k] for k in this thread's quarter
 #pragma unroll
-  for (int k = 0; k < 32; ++k) wq[k] = a.Wt[(size_t)(tq * 32 + k) * D + d];
-  float mrow[KL];  // folded tap matrix column of this d
+  for (int k4 = 0; k4 < 8; ++k4) wq4[k4] = a.Wq4[(size_t)(tq * 8 + k4) * D + d];
+  float4 mq4[8];  // folded tap matrix row of this d
 #pragma unroll
-  for (int j = 0; j < KL; ++j) mrow[j] = (j < a.Kl) ? a.Mt[(size_t)j * D + d] : 0.f;
-  const float* mp = a.mem_proj + (size_t)b * T * D;
-  float mpv[TJ];
+  for (int j4 = 0; j4 < 8; ++j4) mq4[j4] = a.Mq4[(size_t)j4 * D + d];
+  float4 mp4[J4];  // processed memory of this thread's positions
 #pragma unroll
-  for (int j = 0; j < TJ; ++j) {
-    const int t = t0 + j;
-    mpv[j] = (j < TQ && t < T) ? mp[(size_t)t * D + d] : 0.f;
-  }
+  for (int j4 = 0; j4 < J4; ++j4) mp4[j4] = a.mpq4[(((size_t)b * 4 + tq) * J4 + j4) * D + d];
   const float vd = a.vw[d], wb = a.Wb[d], c0d = a.c0[d];
   // staging
   if (tid < D) s_q[tid] = qv;
@@ -242,22 +247,18 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
     const int i2 = tid + 512 * m;
     if (i2 < TMAX + 64) s_cum[i2] = cpre[m];
   }
+  tf_mark(a.trace, TS_LSA, 1, pick);
   __syncthreads();  // B1
+  tf_mark(a.trace, TS_LSA, 2, pick);
   // ---- phase 1: processed query partials (lsa.py:25) ----
   {
     float acc = 0.f;
 #pragma unroll
-    for (int k = 0; k < 32; ++k) acc += wq[k] * s_q[tq * 32 + k];
+    for (int k4 = 0; k4 < 8; ++k4) {
+      const float4 q4 = *reinterpret_cast<const float4*>(&s_q[tq * 32 + k4 * 4]);  // same address for the whole wave: broadcast
+      acc += wq4[k4].x * q4.x; acc += wq4[k4].y * q4.y; acc += wq4[k4].z * q4.z; acc += wq4[k4].w * q4.w;
+    }
     s_pq[tq][d] = acc;
-  }
-  // context rows (stable data): requested now, consumed after the softmax
-  const int p0 = pg * PW;
-  const float* mem = a.memory + (size_t)b * T * P + p0 + lane * 4;
-  float4 memv[TM];
-#pragma unroll
-  for (int j = 0; j < TM; ++j) {
-    const int t = wave + 8 * j;
-    memv[j] = (t < T) ? *reinterpret_cast<const float4*>(mem + (size_t)t * P) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   // chars of this thread's softmax positions (mask), requested early as well
   int chv[(TMAX + 63) / 64];
@@ -267,25 +268,65 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
     chv[m] = (t < T) ? a.chars[(size_t)b * T + t] : 0;
   }
   __syncthreads();  // B2
+  tf_mark(a.trace, TS_LSA, 3, pick);
   const float pqd = ((s_pq[0][d] + s_pq[1][d]) + (s_pq[2][d] + s_pq[3][d])) + wb;
   // ---- phase 2+3: location term from a sliding register window, energies, reduction over d ----
   {
-    float win[TJ + KL - 1];
+    // Plain v_fma_f32 runs at half the packed rate on this chip (16 of 32 lanes' worth per SIMD clock): the 31-tap
+    // location conv -- 992 FMAs per thread, 60 % of the launch's issue slots -- runs as v_pk_fma_f32 on PAIRS of
+    // adjacent positions.  A pair (j, j+1) needs (win[j+jj], win[j+jj+1]) as one aligned register pair for every
+    // tap jj, so the window is kept twice: pairs starting at even and at odd offsets.  Same FMAs, same order per
+    // position as the scalar form.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    constexpr int NWP = (TJ + KL + 1) / 2;
+    f32x2 winE[NWP], winO[NWP];
+    {
+      float wtmp[2 * NWP + 1];
 #pragma unroll
-    for (int m = 0; m < TJ + KL - 1; ++m) win[m] = s_cum[t0 + m < TMAX + 64 ? t0 + m : 0];
+      for (int m = 0; m < 2 * NWP + 1; ++m) wtmp[m] = s_cum[t0 + m < TMAX + 64 ? t0 + m : 0];
 #pragma unroll
-    for (int j = 0; j < TJ; ++j) {
-      float pl = c0d;
+      for (int k = 0; k < NWP; ++k) { winE[k] = f32x2{wtmp[2 * k], wtmp[2 * k + 1]}; winO[k] = f32x2{wtmp[2 * k + 1], wtmp[2 * k + 2]}; }
+    }
 #pragma unroll
-      for (int jj = 0; jj < KL; ++jj) pl += mrow[jj] * win[j + jj];
-      const float x = (pqd + mpv[j]) + pl;
-      const float th = 1.f - 2.f / (__expf(2.f * x) + 1.f);
-      // reduction over d: 16-lane DPP row sums (4 VALU ops), the 8 row partials of a position meet in the softmax
-      const float e = row16_sum(vd * th);
-      if ((lane & 15) == 0 && j < TQ && t0 + j < T) s_up[t0 + j][(wave & 1) * 4 + (lane >> 4)] = e;
+    for (int jp = 0; jp < TJ / 2; ++jp) {  // positions 2 jp, 2 jp + 1
+      f32x2 pl = f32x2{c0d, c0d};
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const float mg[4] = {mq4[g].x, mq4[g].y, mq4[g].z, mq4[g].w};
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const int jj = g * 4 + cc, idx = 2 * jp + jj;
+          if (jj < KL) {
+            const f32x2 w2 = (idx & 1) ? winO[(idx - 1) / 2] : winE[idx / 2];
+            pl = f32x2{mg[cc], mg[cc]} * w2 + pl;
+          }
+        }
+      }
+      const float4 mq = mp4[jp / 2];
+      const float mpu[2] = {(jp & 1) ? mq.z : mq.x, (jp & 1) ? mq.w : mq.y};
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int j = 2 * jp + u;
+        const float x = (pqd + mpu[u]) + pl[u];
+        const float th = 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * x) + 1.f);  // tanh, 1 ulp reciprocal
+        // reduction over d: 16-lane DPP row sums (4 VALU ops), the 8 row partials of a position meet in the softmax
+        const float e = row16_sum(vd * th);
+        if ((lane & 15) == 0 && j < TQ && t0 + j < T) s_up[t0 + j][(wave & 1) * 4 + (lane >> 4)] = e;
+      }
     }
   }
   __syncthreads();  // B3
+  tf_mark(a.trace, TS_LSA, 5, pick);
+  // context rows (stable data): requested now -- their 128 KB per workgroup arrive while wave 0 runs the softmax; issued at
+  // the top they held 64 registers through the energy phase and queued in front of everything else
+  const int p0 = pg * PW;
+  const float* mem = a.memory + (size_t)b * T * P + p0 + lane * 4;
+  float4 memv[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int t = wave + 8 * j;
+    memv[j] = (t < T) ? *reinterpret_cast<const float4*>(mem + (size_t)t * P) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   // ---- phase 4: mask, softmax over T (lsa.py:34-38) by wave 0, cumulative update ----
   if (wave == 0) {
     float uv[(TMAX + 63) / 64];
@@ -326,6 +367,7 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
     }
   }
   __syncthreads();  // B4
+  tf_mark(a.trace, TS_LSA, 6, pick);
   // ---- phase 5: context = scores @ encoder_seq (tacotron.py:104), this group's 256 columns ----
   {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -338,6 +380,7 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
     s_part[wave][lane] = acc;
   }
   __syncthreads();  // B5
+  tf_mark(a.trace, TS_LSA, 7, pick);
   if (wave == 0 && !skip) {
     float4 r = s_part[0][lane];
 #pragma unroll
@@ -347,11 +390,42 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
     }
     *lsa_ctx4(a, b, p0 + lane * 4) = r;
   }
+  tf_mark_end(a.trace, TS_LSA, 8, pick);
+}
+
+// mem_proj [B][T][D] -> quads of 4 consecutive positions per (utterance, quarter of the text, d): what one thread of
+// lsa_fast_body consumes, as 16-byte rows.  Once per decode call.
+__global__ void lsa_pack_memproj_kernel(const float* __restrict__ mp, float4* __restrict__ out, int B, int T, int J4) {
+  constexpr int D = 128;
+  const int TQ = (T + 3) >> 2;
+  const size_t n = (size_t)B * 4 * J4 * D;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D);
+    const int j4 = (int)((i / D) % J4), tq = (int)((i / D / J4) % 4), b = (int)(i / D / J4 / 4);
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j4 * 4 + u, t = tq * TQ + j;
+      v[u] = (j < TQ && t < T) ? mp[((size_t)b * T + t) * D + d] : 0.f;
+    }
+    out[i] = make_float4(v[0], v[1], v[2], v[3]);
+  }
 }
 
 template <int TJ>
 __global__ __launch_bounds__(512) void lsa_fast_kernel(LsaK a) {
   lsa_fast_body<TJ>(a, blockIdx.x, blockIdx.y);
+}
+// The attention launch occupies B * psplit of the 256 CUs for ~10 us of dependent latencies.  The hidden half of the
+// decoder's SECOND LSTM, W_hh2 . h2 (16.8 MB of weights), depends only on the previous iteration's state: it rides here
+// as extra workgroups on the idle CUs (the attention workgroups come first in dispatch order) and leaves the chain.
+template <int TJ, int NT>
+__global__ __launch_bounds__(512) void lsa_hh_kernel(LsaK a, TfHhK hh, int n_lsa, int B, int gy, int nta) {
+  const int id = blockIdx.x;
+  if (id < n_lsa) { lsa_fast_body<TJ>(a, id % B, id / B); return; }
+  __shared__ __attribute__((aligned(16))) float red[FmRed<NT, 1>::floats];
+  const int j = id - n_lsa, mt = j / gy;
+  fm_hh_job<NT>(hh, mt, (j - mt * gy) * NT, nta, a.skip_flag ? *a.skip_flag : 0, red);
 }
 
 // ---------------------------------------------------------------- finalize
@@ -696,6 +770,7 @@ struct mb_taco {
   DevBuf pre1_w, pre1_b, pre2_w, pre2_b;
   DevBuf lsa_conv_w, lsa_conv_b, lsa_L, lsa_W, lsa_Wb, lsa_v;
   DevBuf lsa_Mt, lsa_c0, lsa_Wt;  // folded / transposed copies for lsa_fast_kernel
+  DevBuf lsa_Wq4, lsa_Mq4;        // ... as 16-byte rows per thread
   DevBuf attn_w, attn_bih, attn_bhh;
   DevBuf rin_w, rin_b;
   DevBuf l1_w, l1_bih, l1_bhh, l2_w, l2_bih, l2_bhh;
@@ -713,13 +788,16 @@ struct mb_taco {
   DevBuf gst_qconst, gst_WqS, gst_K, gst_V;
   // fast decoder loop (taco_fast.h), packed when the checkpoint has the production dims
   bool fast = false;
-  DevBuf f_gru_w, f_pre_w, f_bih4, f_bhh4, f_l1_b4, f_l2_b4, f_fc1_w, f_stop_w;
+  DevBuf f_gru_w, f_pre_w, f_bih4, f_bhh4, f_l1_b4, f_l2_b4, f_fc1_w, f_stop_w, f_stopc_w, f_l1_hh, f_l2_hh;
+  hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // loop timing (mb_taco_last_loop_ms)
+  int last_iters = 0; bool timed = false;
   // captured iterations of the fast loop: reused while the call arguments do not change (handle is single-threaded)
   struct GraphKey { const void *mem, *memp, *chars, *drop, *mel, *attn, *ws; int B, T, max_steps, G; float mst; } gkey = {};
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   int* h_flags = nullptr;  // pinned: [2][8] flag snapshots
   hipEvent_t ev_flags[2] = {nullptr, nullptr};
+  unsigned long long* d_trace = nullptr;  // MBHIP_TACO_TRACE
   hipStream_t loop_stream = nullptr;  // the loop runs (and is captured) on its own stream: the caller's may be the
   hipEvent_t ev_in = nullptr;         // legacy default stream, which cannot be captured
   void drop_graph() {
@@ -907,6 +985,18 @@ extern "C" int mb_taco_create(const mb_taco_config* cfg, const float* const* hw,
       for (int k2 = 0; k2 < D; ++k2) Wt[(size_t)k2 * D + dd] = Ww[(size_t)dd * D + k2];
     }
     RC(t->lsa_Mt.upload(Mt.data(), Mt.size())); RC(t->lsa_c0.upload(c0.data(), c0.size())); RC(t->lsa_Wt.upload(Wt.data(), Wt.size()));
+    if (D % 32 == 0 && Kl <= 32) {  // rows of 4: Wq4[(q*8 + k4)*D + d] = W[d][q*(D/4) + 4 k4 ..], Mq4[j4*D + d] = M[d][4 j4 ..]
+      const int KQ = D / 4;  // k range of a quarter (32 for D = 128)
+      std::vector<float> Wq((size_t)D * D, 0.f), Mq((size_t)8 * D * 4, 0.f);
+      for (int dd = 0; dd < D; ++dd) {
+        for (int k2 = 0; k2 < D; ++k2) {
+          const int q = k2 / KQ, k4 = (k2 % KQ) / 4, c4 = k2 % 4;
+          Wq[(((size_t)q * (KQ / 4) + k4) * D + dd) * 4 + c4] = Ww[(size_t)dd * D + k2];
+        }
+        for (int j = 0; j < Kl; ++j) Mq[((size_t)(j / 4) * D + dd) * 4 + (j % 4)] = Mt[(size_t)j * D + dd];
+      }
+      RC(t->lsa_Wq4.upload(Wq.data(), Wq.size())); RC(t->lsa_Mq4.upload(Mq.data(), Mq.size()));
+    }
   }
   ix += 6;
   // attn_rnn GRUCell(P + 2D -> D)
@@ -982,10 +1072,22 @@ extern "C" int mb_taco_create(const mb_taco_config* cfg, const float* const* hw,
       }
       pack_rowtile(wf.data(), 2 * D, H, 4, &packed); RC(t->f_fc1_w.upload(packed.data(), packed.size()));
     }
-    pack_rowtile(stop_w, 1, H + P, 4, &packed); RC(t->f_stop_w.upload(packed.data(), packed.size()));  // one live row
+    // stop_proj as two one-live-row tiles: x half (K = H) for the mel launch, context half (K = [P | 0 x D]) for rnn_input's
+    pack_rowtile(stop_w, 1, H, 4, &packed); RC(t->f_stop_w.upload(packed.data(), packed.size()));
+    {
+      std::vector<float> sc((size_t)P + D, 0.f);
+      memcpy(sc.data(), stop_w + H, sizeof(float) * P);
+      pack_rowtile(sc.data(), 1, P + D, 4, &packed); RC(t->f_stopc_w.upload(packed.data(), packed.size()));
+    }
+    for (int l = 0; l < 2; ++l) {  // hidden halves W_hh in LSTM tile order (K = H)
+      cell_rows(hw[16 + 4 * l + 1], H, H, hw[16 + 4 * l + 1], 0, H, 4, &rows);
+      pack_rowtile(rows.data(), 4 * H, H, 4, &packed);
+      RC((l ? t->f_l2_hh : t->f_l1_hh).upload(packed.data(), packed.size()));
+    }
     if (!rc && (hipHostMalloc((void**)&t->h_flags, sizeof(int) * 16) != hipSuccess ||
                 hipStreamCreateWithFlags(&t->loop_stream, hipStreamNonBlocking) != hipSuccess ||
                 hipEventCreateWithFlags(&t->ev_in, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreate(&t->ev_t0) != hipSuccess || hipEventCreate(&t->ev_t1) != hipSuccess ||
                 hipEventCreateWithFlags(&t->ev_flags[0], hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&t->ev_flags[1], hipEventDisableTiming) != hipSuccess)) {
       set_error("taco_create: pinned flag buffer / events");
@@ -1023,12 +1125,15 @@ extern "C" void mb_taco_destroy(mb_taco* t) {
                   &t->lsa_Wb, &t->lsa_v, &t->attn_w, &t->attn_bih, &t->attn_bhh, &t->rin_w, &t->rin_b, &t->l1_w,
                   &t->l1_bih, &t->l1_bhh, &t->l2_w, &t->l2_bih, &t->l2_bhh, &t->l1_wx, &t->l1_whh, &t->l2_wx, &t->l2_whh, &t->mel_w, &t->stop_w, &t->stop_b,
                   &t->emb, &t->enc_proj_full, &t->lsa_Mt, &t->lsa_c0, &t->lsa_Wt, &t->gst_qconst, &t->gst_WqS, &t->gst_K, &t->gst_V,
-                  &t->f_gru_w, &t->f_pre_w, &t->f_bih4, &t->f_bhh4, &t->f_l1_b4, &t->f_l2_b4, &t->f_fc1_w, &t->f_stop_w};
+                  &t->f_gru_w, &t->f_pre_w, &t->f_bih4, &t->f_bhh4, &t->f_l1_b4, &t->f_l2_b4, &t->f_fc1_w, &t->f_stop_w, &t->f_stopc_w, &t->f_l1_hh, &t->f_l2_hh, &t->lsa_Wq4, &t->lsa_Mq4};
   for (DevBuf* b : bs) b->release();
   t->drop_graph();
   if (t->h_flags) (void)hipHostFree(t->h_flags);
   for (int e = 0; e < 2; ++e) if (t->ev_flags[e]) (void)hipEventDestroy(t->ev_flags[e]);
+  if (t->d_trace) (void)hipFree(t->d_trace);
   if (t->ev_in) (void)hipEventDestroy(t->ev_in);
+  if (t->ev_t0) (void)hipEventDestroy(t->ev_t0);
+  if (t->ev_t1) (void)hipEventDestroy(t->ev_t1);
   if (t->loop_stream) (void)hipStreamDestroy(t->loop_stream);
   t->post.release(); t->post_proj.release(); t->enc.release();
   t->enc_fc1.release(); t->enc_fc2.release(); t->enc_proj.release();
@@ -1039,8 +1144,9 @@ namespace {
 struct TacoLayout {
   float *p1, *p2, *attn_h, *context, *x, *x1, *x2, *h1, *c1, *h2, *c2, *melstep, *cumulative, *stop;
   // fast loop (taco_fast.h): FM activations, CM cell state / gate pre-activations
-  float *f_p1, *f_p2, *f_ah, *f_ctx, *f_x, *f_x1, *f_x2, *f_h1, *f_h2, *f_c1, *f_c2, *f_xpre, *f_hpre;
+  float *f_p1, *f_p2, *f_ah, *f_ctx, *f_x, *f_x1, *f_x2, *f_h1, *f_h2, *f_c1, *f_c2, *f_xpre, *f_hpre, *f_hp1, *f_hp2, *f_stop_part;
   size_t f_state_bytes;  // the region above, zeroed per call
+  float* mpq4;  // mem_proj as position quads for lsa_fast_body: [B][4][TJ/4][D] float4 = B * 4 TJ * D floats, TJ = 32 | 48
   int* flags;  // [0] done, [1] n_frames, [2] arrive, [3] utterances below the stop threshold, [4] iteration base, [6..7] seed
   // postnet
   float *melc, *linc;
@@ -1066,7 +1172,9 @@ static void taco_layout(const mb_taco* t, int B, int T, int max_steps, void* bas
     L->f_p2 = ar.take<float>(fm_floats(2 * D, nta)); L->f_ah = ar.take<float>(fm_floats(D, nta));
     L->f_ctx = ar.take<float>(fm_floats(P, nta));
     L->f_x = ar.take<float>(fm_floats(H, nta)); L->f_x1 = ar.take<float>(fm_floats(H, nta)); L->f_x2 = ar.take<float>(fm_floats(H, nta));
-    L->f_h1 = ar.take<float>(2 * fm_floats(H, nta)); L->f_h2 = ar.take<float>(2 * fm_floats(H, nta));
+    L->f_h1 = ar.take<float>(fm_floats(H, nta)); L->f_h2 = ar.take<float>(fm_floats(H, nta));
+    L->f_hp1 = ar.take<float>(4 * cm_items(H, nta)); L->f_hp2 = ar.take<float>(4 * cm_items(H, nta));
+    L->f_stop_part = ar.take<float>((size_t)nta * 16);
     L->f_c1 = ar.take<float>(cm_items(H, nta)); L->f_c2 = ar.take<float>(cm_items(H, nta));
     L->f_xpre = ar.take<float>(4 * cm_items(D, nta)); L->f_hpre = ar.take<float>(4 * cm_items(D, nta));
     L->f_state_bytes = ar.off - start;
@@ -1074,6 +1182,7 @@ static void taco_layout(const mb_taco* t, int B, int T, int max_steps, void* bas
   L->melstep = ar.take<float>((size_t)B * c.r * M);
   L->cumulative = ar.take<float>((size_t)2 * B * T);
   L->stop = ar.take<float>(B);
+  L->mpq4 = ar.take<float>(T <= 192 ? (size_t)B * 4 * (T <= 128 ? 32 : 48) * 128 : 1);
   L->flags = ar.take<int>(16);
   L->melc = ar.take<float>(B * M * F);
   L->linc = ar.take<float>(B * M * F);
@@ -1118,6 +1227,10 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
   dk.thresh = drop_enabled ? (unsigned)std::min(4294967295.0, (double)c.dropout * 4294967296.0) : 0u;
   dk.scale = drop_enabled ? 1.f / (1.f - c.dropout) : 1.f; dk.enabled = drop_enabled ? 1 : 0;
   int* flags = L.flags;
+  const char* trace_path = getenv("MBHIP_TACO_TRACE");
+  if (trace_path && !t->d_trace) MB_HIP(hipMalloc((void**)&t->d_trace, sizeof(unsigned long long) * 16 * TS_SLOTS));
+  unsigned long long* tr = trace_path ? t->d_trace : nullptr;
+  if (tr) MB_HIP(hipMemsetAsync(tr, 0, sizeof(unsigned long long) * 16 * TS_SLOTS, s));
   MB_HIP(hipMemsetAsync(L.f_p1, 0, L.f_state_bytes, s));
   MB_HIP(hipMemcpyAsync(flags + TF_SEED, &seed, sizeof(seed), hipMemcpyHostToDevice, s));  // pageable source: staged before return
   {
@@ -1131,16 +1244,15 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
     rk.w_rin = t->rin_w.p; rk.b_rin = t->rin_b.p; rk.w_pre = t->f_pre_w.p;
     rk.bih4 = reinterpret_cast<const float4*>(t->f_bih4.p); rk.bhh4 = reinterpret_cast<const float4*>(t->f_bhh4.p);
     rk.ctx = L.f_ctx; rk.ah = L.f_ah; rk.x = L.f_x; rk.xpre = reinterpret_cast<float4*>(L.f_xpre); rk.hpre = reinterpret_cast<float4*>(L.f_hpre);
-    rk.nta = nta; rk.n_rin = H / 16; rk.flags = flags;
+    rk.nta = nta; rk.n_rin = H / 16; rk.flags = flags; rk.trace = nullptr;
+    rk.w_stopc = t->f_stopc_w.p; rk.stop_part = L.f_stop_part;
     if (nta >= 2) hipLaunchKernelGGL(taco_rin_kernel<2>, dim3(H / 16 + D / 4, cdiv(nta, 2)), dim3(512), 0, s, rk);
     else hipLaunchKernelGGL(taco_rin_kernel<1>, dim3(H / 16 + D / 4, nta), dim3(512), 0, s, rk);
   }
   MB_HIP(hipGetLastError());
 
   auto iteration = [&](int pp, int it_off) -> int {
-    const size_t hsz = fm_floats(H, nta);
-    float* h1p = L.f_h1 + (size_t)pp * hsz; float* h1n = L.f_h1 + (size_t)(pp ^ 1) * hsz;
-    float* h2p = L.f_h2 + (size_t)pp * hsz; float* h2n = L.f_h2 + (size_t)(pp ^ 1) * hsz;
+    // (the LSTM state needs no ping-pong: h is read only by the hh jobs, which have finished before the next LSTM launch)
     const dim3 blk(512);
     const int gy = nta >= 2 ? cdiv(nta, 2) : nta;
 #define TF_LAUNCH(KERNEL, GX, ARG)                                                     \
@@ -1151,12 +1263,12 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
     // 1. prenet layer 2 (layer 1 was left by the previous iteration's mel launch / the prologue)
     TfFcK fk;
     fk.w = t->pre2_w.p; fk.bias = t->pre2_b.p; fk.xin = L.f_p1; fk.yout = L.f_p2; fk.nta = nta; fk.B = B; fk.it_off = it_off;
-    fk.flags = flags; fk.drop = dk; fk.drop.layer = 1;
+    fk.flags = flags; fk.drop = dk; fk.drop.layer = 1; fk.trace = tr;
     TF_LAUNCH(taco_fc2_kernel, 2 * D / 16, fk);
     // 2. attention GRU on the prenet columns
     TfGruK gk;
     gk.w = t->f_gru_w.p; gk.xin = L.f_p2; gk.xpre = reinterpret_cast<const float4*>(L.f_xpre);
-    gk.hpre = reinterpret_cast<const float4*>(L.f_hpre); gk.ah = L.f_ah; gk.nta = nta; gk.B = B; gk.flags = flags;
+    gk.hpre = reinterpret_cast<const float4*>(L.f_hpre); gk.ah = L.f_ah; gk.nta = nta; gk.B = B; gk.flags = flags; gk.trace = tr;
     TF_LAUNCH(taco_gru_kernel, D / 4, gk);
     // 3. location-sensitive attention + context
     LsaK lk;
@@ -1165,38 +1277,57 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
     lk.conv_w = t->lsa_conv_w.p; lk.conv_b = t->lsa_conv_b.p; lk.Lw = t->lsa_L.p; lk.Ww = t->lsa_W.p; lk.Wb = t->lsa_Wb.p;
     lk.vw = t->lsa_v.p; lk.context = L.f_ctx; lk.attn_out = d_attn; lk.T = T; lk.D = D; lk.P = P; lk.Fl = c.lsa_filters;
     lk.Kl = c.lsa_kernel; lk.iter = it_off; lk.n_iter_max = n_iter_max; lk.skip_flag = flags + TF_DONE;
-    lk.Mt = t->lsa_Mt.p; lk.c0 = t->lsa_c0.p; lk.Wt = t->lsa_Wt.p; lk.fm_nta = nta; lk.iter_base = flags + TF_ITER;
-    if (lsa_fast && T <= 128) hipLaunchKernelGGL(lsa_fast_kernel<32>, dim3(B, psplit), dim3(512), 0, s, lk);
-    else if (lsa_fast) hipLaunchKernelGGL(lsa_fast_kernel<48>, dim3(B, psplit), dim3(512), 0, s, lk);
-    else hipLaunchKernelGGL(lsa_kernel, dim3(B, psplit), dim3(512), lds_lsa, s, lk);
-    // 4. rnn_input beside the next iteration's attention-GRU pre-activations
+    lk.Mt = t->lsa_Mt.p; lk.c0 = t->lsa_c0.p; lk.Wt = t->lsa_Wt.p; lk.fm_nta = nta; lk.iter_base = flags + TF_ITER; lk.trace = tr;
+    lk.Wq4 = reinterpret_cast<const float4*>(t->lsa_Wq4.p); lk.Mq4 = reinterpret_cast<const float4*>(t->lsa_Mq4.p);
+    lk.mpq4 = reinterpret_cast<const float4*>(L.mpq4);
+    // ... with the hidden half of THIS iteration's second LSTM (W_hh2 . h2 of the previous iteration) on the idle CUs
+    TfHhK hh2;
+    hh2.w = t->f_l2_hh.p; hh2.h = L.f_h2; hh2.hpre = reinterpret_cast<float4*>(L.f_hp2); hh2.n_tiles = H / 4;
+    const int n_lsa = B * psplit;
+    if (lsa_fast) {
+      const dim3 g1(n_lsa + (H / 4) * gy);
+      if (T <= 128 && nta >= 2) hipLaunchKernelGGL((lsa_hh_kernel<32, 2>), g1, blk, 0, s, lk, hh2, n_lsa, B, gy, nta);
+      else if (T <= 128) hipLaunchKernelGGL((lsa_hh_kernel<32, 1>), g1, blk, 0, s, lk, hh2, n_lsa, B, gy, nta);
+      else if (nta >= 2) hipLaunchKernelGGL((lsa_hh_kernel<48, 2>), g1, blk, 0, s, lk, hh2, n_lsa, B, gy, nta);
+      else hipLaunchKernelGGL((lsa_hh_kernel<48, 1>), g1, blk, 0, s, lk, hh2, n_lsa, B, gy, nta);
+    } else {  // long texts: the general attention kernel, hidden half as its own launch in front of it
+      if (nta >= 2) hipLaunchKernelGGL(taco_hh_kernel<2>, dim3(H / 4, gy), blk, 0, s, hh2, nta, (const int*)flags);
+      else hipLaunchKernelGGL(taco_hh_kernel<1>, dim3(H / 4, gy), blk, 0, s, hh2, nta, (const int*)flags);
+      hipLaunchKernelGGL(lsa_kernel, dim3(B, psplit), dim3(512), lds_lsa, s, lk);
+    }
+    // 4. rnn_input beside the next iteration's attention-GRU pre-activations and the stop token's context half
     TfRinK rk;
     rk.w_rin = t->rin_w.p; rk.b_rin = t->rin_b.p; rk.w_pre = t->f_pre_w.p;
     rk.bih4 = reinterpret_cast<const float4*>(t->f_bih4.p); rk.bhh4 = reinterpret_cast<const float4*>(t->f_bhh4.p);
     rk.ctx = L.f_ctx; rk.ah = L.f_ah; rk.x = L.f_x; rk.xpre = reinterpret_cast<float4*>(L.f_xpre); rk.hpre = reinterpret_cast<float4*>(L.f_hpre);
-    rk.nta = nta; rk.n_rin = H / 16; rk.flags = flags;
-    TF_LAUNCH(taco_rin_kernel, H / 16 + D / 4, rk);
+    rk.nta = nta; rk.n_rin = H / 16; rk.flags = flags; rk.trace = tr;
+    rk.w_stopc = t->f_stopc_w.p; rk.stop_part = L.f_stop_part;
+    TF_LAUNCH(taco_rin_kernel, H / 16 + D / 4 + 1, rk);
     // 5./6. residual LSTMs
     TfLstmK lk1;
-    lk1.w = t->l1_w.p; lk1.b4 = reinterpret_cast<const float4*>(t->f_l1_b4.p); lk1.x = L.f_x; lk1.h_prev = h1p; lk1.h_out = h1n;
-    lk1.c = L.f_c1; lk1.x_out = L.f_x1; lk1.nta = nta; lk1.flags = flags;
+    lk1.w = t->l1_wx.p; lk1.b4 = reinterpret_cast<const float4*>(t->f_l1_b4.p); lk1.x = L.f_x; lk1.h_out = L.f_h1;
+    lk1.hpre = reinterpret_cast<const float4*>(L.f_hp1);
+    lk1.c = L.f_c1; lk1.x_out = L.f_x1; lk1.nta = nta; lk1.flags = flags; lk1.trace = tr; lk1.trace_slot = TS_LSTM1;
     TF_LAUNCH(taco_lstm_kernel, H / 4, lk1);
     TfLstmK lk2 = lk1;
-    lk2.w = t->l2_w.p; lk2.b4 = reinterpret_cast<const float4*>(t->f_l2_b4.p); lk2.x = L.f_x1; lk2.h_prev = h2p; lk2.h_out = h2n;
-    lk2.c = L.f_c2; lk2.x_out = L.f_x2;
+    lk2.w = t->l2_wx.p; lk2.b4 = reinterpret_cast<const float4*>(t->f_l2_b4.p); lk2.x = L.f_x1; lk2.h_out = L.f_h2;
+    lk2.hpre = reinterpret_cast<const float4*>(L.f_hp2);
+    lk2.c = L.f_c2; lk2.x_out = L.f_x2; lk2.trace_slot = TS_LSTM2;
     TF_LAUNCH(taco_lstm_kernel, H / 4, lk2);
     // 7. mel frames, next prenet layer 1, stop token + stop rule
     TfMelK mk;
     mk.w_mel = t->mel_w.p; mk.w_fc1 = t->f_fc1_w.p; mk.b_fc1 = t->pre1_b.p; mk.w_stop = t->f_stop_w.p; mk.b_stop = t->stop_b.p;
-    mk.x2 = L.f_x2; mk.ctx = L.f_ctx; mk.p1 = L.f_p1; mk.mel_out = d_mel; mk.stop_out = L.stop;
+    mk.x2 = L.f_x2; mk.stop_part = L.f_stop_part; mk.p1 = L.f_p1; mk.mel_out = d_mel; mk.stop_out = L.stop;
+    mk.hh.w = t->f_l1_hh.p; mk.hh.h = L.f_h1; mk.hh.hpre = reinterpret_cast<float4*>(L.f_hp1); mk.hh.n_tiles = H / 4;
     mk.nta = nta; mk.B = B; mk.n_mel = r * M / 16; mk.M = M; mk.r = r; mk.max_steps = max_steps; mk.it_off = it_off;
-    mk.min_stop_token = min_stop_token; mk.flags = flags; mk.drop = dk; mk.drop.layer = 0; mk.drop.it_add = 1;
-    TF_LAUNCH(taco_mel_kernel, r * M / 16 + 2 * D / 16 + 1, mk);
+    mk.min_stop_token = min_stop_token; mk.flags = flags; mk.drop = dk; mk.drop.layer = 0; mk.drop.it_add = 1; mk.trace = tr;
+    TF_LAUNCH(taco_mel_kernel, r * M / 16 + 2 * D / 16 + 1 + H / 4, mk);
 #undef TF_LAUNCH
     MB_HIP(hipGetLastError());
     return MB_OK;
   };
 
+  MB_HIP(hipEventRecord(t->ev_t0, s));
   int G = 16;  // iterations per graph replay (even: the LSTM state / cumulative-attention parity returns to 0)
   if (const char* ge = getenv("MBHIP_TACO_GRAPH_ITERS")) G = atoi(ge) & ~1;
   const bool use_graph = getenv("MBHIP_NO_GRAPH") == nullptr && G >= 2 && n_iter_max >= G;
@@ -1236,9 +1367,16 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
       if (t->h_flags[TF_DONE]) stopped = true;
     }
   }
+  MB_HIP(hipEventRecord(t->ev_t1, s));
   MB_HIP(hipMemcpyAsync(t->h_flags, flags, sizeof(int) * 8, hipMemcpyDeviceToHost, s));
   MB_HIP(hipStreamSynchronize(s));
   *frames_out = t->h_flags[TF_NFRAMES];
+  t->last_iters = cdiv(*frames_out, r); t->timed = true;
+  if (tr) {
+    std::vector<unsigned long long> host((size_t)16 * TS_SLOTS);
+    MB_HIP(hipMemcpy(host.data(), tr, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(trace_path, "wb")) { fwrite(host.data(), sizeof(unsigned long long), host.size(), f); fclose(f); }
+  }
   return MB_OK;
 }
 
@@ -1284,6 +1422,12 @@ extern "C" int mb_taco_decode(const mb_taco* t, const float* d_memory, const flo
       MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lsa_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lsa));
   }
 
+  if (lsa_fast) {  // processed memory as per-thread position quads (once per call)
+    const int J4 = (T <= 128 ? 32 : 48) / 4;
+    hipLaunchKernelGGL(lsa_pack_memproj_kernel, dim3(std::min(cdiv(B * 4 * J4 * 128, 256), 2048)), dim3(256), 0, s, d_memory_proj,
+                       reinterpret_cast<float4*>(L.mpq4), B, T, J4);
+    MB_HIP(hipGetLastError());
+  }
   // zero initial states (tacotron.py:219-230,261; lsa.py:15-19)
   MB_HIP(hipMemsetAsync(L.attn_h, 0, sizeof(float) * 2 * B * D, s));
   MB_HIP(hipMemsetAsync(L.context, 0, sizeof(float) * 2 * B * P, s));
@@ -1348,7 +1492,9 @@ extern "C" int mb_taco_decode(const mb_taco* t, const float* d_memory, const flo
     lk.conv_w = t->lsa_conv_w.p; lk.conv_b = t->lsa_conv_b.p; lk.Lw = t->lsa_L.p; lk.Ww = t->lsa_W.p; lk.Wb = t->lsa_Wb.p;
     lk.vw = t->lsa_v.p; lk.context = cx_n; lk.attn_out = d_attn; lk.T = T; lk.D = D; lk.P = P; lk.Fl = c.lsa_filters;
     lk.Kl = c.lsa_kernel; lk.iter = it; lk.n_iter_max = n_iter_max; lk.skip_flag = done;
-    lk.Mt = t->lsa_Mt.p; lk.c0 = t->lsa_c0.p; lk.Wt = t->lsa_Wt.p; lk.fm_nta = 0; lk.iter_base = nullptr;
+    lk.Mt = t->lsa_Mt.p; lk.c0 = t->lsa_c0.p; lk.Wt = t->lsa_Wt.p; lk.fm_nta = 0; lk.iter_base = nullptr; lk.trace = nullptr;
+    lk.Wq4 = reinterpret_cast<const float4*>(t->lsa_Wq4.p); lk.Mq4 = reinterpret_cast<const float4*>(t->lsa_Mq4.p);
+    lk.mpq4 = reinterpret_cast<const float4*>(L.mpq4);
     if (lsa_fast && T <= 128) hipLaunchKernelGGL(lsa_fast_kernel<32>, dim3(B, psplit), dim3(512), 0, s, lk);
     else if (lsa_fast) hipLaunchKernelGGL(lsa_fast_kernel<48>, dim3(B, psplit), dim3(512), 0, s, lk);
     else hipLaunchKernelGGL(lsa_kernel, dim3(B, psplit), dim3(512), lds_lsa, s, lk);
@@ -1424,6 +1570,14 @@ void enc_layout(const mb_taco* t, int B, int T, void* base, EncLayout* L) {
   L->bytes = ar.off + 256;
 }
 }  // namespace
+
+extern "C" int mb_taco_last_loop_ms(const mb_taco* t, float* ms, int* iterations) {
+  MB_REQUIRE(t && ms, "taco_last_loop_ms: null pointer");
+  if (!t->timed) { set_error("taco_last_loop_ms: no decode on the fast loop yet"); return MB_ESTATE; }
+  MB_HIP(hipEventElapsedTime(ms, t->ev_t0, t->ev_t1));
+  if (iterations) *iterations = t->last_iters;
+  return MB_OK;
+}
 
 extern "C" size_t mb_taco_encode_workspace_bytes(const mb_taco* t, int batch, int t_text) {
   if (!t || !t->cfg.has_encoder || batch <= 0 || t_text <= 0) return 0;

@@ -77,6 +77,9 @@ class TacotronDevice:
                                     _lib.ptr(attn), C.byref(nf), _lib.ptr(self._ws), self._ws.numel(), _lib.stream_ptr()),
                    "mb_taco_decode")
         F = nf.value
+        ms, its = C.c_float(), C.c_int()
+        if L.mb_taco_last_loop_ms(self._h, C.byref(ms), C.byref(its)) == 0:  # production-dims loop only
+            self.last_loop_ms, self.last_loop_iterations = ms.value, its.value
         return mel[:, :, :F], lin[:, :, :F], attn[:, :F // r]
 
     def encode(self, chars, speaker_embedding, style_idx=0, enc_masks=None, seed=None):

@@ -27,6 +27,10 @@ for name, env in (("fast", {}), ("fast_nograph", {"MBHIP_NO_GRAPH": "1"}), ("gen
             torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
         res[steps] = sorted(ts)[2]
     per_iter = (res[400] - res[40]) / 180 * 1e6
-    out[name] = {"decode400_ms": res[400] * 1e3, "decode40_ms": res[40] * 1e3, "us_per_iteration": per_iter}
+    out[name] = {"decode400_ms": res[400] * 1e3, "decode40_ms": res[40] * 1e3, "us_per_iteration_incl_postnet_growth": per_iter}
+    if name != "general":  # HIP events around the loop itself (mb_taco_last_loop_ms)
+        dev.decode(mem, memp, chars, 400, 11, seed=1)
+        out[name]["loop_ms"] = dev.last_loop_ms
+        out[name]["loop_us_per_iteration"] = dev.last_loop_ms * 1e3 / dev.last_loop_iterations
     print(name, out[name], flush=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "taco_time.json"), "w"), indent=1)
