@@ -227,6 +227,26 @@ __global__ __launch_bounds__(512) void taco_gru_kernel(TfGruK a) {
   tf_mark_end(a.trace, TS_GRU, 4, pick);
 }
 
+// ------------------------------------------------------------------------------------------------ LSTM hidden halves
+// hh job: hpre = W_hh . h (LSTM tile order: the 16 rows of tile mt are the 4 gates of units 4 mt .. 4 mt + 3), one
+// CM4 quad per (unit, column).  Rides as extra workgroups behind the jobs of a latency-bound launch.
+struct TfHhK { const float* w; const float* h; float4* hpre; int n_tiles, tile0; };  // row tiles [tile0, tile0 + n_tiles)
+template <int NT>
+__device__ __forceinline__ void fm_hh_job(const TfHhK& a, const int mt_local, const int nt0, const int nta, const int done, float* red) {
+  const int mt = a.tile0 + mt_local;
+  float sx[4], sh[4];
+  if (!fm_gemm<NT, 8, 8, 4, 1>(a.w, mt, a.h, a.h, nta, nt0, red, sx, sh)) return;
+  const int lane = threadIdx.x & 63, nt = nt0 + (threadIdx.x >> 6);
+  if (nt >= nta || done) return;
+  a.hpre[((size_t)mt * nta + nt) * 64 + lane] = make_float4(sx[0], sx[1], sx[2], sx[3]);
+}
+// stand-alone form (general LSA kernel in use, or diagnostics)
+template <int NT>
+__global__ __launch_bounds__(512) void taco_hh_kernel(TfHhK a, int nta, const int* flags) {
+  __shared__ __attribute__((aligned(16))) float red[FmRed<NT, 1>::floats];
+  fm_hh_job<NT>(a, blockIdx.x, blockIdx.y * NT, nta, flags[TF_DONE], red);
+}
+
 // ------------------------------------------------------------------------------------------------ rnn_input (+ GRU pre)
 // job 0 (blockIdx.x < n_rin): x = rnn_input([context, attn_hidden])  (tacotron.py:108-109) -> FM
 // job 1: the NEXT iteration's attention-GRU pre-activations from the same operands:
@@ -236,6 +256,7 @@ __global__ __launch_bounds__(512) void taco_gru_kernel(TfGruK a) {
 struct TfRinK {
   const float* w_rin; const float* b_rin; const float* w_pre; const float4* bih4; const float4* bhh4;
   const float* w_stopc; float* stop_part;  // job 2: stop_proj's context columns . context -> [nta*16] partial logits
+  TfHhK hh;  // job 3: second half of the row tiles of W_hh1 . h1 (the first half rode in the previous mel launch)
   const float* ctx; const float* ah; float* x; float4* xpre; float4* hpre;
   int nta, n_rin; const int* flags; unsigned long long* trace;
 };
@@ -260,7 +281,8 @@ __global__ __launch_bounds__(512) void taco_rin_kernel(TfRinK a) {
     return;
   }
   const int mt = blockIdx.x - a.n_rin;
-  if (mt >= 32) {  // stop token, context half
+  if (mt > 32) { fm_hh_job<NT>(a.hh, mt - 33, nt0, a.nta, done, red); return; }
+  if (mt == 32) {  // stop token, context half
     if (!fm_gemm<NT, 9, 8, 4, 1>(a.w_stopc, 0, a.ctx, a.ah, a.nta, nt0, red, sx, sh)) return;
     const int nt = nt0 + wv;
     if (nt >= a.nta || done || du != 0) return;
@@ -274,25 +296,6 @@ __global__ __launch_bounds__(512) void taco_rin_kernel(TfRinK a) {
   const size_t cm = ((size_t)mt * a.nta + nt) * 64 + lane;
   a.xpre[cm] = make_float4(sx[0] + bi.x, sx[1] + bi.y, sx[2] + bi.z, 0.f);
   a.hpre[cm] = make_float4(sh[0] + bh.x, sh[1] + bh.y, sh[2] + bh.z, 0.f);
-}
-
-// ------------------------------------------------------------------------------------------------ LSTM hidden halves
-// hh job: hpre = W_hh . h (LSTM tile order: the 16 rows of tile mt are the 4 gates of units 4 mt .. 4 mt + 3), one
-// CM4 quad per (unit, column).  Rides as extra workgroups behind the jobs of a latency-bound launch.
-struct TfHhK { const float* w; const float* h; float4* hpre; int n_tiles; };
-template <int NT>
-__device__ __forceinline__ void fm_hh_job(const TfHhK& a, const int mt, const int nt0, const int nta, const int done, float* red) {
-  float sx[4], sh[4];
-  if (!fm_gemm<NT, 8, 8, 4, 1>(a.w, mt, a.h, a.h, nta, nt0, red, sx, sh)) return;
-  const int lane = threadIdx.x & 63, nt = nt0 + (threadIdx.x >> 6);
-  if (nt >= nta || done) return;
-  a.hpre[((size_t)mt * nta + nt) * 64 + lane] = make_float4(sx[0], sx[1], sx[2], sx[3]);
-}
-// stand-alone form (general LSA kernel in use, or diagnostics)
-template <int NT>
-__global__ __launch_bounds__(512) void taco_hh_kernel(TfHhK a, int nta, const int* flags) {
-  __shared__ __attribute__((aligned(16))) float red[FmRed<NT, 1>::floats];
-  fm_hh_job<NT>(a, blockIdx.x, blockIdx.y * NT, nta, flags[TF_DONE], red);
 }
 
 // ------------------------------------------------------------------------------------------------ residual LSTM

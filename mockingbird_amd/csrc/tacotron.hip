@@ -46,8 +46,9 @@ struct LsaK {
   // the same operands as 16-byte rows per thread (one dwordx4 load where the first generation issued four dword loads:
   // the attention launch was bound by the vector-memory INSTRUCTION count, 118 per lane, profiles/r02_taco_trace_v1.json):
   const float4* Wq4;   // [4 quarters][8][D]: W[d][32 q + 4 k4 .. +3]
-  const float4* Mq4;   // [8][D]: M[d][4 j4 .. +3] (taps padded to 32 with zeros)
-  const float4* mpq4;  // [B][4 quarters][TJ/4][D]: mem_proj[b][q TQ + 4 j4 .. +3][d], built per decode call (lsa_pack_memproj_kernel)
+  const float4* Mf4;   // [8 d-tiles][2][64 lanes]: MFMA B fragments of the folded tap matrix, M[16 dt + i][4 g + kq], g = 4 gh + c
+  const float4* mpf4;  // [B][T tiles][8 d-tiles][64 lanes]: mem_proj[b][16 tile + 4 rq + 0..3][16 dt + i] (D-fragment order),
+                       // built per decode call (lsa_pack_memproj_kernel)
   // fast decoder loop (taco_fast.h): query / context are FM buffers with fm_nta column tiles (0: plain [B][D] / [B][P]),
   // and the iteration index is iter + *iter_base (device word, bumped once per graph replay)
   int fm_nta; const int* iter_base;
@@ -189,31 +190,37 @@ __global__ __launch_bounds__(512) void lsa_kernel(LsaK a) {
   }
 }
 
-// Latency-first LSA for the production shape (D = 128, context column group of 256, Kl <= 32,
-// T <= 4*TJ).  The old kernel walked the text positions with a global load inside every loop
-// iteration (one L2/HBM round trip per position: 73 us per decoder iteration, rocprofv3
-// profiles/r01_bench_kernel_stats.csv); here
-//   * every global load -- query, cumulative attention, this thread's mem_proj column, its tap-matrix
-//     row, its W^T quarter, the context rows -- is issued before the first wait,
-//   * conv1d(1->32,k=31) followed by L (32->128) is one 31-tap conv with the folded matrix M = L.conv_w,
-//     evaluated from registers: thread (d, quarter q) owns positions [q*TQ, (q+1)*TQ) and slides a
-//     register window over the cumulative attention,
+// Latency-first LSA for the production shape (D = 128, context column group of 256, Kl <= 31, T <= 4*TJ).
+// History of this launch at B = 32, T = 111 (profiles/r02_taco_trace_*.json): 19.6 us as a VALU kernel with one
+// dword load per operand word (118 vector-memory instructions per lane: bound by the instruction count), 12.1 us with
+// 16-byte operand rows, a packed-FMA location conv and the memory rows brought in by LDS-DMA -- of which 6.9 us were
+// the energy phase, VALU-issue-bound.  Now:
+//   * every global load -- query, cumulative attention, W rows, tap-matrix and processed-memory fragments -- is issued
+//     before the first wait, 16 bytes per lane and instruction;
+//   * conv1d(1->32,k=31) followed by L (32->128) is one 31-tap conv with the folded matrix M = L.conv_w, run on the
+//     MATRIX pipe: loc[t][d] = sum_j cum[t+j-15] M[d][j] is a [T x 32] x [32 x 128] product whose A operand is a Toeplitz
+//     view of the zero-padded cumulative attention in LDS.  Wave w owns positions 16 w .. 16 w + 15 (and 16 (w+8) ..
+//     for T > 128): 8 d-tiles x 8 k-steps of v_mfma_f32_16x16x4_f32 (exact fp32, same products as the FMA form), its D
+//     fragment hands every lane loc for 4 positions x 8 d, so tanh / v-weighting / the reduction over d (in-lane over
+//     the d-tiles, one 16-lane DPP row sum across them) need no cross-wave partials;
+//   * the workgroup's 256 context columns of every memory row arrive by LDS-DMA (global_load_lds: no registers)
+//     while the energies are computed (T <= 128; for longer texts they are loaded to registers after the energies);
 //   * 5 workgroup barriers in total.
-// tanh is evaluated as 1 - 2/(exp(2x)+1) (absolute error ~1e-7, the parity bar on attention is 1e-4).
+// tanh is evaluated as 1 - 2 rcp(exp(2x)+1) (absolute error ~1e-7, the parity bar on attention is 1e-4).
 template <int TJ>
-__device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const int pg) {
-  constexpr int D = 128, KL = 31, TMAX = 4 * TJ, TM = TMAX / 8, PW = 256;
+__device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const int pg, float* s_mem = nullptr) {
+  constexpr int D = 128, TMAX = 4 * TJ, TM = TMAX / 8, PW = 256, NTILE = TMAX / 16, NPASS = (NTILE + 7) / 8;
   __shared__ __attribute__((aligned(16))) float s_cum[TMAX + 64];   // zero padded by `half` on both sides
   __shared__ __attribute__((aligned(16))) float s_q[D];
   __shared__ __attribute__((aligned(16))) float s_pq[4][D];
-  __shared__ __attribute__((aligned(16))) float s_up[TMAX][8];
-  __shared__ __attribute__((aligned(16))) float s_u[TMAX];
+  __shared__ __attribute__((aligned(16))) float s_vc[2][D];         // v, c0
+  __shared__ __attribute__((aligned(16))) float s_e[TMAX];          // energies
+  __shared__ __attribute__((aligned(16))) float s_u[TMAX];          // scores
   __shared__ __attribute__((aligned(16))) float4 s_part[8][64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int d = tid & (D - 1), tq = __builtin_amdgcn_readfirstlane(tid >> 7);
   const int T = a.T, P = a.P, half = (a.Kl - 1) / 2;
-  const int TQ = (T + 3) >> 2, t0 = tq * TQ;  // this thread's positions [t0, t0 + TQ)
   int skip = 0;
   if (a.skip_flag) skip = *a.skip_flag;
   const bool pick = b == 5 && pg == 1;
@@ -229,19 +236,28 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
     const int i2 = tid + 512 * m, t = i2 - half;
     cpre[m] = (i2 < T + 2 * half && t >= 0 && t < T) ? cg[t] : 0.f;
   }
-  constexpr int J4 = TJ / 4;
   float4 wq4[8];  // W[d][k] for k in this thread's quarter
 #pragma unroll
   for (int k4 = 0; k4 < 8; ++k4) wq4[k4] = a.Wq4[(size_t)(tq * 8 + k4) * D + d];
-  float4 mq4[8];  // folded tap matrix row of this d
+  // B fragments of the tap matrix: lane (i = lane & 15, kq = lane >> 4), d-tile dt, k-step g: M[16 dt + i][4 g + kq]
+  float4 mf[8][2];
 #pragma unroll
-  for (int j4 = 0; j4 < 8; ++j4) mq4[j4] = a.Mq4[(size_t)j4 * D + d];
-  float4 mp4[J4];  // processed memory of this thread's positions
+  for (int dt = 0; dt < 8; ++dt)
 #pragma unroll
-  for (int j4 = 0; j4 < J4; ++j4) mp4[j4] = a.mpq4[(((size_t)b * 4 + tq) * J4 + j4) * D + d];
-  const float vd = a.vw[d], wb = a.Wb[d], c0d = a.c0[d];
+    for (int gh = 0; gh < 2; ++gh) mf[dt][gh] = a.Mf4[(size_t)(dt * 2 + gh) * 64 + lane];
+  // processed memory in D-fragment order: lane (i, rq), tile, d-tile: mem_proj[16 tile + 4 rq + 0..3][16 dt + i]
+  float4 mpf[NPASS][8];
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+    const int tile = wave + 8 * ps < NTILE ? wave + 8 * ps : NTILE - 1;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) mpf[ps][dt] = a.mpf4[(((size_t)b * NTILE + tile) * 8 + dt) * 64 + lane];
+  }
+  const float wb = a.Wb[d];
+  const float vc = (tid < 2 * D) ? (tid < D ? a.vw[tid] : a.c0[tid - D]) : 0.f;
   // staging
   if (tid < D) s_q[tid] = qv;
+  if (tid < 2 * D) s_vc[tid >> 7][tid & (D - 1)] = vc;
 #pragma unroll
   for (int m = 0; m < (TMAX + 64 + 511) / 512; ++m) {
     const int i2 = tid + 512 * m;
@@ -250,9 +266,9 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
   tf_mark(a.trace, TS_LSA, 1, pick);
   __syncthreads();  // B1
   tf_mark(a.trace, TS_LSA, 2, pick);
-  // ---- phase 1: processed query partials (lsa.py:25) ----
+  // ---- phase 1: processed query partials (lsa.py:25); the bias rides in partial 0 ----
   {
-    float acc = 0.f;
+    float acc = tq == 0 ? wb : 0.f;
 #pragma unroll
     for (int k4 = 0; k4 < 8; ++k4) {
       const float4 q4 = *reinterpret_cast<const float4*>(&s_q[tq * 32 + k4 * 4]);  // same address for the whole wave: broadcast
@@ -267,65 +283,94 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
     const int t = lane + 64 * m;
     chv[m] = (t < T) ? a.chars[(size_t)b * T + t] : 0;
   }
-  __syncthreads();  // B2
-  tf_mark(a.trace, TS_LSA, 3, pick);
-  const float pqd = ((s_pq[0][d] + s_pq[1][d]) + (s_pq[2][d] + s_pq[3][d])) + wb;
-  // ---- phase 2+3: location term from a sliding register window, energies, reduction over d ----
-  {
-    // Plain v_fma_f32 runs at half the packed rate on this chip (16 of 32 lanes' worth per SIMD clock): the 31-tap
-    // location conv -- 992 FMAs per thread, 60 % of the launch's issue slots -- runs as v_pk_fma_f32 on PAIRS of
-    // adjacent positions.  A pair (j, j+1) needs (win[j+jj], win[j+jj+1]) as one aligned register pair for every
-    // tap jj, so the window is kept twice: pairs starting at even and at odd offsets.  Same FMAs, same order per
-    // position as the scalar form.
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    constexpr int NWP = (TJ + KL + 1) / 2;
-    f32x2 winE[NWP], winO[NWP];
-    {
-      float wtmp[2 * NWP + 1];
+  const int p0 = pg * PW;
+  const float* mem = a.memory + (size_t)b * T * P + p0 + lane * 4;
+  const bool dma = TJ == 32 && s_mem != nullptr;
+  if (dma) {
+    // Every ordinary load above must have LANDED before the DMA is queued: hipcc waits vmcnt(0) at the next use of a
+    // loaded value while an LDS-DMA is in flight, which would put the 128 KB in front of the energy phase.  Touching
+    // the operands here makes that wait happen now (they were requested microseconds ago), with nothing else outstanding.
 #pragma unroll
-      for (int m = 0; m < 2 * NWP + 1; ++m) wtmp[m] = s_cum[t0 + m < TMAX + 64 ? t0 + m : 0];
+    for (int dt = 0; dt < 8; ++dt) {
+      asm volatile("" : "+v"(mf[dt][0].x), "+v"(mf[dt][0].y), "+v"(mf[dt][0].z), "+v"(mf[dt][0].w));
+      asm volatile("" : "+v"(mf[dt][1].x), "+v"(mf[dt][1].y), "+v"(mf[dt][1].z), "+v"(mf[dt][1].w));
 #pragma unroll
-      for (int k = 0; k < NWP; ++k) { winE[k] = f32x2{wtmp[2 * k], wtmp[2 * k + 1]}; winO[k] = f32x2{wtmp[2 * k + 1], wtmp[2 * k + 2]}; }
+      for (int ps = 0; ps < NPASS; ++ps) asm volatile("" : "+v"(mpf[ps][dt].x), "+v"(mpf[ps][dt].y), "+v"(mpf[ps][dt].z), "+v"(mpf[ps][dt].w));
     }
 #pragma unroll
-    for (int jp = 0; jp < TJ / 2; ++jp) {  // positions 2 jp, 2 jp + 1
-      f32x2 pl = f32x2{c0d, c0d};
+    for (int m = 0; m < (TMAX + 63) / 64; ++m) asm volatile("" : "+v"(chv[m]));
+  }
+  __syncthreads();  // B2
+  tf_mark(a.trace, TS_LSA, 3, pick);
+  if (dma) {  // queued behind B2: a barrier drains the DMA queue (hipcc emits vmcnt(0) in front of s_barrier)
 #pragma unroll
-      for (int g = 0; g < 8; ++g) {
-        const float mg[4] = {mq4[g].x, mq4[g].y, mq4[g].z, mq4[g].w};
+    for (int j = 0; j < TM; ++j) {
+      const int t = wave + 8 * j;  // wave-uniform: row t lands at s_mem[t][0..255], lane l -> floats [4 l, 4 l + 4)
+      if (t < T)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(mem + (size_t)t * P),
+                                         (__attribute__((address_space(3))) void*)(s_mem + t * PW), 16, 0, 0);
+    }
+  }
+  // ---- phase 2+3: location term on the matrix pipe, energies, reduction over d ----
+  {
+    const int i = lane & 15, kq = lane >> 4;
+    float pqv[8], vv[8], c0v[8];
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-          const int jj = g * 4 + cc, idx = 2 * jp + jj;
-          if (jj < KL) {
-            const f32x2 w2 = (idx & 1) ? winO[(idx - 1) / 2] : winE[idx / 2];
-            pl = f32x2{mg[cc], mg[cc]} * w2 + pl;
+    for (int dt = 0; dt < 8; ++dt) {
+      const int dd = dt * 16 + i;
+      pqv[dt] = (s_pq[0][dd] + s_pq[1][dd]) + (s_pq[2][dd] + s_pq[3][dd]);
+      vv[dt] = s_vc[0][dd]; c0v[dt] = s_vc[1][dd];
+    }
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int tile = wave + 8 * ps;
+      if (tile * 16 < T) {  // wave-uniform
+        // A fragments: cum_pad[16 tile + i + 4 g + kq] (s_cum is padded by `half`: index t + j is cum[t + j - half])
+        float av[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) av[g] = s_cum[tile * 16 + i + 4 * g + kq];
+        f32x4 acc[8];
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) acc[dt] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+#pragma unroll
+          for (int dt = 0; dt < 8; ++dt) {  // consecutive MFMAs on different accumulators
+            const float4 m4 = mf[dt][g >> 2];
+            const float bv = (g & 3) == 0 ? m4.x : (g & 3) == 1 ? m4.y : (g & 3) == 2 ? m4.z : m4.w;
+            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g], bv, acc[dt], 0, 0, 0);
+          }
+        // D fragment: acc[dt][r] = loc[16 tile + 4 kq + r][16 dt + i]
+        float e[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+          const float mpr[4] = {mpf[ps][dt].x, mpf[ps][dt].y, mpf[ps][dt].z, mpf[ps][dt].w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float x = (pqv[dt] + mpr[r]) + (acc[dt][r] + c0v[dt]);
+            const float th = 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * x) + 1.f);  // tanh, 1 ulp reciprocal
+            e[r] += vv[dt] * th;
           }
         }
-      }
-      const float4 mq = mp4[jp / 2];
-      const float mpu[2] = {(jp & 1) ? mq.z : mq.x, (jp & 1) ? mq.w : mq.y};
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int j = 2 * jp + u;
-        const float x = (pqd + mpu[u]) + pl[u];
-        const float th = 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * x) + 1.f);  // tanh, 1 ulp reciprocal
-        // reduction over d: 16-lane DPP row sums (4 VALU ops), the 8 row partials of a position meet in the softmax
-        const float e = row16_sum(vd * th);
-        if ((lane & 15) == 0 && j < TQ && t0 + j < T) s_up[t0 + j][(wave & 1) * 4 + (lane >> 4)] = e;
+        for (int r = 0; r < 4; ++r) {
+          const float es = row16_sum(e[r]);  // over the 16 d of a tile column group: 4 VALU ops
+          const int t = tile * 16 + 4 * kq + r;
+          if (i == 0 && t < T) s_e[t] = es;
+        }
       }
     }
   }
   __syncthreads();  // B3
   tf_mark(a.trace, TS_LSA, 5, pick);
-  // context rows (stable data): requested now -- their 128 KB per workgroup arrive while wave 0 runs the softmax; issued at
-  // the top they held 64 registers through the energy phase and queued in front of everything else
-  const int p0 = pg * PW;
-  const float* mem = a.memory + (size_t)b * T * P + p0 + lane * 4;
+  // context rows (stable data) of the register path (no LDS window): requested now, they arrive while wave 0 runs the softmax
   float4 memv[TM];
+  if (!dma) {
 #pragma unroll
-  for (int j = 0; j < TM; ++j) {
-    const int t = wave + 8 * j;
-    memv[j] = (t < T) ? *reinterpret_cast<const float4*>(mem + (size_t)t * P) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < TM; ++j) {
+      const int t = wave + 8 * j;
+      memv[j] = (t < T) ? *reinterpret_cast<const float4*>(mem + (size_t)t * P) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
   // ---- phase 4: mask, softmax over T (lsa.py:34-38) by wave 0, cumulative update ----
   if (wave == 0) {
@@ -335,11 +380,7 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
     for (int q = 0; q < (TMAX + 63) / 64; ++q) {
       const int t = lane + 64 * q;
       float u = -INFINITY;
-      if (t < T) {
-        const float4 ua = *reinterpret_cast<const float4*>(&s_up[t][0]), ub = *reinterpret_cast<const float4*>(&s_up[t][4]);
-        u = ((ua.x + ua.y) + (ua.z + ua.w)) + ((ub.x + ub.y) + (ub.z + ub.w));
-        u = chv[q] != 0 ? u : u * 0.f;  // u * (chars != 0)
-      }
+      if (t < T) { u = s_e[t]; u = chv[q] != 0 ? u : u * 0.f; }  // u * (chars != 0)
       uv[q] = u;
       m = fmaxf(m, u);
     }
@@ -375,7 +416,10 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
     for (int j = 0; j < TM; ++j) {
       const int t = wave + 8 * j;
       const float sc = (t < T) ? s_u[t] : 0.f;
-      acc.x += sc * memv[j].x; acc.y += sc * memv[j].y; acc.z += sc * memv[j].z; acc.w += sc * memv[j].w;
+      float4 mv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (dma) { if (t < T) mv = *reinterpret_cast<const float4*>(s_mem + t * PW + lane * 4); }
+      else mv = memv[j];
+      acc.x += sc * mv.x; acc.y += sc * mv.y; acc.z += sc * mv.z; acc.w += sc * mv.w;
     }
     s_part[wave][lane] = acc;
   }
@@ -393,37 +437,40 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
   tf_mark_end(a.trace, TS_LSA, 8, pick);
 }
 
-// mem_proj [B][T][D] -> quads of 4 consecutive positions per (utterance, quarter of the text, d): what one thread of
-// lsa_fast_body consumes, as 16-byte rows.  Once per decode call.
-__global__ void lsa_pack_memproj_kernel(const float* __restrict__ mp, float4* __restrict__ out, int B, int T, int J4) {
+// mem_proj [B][T][D] -> the order in which the lanes of lsa_fast_body hold the location term (MFMA D fragments):
+// float4 (b, tile, dt, lane = rq * 16 + i) = mem_proj[b][16 tile + 4 rq + 0..3][16 dt + i], zero beyond T.  Once per decode call.
+__global__ void lsa_pack_memproj_kernel(const float* __restrict__ mp, float4* __restrict__ out, int B, int T, int ntile) {
   constexpr int D = 128;
-  const int TQ = (T + 3) >> 2;
-  const size_t n = (size_t)B * 4 * J4 * D;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const int d = (int)(i % D);
-    const int j4 = (int)((i / D) % J4), tq = (int)((i / D / J4) % 4), b = (int)(i / D / J4 / 4);
+  const size_t n = (size_t)B * ntile * 8 * 64;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(idx & 63), dt = (int)((idx >> 6) & 7);
+    const int tile = (int)((idx >> 9) % ntile), b = (int)((idx >> 9) / ntile);
+    const int i = lane & 15, rq = lane >> 4;
     float v[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int j = j4 * 4 + u, t = tq * TQ + j;
-      v[u] = (j < TQ && t < T) ? mp[((size_t)b * T + t) * D + d] : 0.f;
+    for (int r = 0; r < 4; ++r) {
+      const int t = tile * 16 + rq * 4 + r;
+      v[r] = t < T ? mp[((size_t)b * T + t) * D + dt * 16 + i] : 0.f;
     }
-    out[i] = make_float4(v[0], v[1], v[2], v[3]);
+    out[idx] = make_float4(v[0], v[1], v[2], v[3]);
   }
 }
 
 template <int TJ>
 __global__ __launch_bounds__(512) void lsa_fast_kernel(LsaK a) {
-  lsa_fast_body<TJ>(a, blockIdx.x, blockIdx.y);
+  __shared__ __attribute__((aligned(16))) float s_big[TJ == 32 ? 32 * 4 * 256 : 4];
+  lsa_fast_body<TJ>(a, blockIdx.x, blockIdx.y, TJ == 32 ? s_big : nullptr);
 }
 // The attention launch occupies B * psplit of the 256 CUs for ~10 us of dependent latencies.  The hidden half of the
 // decoder's SECOND LSTM, W_hh2 . h2 (16.8 MB of weights), depends only on the previous iteration's state: it rides here
 // as extra workgroups on the idle CUs (the attention workgroups come first in dispatch order) and leaves the chain.
 template <int TJ, int NT>
 __global__ __launch_bounds__(512) void lsa_hh_kernel(LsaK a, TfHhK hh, int n_lsa, int B, int gy, int nta) {
+  // one LDS block serves both jobs: the attention's 128 KB memory window (TJ = 32) / the hh job's reduction buffer
+  __shared__ __attribute__((aligned(16))) float s_big[TJ == 32 ? 32 * 4 * 256 : FmRed<NT, 1>::floats];
+  float* red = s_big;
   const int id = blockIdx.x;
-  if (id < n_lsa) { lsa_fast_body<TJ>(a, id % B, id / B); return; }
-  __shared__ __attribute__((aligned(16))) float red[FmRed<NT, 1>::floats];
+  if (id < n_lsa) { lsa_fast_body<TJ>(a, id % B, id / B, TJ == 32 ? s_big : nullptr); return; }
   const int j = id - n_lsa, mt = j / gy;
   fm_hh_job<NT>(hh, mt, (j - mt * gy) * NT, nta, a.skip_flag ? *a.skip_flag : 0, red);
 }
@@ -987,13 +1034,17 @@ extern "C" int mb_taco_create(const mb_taco_config* cfg, const float* const* hw,
     RC(t->lsa_Mt.upload(Mt.data(), Mt.size())); RC(t->lsa_c0.upload(c0.data(), c0.size())); RC(t->lsa_Wt.upload(Wt.data(), Wt.size()));
     if (D % 32 == 0 && Kl <= 32) {  // rows of 4: Wq4[(q*8 + k4)*D + d] = W[d][q*(D/4) + 4 k4 ..], Mq4[j4*D + d] = M[d][4 j4 ..]
       const int KQ = D / 4;  // k range of a quarter (32 for D = 128)
-      std::vector<float> Wq((size_t)D * D, 0.f), Mq((size_t)8 * D * 4, 0.f);
+      std::vector<float> Wq((size_t)D * D, 0.f), Mq((size_t)8 * 2 * 64 * 4, 0.f);
       for (int dd = 0; dd < D; ++dd) {
         for (int k2 = 0; k2 < D; ++k2) {
           const int q = k2 / KQ, k4 = (k2 % KQ) / 4, c4 = k2 % 4;
           Wq[(((size_t)q * (KQ / 4) + k4) * D + dd) * 4 + c4] = Ww[(size_t)dd * D + k2];
         }
-        for (int j = 0; j < Kl; ++j) Mq[((size_t)(j / 4) * D + dd) * 4 + (j % 4)] = Mt[(size_t)j * D + dd];
+        // MFMA B fragment of tap j = 4 g + kq for d = 16 dt + i: float4 (dt, gh = g / 4) of lane (kq * 16 + i), component g % 4
+        for (int j = 0; j < Kl; ++j) {
+          const int g = j / 4, kq = j % 4, dt = dd / 16, i2 = dd % 16;
+          Mq[(((size_t)dt * 2 + g / 4) * 64 + kq * 16 + i2) * 4 + (g % 4)] = Mt[(size_t)j * D + dd];
+        }
       }
       RC(t->lsa_Wq4.upload(Wq.data(), Wq.size())); RC(t->lsa_Mq4.upload(Mq.data(), Mq.size()));
     }
@@ -1146,7 +1197,7 @@ struct TacoLayout {
   // fast loop (taco_fast.h): FM activations, CM cell state / gate pre-activations
   float *f_p1, *f_p2, *f_ah, *f_ctx, *f_x, *f_x1, *f_x2, *f_h1, *f_h2, *f_c1, *f_c2, *f_xpre, *f_hpre, *f_hp1, *f_hp2, *f_stop_part;
   size_t f_state_bytes;  // the region above, zeroed per call
-  float* mpq4;  // mem_proj as position quads for lsa_fast_body: [B][4][TJ/4][D] float4 = B * 4 TJ * D floats, TJ = 32 | 48
+  float* mpq4;  // mem_proj in MFMA D-fragment order for lsa_fast_body: [B][4 TJ / 16][8][64] float4 = B * 4 TJ * D floats, TJ = 32 | 48
   int* flags;  // [0] done, [1] n_frames, [2] arrive, [3] utterances below the stop threshold, [4] iteration base, [6..7] seed
   // postnet
   float *melc, *linc;
@@ -1245,12 +1296,14 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
     rk.bih4 = reinterpret_cast<const float4*>(t->f_bih4.p); rk.bhh4 = reinterpret_cast<const float4*>(t->f_bhh4.p);
     rk.ctx = L.f_ctx; rk.ah = L.f_ah; rk.x = L.f_x; rk.xpre = reinterpret_cast<float4*>(L.f_xpre); rk.hpre = reinterpret_cast<float4*>(L.f_hpre);
     rk.nta = nta; rk.n_rin = H / 16; rk.flags = flags; rk.trace = nullptr;
-    rk.w_stopc = t->f_stopc_w.p; rk.stop_part = L.f_stop_part;
+    rk.w_stopc = t->f_stopc_w.p; rk.stop_part = L.f_stop_part; rk.hh = TfHhK{nullptr, nullptr, nullptr, 0, 0};
     if (nta >= 2) hipLaunchKernelGGL(taco_rin_kernel<2>, dim3(H / 16 + D / 4, cdiv(nta, 2)), dim3(512), 0, s, rk);
     else hipLaunchKernelGGL(taco_rin_kernel<1>, dim3(H / 16 + D / 4, nta), dim3(512), 0, s, rk);
   }
   MB_HIP(hipGetLastError());
 
+  int hh1_split = H / 8;  // row tiles of W_hh1 . h1 taken by the mel launch (the rest: next rnn_input launch)
+  if (const char* he = getenv("MBHIP_TACO_HH1_SPLIT")) hh1_split = std::max(0, std::min(H / 4, atoi(he)));
   auto iteration = [&](int pp, int it_off) -> int {
     // (the LSTM state needs no ping-pong: h is read only by the hh jobs, which have finished before the next LSTM launch)
     const dim3 blk(512);
@@ -1278,11 +1331,11 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
     lk.vw = t->lsa_v.p; lk.context = L.f_ctx; lk.attn_out = d_attn; lk.T = T; lk.D = D; lk.P = P; lk.Fl = c.lsa_filters;
     lk.Kl = c.lsa_kernel; lk.iter = it_off; lk.n_iter_max = n_iter_max; lk.skip_flag = flags + TF_DONE;
     lk.Mt = t->lsa_Mt.p; lk.c0 = t->lsa_c0.p; lk.Wt = t->lsa_Wt.p; lk.fm_nta = nta; lk.iter_base = flags + TF_ITER; lk.trace = tr;
-    lk.Wq4 = reinterpret_cast<const float4*>(t->lsa_Wq4.p); lk.Mq4 = reinterpret_cast<const float4*>(t->lsa_Mq4.p);
-    lk.mpq4 = reinterpret_cast<const float4*>(L.mpq4);
+    lk.Wq4 = reinterpret_cast<const float4*>(t->lsa_Wq4.p); lk.Mf4 = reinterpret_cast<const float4*>(t->lsa_Mq4.p);
+    lk.mpf4 = reinterpret_cast<const float4*>(L.mpq4);
     // ... with the hidden half of THIS iteration's second LSTM (W_hh2 . h2 of the previous iteration) on the idle CUs
     TfHhK hh2;
-    hh2.w = t->f_l2_hh.p; hh2.h = L.f_h2; hh2.hpre = reinterpret_cast<float4*>(L.f_hp2); hh2.n_tiles = H / 4;
+    hh2.w = t->f_l2_hh.p; hh2.h = L.f_h2; hh2.hpre = reinterpret_cast<float4*>(L.f_hp2); hh2.n_tiles = H / 4; hh2.tile0 = 0;
     const int n_lsa = B * psplit;
     if (lsa_fast) {
       const dim3 g1(n_lsa + (H / 4) * gy);
@@ -1302,7 +1355,11 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
     rk.ctx = L.f_ctx; rk.ah = L.f_ah; rk.x = L.f_x; rk.xpre = reinterpret_cast<float4*>(L.f_xpre); rk.hpre = reinterpret_cast<float4*>(L.f_hpre);
     rk.nta = nta; rk.n_rin = H / 16; rk.flags = flags; rk.trace = tr;
     rk.w_stopc = t->f_stopc_w.p; rk.stop_part = L.f_stop_part;
-    TF_LAUNCH(taco_rin_kernel, H / 16 + D / 4 + 1, rk);
+    // hidden half of THIS iteration's first LSTM: row tiles [hh1_split, H/4) here, [0, hh1_split) rode in the previous
+    // iteration's mel launch (both launches leave most CUs idle; one launch taking all 256 tiles slowed its chain jobs)
+    rk.hh.w = t->f_l1_hh.p; rk.hh.h = L.f_h1; rk.hh.hpre = reinterpret_cast<float4*>(L.f_hp1);
+    rk.hh.tile0 = hh1_split; rk.hh.n_tiles = H / 4 - hh1_split;
+    TF_LAUNCH(taco_rin_kernel, H / 16 + D / 4 + 1 + rk.hh.n_tiles, rk);
     // 5./6. residual LSTMs
     TfLstmK lk1;
     lk1.w = t->l1_wx.p; lk1.b4 = reinterpret_cast<const float4*>(t->f_l1_b4.p); lk1.x = L.f_x; lk1.h_out = L.f_h1;
@@ -1318,10 +1375,10 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
     TfMelK mk;
     mk.w_mel = t->mel_w.p; mk.w_fc1 = t->f_fc1_w.p; mk.b_fc1 = t->pre1_b.p; mk.w_stop = t->f_stop_w.p; mk.b_stop = t->stop_b.p;
     mk.x2 = L.f_x2; mk.stop_part = L.f_stop_part; mk.p1 = L.f_p1; mk.mel_out = d_mel; mk.stop_out = L.stop;
-    mk.hh.w = t->f_l1_hh.p; mk.hh.h = L.f_h1; mk.hh.hpre = reinterpret_cast<float4*>(L.f_hp1); mk.hh.n_tiles = H / 4;
+    mk.hh.w = t->f_l1_hh.p; mk.hh.h = L.f_h1; mk.hh.hpre = reinterpret_cast<float4*>(L.f_hp1); mk.hh.n_tiles = hh1_split; mk.hh.tile0 = 0;
     mk.nta = nta; mk.B = B; mk.n_mel = r * M / 16; mk.M = M; mk.r = r; mk.max_steps = max_steps; mk.it_off = it_off;
     mk.min_stop_token = min_stop_token; mk.flags = flags; mk.drop = dk; mk.drop.layer = 0; mk.drop.it_add = 1; mk.trace = tr;
-    TF_LAUNCH(taco_mel_kernel, r * M / 16 + 2 * D / 16 + 1 + H / 4, mk);
+    TF_LAUNCH(taco_mel_kernel, r * M / 16 + 2 * D / 16 + 1 + hh1_split, mk);
 #undef TF_LAUNCH
     MB_HIP(hipGetLastError());
     return MB_OK;
@@ -1423,9 +1480,9 @@ extern "C" int mb_taco_decode(const mb_taco* t, const float* d_memory, const flo
   }
 
   if (lsa_fast) {  // processed memory as per-thread position quads (once per call)
-    const int J4 = (T <= 128 ? 32 : 48) / 4;
-    hipLaunchKernelGGL(lsa_pack_memproj_kernel, dim3(std::min(cdiv(B * 4 * J4 * 128, 256), 2048)), dim3(256), 0, s, d_memory_proj,
-                       reinterpret_cast<float4*>(L.mpq4), B, T, J4);
+    const int ntile = (T <= 128 ? 128 : 192) / 16;
+    hipLaunchKernelGGL(lsa_pack_memproj_kernel, dim3(std::min(cdiv(B * ntile * 512, 256), 2048)), dim3(256), 0, s, d_memory_proj,
+                       reinterpret_cast<float4*>(L.mpq4), B, T, ntile);
     MB_HIP(hipGetLastError());
   }
   // zero initial states (tacotron.py:219-230,261; lsa.py:15-19)
@@ -1493,8 +1550,8 @@ extern "C" int mb_taco_decode(const mb_taco* t, const float* d_memory, const flo
     lk.vw = t->lsa_v.p; lk.context = cx_n; lk.attn_out = d_attn; lk.T = T; lk.D = D; lk.P = P; lk.Fl = c.lsa_filters;
     lk.Kl = c.lsa_kernel; lk.iter = it; lk.n_iter_max = n_iter_max; lk.skip_flag = done;
     lk.Mt = t->lsa_Mt.p; lk.c0 = t->lsa_c0.p; lk.Wt = t->lsa_Wt.p; lk.fm_nta = 0; lk.iter_base = nullptr; lk.trace = nullptr;
-    lk.Wq4 = reinterpret_cast<const float4*>(t->lsa_Wq4.p); lk.Mq4 = reinterpret_cast<const float4*>(t->lsa_Mq4.p);
-    lk.mpq4 = reinterpret_cast<const float4*>(L.mpq4);
+    lk.Wq4 = reinterpret_cast<const float4*>(t->lsa_Wq4.p); lk.Mf4 = reinterpret_cast<const float4*>(t->lsa_Mq4.p);
+    lk.mpf4 = reinterpret_cast<const float4*>(L.mpq4);
     if (lsa_fast && T <= 128) hipLaunchKernelGGL(lsa_fast_kernel<32>, dim3(B, psplit), dim3(512), 0, s, lk);
     else if (lsa_fast) hipLaunchKernelGGL(lsa_fast_kernel<48>, dim3(B, psplit), dim3(512), 0, s, lk);
     else hipLaunchKernelGGL(lsa_kernel, dim3(B, psplit), dim3(512), lds_lsa, s, lk);
