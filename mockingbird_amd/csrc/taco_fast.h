@@ -26,124 +26,13 @@
 // Reference arithmetic: models/synthesizer/models/tacotron.py:71-138, sublayer/pre_net.py:21-26, torch GRUCell /
 // LSTMCell gate orders as in rnn_body.h.
 #pragma once
-#include "rnn_body.h"
+#include "fm_gemm.h"
 
 namespace mb {
 
 // flags block in the workspace (ints): [0] done, [1] n_frames, [2] arrival ticket, [3] utterances below the stop
 // threshold, [4] iteration index of the first launch of the current graph replay, [6..7] 64-bit dropout seed
 enum { TF_DONE = 0, TF_NFRAMES = 1, TF_ARRIVE = 2, TF_NOTREADY = 3, TF_ITER = 4, TF_SEED = 6 };
-
-__host__ __device__ __forceinline__ size_t fm_floats(int K, int nta) { return (size_t)(K / 16) * nta * 256; }
-__host__ __device__ __forceinline__ size_t cm_items(int units, int nta) { return (size_t)((units + 3) / 4) * nta * 64; }
-// float index of element (column n, feature k) in an FM buffer
-__host__ __device__ __forceinline__ size_t fm_index(int nta, int n, int k) {
-  return ((size_t)(k >> 4) * nta + (n >> 4)) * 256 + ((k >> 2) & 3) * 64 + (n & 15) * 4 + (k & 3);
-}
-
-// diagnostics (MBHIP_TACO_TRACE=<file>): shader-clock stamps of one workgroup per kernel, 16 marks per kernel slot;
-// mark 14 / 15 = 100 MHz wall clock at kernel start / end (aligns the kernels of an iteration with each other)
-enum { TS_FC2 = 0, TS_GRU = 1, TS_LSA = 2, TS_RIN = 3, TS_LSTM1 = 4, TS_LSTM2 = 5, TS_MEL = 6, TS_MEL_FC1 = 7, TS_MEL_STOP = 8, TS_SLOTS = 9 };
-__device__ __forceinline__ void tf_mark(unsigned long long* tr, int slot, int k, bool pick) {
-  if (tr && pick && threadIdx.x == 0) {
-    tr[slot * 16 + k] = (unsigned long long)clock64();
-    if (k == 0) tr[slot * 16 + 14] = (unsigned long long)wall_clock64();
-  }
-}
-__device__ __forceinline__ void tf_mark_end(unsigned long long* tr, int slot, int k, bool pick) {
-  if (tr && pick && (threadIdx.x & 63) == 0 && threadIdx.x < 128) {  // epilogue waves: the later one wins
-    atomicMax(tr + slot * 16 + k, (unsigned long long)clock64());
-    atomicMax(tr + slot * 16 + 15, (unsigned long long)wall_clock64());
-  }
-}
-
-// row sum over the 16 lanes of a DPP row (every lane of the row receives it): 4 VALU ops, no LDS crossbar
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float row16_sum(float v) {
-  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
-  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
-  v += dpp_mov<0x141>(v);  // row_half_mirror
-  v += dpp_mov<0x140>(v);  // row_mirror
-  return v;
-}
-
-// Skinny GEMM core: one 16-row weight tile (mt) x NT column tiles, K = 8 * PW k-blocks split over the 8 waves
-// (wave w owns k-blocks w, w+8, ...), first PS steps from seg0, the rest from seg1 (both FM).  NPART = 2 keeps the
-// seg1 sums apart (GRU hidden part).  All loads are issued before the first MFMA.  Returns true for the NT
-// epilogue waves (wave w finishes column tile nt0 + w) with the reduced sums in sx / sh (k order: waves 0..7).
-template <int NT, int PW, int PS, int RL, int NPART>
-__device__ __forceinline__ bool fm_gemm(const float* __restrict__ w, const int mt, const float* __restrict__ seg0,
-                                        const float* __restrict__ seg1, const int nta, const int nt0, float* red,
-                                        float (&sx)[4], float (&sh)[4], unsigned long long* tr = nullptr, int slot = 0,
-                                        bool pick = false) {
-  constexpr int BLK = 4 * RL * 16, NKB = 8 * PW;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int i = lane & 15, kq = lane >> 4;
-  const int u = i >> 2, tau = (i & 3) < RL ? (i & 3) : RL - 1;  // dead 4th GRU row re-reads row 2 (never used)
-  const float* wl = w + (size_t)mt * NKB * BLK + ((u * RL + tau) * 4 + kq) * 4;
-  int ntc[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) ntc[nt] = (nt0 + nt < nta) ? nt0 + nt : nta - 1;  // odd tile count: duplicate, never stored
-  float4 a[PW], b[PW][NT];
-#pragma unroll
-  for (int p = 0; p < PW; ++p) {
-    const int kb = wave + 8 * p;
-    a[p] = *reinterpret_cast<const float4*>(wl + (size_t)kb * BLK);
-    const float4* sp = reinterpret_cast<const float4*>(p < PS ? seg0 : seg1);
-    const int kl = p < PS ? kb : kb - 8 * PS;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) b[p][nt] = sp[((size_t)kl * nta + ntc[nt]) * 64 + lane];
-  }
-  // the machine scheduler would otherwise sink the loads next to their MFMAs to save registers (50 VGPRs, two or
-  // three k-blocks in flight per wave); the whole point is to have every fragment of the wave in flight at once
-  __builtin_amdgcn_sched_barrier(0);
-  tf_mark(tr, slot, 1, pick);  // every load issued
-  f32x4 accX[NT], accH[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) { accX[nt] = {0.f, 0.f, 0.f, 0.f}; accH[nt] = {0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-  for (int p = 0; p < PW; ++p) {
-    const bool hpart = NPART == 2 && p >= PS;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float av = c == 0 ? a[p].x : c == 1 ? a[p].y : c == 2 ? a[p].z : a[p].w;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const float bv = c == 0 ? b[p][nt].x : c == 1 ? b[p][nt].y : c == 2 ? b[p][nt].z : b[p][nt].w;
-        if (hpart) accH[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, accH[nt], 0, 0, 0);
-        else accX[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, accX[nt], 0, 0, 0);
-      }
-    }
-  }
-  float4* red4 = reinterpret_cast<float4*>(red);  // [8][NT][NPART][64]
-  tf_mark(tr, slot, 2, pick);  // MFMAs of wave 0 issued (its last fragment has arrived)
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    red4[((wave * NT + nt) * NPART + 0) * 64 + lane] = make_float4(accX[nt][0], accX[nt][1], accX[nt][2], accX[nt][3]);
-    if (NPART == 2) red4[((wave * NT + nt) * NPART + 1) * 64 + lane] = make_float4(accH[nt][0], accH[nt][1], accH[nt][2], accH[nt][3]);
-  }
-  __syncthreads();
-  tf_mark(tr, slot, 3, pick);  // all eight waves done
-  if (wave >= NT) return false;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) { sx[g] = 0.f; sh[g] = 0.f; }
-#pragma unroll
-  for (int w8 = 0; w8 < 8; ++w8) {
-    const float4 v = red4[((w8 * NT + wave) * NPART + 0) * 64 + lane];
-    sx[0] += v.x; sx[1] += v.y; sx[2] += v.z; sx[3] += v.w;
-    if (NPART == 2) {
-      const float4 h = red4[((w8 * NT + wave) * NPART + 1) * 64 + lane];
-      sh[0] += h.x; sh[1] += h.y; sh[2] += h.z; sh[3] += h.w;
-    }
-  }
-  return true;
-}
-
-template <int NT, int NPART> struct FmRed { static constexpr int floats = 8 * NT * NPART * 256; };
 
 // ---- always-on PreNet dropout (pre_net.py:23,26) of a relu'd row quad; same masks / same Philox stream as the
 //      general path (rnn_body.h): mask [n_iter][2][B][ld], Philox(iter, layer, n, row/4) ----

@@ -23,6 +23,7 @@
 //     known rnn1 is ELEMENTWISE (wavernn_gru1_finish_kernel) and rnn2 only multiplies its input
 //     half (K = 512 instead of 1024).  Still 5 launches per step, about half the bytes on the chain.
 #include "rnn.h"
+#include "wavernn_fast.h"
 
 namespace mb {
 
@@ -228,6 +229,8 @@ struct mb_wavernn {
   // row-tile linears (rows in torch gate-major order)
   CondConv t_T1;
   DevBuf w_rnn2x, w_hh1, w_hh2;
+  // fast chain (wavernn_fast.h): hidden halves in GRU tile order, their biases as (r, z, n, -) per unit
+  DevBuf f_hh1t, f_hh2t, f_bhh1q, f_bhh2q;
   // Folds are independent sequences: they are dealt to up to MAX_LANES "lanes", each with its own
   // stream + graph, so the per-kernel dependency latency of one lane overlaps with the others.
   static constexpr int MAX_LANES = 8;
@@ -392,6 +395,11 @@ extern "C" int mb_wavernn_create(const mb_wavernn_config* cfg, const float* cons
     }
     pack_rowtile(whh, 3 * R, R, 4, &packed);
     RC(w->w_hh1.upload(packed.data(), packed.size()));
+    cell_rows(whh, R, R, whh, 0, R, 3, &rows); pack_rowtile(rows.data(), 3 * R, R, 3, &packed);
+    RC(w->f_hh1t.upload(packed.data(), packed.size()));
+    std::vector<float> bq((size_t)R * 4);
+    for (int j = 0; j < R; ++j) for (int g = 0; g < 4; ++g) bq[(size_t)j * 4 + g] = g < 3 ? bhh[g * R + j] : 0.f;
+    RC(w->f_bhh1q.upload(bq.data(), bq.size()));
   }
   // rnn2 :110 (input = [x, a2])
   {
@@ -405,6 +413,11 @@ extern "C" int mb_wavernn_create(const mb_wavernn_config* cfg, const float* cons
     RC(w->w_rnn2x.upload(packed.data(), packed.size()));
     pack_rowtile(whh, 3 * R, R, 4, &packed);
     RC(w->w_hh2.upload(packed.data(), packed.size()));
+    cell_rows(whh, R, R, whh, 0, R, 3, &rows); pack_rowtile(rows.data(), 3 * R, R, 3, &packed);
+    RC(w->f_hh2t.upload(packed.data(), packed.size()));
+    std::vector<float> bq((size_t)R * 4);
+    for (int j = 0; j < R; ++j) for (int g = 0; g < 4; ++g) bq[(size_t)j * 4 + g] = g < 3 ? bhh[g * R + j] : 0.f;
+    RC(w->f_bhh2q.upload(bq.data(), bq.size()));
     std::vector<float> wa = col_slice(wih, 3 * R, R + A, R, A);
     RC(make_cond_conv(&w->t_g2, wa.data(), 3 * R, A, 1, 0, bih, nullptr));
   }
@@ -449,7 +462,8 @@ extern "C" void mb_wavernn_destroy(mb_wavernn* w) {
   for (auto& c : w->res2) rel(c);
   for (auto& b : w->up_w) b.release();
   DevBuf* bs[] = {&w->wI0, &w->g1I0, &w->w_rnn1, &w->w_rnn2, &w->w_fc1, &w->w_fc2, &w->w_fc3,
-                  &w->b_ih1, &w->b_hh1, &w->b_hh2, &w->b_fc3, &w->w_rnn2x, &w->w_hh1, &w->w_hh2};
+                  &w->b_ih1, &w->b_hh1, &w->b_hh2, &w->b_fc3, &w->w_rnn2x, &w->w_hh1, &w->w_hh2,
+                  &w->f_hh1t, &w->f_hh2t, &w->f_bhh1q, &w->f_bhh2q};
   for (DevBuf* b : bs) b->release();
   w->drop_graph();
   if (w->ev_in) (void)hipEventDestroy(w->ev_in);
@@ -469,6 +483,8 @@ struct WrnLayout {
   float *r0, *r1, *r2, *aux, *m1, *m2, *cond, *Ipre, *G2, *F1, *F2;
   float *x0, *x1, *x2, *y1, *y2, *logits, *h1, *h2;
   float *T1, *P1, *P2;  // split-hidden chain: per-position rnn1 input table, hidden-half pre-activations
+  float *f_x1, *f_x2, *f_y1, *f_y2, *f_h1, *f_h2, *f_P1, *f_P2, *f_Tq;  // fast chain: FM activations / state, CM4 hidden halves, staged table rows
+  size_t f_bytes;
   int* step; unsigned long long* slots;
   size_t bytes;
 };
@@ -506,6 +522,16 @@ static void wavernn_layout(const mb_wavernn* w, const mb_wavernn_plan* p, void* 
   L->h1 = ar.take<float>(2 * N * R); L->h2 = ar.take<float>(2 * N * R);
   L->P1 = ar.take<float>(N * 3 * R); L->P2 = ar.take<float>(N * 3 * R);
   L->T1 = ar.take<float>(wavernn_split_chain() ? (T + 1) * 3 * R : 1);
+  {
+    const int nta = (int)((N + 15) / 16);
+    L->f_x1 = ar.take<float>(fm_floats((int)R, nta));
+    const size_t start = ar.off - fm_floats((int)R, nta) * sizeof(float);
+    L->f_x2 = ar.take<float>(fm_floats((int)R, nta)); L->f_y1 = ar.take<float>(fm_floats((int)FC, nta)); L->f_y2 = ar.take<float>(fm_floats((int)FC, nta));
+    L->f_h1 = ar.take<float>(fm_floats((int)R, nta)); L->f_h2 = ar.take<float>(fm_floats((int)R, nta));
+    L->f_P1 = ar.take<float>(4 * cm_items((int)R, nta)); L->f_P2 = ar.take<float>(4 * cm_items((int)R, nta));
+    L->f_Tq = ar.take<float>(2 * 4 * cm_items((int)R, nta));  // ping-pong: the finish launch reads one, stages the next step's into the other
+    L->f_bytes = ar.off - start;
+  }
   L->step = ar.take<int>(16);
   L->slots = ar.take<unsigned long long>(2 * N);
   L->bytes = ar.off + 256;
@@ -609,6 +635,16 @@ extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* 
   // 26.4 us/step against 25.7 with the kernel boundary -- the 64-arrival fan-in + poll + fresh slot
   // read costs more than the 1.7 us boundary it removes, so the boundary stays.
   const bool merged = split && getenv("MBHIP_WAVERNN_MERGE") && atoi(getenv("MBHIP_WAVERNN_MERGE")) == 1;
+  // Production shape (rnn 512 / fc 512, <= 64 fold columns): the same chain on fragment-major activations
+  // (wavernn_fast.h), bit-identical sample stream.  MBHIP_WAVERNN_FAST=0 keeps the rnn_rowtile_body instances.
+  const char* fenv = getenv("MBHIP_WAVERNN_FAST");
+  const char* lenv = getenv("MBHIP_WAVERNN_LANES");
+  const bool fastk = split && !merged && R == 512 && FC == 512 && C % 16 == 0 && N <= 64 && !(fenv && atoi(fenv) == 0) &&
+                     !(lenv && atoi(lenv) > 1) && getenv("MBHIP_WAVERNN_NT2") == nullptr;
+  const int nta = cdiv(N, 16);
+  int fnt = 2;  // fold-column tiles per workgroup of the fast chain
+  if (const char* te = getenv("MBHIP_WAVERNN_FAST_NT")) fnt = atoi(te) == 1 ? 1 : 2;
+  if (nta < 2) fnt = 1;
   // ---- tables (time-major) + the zero-conditioning row = bias ----
   RC(run_cond_conv(w->t_I, L.cond, T, L.Ipre, nullptr, 0, 1, s));
   RC(run_cond_conv(w->t_g2, L.aux + (size_t)1 * A * F, F, L.G2, nullptr, 0, 1, s));
@@ -627,6 +663,31 @@ extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* 
     MB_HIP(hipMemsetAsync(L.step, 0, sizeof(int) * 16, s));
     MB_HIP(hipMemsetAsync(L.slots, 0, sizeof(unsigned long long) * 2 * N, s));
   }
+  WfGeom wg;
+  wg.step_base = L.step; wg.step_off = 0; wg.fold_stride = plan->fold_stride; wg.total_len = T; wg.hop = w->hop; wg.frames = F;
+  wg.nta = nta; wg.N = N;
+  auto fc_hh = [&](int g, int n_fc, int soff, hipStream_t st) {  // launch C (g = 0) / D (g = 1); n_fc = 0: hidden halves only
+    WfFcHhK k;
+    k.g = wg; k.g.step_off = soff;
+    k.w_fc = g ? w->w_fc2.p : w->w_fc1.p; k.xin = g ? L.f_y1 : L.f_x2; k.F = g ? L.F2 : L.F1; k.y = g ? L.f_y2 : L.f_y1;
+    k.n_fc = n_fc; k.FC = FC;
+    k.w_hh = g ? w->f_hh2t.p : w->f_hh1t.p; k.h = g ? L.f_h2 : L.f_h1;
+    k.bhh4 = reinterpret_cast<const float4*>(g ? w->f_bhh2q.p : w->f_bhh1q.p); k.P = reinterpret_cast<float4*>(g ? L.f_P2 : L.f_P1);
+    const dim3 grid(n_fc + R / 4, cdiv(nta, fnt));
+    if (fnt == 2) hipLaunchKernelGGL(wf_fc_hh_kernel<2>, grid, dim3(512), 0, st, k);
+    else hipLaunchKernelGGL(wf_fc_hh_kernel<1>, grid, dim3(512), 0, st, k);
+  };
+  if (fastk && !rc) {  // zero state; P = W_hh.0 + b_hh for the first step by the loop's own hidden-half jobs
+    MB_HIP(hipMemsetAsync(L.f_x1, 0, L.f_bytes, s));
+    fc_hh(0, 0, 0, s);
+    fc_hh(1, 0, 0, s);
+    {  // table rows of step 0
+      WfStageK sk;
+      sk.T1 = L.T1; sk.Ipre = L.Ipre; sk.Tq = reinterpret_cast<float4*>(L.f_Tq); sk.R = R; sk.step_add = 0;
+      hipLaunchKernelGGL(wf_stage_kernel, dim3(cdiv((R / 4) * nta, 8)), dim3(512), 0, s, sk, wg);  // -> buffer 0 (step parity 0)
+    }
+    MB_HIP(hipGetLastError());
+  } else
   if (split && !rc) {  // P = W_hh.0 + b_hh for the first step, by the same launch the loop uses
     for (int g = 0; g < 2 && !rc; ++g) {
       RnnK k;
@@ -677,6 +738,36 @@ extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* 
     // h1 = rnn1(x, h1); x = x + h1   :196-198
     unsigned long long* slot_prev = L.slots + (size_t)(pp ^ 1) * N + n0;  // written by fc3 of step s-1
     unsigned long long* slot_cur = L.slots + (size_t)pp * N + n0;         // written by fc3 of this step
+    if (fastk) {  // wavernn_fast.h: A | B | C | D | E on FM activations (one lane: n0 = 0, nl = N)
+      if (which & 1) {
+        WfFinK f;
+        f.g = wg; f.g.step_off = soff; f.slot = slot_prev; f.P1 = reinterpret_cast<const float4*>(L.f_P1);
+        const size_t tqn = cm_items(R, nta);  // float4 items per buffer
+        f.Tq = reinterpret_cast<const float4*>(L.f_Tq) + (size_t)pp * tqn;
+        f.stage.T1 = L.T1; f.stage.Ipre = L.Ipre; f.stage.Tq = reinterpret_cast<float4*>(L.f_Tq) + (size_t)(pp ^ 1) * tqn; f.stage.R = R; f.stage.step_add = 1;
+        f.n_fin = R / 16;
+        f.g1 = w->g1I0.p; f.wI0 = w->wI0.p; f.h1 = L.f_h1; f.x1 = L.f_x1; f.samples = d_samples; f.progress = h_progress;
+        f.R = R; f.C = C; f.S = S;
+        hipLaunchKernelGGL(wf_finish_kernel, dim3(R / 16 + cdiv((R / 4) * nta, 4), nta), dim3(256), 0, ls, f);
+      }
+      if (which & 2) {
+        WfRnn2K k2;
+        k2.g = wg; k2.g.step_off = soff; k2.w = w->w_rnn2x.p; k2.x1 = L.f_x1; k2.P2 = reinterpret_cast<const float4*>(L.f_P2); k2.G2 = L.G2;
+        k2.h2 = L.f_h2; k2.x2 = L.f_x2; k2.zero_slot = slot_prev; k2.R = R;
+        if (fnt == 2) hipLaunchKernelGGL(wf_rnn2_kernel<2>, dim3(R / 4, cdiv(nta, 2)), dim3(512), 0, ls, k2);
+        else hipLaunchKernelGGL(wf_rnn2_kernel<1>, dim3(R / 4, nta), dim3(512), 0, ls, k2);
+      }
+      if (which & 4) fc_hh(0, FC / 16, soff, ls);
+      if (which & 8) fc_hh(1, FC / 16, soff, ls);
+      if (which & 16) {
+        WfFc3K k3;
+        k3.g = wg; k3.g.step_off = soff; k3.w = w->w_fc3.p; k3.bias = w->b_fc3.p; k3.xin = L.f_y2; k3.slot = slot_cur; k3.seed = seed; k3.C = C;
+        if (fnt == 2) hipLaunchKernelGGL(wf_fc3_kernel<2>, dim3(C / 16, cdiv(nta, 2)), dim3(512), 0, ls, k3);
+        else hipLaunchKernelGGL(wf_fc3_kernel<1>, dim3(C / 16, nta), dim3(512), 0, ls, k3);
+      }
+      MB_HIP(hipGetLastError());
+      return MB_OK;
+    }
     if (split) {
       float* P1 = L.P1 + (size_t)n0 * 3 * R; float* P2 = L.P2 + (size_t)n0 * 3 * R;
       // (A) rnn1, elementwise: every product is precomputed (T1 table, P1 from the previous step).
