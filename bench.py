@@ -669,13 +669,14 @@ def main():
                 torch.cuda.synchronize()
                 tp = (time.perf_counter() - t0p) / 3
                 steps_p = pm.shape[1]
-                entry[f"batch{pb}"] = {"ms": tp * 1e3, "steps": int(steps_p), "us_per_step": tp * 1e6 / steps_p,
-                                       "mel_frames_per_s": pb * steps_p * 2 / tp}
+                lm = getattr(pdec, "last_loop_ms", None)  # HIP events around the loop (mb_ppg2mel_last_loop_ms)
+                entry[f"batch{pb}"] = {"ms": tp * 1e3, "steps": int(steps_p), "us_per_step": (lm * 1e3 if lm else tp * 1e6) / steps_p,
+                                       "wall_us_per_step": tp * 1e6 / steps_p, "mel_frames_per_s": pb * steps_p * 2 / tp}
             # 19.1 MB of fp32 weights are touched once per step (attention LSTM 7.3 MB, decoder LSTM 10.5 MB, rest 1.3 MB)
             wbytes = 4.0 * (256 * 80 + 128 * 256 + 2048 * (384 + 512) + 256 * 512 + 15 * 256 + 2048 * (768 + 512) + 161 * 768)
             entry["workload"] = ("ppg2mel Decoder.inference loop (prenet, attention LSTMCell, MoL attention, decoder LSTMCell, "
                                  "projection + stop), T_enc = 200, 400 steps forced, fp32, on-device dropout RNG")
-            entry["roofline"] = {"bound": "hbm", "kernel": "decoder step (8 launches), weights streamed once per step",
+            entry["roofline"] = {"bound": "hbm", "kernel": "decoder step (ppg_fast.h: 6 launches per step, hipGraph replays), weights streamed once per step",
                                  "achieved": wbytes / (entry["batch1"]["us_per_step"] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": wbytes / (entry["batch1"]["us_per_step"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                  "traffic": None, "algorithmic_bytes_per_step": wbytes}

@@ -435,6 +435,9 @@ size_t mb_ppg2mel_workspace_bytes(const mb_ppg2mel* p, int batch);
  * [max_steps][batch][prenet_dims[l]] inside; NULL -> Philox(seed).  Outputs are per step, untruncated:
  * d_mel [batch][max_steps][frames_per_step*num_mels], d_align [batch][max_steps][t_enc],
  * d_stop [batch][max_steps] (logits); *h_n_steps = steps produced. */
+/* Duration of the decoder loop of the last mb_ppg2mel_decode call (HIP events on the loop's stream) and the steps it
+ * produced; production-dims handles only (the graph-replayed step of ppg_fast.h), MB_ESTATE otherwise. */
+int mb_ppg2mel_last_loop_ms(const mb_ppg2mel* p, float* ms, int* steps);
 int mb_ppg2mel_decode(const mb_ppg2mel* p, const float* d_memory, int batch, int t_enc, int max_steps,
                       int min_steps, float stop_threshold, const float* d_dropout, uint64_t seed,
                       float* d_mel, float* d_align, float* d_stop, int* h_n_steps, void* d_workspace,

@@ -123,4 +123,37 @@ __device__ __forceinline__ bool fm_gemm(const float* __restrict__ w, const int m
 
 template <int NT, int NPART> struct FmRed { static constexpr int floats = 8 * NT * NPART * 256; };
 
+// flags block in the workspace (ints): [0] done, [1] n_frames, [2] arrival ticket, [3] utterances below the stop
+// threshold, [4] iteration index of the first launch of the current graph replay, [6..7] 64-bit dropout seed
+enum { TF_DONE = 0, TF_NFRAMES = 1, TF_ARRIVE = 2, TF_NOTREADY = 3, TF_ITER = 4, TF_SEED = 6 };
+
+// ---- always-on PreNet dropout (pre_net.py:23,26) of a relu'd row quad; same masks / same Philox stream as the
+//      general paths (rnn_body.h): Philox(iter, layer, n, row/4); masks [iteration][column][row] per layer ----
+struct DropK {
+  const float* mask;       // injected keep masks of THIS layer (iteration 0) or null
+  long long it_stride;     // floats between the masks of consecutive iterations
+  int ld;                  // row length of a mask
+  int layer, it_add;       // prenet layer (Philox key); iteration offset (a job of launch `it` may prepare iteration it + 1)
+  int it_limit;            // iterations covered by `mask`: the job that prepares iteration it_limit (never run) reads nothing
+  unsigned thresh; float scale; int enabled;
+};
+__device__ __forceinline__ void relu_drop_quad(const DropK& d, const int* flags, int it, int n, int row0, float (&v)[4]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+  if (!d.enabled) return;
+  const int iter = it + d.it_add;
+  if (d.mask) {
+    if (iter >= d.it_limit) return;
+    const float4 m = *reinterpret_cast<const float4*>(d.mask + (long long)iter * d.it_stride + (size_t)n * d.ld + row0);
+    v[0] *= m.x * d.scale; v[1] *= m.y * d.scale; v[2] *= m.z * d.scale; v[3] *= m.w * d.scale;
+  } else {
+    const unsigned long long seed = *reinterpret_cast<const unsigned long long*>(flags + TF_SEED);
+    uint32_t rr[4];
+    philox4x32((uint32_t)iter, (uint32_t)d.layer, (uint32_t)n, (uint32_t)(row0 >> 2), (uint32_t)seed, (uint32_t)(seed >> 32), rr);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] *= (rr[r] >= d.thresh) ? d.scale : 0.f;
+  }
+}
+
+
 }  // namespace mb

@@ -13,6 +13,7 @@
 // (frames / stop logits to the outputs, batch-wide stop rule).  The next step's prenet reads the last
 // frame straight out of the projection buffer.  fp32 throughout.
 #include "rnn.h"
+#include "ppg_fast.h"
 
 namespace mb {
 
@@ -136,6 +137,20 @@ struct mb_ppg2mel {
   DevBuf q0_w, q0_b, q2_w, q2_b;
   std::vector<DevBuf> dec_w, dec_bih, dec_bhh;
   DevBuf out_w, out_b;  // projection rows then the stop row
+  // fast step (ppg_fast.h), production dims only
+  bool fast = false;
+  DevBuf f_att_p, f_att_c, f_att_h, f_att_b4, f_dec_x, f_dec_h, f_dec_b4, f_fc0_w, f_fc0_b;
+  struct GraphKey { const void *mem, *drop, *mel, *align, *stop, *ws; int B, T, max_steps, min_steps, G; float thr; } gkey = {};
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  int* h_flags = nullptr;
+  hipEvent_t ev_flags[2] = {nullptr, nullptr}, ev_in = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+  hipStream_t loop_stream = nullptr;
+  int last_steps = 0; bool timed = false;
+  void drop_graph() {
+    if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+    if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
+  }
 };
 
 static int ppg_shapes(const mb_ppg2mel_config* c, std::vector<size_t>* numel) {
@@ -179,8 +194,14 @@ extern "C" void mb_ppg2mel_destroy(mb_ppg2mel* p) {
   for (auto& b : p->dec_w) b.release();
   for (auto& b : p->dec_bih) b.release();
   for (auto& b : p->dec_bhh) b.release();
-  DevBuf* bs[] = {&p->zero_bias, &p->att_w, &p->att_bih, &p->att_bhh, &p->q0_w, &p->q0_b, &p->q2_w, &p->q2_b, &p->out_w, &p->out_b};
+  DevBuf* bs[] = {&p->zero_bias, &p->att_w, &p->att_bih, &p->att_bhh, &p->q0_w, &p->q0_b, &p->q2_w, &p->q2_b, &p->out_w, &p->out_b,
+                  &p->f_att_p, &p->f_att_c, &p->f_att_h, &p->f_att_b4, &p->f_dec_x, &p->f_dec_h, &p->f_dec_b4, &p->f_fc0_w, &p->f_fc0_b};
   for (DevBuf* b : bs) b->release();
+  p->drop_graph();
+  if (p->h_flags) (void)hipHostFree(p->h_flags);
+  hipEvent_t evs[] = {p->ev_flags[0], p->ev_flags[1], p->ev_in, p->ev_t0, p->ev_t1};
+  for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+  if (p->loop_stream) (void)hipStreamDestroy(p->loop_stream);
   delete p;
 }
 
@@ -237,6 +258,54 @@ extern "C" int mb_ppg2mel_create(const mb_ppg2mel_config* cfg, const float* cons
     RC(p->out_w.upload(packed.data(), packed.size())); RC(p->out_b.upload(b.data(), b.size()));
     ix += 4;
   }
+  p->fast = cfg->n_prenet == 2 && cfg->prenet_dims[0] == 256 && cfg->prenet_dims[1] == 128 && E == 256 && A == 512 && D == 512 &&
+            cfg->num_decoder_rnn_layer == 1 && cfg->concat_context_to_last && (nm * r) % 16 == 0 && nm % 4 == 0 && M <= 16;
+  if (p->fast && !rc) {
+    // weight list: 0-1 prenet, 2-5 attention_rnn (w_ih [4A][P+E], w_hh, b_ih, b_hh), 6-9 query layers, 10-13 decoder rnn, 14-17 projection / stop
+    const int Pn = cfg->prenet_dims[1];
+    const float *a_wih = hw[2], *a_whh = hw[3], *a_bih = hw[4], *a_bhh = hw[5];
+    const float *d_wih = hw[10], *d_whh = hw[11], *d_bih = hw[12], *d_bhh = hw[13];
+    const float *w_proj = hw[14], *b_proj = hw[15];
+    cell_rows(a_wih, Pn, Pn + E, a_whh, 0, A, 4, &rows); pack_rowtile(rows.data(), 4 * A, Pn, 4, &packed); RC(p->f_att_p.upload(packed.data(), packed.size()));
+    cell_rows(a_wih + Pn, E, Pn + E, a_whh, 0, A, 4, &rows); pack_rowtile(rows.data(), 4 * A, E, 4, &packed); RC(p->f_att_c.upload(packed.data(), packed.size()));
+    cell_rows(a_whh, A, A, a_whh, 0, A, 4, &rows); pack_rowtile(rows.data(), 4 * A, A, 4, &packed); RC(p->f_att_h.upload(packed.data(), packed.size()));
+    cell_rows(d_wih, A + E, A + E, d_whh, 0, D, 4, &rows); pack_rowtile(rows.data(), 4 * D, A + E, 4, &packed); RC(p->f_dec_x.upload(packed.data(), packed.size()));
+    cell_rows(d_whh, D, D, d_whh, 0, D, 4, &rows); pack_rowtile(rows.data(), 4 * D, D, 4, &packed); RC(p->f_dec_h.upload(packed.data(), packed.size()));
+    std::vector<float> b4((size_t)A * 4);
+    for (int j = 0; j < A; ++j) for (int g = 0; g < 4; ++g) b4[(size_t)j * 4 + g] = a_bih[g * A + j] + a_bhh[g * A + j];
+    RC(p->f_att_b4.upload(b4.data(), b4.size()));
+    b4.assign((size_t)D * 4, 0.f);
+    for (int j = 0; j < D; ++j) for (int g = 0; g < 4; ++g) b4[(size_t)j * 4 + g] = d_bih[g * D + j] + d_bhh[g * D + j];
+    RC(p->f_dec_b4.upload(b4.data(), b4.size()));
+    {  // prenet.0 (bias-free, [P0][nm]) folded through the projection's LAST frame rows (r-1)*nm + m: W' = W0 . Wp_last, b' = W0 . bp_last
+      const int P0 = cfg->prenet_dims[0], kout = D + E;
+      std::vector<float> wf((size_t)P0 * kout), bf(P0);
+      std::vector<double> acc(kout);
+      for (int o = 0; o < P0; ++o) {
+        std::fill(acc.begin(), acc.end(), 0.0);
+        double ab = 0.0;
+        for (int m = 0; m < nm; ++m) {
+          const double f = hw[0][(size_t)o * nm + m];
+          const float* pr = w_proj + ((size_t)(r - 1) * nm + m) * kout;
+          for (int k2 = 0; k2 < kout; ++k2) acc[k2] += f * (double)pr[k2];
+          ab += f * (double)b_proj[(r - 1) * nm + m];
+        }
+        for (int k2 = 0; k2 < kout; ++k2) wf[(size_t)o * kout + k2] = (float)acc[k2];
+        bf[o] = (float)ab;
+      }
+      pack_rowtile(wf.data(), P0, kout, 4, &packed); RC(p->f_fc0_w.upload(packed.data(), packed.size()));
+      RC(p->f_fc0_b.upload(bf.data(), bf.size()));
+    }
+    if (!rc && (hipHostMalloc((void**)&p->h_flags, sizeof(int) * 16) != hipSuccess ||
+                hipStreamCreateWithFlags(&p->loop_stream, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&p->ev_in, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreate(&p->ev_t0) != hipSuccess || hipEventCreate(&p->ev_t1) != hipSuccess ||
+                hipEventCreateWithFlags(&p->ev_flags[0], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&p->ev_flags[1], hipEventDisableTiming) != hipSuccess)) {
+      set_error("ppg2mel_create: stream / events / pinned flags");
+      rc = MB_EHIP;
+    }
+  }
 #undef RC
   if (rc) { mb_ppg2mel_destroy(p); return rc; }
   *out = p;
@@ -246,6 +315,9 @@ extern "C" int mb_ppg2mel_create(const mb_ppg2mel_config* cfg, const float* cons
 namespace {
 struct PpgLayout {
   float *pbuf[4], *att_h, *att_c, *ctx, *q, *mu, *dec_h[4], *dec_c[4], *y, *zero;
+  // fast step: FM activations (p0, p1, att_h, q, ctx, dec_h), CM1 cells, CM4 gate parts
+  float *f_p0, *f_p1, *f_ah, *f_q, *f_ctx, *f_dh, *f_ac, *f_dc, *f_prec, *f_preh, *f_pred;
+  size_t f_bytes;
   int* flags;
   size_t bytes;
   int ldy;
@@ -264,7 +336,19 @@ void ppg_layout(const mb_ppg2mel* p, int B, void* base, PpgLayout* L) {
   L->ldy = (c.num_mels * c.frames_per_step + 1 + 3) & ~3;  // rows of 16-byte multiples: the next prenet reads frames in place
   L->y = ar.take<float>((size_t)B * L->ldy);
   L->zero = ar.take<float>((size_t)B * L->ldy);
-  L->flags = ar.take<int>(8);
+  {
+    const int nta = (B + 15) / 16, A = c.attention_rnn_dim, D = c.decoder_rnn_dim;
+    L->f_p0 = ar.take<float>(fm_floats(c.prenet_dims[0], nta));
+    const size_t start = ar.off - fm_floats(c.prenet_dims[0], nta) * sizeof(float);
+    L->f_p1 = ar.take<float>(fm_floats(c.prenet_dims[c.n_prenet - 1], nta));
+    L->f_ah = ar.take<float>(fm_floats(A, nta)); L->f_q = ar.take<float>(fm_floats(256, nta));
+    L->f_ctx = ar.take<float>(fm_floats(c.enc_dim, nta)); L->f_dh = ar.take<float>(fm_floats(D, nta));
+    L->f_ac = ar.take<float>(cm_items(A, nta)); L->f_dc = ar.take<float>(cm_items(D, nta));
+    L->f_prec = ar.take<float>(4 * cm_items(A, nta)); L->f_preh = ar.take<float>(4 * cm_items(A, nta));
+    L->f_pred = ar.take<float>(4 * cm_items(D, nta));
+    L->f_bytes = ar.off - start;
+  }
+  L->flags = ar.take<int>(16);
   L->bytes = ar.off + 256;
 }
 }  // namespace
@@ -274,6 +358,128 @@ extern "C" size_t mb_ppg2mel_workspace_bytes(const mb_ppg2mel* p, int batch) {
   PpgLayout L;
   ppg_layout(p, batch, nullptr, &L);
   return L.bytes;
+}
+
+// ---- fast step (ppg_fast.h): 6 launches per step, hipGraph replays of 16 steps, stop flag polled one replay behind ----
+static int ppg_fast_loop_body(mb_ppg2mel* p, const PpgLayout& L, const float* d_memory, int B, int T, int max_steps, int min_steps,
+                              float thr, const float* d_dropout, uint64_t seed, float* d_mel, float* d_align, float* d_stop,
+                              void* d_workspace, hipStream_t s, int* steps_out) {
+  const mb_ppg2mel_config& c = p->cfg;
+  const int E = c.enc_dim, A = c.attention_rnn_dim, D = c.decoder_rnn_dim, nm = c.num_mels, r = c.frames_per_step;
+  const int RM = nm * r, Q = 256, M = c.num_mixtures, P0 = c.prenet_dims[0], P1 = c.prenet_dims[1];
+  const int nta = cdiv(B, 16), gy = nta >= 2 ? cdiv(nta, 2) : nta;
+  int* flags = L.flags;
+  MB_HIP(hipMemsetAsync(L.f_p0, 0, L.f_bytes, s));  // zero states, zero go frame -> p0 = 0, gate parts = 0 (DecoderPrenet is bias-free)
+  MB_HIP(hipMemcpyAsync(flags + TF_SEED, &seed, sizeof(seed), hipMemcpyHostToDevice, s));
+  DropK dk;
+  dk.thresh = 0x80000000u; dk.scale = 2.f; dk.enabled = 1; dk.it_add = 0; dk.it_limit = max_steps;  // F.dropout(p = 0.5, training = True)   DecoderPrenet :18-21
+  const size_t lds_mol = std::max(sizeof(float) * (((size_t)Q + 3 * M + 1 + 2 * T + 1 + 3) & ~(size_t)3) + 8 * 64 * 16,
+                                  sizeof(float) * (size_t)(nta >= 2 ? FmRed<2, 1>::floats : FmRed<1, 1>::floats));
+  MB_REQUIRE(lds_mol <= 160 * 1024, "ppg2mel_decode: memory too long for the attention window in LDS (T=%d)", T);
+  if (lds_mol > 48 * 1024) {
+    MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppg_mol_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mol));
+    MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppg_mol_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mol));
+  }
+  auto step = [&](int it_off) -> int {
+    const dim3 blk(512);
+#define PF_LAUNCH(KERNEL, GX, ...)                                                            \
+    do {                                                                                       \
+      if (nta >= 2) hipLaunchKernelGGL((KERNEL<2>), dim3(GX, gy), blk, 0, s, __VA_ARGS__);     \
+      else hipLaunchKernelGGL((KERNEL<1>), dim3(GX, gy), blk, 0, s, __VA_ARGS__);              \
+    } while (0)
+    PfFc1K f1;
+    f1.w = p->pre_w[1].p; f1.p0 = L.f_p0; f1.p1 = L.f_p1; f1.nta = nta; f1.B = B; f1.it_off = it_off; f1.flags = flags;
+    f1.drop = dk; f1.drop.layer = 1; f1.drop.ld = P1; f1.drop.it_stride = (long long)B * P1;
+    f1.drop.mask = d_dropout ? d_dropout + (size_t)max_steps * B * P0 : nullptr;
+    PF_LAUNCH(ppg_fc1_kernel, P1 / 16, f1);
+    PfLstmK la;
+    la.w = p->f_att_p.p; la.x0 = L.f_p1; la.x1 = L.f_p1; la.pre_a = reinterpret_cast<const float4*>(L.f_prec);
+    la.pre_b = reinterpret_cast<const float4*>(L.f_preh); la.b4 = reinterpret_cast<const float4*>(p->f_att_b4.p);
+    la.h = L.f_ah; la.c = L.f_ac; la.nta = nta; la.flags = flags;
+    if (nta >= 2) hipLaunchKernelGGL((ppg_lstm_kernel<2, 1, 1>), dim3(A / 4, gy), blk, 0, s, la);
+    else hipLaunchKernelGGL((ppg_lstm_kernel<1, 1, 1>), dim3(A / 4, gy), blk, 0, s, la);
+    PfQ0K q0;
+    q0.w = p->q0_w.p; q0.bias = p->q0_b.p; q0.att_h = L.f_ah; q0.q = L.f_q; q0.n_q = Q / 16; q0.nta = nta; q0.flags = flags;
+    q0.hh.w = p->f_att_h.p; q0.hh.x = L.f_ah; q0.hh.out = reinterpret_cast<float4*>(L.f_preh); q0.hh.n_tiles = A / 4;
+    PF_LAUNCH(ppg_q0_kernel, Q / 16 + A / 4, q0);
+    PfMolK mk;
+    mk.q = L.f_q; mk.w2 = p->q2_w.p; mk.b2 = p->q2_b.p; mk.memory = d_memory; mk.mu = L.mu; mk.ctx = L.f_ctx; mk.align_out = d_align;
+    mk.T = T; mk.E = E; mk.Q = Q; mk.M = M; mk.nta = nta; mk.it_off = it_off; mk.max_steps = max_steps; mk.eps = 1e-5f; mk.flags = flags;
+    PfPreK dh;
+    dh.w = p->f_dec_h.p; dh.x = L.f_dh; dh.out = reinterpret_cast<float4*>(L.f_pred); dh.n_tiles = D / 4;
+    if (nta >= 2) hipLaunchKernelGGL(ppg_mol_kernel<2>, dim3(B + (D / 4) * gy), blk, lds_mol, s, mk, dh, B, gy);
+    else hipLaunchKernelGGL(ppg_mol_kernel<1>, dim3(B + (D / 4) * gy), blk, lds_mol, s, mk, dh, B, gy);
+    PfLstmK ld;
+    ld.w = p->f_dec_x.p; ld.x0 = L.f_ah; ld.x1 = L.f_ctx; ld.pre_a = reinterpret_cast<const float4*>(L.f_pred); ld.pre_b = nullptr;
+    ld.b4 = reinterpret_cast<const float4*>(p->f_dec_b4.p); ld.h = L.f_dh; ld.c = L.f_dc; ld.nta = nta; ld.flags = flags;
+    if (nta >= 2) hipLaunchKernelGGL((ppg_lstm_kernel<2, 6, 4>), dim3(D / 4, gy), blk, 0, s, ld);
+    else hipLaunchKernelGGL((ppg_lstm_kernel<1, 6, 4>), dim3(D / 4, gy), blk, 0, s, ld);
+    PfOutK ok;
+    ok.w_out = p->out_w.p; ok.b_out = p->out_b.p; ok.w_fc0 = p->f_fc0_w.p; ok.b_fc0 = p->f_fc0_b.p; ok.h = L.f_dh; ok.ctx = L.f_ctx;
+    ok.p0 = L.f_p0; ok.mel_out = d_mel; ok.stop_out = d_stop;
+    ok.cpart.w = p->f_att_c.p; ok.cpart.x = L.f_ctx; ok.cpart.out = reinterpret_cast<float4*>(L.f_prec); ok.cpart.n_tiles = A / 4;
+    ok.nta = nta; ok.B = B; ok.n_proj = RM / 16; ok.n_fc0 = P0 / 16; ok.RM = RM; ok.max_steps = max_steps; ok.min_steps = min_steps;
+    ok.it_off = it_off; ok.thr = thr; ok.flags = flags;
+    ok.drop = dk; ok.drop.layer = 0; ok.drop.it_add = 1; ok.drop.ld = P0; ok.drop.it_stride = (long long)B * P0; ok.drop.mask = d_dropout;
+    PF_LAUNCH(ppg_out_kernel, RM / 16 + P0 / 16 + 1 + A / 4, ok);
+#undef PF_LAUNCH
+    MB_HIP(hipGetLastError());
+    return MB_OK;
+  };
+  MB_HIP(hipEventRecord(p->ev_t0, s));
+  int G = 16;
+  if (const char* ge = getenv("MBHIP_PPG_GRAPH_STEPS")) G = std::max(1, atoi(ge));
+  const bool use_graph = getenv("MBHIP_NO_GRAPH") == nullptr && max_steps >= G;
+  int done_steps = 0, rc = MB_OK;
+  bool stopped = false;
+  if (use_graph) {
+    mb_ppg2mel::GraphKey key = {d_memory, d_dropout, d_mel, d_align, d_stop, d_workspace, B, T, max_steps, min_steps, G, thr};
+    if (!p->graph_exec || memcmp(&key, &p->gkey, sizeof(key)) != 0) {
+      p->drop_graph();
+      MB_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+      for (int i = 0; i < G && !rc; ++i) rc = step(i);
+      hipLaunchKernelGGL(ppg_bump_kernel, dim3(1), dim3(1), 0, s, flags, G);
+      hipError_t e = hipStreamEndCapture(s, &p->graph);
+      if (rc) { p->drop_graph(); return rc; }
+      if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture", __FILE__, __LINE__);
+      e = hipGraphInstantiate(&p->graph_exec, p->graph, nullptr, nullptr, 0);
+      if (e != hipSuccess) { p->drop_graph(); return hip_fail(e, "hipGraphInstantiate", __FILE__, __LINE__); }
+      p->gkey = key;
+    }
+    const int reps = max_steps / G;
+    for (int rep = 0; rep < reps; ++rep) {
+      MB_HIP(hipGraphLaunch(p->graph_exec, s));
+      MB_HIP(hipMemcpyAsync(p->h_flags + 8 * (rep & 1), flags, sizeof(int) * 8, hipMemcpyDeviceToHost, s));
+      MB_HIP(hipEventRecord(p->ev_flags[rep & 1], s));
+      done_steps += G;
+      if (rep > 0) {
+        MB_HIP(hipEventSynchronize(p->ev_flags[(rep - 1) & 1]));
+        if (p->h_flags[8 * ((rep - 1) & 1) + TF_DONE]) { stopped = true; break; }
+      }
+    }
+  }
+  for (int st = done_steps; st < max_steps && !stopped; ++st) {
+    if ((rc = step(st - done_steps))) return rc;
+    if (((st - done_steps) & 15) == 15) {
+      MB_HIP(hipMemcpyAsync(p->h_flags, flags, sizeof(int) * 8, hipMemcpyDeviceToHost, s));
+      MB_HIP(hipStreamSynchronize(s));
+      if (p->h_flags[TF_DONE]) stopped = true;
+    }
+  }
+  MB_HIP(hipEventRecord(p->ev_t1, s));
+  MB_HIP(hipMemcpyAsync(p->h_flags, flags, sizeof(int) * 8, hipMemcpyDeviceToHost, s));
+  MB_HIP(hipStreamSynchronize(s));
+  *steps_out = p->h_flags[TF_NFRAMES];
+  p->last_steps = *steps_out; p->timed = true;
+  return MB_OK;
+}
+
+extern "C" int mb_ppg2mel_last_loop_ms(const mb_ppg2mel* p, float* ms, int* steps) {
+  MB_REQUIRE(p && ms, "ppg2mel_last_loop_ms: null pointer");
+  if (!p->timed) { set_error("ppg2mel_last_loop_ms: no decode on the fast loop yet"); return MB_ESTATE; }
+  MB_HIP(hipEventElapsedTime(ms, p->ev_t0, p->ev_t1));
+  if (steps) *steps = p->last_steps;
+  return MB_OK;
 }
 
 extern "C" int mb_ppg2mel_decode(const mb_ppg2mel* p, const float* d_memory, int batch, int t_enc, int max_steps,
@@ -308,6 +514,16 @@ extern "C" int mb_ppg2mel_decode(const mb_ppg2mel* p, const float* d_memory, int
   MB_HIP(hipMemsetAsync(d_mel, 0, sizeof(float) * (size_t)B * max_steps * RM, s));
   MB_HIP(hipMemsetAsync(d_align, 0, sizeof(float) * (size_t)B * max_steps * T, s));
   MB_HIP(hipMemsetAsync(d_stop, 0, sizeof(float) * (size_t)B * max_steps, s));
+  const char* fenv = getenv("MBHIP_PPG_FAST");
+  if (p->fast && !(fenv && atoi(fenv) == 0)) {  // production dims: ppg_fast.h (MBHIP_PPG_FAST=0 keeps the general loop)
+    mb_ppg2mel* pm = const_cast<mb_ppg2mel*>(p);
+    MB_HIP(hipEventRecord(pm->ev_in, s));
+    MB_HIP(hipStreamWaitEvent(pm->loop_stream, pm->ev_in, 0));
+    const int rcf = ppg_fast_loop_body(pm, L, d_memory, B, T, max_steps, min_steps, stop_threshold, d_dropout, seed, d_mel, d_align,
+                                       d_stop, d_workspace, pm->loop_stream, h_n_steps);
+    if (rcf) (void)hipStreamSynchronize(pm->loop_stream);
+    return rcf;
+  }
   int* done = L.flags;
   int* n_steps = L.flags + 1;
   // dropout masks: layer l at d_dropout + sum_{k<l} max_steps*B*dims[k], step-major inside

@@ -30,35 +30,6 @@
 
 namespace mb {
 
-// flags block in the workspace (ints): [0] done, [1] n_frames, [2] arrival ticket, [3] utterances below the stop
-// threshold, [4] iteration index of the first launch of the current graph replay, [6..7] 64-bit dropout seed
-enum { TF_DONE = 0, TF_NFRAMES = 1, TF_ARRIVE = 2, TF_NOTREADY = 3, TF_ITER = 4, TF_SEED = 6 };
-
-// ---- always-on PreNet dropout (pre_net.py:23,26) of a relu'd row quad; same masks / same Philox stream as the
-//      general path (rnn_body.h): mask [n_iter][2][B][ld], Philox(iter, layer, n, row/4) ----
-struct DropK {
-  const float* mask;  // injected keep masks or null
-  int ld;             // 2 * decoder_dims
-  int layer, it_add;  // prenet layer (0/1); iteration offset (the fc1 job of launch `it` prepares iteration it + 1)
-  unsigned thresh; float scale; int enabled;
-};
-__device__ __forceinline__ void relu_drop_quad(const DropK& d, const int* flags, int it, int B, int n, int row0, float (&v)[4]) {
-#pragma unroll
-  for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-  if (!d.enabled) return;
-  const int iter = it + d.it_add;
-  if (d.mask) {
-    const float4 m = *reinterpret_cast<const float4*>(d.mask + ((size_t)iter * 2 + d.layer) * B * d.ld + (size_t)n * d.ld + row0);
-    v[0] *= m.x * d.scale; v[1] *= m.y * d.scale; v[2] *= m.z * d.scale; v[3] *= m.w * d.scale;
-  } else {
-    const unsigned long long seed = *reinterpret_cast<const unsigned long long*>(flags + TF_SEED);
-    uint32_t rr[4];
-    philox4x32((uint32_t)iter, (uint32_t)d.layer, (uint32_t)n, (uint32_t)(row0 >> 2), (uint32_t)seed, (uint32_t)(seed >> 32), rr);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] *= (rr[r] >= d.thresh) ? d.scale : 0.f;
-  }
-}
-
 // ------------------------------------------------------------------------------------------------ fc2
 // p2 = dropout(relu(fc2 . p1 + b2))   (pre_net.py:24-26).  K = 2D = 256 -> PW = 2.
 struct TfFcK {
@@ -79,7 +50,7 @@ __global__ __launch_bounds__(512) void taco_fc2_kernel(TfFcK a) {
   if (nt >= a.nta || done) return;
   const float4 bq = *reinterpret_cast<const float4*>(a.bias + row0);
   float v[4] = {sx[0] + bq.x, sx[1] + bq.y, sx[2] + bq.z, sx[3] + bq.w};
-  relu_drop_quad(a.drop, a.flags, it, a.B, n < a.B ? n : a.B - 1, row0, v);
+  relu_drop_quad(a.drop, a.flags, it, n < a.B ? n : a.B - 1, row0, v);
   reinterpret_cast<float4*>(a.yout)[((size_t)mt * a.nta + nt) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
   tf_mark_end(a.trace, TS_FC2, 4, pick);
 }
@@ -276,7 +247,7 @@ __global__ __launch_bounds__(512) void taco_mel_kernel(TfMelK a) {
     if (nt >= a.nta || done) return;
     const float4 bq = *reinterpret_cast<const float4*>(a.b_fc1 + row0);
     float v[4] = {sx[0] + bq.x, sx[1] + bq.y, sx[2] + bq.z, sx[3] + bq.w};
-    relu_drop_quad(a.drop, a.flags, it, a.B, n < a.B ? n : a.B - 1, row0, v);
+    relu_drop_quad(a.drop, a.flags, it, n < a.B ? n : a.B - 1, row0, v);
     reinterpret_cast<float4*>(a.p1)[((size_t)mt * a.nta + nt) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
     tf_mark_end(a.trace, TS_MEL_FC1, 4, pick);
     return;
@@ -322,7 +293,7 @@ __global__ __launch_bounds__(64) void taco_p1_init_kernel(TfP1K a) {
   const int mt = blockIdx.x, nt = blockIdx.y, lane = threadIdx.x, du = lane >> 4, n = nt * 16 + (lane & 15), row0 = mt * 16 + du * 4;
   const float4 bq = *reinterpret_cast<const float4*>(a.b_fc1 + row0);
   float v[4] = {bq.x, bq.y, bq.z, bq.w};
-  relu_drop_quad(a.drop, a.flags, a.flags[TF_ITER], a.B, n < a.B ? n : a.B - 1, row0, v);
+  relu_drop_quad(a.drop, a.flags, a.flags[TF_ITER], n < a.B ? n : a.B - 1, row0, v);
   reinterpret_cast<float4*>(a.p1)[((size_t)mt * a.nta + nt) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
 }
 

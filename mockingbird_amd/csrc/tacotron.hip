@@ -1275,6 +1275,8 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
   const bool drop_enabled = c.dropout > 0.f;
   DropK dk;
   dk.mask = drop_enabled ? d_dropout : nullptr; dk.ld = 2 * D; dk.layer = 0; dk.it_add = 0;
+  dk.it_stride = (long long)2 * B * 2 * D;  // masks [n_iter][2 layers][B][2D]
+  dk.it_limit = n_iter_max;
   dk.thresh = drop_enabled ? (unsigned)std::min(4294967295.0, (double)c.dropout * 4294967296.0) : 0u;
   dk.scale = drop_enabled ? 1.f / (1.f - c.dropout) : 1.f; dk.enabled = drop_enabled ? 1 : 0;
   int* flags = L.flags;
@@ -1317,6 +1319,7 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
     TfFcK fk;
     fk.w = t->pre2_w.p; fk.bias = t->pre2_b.p; fk.xin = L.f_p1; fk.yout = L.f_p2; fk.nta = nta; fk.B = B; fk.it_off = it_off;
     fk.flags = flags; fk.drop = dk; fk.drop.layer = 1; fk.trace = tr;
+    if (fk.drop.mask) fk.drop.mask += (size_t)B * 2 * D;  // layer 1
     TF_LAUNCH(taco_fc2_kernel, 2 * D / 16, fk);
     // 2. attention GRU on the prenet columns
     TfGruK gk;

@@ -114,6 +114,9 @@ class Ppg2MelDecoder:
                                        C.byref(n), _lib.ptr(self._ws), self._ws.numel(), _lib.stream_ptr()),
                    "mb_ppg2mel_decode")
         s = n.value
+        ms, st = C.c_float(), C.c_int()
+        if L.mb_ppg2mel_last_loop_ms(self._h, C.byref(ms), C.byref(st)) == 0:  # production-dims step only
+            self.last_loop_ms, self.last_loop_steps = ms.value, st.value
         return mel[:, :s], align[:, :s], stop[:, :s]
 
     def inference(self, memory, stop_threshold=0.5, dropout=None, seed=None):
