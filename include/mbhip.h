@@ -240,7 +240,8 @@ typedef struct mb_wavernn_config {
   int rnn_dims, fc_dims, bits, pad;
   int n_upsample; int upsample_factors[4];
   int feat_dims, compute_dims, res_out_dims, res_blocks;
-  int mode;  /* 0 = RAW (softmax over 2^bits classes); MOL is not on the hot path */
+  int mode;  /* 0 = RAW (softmax over 2^bits classes, fatchord_version.py:222-228); 1 = MOL (30 fc3 outputs = 10 x (logit, mean,
+              * log scale) of a discretised mixture of logistics, :213-220 + models/vocoder/distribution.py:87-123) */
 } mb_wavernn_config;
 
 typedef struct mb_wavernn mb_wavernn;
@@ -269,7 +270,10 @@ int mb_wavernn_plan_generate(const mb_wavernn* w, int frames, int batched, int t
  * d_noise: NULL -> on-device counter RNG (seed); else Exp(1) draws
  *        [seq_len][n_folds][n_classes] consumed exactly like
  *        torch.multinomial(p,1) == argmax(p / noise).
- * d_samples: [n_folds][seq_len] float32 in [-1,1] (2*k/(C-1)-1), the tensor the
+ *        MOL mode: uniform(1e-5, 1 - 1e-5) draws [seq_len][n_folds][11]: per step and fold the 10 mixture-indicator
+ *        draws, then the logistic draw -- the order sample_from_discretized_mix_logistic consumes them
+ *        (models/vocoder/distribution.py:105,118).
+ * d_samples: [n_folds][seq_len] float32 in [-1,1] (RAW: 2*k/(C-1)-1; MOL: the logistic sample), the tensor the
  *        reference stacks at fatchord_version.py:236.
  * d_logits_out: optional [seq_len][n_folds][n_classes] dump of fc3 outputs (tests).
  * d_forced: optional teacher forcing: [n_folds][seq_len] samples fed back

@@ -202,6 +202,70 @@ __global__ __launch_bounds__(64) void wavernn_sample_kernel(SampK a) {
   trace_end(a.trace);
 }
 
+// MOL mode (fatchord_version.py:213-220 -> models/vocoder/distribution.py:87-123, B = 1, T = folds): the 3 * nr_mix fc3
+// outputs are (mixture logits | means | log scales); pick the mixture by Gumbel-argmax over logits - log(-log u_m),
+// sample x = mean + exp(max(log_scale, log 1e-14)) * (log u - log(1 - u)), clamp to [-1, 1].  One wavefront per fold,
+// lane c holds output c.  Noise: injected uniforms [S][N_total][nr_mix + 1] (the reference's two uniform_(1e-5, 1 - 1e-5)
+// draws of a step: nr_mix indicator draws, then the logistic draw) or Philox.
+__global__ __launch_bounds__(64) void wavernn_sample_mol_kernel(SampK a, int nr_mix) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  const int gn = a.n_off + n;
+  const float lg = lane < a.C ? a.logits[(size_t)n * a.C + lane] : 0.f;
+  const int s = *a.step_base + a.step_off;
+  const long long pos = (long long)gn * a.fold_stride + (s + 1);
+  const long long ipos = pos < a.total_len ? pos : a.total_len;
+  const float* ip = a.Ipre + ipos * a.R;
+  constexpr int R4MAX = 4;  // R <= 1024
+  float4 ipv[R4MAX], w0v[R4MAX];
+#pragma unroll
+  for (int q = 0; q < R4MAX; ++q) {
+    const int j = (q * 64 + lane) * 4;
+    const int jc = j < a.R ? j : 0;
+    ipv[q] = *reinterpret_cast<const float4*>(ip + jc);
+    w0v[q] = *reinterpret_cast<const float4*>(a.wI0 + jc);
+  }
+  float u;
+  if (a.noise) u = lane <= nr_mix ? a.noise[((size_t)s * a.N_total + gn) * (nr_mix + 1) + lane] : 0.5f;
+  else {
+    uint32_t r[4];
+    philox4x32((uint32_t)s, (uint32_t)gn, (uint32_t)(lane >> 2), 0x4d4f4c21u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r);
+    u = 1e-5f + (1.0f - 2e-5f) * (u32_to_unit(r[lane & 3]) - 0.5f / 16777216.0f);  // uniform_(1e-5, 1 - 1e-5)
+  }
+  const float forced = a.forced ? a.forced[(size_t)gn * a.S + s] : 0.f;
+  if (a.logits_out && lane < a.C) a.logits_out[((size_t)s * a.N_total + gn) * a.C + lane] = lg;
+  // mixture indicator: argmax_m logit_m - log(-log u_m), first maximum on ties
+  float best = lane < nr_mix ? lg - logf(-logf(u)) : -INFINITY;
+  int bidx = lane < nr_mix ? lane : 0x7fffffff;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bidx, o, 64);
+    if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+  }
+  const float mean = __shfl(lg, nr_mix + bidx, 64);
+  const float ls = fmaxf(__shfl(lg, 2 * nr_mix + bidx, 64), -32.23619130191664f);  // log(1e-14)
+  const float uu = __shfl(u, nr_mix, 64);
+  float x = mean + expf(ls) * (logf(uu) - logf(1.f - uu));
+  x = fminf(fmaxf(x, -1.f), 1.f);
+  if (lane == 0) {
+    a.samples[(size_t)gn * a.S + s] = x;
+    if (a.progress && gn == 0 && (s % 100 == 0 || s == a.S - 1)) *a.progress = s + 1;
+  }
+  const float xfb = a.forced ? forced : x;
+  if (s + 1 < a.S) {
+#pragma unroll
+    for (int q = 0; q < R4MAX; ++q) {
+      const int j = (q * 64 + lane) * 4;
+      if (j < a.R) {
+        float4 o;
+        o.x = ipv[q].x + xfb * w0v[q].x; o.y = ipv[q].y + xfb * w0v[q].y;
+        o.z = ipv[q].z + xfb * w0v[q].z; o.w = ipv[q].w + xfb * w0v[q].w;
+        *reinterpret_cast<float4*>(a.x0 + (size_t)n * a.R + j) = o;
+      }
+    }
+  }
+}
+
 }  // namespace mb
 
 using namespace mb;
@@ -253,14 +317,14 @@ struct mb_wavernn {
 
 static int wavernn_shapes(const mb_wavernn_config* c, std::vector<size_t>* numel) {
   MB_REQUIRE(c, "wavernn: null config");
-  MB_REQUIRE(c->mode == 0, "wavernn: only RAW mode is on the hot path (hparams.py voc_mode='RAW')");
+  MB_REQUIRE(c->mode == 0 || c->mode == 1, "wavernn: mode must be 0 (RAW) or 1 (MOL)");
   MB_REQUIRE(c->n_upsample >= 1 && c->n_upsample <= 4, "wavernn: n_upsample");
   MB_REQUIRE(c->rnn_dims % 16 == 0 && c->fc_dims % 16 == 0, "wavernn: rnn_dims/fc_dims must be multiples of 16");
   MB_REQUIRE(c->res_out_dims % 4 == 0, "wavernn: res_out_dims %% 4");
-  MB_REQUIRE(c->bits >= 8 && c->bits <= 10, "wavernn: bits=%d unsupported by the one-wave sampler (8..10)", c->bits);
+  MB_REQUIRE(c->mode == 1 || (c->bits >= 8 && c->bits <= 10), "wavernn: bits=%d unsupported by the one-wave sampler (8..10)", c->bits);
   MB_REQUIRE(c->rnn_dims <= 1024, "wavernn: rnn_dims=%d > 1024", c->rnn_dims);
   const size_t R = c->rnn_dims, FC = c->fc_dims, A = c->res_out_dims / 4, CD = c->compute_dims;
-  const size_t C = (size_t)1 << c->bits;
+  const size_t C = c->mode == 1 ? 30 : (size_t)1 << c->bits;  // fatchord_version.py:95-98
   numel->clear();
   auto bn = [&](size_t n) { for (int i = 0; i < 4; ++i) numel->push_back(n); };
   numel->push_back(CD * c->feat_dims * (2 * c->pad + 1));  // conv_in
@@ -332,7 +396,7 @@ extern "C" int mb_wavernn_create(const mb_wavernn_config* cfg, const float* cons
   mb_wavernn* w = new mb_wavernn();
   w->cfg = *cfg;
   const int R = cfg->rnn_dims, FC = cfg->fc_dims, A = cfg->res_out_dims / 4, CD = cfg->compute_dims;
-  const int C = 1 << cfg->bits, FEAT = cfg->feat_dims;
+  const int C = cfg->mode == 1 ? 30 : 1 << cfg->bits, FEAT = cfg->feat_dims;
   w->aux_dims = A; w->n_classes = C;
   w->hop = 1;
   for (int i = 0; i < cfg->n_upsample; ++i) w->hop *= cfg->upsample_factors[i];
@@ -628,7 +692,9 @@ extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* 
   }
   // Production path (no injected noise / teacher forcing / logits dump): the sampler is fused into the
   // fc3 launch and the next step's input is rebuilt from the argmax word -> 5 launches per step.
-  const bool fused = !d_noise && !d_forced && !d_logits_out && getenv("MBHIP_WAVERNN_NOFUSE") == nullptr;
+  // (MOL mode, fatchord_version.py:213-220, runs the exact 6-launch chain with its own sampler kernel: the fused Gumbel-argmax
+  // epilogue and the split-hidden chain decode a CLASS from the argmax word, a MOL sample is a real number)
+  const bool fused = !d_noise && !d_forced && !d_logits_out && getenv("MBHIP_WAVERNN_NOFUSE") == nullptr && c.mode == 0;
   const bool split = fused && wavernn_split_chain();
   // MBHIP_WAVERNN_MERGE=1 (experiment, off): fc3 + the next step's elementwise rnn1 in ONE launch (4 per
   // step) through an in-launch arrival counter.  Measured on MI355X (profiles/r01_wavernn_chain_ab.json):
@@ -881,7 +947,8 @@ extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* 
       SampK sk = make_sk(l);
       sk.step_off = soff;
       sk.trace = tr ? tr + 10 * TRACE_SLOTS : nullptr;
-      if (C == 512) hipLaunchKernelGGL(wavernn_sample_kernel<2>, dim3(nl), dim3(64), 0, ls, sk);
+      if (c.mode == 1) hipLaunchKernelGGL(wavernn_sample_mol_kernel, dim3(nl), dim3(64), 0, ls, sk, C / 3);
+      else if (C == 512) hipLaunchKernelGGL(wavernn_sample_kernel<2>, dim3(nl), dim3(64), 0, ls, sk);
       else if (C == 256) hipLaunchKernelGGL(wavernn_sample_kernel<1>, dim3(nl), dim3(64), 0, ls, sk);
       else hipLaunchKernelGGL(wavernn_sample_kernel<4>, dim3(nl), dim3(64), 0, ls, sk);
       MB_HIP(hipGetLastError());
@@ -1056,6 +1123,7 @@ extern "C" int mb_wavernn_generate_batch(const mb_wavernn* wc, const mb_wavernn_
                                          void* d_workspace, size_t workspace_bytes, mb_stream_t stream) {
   mb_wavernn* w = const_cast<mb_wavernn*>(wc);
   MB_REQUIRE(w && plan && h_frames && h_d_mels && h_seeds && d_samples, "wavernn_generate_batch: null pointer");
+  MB_REQUIRE(w->cfg.mode == 0, "wavernn_generate_batch: RAW mode only (the shared loop is the fused-sampler chain); run MOL utterances one by one");
   const int n_utt = plan->n_utt, N = plan->n_folds, S = plan->seq_len;
   WrnBatchLayout L;
   wavernn_batch_layout(w, n_utt, h_frames, N, d_workspace, &L);

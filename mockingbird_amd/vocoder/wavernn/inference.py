@@ -33,7 +33,8 @@ class WaveRNNDevice:
         _lib.check(L.mb_wavernn_create(C.byref(self.cfg), _lib.host_ptr_array(ws), len(ws), C.byref(h)),
                    "mb_wavernn_create")
         self._h = h
-        self.n_classes = 2 ** self.cfg.bits
+        self.n_classes = 30 if self.cfg.mode == 1 else 2 ** self.cfg.bits  # fatchord_version.py:95-98
+        self.noise_width = 11 if self.cfg.mode == 1 else self.n_classes   # MOL: 10 mixture-indicator uniforms + 1 logistic uniform
         self.hop_length = hparams.hop_length
         self.sample_rate = hparams.sample_rate
         self._ws = None
@@ -71,8 +72,8 @@ class WaveRNNDevice:
                   if want_logits else None)
         if noise is not None:
             noise = noise.to(dev, torch.float32).contiguous()
-            if tuple(noise.shape) != (p.seq_len, p.n_folds, self.n_classes):
-                raise _lib.MbHipError(f"noise must be {(p.seq_len, p.n_folds, self.n_classes)}, got {tuple(noise.shape)}")
+            if tuple(noise.shape) != (p.seq_len, p.n_folds, self.noise_width):
+                raise _lib.MbHipError(f"noise must be {(p.seq_len, p.n_folds, self.noise_width)}, got {tuple(noise.shape)}")
         if forced is not None:
             forced = forced.to(dev, torch.float32).contiguous()
             if tuple(forced.shape) != (p.n_folds, p.seq_len):
@@ -115,6 +116,8 @@ class WaveRNNDevice:
         mels = [m.to(torch.float32).contiguous() for m in mels]
         n = len(mels)
         seeds = [_lib.fresh_seed() for _ in range(n)] if seeds is None else [int(x) for x in seeds]
+        if self.cfg.mode == 1:  # MOL: the shared loop is the RAW fused-sampler chain; utterances run one by one
+            return [self.generate_samples(m, True, target, overlap, seed=sd) for m, sd in zip(mels, seeds)]
         frames = (C.c_int * n)(*[int(m.shape[1]) for m in mels])
         offs = (C.c_int * (n + 1))()
         plan = _lib.WaveRNNBatchPlan()
@@ -139,12 +142,14 @@ class WaveRNNDevice:
 
     def generate_batch(self, mels, target, overlap, mu_law, seeds=None):
         """Batch counterpart of generate(): list of [80, F_u] mels -> list of float64 waveforms."""
+        mu_law = mu_law if self.cfg.mode == 0 else False  # fatchord_version.py:154
         outs = self.generate_samples_batch([m.cuda() for m in mels], target, overlap, seeds)
         return [self.finish(smp, True, overlap, mu_law, (m.shape[-1] - 1) * self.hop_length) for smp, m in zip(outs, mels)]
 
     def generate(self, mels, batched, target, overlap, mu_law, progress_callback=None, noise=None, seed=None):
         """Signature of WaveRNN.generate (fatchord_version.py:153): mels [1, 80, F] tensor -> float64 wav."""
         mel = mels[0] if mels.dim() == 3 else mels
+        mu_law = mu_law if self.cfg.mode == 0 else False  # fatchord_version.py:154
         wave_len = (mel.shape[-1] - 1) * self.hop_length
         samples = self.generate_samples(mel.cuda(), batched, target, overlap, noise=noise, seed=seed,
                                         progress_callback=progress_callback)

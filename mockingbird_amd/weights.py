@@ -103,9 +103,9 @@ def wavernn_config(hp) -> "_lib.WaveRNNConfig":
     c.feat_dims, c.compute_dims = int(g("num_mels")), int(g("voc_compute_dims"))
     c.res_out_dims, c.res_blocks = int(g("voc_res_out_dims")), int(g("voc_res_blocks"))
     mode = g("voc_mode")
-    if mode != "RAW":
-        raise _lib.MbHipError("only voc_mode='RAW' (the reference default, wavernn/hparams.py:23) is implemented")
-    c.mode = 0
+    if mode not in ("RAW", "MOL"):
+        raise RuntimeError(f"Unknown model mode value - {mode}")  # fatchord_version.py:98,230
+    c.mode = 0 if mode == "RAW" else 1
     return c
 
 

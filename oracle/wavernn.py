@@ -117,13 +117,50 @@ def _gru_cell(w, name, x, h):  # get_gru_cell :265-271 -> nn.GRUCell
                           w[name + ".bias_ih_l0"], w[name + ".bias_hh_l0"])
 
 
+LOG_SCALE_MIN = float(np.log(1e-14))  # distribution.py:96-97
+
+
+def sample_mol(logits, u=None):
+    """sample_from_discretized_mix_logistic (models/vocoder/distribution.py:87-123) as WaveRNN.generate calls it
+    (fatchord_version.py:213-214: y = logits.unsqueeze(0).transpose(1, 2), i.e. B = 1, C = 3 * nr_mix, T = folds).
+    logits [b, 3 * nr_mix] -> sample [b] in [-1, 1].
+    u: None -> the two uniform_(1e-5, 1 - 1e-5) draws on the global torch RNG in the reference's order
+       (mixture indicator [1, b, nr_mix] first, then the logistic [1, b]); else [b, nr_mix + 1] pre-drawn
+       uniforms: columns 0..nr_mix-1 the indicator draws, column nr_mix the logistic draw."""
+    y = logits.unsqueeze(0).transpose(1, 2)  # B x C x T
+    nr_mix = y.size(1) // 3
+    y = y.transpose(1, 2)  # B x T x C
+    logit_probs = y[:, :, :nr_mix]
+    if u is None:
+        temp = logit_probs.data.new(logit_probs.size()).uniform_(1e-5, 1.0 - 1e-5)
+    else:
+        temp = u[:, :nr_mix].unsqueeze(0)
+    temp = logit_probs.data - torch.log(-torch.log(temp))
+    _, argmax = temp.max(dim=-1)
+    one_hot = torch.zeros(argmax.size() + (nr_mix,)).scatter_(len(argmax.size()), argmax.unsqueeze(-1), 1.0)
+    means = torch.sum(y[:, :, nr_mix:2 * nr_mix] * one_hot, dim=-1)
+    log_scales = torch.clamp(torch.sum(y[:, :, 2 * nr_mix:3 * nr_mix] * one_hot, dim=-1), min=LOG_SCALE_MIN)
+    if u is None:
+        uu = means.data.new(means.size()).uniform_(1e-5, 1.0 - 1e-5)
+    else:
+        uu = u[:, nr_mix].unsqueeze(0)
+    x = means + torch.exp(log_scales) * (torch.log(uu) - torch.log(1. - uu))
+    x = torch.clamp(torch.clamp(x, min=-1.), max=1.)
+    return x.view(-1)
+
+
+def n_classes_of(hp):  # fatchord_version.py:95-98
+    return 30 if hp["mode"] == "MOL" else 2 ** hp["bits"]
+
+
 def sample_loop(w, hp, mels, aux, noise=None, forced=None, return_logits=False, max_steps=None):
-    """Loop body :176-234 (RAW mode).  mels [b, T, 80], aux [b, T, 128].
-    noise: None -> Categorical(p).sample() on the global torch RNG (the reference's call);
+    """Loop body :176-234.  mels [b, T, 80], aux [b, T, 128].
+    RAW mode -- noise: None -> Categorical(p).sample() on the global torch RNG (the reference's call);
            else [T, b, C] Exp(1) draws, sample = argmax(p / noise) (the same arithmetic
            torch.multinomial(p, 1) performs on CPU).
+    MOL mode (:213-220) -- noise: None -> global RNG, else [T, b, nr_mix + 1] uniforms (sample_mol).
     forced: optional [b, T] samples fed back instead of the drawn ones (teacher forcing)."""
-    n_classes = 2 ** hp["bits"]
+    n_classes = n_classes_of(hp)
     b_size, seq_len, _ = mels.size()
     if max_steps is not None:
         seq_len = min(seq_len, max_steps)
@@ -150,12 +187,15 @@ def sample_loop(w, hp, mels, aux, noise=None, forced=None, return_logits=False, 
         logits = F.linear(x, w["fc3.weight"], w["fc3.bias"])
         if return_logits:
             logits_all.append(logits)
-        posterior = F.softmax(logits, dim=1)
-        if noise is None:
-            k = torch.distributions.Categorical(posterior).sample()
+        if hp["mode"] == "MOL":
+            sample = sample_mol(logits, None if noise is None else noise[i])
         else:
-            k = (posterior / noise[i]).argmax(dim=1)
-        sample = 2 * k.float() / (n_classes - 1.) - 1.
+            posterior = F.softmax(logits, dim=1)
+            if noise is None:
+                k = torch.distributions.Categorical(posterior).sample()
+            else:
+                k = (posterior / noise[i]).argmax(dim=1)
+            sample = 2 * k.float() / (n_classes - 1.) - 1.
         output.append(sample)
         x = (forced[:, i] if forced is not None else sample).unsqueeze(-1)
     out = torch.stack(output).transpose(0, 1)
@@ -176,8 +216,8 @@ def postprocess(hp, output, wave_len, batched, target, overlap):
     """generate() :236-257 from the stacked samples [b, T] (torch) to the float64 waveform."""
     output = output.cpu().numpy().astype(np.float64)
     output = xfade_and_unfold(output, target, overlap) if batched else output[0]
-    if hp["mu_law"] and hp["mode"] == "RAW":
-        output = decode_mu_law(output, 2 ** hp["bits"])
+    if hp["mu_law"] and hp["mode"] == "RAW":  # :154: mu_law = mu_law if self.mode == 'RAW' else False
+        output = decode_mu_law(output, n_classes_of(hp))
     if hp["apply_preemphasis"]:
         output = de_emphasis(output, hp["preemphasis"])
     fade_out = np.linspace(1, 0, 20 * hp["hop_length"])

@@ -90,6 +90,23 @@ def wavernn():
         mels, aux = m.upsample(mp.transpose(1, 2))
     out["cond_mels_f30_stride97"] = mels[0, ::97].numpy()
     out["cond_aux_f30_stride97"] = aux[0, ::97].numpy()
+    # ---- MOL mode (fatchord_version.py:213-220): the sampler alone, then generate() of a MOL model ----
+    from models.vocoder.distribution import sample_from_discretized_mix_logistic
+    torch.manual_seed(5)
+    lg = torch.randn(7, 30) * 2
+    lg[:, 20:] -= 3
+    out["mol_direct_logits"] = lg.numpy()
+    torch.manual_seed(9)
+    out["mol_direct_sample_seed9"] = sample_from_discretized_mix_logistic(lg.unsqueeze(0).transpose(1, 2)).view(-1).numpy()
+    stm = synth.wavernn_state(synth.WAVERNN_HP_MOL, seed=6)
+    mm = WaveRNN(rnn_dims=hp.voc_rnn_dims, fc_dims=hp.voc_fc_dims, bits=hp.bits, pad=hp.voc_pad,
+                 upsample_factors=hp.voc_upsample_factors, feat_dims=hp.num_mels, compute_dims=hp.voc_compute_dims,
+                 res_out_dims=hp.voc_res_out_dims, res_blocks=hp.voc_res_blocks, hop_length=hp.hop_length,
+                 sample_rate=hp.sample_rate, mode="MOL")
+    mm.load_state_dict(stm["model_state"])
+    mm.eval()
+    torch.manual_seed(13)
+    out["mol_batched_f30_t600_o100_seed13"] = mm.generate(torch.from_numpy(mel[None] / 4.0), True, 600, 100, True, quiet)
     np.savez_compressed(os.path.join(HERE, "wavernn.npz"), torch_version=torch.__version__, **out)
     print("wavernn.npz", {k: v.shape for k, v in out.items()})
 

@@ -110,7 +110,8 @@ def wavernn_state(hp=WAVERNN_HP, seed=0):
     """{'model_state': state_dict} in the reference WaveRNN layout (fatchord_version.py:88-122)."""
     rng = np.random.default_rng(seed)
     R, FC, A = hp["rnn_dims"], hp["fc_dims"], hp["res_out_dims"] // 4
-    CD, FEAT, C = hp["compute_dims"], hp["feat_dims"], 2 ** hp["bits"]
+    mol = hp.get("mode", "RAW") == "MOL"
+    CD, FEAT, C = hp["compute_dims"], hp["feat_dims"], (30 if mol else 2 ** hp["bits"])
     sd = {}
 
     def t(shape, scale):
@@ -148,8 +149,27 @@ def wavernn_state(hp=WAVERNN_HP, seed=0):
     sd["fc1.weight"] = t((FC, R + A), 1.0 / math.sqrt(R + A)); sd["fc1.bias"] = t((FC,), 0.1)
     sd["fc2.weight"] = t((FC, FC + A), 1.4 / math.sqrt(FC + A)); sd["fc2.bias"] = t((FC,), 0.1)
     sd["fc3.weight"] = t((C, FC), 2.0 / math.sqrt(FC)); sd["fc3.bias"] = t((C,), 0.1)
+    if mol:  # (logits | means | log scales) x 10: means inside [-1, 1], scales ~ exp(-3.5)
+        sd["fc3.weight"][10:20] *= 0.25
+        sd["fc3.weight"][20:30] *= 0.15
+        sd["fc3.bias"][20:30] -= 3.5
     sd["step"] = torch.zeros(1, dtype=torch.long)
     return {"model_state": sd}
+
+
+WAVERNN_HP_MOL = dict(WAVERNN_HP, mode="MOL")
+
+
+def mol_uniforms(seed, steps, folds, nr_mix=10):
+    """uniform_(1e-5, 1 - 1e-5) draws in the order sample_from_discretized_mix_logistic consumes them per step
+    (distribution.py:105,118): [folds, nr_mix] indicator draws, then [folds] logistic draws -> [steps, folds, nr_mix + 1]."""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(steps):
+        t1 = torch.empty(1, folds, nr_mix).uniform_(1e-5, 1.0 - 1e-5, generator=g)
+        t2 = torch.empty(1, folds).uniform_(1e-5, 1.0 - 1e-5, generator=g)
+        out.append(torch.cat([t1[0], t2[0][:, None]], dim=1))
+    return torch.stack(out)
 
 
 def wavernn_mel(frames, seed=1, n_mels=80):

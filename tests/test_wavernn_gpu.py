@@ -323,3 +323,67 @@ def test_wide_batch_tile_split_equals_single_runs(model, monkeypatch, form):
         assert torch.equal(outs[u], single), (form, u, int((outs[u] != single).sum()))
     # utterances 0 and 2 have different mels but equal length; 1 and 3 share a seed but not a mel
     assert not torch.equal(outs[0], outs[2])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# MOL mode (fatchord_version.py:213-220, models/vocoder/distribution.py:87-123)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def mol_model(cuda, lib):
+    import types
+    from mockingbird_amd.vocoder.wavernn import hparams as hp
+    from mockingbird_amd.vocoder.wavernn.inference import WaveRNNDevice
+    st = synth.wavernn_state(synth.WAVERNN_HP_MOL, seed=6)
+    hpm = types.SimpleNamespace(**{k: getattr(hp, k) for k in dir(hp) if not k.startswith("_")})
+    hpm.voc_mode = "MOL"
+    return WaveRNNDevice(st["model_state"], hpm), dict(st["model_state"])
+
+
+def test_mol_teacher_forced_matches_oracle(mol_model):
+    """30 fc3 outputs per fold, mixture indicator by Gumbel-argmax, logistic sample, clamp: with the oracle's uniforms
+    injected and its samples fed back, the device's fc3 outputs agree to 1e-3 and its samples to 1e-4 (continuous
+    values: libm differences only) wherever the mixture choice is not a near-tie."""
+    dev, w = mol_model
+    hpo = dict(ow.HP, mode="MOL")
+    assert dev.n_classes == 30 and dev.noise_width == 11
+    frames, target, overlap, steps = 40, 1100, 50, 96
+    mel = synth.wavernn_mel(frames, seed=3)
+    with torch.no_grad():
+        mels, aux = ow.conditioning(w, hpo, torch.from_numpy(mel[None] / 4.0), True, target, overlap)
+    n, S = mels.shape[0], mels.shape[1]
+    u = synth.mol_uniforms(17, S, n)
+    with torch.no_grad():
+        o_samples, o_logits = ow.sample_loop(w, hpo, mels, aux, noise=u, return_logits=True, max_steps=steps)
+    forced = torch.zeros(n, S)
+    forced[:, :steps] = o_samples
+    s, lg = dev.generate_samples(torch.from_numpy(mel / 4.0).cuda(), True, target, overlap, noise=u, forced=forced, want_logits=True)
+    assert lg.shape == (S, n, 30)
+    e = hiputil.relerr(lg[:steps], o_logits)
+    assert e["nan"] == 0 and e["max_abs"] <= 1e-3, e
+    d = (s[:, :steps].cpu() - o_samples).abs()
+    # a flipped mixture indicator needs the two best perturbed logits within the logit error
+    pert = o_logits[:, :, :10] - torch.log(-torch.log(u[:steps, :, :10]))
+    top2 = pert.topk(2, dim=2).values
+    near_tie = ((top2[..., 0] - top2[..., 1]) < 5e-3).t()
+    assert float(d[~near_tie].max()) <= 1e-4, float(d[~near_tie].max())
+    assert float(s.min()) >= -1 and float(s.max()) <= 1
+
+
+def test_mol_free_running_facade(mol_model):
+    """generate(): free-running MOL sampling with the on-device RNG -- same seed -> same stream, samples in [-1, 1] and
+    not on the RAW class grid, mu-law decoding is skipped in MOL mode (fatchord_version.py:154) even when asked for."""
+    dev, w = mol_model
+    m = torch.from_numpy(synth.wavernn_mel(30, seed=4) / 4.0).cuda()
+    a = dev.generate_samples(m, True, 600, 100, seed=5)
+    b = dev.generate_samples(m, True, 600, 100, seed=5)
+    c = dev.generate_samples(m, True, 600, 100, seed=6)
+    assert dev.last_loop_launches == 6 * dev.last_plan.seq_len
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert float(a.min()) >= -1 and float(a.max()) <= 1 and torch.isfinite(a).all()
+    k = (a + 1) * 511 / 2
+    assert float((k - k.round()).abs().max()) > 0.05
+    wav = dev.generate(m[None].cpu(), True, 600, 100, True, seed=5)
+    ref = ow.postprocess(dict(ow.HP, mode="MOL"), a.cpu(), 29 * 256, True, 600, 100)
+    assert wav.dtype == np.float64 and wav.shape == ref.shape and float(np.abs(wav - ref).max()) <= 1e-12
+    outs = dev.generate_samples_batch([m, m[:, :27]], 600, 100, seeds=[5, 9])
+    assert torch.equal(outs[0], a) and outs[1].shape[1] == 800
