@@ -86,6 +86,9 @@ typedef struct mb_conv1d_args {
                              positions); fregan/generator.py:104-110            */
   int transpose_out;      /* store y[b][t][c_out] (time-major)                    */
   const float* d_gate;    /* out_act 4 only: sigmoid gate, same layout as y       */
+  /* ragged batches: item b is valid for its first d_valid[b] * valid_mul stored rows of x (int32 device array, NULL = all of
+   * t_in); positions beyond read as zero padding, output tiles wholly beyond an item's valid output are skipped */
+  const int* d_valid; int valid_mul;
 } mb_conv1d_args;
 
 int mb_conv1d(const mb_conv1d_args* a, mb_stream_t stream);
@@ -121,6 +124,7 @@ typedef struct mb_conv1d_f16_args {
   int accumulate;         /* y += result                                          */
   int in_repeat;          /* nearest-neighbour upsampled read, as mb_conv1d_args  */
   int y_f32;              /* store y as fp32 (final conv_post -> waveform)        */
+  const int* d_valid; int valid_mul;  /* ragged batches, as mb_conv1d_args */
 } mb_conv1d_f16_args;
 
 int mb_conv1d_f16(const mb_conv1d_f16_args* a, mb_stream_t stream);
@@ -149,6 +153,7 @@ typedef struct mb_resblock_pair_f16_args {
   float slope;            /* leaky_relu slope in (0,1), applied before both convs */
   float out_scale;        /* 0 = 1.0                                              */
   int accumulate;
+  const int* d_valid; int valid_mul;  /* ragged batches: item b has d_valid[b] * valid_mul positions (NULL = t) */
 } mb_resblock_pair_f16_args;
 int mb_resblock_pair_f16(const mb_resblock_pair_f16_args* a, mb_stream_t stream);
 
@@ -227,6 +232,13 @@ int mb_gan_forward(const mb_gan* g, const float* d_mel, int batch, int frames,
  * d_chan_bias fp32 [batch][upsample_initial_channel] or NULL.  With kind = MB_GAN_HIFIGAN and num_mels =
  * the latent width this is the VITS decoder, Generator.forward models/synthesizer/models/vits.py:273-291
  * (x = conv_pre(x) + cond(g); cond(g) is constant over time), conv_post's missing bias passed as zeros. */
+/* Ragged batch: item b has d_frames[b] <= frames mel frames (int32 device array); d_mel is zero- (or anything-) padded to
+ * [batch][num_mels][frames], d_wav is [batch][mb_gan_out_samples(g, frames)] and item b's first mb_gan_out_samples(g,
+ * d_frames[b]) samples equal its own single-utterance forward: every conv reads positions beyond an item's length as
+ * its zero padding (the generators are not causal: merely zero-padding the mel changes the tail).  One launch sequence
+ * for the whole batch.  Not for interp_ups configs (their stage lengths are not multiples of the frame count). */
+int mb_gan_forward_ragged(const mb_gan* g, const float* d_mel, int batch, int frames, const int32_t* d_frames, float* d_wav,
+                          const float* d_chan_bias, void* d_workspace, size_t workspace_bytes, mb_stream_t stream);
 int mb_gan_forward_ex(const mb_gan* g, const float* d_mel, int batch, int frames, float* d_wav,
                       const float* d_chan_bias, void* d_workspace, size_t workspace_bytes, mb_stream_t stream);
 

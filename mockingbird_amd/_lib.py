@@ -32,6 +32,7 @@ class ConvArgs(C.Structure):
         ("in_act", C.c_int), ("in_slope", C.c_float), ("in_scale", C.c_float),
         ("out_act", C.c_int), ("out_scale", C.c_float), ("accumulate", C.c_int),
         ("in_repeat", C.c_int), ("transpose_out", C.c_int), ("d_gate", C.c_void_p),
+        ("d_valid", C.c_void_p), ("valid_mul", C.c_int),
     ]
 
 
@@ -45,6 +46,7 @@ class ConvF16Args(C.Structure):
         ("in_act", C.c_int), ("in_slope", C.c_float),
         ("out_act", C.c_int), ("out_scale", C.c_float),
         ("accumulate", C.c_int), ("in_repeat", C.c_int), ("y_f32", C.c_int),
+        ("d_valid", C.c_void_p), ("valid_mul", C.c_int),
     ]
 
 
@@ -54,6 +56,7 @@ class ResPairF16Args(C.Structure):
         ("d_b2", C.c_void_p),
         ("batch", C.c_int), ("channels", C.c_int), ("t", C.c_int), ("ksize", C.c_int), ("dilation", C.c_int),
         ("slope", C.c_float), ("out_scale", C.c_float), ("accumulate", C.c_int),
+        ("d_valid", C.c_void_p), ("valid_mul", C.c_int),
     ]
 
 
@@ -150,6 +153,8 @@ SIGNATURES = {
     "mb_gan_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "mb_gan_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_size_t, C.c_void_p]),
+    "mb_gan_forward_ragged": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_size_t, C.c_void_p]),
     "mb_gan_forward_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_size_t, C.c_void_p]),
     "mb_wavernn_num_weights": (C.c_int, [C.POINTER(WaveRNNConfig)]),

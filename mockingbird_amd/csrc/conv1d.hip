@@ -37,6 +37,7 @@ struct ConvK {
   int in_act; float in_slope, in_scale;
   int out_act, accumulate, in_repeat;
   float out_scale;
+  const int* valid; int valid_mul;  // ragged batches (mb_conv1d_args.d_valid)
 };
 
 template <int WM, int WN, bool TR>
@@ -49,6 +50,12 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvK a) {
   const int q0 = blockIdx.x * NT;
   const int Tq = (a.t_out - p + a.up - 1) / a.up;  // outputs of this phase
   if (q0 >= Tq) return;
+  // ragged batch: this item's valid input / output extent (positions beyond are its zero padding / never consumed)
+  const int t_lim = a.valid ? min(a.t_in, a.valid[b] * a.valid_mul * a.in_repeat) : a.t_in;
+  if (a.valid) {
+    const int t_out_b = a.up > 1 ? t_lim * a.up : t_lim + (a.t_out - a.t_in);
+    if (q0 * a.up + p >= t_out_b) return;
+  }
   const int n_mt = (a.c_out + 31) >> 5;
   const int mt = blockIdx.y * WM + wm;
   const bool active = mt < n_mt;
@@ -78,7 +85,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvK a) {
       for (int tt = lane; tt < rowlen; tt += 64) {
         const int ti = q0 + a.min_off + tt;
         float v = 0.f;
-        if (cok && ti >= 0 && ti < a.t_in) {
+        if (cok && ti >= 0 && ti < t_lim) {
           if (a.in_repeat > 1) {
             v = xr[ti / a.in_repeat] * a.in_scale;
             if (a.in_act == 1) v = v > 0.f ? v : v * a.in_slope;
@@ -246,6 +253,7 @@ extern "C" int mb_conv1d(const mb_conv1d_args* a, mb_stream_t stream) {
   k.out_act = a->out_act; k.accumulate = a->accumulate;
   k.in_repeat = a->in_repeat > 1 ? a->in_repeat : 1;
   k.out_scale = a->out_scale == 0.f ? 1.f : a->out_scale;
+  k.valid = a->d_valid; k.valid_mul = a->valid_mul > 0 ? a->valid_mul : 1;
   MB_REQUIRE(k.in_repeat == 1 || a->t_in % k.in_repeat == 0, "conv1d: t_in %% in_repeat != 0");
   if (a->batch <= 0 || a->t_out <= 0) return MB_OK;
 

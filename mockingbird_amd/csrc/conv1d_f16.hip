@@ -39,6 +39,7 @@ struct ConvHK {
   int in_act; float in_slope;
   int out_act; float out_scale;
   int accumulate, in_repeat, y_f32, ck;
+  const int* valid; int valid_mul;  // ragged batches (mb_conv1d_f16_args.d_valid)
 };
 
 __device__ __forceinline__ h16x8 lrelu8(h16x8 v, h16 slope) {
@@ -61,6 +62,12 @@ __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void conv1d_f16_kernel(ConvHK
   const int q0 = blockIdx.x * NB;
   const int Tq = (a.t_out - p + a.up - 1) / a.up;  // outputs of this phase
   if (q0 >= Tq) return;
+  // ragged batch: this item's valid input / output extent (positions beyond are its zero padding / never consumed)
+  const int t_lim = a.valid ? min(a.t_in, a.valid[b] * a.valid_mul * a.in_repeat) : a.t_in;
+  if (a.valid) {
+    const int t_out_b = a.up > 1 ? t_lim * a.up : t_lim + (a.t_out - a.t_in);
+    if (q0 * a.up + p >= t_out_b) return;
+  }
   const int n_mt = (a.c_out + 31) >> 5;
   const int mt0 = (blockIdx.y * WM + wm) * MT;
   const bool active = mt0 < n_mt;
@@ -104,7 +111,7 @@ __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void conv1d_f16_kernel(ConvHK
       h16x8 v;
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] = (h16)0.f;
-      if (ti >= 0 && ti < a.t_in && ci < a.c_in) {
+      if (ti >= 0 && ti < t_lim && ci < a.c_in) {
         const int ts = a.in_repeat > 1 ? ti / a.in_repeat : ti;
         v = *reinterpret_cast<const h16x8*>(xb + (long long)ts * a.c_in + ci);
         if (a.in_act == 1) v = lrelu8(v, slope);
@@ -347,6 +354,7 @@ extern "C" int mb_conv1d_f16(const mb_conv1d_f16_args* a, mb_stream_t stream) {
   k.x_bstride = a->x_bstride; k.y_bstride = a->y_bstride; k.res_bstride = a->res_bstride;
   k.c_in = a->c_in; k.n_cb = (a->c_in + 15) / 16; k.c_out = a->c_out;
   k.t_in = a->t_in; k.t_out = a->t_out;
+  k.valid = a->d_valid; k.valid_mul = a->valid_mul > 0 ? a->valid_mul : 1;
   k.in_act = a->in_act; k.in_slope = a->in_slope;
   MB_REQUIRE(a->in_act == 0 || (a->in_act == 1 && a->in_slope > 0.f && a->in_slope < 1.f),
              "conv1d_f16: in_act must be 0 or leaky_relu with 0 < slope < 1");

@@ -290,6 +290,8 @@ struct Launcher {
   int batch;
   int dtype;
   int rc = MB_OK;
+  int frames_max = 1;          // mel frames of the padded batch: a tensor of t stored rows has t / frames_max rows per mel frame
+  const int* valid = nullptr;  // ragged batch: per-item mel frames (device); every launch masks by frames * (samples per frame so far)
   void add(void* y, const void* x, size_t n) {
     if (rc) return;
     rc = dtype == MB_F16 ? add_inplace_f16(y, x, n, s) : add_inplace((float*)y, (const float*)x, n, s);
@@ -309,6 +311,7 @@ struct Launcher {
     a.in_act = in_act; a.in_slope = in_slope;
     a.out_act = out_act; a.out_scale = out_scale; a.accumulate = accumulate;
     a.in_repeat = in_repeat; a.y_f32 = y_f32;
+    a.d_valid = valid; a.valid_mul = t_in / frames_max;
     rc = mb_conv1d_f16(&a, (mb_stream_t)s);
   }
   // fp16 fused ResBlock unit: y = (acc ? y : 0) + scale * (x + c2(lrelu(c1(lrelu(x)))))
@@ -320,6 +323,7 @@ struct Launcher {
     a.d_x = x; a.d_y = y; a.d_wpacked = w.p; a.d_b1 = c1.b.p; a.d_b2 = c2.b.p;
     a.batch = batch; a.channels = c1.s.c_in; a.t = t; a.ksize = c1.s.k; a.dilation = c1.s.dil;
     a.slope = slope; a.out_scale = out_scale; a.accumulate = accumulate;
+    a.d_valid = valid; a.valid_mul = t / frames_max;
     rc = mb_resblock_pair_f16(&a, (mb_stream_t)s);
   }
   // y = conv(x) with fused pro/epilogue; lengths are per batch item.  `last` = conv_post (fp32 out).
@@ -345,6 +349,7 @@ struct Launcher {
     a.in_act = in_act; a.in_slope = in_slope; a.in_scale = 1.f;
     a.out_act = out_act; a.out_scale = out_scale; a.accumulate = accumulate;
     a.in_repeat = in_repeat;
+    a.d_valid = valid; a.valid_mul = t_in / frames_max;
     rc = mb_conv1d(&a, (mb_stream_t)s);
   }
 };
@@ -355,9 +360,25 @@ extern "C" int mb_gan_forward(const mb_gan* g, const float* d_mel, int batch, in
   return mb_gan_forward_ex(g, d_mel, batch, frames, d_wav, nullptr, d_workspace, workspace_bytes, stream);
 }
 
+static int gan_forward_impl(const mb_gan* g, const float* d_mel, int batch, int frames, const int32_t* d_frames, float* d_wav,
+                            const float* d_chan_bias, void* d_workspace, size_t workspace_bytes, mb_stream_t stream);
+
 extern "C" int mb_gan_forward_ex(const mb_gan* g, const float* d_mel, int batch, int frames, float* d_wav,
                                  const float* d_chan_bias, void* d_workspace, size_t workspace_bytes,
                                  mb_stream_t stream) {
+  return gan_forward_impl(g, d_mel, batch, frames, nullptr, d_wav, d_chan_bias, d_workspace, workspace_bytes, stream);
+}
+
+extern "C" int mb_gan_forward_ragged(const mb_gan* g, const float* d_mel, int batch, int frames, const int32_t* d_frames, float* d_wav,
+                                     const float* d_chan_bias, void* d_workspace, size_t workspace_bytes, mb_stream_t stream) {
+  MB_REQUIRE(g && d_frames, "gan_forward_ragged: null pointer");
+  MB_REQUIRE(!g->cfg.interp_ups, "gan_forward_ragged: interp_ups configs (24 kHz variant) have stage lengths that are not multiples "
+                                 "of the frame count; run their utterances in equal-length batches");
+  return gan_forward_impl(g, d_mel, batch, frames, d_frames, d_wav, d_chan_bias, d_workspace, workspace_bytes, stream);
+}
+
+static int gan_forward_impl(const mb_gan* g, const float* d_mel, int batch, int frames, const int32_t* d_frames, float* d_wav,
+                            const float* d_chan_bias, void* d_workspace, size_t workspace_bytes, mb_stream_t stream) {
   MB_REQUIRE(g && d_mel && d_wav, "gan_forward: null pointer");
   MB_REQUIRE(batch > 0 && frames > 0, "gan_forward: empty input (batch=%d frames=%d)", batch, frames);
   const size_t need = mb_gan_workspace_bytes(g, batch, frames);
@@ -381,6 +402,7 @@ extern "C" int mb_gan_forward_ex(const mb_gan* g, const float* d_mel, int batch,
     OUTA = ar.take<char>(per); OUTB = ar.take<char>(per);
   }
   Launcher L{(hipStream_t)stream, batch, g->dtype};
+  L.valid = d_frames; L.frames_max = frames;  // ragged batch: every launch masks its input by frames[b] * (rows per frame)
   const void* mel_in = d_mel;
   if (f16) {  // [B][80][F] fp32 -> time-major fp16
     char* melh = ar.take<char>((size_t)batch * frames * c.num_mels * 2);

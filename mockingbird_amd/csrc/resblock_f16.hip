@@ -48,6 +48,7 @@ struct ResPairK {
   int nbuf;  // LDS buffers of the x window (1 = single buffer, refilled while phase 2 runs; C <= 64 only)
   float slope, out_scale;
   int accumulate;
+  const int* valid; int valid_mul;  // ragged batches: item b has valid[b] * valid_mul positions (null: T)
 };
 
 #ifndef MB_PAIR_NL
@@ -120,6 +121,7 @@ void resblock_pair_f16_kernel(ResPairK a) {
     auto load_batch = [&](int q, int base) {
       const int tile = (int)blockIdx.x + (q / NCH) * (int)gridDim.x, c = q % NCH;
       const int b = tile / a.tiles_per_item, t0 = (tile - b * a.tiles_per_item) * a.NB;
+      const int Tb = a.valid ? min(a.T, a.valid[b] * a.valid_mul) : a.T;  // beyond: this item's zero padding
       const int tx0 = t0 - p2 - p1;
       const h16* xb = a.x + (long long)b * a.bstride + c * CK;
 #pragma unroll
@@ -128,7 +130,7 @@ void resblock_pair_f16_kernel(ResPairK a) {
         const int row = idx / PPR, pc = idx - row * PPR;
         const int tx = tx0 + row;
         v[i] = (h16x8)(h16)0.f;
-        if (idx < total && tx >= 0 && tx < a.T)
+        if (idx < total && tx >= 0 && tx < Tb)
           v[i] = PAIR_NT ? __builtin_nontemporal_load(reinterpret_cast<const h16x8*>(xb + (long long)tx * C + pc * 8))
                          : *reinterpret_cast<const h16x8*>(xb + (long long)tx * C + pc * 8);
       }
@@ -154,7 +156,8 @@ void resblock_pair_f16_kernel(ResPairK a) {
     auto write_out = [&](int it, int lo, int hi, int den) {  // batches [nbt*lo/den, nbt*hi/den) of tile `it`
       const int tile = (int)blockIdx.x + it * (int)gridDim.x;
       const int b = tile / a.tiles_per_item, t0 = (tile - b * a.tiles_per_item) * a.NB;
-      const int rows = min(a.NB, a.T - t0);
+      const int Tb = a.valid ? min(a.T, a.valid[b] * a.valid_mul) : a.T;
+      const int rows = max(0, min(a.NB, Tb - t0));
       const int ytotal = rows * YPR;
       const h16* xb = a.x + (long long)b * a.bstride + (long long)t0 * C;
       h16* yb = a.y + (long long)b * a.bstride + (long long)t0 * C;
@@ -320,6 +323,7 @@ void resblock_pair_f16_kernel(ResPairK a) {
   for (int it = 0; it < my_tiles; ++it) {
     const int tile = (int)blockIdx.x + it * (int)gridDim.x;
     const int t0 = (tile % a.tiles_per_item) * a.NB;
+    const int Tb = a.valid ? min(a.T, a.valid[tile / a.tiles_per_item] * a.valid_mul) : a.T;
     // ---------------- phase 1: h = lrelu(conv1(lrelu(x)) + b1) ----------------
     zero_acc();
     MB_PMARK(0, it, 0);
@@ -347,7 +351,7 @@ void resblock_pair_f16_kernel(ResPairK a) {
         for (int n = 0; n < NTW; ++n) {
           const int row = lrow + n * 32;
           const int th = t0 - p2 + row;
-          const bool inside = th >= 0 && th < a.T;
+          const bool inside = th >= 0 && th < Tb;
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int co0 = (mt0 + i) * 32 + 8 * g + 4 * (lane >> 5);
@@ -546,6 +550,7 @@ extern "C" int mb_resblock_pair_f16(const mb_resblock_pair_f16_args* a, mb_strea
   k.w = reinterpret_cast<const h16*>(a->d_wpacked); k.b1 = a->d_b1; k.b2 = a->d_b2;
   k.bstride = (long long)a->t * a->channels;
   k.T = a->t; k.ntaps = a->ksize; k.dil = a->dilation;
+  k.valid = a->d_valid; k.valid_mul = a->valid_mul > 0 ? a->valid_mul : 1;
   k.slope = a->slope; k.out_scale = a->out_scale == 0.f ? 1.f : a->out_scale; k.accumulate = a->accumulate;
   hipStream_t s = (hipStream_t)stream;
   // N-tile count per wave: the candidate with the smallest makespan (rounds of 256 persistent

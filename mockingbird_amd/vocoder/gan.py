@@ -87,6 +87,37 @@ class GanGenerator:
 
     __call__ = forward
 
+    def forward_ragged(self, mels) -> list:
+        """A list of [80, F_i] mels of DIFFERENT lengths in ONE batched launch sequence (mb_gan_forward_ragged): item i
+        equals forward(mels[i]) -- every conv treats positions beyond an item's length as its zero padding (the
+        generators are not causal, so merely zero-padding the mel would change the tail).  Returns the list of
+        [1, F_i * hop] device tensors."""
+        if not mels:
+            return []
+        if self.cfg.interp_ups:  # 24 kHz variant: stage lengths are not multiples of the frame count
+            return [self.forward(m.unsqueeze(0) if m.dim() == 2 else m)[0] for m in mels]
+        dev = torch.device("cuda", torch.cuda.current_device())
+        frames = [int(m.shape[-1]) for m in mels]
+        if min(frames) <= 0:
+            raise _lib.MbHipError("forward_ragged: empty mel")
+        B, M, Fm = len(mels), self.cfg.num_mels, max(frames)
+        batch = torch.zeros(B, M, Fm, dtype=torch.float32, device=dev)
+        for i, m in enumerate(mels):
+            m = torch.as_tensor(m, dtype=torch.float32)
+            if m.shape[0] != M:
+                raise _lib.MbHipError(f"mel has {m.shape[0]} channels, model expects {M}")
+            batch[i, :, :frames[i]] = m.to(dev)
+        d_frames = torch.tensor(frames, dtype=torch.int32, device=dev)
+        L = _lib.lib()
+        need = L.mb_gan_workspace_bytes(self._h, B, Fm)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        n_out = int(L.mb_gan_out_samples(self._h, Fm))
+        wav = torch.empty(B, 1, n_out, dtype=torch.float32, device=dev)
+        _lib.check(L.mb_gan_forward_ragged(self._h, _lib.ptr(batch), B, Fm, _lib.ptr(d_frames), _lib.ptr(wav), None,
+                                           _lib.ptr(self._ws), self._ws.numel(), _lib.stream_ptr()), "mb_gan_forward_ragged")
+        return [wav[i, :, :int(L.mb_gan_out_samples(self._h, f))] for i, f in enumerate(frames)]
+
 
 class GanFacade:
     """Module-global-singleton semantics of the reference inference modules."""
@@ -133,8 +164,8 @@ class GanFacade:
 
     def infer_waveform_batch(self, mels, progress_callback=None, normalize=None, pcm16=None, breaks=None,
                              break_hop=None, break_seconds=0.15, device_out=False):
-        """Additive API: a list of (80, Fi) mels -> list of waveforms, run as batches of
-        equal length (conv stacks are not causal: a zero-padded item differs from its own run near the padded tail).
+        """Additive API: a list of (80, Fi) mels of any lengths -> list of waveforms, run as ragged
+        batches (GanGenerator.forward_ragged: per-item lengths inside the kernels, each item equals its own run).
 
         The reference's host-side tail can run on the device, in gen_voice.py's order, before anything leaves HBM:
           breaks[i] = frames per sentence of item i -> cut at the sentence boundaries (frames * break_hop samples,
@@ -146,14 +177,13 @@ class GanFacade:
             raise Exception(f"Please load {self.name} in memory before using it")
         from . import wave
         out = [None] * len(mels)
-        by_len = {}
-        for i, m in enumerate(mels):
-            by_len.setdefault(int(np.shape(m)[1]), []).append(i)
-        for _, idx in by_len.items():
-            batch = torch.stack([torch.as_tensor(mels[i], dtype=torch.float32) for i in idx]).to(self._device)
-            y = self.generator(batch).squeeze(1)
+        max_batch = 64  # items per launch sequence (workspace = batch x longest item)
+        order = sorted(range(len(mels)), key=lambda i: -int(np.shape(mels[i])[1]))  # similar lengths share a batch
+        for c0 in range(0, len(order), max_batch):
+            idx = order[c0:c0 + max_batch]
+            ys = self.generator.forward_ragged([torch.as_tensor(mels[i], dtype=torch.float32) for i in idx])
             for k, i in enumerate(idx):
-                r = y[k]
+                r = ys[k].reshape(-1)
                 if breaks is not None:
                     r = wave.insert_breaks(r, breaks[i], break_hop, self.output_sample_rate, break_seconds)
                 if normalize is not None:

@@ -198,3 +198,58 @@ def test_gan_f16_unfused_path_matches_oracle(cuda, lib, monkeypatch, kind, cfg, 
     assert e["nan"] == 0 and e["rel_rms"] <= F16_REL_TOL, e
     d = hiputil.relerr(unfused, fused)
     assert d["rel_rms"] <= F16_REL_TOL, d
+
+
+@pytest.mark.parametrize("kind,cfg,uic,dtype", [("hifigan", synth.HIFIGAN_16K, 64, "f32"), ("fregan", synth.FREGAN_16K, 64, "f32"),
+                                                ("hifigan", synth.HIFIGAN_16K, 256, "f16"), ("fregan", synth.FREGAN_16K, 256, "f16")])
+def test_ragged_batch_equals_single_runs(cuda, lib, kind, cfg, uic, dtype):
+    """mb_gan_forward_ragged: utterances of different lengths in one launch sequence.  The generators are not causal
+    (a zero-padded mel changes the tail), so every conv masks positions beyond an item's length as ITS zero padding:
+    item i must equal forward(mel_i) -- bit for bit on the fp32 path (same products, same order per output position),
+    within fp16 rounding of the oracle on the fp16 path -- and the oracle."""
+    from mockingbird_amd.vocoder.gan import GanGenerator
+    h = synth.small(cfg, uic)
+    st = synth.gan_state(h, kind, seed=7)
+    gen = GanGenerator(h, st["generator"], 0 if kind == "hifigan" else 1, dtype=dtype)
+    frames = [37, 5, 23, 37, 1, 16]
+    mels = [torch.from_numpy(synth.mel_input(f, 1, seed=30 + i)[0]) for i, f in enumerate(frames)]
+    outs = gen.forward_ragged(mels)
+    w = og.fold_weight_norm_state(st["generator"])
+    for m, f, y in zip(mels, frames, outs):
+        assert tuple(y.shape) == (1, f * 200)
+        single = gen(m[None].cuda())[0]
+        with torch.no_grad():
+            ref = (og.hifigan_forward if kind == "hifigan" else og.fregan_forward)(w, h, m[None])[0]
+        e = hiputil.relerr(y, ref)
+        if dtype == "f32":
+            assert torch.equal(y, single), (f, float((y - single).abs().max()))
+            assert e["nan"] == 0 and e["rms"] <= RMS_TOL and e["rel_rms"] <= REL_TOL, (f, e)
+        else:
+            d = hiputil.relerr(y, single)
+            assert d["rel_rms"] <= 1e-6 or d["max_abs"] <= 2e-3, (f, d)
+            assert e["nan"] == 0 and e["rel_rms"] <= F16_REL_TOL, (f, e)
+
+
+def test_infer_waveform_batch_ragged_facade(cuda, lib, tmp_path):
+    """hifigan.infer_waveform_batch on mels of different lengths (BASELINE configs[3]: tail-trimmed spectrograms) ==
+    infer_waveform per utterance, with the device-side tail (breaks, normalise, PCM) applied per item."""
+    import importlib
+    import json
+    import mockingbird_amd.vocoder.hifigan.inference as voc
+    voc = importlib.reload(voc)
+    h = synth.small(synth.HIFIGAN_16K, 64)
+    torch.save(synth.gan_state(h, "hifigan", seed=1), tmp_path / "g_test.pt")
+    (tmp_path / "config.json").write_text(json.dumps(h))
+    voc.load_model(tmp_path / "g_test.pt", verbose=False)
+    frames = [31, 12, 31, 7, 19]
+    mels = [synth.mel_input(f, 1, seed=50 + i)[0] for i, f in enumerate(frames)]
+    wavs, sr = voc.infer_waveform_batch(mels)
+    assert sr == 16000 and len(wavs) == len(frames)
+    for m, f, wv in zip(mels, frames, wavs):
+        single, _ = voc.infer_waveform(m)
+        assert wv.shape == (f * 200,) and wv.dtype == np.float32 and np.array_equal(wv, single)
+    pcm, _ = voc.infer_waveform_batch(mels, normalize=0.97, pcm16="sndfile", breaks=[[f] for f in frames], break_hop=256)
+    from oracle import wave as owv
+    for wv, pc in zip(wavs, pcm):
+        ref = owv.sndfile_pcm16(owv.peak_normalize(np.concatenate([wv, np.zeros(2400, np.float32)]), np.float32(0.97)))
+        assert pc.dtype == np.int16 and np.array_equal(pc, ref)
