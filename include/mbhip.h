@@ -76,7 +76,7 @@ typedef struct mb_conv1d_args {
   int in_act;             /* 0 none, 1 leaky_relu(in_slope) applied to x on load  */
   float in_slope;
   float in_scale;         /* x is multiplied by this before in_act (0 or 1.0 = none) */
-  int out_act;            /* 0 none, 1 relu, 2 tanh, 3 sigmoid, 4 highway:
+  int out_act;            /* 0 none, 1 relu, 2 tanh, 3 sigmoid, 5 leaky_relu(out_slope), 4 highway:
                              y = g*relu(conv+b) + (1-g)*res with g = d_gate
                              (common/highway_network.py:12-17)                  */
   float out_scale;        /* result *= out_scale after the residual add (0 or 1.0 = none) */
@@ -89,6 +89,9 @@ typedef struct mb_conv1d_args {
   /* ragged batches: item b is valid for its first d_valid[b] * valid_mul stored rows of x (int32 device array, NULL = all of
    * t_in); positions beyond read as zero padding, output tiles wholly beyond an item's valid output are skipped */
   const int* d_valid; int valid_mul;
+  int down;               /* >1: strided Conv1d (torch `stride`), t_out = (t_in + 2*pad - dilation*(ksize-1) - 1)/down + 1;
+                             needs up == 1, in_repeat <= 1, d_valid == NULL (models/ppg2mel/__init__.py:55-70) */
+  float out_slope;        /* out_act 5: leaky_relu(out_slope) */
 } mb_conv1d_args;
 
 int mb_conv1d(const mb_conv1d_args* a, mb_stream_t stream);
@@ -458,6 +461,36 @@ int mb_ppg2mel_decode(const mb_ppg2mel* p, const float* d_memory, int batch, int
                       int min_steps, float stop_threshold, const float* d_dropout, uint64_t seed,
                       float* d_mel, float* d_align, float* d_stop, int* h_n_steps, void* d_workspace,
                       size_t workspace_bytes, mb_stream_t stream);
+
+/* 6b. The one-shot networks either side of that loop in MelDecoderMOLv2.inference
+ *     (models/ppg2mel/__init__.py:166-192): encode = bnf_prenet + pitch_convs (:50-98; strided Conv1d, LeakyReLU(0.1),
+ *     InstanceNorm1d), their sum, concat with F.normalize(spembs), reduce_proj -> decoder memory;
+ *     postnet = mel + Postnet(mel) (utils/cnn_postnet.py:8-52, eval-mode BatchNorm folded on the host).
+ *    h_weights (fp32 host, state_dict order): bnf_prenet.0.weight, .3.weight, .3.bias, .6.weight, .6.bias;
+ *    pitch_convs.0.weight, .3.weight, .3.bias, .6.weight, .6.bias; reduce_proj.weight, .bias; per postnet layer
+ *    conv.weight, conv.bias, BatchNorm weight, bias, running_mean, running_var. */
+typedef struct mb_ppg2mel_net_config {
+  int bnf_dim, spk_dim, enc_dim;   /* bottle_neck_feature_dim, spk_embed_dim, encoder_dim */
+  int down0, down1;                /* encoder_downsample_rates */
+  int num_mels, postnet_layers, postnet_dim, postnet_ksize;
+} mb_ppg2mel_net_config;
+typedef struct mb_ppg2mel_net mb_ppg2mel_net;
+int mb_ppg2mel_net_num_weights(const mb_ppg2mel_net_config* cfg);
+size_t mb_ppg2mel_net_weight_numel(const mb_ppg2mel_net_config* cfg, int index);
+int mb_ppg2mel_net_create(const mb_ppg2mel_net_config* cfg, const float* const* h_weights, int n_weights,
+                          mb_ppg2mel_net** out);
+void mb_ppg2mel_net_destroy(mb_ppg2mel_net* p);
+/* decoder memory length for t input frames (two strided convolutions), 0 if t is too short */
+int mb_ppg2mel_net_t_enc(const mb_ppg2mel_net_config* cfg, int t);
+size_t mb_ppg2mel_net_workspace_bytes(const mb_ppg2mel_net* p, int batch, int t);  /* t: frames of either call */
+/* d_bnf fp32 [batch][t][bnf_dim], d_logf0_uv [batch][t][2], d_spk [batch][spk_dim] (not normalised)
+ * -> d_memory [batch][t_enc][enc_dim], the layout mb_ppg2mel_decode takes. */
+int mb_ppg2mel_net_encode(const mb_ppg2mel_net* p, const float* d_bnf, const float* d_logf0_uv, const float* d_spk,
+                          int batch, int t, float* d_memory, void* d_workspace, size_t workspace_bytes,
+                          mb_stream_t stream);
+/* d_mel fp32 [batch][t][num_mels] (the decoder's frames) -> d_out = d_mel + postnet(d_mel), same layout. */
+int mb_ppg2mel_net_postnet(const mb_ppg2mel_net* p, const float* d_mel, int batch, int t, float* d_out,
+                           void* d_workspace, size_t workspace_bytes, mb_stream_t stream);
 
 /* ----------------------------------------------------------------------
  * 7. Waveform wire format on device: the elementwise tail between the

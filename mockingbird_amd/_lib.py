@@ -32,7 +32,7 @@ class ConvArgs(C.Structure):
         ("in_act", C.c_int), ("in_slope", C.c_float), ("in_scale", C.c_float),
         ("out_act", C.c_int), ("out_scale", C.c_float), ("accumulate", C.c_int),
         ("in_repeat", C.c_int), ("transpose_out", C.c_int), ("d_gate", C.c_void_p),
-        ("d_valid", C.c_void_p), ("valid_mul", C.c_int),
+        ("d_valid", C.c_void_p), ("valid_mul", C.c_int), ("down", C.c_int), ("out_slope", C.c_float),
     ]
 
 
@@ -58,6 +58,11 @@ class ResPairF16Args(C.Structure):
         ("slope", C.c_float), ("out_scale", C.c_float), ("accumulate", C.c_int),
         ("d_valid", C.c_void_p), ("valid_mul", C.c_int),
     ]
+
+
+class Ppg2MelNetConfig(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("bnf_dim", "spk_dim", "enc_dim", "down0", "down1", "num_mels", "postnet_layers",
+                                       "postnet_dim", "postnet_ksize")]
 
 
 class Ppg2MelConfig(C.Structure):
@@ -183,6 +188,16 @@ SIGNATURES = {
     "mb_wavernn_bench_kernel": (C.c_int, [C.c_void_p, C.POINTER(WaveRNNPlan), C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_float),
                                           C.POINTER(C.c_double), C.c_void_p]),
+    "mb_ppg2mel_net_num_weights": (C.c_int, [C.POINTER(Ppg2MelNetConfig)]),
+    "mb_ppg2mel_net_weight_numel": (C.c_size_t, [C.POINTER(Ppg2MelNetConfig), C.c_int]),
+    "mb_ppg2mel_net_create": (C.c_int, [C.POINTER(Ppg2MelNetConfig), _PP, C.c_int, _PP]),
+    "mb_ppg2mel_net_destroy": (None, [C.c_void_p]),
+    "mb_ppg2mel_net_t_enc": (C.c_int, [C.POINTER(Ppg2MelNetConfig), C.c_int]),
+    "mb_ppg2mel_net_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    "mb_ppg2mel_net_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                        C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mb_ppg2mel_net_postnet": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
+                                         C.c_void_p]),
     "mb_ppg2mel_num_weights": (C.c_int, [C.POINTER(Ppg2MelConfig)]),
     "mb_ppg2mel_weight_numel": (C.c_size_t, [C.POINTER(Ppg2MelConfig), C.c_int]),
     "mb_ppg2mel_create": (C.c_int, [C.POINTER(Ppg2MelConfig), _PP, C.c_int, _PP]),

@@ -32,11 +32,11 @@ struct ConvK {
   const float* post_scale; const float* post_shift; const float* gate; float* y;
   long long x_bstride, y_bstride, res_bstride;
   int c_in, cin_pad, c_out, t_in, t_out;
-  int ntaps, up, step, min_off, span;
+  int ntaps, up, down, step, min_off, span;
   int off0[8];
   int in_act; float in_slope, in_scale;
   int out_act, accumulate, in_repeat;
-  float out_scale;
+  float out_scale, out_slope;
   const int* valid; int valid_mul;  // ragged batches (mb_conv1d_args.d_valid)
 };
 
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvK a) {
   const int n_mt = (a.c_out + 31) >> 5;
   const int mt = blockIdx.y * WM + wm;
   const bool active = mt < n_mt;
-  const int rowlen = NT + a.span;
+  const int rowlen = NT * a.down + a.span;  // down > 1: strided conv, LDS holds every input position
   const int n_cb = a.cin_pad >> 3;
   const int n_w = n_cb * a.ntaps;  // A fragments this wave walks
   const float* xb = a.x + (long long)b * a.x_bstride;
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvK a) {
       const float* xr = xb + (long long)ci * t_src;
       float* lrow = lds + c * rowlen;
       for (int tt = lane; tt < rowlen; tt += 64) {
-        const int ti = q0 + a.min_off + tt;
+        const int ti = q0 * a.down + a.min_off + tt;
         float v = 0.f;
         if (cok && ti >= 0 && ti < t_lim) {
           if (a.in_repeat > 1) {
@@ -105,15 +105,16 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvK a) {
     if (active) {
       const int ncb2 = min(CK / 8, n_cb - (c0 >> 3));
       for (int cb2 = 0; cb2 < ncb2; ++cb2) {
-        const float* lbase = lds + (cb2 * 8 + (lane >> 5)) * rowlen + wn * 64 + (lane & 31) + off_base;
+        const float* lbase = lds + (cb2 * 8 + (lane >> 5)) * rowlen + (wn * 64 + (lane & 31)) * a.down + off_base;
+        const int h32 = 32 * a.down;
         for (int j = 0; j < a.ntaps; ++j) {
           ++wi;
           const float4 an = (wi < n_w) ? wp[(size_t)wi * 64] : av;
           const float* lp = lbase + j * a.step;
-          const float b00 = lp[0], b01 = lp[32];
-          const float b10 = lp[2 * rowlen], b11 = lp[2 * rowlen + 32];
-          const float b20 = lp[4 * rowlen], b21 = lp[4 * rowlen + 32];
-          const float b30 = lp[6 * rowlen], b31 = lp[6 * rowlen + 32];
+          const float b00 = lp[0], b01 = lp[h32];
+          const float b10 = lp[2 * rowlen], b11 = lp[2 * rowlen + h32];
+          const float b20 = lp[4 * rowlen], b21 = lp[4 * rowlen + h32];
+          const float b30 = lp[6 * rowlen], b31 = lp[6 * rowlen + h32];
           if (!TR) {
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b00, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b01, acc1, 0, 0, 0);
@@ -159,6 +160,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvK a) {
         if (a.out_act == 1) v = fmaxf(v, 0.f);
         else if (a.out_act == 2) v = tanhf(v);
         else if (a.out_act == 3) v = 1.0f / (1.0f + expf(-v));
+        else if (a.out_act == 5) v = v > 0.f ? v : v * a.out_slope;
         if (a.post_scale) v = v * a.post_scale[co] + a.post_shift[co];
         const long long o = TR ? ((long long)t * a.c_out + co) : ((long long)co * a.t_out + t);
         if (a.out_act == 4) {
@@ -177,6 +179,9 @@ static int conv_geometry(const mb_conv1d_args* a, ConvK* k) {
   MB_REQUIRE(a->up >= 1 && a->up <= 8, "conv1d: up=%d out of range", a->up);
   MB_REQUIRE(a->ksize >= 1 && a->c_in >= 1 && a->c_out >= 1, "conv1d: bad shape");
   k->up = a->up;
+  k->down = a->down > 1 ? a->down : 1;
+  MB_REQUIRE(k->down == 1 || (a->up == 1 && a->in_repeat <= 1 && !a->d_valid),
+             "conv1d: down=%d (strided conv) excludes up / in_repeat / d_valid", a->down);
   if (a->up == 1) {
     k->ntaps = a->ksize;
     k->step = a->dilation;
@@ -253,6 +258,7 @@ extern "C" int mb_conv1d(const mb_conv1d_args* a, mb_stream_t stream) {
   k.out_act = a->out_act; k.accumulate = a->accumulate;
   k.in_repeat = a->in_repeat > 1 ? a->in_repeat : 1;
   k.out_scale = a->out_scale == 0.f ? 1.f : a->out_scale;
+  k.out_slope = a->out_slope;
   k.valid = a->d_valid; k.valid_mul = a->valid_mul > 0 ? a->valid_mul : 1;
   MB_REQUIRE(k.in_repeat == 1 || a->t_in % k.in_repeat == 0, "conv1d: t_in %% in_repeat != 0");
   if (a->batch <= 0 || a->t_out <= 0) return MB_OK;
@@ -265,7 +271,7 @@ extern "C" int mb_conv1d(const mb_conv1d_args* a, mb_stream_t stream) {
   const int wn = 4 / wm;
   const int NT = 64 * wn;
   dim3 grid(cdiv(tq, NT), cdiv(n_mt, wm), a->batch * a->up);
-  const size_t lds = (size_t)CK * (NT + k.span) * sizeof(float);
+  const size_t lds = (size_t)CK * (NT * k.down + k.span) * sizeof(float);
   MB_REQUIRE(lds <= 160 * 1024, "conv1d: halo too large for LDS (%zu B)", lds);
 #define MB_LAUNCH(WM_, WN_)                                                                     \
   do {                                                                                          \

@@ -3,8 +3,10 @@ models/ppg2mel/rnn_decoder_mol.py:Decoder.inference / inference_batched on HIP k
 (csrc/ppg2mel.hip, mb_ppg2mel_*).  `Ppg2MelDecoder` mirrors the reference Decoder's inference-time
 surface: `inference(memory, stop_threshold=0.5)` and `inference_batched(memory, stop_threshold=0.5)` with
 the reference's return values; it is built from the `decoder.*` entries of a MelDecoderMOLv2 checkpoint.
-The convolutional front end (bnf_prenet, pitch_convs), the speaker projection and the CNN postnet of
-MelDecoderMOLv2 (models/ppg2mel/__init__.py:50-118,166-192) are one-shot and stay with the caller.
+`MelDecoderMOLv2` mirrors the whole reference model at inference time (models/ppg2mel/__init__.py:20-192,
+`inference(bottle_neck_features, logf0_uv, spembs)`): the convolutional front end (bnf_prenet, pitch_convs),
+the speaker projection and the CNN postnet run on csrc/ppg_net.hip (mb_ppg2mel_net_*), the decoder loop in
+between on `Ppg2MelDecoder`; `load_model(model_file, device)` is the reference's loader of the same name.
 There is no CPU path."""
 import ctypes as C
 
@@ -141,3 +143,149 @@ class Ppg2MelDecoder:
             idx = np.argwhere(sg[b] > stop_threshold)[0][0].item()
             parts.append(melf[b, :idx, :])
         return torch.cat(parts, dim=0).unsqueeze(0), al
+
+
+NET_DEFAULT = dict(encoder_dim=256, encoder_downsample_rates=(2, 2), attention_rnn_dim=512, decoder_rnn_dim=512,
+                   num_decoder_rnn_layer=1, concat_context_to_last=True, prenet_dims=(256, 128), num_mixtures=5,
+                   frames_per_step=2)
+
+
+def net_weight_list(state, n_post):
+    """MelDecoderMOLv2 state_dict -> the host tensors of mb_ppg2mel_net_create (include/mbhip.h section 6b)."""
+    names = []
+    for br in ("bnf_prenet", "pitch_convs"):
+        names += [f"{br}.0.weight", f"{br}.3.weight", f"{br}.3.bias", f"{br}.6.weight", f"{br}.6.bias"]
+    names += ["reduce_proj.weight", "reduce_proj.bias"]
+    for i in range(n_post):
+        p = f"postnet.convolutions.{i}"
+        names += [p + ".0.conv.weight", p + ".0.conv.bias", p + ".1.weight", p + ".1.bias", p + ".1.running_mean",
+                  p + ".1.running_var"]
+    return [state[n].detach().to(torch.float32).contiguous().cpu() for n in names]
+
+
+class MelDecoderMOLv2:
+    """Inference-time mirror of models/ppg2mel/__init__.py:MelDecoderMOLv2 built from its state_dict and the
+    constructor arguments of the checkpoint's yaml (`model:` section)."""
+
+    def __init__(self, state_dict, num_speakers=None, spk_embed_dim=256, bottle_neck_feature_dim=144, encoder_dim=256,
+                 encoder_downsample_rates=(2, 2), attention_rnn_dim=512, decoder_rnn_dim=512, num_decoder_rnn_layer=1,
+                 concat_context_to_last=True, prenet_dims=(256, 128), num_mixtures=5, frames_per_step=2,
+                 mask_padding=True):
+        if not torch.cuda.is_available():
+            raise _lib.MbHipError("ppg2mel: no MI355X visible; this build has no CPU path")
+        rates = [int(r) for r in encoder_downsample_rates]
+        if len(rates) != 2:
+            raise _lib.MbHipError("ppg2mel: the reference model has exactly two downsampling convolutions")
+        self.num_mels, self.frames_per_step = 80, frames_per_step
+        self.encoder_down_factor = int(np.cumprod(rates)[-1])
+        n_post = 0
+        while f"postnet.convolutions.{n_post}.0.conv.weight" in state_dict:
+            n_post += 1
+        pw = state_dict["postnet.convolutions.0.0.conv.weight"]
+        cfg = _lib.Ppg2MelNetConfig()
+        cfg.bnf_dim, cfg.spk_dim, cfg.enc_dim = bottle_neck_feature_dim, spk_embed_dim, encoder_dim
+        cfg.down0, cfg.down1, cfg.num_mels = rates[0], rates[1], self.num_mels
+        cfg.postnet_layers, cfg.postnet_dim, cfg.postnet_ksize = n_post, pw.shape[0], pw.shape[2]
+        self.cfg = cfg
+        L = _lib.lib()
+        ws = net_weight_list(state_dict, n_post)
+        n = L.mb_ppg2mel_net_num_weights(C.byref(cfg))
+        if n != len(ws):
+            raise _lib.MbHipError(f"ppg2mel net: ABI expects {n} weight tensors, checkpoint mapping gives {len(ws)}")
+        for i, w in enumerate(ws):
+            want = L.mb_ppg2mel_net_weight_numel(C.byref(cfg), i)
+            if w.numel() != want:
+                raise _lib.MbHipError(f"ppg2mel net weight {i}: {tuple(w.shape)} has {w.numel()} elements, expected {want}")
+        hnd = C.c_void_p()
+        _lib.check(L.mb_ppg2mel_net_create(C.byref(cfg), _lib.host_ptr_array(ws), len(ws), C.byref(hnd)),
+                   "mb_ppg2mel_net_create")
+        self._h = hnd
+        self._ws = None
+        dhp = dict(enc_dim=encoder_dim, num_mels=self.num_mels, frames_per_step=frames_per_step,
+                   attention_rnn_dim=attention_rnn_dim, decoder_rnn_dim=decoder_rnn_dim, prenet_dims=tuple(prenet_dims),
+                   num_mixtures=num_mixtures, encoder_down_factor=self.encoder_down_factor,
+                   num_decoder_rnn_layer=num_decoder_rnn_layer, concat_context_to_last=concat_context_to_last)
+        self.decoder = Ppg2MelDecoder({k[len("decoder."):]: v for k, v in state_dict.items() if k.startswith("decoder.")}, dhp)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _lib.lib().mb_ppg2mel_net_destroy(h)
+            except Exception:  # interpreter shutdown
+                pass
+            self._h = None
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        return self
+
+    def _workspace(self, B, T, dev):
+        need = _lib.lib().mb_ppg2mel_net_workspace_bytes(self._h, B, T)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        return self._ws
+
+    def encode(self, bottle_neck_features, logf0_uv, spembs):
+        """:172-179 -> decoder memory [B, T_enc, encoder_dim]."""
+        for name, t in (("bottle_neck_features", bottle_neck_features), ("logf0_uv", logf0_uv), ("spembs", spembs)):
+            if t is None:
+                raise AssertionError(f"{name} is required")  # the reference asserts spembs is not None
+            if not t.is_cuda:
+                raise _lib.MbHipError(f"ppg2mel: {name} must be a CUDA(HIP) tensor; there is no CPU path")
+        bnf = bottle_neck_features.to(torch.float32).contiguous()
+        lf0 = logf0_uv.to(torch.float32).contiguous()
+        spk = spembs.to(torch.float32).contiguous()
+        B, T, D = bnf.shape
+        if D != self.cfg.bnf_dim or tuple(lf0.shape) != (B, T, 2) or tuple(spk.shape) != (B, self.cfg.spk_dim):
+            raise _lib.MbHipError(f"ppg2mel: got features {tuple(bnf.shape)}, logf0_uv {tuple(lf0.shape)}, spembs "
+                                  f"{tuple(spk.shape)}; expected [B, T, {self.cfg.bnf_dim}], [B, T, 2], [B, {self.cfg.spk_dim}]")
+        L = _lib.lib()
+        t_enc = L.mb_ppg2mel_net_t_enc(C.byref(self.cfg), T)
+        if t_enc < 1:
+            raise _lib.MbHipError(f"ppg2mel: {T} frames are too few for the downsampling convolutions")
+        ws = self._workspace(B, T, bnf.device)
+        mem = torch.empty(B, t_enc, self.cfg.enc_dim, device=bnf.device)
+        _lib.check(L.mb_ppg2mel_net_encode(self._h, _lib.ptr(bnf), _lib.ptr(lf0), _lib.ptr(spk), B, T, _lib.ptr(mem),
+                                           _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "mb_ppg2mel_net_encode")
+        return mem
+
+    def postnet(self, mel_outputs):
+        """:186-187: mel_outputs [B, T, num_mels] -> mel_outputs + Postnet(mel_outputs)."""
+        mel = mel_outputs.to(torch.float32).contiguous()
+        B, T, nm = mel.shape
+        if nm != self.num_mels:
+            raise _lib.MbHipError(f"ppg2mel postnet: {nm} mel channels, expected {self.num_mels}")
+        out = torch.empty_like(mel)
+        if T == 0:
+            return out
+        ws = self._workspace(B, T, mel.device)
+        _lib.check(_lib.lib().mb_ppg2mel_net_postnet(self._h, _lib.ptr(mel), B, T, _lib.ptr(out), _lib.ptr(ws), ws.numel(),
+                                                      _lib.stream_ptr()), "mb_ppg2mel_net_postnet")
+        return out
+
+    def inference(self, bottle_neck_features, logf0_uv=None, spembs=None, dropout=None, seed=None):
+        """MelDecoderMOLv2.inference :166-192 -> (mel_outputs[0], mel_outputs_postnet[0], alignments[0])."""
+        memory = self.encode(bottle_neck_features, logf0_uv, spembs)
+        if memory.size(0) > 1:
+            mel, al = self.decoder.inference_batched(memory, dropout=dropout, seed=seed)
+        else:
+            mel, al = self.decoder.inference(memory, dropout=dropout, seed=seed)
+        return mel[0], self.postnet(mel)[0], al[0]
+
+
+def load_model(model_file, device=None):
+    """models/ppg2mel/__init__.py:194-209: the yaml next to the checkpoint gives the constructor arguments
+    (`model:` section), the checkpoint's "model" entry the weights."""
+    import yaml
+    from pathlib import Path
+    model_file = Path(model_file)
+    cfgs = list(model_file.parent.rglob("*.yaml"))
+    if len(cfgs) == 0:
+        raise FileNotFoundError("No model yaml config found for convertor")
+    with open(cfgs[0]) as f:
+        model_cfg = yaml.safe_load(f)["model"]
+    ckpt = torch.load(model_file, map_location="cpu")
+    return MelDecoderMOLv2(ckpt["model"], **model_cfg)

@@ -10,7 +10,11 @@ Dropout: DecoderPrenet applies F.dropout(p=0.5, training=True) at inference (:20
 to draw from the global torch RNG exactly like the reference, or a MaskSource (oracle/tacotron.py) to
 inject pre-drawn keep masks.  MOLAttention's own dropout (:90) is off in eval mode.
 
-Pinned by tests/golden/ppg2mel.npz (outputs of the reference module itself, tests/golden/make_golden.py)."""
+The one-shot networks around the loop -- MelDecoderMOLv2's bnf_prenet / pitch_convs / reduce_proj
+(models/ppg2mel/__init__.py:50-100,166-179) and the CNN postnet (models/ppg2mel/utils/cnn_postnet.py:8-52) --
+are restated by encode() / postnet() / model_inference() on the MelDecoderMOLv2 state_dict.
+
+Pinned by tests/golden/ppg2mel.npz (outputs of the reference modules themselves, tests/golden/make_golden.py)."""
 import torch
 import torch.nn.functional as F
 
@@ -99,3 +103,70 @@ def inference(w, hp, memory, stop_threshold=0.5, masks=None):
     """Decoder.inference :267-316 (memory [1, T_enc, enc_dim]) -> (mel [1, steps*r, num_mels], alignments [1, steps, T_enc])."""
     mel, al, _ = inference_batched(w, hp, memory, stop_threshold, masks)
     return mel, al
+
+
+def inference_batched_cut(w, hp, memory, stop_threshold=0.5, masks=None):
+    """Decoder.inference_batched :318-374 including the per-item cut at the first step above the threshold
+    (:369-373; IndexError, like the reference, for an utterance that never crosses it)."""
+    mel, al, stop = inference_batched(w, hp, memory, stop_threshold, masks)
+    parts = []
+    for b in range(mel.size(0)):
+        idx = int(torch.nonzero(torch.sigmoid(stop[b]) > stop_threshold)[0][0])
+        parts.append(mel[b, :idx, :])
+    return torch.cat(parts, dim=0).unsqueeze(0), al
+
+
+NET_HP = dict(bnf_dim=144, spk_dim=256, enc_dim=256, downsample_rates=(2, 2), num_mels=80)
+
+
+def instance_norm(x, eps=1e-5):  # nn.InstanceNorm1d(affine=False): per (utterance, channel) row, biased variance
+    mean = x.mean(dim=-1, keepdim=True)
+    var = ((x - mean) ** 2).mean(dim=-1, keepdim=True)
+    return (x - mean) / torch.sqrt(var + eps)
+
+
+def _down_branch(w, name, x, rates):  # bnf_prenet / pitch_convs Sequential, models/ppg2mel/__init__.py:50-98
+    x = instance_norm(F.leaky_relu(F.conv1d(x, w[name + ".0.weight"]), 0.1))
+    for idx, r in zip((3, 6), rates):
+        x = F.conv1d(x, w[f"{name}.{idx}.weight"], w[f"{name}.{idx}.bias"], stride=r, padding=r // 2)
+        x = instance_norm(F.leaky_relu(x, 0.1))
+    return x
+
+
+def encode(w, hp, bnf, logf0_uv, spembs):
+    """MelDecoderMOLv2.inference :172-179: bnf [B, T, bnf_dim], logf0_uv [B, T, 2], spembs [B, spk_dim]
+    -> decoder memory [B, T_enc, enc_dim]."""
+    rates = hp["downsample_rates"]
+    x = _down_branch(w, "bnf_prenet", bnf.transpose(1, 2), rates).transpose(1, 2)
+    x = x + _down_branch(w, "pitch_convs", logf0_uv.transpose(1, 2), rates).transpose(1, 2)
+    spk = F.normalize(spembs).unsqueeze(1).expand(-1, x.size(1), -1)
+    return F.linear(torch.cat([x, spk], dim=-1), w["reduce_proj.weight"], w["reduce_proj.bias"])
+
+
+def postnet(w, mel):
+    """mel_outputs + Postnet(mel_outputs) (:186-187; cnn_postnet.py:47-52, eval: BatchNorm running stats, no dropout).
+    mel [B, T, num_mels] -> same shape."""
+    x = mel.transpose(1, 2)
+    n = 0
+    while f"postnet.convolutions.{n}.0.conv.weight" in w:
+        n += 1
+    for i in range(n):
+        p = f"postnet.convolutions.{i}"
+        k = w[p + ".0.conv.weight"].shape[-1]
+        x = F.conv1d(x, w[p + ".0.conv.weight"], w[p + ".0.conv.bias"], padding=(k - 1) // 2)
+        x = F.batch_norm(x, w[p + ".1.running_mean"], w[p + ".1.running_var"], w[p + ".1.weight"], w[p + ".1.bias"],
+                         False, 0.0, 1e-5)
+        if i < n - 1:
+            x = torch.tanh(x)
+    return mel + x.transpose(1, 2)
+
+
+def model_inference(w, hp, net_hp, bnf, logf0_uv, spembs, masks=None):
+    """MelDecoderMOLv2.inference :166-192 -> (mel_outputs[0], mel_outputs_postnet[0], alignments[0])."""
+    memory = encode(w, net_hp, bnf, logf0_uv, spembs)
+    dw = {k[len("decoder."):]: v for k, v in w.items() if k.startswith("decoder.")}
+    if memory.size(0) > 1:
+        mel, al = inference_batched_cut(dw, hp, memory, masks=masks)
+    else:
+        mel, al = inference(dw, hp, memory, masks=masks)
+    return mel[0], postnet(w, mel)[0], al[0]

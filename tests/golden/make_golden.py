@@ -176,6 +176,22 @@ def ppg2mel():
         with torch.no_grad():
             mel, al = d.inference(mem) if B == 1 else d.inference_batched(mem)
         out[name + "_mel"], out[name + "_align"] = mel.numpy(), al.numpy()
+    # the whole MelDecoderMOLv2.inference (models/ppg2mel/__init__.py:166-192) of the real package
+    pkg = refimport.import_ppg2mel_package()
+    nh = synth.PPG2MEL_NET_HP
+    for name, B, T, wseed, sb, iseed, rseed in synth.PPG2MEL_MODEL_CASES:
+        mm = pkg.MelDecoderMOLv2(num_speakers=1, spk_embed_dim=nh["spk_dim"], bottle_neck_feature_dim=nh["bnf_dim"],
+                                 encoder_dim=nh["enc_dim"], encoder_downsample_rates=list(nh["downsample_rates"]))
+        mm.load_state_dict(synth.ppg2mel_model_state(hp, nh, seed=wseed, stop_bias=sb), strict=False)
+        mm.eval()
+        bnf, lf0, spk = (torch.from_numpy(a) for a in synth.ppg2mel_inputs(B, T, seed=iseed))
+        with torch.no_grad():
+            x = mm.bnf_prenet(bnf.transpose(1, 2)).transpose(1, 2) + mm.pitch_convs(lf0.transpose(1, 2)).transpose(1, 2)
+            spk_e = torch.nn.functional.normalize(spk).unsqueeze(1).expand(-1, x.size(1), -1)
+            out[name + "_memory"] = mm.reduce_proj(torch.cat([x, spk_e], dim=-1)).numpy()
+            torch.manual_seed(rseed)
+            mel, melp, al = mm.inference(bnf, logf0_uv=lf0, spembs=spk)
+        out[name + "_mel"], out[name + "_mel_postnet"], out[name + "_align"] = mel.numpy(), melp.numpy(), al.numpy()
     np.savez_compressed(os.path.join(HERE, "ppg2mel.npz"), torch_version=torch.__version__, **out)
     print("ppg2mel.npz", {k: v.shape for k, v in out.items()})
 

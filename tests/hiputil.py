@@ -23,7 +23,7 @@ def pack_conv(w: torch.Tensor, transposed=False, up=1, pad=0):
 
 def conv1d_hip(x, w, bias=None, *, dilation=1, pad=0, transposed=False, up=1, in_act=0, in_slope=0.0,
                in_scale=1.0, out_act=0, out_scale=1.0, res=None, accumulate_into=None, post=None,
-               transpose_out=False, in_repeat=1, device="cuda"):
+               transpose_out=False, in_repeat=1, stride=1, out_slope=0.0, device="cuda"):
     """x [B, Cin, T] CPU/GPU tensor -> y (new tensor, or accumulate_into updated in place)."""
     L = _lib.lib()
     packed, (c_out, c_in, k) = pack_conv(w, transposed, up, pad)
@@ -31,7 +31,7 @@ def conv1d_hip(x, w, bias=None, *, dilation=1, pad=0, transposed=False, up=1, in
     x = x.float().contiguous().to(dev)
     B, _, t_src = x.shape
     t_in = t_src * in_repeat
-    t_out = t_in * up if transposed else t_in + 2 * pad - dilation * (k - 1)
+    t_out = t_in * up if transposed else (t_in + 2 * pad - dilation * (k - 1) - 1) // stride + 1
     a = _lib.ConvArgs()
     pw = packed.to(dev)
     pb = bias.float().contiguous().to(dev) if bias is not None else None
@@ -54,6 +54,7 @@ def conv1d_hip(x, w, bias=None, *, dilation=1, pad=0, transposed=False, up=1, in
     a.in_act, a.in_slope, a.in_scale = in_act, in_slope, in_scale
     a.out_act, a.out_scale, a.accumulate = out_act, out_scale, int(accumulate_into is not None)
     a.in_repeat, a.transpose_out = in_repeat, int(transpose_out)
+    a.down, a.out_slope = stride, out_slope
     _lib.check(L.mb_conv1d(C.byref(a), _lib.stream_ptr()), "mb_conv1d")
     torch.cuda.synchronize()
     return y

@@ -39,3 +39,13 @@ def import_ppg2mel_decoder():
         pkg.__path__ = [os.path.join(REF, "models", "ppg2mel")]
         sys.modules["models.ppg2mel"] = pkg
     return importlib.import_module("models.ppg2mel.rnn_decoder_mol")
+
+
+def import_ppg2mel_package():
+    """The real models/ppg2mel package (__init__.py: MelDecoderMOLv2 with its conv front end and CNN postnet)."""
+    import importlib
+    setup()
+    sys.modules.pop("models.ppg2mel", None)  # drop the stub package import_ppg2mel_decoder() may have registered
+    for k in [k for k in sys.modules if k.startswith("models.ppg2mel.")]:
+        del sys.modules[k]
+    return importlib.import_module("models.ppg2mel")

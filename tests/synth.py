@@ -320,6 +320,57 @@ def ppg2mel_decoder_state(hp=PPG2MEL_HP, seed=0, stop_bias=-2.0):
     return sd
 
 
+PPG2MEL_NET_HP = dict(bnf_dim=144, spk_dim=256, enc_dim=256, downsample_rates=(2, 2), num_mels=80)
+
+
+def ppg2mel_model_state(hp=PPG2MEL_HP, net_hp=PPG2MEL_NET_HP, seed=0, stop_bias=-2.0):
+    """state_dict of models/ppg2mel/__init__.py:MelDecoderMOLv2 (decoder.* from ppg2mel_decoder_state, plus the
+    bnf_prenet / pitch_convs / reduce_proj / postnet entries as the reference registers them); BatchNorm running
+    statistics away from (0, 1) so the eval-mode affine is exercised."""
+    rng = np.random.default_rng(seed + 77)
+    E, S, nm = net_hp["enc_dim"], net_hp["spk_dim"], net_hp["num_mels"]
+    sd = {"decoder." + k: v for k, v in ppg2mel_decoder_state(hp, seed, stop_bias).items()}
+
+    def t(*shape, fan):
+        return torch.from_numpy((rng.standard_normal(shape) / np.sqrt(fan)).astype(np.float32))
+
+    for name, cin in (("bnf_prenet", net_hp["bnf_dim"]), ("pitch_convs", 2)):
+        sd[f"{name}.0.weight"] = t(E, cin, 1, fan=cin)
+        for idx, r in zip((3, 6), net_hp["downsample_rates"]):
+            sd[f"{name}.{idx}.weight"] = t(E, E, 2 * r, fan=E * 2 * r)
+            sd[f"{name}.{idx}.bias"] = t(E, fan=100)
+    sd["reduce_proj.weight"] = t(E, E + S, fan=E)
+    sd["reduce_proj.bias"] = t(E, fan=100)
+    dims = [nm, 512, 512, 512, 512, nm]
+    for i in range(5):
+        p = f"postnet.convolutions.{i}"
+        sd[p + ".0.conv.weight"] = t(dims[i + 1], dims[i], 5, fan=dims[i] * 5)
+        sd[p + ".0.conv.bias"] = t(dims[i + 1], fan=100)
+        sd[p + ".1.weight"] = torch.from_numpy(rng.uniform(0.5, 1.5, dims[i + 1]).astype(np.float32))
+        sd[p + ".1.bias"] = t(dims[i + 1], fan=100)
+        sd[p + ".1.running_mean"] = t(dims[i + 1], fan=100)
+        sd[p + ".1.running_var"] = torch.from_numpy(rng.uniform(0.5, 1.5, dims[i + 1]).astype(np.float32))
+        sd[p + ".1.num_batches_tracked"] = torch.tensor(100)
+    return sd
+
+
+def ppg2mel_inputs(batch, t, seed=0, net_hp=PPG2MEL_NET_HP):
+    """(bottle_neck_features [B, T, bnf_dim], logf0_uv [B, T, 2], spembs [B, spk_dim]) like the convertor feeds
+    MelDecoderMOLv2.inference: PPG posteriors-ish features, normalised log-f0 + a 0/1 voicing flag, a d-vector."""
+    rng = np.random.default_rng(seed + 5)
+    bnf = rng.standard_normal((batch, t, net_hp["bnf_dim"])).astype(np.float32)
+    lf0 = rng.standard_normal((batch, t, 1)).astype(np.float32)
+    uv = (rng.uniform(size=(batch, t, 1)) > 0.3).astype(np.float32)
+    spk = np.abs(rng.standard_normal((batch, net_hp["spk_dim"]))).astype(np.float32)
+    return bnf, np.concatenate([lf0 * uv, uv], axis=-1), spk
+
+
+PPG2MEL_MODEL_CASES = [  # (name, batch, frames, weight seed, stop bias, input seed, torch RNG seed)
+    ("model_b1_t101", 1, 101, 5, -2.0, 1, 11),
+    ("model_b2_t96", 2, 96, 3, 0.0, 2, 12),
+]
+
+
 def ppg2mel_memory(batch, t_enc, seed=0, enc_dim=256):
     """Decoder memory [B, T_enc, enc_dim] (the reference feeds InstanceNorm'd features: O(1))."""
     return np.random.default_rng(seed).standard_normal((batch, t_enc, enc_dim)).astype(np.float32)

@@ -124,3 +124,31 @@ def test_transpose_out_and_repeat(cuda, lib):
     y = hiputil.conv1d_hip(x, w, b, in_repeat=2)
     e = hiputil.relerr(y, ref)
     assert y.shape == ref.shape and e["max_abs"] < 1e-4, e
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T,k,stride,pad", [
+    (2, 256, 256, 403, 4, 2, 1),   # ppg2mel bnf_prenet / pitch_convs downsampling convs (odd T)
+    (1, 256, 256, 96, 4, 2, 1),
+    (1, 64, 96, 1000, 6, 3, 1),    # encoder_downsample_rates = 3
+    (3, 8, 32, 77, 8, 4, 2),
+    (1, 2, 256, 50, 1, 1, 0),      # pitch_convs.0 (two input channels)
+])
+def test_strided_conv_and_leaky_epilogue(cuda, lib, B, Cin, Cout, T, k, stride, pad):
+    """mb_conv1d_args.down (torch `stride`) and out_act 5 (LeakyReLU epilogue): models/ppg2mel/__init__.py:50-98."""
+    x = _rand(B, Cin, T, seed=21)
+    w = _rand(Cout, Cin, k, seed=22) / (Cin * k) ** 0.5
+    b = _rand(Cout, seed=23)
+    ref = F.leaky_relu(F.conv1d(x, w, b, stride=stride, padding=pad), 0.1)
+    y = hiputil.conv1d_hip(x, w, b, pad=pad, stride=stride, out_act=5, out_slope=0.1)
+    assert y.shape == ref.shape
+    e = hiputil.relerr(y, ref)
+    assert e["nan"] == 0 and e["max_abs"] < 1e-4, e
+    yt = hiputil.conv1d_hip(x, w, b, pad=pad, stride=stride, transpose_out=True)
+    assert torch.equal(yt.transpose(1, 2).cpu(), hiputil.conv1d_hip(x, w, b, pad=pad, stride=stride).cpu())
+
+
+def test_strided_conv_rejects_mixed_modes(cuda, lib):
+    from mockingbird_amd._lib import MbHipError
+    x, w = _rand(1, 8, 32), _rand(8, 8, 4)
+    with pytest.raises(MbHipError):
+        hiputil.conv1d_hip(x, w, None, pad=1, stride=2, in_repeat=2)

@@ -234,6 +234,30 @@ def test_ppg2mel_oracle_vs_golden(case):
         assert np.array_equal(torch.cat(parts, 0).unsqueeze(0).numpy(), g[name + "_mel"])
 
 
+@pytest.mark.parametrize("case", synth.PPG2MEL_MODEL_CASES, ids=lambda c: c[0])
+def test_ppg2mel_model_oracle_vs_golden(case):
+    """oracle.ppg2mel encode / postnet / model_inference against the real MelDecoderMOLv2 (conv front end with
+    InstanceNorm, speaker projection, decoder loop on the global RNG, CNN postnet with eval BatchNorm)."""
+    from oracle import ppg2mel as op
+    name, B, T, wseed, sb, iseed, rseed = case
+    g = np.load(os.path.join(G, "ppg2mel.npz"))
+    w = synth.ppg2mel_model_state(synth.PPG2MEL_HP, synth.PPG2MEL_NET_HP, seed=wseed, stop_bias=sb)
+    bnf, lf0, spk = (torch.from_numpy(a) for a in synth.ppg2mel_inputs(B, T, seed=iseed))
+    torch.set_num_threads(1)
+    with torch.no_grad():
+        mem = op.encode(w, synth.PPG2MEL_NET_HP, bnf, lf0, spk)
+        assert mem.shape == g[name + "_memory"].shape == (B, T // 4, 256)
+        assert float(np.abs(mem.numpy() - g[name + "_memory"]).max()) <= 2e-5  # InstanceNorm summation order
+        # downstream of the reference's own memory the chain is bit-exact again
+        gm = torch.from_numpy(g[name + "_memory"])
+        dw = {k[len("decoder."):]: v for k, v in w.items() if k.startswith("decoder.")}
+        torch.manual_seed(rseed)
+        mel, al = (op.inference_batched_cut if B > 1 else op.inference)(dw, dict(op.HP), gm)
+        assert np.array_equal(mel[0].numpy(), g[name + "_mel"]) and np.array_equal(al[0].numpy(), g[name + "_align"])
+        post = op.postnet(w, mel)[0].numpy()
+    assert float(np.abs(post - g[name + "_mel_postnet"]).max()) <= 1e-5
+
+
 def test_ppg2mel_injected_masks_equal_global_rng():
     """The injected-mask mode (what the GPU parity tests use) reproduces the global-RNG mode when the masks
     are drawn with the same generator calls in program order."""

@@ -80,3 +80,51 @@ def test_device_rng_and_errors(cuda, lib):
         dec.decode(mem.cpu())
     with pytest.raises(MbHipError, match="enc_dim"):
         dec.decode(torch.zeros(1, 8, 128).cuda())
+
+
+@pytest.mark.parametrize("B,T,seed", [(1, 101, 1), (2, 96, 2), (3, 1203, 3), (1, 7, 4)])
+def test_net_encode_and_postnet_match_oracle(cuda, lib, B, T, seed):
+    """mb_ppg2mel_net_encode / _postnet (strided convs + LeakyReLU + InstanceNorm, branch sum, speaker concat,
+    reduce_proj; CNN postnet with folded eval BatchNorm + residual) against the oracle restatement of
+    models/ppg2mel/__init__.py:50-100,172-187 (pinned to the real module by ppg2mel.npz)."""
+    from mockingbird_amd.ppg2mel import MelDecoderMOLv2
+    nh = synth.PPG2MEL_NET_HP
+    w = synth.ppg2mel_model_state(synth.PPG2MEL_HP, nh, seed=seed)
+    m = MelDecoderMOLv2(w, spk_embed_dim=nh["spk_dim"], bottle_neck_feature_dim=nh["bnf_dim"])
+    bnf, lf0, spk = (torch.from_numpy(a) for a in synth.ppg2mel_inputs(B, T, seed=seed))
+    with torch.no_grad():
+        omem = op.encode(w, nh, bnf, lf0, spk)
+    mem = m.encode(bnf.cuda(), lf0.cuda(), spk.cuda()).cpu()
+    assert mem.shape == omem.shape == (B, T // 4, 256)
+    assert float((mem - omem).abs().max()) <= 1e-4, float((mem - omem).abs().max())
+    assert float(omem.abs().mean()) > (0.1 if T >= 16 else 0.02)  # T_enc == 1: InstanceNorm zeroes the conv branches
+    mel = torch.from_numpy(np.random.default_rng(seed).standard_normal((B, 2 * (T // 4), 80)).astype(np.float32))
+    with torch.no_grad():
+        opost = op.postnet(w, mel)
+    post = m.postnet(mel.cuda()).cpu()
+    assert float((post - opost).abs().max()) <= 1e-4, float((post - opost).abs().max())
+    assert float((opost - mel).abs().mean()) > 0.05  # the postnet contributes
+
+
+def test_model_inference_surface_and_golden(cuda, lib):
+    """MelDecoderMOLv2.inference end to end against the golden outputs of the real reference model (global-RNG
+    prenet dropout re-drawn with the same generator calls)."""
+    import os
+    from mockingbird_amd.ppg2mel import MelDecoderMOLv2
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ppg2mel.npz"))
+    nh = synth.PPG2MEL_NET_HP
+    for name, B, T, wseed, sb, iseed, rseed in synth.PPG2MEL_MODEL_CASES:
+        w = synth.ppg2mel_model_state(synth.PPG2MEL_HP, nh, seed=wseed, stop_bias=sb)
+        m = MelDecoderMOLv2(w, spk_embed_dim=nh["spk_dim"], bottle_neck_feature_dim=nh["bnf_dim"]).to("cuda").eval()
+        bnf, lf0, spk = (torch.from_numpy(a).cuda() for a in synth.ppg2mel_inputs(B, T, seed=iseed))
+        mem = m.encode(bnf, lf0, spk)
+        assert float(np.abs(mem.cpu().numpy() - g[name + "_memory"]).max()) <= 1e-4
+        torch.manual_seed(rseed)
+        masks = [torch.empty(B, d).bernoulli_(0.5) for _ in range((T // 4) * 2) for d in (256, 128)]
+        mel, melp, al = m.inference(bnf, logf0_uv=lf0, spembs=spk, dropout=masks)
+        assert tuple(mel.shape) == g[name + "_mel"].shape and tuple(al.shape) == g[name + "_align"].shape
+        assert float(np.abs(mel.cpu().numpy() - g[name + "_mel"]).max()) <= MEL_TOL
+        assert float(np.abs(melp.cpu().numpy() - g[name + "_mel_postnet"]).max()) <= MEL_TOL
+        assert float(np.abs(al.cpu().numpy() - g[name + "_align"]).max()) <= ALIGN_TOL
+    with pytest.raises(AssertionError):
+        m.inference(bnf, logf0_uv=lf0, spembs=None)
