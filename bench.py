@@ -330,6 +330,39 @@ def sharded_objects(args, rank, world, dev, use_dist, timed, total_over_ranks):
     return out
 
 
+def gan_floor_bytes(h, batch, frames):
+    """Read-x + write-y floor of one fp16 generator forward (every layer reads its input and writes its output
+    once, 2 B per element; the mean over the parallel ResBlocks adds a read of the accumulator for all but the
+    first): conv_pre, per stage the upsampler and num_kernels x len(dilations) fused pair units, conv_post."""
+    B, T, C = batch, frames, h["upsample_initial_channel"]
+    b = B * T * (h["num_mels"] + C) * 2.0
+    nk, nd = len(h["resblock_kernel_sizes"]), len(h["resblock_dilation_sizes"][0])
+    for u in h["upsample_rates"]:
+        b += B * T * C * 2.0
+        T, C = T * u, C // 2
+        b += B * T * C * 2.0
+        b += nk * nd * 2 * B * T * C * 2.0 + (nk - 1) * B * T * C * 2.0
+    return b + B * T * C * 2.0 + B * T * 4.0
+
+
+def pmc_traffic(what, keys=None):
+    """HBM bytes from the committed rocprofv3 PMC passes of the benchmarked configuration (profiles/r02_pmc_<what>.json,
+    tools/pmc_r02.sh: 2 x FETCH_SIZE + WRITE_SIZE per launch; counters cannot be read in-process).  keys = kernels to
+    sum per launch; None = all bytes of the profiled command.  Returns (bytes, source) or (None, None)."""
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", f"r02_pmc_{what}.json")))
+    except Exception:
+        return None, None
+    if keys is None:
+        tot = sum(v for k, v in pm.items() if k.endswith("_hbm_bytes_total")) / max(pm.get("forwards", 1), 1)
+    else:
+        vals = [pm.get(k + "_hbm_bytes_per_launch") for k in keys]
+        if any(v is None for v in vals):
+            return None, None
+        tot = sum(vals)
+    return tot, f"profiles/r02_pmc_{what}.json: {pm.get('source', '')[:200]}"
+
+
 def main():
     args = parse()
     spawn_ranks_if_needed(args)
@@ -490,7 +523,7 @@ def main():
             except Exception:
                 pass
         result["roofline"] = {
-            "kernel": ("mb::rnn_dual_linear_kernel<4, ..., 4, ...> (WaveRNN fc1 beside the hidden half of the next step's "
+            "kernel": ("mb::wf_fc_hh_kernel<NT> (wavernn_fast.h: WaveRNN fc1 beside the hidden half of the next step's "
                        "rnn1, in-situ marginal duration)" if split else
                        "mb::rnn_rowtile_kernel<EPI_GRU, 1, 8, ...> (WaveRNN rnn2 instance, in-situ marginal duration)"),
             "chain": "split-hidden" if split else "classic",
@@ -589,6 +622,9 @@ def main():
                     "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": peak,
                                  "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / 1e12 / peak, "traffic": None},
                 }
+                if dt == "f16":  # PMC pass of this object: HBM bytes of one forward against the read-x + write-y floor
+                    tr, src = pmc_traffic("hifigan")
+                    entry["roofline"].update({"traffic": tr, "traffic_source": src, "traffic_floor_bytes": gan_floor_bytes(h, 32, 200)})
                 if dt == "f32":
                     y32 = y
                 else:
@@ -610,6 +646,9 @@ def main():
                 "roofline": {"bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12, "peak": MFMA_F16_PEAK_TFLOPS,
                              "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, "traffic": None},
             }
+            tr, src = pmc_traffic("fregan")
+            result["fregan_f16"]["roofline"].update({"traffic": tr, "traffic_source": src,
+                                                     "traffic_floor_bytes": gan_floor_bytes(hf, 8, 3000)})
             del gen, y, gmf
         # ---- secondary: Tacotron synthesize (BASELINE configs[2]): B=32, ~100 tokens, r=2, 400 frames forced
         if not args.no_tacotron:
@@ -639,6 +678,8 @@ def main():
             iters = getattr(tdev, "last_loop_iterations", 200) or 200
             it_us = loop_ms * 1e3 / iters if loop_ms else td * 1e6 / 200
             bytes_it = 81.06e6 + 32 * Tt * (1024 + 128) * 4  # decoder weights + attention memory, per iteration
+            # PMC pass of this configuration: the launches of one iteration (lstm runs twice)
+            t_traffic, t_src = pmc_traffic("tacotron", ["prenet_fc2", "attn_gru", "lsa", "rnn_input", "lstm", "lstm", "mel_proj"])
             result["tacotron"] = {
                 "workload": "Tacotron generate (text encoder + GST + 200 decoder iterations r=2 + CBHG postnet), "
                             f"batch 32 x ~100 tokens (T={Tt}), 400 mel frames forced, fp32, on-device dropout RNG",
@@ -648,8 +689,8 @@ def main():
                 "roofline": {"bound": "hbm", "kernel": "decoder iteration (taco_fast.h: 7 launches per iteration, hipGraph replays; 81.06 MB "
                                                        "fp32 weights + attention memory per iteration)",
                              "achieved": bytes_it / (it_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": bytes_it / (it_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                             "algorithmic_bytes_per_iteration": bytes_it,
+                             "frac": bytes_it / (it_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": t_traffic,
+                             "traffic_source": t_src, "algorithmic_bytes_per_iteration": bytes_it,
                              "timing": "HIP events on the loop's stream around the 200 iterations" if loop_ms else
                                        "decode + postnet wall time / 200 (upper bound on the iteration time)"},
             }

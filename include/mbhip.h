@@ -18,6 +18,10 @@
  *  - Handles own their device weights (hipMalloc); workspaces are caller
  *    owned so the caller's allocator (e.g. torch's caching allocator) decides
  *    placement.  Query the size first.
+ *  - A handle is single-threaded: the loop handles (mb_wavernn, mb_taco, mb_ppg2mel) keep mutable
+ *    stream / event / hipGraph state, so concurrent calls need one handle each.  When a call that
+ *    already queued work on the handle's own streams fails, it drains those streams before it
+ *    returns the error, so the caller may release the buffers it passed.
  */
 #ifndef MBHIP_H
 #define MBHIP_H

@@ -640,10 +640,21 @@ static int run_cond_conv(const CondConv& cc, const float* x, int t, float* y, co
   return mb_conv1d(&a, (mb_stream_t)s);
 }
 
-extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* plan, const float* d_mel,
-                                   const float* d_noise, uint64_t seed, float* d_samples,
-                                   float* d_logits_out, const float* d_forced, int* h_progress,
-                                   void* d_workspace, size_t workspace_bytes, mb_stream_t stream) {
+// Error exits of the two generate entry points: work may already be queued on the handle's own lane streams, which
+// the caller's stream is not ordered after until the final join.  Drain them so that the caller may free or reuse
+// the workspace / mel / sample buffers once the error is returned.  (A handle is single-threaded: it owns mutable
+// graph, event and stream state; concurrent calls need one handle each.)
+static int wavernn_join_on_error(mb_wavernn* w, int rc) {
+  if (rc && w)
+    for (int l = 0; l < mb_wavernn::MAX_LANES; ++l)
+      if (w->lane_stream[l]) (void)hipStreamSynchronize(w->lane_stream[l]);
+  return rc;
+}
+
+static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* plan, const float* d_mel,
+                                 const float* d_noise, uint64_t seed, float* d_samples,
+                                 float* d_logits_out, const float* d_forced, int* h_progress,
+                                 void* d_workspace, size_t workspace_bytes, mb_stream_t stream) {
   mb_wavernn* w = const_cast<mb_wavernn*>(wc);
   MB_REQUIRE(w && plan && d_mel && d_samples, "wavernn_generate: null pointer");
   WrnLayout L;
@@ -1118,9 +1129,18 @@ extern "C" int mb_wavernn_plan_generate_batch(const mb_wavernn* w, int n_utt, co
   return MB_OK;
 }
 
-extern "C" int mb_wavernn_generate_batch(const mb_wavernn* wc, const mb_wavernn_batch_plan* plan, const int* h_frames,
-                                         const float* const* h_d_mels, const uint64_t* h_seeds, float* d_samples,
-                                         void* d_workspace, size_t workspace_bytes, mb_stream_t stream) {
+extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* plan, const float* d_mel,
+                                   const float* d_noise, uint64_t seed, float* d_samples,
+                                   float* d_logits_out, const float* d_forced, int* h_progress,
+                                   void* d_workspace, size_t workspace_bytes, mb_stream_t stream) {
+  return wavernn_join_on_error(const_cast<mb_wavernn*>(wc),
+                               wavernn_generate_impl(wc, plan, d_mel, d_noise, seed, d_samples, d_logits_out, d_forced,
+                                                     h_progress, d_workspace, workspace_bytes, stream));
+}
+
+static int wavernn_generate_batch_impl(const mb_wavernn* wc, const mb_wavernn_batch_plan* plan, const int* h_frames,
+                                       const float* const* h_d_mels, const uint64_t* h_seeds, float* d_samples,
+                                       void* d_workspace, size_t workspace_bytes, mb_stream_t stream) {
   mb_wavernn* w = const_cast<mb_wavernn*>(wc);
   MB_REQUIRE(w && plan && h_frames && h_d_mels && h_seeds && d_samples, "wavernn_generate_batch: null pointer");
   MB_REQUIRE(w->cfg.mode == 0, "wavernn_generate_batch: RAW mode only (the shared loop is the fused-sampler chain); run MOL utterances one by one");
@@ -1288,6 +1308,14 @@ extern "C" int mb_wavernn_generate_batch(const mb_wavernn* wc, const mb_wavernn_
   MB_HIP(hipStreamWaitEvent(cs, w->ev_out, 0));
 #undef RC
   return MB_OK;
+}
+
+extern "C" int mb_wavernn_generate_batch(const mb_wavernn* wc, const mb_wavernn_batch_plan* plan, const int* h_frames,
+                                         const float* const* h_d_mels, const uint64_t* h_seeds, float* d_samples,
+                                         void* d_workspace, size_t workspace_bytes, mb_stream_t stream) {
+  return wavernn_join_on_error(const_cast<mb_wavernn*>(wc),
+                               wavernn_generate_batch_impl(wc, plan, h_frames, h_d_mels, h_seeds, d_samples, d_workspace,
+                                                           workspace_bytes, stream));
 }
 
 extern "C" int mb_wavernn_last_loop_ms(const mb_wavernn* w, float* ms, int* launches) {

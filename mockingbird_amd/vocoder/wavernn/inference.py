@@ -118,13 +118,60 @@ class WaveRNNDevice:
         seeds = [_lib.fresh_seed() for _ in range(n)] if seeds is None else [int(x) for x in seeds]
         if self.cfg.mode == 1:  # MOL: the shared loop is the RAW fused-sampler chain; utterances run one by one
             return [self.generate_samples(m, True, target, overlap, seed=sd) for m, sd in zip(mels, seeds)]
-        frames = (C.c_int * n)(*[int(m.shape[1]) for m in mels])
+        dev = mels[0].device
+        out = []
+        for lo, hi in self.batch_groups([int(m.shape[1]) for m in mels], target, overlap, self._budget(dev)):
+            out += self._run_group(mels[lo:hi], seeds[lo:hi], target, overlap, dev)
+        return out
+
+    workspace_budget_bytes = None  # cap on one sample loop's workspace; None = 85 % of the HBM free at call time
+
+    def _budget(self, dev):
+        if self.workspace_budget_bytes is not None:
+            return int(self.workspace_budget_bytes)
+        free, _ = torch.cuda.mem_get_info(dev)
+        held = self._ws.numel() if self._ws is not None and self._ws.device == dev else 0
+        return int(0.85 * (free + held))
+
+    def _plan_batch(self, frames, target, overlap):
+        n = len(frames)
+        cfr = (C.c_int * n)(*frames)
         offs = (C.c_int * (n + 1))()
         plan = _lib.WaveRNNBatchPlan()
-        L = _lib.lib()
-        _lib.check(L.mb_wavernn_plan_generate_batch(self._h, n, frames, int(target), int(overlap), C.byref(plan), offs),
+        _lib.check(_lib.lib().mb_wavernn_plan_generate_batch(self._h, n, cfr, int(target), int(overlap), C.byref(plan), offs),
                    "mb_wavernn_plan_generate_batch")
-        dev = mels[0].device
+        return plan, cfr, offs
+
+    def batch_groups(self, frames, target, overlap, budget):
+        """The conditioning tables cost about 8.6 KB per output sample (1.7 GB per 1000 mel frames), so a large
+        batch is cut into consecutive groups whose workspace fits `budget` bytes and the groups run one sample
+        loop after the other (per-utterance seeds make the result independent of the grouping).  One utterance
+        that does not fit by itself is an error, not an allocator failure."""
+        groups, lo = [], 0
+        while lo < len(frames):
+            hi = lo + 1
+            if self._plan_batch(frames[lo:hi], target, overlap)[0].workspace_bytes > budget:
+                need = self._plan_batch(frames[lo:hi], target, overlap)[0].workspace_bytes
+                raise _lib.MbHipError(f"WaveRNN: utterance {lo} ({frames[lo]} frames) needs a {need / 2**30:.1f} GiB "
+                                      f"workspace, over the {budget / 2**30:.1f} GiB budget")
+            # grow geometrically, then bisect: plan calls are host arithmetic
+            step = 1
+            while hi < len(frames):
+                nxt = min(len(frames), hi + step)
+                if self._plan_batch(frames[lo:nxt], target, overlap)[0].workspace_bytes > budget:
+                    if step == 1:
+                        break
+                    step = max(1, step // 2)
+                    continue
+                hi, step = nxt, step * 2
+            groups.append((lo, hi))
+            lo = hi
+        return groups
+
+    def _run_group(self, mels, seeds, target, overlap, dev):
+        n = len(mels)
+        L = _lib.lib()
+        plan, frames, offs = self._plan_batch([int(m.shape[1]) for m in mels], target, overlap)
         if self._ws is None or self._ws.numel() < plan.workspace_bytes or self._ws.device != dev:
             self._ws = None
             self._ws = torch.empty(plan.workspace_bytes, dtype=torch.uint8, device=dev)

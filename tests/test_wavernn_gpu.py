@@ -300,6 +300,31 @@ def test_batch_loop_equals_single_utterance_runs(model):
         assert wv.dtype == np.float64 and np.isfinite(wv).all() and len(wv) <= (f - 1) * 256
 
 
+def test_batch_degrades_into_groups_under_a_workspace_budget(model):
+    """A batch whose conditioning tables exceed the workspace budget runs as consecutive groups (one sample loop
+    each) with the same result; one utterance over the budget is a clear error, not an allocator failure."""
+    from mockingbird_amd._lib import MbHipError
+    dev, w = model
+    frames = [41, 30, 57, 22, 35]
+    mels = [torch.from_numpy(synth.wavernn_mel(f, seed=40 + i) / 4.0).cuda() for i, f in enumerate(frames)]
+    seeds = [3, 1, 4, 1, 5]
+    whole = dev.generate_samples_batch(mels, 2000, 200, seeds)
+    one = dev._plan_batch([57], 2000, 200)[0].workspace_bytes
+    alln = dev._plan_batch(frames, 2000, 200)[0].workspace_bytes
+    try:
+        dev.workspace_budget_bytes = int(one * 1.7)
+        groups = dev.batch_groups(frames, 2000, 200, dev.workspace_budget_bytes)
+        assert len(groups) >= 3 and groups[0][0] == 0 and groups[-1][1] == len(frames), (groups, one, alln)
+        assert all(a[1] == b[0] for a, b in zip(groups, groups[1:]))
+        parts = dev.generate_samples_batch(mels, 2000, 200, seeds)
+        assert all(torch.equal(a, b) for a, b in zip(whole, parts))
+        dev.workspace_budget_bytes = one // 2
+        with pytest.raises(MbHipError, match="budget"):
+            dev.generate_samples_batch(mels, 2000, 200, seeds)
+    finally:
+        dev.workspace_budget_bytes = None
+
+
 @pytest.mark.parametrize("form", ["auto", "ts", "ts2_nt1", "ts2_nt2", "ts2_nt3"])
 def test_wide_batch_tile_split_equals_single_runs(model, monkeypatch, form):
     """More than 64 columns: the loop switches to the wide forms of the recurrent GEMM -- rnn_body.h TS (one tile

@@ -1,0 +1,46 @@
+"""Combine the FETCH_SIZE / WRITE_SIZE summaries of tools/pmc_r02.sh into profiles/r02_pmc_<what>.json: HBM bytes per
+launch per kernel = 2 x FETCH_SIZE (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md) + WRITE_SIZE, both in
+KB per dispatch, mean over all dispatches of the benchmarked configuration."""
+import json, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two separate passes), %s, MBHIP_NO_GRAPH=1 (counter mode "
+       "crashes on hipGraph replays; same kernels and arguments); KB per dispatch, mean over all dispatches; FETCH_SIZE "
+       "doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B)")
+WHAT = {
+    "wavernn": ("tools/wrn_run.py 1000 (BASELINE configs[1]: 23 folds x 9600 steps)",
+                {"gru1_finish": ["wf_finish_kernel"], "rnn2_input_half": ["wf_rnn2_kernel"], "fc1_hh1": ["wf_fc_hh_kernel"],
+                 "fc3_sampler": ["wf_fc3_kernel"]}),
+    "tacotron": ("tools/taco_run.py (BASELINE configs[2]: B=32, ~100 tokens, 400 decoder iterations)",
+                 {"prenet_fc2": ["taco_fc2_kernel"], "attn_gru": ["taco_gru_kernel"], "lsa": ["lsa_hh_kernel"],
+                  "rnn_input": ["taco_rin_kernel"], "lstm": ["taco_lstm_kernel"], "mel_proj": ["taco_mel_kernel"]}),
+    "hifigan": ("tools/gan_run.py hifigan f16 32 200 (bench object hifigan_f16)",
+                {"resblock_pair": ["resblock_pair"], "conv1d_f16": ["conv1d_f16"]}),
+    "fregan": ("tools/gan_run.py fregan f16 8 3000 (bench object fregan_f16)",
+               {"resblock_pair": ["resblock_pair"], "conv1d_f16": ["conv1d_f16"]}),
+}
+for what, (cmd, names) in WHAT.items():
+    try:
+        f = json.load(open(os.path.join(ROOT, "gpurun_out", f"pmc2_{what}_FETCH_SIZE.json")))
+        w = json.load(open(os.path.join(ROOT, "gpurun_out", f"pmc2_{what}_WRITE_SIZE.json")))
+    except Exception as e:
+        print(what, "skipped:", e)
+        continue
+    out = {"source": SRC % cmd, "kernels": {}}
+    if what in ("hifigan", "fregan"):
+        out["forwards"] = 3  # tools/gan_run.py: one warm-up + two timed forwards
+    for name, subs in names.items():
+        # every instance (template arguments differ per layer shape): aggregate all kernels matching the substrings
+        ks = [k for k in f if all(s in k for s in subs) and k in w]
+        per = []
+        for k in ks:
+            fe, wr = f[k]["FETCH_SIZE"]["mean_per_dispatch"], w[k]["WRITE_SIZE"]["mean_per_dispatch"]
+            per.append({"kernel": k[:160], "dispatches": f[k]["FETCH_SIZE"]["dispatches"], "FETCH_SIZE_KB": fe, "WRITE_SIZE_KB": wr,
+                        "hbm_bytes_per_launch": (2.0 * fe + wr) * 1024.0})
+        if not per:
+            continue
+        n = sum(p["dispatches"] for p in per)
+        out["kernels"][name] = per
+        out[name + "_hbm_bytes_per_launch"] = sum(p["hbm_bytes_per_launch"] * p["dispatches"] for p in per) / max(n, 1)
+        out[name + "_hbm_bytes_total"] = sum(p["hbm_bytes_per_launch"] * p["dispatches"] for p in per)
+    json.dump(out, open(os.path.join(ROOT, "profiles", f"r02_pmc_{what}.json"), "w"), indent=1)
+    print(what, json.dumps({k: round(v) for k, v in out.items() if k.endswith("per_launch")}))
