@@ -816,6 +816,9 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
     unsigned long long* slot_prev = L.slots + (size_t)(pp ^ 1) * N + n0;  // written by fc3 of step s-1
     unsigned long long* slot_cur = L.slots + (size_t)pp * N + n0;         // written by fc3 of this step
     if (fastk) {  // wavernn_fast.h: A | B | C | D | E on FM activations (one lane: n0 = 0, nl = N)
+      // diagnostics only (tools/pmc_wavernn_r02.sh): run just the launches whose bit is set -- rocprofv3 counter mode
+      // cannot survive the interleaved chain, one launch type at a time it can.  Results are garbage.
+      if (const char* dbg = getenv("MBHIP_WF_DBG_WHICH")) which &= atoi(dbg);
       if (which & 1) {
         WfFinK f;
         f.g = wg; f.g.step_off = soff; f.slot = slot_prev; f.P1 = reinterpret_cast<const float4*>(L.f_P1);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-2 HBM-traffic counters (rocprofv3 counter mode, FETCH_SIZE and WRITE_SIZE in separate passes) of the
-# BENCHMARKED configurations: WaveRNN configs[1] (23 folds x 9600 steps), Tacotron configs[2] (B=32, 400 steps),
+# BENCHMARKED configurations (WaveRNN: tools/pmc_wavernn_r02.sh): Tacotron configs[2] (B=32, 400 steps),
 # HiFi-GAN f16 32x200 and Fre-GAN f16 8x3000.  Counter mode crashes on hipGraph replays, so the loops run
 # eagerly (MBHIP_NO_GRAPH=1): same kernels, same arguments.  Summaries -> gpurun_out/pmc2_<what>_<counter>.json
 export TMPDIR=/tmp MBHIP_NO_GRAPH=1
@@ -9,15 +9,14 @@ run() {  # name, command...
   local name=$1; shift
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rm -rf gpurun_out/pmc2_tmp
-    timeout 900 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d gpurun_out/pmc2_tmp -o p -- "$@" > gpurun_out/pmc2_${name}_$ctr.log 2>&1
+    timeout -k 5 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d gpurun_out/pmc2_tmp -o p -- "$@" > gpurun_out/pmc2_${name}_$ctr.log 2>&1
     echo "$name $ctr rc=$?"
     python tools/pmc_summary.py gpurun_out/pmc2_tmp gpurun_out/pmc2_${name}_$ctr.json | head -8
     rm -rf gpurun_out/pmc2_tmp
   done
 }
-for what in ${@:-wavernn tacotron hifigan fregan}; do
+for what in ${@:-tacotron hifigan fregan}; do
   case $what in
-    wavernn) run wavernn python tools/wrn_run.py 1000 1 ;;
     tacotron) run tacotron python tools/taco_run.py 1 ;;
     hifigan) run hifigan python tools/gan_run.py hifigan f16 32 200 2 ;;
     fregan) run fregan python tools/gan_run.py fregan f16 8 3000 2 ;;

@@ -1,4 +1,5 @@
-"""Combine the FETCH_SIZE / WRITE_SIZE summaries of tools/pmc_r02.sh into profiles/r02_pmc_<what>.json: HBM bytes per
+"""(WaveRNN: tools/pmc_wavernn_r02.sh -- its fast chain has to be profiled one launch type at a time.)
+Combine the FETCH_SIZE / WRITE_SIZE summaries of tools/pmc_r02.sh into profiles/r02_pmc_<what>.json: HBM bytes per
 launch per kernel = 2 x FETCH_SIZE (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md) + WRITE_SIZE, both in
 KB per dispatch, mean over all dispatches of the benchmarked configuration."""
 import json, os
@@ -7,9 +8,6 @@ SRC = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two separate pas
        "crashes on hipGraph replays; same kernels and arguments); KB per dispatch, mean over all dispatches; FETCH_SIZE "
        "doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B)")
 WHAT = {
-    "wavernn": ("tools/wrn_run.py 1000 (BASELINE configs[1]: 23 folds x 9600 steps)",
-                {"gru1_finish": ["wf_finish_kernel"], "rnn2_input_half": ["wf_rnn2_kernel"], "fc1_hh1": ["wf_fc_hh_kernel"],
-                 "fc3_sampler": ["wf_fc3_kernel"]}),
     "tacotron": ("tools/taco_run.py (BASELINE configs[2]: B=32, ~100 tokens, 400 decoder iterations)",
                  {"prenet_fc2": ["taco_fc2_kernel"], "attn_gru": ["taco_gru_kernel"], "lsa": ["lsa_hh_kernel"],
                   "rnn_input": ["taco_rin_kernel"], "lstm": ["taco_lstm_kernel"], "mel_proj": ["taco_mel_kernel"]}),
