@@ -522,14 +522,21 @@ def main():
                     break
             except Exception:
                 pass
+        launch_us = result["config"]["us_per_time_step"] / 5.0  # every launch of the chain, back to back
+        dom_gbps = dom["algorithmic_bytes"] / (launch_us * 1e-6) / 1e9
         result["roofline"] = {
             "kernel": ("mb::wf_fc_hh_kernel<NT> (wavernn_fast.h: WaveRNN fc1 beside the hidden half of the next step's "
-                       "rnn1, in-situ marginal duration)" if split else
+                       "rnn1; the launch with the most bytes of the chain)" if split else
                        "mb::rnn_rowtile_kernel<EPI_GRU, 1, 8, ...> (WaveRNN rnn2 instance, in-situ marginal duration)"),
             "chain": "split-hidden" if split else "classic",
-            "bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-            "algorithmic_bytes_per_launch": dom["algorithmic_bytes"], "avg_launch_us": dom["avg_us"],
+            "bound": "hbm", "achieved": dom_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": dom_gbps / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": dom["algorithmic_bytes"], "avg_launch_us": launch_us,
+            "avg_launch_us_method": "HIP events on the loop's stream around the whole sample loop / launches: the mean "
+                                    "launch-to-launch period of the 5-launch chain, which is what rocprofv3 --kernel-trace "
+                                    "reports per kernel (4.5-4.8 us each with tracing attached, profiles/r02_bench_*_kernel_stats.csv); "
+                                    "per_kernel[*].avg_us are in-situ MARGINAL times (loop timed with and without that launch)",
+            "marginal_us": dom["avg_us"], "marginal_GBps": dom["GBps"],
             "whole_step": {"algorithmic_bytes": 16.3e6 + 452.0 * plan.n_folds,
                            "us": result["config"]["us_per_time_step"],
                            "GBps": (16.3e6 + 452.0 * plan.n_folds) / (result["config"]["us_per_time_step"] * 1e-6) / 1e9},
