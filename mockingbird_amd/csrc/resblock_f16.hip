@@ -442,7 +442,6 @@ static int launch_pair(ResPairK k, int batch, hipStream_t s) {
   // as many x-window buffers as fit (<= 4): the loaders run nbuf-1 chunks ahead of the MMA waves
   int nbuf = pair_min_nbuf<C>(NTW, k.ntaps, k.dil);
   while (nbuf < 4 && pair_lds_bytes<C>(NTW, k.ntaps, k.dil, nbuf + 1, YS) <= PAIR_LDS_CAP) ++nbuf;
-  if (const char* e = getenv("MBHIP_PAIR_NBUF")) { const int f = atoi(e); if (f >= pair_min_nbuf<C>(NTW, k.ntaps, k.dil) && f <= nbuf) nbuf = f; }
   k.nbuf = nbuf;
   if (const char* e = getenv("MBHIP_PAIR_DBG")) k.dbg = atoi(e);
   static unsigned long long* d_trace = nullptr;
@@ -575,9 +574,8 @@ extern "C" int mb_resblock_pair_f16(const mb_resblock_pair_f16_args* a, mb_strea
     case 256: MB_PICK2(256, 1, 3, 2, false, 4, 1, false);
     case 128: MB_PICK2(128, 2, 2, 2, false, 3, 2, false);
     case 64:
-      // N1 = 256 with its own y tile (support waves overlap the whole tile) vs N1 = 512 sharing the h tile;
-      // MBHIP_PAIR_C64=big selects the latter
-      prefer_b = !(getenv("MBHIP_PAIR_C64") && strcmp(getenv("MBHIP_PAIR_C64"), "big") == 0);
+      // N1 = 256 with its own y tile (support waves overlap the whole tile) measured faster than N1 = 512 sharing the h tile
+      prefer_b = true;
       MB_PICK2(64, 4, 4, 1, false, 2, 2, true);
     case 16: prefer_b = true; MB_PICK2(16, 4, 4, 2, true, 8, 2, true);  // 1024-position tiles: per-tile overheads amortise
     default: prefer_b = true; MB_PICK2(32, 4, 2, 2, true, 4, 2, true);

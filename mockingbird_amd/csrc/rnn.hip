@@ -136,10 +136,6 @@ __global__ __launch_bounds__(256) void rnn_dual_linear_ts2_kernel(RnnDev d0, Rnn
   if ((int)blockIdx.x < nx0) rnn_ts2_body<EPI_LINEAR, F0, MT, NT>(d0, blockIdx.x, blockIdx.y);
   else rnn_ts2_body<EPI_LINEAR, F1, MT, NT>(d1, blockIdx.x - nx0, blockIdx.y);
 }
-static unsigned rnn_ts2_lds() {  // diagnostics: dynamic LDS per workgroup (limits workgroups per CU)
-  const char* e = getenv("MBHIP_TS2_LDS");
-  return e ? (unsigned)atoi(e) : 0u;
-}
 // Column tiles per wave of the register-tiled wide form, 0 = use the first wide form (rnn_body.h TS).
 // 128 row tiles in pieces of 2 make 16 workgroup rows, so the piece must be narrow enough for >= 256 workgroups:
 // 3 column tiles from 44 column tiles up (736 columns: exactly one piece per SIMD), 2 from 28, 1 from 14; narrower
@@ -153,10 +149,7 @@ static int rnn_ts2_nt(int N) {
   const int ct = cdiv(N, 16);
   return ct >= 44 ? 3 : ct >= 28 ? 2 : ct >= 14 ? 1 : 0;
 }
-static bool rnn_ts_enabled(int N) {
-  const char* e = getenv("MBHIP_RNN_TS");
-  return N > 64 && !(e && atoi(e) == 0);
-}
+static bool rnn_ts_enabled(int N) { return N > 64; }
 
 // Two independent GRU steps in ONE launch (the forward and backward directions of a bidirectional scan,
 // cbhg.py:76-77): blockIdx.x < nx0 -> job 0, else job 1.  Halves the launch count of the CBHG scans.
@@ -254,9 +247,9 @@ int rnn_launch_dual_linear(const RnnK& k0, const RnnK& k1, hipStream_t s) {
     dim3 g2(cdiv(nx0, MT * TS2_WAVES) + cdiv(nx1, MT * TS2_WAVES), cdiv(cdiv(k0.N, 16), nt2));
     MB_REQUIRE(k0.nkb_total == k1.nkb_total, "rnn_launch_dual(ts2): jobs must share K");
     const int nxw = cdiv(nx0, MT * TS2_WAVES);
-    if (nt2 == 3) hipLaunchKernelGGL((rnn_dual_linear_ts2_kernel<F0 | RF_FOLDTAB, F1, MT, 3>), g2, dim3(256), rnn_ts2_lds(), s, d0, d1, nxw);
-    else if (nt2 == 2) hipLaunchKernelGGL((rnn_dual_linear_ts2_kernel<F0 | RF_FOLDTAB, F1, MT, 2>), g2, dim3(256), rnn_ts2_lds(), s, d0, d1, nxw);
-    else hipLaunchKernelGGL((rnn_dual_linear_ts2_kernel<F0 | RF_FOLDTAB, F1, MT, 1>), g2, dim3(256), rnn_ts2_lds(), s, d0, d1, nxw);
+    if (nt2 == 3) hipLaunchKernelGGL((rnn_dual_linear_ts2_kernel<F0 | RF_FOLDTAB, F1, MT, 3>), g2, dim3(256), 0, s, d0, d1, nxw);
+    else if (nt2 == 2) hipLaunchKernelGGL((rnn_dual_linear_ts2_kernel<F0 | RF_FOLDTAB, F1, MT, 2>), g2, dim3(256), 0, s, d0, d1, nxw);
+    else hipLaunchKernelGGL((rnn_dual_linear_ts2_kernel<F0 | RF_FOLDTAB, F1, MT, 1>), g2, dim3(256), 0, s, d0, d1, nxw);
     MB_HIP(hipGetLastError());
     return MB_OK;
   }
@@ -357,13 +350,13 @@ int rnn_launch(int epi, const RnnK& k, hipStream_t s) {
     if (const int nt2 = rnn_ts2_nt(k.N)) {
       if (epi == EPI_GRU && feat == FG) {  // rnn2: 128 row tiles -> 2 x nt2 tiles per wave
         dim3 g2(cdiv(n_mt, 2 * TS2_WAVES), cdiv(cdiv(k.N, 16), nt2));
-        if (nt2 == 3) hipLaunchKernelGGL((rnn_ts2_kernel<EPI_GRU, FG, 2, 3>), g2, dim3(256), rnn_ts2_lds(), s, d);
-        else if (nt2 == 2) hipLaunchKernelGGL((rnn_ts2_kernel<EPI_GRU, FG, 2, 2>), g2, dim3(256), rnn_ts2_lds(), s, d);
-        else hipLaunchKernelGGL((rnn_ts2_kernel<EPI_GRU, FG, 2, 1>), g2, dim3(256), rnn_ts2_lds(), s, d);
+        if (nt2 == 3) hipLaunchKernelGGL((rnn_ts2_kernel<EPI_GRU, FG, 2, 3>), g2, dim3(256), 0, s, d);
+        else if (nt2 == 2) hipLaunchKernelGGL((rnn_ts2_kernel<EPI_GRU, FG, 2, 2>), g2, dim3(256), 0, s, d);
+        else hipLaunchKernelGGL((rnn_ts2_kernel<EPI_GRU, FG, 2, 1>), g2, dim3(256), 0, s, d);
         done = true;
       } else if (epi == EPI_LINEAR && feat == FL) {  // fc3 + sampler: 32 row tiles only -> 2 x 1 tiles per wave at every width
         dim3 g2(cdiv(n_mt, MB_TS2_FC3_MT * TS2_WAVES), cdiv(cdiv(k.N, 16), MB_TS2_FC3_NT));
-        hipLaunchKernelGGL((rnn_ts2_kernel<EPI_LINEAR, FL, MB_TS2_FC3_MT, MB_TS2_FC3_NT>), g2, dim3(256), rnn_ts2_lds(), s, d); done = true;
+        hipLaunchKernelGGL((rnn_ts2_kernel<EPI_LINEAR, FL, MB_TS2_FC3_MT, MB_TS2_FC3_NT>), g2, dim3(256), 0, s, d); done = true;
       }
     }
     if (done) {}

@@ -1,0 +1,89 @@
+"""Every run-time switch of libmbhip that selects another code path for the SAME arithmetic is exercised here (or in
+the test named beside it in DESIGN.md's switch table): a switch that is not tested does not stay in the library."""
+import numpy as np
+import pytest
+import torch
+
+import hiputil
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def wavernn(cuda, lib):
+    from mockingbird_amd.vocoder.wavernn.inference import WaveRNNDevice
+    return WaveRNNDevice(synth.wavernn_state(seed=5)["model_state"])
+
+
+@pytest.mark.parametrize("env", [{"MBHIP_WAVERNN_FAST": "0"}, {"MBHIP_WAVERNN_FAST_NT": "1"}, {"MBHIP_GRAPH_STEPS": "32"},
+                                 {"MBHIP_NO_GRAPH": "1"}, {"MBHIP_WAVERNN_LANES": "2"},
+                                 {"MBHIP_WAVERNN_FAST": "0", "MBHIP_WAVERNN_CHAIN": "classic"}],
+                         ids=lambda e: ",".join(f"{k[6:]}={v}" for k, v in e.items()))
+def test_wavernn_switches_keep_the_sample_stream(wavernn, monkeypatch, env):
+    """FM fast chain (default) == round-1 row-tile chain == classic chain, one or two column tiles per workgroup,
+    any graph length, eager launches, two lanes: the same Philox stream and bit-identical sums -> identical samples."""
+    mel = torch.from_numpy(synth.wavernn_mel(45, seed=8) / 4.0).cuda()  # 3 folds of 4400: > 16 columns never; nta = 1
+    mel2 = torch.from_numpy(synth.wavernn_mel(330, seed=9) / 4.0).cuda()  # 18 folds -> two column tiles
+    for k in list(env):
+        monkeypatch.delenv(k, raising=False)
+    base = [wavernn.generate_samples(mel, True, 4000, 200, seed=11), wavernn.generate_samples(mel2, True, 4000, 400, seed=12)]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    alt = [wavernn.generate_samples(mel, True, 4000, 200, seed=11), wavernn.generate_samples(mel2, True, 4000, 400, seed=12)]
+    for a, b in zip(base, alt):
+        assert a.shape == b.shape and torch.equal(a, b), int((a != b).sum())
+
+
+@pytest.fixture(scope="module")
+def taco(cuda, lib):
+    from mockingbird_amd.synthesizer.inference import TacotronDevice
+    st = synth.tacotron_state(seed=3)["model_state"]
+    dev = TacotronDevice(st, torch.device("cuda"))
+    seqs, emb = synth.tacotron_inputs(20, 30, 45, seed=6)
+    T = max(len(s) for s in seqs)
+    chars = torch.tensor(np.stack([np.pad(s, (0, T - len(s))) for s in seqs])).long().cuda()
+    spk = torch.tensor(np.stack(emb)).cuda()
+    mem, memp = dev.encode(chars, spk, -1, None, 1)
+    return dev, mem, memp, chars
+
+
+@pytest.mark.parametrize("env", [{"MBHIP_TACO_HH1_SPLIT": "64"}, {"MBHIP_TACO_HH1_SPLIT": "240"}, {"MBHIP_TACO_GRAPH_ITERS": "4"},
+                                 {"MBHIP_NO_GRAPH": "1"}], ids=lambda e: ",".join(f"{k[6:]}={v}" for k, v in e.items()))
+def test_tacotron_fast_loop_switches_are_bit_identical(taco, monkeypatch, env):
+    """Where the LSTM-1 hidden half rides (mel vs rnn_input launch), how many iterations a graph holds, eager launches:
+    the same kernels on the same operands."""
+    dev, mem, memp, chars = taco
+    for k in list(env):
+        monkeypatch.delenv(k, raising=False)
+    base = dev.decode(mem, memp, chars, 90, 11.0, seed=5)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    alt = dev.decode(mem, memp, chars, 90, 11.0, seed=5)
+    for a, b in zip(base, alt):
+        assert a.shape == b.shape and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("env,exact", [({"MBHIP_PPG_FAST": "0"}, False), ({"MBHIP_PPG_GRAPH_STEPS": "4"}, True),
+                                       ({"MBHIP_NO_GRAPH": "1"}, True)], ids=["PPG_FAST=0", "PPG_GRAPH_STEPS=4", "NO_GRAPH"])
+@pytest.mark.parametrize("B", [1, 19])
+def test_ppg2mel_switches(cuda, lib, monkeypatch, env, exact, B):
+    """The 6-launch FM step against the 8-launch general step (different summation orders: tolerance) and against
+    itself with another graph length / eager launches (bit-identical)."""
+    from mockingbird_amd.ppg2mel import Ppg2MelDecoder
+    dec = Ppg2MelDecoder(synth.ppg2mel_decoder_state(synth.PPG2MEL_HP, seed=3, stop_bias=-6.0), synth.PPG2MEL_HP)
+    mem = torch.from_numpy(synth.ppg2mel_memory(B, 20, seed=2)).cuda()
+    masks = synth.ppg2mel_dropout_masks(4, 40, B)
+    for k in list(env):
+        monkeypatch.delenv(k, raising=False)
+    base = dec.decode(mem, dropout=masks)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    alt = dec.decode(mem, dropout=masks)
+    for a, b in zip(base, alt):
+        assert a.shape == b.shape
+        if exact:
+            assert torch.equal(a, b)
+        else:
+            e = hiputil.relerr(a, b)
+            assert e["nan"] == 0 and e["max_abs"] <= 2e-4, e
