@@ -24,6 +24,7 @@
 //     half (K = 512 instead of 1024).  Still 5 launches per step, about half the bytes on the chain.
 #include "rnn.h"
 #include "wavernn_fast.h"
+#include "wavernn_persist.h"
 
 namespace mb {
 
@@ -550,6 +551,7 @@ struct WrnLayout {
   float *f_x1, *f_x2, *f_y1, *f_y2, *f_h1, *f_h2, *f_P1, *f_P2, *f_Tq;  // fast chain: FM activations / state, CM4 hidden halves, staged table rows
   size_t f_bytes;
   int* step; unsigned long long* slots;
+  unsigned long long* px;  // persistent kernel (wavernn_persist.h): granule exchange area + abort word
   size_t bytes;
 };
 // python-style floor division
@@ -598,6 +600,7 @@ static void wavernn_layout(const mb_wavernn* w, const mb_wavernn_plan* p, void* 
   }
   L->step = ar.take<int>(16);
   L->slots = ar.take<unsigned long long>(2 * N);
+  L->px = ar.take<unsigned long long>(wp_exchange_bytes() / 8);
   L->bytes = ar.off + 256;
 }
 
@@ -754,6 +757,45 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
     if (fnt == 2) hipLaunchKernelGGL(wf_fc_hh_kernel<2>, grid, dim3(512), 0, st, k);
     else hipLaunchKernelGGL(wf_fc_hh_kernel<1>, grid, dim3(512), 0, st, k);
   };
+  // Few fold columns (batched=False, short utterances): ONE persistent launch with every weight tile resident in LDS and
+  // granule hand-offs between the layers (wavernn_persist.h); same sample stream.  MBHIP_WAVERNN_PERSIST=0 keeps the chain.
+  const char* penv = getenv("MBHIP_WAVERNN_PERSIST");
+  const bool persist = fastk && N <= WP_NCOL && C <= 512 && !w->bench_which && !getenv("MBHIP_TRACE_FILE") && penv && atoi(penv) != 0;
+  if (persist && !rc) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WP_LDS_BYTES));
+      attr_set = true;
+    }
+    MB_HIP(hipMemsetAsync(L.px, 0, wp_exchange_bytes(), s));
+    WpK pk;
+    pk.w_rnn2 = w->w_rnn2x.p; pk.w_fc1 = w->w_fc1.p; pk.w_fc2 = w->w_fc2.p; pk.w_fc3 = w->w_fc3.p; pk.w_hh1 = w->f_hh1t.p; pk.w_hh2 = w->f_hh2t.p;
+    pk.bhh1q = reinterpret_cast<const float4*>(w->f_bhh1q.p); pk.bhh2q = reinterpret_cast<const float4*>(w->f_bhh2q.p);
+    pk.b_fc3 = w->b_fc3.p; pk.g1 = w->g1I0.p; pk.wI0 = w->wI0.p;
+    pk.T1 = L.T1; pk.Ipre = L.Ipre; pk.G2 = L.G2; pk.F1 = L.F1; pk.F2 = L.F2;
+    pk.g = wg; pk.ex = L.px; pk.abort_word = reinterpret_cast<int*>(L.px + (size_t)2 * WPX_PER_PARITY);
+    pk.samples = d_samples; pk.progress = h_progress; pk.seed = seed; pk.R = R; pk.FC = FC; pk.C = C; pk.S = S; pk.N = N;
+    const char* wtrace = getenv("MBHIP_WP_TRACE");  // diagnostics: dump the marks of wavernn_persist.h to this file
+    pk.trace = wtrace ? L.px + (size_t)2 * WPX_PER_PARITY + 32 : nullptr;
+    MB_HIP(hipEventRecord(w->ev_t0, s));
+    hipLaunchKernelGGL(wf_persist_kernel, dim3(WP_ON + WP_OFF), dim3(512), WP_LDS_BYTES, s, pk);
+    MB_HIP(hipGetLastError());
+    MB_HIP(hipEventRecord(w->ev_t1, s));
+    w->last_launches = 1; w->last_lanes = 1; w->timed = true;
+    MB_HIP(hipEventRecord(w->ev_out, s));
+    MB_HIP(hipStreamWaitEvent(cs, w->ev_out, 0));
+    // the abort word is the only way a broken hand-off shows: wait for the launch and look at it
+    int aborted = 0;
+    MB_HIP(hipStreamSynchronize(s));
+    MB_HIP(hipMemcpy(&aborted, pk.abort_word, sizeof(int), hipMemcpyDeviceToHost));
+    if (aborted) { set_error("wavernn_generate: persistent kernel gave up waiting for a hand-off (spin limit)"); return MB_ESTATE; }
+    if (wtrace) {
+      unsigned long long marks[2 * 4 * 16];
+      MB_HIP(hipMemcpy(marks, pk.trace, sizeof(marks), hipMemcpyDeviceToHost));
+      if (FILE* f = fopen(wtrace, "wb")) { fwrite(marks, sizeof(marks), 1, f); fclose(f); }
+    }
+    return MB_OK;
+  }
   if (fastk && !rc) {  // zero state; P = W_hh.0 + b_hh for the first step by the loop's own hidden-half jobs
     MB_HIP(hipMemsetAsync(L.f_x1, 0, L.f_bytes, s));
     fc_hh(0, 0, 0, s);

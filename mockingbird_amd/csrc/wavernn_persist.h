@@ -1,0 +1,464 @@
+// WaveRNN sample loop for FEW fold columns (batched=False and short batched utterances, N <= 4) as ONE persistent
+// launch with the weights resident on chip -- the A/B partner of the 5-launch chain of wavernn_fast.h
+// (profiles/r02_wavernn_persistent_ab.json).
+//
+// With <= 8 columns the chain is pure latency: 5 dependent launches x (boundary + ramp + first HBM round trip) per
+// sample, 16.3 MB of weights re-streamed every step for a few MFLOP.  Here 192 workgroups stay resident for the whole
+// utterance, every weight tile lives in LDS from the first step on, and the layers hand their output vectors to each
+// other through 8-byte {value, step tag} granules in device memory (one relaxed agent-scope store / load each:
+// global_store/load_dwordx2 sc1, MI355X_MICROARCH.md "R2 granule" -- no fences, the tag IS the flag).
+//
+//   on-chain workgroups g = 0..63 (the dependent chain of fatchord_version.py:190-228):
+//     keys(s-1) -> x      every workgroup reduces the 32 fc3 tiles' Gumbel-argmax keys itself
+//     finish              rnn1 elementwise for ALL 512 units, redundantly (no exchange: h1 is private state)
+//     rnn2                row tiles 2g, 2g+1 (8 units; h2 of those units is private state)  -> publishes x2, h2
+//     fc1  (g <  32)      tile g on x2                                                      -> publishes y1
+//     fc2  (g >= 32)      tile g-32 on y1                                                   -> publishes y2
+//     fc3  (g >= 32)      tile g-32 on y2 + Gumbel-argmax                                   -> publishes keys
+//   off-chain workgroups g = 64..191: row tile g-64 of W_hh1 and of W_hh2 -- the hidden halves of the NEXT step's GRUs
+//     (they have a whole step of slack), fed by h1 (published by workgroup 0) and h2, publishing P1 / P2.
+//
+// Arithmetic: the GEMM of a row tile is the 8-wave K split of fm_gemm.h with the same MFMA sequence and the same
+// wave-order reduction, epilogues are the expressions of wavernn_fast.h, the sampler draws the same Philox words:
+// the sample stream is bit-identical to the chain's (tests/test_wavernn_gpu.py).
+//
+// Every exchange buffer is double-buffered by tag parity.  Why that is enough: a granule of tag t is overwritten by
+// tag t+2, and the chain is a cycle -- whoever writes tag t+2 of any buffer has (transitively) consumed a value that
+// needed every reader of tag t of that buffer to have finished (derivation in DESIGN.md section 4d).
+// Every spin has a bail-out: after SPIN_LIMIT polls a workgroup raises the abort word and the launch drains.
+#pragma once
+#include "wavernn_fast.h"
+
+namespace mb {
+
+constexpr int WP_NCOL = 4;        // fold columns supported (LDS budget of the busiest workgroup: 152 KB of 160)
+constexpr int WP_ON = 64;         // on-chain workgroups
+constexpr int WP_OFF = 128;       // off-chain workgroups (one GRU row tile of each hidden half)
+constexpr int WP_SPIN_LIMIT = 4000000;
+
+// exchange area, in granules, per parity
+enum { WPX_X2 = 0, WPX_H2 = 8192, WPX_H1 = 16384, WPX_Y1 = 24576, WPX_Y2 = 32768, WPX_P1 = 40960, WPX_P2 = 65536,
+       WPX_KEY = 90112, WPX_PER_PARITY = 91136 };
+inline size_t wp_exchange_bytes() { return (size_t)2 * WPX_PER_PARITY * 8 + 256 + 8192; }  // + abort word + diagnostics marks
+
+struct WpK {
+  const float* w_rnn2; const float* w_fc1; const float* w_fc2; const float* w_fc3; const float* w_hh1; const float* w_hh2;
+  const float4* bhh1q; const float4* bhh2q; const float* b_fc3; const float* g1; const float* wI0;
+  const float* T1; const float* Ipre; const float* G2; const float* F1; const float* F2;
+  WfGeom g;
+  unsigned long long* ex; int* abort_word;
+  float* samples; volatile int* progress;
+  unsigned long long seed; int R, FC, C, S, N;
+  unsigned long long* trace;  // diagnostics (MBHIP_WP_TRACE): wall-clock marks of workgroups 0 and 32, steps 1000..1003
+};
+
+__device__ __forceinline__ void wp_put(unsigned long long* p, float v, unsigned tag) {
+  __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void wp_put_u(unsigned long long* p, unsigned v, unsigned tag) {
+  __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long wp_get(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// spin until the NQ granules p[q * stride] all carry `tag`; false = aborted
+template <int NQ>
+__device__ __forceinline__ bool wp_wait(const unsigned long long* p, const size_t stride, const unsigned tag, unsigned (&out)[NQ], int* abort_word) {
+  unsigned long long v[NQ];
+  for (int tries = 0;; ++tries) {
+    bool ok = true;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) v[q] = wp_get(p + q * stride);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) ok = ok && (unsigned)(v[q] >> 32) == tag;
+    if (ok) break;
+    if ((tries & 1023) == 1023) {
+      if (tries >= WP_SPIN_LIMIT) atomicExch(abort_word, 1);
+      if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) out[q] = (unsigned)v[q];
+  return true;
+}
+
+// the same in two halves: issue the loads early (the producer had a whole step), check -- and only then spin -- at the use
+template <int NQ>
+__device__ __forceinline__ void wp_issue(const unsigned long long* p, const size_t stride, unsigned long long (&v)[NQ]) {
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) v[q] = wp_get(p + q * stride);
+}
+template <int NQ>
+__device__ __forceinline__ bool wp_take(const unsigned long long* p, const size_t stride, const unsigned tag, const unsigned long long (&v)[NQ],
+                                        unsigned (&out)[NQ], int* abort_word) {
+  bool ok = true;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) ok = ok && (unsigned)(v[q] >> 32) == tag;
+  if (!ok) return wp_wait<NQ>(p, stride, tag, out, abort_word);
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) out[q] = (unsigned)v[q];
+  return true;
+}
+
+// B fragments of this lane for the 4 k-blocks of its wave from an exchange vector [k][16 columns]; dead columns = 0.
+// Two stages: poll ONE granule (sleeping SLEEP x 64 cycles between polls: hundreds of waves spin most of a step, and
+// every poll is a fabric request) until the step's tag shows up, then fetch all 16 and re-check.
+template <int SLEEP>
+__device__ __forceinline__ bool wp_gather(const unsigned long long* vec, const unsigned tag, const int N, float4 (&b)[4], int* abort_word) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) b[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i >= N) return true;
+  // granule of (feature k, column n) at k * 16 + n; this lane: k = (wave + 8 p) * 16 + kq * 4 + c
+  const unsigned long long* base = vec + ((size_t)(wave * 16 + kq * 4) * 16 + i);
+  if (SLEEP > 1) {  // off-chain: a whole step of slack
+    for (int tries = 0; (unsigned)(wp_get(base + (size_t)(3 * 128 + 3) * 16) >> 32) != tag; ++tries) {
+      if ((tries & 1023) == 1023) {
+        if (tries >= WP_SPIN_LIMIT) atomicExch(abort_word, 1);
+        if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+      }
+      __builtin_amdgcn_s_sleep(SLEEP);
+    }
+  }
+  // (two sweeps in flight -- the second requested before the first is examined -- measured SLOWER, 18.1 vs 13.1 us per
+  //  step: every extra poll is a fabric request the other 1500 waves' polls queue behind, and the sweep left in flight
+  //  at exit sits in front of the next vector-memory wait)
+  unsigned long long v[16];
+  for (int tries = 0;; ++tries) {
+    bool ok = true;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[p * 4 + c] = wp_get(base + ((size_t)p * 128 + c) * 16);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) ok = ok && (unsigned)(v[q] >> 32) == tag;
+    if (ok) break;
+    if ((tries & 1023) == 1023) {
+      if (tries >= WP_SPIN_LIMIT) atomicExch(abort_word, 1);
+      if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+    b[p] = make_float4(__uint_as_float((unsigned)v[p * 4]), __uint_as_float((unsigned)v[p * 4 + 1]), __uint_as_float((unsigned)v[p * 4 + 2]),
+                       __uint_as_float((unsigned)v[p * 4 + 3]));
+  return true;
+}
+
+// One 16-row tile (weights in LDS at lw: [32 k-blocks][BLK]) x one column tile, K = 512: the MFMA sequence and the
+// reduction order of fm_gemm<1, 4, 4, RL, 1>.  Returns true for wave 0 with the sums in sx.
+template <int RL>
+__device__ __forceinline__ bool wp_gemm(const float* lw, const float4 (&b)[4], float* red, float (&sx)[4]) {
+  constexpr int BLK = 4 * RL * 16;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, kq = lane >> 4;
+  const int u = i >> 2, tau = (i & 3) < RL ? (i & 3) : RL - 1;
+  const float* wl = lw + ((u * RL + tau) * 4 + kq) * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float4 a = *reinterpret_cast<const float4*>(wl + (size_t)(wave + 8 * p) * BLK);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[p].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[p].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[p].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[p].w, acc, 0, 0, 0);
+  }
+  float4* red4 = reinterpret_cast<float4*>(red);
+  red4[wave * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  __syncthreads();
+  if (wave != 0) return false;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) sx[g] = 0.f;
+#pragma unroll
+  for (int w8 = 0; w8 < 8; ++w8) {
+    const float4 v = red4[w8 * 64 + lane];
+    sx[0] += v.x; sx[1] += v.y; sx[2] += v.z; sx[3] += v.w;
+  }
+  return true;
+}
+
+// Two row tiles against the same B fragments in one pass (one barrier); wave tt (0 / 1) gets tile tt's sums.
+template <int RL>
+__device__ __forceinline__ bool wp_gemm2(const float* lw, const int tile_floats, const float4 (&b)[4], float* red, float (&sx)[4]) {
+  constexpr int BLK = 4 * RL * 16;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, kq = lane >> 4;
+  const int u = i >> 2, tau = (i & 3) < RL ? (i & 3) : RL - 1;
+  const float* wl = lw + ((u * RL + tau) * 4 + kq) * 4;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float4 a0 = *reinterpret_cast<const float4*>(wl + (size_t)(wave + 8 * p) * BLK);
+    const float4 a1 = *reinterpret_cast<const float4*>(wl + tile_floats + (size_t)(wave + 8 * p) * BLK);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b[p].x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b[p].x, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b[p].y, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b[p].y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b[p].z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b[p].z, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b[p].w, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b[p].w, acc1, 0, 0, 0);
+  }
+  float4* red4 = reinterpret_cast<float4*>(red);  // [2 tiles][8 waves][64]
+  red4[wave * 64 + lane] = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
+  red4[512 + wave * 64 + lane] = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
+  __syncthreads();
+  if (wave >= 2) return false;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) sx[g] = 0.f;
+#pragma unroll
+  for (int w8 = 0; w8 < 8; ++w8) {
+    const float4 v = red4[wave * 512 + w8 * 64 + lane];
+    sx[0] += v.x; sx[1] += v.y; sx[2] += v.z; sx[3] += v.w;
+  }
+  return true;
+}
+
+__device__ __forceinline__ void wp_copy_tile(float* dst, const float* __restrict__ src, const int floats) {
+  for (int i = threadIdx.x * 4; i < floats; i += blockDim.x * 4)
+    *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(src + i);
+}
+
+// dynamic LDS (floats): [weights: 12288 rnn2 (2 GRU tiles) | 8192 fc a | 8192 fc b] [red 4096 (two-tile pass) + 2 x 2048 (single-tile GEMMs, alternating)] [x1s 128 x NCOL x 4] [keys]
+constexpr int WP_LDS_W = 12288 + 8192 + 8192, WP_LDS_RED = 2 * 4096, WP_LDS_X = 128 * WP_NCOL * 4;
+constexpr size_t WP_LDS_BYTES = (size_t)(WP_LDS_W + WP_LDS_RED + WP_LDS_X) * 4 + 2 * WP_NCOL * 8 + 64;
+
+__global__ __launch_bounds__(512) void wf_persist_kernel(WpK a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* lw = lds;
+  float* red = lds + WP_LDS_W;
+  float* x1s = red + WP_LDS_RED;  // float4 index (k / 4) * NCOL + n
+  unsigned long long* s_key = reinterpret_cast<unsigned long long*>(x1s + WP_LDS_X);  // [NCOL] max key of the step
+  float* s_x = reinterpret_cast<float*>(s_key + WP_NCOL);                             // [NCOL] decoded sample
+  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int du = lane >> 4, i = lane & 15;
+  const int N = a.N, H = a.R, S = a.S;
+  const int n_t3 = a.C / 16;  // fc3 row tiles
+  int rb = 0;                 // red buffer of the next GEMM
+  auto EX = [&](int what, unsigned tag) { return a.ex + (size_t)(tag & 1) * WPX_PER_PARITY + what; };
+
+  if (g >= WP_ON) {
+    // ------------------------------------------------------------------ off-chain: hidden halves of the next step
+    const int mt = g - WP_ON;
+    wp_copy_tile(lw, a.w_hh1 + (size_t)mt * 6144, 6144);
+    wp_copy_tile(lw + 6144, a.w_hh2 + (size_t)mt * 6144, 6144);
+    const float4 bq1 = a.bhh1q[mt * 4 + du], bq2 = a.bhh2q[mt * 4 + du];
+    __syncthreads();
+    for (int s = 0; s < S; ++s) {
+#pragma unroll
+      for (int which = 0; which < 2; ++which) {
+        float4 b[4];
+        if (s == 0) {
+#pragma unroll
+          for (int p = 0; p < 4; ++p) b[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else if (!wp_gather<6>(EX(which ? WPX_H2 : WPX_H1, (unsigned)s), (unsigned)s, N, b, a.abort_word)) return;
+        float sx[4];
+        const bool epi = wp_gemm<3>(lw + which * 6144, b, red + 4096 + rb * 2048, sx);
+        rb ^= 1;
+        if (epi && i < N) {
+          const float4 bq = which ? bq2 : bq1;
+          unsigned long long* P = EX(which ? WPX_P2 : WPX_P1, (unsigned)s + 1) + (size_t)(mt * 4 + du) * 16 + i;
+          wp_put(P, sx[0] + bq.x, (unsigned)s + 1);
+          wp_put(P + 8192, sx[1] + bq.y, (unsigned)s + 1);
+          wp_put(P + 16384, sx[2] + bq.z, (unsigned)s + 1);
+        }
+      }
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- on-chain
+  const bool lo = g < 32;
+  const int ft = lo ? g : g - 32;           // fc1 tile (lo) / fc2 + fc3 tile (hi)
+  wp_copy_tile(lw, a.w_rnn2 + (size_t)(2 * g) * 6144, 12288);
+  wp_copy_tile(lw + 12288, (lo ? a.w_fc1 : a.w_fc2) + (size_t)ft * 8192, 8192);
+  if (!lo && ft < n_t3) wp_copy_tile(lw + 20480, a.w_fc3 + (size_t)ft * 8192, 8192);
+  if (tid < WP_NCOL) { s_key[tid] = 0ull; s_x[tid] = 0.f; }
+  // finish: thread j = unit j
+  const int j = tid;
+  const float gr = a.g1[j], gz = a.g1[H + j], gn = a.g1[2 * H + j], w0 = a.wI0[j];
+  float h1[WP_NCOL], tq[WP_NCOL][4];
+#pragma unroll
+  for (int n = 0; n < WP_NCOL; ++n) {
+    h1[n] = 0.f;
+    if (n < N) {
+      const unsigned pos = wf_pos(a.g, n, 0);
+      const float* t1 = a.T1 + (size_t)pos * 3 * H + j;
+      tq[n][0] = t1[0]; tq[n][1] = t1[H]; tq[n][2] = t1[2 * H]; tq[n][3] = a.Ipre[(size_t)pos * H + j];
+    }
+  }
+  float h2 = 0.f;  // waves 0 / 1: unit (2g + wave) * 4 + du, column i
+  float g2r = 0.f, g2z = 0.f, g2n = 0.f; int g2_row = -1;   // cached per-frame rows (they change once per hop)
+  float4 fpre = make_float4(0.f, 0.f, 0.f, 0.f); int f_row = -1;
+  const float4 b3q = (!lo && ft < n_t3) ? *reinterpret_cast<const float4*>(a.b_fc3 + ft * 16 + du * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+
+#define WP_MARK(k)                                                                                          \
+  do {                                                                                                      \
+    if (a.trace && tid == 0 && (g == 0 || g == 32) && s >= 1000 && s < 1004)                                \
+      a.trace[((g ? 1 : 0) * 4 + (s - 1000)) * 16 + (k)] = (unsigned long long)wall_clock64();              \
+  } while (0)
+  constexpr int WP_PRE = 2;  // columns whose hidden-half granules are requested before the key wait
+  for (int s = 0; s <= S; ++s) {
+    const unsigned tag_prev = (unsigned)s, tag = (unsigned)s + 1;
+    // the hidden halves of this step were published a step ago: request them now, in the shadow of the key wait
+    unsigned long long p1v[WP_PRE][3], p2v[3];
+    if (s < S) {
+#pragma unroll
+      for (int n = 0; n < WP_PRE; ++n)
+        if (n < N) wp_issue<3>(EX(WPX_P1, tag) + (size_t)j * 16 + n, 8192, p1v[n]);
+    }
+    const int ncl = i < N ? i : N - 1;  // clamped column: loads legal, nothing published for dead columns
+    const int frow = s < S ? wf_frame_row(a.g, ncl, s) : 0;
+    WP_MARK(0);
+    // ---- A: keys of step s-1 -> sample x (every workgroup for itself) ----
+    if (s > 0) {
+      if (tid < 32 * N && (tid & 31) < n_t3) {
+        const int tile = tid & 31, n = tid >> 5;
+        unsigned kv[2];
+        if (!wp_wait<2>(EX(WPX_KEY, tag_prev) + (size_t)tile * 16 + n, 512, tag_prev, kv, a.abort_word)) return;
+        atomicMax(&s_key[n], ((unsigned long long)kv[0] << 32) | (unsigned long long)kv[1]);
+      }
+      WP_MARK(1);
+      __syncthreads();
+      WP_MARK(2);
+      if (tid < N) {
+        const unsigned long long slot = s_key[tid];
+        const float x = slot ? 2.f * (float)argmax_class(slot) / ((float)a.C - 1.f) - 1.f : 0.f;
+        s_x[tid] = x;
+        if (g == 0) {
+          a.samples[(size_t)tid * S + (s - 1)] = x;
+          if (a.progress && tid == 0 && (s - 1) % 100 == 0) *a.progress = s;
+        }
+      }
+      __syncthreads();
+      if (tid < N) s_key[tid] = 0ull;  // next atomicMax is several barriers away
+    }
+    if (s == S) break;
+    // rnn2's hidden half (published ~3 us after rnn2 of the previous step): requested here, used after the GEMM
+    if (wave < 2 && i < N) wp_issue<3>(EX(WPX_P2, tag) + (size_t)((2 * g + wave) * 4 + du) * 16 + i, 8192, p2v);
+    WP_MARK(3);
+    // ---- B: rnn1 finish for unit j, all columns (wf_finish_kernel's expressions) ----
+#pragma unroll
+    for (int n = 0; n < WP_NCOL; ++n) {
+      if (n >= N) continue;
+      unsigned pu[3];
+      if (n < WP_PRE) { if (!wp_take<3>(EX(WPX_P1, tag) + (size_t)j * 16 + n, 8192, tag, p1v[n], pu, a.abort_word)) return; }
+      else if (!wp_wait<3>(EX(WPX_P1, tag) + (size_t)j * 16 + n, 8192, tag, pu, a.abort_word)) return;
+      const float hqx = __uint_as_float(pu[0]), hqy = __uint_as_float(pu[1]), hqz = __uint_as_float(pu[2]);
+      const float x = s_x[n];
+      const float rg = sigmoidf_((tq[n][0] + x * gr) + hqx);
+      const float zg = sigmoidf_((tq[n][1] + x * gz) + hqy);
+      const float ng = tanhf((tq[n][2] + x * gn) + rg * hqz);
+      const float hy = ng + zg * (h1[n] - ng);
+      h1[n] = hy;
+      x1s[((j >> 2) * WP_NCOL + n) * 4 + (j & 3)] = (tq[n][3] + x * w0) + hy;
+      if (g == 0) wp_put(EX(WPX_H1, tag) + (size_t)j * 16 + n, hy, tag);
+    }
+    WP_MARK(4);
+    __syncthreads();
+    WP_MARK(5);
+    // ---- C: next step's table rows (a whole step of latency to hide behind) ----
+    if (s + 1 < S) {
+#pragma unroll
+      for (int n = 0; n < WP_NCOL; ++n) {
+        if (n >= N) continue;
+        const unsigned pos = wf_pos(a.g, n, s + 1);
+        const float* t1 = a.T1 + (size_t)pos * 3 * H + j;
+        tq[n][0] = t1[0]; tq[n][1] = t1[H]; tq[n][2] = t1[2 * H]; tq[n][3] = a.Ipre[(size_t)pos * H + j];
+      }
+    }
+    // ---- D: rnn2, row tiles 2g and 2g+1 in one pass; wave tt finishes tile tt ----
+    {
+      float4 b[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        b[p] = i < WP_NCOL ? *reinterpret_cast<const float4*>(x1s + (((wave + 8 * p) * 4 + (lane >> 4)) * WP_NCOL + i) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float sx[4];
+      const bool epi = wp_gemm2<3>(lw, 6144, b, red, sx);
+      WP_MARK(11);
+      if (epi && i < N) {
+        const int ju = (2 * g + wave) * 4 + du;
+        if (frow != g2_row) {  // the per-frame rows change once per hop: kept in registers in between
+          const float* gp = a.G2 + (size_t)frow * 3 * H + ju;
+          g2r = gp[0]; g2z = gp[H]; g2n = gp[2 * H];
+          g2_row = frow;
+        }
+        unsigned pu[3];
+        if (!wp_take<3>(EX(WPX_P2, tag) + (size_t)ju * 16 + i, 8192, tag, p2v, pu, a.abort_word)) return;
+        WP_MARK(12);
+        const float xr = x1s[((ju >> 2) * WP_NCOL + i) * 4 + (ju & 3)];
+        const float rg = sigmoidf_((sx[0] + g2r) + __uint_as_float(pu[0]));
+        const float zg = sigmoidf_((sx[1] + g2z) + __uint_as_float(pu[1]));
+        const float ng = tanhf((sx[2] + g2n) + rg * __uint_as_float(pu[2]));
+        const float hy = ng + zg * (h2 - ng);
+        h2 = hy;
+        wp_put(EX(WPX_X2, tag) + (size_t)ju * 16 + i, xr + hy, tag);
+        wp_put(EX(WPX_H2, tag) + (size_t)ju * 16 + i, hy, tag);
+      }
+    }
+    WP_MARK(6);
+    // ---- E: fc1 (lo) | fc2 then fc3 (hi) ----
+    {
+      if (wave == 0 && frow != f_row) {
+        fpre = *reinterpret_cast<const float4*>((lo ? a.F1 : a.F2) + (size_t)frow * a.FC + ft * 16 + du * 4);
+        f_row = frow;
+      }
+      const float4 pre = fpre;
+      float4 b[4];
+      if (!wp_gather<1>(EX(lo ? WPX_X2 : WPX_Y1, tag), tag, N, b, a.abort_word)) return;
+      WP_MARK(7);
+      float sx[4];
+      const bool epi = wp_gemm<4>(lw + 12288, b, red + 4096 + rb * 2048, sx);
+      rb ^= 1;
+      WP_MARK(8);
+      if (epi && i < N) {
+        unsigned long long* Y = EX(lo ? WPX_Y1 : WPX_Y2, tag) + (size_t)(ft * 16 + du * 4) * 16 + i;
+        wp_put(Y, fmaxf(sx[0] + pre.x, 0.f), tag);
+        wp_put(Y + 16, fmaxf(sx[1] + pre.y, 0.f), tag);
+        wp_put(Y + 32, fmaxf(sx[2] + pre.z, 0.f), tag);
+        wp_put(Y + 48, fmaxf(sx[3] + pre.w, 0.f), tag);
+      }
+    }
+    if (!lo && ft < n_t3) {
+      float4 b[4];
+      if (!wp_gather<1>(EX(WPX_Y2, tag), tag, N, b, a.abort_word)) return;
+      WP_MARK(9);
+      float sx[4];
+      const bool epi = wp_gemm<4>(lw + 20480, b, red + 4096 + rb * 2048, sx);
+      rb ^= 1;
+      WP_MARK(10);
+      if (epi) {  // wf_fc3_kernel's sampler; lanes of dead columns take part in the shuffles only
+        uint32_t grn[4];
+        philox4x32((uint32_t)s, (uint32_t)ncl, (uint32_t)((ft * 16 + du * 4) >> 2), 0x57415645u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), grn);
+        const float bv[4] = {b3q.x, b3q.y, b3q.z, b3q.w};
+        float best = -INFINITY;
+        int bcls = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = ft * 16 + du * 4 + r;
+          const float v = sx[r] + bv[r];
+          const float gmb = v - logf(-logf(u32_to_unit(grn[r])));
+          if (gmb > best) { best = gmb; bcls = row; }
+        }
+        unsigned long long pk = pack_argmax(best, bcls);
+        const unsigned long long o1 = __shfl_xor(pk, 16, 64);
+        pk = o1 > pk ? o1 : pk;
+        const unsigned long long o2 = __shfl_xor(pk, 32, 64);
+        pk = o2 > pk ? o2 : pk;
+        if (du == 0 && i < N) {
+          unsigned long long* K = EX(WPX_KEY, tag) + (size_t)ft * 16 + i;
+          wp_put_u(K, (unsigned)(pk >> 32), tag);
+          wp_put_u(K + 512, (unsigned)pk, tag);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace mb

@@ -87,3 +87,19 @@ def test_ppg2mel_switches(cuda, lib, monkeypatch, env, exact, B):
         else:
             e = hiputil.relerr(a, b)
             assert e["nan"] == 0 and e["max_abs"] <= 2e-4, e
+
+
+@pytest.mark.parametrize("frames,batched,target,overlap", [(9, False, 0, 0), (40, True, 3000, 100), (40, True, 2200, 100)],
+                         ids=["unbatched", "3-folds", "4-folds"])
+def test_wavernn_persistent_kernel_keeps_the_sample_stream(wavernn, monkeypatch, frames, batched, target, overlap):
+    """wavernn_persist.h: ONE launch for the whole utterance, weights resident in LDS, layers handing their vectors over
+    through tagged granules -- against the 5-launch chain: the same samples, sample for sample (<= 4 fold columns)."""
+    mel = torch.from_numpy(synth.wavernn_mel(frames, seed=13) / 4.0).cuda()
+    monkeypatch.delenv("MBHIP_WAVERNN_PERSIST", raising=False)
+    base = wavernn.generate_samples(mel, batched, target, overlap, seed=21)
+    assert wavernn.last_loop_launches > 1
+    monkeypatch.setenv("MBHIP_WAVERNN_PERSIST", "1")
+    alt = wavernn.generate_samples(mel, batched, target, overlap, seed=21)
+    assert wavernn.last_loop_launches == 1, "the persistent kernel did not run"
+    assert base.shape == alt.shape and base.shape[0] <= 4
+    assert torch.equal(base, alt), (int((base != alt).sum()), int((base != alt).any(0).nonzero()[0]) if (base != alt).any() else -1)
