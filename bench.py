@@ -557,6 +557,11 @@ def main():
                 "workload": f"mel 80x{F}, batched=False: {pu.n_folds} fold x {pu.seq_len} dependent steps, Philox sampling, fp32",
                 "value": len(wu) / tu, "unit": "samples/s", "x_realtime": len(wu) / tu / 16000.0, "s_total": tu,
                 "sample_loop_ms": model.last_loop_ms, "us_per_time_step": model.last_loop_ms * 1e3 / pu.seq_len,
+                "loop_launches": model.last_loop_launches,
+                "loop": ("ONE persistent launch, weight tiles resident in LDS, tagged-granule hand-offs between the layers "
+                         "(wavernn_persist.h); A/B against the 5-launch chain with identical sample streams: "
+                         "profiles/r02_wavernn_persistent_ab.json (10.4 vs 16.4 us per step)"
+                         if model.last_loop_launches == 1 else "5-launch chain, hipGraph replays"),
             }
             del su, wu
         # ---- secondary: WaveRNN throughput mode -- north_star's "batch-32 synthetic input": 32 utterances of

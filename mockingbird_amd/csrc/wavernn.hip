@@ -757,14 +757,18 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
     if (fnt == 2) hipLaunchKernelGGL(wf_fc_hh_kernel<2>, grid, dim3(512), 0, st, k);
     else hipLaunchKernelGGL(wf_fc_hh_kernel<1>, grid, dim3(512), 0, st, k);
   };
-  // Few fold columns (batched=False, short utterances): ONE persistent launch with every weight tile resident in LDS and
-  // granule hand-offs between the layers (wavernn_persist.h); same sample stream.  MBHIP_WAVERNN_PERSIST=0 keeps the chain.
+  // Few fold columns: ONE persistent launch with every weight tile resident in LDS and granule hand-offs between the
+  // layers (wavernn_persist.h), same sample stream.  One column (batched=False) runs it by default -- 10.4 vs 16.4 us
+  // per step (profiles/r02_wavernn_persistent_ab.json); 2..4 columns are at parity with the chain and stay on it
+  // unless MBHIP_WAVERNN_PERSIST=1; MBHIP_WAVERNN_PERSIST=0 keeps the chain everywhere.
   const char* penv = getenv("MBHIP_WAVERNN_PERSIST");
-  const bool persist = fastk && N <= WP_NCOL && C <= 512 && !w->bench_which && !getenv("MBHIP_TRACE_FILE") && penv && atoi(penv) != 0;
+  const bool persist = fastk && N <= WP_NCOL && C <= 512 && !w->bench_which && !getenv("MBHIP_TRACE_FILE") && !getenv("MBHIP_WF_DBG_WHICH") &&
+                       (penv ? atoi(penv) != 0 : N == 1);
   if (persist && !rc) {
     static bool attr_set = false;
     if (!attr_set) {
       MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WP_LDS_BYTES));
+      MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_persist1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WP1_LDS_BYTES));
       attr_set = true;
     }
     MB_HIP(hipMemsetAsync(L.px, 0, wp_exchange_bytes(), s));
@@ -778,7 +782,8 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
     const char* wtrace = getenv("MBHIP_WP_TRACE");  // diagnostics: dump the marks of wavernn_persist.h to this file
     pk.trace = wtrace ? L.px + (size_t)2 * WPX_PER_PARITY + 32 : nullptr;
     MB_HIP(hipEventRecord(w->ev_t0, s));
-    hipLaunchKernelGGL(wf_persist_kernel, dim3(WP_ON + WP_OFF), dim3(512), WP_LDS_BYTES, s, pk);
+    if (N == 1 && !getenv("MBHIP_WP_MFMA")) hipLaunchKernelGGL(wf_persist1_kernel, dim3(WP_ON + WP_OFF), dim3(512), WP1_LDS_BYTES, s, pk);
+    else hipLaunchKernelGGL(wf_persist_kernel, dim3(WP_ON + WP_OFF), dim3(512), WP_LDS_BYTES, s, pk);
     MB_HIP(hipGetLastError());
     MB_HIP(hipEventRecord(w->ev_t1, s));
     w->last_launches = 1; w->last_lanes = 1; w->timed = true;

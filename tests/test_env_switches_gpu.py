@@ -95,11 +95,18 @@ def test_wavernn_persistent_kernel_keeps_the_sample_stream(wavernn, monkeypatch,
     """wavernn_persist.h: ONE launch for the whole utterance, weights resident in LDS, layers handing their vectors over
     through tagged granules -- against the 5-launch chain: the same samples, sample for sample (<= 4 fold columns)."""
     mel = torch.from_numpy(synth.wavernn_mel(frames, seed=13) / 4.0).cuda()
-    monkeypatch.delenv("MBHIP_WAVERNN_PERSIST", raising=False)
+    monkeypatch.setenv("MBHIP_WAVERNN_PERSIST", "0")
     base = wavernn.generate_samples(mel, batched, target, overlap, seed=21)
     assert wavernn.last_loop_launches > 1
-    monkeypatch.setenv("MBHIP_WAVERNN_PERSIST", "1")
+    if batched:
+        monkeypatch.setenv("MBHIP_WAVERNN_PERSIST", "1")   # 2..4 columns: opt-in (MFMA tiles, at parity with the chain)
+    else:
+        monkeypatch.delenv("MBHIP_WAVERNN_PERSIST")        # one column: the default (fmaf chains in the MFMA's order)
     alt = wavernn.generate_samples(mel, batched, target, overlap, seed=21)
     assert wavernn.last_loop_launches == 1, "the persistent kernel did not run"
+    if not batched:
+        monkeypatch.setenv("MBHIP_WP_MFMA", "1")           # the MFMA form of the one-column kernel
+        alt2 = wavernn.generate_samples(mel, batched, target, overlap, seed=21)
+        assert wavernn.last_loop_launches == 1 and torch.equal(base, alt2)
     assert base.shape == alt.shape and base.shape[0] <= 4
     assert torch.equal(base, alt), (int((base != alt).sum()), int((base != alt).any(0).nonzero()[0]) if (base != alt).any() else -1)

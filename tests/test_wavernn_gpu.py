@@ -180,6 +180,7 @@ def test_fused_sampler_matches_exact_sampler(model, monkeypatch):
     assert sum(fb == S for fb in first_bad) >= n - 2, first_bad
     # unbatched (one sequence, eager tail after the graph replays) exercises the flush of the last sample
     monkeypatch.delenv("MBHIP_WAVERNN_NOFUSE", raising=False)
+    monkeypatch.setenv("MBHIP_WAVERNN_PERSIST", "0")  # the chain (one column defaults to the persistent kernel, tested elsewhere)
     f1 = dev.generate_samples(m[:, :27], False, 0, 0, seed=5).cpu()
     monkeypatch.setenv("MBHIP_WAVERNN_NOFUSE", "1")
     e1 = dev.generate_samples(m[:, :27], False, 0, 0, seed=5).cpu()
