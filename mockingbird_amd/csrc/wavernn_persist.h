@@ -101,36 +101,43 @@ __device__ __forceinline__ bool wp_take(const unsigned long long* p, const size_
   return true;
 }
 
-// B fragments of this lane for the 4 k-blocks of its wave from an exchange vector [k][16 columns]; dead columns = 0.
-// Two stages: poll ONE granule (sleeping SLEEP x 64 cycles between polls: hundreds of waves spin most of a step, and
-// every poll is a fabric request) until the step's tag shows up, then fetch all 16 and re-check.
+// One lane of the workgroup spins on one granule until the step's tag shows up; nobody else touches memory meanwhile
+// (the latency of a hand-off is set by the CONSUMER compute unit's own memory queue: 512 pollers per unit made every
+// exchange 2.5-3 us).  Ends in a barrier.
 template <int SLEEP>
-__device__ __forceinline__ bool wp_gather(const unsigned long long* vec, const unsigned tag, const int N, float4 (&b)[4], int* abort_word) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, kq = lane >> 4;
-#pragma unroll
-  for (int p = 0; p < 4; ++p) b[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (i >= N) return true;
-  // granule of (feature k, column n) at k * 16 + n; this lane: k = (wave + 8 p) * 16 + kq * 4 + c
-  const unsigned long long* base = vec + ((size_t)(wave * 16 + kq * 4) * 16 + i);
-  if (SLEEP > 1) {  // off-chain: a whole step of slack
-    for (int tries = 0; (unsigned)(wp_get(base + (size_t)(3 * 128 + 3) * 16) >> 32) != tag; ++tries) {
+__device__ __forceinline__ bool wp_watch(const unsigned long long* p, const unsigned tag, int* abort_word) {
+  // (one lane per PRODUCER -- 32 to 64 watching lanes, so that the sweep never starts before the slowest producer --
+  //  measured slower, 13.6 vs 11.9 us per step: what counts is how few requests sit in this unit's memory queue)
+  if (threadIdx.x == 0) {
+    for (int tries = 0; (unsigned)(wp_get(p) >> 32) != tag; ++tries) {
       if ((tries & 1023) == 1023) {
         if (tries >= WP_SPIN_LIMIT) atomicExch(abort_word, 1);
-        if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+        if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
       }
       __builtin_amdgcn_s_sleep(SLEEP);
     }
   }
-  // (two sweeps in flight -- the second requested before the first is examined -- measured SLOWER, 18.1 vs 13.1 us per
-  //  step: every extra poll is a fabric request the other 1500 waves' polls queue behind, and the sweep left in flight
-  //  at exit sits in front of the next vector-memory wait)
+  __syncthreads();
+  return true;
+}
+// B fragments of this lane for the 4 k-blocks of its wave from an exchange vector, dense [k][N columns]; dead columns = 0.
+// One watching lane first (wp_watch), then every live lane fetches its 16 granules.
+template <int SLEEP>
+__device__ __forceinline__ bool wp_gather(const unsigned long long* vec, const unsigned tag, const int N, float4 (&b)[4], int* abort_word) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, kq = lane >> 4;
+  wp_watch<SLEEP>(vec + (size_t)511 * N + (N - 1), tag, abort_word);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) b[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i >= N) return true;
+  // granule of (feature k, column n) at k * N + n; this lane: k = (wave + 8 p) * 16 + kq * 4 + c
+  const unsigned long long* base = vec + ((size_t)(wave * 16 + kq * 4) * N + i);
   unsigned long long v[16];
   for (int tries = 0;; ++tries) {
     bool ok = true;
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) v[p * 4 + c] = wp_get(base + ((size_t)p * 128 + c) * 16);
+      for (int c = 0; c < 4; ++c) v[p * 4 + c] = wp_get(base + ((size_t)p * 128 + c) * N);
 #pragma unroll
     for (int q = 0; q < 16; ++q) ok = ok && (unsigned)(v[q] >> 32) == tag;
     if (ok) break;
@@ -262,10 +269,10 @@ __global__ __launch_bounds__(512) void wf_persist_kernel(WpK a) {
         rb ^= 1;
         if (epi && i < N) {
           const float4 bq = which ? bq2 : bq1;
-          unsigned long long* P = EX(which ? WPX_P2 : WPX_P1, (unsigned)s + 1) + (size_t)(mt * 4 + du) * 16 + i;
+          unsigned long long* P = EX(which ? WPX_P2 : WPX_P1, (unsigned)s + 1) + (size_t)(mt * 4 + du) * 4 * N + i;  // dense [unit][gate][column]
           wp_put(P, sx[0] + bq.x, (unsigned)s + 1);
-          wp_put(P + 8192, sx[1] + bq.y, (unsigned)s + 1);
-          wp_put(P + 16384, sx[2] + bq.z, (unsigned)s + 1);
+          wp_put(P + N, sx[1] + bq.y, (unsigned)s + 1);
+          wp_put(P + 2 * N, sx[2] + bq.z, (unsigned)s + 1);
         }
       }
     }
@@ -311,17 +318,18 @@ __global__ __launch_bounds__(512) void wf_persist_kernel(WpK a) {
     if (s < S) {
 #pragma unroll
       for (int n = 0; n < WP_PRE; ++n)
-        if (n < N) wp_issue<3>(EX(WPX_P1, tag) + (size_t)j * 16 + n, 8192, p1v[n]);
+        if (n < N) wp_issue<3>(EX(WPX_P1, tag) + (size_t)j * 4 * N + n, N, p1v[n]);
     }
     const int ncl = i < N ? i : N - 1;  // clamped column: loads legal, nothing published for dead columns
     const int frow = s < S ? wf_frame_row(a.g, ncl, s) : 0;
     WP_MARK(0);
     // ---- A: keys of step s-1 -> sample x (every workgroup for itself) ----
     if (s > 0) {
+      wp_watch<1>(EX(WPX_KEY, tag_prev) + (size_t)((n_t3 - 1) * 2 + 1) * N + (N - 1), tag_prev, a.abort_word);
       if (tid < 32 * N && (tid & 31) < n_t3) {
         const int tile = tid & 31, n = tid >> 5;
         unsigned kv[2];
-        if (!wp_wait<2>(EX(WPX_KEY, tag_prev) + (size_t)tile * 16 + n, 512, tag_prev, kv, a.abort_word)) return;
+        if (!wp_wait<2>(EX(WPX_KEY, tag_prev) + (size_t)tile * 2 * N + n, N, tag_prev, kv, a.abort_word)) return;
         atomicMax(&s_key[n], ((unsigned long long)kv[0] << 32) | (unsigned long long)kv[1]);
       }
       WP_MARK(1);
@@ -341,15 +349,15 @@ __global__ __launch_bounds__(512) void wf_persist_kernel(WpK a) {
     }
     if (s == S) break;
     // rnn2's hidden half (published ~3 us after rnn2 of the previous step): requested here, used after the GEMM
-    if (wave < 2 && i < N) wp_issue<3>(EX(WPX_P2, tag) + (size_t)((2 * g + wave) * 4 + du) * 16 + i, 8192, p2v);
+    if (wave < 2 && i < N) wp_issue<3>(EX(WPX_P2, tag) + (size_t)((2 * g + wave) * 4 + du) * 4 * N + i, N, p2v);
     WP_MARK(3);
     // ---- B: rnn1 finish for unit j, all columns (wf_finish_kernel's expressions) ----
 #pragma unroll
     for (int n = 0; n < WP_NCOL; ++n) {
       if (n >= N) continue;
       unsigned pu[3];
-      if (n < WP_PRE) { if (!wp_take<3>(EX(WPX_P1, tag) + (size_t)j * 16 + n, 8192, tag, p1v[n], pu, a.abort_word)) return; }
-      else if (!wp_wait<3>(EX(WPX_P1, tag) + (size_t)j * 16 + n, 8192, tag, pu, a.abort_word)) return;
+      if (n < WP_PRE) { if (!wp_take<3>(EX(WPX_P1, tag) + (size_t)j * 4 * N + n, N, tag, p1v[n], pu, a.abort_word)) return; }
+      else if (!wp_wait<3>(EX(WPX_P1, tag) + (size_t)j * 4 * N + n, N, tag, pu, a.abort_word)) return;
       const float hqx = __uint_as_float(pu[0]), hqy = __uint_as_float(pu[1]), hqz = __uint_as_float(pu[2]);
       const float x = s_x[n];
       const float rg = sigmoidf_((tq[n][0] + x * gr) + hqx);
@@ -358,7 +366,7 @@ __global__ __launch_bounds__(512) void wf_persist_kernel(WpK a) {
       const float hy = ng + zg * (h1[n] - ng);
       h1[n] = hy;
       x1s[((j >> 2) * WP_NCOL + n) * 4 + (j & 3)] = (tq[n][3] + x * w0) + hy;
-      if (g == 0) wp_put(EX(WPX_H1, tag) + (size_t)j * 16 + n, hy, tag);
+      if ((j >> 3) == g) wp_put(EX(WPX_H1, tag) + (size_t)j * N + n, hy, tag);  // every workgroup has all of h1: each publishes 8 units
     }
     WP_MARK(4);
     __syncthreads();
@@ -390,7 +398,7 @@ __global__ __launch_bounds__(512) void wf_persist_kernel(WpK a) {
           g2_row = frow;
         }
         unsigned pu[3];
-        if (!wp_take<3>(EX(WPX_P2, tag) + (size_t)ju * 16 + i, 8192, tag, p2v, pu, a.abort_word)) return;
+        if (!wp_take<3>(EX(WPX_P2, tag) + (size_t)ju * 4 * N + i, N, tag, p2v, pu, a.abort_word)) return;
         WP_MARK(12);
         const float xr = x1s[((ju >> 2) * WP_NCOL + i) * 4 + (ju & 3)];
         const float rg = sigmoidf_((sx[0] + g2r) + __uint_as_float(pu[0]));
@@ -398,8 +406,8 @@ __global__ __launch_bounds__(512) void wf_persist_kernel(WpK a) {
         const float ng = tanhf((sx[2] + g2n) + rg * __uint_as_float(pu[2]));
         const float hy = ng + zg * (h2 - ng);
         h2 = hy;
-        wp_put(EX(WPX_X2, tag) + (size_t)ju * 16 + i, xr + hy, tag);
-        wp_put(EX(WPX_H2, tag) + (size_t)ju * 16 + i, hy, tag);
+        wp_put(EX(WPX_X2, tag) + (size_t)ju * N + i, xr + hy, tag);
+        wp_put(EX(WPX_H2, tag) + (size_t)ju * N + i, hy, tag);
       }
     }
     WP_MARK(6);
@@ -418,11 +426,11 @@ __global__ __launch_bounds__(512) void wf_persist_kernel(WpK a) {
       rb ^= 1;
       WP_MARK(8);
       if (epi && i < N) {
-        unsigned long long* Y = EX(lo ? WPX_Y1 : WPX_Y2, tag) + (size_t)(ft * 16 + du * 4) * 16 + i;
+        unsigned long long* Y = EX(lo ? WPX_Y1 : WPX_Y2, tag) + (size_t)(ft * 16 + du * 4) * N + i;
         wp_put(Y, fmaxf(sx[0] + pre.x, 0.f), tag);
-        wp_put(Y + 16, fmaxf(sx[1] + pre.y, 0.f), tag);
-        wp_put(Y + 32, fmaxf(sx[2] + pre.z, 0.f), tag);
-        wp_put(Y + 48, fmaxf(sx[3] + pre.w, 0.f), tag);
+        wp_put(Y + N, fmaxf(sx[1] + pre.y, 0.f), tag);
+        wp_put(Y + 2 * N, fmaxf(sx[2] + pre.z, 0.f), tag);
+        wp_put(Y + 3 * N, fmaxf(sx[3] + pre.w, 0.f), tag);
       }
     }
     if (!lo && ft < n_t3) {
@@ -452,9 +460,9 @@ __global__ __launch_bounds__(512) void wf_persist_kernel(WpK a) {
         const unsigned long long o2 = __shfl_xor(pk, 32, 64);
         pk = o2 > pk ? o2 : pk;
         if (du == 0 && i < N) {
-          unsigned long long* K = EX(WPX_KEY, tag) + (size_t)ft * 16 + i;
+          unsigned long long* K = EX(WPX_KEY, tag) + (size_t)ft * 2 * N + i;
           wp_put_u(K, (unsigned)(pk >> 32), tag);
-          wp_put_u(K + 512, (unsigned)pk, tag);
+          wp_put_u(K + N, (unsigned)pk, tag);
         }
       }
     }
@@ -507,25 +515,6 @@ __device__ __forceinline__ float wp_rowsum(const float* red, const int row) {
 #pragma unroll
   for (int w = 0; w < 8; ++w) s += red[row * 8 + w];
   return s;
-}
-// One lane of the workgroup spins on one granule until the step's tag shows up; nobody else touches memory meanwhile
-// (the latency of a hand-off is set by the CONSUMER compute unit's own memory queue: 512 pollers per unit made every
-// exchange 2.5-3 us).  Ends in a barrier.
-template <int SLEEP>
-__device__ __forceinline__ bool wp_watch(const unsigned long long* p, const unsigned tag, int* abort_word) {
-  // (one lane per PRODUCER -- 32 to 64 watching lanes, so that the sweep never starts before the slowest producer --
-  //  measured slower, 13.6 vs 11.9 us per step: what counts is how few requests sit in this unit's memory queue)
-  if (threadIdx.x == 0) {
-    for (int tries = 0; (unsigned)(wp_get(p) >> 32) != tag; ++tries) {
-      if ((tries & 1023) == 1023) {
-        if (tries >= WP_SPIN_LIMIT) atomicExch(abort_word, 1);
-        if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-      }
-      __builtin_amdgcn_s_sleep(SLEEP);
-    }
-  }
-  __syncthreads();
-  return true;
 }
 // thread t fetches feature t of an exchange vector (column 0) into LDS (chain order); SLEEP as above for the watch
 template <int SLEEP>
