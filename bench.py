@@ -560,7 +560,7 @@ def main():
                 "loop_launches": model.last_loop_launches,
                 "loop": ("ONE persistent launch, weight tiles resident in LDS, tagged-granule hand-offs between the layers "
                          "(wavernn_persist.h); A/B against the 5-launch chain with identical sample streams: "
-                         "profiles/r02_wavernn_persistent_ab.json (10.4 vs 16.4 us per step)"
+                         "profiles/r02_wavernn_persistent_ab.json (10.0 vs 16.4 us per step)"
                          if model.last_loop_launches == 1 else "5-launch chain, hipGraph replays"),
             }
             del su, wu

@@ -758,7 +758,7 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
     else hipLaunchKernelGGL(wf_fc_hh_kernel<1>, grid, dim3(512), 0, st, k);
   };
   // Few fold columns: ONE persistent launch with every weight tile resident in LDS and granule hand-offs between the
-  // layers (wavernn_persist.h), same sample stream.  One column (batched=False) runs it by default -- 10.4 vs 16.4 us
+  // layers (wavernn_persist.h), same sample stream.  One column (batched=False) runs it by default -- 10.0 vs 16.4 us
   // per step (profiles/r02_wavernn_persistent_ab.json); 2..4 columns are at parity with the chain and stay on it
   // unless MBHIP_WAVERNN_PERSIST=1; MBHIP_WAVERNN_PERSIST=0 keeps the chain everywhere.
   const char* penv = getenv("MBHIP_WAVERNN_PERSIST");

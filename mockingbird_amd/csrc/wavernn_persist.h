@@ -696,14 +696,20 @@ __global__ __launch_bounds__(512) void wf_persist1_kernel(WpK a) {
       wp_put(Y + 3, fmaxf(wp_rowsum(red, du * 4 + 3) + fpre.w, 0.f), tag);
     }
     if (!lo && ft < n_t3) {
+      // the Gumbel noise of this step does not depend on the data: drawn before the wait for y2, off the key edge
+      float lgn[4] = {0.f, 0.f, 0.f, 0.f};
+      if (tid < 4) {
+        uint32_t grn[4];
+        philox4x32((uint32_t)s, 0u, (uint32_t)((ft * 16 + du * 4) >> 2), 0x57415645u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), grn);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lgn[r] = logf(-logf(u32_to_unit(grn[r])));
+      }
       if (!wp_fetch1<1>(EX(WPX_Y2, tag), tag, xg, a.abort_word)) return;
       __syncthreads();
       WP_MARK(9);
       wp_dot<1>(lw + 24576, xg, red);
       WP_MARK(10);
       if (tid < 4) {  // wf_fc3_kernel's sampler for column 0
-        uint32_t grn[4];
-        philox4x32((uint32_t)s, 0u, (uint32_t)((ft * 16 + du * 4) >> 2), 0x57415645u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), grn);
         const float bv[4] = {b3q.x, b3q.y, b3q.z, b3q.w};
         float best = -INFINITY;
         int bcls = 0;
@@ -711,7 +717,7 @@ __global__ __launch_bounds__(512) void wf_persist1_kernel(WpK a) {
         for (int r = 0; r < 4; ++r) {
           const int row = ft * 16 + du * 4 + r;
           const float v = wp_rowsum(red, du * 4 + r) + bv[r];
-          const float gmb = v - logf(-logf(u32_to_unit(grn[r])));
+          const float gmb = v - lgn[r];
           if (gmb > best) { best = gmb; bcls = row; }
         }
         unsigned long long pk = pack_argmax(best, bcls);
