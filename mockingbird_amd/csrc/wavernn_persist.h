@@ -25,7 +25,9 @@
 // Every exchange buffer is double-buffered by tag parity.  Why that is enough: a granule of tag t is overwritten by
 // tag t+2, and the chain is a cycle -- whoever writes tag t+2 of any buffer has (transitively) consumed a value that
 // needed every reader of tag t of that buffer to have finished (derivation in DESIGN.md section 4d).
-// Every spin has a bail-out: after SPIN_LIMIT polls a workgroup raises the abort word and the launch drains.
+// Every spin has a bail-out: after SPIN_LIMIT polls a workgroup raises the abort word and the launch drains; the host
+// then runs the launch chain instead (same samples) -- co-residency of the 192 workgroups is not something a launch can
+// demand when other work shares the GPU.
 #pragma once
 #include "wavernn_fast.h"
 
@@ -34,7 +36,7 @@ namespace mb {
 constexpr int WP_NCOL = 4;        // fold columns supported (LDS budget of the busiest workgroup: 152 KB of 160)
 constexpr int WP_ON = 64;         // on-chain workgroups
 constexpr int WP_OFF = 128;       // off-chain workgroups (one GRU row tile of each hidden half)
-constexpr int WP_SPIN_LIMIT = 4000000;
+constexpr int WP_SPIN_LIMIT = 1500000;  // polls (about a microsecond each) before a wait is declared lost
 
 // exchange area, in granules, per parity
 enum { WPX_X2 = 0, WPX_H2 = 8192, WPX_H1 = 16384, WPX_Y1 = 24576, WPX_Y2 = 32768, WPX_P1 = 40960, WPX_P2 = 65536,
@@ -241,6 +243,7 @@ __global__ __launch_bounds__(512) void wf_persist_kernel(WpK a) {
   float* x1s = red + WP_LDS_RED;  // float4 index (k / 4) * NCOL + n
   unsigned long long* s_key = reinterpret_cast<unsigned long long*>(x1s + WP_LDS_X);  // [NCOL] max key of the step
   float* s_x = reinterpret_cast<float*>(s_key + WP_NCOL);                             // [NCOL] decoded sample
+  if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // (tests: the fallback path)
   const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int du = lane >> 4, i = lane & 15;
@@ -547,6 +550,7 @@ __global__ __launch_bounds__(512) void wf_persist1_kernel(WpK a) {
   float* xs1 = red + 256;        // x1 of this step
   float* xg = xs1 + 512;         // the vector fetched last
   unsigned long long* s_key = reinterpret_cast<unsigned long long*>(xg + 512);
+  if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // (tests: the fallback path)
   const int g = blockIdx.x, tid = threadIdx.x;
   const int H = a.R, S = a.S;
   const int n_t3 = a.C / 16;

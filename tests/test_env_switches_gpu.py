@@ -110,3 +110,20 @@ def test_wavernn_persistent_kernel_keeps_the_sample_stream(wavernn, monkeypatch,
         assert wavernn.last_loop_launches == 1 and torch.equal(base, alt2)
     assert base.shape == alt.shape and base.shape[0] <= 4
     assert torch.equal(base, alt), (int((base != alt).sum()), int((base != alt).any(0).nonzero()[0]) if (base != alt).any() else -1)
+
+
+def test_wavernn_persistent_kernel_falls_back_to_the_chain(cuda, lib, monkeypatch):
+    """When the persistent launch gives up (its workgroups were not all resident: a hand-off never arrives), the same
+    call runs the launch chain -- same samples -- and the handle stops defaulting to the persistent kernel."""
+    from mockingbird_amd.vocoder.wavernn.inference import WaveRNNDevice
+    dev = WaveRNNDevice(synth.wavernn_state(seed=5)["model_state"])
+    mel = torch.from_numpy(synth.wavernn_mel(9, seed=13) / 4.0).cuda()
+    monkeypatch.setenv("MBHIP_WAVERNN_PERSIST", "0")
+    base = dev.generate_samples(mel, False, 0, 0, seed=4)
+    monkeypatch.delenv("MBHIP_WAVERNN_PERSIST")
+    monkeypatch.setenv("MBHIP_WP_TEST_ABORT", "1")
+    alt = dev.generate_samples(mel, False, 0, 0, seed=4)
+    assert dev.last_loop_launches > 1 and torch.equal(base, alt)
+    monkeypatch.delenv("MBHIP_WP_TEST_ABORT")
+    again = dev.generate_samples(mel, False, 0, 0, seed=4)
+    assert dev.last_loop_launches > 1 and torch.equal(base, again)  # persist_failed sticks for this handle
