@@ -299,6 +299,7 @@ struct mb_wavernn {
   // Folds are independent sequences: they are dealt to up to MAX_LANES "lanes", each with its own
   // stream + graph, so the per-kernel dependency latency of one lane overlaps with the others.
   static constexpr int MAX_LANES = 8;
+  bool persist_attr_set = false;              // dynamic-LDS attribute of the persistent kernels set on this handle's device
   bool persist_failed = false;                // the persistent kernel once failed to stay co-resident on this GPU: stop defaulting to it
   hipStream_t loop_stream = nullptr;          // lane 0 (also runs the conditioning networks)
   hipStream_t lane_stream[MAX_LANES] = {};
@@ -766,11 +767,10 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
   const bool persist = fastk && N <= WP_NCOL && C <= 512 && !w->bench_which && !getenv("MBHIP_TRACE_FILE") && !getenv("MBHIP_WF_DBG_WHICH") &&
                        (penv ? atoi(penv) != 0 : (N == 1 && !w->persist_failed));
   if (persist && !rc) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!w->persist_attr_set) {  // per handle = per device: the attribute belongs to the function on the current device
       MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WP_LDS_BYTES));
       MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_persist1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WP1_LDS_BYTES));
-      attr_set = true;
+      w->persist_attr_set = true;
     }
     MB_HIP(hipMemsetAsync(L.px, 0, wp_exchange_bytes(), s));
     if (getenv("MBHIP_WP_TEST_ABORT"))  // tests only: the launch finds its abort word raised, the chain takes over
