@@ -164,13 +164,15 @@ def net_weight_list(state, n_post):
 
 
 class MelDecoderMOLv2:
-    """Inference-time mirror of models/ppg2mel/__init__.py:MelDecoderMOLv2 built from its state_dict and the
-    constructor arguments of the checkpoint's yaml (`model:` section)."""
+    """Inference-time mirror of models/ppg2mel/__init__.py:MelDecoderMOLv2 with the reference's constructor arguments
+    (the `model:` section of the checkpoint's yaml).  Either pass `state_dict=` or call `load_state_dict()` afterwards,
+    as the reference's callers do (run.py: `MelDecoderMOLv2(**cfg["model"]).to(device)`, `.load_state_dict(ckpt["model"])`,
+    `.eval()`); the device handles are built when the weights arrive."""
 
-    def __init__(self, state_dict, num_speakers=None, spk_embed_dim=256, bottle_neck_feature_dim=144, encoder_dim=256,
+    def __init__(self, num_speakers=None, spk_embed_dim=256, bottle_neck_feature_dim=144, encoder_dim=256,
                  encoder_downsample_rates=(2, 2), attention_rnn_dim=512, decoder_rnn_dim=512, num_decoder_rnn_layer=1,
                  concat_context_to_last=True, prenet_dims=(256, 128), num_mixtures=5, frames_per_step=2,
-                 mask_padding=True):
+                 mask_padding=True, state_dict=None):
         if not torch.cuda.is_available():
             raise _lib.MbHipError("ppg2mel: no MI355X visible; this build has no CPU path")
         rates = [int(r) for r in encoder_downsample_rates]
@@ -178,15 +180,24 @@ class MelDecoderMOLv2:
             raise _lib.MbHipError("ppg2mel: the reference model has exactly two downsampling convolutions")
         self.num_mels, self.frames_per_step = 80, frames_per_step
         self.encoder_down_factor = int(np.cumprod(rates)[-1])
+        self._args = dict(rates=rates, spk_embed_dim=spk_embed_dim, bottle_neck_feature_dim=bottle_neck_feature_dim,
+                          encoder_dim=encoder_dim, attention_rnn_dim=attention_rnn_dim, decoder_rnn_dim=decoder_rnn_dim,
+                          num_decoder_rnn_layer=num_decoder_rnn_layer, concat_context_to_last=concat_context_to_last,
+                          prenet_dims=tuple(prenet_dims), num_mixtures=num_mixtures)
+        self._h, self._ws, self.decoder, self.cfg = None, None, None, None
+        if state_dict is not None:
+            self.load_state_dict(state_dict)
+
+    def load_state_dict(self, state_dict, strict=True):
+        a = self._args
         n_post = 0
         while f"postnet.convolutions.{n_post}.0.conv.weight" in state_dict:
             n_post += 1
         pw = state_dict["postnet.convolutions.0.0.conv.weight"]
         cfg = _lib.Ppg2MelNetConfig()
-        cfg.bnf_dim, cfg.spk_dim, cfg.enc_dim = bottle_neck_feature_dim, spk_embed_dim, encoder_dim
-        cfg.down0, cfg.down1, cfg.num_mels = rates[0], rates[1], self.num_mels
+        cfg.bnf_dim, cfg.spk_dim, cfg.enc_dim = a["bottle_neck_feature_dim"], a["spk_embed_dim"], a["encoder_dim"]
+        cfg.down0, cfg.down1, cfg.num_mels = a["rates"][0], a["rates"][1], self.num_mels
         cfg.postnet_layers, cfg.postnet_dim, cfg.postnet_ksize = n_post, pw.shape[0], pw.shape[2]
-        self.cfg = cfg
         L = _lib.lib()
         ws = net_weight_list(state_dict, n_post)
         n = L.mb_ppg2mel_net_num_weights(C.byref(cfg))
@@ -199,13 +210,14 @@ class MelDecoderMOLv2:
         hnd = C.c_void_p()
         _lib.check(L.mb_ppg2mel_net_create(C.byref(cfg), _lib.host_ptr_array(ws), len(ws), C.byref(hnd)),
                    "mb_ppg2mel_net_create")
-        self._h = hnd
-        self._ws = None
-        dhp = dict(enc_dim=encoder_dim, num_mels=self.num_mels, frames_per_step=frames_per_step,
-                   attention_rnn_dim=attention_rnn_dim, decoder_rnn_dim=decoder_rnn_dim, prenet_dims=tuple(prenet_dims),
-                   num_mixtures=num_mixtures, encoder_down_factor=self.encoder_down_factor,
-                   num_decoder_rnn_layer=num_decoder_rnn_layer, concat_context_to_last=concat_context_to_last)
+        self.__del__()  # a second load replaces the first
+        self.cfg, self._h, self._ws = cfg, hnd, None
+        dhp = dict(enc_dim=a["encoder_dim"], num_mels=self.num_mels, frames_per_step=self.frames_per_step,
+                   attention_rnn_dim=a["attention_rnn_dim"], decoder_rnn_dim=a["decoder_rnn_dim"], prenet_dims=a["prenet_dims"],
+                   num_mixtures=a["num_mixtures"], encoder_down_factor=self.encoder_down_factor,
+                   num_decoder_rnn_layer=a["num_decoder_rnn_layer"], concat_context_to_last=a["concat_context_to_last"])
         self.decoder = Ppg2MelDecoder({k[len("decoder."):]: v for k, v in state_dict.items() if k.startswith("decoder.")}, dhp)
+        return self
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -230,6 +242,8 @@ class MelDecoderMOLv2:
 
     def encode(self, bottle_neck_features, logf0_uv, spembs):
         """:172-179 -> decoder memory [B, T_enc, encoder_dim]."""
+        if self._h is None:
+            raise _lib.MbHipError("ppg2mel: no weights yet (load_state_dict)")
         for name, t in (("bottle_neck_features", bottle_neck_features), ("logf0_uv", logf0_uv), ("spembs", spembs)):
             if t is None:
                 raise AssertionError(f"{name} is required")  # the reference asserts spembs is not None
@@ -288,4 +302,4 @@ def load_model(model_file, device=None):
     with open(cfgs[0]) as f:
         model_cfg = yaml.safe_load(f)["model"]
     ckpt = torch.load(model_file, map_location="cpu")
-    return MelDecoderMOLv2(ckpt["model"], **model_cfg)
+    return MelDecoderMOLv2(**model_cfg).load_state_dict(ckpt["model"]).eval()

@@ -155,3 +155,36 @@ def test_statics_and_seed_semantics_of_the_synthesizer_facade(monkeypatch, tmp_p
     assert all(np.array_equal(x, y) for x, y in zip(a, b)) and len(a) == 35
     assert all(m.shape[0] == 80 and m.shape[1] == 33 and m.dtype == np.float32 for m in a)  # 40 frames - 7 trimmed
     assert s._model.calls[0]["style_idx"] == 0 and s._model.calls[0]["min_stop_token"] == 5 and s._model.calls[0]["steps"] == 2000
+
+
+def test_install_can_alias_the_voice_conversion_model_package(monkeypatch):
+    """install(ppg2mel=True): `models.ppg2mel` (run.py:13,45,77; control/mkgui/app_vc.py:12,144) becomes the HIP-backed
+    module -- MelDecoderMOLv2 with the reference's constructor keywords, load_model -- while the package's reference
+    submodules (utils, train, ...) still import from the reference's own directory."""
+    import importlib
+    import inspect
+    import mockingbird_amd
+    monkeypatch.syspath_prepend(str(REF))
+    saved = {k: v for k, v in sys.modules.items() if k == "models" or k.startswith("models.")}
+    for k in saved:
+        monkeypatch.delitem(sys.modules, k, raising=False)
+    try:
+        names = mockingbird_amd.install(ppg2mel=True)
+        assert "models.ppg2mel" in names
+        conv = importlib.import_module("models.ppg2mel")
+        import mockingbird_amd.ppg2mel as mine
+        assert conv is mine and conv.MelDecoderMOLv2 is mine.MelDecoderMOLv2 and callable(conv.load_model)
+        ref_params = ["num_speakers", "spk_embed_dim", "bottle_neck_feature_dim", "encoder_dim", "encoder_downsample_rates",
+                      "attention_rnn_dim", "decoder_rnn_dim", "num_decoder_rnn_layer", "concat_context_to_last", "prenet_dims",
+                      "num_mixtures", "frames_per_step", "mask_padding"]
+        got = list(inspect.signature(conv.MelDecoderMOLv2.__init__).parameters)[1:]
+        assert got[:len(ref_params)] == ref_params, got  # models/ppg2mel/__init__.py:22-37, keyword for keyword
+        post = importlib.import_module("models.ppg2mel.utils.cnn_postnet")  # reference CPU code, still reachable
+        assert post.__file__.startswith(str(REF)) and hasattr(post, "Postnet")
+        assert "models.ppg2mel" not in mockingbird_amd.install()  # opt-in only
+    finally:
+        for k in [k for k in sys.modules if k == "models" or k.startswith("models.")]:
+            sys.modules.pop(k, None)
+        sys.modules.update(saved)
+        if str(REF / "models" / "ppg2mel") in mockingbird_amd.ppg2mel.__path__:
+            mockingbird_amd.ppg2mel.__path__.remove(str(REF / "models" / "ppg2mel"))

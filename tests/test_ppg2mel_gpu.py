@@ -90,7 +90,7 @@ def test_net_encode_and_postnet_match_oracle(cuda, lib, B, T, seed):
     from mockingbird_amd.ppg2mel import MelDecoderMOLv2
     nh = synth.PPG2MEL_NET_HP
     w = synth.ppg2mel_model_state(synth.PPG2MEL_HP, nh, seed=seed)
-    m = MelDecoderMOLv2(w, spk_embed_dim=nh["spk_dim"], bottle_neck_feature_dim=nh["bnf_dim"])
+    m = MelDecoderMOLv2(spk_embed_dim=nh["spk_dim"], bottle_neck_feature_dim=nh["bnf_dim"], state_dict=w)
     bnf, lf0, spk = (torch.from_numpy(a) for a in synth.ppg2mel_inputs(B, T, seed=seed))
     with torch.no_grad():
         omem = op.encode(w, nh, bnf, lf0, spk)
@@ -115,7 +115,7 @@ def test_model_inference_surface_and_golden(cuda, lib):
     nh = synth.PPG2MEL_NET_HP
     for name, B, T, wseed, sb, iseed, rseed in synth.PPG2MEL_MODEL_CASES:
         w = synth.ppg2mel_model_state(synth.PPG2MEL_HP, nh, seed=wseed, stop_bias=sb)
-        m = MelDecoderMOLv2(w, spk_embed_dim=nh["spk_dim"], bottle_neck_feature_dim=nh["bnf_dim"]).to("cuda").eval()
+        m = MelDecoderMOLv2(spk_embed_dim=nh["spk_dim"], bottle_neck_feature_dim=nh["bnf_dim"], state_dict=w).to("cuda").eval()
         bnf, lf0, spk = (torch.from_numpy(a).cuda() for a in synth.ppg2mel_inputs(B, T, seed=iseed))
         mem = m.encode(bnf, lf0, spk)
         assert float(np.abs(mem.cpu().numpy() - g[name + "_memory"]).max()) <= 1e-4
