@@ -128,3 +128,20 @@ def test_model_inference_surface_and_golden(cuda, lib):
         assert float(np.abs(al.cpu().numpy() - g[name + "_align"]).max()) <= ALIGN_TOL
     with pytest.raises(AssertionError):
         m.inference(bnf, logf0_uv=lf0, spembs=None)
+
+
+def test_net_encode_non_default_front_end(cuda, lib):
+    """Other constructor arguments than the shipped yaml: downsample rates (3, 2) (k = 6 stride 3 pad 1, then k = 4 stride 2),
+    a 128-dim speaker vector, 72 bottleneck features -- the strided conv, InstanceNorm and concat paths at other sizes."""
+    from mockingbird_amd.ppg2mel import MelDecoderMOLv2
+    nh = dict(bnf_dim=72, spk_dim=128, enc_dim=256, downsample_rates=(3, 2), num_mels=80)
+    w = synth.ppg2mel_model_state(synth.PPG2MEL_HP, nh, seed=9)
+    m = MelDecoderMOLv2(spk_embed_dim=128, bottle_neck_feature_dim=72, encoder_downsample_rates=[3, 2], state_dict=w)
+    assert m.encoder_down_factor == 6
+    for B, T in ((2, 125), (1, 37)):
+        bnf, lf0, spk = (torch.from_numpy(a) for a in synth.ppg2mel_inputs(B, T, seed=T, net_hp=nh))
+        with torch.no_grad():
+            omem = op.encode(w, nh, bnf, lf0, spk)
+        mem = m.encode(bnf.cuda(), lf0.cuda(), spk.cuda()).cpu()
+        assert mem.shape == omem.shape, (mem.shape, omem.shape)
+        assert float((mem - omem).abs().max()) <= 1e-4, float((mem - omem).abs().max())
