@@ -336,6 +336,12 @@ int mb_wavernn_finish(const float* d_samples, int n_folds, int seq_len, int batc
                       int n_classes, int mu_law, int apply_preemphasis, double preemphasis,
                       int wave_len, int fade_len, double* d_wav, int* out_len, void* d_workspace,
                       size_t workspace_bytes, mb_stream_t stream);
+/* Test hook: the Exp(1) noise the on-device sampler of the production paths draws for `seed`:
+ * d_out [steps][folds][n_classes] = E for steps step0 .. step0+steps-1, i.e. exactly the tensor which, passed as d_noise
+ * to the oracle's sample loop (argmax(softmax(l) / E), torch.multinomial's rule), reproduces what
+ * mb_wavernn_generate(d_noise = NULL, seed) samples with its fused Gumbel-argmax (argmax(l - log E)).
+ * For mb_wavernn_generate_batch, `folds` is utterance u's own fold count and seed = h_seeds[u]. */
+int mb_wavernn_debug_noise(uint64_t seed, int step0, int steps, int folds, int n_classes, float* d_out, mb_stream_t stream);
 int mb_wavernn_last_loop_ms(const mb_wavernn* w, float* ms, int* launches);
 /* Measurement hook (bench.py roofline leg): runs the real generate loop twice on its
  * stream, bracketed by hipEvents, with and without kernel `which` (0 rnn1 GRU, 1 rnn2 GRU,

@@ -1379,6 +1379,32 @@ extern "C" int mb_wavernn_generate_batch(const mb_wavernn* wc, const mb_wavernn_
                                                            workspace_bytes, stream));
 }
 
+// Test hook (tests/test_wavernn_gpu.py): the Exp(1) draws E[step][fold][class] = -log u that every fused Gumbel-argmax
+// sampler of the production paths consumes -- wf_fc3_kernel, the gum epilogue of rnn_body.h / rnn_ts2_body.h,
+// wf_persist(1)_kernel: Philox(counter = (step, fold, class / 4, 'WAVE'), key = seed), word class % 4 -- so that the
+// oracle can run sample_loop(noise = E) against the DEFAULT generate(seed) path (argmax_c l_c - log E_c ==
+// argmax_c softmax(l)_c / E_c, torch.multinomial's rule, fatchord_version.py:222-226).
+__global__ void wavernn_debug_noise_kernel(unsigned long long seed, int step0, int steps, int folds, int C4, float4* out) {
+  const size_t total = (size_t)steps * folds * C4;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int q = (int)(idx % C4);
+    const size_t r = idx / C4;
+    const int n = (int)(r % folds), s = step0 + (int)(r / folds);
+    uint32_t g[4];
+    mb::philox4x32((uint32_t)s, (uint32_t)n, (uint32_t)q, 0x57415645u, (uint32_t)seed, (uint32_t)(seed >> 32), g);
+    out[idx] = make_float4(-logf(mb::u32_to_unit(g[0])), -logf(mb::u32_to_unit(g[1])), -logf(mb::u32_to_unit(g[2])), -logf(mb::u32_to_unit(g[3])));
+  }
+}
+extern "C" int mb_wavernn_debug_noise(uint64_t seed, int step0, int steps, int folds, int n_classes, float* d_out, mb_stream_t stream) {
+  MB_REQUIRE(d_out && steps >= 1 && folds >= 1 && step0 >= 0 && n_classes >= 4 && n_classes % 4 == 0, "wavernn_debug_noise: bad arguments");
+  const size_t total = (size_t)steps * folds * (n_classes / 4);
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL(wavernn_debug_noise_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (unsigned long long)seed, step0, steps, folds,
+                     n_classes / 4, reinterpret_cast<float4*>(d_out));
+  MB_HIP(hipGetLastError());
+  return MB_OK;
+}
+
 extern "C" int mb_wavernn_last_loop_ms(const mb_wavernn* w, float* ms, int* launches) {
   MB_REQUIRE(w && ms, "wavernn_last_loop_ms: null pointer");
   if (!w->timed) { set_error("wavernn_last_loop_ms: no generate call yet"); return MB_ESTATE; }

@@ -103,6 +103,18 @@ class WaveRNNDevice:
         self.last_loop_ms, self.last_loop_launches, self.last_plan = ms.value, nl.value, p
         return (samples, logits) if want_logits else samples
 
+    def sampler_noise(self, seed, steps, folds, step0=0):
+        """Test hook (mb_wavernn_debug_noise): the Exp(1) draws the on-device sampler of the production paths consumes
+        for `seed` -> CUDA tensor [steps, folds, n_classes]; handed to the oracle's sample loop as `noise`, it makes
+        the oracle sample what generate_samples(seed=seed) samples (RAW mode)."""
+        if self.cfg.mode != 0:
+            raise _lib.MbHipError("sampler_noise: RAW mode only")
+        out = torch.empty(steps, folds, self.n_classes, dtype=torch.float32, device="cuda")
+        _lib.check(_lib.lib().mb_wavernn_debug_noise(int(seed), int(step0), int(steps), int(folds), self.n_classes,
+                                                     _lib.ptr(out), _lib.stream_ptr()), "mb_wavernn_debug_noise")
+        torch.cuda.current_stream().synchronize()
+        return out
+
     def generate_samples_batch(self, mels, target, overlap, seeds=None):
         """Several utterances in ONE sample loop (mb_wavernn_generate_batch; additive API).  mels: list of
         [80, F_u] CUDA tensors (already divided by mel_max_abs_value); seeds: one per utterance (default: drawn

@@ -413,3 +413,121 @@ def test_mol_free_running_facade(mol_model):
     assert wav.dtype == np.float64 and wav.shape == ref.shape and float(np.abs(wav - ref).max()) <= 1e-12
     outs = dev.generate_samples_batch([m, m[:, :27]], 600, 100, seeds=[5, 9])
     assert torch.equal(outs[0], a) and outs[1].shape[1] == 800
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The DEFAULT production paths (no injected noise, no teacher forcing, no logits dump) against the oracle.
+# mb_wavernn_debug_noise exports the Exp(1) words the fused Gumbel-argmax epilogues consume for a seed; the oracle
+# then runs the reference loop body (fatchord_version.py:190-228) on the device's own sample history with that
+# noise: at EVERY step its multinomial pick must be the class the device emitted, except provable near-ties.
+# ---------------------------------------------------------------------------------------------------------
+def _oracle_replay(w, mel, batched, target, overlap, samples, noise, steps):
+    """Oracle picks at steps [0, steps) given the device's history (teacher forcing on the device samples)."""
+    mels, aux = _oracle_cond(w, mel, batched, target, overlap)
+    nt = torch.get_num_threads()
+    torch.set_num_threads(min(nt, 8))  # tiny GEMVs: the 128 default threads of the GPU box's host make each step slower
+    try:
+        with torch.no_grad():
+            o_s, o_l = ow.sample_loop(w, ow.HP, mels, aux, noise=noise, forced=samples, return_logits=True, max_steps=steps)
+    finally:
+        torch.set_num_threads(nt)
+    return o_s, o_l
+
+
+def _assert_same_picks(s_dev, o_s, o_l, noise, steps, max_ties):
+    k_dev = torch.round((s_dev[:, :steps] + 1) * 511 / 2).long()
+    k_or = torch.round((o_s + 1) * 511 / 2).long()
+    assert float(((s_dev[:, :steps] + 1) * 511 / 2 - k_dev).abs().max()) < 1e-3  # class centres
+    mism = (k_dev != k_or)
+    n_mis = int(mism.sum())
+    if n_mis:
+        post = torch.softmax(o_l, dim=2) / noise[:steps]
+        top2 = post.topk(2, dim=2).values
+        ratio = ((top2[..., 0] - top2[..., 1]) / top2[..., 0]).t()
+        assert not (mism & (ratio > 1e-4)).any(), f"{int((mism & (ratio > 1e-4)).sum())} non-tie mismatches of {n_mis}"
+        # and the device's pick is the oracle's runner-up there
+        second = post.topk(2, dim=2).indices[..., 1].t()
+        assert bool((k_dev[mism] == second[mism]).all())
+    assert n_mis <= max_ties, n_mis
+    return n_mis
+
+
+def test_debug_noise_is_exponential(model):
+    """The exported words are Exp(1) draws (mean 1, variance 1, P(E > 1) = 1/e), deterministic per seed, and a window
+    starting at step0 equals the same steps of a longer export."""
+    dev, w = model
+    e = dev.sampler_noise(3, 64, 5)
+    assert e.shape == (64, 5, 512) and bool((e > 0).all()) and torch.isfinite(e).all()
+    assert abs(float(e.mean()) - 1.0) < 0.02 and abs(float(e.var()) - 1.0) < 0.05
+    assert abs(float((e > 1).float().mean()) - 0.36788) < 0.01
+    assert torch.equal(e, dev.sampler_noise(3, 64, 5)) and not torch.equal(e, dev.sampler_noise(4, 64, 5))
+    assert torch.equal(e[10:20], dev.sampler_noise(3, 10, 5, step0=10))
+
+
+def test_production_fast_chain_23_folds_vs_oracle(model, monkeypatch):
+    """BASELINE configs[1]: the benchmarked wf_* launches (FM fast chain, fused sampler, hipGraph replays), default
+    call, 23 folds x 2000 steps against the oracle."""
+    dev, w = model
+    for k in ("MBHIP_WAVERNN_FAST", "MBHIP_WAVERNN_PERSIST", "MBHIP_WAVERNN_NOFUSE", "MBHIP_WAVERNN_CHAIN", "MBHIP_NO_GRAPH"):
+        monkeypatch.delenv(k, raising=False)
+    frames, target, overlap, steps, seed = 1000, 8000, 800, 2000, 1234
+    mel = synth.wavernn_mel(frames, seed=1)
+    s = dev.generate_samples(torch.from_numpy(mel / 4.0).cuda(), True, target, overlap, seed=seed).cpu()
+    assert (dev.last_plan.n_folds, dev.last_plan.seq_len) == (23, 9600)
+    assert dev.last_loop_launches in (5 * 9600, 1)  # the 5-launch chain (or ONE persistent launch once it is the default)
+    noise = dev.sampler_noise(seed, steps, 23).cpu()
+    o_s, o_l = _oracle_replay(w, mel, True, target, overlap, s, noise, steps)
+    _assert_same_picks(s, o_s, o_l, noise, steps, max_ties=8)
+
+
+@pytest.mark.parametrize("form", ["fmaf", "mfma", "chain"])
+def test_production_one_column_vs_oracle(model, monkeypatch, form):
+    """batched=False (one fold column): the persistent kernel (default: fmaf chains; MBHIP_WP_MFMA=1: MFMA tiles) and the
+    launch chain it replaces, 2000 steps each against the oracle."""
+    dev, w = model
+    monkeypatch.delenv("MBHIP_WAVERNN_PERSIST", raising=False)
+    monkeypatch.delenv("MBHIP_WP_MFMA", raising=False)
+    if form == "mfma":
+        monkeypatch.setenv("MBHIP_WP_MFMA", "1")
+    if form == "chain":
+        monkeypatch.setenv("MBHIP_WAVERNN_PERSIST", "0")
+    frames, steps, seed = 30, 2000, 77
+    mel = synth.wavernn_mel(frames, seed=13)
+    s = dev.generate_samples(torch.from_numpy(mel / 4.0).cuda(), False, 0, 0, seed=seed).cpu()
+    assert s.shape == (1, 6000)
+    assert dev.last_loop_launches == (5 * 6000 if form == "chain" else 1)
+    noise = dev.sampler_noise(seed, steps, 1).cpu()
+    o_s, o_l = _oracle_replay(w, mel, False, 0, 0, s, noise, steps)
+    _assert_same_picks(s, o_s, o_l, noise, steps, max_ties=2)
+
+
+def test_production_three_columns_persistent_vs_oracle(model, monkeypatch):
+    """MBHIP_WAVERNN_PERSIST=1 at three fold columns (wf_persist_kernel, MFMA tiles, column-dense exchange vectors)."""
+    dev, w = model
+    monkeypatch.setenv("MBHIP_WAVERNN_PERSIST", "1")
+    frames, target, overlap, steps, seed = 40, 2400, 200, 2000, 5
+    mel = synth.wavernn_mel(frames, seed=14)
+    s = dev.generate_samples(torch.from_numpy(mel / 4.0).cuda(), True, target, overlap, seed=seed).cpu()
+    assert s.shape == (3, 2800) and dev.last_loop_launches == 1
+    noise = dev.sampler_noise(seed, steps, 3).cpu()
+    o_s, o_l = _oracle_replay(w, mel, True, target, overlap, s, noise, steps)
+    _assert_same_picks(s, o_s, o_l, noise, steps, max_ties=2)
+
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_production_batch_loop_vs_oracle(model, wide):
+    """mb_wavernn_generate_batch (the `wavernn_batch32` bench object's kernels: rnn_rowtile_body with the Gumbel epilogue
+    up to 64 columns, rnn_ts2_body above): every utterance against the oracle with ITS seed's noise."""
+    dev, w = model
+    frames = [100, 93, 100, 77] if wide else [41, 30, 57]
+    target, overlap = (1000, 100) if wide else (2000, 200)
+    steps = 300
+    mels_np = [synth.wavernn_mel(f, seed=60 + i) for i, f in enumerate(frames)]
+    seeds = [11, 12, 13, 14][:len(frames)]
+    outs = dev.generate_samples_batch([torch.from_numpy(m / 4.0).cuda() for m in mels_np], target, overlap, seeds)
+    assert (dev.last_batch_plan.n_folds > 64) == wide
+    for u in ((0, 3) if wide else (0, 1, 2)):
+        s = outs[u].cpu()
+        noise = dev.sampler_noise(seeds[u], steps, s.shape[0]).cpu()
+        o_s, o_l = _oracle_replay(w, mels_np[u], True, target, overlap, s, noise, steps)
+        _assert_same_picks(s, o_s, o_l, noise, steps, max_ties=3)
