@@ -289,7 +289,7 @@ def sharded_objects(args, rank, world, dev, use_dist, timed, total_over_ranks):
 
     def e2e(_):
         with contextlib.redirect_stdout(io.StringIO()):  # the facade prints the prompts, like the reference
-            wavs = pipeline.gen_wavs(syn, voc, requests, steps=400, min_stop_token=11, normalize=0.97, pcm16="sndfile")
+            wavs = pipeline.gen_wavs(syn, voc, requests, steps=400, min_stop_token=11, normalize=0.97, pcm16="save_wav")
         return sum(len(w) for w in wavs)  # rank 0 holds everything after the gather; other ranks 0
 
     el, res = timed(e2e, 1, 1)
@@ -312,7 +312,7 @@ def sharded_objects(args, rank, world, dev, use_dist, timed, total_over_ranks):
     from mockingbird_amd import sharding
 
     def fre(_):
-        wavs, _sr = gen.infer_waveform_batch(mels, pcm16="sndfile", device_out=True)
+        wavs, _sr = gen.infer_waveform_batch(mels, pcm16="encode_16bits", device_out=True)
         got = sharding.gather_waveforms(wavs, dev, dst=0)
         return sum(len(w) for w in got)
 

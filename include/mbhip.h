@@ -371,7 +371,7 @@ typedef struct mb_taco_config {
   int has_gst, gst_tokens, gst_heads, gst_n_convs, gst_width;
   int gst_filters[8];
   /* PreNet dropout probability (hparams.tts_dropout, pre_net.py:23,26: applied at inference too); kept values are
-   * scaled by 1/(1-p).  0 disables dropout. */
+   * scaled by 1/(1-p).  0 (a zero-initialised struct) = the reference's 0.5; a negative value disables dropout. */
   float dropout;
 } mb_taco_config;
 typedef struct mb_taco mb_taco;

@@ -140,7 +140,13 @@ struct mb_ppg2mel {
   // fast step (ppg_fast.h), production dims only
   bool fast = false;
   DevBuf f_att_p, f_att_c, f_att_h, f_att_b4, f_dec_x, f_dec_h, f_dec_b4, f_fc0_w, f_fc0_b;
-  struct GraphKey { const void *mem, *drop, *mel, *align, *stop, *ws; int B, T, max_steps, min_steps, G; float thr; } gkey = {};
+  struct GraphKey {
+    const void *mem, *drop, *mel, *align, *stop, *ws; int B, T, max_steps, min_steps, G; float thr;
+    bool operator==(const GraphKey& o) const {  // field by field (padding bytes are unspecified)
+      return mem == o.mem && drop == o.drop && mel == o.mel && align == o.align && stop == o.stop && ws == o.ws && B == o.B && T == o.T &&
+             max_steps == o.max_steps && min_steps == o.min_steps && G == o.G && thr == o.thr;
+    }
+  } gkey = {};
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   int* h_flags = nullptr;
@@ -434,7 +440,7 @@ static int ppg_fast_loop_body(mb_ppg2mel* p, const PpgLayout& L, const float* d_
   bool stopped = false;
   if (use_graph) {
     mb_ppg2mel::GraphKey key = {d_memory, d_dropout, d_mel, d_align, d_stop, d_workspace, B, T, max_steps, min_steps, G, thr};
-    if (!p->graph_exec || memcmp(&key, &p->gkey, sizeof(key)) != 0) {
+    if (!p->graph_exec || !(key == p->gkey)) {
       p->drop_graph();
       MB_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
       for (int i = 0; i < G && !rc; ++i) rc = step(i);

@@ -839,7 +839,13 @@ struct mb_taco {
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // loop timing (mb_taco_last_loop_ms)
   int last_iters = 0; bool timed = false;
   // captured iterations of the fast loop: reused while the call arguments do not change (handle is single-threaded)
-  struct GraphKey { const void *mem, *memp, *chars, *drop, *mel, *attn, *ws; int B, T, max_steps, G; float mst; } gkey = {};
+  struct GraphKey {
+    const void *mem, *memp, *chars, *drop, *mel, *attn, *ws; int B, T, max_steps, G; float mst;
+    bool operator==(const GraphKey& o) const {  // field by field: the struct has tail padding, memcmp would read it
+      return mem == o.mem && memp == o.memp && chars == o.chars && drop == o.drop && mel == o.mel && attn == o.attn && ws == o.ws &&
+             B == o.B && T == o.T && max_steps == o.max_steps && G == o.G && mst == o.mst;
+    }
+  } gkey = {};
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   int* h_flags = nullptr;  // pinned: [2][8] flag snapshots
@@ -943,7 +949,7 @@ static int taco_shapes(const mb_taco_config* c, std::vector<size_t>* n) {
   MB_REQUIRE(c->n_mels % 16 == 0 && c->project_dims % 16 == 0 && c->decoder_dims % 16 == 0 && c->lstm_dims % 16 == 0,
              "taco: n_mels/project_dims/decoder_dims/lstm_dims must be multiples of 16");
   MB_REQUIRE(c->r >= 1 && c->r <= c->max_r, "taco: r=%d out of range", c->r);
-  MB_REQUIRE(c->dropout >= 0.f && c->dropout < 1.f, "taco: dropout probability %g outside [0, 1)", (double)c->dropout);
+  MB_REQUIRE(c->dropout < 1.f, "taco: dropout probability %g must be < 1 (0 = the reference's 0.5, negative = off)", (double)c->dropout);
   MB_REQUIRE(c->postnet_dims % 32 == 0 && c->postnet_K >= 1 && c->postnet_K <= 16, "taco: postnet dims");
   const size_t M = c->n_mels, P = c->project_dims, D = c->decoder_dims, H = c->lstm_dims, C = c->postnet_dims;
   n->clear();
@@ -1004,6 +1010,8 @@ extern "C" int mb_taco_create(const mb_taco_config* cfg, const float* const* hw,
   MB_REQUIRE(n_weights == (int)shapes.size(), "taco_create: expected %d weight tensors, got %d", (int)shapes.size(), n_weights);
   mb_taco* t = new mb_taco();
   t->cfg = *cfg;
+  // dropout: 0 (a zero-initialised config) = the reference's always-on 0.5 (pre_net.py:23,26); negative = disabled
+  t->cfg.dropout = cfg->dropout == 0.f ? 0.5f : (cfg->dropout < 0.f ? 0.f : cfg->dropout);
   const int M = cfg->n_mels, P = cfg->project_dims, D = cfg->decoder_dims, H = cfg->lstm_dims, C = cfg->postnet_dims;
   std::vector<float> rows, packed;
   int ix = 0;
@@ -1395,7 +1403,7 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
   bool stopped = false;
   if (use_graph) {
     mb_taco::GraphKey key = {d_memory, d_memory_proj, d_chars, d_dropout, d_mel, d_attn, d_workspace, B, T, max_steps, G, min_stop_token};
-    if (!t->graph_exec || memcmp(&key, &t->gkey, sizeof(key)) != 0) {
+    if (!t->graph_exec || !(key == t->gkey)) {
       t->drop_graph();
       MB_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
       for (int i = 0; i < G && !rc; ++i) rc = iteration(i & 1, i);

@@ -25,6 +25,7 @@
 #include "rnn.h"
 #include "wavernn_fast.h"
 #include "wavernn_persist.h"
+#include "wavernn_pipe.h"
 
 namespace mb {
 
@@ -299,8 +300,8 @@ struct mb_wavernn {
   // Folds are independent sequences: they are dealt to up to MAX_LANES "lanes", each with its own
   // stream + graph, so the per-kernel dependency latency of one lane overlaps with the others.
   static constexpr int MAX_LANES = 8;
-  bool persist_attr_set = false;              // dynamic-LDS attribute of the persistent kernels set on this handle's device
-  bool persist_failed = false;                // the persistent kernel once failed to stay co-resident on this GPU: stop defaulting to it
+  int resident_cus = -1;                      // compute units a resident launch may count on (-1: not probed yet, 0: none)
+  int* h_abort = nullptr;                     // pinned host copy of the resident launch's abort word
   hipStream_t loop_stream = nullptr;          // lane 0 (also runs the conditioning networks)
   hipStream_t lane_stream[MAX_LANES] = {};
   hipEvent_t lane_ev[MAX_LANES] = {};
@@ -317,6 +318,9 @@ struct mb_wavernn {
     }
   }
 };
+
+// a resident launch (wavernn_persist.h / wavernn_pipe.h) once lost a hand-off on this device: stop defaulting to them there
+static bool g_resident_failed[64] = {};
 
 static int wavernn_shapes(const mb_wavernn_config* c, std::vector<size_t>* numel) {
   MB_REQUIRE(c, "wavernn: null config");
@@ -533,6 +537,7 @@ extern "C" void mb_wavernn_destroy(mb_wavernn* w) {
                   &w->f_hh1t, &w->f_hh2t, &w->f_bhh1q, &w->f_bhh2q};
   for (DevBuf* b : bs) b->release();
   w->drop_graph();
+  if (w->h_abort) (void)hipHostFree(w->h_abort);
   if (w->ev_in) (void)hipEventDestroy(w->ev_in);
   if (w->ev_out) (void)hipEventDestroy(w->ev_out);
   if (w->ev_t0) (void)hipEventDestroy(w->ev_t0);
@@ -602,7 +607,7 @@ static void wavernn_layout(const mb_wavernn* w, const mb_wavernn_plan* p, void* 
   }
   L->step = ar.take<int>(16);
   L->slots = ar.take<unsigned long long>(2 * N);
-  L->px = ar.take<unsigned long long>(wp_exchange_bytes() / 8);
+  L->px = ar.take<unsigned long long>(std::max(wp_exchange_bytes(), wq_exchange_bytes()) / 8);
   L->bytes = ar.off + 256;
 }
 
@@ -759,58 +764,99 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
     if (fnt == 2) hipLaunchKernelGGL(wf_fc_hh_kernel<2>, grid, dim3(512), 0, st, k);
     else hipLaunchKernelGGL(wf_fc_hh_kernel<1>, grid, dim3(512), 0, st, k);
   };
-  // Few fold columns: ONE persistent launch with every weight tile resident in LDS and granule hand-offs between the
-  // layers (wavernn_persist.h), same sample stream.  One column (batched=False) runs it by default -- 10.0 vs 16.4 us
-  // per step (profiles/r02_wavernn_persistent_ab.json); 2..4 columns are at parity with the chain and stay on it
-  // unless MBHIP_WAVERNN_PERSIST=1; MBHIP_WAVERNN_PERSIST=0 keeps the chain everywhere.
+  // Resident forms of the loop: ONE launch for the whole utterance, every weight tile in LDS, granule hand-offs between
+  // the layers, same sample stream as the chain.
+  //   * wf_pipe_kernel (wavernn_pipe.h), 2..32 fold columns: role-specialised workgroups, two column groups in flight.
+  //     MBHIP_WAVERNN_PIPE=0 keeps the chain, =1 forces it wherever it is legal.
+  //   * wf_persist1_kernel / wf_persist_kernel (wavernn_persist.h), 1 (default) .. 4 columns (MBHIP_WAVERNN_PERSIST=1).
+  // Both need their workgroups co-resident, one per compute unit: checked here against the device (CU count, occupancy
+  // of the kernel, a per-device "it failed before" flag); a launch that still loses a hand-off (another process holds
+  // compute units) times out after 0.2 s, raises its abort word and the chain below computes the same samples.
+  // NOTE: a resident launch makes this call host-blocking (the abort word has to be looked at before returning).
   const char* penv = getenv("MBHIP_WAVERNN_PERSIST");
-  const bool persist = fastk && N <= WP_NCOL && C <= 512 && !w->bench_which && !getenv("MBHIP_TRACE_FILE") && !getenv("MBHIP_WF_DBG_WHICH") &&
-                       (penv ? atoi(penv) != 0 : (N == 1 && !w->persist_failed));
-  if (persist && !rc) {
-    if (!w->persist_attr_set) {  // per handle = per device: the attribute belongs to the function on the current device
+  const char* qenv = getenv("MBHIP_WAVERNN_PIPE");
+  const bool resident_ok = fastk && C <= 512 && !w->bench_which && !getenv("MBHIP_TRACE_FILE") && !getenv("MBHIP_WF_DBG_WHICH");
+  bool pipe = resident_ok && N >= 2 && N <= WQ_G * WQ_GC && (qenv ? atoi(qenv) != 0 : WQ_DEFAULT_ON != 0);
+  bool persist = resident_ok && !pipe && N <= WP_NCOL && (penv ? atoi(penv) != 0 : N == 1);
+  if ((pipe || persist) && !rc) {
+    int dev = 0;
+    MB_HIP(hipGetDevice(&dev));
+    if (w->resident_cus < 0) {  // once per handle = per device
+      hipDeviceProp_t prop;
+      MB_HIP(hipGetDeviceProperties(&prop, dev));
       MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WP_LDS_BYTES));
       MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_persist1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WP1_LDS_BYTES));
-      w->persist_attr_set = true;
+      MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_pipe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WQ_LDS_BYTES));
+      int nb0 = 0, nb1 = 0, nb2 = 0;
+      MB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb0, reinterpret_cast<const void*>(wf_persist_kernel), 512, WP_LDS_BYTES));
+      MB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, reinterpret_cast<const void*>(wf_persist1_kernel), 512, WP1_LDS_BYTES));
+      MB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, reinterpret_cast<const void*>(wf_pipe_kernel), 512, WQ_LDS_BYTES));
+      w->resident_cus = (nb0 >= 1 && nb1 >= 1 && nb2 >= 1) ? prop.multiProcessorCount : 0;
+      if (!w->h_abort) MB_HIP(hipHostMalloc((void**)&w->h_abort, sizeof(int), hipHostMallocDefault));
     }
-    MB_HIP(hipMemsetAsync(L.px, 0, wp_exchange_bytes(), s));
+    const bool dev_failed = dev >= 0 && dev < 64 && g_resident_failed[dev];
+    if (dev_failed && !(pipe ? qenv : penv)) { pipe = false; persist = false; }  // (an explicit switch still tries)
+    if (pipe && w->resident_cus < WQ_WGS) pipe = false;
+    if (persist && w->resident_cus < WP_ON + WP_OFF) persist = false;
+  }
+  if ((pipe || persist) && !rc) {
+    const size_t ex_bytes = pipe ? wq_exchange_bytes() : wp_exchange_bytes();
+    int* abort_word = reinterpret_cast<int*>(L.px + (pipe ? (size_t)WQ_G * 2 * WQX_PER : (size_t)2 * WPX_PER_PARITY));
+    MB_HIP(hipMemsetAsync(L.px, 0, ex_bytes, s));
     if (getenv("MBHIP_WP_TEST_ABORT"))  // tests only: the launch finds its abort word raised, the chain takes over
-      MB_HIP(hipMemsetAsync(reinterpret_cast<int*>(L.px + (size_t)2 * WPX_PER_PARITY), 1, 1, s));
-    WpK pk;
-    pk.w_rnn2 = w->w_rnn2x.p; pk.w_fc1 = w->w_fc1.p; pk.w_fc2 = w->w_fc2.p; pk.w_fc3 = w->w_fc3.p; pk.w_hh1 = w->f_hh1t.p; pk.w_hh2 = w->f_hh2t.p;
-    pk.bhh1q = reinterpret_cast<const float4*>(w->f_bhh1q.p); pk.bhh2q = reinterpret_cast<const float4*>(w->f_bhh2q.p);
-    pk.b_fc3 = w->b_fc3.p; pk.g1 = w->g1I0.p; pk.wI0 = w->wI0.p;
-    pk.T1 = L.T1; pk.Ipre = L.Ipre; pk.G2 = L.G2; pk.F1 = L.F1; pk.F2 = L.F2;
-    pk.g = wg; pk.ex = L.px; pk.abort_word = reinterpret_cast<int*>(L.px + (size_t)2 * WPX_PER_PARITY);
-    pk.samples = d_samples; pk.progress = h_progress; pk.seed = seed; pk.R = R; pk.FC = FC; pk.C = C; pk.S = S; pk.N = N;
-    const char* wtrace = getenv("MBHIP_WP_TRACE");  // diagnostics: dump the marks of wavernn_persist.h to this file
-    pk.trace = wtrace ? L.px + (size_t)2 * WPX_PER_PARITY + 32 : nullptr;
+      MB_HIP(hipMemsetAsync(abort_word, 1, 1, s));
+    const char* wtrace = getenv("MBHIP_WP_TRACE");  // diagnostics: dump the wall-clock marks of the kernel to this file
+    unsigned long long* trace = wtrace ? reinterpret_cast<unsigned long long*>(abort_word) + 32 : nullptr;
     MB_HIP(hipEventRecord(w->ev_t0, s));
-    if (N == 1 && !getenv("MBHIP_WP_MFMA")) hipLaunchKernelGGL(wf_persist1_kernel, dim3(WP_ON + WP_OFF), dim3(512), WP1_LDS_BYTES, s, pk);
-    else hipLaunchKernelGGL(wf_persist_kernel, dim3(WP_ON + WP_OFF), dim3(512), WP_LDS_BYTES, s, pk);
+    if (pipe) {
+      WqK qk;
+      qk.w_rnn2 = w->w_rnn2x.p; qk.w_hh2 = w->f_hh2t.p; qk.w_hh1 = w->f_hh1t.p; qk.w_fc1 = w->w_fc1.p; qk.w_fc2 = w->w_fc2.p; qk.w_fc3 = w->w_fc3.p;
+      qk.bhh1q = reinterpret_cast<const float4*>(w->f_bhh1q.p); qk.bhh2q = reinterpret_cast<const float4*>(w->f_bhh2q.p);
+      qk.b_fc3 = w->b_fc3.p; qk.g1 = w->g1I0.p; qk.wI0 = w->wI0.p;
+      qk.T1 = L.T1; qk.Ipre = L.Ipre; qk.G2 = L.G2; qk.F1 = L.F1; qk.F2 = L.F2;
+      qk.g = wg; qk.ex = L.px; qk.abort_word = abort_word;
+      qk.samples = d_samples; qk.progress = h_progress; qk.seed = seed; qk.R = R; qk.FC = FC; qk.C = C; qk.S = S; qk.N = N;
+      qk.gn0[0] = 0; qk.gn0[1] = (N + 1) / 2; qk.gn0[2] = N;  // two groups of ceil / floor (N / 2) columns
+      if (const char* ge = getenv("MBHIP_WQ_GROUPS")) { if (atoi(ge) == 1 && N <= WQ_GC) qk.gn0[1] = N; }  // A/B: one group, no pipelining
+      qk.trace = trace;
+      hipLaunchKernelGGL(wf_pipe_kernel, dim3(WQ_WGS), dim3(512), WQ_LDS_BYTES, s, qk);
+    } else {
+      WpK pk;
+      pk.w_rnn2 = w->w_rnn2x.p; pk.w_fc1 = w->w_fc1.p; pk.w_fc2 = w->w_fc2.p; pk.w_fc3 = w->w_fc3.p; pk.w_hh1 = w->f_hh1t.p; pk.w_hh2 = w->f_hh2t.p;
+      pk.bhh1q = reinterpret_cast<const float4*>(w->f_bhh1q.p); pk.bhh2q = reinterpret_cast<const float4*>(w->f_bhh2q.p);
+      pk.b_fc3 = w->b_fc3.p; pk.g1 = w->g1I0.p; pk.wI0 = w->wI0.p;
+      pk.T1 = L.T1; pk.Ipre = L.Ipre; pk.G2 = L.G2; pk.F1 = L.F1; pk.F2 = L.F2;
+      pk.g = wg; pk.ex = L.px; pk.abort_word = abort_word;
+      pk.samples = d_samples; pk.progress = h_progress; pk.seed = seed; pk.R = R; pk.FC = FC; pk.C = C; pk.S = S; pk.N = N;
+      pk.trace = trace;
+      if (N == 1 && !getenv("MBHIP_WP_MFMA")) hipLaunchKernelGGL(wf_persist1_kernel, dim3(WP_ON + WP_OFF), dim3(512), WP1_LDS_BYTES, s, pk);
+      else hipLaunchKernelGGL(wf_persist_kernel, dim3(WP_ON + WP_OFF), dim3(512), WP_LDS_BYTES, s, pk);
+    }
     MB_HIP(hipGetLastError());
     MB_HIP(hipEventRecord(w->ev_t1, s));
     w->last_launches = 1; w->last_lanes = 1; w->timed = true;
+    // the abort word is the only way a broken hand-off shows: one D2H copy into pinned memory behind the launch, one wait
+    MB_HIP(hipMemcpyAsync(w->h_abort, abort_word, sizeof(int), hipMemcpyDeviceToHost, s));
     MB_HIP(hipEventRecord(w->ev_out, s));
     MB_HIP(hipStreamWaitEvent(cs, w->ev_out, 0));
-    // the abort word is the only way a broken hand-off shows: wait for the launch and look at it
-    int aborted = 0;
-    MB_HIP(hipStreamSynchronize(s));
-    MB_HIP(hipMemcpy(&aborted, pk.abort_word, sizeof(int), hipMemcpyDeviceToHost));
+    MB_HIP(hipEventSynchronize(w->ev_out));
+    const int aborted = *w->h_abort;
     if (wtrace && !aborted) {
-      unsigned long long marks[2 * 4 * 16];
-      MB_HIP(hipMemcpy(marks, pk.trace, sizeof(marks), hipMemcpyDeviceToHost));
+      unsigned long long marks[5 * 4 * 16];
+      MB_HIP(hipMemcpy(marks, trace, sizeof(marks), hipMemcpyDeviceToHost));
       if (FILE* f = fopen(wtrace, "wb")) { fwrite(marks, sizeof(marks), 1, f); fclose(f); }
     }
     if (!aborted) return MB_OK;
-    // A hand-off never arrived within the spin limit: the 192 workgroups were not all resident (something else holds
+    // A hand-off never arrived within the time limit: the workgroups were not all resident (something else holds
     // compute units -- another stream or process) and the launch drained itself.  The chain below computes the same
-    // samples bit for bit without needing co-residency; say so once and use it.
+    // samples bit for bit without needing co-residency; say so once and stop defaulting to resident launches here.
     static bool warned = false;
     if (!warned) {
-      fprintf(stderr, "[mbhip] wavernn: persistent kernel could not keep its workgroups co-resident; using the launch chain\n");
+      fprintf(stderr, "[mbhip] wavernn: resident kernel could not keep its workgroups co-resident; using the launch chain\n");
       warned = true;
     }
-    w->persist_failed = true;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !getenv("MBHIP_WP_TEST_ABORT")) g_resident_failed[dev] = true;
   }
   if (fastk && !rc) {  // zero state; P = W_hh.0 + b_hh for the first step by the loop's own hidden-half jobs
     MB_HIP(hipMemsetAsync(L.f_x1, 0, L.f_bytes, s));

@@ -25,7 +25,7 @@
 // Every exchange buffer is double-buffered by tag parity.  Why that is enough: a granule of tag t is overwritten by
 // tag t+2, and the chain is a cycle -- whoever writes tag t+2 of any buffer has (transitively) consumed a value that
 // needed every reader of tag t of that buffer to have finished (derivation in DESIGN.md section 4d).
-// Every spin has a bail-out: after SPIN_LIMIT polls a workgroup raises the abort word and the launch drains; the host
+// Every spin has a bail-out: after 0.2 s of wall clock a waiting workgroup raises the abort word and the launch drains; the host
 // then runs the launch chain instead (same samples) -- co-residency of the 192 workgroups is not something a launch can
 // demand when other work shares the GPU.
 #pragma once
@@ -36,7 +36,15 @@ namespace mb {
 constexpr int WP_NCOL = 4;        // fold columns supported (LDS budget of the busiest workgroup: 152 KB of 160)
 constexpr int WP_ON = 64;         // on-chain workgroups
 constexpr int WP_OFF = 128;       // off-chain workgroups (one GRU row tile of each hidden half)
-constexpr int WP_SPIN_LIMIT = 1500000;  // polls (about a microsecond each) before a wait is declared lost
+constexpr unsigned long long WP_TIMEOUT_TICKS = 20000000ull;  // 0.2 s of the 100 MHz wall clock before a wait is declared lost
+// every 1024th poll of a spin: start the wall clock at the first check, raise the abort word once the wait is older than
+// WP_TIMEOUT_TICKS; true = the launch is aborting (this or another workgroup gave up), drain
+__device__ __forceinline__ bool wp_lost(const int tries, unsigned long long& t0, int* abort_word) {
+  const unsigned long long now = (unsigned long long)wall_clock64();
+  if (tries == 1023) t0 = now;
+  else if (now - t0 > WP_TIMEOUT_TICKS) atomicExch(abort_word, 1);
+  return __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
 
 // exchange area, in granules, per parity
 enum { WPX_X2 = 0, WPX_H2 = 8192, WPX_H1 = 16384, WPX_Y1 = 24576, WPX_Y2 = 32768, WPX_P1 = 40960, WPX_P2 = 65536,
@@ -67,6 +75,7 @@ __device__ __forceinline__ unsigned long long wp_get(const unsigned long long* p
 template <int NQ>
 __device__ __forceinline__ bool wp_wait(const unsigned long long* p, const size_t stride, const unsigned tag, unsigned (&out)[NQ], int* abort_word) {
   unsigned long long v[NQ];
+  unsigned long long t0 = 0;
   for (int tries = 0;; ++tries) {
     bool ok = true;
 #pragma unroll
@@ -74,10 +83,7 @@ __device__ __forceinline__ bool wp_wait(const unsigned long long* p, const size_
 #pragma unroll
     for (int q = 0; q < NQ; ++q) ok = ok && (unsigned)(v[q] >> 32) == tag;
     if (ok) break;
-    if ((tries & 1023) == 1023) {
-      if (tries >= WP_SPIN_LIMIT) atomicExch(abort_word, 1);
-      if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
-    }
+    if ((tries & 1023) == 1023 && wp_lost(tries, t0, abort_word)) return false;
     __builtin_amdgcn_s_sleep(1);
   }
 #pragma unroll
@@ -111,11 +117,9 @@ __device__ __forceinline__ bool wp_watch(const unsigned long long* p, const unsi
   // (one lane per PRODUCER -- 32 to 64 watching lanes, so that the sweep never starts before the slowest producer --
   //  measured slower, 13.6 vs 11.9 us per step: what counts is how few requests sit in this unit's memory queue)
   if (threadIdx.x == 0) {
+    unsigned long long t0 = 0;
     for (int tries = 0; (unsigned)(wp_get(p) >> 32) != tag; ++tries) {
-      if ((tries & 1023) == 1023) {
-        if (tries >= WP_SPIN_LIMIT) atomicExch(abort_word, 1);
-        if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-      }
+      if ((tries & 1023) == 1023 && wp_lost(tries, t0, abort_word)) break;
       __builtin_amdgcn_s_sleep(SLEEP);
     }
   }
@@ -134,6 +138,7 @@ __device__ __forceinline__ bool wp_gather(const unsigned long long* vec, const u
   // granule of (feature k, column n) at k * N + n; this lane: k = (wave + 8 p) * 16 + kq * 4 + c
   const unsigned long long* base = vec + ((size_t)(wave * 16 + kq * 4) * N + i);
   unsigned long long v[16];
+  unsigned long long t0 = 0;
   for (int tries = 0;; ++tries) {
     bool ok = true;
 #pragma unroll
@@ -143,10 +148,7 @@ __device__ __forceinline__ bool wp_gather(const unsigned long long* vec, const u
 #pragma unroll
     for (int q = 0; q < 16; ++q) ok = ok && (unsigned)(v[q] >> 32) == tag;
     if (ok) break;
-    if ((tries & 1023) == 1023) {
-      if (tries >= WP_SPIN_LIMIT) atomicExch(abort_word, 1);
-      if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
-    }
+    if ((tries & 1023) == 1023 && wp_lost(tries, t0, abort_word)) return false;
     __builtin_amdgcn_s_sleep(1);
   }
 #pragma unroll
@@ -527,13 +529,11 @@ __device__ __forceinline__ bool wp_fetch1(const unsigned long long* vec, const u
   wp_watch<SLEEP>(vec + 511, tag, abort_word);
   const unsigned long long* p = vec + threadIdx.x;
   unsigned long long v;
+  unsigned long long t0 = 0;
   for (int tries = 0;; ++tries) {
     v = wp_get(p);
     if ((unsigned)(v >> 32) == tag) break;
-    if ((tries & 1023) == 1023) {
-      if (tries >= WP_SPIN_LIMIT) atomicExch(abort_word, 1);
-      if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
-    }
+    if ((tries & 1023) == 1023 && wp_lost(tries, t0, abort_word)) return false;
     __builtin_amdgcn_s_sleep(1);
   }
   xs[wp_xperm(threadIdx.x)] = __uint_as_float((unsigned)v);

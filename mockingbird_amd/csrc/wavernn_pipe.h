@@ -1,0 +1,300 @@
+// WaveRNN sample loop for 2..32 fold columns (BASELINE configs[1]: 23 folds) as ONE persistent launch: the layers of the
+// step are ROLES of resident workgroups with their weight tiles in LDS, and the folds -- independent sequences -- are cut
+// into two column GROUPS that travel through the roles half a period apart, so that the hand-off latency of one group is
+// covered by the arithmetic of the other.  (The 5-launch chain of wavernn_fast.h pays a kernel boundary + ramp per layer,
+// 4.3 us x 5; two streams do not overlap on this chip, profiles/r01_wavernn_lane_sweep.json.  wavernn_persist.h is the
+// few-column ancestor: every on-chain workgroup there recomputes the whole rnn1 finish and fetches all of P1 per column,
+// which is what stops it at 4 columns.)
+//
+//   role  workgroups  LDS weights                                   per (step, group)
+//   R1    64          W_hh1 GRU tiles 2b, 2b+1 (8 units)            keys(s-1) -> x | rnn1 finish for its 8 units (P1, h1, table rows
+//                                                                   are lane-private) -> publishes x1, h1 | gathers h1, P1(s+1) = W_hh1.h1 + b
+//   R2    64          W_ih2[x] and W_hh2 tiles 2b, 2b+1             gathers x1 | GRU on its 8 units (P2 lane-private) -> publishes x2, h2
+//                                                                   | gathers h2, P2(s+1) = W_hh2.h2 + b
+//   F1    32          fc1 tile                                      gathers x2 -> relu(fc1 . x2 + F1[frame]) -> publishes y1
+//   F2    32          fc2 tile                                      gathers y1 -> publishes y2
+//   F3    32          fc3 tile                                      gathers y2 -> logits + Gumbel-argmax over its 16 classes -> publishes keys
+// (fatchord_version.py:190-228; split-hidden algebra of wavernn.hip's header).  Hidden halves never travel: the
+// workgroup that owns a unit's W_hh rows also owns its state, its gate pre-activations and its elementwise update.
+//
+// Hand-offs are the 8-byte {value, step tag} granules of wavernn_persist.h (one relaxed agent-scope store / load each,
+// the tag is the flag), dense [feature][column of the group], double-buffered by tag parity per group.  Why two
+// parities suffice (tag t is overwritten by tag t+2): whoever writes tag t+2 of a vector has consumed keys(t+1), which
+// needed every tile of y2(t+1) <- y1(t+1) <- x2(t+1) <- x1(t+1), i.e. every workgroup of every role has finished step
+// t+1 and with it its reads of tag t (h1 / h2: P(t+1) is needed by the owner's own step t+1, so its gather of h(t) is
+// over as well).  Every workgroup walks the (step, group) items in the same order and an item only depends on earlier
+// items or on the same item at an earlier role: no cycle, no deadlock as long as the 224 workgroups are resident
+// (checked on the host; every spin still has a wall-clock bail-out -> abort word -> the launch chain runs instead).
+//
+// Arithmetic: per tile the MFMA sequence and the wave-order reduction of fm_gemm<1, 4, 4, RL, 1>, epilogue expressions of
+// wavernn_fast.h, the same Philox words: the sample stream is bit-identical to the chain's (tests/test_env_switches_gpu.py,
+// and against the oracle in tests/test_wavernn_gpu.py).
+#pragma once
+#include "wavernn_persist.h"
+
+namespace mb {
+
+constexpr int WQ_R1 = 64, WQ_R2 = 64, WQ_F = 32;
+constexpr int WQ_WGS = WQ_R1 + WQ_R2 + 3 * WQ_F;  // 224 resident workgroups, one per compute unit
+constexpr int WQ_G = 2;                           // column groups in flight
+constexpr int WQ_GC = 16;                         // columns per group (one MFMA column tile)
+constexpr int WQ_DEFAULT_ON = 0;                  // default for 2..32 columns (MBHIP_WAVERNN_PIPE overrides)
+
+// exchange area per (group, parity), in granules
+enum { WQX_X1 = 0, WQX_X2 = 8192, WQX_H1 = 16384, WQX_H2 = 24576, WQX_Y1 = 32768, WQX_Y2 = 40960, WQX_KEY = 49152, WQX_PER = 50176 };
+inline size_t wq_exchange_bytes() { return (size_t)WQ_G * 2 * WQX_PER * 8 + 256 + 8192; }  // + abort word + diagnostics marks
+
+struct WqK {
+  const float* w_rnn2; const float* w_hh2; const float* w_hh1; const float* w_fc1; const float* w_fc2; const float* w_fc3;
+  const float4* bhh1q; const float4* bhh2q; const float* b_fc3; const float* g1; const float* wI0;
+  const float* T1; const float* Ipre; const float* G2; const float* F1; const float* F2;
+  WfGeom g;
+  unsigned long long* ex; int* abort_word;
+  float* samples; volatile int* progress;
+  unsigned long long seed; int R, FC, C, S, N;
+  int gn0[WQ_G + 1];          // group g owns fold columns [gn0[g], gn0[g + 1])
+  unsigned long long* trace;  // diagnostics (MBHIP_WP_TRACE): wall-clock marks of one workgroup per role, steps 1000..1003
+};
+
+// dynamic LDS (floats): [weights: up to 4 GRU tiles] [red: two 4096-float buffers, alternating] [keys / samples]
+constexpr int WQ_LDS_W = 4 * 6144, WQ_LDS_RED = 2 * 4096;
+constexpr size_t WQ_LDS_BYTES = (size_t)(WQ_LDS_W + WQ_LDS_RED) * 4 + 2 * WQ_GC * 8 + 64;
+
+__global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* lw = lds;
+  float* red = lds + WQ_LDS_W;
+  unsigned long long* s_key = reinterpret_cast<unsigned long long*>(red + WQ_LDS_RED);  // [GC] max key of the step
+  float* s_x = reinterpret_cast<float*>(s_key + WQ_GC);                                 // [GC] decoded sample
+  if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // (tests: the fallback path)
+  const int blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int du = lane >> 4, i = lane & 15;
+  const int H = a.R, S = a.S;
+  const int n_t3 = a.C / 16;
+  int rb = 0;  // red buffer of the next GEMM
+  auto EX = [&](int what, int g, unsigned tag) { return a.ex + ((size_t)g * 2 + (tag & 1)) * WQX_PER + what; };
+#define WQ_MARK(role, k)                                                                                   \
+  do {                                                                                                     \
+    if (a.trace && tid == 0 && mark_wg && g == 0 && s >= 1000 && s < 1004)                                 \
+      a.trace[((role) * 4 + (s - 1000)) * 16 + (k)] = (unsigned long long)wall_clock64();                  \
+  } while (0)
+
+  if (blk < WQ_R1) {
+    // ---------------------------------------------------------------------------------------------- R1: rnn1
+    const bool mark_wg = blk == 0;
+    wp_copy_tile(lw, a.w_hh1 + (size_t)(2 * blk) * 6144, 12288);
+    if (tid < WQ_GC) { s_key[tid] = 0ull; s_x[tid] = 0.f; }
+    const int ju = (2 * blk + (wave & 1)) * 4 + du;  // unit of an epilogue lane (waves 0 / 1)
+    const float4 bq = a.bhh1q[ju];
+    const float gr = a.g1[ju], gz = a.g1[H + ju], gn = a.g1[2 * H + ju], w0 = a.wI0[ju];
+    float h1[WQ_G], P1[WQ_G][3], tq[WQ_G][4];
+#pragma unroll
+    for (int g = 0; g < WQ_G; ++g) {
+      h1[g] = 0.f; P1[g][0] = bq.x; P1[g][1] = bq.y; P1[g][2] = bq.z;  // W_hh . 0 + b_hh
+      const int Ng = a.gn0[g + 1] - a.gn0[g];
+      const int ncl = a.gn0[g] + (i < Ng ? i : (Ng > 0 ? Ng - 1 : 0));
+      const unsigned pos = wf_pos(a.g, ncl, 0);
+      const float* t1 = a.T1 + (size_t)pos * 3 * H + ju;
+      tq[g][0] = t1[0]; tq[g][1] = t1[H]; tq[g][2] = t1[2 * H]; tq[g][3] = a.Ipre[(size_t)pos * H + ju];
+    }
+    __syncthreads();
+    for (int s = 0; s <= S; ++s) {
+      const unsigned tag_prev = (unsigned)s, tag = (unsigned)s + 1;
+#pragma unroll
+      for (int g = 0; g < WQ_G; ++g) {
+        const int n0 = a.gn0[g], Ng = a.gn0[g + 1] - n0;
+        if (Ng <= 0) continue;
+        WQ_MARK(0, 0);
+        // ---- keys of step s-1 -> sample x of every column of the group ----
+        if (s > 0) {
+          const unsigned long long* K = EX(WQX_KEY, g, tag_prev);
+          wp_watch<1>(K + (size_t)((n_t3 - 1) * 2 + 1) * Ng + (Ng - 1), tag_prev, a.abort_word);
+          if (tid < 32 * Ng && (tid & 31) < n_t3) {
+            const int tile = tid & 31, n = tid >> 5;
+            unsigned kv[2];
+            if (!wp_wait<2>(K + (size_t)tile * 2 * Ng + n, Ng, tag_prev, kv, a.abort_word)) return;
+            atomicMax(&s_key[n], ((unsigned long long)kv[0] << 32) | (unsigned long long)kv[1]);
+          }
+          __syncthreads();
+          WQ_MARK(0, 1);
+          if (tid < Ng) {
+            const unsigned long long slot = s_key[tid];
+            const float x = slot ? 2.f * (float)argmax_class(slot) / ((float)a.C - 1.f) - 1.f : 0.f;
+            s_x[tid] = x;
+            s_key[tid] = 0ull;
+            if (blk == 0) {
+              a.samples[(size_t)(n0 + tid) * S + (s - 1)] = x;
+              if (a.progress && n0 + tid == 0 && (s - 1) % 100 == 0) *a.progress = s;
+            }
+          }
+          __syncthreads();
+        }
+        if (s == S) continue;
+        // ---- rnn1 finish for (unit ju, column i): wf_finish_kernel's expressions ----
+        if (wave < 2 && i < Ng) {
+          const float x = s_x[i];
+          const float rg = sigmoidf_((tq[g][0] + x * gr) + P1[g][0]);
+          const float zg = sigmoidf_((tq[g][1] + x * gz) + P1[g][1]);
+          const float ng = tanhf((tq[g][2] + x * gn) + rg * P1[g][2]);
+          const float hy = ng + zg * (h1[g] - ng);
+          h1[g] = hy;
+          wp_put(EX(WQX_X1, g, tag) + (size_t)ju * Ng + i, (tq[g][3] + x * w0) + hy, tag);
+          wp_put(EX(WQX_H1, g, tag) + (size_t)ju * Ng + i, hy, tag);
+        }
+        WQ_MARK(0, 2);
+        if (s + 1 >= S) continue;
+        // ---- next step's table rows (a whole step to arrive) ----
+        if (wave < 2) {
+          const unsigned pos = wf_pos(a.g, n0 + (i < Ng ? i : Ng - 1), s + 1);
+          const float* t1 = a.T1 + (size_t)pos * 3 * H + ju;
+          tq[g][0] = t1[0]; tq[g][1] = t1[H]; tq[g][2] = t1[2 * H]; tq[g][3] = a.Ipre[(size_t)pos * H + ju];
+        }
+        // ---- hidden half of the next step: P1 = W_hh1 . h1 + b_hh1, kept by the lane that will use it ----
+        float4 b[4];
+        if (!wp_gather<2>(EX(WQX_H1, g, tag), tag, Ng, b, a.abort_word)) return;
+        WQ_MARK(0, 3);
+        float sx[4];
+        const bool epi = wp_gemm2<3>(lw, 6144, b, red + rb * 4096, sx);
+        rb ^= 1;
+        if (epi) { P1[g][0] = sx[0] + bq.x; P1[g][1] = sx[1] + bq.y; P1[g][2] = sx[2] + bq.z; }
+        WQ_MARK(0, 4);
+      }
+    }
+    return;
+  }
+
+  if (blk < WQ_R1 + WQ_R2) {
+    // ---------------------------------------------------------------------------------------------- R2: rnn2
+    const int b2 = blk - WQ_R1;
+    const bool mark_wg = b2 == 0;
+    wp_copy_tile(lw, a.w_rnn2 + (size_t)(2 * b2) * 6144, 12288);
+    wp_copy_tile(lw + 12288, a.w_hh2 + (size_t)(2 * b2) * 6144, 12288);
+    const int ju = (2 * b2 + (wave & 1)) * 4 + du;
+    const float4 bq = a.bhh2q[ju];
+    float h2[WQ_G], P2[WQ_G][3], g2v[WQ_G][3];
+    int g2_row[WQ_G];
+#pragma unroll
+    for (int g = 0; g < WQ_G; ++g) { h2[g] = 0.f; P2[g][0] = bq.x; P2[g][1] = bq.y; P2[g][2] = bq.z; g2_row[g] = -1; g2v[g][0] = g2v[g][1] = g2v[g][2] = 0.f; }
+    __syncthreads();
+    for (int s = 0; s < S; ++s) {
+      const unsigned tag = (unsigned)s + 1;
+#pragma unroll
+      for (int g = 0; g < WQ_G; ++g) {
+        const int n0 = a.gn0[g], Ng = a.gn0[g + 1] - n0;
+        if (Ng <= 0) continue;
+        const int frow = wf_frame_row(a.g, n0 + (i < Ng ? i : Ng - 1), s);
+        if (wave < 2 && frow != g2_row[g]) {  // the per-frame rows change once per hop: kept in registers in between
+          const float* gp = a.G2 + (size_t)frow * 3 * H + ju;
+          g2v[g][0] = gp[0]; g2v[g][1] = gp[H]; g2v[g][2] = gp[2 * H];
+          g2_row[g] = frow;
+        }
+        WQ_MARK(1, 0);
+        float4 b[4];
+        if (!wp_gather<1>(EX(WQX_X1, g, tag), tag, Ng, b, a.abort_word)) return;
+        WQ_MARK(1, 1);
+        float sx[4];
+        const bool epi = wp_gemm2<3>(lw, 6144, b, red + rb * 4096, sx);
+        rb ^= 1;
+        if (epi && i < Ng) {
+          unsigned xu[1];
+          if (!wp_wait<1>(EX(WQX_X1, g, tag) + (size_t)ju * Ng + i, 1, tag, xu, a.abort_word)) return;
+          const float xr = __uint_as_float(xu[0]);
+          const float rg = sigmoidf_((sx[0] + g2v[g][0]) + P2[g][0]);
+          const float zg = sigmoidf_((sx[1] + g2v[g][1]) + P2[g][1]);
+          const float ng = tanhf((sx[2] + g2v[g][2]) + rg * P2[g][2]);
+          const float hy = ng + zg * (h2[g] - ng);
+          h2[g] = hy;
+          wp_put(EX(WQX_X2, g, tag) + (size_t)ju * Ng + i, xr + hy, tag);
+          wp_put(EX(WQX_H2, g, tag) + (size_t)ju * Ng + i, hy, tag);
+        }
+        WQ_MARK(1, 2);
+        if (s + 1 >= S) continue;
+        if (!wp_gather<2>(EX(WQX_H2, g, tag), tag, Ng, b, a.abort_word)) return;
+        WQ_MARK(1, 3);
+        const bool epi2 = wp_gemm2<3>(lw + 12288, 6144, b, red + rb * 4096, sx);
+        rb ^= 1;
+        if (epi2) { P2[g][0] = sx[0] + bq.x; P2[g][1] = sx[1] + bq.y; P2[g][2] = sx[2] + bq.z; }
+        WQ_MARK(1, 4);
+      }
+    }
+    return;
+  }
+
+  // ------------------------------------------------------------------------------------------------ F1 / F2 / F3
+  const int fr = (blk - WQ_R1 - WQ_R2) / WQ_F, ft = (blk - WQ_R1 - WQ_R2) % WQ_F;  // role 0 / 1 / 2, row tile
+  const bool mark_wg = ft == 0;
+  if (fr == 2 && ft >= n_t3) return;
+  wp_copy_tile(lw, (fr == 0 ? a.w_fc1 : fr == 1 ? a.w_fc2 : a.w_fc3) + (size_t)ft * 8192, 8192);
+  const float4 b3q = fr == 2 ? *reinterpret_cast<const float4*>(a.b_fc3 + ft * 16 + du * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 fpre[WQ_G];
+  int f_row[WQ_G];
+#pragma unroll
+  for (int g = 0; g < WQ_G; ++g) { fpre[g] = make_float4(0.f, 0.f, 0.f, 0.f); f_row[g] = -1; }
+  const int src = fr == 0 ? WQX_X2 : fr == 1 ? WQX_Y1 : WQX_Y2;
+  __syncthreads();
+  for (int s = 0; s < S; ++s) {
+    const unsigned tag = (unsigned)s + 1;
+#pragma unroll
+    for (int g = 0; g < WQ_G; ++g) {
+      const int n0 = a.gn0[g], Ng = a.gn0[g + 1] - n0;
+      if (Ng <= 0) continue;
+      const int ncl = n0 + (i < Ng ? i : Ng - 1);
+      float lgn[4] = {0.f, 0.f, 0.f, 0.f};
+      if (fr < 2) {
+        const int frow = wf_frame_row(a.g, ncl, s);
+        if (wave == 0 && frow != f_row[g]) {
+          fpre[g] = *reinterpret_cast<const float4*>((fr == 0 ? a.F1 : a.F2) + (size_t)frow * a.FC + ft * 16 + du * 4);
+          f_row[g] = frow;
+        }
+      } else if (wave == 0) {  // the step's Gumbel noise does not depend on the data: drawn before the wait
+        uint32_t grn[4];
+        philox4x32((uint32_t)s, (uint32_t)ncl, (uint32_t)((ft * 16 + du * 4) >> 2), 0x57415645u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), grn);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lgn[r] = logf(-logf(u32_to_unit(grn[r])));
+      }
+      WQ_MARK(2 + fr, 0);
+      float4 b[4];
+      if (!wp_gather<1>(EX(src, g, tag), tag, Ng, b, a.abort_word)) return;
+      WQ_MARK(2 + fr, 1);
+      float sx[4];
+      const bool epi = wp_gemm<4>(lw, b, red + rb * 4096, sx);
+      rb ^= 1;
+      if (!epi) continue;
+      if (fr < 2) {
+        if (i < Ng) {
+          unsigned long long* Y = EX(fr == 0 ? WQX_Y1 : WQX_Y2, g, tag) + (size_t)(ft * 16 + du * 4) * Ng + i;
+          wp_put(Y, fmaxf(sx[0] + fpre[g].x, 0.f), tag);
+          wp_put(Y + Ng, fmaxf(sx[1] + fpre[g].y, 0.f), tag);
+          wp_put(Y + 2 * Ng, fmaxf(sx[2] + fpre[g].z, 0.f), tag);
+          wp_put(Y + 3 * Ng, fmaxf(sx[3] + fpre[g].w, 0.f), tag);
+        }
+      } else {  // wf_fc3_kernel's sampler; lanes of dead columns take part in the shuffles only
+        const float bv[4] = {b3q.x, b3q.y, b3q.z, b3q.w};
+        float best = -INFINITY;
+        int bcls = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = ft * 16 + du * 4 + r;
+          const float v = sx[r] + bv[r];
+          const float gmb = v - lgn[r];
+          if (gmb > best) { best = gmb; bcls = row; }
+        }
+        unsigned long long pk = pack_argmax(best, bcls);
+        const unsigned long long o1 = __shfl_xor(pk, 16, 64);
+        pk = o1 > pk ? o1 : pk;
+        const unsigned long long o2 = __shfl_xor(pk, 32, 64);
+        pk = o2 > pk ? o2 : pk;
+        if (du == 0 && i < Ng) {
+          unsigned long long* K = EX(WQX_KEY, g, tag) + (size_t)ft * 2 * Ng + i;
+          wp_put_u(K, (unsigned)(pk >> 32), tag);
+          wp_put_u(K + Ng, (unsigned)pk, tag);
+        }
+      }
+      WQ_MARK(2 + fr, 2);
+    }
+  }
+#undef WQ_MARK
+}
+
+}  // namespace mb

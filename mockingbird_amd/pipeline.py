@@ -12,6 +12,7 @@ package and soundfile and stay on the reference's CPU path (north_star).
 Sharding: requests are dealt to ranks by sharding.shard_indices (length-sorted
 round robin), each rank runs ITS requests through both models on its GPU, and the finished waveforms are
 gathered once to rank 0 (sharding.gather_waveforms).  There is no collective inside a request."""
+import inspect
 from typing import List, Sequence, Tuple
 
 import numpy as np
@@ -46,8 +47,9 @@ def gen_wavs(synthesizer, vocoder, requests: List[Tuple[List[str], np.ndarray]],
     do not move the peak, so only a trim that removed the loudest sample would change the normalised result.
 
     synthesizer: object with synthesize_spectrograms / hparams.hop_size / sample_rate (the Synthesizer facade);
-    vocoder: module or object with infer_waveform_batch(mels, normalize=, pcm16=, breaks=, break_hop=, device_out=)
-    -> (wavs, sample_rate) (hifigan / fregan facade)."""
+    vocoder: module or object with infer_waveform_batch(mels, normalize= | peak_normalize=, pcm16=, breaks=, break_hop=,
+    break_sample_rate=, device_out=) -> (wavs, sample_rate): the hifigan / fregan facades (`normalize` = peak
+    normalisation) or the wavernn facade (`peak_normalize`; its `normalize` keeps meaning the mel scaling)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     lengths = [sum(len(t) for t in texts) for texts, _ in requests]
@@ -64,9 +66,16 @@ def gen_wavs(synthesizer, vocoder, requests: List[Tuple[List[str], np.ndarray]],
                                                     min_stop_token=min_stop_token, steps=steps)
         per_req = {i: [s for s, o in zip(specs, owner) if o == i] for i in mine}
         mels = [np.concatenate(per_req[i], axis=1) for i in mine]
-        local, _sr = vocoder.infer_waveform_batch(mels, normalize=normalize, pcm16=pcm16,
-                                                  breaks=[[s.shape[1] for s in per_req[i]] for i in mine],
-                                                  break_hop=synthesizer.hparams.hop_size, device_out=True)
+        kw = dict(pcm16=pcm16, breaks=[[s.shape[1] for s in per_req[i]] for i in mine],
+                  break_hop=synthesizer.hparams.hop_size, device_out=True)
+        params = inspect.signature(vocoder.infer_waveform_batch).parameters
+        if "break_sample_rate" in params:  # gen_voice.py:33: the gap is 0.15 s at the SYNTHESIZER's sample rate
+            kw["break_sample_rate"] = synthesizer.sample_rate
+        if "peak_normalize" in params:  # WaveRNN facade: its `normalize` is infer_waveform's mel scaling (inference.py:60-61)
+            kw["peak_normalize"] = normalize
+        else:
+            kw["normalize"] = normalize
+        local, _sr = vocoder.infer_waveform_batch(mels, **kw)
     gathered = sharding.gather_waveforms(local, group=group, dst=dst)
     if dst is not None and rank != dst:
         return []

@@ -163,13 +163,16 @@ class GanFacade:
         return audio, self.output_sample_rate
 
     def infer_waveform_batch(self, mels, progress_callback=None, normalize=None, pcm16=None, breaks=None,
-                             break_hop=None, break_seconds=0.15, device_out=False):
+                             break_hop=None, break_seconds=0.15, device_out=False, break_sample_rate=None):
         """Additive API: a list of (80, Fi) mels of any lengths -> list of waveforms, run as ragged
         batches (GanGenerator.forward_ragged: per-item lengths inside the kernels, each item equals its own run).
 
         The reference's host-side tail can run on the device, in gen_voice.py's order, before anything leaves HBM:
           breaks[i] = frames per sentence of item i -> cut at the sentence boundaries (frames * break_hop samples,
-                      gen_voice.py:30-32) and put break_seconds of silence after every sentence (:33-34);
+                      gen_voice.py:30-32) and put break_seconds of silence after every sentence (:33-34); the gap is
+                      int(break_seconds * break_sample_rate) samples -- gen_voice.py:33 uses the SYNTHESIZER's
+                      sample rate, which differs from this vocoder's for the 24 kHz generator (default: this
+                      vocoder's output rate);
           normalize = 0.97 -> wav / abs(wav).max() * 0.97 (gen_voice.py:41);
           pcm16 = 'sndfile' | 'encode_16bits' | 'save_wav' -> int16 PCM (run.py:91).
         device_out=True returns the device tensors themselves (for a device-to-device gather) instead of numpy."""
@@ -185,7 +188,7 @@ class GanFacade:
             for k, i in enumerate(idx):
                 r = ys[k].reshape(-1)
                 if breaks is not None:
-                    r = wave.insert_breaks(r, breaks[i], break_hop, self.output_sample_rate, break_seconds)
+                    r = wave.insert_breaks(r, breaks[i], break_hop, break_sample_rate or self.output_sample_rate, break_seconds)
                 if normalize is not None:
                     r = r.contiguous()
                     wave.peak_normalize_(r, normalize)

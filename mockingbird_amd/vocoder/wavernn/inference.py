@@ -269,10 +269,35 @@ def infer_waveform(mel, normalize=True, batched=True, target=8000, overlap=800, 
     return wav, hp.sample_rate
 
 
-def infer_waveform_batch(mels, normalize=True, target=8000, overlap=800, seeds=None):
+def infer_waveform_batch(mels, normalize=True, target=8000, overlap=800, seeds=None, *, peak_normalize=None, pcm16=None,
+                         breaks=None, break_hop=None, break_seconds=0.15, break_sample_rate=None, device_out=False):
     """Additive API: a list of (80, F_u) numpy mels -> (list of float64 waveforms, sample
-    rate), all utterances sharing ONE batched sample loop."""
+    rate), all utterances sharing ONE batched sample loop.  `normalize` is infer_waveform's mel scaling
+    (inference.py:60-61).  The keyword-only tail is the one of the GAN facades' infer_waveform_batch, so that
+    pipeline.gen_wavs drives any vocoder: gen_voice.py's host-side tail on the device, in its order --
+      breaks[i] = frames per sentence of item i, cut at frames * break_hop samples + break_seconds of silence
+                  (gen_voice.py:30-34; gap length from break_sample_rate, default this vocoder's rate);
+      peak_normalize = 0.97 -> wav / abs(wav).max() * 0.97 (gen_voice.py:41);
+      pcm16 = 'encode_16bits' | 'save_wav' | 'sndfile' -> int16 PCM;
+      device_out=True keeps the results in HBM (device-to-device gather)."""
     if _model is None:
         raise Exception("Please load Wave-RNN in memory before using it")
     ms = [torch.from_numpy(np.asarray(m, np.float32) / (hp.mel_max_abs_value if normalize else 1.0)) for m in mels]
-    return _model.generate_batch(ms, target, overlap, hp.mu_law, seeds), hp.sample_rate
+    plain = peak_normalize is None and pcm16 is None and breaks is None and not device_out
+    if plain:
+        return _model.generate_batch(ms, target, overlap, hp.mu_law, seeds), hp.sample_rate
+    from .. import wave
+    mu_law = hp.mu_law if _model.cfg.mode == 0 else False  # fatchord_version.py:154
+    outs = _model.generate_samples_batch([m.cuda() for m in ms], target, overlap, seeds)
+    res = []
+    for i, (smp, m) in enumerate(zip(outs, ms)):
+        r = _model.finish(smp, True, overlap, mu_law, (m.shape[-1] - 1) * _model.hop_length, device_out=True)
+        if breaks is not None:
+            r = wave.insert_breaks(r, breaks[i], break_hop, break_sample_rate or hp.sample_rate, break_seconds)
+        if peak_normalize is not None:
+            r = r.contiguous()
+            wave.peak_normalize_(r, peak_normalize)
+        if pcm16 is not None:
+            r = wave.pack_pcm16(r, pcm16)
+        res.append(r if device_out else r.cpu().numpy())
+    return res, hp.sample_rate

@@ -132,7 +132,7 @@ def taco_config(state: Dict[str, torch.Tensor], r: int = None, max_r: int = 20, 
     """Shapes are read from the checkpoint (config must come from the loaded
     objects, not be hard-coded)."""
     c = _lib.TacoConfig()
-    c.dropout = float(dropout)  # hparams.tts_dropout: PreNet dropout stays on at inference (pre_net.py:23,26)
+    c.dropout = float(dropout) if dropout and dropout > 0 else -1.0  # hparams.tts_dropout: PreNet dropout stays on at inference (pre_net.py:23,26); ABI: 0 = default 0.5, < 0 = off
     fc1 = state["decoder.prenet.fc1.weight"]
     c.n_mels = fc1.shape[1]
     c.decoder_dims = fc1.shape[0] // 2

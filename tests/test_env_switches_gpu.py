@@ -125,5 +125,35 @@ def test_wavernn_persistent_kernel_falls_back_to_the_chain(cuda, lib, monkeypatc
     alt = dev.generate_samples(mel, False, 0, 0, seed=4)
     assert dev.last_loop_launches > 1 and torch.equal(base, alt)
     monkeypatch.delenv("MBHIP_WP_TEST_ABORT")
-    again = dev.generate_samples(mel, False, 0, 0, seed=4)
-    assert dev.last_loop_launches > 1 and torch.equal(base, again)  # persist_failed sticks for this handle
+    again = dev.generate_samples(mel, False, 0, 0, seed=4)  # (the test switch does not mark the device as failed)
+    assert dev.last_loop_launches == 1 and torch.equal(base, again)
+    # the pipelined resident kernel (wavernn_pipe.h) takes the same way out
+    mel3 = torch.from_numpy(synth.wavernn_mel(40, seed=13) / 4.0).cuda()
+    monkeypatch.setenv("MBHIP_WAVERNN_PIPE", "0")
+    base3 = dev.generate_samples(mel3, True, 3000, 100, seed=4)
+    monkeypatch.setenv("MBHIP_WAVERNN_PIPE", "1")
+    monkeypatch.setenv("MBHIP_WP_TEST_ABORT", "1")
+    alt3 = dev.generate_samples(mel3, True, 3000, 100, seed=4)
+    assert dev.last_loop_launches > 1 and torch.equal(base3, alt3)
+
+
+@pytest.mark.parametrize("frames,target,overlap,folds,groups", [(40, 4000, 200, 2, 2), (40, 3000, 100, 3, 2), (330, 4000, 400, 18, 2),
+                                                                (1000, 8000, 800, 23, 2), (330, 2000, 100, 32, 2), (40, 3000, 100, 3, 1),
+                                                                (200, 3000, 300, 12, 1)],
+                         ids=["2-folds", "3-folds", "18-folds", "23-folds", "32-folds", "3-folds-1-group", "12-folds-1-group"])
+def test_wavernn_pipe_kernel_keeps_the_sample_stream(wavernn, monkeypatch, frames, target, overlap, folds, groups):
+    """wavernn_pipe.h: ONE launch of role-specialised resident workgroups, two fold-column groups in flight (one with
+    MBHIP_WQ_GROUPS=1) -- against the 5-launch chain: the same samples, sample for sample, from 2 to 32 columns
+    (BASELINE configs[1] = 23)."""
+    mel = torch.from_numpy(synth.wavernn_mel(frames, seed=17) / 4.0).cuda()
+    monkeypatch.setenv("MBHIP_WAVERNN_PIPE", "0")
+    monkeypatch.setenv("MBHIP_WAVERNN_PERSIST", "0")
+    base = wavernn.generate_samples(mel, True, target, overlap, seed=31)
+    assert base.shape[0] == folds and wavernn.last_loop_launches == 5 * base.shape[1]
+    monkeypatch.setenv("MBHIP_WAVERNN_PIPE", "1")
+    if groups == 1:
+        monkeypatch.setenv("MBHIP_WQ_GROUPS", "1")
+    alt = wavernn.generate_samples(mel, True, target, overlap, seed=31)
+    assert wavernn.last_loop_launches == 1, "the resident kernel did not run"
+    bad = (base != alt)
+    assert torch.equal(base, alt), (int(bad.sum()), int(bad.any(0).nonzero()[0]) if bad.any() else -1, bad.any(1).nonzero().flatten().tolist())

@@ -248,8 +248,8 @@ def test_infer_waveform_batch_ragged_facade(cuda, lib, tmp_path):
     for m, f, wv in zip(mels, frames, wavs):
         single, _ = voc.infer_waveform(m)
         assert wv.shape == (f * 200,) and wv.dtype == np.float32 and np.array_equal(wv, single)
-    pcm, _ = voc.infer_waveform_batch(mels, normalize=0.97, pcm16="sndfile", breaks=[[f] for f in frames], break_hop=256)
+    pcm, _ = voc.infer_waveform_batch(mels, normalize=0.97, pcm16="encode_16bits", breaks=[[f] for f in frames], break_hop=256)
     from oracle import wave as owv
     for wv, pc in zip(wavs, pcm):
-        ref = owv.sndfile_pcm16(owv.peak_normalize(np.concatenate([wv, np.zeros(2400, np.float32)]), np.float32(0.97)))
+        ref = owv.encode_16bits(owv.peak_normalize(np.concatenate([wv, np.zeros(2400, np.float32)]), np.float32(0.97)))
         assert pc.dtype == np.int16 and np.array_equal(pc, ref)

@@ -55,10 +55,39 @@ def test_gen_wavs_single_rank(cuda, lib, tmp_path):
     # numpy tail applied to the float waveforms above (normalise per request before the zero gaps, then PCM_16)
     from oracle import wave as owv
     torch.manual_seed(5)
-    pcm = pipeline.gen_wavs(syn, voc, requests, steps=24, min_stop_token=11, normalize=0.97, pcm16="sndfile")
+    pcm = pipeline.gen_wavs(syn, voc, requests, steps=24, min_stop_token=11, normalize=0.97, pcm16="save_wav")
     for p, w in zip(pcm, wavs):
         assert p.dtype == np.int16 and p.shape == w.shape
-        assert np.array_equal(p, owv.sndfile_pcm16(owv.peak_normalize(w, np.float32(0.97))))
+        assert np.array_equal(p, owv.save_wav_pcm(owv.peak_normalize(w, np.float32(0.97))))  # synthesizer/audio.py:12-15 (pinned by a golden)
     torch.manual_seed(6)  # another seed -> other dropout masks -> another waveform (the toolbox's "random seed" box)
     other = pipeline.gen_wavs(syn, voc, requests, steps=24, min_stop_token=11)
     assert any(o.shape != w.shape or not np.array_equal(o, w) for o, w in zip(other, wavs))
+
+
+def test_gen_wavs_with_the_wavernn_facade(cuda, lib, tmp_path):
+    """gen_voice.py's other vocoder: the same request batch through the WaveRNN facade (float64 waveforms, its
+    `normalize` keyword is the mel scaling, the device tail arrives through peak_normalize= / pcm16= / breaks=)."""
+    from mockingbird_amd import pipeline
+    from mockingbird_amd.synthesizer.inference import Synthesizer
+    import mockingbird_amd.vocoder.wavernn.inference as wr
+    from oracle import wave as owv
+    wr = importlib.reload(wr)
+    torch.save(synth.tacotron_state(seed=3), tmp_path / "taco.pt")
+    syn = Synthesizer(tmp_path / "taco.pt", verbose=False)
+    torch.save(synth.wavernn_state(seed=5), tmp_path / "voc.pt")
+    wr.load_model(tmp_path / "voc.pt", False)
+    rng = np.random.default_rng(1)
+    embeds = [e / np.linalg.norm(e) for e in rng.standard_normal((2, 256)).astype(np.float32)]
+    requests = [(["hello world.", "second sentence"], embeds[0]), (["a b c", "d e f g", "the last one."], embeds[1])]
+    torch.manual_seed(5)  # dropout keys AND the sampler seeds come from torch's global generator, in call order
+    wavs = pipeline.gen_wavs(syn, wr, requests, steps=24, min_stop_token=11)
+    gap = int(0.15 * 16000)
+    assert len(wavs) == 2
+    for w, (texts, _) in zip(wavs, requests):
+        assert w.dtype == np.float64 and np.isfinite(w).all() and np.abs(w).max() > 0
+        assert len(w) > len(texts) * gap and (w[-gap:] == 0).all()
+    torch.manual_seed(5)
+    pcm = pipeline.gen_wavs(syn, wr, requests, steps=24, min_stop_token=11, normalize=0.97, pcm16="encode_16bits")
+    for p, w in zip(pcm, wavs):
+        assert p.dtype == np.int16 and p.shape == w.shape
+        assert np.array_equal(p, owv.encode_16bits(owv.peak_normalize(w, 0.97)))

@@ -464,17 +464,21 @@ def test_debug_noise_is_exponential(model):
     assert torch.equal(e[10:20], dev.sampler_noise(3, 10, 5, step0=10))
 
 
-def test_production_fast_chain_23_folds_vs_oracle(model, monkeypatch):
-    """BASELINE configs[1]: the benchmarked wf_* launches (FM fast chain, fused sampler, hipGraph replays), default
-    call, 23 folds x 2000 steps against the oracle."""
+@pytest.mark.parametrize("form", ["default", "chain", "pipe"])
+def test_production_fast_chain_23_folds_vs_oracle(model, monkeypatch, form):
+    """BASELINE configs[1], 23 folds x 2000 steps against the oracle: the default call (whatever bench.py times), the
+    wf_* launch chain (FM fast chain, fused sampler, hipGraph replays) and the resident pipelined kernel
+    (wavernn_pipe.h), each forced in turn."""
     dev, w = model
-    for k in ("MBHIP_WAVERNN_FAST", "MBHIP_WAVERNN_PERSIST", "MBHIP_WAVERNN_NOFUSE", "MBHIP_WAVERNN_CHAIN", "MBHIP_NO_GRAPH"):
+    for k in ("MBHIP_WAVERNN_FAST", "MBHIP_WAVERNN_PERSIST", "MBHIP_WAVERNN_NOFUSE", "MBHIP_WAVERNN_CHAIN", "MBHIP_NO_GRAPH", "MBHIP_WAVERNN_PIPE"):
         monkeypatch.delenv(k, raising=False)
+    if form != "default":
+        monkeypatch.setenv("MBHIP_WAVERNN_PIPE", "1" if form == "pipe" else "0")
     frames, target, overlap, steps, seed = 1000, 8000, 800, 2000, 1234
     mel = synth.wavernn_mel(frames, seed=1)
     s = dev.generate_samples(torch.from_numpy(mel / 4.0).cuda(), True, target, overlap, seed=seed).cpu()
     assert (dev.last_plan.n_folds, dev.last_plan.seq_len) == (23, 9600)
-    assert dev.last_loop_launches in (5 * 9600, 1)  # the 5-launch chain (or ONE persistent launch once it is the default)
+    assert dev.last_loop_launches == {"default": dev.last_loop_launches, "chain": 5 * 9600, "pipe": 1}[form]
     noise = dev.sampler_noise(seed, steps, 23).cpu()
     o_s, o_l = _oracle_replay(w, mel, True, target, overlap, s, noise, steps)
     _assert_same_picks(s, o_s, o_l, noise, steps, max_ties=8)
