@@ -413,17 +413,24 @@ def main():
     mel = torch.from_numpy(synth.wavernn_mel(F, seed=1 + rank) / 4.0).to(dev)
     wave_len = (F - 1) * model.hop_length
 
+    phase_s = []  # (compute, gather) seconds of every pass of this rank: a 1 -> 8 run must show which of the two grows
+
     def one_pass(seed):
+        tc0 = time.perf_counter()
         samples = model.generate_samples(mel, True, target, overlap, seed=seed)
         if use_dist and not stub:
             # float64 tail on the device; the finished waveform goes device-to-device to rank 0 (the only exchange
             # of the whole path), which copies the gathered set to the host once
             wav = model.finish(samples, True, overlap, True, wave_len, device_out=True)
+            sync()
+            tc1 = time.perf_counter()
             sharding.gather_waveforms([wav.to(torch.float32)], dev, dst=0)
         else:
             wav = model.finish(samples, True, overlap, True, wave_len)  # float64 tail on the device, D2H of the waveform
+            tc1 = time.perf_counter()
             if use_dist:
                 sharding.gather_waveforms([wav.astype(np.float32)], dev, dst=0)
+        phase_s.append((tc1 - tc0, time.perf_counter() - tc1))
         return wav, len(wav)
 
     def timed(fn, steps, warmup):
@@ -464,6 +471,14 @@ def main():
 
     elapsed, res = timed(headline, args.steps, args.warmup)
     loop_ms = loop_ms[args.warmup:]
+    my_phase = [float(np.median([p[k] for p in phase_s[args.warmup:]])) * 1e3 for k in (0, 1)]
+    if use_dist:  # per-rank medians, in rank order
+        tp = torch.tensor(my_phase, device=dev, dtype=torch.float64)
+        parts = [torch.zeros_like(tp) for _ in range(world)]
+        dist.all_gather(parts, tp)
+        per_rank = [[float(x) for x in p.cpu()] for p in parts]
+    else:
+        per_rank = [my_phase]
     wav = res[-1][0]
     total_samples = total_over_ranks(sum(n for _, n in res))  # every rank vocoded its own utterance
     plan = model.last_plan
@@ -480,6 +495,10 @@ def main():
                    "samples_per_utterance": int(len(wav)), "utterances": world,
                    "sample_loop_ms": float(np.median(loop_ms)),
                    "us_per_time_step": float(np.median(loop_ms)) * 1000.0 / plan.seq_len},
+        "per_rank_ms": {"compute": [p[0] for p in per_rank], "gather": [p[1] for p in per_rank],
+                        "what": "median over the timed passes of each rank: compute = conditioning + sample loop + float64 tail "
+                                "(+ D2H at 1 GPU); gather = the device-to-device gather of the finished waveforms to rank 0 "
+                                "(0 at 1 GPU)"},
     }
 
     if stub:
@@ -492,15 +511,17 @@ def main():
     if not args.no_e2e:
         result.update(sharded_objects(args, rank, world, dev, use_dist, timed, total_over_ranks))
     if rank == 0:
-        # ---- roofline of the dominant loop kernel: rnn_rowtile_kernel<GRU> (rnn1), HBM/L2-bound on weights
+        # ---- roofline of the dominant loop kernel
         L = _lib.lib()
         ws = model._ws
         smp = torch.empty(plan.n_folds, plan.seq_len, device=dev)
+        resident = model.last_loop_launches == 1  # wavernn_pipe.h: the whole sample loop is ONE resident launch
+        step_bytes = 16.3e6 + 452.0 * plan.n_folds  # fp32 weights + conditioning per step per fold-batch
         per_kernel = {}
         split = os.environ.get("MBHIP_WAVERNN_CHAIN", "") != "classic"
         names = (("gru1_finish", "rnn2_input_half", "fc1+hh1", "fc2+hh2", "fc3_sampler") if split
                  else ("rnn1_gru", "rnn2_gru", "fc1", "fc2", "fc3_sampler"))
-        for which, name in enumerate(names):
+        for which, name in enumerate(names):  # (mb_wavernn_bench_kernel always times the launch chain)
             us, ab = C.c_float(), C.c_double()
             _lib.check(L.mb_wavernn_bench_kernel(model._h, C.byref(plan), _lib.ptr(mel), _lib.ptr(smp),
                                                  _lib.ptr(ws), ws.numel(), which, 0, C.byref(us), C.byref(ab),
@@ -510,38 +531,85 @@ def main():
                                 "GBps": ab.value / (us.value * 1e-6) / 1e9}
         dom_name = "fc1+hh1" if split else "rnn2_gru"
         dom = per_kernel[dom_name]
-        # HBM traffic of that kernel from the committed rocprofv3 PMC pass (FETCH_SIZE doubled per
-        # MI355X_MICROARCH.md's gfx950 correction + WRITE_SIZE); counters cannot be read in-process
-        traffic, traffic_src = None, None
-        for cand in ("r02_pmc_wavernn.json", "r01_pmc_wavernn.json"):
+
+        def committed(key, files):
+            """HBM traffic from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950
+            correction + WRITE_SIZE); counters cannot be read in-process."""
+            for cand in files:
+                try:
+                    pm = json.load(open(os.path.join(ROOT, "profiles", cand)))
+                    if pm.get(key) is not None:
+                        return pm[key], f"profiles/{cand}: {pm.get('source', '')[:200]}"
+                except Exception:
+                    pass
+            return None, None
+
+        def rocprof_avg_us(kernel_substr):
+            """average duration of a kernel in the committed rocprofv3 --kernel-trace --stats summary of this command"""
             try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", cand)))
-                traffic = pm.get(("fc1_hh1" if split else "rnn2_gru") + "_hbm_bytes_per_launch")
-                traffic_src = f"profiles/{cand}: {pm.get('source', '')[:160]}"
-                if traffic is not None:
-                    break
+                import csv
+                for row in csv.DictReader(open(os.path.join(ROOT, "profiles", "r03_bench_kernel_stats.csv"))):
+                    if kernel_substr in row.get("Name", ""):
+                        return float(row["AverageNs"]) / 1e3
             except Exception:
                 pass
-        launch_us = result["config"]["us_per_time_step"] / 5.0  # every launch of the chain, back to back
-        dom_gbps = dom["algorithmic_bytes"] / (launch_us * 1e-6) / 1e9
-        result["roofline"] = {
-            "kernel": ("mb::wf_fc_hh_kernel<NT> (wavernn_fast.h: WaveRNN fc1 beside the hidden half of the next step's "
-                       "rnn1; the launch with the most bytes of the chain)" if split else
-                       "mb::rnn_rowtile_kernel<EPI_GRU, 1, 8, ...> (WaveRNN rnn2 instance, in-situ marginal duration)"),
-            "chain": "split-hidden" if split else "classic",
-            "bound": "hbm", "achieved": dom_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": dom_gbps / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-            "algorithmic_bytes_per_launch": dom["algorithmic_bytes"], "avg_launch_us": launch_us,
-            "avg_launch_us_method": "HIP events on the loop's stream around the whole sample loop / launches: the mean "
-                                    "launch-to-launch period of the 5-launch chain, which is what rocprofv3 --kernel-trace "
-                                    "reports per kernel (4.5-4.8 us each with tracing attached, profiles/r02_bench_*_kernel_stats.csv); "
-                                    "per_kernel[*].avg_us are in-situ MARGINAL times (loop timed with and without that launch)",
-            "marginal_us": dom["avg_us"], "marginal_GBps": dom["GBps"],
-            "whole_step": {"algorithmic_bytes": 16.3e6 + 452.0 * plan.n_folds,
-                           "us": result["config"]["us_per_time_step"],
-                           "GBps": (16.3e6 + 452.0 * plan.n_folds) / (result["config"]["us_per_time_step"] * 1e-6) / 1e9},
-            "per_kernel": per_kernel,
-        }
+            return None
+
+        if resident:
+            launch_us = float(np.median(loop_ms)) * 1000.0
+            launch_bytes = step_bytes * plan.seq_len
+            gbps = launch_bytes / (launch_us * 1e-6) / 1e9
+            traffic, traffic_src = committed("pipe_hbm_bytes_per_launch", ("r03_pmc_wavernn.json",))
+            os.environ["MBHIP_WAVERNN_PIPE"] = "0"  # the launch chain on the same utterance, for reference
+            model.generate_samples(mel, True, target, overlap, seed=0)
+            chain_us = model.last_loop_ms * 1e3 / plan.seq_len
+            os.environ.pop("MBHIP_WAVERNN_PIPE")
+            rp = rocprof_avg_us("wf_pipe_kernel")
+            result["roofline"] = {
+                "kernel": "mb::wf_pipe_kernel (wavernn_pipe.h): the whole sample loop of the utterance as ONE resident launch -- 224 "
+                          "role-specialised workgroups, weight tiles in LDS, two fold-column groups in flight, granule hand-offs",
+                "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
+                "frac_rocprof": (launch_bytes / (rp * 1e-6) / 1e9 / HBM_PEAK_GBS) if rp else None, "rocprof_avg_launch_us": rp,
+                "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": launch_bytes,
+                "algorithmic_bytes_per_step": step_bytes, "steps_per_launch": plan.seq_len,
+                "avg_launch_us": launch_us,
+                "avg_launch_us_method": "HIP events recorded on the loop's own stream right before and after the launch "
+                                        "(mb_wavernn_last_loop_ms), median over the timed passes; frac_rocprof uses the average "
+                                        "duration of the same kernel in profiles/r03_bench_kernel_stats.csv",
+                "note": "algorithmic bytes follow SURVEY 8(d) (16.3 MB of fp32 weights per step as if streamed); the resident kernel "
+                        "reads each weight ONCE per utterance, so `traffic` is far below them -- the bound that matters is the "
+                        "hand-off latency of the 5 all-to-all edges per step, DESIGN.md section 4e",
+                "whole_step": {"algorithmic_bytes": step_bytes, "us": result["config"]["us_per_time_step"],
+                               "GBps": step_bytes / (result["config"]["us_per_time_step"] * 1e-6) / 1e9},
+                "chain_reference": {"us_per_time_step": chain_us, "loop": "5-launch chain (wavernn_fast.h), hipGraph replays, same utterance",
+                                    "dominant_launch": dom_name, "per_kernel_marginal": per_kernel},
+            }
+        else:
+            traffic, traffic_src = committed(("fc1_hh1" if split else "rnn2_gru") + "_hbm_bytes_per_launch",
+                                             ("r02_pmc_wavernn.json", "r01_pmc_wavernn.json"))
+            launch_us = result["config"]["us_per_time_step"] / 5.0  # every launch of the chain, back to back
+            dom_gbps = dom["algorithmic_bytes"] / (launch_us * 1e-6) / 1e9
+            rp = rocprof_avg_us("wf_fc_hh_kernel")
+            result["roofline"] = {
+                "kernel": ("mb::wf_fc_hh_kernel<NT> (wavernn_fast.h: WaveRNN fc1 beside the hidden half of the next step's "
+                           "rnn1; the launch with the most bytes of the chain)" if split else
+                           "mb::rnn_rowtile_kernel<EPI_GRU, 1, 8, ...> (WaveRNN rnn2 instance, in-situ marginal duration)"),
+                "chain": "split-hidden" if split else "classic",
+                "bound": "hbm", "achieved": dom_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": dom_gbps / HBM_PEAK_GBS,
+                "frac_rocprof": (dom["algorithmic_bytes"] / (rp * 1e-6) / 1e9 / HBM_PEAK_GBS) if rp else None, "rocprof_avg_launch_us": rp,
+                "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": dom["algorithmic_bytes"], "avg_launch_us": launch_us,
+                "avg_launch_us_method": "HIP events on the loop's stream around the whole sample loop / launches: the mean "
+                                        "launch-to-launch period of the 5-launch chain; frac_rocprof uses the kernel's average in the "
+                                        "committed rocprofv3 summary; per_kernel[*].avg_us are in-situ MARGINAL times (loop timed with "
+                                        "and without that launch)",
+                "marginal_us": dom["avg_us"], "marginal_GBps": dom["GBps"],
+                "whole_step": {"algorithmic_bytes": step_bytes, "us": result["config"]["us_per_time_step"],
+                               "GBps": step_bytes / (result["config"]["us_per_time_step"] * 1e-6) / 1e9},
+                "per_kernel": per_kernel,
+            }
         # ---- secondary: the same utterance with batched=False (SURVEY.md section 8d config 1 "also report"): ONE
         # fold, one column per launch, every sample a dependent step -- the pure latency floor of the chain
         if not args.no_wavernn_unbatched:

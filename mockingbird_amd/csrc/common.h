@@ -87,9 +87,10 @@ __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2
   }
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
-// uniform in (0,1]
+// uniform strictly inside (0, 1): the centres of 2^23 equal cells (exact in fp32), so that -log(u) is a positive finite
+// Exp(1) draw (torch's exponential_ never returns 0 either) and log(-log(u)) is finite
 __device__ __forceinline__ float u32_to_unit(uint32_t x) {
-  return ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f);
+  return ((float)(x >> 9) + 0.5f) * (1.0f / 8388608.0f);
 }
 
 }  // namespace mb

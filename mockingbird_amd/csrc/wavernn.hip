@@ -231,7 +231,7 @@ __global__ __launch_bounds__(64) void wavernn_sample_mol_kernel(SampK a, int nr_
   else {
     uint32_t r[4];
     philox4x32((uint32_t)s, (uint32_t)gn, (uint32_t)(lane >> 2), 0x4d4f4c21u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r);
-    u = 1e-5f + (1.0f - 2e-5f) * (u32_to_unit(r[lane & 3]) - 0.5f / 16777216.0f);  // uniform_(1e-5, 1 - 1e-5)
+    u = 1e-5f + (1.0f - 2e-5f) * u32_to_unit(r[lane & 3]);  // uniform_(1e-5, 1 - 1e-5)
   }
   const float forced = a.forced ? a.forced[(size_t)gn * a.S + s] : 0.f;
   if (a.logits_out && lane < a.C) a.logits_out[((size_t)s * a.N_total + gn) * a.C + lane] = lg;
@@ -311,6 +311,7 @@ struct mb_wavernn {
   int last_launches = 0, last_lanes = 1;
   bool timed = false;
   int bench_which = 0, bench_iters = 0;  // set by mb_wavernn_bench_kernel
+  bool bench_chain = false;              // mb_wavernn_bench_kernel times the launch chain: no resident launch meanwhile
   void drop_graph() {
     for (int l = 0; l < MAX_LANES; ++l) {
       if (graph_exec[l]) { (void)hipStreamSynchronize(lane_stream[l]); (void)hipGraphExecDestroy(graph_exec[l]); graph_exec[l] = nullptr; }
@@ -775,8 +776,9 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
   // NOTE: a resident launch makes this call host-blocking (the abort word has to be looked at before returning).
   const char* penv = getenv("MBHIP_WAVERNN_PERSIST");
   const char* qenv = getenv("MBHIP_WAVERNN_PIPE");
-  const bool resident_ok = fastk && C <= 512 && !w->bench_which && !getenv("MBHIP_TRACE_FILE") && !getenv("MBHIP_WF_DBG_WHICH");
-  bool pipe = resident_ok && N >= 2 && N <= WQ_G * WQ_GC && (qenv ? atoi(qenv) != 0 : WQ_DEFAULT_ON != 0);
+  const bool resident_ok = fastk && C <= 512 && !w->bench_which && !w->bench_chain && !getenv("MBHIP_TRACE_FILE") && !getenv("MBHIP_WF_DBG_WHICH");
+  const bool persist_asked = penv && atoi(penv) == 1 && N <= WP_NCOL;  // MBHIP_WAVERNN_PERSIST=1 keeps meaning wavernn_persist.h
+  bool pipe = resident_ok && N >= 2 && N <= WQ_G * WQ_GC && (qenv ? atoi(qenv) != 0 : (WQ_DEFAULT_ON != 0 && !persist_asked));
   bool persist = resident_ok && !pipe && N <= WP_NCOL && (penv ? atoi(penv) != 0 : N == 1);
   if ((pipe || persist) && !rc) {
     int dev = 0;
@@ -1471,6 +1473,7 @@ extern "C" int mb_wavernn_bench_kernel(mb_wavernn* w, const mb_wavernn_plan* pla
   (void)iters;
   float ms_full = 0.f, ms_wo = 0.f;
   int rc = MB_OK;
+  w->bench_chain = true;
   for (int pass = 0; pass < 2 && !rc; ++pass) {
     w->bench_which = pass ? (1 << which) : 0;
     rc = mb_wavernn_generate(w, plan, d_mel, nullptr, 0, d_samples, nullptr, nullptr, nullptr, d_workspace,
@@ -1478,6 +1481,7 @@ extern "C" int mb_wavernn_bench_kernel(mb_wavernn* w, const mb_wavernn_plan* pla
     if (!rc) rc = mb_wavernn_last_loop_ms(w, pass ? &ms_wo : &ms_full, nullptr);
   }
   w->bench_which = 0;
+  w->bench_chain = false;
   if (rc) return rc;
   const float ms = ms_full - ms_wo;
   iters = plan->seq_len;

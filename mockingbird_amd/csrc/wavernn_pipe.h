@@ -38,7 +38,7 @@ constexpr int WQ_R1 = 64, WQ_R2 = 64, WQ_F = 32;
 constexpr int WQ_WGS = WQ_R1 + WQ_R2 + 3 * WQ_F;  // 224 resident workgroups, one per compute unit
 constexpr int WQ_G = 2;                           // column groups in flight
 constexpr int WQ_GC = 16;                         // columns per group (one MFMA column tile)
-constexpr int WQ_DEFAULT_ON = 0;                  // default for 2..32 columns (MBHIP_WAVERNN_PIPE overrides)
+constexpr int WQ_DEFAULT_ON = 1;                  // default for 2..32 columns (MBHIP_WAVERNN_PIPE overrides)
 
 // exchange area per (group, parity), in granules
 enum { WQX_X1 = 0, WQX_X2 = 8192, WQX_H1 = 16384, WQX_H2 = 24576, WQX_Y1 = 32768, WQX_Y2 = 40960, WQX_KEY = 49152, WQX_PER = 50176 };

@@ -34,15 +34,18 @@ def gather_waveforms(local, device=None, group=None, dst=0) -> List[np.ndarray]:
     The items may be numpy arrays or torch tensors that already live on the GPU: they are packed into ONE flat
     device buffer per rank and travel device-to-device (nccl = RCCL on GPUs, gloo on CPU); only rank `dst` copies
     the result to the host, once.  Sample type = that of the first local waveform (int16 PCM stays int16 -- half
-    the bytes on the wire -- anything else travels as float32) and must agree across ranks."""
-    def kind(w):
-        return (w.dtype == torch.int16) if isinstance(w, torch.Tensor) else (np.asarray(w).dtype == np.int16)
+    the bytes on the wire --, float64 (WaveRNN) stays float64, anything else travels as float32) and must agree across ranks."""
+    KINDS = {0: (np.float32, torch.float32), 1: (np.int16, torch.int16), 2: (np.float64, torch.float64)}
+
+    def kind(w):  # wire type code: int16 PCM and float64 (WaveRNN.generate's dtype) travel as they are, anything else as float32
+        dt = w.dtype if isinstance(w, torch.Tensor) else np.asarray(w).dtype
+        return 1 if dt in (torch.int16, np.dtype(np.int16)) else 2 if dt in (torch.float64, np.dtype(np.float64)) else 0
 
     def host(w, np_dt):
         return w.detach().cpu().numpy().astype(np_dt, copy=False) if isinstance(w, torch.Tensor) else np.asarray(w, np_dt)
 
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return [host(w, np.int16 if kind(w) else np.float32) for w in local]
+        return [host(w, KINDS[kind(w)][0]) for w in local]
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     backend = dist.get_backend(group)
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device()) \
@@ -51,7 +54,7 @@ def gather_waveforms(local, device=None, group=None, dst=0) -> List[np.ndarray]:
     MAXI = 1 + max(int(x) for x in _all_gather_ints([len(local)], dev, group))
     head = torch.zeros(2 + MAXI, dtype=torch.int64, device=dev)
     head[0] = len(local)
-    head[1] = (1 if kind(local[0]) else 0) if local else -1
+    head[1] = kind(local[0]) if local else -1
     for i, w in enumerate(local):
         head[2 + i] = int(w.numel() if isinstance(w, torch.Tensor) else np.asarray(w).size)
     heads = [torch.zeros_like(head) for _ in range(world)]
@@ -59,8 +62,8 @@ def gather_waveforms(local, device=None, group=None, dst=0) -> List[np.ndarray]:
     heads = [h.cpu() for h in heads]
     votes = {int(h[1]) for h in heads if int(h[1]) >= 0}  # ranks with no waveform do not vote
     if len(votes) > 1:
-        raise ValueError("gather_waveforms: ranks disagree on the sample type (int16 vs float)")
-    np_dt, t_dt = (np.int16, torch.int16) if votes == {1} else (np.float32, torch.float32)
+        raise ValueError("gather_waveforms: ranks disagree on the sample type (int16 / float32 / float64)")
+    np_dt, t_dt = KINDS[votes.pop() if votes else 0]
     totals = [int(h[2:2 + int(h[0])].sum()) for h in heads]
     cap = max(max(totals), 1)
     cap += cap & 1  # even sample count: the int16 payload travels as bytes / stays 4-byte aligned
@@ -71,7 +74,7 @@ def gather_waveforms(local, device=None, group=None, dst=0) -> List[np.ndarray]:
         t = _as_tensor(w, dev, np_dt, t_dt)
         buf[o:o + t.numel()] = t
         o += t.numel()
-    wire = buf.view(torch.uint8) if t_dt == torch.int16 else buf  # gloo has no int16 collectives
+    wire = buf if t_dt == torch.float32 else buf.view(torch.uint8)  # gloo has no int16 collectives; bytes for float64 too
     if dst is None:
         bufs = [torch.zeros_like(wire) for _ in range(world)]
         dist.all_gather(bufs, wire, group=group)

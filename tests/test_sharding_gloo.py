@@ -39,6 +39,10 @@ def _worker(rank, world, port, q):
     ok = ok and complete(gather_waveforms(local, device="cpu", dst=None))  # all ranks
     pcm = gather_waveforms([np.full(lens[i], i + 1, np.int16) for i in mine], device="cpu", dst=None)
     ok = ok and complete(pcm) and all(w.dtype == np.int16 for w in pcm)
+    f64 = gather_waveforms([np.full(lens[i], i + 1 + 2.0 ** -40, np.float64) for i in mine], device="cpu")  # WaveRNN's dtype survives
+    if rank == 0:
+        ok = ok and len(f64) == len(lens) and all(w.dtype == np.float64 and len(w) == lens[i] and (w == i + 1 + 2.0 ** -40).all()
+                                                  for w, i in zip(f64, order))
     q.put((rank, ok))
     dist.destroy_process_group()
 

@@ -157,6 +157,7 @@ def test_fused_sampler_matches_exact_sampler(model, monkeypatch):
     monkeypatch.delenv("MBHIP_WAVERNN_NOFUSE", raising=False)
     monkeypatch.delenv("MBHIP_WAVERNN_CHAIN", raising=False)
     monkeypatch.delenv("MBHIP_WAVERNN_MERGE", raising=False)
+    monkeypatch.setenv("MBHIP_WAVERNN_PIPE", "0")  # the launch chains (the resident kernel is tested against them elsewhere)
     fused = dev.generate_samples(m, True, 600, 100, seed=77).cpu()
     assert dev.last_loop_launches == 5 * dev.last_plan.seq_len  # split-hidden chain
     # the other production chains draw the same Philox noise: identical streams up to a near-tie flip
@@ -257,7 +258,7 @@ def test_baseline_config1_full_size_properties(model):
     m = torch.from_numpy(synth.wavernn_mel(1000, seed=1) / 4.0).cuda()
     a = dev.generate_samples(m, True, 8000, 800, seed=11)
     p = dev.last_plan
-    assert (p.n_folds, p.seq_len) == (23, 9600) and dev.last_loop_launches == 5 * 9600
+    assert (p.n_folds, p.seq_len) == (23, 9600) and dev.last_loop_launches in (1, 5 * 9600)  # resident kernel (default) or chain
     b = dev.generate_samples(m, True, 8000, 800, seed=11)
     c = dev.generate_samples(m, True, 8000, 800, seed=12)
     assert torch.equal(a, b) and not torch.equal(a, c)
@@ -457,7 +458,7 @@ def test_debug_noise_is_exponential(model):
     starting at step0 equals the same steps of a longer export."""
     dev, w = model
     e = dev.sampler_noise(3, 64, 5)
-    assert e.shape == (64, 5, 512) and bool((e > 0).all()) and torch.isfinite(e).all()
+    assert e.shape == (64, 5, 512) and bool((e > 0).all()) and torch.isfinite(e).all()  # strictly positive, like torch's exponential_
     assert abs(float(e.mean()) - 1.0) < 0.02 and abs(float(e.var()) - 1.0) < 0.05
     assert abs(float((e > 1).float().mean()) - 0.36788) < 0.01
     assert torch.equal(e, dev.sampler_noise(3, 64, 5)) and not torch.equal(e, dev.sampler_noise(4, 64, 5))
