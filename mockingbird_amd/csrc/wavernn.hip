@@ -820,6 +820,7 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
       qk.samples = d_samples; qk.progress = h_progress; qk.seed = seed; qk.R = R; qk.FC = FC; qk.C = C; qk.S = S; qk.N = N;
       qk.gn0[0] = 0; qk.gn0[1] = (N + 1) / 2; qk.gn0[2] = N;  // two groups of ceil / floor (N / 2) columns
       if (const char* ge = getenv("MBHIP_WQ_GROUPS")) { if (atoi(ge) == 1 && N <= WQ_GC) qk.gn0[1] = N; }  // A/B: one group, no pipelining
+      qk.flags = getenv("MBHIP_WQ_FLAGS") ? atoi(getenv("MBHIP_WQ_FLAGS")) : 1;  // A/B switches of wavernn_pipe.h
       qk.trace = trace;
       hipLaunchKernelGGL(wf_pipe_kernel, dim3(WQ_WGS), dim3(512), WQ_LDS_BYTES, s, qk);
     } else {

@@ -53,12 +53,44 @@ struct WqK {
   float* samples; volatile int* progress;
   unsigned long long seed; int R, FC, C, S, N;
   int gn0[WQ_G + 1];          // group g owns fold columns [gn0[g], gn0[g + 1])
+  int flags;                  // A/B switches (MBHIP_WQ_FLAGS): 1 = exchange rows padded to 16 columns (default), 2 = R2's residual x1 by a global load
   unsigned long long* trace;  // diagnostics (MBHIP_WP_TRACE): wall-clock marks of one workgroup per role, steps 1000..1003
 };
 
+// wp_gather with the row stride LD apart from the live column count N
+template <int SLEEP>
+__device__ __forceinline__ bool wq_gather(const unsigned long long* vec, const unsigned tag, const int N, const int LD, float4 (&b)[4], int* abort_word) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, kq = lane >> 4;
+  // ONE watching lane, then a barrier, then one sweep (four staggered watchers + an LDS flag instead: 14.2 vs 13.9 us per step)
+  wp_watch<SLEEP>(vec + (size_t)511 * LD + (N - 1), tag, abort_word);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) b[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i >= N) return true;
+  const unsigned long long* base = vec + ((size_t)(wave * 16 + kq * 4) * LD + i);
+  unsigned long long v[16];
+  unsigned long long t0 = 0;
+  for (int tries = 0;; ++tries) {
+    bool ok = true;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[p * 4 + c] = wp_get(base + ((size_t)p * 128 + c) * LD);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) ok = ok && (unsigned)(v[q] >> 32) == tag;
+    if (ok) break;
+    if ((tries & 1023) == 1023 && wp_lost(tries, t0, abort_word)) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+    b[p] = make_float4(__uint_as_float((unsigned)v[p * 4]), __uint_as_float((unsigned)v[p * 4 + 1]), __uint_as_float((unsigned)v[p * 4 + 2]),
+                       __uint_as_float((unsigned)v[p * 4 + 3]));
+  return true;
+}
+
 // dynamic LDS (floats): [weights: up to 4 GRU tiles] [red: two 4096-float buffers, alternating] [keys / samples]
 constexpr int WQ_LDS_W = 4 * 6144, WQ_LDS_RED = 2 * 4096;
-constexpr size_t WQ_LDS_BYTES = (size_t)(WQ_LDS_W + WQ_LDS_RED) * 4 + 2 * WQ_GC * 8 + 64;
+constexpr size_t WQ_LDS_BYTES = (size_t)(WQ_LDS_W + WQ_LDS_RED) * 4 + 2 * WQ_GC * 8 + 8 * 16 * 4 + 64;
 
 __global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -103,7 +135,7 @@ __global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
       const unsigned tag_prev = (unsigned)s, tag = (unsigned)s + 1;
 #pragma unroll
       for (int g = 0; g < WQ_G; ++g) {
-        const int n0 = a.gn0[g], Ng = a.gn0[g + 1] - n0;
+        const int n0 = a.gn0[g], Ng = a.gn0[g + 1] - n0, LD = (a.flags & 1) ? WQ_GC : Ng;
         if (Ng <= 0) continue;
         WQ_MARK(0, 0);
         // ---- keys of step s-1 -> sample x of every column of the group ----
@@ -139,8 +171,8 @@ __global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
           const float ng = tanhf((tq[g][2] + x * gn) + rg * P1[g][2]);
           const float hy = ng + zg * (h1[g] - ng);
           h1[g] = hy;
-          wp_put(EX(WQX_X1, g, tag) + (size_t)ju * Ng + i, (tq[g][3] + x * w0) + hy, tag);
-          wp_put(EX(WQX_H1, g, tag) + (size_t)ju * Ng + i, hy, tag);
+          wp_put(EX(WQX_X1, g, tag) + (size_t)ju * LD + i, (tq[g][3] + x * w0) + hy, tag);
+          wp_put(EX(WQX_H1, g, tag) + (size_t)ju * LD + i, hy, tag);
         }
         WQ_MARK(0, 2);
         if (s + 1 >= S) continue;
@@ -152,7 +184,7 @@ __global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
         }
         // ---- hidden half of the next step: P1 = W_hh1 . h1 + b_hh1, kept by the lane that will use it ----
         float4 b[4];
-        if (!wp_gather<2>(EX(WQX_H1, g, tag), tag, Ng, b, a.abort_word)) return;
+        if (!wq_gather<2>(EX(WQX_H1, g, tag), tag, Ng, LD, b, a.abort_word)) return;
         WQ_MARK(0, 3);
         float sx[4];
         const bool epi = wp_gemm2<3>(lw, 6144, b, red + rb * 4096, sx);
@@ -171,6 +203,8 @@ __global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
     wp_copy_tile(lw, a.w_rnn2 + (size_t)(2 * b2) * 6144, 12288);
     wp_copy_tile(lw + 12288, a.w_hh2 + (size_t)(2 * b2) * 6144, 12288);
     const int ju = (2 * b2 + (wave & 1)) * 4 + du;
+    const int xr_wave = (b2 >> 1) & 7, xr_p = b2 >> 4, xr_kq0 = (b2 & 1) * 2;  // where units 8 b2 .. 8 b2 + 7 sit in the B fragments
+    float* s_xr = s_x + WQ_GC;  // [2 tiles][4 units][16 columns]
     const float4 bq = a.bhh2q[ju];
     float h2[WQ_G], P2[WQ_G][3], g2v[WQ_G][3];
     int g2_row[WQ_G];
@@ -181,7 +215,7 @@ __global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
       const unsigned tag = (unsigned)s + 1;
 #pragma unroll
       for (int g = 0; g < WQ_G; ++g) {
-        const int n0 = a.gn0[g], Ng = a.gn0[g + 1] - n0;
+        const int n0 = a.gn0[g], Ng = a.gn0[g + 1] - n0, LD = (a.flags & 1) ? WQ_GC : Ng;
         if (Ng <= 0) continue;
         const int frow = wf_frame_row(a.g, n0 + (i < Ng ? i : Ng - 1), s);
         if (wave < 2 && frow != g2_row[g]) {  // the per-frame rows change once per hop: kept in registers in between
@@ -191,26 +225,37 @@ __global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
         }
         WQ_MARK(1, 0);
         float4 b[4];
-        if (!wp_gather<1>(EX(WQX_X1, g, tag), tag, Ng, b, a.abort_word)) return;
+        if (!wq_gather<1>(EX(WQX_X1, g, tag), tag, Ng, LD, b, a.abort_word)) return;
         WQ_MARK(1, 1);
+        // the residual x1 of this workgroup's own 8 units sits in the fragments just gathered (one k-block, wave xr_wave,
+        // register xr_p, lanes kq = xr_kq0 + tile): handed to the epilogue lanes through LDS behind the GEMM's own barrier
+        if (wave == xr_wave && (lane >> 4) >= xr_kq0 && (lane >> 4) < xr_kq0 + 2) {
+          float* dst = s_xr + (((lane >> 4) - xr_kq0) * 4) * 16 + i;
+#pragma unroll
+          for (int p = 0; p < 4; ++p)  // (static register index: a run-time b[xr_p] would put the fragments in scratch)
+            if (p == xr_p) { dst[0] = b[p].x; dst[16] = b[p].y; dst[32] = b[p].z; dst[48] = b[p].w; }
+        }
         float sx[4];
         const bool epi = wp_gemm2<3>(lw, 6144, b, red + rb * 4096, sx);
         rb ^= 1;
         if (epi && i < Ng) {
-          unsigned xu[1];
-          if (!wp_wait<1>(EX(WQX_X1, g, tag) + (size_t)ju * Ng + i, 1, tag, xu, a.abort_word)) return;
-          const float xr = __uint_as_float(xu[0]);
+          float xr = s_xr[((wave & 1) * 4 + du) * 16 + i];
+          if (a.flags & 2) {
+            unsigned xu[1];
+            if (!wp_wait<1>(EX(WQX_X1, g, tag) + (size_t)ju * LD + i, 1, tag, xu, a.abort_word)) return;
+            xr = __uint_as_float(xu[0]);
+          }
           const float rg = sigmoidf_((sx[0] + g2v[g][0]) + P2[g][0]);
           const float zg = sigmoidf_((sx[1] + g2v[g][1]) + P2[g][1]);
           const float ng = tanhf((sx[2] + g2v[g][2]) + rg * P2[g][2]);
           const float hy = ng + zg * (h2[g] - ng);
           h2[g] = hy;
-          wp_put(EX(WQX_X2, g, tag) + (size_t)ju * Ng + i, xr + hy, tag);
-          wp_put(EX(WQX_H2, g, tag) + (size_t)ju * Ng + i, hy, tag);
+          wp_put(EX(WQX_X2, g, tag) + (size_t)ju * LD + i, xr + hy, tag);
+          wp_put(EX(WQX_H2, g, tag) + (size_t)ju * LD + i, hy, tag);
         }
         WQ_MARK(1, 2);
         if (s + 1 >= S) continue;
-        if (!wp_gather<2>(EX(WQX_H2, g, tag), tag, Ng, b, a.abort_word)) return;
+        if (!wq_gather<2>(EX(WQX_H2, g, tag), tag, Ng, LD, b, a.abort_word)) return;
         WQ_MARK(1, 3);
         const bool epi2 = wp_gemm2<3>(lw + 12288, 6144, b, red + rb * 4096, sx);
         rb ^= 1;
@@ -237,7 +282,7 @@ __global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
     const unsigned tag = (unsigned)s + 1;
 #pragma unroll
     for (int g = 0; g < WQ_G; ++g) {
-      const int n0 = a.gn0[g], Ng = a.gn0[g + 1] - n0;
+      const int n0 = a.gn0[g], Ng = a.gn0[g + 1] - n0, LD = (a.flags & 1) ? WQ_GC : Ng;
       if (Ng <= 0) continue;
       const int ncl = n0 + (i < Ng ? i : Ng - 1);
       float lgn[4] = {0.f, 0.f, 0.f, 0.f};
@@ -255,7 +300,7 @@ __global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
       }
       WQ_MARK(2 + fr, 0);
       float4 b[4];
-      if (!wp_gather<1>(EX(src, g, tag), tag, Ng, b, a.abort_word)) return;
+      if (!wq_gather<1>(EX(src, g, tag), tag, Ng, LD, b, a.abort_word)) return;
       WQ_MARK(2 + fr, 1);
       float sx[4];
       const bool epi = wp_gemm<4>(lw, b, red + rb * 4096, sx);
@@ -263,11 +308,11 @@ __global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
       if (!epi) continue;
       if (fr < 2) {
         if (i < Ng) {
-          unsigned long long* Y = EX(fr == 0 ? WQX_Y1 : WQX_Y2, g, tag) + (size_t)(ft * 16 + du * 4) * Ng + i;
+          unsigned long long* Y = EX(fr == 0 ? WQX_Y1 : WQX_Y2, g, tag) + (size_t)(ft * 16 + du * 4) * LD + i;
           wp_put(Y, fmaxf(sx[0] + fpre[g].x, 0.f), tag);
-          wp_put(Y + Ng, fmaxf(sx[1] + fpre[g].y, 0.f), tag);
-          wp_put(Y + 2 * Ng, fmaxf(sx[2] + fpre[g].z, 0.f), tag);
-          wp_put(Y + 3 * Ng, fmaxf(sx[3] + fpre[g].w, 0.f), tag);
+          wp_put(Y + LD, fmaxf(sx[1] + fpre[g].y, 0.f), tag);
+          wp_put(Y + 2 * LD, fmaxf(sx[2] + fpre[g].z, 0.f), tag);
+          wp_put(Y + 3 * LD, fmaxf(sx[3] + fpre[g].w, 0.f), tag);
         }
       } else {  // wf_fc3_kernel's sampler; lanes of dead columns take part in the shuffles only
         const float bv[4] = {b3q.x, b3q.y, b3q.z, b3q.w};
