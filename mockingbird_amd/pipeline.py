@@ -35,7 +35,7 @@ def insert_breaks(wav: np.ndarray, frames_per_sentence: Sequence[int], hop_size:
 
 
 def gen_wavs(synthesizer, vocoder, requests: List[Tuple[List[str], np.ndarray]], *, style_idx=-1, min_stop_token=4,
-             steps=400, group=None, normalize=None, pcm16=None, dst=0) -> List[np.ndarray]:
+             steps=400, group=None, normalize=None, pcm16=None, dst=0, chunk_size=None) -> List[np.ndarray]:
     """requests: [(texts, embed)] -> one waveform per request, in request order, on rank `dst` (every other rank
     returns []; dst=None: on every rank).
 
@@ -62,8 +62,9 @@ def gen_wavs(synthesizer, vocoder, requests: List[Tuple[List[str], np.ndarray]],
             flat_texts += list(texts)
             flat_embeds += [embed] * len(texts)
             owner += [i] * len(texts)
+        skw = {"chunk_size": chunk_size} if chunk_size else {}  # additive keyword of the Synthesizer facade (utterances per decoder loop)
         specs = synthesizer.synthesize_spectrograms(flat_texts, flat_embeds, style_idx=style_idx,
-                                                    min_stop_token=min_stop_token, steps=steps)
+                                                    min_stop_token=min_stop_token, steps=steps, **skw)
         per_req = {i: [s for s, o in zip(specs, owner) if o == i] for i in mine}
         mels = [np.concatenate(per_req[i], axis=1) for i in mine]
         kw = dict(pcm16=pcm16, breaks=[[s.shape[1] for s in per_req[i]] for i in mine],

@@ -144,20 +144,25 @@ class Synthesizer:
             print("Loaded synthesizer \"%s\" trained to step %d" % (self.model_fpath.name, self._step))
 
     def synthesize_spectrograms(self, texts: List[str], embeddings: Union[np.ndarray, List[np.ndarray]],
-                                return_alignments=False, style_idx=0, min_stop_token=5, steps=2000):
+                                return_alignments=False, style_idx=0, min_stop_token=5, steps=2000, chunk_size=None):
+        """Reference signature (inference.py:75) plus one additive keyword: chunk_size = utterances per decoder loop
+        (default hparams.synthesis_batch_size = 16, hparams.py:56, as the reference chunks).  The encoder runs on the
+        device too, so nothing limits a chunk to 16: 32 utterances in ONE loop cost about what 16 do (the loop is
+        latency-bound), two chunks of 16 cost twice that.  The batch-wide stop rule (tacotron.py:275) then spans the
+        larger chunk, exactly as it would in the reference with a larger synthesis_batch_size."""
         if not self.is_loaded():
             self.load()
         print("Read " + str(texts))
         texts = to_pinyin(texts)
         print("Synthesizing " + str(texts))
         inputs = [text_to_sequence(text, hparams.tts_cleaner_names) for text in texts]
-        specs, alignments = self.synthesize_from_tokens(inputs, embeddings, style_idx, min_stop_token, steps)
+        specs, alignments = self.synthesize_from_tokens(inputs, embeddings, style_idx, min_stop_token, steps, chunk_size=chunk_size)
         if self.verbose:
             print("\n\nDone.\n")
         return (specs, alignments) if return_alignments else specs
 
     def synthesize_from_tokens(self, inputs, embeddings, style_idx=0, min_stop_token=5, steps=2000, enc_masks=None,
-                               dropout=None, seed=None):
+                               dropout=None, seed=None, chunk_size=None):
         """inference.py:104-139 from token id sequences (benchmarks feed these directly).  seed=None: every
         chunk draws its own RNG key from torch's global generator (fresh_seed); an explicit seed is advanced
         per chunk so that no two chunks share dropout masks."""
@@ -165,7 +170,9 @@ class Synthesizer:
             self.load()
         if not isinstance(embeddings, list):
             embeddings = [embeddings]
-        bs = hparams.synthesis_batch_size
+        bs = int(chunk_size) if chunk_size else hparams.synthesis_batch_size
+        if bs < 1:
+            raise ValueError(f"chunk_size must be >= 1, got {chunk_size}")
         specs, alignments = [], None
         for i in range(0, len(inputs), bs):
             batch = inputs[i:i + bs]

@@ -185,6 +185,34 @@ def test_fregan_f16_config4_share_properties(cuda, lib):
     assert e["rel_rms"] <= F16_REL_TOL, e
 
 
+def test_fregan_f16_config4_share_vs_oracle(cuda, lib):
+    """BASELINE configs[4] per-GPU share at FULL size against the oracle itself: Fre-GAN fp16, batch 8 x mel (80,3000); the
+    first and the last item of the batch against oracle.gan.fregan_forward (fp32 ATen CPU, 1.15 TFLOP per item), fp16 gate
+    (relative RMS <= 5e-3).  The HiFi-GAN `hifigan_f16` bench object's shape (32 x 200) rides along."""
+    from mockingbird_amd.vocoder.gan import GanGenerator
+    h = synth.FREGAN_16K
+    st = synth.gan_state(h, "fregan", seed=5)["generator"]
+    g16 = GanGenerator(h, st, 1, dtype="f16")
+    mel = torch.from_numpy(synth.mel_input(3000, 8, seed=0))
+    y16 = g16(mel.cuda()).cpu()
+    w = og.fold_weight_norm_state(st)
+    for k in (0, 7):
+        with torch.no_grad():
+            ref = og.fregan_forward(w, h, mel[k:k + 1])
+        e = hiputil.relerr(y16[k:k + 1], ref)
+        print("fregan f16 8x3000 item", k, e)
+        assert e["nan"] == 0 and e["rel_rms"] <= F16_REL_TOL, (k, e)
+    hh = synth.HIFIGAN_16K
+    sth = synth.gan_state(hh, "hifigan", seed=6)["generator"]
+    gh = GanGenerator(hh, sth, 0, dtype="f16")
+    melh = torch.from_numpy(synth.mel_input(200, 32, seed=1))
+    yh = gh(melh.cuda()).cpu()
+    with torch.no_grad():
+        refh = og.hifigan_forward(og.fold_weight_norm_state(sth), hh, melh[::31])  # items 0 and 31
+    e = hiputil.relerr(yh[::31], refh)
+    assert e["nan"] == 0 and e["rel_rms"] <= F16_REL_TOL, e
+
+
 @pytest.mark.parametrize("kind,cfg,uic,frames,batch", [("hifigan", synth.HIFIGAN_16K, 256, 23, 2),
                                                        ("fregan", synth.FREGAN_16K, 512, 12, 1)])
 def test_gan_f16_unfused_path_matches_oracle(cuda, lib, monkeypatch, kind, cfg, uic, frames, batch):

@@ -42,6 +42,26 @@ def test_decode_matches_oracle(cuda, lib, B, T, wseed, sb, mseed):
     assert torch.allclose(oal.sum(2), al.sum(2), atol=1e-4)
 
 
+def test_decode_matches_oracle_at_the_benchmarked_shape(cuda, lib):
+    """bench.py's ppg2mel object: T_enc = 200, batch 32 (and batch 1) -- the loop instances it times (ppg_fast.h, batch-32
+    column tiles, the long MoL attention window), 48 decoder steps against the oracle with injected masks."""
+    from mockingbird_amd.ppg2mel import Ppg2MelDecoder
+    w = synth.ppg2mel_decoder_state(synth.PPG2MEL_HP, seed=6, stop_bias=-8.0)  # never stops inside the compared prefix
+    dec = Ppg2MelDecoder(w, synth.PPG2MEL_HP)
+    steps = 48
+    for B in (32, 1):
+        mem = torch.from_numpy(synth.ppg2mel_memory(B, 200, seed=7 + B))
+        masks = synth.ppg2mel_dropout_masks(5, 400, B)
+        with torch.no_grad():
+            omel, oal, ostop = op.inference_batched(w, dict(op.HP), mem, masks=op.MaskSource(list(masks)), max_steps=steps)
+        mel, al, stop = dec.decode(mem.cuda(), dropout=masks)
+        mel, al, stop = mel.cpu().reshape(B, -1, 80)[:, :omel.shape[1]], al.cpu()[:, :steps], stop.cpu()[:, :steps]
+        assert omel.shape[1] == steps * 2 and al.shape == oal.shape
+        e = hiputil.relerr(mel, omel)
+        assert e["nan"] == 0 and e["max_abs"] <= MEL_TOL, (B, e)
+        assert float((al - oal).abs().max()) <= ALIGN_TOL and float((stop - ostop).abs().max()) <= 1e-2
+
+
 def test_reference_surface_and_golden(cuda, lib):
     """inference / inference_batched return what the reference returns (shapes, per-item truncation,
     concatenation) -- checked against the golden outputs of the reference module itself.  The golden was

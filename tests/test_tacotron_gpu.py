@@ -124,6 +124,35 @@ def test_full_generate_facade_vs_oracle(model, tmp_path):
     assert len(out) == 2 and all(o.shape[0] == 80 and o.dtype == np.float32 for o in out)
 
 
+def test_chunk_size_keyword_runs_one_loop(model, tmp_path):
+    """Additive keyword chunk_size (hparams.synthesis_batch_size = 16 stays the default, hparams.py:56): 20 utterances with
+    chunk_size=32 are ONE padded batch through generate (same seed -> the same mels as the direct call, tail-trimmed as
+    inference.py:135-139 does); without it they are chunks of 16 + 4."""
+    from mockingbird_amd.synthesizer.inference import Synthesizer, hparams as hp
+    dev, w = model
+    torch.save(synth.tacotron_state(seed=3), tmp_path / "taco.pt")
+    syn = Synthesizer(tmp_path / "taco.pt", verbose=False)
+    chars, spk, seqs, emb = _batch(20, 15, 30, seed=33)
+    steps = 24
+    one, _ = syn.synthesize_from_tokens(seqs, emb, style_idx=-1, min_stop_token=11, steps=steps, seed=7, chunk_size=32)
+    _, mels, _ = syn._model.generate(chars.cuda(), spk.cuda(), steps=steps, style_idx=-1, min_stop_token=11, seed=7)
+    mels = mels.cpu().numpy()
+    assert len(one) == 20
+    for a, m in zip(one, mels):
+        while np.max(m[:, -1]) < hp.tts_stop_threshold:
+            m = m[:, :-1]
+        assert a.shape == m.shape and np.array_equal(a, m)
+    two, _ = syn.synthesize_from_tokens(seqs, emb, style_idx=-1, min_stop_token=11, steps=steps, seed=7)  # default: 16 + 4
+    c16 = torch.tensor(np.stack([np.pad(t, (0, max(len(x) for x in seqs[:16]) - len(t))) for t in seqs[:16]])).long()
+    _, m16, _ = syn._model.generate(c16.cuda(), spk[:16].cuda(), steps=steps, style_idx=-1, min_stop_token=11, seed=7)
+    m0 = m16[0].cpu().numpy()
+    while np.max(m0[:, -1]) < hp.tts_stop_threshold:
+        m0 = m0[:, :-1]
+    assert len(two) == 20 and np.array_equal(two[0], m0)
+    with pytest.raises(ValueError):
+        syn.synthesize_from_tokens(seqs, emb, chunk_size=-1)
+
+
 def test_baseline_config2_shape_properties(model):
     """BASELINE configs[2] size: B=32 (two facade chunks of 16), ~100 tokens, r=2, 400 steps forced
     (min_stop_token=11).  Size-independent properties: attention rows are distributions, masked

@@ -536,3 +536,23 @@ def test_production_batch_loop_vs_oracle(model, wide):
         noise = dev.sampler_noise(seeds[u], steps, s.shape[0]).cpu()
         o_s, o_l = _oracle_replay(w, mels_np[u], True, target, overlap, s, noise, steps)
         _assert_same_picks(s, o_s, o_l, noise, steps, max_ties=3)
+
+
+def test_production_batch32_full_size_vs_oracle(model):
+    """bench.py's `wavernn_batch32` object at FULL size: 32 utterances x mel 80x1000 in ONE sample loop = 736 fold columns
+    (rnn_ts2_body.h, three column tiles per wave) x 9600 steps; utterances 0, 17 and 31, 150 steps each, against the
+    oracle with their own seeds' noise."""
+    dev, w = model
+    mels_np = [synth.wavernn_mel(1000, seed=100 + u) for u in range(32)]
+    seeds = list(range(500, 532))
+    outs = dev.generate_samples_batch([torch.from_numpy(m / 4.0).cuda() for m in mels_np], 8000, 800, seeds)
+    assert dev.last_batch_plan.n_folds == 736 and outs[0].shape == (23, 9600)
+    steps = 150
+    for u in (0, 17, 31):
+        s = outs[u].cpu()
+        noise = dev.sampler_noise(seeds[u], steps, 23).cpu()
+        o_s, o_l = _oracle_replay(w, mels_np[u], True, 8000, 800, s, noise, steps)
+        _assert_same_picks(s, o_s, o_l, noise, steps, max_ties=2)
+    del outs
+    dev._ws = None  # 53 GB of tables: give them back before the next test
+    torch.cuda.empty_cache()
