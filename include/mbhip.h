@@ -55,7 +55,9 @@ int mb_abi_version(void);
  *      models/vocoder/wavernn/models/fatchord_version.py:9-44
  * ---------------------------------------------------------------------- */
 
-/* Number of floats of the packed (MFMA A-fragment ordered) weight image. */
+/* Number of floats of the packed weight image: the fp32 A fragments of the exact fp32-input MFMA kernel, a 64-float header
+ * and the fp16 hi / lo A fragments of the error-compensated fp16 MFMA kernel (conv1d.hip; the default from 16 input channels
+ * up, MBHIP_CONV_SPLIT=0 selects the fp32-input kernel). */
 size_t mb_conv1d_packed_floats(int c_out, int c_in, int ksize, int up);
 
 /* Pack torch-layout weights on the host.

@@ -22,6 +22,7 @@
 //     fused; optional time-major store by swapping the MFMA operands (the A and
 //     B fragment lane maps are identical, so D comes out transposed for free).
 #include "common.h"
+#include <cmath>
 
 namespace mb {
 
@@ -175,6 +176,197 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvK a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same implicit GEMM on the fp16 matrix pipe with error compensation ("split" path, the default for c_in >= 16):
+//   x = xh + xl,  w * 2^s = wh + wl   (xh = fp16(x), xl = fp16(x - xh); s per conv so that max |w| 2^s is in [2^13, 2^14))
+//   acc += wh.xh + wh.xl + wl.xh      three v_mfma_f32_32x32x16_f16 per (16 channels, tap), fp32 accumulate,
+//   y = acc * 2^-s ...                the dropped wl.xl term is 2^-22 of a product: fp32-grade results (each operand keeps
+//                                     22 bits; an |x| below 0.125 keeps an absolute 3e-8 instead -- fp16 subnormals)
+// at 1/5.3 of the matrix-pipe time of the fp32-input MFMA (3 x 32 cycles per 32x32x16 block instead of 8 x 64).
+// Range: |x| <= 131008 (hi and lo both saturate at fp16's 65504; the audio / mel activations of this path are O(1..100)).
+// MBHIP_CONV_SPLIT=0 selects the exact fp32-input kernel above (tests/test_conv1d_gpu.py runs both).
+// Layout: x staged per chunk of SCK = 32 channels as [position][32 hi | 32 lo | pad] fp16 rows of 144 bytes (16-byte
+// B fragments = 8 consecutive channels of one position, conflict-free for ds_read_b128 / ds_write_b128: 144 / 16 is odd);
+// weights pre-split on the host in A-fragment order [phase][mt][16-channel step][tap][hi | lo][lane][8].
+typedef _Float16 h16;
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+static constexpr int SCK = 32;
+static constexpr int SROW = SCK * 4 + 16;  // bytes per staged position
+
+__device__ __forceinline__ void split_store(char* row, const int grp, const float (&v)[8]) {
+  h16x8 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float c = fminf(fmaxf(v[e], -65504.f), 65504.f);
+    const h16 h = (h16)c;
+    hi[e] = h;
+    lo[e] = (h16)fminf(fmaxf(v[e] - (float)h, -65504.f), 65504.f);
+  }
+  *reinterpret_cast<h16x8*>(row + grp * 16) = hi;
+  *reinterpret_cast<h16x8*>(row + SCK * 2 + grp * 16) = lo;
+}
+
+// One workgroup = 4 waves on 128 output positions (WM x WN waves, NTW 32-position tiles per wave: 4x1x4, 2x2x2 or 1x4x1).
+// Pipeline per 32-channel chunk: the NEXT chunk's x values are already in flight to registers (SITEMS x 8 floats per
+// thread, issued before this chunk's MFMAs), the chunk itself is computed from one of two LDS buffers, then the registers
+// are split into hi / lo halves and stored into the other buffer: one barrier per chunk, global latency behind the MFMAs.
+static constexpr int SNT = 128;    // output positions per workgroup
+static constexpr int SITEMS = 4;   // (position, 8-channel group) items per thread and chunk: rowlen <= 256
+
+template <int WM, int WN, int NTW, bool TR, bool POOL>
+__global__ __launch_bounds__(256) void conv1d_split_kernel(ConvK a, const uint4* __restrict__ wsplit, const float* __restrict__ whdr) {
+  extern __shared__ __attribute__((aligned(16))) char slds[];
+  static_assert(32 * NTW * WN == SNT, "tile shape");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int p = blockIdx.z % a.up, b = blockIdx.z / a.up;
+  const int q0 = blockIdx.x * SNT;
+  const int Tq = (a.t_out - p + a.up - 1) / a.up;
+  if (q0 >= Tq) return;
+  const int t_lim = a.valid ? min(a.t_in, a.valid[b] * a.valid_mul * a.in_repeat) : a.t_in;
+  if (a.valid) {
+    const int t_out_b = a.up > 1 ? t_lim * a.up : t_lim + (a.t_out - a.t_in);
+    if (q0 * a.up + p >= t_out_b) return;
+  }
+  const int n_mt = (a.c_out + 31) >> 5;
+  const int mt = blockIdx.y * WM + wm;
+  const bool active = mt < n_mt;
+  const int rowlen = SNT * a.down + a.span;  // <= 256 (host)
+  const int n_ks = (a.c_in + 15) >> 4;
+  const int n_w = n_ks * a.ntaps;
+  const float* xb = a.x + (long long)b * a.x_bstride;
+  const uint4* wp = wsplit + ((size_t)(p * n_mt + (active ? mt : 0)) * n_w) * 128 + lane;
+  const int off_base = a.off0[p] - a.min_off;
+  const int t_src = a.in_repeat > 1 ? a.t_in / a.in_repeat : a.t_in;
+  const size_t buf_bytes = (size_t)rowlen * SROW;
+
+  // this thread's staging position (one per chunk; group g = item index)
+  const int tt = tid;                                  // 0..255
+  const int ti = q0 * a.down + a.min_off + tt;         // input position
+  const bool pos_ok = tt < rowlen && ti >= 0 && ti < t_lim;
+  const int tsrc_i = pos_ok ? (a.in_repeat > 1 ? ti / a.in_repeat : ti) : 0;
+  const bool pool_prev = POOL && pos_ok && ti > 0;
+
+  float pre[SITEMS][8], pre2[POOL ? SITEMS : 1][8];
+  auto issue = [&](const int c0) {  // global loads of chunk c0 -> registers (nothing waits here)
+#pragma unroll
+    for (int g = 0; g < SITEMS; ++g)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ci = c0 + g * 8 + e;
+        const bool ok = pos_ok && ci < a.c_in;
+        const float* xr = xb + (long long)(ok ? ci : 0) * t_src + tsrc_i;
+        pre[g][e] = ok ? xr[0] : 0.f;
+        if (POOL) pre2[g][e] = (ok && pool_prev) ? xr[-1] : -INFINITY;
+      }
+  };
+  auto store = [&](char* buf) {  // registers -> fused input activation -> fp16 hi / lo rows
+    if (tt >= rowlen) return;
+#pragma unroll
+    for (int g = 0; g < SITEMS; ++g) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float x = pre[g][e];
+        if (POOL) x = fmaxf(x, pre2[g][e]);  // MaxPool1d(2, stride 1, pad 1)[:T] (cbhg.py:20,61)
+        else {
+          x *= a.in_scale;
+          if (a.in_act == 1) x = x > 0.f ? x : x * a.in_slope;
+        }
+        v[e] = x;
+      }
+      split_store(buf + (size_t)tt * SROW, g, v);
+    }
+  };
+
+  f32x16 acc[NTW];
+#pragma unroll
+  for (int n = 0; n < NTW; ++n)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
+
+  int wi = 0;
+  uint4 ah = make_uint4(0, 0, 0, 0), al = make_uint4(0, 0, 0, 0);
+  if (active) { ah = wp[0]; al = wp[64]; }
+
+  const int cin16 = n_ks * 16;
+  issue(0);
+  store(slds);
+  if (SCK < cin16) issue(SCK);
+  int cur = 0;
+  for (int c0 = 0; c0 < cin16; c0 += SCK) {
+    __syncthreads();  // chunk c0 is in LDS[cur]; every wave is done with LDS[cur ^ 1]
+    if (active) {
+      const int nks2 = min(SCK, cin16 - c0) >> 4;
+      const char* lcur = slds + cur * buf_bytes;
+      for (int ks2 = 0; ks2 < nks2; ++ks2) {
+        const char* lbase = lcur + (size_t)((wn * NTW * 32 + (lane & 31)) * a.down + off_base) * SROW + (ks2 * 2 + (lane >> 5)) * 16;
+        for (int j = 0; j < a.ntaps; ++j) {
+          ++wi;
+          uint4 nh = ah, nl = al;
+          if (wi < n_w) { nh = wp[(size_t)wi * 128]; nl = wp[(size_t)wi * 128 + 64]; }
+          const h16x8 Ah = __builtin_bit_cast(h16x8, ah), Al = __builtin_bit_cast(h16x8, al);
+          const char* lp = lbase + (ptrdiff_t)j * a.step * SROW;
+#pragma unroll
+          for (int n = 0; n < NTW; ++n) {
+            const char* lq = lp + (size_t)(n * 32 * a.down) * SROW;
+            const h16x8 Bh = *reinterpret_cast<const h16x8*>(lq);
+            const h16x8 Bl = *reinterpret_cast<const h16x8*>(lq + SCK * 2);
+            if (!TR) {
+              acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, acc[n], 0, 0, 0);
+              acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc[n], 0, 0, 0);
+              acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, acc[n], 0, 0, 0);
+            } else {
+              acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bh, Al, acc[n], 0, 0, 0);
+              acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bl, Ah, acc[n], 0, 0, 0);
+              acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bh, Ah, acc[n], 0, 0, 0);
+            }
+          }
+          ah = nh; al = nl;
+        }
+      }
+    }
+    if (c0 + SCK < cin16) {  // the next chunk has arrived in the registers by now: into the other buffer, then fetch the one after
+      store(slds + (cur ^ 1) * buf_bytes);
+      if (c0 + 2 * SCK < cin16) issue(c0 + 2 * SCK);
+    }
+    cur ^= 1;
+  }
+  if (!active) return;
+
+  const float w_unscale = whdr[0];  // 2^-s of the host-side weight scaling
+  float* yb = a.y + (long long)b * a.y_bstride;
+  const float* rb = a.res ? a.res + (long long)b * a.res_bstride : nullptr;
+#pragma unroll
+  for (int n = 0; n < NTW; ++n) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int drow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int dcol = lane & 31;
+      const int co = mt * 32 + (TR ? dcol : drow);
+      const int q = q0 + (wn * NTW + n) * 32 + (TR ? drow : dcol);
+      const int t = q * a.up + p;
+      if (co < a.c_out && q < Tq) {
+        float v = acc[n][r] * w_unscale;
+        if (a.bias) v += a.bias[co];
+        if (a.out_act == 1) v = fmaxf(v, 0.f);
+        else if (a.out_act == 2) v = tanhf(v);
+        else if (a.out_act == 3) v = 1.0f / (1.0f + expf(-v));
+        else if (a.out_act == 5) v = v > 0.f ? v : v * a.out_slope;
+        if (a.post_scale) v = v * a.post_scale[co] + a.post_shift[co];
+        const long long o = TR ? ((long long)t * a.c_out + co) : ((long long)co * a.t_out + t);
+        if (a.out_act == 4) {
+          const float g = a.gate[(long long)b * a.y_bstride + o];
+          v = g * fmaxf(v, 0.f) + (1.f - g) * rb[o];
+        } else if (rb) v += rb[o];
+        v *= a.out_scale;
+        if (a.accumulate) v += yb[o];
+        yb[o] = v;
+      }
+    }
+  }
+}
+
 static int conv_geometry(const mb_conv1d_args* a, ConvK* k) {
   MB_REQUIRE(a->up >= 1 && a->up <= 8, "conv1d: up=%d out of range", a->up);
   MB_REQUIRE(a->ksize >= 1 && a->c_in >= 1 && a->c_out >= 1, "conv1d: bad shape");
@@ -209,9 +401,19 @@ static int conv_geometry(const mb_conv1d_args* a, ConvK* k) {
 
 using namespace mb;
 
-extern "C" size_t mb_conv1d_packed_floats(int c_out, int c_in, int ksize, int up) {
+// image = [fp32 A fragments: n_mt * n_cb * ksize * 256 floats][split header: 64 floats, [0] = 2^-s][split A fragments:
+// n_mt * n_ks * ksize * (hi 512 + lo 512) halves]
+static size_t conv_f32_image_floats(int c_out, int c_in, int ksize) {
   const int n_mt = (c_out + 31) / 32, n_cb = (c_in + 7) / 8;
   return (size_t)n_mt * n_cb * ksize * 256;  // up phases x (ksize/up) taps == ksize
+}
+static size_t conv_split_image_floats(int c_out, int c_in, int ksize) {
+  const int n_mt = (c_out + 31) / 32, n_ks = (c_in + 15) / 16;
+  return (size_t)n_mt * n_ks * ksize * 512;
+}
+extern "C" size_t mb_conv1d_packed_floats(int c_out, int c_in, int ksize, int up) {
+  (void)up;
+  return conv_f32_image_floats(c_out, c_in, ksize) + 64 + conv_split_image_floats(c_out, c_in, ksize);
 }
 
 extern "C" int mb_conv1d_pack(const float* h_w, int c_out, int c_in, int ksize, int up,
@@ -236,6 +438,43 @@ extern "C" int mb_conv1d_pack(const float* h_w, int c_out, int c_in, int ksize, 
                                : h_w[((size_t)co * c_in + ci) * ksize + jj];
               h_packed[o++] = v;
             }
+        }
+  }
+  // ---- split image (conv1d_split_kernel): weights scaled by a power of two so that their low halves are fp16 normals ----
+  const size_t total = (size_t)c_out * c_in * ksize;
+  float wmax = 0.f;
+  for (size_t i = 0; i < total; ++i) wmax = std::max(wmax, std::fabs(h_w[i]));
+  int sexp = 0;
+  if (wmax > 0.f && std::isfinite(wmax)) {
+    int e2;
+    std::frexp(wmax, &e2);            // wmax = f * 2^e2, f in [0.5, 1)
+    sexp = std::max(-24, std::min(40, 14 - e2));  // wmax * 2^sexp in [2^13, 2^14)
+  }
+  const float scale = std::ldexp(1.f, sexp);
+  float* hdr = h_packed + o;
+  for (int i = 0; i < 64; ++i) hdr[i] = 0.f;
+  hdr[0] = std::ldexp(1.f, -sexp);
+  h16* hp = reinterpret_cast<h16*>(hdr + 64);
+  const int n_ks = (c_in + 15) / 16;
+  size_t oh = 0;
+  for (int p = 0; p < up; ++p) {
+    const int j0 = transposed ? (p + pad) % up : 0;
+    for (int mt = 0; mt < n_mt; ++mt)
+      for (int ks = 0; ks < n_ks; ++ks)
+        for (int j = 0; j < ntaps; ++j) {
+          const int jj = transposed ? j0 + j * up : j;
+          for (int part = 0; part < 2; ++part)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int e = 0; e < 8; ++e) {
+                // A fragment of v_mfma_f32_32x32x16_f16: lane l holds A[m = l & 31][k = 8 * (l >> 5) + e]
+                const int co = mt * 32 + (lane & 31);
+                const int ci = ks * 16 + (lane >> 5) * 8 + e;
+                float v = 0.f;
+                if (co < c_out && ci < c_in)
+                  v = (transposed ? h_w[((size_t)ci * c_out + co) * ksize + jj] : h_w[((size_t)co * c_in + ci) * ksize + jj]) * scale;
+                const h16 hi = (h16)v;
+                hp[oh++] = part == 0 ? hi : (h16)(v - (float)hi);
+              }
         }
   }
   return MB_OK;
@@ -266,6 +505,39 @@ extern "C" int mb_conv1d(const mb_conv1d_args* a, mb_stream_t stream) {
   const int n_mt = (a->c_out + 31) / 32;
   const int tq = cdiv(a->t_out, a->up);
   hipStream_t s = (hipStream_t)stream;
+  // ---- split path (error-compensated fp16 MFMA), the default from 16 input channels up ----
+  const char* senv = getenv("MBHIP_CONV_SPLIT");
+  const bool split_off = senv && atoi(senv) == 0;
+  if (!split_off && a->c_in >= 16) {
+    const float* hdr = a->d_wpacked + conv_f32_image_floats(a->c_out, a->c_in, a->ksize);
+    const uint4* wsplit = reinterpret_cast<const uint4*>(hdr + 64);
+    // 128 output positions per workgroup; waves along the output channels when there are enough of them (A fragments are
+    // then reused over 4 position tiles), else along time
+    const int wm = n_mt >= 4 ? 4 : (n_mt >= 2 ? 2 : 1);
+    dim3 grid(cdiv(tq, SNT), cdiv(n_mt, wm), a->batch * a->up);
+    const int rowlen = SNT * k.down + k.span;
+    const size_t lds = (size_t)(k.c_in <= SCK ? 1 : 2) * rowlen * SROW;  // one chunk: no second buffer (more workgroups per CU instead)
+    if (rowlen <= 256) {  // (strided convs with long halos: the fp32-input kernel below)
+      const bool pool = a->in_act == 2;
+#define MB_SLAUNCH2(WM_, WN_, NTW_, TR_)                                                                                          \
+  do {                                                                                                                            \
+    if (pool) hipLaunchKernelGGL((conv1d_split_kernel<WM_, WN_, NTW_, TR_, true>), grid, dim3(256), lds, s, k, wsplit, hdr);      \
+    else hipLaunchKernelGGL((conv1d_split_kernel<WM_, WN_, NTW_, TR_, false>), grid, dim3(256), lds, s, k, wsplit, hdr);          \
+  } while (0)
+#define MB_SLAUNCH(WM_, WN_, NTW_)                                          \
+  do {                                                                      \
+    if (a->transpose_out) MB_SLAUNCH2(WM_, WN_, NTW_, true);                \
+    else MB_SLAUNCH2(WM_, WN_, NTW_, false);                                \
+  } while (0)
+      if (wm == 4) MB_SLAUNCH(4, 1, 4);
+      else if (wm == 2) MB_SLAUNCH(2, 2, 2);
+      else MB_SLAUNCH(1, 4, 1);
+#undef MB_SLAUNCH
+#undef MB_SLAUNCH2
+      MB_HIP(hipGetLastError());
+      return MB_OK;
+    }
+  }
   // wave arrangement: few output channels -> all 4 waves along time.
   const int wm = (n_mt >= 4 && tq <= 64) ? 4 : (n_mt >= 2 ? 2 : 1);
   const int wn = 4 / wm;

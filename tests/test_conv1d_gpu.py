@@ -35,8 +35,38 @@ CONV_CASES = [
 ]
 
 
+@pytest.fixture(params=["split", "f32"])
+def conv_path(request, monkeypatch):
+    """Both conv kernels behind mb_conv1d: the error-compensated fp16 MFMA kernel (default) and the exact fp32-input one."""
+    if request.param == "f32":
+        monkeypatch.setenv("MBHIP_CONV_SPLIT", "0")
+    else:
+        monkeypatch.delenv("MBHIP_CONV_SPLIT", raising=False)
+    return request.param
+
+
+def test_split_kernel_is_fp32_grade(cuda, lib, monkeypatch):
+    """x = xh + xl, w = wh + wl in fp16, three fp16 MFMA products, fp32 accumulate: against a float64 reference the error
+    must be of the size of the fp32-input kernel's own (one rounding per product and sum), not fp16's -- on O(1) data, on
+    data with a wide dynamic range (|x| from 1e-4 to 1e3, small values meet fp16 subnormals in their low halves) and on
+    tiny weights (the host-side power-of-two scaling)."""
+    g = torch.Generator().manual_seed(3)
+    for name, xs, ws in (("unit", 1.0, 1.0), ("wide", None, 1.0), ("tiny_w", 1.0, 1e-4), ("big_x", 300.0, 1.0)):
+        x = torch.randn(2, 256, 300, generator=g)
+        x = x * xs if xs is not None else x * torch.exp(torch.empty(2, 256, 300).uniform_(-9.2, 6.9, generator=g))
+        w = torch.randn(256, 256, 7, generator=g) / (256 * 7) ** 0.5 * ws
+        ref = F.conv1d(x.double(), w.double(), None, padding=3)
+        scale = float(ref.abs().pow(2).mean().sqrt())
+        monkeypatch.delenv("MBHIP_CONV_SPLIT", raising=False)
+        e_split = float((hiputil.conv1d_hip(x, w, None, pad=3).cpu().double() - ref).abs().max()) / scale
+        monkeypatch.setenv("MBHIP_CONV_SPLIT", "0")
+        e_f32 = float((hiputil.conv1d_hip(x, w, None, pad=3).cpu().double() - ref).abs().max()) / scale
+        print(name, "max err / rms: split", e_split, "fp32 kernel", e_f32)
+        assert e_split <= max(4 * e_f32, 2e-6), (name, e_split, e_f32)
+
+
 @pytest.mark.parametrize("B,Cin,Cout,T,k,dil", CONV_CASES)
-def test_conv1d_same(cuda, lib, B, Cin, Cout, T, k, dil):
+def test_conv1d_same(cuda, lib, conv_path, B, Cin, Cout, T, k, dil):
     x = _rand(B, Cin, T, seed=1)
     w = _rand(Cout, Cin, k, seed=2) / (Cin * k) ** 0.5
     b = _rand(Cout, seed=3)
