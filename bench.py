@@ -632,6 +632,23 @@ def main():
                          if model.last_loop_launches == 1 else "5-launch chain, hipGraph replays"),
             }
             del su, wu
+        # ---- secondary: MOL mode (hparams voc_mode = 'MOL': 30 fc3 outputs, mixture-of-logistics sampler) on the production chain
+        if not args.no_wavernn_unbatched:
+            import types
+            from mockingbird_amd.vocoder.wavernn import hparams as whp
+            hpm = types.SimpleNamespace(**{k_: getattr(whp, k_) for k_ in dir(whp) if not k_.startswith("_")})
+            hpm.voc_mode = "MOL"
+            mol = WaveRNNDevice(synth.wavernn_state(synth.WAVERNN_HP_MOL, seed=6)["model_state"], hpm)
+            mol.generate_samples(mel[:, :60], True, 2000, 200, seed=1)
+            sm = mol.generate_samples(mel, True, target, overlap, seed=2)
+            torch.cuda.synchronize()
+            result["wavernn_mol"] = {
+                "workload": f"MOL-mode WaveRNN, mel 80x{F}, batched: {mol.last_plan.n_folds} folds x {mol.last_plan.seq_len} steps; 5-launch chain "
+                            "with fc3 + sample_from_discretized_mix_logistic fused in one launch (wf_fc3_mol_kernel)",
+                "sample_loop_ms": mol.last_loop_ms, "us_per_time_step": mol.last_loop_ms * 1e3 / mol.last_plan.seq_len,
+                "loop_launches": mol.last_loop_launches,
+                "value": sm.numel() / (mol.last_loop_ms * 1e-3), "unit": "fold samples/s (loop only)"}
+            del mol, sm
         # ---- secondary: WaveRNN throughput mode -- north_star's "batch-32 synthetic input": 32 utterances of
         # mel 80x{F} share ONE sample loop (736 fold columns instead of 23 per launch)
         if not args.no_wavernn_batch:

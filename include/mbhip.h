@@ -344,6 +344,9 @@ int mb_wavernn_finish(const float* d_samples, int n_folds, int seq_len, int batc
  * mb_wavernn_generate(d_noise = NULL, seed) samples with its fused Gumbel-argmax (argmax(l - log E)).
  * For mb_wavernn_generate_batch, `folds` is utterance u's own fold count and seed = h_seeds[u]. */
 int mb_wavernn_debug_noise(uint64_t seed, int step0, int steps, int folds, int n_classes, float* d_out, mb_stream_t stream);
+/* MOL mode: d_out [steps][folds][nr_mix + 1] = the uniform(1e-5, 1 - 1e-5) draws of the on-device mixture sampler, in the layout
+ * mb_wavernn_generate takes as d_noise for a MOL model. */
+int mb_wavernn_debug_noise_mol(uint64_t seed, int step0, int steps, int folds, int nr_mix, float* d_out, mb_stream_t stream);
 int mb_wavernn_last_loop_ms(const mb_wavernn* w, float* ms, int* launches);
 /* Measurement hook (bench.py roofline leg): runs the real generate loop twice on its
  * stream, bracketed by hipEvents, with and without kernel `which` (0 rnn1 GRU, 1 rnn2 GRU,

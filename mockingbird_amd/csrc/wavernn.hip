@@ -96,9 +96,9 @@ __global__ __launch_bounds__(128) void wavernn_init_kernel(SampK a) {
 }
 
 // fused-sampling path: the sample of the LAST step is still only an argmax word; decode it.
-__global__ void wavernn_flush_kernel(const unsigned long long* slot, float* samples, int N, int S, int C) {
+__global__ void wavernn_flush_kernel(const unsigned long long* slot, float* samples, int N, int S, int C, int mol) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n < N) samples[(size_t)n * S + (S - 1)] = slot[n] ? 2.f * (float)argmax_class(slot[n]) / ((float)C - 1.f) - 1.f : 0.f;
+  if (n < N) samples[(size_t)n * S + (S - 1)] = !slot[n] ? 0.f : mol ? __uint_as_float((unsigned)slot[n]) : 2.f * (float)argmax_class(slot[n]) / ((float)C - 1.f) - 1.f;
 }
 
 // step_base += n (last node of every graph replay / after every eager step)
@@ -714,9 +714,13 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
   }
   // Production path (no injected noise / teacher forcing / logits dump): the sampler is fused into the
   // fc3 launch and the next step's input is rebuilt from the argmax word -> 5 launches per step.
-  // (MOL mode, fatchord_version.py:213-220, runs the exact 6-launch chain with its own sampler kernel: the fused Gumbel-argmax
-  // epilogue and the split-hidden chain decode a CLASS from the argmax word, a MOL sample is a real number)
-  const bool fused = !d_noise && !d_forced && !d_logits_out && getenv("MBHIP_WAVERNN_NOFUSE") == nullptr && c.mode == 0;
+  // MOL mode: the fused form exists on the fragment-major chain only (wf_fc3_mol_kernel: fc3 + the mixture sampler in one launch,
+  // the sample itself in the slot word); every other configuration of a MOL model keeps the exact 6-launch chain.
+  const bool mol_fast = c.mode == 1 && R == 512 && FC == 512 && C <= 32 && N <= 64 && wavernn_split_chain() &&
+                        !(getenv("MBHIP_WAVERNN_FAST") && atoi(getenv("MBHIP_WAVERNN_FAST")) == 0) &&
+                        !(getenv("MBHIP_WAVERNN_LANES") && atoi(getenv("MBHIP_WAVERNN_LANES")) > 1) && !getenv("MBHIP_WAVERNN_MERGE") &&
+                        !getenv("MBHIP_WAVERNN_NT2");
+  const bool fused = !d_noise && !d_forced && !d_logits_out && getenv("MBHIP_WAVERNN_NOFUSE") == nullptr && (c.mode == 0 || mol_fast);
   const bool split = fused && wavernn_split_chain();
   // MBHIP_WAVERNN_MERGE=1 (experiment, off): fc3 + the next step's elementwise rnn1 in ONE launch (4 per
   // step) through an in-launch arrival counter.  Measured on MI355X (profiles/r01_wavernn_chain_ab.json):
@@ -727,7 +731,7 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
   // (wavernn_fast.h), bit-identical sample stream.  MBHIP_WAVERNN_FAST=0 keeps the rnn_rowtile_body instances.
   const char* fenv = getenv("MBHIP_WAVERNN_FAST");
   const char* lenv = getenv("MBHIP_WAVERNN_LANES");
-  const bool fastk = split && !merged && R == 512 && FC == 512 && C % 16 == 0 && N <= 64 && !(fenv && atoi(fenv) == 0) &&
+  const bool fastk = split && !merged && R == 512 && FC == 512 && (C % 16 == 0 || c.mode == 1) && N <= 64 && !(fenv && atoi(fenv) == 0) &&
                      !(lenv && atoi(lenv) > 1) && getenv("MBHIP_WAVERNN_NT2") == nullptr;
   const int nta = cdiv(N, 16);
   int fnt = 2;  // fold-column tiles per workgroup of the fast chain
@@ -776,7 +780,7 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
   // NOTE: a resident launch makes this call host-blocking (the abort word has to be looked at before returning).
   const char* penv = getenv("MBHIP_WAVERNN_PERSIST");
   const char* qenv = getenv("MBHIP_WAVERNN_PIPE");
-  const bool resident_ok = fastk && C <= 512 && !w->bench_which && !w->bench_chain && !getenv("MBHIP_TRACE_FILE") && !getenv("MBHIP_WF_DBG_WHICH");
+  const bool resident_ok = fastk && c.mode == 0 && C <= 512 && !w->bench_which && !w->bench_chain && !getenv("MBHIP_TRACE_FILE") && !getenv("MBHIP_WF_DBG_WHICH");
   const bool persist_asked = penv && atoi(penv) == 1 && N <= WP_NCOL;  // MBHIP_WAVERNN_PERSIST=1 keeps meaning wavernn_persist.h
   bool pipe = resident_ok && N >= 2 && N <= WQ_G * WQ_GC && (qenv ? atoi(qenv) != 0 : (WQ_DEFAULT_ON != 0 && !persist_asked));
   bool persist = resident_ok && !pipe && N <= WP_NCOL && (penv ? atoi(penv) != 0 : N == 1);
@@ -934,7 +938,7 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
         f.stage.T1 = L.T1; f.stage.Ipre = L.Ipre; f.stage.Tq = reinterpret_cast<float4*>(L.f_Tq) + (size_t)(pp ^ 1) * tqn; f.stage.R = R; f.stage.step_add = 1;
         f.n_fin = R / 16;
         f.g1 = w->g1I0.p; f.wI0 = w->wI0.p; f.h1 = L.f_h1; f.x1 = L.f_x1; f.samples = d_samples; f.progress = h_progress;
-        f.R = R; f.C = C; f.S = S;
+        f.R = R; f.C = C; f.S = S; f.mol = c.mode == 1 ? 1 : 0;
         hipLaunchKernelGGL(wf_finish_kernel, dim3(R / 16 + cdiv((R / 4) * nta, 4), nta), dim3(256), 0, ls, f);
       }
       if (which & 2) {
@@ -946,7 +950,12 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
       }
       if (which & 4) fc_hh(0, FC / 16, soff, ls);
       if (which & 8) fc_hh(1, FC / 16, soff, ls);
-      if (which & 16) {
+      if ((which & 16) && c.mode == 1) {
+        WfFc3MolK km;
+        km.g = wg; km.g.step_off = soff; km.w = w->w_fc3.p; km.bias = w->b_fc3.p; km.xin = L.f_y2; km.slot = slot_cur; km.seed = seed; km.C = C; km.nr_mix = C / 3;
+        if (fnt == 2) hipLaunchKernelGGL(wf_fc3_mol_kernel<2>, dim3(1, cdiv(nta, 2)), dim3(512), 0, ls, km);
+        else hipLaunchKernelGGL(wf_fc3_mol_kernel<1>, dim3(1, nta), dim3(512), 0, ls, km);
+      } else if (which & 16) {
         WfFc3K k3;
         k3.g = wg; k3.g.step_off = soff; k3.w = w->w_fc3.p; k3.bias = w->b_fc3.p; k3.xin = L.f_y2; k3.slot = slot_cur; k3.seed = seed; k3.C = C;
         if (fnt == 2) hipLaunchKernelGGL(wf_fc3_kernel<2>, dim3(C / 16, cdiv(nta, 2)), dim3(512), 0, ls, k3);
@@ -1139,7 +1148,7 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
     for (int l = 0; l < lanes; ++l) {
       const int n0 = lane_n0[l], nl = lane_n0[l + 1] - n0;
       hipLaunchKernelGGL(wavernn_flush_kernel, dim3(cdiv(nl, 64)), dim3(64), 0, w->lane_stream[l],
-                         L.slots + (size_t)((S - 1) & 1) * N + n0, d_samples + (size_t)n0 * S, nl, S, C);
+                         L.slots + (size_t)((S - 1) & 1) * N + n0, d_samples + (size_t)n0 * S, nl, S, C, c.mode == 1 ? 1 : 0);
     }
     MB_HIP(hipGetLastError());
   }
@@ -1410,7 +1419,7 @@ static int wavernn_generate_batch_impl(const mb_wavernn* wc, const mb_wavernn_ba
   }
   for (int i = done; i < S && !rc; ++i) rc = step(i & 1, i - done);
   if (rc) return rc;
-  hipLaunchKernelGGL(wavernn_flush_kernel, dim3(cdiv(N, 64)), dim3(64), 0, s, L.slots + (size_t)((S - 1) & 1) * N, d_samples, N, S, C);
+  hipLaunchKernelGGL(wavernn_flush_kernel, dim3(cdiv(N, 64)), dim3(64), 0, s, L.slots + (size_t)((S - 1) & 1) * N, d_samples, N, S, C, 0);
   MB_HIP(hipGetLastError());
   MB_HIP(hipEventRecord(w->ev_t1, s));
   w->last_launches = 5 * S; w->last_lanes = 1; w->timed = true;
@@ -1454,6 +1463,29 @@ extern "C" int mb_wavernn_debug_noise(uint64_t seed, int step0, int steps, int f
   return MB_OK;
 }
 
+// the same hook for MOL mode: the uniform_(1e-5, 1 - 1e-5) draws [step][fold][nr_mix + 1] (nr_mix mixture-indicator draws, then
+// the logistic draw) of wavernn_sample_mol_kernel / wf_fc3_mol_kernel: Philox(counter = (step, fold, m / 4, 'MOL!'), key = seed), word m % 4
+__global__ void wavernn_debug_noise_mol_kernel(unsigned long long seed, int step0, int steps, int folds, int nr_mix, float* out) {
+  const int W = nr_mix + 1;
+  const size_t total = (size_t)steps * folds * W;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(idx % W);
+    const size_t r = idx / W;
+    const int n = (int)(r % folds), s = step0 + (int)(r / folds);
+    uint32_t g[4];
+    mb::philox4x32((uint32_t)s, (uint32_t)n, (uint32_t)(m >> 2), 0x4d4f4c21u, (uint32_t)seed, (uint32_t)(seed >> 32), g);
+    out[idx] = 1e-5f + (1.0f - 2e-5f) * mb::u32_to_unit(g[m & 3]);
+  }
+}
+extern "C" int mb_wavernn_debug_noise_mol(uint64_t seed, int step0, int steps, int folds, int nr_mix, float* d_out, mb_stream_t stream) {
+  MB_REQUIRE(d_out && steps >= 1 && folds >= 1 && step0 >= 0 && nr_mix >= 1 && nr_mix <= 63, "wavernn_debug_noise_mol: bad arguments");
+  const size_t total = (size_t)steps * folds * (nr_mix + 1);
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL(wavernn_debug_noise_mol_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (unsigned long long)seed, step0, steps, folds,
+                     nr_mix, d_out);
+  MB_HIP(hipGetLastError());
+  return MB_OK;
+}
 extern "C" int mb_wavernn_last_loop_ms(const mb_wavernn* w, float* ms, int* launches) {
   MB_REQUIRE(w && ms, "wavernn_last_loop_ms: null pointer");
   if (!w->timed) { set_error("wavernn_last_loop_ms: no generate call yet"); return MB_ESTATE; }

@@ -61,6 +61,7 @@ struct WfFinK {
   float* h1; float* x1;            // FM (h1 updated in place)
   float* samples; volatile int* progress;
   int R, C, S;
+  int mol;  // MOL mode: the slot holds the sample itself (wf_fc3_mol_kernel), not a packed argmax
   WfStageK stage; int n_fin;  // blockIdx.x >= n_fin (blockIdx.y == 0): stage the NEXT step's table rows into stage.Tq (other buffer)
 };
 __global__ __launch_bounds__(256) void wf_finish_kernel(WfFinK a) {
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) void wf_finish_kernel(WfFinK a) {
   const float gr = a.g1[j], gz = a.g1[H + j], gn = a.g1[2 * H + j], w0 = a.wI0[j];
   const unsigned long long slot = a.slot[n];
   if (n_raw >= a.g.N) return;
-  const float x = slot ? 2.f * (float)argmax_class(slot) / ((float)a.C - 1.f) - 1.f : 0.f;
+  const float x = !slot ? 0.f : a.mol ? __uint_as_float((unsigned)slot) : 2.f * (float)argmax_class(slot) / ((float)a.C - 1.f) - 1.f;
   // torch GRUCell, gate order (r, z, n)
   const float rg = sigmoidf_((tr + x * gr) + hq.x);
   const float zg = sigmoidf_((tz + x * gz) + hq.y);
@@ -201,6 +202,62 @@ __global__ __launch_bounds__(512) void wf_fc3_kernel(WfFc3K a) {
   const unsigned long long o2 = __shfl_xor(pk, 32, 64);
   pk = o2 > pk ? o2 : pk;
   if (du == 0) atomicMax(a.slot + n, pk);
+}
+
+// ---------------------------------------------------------------------------------------------- E (MOL mode): fc3 + mixture-of-logistics sampler
+//   fc3 has 3 * nr_mix = 30 outputs (mixture logits | means | log scales; fatchord_version.py:95-98, :213-220): ONE workgroup
+//   per column-tile group multiplies both 16-row tiles, leaves the 30 values of every column in LDS, and one lane per column
+//   runs sample_from_discretized_mix_logistic (models/vocoder/distribution.py:87-123) with the draws and the expressions of
+//   wavernn_sample_mol_kernel (wavernn.hip) -- the stand-alone sampler of the 6-launch path, which it equals bit for bit.
+//   slot[fold] = marker << 32 | float bits of the sample (the finish launch feeds it back: mol = 1).
+struct WfFc3MolK {
+  WfGeom g;
+  const float* w; const float* bias; const float* xin; unsigned long long* slot; unsigned long long seed; int C, nr_mix;
+};
+template <int NT>
+__global__ __launch_bounds__(512) void wf_fc3_mol_kernel(WfFc3MolK a) {
+  __shared__ __attribute__((aligned(16))) float red[FmRed<NT, 1>::floats];
+  __shared__ float lg[NT * 16][33];
+  const int nt0 = blockIdx.y * NT;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, du = lane >> 4, i = lane & 15;
+  const int s = *a.g.step_base + a.g.step_off;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    float sx[4], sh[4];
+    if (fm_gemm<NT, 4, 4, 4, 1>(a.w, mt, a.xin, a.xin, a.g.nta, nt0, red, sx, sh)) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = mt * 16 + du * 4 + r;
+        lg[wv * 16 + i][row] = sx[r] + (row < a.C ? a.bias[row] : 0.f);
+      }
+    }
+    __syncthreads();  // red is free for the second tile; lg complete after it
+  }
+  if ((int)threadIdx.x >= NT * 16) return;
+  const int nt = nt0 + ((int)threadIdx.x >> 4), n = nt * 16 + ((int)threadIdx.x & 15);
+  if (nt >= a.g.nta || n >= a.g.N) return;
+  const float* l = lg[threadIdx.x];
+  const int M = a.nr_mix;
+  float best = -INFINITY, uu = 0.5f;
+  int bidx = 0;
+  for (int q = 0; q <= M / 4; ++q) {  // draws 0 .. M: M mixture-indicator uniforms, then the logistic one (word m & 3 of call m >> 2)
+    uint32_t r[4];
+    philox4x32((uint32_t)s, (uint32_t)n, (uint32_t)q, 0x4d4f4c21u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int m = q * 4 + e;
+      const float u = 1e-5f + (1.0f - 2e-5f) * u32_to_unit(r[e]);  // uniform_(1e-5, 1 - 1e-5)
+      if (m < M) {
+        const float v = l[m] - logf(-logf(u));
+        if (v > best) { best = v; bidx = m; }  // first maximum on ties
+      } else if (m == M) uu = u;
+    }
+  }
+  const float mean = l[M + bidx];
+  const float ls = fmaxf(l[2 * M + bidx], -32.23619130191664f);  // log(1e-14)
+  float x = mean + expf(ls) * (logf(uu) - logf(1.f - uu));
+  x = fminf(fmaxf(x, -1.f), 1.f);
+  a.slot[n] = (0x80000000ull << 32) | (unsigned long long)__float_as_uint(x);
 }
 
 }  // namespace mb

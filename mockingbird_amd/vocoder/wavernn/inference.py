@@ -105,13 +105,15 @@ class WaveRNNDevice:
 
     def sampler_noise(self, seed, steps, folds, step0=0):
         """Test hook (mb_wavernn_debug_noise): the Exp(1) draws the on-device sampler of the production paths consumes
-        for `seed` -> CUDA tensor [steps, folds, n_classes]; handed to the oracle's sample loop as `noise`, it makes
-        the oracle sample what generate_samples(seed=seed) samples (RAW mode)."""
-        if self.cfg.mode != 0:
-            raise _lib.MbHipError("sampler_noise: RAW mode only")
-        out = torch.empty(steps, folds, self.n_classes, dtype=torch.float32, device="cuda")
-        _lib.check(_lib.lib().mb_wavernn_debug_noise(int(seed), int(step0), int(steps), int(folds), self.n_classes,
-                                                     _lib.ptr(out), _lib.stream_ptr()), "mb_wavernn_debug_noise")
+        for `seed` -> CUDA tensor [steps, folds, n_classes] (RAW: Exp(1) words; MOL: [steps, folds, 11] uniforms); handed to
+        the oracle's sample loop as `noise`, it makes the oracle sample what generate_samples(seed=seed) samples."""
+        out = torch.empty(steps, folds, self.noise_width, dtype=torch.float32, device="cuda")
+        if self.cfg.mode != 0:  # MOL: the uniform draws (mixture indicators, then the logistic one)
+            _lib.check(_lib.lib().mb_wavernn_debug_noise_mol(int(seed), int(step0), int(steps), int(folds), self.noise_width - 1,
+                                                         _lib.ptr(out), _lib.stream_ptr()), "mb_wavernn_debug_noise_mol")
+        else:
+            _lib.check(_lib.lib().mb_wavernn_debug_noise(int(seed), int(step0), int(steps), int(folds), self.n_classes,
+                                                         _lib.ptr(out), _lib.stream_ptr()), "mb_wavernn_debug_noise")
         torch.cuda.current_stream().synchronize()
         return out
 
