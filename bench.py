@@ -654,7 +654,7 @@ def main():
         if not args.no_wavernn_batch:
             nb = 32
             bm = [torch.from_numpy(synth.wavernn_mel(F, seed=100 + u) / 4.0).to(dev) for u in range(nb)]
-            model.generate_samples_batch(bm, target, overlap, list(range(nb)))  # untimed: allocates the 53 GB of tables
+            model.generate_samples_batch(bm, target, overlap, list(range(nb)))  # untimed: allocates the workspace
             torch.cuda.synchronize()
             t0b = time.perf_counter()
             outs = model.generate_samples_batch(bm, target, overlap, list(range(nb)))

@@ -56,8 +56,8 @@ struct RnnK {
   // word the previous launch has just written except the activations themselves.
   const int* fr_base; int fr_off, fr_n_off, fr_fold_stride, fr_total_len, fr_hop, fr_frames;
   // Several utterances in one loop (mb_wavernn_generate_batch): per-fold descriptors replace the arithmetic
-  // above.  fr_desc[(fr_n_off + n) * 8 + ..] = {pos0, total_len_u, pos_row_base, frame_row_base, frames_u,
-  // local fold index, seed lo, seed hi}:  pos = pos0 + s; position-table row = pos_row_base + min(pos, total_len_u);
+  // above.  fr_desc[(fr_n_off + n) * 8 + ..] = {pos0, total_len_u, first row of the utterance in the U tables (WfCond), frame_row_base, frames_u,
+  // local fold index, seed lo, seed hi}:  pos = pos0 + s (zero conditioning from total_len_u on);
   // frame-table row = frame_row_base + (pos < total_len_u ? pos / fr_hop : frames_u); the Gumbel noise of fold n
   // is Philox(seed_u; s, local fold, class/4) -- exactly what utterance u alone with seed_u would draw.
   const int* fr_desc;
@@ -135,6 +135,57 @@ void pack_rowtile(const float* rows, int n_live_rows, int K, int RL, std::vector
 void cell_rows(const float* w_ih, int kx, int ldx, const float* w_hh, int kh, int H, int G,
                std::vector<float>* rows);
 
+// Per-FRAME conditioning tables of the WaveRNN loop (round 3: they replace the per-position Ipre / T1 tables, 8.2 KB per output
+// sample -> 8 KB per mel frame).  I([x, m_t, a1_t]) is affine in the conditioning; the upsampled mel m_t (UpsampleNetwork: three
+// stretch + box-filter stages, fatchord_version.py:60-85) is a fixed linear combination of 5 neighbouring mel frames with weights
+// that depend on t mod hop only (Kw[hop][5], computed at create time by pushing an impulse through the stages); a1_t is constant
+// over a frame.  So for position t = hop f + p:
+//   Ipre[t] = AI[f] + sum_o Kw[p][o] UI[f + o - 2]     UI[f] = W_I[:, 1:1+feat] mel_f,   AI[f] = W_I[:, 1+feat:] a1_f + b_I
+//   T1[t]   = AT[f] + sum_o Kw[p][o] UT[f + o - 2]     (the same with W_ih1 folded in, gate-major rows)
+// evaluated as ONE fmaf chain (aux/bias term first, then o = 0..4) by every consumer: all loop variants see the same bits.
+// Rows: U* [frames + 9] (2 zero rows, the frames, 7 zero rows: fold_with_overlap's zero padding and the sequence ends),
+//       A* [frames + 1] (row `frames` = the zero-conditioning row: the bias alone).
+struct WfCond {
+  const float* UT; const float* AT; const float* UI; const float* AI; const float* Kw;
+  int hop, frames;
+};
+// (T1[pos][r, z, n], Ipre[pos]) of unit j; pos >= total_len = zero conditioning.  u_row0 / a_row0: first row of this utterance's
+// block in concatenated tables (batch loop).
+__device__ __forceinline__ float4 wf_cond_row4(const WfCond& c, const unsigned pos, const unsigned total_len, const int j, const int H,
+                                               const int frames, const long long u_row0 = 0, const long long a_row0 = 0) {
+  const bool live = pos < total_len;
+  const unsigned f = live ? pos / (unsigned)c.hop : (unsigned)frames + 4u;   // dead: five zero rows
+  const unsigned p = live ? pos - f * (unsigned)c.hop : 0u;
+  const long long fa = a_row0 + (live ? (long long)f : (long long)frames);
+  const float* kw = c.Kw + p * 5;
+  const float* at = c.AT + fa * 3 * H + j;
+  float4 acc = make_float4(at[0], at[H], at[2 * H], c.AI[fa * H + j]);
+  const float* ut = c.UT + (u_row0 + f) * 3 * H + j;   // row f = frame f - 2
+  const float* ui = c.UI + (u_row0 + f) * H + j;
+#pragma unroll
+  for (int o = 0; o < 5; ++o) {
+    const float k = kw[o];
+    acc.x = fmaf(k, ut[(size_t)o * 3 * H], acc.x);
+    acc.y = fmaf(k, ut[(size_t)o * 3 * H + H], acc.y);
+    acc.z = fmaf(k, ut[(size_t)o * 3 * H + 2 * H], acc.z);
+    acc.w = fmaf(k, ui[(size_t)o * H], acc.w);
+  }
+  return acc;
+}
+// Ipre[pos][j] alone (the exact 6-launch chain feeds I(..) itself to rnn1)
+__device__ __forceinline__ float wf_cond_ipre(const WfCond& c, const unsigned pos, const unsigned total_len, const int j, const int H,
+                                              const int frames) {
+  const bool live = pos < total_len;
+  const unsigned f = live ? pos / (unsigned)c.hop : (unsigned)frames + 4u;
+  const unsigned p = live ? pos - f * (unsigned)c.hop : 0u;
+  const float* kw = c.Kw + p * 5;
+  float acc = c.AI[(size_t)(live ? f : (unsigned)frames) * H + j];
+  const float* ui = c.UI + (size_t)f * H + j;
+#pragma unroll
+  for (int o = 0; o < 5; ++o) acc = fmaf(kw[o], ui[(size_t)o * H], acc);
+  return acc;
+}
+
 // WaveRNN split-hidden chain, rnn1 of a step as an ELEMENTWISE job (wavernn.hip header):
 //   h1 = GRUCell(I([x, m_t, a1_t]), h1); x1 = I(..) + h1   (fatchord_version.py:195-198) with
 //   i_g = T1[pos][g] + x * g1[g]      T1 = W_ih1.(W_I[:,1:].[m;a1] + b_I) + b_ih1,  g1 = W_ih1.W_I[:,0]
@@ -142,7 +193,7 @@ void cell_rows(const float* w_ih, int kx, int ldx, const float* w_hh, int kh, in
 // x is decoded from the argmax word of the previous step's fc3 launch (0 = no sample yet -> x = 0).
 struct Fin1K {
   const unsigned long long* slot;  // [nl]
-  const float* T1; const float* Ipre; const float* P1; const float* g1; const float* wI0; const float* h_prev;
+  WfCond cond; const float* P1; const float* g1; const float* wI0; const float* h_prev;
   float* h_out; float* x_out; float* samples; volatile int* progress;
   const int* step_base; int step_off, n_off, nl, R, C, S, fold_stride, total_len;
   const int* desc;  // optional per-fold descriptors (RnnK::fr_desc layout)

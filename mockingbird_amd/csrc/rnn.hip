@@ -33,19 +33,15 @@ __device__ __forceinline__ void gru1_finish_body(const Fin1K& a, const int block
   const float* p1 = a.P1 + (size_t)n * 3 * H + j;
   const float hr = p1[0], hz = p1[H], hn = p1[2 * H];
   const float hp = a.h_prev[(size_t)n * H + j];
-  unsigned pos;
-  if (a.desc) {  // several utterances: row = pos_row_base + min(pos0 + s, total_len_u)
+  float4 tq;
+  if (a.desc) {  // several utterances: (pos0 of the fold, total_len_u, first U row, first A row, frames_u, ...)
     const int4 d0 = *reinterpret_cast<const int4*>(a.desc + (size_t)(a.n_off + n) * 8);
-    pos = (unsigned)(d0.x + s);
-    if (pos > (unsigned)d0.y) pos = (unsigned)d0.y;
-    pos += (unsigned)d0.z;
+    const int frames_u = a.desc[(size_t)(a.n_off + n) * 8 + 4];
+    tq = wf_cond_row4(a.cond, (unsigned)(d0.x + s), (unsigned)d0.y, j, H, frames_u, d0.z, d0.w);
   } else {
-    pos = (unsigned)(a.n_off + n) * (unsigned)a.fold_stride + (unsigned)s;
-    if (pos > (unsigned)a.total_len) pos = (unsigned)a.total_len;  // zero-conditioning row
+    tq = wf_cond_row4(a.cond, (unsigned)(a.n_off + n) * (unsigned)a.fold_stride + (unsigned)s, (unsigned)a.total_len, j, H, a.cond.frames);
   }
-  const float* t1 = a.T1 + (size_t)pos * 3 * H + j;
-  const float tr = t1[0], tz = t1[H], tn = t1[2 * H];
-  const float ip = a.Ipre[(size_t)pos * H + j];
+  const float tr = tq.x, tz = tq.y, tn = tq.z, ip = tq.w;
   const float gr = a.g1[j], gz = a.g1[H + j], gn = a.g1[2 * H + j], w0 = a.wI0[j];
   unsigned long long slot;
   if (WAIT) {

@@ -6,8 +6,10 @@
 //
 // Loop restructuring (all exact algebra, fp32 throughout):
 //   * I([x_prev, m_t, a1_t]) = W_I[:,0]*x_prev + (W_I[:,1:].[m_t;a1_t] + b_I): the
-//     second term does not depend on the recurrence, so it is one MFMA GEMM
-//     over all conditioning positions before the loop (table Ipre, time-major).
+//     second term does not depend on the recurrence.  The upsampled mel m_t is a fixed 5-tap
+//     combination of neighbouring mel frames and a1_t is constant over a frame, so the term is
+//     rebuilt per position from per-FRAME tables (rnn.h WfCond / wf_cond_row4: 8 KB per mel frame
+//     instead of a per-position table of 8.2 KB per output sample).
 //   * the aux columns of rnn2 / fc1 / fc2 (a2,a3,a4 are constant over the 200
 //     samples of a mel frame) become per-FRAME tables G2pre/F1pre/F2pre with
 //     the biases folded in.  One extra all-zero conditioning row stands for
@@ -75,7 +77,7 @@ struct SampK {
   int n_off, N_total;   // this lane covers folds [n_off, n_off + gridDim.x)
   int C, S, R;
   int fold_stride, total_len, hop, frames;
-  const float* Ipre;    // [(total_len+1)][R]
+  WfCond cond;          // per-frame conditioning tables (rnn.h): Ipre[pos] is rebuilt from them
   const float* wI0;     // [R]
   float* x0;            // [n][R] (lane-local)
   volatile int* progress;
@@ -84,15 +86,20 @@ struct SampK {
 
 // x0 / table row for lane-local fold n at step s1 with fed-back sample xfb (:192-195 + fold indexing :334-336)
 __device__ __forceinline__ void prep_step(const SampK& a, int n, int s1, float xfb, int tid, int nthreads) {
-  const long long pos = (long long)(a.n_off + n) * a.fold_stride + s1;
-  const bool livep = pos < a.total_len;
-  const long long ipos = livep ? pos : a.total_len;
-  const float* ip = a.Ipre + ipos * a.R;
-  for (int j = tid; j < a.R; j += nthreads) a.x0[(size_t)n * a.R + j] = ip[j] + xfb * a.wI0[j];
+  const unsigned pos = (unsigned)(a.n_off + n) * (unsigned)a.fold_stride + (unsigned)s1;
+  for (int j = tid; j < a.R; j += nthreads)
+    a.x0[(size_t)n * a.R + j] = wf_cond_ipre(a.cond, pos, (unsigned)a.total_len, j, a.R, a.frames) + xfb * a.wI0[j];
 }
 
 __global__ __launch_bounds__(128) void wavernn_init_kernel(SampK a) {
   prep_step(a, blockIdx.x, 0, 0.f, threadIdx.x, blockDim.x);
+}
+
+// MBHIP_WAVERNN_CHAIN=classic only: its rnn1 launch reads the Ipre rows as a GEMM operand -> materialise them ([total_len + 1][R])
+__global__ void wavernn_materialize_ipre_kernel(WfCond c, int total_len, int R, float* out) {
+  const size_t total = (size_t)(total_len + 1) * R;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x)
+    out[idx] = wf_cond_ipre(c, (unsigned)(idx / R), (unsigned)total_len, (int)(idx % R), R, c.frames);
 }
 
 // fused-sampling path: the sample of the LAST step is still only an argmax word; decode it.
@@ -123,17 +130,15 @@ __global__ __launch_bounds__(64) void wavernn_sample_kernel(SampK a) {
   for (int q = 0; q < C4; ++q) v[q] = *reinterpret_cast<const float4*>(lg + (q * 64 + lane) * 4);
   const int s = *a.step_base + a.step_off;
   // next step's input row: position known from s alone (fold indexing :334-336)
-  const long long pos = (long long)gn * a.fold_stride + (s + 1);
-  const bool livep = pos < a.total_len;
-  const long long ipos = livep ? pos : a.total_len;
-  const float* ip = a.Ipre + ipos * a.R;
+  const unsigned pos = (unsigned)gn * (unsigned)a.fold_stride + (unsigned)(s + 1);
   constexpr int R4MAX = 4;  // R <= 1024
   float4 ipv[R4MAX], w0v[R4MAX];
 #pragma unroll
   for (int q = 0; q < R4MAX; ++q) {
     const int j = (q * 64 + lane) * 4;
     const int jc = j < a.R ? j : 0;
-    ipv[q] = *reinterpret_cast<const float4*>(ip + jc);
+    ipv[q] = make_float4(wf_cond_ipre(a.cond, pos, (unsigned)a.total_len, jc, a.R, a.frames), wf_cond_ipre(a.cond, pos, (unsigned)a.total_len, jc + 1, a.R, a.frames),
+                         wf_cond_ipre(a.cond, pos, (unsigned)a.total_len, jc + 2, a.R, a.frames), wf_cond_ipre(a.cond, pos, (unsigned)a.total_len, jc + 3, a.R, a.frames));
     w0v[q] = *reinterpret_cast<const float4*>(a.wI0 + jc);
   }
   const size_t nb = ((size_t)s * a.N_total + gn) * a.C;
@@ -214,16 +219,15 @@ __global__ __launch_bounds__(64) void wavernn_sample_mol_kernel(SampK a, int nr_
   const int gn = a.n_off + n;
   const float lg = lane < a.C ? a.logits[(size_t)n * a.C + lane] : 0.f;
   const int s = *a.step_base + a.step_off;
-  const long long pos = (long long)gn * a.fold_stride + (s + 1);
-  const long long ipos = pos < a.total_len ? pos : a.total_len;
-  const float* ip = a.Ipre + ipos * a.R;
+  const unsigned pos = (unsigned)gn * (unsigned)a.fold_stride + (unsigned)(s + 1);
   constexpr int R4MAX = 4;  // R <= 1024
   float4 ipv[R4MAX], w0v[R4MAX];
 #pragma unroll
   for (int q = 0; q < R4MAX; ++q) {
     const int j = (q * 64 + lane) * 4;
     const int jc = j < a.R ? j : 0;
-    ipv[q] = *reinterpret_cast<const float4*>(ip + jc);
+    ipv[q] = make_float4(wf_cond_ipre(a.cond, pos, (unsigned)a.total_len, jc, a.R, a.frames), wf_cond_ipre(a.cond, pos, (unsigned)a.total_len, jc + 1, a.R, a.frames),
+                         wf_cond_ipre(a.cond, pos, (unsigned)a.total_len, jc + 2, a.R, a.frames), wf_cond_ipre(a.cond, pos, (unsigned)a.total_len, jc + 3, a.R, a.frames));
     w0v[q] = *reinterpret_cast<const float4*>(a.wI0 + jc);
   }
   float u;
@@ -287,13 +291,15 @@ struct mb_wavernn {
   std::vector<CondConv> res1, res2;
   std::vector<DevBuf> up_w;
   // tables
-  CondConv t_I, t_g2, t_f1, t_f2;  // 1x1 convs producing Ipre / G2pre / F1pre / F2pre
+  CondConv t_g2, t_f1, t_f2;  // 1x1 convs producing the per-frame tables G2pre / F1pre / F2pre
+  // per-frame tables of the position-dependent terms (rnn.h WfCond): mel part (no bias) and aux part (+ bias) of Ipre and of T1
+  CondConv t_UI, t_AI, t_UT, t_AT;
+  DevBuf kw;  // [hop][5] upsampling weights of frame offsets -2 .. +2
   // loop weights
   DevBuf wI0, g1I0, w_rnn1, w_rnn2, w_fc1, w_fc2, w_fc3;
   DevBuf b_ih1, b_hh1, b_hh2, b_fc3;
   // split-hidden chain: T1 table conv, rnn2 input half (GRU tile order, K = R), hidden halves as plain
   // row-tile linears (rows in torch gate-major order)
-  CondConv t_T1;
   DevBuf w_rnn2x, w_hh1, w_hh2;
   // fast chain (wavernn_fast.h): hidden halves in GRU tile order, their biases as (r, z, n, -) per unit
   DevBuf f_hh1t, f_hh2t, f_bhh1q, f_bhh2q;
@@ -427,8 +433,43 @@ extern "C" int mb_wavernn_create(const mb_wavernn_config* cfg, const float* cons
   {
     std::vector<float> c0 = col_slice(WI, R, KI, 0, 1);
     RC(w->wI0.upload(c0.data(), c0.size()));
-    std::vector<float> wc = col_slice(WI, R, KI, 1, FEAT + A);
-    RC(make_cond_conv(&w->t_I, wc.data(), R, FEAT + A, 1, 0, bI, nullptr));
+    std::vector<float> wm = col_slice(WI, R, KI, 1, FEAT), wa = col_slice(WI, R, KI, 1 + FEAT, A);
+    RC(make_cond_conv(&w->t_UI, wm.data(), R, FEAT, 1, 0, nullptr, nullptr));   // UI[f] = W_I[:, 1:1+feat] . mel_f
+    RC(make_cond_conv(&w->t_AI, wa.data(), R, A, 1, 0, bI, nullptr));           // AI[f] = W_I[:, 1+feat:] . a1_f + b_I
+  }
+  {  // Kw[p][o]: weight of mel frame f + o - 2 in the upsampled mel at position hop f + p -- an impulse pushed through the
+     // stretch + box-filter stages (UpsampleNetwork :69-74 with this checkpoint's filter taps) in double precision
+    const int NF = 9, c0 = 4;
+    std::vector<double> cur(NF, 0.0), nxt;
+    cur[c0] = 1.0;
+    for (int i = 0; i < cfg->n_upsample; ++i) {
+      const int sc = cfg->upsample_factors[i];
+      const int tv = (int)cur.size() * sc;
+      nxt.assign(tv, 0.0);
+      for (int t = 0; t < tv; ++t) {
+        double acc = 0.0;
+        for (int j = 0; j <= 2 * sc; ++j) {
+          const int uu = t + j - sc;
+          if (uu >= 0 && uu < tv) acc += (double)hw[ix - cfg->n_upsample - 2 + i][j] * cur[uu / sc];
+        }
+        nxt[t] = acc;
+      }
+      cur.swap(nxt);
+    }
+    const int hop = w->hop;
+    std::vector<float> kw((size_t)hop * 5);
+    double outside = 0.0;
+    for (int f = 0; f < NF; ++f)
+      for (int p = 0; p < hop; ++p) {
+        const int o = c0 + 2 - f;  // frame f of the response = offset o of the table
+        if (o >= 0 && o < 5) kw[(size_t)p * 5 + o] = (float)cur[(size_t)f * hop + p];
+        else outside = std::max(outside, std::fabs(cur[(size_t)f * hop + p]));
+      }
+    if (outside > 0.0) {  // (upsample factors whose filters reach further than two frames: not a fatchord configuration)
+      set_error("wavernn_create: the upsampling filters reach beyond +-2 mel frames (%g outside)", outside);
+      rc = MB_EINVAL;
+    }
+    RC(w->kw.upload(kw.data(), kw.size()));
   }
   std::vector<float> rows, packed;
   // rnn1 :109
@@ -447,7 +488,7 @@ extern "C" int mb_wavernn_create(const mb_wavernn_config* cfg, const float* cons
       RC(w->g1I0.upload(g.data(), g.size()));
     }
     RC(w->b_ih1.upload(bih, 3 * R)); RC(w->b_hh1.upload(bhh, 3 * R));
-    {  // T1 = (W_ih1 . W_I[:,1:]) . [m; a1] + (W_ih1 . b_I + b_ih1): one more 1x1 conv over the conditioning
+    {  // T1 = (W_ih1 . W_I[:,1:]) . [m; a1] + (W_ih1 . b_I + b_ih1), as per-frame tables: mel columns (UT) and aux columns + bias (AT)
       const int KC = FEAT + A;
       std::vector<float> m((size_t)3 * R * KC), mb(3 * R);
       std::vector<double> acc(KC);
@@ -463,7 +504,9 @@ extern "C" int mb_wavernn_create(const mb_wavernn_config* cfg, const float* cons
         for (int q = 0; q < KC; ++q) m[(size_t)r * KC + q] = (float)acc[q];
         mb[r] = (float)ab;
       }
-      RC(make_cond_conv(&w->t_T1, m.data(), 3 * R, KC, 1, 0, mb.data(), nullptr));
+      std::vector<float> mm = col_slice(m.data(), 3 * R, KC, 0, FEAT), ma = col_slice(m.data(), 3 * R, KC, FEAT, A);
+      RC(make_cond_conv(&w->t_UT, mm.data(), 3 * R, FEAT, 1, 0, nullptr, nullptr));
+      RC(make_cond_conv(&w->t_AT, ma.data(), 3 * R, A, 1, 0, mb.data(), nullptr));
     }
     pack_rowtile(whh, 3 * R, R, 4, &packed);
     RC(w->w_hh1.upload(packed.data(), packed.size()));
@@ -529,13 +572,13 @@ extern "C" int mb_wavernn_create(const mb_wavernn_config* cfg, const float* cons
 extern "C" void mb_wavernn_destroy(mb_wavernn* w) {
   if (!w) return;
   auto rel = [](CondConv& c) { c.w.release(); c.b.release(); };
-  rel(w->conv_in); rel(w->conv_out); rel(w->t_I); rel(w->t_g2); rel(w->t_f1); rel(w->t_f2); rel(w->t_T1);
+  rel(w->conv_in); rel(w->conv_out); rel(w->t_UI); rel(w->t_AI); rel(w->t_UT); rel(w->t_AT); rel(w->t_g2); rel(w->t_f1); rel(w->t_f2);
   for (auto& c : w->res1) rel(c);
   for (auto& c : w->res2) rel(c);
   for (auto& b : w->up_w) b.release();
   DevBuf* bs[] = {&w->wI0, &w->g1I0, &w->w_rnn1, &w->w_rnn2, &w->w_fc1, &w->w_fc2, &w->w_fc3,
                   &w->b_ih1, &w->b_hh1, &w->b_hh2, &w->b_fc3, &w->w_rnn2x, &w->w_hh1, &w->w_hh2,
-                  &w->f_hh1t, &w->f_hh2t, &w->f_bhh1q, &w->f_bhh2q};
+                  &w->f_hh1t, &w->f_hh2t, &w->f_bhh1q, &w->f_bhh2q, &w->kw};
   for (DevBuf* b : bs) b->release();
   w->drop_graph();
   if (w->h_abort) (void)hipHostFree(w->h_abort);
@@ -553,9 +596,9 @@ extern "C" void mb_wavernn_destroy(mb_wavernn* w) {
 
 namespace {
 struct WrnLayout {
-  float *r0, *r1, *r2, *aux, *m1, *m2, *cond, *Ipre, *G2, *F1, *F2;
+  float *r0, *r1, *r2, *aux, *UT, *AT, *UI, *AI, *Ipre, *G2, *F1, *F2;  // Ipre: MBHIP_WAVERNN_CHAIN=classic only
   float *x0, *x1, *x2, *y1, *y2, *logits, *h1, *h2;
-  float *T1, *P1, *P2;  // split-hidden chain: per-position rnn1 input table, hidden-half pre-activations
+  float *P1, *P2;  // split-hidden chain: hidden-half pre-activations
   float *f_x1, *f_x2, *f_y1, *f_y2, *f_h1, *f_h2, *f_P1, *f_P2, *f_Tq;  // fast chain: FM activations / state, CM4 hidden halves, staged table rows
   size_t f_bytes;
   int* step; unsigned long long* slots;
@@ -576,17 +619,14 @@ static bool wavernn_split_chain() {
 static void wavernn_layout(const mb_wavernn* w, const mb_wavernn_plan* p, void* base, WrnLayout* L) {
   const mb_wavernn_config& c = w->cfg;
   const size_t F = p->frames, T = p->total_len, N = p->n_folds, R = c.rnn_dims, FC = c.fc_dims;
-  const size_t CD = c.compute_dims, A = w->aux_dims;
+  const size_t CD = c.compute_dims;
   Arena ar(base, (size_t)-1);
   L->r0 = ar.take<float>(CD * F); L->r1 = ar.take<float>(CD * F); L->r2 = ar.take<float>(CD * F);
   L->aux = ar.take<float>((size_t)c.res_out_dims * F);
-  // intermediate mel upsampling stages (the last stage writes straight into cond)
-  const size_t s1 = (F + 2 * c.pad) * c.upsample_factors[0];
-  const size_t s2 = s1 * (c.n_upsample > 1 ? c.upsample_factors[1] : 1);
-  L->m1 = ar.take<float>(c.n_upsample >= 2 ? (size_t)c.feat_dims * s1 : 1);
-  L->m2 = ar.take<float>(c.n_upsample >= 3 ? (size_t)c.feat_dims * s2 : 1);
-  L->cond = ar.take<float>((c.feat_dims + A) * T);
-  L->Ipre = ar.take<float>((T + 1) * R);
+  // per-frame tables of the position-dependent conditioning terms (rnn.h WfCond): 2 zero rows, F frames, 7 zero rows / F + 1 rows
+  L->UT = ar.take<float>((F + 9) * 3 * R); L->UI = ar.take<float>((F + 9) * R);
+  L->AT = ar.take<float>((F + 1) * 3 * R); L->AI = ar.take<float>((F + 1) * R);
+  L->Ipre = ar.take<float>(wavernn_split_chain() ? 1 : (T + 1) * R);
   L->G2 = ar.take<float>((F + 1) * 3 * R);
   L->F1 = ar.take<float>((F + 1) * FC);
   L->F2 = ar.take<float>((F + 1) * FC);
@@ -595,7 +635,6 @@ static void wavernn_layout(const mb_wavernn* w, const mb_wavernn_plan* p, void* 
   L->logits = ar.take<float>(N * w->n_classes);
   L->h1 = ar.take<float>(2 * N * R); L->h2 = ar.take<float>(2 * N * R);
   L->P1 = ar.take<float>(N * 3 * R); L->P2 = ar.take<float>(N * 3 * R);
-  L->T1 = ar.take<float>(wavernn_split_chain() ? (T + 1) * 3 * R : 1);
   {
     const int nta = (int)((N + 15) / 16);
     L->f_x1 = ar.take<float>(fm_floats((int)R, nta));
@@ -676,7 +715,7 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
   }
   const mb_wavernn_config& c = w->cfg;
   const int F = plan->frames, T = plan->total_len, N = plan->n_folds, S = plan->seq_len;
-  const int R = c.rnn_dims, FC = c.fc_dims, A = w->aux_dims, C = w->n_classes, FEAT = c.feat_dims;
+  const int R = c.rnn_dims, FC = c.fc_dims, A = w->aux_dims, C = w->n_classes;
   hipStream_t cs = (hipStream_t)stream, s = w->loop_stream;
   MB_HIP(hipEventRecord(w->ev_in, cs));
   MB_HIP(hipStreamWaitEvent(s, w->ev_in, 0));
@@ -691,26 +730,20 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
     std::swap(cur, oth);
   }
   RC(run_cond_conv(w->conv_out, cur, F, L.aux, nullptr, 0, 0, s));
-  // ---- mel upsampling :78-85 -> cond rows [0, FEAT) ----
+  // ---- the position-dependent conditioning terms as per-FRAME tables (rnn.h WfCond; the upsampled mel :78-85 is never built) ----
+  WfCond cond;
+  cond.UT = L.UT; cond.AT = L.AT; cond.UI = L.UI; cond.AI = L.AI; cond.Kw = w->kw.p; cond.hop = w->hop; cond.frames = F;
   if (!rc) {
-    const float* in = d_mel; int t_stored = F, in_pad = c.pad;
-    float* bufs[2] = {L.m1, L.m2};
-    for (int i = 0; i < c.n_upsample; ++i) {
-      const int sc = c.upsample_factors[i];
-      const bool last = i == c.n_upsample - 1;
-      const int t_full = (t_stored + 2 * in_pad) * sc;
-      const int off = last ? c.pad * w->hop : 0;  // indent crop :66,84
-      const int t_out = last ? T : t_full;
-      float* o = last ? L.cond : bufs[i & 1];
-      dim3 grid(std::min(cdiv(t_out, 256), 4096), FEAT);
-      hipLaunchKernelGGL(upsample_stage_kernel, grid, dim3(256), 0, s, in, t_stored, in_pad, o, sc,
-                         w->up_w[i].p, off, t_out);
-      in = o; t_stored = t_out; in_pad = 0;
-    }
-    // a1 rows: cond[FEAT + c][t] = aux[c][t / hop]
-    dim3 grid(std::min(cdiv(T, 256), 4096), A);
-    hipLaunchKernelGGL(repeat_rows_kernel, grid, dim3(256), 0, s, L.aux, F, L.cond + (size_t)FEAT * T, w->hop);
-    if (hipGetLastError() != hipSuccess) { set_error("wavernn: conditioning launch failed"); rc = MB_EHIP; }
+    MB_HIP(hipMemsetAsync(L.UT, 0, sizeof(float) * (size_t)(F + 9) * 3 * R, s));
+    MB_HIP(hipMemsetAsync(L.UI, 0, sizeof(float) * (size_t)(F + 9) * R, s));
+  }
+  RC(run_cond_conv(w->t_UT, d_mel, F, L.UT + (size_t)2 * 3 * R, nullptr, 0, 1, s));
+  RC(run_cond_conv(w->t_UI, d_mel, F, L.UI + (size_t)2 * R, nullptr, 0, 1, s));
+  RC(run_cond_conv(w->t_AT, L.aux, F, L.AT, nullptr, 0, 1, s));   // a1 = aux rows [0, A)
+  RC(run_cond_conv(w->t_AI, L.aux, F, L.AI, nullptr, 0, 1, s));
+  if (!rc) {  // zero-conditioning rows = the biases
+    MB_HIP(hipMemcpyAsync(L.AT + (size_t)F * 3 * R, w->t_AT.b.p, sizeof(float) * 3 * R, hipMemcpyDeviceToDevice, s));
+    MB_HIP(hipMemcpyAsync(L.AI + (size_t)F * R, w->t_AI.b.p, sizeof(float) * R, hipMemcpyDeviceToDevice, s));
   }
   // Production path (no injected noise / teacher forcing / logits dump): the sampler is fused into the
   // fc3 launch and the next step's input is rebuilt from the argmax word -> 5 launches per step.
@@ -737,16 +770,15 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
   int fnt = 2;  // fold-column tiles per workgroup of the fast chain
   if (const char* te = getenv("MBHIP_WAVERNN_FAST_NT")) fnt = atoi(te) == 1 ? 1 : 2;
   if (nta < 2) fnt = 1;
-  // ---- tables (time-major) + the zero-conditioning row = bias ----
-  RC(run_cond_conv(w->t_I, L.cond, T, L.Ipre, nullptr, 0, 1, s));
+  // ---- per-frame tables of the aux columns (time-major) + the zero-conditioning row = bias ----
   RC(run_cond_conv(w->t_g2, L.aux + (size_t)1 * A * F, F, L.G2, nullptr, 0, 1, s));
   RC(run_cond_conv(w->t_f1, L.aux + (size_t)2 * A * F, F, L.F1, nullptr, 0, 1, s));
   RC(run_cond_conv(w->t_f2, L.aux + (size_t)3 * A * F, F, L.F2, nullptr, 0, 1, s));
-  if (split) RC(run_cond_conv(w->t_T1, L.cond, T, L.T1, nullptr, 0, 1, s));
   if (!rc) {
-    if (split)
-      MB_HIP(hipMemcpyAsync(L.T1 + (size_t)T * 3 * R, w->t_T1.b.p, sizeof(float) * 3 * R, hipMemcpyDeviceToDevice, s));
-    MB_HIP(hipMemcpyAsync(L.Ipre + (size_t)T * R, w->t_I.b.p, sizeof(float) * R, hipMemcpyDeviceToDevice, s));
+    if (fused && !split) {  // classic chain: its rnn1 launch reads the I(..) rows as a GEMM operand
+      hipLaunchKernelGGL(wavernn_materialize_ipre_kernel, dim3(2048), dim3(256), 0, s, cond, T, R, L.Ipre);
+      MB_HIP(hipGetLastError());
+    }
     MB_HIP(hipMemcpyAsync(L.G2 + (size_t)F * 3 * R, w->t_g2.b.p, sizeof(float) * 3 * R, hipMemcpyDeviceToDevice, s));
     MB_HIP(hipMemcpyAsync(L.F1 + (size_t)F * FC, w->t_f1.b.p, sizeof(float) * FC, hipMemcpyDeviceToDevice, s));
     MB_HIP(hipMemcpyAsync(L.F2 + (size_t)F * FC, w->t_f2.b.p, sizeof(float) * FC, hipMemcpyDeviceToDevice, s));
@@ -819,7 +851,7 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
       qk.w_rnn2 = w->w_rnn2x.p; qk.w_hh2 = w->f_hh2t.p; qk.w_hh1 = w->f_hh1t.p; qk.w_fc1 = w->w_fc1.p; qk.w_fc2 = w->w_fc2.p; qk.w_fc3 = w->w_fc3.p;
       qk.bhh1q = reinterpret_cast<const float4*>(w->f_bhh1q.p); qk.bhh2q = reinterpret_cast<const float4*>(w->f_bhh2q.p);
       qk.b_fc3 = w->b_fc3.p; qk.g1 = w->g1I0.p; qk.wI0 = w->wI0.p;
-      qk.T1 = L.T1; qk.Ipre = L.Ipre; qk.G2 = L.G2; qk.F1 = L.F1; qk.F2 = L.F2;
+      qk.cond = cond; qk.G2 = L.G2; qk.F1 = L.F1; qk.F2 = L.F2;
       qk.g = wg; qk.ex = L.px; qk.abort_word = abort_word;
       qk.samples = d_samples; qk.progress = h_progress; qk.seed = seed; qk.R = R; qk.FC = FC; qk.C = C; qk.S = S; qk.N = N;
       qk.gn0[0] = 0; qk.gn0[1] = (N + 1) / 2; qk.gn0[2] = N;  // two groups of ceil / floor (N / 2) columns
@@ -832,7 +864,7 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
       pk.w_rnn2 = w->w_rnn2x.p; pk.w_fc1 = w->w_fc1.p; pk.w_fc2 = w->w_fc2.p; pk.w_fc3 = w->w_fc3.p; pk.w_hh1 = w->f_hh1t.p; pk.w_hh2 = w->f_hh2t.p;
       pk.bhh1q = reinterpret_cast<const float4*>(w->f_bhh1q.p); pk.bhh2q = reinterpret_cast<const float4*>(w->f_bhh2q.p);
       pk.b_fc3 = w->b_fc3.p; pk.g1 = w->g1I0.p; pk.wI0 = w->wI0.p;
-      pk.T1 = L.T1; pk.Ipre = L.Ipre; pk.G2 = L.G2; pk.F1 = L.F1; pk.F2 = L.F2;
+      pk.cond = cond; pk.G2 = L.G2; pk.F1 = L.F1; pk.F2 = L.F2;
       pk.g = wg; pk.ex = L.px; pk.abort_word = abort_word;
       pk.samples = d_samples; pk.progress = h_progress; pk.seed = seed; pk.R = R; pk.FC = FC; pk.C = C; pk.S = S; pk.N = N;
       pk.trace = trace;
@@ -871,7 +903,7 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
     fc_hh(1, 0, 0, s);
     {  // table rows of step 0
       WfStageK sk;
-      sk.T1 = L.T1; sk.Ipre = L.Ipre; sk.Tq = reinterpret_cast<float4*>(L.f_Tq); sk.R = R; sk.step_add = 0;
+      sk.cond = cond; sk.Tq = reinterpret_cast<float4*>(L.f_Tq); sk.R = R; sk.step_add = 0;
       hipLaunchKernelGGL(wf_stage_kernel, dim3(cdiv((R / 4) * nta, 8)), dim3(512), 0, s, sk, wg);  // -> buffer 0 (step parity 0)
     }
     MB_HIP(hipGetLastError());
@@ -904,7 +936,7 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
     sk.logits = L.logits + (size_t)n0 * C; sk.noise = d_noise; sk.seed = seed; sk.forced = d_forced;
     sk.samples = d_samples; sk.logits_out = d_logits_out; sk.step_base = L.step + l; sk.step_off = 0; sk.n_off = n0; sk.N_total = N;
     sk.C = C; sk.S = S; sk.R = R; sk.fold_stride = plan->fold_stride; sk.total_len = T; sk.hop = w->hop; sk.frames = F;
-    sk.Ipre = L.Ipre; sk.wI0 = w->wI0.p; sk.x0 = L.x0 + (size_t)n0 * R;
+    sk.cond = cond; sk.wI0 = w->wI0.p; sk.x0 = L.x0 + (size_t)n0 * R;
     sk.progress = h_progress; sk.trace = nullptr;
     return sk;
   };
@@ -935,7 +967,7 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
         f.g = wg; f.g.step_off = soff; f.slot = slot_prev; f.P1 = reinterpret_cast<const float4*>(L.f_P1);
         const size_t tqn = cm_items(R, nta);  // float4 items per buffer
         f.Tq = reinterpret_cast<const float4*>(L.f_Tq) + (size_t)pp * tqn;
-        f.stage.T1 = L.T1; f.stage.Ipre = L.Ipre; f.stage.Tq = reinterpret_cast<float4*>(L.f_Tq) + (size_t)(pp ^ 1) * tqn; f.stage.R = R; f.stage.step_add = 1;
+        f.stage.cond = cond; f.stage.Tq = reinterpret_cast<float4*>(L.f_Tq) + (size_t)(pp ^ 1) * tqn; f.stage.R = R; f.stage.step_add = 1;
         f.n_fin = R / 16;
         f.g1 = w->g1I0.p; f.wI0 = w->wI0.p; f.h1 = L.f_h1; f.x1 = L.f_x1; f.samples = d_samples; f.progress = h_progress;
         f.R = R; f.C = C; f.S = S; f.mol = c.mode == 1 ? 1 : 0;
@@ -973,7 +1005,7 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
         Fin1K f;
         memset(&f, 0, sizeof(f));
         f.slot = L.slots + (size_t)(parity ^ 1) * N + n0;
-        f.T1 = L.T1; f.Ipre = L.Ipre; f.P1 = P1; f.g1 = w->g1I0.p; f.wI0 = w->wI0.p;
+        f.cond = cond; f.P1 = P1; f.g1 = w->g1I0.p; f.wI0 = w->wI0.p;
         f.h_prev = L.h1 + ((size_t)parity * N + n0) * R; f.h_out = L.h1 + ((size_t)(parity ^ 1) * N + n0) * R;
         f.x_out = x1; f.samples = d_samples; f.progress = h_progress;
         f.step_base = L.step + l; f.step_off = off; f.n_off = n0; f.nl = nl; f.R = R; f.C = C; f.S = S;
@@ -1183,31 +1215,26 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
 // ---------------------------------------------------------------------------------------------
 namespace {
 struct WrnBatchLayout {
-  float *r0, *r1, *r2, *aux, *m1, *m2, *cond;           // per-utterance conditioning scratch (max frames)
-  float *Ipre, *T1, *G2, *F1, *F2;                       // concatenated tables, one zero-conditioning row per utterance
+  float *r0, *r1, *r2, *aux;                             // per-utterance conditioning scratch (max frames)
+  float *UT, *UI, *AT, *AI, *G2, *F1, *F2;               // concatenated per-frame tables: U* frames + 9 rows per utterance, the others frames + 1
   float *x1, *x2, *y1, *y2, *h1, *h2, *P1, *P2;
   int* step; unsigned long long* slots; int* desc;
   size_t bytes;
 };
 void wavernn_batch_layout(const mb_wavernn* w, int n_utt, const int* frames, int n_folds, void* base, WrnBatchLayout* L) {
   const mb_wavernn_config& c = w->cfg;
-  const size_t R = c.rnn_dims, FC = c.fc_dims, CD = c.compute_dims, A = w->aux_dims, N = n_folds;
-  size_t fmax = 0, pos_rows = 0, frame_rows = 0;
+  const size_t R = c.rnn_dims, FC = c.fc_dims, CD = c.compute_dims, N = n_folds;
+  size_t fmax = 0, u_rows = 0, frame_rows = 0;
   for (int u = 0; u < n_utt; ++u) {
     fmax = std::max(fmax, (size_t)frames[u]);
-    pos_rows += (size_t)frames[u] * w->hop + 1;
+    u_rows += (size_t)frames[u] + 9;
     frame_rows += (size_t)frames[u] + 1;
   }
-  const size_t Tmax = fmax * w->hop;
   Arena ar(base, (size_t)-1);
   L->r0 = ar.take<float>(CD * fmax); L->r1 = ar.take<float>(CD * fmax); L->r2 = ar.take<float>(CD * fmax);
   L->aux = ar.take<float>((size_t)c.res_out_dims * fmax);
-  const size_t s1 = (fmax + 2 * c.pad) * c.upsample_factors[0];
-  const size_t s2 = s1 * (c.n_upsample > 1 ? c.upsample_factors[1] : 1);
-  L->m1 = ar.take<float>(c.n_upsample >= 2 ? (size_t)c.feat_dims * s1 : 1);
-  L->m2 = ar.take<float>(c.n_upsample >= 3 ? (size_t)c.feat_dims * s2 : 1);
-  L->cond = ar.take<float>((c.feat_dims + A) * Tmax);
-  L->Ipre = ar.take<float>(pos_rows * R); L->T1 = ar.take<float>(pos_rows * 3 * R);
+  L->UT = ar.take<float>(u_rows * 3 * R); L->UI = ar.take<float>(u_rows * R);
+  L->AT = ar.take<float>(frame_rows * 3 * R); L->AI = ar.take<float>(frame_rows * R);
   L->G2 = ar.take<float>(frame_rows * 3 * R); L->F1 = ar.take<float>(frame_rows * FC); L->F2 = ar.take<float>(frame_rows * FC);
   L->x1 = ar.take<float>(N * R); L->x2 = ar.take<float>(N * R); L->y1 = ar.take<float>(N * FC); L->y2 = ar.take<float>(N * FC);
   L->h1 = ar.take<float>(2 * N * R); L->h2 = ar.take<float>(2 * N * R);
@@ -1271,21 +1298,27 @@ static int wavernn_generate_batch_impl(const mb_wavernn* wc, const mb_wavernn_ba
     return MB_ENOMEM;
   }
   const mb_wavernn_config& c = w->cfg;
-  const int R = c.rnn_dims, FC = c.fc_dims, A = w->aux_dims, C = w->n_classes, FEAT = c.feat_dims;
+  const int R = c.rnn_dims, FC = c.fc_dims, A = w->aux_dims, C = w->n_classes;
   hipStream_t cs = (hipStream_t)stream, s = w->loop_stream;
   MB_HIP(hipEventRecord(w->ev_in, cs));
   MB_HIP(hipStreamWaitEvent(s, w->ev_in, 0));
   int rc = MB_OK;
 #define RC(x) do { if (!rc) rc = (x); } while (0)
   // ---- conditioning networks + tables, one utterance after the other into the concatenated tables ----
+  {
+    size_t ur = 0;
+    for (int u = 0; u < n_utt; ++u) ur += (size_t)h_frames[u] + 9;
+    MB_HIP(hipMemsetAsync(L.UT, 0, sizeof(float) * ur * 3 * R, s));
+    MB_HIP(hipMemsetAsync(L.UI, 0, sizeof(float) * ur * R, s));
+  }
   std::vector<int> desc((size_t)N * 8);
-  size_t pos_row = 0, frame_row = 0;
+  size_t u_row = 0, frame_row = 0;
   int fold = 0;
   for (int u = 0; u < n_utt && !rc; ++u) {
     const int F = h_frames[u], T = F * w->hop;
     const float* d_mel = h_d_mels[u];
     MB_REQUIRE(d_mel, "wavernn_generate_batch: mel %d is null", u);
-    MB_REQUIRE(pos_row + T + 1 < ((size_t)1 << 31) / 2, "wavernn_generate_batch: batch too long for 32-bit table rows");
+    MB_REQUIRE(u_row + F + 9 < ((size_t)1 << 30), "wavernn_generate_batch: batch too long for 32-bit table rows");
     RC(run_cond_conv(w->conv_in, d_mel, F, L.r0, nullptr, 1, 0, s));  // MelResNet :37-44
     float* cur = L.r0; float* oth = L.r1;
     for (int i = 0; i < c.res_blocks; ++i) {
@@ -1294,34 +1327,19 @@ static int wavernn_generate_batch_impl(const mb_wavernn* wc, const mb_wavernn_ba
       std::swap(cur, oth);
     }
     RC(run_cond_conv(w->conv_out, cur, F, L.aux, nullptr, 0, 0, s));
-    if (!rc) {  // mel upsampling :78-85
-      const float* in = d_mel; int t_stored = F, in_pad = c.pad;
-      float* bufs[2] = {L.m1, L.m2};
-      for (int i = 0; i < c.n_upsample; ++i) {
-        const int sc = c.upsample_factors[i];
-        const bool last = i == c.n_upsample - 1;
-        const int t_full = (t_stored + 2 * in_pad) * sc;
-        const int off = last ? c.pad * w->hop : 0;
-        const int t_out = last ? T : t_full;
-        float* o = last ? L.cond : bufs[i & 1];
-        dim3 grid(std::min(cdiv(t_out, 256), 4096), FEAT);
-        hipLaunchKernelGGL(upsample_stage_kernel, grid, dim3(256), 0, s, in, t_stored, in_pad, o, sc, w->up_w[i].p, off, t_out);
-        in = o; t_stored = t_out; in_pad = 0;
-      }
-      dim3 grid(std::min(cdiv(T, 256), 4096), A);
-      hipLaunchKernelGGL(repeat_rows_kernel, grid, dim3(256), 0, s, L.aux, F, L.cond + (size_t)FEAT * T, w->hop);
-      if (hipGetLastError() != hipSuccess) { set_error("wavernn_batch: conditioning launch failed"); rc = MB_EHIP; }
-    }
-    float* Ipre = L.Ipre + pos_row * R; float* T1 = L.T1 + pos_row * 3 * R;
+    float* UT = L.UT + u_row * 3 * R; float* UI = L.UI + u_row * R;
+    float* AT = L.AT + frame_row * 3 * R; float* AI = L.AI + frame_row * R;
     float* G2 = L.G2 + frame_row * 3 * R; float* F1 = L.F1 + frame_row * FC; float* F2 = L.F2 + frame_row * FC;
-    RC(run_cond_conv(w->t_I, L.cond, T, Ipre, nullptr, 0, 1, s));
-    RC(run_cond_conv(w->t_T1, L.cond, T, T1, nullptr, 0, 1, s));
+    RC(run_cond_conv(w->t_UT, d_mel, F, UT + (size_t)2 * 3 * R, nullptr, 0, 1, s));   // rows 0..1 and F+2..F+8 stay zero
+    RC(run_cond_conv(w->t_UI, d_mel, F, UI + (size_t)2 * R, nullptr, 0, 1, s));
+    RC(run_cond_conv(w->t_AT, L.aux, F, AT, nullptr, 0, 1, s));
+    RC(run_cond_conv(w->t_AI, L.aux, F, AI, nullptr, 0, 1, s));
     RC(run_cond_conv(w->t_g2, L.aux + (size_t)1 * A * F, F, G2, nullptr, 0, 1, s));
     RC(run_cond_conv(w->t_f1, L.aux + (size_t)2 * A * F, F, F1, nullptr, 0, 1, s));
     RC(run_cond_conv(w->t_f2, L.aux + (size_t)3 * A * F, F, F2, nullptr, 0, 1, s));
     if (!rc) {  // zero-conditioning rows = the biases
-      MB_HIP(hipMemcpyAsync(Ipre + (size_t)T * R, w->t_I.b.p, sizeof(float) * R, hipMemcpyDeviceToDevice, s));
-      MB_HIP(hipMemcpyAsync(T1 + (size_t)T * 3 * R, w->t_T1.b.p, sizeof(float) * 3 * R, hipMemcpyDeviceToDevice, s));
+      MB_HIP(hipMemcpyAsync(AT + (size_t)F * 3 * R, w->t_AT.b.p, sizeof(float) * 3 * R, hipMemcpyDeviceToDevice, s));
+      MB_HIP(hipMemcpyAsync(AI + (size_t)F * R, w->t_AI.b.p, sizeof(float) * R, hipMemcpyDeviceToDevice, s));
       MB_HIP(hipMemcpyAsync(G2 + (size_t)F * 3 * R, w->t_g2.b.p, sizeof(float) * 3 * R, hipMemcpyDeviceToDevice, s));
       MB_HIP(hipMemcpyAsync(F1 + (size_t)F * FC, w->t_f1.b.p, sizeof(float) * FC, hipMemcpyDeviceToDevice, s));
       MB_HIP(hipMemcpyAsync(F2 + (size_t)F * FC, w->t_f2.b.p, sizeof(float) * FC, hipMemcpyDeviceToDevice, s));
@@ -1331,10 +1349,10 @@ static int wavernn_generate_batch_impl(const mb_wavernn* wc, const mb_wavernn_ba
     for (int f = 0; f < nf && !rc; ++f, ++fold) {
       MB_REQUIRE(fold < N, "wavernn_generate_batch: plan does not match the frame counts");
       int* d = &desc[(size_t)fold * 8];
-      d[0] = f * plan->fold_stride; d[1] = T; d[2] = (int)pos_row; d[3] = (int)frame_row; d[4] = F; d[5] = f;
+      d[0] = f * plan->fold_stride; d[1] = T; d[2] = (int)u_row; d[3] = (int)frame_row; d[4] = F; d[5] = f;
       d[6] = (int)(uint32_t)h_seeds[u]; d[7] = (int)(uint32_t)(h_seeds[u] >> 32);
     }
-    pos_row += (size_t)T + 1; frame_row += (size_t)F + 1;
+    u_row += (size_t)F + 9; frame_row += (size_t)F + 1;
   }
   if (!rc && fold != N) { set_error("wavernn_generate_batch: plan has %d folds, frames give %d", N, fold); rc = MB_EINVAL; }
   if (rc) return rc;
@@ -1353,6 +1371,8 @@ static int wavernn_generate_batch_impl(const mb_wavernn* wc, const mb_wavernn_ba
   }
   if (rc) return rc;
 
+  WfCond bcond;
+  bcond.UT = L.UT; bcond.AT = L.AT; bcond.UI = L.UI; bcond.AI = L.AI; bcond.Kw = w->kw.p; bcond.hop = w->hop; bcond.frames = 0;
   // one time step = the split-hidden chain of mb_wavernn_generate with per-fold descriptors
   auto step = [&](int pp, int soff) -> int {
     float* h1p = L.h1 + (size_t)pp * N * R; float* h1n = L.h1 + (size_t)(pp ^ 1) * N * R;
@@ -1366,7 +1386,7 @@ static int wavernn_generate_batch_impl(const mb_wavernn* wc, const mb_wavernn_ba
     int r;
     Fin1K f;
     memset(&f, 0, sizeof(f));
-    f.slot = slot_prev; f.T1 = L.T1; f.Ipre = L.Ipre; f.P1 = L.P1; f.g1 = w->g1I0.p; f.wI0 = w->wI0.p;
+    f.slot = slot_prev; f.cond = bcond; f.P1 = L.P1; f.g1 = w->g1I0.p; f.wI0 = w->wI0.p;
     f.h_prev = h1p; f.h_out = h1n; f.x_out = L.x1; f.samples = d_samples; f.progress = nullptr;
     f.step_base = L.step; f.step_off = soff; f.n_off = 0; f.nl = N; f.R = R; f.C = C; f.S = S;
     f.fold_stride = plan->fold_stride; f.total_len = 0; f.desc = L.desc;

@@ -32,10 +32,10 @@ __device__ __forceinline__ int wf_frame_row(const WfGeom& g, int n, int s) {
   return pos < (unsigned)g.total_len ? (int)(pos / (unsigned)g.hop) : g.frames;
 }
 
-// The T1 / Ipre rows of a step do not depend on the sample: they are copied out of the 1.2 GB position tables (an HBM miss
-// per row, on the critical path of the finish launch when read there) into a dense CM4 block one launch ahead, by a
-// job that rides in the FINISH launch of the previous step (the shortest launch of the chain: elementwise work only).
-struct WfStageK { const float* T1; const float* Ipre; float4* Tq; int R, step_add; };
+// The T1 / Ipre rows of a step do not depend on the sample: they are rebuilt from the per-frame tables (rnn.h WfCond: 24 scattered
+// reads + 20 FMAs per (unit, column)) into a dense CM4 block one launch ahead, by a job that rides in the FINISH launch of the
+// previous step (the shortest launch of the chain: elementwise work only).
+struct WfStageK { WfCond cond; float4* Tq; int R, step_add; };
 __device__ __forceinline__ void wf_stage_rows(const WfStageK& a, const WfGeom& g, const int wg_index) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int item = wg_index * (blockDim.x >> 6) + wave;  // (row tile of 4 units, column tile)
@@ -44,9 +44,7 @@ __device__ __forceinline__ void wf_stage_rows(const WfStageK& a, const WfGeom& g
   const int du = lane >> 4, i = lane & 15, j = mt * 4 + du, H = a.R;
   const int n_raw = nt * 16 + i, n = n_raw < g.N ? n_raw : g.N - 1;
   const int s = *g.step_base + g.step_off + a.step_add;
-  const unsigned pos = wf_pos(g, n, s);
-  const float* t1 = a.T1 + (size_t)pos * 3 * H + j;
-  a.Tq[((size_t)mt * g.nta + nt) * 64 + lane] = make_float4(t1[0], t1[H], t1[2 * H], a.Ipre[(size_t)pos * H + j]);
+  a.Tq[((size_t)mt * g.nta + nt) * 64 + lane] = wf_cond_row4(a.cond, wf_pos(g, n, s), (unsigned)g.total_len, j, H, g.frames);
 }
 __global__ __launch_bounds__(512) void wf_stage_kernel(WfStageK a, WfGeom g) { wf_stage_rows(a, g, blockIdx.x); }
 

@@ -54,7 +54,7 @@ inline size_t wp_exchange_bytes() { return (size_t)2 * WPX_PER_PARITY * 8 + 256 
 struct WpK {
   const float* w_rnn2; const float* w_fc1; const float* w_fc2; const float* w_fc3; const float* w_hh1; const float* w_hh2;
   const float4* bhh1q; const float4* bhh2q; const float* b_fc3; const float* g1; const float* wI0;
-  const float* T1; const float* Ipre; const float* G2; const float* F1; const float* F2;
+  WfCond cond; const float* G2; const float* F1; const float* F2;
   WfGeom g;
   unsigned long long* ex; int* abort_word;
   float* samples; volatile int* progress;
@@ -299,9 +299,8 @@ __global__ __launch_bounds__(512) void wf_persist_kernel(WpK a) {
   for (int n = 0; n < WP_NCOL; ++n) {
     h1[n] = 0.f;
     if (n < N) {
-      const unsigned pos = wf_pos(a.g, n, 0);
-      const float* t1 = a.T1 + (size_t)pos * 3 * H + j;
-      tq[n][0] = t1[0]; tq[n][1] = t1[H]; tq[n][2] = t1[2 * H]; tq[n][3] = a.Ipre[(size_t)pos * H + j];
+      const float4 t4 = wf_cond_row4(a.cond, wf_pos(a.g, n, 0), (unsigned)a.g.total_len, j, H, a.g.frames);
+      tq[n][0] = t4.x; tq[n][1] = t4.y; tq[n][2] = t4.z; tq[n][3] = t4.w;
     }
   }
   float h2 = 0.f;  // waves 0 / 1: unit (2g + wave) * 4 + du, column i
@@ -381,9 +380,8 @@ __global__ __launch_bounds__(512) void wf_persist_kernel(WpK a) {
 #pragma unroll
       for (int n = 0; n < WP_NCOL; ++n) {
         if (n >= N) continue;
-        const unsigned pos = wf_pos(a.g, n, s + 1);
-        const float* t1 = a.T1 + (size_t)pos * 3 * H + j;
-        tq[n][0] = t1[0]; tq[n][1] = t1[H]; tq[n][2] = t1[2 * H]; tq[n][3] = a.Ipre[(size_t)pos * H + j];
+        const float4 t4 = wf_cond_row4(a.cond, wf_pos(a.g, n, s + 1), (unsigned)a.g.total_len, j, H, a.g.frames);
+        tq[n][0] = t4.x; tq[n][1] = t4.y; tq[n][2] = t4.z; tq[n][3] = t4.w;
       }
     }
     // ---- D: rnn2, row tiles 2g and 2g+1 in one pass; wave tt finishes tile tt ----
@@ -599,9 +597,8 @@ __global__ __launch_bounds__(512) void wf_persist1_kernel(WpK a) {
   const float gr = a.g1[j], gz = a.g1[H + j], gn = a.g1[2 * H + j], w0 = a.wI0[j];
   float h1 = 0.f, h2 = 0.f, tq[4];
   {
-    const unsigned pos = wf_pos(a.g, 0, 0);
-    const float* t1 = a.T1 + (size_t)pos * 3 * H + j;
-    tq[0] = t1[0]; tq[1] = t1[H]; tq[2] = t1[2 * H]; tq[3] = a.Ipre[(size_t)pos * H + j];
+    const float4 t4 = wf_cond_row4(a.cond, wf_pos(a.g, 0, 0), (unsigned)a.g.total_len, j, H, a.g.frames);
+    tq[0] = t4.x; tq[1] = t4.y; tq[2] = t4.z; tq[3] = t4.w;
   }
   float g2r = 0.f, g2z = 0.f, g2n = 0.f; int g2_row = -1;
   float4 fpre = make_float4(0.f, 0.f, 0.f, 0.f); int f_row = -1;
@@ -653,9 +650,8 @@ __global__ __launch_bounds__(512) void wf_persist1_kernel(WpK a) {
     if (tid == 0) s_key[0] = 0ull;  // everybody decoded x before the barrier; the next atomicMax is a step away
     // ---- C: next step's table rows ----
     if (s + 1 < S) {
-      const unsigned pos = wf_pos(a.g, 0, s + 1);
-      const float* t1 = a.T1 + (size_t)pos * 3 * H + j;
-      tq[0] = t1[0]; tq[1] = t1[H]; tq[2] = t1[2 * H]; tq[3] = a.Ipre[(size_t)pos * H + j];
+      const float4 t4 = wf_cond_row4(a.cond, wf_pos(a.g, 0, s + 1), (unsigned)a.g.total_len, j, H, a.g.frames);
+      tq[0] = t4.x; tq[1] = t4.y; tq[2] = t4.z; tq[3] = t4.w;
     }
     // ---- D: rnn2, row tiles 2g and 2g+1 ----
     wp_dot<2>(lw, xs1, red);

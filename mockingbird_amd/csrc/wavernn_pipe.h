@@ -47,7 +47,7 @@ inline size_t wq_exchange_bytes() { return (size_t)WQ_G * 2 * WQX_PER * 8 + 256 
 struct WqK {
   const float* w_rnn2; const float* w_hh2; const float* w_hh1; const float* w_fc1; const float* w_fc2; const float* w_fc3;
   const float4* bhh1q; const float4* bhh2q; const float* b_fc3; const float* g1; const float* wI0;
-  const float* T1; const float* Ipre; const float* G2; const float* F1; const float* F2;
+  WfCond cond; const float* G2; const float* F1; const float* F2;
   WfGeom g;
   unsigned long long* ex; int* abort_word;
   float* samples; volatile int* progress;
@@ -126,9 +126,8 @@ __global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
       h1[g] = 0.f; P1[g][0] = bq.x; P1[g][1] = bq.y; P1[g][2] = bq.z;  // W_hh . 0 + b_hh
       const int Ng = a.gn0[g + 1] - a.gn0[g];
       const int ncl = a.gn0[g] + (i < Ng ? i : (Ng > 0 ? Ng - 1 : 0));
-      const unsigned pos = wf_pos(a.g, ncl, 0);
-      const float* t1 = a.T1 + (size_t)pos * 3 * H + ju;
-      tq[g][0] = t1[0]; tq[g][1] = t1[H]; tq[g][2] = t1[2 * H]; tq[g][3] = a.Ipre[(size_t)pos * H + ju];
+      const float4 t4 = wf_cond_row4(a.cond, wf_pos(a.g, ncl, 0), (unsigned)a.g.total_len, ju, H, a.g.frames);
+      tq[g][0] = t4.x; tq[g][1] = t4.y; tq[g][2] = t4.z; tq[g][3] = t4.w;
     }
     __syncthreads();
     for (int s = 0; s <= S; ++s) {
@@ -178,9 +177,8 @@ __global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
         if (s + 1 >= S) continue;
         // ---- next step's table rows (a whole step to arrive) ----
         if (wave < 2) {
-          const unsigned pos = wf_pos(a.g, n0 + (i < Ng ? i : Ng - 1), s + 1);
-          const float* t1 = a.T1 + (size_t)pos * 3 * H + ju;
-          tq[g][0] = t1[0]; tq[g][1] = t1[H]; tq[g][2] = t1[2 * H]; tq[g][3] = a.Ipre[(size_t)pos * H + ju];
+          const float4 t4 = wf_cond_row4(a.cond, wf_pos(a.g, n0 + (i < Ng ? i : Ng - 1), s + 1), (unsigned)a.g.total_len, ju, H, a.g.frames);
+          tq[g][0] = t4.x; tq[g][1] = t4.y; tq[g][2] = t4.z; tq[g][3] = t4.w;
         }
         // ---- hidden half of the next step: P1 = W_hh1 . h1 + b_hh1, kept by the lane that will use it ----
         float4 b[4];

@@ -157,8 +157,8 @@ class WaveRNNDevice:
         return plan, cfr, offs
 
     def batch_groups(self, frames, target, overlap, budget):
-        """The conditioning tables cost about 8.6 KB per output sample (1.7 GB per 1000 mel frames), so a large
-        batch is cut into consecutive groups whose workspace fits `budget` bytes and the groups run one sample
+        """The conditioning tables cost about 27 MB per 1000 mel frames (per-frame tables); a batch
+        that still does not fit is cut into consecutive groups whose workspace fits `budget` bytes and the groups run one sample
         loop after the other (per-utterance seeds make the result independent of the grouping).  One utterance
         that does not fit by itself is an error, not an allocator failure."""
         groups, lo = [], 0
