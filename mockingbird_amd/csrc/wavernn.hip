@@ -31,39 +31,6 @@
 
 namespace mb {
 
-// ---- conditioning helpers -------------------------------------------------
-
-// One UpsampleNetwork stage: Stretch2d(s,1) then Conv2d(1,1,(1,2s+1),padding=(0,s)) :47-57,69-74
-__global__ void upsample_stage_kernel(const float* __restrict__ in, int t_stored, int in_pad,
-                                      float* __restrict__ out, int s, const float* __restrict__ w,
-                                      int out_off, int t_out) {
-  const int c = blockIdx.y;
-  const int tv = (t_stored + 2 * in_pad) * s;  // stretched virtual length
-  const float* ic = in + (size_t)c * t_stored;
-  float* oc = out + (size_t)c * t_out;
-  for (int tp = blockIdx.x * blockDim.x + threadIdx.x; tp < t_out; tp += gridDim.x * blockDim.x) {
-    const int t = tp + out_off;
-    float acc = 0.f;
-    for (int j = 0; j <= 2 * s; ++j) {
-      const int uu = t + j - s;
-      if (uu >= 0 && uu < tv) {
-        const int f = uu / s - in_pad;
-        if (f >= 0 && f < t_stored) acc += w[j] * ic[f];
-      }
-    }
-    oc[tp] = acc;
-  }
-}
-
-// out[c][t] = in[c][t / rep]  (Stretch2d of the aux features :82-83)
-__global__ void repeat_rows_kernel(const float* __restrict__ in, int t_in, float* __restrict__ out,
-                                   int rep) {
-  const int c = blockIdx.y;
-  const int t_out = t_in * rep;
-  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < t_out; t += gridDim.x * blockDim.x)
-    out[(size_t)c * t_out + t] = in[(size_t)c * t_in + t / rep];
-}
-
 // ---- sampler ----------------------------------------------------------------
 struct SampK {
   const float* logits;  // [n][C] (lane-local)
@@ -289,7 +256,6 @@ struct mb_wavernn {
   // conditioning
   CondConv conv_in, conv_out;
   std::vector<CondConv> res1, res2;
-  std::vector<DevBuf> up_w;
   // tables
   CondConv t_g2, t_f1, t_f2;  // 1x1 convs producing the per-frame tables G2pre / F1pre / F2pre
   // per-frame tables of the position-dependent terms (rnn.h WfCond): mel part (no bias) and aux part (+ bias) of Ipre and of T1
@@ -425,8 +391,7 @@ extern "C" int mb_wavernn_create(const mb_wavernn_config* cfg, const float* cons
     RC(make_cond_conv(&w->res2[i], hw[ix], CD, CD, 1, 0, nullptr, hw + ix + 1)); ix += 5;
   }
   RC(make_cond_conv(&w->conv_out, hw[ix], cfg->res_out_dims, CD, 1, 0, hw[ix + 1], nullptr)); ix += 2;
-  w->up_w.resize(cfg->n_upsample);
-  for (int i = 0; i < cfg->n_upsample; ++i) RC(w->up_w[i].upload(hw[ix++], 2 * cfg->upsample_factors[i] + 1));
+  ix += cfg->n_upsample;  // the upsampling filter taps: folded into the Kw table below
   // I :108,195
   const float* WI = hw[ix]; const float* bI = hw[ix + 1]; ix += 2;
   const int KI = FEAT + A + 1;
@@ -575,7 +540,6 @@ extern "C" void mb_wavernn_destroy(mb_wavernn* w) {
   rel(w->conv_in); rel(w->conv_out); rel(w->t_UI); rel(w->t_AI); rel(w->t_UT); rel(w->t_AT); rel(w->t_g2); rel(w->t_f1); rel(w->t_f2);
   for (auto& c : w->res1) rel(c);
   for (auto& c : w->res2) rel(c);
-  for (auto& b : w->up_w) b.release();
   DevBuf* bs[] = {&w->wI0, &w->g1I0, &w->w_rnn1, &w->w_rnn2, &w->w_fc1, &w->w_fc2, &w->w_fc3,
                   &w->b_ih1, &w->b_hh1, &w->b_hh2, &w->b_fc3, &w->w_rnn2x, &w->w_hh1, &w->w_hh2,
                   &w->f_hh1t, &w->f_hh2t, &w->f_bhh1q, &w->f_bhh2q, &w->kw};
