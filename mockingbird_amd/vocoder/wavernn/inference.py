@@ -81,22 +81,42 @@ class WaveRNNDevice:
         self._progress.zero_()
         L = _lib.lib()
         start = time.time()
-        _lib.check(L.mb_wavernn_generate(self._h, C.byref(p), _lib.ptr(mel), _lib.ptr(noise), int(seed),
-                                         _lib.ptr(samples), _lib.ptr(logits), _lib.ptr(forced),
-                                         _lib.ptr(self._progress), _lib.ptr(self._ws), self._ws.numel(),
-                                         _lib.stream_ptr()), "mb_wavernn_generate")
-        if progress_callback is not None:
-            # the kernels publish the completed step count every 100 steps (fatchord_version.py:232-234)
-            done_ev = torch.cuda.Event()
-            done_ev.record()
-            last = -1
-            while not done_ev.query():
+        args = (self._h, C.byref(p), _lib.ptr(mel), _lib.ptr(noise), int(seed), _lib.ptr(samples), _lib.ptr(logits), _lib.ptr(forced),
+                _lib.ptr(self._progress), _lib.ptr(self._ws), self._ws.numel(), _lib.stream_ptr())
+        if progress_callback is None:
+            _lib.check(L.mb_wavernn_generate(*args), "mb_wavernn_generate")
+        else:
+            # the kernels publish the completed step count every 100 steps through the pinned word (fatchord_version.py:232-234).
+            # The resident kernels make mb_wavernn_generate host-blocking, so the call runs on a worker thread (ctypes drops the
+            # GIL) while this thread reports progress; the device / stream context is the caller's either way.
+            import threading
+            res, dev_index, stream = {}, mel.device.index, torch.cuda.current_stream()
+
+            def run():
+                torch.cuda.set_device(dev_index)
+                with torch.cuda.stream(stream):
+                    res["rc"] = L.mb_wavernn_generate(*args)
+                    msg = L.mb_last_error() if res["rc"] else None  # (the error text is per thread: read it here)
+                    res["err"] = msg.decode() if msg else ""
+
+            th = threading.Thread(target=run)
+            th.start()
+            last, done_ev = -1, None
+            while True:
+                if not th.is_alive() and done_ev is None:
+                    done_ev = torch.cuda.Event()
+                    done_ev.record()
+                if done_ev is not None and done_ev.query():
+                    break
                 i = int(self._progress[0]) - 1
                 if i >= 0 and i != last:
                     last = i
                     gen_rate = (i + 1) / max(time.time() - start, 1e-9) * p.n_folds / 1000
                     progress_callback(i, p.seq_len, p.n_folds, gen_rate)
                 time.sleep(0.002)
+            th.join()
+            if res.get("rc", -1) < 0:
+                raise _lib.MbHipError(f"mb_wavernn_generate failed ({res.get('rc')}): {res.get('err')}")
         torch.cuda.current_stream().synchronize()
         ms, nl = C.c_float(), C.c_int()
         _lib.check(L.mb_wavernn_last_loop_ms(self._h, C.byref(ms), C.byref(nl)), "mb_wavernn_last_loop_ms")
