@@ -46,14 +46,28 @@ def test_wavernn_weight_list_matches_abi_counts(lib):
 
 
 def test_conv_pack_is_a_permutation_with_zero_padding(lib):
-    """mb_conv1d_pack: every weight appears exactly once in the A-fragment image (conv and all
-    polyphase taps of the transposed conv), padding is zero."""
+    """mb_conv1d_pack: the image is [fp32 A fragments | 64-float header | fp16 hi / lo A fragments].  Every weight appears
+    exactly once in the fp32 part (conv and all polyphase taps of the transposed conv), padding is zero; the split part
+    holds w * 2^s as hi + lo halves (header word 0 = 2^-s) that add back to the weight to 22 bits."""
     import hiputil
     for (shape, transposed, up, pad) in (((40, 20, 3), False, 1, 1), ((24, 16, 10), True, 5, 3), ((64, 32, 4), True, 2, 1)):
-        w = torch.arange(1, int(np.prod(shape)) + 1, dtype=torch.float32).reshape(shape)
-        packed, _ = hiputil.pack_conv(w, transposed, up, pad)
-        nz = packed[packed != 0]
+        w = torch.arange(1, int(np.prod(shape)) + 1, dtype=torch.float32).reshape(shape) / 1000.0
+        packed, (c_out, c_in, k) = hiputil.pack_conv(w, transposed, up, pad)
+        n_mt, n_cb, n_ks = (c_out + 31) // 32, (c_in + 7) // 8, (c_in + 15) // 16
+        n_f32 = n_mt * n_cb * k * 256
+        assert packed.numel() == n_f32 + 64 + n_mt * n_ks * k * 512
+        f32 = packed[:n_f32]
+        nz = f32[f32 != 0]
         assert nz.numel() == w.numel() and torch.equal(nz.sort().values, w.flatten().sort().values)
+        unscale = float(packed[n_f32])
+        assert unscale > 0 and np.log2(unscale) == round(np.log2(unscale)) and float(packed[n_f32 + 1:n_f32 + 64].abs().max()) == 0
+        assert 2 ** 13 <= float(w.abs().max()) / unscale < 2 ** 14
+        halves = packed[n_f32 + 64:].view(torch.float16).reshape(-1, 2, 512).double()  # [(p, mt, ks, tap)][hi | lo][lane * 8 + e]
+        rec = ((halves[:, 0] + halves[:, 1]) * unscale).flatten()
+        rnz = rec[rec != 0]
+        assert rnz.numel() == w.numel()
+        err = (rnz.sort().values - w.flatten().double().sort().values).abs() / w.flatten().double().sort().values
+        assert float(err.max()) < 2.0 ** -21, float(err.max())
 
 
 @pytest.mark.parametrize("frames,target,overlap", [(30, 600, 100), (1000, 8000, 800), (200, 8000, 800), (44, 8000, 800)])
