@@ -824,6 +824,12 @@ def main():
                                  "achieved": wbytes / (entry["batch1"]["us_per_step"] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": wbytes / (entry["batch1"]["us_per_step"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                  "traffic": None, "algorithmic_bytes_per_step": wbytes}
+            try:  # HBM bytes of one step (all six launches) from the committed PMC passes (tools/pmc_r03_ppg.sh)
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_ppg2mel.json")))
+                entry["roofline"]["traffic"] = pm["step_hbm_bytes_per_launch"]
+                entry["roofline"]["traffic_source"] = "profiles/r03_pmc_ppg2mel.json: " + pm.get("source", "")[:200]
+            except Exception:
+                pass
             result["ppg2mel"] = entry
         # ---- CPU baselines: the reference itself when its checkout is importable (this container), else the oracle
         # port (the GPU box has no /root/reference); torch's default thread count = what the reference would use
