@@ -193,28 +193,31 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 static constexpr int SCK = 32;
 static constexpr int SROW = SCK * 4 + 16;  // bytes per staged position
 
-__device__ __forceinline__ void split_store(char* row, const int grp, const float (&v)[8]) {
+// One workgroup = 4 waves on 128 output positions (WM x WN waves, NTW 32-position tiles per wave: 4x1x4, 2x2x2 or 1x4x1).
+// Pipeline per 32-channel chunk: the NEXT chunk's x values are already in flight to registers (SITEMS x 8 floats per
+// thread, issued before this chunk's MFMAs), the chunk itself is computed from LDS, then the registers are split into
+// hi / lo halves and stored: global latency sits behind the MFMAs, five workgroups per CU hide the rest.
+// The first version of this kernel was VALU-bound, not matrix-bound: ~5500 vector instructions per wave next to 168 MFMAs
+// (rocprofv3 SQ_INSTS_VALU; the do-nothing skeleton alone cost half the kernel).  Hence: loads are unconditional from
+// clamped 32-bit offsets (one add per element, the select happens on the value), work items (position, 8-channel group) are
+// dealt evenly over the 256 threads, every stride is hoisted, and the epilogue has a straight-line path for interior tiles.
+static constexpr int SNT = 128;    // output positions per workgroup
+static constexpr int SITEMS = 4;   // (position, 8-channel group) items per thread and chunk: rowlen <= 256
+
+__device__ __forceinline__ void split_store2(char* row, const int grp, const float (&v)[8]) {
   h16x8 hi, lo;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const float c = fminf(fmaxf(v[e], -65504.f), 65504.f);
-    const h16 h = (h16)c;
+    const h16 h = (h16)__builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
     hi[e] = h;
-    lo[e] = (h16)fminf(fmaxf(v[e] - (float)h, -65504.f), 65504.f);
+    lo[e] = (h16)__builtin_amdgcn_fmed3f(v[e] - (float)h, -65504.f, 65504.f);
   }
   *reinterpret_cast<h16x8*>(row + grp * 16) = hi;
   *reinterpret_cast<h16x8*>(row + SCK * 2 + grp * 16) = lo;
 }
 
-// One workgroup = 4 waves on 128 output positions (WM x WN waves, NTW 32-position tiles per wave: 4x1x4, 2x2x2 or 1x4x1).
-// Pipeline per 32-channel chunk: the NEXT chunk's x values are already in flight to registers (SITEMS x 8 floats per
-// thread, issued before this chunk's MFMAs), the chunk itself is computed from one of two LDS buffers, then the registers
-// are split into hi / lo halves and stored into the other buffer: one barrier per chunk, global latency behind the MFMAs.
-static constexpr int SNT = 128;    // output positions per workgroup
-static constexpr int SITEMS = 4;   // (position, 8-channel group) items per thread and chunk: rowlen <= 256
-
 template <int WM, int WN, int NTW, bool TR, bool POOL>
-__global__ __launch_bounds__(256) void conv1d_split_kernel(ConvK a, const uint4* __restrict__ wsplit, const float* __restrict__ whdr) {
+__global__ __launch_bounds__(256) void conv1d_split_kernel(ConvK a, const uint4* __restrict__ wsplit, const float* __restrict__ whdr, const int nbuf) {
   extern __shared__ __attribute__((aligned(16))) char slds[];
   static_assert(32 * NTW * WN == SNT, "tile shape");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -238,44 +241,59 @@ __global__ __launch_bounds__(256) void conv1d_split_kernel(ConvK a, const uint4*
   const uint4* wp = wsplit + ((size_t)(p * n_mt + (active ? mt : 0)) * n_w) * 128 + lane;
   const int off_base = a.off0[p] - a.min_off;
   const int t_src = a.in_repeat > 1 ? a.t_in / a.in_repeat : a.t_in;
-  const size_t buf_bytes = (size_t)rowlen * SROW;
 
-  // this thread's staging position (one per chunk; group g = item index)
-  const int tt = tid;                                  // 0..255
-  const int ti = q0 * a.down + a.min_off + tt;         // input position
-  const bool pos_ok = tt < rowlen && ti >= 0 && ti < t_lim;
-  const int tsrc_i = pos_ok ? (a.in_repeat > 1 ? ti / a.in_repeat : ti) : 0;
-  const bool pool_prev = POOL && pos_ok && ti > 0;
+  // ---- staging items of this thread: item = tid + 256 i -> row = item >> 2 (position of the window), grp = item & 3 ----
+  int lds_off[SITEMS];        // byte offset of the row (hi part of group 0) or -1: no such row
+  unsigned x_off[SITEMS];     // element offset of (channel grp * 8 of chunk 0, position) inside this batch item, clamped to a legal one
+  bool x_ok[SITEMS], x_prev[SITEMS];
+  const int ti0 = q0 * a.down + a.min_off;
+#pragma unroll
+  for (int it = 0; it < SITEMS; ++it) {
+    const int item = tid + 256 * it, row = item >> 2, grp = item & 3;
+    const int ti = ti0 + row;
+    lds_off[it] = row < rowlen ? row * SROW + grp * 16 : -1;
+    x_ok[it] = row < rowlen && ti >= 0 && ti < t_lim;
+    const int tsi = x_ok[it] ? (a.in_repeat > 1 ? ti / a.in_repeat : ti) : 0;
+    x_prev[it] = POOL && x_ok[it] && ti > 0;
+    x_off[it] = (unsigned)(grp * 8) * (unsigned)t_src + (unsigned)tsi;
+  }
+  const unsigned chunk_step = (unsigned)SCK * (unsigned)t_src;
+  const unsigned last_ch = (unsigned)(a.c_in - 1) * (unsigned)t_src;  // offsets beyond the last channel are clamped (value zeroed)
 
   float pre[SITEMS][8], pre2[POOL ? SITEMS : 1][8];
   auto issue = [&](const int c0) {  // global loads of chunk c0 -> registers (nothing waits here)
 #pragma unroll
-    for (int g = 0; g < SITEMS; ++g)
+    for (int it = 0; it < SITEMS; ++it) {
+      unsigned o = x_off[it] + (unsigned)(c0 / SCK) * chunk_step;
+      const int cbase = c0 + (tid & 3) * 8;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int ci = c0 + g * 8 + e;
-        const bool ok = pos_ok && ci < a.c_in;
-        const float* xr = xb + (long long)(ok ? ci : 0) * t_src + tsrc_i;
-        pre[g][e] = ok ? xr[0] : 0.f;
-        if (POOL) pre2[g][e] = (ok && pool_prev) ? xr[-1] : -INFINITY;
+        const bool ok = x_ok[it] && cbase + e < a.c_in;
+        const unsigned oc = min(o, last_ch + (unsigned)(t_src - 1));
+        const float v = xb[oc];
+        pre[it][e] = ok ? v : 0.f;
+        if (POOL) { const float v2 = xb[oc > 0 ? oc - 1 : 0]; pre2[it][e] = (ok && x_prev[it]) ? v2 : -INFINITY; }
+        o += (unsigned)t_src;
       }
+    }
   };
-  auto store = [&](char* buf) {  // registers -> fused input activation -> fp16 hi / lo rows
-    if (tt >= rowlen) return;
+  const float slope_eff = a.in_act == 1 ? a.in_slope : 1.f;
+  auto store = [&](const int boff) {  // registers -> fused input activation -> fp16 hi / lo rows (buffer at byte offset boff)
 #pragma unroll
-    for (int g = 0; g < SITEMS; ++g) {
+    for (int it = 0; it < SITEMS; ++it) {
+      if (lds_off[it] < 0) continue;
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float x = pre[g][e];
-        if (POOL) x = fmaxf(x, pre2[g][e]);  // MaxPool1d(2, stride 1, pad 1)[:T] (cbhg.py:20,61)
+        float x = pre[it][e];
+        if (POOL) x = fmaxf(x, pre2[it][e]);  // MaxPool1d(2, stride 1, pad 1)[:T] (cbhg.py:20,61)
         else {
-          x *= a.in_scale;
-          if (a.in_act == 1) x = x > 0.f ? x : x * a.in_slope;
+          x *= a.in_scale;                        // (1.0 when unused: exact)
+          x = x > 0.f ? x : x * slope_eff;        // leaky_relu, slope_eff = 1 when there is no input activation: exact
         }
         v[e] = x;
       }
-      split_store(buf + (size_t)tt * SROW, g, v);
+      split_store2(slds + boff + lds_off[it], 0, v);
     }
   };
 
@@ -290,28 +308,29 @@ __global__ __launch_bounds__(256) void conv1d_split_kernel(ConvK a, const uint4*
   if (active) { ah = wp[0]; al = wp[64]; }
 
   const int cin16 = n_ks * 16;
-  issue(0);
-  store(slds);
-  if (SCK < cin16) issue(SCK);
+  const int tap_stride = a.step * SROW, tile_stride = 32 * a.down * SROW;
+  const char* lbase0 = slds + ((wn * NTW * 32 + (lane & 31)) * a.down + off_base) * SROW + (lane >> 5) * 16;
+  // nbuf = 2 (many chunks, e.g. the 2560-channel CBHG projection): the next chunk is stored into the other buffer while slower
+  // waves still compute -- one barrier per chunk; nbuf = 1: half the LDS, more workgroups per CU, two barriers per chunk.
+  const int buf_bytes = rowlen * SROW;
   int cur = 0;
+  issue(0);
+  store(0);
+  if (SCK < cin16) issue(SCK);
   for (int c0 = 0; c0 < cin16; c0 += SCK) {
-    __syncthreads();  // chunk c0 is in LDS[cur]; every wave is done with LDS[cur ^ 1]
+    __syncthreads();  // chunk c0 is in LDS[cur] (and every wave is done with the other buffer)
     if (active) {
       const int nks2 = min(SCK, cin16 - c0) >> 4;
-      const char* lcur = slds + cur * buf_bytes;
       for (int ks2 = 0; ks2 < nks2; ++ks2) {
-        const char* lbase = lcur + (size_t)((wn * NTW * 32 + (lane & 31)) * a.down + off_base) * SROW + (ks2 * 2 + (lane >> 5)) * 16;
-        for (int j = 0; j < a.ntaps; ++j) {
+        const char* lp = lbase0 + cur * buf_bytes + ks2 * 32;
+        for (int j = 0; j < a.ntaps; ++j, lp += tap_stride) {
           ++wi;
-          uint4 nh = ah, nl = al;
-          if (wi < n_w) { nh = wp[(size_t)wi * 128]; nl = wp[(size_t)wi * 128 + 64]; }
           const h16x8 Ah = __builtin_bit_cast(h16x8, ah), Al = __builtin_bit_cast(h16x8, al);
-          const char* lp = lbase + (ptrdiff_t)j * a.step * SROW;
+          if (wi < n_w) { ah = wp[(size_t)wi * 128]; al = wp[(size_t)wi * 128 + 64]; }
 #pragma unroll
           for (int n = 0; n < NTW; ++n) {
-            const char* lq = lp + (size_t)(n * 32 * a.down) * SROW;
-            const h16x8 Bh = *reinterpret_cast<const h16x8*>(lq);
-            const h16x8 Bl = *reinterpret_cast<const h16x8*>(lq + SCK * 2);
+            const h16x8 Bh = *reinterpret_cast<const h16x8*>(lp + n * tile_stride);
+            const h16x8 Bl = *reinterpret_cast<const h16x8*>(lp + n * tile_stride + SCK * 2);
             if (!TR) {
               acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, acc[n], 0, 0, 0);
               acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc[n], 0, 0, 0);
@@ -322,48 +341,90 @@ __global__ __launch_bounds__(256) void conv1d_split_kernel(ConvK a, const uint4*
               acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bh, Ah, acc[n], 0, 0, 0);
             }
           }
-          ah = nh; al = nl;
         }
       }
     }
-    if (c0 + SCK < cin16) {  // the next chunk has arrived in the registers by now: into the other buffer, then fetch the one after
-      store(slds + (cur ^ 1) * buf_bytes);
+    if (c0 + SCK < cin16) {  // the next chunk has arrived in the registers by now
+      if (nbuf == 1) __syncthreads();  // one buffer: every wave is done reading it
+      else cur ^= 1;
+      store(cur * buf_bytes);
       if (c0 + 2 * SCK < cin16) issue(c0 + 2 * SCK);
     }
-    cur ^= 1;
   }
   if (!active) return;
 
+  // ---- epilogue.  D fragment (32x32): col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); without TR row = output channel,
+  //      col = position; with TR (operands swapped) row = position, col = output channel.  32-bit element offsets inside the batch
+  //      item (c_out * t_out < 2^31, checked on the host), built by additions. ----
   const float w_unscale = whdr[0];  // 2^-s of the host-side weight scaling
   float* yb = a.y + (long long)b * a.y_bstride;
   const float* rb = a.res ? a.res + (long long)b * a.res_bstride : nullptr;
+  const float* gb = a.out_act == 4 ? a.gate + (long long)b * a.y_bstride : nullptr;
+  const int dcol = lane & 31, drow0 = 4 * (lane >> 5);
+  const unsigned ch_stride = TR ? 1u : (unsigned)a.t_out;
+  const unsigned pos_stride = (TR ? (unsigned)a.c_out : 1u) * (unsigned)a.up;
+  const unsigned row_step = TR ? pos_stride : ch_stride;
+  const int co_b = mt * 32 + (TR ? dcol : drow0);
+  const bool simple = a.out_act == 0 || a.out_act == 1 || a.out_act == 5;
 #pragma unroll
   for (int n = 0; n < NTW; ++n) {
+    const int q_b = q0 + (wn * NTW + n) * 32 + (TR ? drow0 : dcol);
+    const unsigned o_b = (unsigned)co_b * ch_stride + ((unsigned)q_b * (unsigned)a.up + (unsigned)p) * (TR ? (unsigned)a.c_out : 1u);
+    const bool full = (TR ? (mt * 32 + 31 < a.c_out && q_b + 27 < Tq) : (mt * 32 + 31 < a.c_out && q0 + (wn * NTW + n) * 32 + 31 < Tq));
+    // every residual / running-sum value of the tile is requested before the first is used: one round trip per tile (a
+    // load -> add -> store chain per element made the second conv of a ResBlock unit twice as slow as the first)
+    float rv[16], yv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int drow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const int dcol = lane & 31;
-      const int co = mt * 32 + (TR ? dcol : drow);
-      const int q = q0 + (wn * NTW + n) * 32 + (TR ? drow : dcol);
-      const int t = q * a.up + p;
-      if (co < a.c_out && q < Tq) {
+      const int dr = (r & 3) + 8 * (r >> 2);
+      const bool ok = full || ((TR ? co_b : co_b + dr) < a.c_out && (TR ? q_b + dr : q_b) < Tq);
+      const unsigned o = ok ? o_b + (unsigned)dr * row_step : 0u;
+      rv[r] = rb ? rb[o] : 0.f;
+      yv[r] = a.accumulate ? yb[o] : 0.f;
+    }
+    if (simple && !gb) {  // no / relu / leaky-relu activation: no branch per element (absent operands read as 0 / 1 through selects)
+      const float* bp = a.bias ? a.bias : whdr;
+      const float* psp = a.post_scale ? a.post_scale : whdr;
+      const float* ptp = a.post_scale ? a.post_shift : whdr;
+      const float bsel = a.bias ? 1.f : 0.f, psel = a.post_scale ? 1.f : 0.f;
+      const float oslope = a.out_act == 1 ? 0.f : (a.out_act == 5 ? a.out_slope : 1.f);  // v > 0 ? v : v * oslope
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int dr = (r & 3) + 8 * (r >> 2);
+        const int co = TR ? co_b : co_b + dr, q = TR ? q_b + dr : q_b;
+        const int cc = min(co, a.c_out - 1);
+        float v = fmaf(acc[n][r], w_unscale, bp[a.bias ? cc : 0] * bsel);
+        v = v > 0.f ? v : v * oslope;
+        v = fmaf(v, fmaf(psp[a.post_scale ? cc : 0], psel, 1.f - psel), ptp[a.post_scale ? cc : 0] * psel);
+        v += rv[r];
+        v *= a.out_scale;
+        v += yv[r];
+        if (full || (co < a.c_out && q < Tq)) yb[o_b + (unsigned)dr * row_step] = v;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int dr = (r & 3) + 8 * (r >> 2);
+        const int co = TR ? co_b : co_b + dr, q = TR ? q_b + dr : q_b;
+        const unsigned o = o_b + (unsigned)dr * row_step;
+        const int cc = min(co, a.c_out - 1);
         float v = acc[n][r] * w_unscale;
-        if (a.bias) v += a.bias[co];
+        if (a.bias) v += a.bias[cc];
         if (a.out_act == 1) v = fmaxf(v, 0.f);
         else if (a.out_act == 2) v = tanhf(v);
         else if (a.out_act == 3) v = 1.0f / (1.0f + expf(-v));
         else if (a.out_act == 5) v = v > 0.f ? v : v * a.out_slope;
-        if (a.post_scale) v = v * a.post_scale[co] + a.post_shift[co];
-        const long long o = TR ? ((long long)t * a.c_out + co) : ((long long)co * a.t_out + t);
-        if (a.out_act == 4) {
-          const float g = a.gate[(long long)b * a.y_bstride + o];
-          v = g * fmaxf(v, 0.f) + (1.f - g) * rb[o];
-        } else if (rb) v += rb[o];
-        v *= a.out_scale;
-        if (a.accumulate) v += yb[o];
-        yb[o] = v;
+        if (a.post_scale) v = v * a.post_scale[cc] + a.post_shift[cc];
+        if (full || (co < a.c_out && q < Tq)) {
+          if (gb) { const float g = gb[o]; v = g * fmaxf(v, 0.f) + (1.f - g) * rv[r]; }  // highway (rare: per-element gate load)
+          else v += rv[r];
+          v *= a.out_scale;
+          v += yv[r];
+          yb[o] = v;
+        }
       }
     }
+    __builtin_amdgcn_sched_barrier(0);  // one tile's operands in flight at a time
   }
 }
 
@@ -516,13 +577,16 @@ extern "C" int mb_conv1d(const mb_conv1d_args* a, mb_stream_t stream) {
     const int wm = n_mt >= 4 ? 4 : (n_mt >= 2 ? 2 : 1);
     dim3 grid(cdiv(tq, SNT), cdiv(n_mt, wm), a->batch * a->up);
     const int rowlen = SNT * k.down + k.span;
-    const size_t lds = (size_t)(k.c_in <= SCK ? 1 : 2) * rowlen * SROW;  // one chunk: no second buffer (more workgroups per CU instead)
-    if (rowlen <= 256) {  // (strided convs with long halos: the fp32-input kernel below)
+    const char* l2env = getenv("MBHIP_CONV_SPLIT_LDS2");  // A/B: force one (0) or two (1) x-tile buffers
+    const int nbuf = l2env ? (atoi(l2env) == 1 && k.c_in > SCK ? 2 : 1) : (k.c_in >= 512 ? 2 : 1);
+    const size_t lds = (size_t)nbuf * rowlen * SROW;
+    const bool fits32 = (long long)a->c_in * a->t_in < (1ll << 31) && (long long)a->c_out * a->t_out < (1ll << 31);  // 32-bit offsets inside an item
+    if (rowlen <= 256 && fits32) {  // (strided convs with long halos, giant items: the fp32-input kernel below)
       const bool pool = a->in_act == 2;
 #define MB_SLAUNCH2(WM_, WN_, NTW_, TR_)                                                                                          \
   do {                                                                                                                            \
-    if (pool) hipLaunchKernelGGL((conv1d_split_kernel<WM_, WN_, NTW_, TR_, true>), grid, dim3(256), lds, s, k, wsplit, hdr);      \
-    else hipLaunchKernelGGL((conv1d_split_kernel<WM_, WN_, NTW_, TR_, false>), grid, dim3(256), lds, s, k, wsplit, hdr);          \
+    if (pool) hipLaunchKernelGGL((conv1d_split_kernel<WM_, WN_, NTW_, TR_, true>), grid, dim3(256), lds, s, k, wsplit, hdr, nbuf);      \
+    else hipLaunchKernelGGL((conv1d_split_kernel<WM_, WN_, NTW_, TR_, false>), grid, dim3(256), lds, s, k, wsplit, hdr, nbuf);          \
   } while (0)
 #define MB_SLAUNCH(WM_, WN_, NTW_)                                          \
   do {                                                                      \
