@@ -472,6 +472,10 @@ size_t mb_ppg2mel_workspace_bytes(const mb_ppg2mel* p, int batch);
 /* Duration of the decoder loop of the last mb_ppg2mel_decode call (HIP events on the loop's stream) and the steps it
  * produced; production-dims handles only (the graph-replayed step of ppg_fast.h), MB_ESTATE otherwise. */
 int mb_ppg2mel_last_loop_ms(const mb_ppg2mel* p, float* ms, int* steps);
+/* Kernel launches the decoder loop of the last mb_ppg2mel_decode call took: 1 = the resident loop (one utterance,
+ * csrc/ppg_resident.h: the whole Decoder.inference loop, rnn_decoder_mol.py:267-316, as one launch), 6 per step on the
+ * graph-replayed chain (csrc/ppg_fast.h).  Production-dims handles only, MB_ESTATE otherwise. */
+int mb_ppg2mel_last_loop_launches(const mb_ppg2mel* p, int* launches);
 int mb_ppg2mel_decode(const mb_ppg2mel* p, const float* d_memory, int batch, int t_enc, int max_steps,
                       int min_steps, float stop_threshold, const float* d_dropout, uint64_t seed,
                       float* d_mel, float* d_align, float* d_stop, int* h_n_steps, void* d_workspace,

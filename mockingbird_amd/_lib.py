@@ -206,6 +206,7 @@ SIGNATURES = {
     "mb_ppg2mel_destroy": (None, [C.c_void_p]),
     "mb_ppg2mel_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
     "mb_ppg2mel_last_loop_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "mb_ppg2mel_last_loop_launches": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "mb_ppg2mel_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                     C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p,
                                     C.c_size_t, C.c_void_p]),

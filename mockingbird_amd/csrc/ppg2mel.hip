@@ -14,6 +14,7 @@
 // frame straight out of the projection buffer.  fp32 throughout.
 #include "rnn.h"
 #include "ppg_fast.h"
+#include "ppg_resident.h"
 
 namespace mb {
 
@@ -140,6 +141,12 @@ struct mb_ppg2mel {
   // fast step (ppg_fast.h), production dims only
   bool fast = false;
   DevBuf f_att_p, f_att_c, f_att_h, f_att_b4, f_dec_x, f_dec_h, f_dec_b4, f_fc0_w, f_fc0_b;
+  // resident loop at batch 1 (ppg_resident.h): per-workgroup LDS images of the same weights
+  bool resident = false;
+  DevBuf r_att, r_w1, r_dec, r_q0, r_out;
+  int resident_cus = -1;  // compute units a resident launch may count on (-1: not probed yet, 0: none)
+  int* h_abort = nullptr;
+  hipEvent_t ev_res = nullptr;
   struct GraphKey {
     const void *mem, *drop, *mel, *align, *stop, *ws; int B, T, max_steps, min_steps, G; float thr;
     bool operator==(const GraphKey& o) const {  // field by field (padding bytes are unspecified)
@@ -152,12 +159,15 @@ struct mb_ppg2mel {
   int* h_flags = nullptr;
   hipEvent_t ev_flags[2] = {nullptr, nullptr}, ev_in = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
   hipStream_t loop_stream = nullptr;
-  int last_steps = 0; bool timed = false;
+  int last_steps = 0, last_chain_steps = 0; bool timed = false, last_resident = false;
   void drop_graph() {
     if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
     if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
   }
 };
+
+// a resident launch (ppg_resident.h) once lost a hand-off on this device: stop defaulting to it there
+static bool g_ppg_resident_failed[64] = {};
 
 static int ppg_shapes(const mb_ppg2mel_config* c, std::vector<size_t>* numel) {
   MB_REQUIRE(c, "ppg2mel: null config");
@@ -201,11 +211,13 @@ extern "C" void mb_ppg2mel_destroy(mb_ppg2mel* p) {
   for (auto& b : p->dec_bih) b.release();
   for (auto& b : p->dec_bhh) b.release();
   DevBuf* bs[] = {&p->zero_bias, &p->att_w, &p->att_bih, &p->att_bhh, &p->q0_w, &p->q0_b, &p->q2_w, &p->q2_b, &p->out_w, &p->out_b,
-                  &p->f_att_p, &p->f_att_c, &p->f_att_h, &p->f_att_b4, &p->f_dec_x, &p->f_dec_h, &p->f_dec_b4, &p->f_fc0_w, &p->f_fc0_b};
+                  &p->f_att_p, &p->f_att_c, &p->f_att_h, &p->f_att_b4, &p->f_dec_x, &p->f_dec_h, &p->f_dec_b4, &p->f_fc0_w, &p->f_fc0_b,
+                  &p->r_att, &p->r_w1, &p->r_dec, &p->r_q0, &p->r_out};
   for (DevBuf* b : bs) b->release();
   p->drop_graph();
   if (p->h_flags) (void)hipHostFree(p->h_flags);
-  hipEvent_t evs[] = {p->ev_flags[0], p->ev_flags[1], p->ev_in, p->ev_t0, p->ev_t1};
+  if (p->h_abort) (void)hipHostFree(p->h_abort);
+  hipEvent_t evs[] = {p->ev_flags[0], p->ev_flags[1], p->ev_in, p->ev_t0, p->ev_t1, p->ev_res};
   for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
   if (p->loop_stream) (void)hipStreamDestroy(p->loop_stream);
   delete p;
@@ -265,7 +277,7 @@ extern "C" int mb_ppg2mel_create(const mb_ppg2mel_config* cfg, const float* cons
     ix += 4;
   }
   p->fast = cfg->n_prenet == 2 && cfg->prenet_dims[0] == 256 && cfg->prenet_dims[1] == 128 && E == 256 && A == 512 && D == 512 &&
-            cfg->num_decoder_rnn_layer == 1 && cfg->concat_context_to_last && (nm * r) % 16 == 0 && nm % 4 == 0 && M <= 16;
+            cfg->num_decoder_rnn_layer == 1 && cfg->concat_context_to_last && (nm * r) % 16 == 0 && nm % 4 == 0 && 3 * M <= 16;  // (ppg_mol_kernel: 16 parameter rows)
   if (p->fast && !rc) {
     // weight list: 0-1 prenet, 2-5 attention_rnn (w_ih [4A][P+E], w_hh, b_ih, b_hh), 6-9 query layers, 10-13 decoder rnn, 14-17 projection / stop
     const int Pn = cfg->prenet_dims[1];
@@ -301,13 +313,71 @@ extern "C" int mb_ppg2mel_create(const mb_ppg2mel_config* cfg, const float* cons
       }
       pack_rowtile(wf.data(), P0, kout, 4, &packed); RC(p->f_fc0_w.upload(packed.data(), packed.size()));
       RC(p->f_fc0_b.upload(bf.data(), bf.size()));
+      // resident loop (ppg_resident.h): float4 chunk c of thread t at (c * threads + t) * 4, slice sl = t & 15 owns k = (c * 16 + sl) * 4 .. + 3
+      const int RMr = nm * r, nmel = RMr / 16;
+      p->resident = 17 + nmel <= 32;
+      if (p->resident) {
+        const float *w_stop = hw[16], *q0w = hw[6], *w1 = hw[1];
+        std::vector<float> img;
+        img.assign((size_t)PR_ATT * PR_IMG_ATT, 0.f);
+        for (int g = 0; g < PR_ATT; ++g)
+          for (int c = 0; c < 14; ++c)
+            for (int t = 0; t < 512; ++t) {
+              const int rl = t >> 4, sl = t & 15, row = (rl & 3) * A + g * 8 + (rl >> 2);
+              for (int e = 0; e < 4; ++e) {
+                float v;
+                if (c < 2) v = a_wih[(size_t)row * (Pn + E) + (c * 16 + sl) * 4 + e];
+                else if (c < 6) v = a_wih[(size_t)row * (Pn + E) + Pn + ((c - 2) * 16 + sl) * 4 + e];
+                else v = a_whh[(size_t)row * A + ((c - 6) * 16 + sl) * 4 + e];
+                img[(size_t)g * PR_IMG_ATT + ((size_t)c * 512 + t) * 4 + e] = v;
+              }
+            }
+        RC(p->r_att.upload(img.data(), img.size()));
+        img.assign((size_t)PR_IMG_W1, 0.f);
+        for (int c = 0; c < 16; ++c)
+          for (int t = 0; t < 512; ++t)
+            for (int e = 0; e < 4; ++e) img[((size_t)c * 512 + t) * 4 + e] = w1[(size_t)(t >> 2) * P0 + (c * 4 + (t & 3)) * 4 + e];
+        RC(p->r_w1.upload(img.data(), img.size()));
+        img.assign((size_t)PR_DEC * PR_IMG_DEC, 0.f);
+        for (int d = 0; d < PR_DEC; ++d)
+          for (int t = 0; t < 256; ++t) {
+            const int rl = t >> 4, sl = t & 15, row = (rl & 3) * D + d * 4 + (rl >> 2);
+            for (int c = 0; c < 12; ++c)
+              for (int e = 0; e < 4; ++e)
+                img[(size_t)d * PR_IMG_DEC + ((size_t)c * 256 + t) * 4 + e] = d_wih[(size_t)row * (A + E) + (c * 16 + sl) * 4 + e];
+            for (int c = 0; c < 8; ++c)
+              for (int e = 0; e < 4; ++e)
+                img[(size_t)d * PR_IMG_DEC + ((size_t)(12 + c) * 256 + t) * 4 + e] = d_whh[(size_t)row * D + (c * 16 + sl) * 4 + e];
+          }
+        RC(p->r_dec.upload(img.data(), img.size()));
+        img.assign((size_t)PR_Q0 * PR_IMG_Q0, 0.f);
+        for (int j = 0; j < PR_Q0; ++j)
+          for (int c = 0; c < 8; ++c)
+            for (int t = 0; t < 512; ++t)
+              for (int e = 0; e < 4; ++e)
+                img[(size_t)j * PR_IMG_Q0 + ((size_t)c * 512 + t) * 4 + e] = q0w[(size_t)(j * 32 + (t >> 4)) * A + (c * 16 + (t & 15)) * 4 + e];
+        RC(p->r_q0.upload(img.data(), img.size()));
+        img.assign((size_t)PR_OUT * PR_IMG_OUT, 0.f);
+        for (int j = 0; j < PR_OUT; ++j)
+          for (int t = 0; t < 512; ++t) {
+            const int lr = t >> 4, sl = t & 15;
+            const float* src = lr == 0 ? w_stop : lr <= 16 ? wf.data() + (size_t)(j * 16 + lr - 1) * kout
+                                                 : lr < 17 + nmel ? w_proj + (size_t)(j * nmel + lr - 17) * kout : nullptr;
+            if (!src) continue;
+            for (int c = 0; c < 12; ++c)
+              for (int e = 0; e < 4; ++e) img[(size_t)j * PR_IMG_OUT + ((size_t)c * 512 + t) * 4 + e] = src[(c * 16 + sl) * 4 + e];
+          }
+        RC(p->r_out.upload(img.data(), img.size()));
+      }
     }
     if (!rc && (hipHostMalloc((void**)&p->h_flags, sizeof(int) * 16) != hipSuccess ||
                 hipStreamCreateWithFlags(&p->loop_stream, hipStreamNonBlocking) != hipSuccess ||
                 hipEventCreateWithFlags(&p->ev_in, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreate(&p->ev_t0) != hipSuccess || hipEventCreate(&p->ev_t1) != hipSuccess ||
                 hipEventCreateWithFlags(&p->ev_flags[0], hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&p->ev_flags[1], hipEventDisableTiming) != hipSuccess)) {
+                hipEventCreateWithFlags(&p->ev_flags[1], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&p->ev_res, hipEventDisableTiming) != hipSuccess ||
+                hipHostMalloc((void**)&p->h_abort, sizeof(int), hipHostMallocDefault) != hipSuccess)) {
       set_error("ppg2mel_create: stream / events / pinned flags");
       rc = MB_EHIP;
     }
@@ -325,6 +395,7 @@ struct PpgLayout {
   float *f_p0, *f_p1, *f_ah, *f_q, *f_ctx, *f_dh, *f_ac, *f_dc, *f_prec, *f_preh, *f_pred;
   size_t f_bytes;
   int* flags;
+  unsigned long long* px;  // resident loop (ppg_resident.h): granule exchange area + abort word + diagnostics marks
   size_t bytes;
   int ldy;
 };
@@ -355,6 +426,7 @@ void ppg_layout(const mb_ppg2mel* p, int B, void* base, PpgLayout* L) {
     L->f_bytes = ar.off - start;
   }
   L->flags = ar.take<int>(16);
+  L->px = ar.take<unsigned long long>(pr_exchange_bytes() / 8);
   L->bytes = ar.off + 256;
 }
 }  // namespace
@@ -436,7 +508,7 @@ static int ppg_fast_loop_body(mb_ppg2mel* p, const PpgLayout& L, const float* d_
   int G = 16;
   if (const char* ge = getenv("MBHIP_PPG_GRAPH_STEPS")) G = std::max(1, atoi(ge));
   const bool use_graph = getenv("MBHIP_NO_GRAPH") == nullptr && max_steps >= G;
-  int done_steps = 0, rc = MB_OK;
+  int done_steps = 0, eager_steps = 0, rc = MB_OK;
   bool stopped = false;
   if (use_graph) {
     mb_ppg2mel::GraphKey key = {d_memory, d_dropout, d_mel, d_align, d_stop, d_workspace, B, T, max_steps, min_steps, G, thr};
@@ -466,6 +538,7 @@ static int ppg_fast_loop_body(mb_ppg2mel* p, const PpgLayout& L, const float* d_
   }
   for (int st = done_steps; st < max_steps && !stopped; ++st) {
     if ((rc = step(st - done_steps))) return rc;
+    ++eager_steps;
     if (((st - done_steps) & 15) == 15) {
       MB_HIP(hipMemcpyAsync(p->h_flags, flags, sizeof(int) * 8, hipMemcpyDeviceToHost, s));
       MB_HIP(hipStreamSynchronize(s));
@@ -476,7 +549,7 @@ static int ppg_fast_loop_body(mb_ppg2mel* p, const PpgLayout& L, const float* d_
   MB_HIP(hipMemcpyAsync(p->h_flags, flags, sizeof(int) * 8, hipMemcpyDeviceToHost, s));
   MB_HIP(hipStreamSynchronize(s));
   *steps_out = p->h_flags[TF_NFRAMES];
-  p->last_steps = *steps_out; p->timed = true;
+  p->last_steps = *steps_out; p->timed = true; p->last_chain_steps = done_steps + eager_steps;
   return MB_OK;
 }
 
@@ -485,6 +558,13 @@ extern "C" int mb_ppg2mel_last_loop_ms(const mb_ppg2mel* p, float* ms, int* step
   if (!p->timed) { set_error("ppg2mel_last_loop_ms: no decode on the fast loop yet"); return MB_ESTATE; }
   MB_HIP(hipEventElapsedTime(ms, p->ev_t0, p->ev_t1));
   if (steps) *steps = p->last_steps;
+  return MB_OK;
+}
+
+extern "C" int mb_ppg2mel_last_loop_launches(const mb_ppg2mel* p, int* launches) {
+  MB_REQUIRE(p && launches, "ppg2mel_last_loop_launches: null pointer");
+  if (!p->timed) { set_error("ppg2mel_last_loop_launches: no decode on the fast loop yet"); return MB_ESTATE; }
+  *launches = p->last_resident ? 1 : 6 * p->last_chain_steps;
   return MB_OK;
 }
 
@@ -525,6 +605,72 @@ extern "C" int mb_ppg2mel_decode(const mb_ppg2mel* p, const float* d_memory, int
     mb_ppg2mel* pm = const_cast<mb_ppg2mel*>(p);
     MB_HIP(hipEventRecord(pm->ev_in, s));
     MB_HIP(hipStreamWaitEvent(pm->loop_stream, pm->ev_in, 0));
+    // One utterance: the whole loop as ONE resident launch (ppg_resident.h; MBHIP_PPG_RESIDENT=0 keeps the 6-launch step,
+    // =1 retries on a device where a resident launch lost a hand-off before).  Needs its 217 workgroups co-resident, one
+    // per compute unit: checked against the device; a launch that still loses a hand-off drains itself (abort word = 1)
+    // and the launch chain below redoes the utterance.
+    const char* renv = getenv("MBHIP_PPG_RESIDENT");
+    bool resident = pm->resident && B == 1 && T <= PR_T_MAX && !(renv && atoi(renv) == 0);
+    int dev = 0;
+    if (resident) {
+      MB_HIP(hipGetDevice(&dev));
+      if (pm->resident_cus < 0) {
+        hipDeviceProp_t prop;
+        MB_HIP(hipGetDeviceProperties(&prop, dev));
+        MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppg_resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PR_LDS_BYTES));
+        int nb = 0;
+        MB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(ppg_resident_kernel), 512, PR_LDS_BYTES));
+        pm->resident_cus = nb >= 1 ? prop.multiProcessorCount : 0;
+      }
+      if (pm->resident_cus < PR_WGS) resident = false;
+      if (dev >= 0 && dev < 64 && g_ppg_resident_failed[dev] && !renv) resident = false;
+    }
+    if (resident) {
+      hipStream_t ls = pm->loop_stream;
+      int* abort_word = reinterpret_cast<int*>(L.px + (size_t)2 * PRX_PER);
+      MB_HIP(hipMemsetAsync(L.px, 0, pr_exchange_bytes(), ls));
+      if (getenv("MBHIP_PR_TEST_ABORT")) MB_HIP(hipMemsetAsync(abort_word, 1, 1, ls));  // tests only: the chain takes over
+      const char* rtrace = getenv("MBHIP_PR_TRACE");  // diagnostics: dump the wall-clock marks of the kernel to this file
+      PrK k;
+      k.img_att = pm->r_att.p; k.img_w1 = pm->r_w1.p; k.img_dec = pm->r_dec.p; k.img_q0 = pm->r_q0.p; k.img_out = pm->r_out.p;
+      k.att_b4 = reinterpret_cast<const float4*>(pm->f_att_b4.p); k.dec_b4 = reinterpret_cast<const float4*>(pm->f_dec_b4.p);
+      k.q0_b = pm->q0_b.p; k.out_b = pm->out_b.p; k.fc0_b = pm->f_fc0_b.p; k.w2 = pm->q2_w.p; k.b2 = pm->q2_b.p;
+      k.memory = d_memory; k.mel_out = d_mel; k.align_out = d_align; k.stop_out = d_stop; k.drop_mask = d_dropout;
+      k.ex = L.px; k.abort_word = abort_word; k.flags = L.flags; k.seed = seed;
+      k.T = T; k.M = M; k.RM = RM; k.S = max_steps; k.min_steps = min_steps; k.thr = stop_threshold; k.eps = 1e-5f;
+      k.trace = rtrace ? reinterpret_cast<unsigned long long*>(abort_word) + 32 : nullptr;
+      MB_HIP(hipEventRecord(pm->ev_t0, ls));
+      hipLaunchKernelGGL(ppg_resident_kernel, dim3(PR_WGS), dim3(512), PR_LDS_BYTES, ls, k);
+      MB_HIP(hipGetLastError());
+      MB_HIP(hipEventRecord(pm->ev_t1, ls));
+      MB_HIP(hipMemcpyAsync(pm->h_abort, abort_word, sizeof(int), hipMemcpyDeviceToHost, ls));
+      MB_HIP(hipMemcpyAsync(pm->h_flags, L.flags, sizeof(int) * 8, hipMemcpyDeviceToHost, ls));
+      MB_HIP(hipEventRecord(pm->ev_res, ls));
+      MB_HIP(hipEventSynchronize(pm->ev_res));
+      if (*pm->h_abort != 1) {
+        if (rtrace) {
+          unsigned long long marks[5 * 4 * 16];
+          MB_HIP(hipMemcpy(marks, k.trace, sizeof(marks), hipMemcpyDeviceToHost));
+          if (FILE* f = fopen(rtrace, "wb")) { fwrite(marks, sizeof(marks), 1, f); fclose(f); }
+        }
+        *h_n_steps = pm->h_flags[TF_NFRAMES];
+        pm->last_steps = *h_n_steps; pm->timed = true; pm->last_resident = true;
+        return MB_OK;
+      }
+      static bool warned = false;
+      if (!warned) {
+        fprintf(stderr, "[mbhip] ppg2mel: resident kernel could not keep its workgroups co-resident; using the launch chain\n");
+        warned = true;
+      }
+      if (dev >= 0 && dev < 64 && !getenv("MBHIP_PR_TEST_ABORT")) g_ppg_resident_failed[dev] = true;
+      // whatever the drained launch left behind: outputs and flags back to zero, then the chain from step 0
+      MB_HIP(hipMemsetAsync(L.mu, 0, sizeof(float) * B * M, ls));
+      MB_HIP(hipMemsetAsync(L.flags, 0, sizeof(int) * 8, ls));
+      MB_HIP(hipMemsetAsync(d_mel, 0, sizeof(float) * (size_t)B * max_steps * RM, ls));
+      MB_HIP(hipMemsetAsync(d_align, 0, sizeof(float) * (size_t)B * max_steps * T, ls));
+      MB_HIP(hipMemsetAsync(d_stop, 0, sizeof(float) * (size_t)B * max_steps, ls));
+    }
+    pm->last_resident = false;
     const int rcf = ppg_fast_loop_body(pm, L, d_memory, B, T, max_steps, min_steps, stop_threshold, d_dropout, seed, d_mel, d_align,
                                        d_stop, d_workspace, pm->loop_stream, h_n_steps);
     if (rcf) (void)hipStreamSynchronize(pm->loop_stream);

@@ -30,22 +30,13 @@
 // demand when other work shares the GPU.
 #pragma once
 #include "wavernn_fast.h"
+#include "granule.h"
 
 namespace mb {
 
 constexpr int WP_NCOL = 4;        // fold columns supported (LDS budget of the busiest workgroup: 152 KB of 160)
 constexpr int WP_ON = 64;         // on-chain workgroups
 constexpr int WP_OFF = 128;       // off-chain workgroups (one GRU row tile of each hidden half)
-constexpr unsigned long long WP_TIMEOUT_TICKS = 20000000ull;  // 0.2 s of the 100 MHz wall clock before a wait is declared lost
-// every 1024th poll of a spin: start the wall clock at the first check, raise the abort word once the wait is older than
-// WP_TIMEOUT_TICKS; true = the launch is aborting (this or another workgroup gave up), drain
-__device__ __forceinline__ bool wp_lost(const int tries, unsigned long long& t0, int* abort_word) {
-  const unsigned long long now = (unsigned long long)wall_clock64();
-  if (tries == 1023) t0 = now;
-  else if (now - t0 > WP_TIMEOUT_TICKS) atomicExch(abort_word, 1);
-  return __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-}
-
 // exchange area, in granules, per parity
 enum { WPX_X2 = 0, WPX_H2 = 8192, WPX_H1 = 16384, WPX_Y1 = 24576, WPX_Y2 = 32768, WPX_P1 = 40960, WPX_P2 = 65536,
        WPX_KEY = 90112, WPX_PER_PARITY = 91136 };
@@ -62,15 +53,6 @@ struct WpK {
   unsigned long long* trace;  // diagnostics (MBHIP_WP_TRACE): wall-clock marks of workgroups 0 and 32, steps 1000..1003
 };
 
-__device__ __forceinline__ void wp_put(unsigned long long* p, float v, unsigned tag) {
-  __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void wp_put_u(unsigned long long* p, unsigned v, unsigned tag) {
-  __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned long long wp_get(const unsigned long long* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 // spin until the NQ granules p[q * stride] all carry `tag`; false = aborted
 template <int NQ>
 __device__ __forceinline__ bool wp_wait(const unsigned long long* p, const size_t stride, const unsigned tag, unsigned (&out)[NQ], int* abort_word) {

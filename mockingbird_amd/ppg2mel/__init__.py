@@ -119,6 +119,9 @@ class Ppg2MelDecoder:
         ms, st = C.c_float(), C.c_int()
         if L.mb_ppg2mel_last_loop_ms(self._h, C.byref(ms), C.byref(st)) == 0:  # production-dims step only
             self.last_loop_ms, self.last_loop_steps = ms.value, st.value
+            nl = C.c_int()
+            if L.mb_ppg2mel_last_loop_launches(self._h, C.byref(nl)) == 0:
+                self.last_loop_launches = nl.value  # 1 = the resident loop (one utterance, csrc/ppg_resident.h)
         return mel[:, :s], align[:, :s], stop[:, :s]
 
     def inference(self, memory, stop_threshold=0.5, dropout=None, seed=None):

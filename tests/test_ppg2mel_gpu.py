@@ -62,6 +62,61 @@ def test_decode_matches_oracle_at_the_benchmarked_shape(cuda, lib):
         assert float((al - oal).abs().max()) <= ALIGN_TOL and float((stop - ostop).abs().max()) <= 1e-2
 
 
+@pytest.mark.parametrize("T,wseed,sb,mseed", [(30, 3, -2.0, 1), (26, 4, 0.0, 2), (200, 6, -8.0, 8), (301, 5, -1.0, 9)])
+def test_resident_loop_matches_oracle_and_the_chain(cuda, lib, monkeypatch, T, wseed, sb, mseed):
+    """ppg_resident.h: one utterance = ONE launch (217 resident workgroups, weights in LDS, granule hand-offs) against the
+    oracle with injected masks -- stop step included -- and against the 6-launch chain (other summation orders: tolerance).
+    T = 301: memory rows beyond the 256 the attention workgroup keeps in registers."""
+    from mockingbird_amd.ppg2mel import Ppg2MelDecoder
+    w = synth.ppg2mel_decoder_state(synth.PPG2MEL_HP, seed=wseed, stop_bias=sb)
+    dec = Ppg2MelDecoder(w, synth.PPG2MEL_HP)
+    mem = torch.from_numpy(synth.ppg2mel_memory(1, T, seed=mseed))
+    steps = min(T * 2, 64)
+    masks = synth.ppg2mel_dropout_masks(13, T * 2, 1)
+    with torch.no_grad():
+        omel, oal, ostop = op.inference_batched(w, dict(op.HP), mem, masks=op.MaskSource(list(masks)), max_steps=steps if T > 60 else None)
+    monkeypatch.setenv("MBHIP_PPG_RESIDENT", "1")
+    mel, al, stop = dec.decode(mem.cuda(), dropout=masks)
+    assert dec.last_loop_launches == 1
+    monkeypatch.setenv("MBHIP_PPG_RESIDENT", "0")
+    cmel, cal, cstop = dec.decode(mem.cuda(), dropout=masks)
+    assert dec.last_loop_launches >= 6 * cmel.shape[1]
+    if T <= 60:  # whole utterance: the same stop step on all three
+        assert al.shape == oal.shape == cal.shape, (al.shape, oal.shape, cal.shape)
+    n = oal.shape[1]
+    for got in ((mel, al, stop), (cmel, cal, cstop)):
+        gm, ga, gs = got[0].cpu().reshape(1, -1, 80)[:, :n * 2], got[1].cpu()[:, :n], got[2].cpu()[:, :n]
+        e = hiputil.relerr(gm, omel)
+        assert e["nan"] == 0 and e["max_abs"] <= MEL_TOL, e
+        assert float((ga - oal).abs().max()) <= ALIGN_TOL and float((gs - ostop).abs().max()) <= 1e-2
+    e = hiputil.relerr(mel, cmel)
+    assert mel.shape == cmel.shape and e["max_abs"] <= 2e-4, e
+    # device RNG: the same Philox draws as the chain (keep factors are exact, so only rounding separates the two)
+    monkeypatch.setenv("MBHIP_PPG_RESIDENT", "1")
+    a = dec.decode(mem.cuda(), seed=5, max_steps=steps)
+    a2 = dec.decode(mem.cuda(), seed=5, max_steps=steps)
+    monkeypatch.setenv("MBHIP_PPG_RESIDENT", "0")
+    b = dec.decode(mem.cuda(), seed=5, max_steps=steps)
+    assert torch.equal(a[0], a2[0]) and a[0].shape == b[0].shape
+    assert hiputil.relerr(a[0], b[0])["max_abs"] <= 2e-4
+
+
+def test_resident_loop_falls_back_to_the_chain(cuda, lib, monkeypatch):
+    """A resident launch that finds its abort word raised (a lost hand-off) drains; the chain redoes the utterance."""
+    from mockingbird_amd.ppg2mel import Ppg2MelDecoder
+    dec = Ppg2MelDecoder(synth.ppg2mel_decoder_state(synth.PPG2MEL_HP, seed=3, stop_bias=-2.0), synth.PPG2MEL_HP)
+    mem = torch.from_numpy(synth.ppg2mel_memory(1, 20, seed=2)).cuda()
+    masks = synth.ppg2mel_dropout_masks(4, 40, 1)
+    monkeypatch.setenv("MBHIP_PPG_RESIDENT", "0")
+    base = dec.decode(mem, dropout=masks)
+    monkeypatch.setenv("MBHIP_PPG_RESIDENT", "1")
+    monkeypatch.setenv("MBHIP_PR_TEST_ABORT", "1")
+    alt = dec.decode(mem, dropout=masks)
+    assert dec.last_loop_launches > 1
+    for x, y in zip(base, alt):
+        assert x.shape == y.shape and torch.equal(x, y)
+
+
 def test_reference_surface_and_golden(cuda, lib):
     """inference / inference_batched return what the reference returns (shapes, per-item truncation,
     concatenation) -- checked against the golden outputs of the reference module itself.  The golden was
