@@ -815,19 +815,37 @@ def main():
                 steps_p = pm.shape[1]
                 lm = getattr(pdec, "last_loop_ms", None)  # HIP events around the loop (mb_ppg2mel_last_loop_ms)
                 entry[f"batch{pb}"] = {"ms": tp * 1e3, "steps": int(steps_p), "us_per_step": (lm * 1e3 if lm else tp * 1e6) / steps_p,
-                                       "wall_us_per_step": tp * 1e6 / steps_p, "mel_frames_per_s": pb * steps_p * 2 / tp}
+                                       "wall_us_per_step": tp * 1e6 / steps_p, "mel_frames_per_s": pb * steps_p * 2 / tp,
+                                       "loop_launches": getattr(pdec, "last_loop_launches", None)}
+                if pb == 1 and getattr(pdec, "last_loop_launches", 0) == 1:  # A/B partner of the resident loop: the 6-launch chain
+                    os.environ["MBHIP_PPG_RESIDENT"] = "0"
+                    try:
+                        pdec.decode(pmem, seed=1)
+                        cm, _, _ = pdec.decode(pmem, seed=4)  # the seed of the last timed resident pass
+                        torch.cuda.synchronize()
+                        entry["batch1"]["chain_reference"] = {"us_per_step": pdec.last_loop_ms * 1e3 / cm.shape[1], "loop_launches": pdec.last_loop_launches,
+                                                              "loop": "6-launch step (ppg_fast.h), hipGraph replays, same utterance",
+                                                              "mel_max_abs_diff_vs_resident": float((cm - pm).abs().max())}
+                    finally:
+                        os.environ.pop("MBHIP_PPG_RESIDENT", None)
             # 19.1 MB of fp32 weights are touched once per step (attention LSTM 7.3 MB, decoder LSTM 10.5 MB, rest 1.3 MB)
             wbytes = 4.0 * (256 * 80 + 128 * 256 + 2048 * (384 + 512) + 256 * 512 + 15 * 256 + 2048 * (768 + 512) + 161 * 768)
             entry["workload"] = ("ppg2mel Decoder.inference loop (prenet, attention LSTMCell, MoL attention, decoder LSTMCell, "
                                  "projection + stop), T_enc = 200, 400 steps forced, fp32, on-device dropout RNG")
-            entry["roofline"] = {"bound": "hbm", "kernel": "decoder step (ppg_fast.h: 6 launches per step, hipGraph replays), weights streamed once per step",
+            resident_p = entry["batch1"].get("loop_launches") == 1
+            entry["roofline"] = {"bound": "hbm", "kernel": ("mb::ppg_resident_kernel (ppg_resident.h): the whole loop of the utterance as ONE resident launch -- 217 "
+                                                            "role-specialised workgroups, weights in LDS, 5 granule hand-offs per step; algorithmic bytes as if the "
+                                                            "weights were streamed once per step (the kernel reads them once per utterance)") if resident_p else
+                                 "decoder step (ppg_fast.h: 6 launches per step, hipGraph replays), weights streamed once per step",
                                  "achieved": wbytes / (entry["batch1"]["us_per_step"] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": wbytes / (entry["batch1"]["us_per_step"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                  "traffic": None, "algorithmic_bytes_per_step": wbytes}
             try:  # HBM bytes of one step (all six launches) from the committed PMC passes (tools/pmc_r03_ppg.sh)
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_ppg2mel.json")))
-                entry["roofline"]["traffic"] = pm["step_hbm_bytes_per_launch"]
+                entry["roofline"]["traffic_chain_step"] = pm["step_hbm_bytes_per_launch"]  # measured on the 6-launch chain
                 entry["roofline"]["traffic_source"] = "profiles/r03_pmc_ppg2mel.json: " + pm.get("source", "")[:200]
+                if not resident_p:
+                    entry["roofline"]["traffic"] = pm["step_hbm_bytes_per_launch"]
             except Exception:
                 pass
             result["ppg2mel"] = entry

@@ -638,6 +638,7 @@ extern "C" int mb_ppg2mel_decode(const mb_ppg2mel* p, const float* d_memory, int
       k.memory = d_memory; k.mel_out = d_mel; k.align_out = d_align; k.stop_out = d_stop; k.drop_mask = d_dropout;
       k.ex = L.px; k.abort_word = abort_word; k.flags = L.flags; k.seed = seed;
       k.T = T; k.M = M; k.RM = RM; k.S = max_steps; k.min_steps = min_steps; k.thr = stop_threshold; k.eps = 1e-5f;
+      k.variant = getenv("MBHIP_PR_VARIANT") ? atoi(getenv("MBHIP_PR_VARIANT")) : 0;
       k.trace = rtrace ? reinterpret_cast<unsigned long long*>(abort_word) + 32 : nullptr;
       MB_HIP(hipEventRecord(pm->ev_t0, ls));
       hipLaunchKernelGGL(ppg_resident_kernel, dim3(PR_WGS), dim3(512), PR_LDS_BYTES, ls, k);
@@ -649,7 +650,7 @@ extern "C" int mb_ppg2mel_decode(const mb_ppg2mel* p, const float* d_memory, int
       MB_HIP(hipEventSynchronize(pm->ev_res));
       if (*pm->h_abort != 1) {
         if (rtrace) {
-          unsigned long long marks[5 * 4 * 16];
+          unsigned long long marks[1000];
           MB_HIP(hipMemcpy(marks, k.trace, sizeof(marks), hipMemcpyDeviceToHost));
           if (FILE* f = fopen(rtrace, "wb")) { fwrite(marks, sizeof(marks), 1, f); fclose(f); }
         }

@@ -59,6 +59,7 @@ struct PrK {
   unsigned long long seed;
   int T, M, RM, S, min_steps;
   float thr, eps;
+  int variant;                                     // A/B switches (MBHIP_PR_VARIANT): 1 = DEC polls the context as a whole vector, 2 = ATT polls p0 as a whole vector
   unsigned long long* trace;                       // diagnostics (MBHIP_PR_TRACE): wall-clock marks, steps 100..103
 };
 
@@ -245,7 +246,8 @@ __global__ __launch_bounds__(512) void ppg_resident_kernel(PrK a) {
       if (s > 0) {  // p0(0) = 0: the go frame through a bias-free prenet
         PR_MARK(0, 0);
         // (watched granule: row 0 of the next prenet input, one of those a stopping OUT workgroup holds back)
-        if (!pr_fetch<1>(EX(PRX_P0, tag), 256, tag, xa, a.abort_word, s_flag, false, 0, PR_MK(0, 6))) return;
+        if (a.variant & 2) { if (!pr_poll<4>(EX(PRX_P0, tag), tag, xa, a.abort_word, s_flag, false, PR_MK(0, 6))) return; }
+        else if (!pr_fetch<1>(EX(PRX_P0, tag), 256, tag, xa, a.abort_word, s_flag, false, 0, PR_MK(0, 6))) return;
         PR_MARK(0, 1);
         const float4* x4 = reinterpret_cast<const float4*>(xa) + q1;
         float4 xv[16];
@@ -268,8 +270,14 @@ __global__ __launch_bounds__(512) void ppg_resident_kernel(PrK a) {
       const float gg = pr_tanh(pr_lane(v, 32) + bq.z), go = pr_sigmoid(pr_lane(v, 48) + bq.w);
       cst = gf * cst + gi * gg;
       const float h = go * pr_tanh(cst);
-      if (lane == 0) wp_put(EX(PRX_AH, tag) + u, h, tag);
+      // one store instruction per workgroup (8 granules = 64 contiguous bytes): granules stored one by one from eight waves
+      // reached the consumers ~1 us later (8-byte pieces of a 32-byte ECC word are merged one after the other at the memory side);
+      // padding every workgroup's granules to a whole 128-byte line on top of this measured no faster (8.81 vs 8.74 us per step)
+      if (lane == 0) s_pre[wave] = h;
+      __syncthreads();
+      if (tid < 8) wp_put(EX(PRX_AH, tag) + g * 8 + tid, s_pre[tid], tag);
       PR_MARK(0, 3);
+      if (a.trace && tid == 0 && s == 101) a.trace[512 + g] = (unsigned long long)wall_clock64();  // every workgroup's publish time
       if (s + 1 == S) break;
       // in the shadow of the rest of the step: the parts of the next step's gates that do not need its prenet output.
       // Nothing polls att_h here (Q0 and DEC are waiting for it on the chain): the context arrives two hand-offs later,
@@ -312,7 +320,8 @@ __global__ __launch_bounds__(512) void ppg_resident_kernel(PrK a) {
       if (half == 0) acc = pr_dot<8>(Wx, 256, reinterpret_cast<const float4*>(xa) + sl, 0.f);
       else if (s > 0) s_pre[tl] = pr_dot<8>(Wh, 256, reinterpret_cast<const float4*>(xc) + sl, 0.f);
       PR_MARK(1, 2);
-      if (!pr_fetch<1>(EX(PRX_CTX, tag), 256, tag, xb, a.abort_word, s_flag, false, -1, PR_MK(1, 6))) return;
+      if (a.variant & 1) { if (!pr_poll<4>(EX(PRX_CTX, tag), tag, xb, a.abort_word, s_flag, false, PR_MK(1, 6))) return; }
+      else if (!pr_fetch<1>(EX(PRX_CTX, tag), 256, tag, xb, a.abort_word, s_flag, false, -1, PR_MK(1, 6))) return;
       PR_MARK(1, 3);
       if (half == 0) {
         acc = pr_dot<4>(Wx + 8 * 256, 256, reinterpret_cast<const float4*>(xb) + sl, acc);
@@ -321,9 +330,12 @@ __global__ __launch_bounds__(512) void ppg_resident_kernel(PrK a) {
         const float gg = pr_tanh(pr_lane(v, 32) + bq.z), go = pr_sigmoid(pr_lane(v, 48) + bq.w);
         cst = gf * cst + gi * gg;
         const float h = go * pr_tanh(cst);
-        if (lane == 0) wp_put(EX(PRX_DH, tag) + u, h, tag);
+        if (lane == 0) s_p1[wave] = h;
       }
+      __syncthreads();
+      if (tid < 4) wp_put(EX(PRX_DH, tag) + d * 4 + tid, s_p1[tid], tag);  // one 32-byte store per workgroup
       PR_MARK(1, 4);
+      if (a.trace && tid == 0 && s == 101) a.trace[512 + g] = (unsigned long long)wall_clock64();
     }
     return;
   }
@@ -342,8 +354,11 @@ __global__ __launch_bounds__(512) void ppg_resident_kernel(PrK a) {
       if (!pr_poll<8>(EX(PRX_AH, tag), tag, xa, a.abort_word, s_flag, false, PR_MK(2, 3))) return;
       PR_MARK(2, 1);
       const float v = pr_sum16(pr_dot<8>(W4, 512, reinterpret_cast<const float4*>(xa) + sl, 0.f));
-      if (sl == 0) wp_put(EX(PRX_Q, tag) + row, fmaxf(v + b, 0.f), tag);
+      if (sl == 0) xb[tid >> 4] = fmaxf(v + b, 0.f);
+      __syncthreads();
+      if (tid < 32) wp_put(EX(PRX_Q, tag) + j * 32 + tid, xb[tid], tag);  // one 256-byte store per workgroup
       PR_MARK(2, 2);
+      if (a.trace && tid == 0 && s == 101) a.trace[512 + g] = (unsigned long long)wall_clock64();
     }
     return;
   }
@@ -385,12 +400,15 @@ __global__ __launch_bounds__(512) void ppg_resident_kernel(PrK a) {
       }
       if (sl == 0) {
         if (kind == 1) {  // next step's prenet.0 through the projection's last frame (ppg_fast.h launch 6), relu, dropout
-          if (!(wave == 0 && stopped)) wp_put(EX(PRX_P0, tag + 1) + f, fmaxf(v, 0.f) * dropf, tag + 1);
+          s_p1[lr - 1] = fmaxf(v, 0.f) * dropf;
         } else if (kind == 2) {
           a.mel_out[(size_t)s * a.RM + m] = v;  // mel_output = linear_projection([h, context])   :281-287
         }
       }
+      __syncthreads();
+      if (tid < 16 && !stopped) wp_put(EX(PRX_P0, tag + 1) + j * 16 + tid, s_p1[tid], tag + 1);  // one 128-byte store per workgroup
       PR_MARK(3, 3);
+      if (a.trace && tid == 0 && s == 101) a.trace[512 + g] = (unsigned long long)wall_clock64();
       if (kind == 1) dropf = pr_drop(a, 0, s + 2, f);
     }
     return;
@@ -469,7 +487,7 @@ __global__ __launch_bounds__(512) void ppg_resident_kernel(PrK a) {
         const float ew = (live && r3 == 0) ? e : 0.f;
         float se = 0.f;
 #pragma unroll
-        for (int mm = 0; mm < 5; ++mm) if (mm < M) se += pr_lane(ew, mm);  // ascending m, as the sequential sum
+        for (int mm = 0; mm < 5; ++mm) se += pr_lane(ew, mm);  // ascending m, as the sequential sum (lanes >= M hold 0)
         const float sp = pr_softplus(x, e);
         float val = ew * __builtin_amdgcn_rcpf(se) + a.eps;          // row 0: w
         if (r3 == 1) val = __builtin_amdgcn_rcpf(sp + a.eps);        // row 1: 1 / sigma
@@ -481,7 +499,8 @@ __global__ __launch_bounds__(512) void ppg_resident_kernel(PrK a) {
 #pragma unroll
       for (int mm = 0; mm < 5; ++mm) { wm[mm] = s_mix[mm]; isg[mm] = s_mix[16 + mm]; mum[mm] = s_mix[32 + mm]; }
       PR_MARK(4, 2);
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);  // this wave's share of context = alpha . memory   :115
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      f32x2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};  // this wave's share of context = alpha . memory   :115 (v_pk_fma_f32)
       float* al = a.align_out + (size_t)s * T;
       for (int t0 = wave * NR; t0 < T; t0 += 8 * NR) {  // (one pass up to T_enc = 256)
         // alpha_full[j] = sum_m w_m / (1 + sigmoid((mu_m - (j + 0.5)) / sigma_m))   :101-107, at j = t0 + lane (33 of them matter).
@@ -503,7 +522,8 @@ __global__ __launch_bounds__(512) void ppg_resident_kernel(PrK a) {
 #pragma unroll
           for (int jj = 0; jj < NR; ++jj) {
             const float sc = pr_lane(v, jj);
-            acc.x += sc * mv[jj].x; acc.y += sc * mv[jj].y; acc.z += sc * mv[jj].z; acc.w += sc * mv[jj].w;
+            const f32x2 sc2 = {sc, sc}, m01 = {mv[jj].x, mv[jj].y}, m23 = {mv[jj].z, mv[jj].w};
+            acc01 = __builtin_elementwise_fma(sc2, m01, acc01); acc23 = __builtin_elementwise_fma(sc2, m23, acc23);
           }
         } else {  // T_enc > 256: these rows come from L2, 4 in flight
 #pragma unroll 1
@@ -517,13 +537,14 @@ __global__ __launch_bounds__(512) void ppg_resident_kernel(PrK a) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
               const float sc = __shfl(v, j8 + jj, 64);
-              acc.x += sc * vv[jj].x; acc.y += sc * vv[jj].y; acc.z += sc * vv[jj].z; acc.w += sc * vv[jj].w;
+              const f32x2 sc2 = {sc, sc}, m01 = {vv[jj].x, vv[jj].y}, m23 = {vv[jj].z, vv[jj].w};
+              acc01 = __builtin_elementwise_fma(sc2, m01, acc01); acc23 = __builtin_elementwise_fma(sc2, m23, acc23);
             }
           }
         }
       }
       PR_MARK(4, 3);
-      *reinterpret_cast<float4*>(s_part + wave * 256 + lane * 4) = acc;
+      *reinterpret_cast<float4*>(s_part + wave * 256 + lane * 4) = make_float4(acc01.x, acc01.y, acc23.x, acc23.y);
       __syncthreads();
       if (tid < 256) {
         float r = s_part[tid];

@@ -538,10 +538,10 @@ __global__ __launch_bounds__(512) void wf_persist1_kernel(WpK a) {
 
   if (g >= WP_ON) {
     // ------------------------------------------------------------------ off-chain: hidden halves of the next step
-    const int mt = g - WP_ON, du = tid & 3;
+    const int mt = g - WP_ON;
     wp_copy_tile_chain<3>(lw, a.w_hh1 + (size_t)mt * 6144);
     wp_copy_tile_chain<3>(lw + 8192, a.w_hh2 + (size_t)mt * 6144);
-    const float4 bq1 = a.bhh1q[mt * 4 + du], bq2 = a.bhh2q[mt * 4 + du];
+    const float4 bq1q = a.bhh1q[mt * 4 + ((tid >> 2) & 3)], bq2q = a.bhh2q[mt * 4 + ((tid >> 2) & 3)];  // thread t < 16: unit t >> 2, gate t & 3
     xg[tid] = 0.f;
     __syncthreads();
     for (int s = 0; s < S; ++s) {
@@ -552,12 +552,12 @@ __global__ __launch_bounds__(512) void wf_persist1_kernel(WpK a) {
           __syncthreads();
         }
         wp_dot<1>(lw + which * 8192, xg, red);
-        if (tid < 4) {
-          const float4 bq = which ? bq2 : bq1;
-          unsigned long long* P = EX(which ? WPX_P2 : WPX_P1, (unsigned)s + 1) + (size_t)(mt * 4 + du) * 4;  // dense: [unit][r, z, n, -]
-          wp_put(P, wp_rowsum(red, du * 4) + bq.x, (unsigned)s + 1);
-          wp_put(P + 1, wp_rowsum(red, du * 4 + 1) + bq.y, (unsigned)s + 1);
-          wp_put(P + 2, wp_rowsum(red, du * 4 + 2) + bq.z, (unsigned)s + 1);
+        if (tid < 16) {  // dense [unit][r, z, n, -]: the tile's 16 granules as ONE 128-byte store (8-byte pieces of a line, stored
+                         // one by one, are merged one after the other at the memory side and reach the readers ~1 us later)
+          const float4 bq = which ? bq2q : bq1q;
+          const int comp = tid & 3;
+          const float bv = comp == 0 ? bq.x : comp == 1 ? bq.y : bq.z;
+          wp_put(EX(which ? WPX_P2 : WPX_P1, (unsigned)s + 1) + (size_t)mt * 16 + tid, comp < 3 ? wp_rowsum(red, tid) + bv : 0.f, (unsigned)s + 1);
         }
         // (red / xg are rewritten only behind the next fetch's barrier, which threads 0..3 reach after these reads)
         if (s == 0) __syncthreads();
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(512) void wf_persist1_kernel(WpK a) {
     tq[0] = t4.x; tq[1] = t4.y; tq[2] = t4.z; tq[3] = t4.w;
   }
   float g2r = 0.f, g2z = 0.f, g2n = 0.f; int g2_row = -1;
-  float4 fpre = make_float4(0.f, 0.f, 0.f, 0.f); int f_row = -1;
+  float fpre1 = 0.f; int f_row = -1;
   const float4 b3q = (!lo && ft < n_t3 && tid < 4) ? *reinterpret_cast<const float4*>(a.b_fc3 + ft * 16 + du * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
   float x = 0.f;
   __syncthreads();
@@ -597,10 +597,10 @@ __global__ __launch_bounds__(512) void wf_persist1_kernel(WpK a) {
     // ---- A: keys of step s-1 -> sample x ----
     if (s > 0) {
       // (the 32 key lanes polling directly, without the watching lane: 11.0 vs 10.3 us per step)
-      wp_watch<1>(EX(WPX_KEY, tag_prev) + (size_t)(n_t3 - 1) * 2 + 1, tag_prev, a.abort_word);
+      wp_watch<1>(EX(WPX_KEY, tag_prev) + (size_t)(n_t3 - 1) * 4 + 1, tag_prev, a.abort_word);
       if (tid < n_t3) {
         unsigned kv[2];
-        if (!wp_wait<2>(EX(WPX_KEY, tag_prev) + (size_t)tid * 2, 1, tag_prev, kv, a.abort_word)) return;
+        if (!wp_wait<2>(EX(WPX_KEY, tag_prev) + (size_t)tid * 4, 1, tag_prev, kv, a.abort_word)) return;
         atomicMax(&s_key[0], ((unsigned long long)kv[0] << 32) | (unsigned long long)kv[1]);
       }
       __syncthreads();
@@ -666,16 +666,12 @@ __global__ __launch_bounds__(512) void wf_persist1_kernel(WpK a) {
     WP_MARK(7);
     wp_dot<1>(lw + 16384, xg, red);
     WP_MARK(8);
-    if (tid < 4) {
+    if (tid < 16) {  // the tile's 16 outputs as ONE 128-byte store
       if (frow != f_row) {
-        fpre = *reinterpret_cast<const float4*>((lo ? a.F1 : a.F2) + (size_t)frow * a.FC + ft * 16 + du * 4);
+        fpre1 = (lo ? a.F1 : a.F2)[(size_t)frow * a.FC + ft * 16 + tid];
         f_row = frow;
       }
-      unsigned long long* Y = EX(lo ? WPX_Y1 : WPX_Y2, tag) + (ft * 16 + du * 4);
-      wp_put(Y, fmaxf(wp_rowsum(red, du * 4) + fpre.x, 0.f), tag);
-      wp_put(Y + 1, fmaxf(wp_rowsum(red, du * 4 + 1) + fpre.y, 0.f), tag);
-      wp_put(Y + 2, fmaxf(wp_rowsum(red, du * 4 + 2) + fpre.z, 0.f), tag);
-      wp_put(Y + 3, fmaxf(wp_rowsum(red, du * 4 + 3) + fpre.w, 0.f), tag);
+      wp_put(EX(lo ? WPX_Y1 : WPX_Y2, tag) + (ft * 16 + tid), fmaxf(wp_rowsum(red, tid) + fpre1, 0.f), tag);
     }
     if (!lo && ft < n_t3) {
       // the Gumbel noise of this step does not depend on the data: drawn before the wait for y2, off the key edge
@@ -707,11 +703,8 @@ __global__ __launch_bounds__(512) void wf_persist1_kernel(WpK a) {
         pk = o1 > pk ? o1 : pk;
         const unsigned long long o2 = __shfl_xor(pk, 2, 64);
         pk = o2 > pk ? o2 : pk;
-        if (tid == 0) {
-          unsigned long long* K = EX(WPX_KEY, tag) + (size_t)ft * 2;
-          wp_put_u(K, (unsigned)(pk >> 32), tag);
-          wp_put_u(K + 1, (unsigned)pk, tag);
-        }
+        // both halves in one 16-byte store, every tile in its own 32-byte word (all four lanes hold the maximum)
+        if (tid < 2) wp_put_u(EX(WPX_KEY, tag) + (size_t)ft * 4 + tid, tid == 0 ? (unsigned)(pk >> 32) : (unsigned)pk, tag);
       }
     }
   }

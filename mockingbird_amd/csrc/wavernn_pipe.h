@@ -139,12 +139,12 @@ __global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
         WQ_MARK(0, 0);
         // ---- keys of step s-1 -> sample x of every column of the group ----
         if (s > 0) {
-          const unsigned long long* K = EX(WQX_KEY, g, tag_prev);
-          wp_watch<1>(K + (size_t)((n_t3 - 1) * 2 + 1) * Ng + (Ng - 1), tag_prev, a.abort_word);
+          const unsigned long long* K = EX(WQX_KEY, g, tag_prev);  // key halves of a tile: rows of LD granules (whole lines per store)
+          wp_watch<1>(K + (size_t)((n_t3 - 1) * 2 + 1) * LD + (Ng - 1), tag_prev, a.abort_word);
           if (tid < 32 * Ng && (tid & 31) < n_t3) {
             const int tile = tid & 31, n = tid >> 5;
             unsigned kv[2];
-            if (!wp_wait<2>(K + (size_t)tile * 2 * Ng + n, Ng, tag_prev, kv, a.abort_word)) return;
+            if (!wp_wait<2>(K + (size_t)tile * 2 * LD + n, LD, tag_prev, kv, a.abort_word)) return;
             atomicMax(&s_key[n], ((unsigned long long)kv[0] << 32) | (unsigned long long)kv[1]);
           }
           __syncthreads();
@@ -236,6 +236,7 @@ __global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
         float sx[4];
         const bool epi = wp_gemm2<3>(lw, 6144, b, red + rb * 4096, sx);
         rb ^= 1;
+        WQ_MARK(1, 5);
         if (epi && i < Ng) {
           float xr = s_xr[((wave & 1) * 4 + du) * 16 + i];
           if (a.flags & 2) {
@@ -303,6 +304,7 @@ __global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
       float sx[4];
       const bool epi = wp_gemm<4>(lw, b, red + rb * 4096, sx);
       rb ^= 1;
+      WQ_MARK(2 + fr, 3);
       if (!epi) continue;
       if (fr < 2) {
         if (i < Ng) {
@@ -329,9 +331,9 @@ __global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
         const unsigned long long o2 = __shfl_xor(pk, 32, 64);
         pk = o2 > pk ? o2 : pk;
         if (du == 0 && i < Ng) {
-          unsigned long long* K = EX(WQX_KEY, g, tag) + (size_t)ft * 2 * Ng + i;
+          unsigned long long* K = EX(WQX_KEY, g, tag) + (size_t)ft * 2 * LD + i;
           wp_put_u(K, (unsigned)(pk >> 32), tag);
-          wp_put_u(K + Ng, (unsigned)pk, tag);
+          wp_put_u(K + LD, (unsigned)pk, tag);
         }
       }
       WQ_MARK(2 + fr, 2);

@@ -7,3 +7,4 @@ timeout 600 python -m pytest tests/test_ppg2mel_gpu.py tests/test_env_switches_g
 tail -25 gpurun_out/pytest_ppg.log
 MBHIP_PR_TRACE=/tmp/pr_trace.bin timeout 300 python tools/ppg_resident_ab.py > gpurun_out/ppg_resident_ab.log 2>&1; echo "ab rc=$?"
 tail -c 4000 gpurun_out/ppg_resident_ab.log
+for v in 1 2 3; do echo "variant $v"; MBHIP_PR_VARIANT=$v timeout 300 python tools/ppg_resident_ab.py 2>&1 | grep T_enc; done

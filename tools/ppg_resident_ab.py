@@ -46,4 +46,10 @@ if tr and os.path.exists(tr):
     for r in range(5):
         for st in range(4):
             row = marks[(r * 4 + st) * 16:(r * 4 + st) * 16 + 16]
-            print(names[r], 100 + st, " ".join("%7.2f" % ((x - base) / 100.0) if x else "      -" for x in row[:7]))
+            print(names[r], 100 + st, " ".join("%7.2f" % ((x - base) / 100.0) if x else "      -" for x in row[:8]))
+    if len(marks) >= 1000:
+        for name, lo, hi in (("ATT publish", 512, 576), ("DEC publish", 576, 704), ("Q0 publish", 704, 712), ("OUT publish", 712, 728), ("ATT p0 fetched", 768, 832)):
+            v = [(x - base) / 100.0 for x in marks[lo:hi] if x]
+            if v:
+                srt = sorted(range(len(v)), key=lambda i: v[i])
+                print(name, "min %.2f max %.2f" % (min(v), max(v)), "latest:", [(i, round(v[i], 2)) for i in srt[-4:]], "earliest:", [(i, round(v[i], 2)) for i in srt[:2]])

@@ -39,7 +39,7 @@ for name, F, target, overlap, modes in CASES:
             if os.path.exists(tf):
                 m = struct.unpack("<320Q", open(tf, "rb").read())
                 t0 = m[0]  # R1, step 1000, mark 0
-                res["pipe_marks_us"] = {role: [[(m[(r * 4 + st) * 16 + k] - t0) / 100.0 if m[(r * 4 + st) * 16 + k] else None for k in range(5)]
+                res["pipe_marks_us"] = {role: [[(m[(r * 4 + st) * 16 + k] - t0) / 100.0 if m[(r * 4 + st) * 16 + k] else None for k in range(6)]
                                                for st in range(4)] for r, role in enumerate(("R1", "R2", "F1", "F2", "F3"))}
     ref = res.pop("chain_samples")
     res["sample_streams_identical"] = {m: bool(torch.equal(ref, res.pop(m + "_samples"))) for m in modes[1:]}
