@@ -166,6 +166,35 @@ typedef struct mb_resblock_pair_f16_args {
 } mb_resblock_pair_f16_args;
 int mb_resblock_pair_f16(const mb_resblock_pair_f16_args* a, mb_stream_t stream);
 
+/* One upsampling stage's whole ResBlock group (fp16 path) in ONE launch:
+ *   y = out_scale * sum_j ResBlock_j(x),  ResBlock_j = num_dilations units x <- x + conv2(lrelu(conv1_d(lrelu(x)) + b1)) + b2
+ * i.e. the loop over self.resblocks of Generator.forward
+ *   models/vocoder/hifigan/models.py:139-145, models/vocoder/fregan/generator.py:150-157
+ * with ResBlock1.forward (hifigan/models.py:39-46, fregan/generator.py:43-50), the activations of a tile LDS-resident across
+ * all units of all chains (resblock_stage_f16.hip): x is read once and y written once per stage.
+ * Supported: channels in {16, 32}, 1..4 kernels (k odd >= 3), 1..4 dilations, the tile must fit LDS
+ * (mb_resblock_stage_f16_supported); wider stages run mb_resblock_pair_f16 per unit. */
+int mb_resblock_stage_f16_supported(int channels, int num_kernels, const int* ksizes, int num_dilations,
+                                    const int* dilations /* [num_kernels][num_dilations] */);
+size_t mb_resblock_stage_f16_packed_halves(int channels, int num_kernels, const int* ksizes, int num_dilations);
+/* h_w1[j * num_dilations + u], h_w2[...]: fp32 torch Conv1d weights [C][C][k_j] of convs1[u] / convs2[u] of ResBlock j */
+int mb_resblock_stage_f16_pack(const float* const* h_w1, const float* const* h_w2, int channels, int num_kernels,
+                               const int* ksizes, int num_dilations, uint16_t* h_packed);
+typedef struct mb_resblock_stage_f16_args {
+  const void* d_x;        /* fp16 [B][t][channels]                                          */
+  void* d_y;              /* fp16 [B][t][channels], must not alias d_x                      */
+  const void* d_wpacked;  /* image from mb_resblock_stage_f16_pack                          */
+  const float* d_bias;    /* fp32 [num_kernels][num_dilations][2][channels]: b1, b2 per unit */
+  int batch, channels, t;
+  int num_kernels, num_dilations;
+  int ksize[4];
+  int dilation[4][4];     /* [kernel][unit]: dilation of convs1[unit]; convs2 have dilation 1 */
+  float slope;            /* leaky_relu slope in (0,1)                                      */
+  float out_scale;        /* 0 = 1 / num_kernels                                            */
+  const int* d_valid; int valid_mul;  /* ragged batches, as mb_resblock_pair_f16_args */
+} mb_resblock_stage_f16_args;
+int mb_resblock_stage_f16(const mb_resblock_stage_f16_args* a, mb_stream_t stream);
+
 /* Layout/precision converters between the reference's [B][C][T] fp32 tensors and the
  * time-major fp16 activations above (mel upload; tests). */
 int mb_f32_to_f16_tm(const float* d_x, void* d_y, int batch, int channels, int t, mb_stream_t stream);

@@ -60,6 +60,16 @@ class ResPairF16Args(C.Structure):
     ]
 
 
+class ResStageF16Args(C.Structure):
+    _fields_ = [
+        ("d_x", C.c_void_p), ("d_y", C.c_void_p), ("d_wpacked", C.c_void_p), ("d_bias", C.c_void_p),
+        ("batch", C.c_int), ("channels", C.c_int), ("t", C.c_int), ("num_kernels", C.c_int), ("num_dilations", C.c_int),
+        ("ksize", C.c_int * 4), ("dilation", (C.c_int * 4) * 4),
+        ("slope", C.c_float), ("out_scale", C.c_float),
+        ("d_valid", C.c_void_p), ("valid_mul", C.c_int),
+    ]
+
+
 class Ppg2MelNetConfig(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("bnf_dim", "spk_dim", "enc_dim", "down0", "down1", "num_mels", "postnet_layers",
                                        "postnet_dim", "postnet_ksize")]
@@ -145,6 +155,10 @@ SIGNATURES = {
     "mb_resblock_pair_f16_packed_halves": (C.c_size_t, [C.c_int] * 2),
     "mb_resblock_pair_f16_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "mb_resblock_pair_f16": (C.c_int, [C.POINTER(ResPairF16Args), C.c_void_p]),
+    "mb_resblock_stage_f16_supported": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "mb_resblock_stage_f16_packed_halves": (C.c_size_t, [C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "mb_resblock_stage_f16_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "mb_resblock_stage_f16": (C.c_int, [C.POINTER(ResStageF16Args), C.c_void_p]),
     "mb_f32_to_f16_tm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mb_f16_tm_to_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mb_gan_num_weights": (C.c_int, [C.POINTER(GanConfig)]),

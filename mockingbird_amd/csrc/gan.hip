@@ -140,6 +140,9 @@ struct mb_gan {
   // fp16 path: fused (convs1[d], convs2[d]) weight streams of the ResBlocks (resblock_f16.hip), indexed
   // ((stage * num_kernels + kernel) * num_dilations + d); empty buffer = pair not fusable -> two launches
   std::vector<DevBuf> pairs;
+  // fp16 path, narrow stages (C <= 32): the whole ResBlock group of a stage as ONE launch (resblock_stage_f16.hip); per stage the
+  // weight stream and the [kernel][unit][2][C] bias block; empty = the stage runs its units one by one
+  std::vector<DevBuf> stage_w, stage_b;
   int hop;
   // indices into convs
   int i_pre, i_ups, i_cond, i_resout, i_rb, i_post;
@@ -235,6 +238,41 @@ extern "C" int mb_gan_create_ex(const mb_gan_config* cfg, const float* const* h_
           if (rc) { mb_gan_destroy(g); return rc; }
         }
   }
+  if (dtype == MB_F16 && !getenv("MBHIP_GAN_NOFUSE") && !getenv("MBHIP_GAN_NOSTAGE") && cfg->num_kernels <= 4 &&
+      cfg->num_dilations <= 4) {
+    const int nd = cfg->num_dilations, nk = cfg->num_kernels;
+    g->stage_w.resize(cfg->num_upsamples);
+    g->stage_b.resize(cfg->num_upsamples);
+    std::vector<float> img, bias;
+    for (int i = 0; i < cfg->num_upsamples; ++i) {
+      const int ch = cfg->upsample_initial_channel >> (i + 1);
+      int ks[4], dil[16];
+      std::vector<const float*> w1((size_t)nk * nd), w2((size_t)nk * nd);
+      bool ok = ch == 16 || ch == 32;
+      bias.assign((size_t)nk * nd * 2 * ch, 0.f);
+      for (int j = 0; j < nk && ok; ++j)
+        for (int d = 0; d < nd && ok; ++d) {
+          const int base = g->i_rb + ((i * nk + j) * nd) * 2;
+          const ConvSpec& s1 = v[base + d];
+          const ConvSpec& s2 = v[base + nd + d];
+          ok = s1.c_in == ch && s1.c_out == ch && s2.c_in == ch && s2.c_out == ch && s1.k == s2.k && s2.dil == 1 && !s1.transposed &&
+               !s2.transposed && s1.pad == s1.dil * (s1.k - 1) / 2 && s2.pad == (s2.k - 1) / 2 && (d == 0 || s1.k == ks[j]);
+          ks[j] = s1.k; dil[j * nd + d] = s1.dil;
+          w1[(size_t)j * nd + d] = h_weights[2 * (base + d)];
+          w2[(size_t)j * nd + d] = h_weights[2 * (base + nd + d)];
+          if (ok) {
+            memcpy(&bias[(((size_t)j * nd + d) * 2) * ch], h_weights[2 * (base + d) + 1], ch * sizeof(float));
+            memcpy(&bias[(((size_t)j * nd + d) * 2 + 1) * ch], h_weights[2 * (base + nd + d) + 1], ch * sizeof(float));
+          }
+        }
+      if (!ok || !mb_resblock_stage_f16_supported(ch, nk, ks, nd, dil)) continue;
+      img.assign(mb_resblock_stage_f16_packed_halves(ch, nk, ks, nd) / 2, 0.f);
+      rc = mb_resblock_stage_f16_pack(w1.data(), w2.data(), ch, nk, ks, nd, reinterpret_cast<uint16_t*>(img.data()));
+      if (!rc) rc = g->stage_w[i].upload(img.data(), img.size());
+      if (!rc) rc = g->stage_b[i].upload(bias.data(), bias.size());
+      if (rc) { mb_gan_destroy(g); return rc; }
+    }
+  }
   *out = g;
   return MB_OK;
 }
@@ -243,6 +281,8 @@ extern "C" void mb_gan_destroy(mb_gan* g) {
   if (!g) return;
   for (auto& c : g->convs) { c.w.release(); c.b.release(); }
   for (auto& p : g->pairs) p.release();
+  for (auto& p : g->stage_w) p.release();
+  for (auto& p : g->stage_b) p.release();
   delete g;
 }
 
@@ -456,6 +496,20 @@ static int gan_forward_impl(const mb_gan* g, const float* d_mel, int batch, int 
     t = (int)gan_up_len(c, i, t);
     MB_REQUIRE(t > 0, "gan_forward: %d frames vanish in upsample stage %d", frames, i);
     // xs = mean_j resblock_j(x)
+    if (f16 && !g->stage_w.empty() && g->stage_w[i].p) {  // narrow stage: every unit of every ResBlock in one launch, X -> XS
+      mb_resblock_stage_f16_args a;
+      memset(&a, 0, sizeof(a));
+      a.d_x = X; a.d_y = XS; a.d_wpacked = g->stage_w[i].p; a.d_bias = g->stage_b[i].p;
+      a.batch = batch; a.channels = ch; a.t = t; a.num_kernels = c.num_kernels; a.num_dilations = c.num_dilations;
+      for (int j = 0; j < c.num_kernels; ++j) {
+        const int base = g->i_rb + ((i * c.num_kernels + j) * c.num_dilations) * 2;
+        a.ksize[j] = g->convs[base].s.k;
+        for (int d = 0; d < c.num_dilations; ++d) a.dilation[j][d] = g->convs[base + d].s.dil;
+      }
+      a.slope = LRELU; a.out_scale = inv_nk;
+      a.d_valid = L.valid; a.valid_mul = t / L.frames_max;
+      if (!L.rc) L.rc = mb_resblock_stage_f16(&a, stream);
+    } else
     for (int j = 0; j < c.num_kernels; ++j) {
       const int base = g->i_rb + ((i * c.num_kernels + j) * c.num_dilations) * 2;
       const char* xr = X;

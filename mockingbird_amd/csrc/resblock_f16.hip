@@ -61,14 +61,36 @@ constexpr int PAIR_LB = 80 / PAIR_NL;  // x-window loads in flight per support l
 #ifndef MB_PAIR_NT
 #define MB_PAIR_NT 0
 #endif
+// The MBHIP_PAIR_DBG bits exist only in diagnostics builds (-DMB_PAIR_DBG_BUILD): a run-time test around the weight
+// prefetch made every ring refill a conditional load, and the compiler then drained vmcnt to 0 at every tap pair.
+#ifdef MB_PAIR_DBG_BUILD
+#define MB_PDBG(a_, bit) ((a_).dbg & (bit))
+#else
+#define MB_PDBG(a_, bit) 0
+#endif
 constexpr bool PAIR_NT = MB_PAIR_NT != 0;
 
 // diagnostics: mark k of tile `it`, role 0 = MMA wave 0, 1 = support wave 4 (workgroup 0, first 8 tiles)
+#ifdef MB_PAIR_TRACE_BUILD
 #define MB_PMARK(role, it, k)                                                                  \
   do {                                                                                         \
     if (a.trace && blockIdx.x == 0 && (it) < 8 && (tid & 63) == 0 && wave == ((role) ? 4 : 0)) \
       a.trace[((role) * 8 + (it)) * 16 + (k)] = (unsigned long long)clock64();                 \
   } while (0)
+#else  // a conditional global store in front of an MFMA loop makes the compiler's vmcnt bookkeeping give up (vmcnt(0) per iteration)
+#define MB_PMARK(role, it, k) do { } while (0)
+#endif
+
+// Valid length of batch item b (ragged batches).  A SCALAR load with its own wait: as a vector-memory load (what the compiler
+// emits for a pointer it cannot prove read-only) it sat, conditionally, at the head of every tile -- draining the MMA waves'
+// weight ring and leaving the compiler's vmcnt bookkeeping imprecise (vmcnt(0) in every iteration of the first tap loops).
+__device__ __forceinline__ int pair_valid_len(const ResPairK& a, int b) {
+  if (!a.valid) return a.T;
+  int v;
+  const int* p = a.valid + b;
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+  return min(a.T, v * a.valid_mul);
+}
 
 template <int C> struct PairGeom {
   static constexpr int CK = C >= 64 ? 64 : (C >= 32 ? 32 : 16);  // channels per x chunk
@@ -121,7 +143,7 @@ void resblock_pair_f16_kernel(ResPairK a) {
     auto load_batch = [&](int q, int base) {
       const int tile = (int)blockIdx.x + (q / NCH) * (int)gridDim.x, c = q % NCH;
       const int b = tile / a.tiles_per_item, t0 = (tile - b * a.tiles_per_item) * a.NB;
-      const int Tb = a.valid ? min(a.T, a.valid[b] * a.valid_mul) : a.T;  // beyond: this item's zero padding
+      const int Tb = pair_valid_len(a, b);  // beyond: this item's zero padding
       const int tx0 = t0 - p2 - p1;
       const h16* xb = a.x + (long long)b * a.bstride + c * CK;
 #pragma unroll
@@ -156,7 +178,7 @@ void resblock_pair_f16_kernel(ResPairK a) {
     auto write_out = [&](int it, int lo, int hi, int den) {  // batches [nbt*lo/den, nbt*hi/den) of tile `it`
       const int tile = (int)blockIdx.x + it * (int)gridDim.x;
       const int b = tile / a.tiles_per_item, t0 = (tile - b * a.tiles_per_item) * a.NB;
-      const int Tb = a.valid ? min(a.T, a.valid[b] * a.valid_mul) : a.T;
+      const int Tb = pair_valid_len(a, b);
       const int rows = max(0, min(a.NB, Tb - t0));
       const int ytotal = rows * YPR;
       const h16* xb = a.x + (long long)b * a.bstride + (long long)t0 * C;
@@ -170,7 +192,7 @@ void resblock_pair_f16_kernel(ResPairK a) {
         for (int i = 0; i < WB; ++i) {
           int idx = base + i * (64 * PAIR_NL) + ltid;
           idx = idx < ytotal ? idx : ytotal - 1;  // clamped: loads legal, store predicated
-          rx[i] = (a.dbg & 2) ? (h16x8)(h16)0.f : *reinterpret_cast<const h16x8*>(xb + (long long)idx * 8);
+          rx[i] = MB_PDBG(a, 2) ? (h16x8)(h16)0.f : *reinterpret_cast<const h16x8*>(xb + (long long)idx * 8);
           if (a.accumulate) ry[i] = *reinterpret_cast<const h16x8*>(yb + (long long)idx * 8);
         }
 #pragma unroll
@@ -186,7 +208,7 @@ void resblock_pair_f16_kernel(ResPairK a) {
             if (a.accumulate) f += (float)ry[i][e];
             o[e] = (h16)f;
           }
-          if (idx < ytotal && !(a.dbg & 4)) *reinterpret_cast<h16x8*>(yb + (long long)idx * 8) = o;
+          if (idx < ytotal && !MB_PDBG(a, 4)) *reinterpret_cast<h16x8*>(yb + (long long)idx * 8) = o;
         }
       }
     };
@@ -275,19 +297,26 @@ void resblock_pair_f16_kernel(ResPairK a) {
   do {                                                                                             \
     const h16* bp_ = (BPTR);                                                                       \
     const h16* np_ = (NEXT);                                                                       \
-    const size_t nf_ = (size_t)((a.dbg & 1) ? (ftn & 1) : ftn) * KB;                               \
+    const size_t nf_ = (size_t)(MB_PDBG(a, 1) ? (ftn & 1) : ftn) * KB;                             \
     _Pragma("unroll") for (int u = 0; u < KB; ++u) {                                               \
-      h16x8 af_[MT];                                                                               \
-      _Pragma("unroll") for (int i = 0; i < MT; ++i) af_[i] = ring[S][u][i];                       \
-      if (!(a.dbg & 8)) { _Pragma("unroll") for (int i = 0; i < MT; ++i) ring[S][u][i] = wp[i][(nf_ + u) * 64]; } \
       h16x8 bfn_[NTW];                                                                             \
       const h16* rp_ = u + 1 < KB ? bp_ + (u + 1) * 16 : np_;                                      \
       _Pragma("unroll") for (int n = 0; n < NTW; ++n)                                              \
         bfn_[n] = *reinterpret_cast<const h16x8*>(rp_ + n * 32 * (RS));                            \
-      __builtin_amdgcn_sched_barrier(0);                                                           \
       _Pragma("unroll") for (int i = 0; i < MT; ++i)                                               \
         _Pragma("unroll") for (int n = 0; n < NTW; ++n)                                            \
-          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[i], bfc_[n], acc[i][n], 0, 0, 0); \
+          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[S][u][i], bfc_[n], acc[i][n], 0, 0, 0); \
+      /* the refill of a ring slot is issued AFTER the MFMAs that read it: old and new value never live together, */ \
+      /* so the slot keeps its registers around the loop (no copies, no vmcnt drain at the back edge) */ \
+      if (!MB_PDBG(a, 8)) { _Pragma("unroll") for (int i = 0; i < MT; ++i) ring[S][u][i] = wp[i][(nf_ + u) * 64]; } \
+      /* issue order: ONE LDS read behind each of the first NTW MFMAs (a burst of NTW reads from four waves at once backs */ \
+      /* the LDS queue up into the issuing wave: 46 -> 41 cycles per MFMA measured in resblock_stage_f16.hip), then the refills */ \
+      _Pragma("unroll") for (int m = 0; m < MT * NTW; ++m) {                                       \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
+        if (m < NTW) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
+      }                                                                                            \
+      __builtin_amdgcn_sched_group_barrier(0x020, MT, 0);                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                           \
       _Pragma("unroll") for (int n = 0; n < NTW; ++n) bfc_[n] = bfn_[n];                           \
     }                                                                                              \
     ftn = ftn + 1 == NFT ? 0 : ftn + 1;                                                            \
@@ -323,8 +352,9 @@ void resblock_pair_f16_kernel(ResPairK a) {
   for (int it = 0; it < my_tiles; ++it) {
     const int tile = (int)blockIdx.x + it * (int)gridDim.x;
     const int t0 = (tile % a.tiles_per_item) * a.NB;
-    const int Tb = a.valid ? min(a.T, a.valid[tile / a.tiles_per_item] * a.valid_mul) : a.T;
+    const int Tb = pair_valid_len(a, tile / a.tiles_per_item);
     // ---------------- phase 1: h = lrelu(conv1(lrelu(x)) + b1) ----------------
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     zero_acc();
     MB_PMARK(0, it, 0);
     if (NCH == 1) {
@@ -571,7 +601,12 @@ extern "C" int mb_resblock_pair_f16(const mb_resblock_pair_f16_args* a, mb_strea
   } while (0)
   bool prefer_b = false;
   switch (a->channels) {
-    case 256: MB_PICK2(256, 1, 3, 2, false, 4, 1, false);
+    case 256:
+      // a third candidate for short stages: 160-row tiles (7 per 1000 positions: one round of 224 workgroups where 96-row tiles
+      // take two rounds of 384 -- the makespan estimate decides)
+      if (pair_fits<256>(5, a->ksize, a->dilation) && cost(160) < cost(96) && cost(160) < cost(128))
+        return launch_pair<256, 5, 1, false>(k, a->batch, s);
+      MB_PICK2(256, 1, 3, 2, false, 4, 1, false);
     case 128: MB_PICK2(128, 2, 2, 2, false, 3, 2, false);
     case 64:
       // N1 = 256 with its own y tile (support waves overlap the whole tile) measured faster than N1 = 512 sharing the h tile

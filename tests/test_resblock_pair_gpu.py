@@ -32,6 +32,7 @@ def _ref(x, w1, b1, w2, b2, d, slope):
 CASES = [
     # (B, C, T, k, dil): every (C, tile) instance, ragged T, T shorter than a tile, Fre-GAN dilation 7
     (2, 256, 1000, 3, 1), (1, 256, 130, 11, 5), (1, 256, 300, 7, 7),
+    (32, 256, 1000, 7, 3),  # the bench shape of the first stage: 160-row tiles win the makespan estimate (<256, 5, 1>)
     (2, 128, 333, 7, 3), (1, 128, 5000, 11, 5), (1, 128, 64, 3, 1),
     (1, 64, 700, 11, 7), (3, 64, 2000, 3, 5), (1, 64, 37, 7, 1),
     (3, 32, 1000, 3, 5), (1, 32, 4100, 11, 1), (1, 32, 9, 7, 3),
