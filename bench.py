@@ -331,9 +331,10 @@ def sharded_objects(args, rank, world, dev, use_dist, timed, total_over_ranks):
 
 
 def gan_floor_bytes(h, batch, frames):
-    """Read-x + write-y floor of one fp16 generator forward (every layer reads its input and writes its output
-    once, 2 B per element; the mean over the parallel ResBlocks adds a read of the accumulator for all but the
-    first): conv_pre, per stage the upsampler and num_kernels x len(dilations) fused pair units, conv_post."""
+    """Read-x + write-y floor of one fp16 generator forward AS LAUNCHED (every launch reads its input and writes its output
+    once, 2 B per element): conv_pre, per stage the upsampler and either num_kernels x len(dilations) fused pair units (the mean
+    over the parallel ResBlocks adds a read of the accumulator for all but the first) or, for the narrow stages (<= 32 channels),
+    ONE launch for the whole ResBlock group (resblock_stage_f16.hip: one read, one write), conv_post."""
     B, T, C = batch, frames, h["upsample_initial_channel"]
     b = B * T * (h["num_mels"] + C) * 2.0
     nk, nd = len(h["resblock_kernel_sizes"]), len(h["resblock_dilation_sizes"][0])
@@ -341,7 +342,10 @@ def gan_floor_bytes(h, batch, frames):
         b += B * T * C * 2.0
         T, C = T * u, C // 2
         b += B * T * C * 2.0
-        b += nk * nd * 2 * B * T * C * 2.0 + (nk - 1) * B * T * C * 2.0
+        if C <= 32:
+            b += 2 * B * T * C * 2.0
+        else:
+            b += nk * nd * 2 * B * T * C * 2.0 + (nk - 1) * B * T * C * 2.0
     return b + B * T * C * 2.0 + B * T * 4.0
 
 
@@ -349,9 +353,15 @@ def pmc_traffic(what, keys=None):
     """HBM bytes from the committed rocprofv3 PMC passes of the benchmarked configuration (profiles/r02_pmc_<what>.json,
     tools/pmc_r02.sh: 2 x FETCH_SIZE + WRITE_SIZE per launch; counters cannot be read in-process).  keys = kernels to
     sum per launch; None = all bytes of the profiled command.  Returns (bytes, source) or (None, None)."""
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", f"r02_pmc_{what}.json")))
-    except Exception:
+    pm = name = None
+    for rnd in ("r03", "r02"):  # the newest committed pass of this object
+        try:
+            name = f"profiles/{rnd}_pmc_{what}.json"
+            pm = json.load(open(os.path.join(ROOT, name)))
+            break
+        except Exception:
+            pm = None
+    if pm is None:
         return None, None
     if keys is None:
         tot = sum(v for k, v in pm.items() if k.endswith("_hbm_bytes_total")) / max(pm.get("forwards", 1), 1)
@@ -360,7 +370,7 @@ def pmc_traffic(what, keys=None):
         if any(v is None for v in vals):
             return None, None
         tot = sum(vals)
-    return tot, f"profiles/r02_pmc_{what}.json: {pm.get('source', '')[:200]}"
+    return tot, f"{name}: {pm.get('source', '')[:200]}"
 
 
 def main():

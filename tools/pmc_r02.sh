@@ -22,4 +22,4 @@ for what in ${@:-tacotron hifigan fregan}; do
     fregan) run fregan python tools/gan_run.py fregan f16 8 3000 2 ;;
   esac
 done
-python tools/pmc_r02_json.py
+python tools/pmc_r02_json.py ${@:-tacotron hifigan fregan}   # MB_PMC_ROUND=r03 -> profiles/r03_pmc_<what>.json

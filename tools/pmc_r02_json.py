@@ -2,7 +2,9 @@
 Combine the FETCH_SIZE / WRITE_SIZE summaries of tools/pmc_r02.sh into profiles/r02_pmc_<what>.json: HBM bytes per
 launch per kernel = 2 x FETCH_SIZE (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md) + WRITE_SIZE, both in
 KB per dispatch, mean over all dispatches of the benchmarked configuration."""
-import json, os
+import json, os, sys
+RND = os.environ.get("MB_PMC_ROUND", "r02")  # output prefix: profiles/<RND>_pmc_<what>.json
+ONLY = sys.argv[1:]                           # restrict to these objects (default: all that have summaries)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two separate passes), %s, MBHIP_NO_GRAPH=1 (counter mode "
        "crashes on hipGraph replays; same kernels and arguments); KB per dispatch, mean over all dispatches; FETCH_SIZE "
@@ -12,11 +14,14 @@ WHAT = {
                  {"prenet_fc2": ["taco_fc2_kernel"], "attn_gru": ["taco_gru_kernel"], "lsa": ["lsa_hh_kernel"],
                   "rnn_input": ["taco_rin_kernel"], "lstm": ["taco_lstm_kernel"], "mel_proj": ["taco_mel_kernel"]}),
     "hifigan": ("tools/gan_run.py hifigan f16 32 200 (bench object hifigan_f16)",
-                {"resblock_pair": ["resblock_pair"], "conv1d_f16": ["conv1d_f16"]}),
+                {"resblock_pair": ["resblock_pair"], "resblock_stage": ["resblock_stage"], "conv1d_f16": ["conv1d_f16"]}),
     "fregan": ("tools/gan_run.py fregan f16 8 3000 (bench object fregan_f16)",
-               {"resblock_pair": ["resblock_pair"], "conv1d_f16": ["conv1d_f16"]}),
+               {"resblock_pair": ["resblock_pair"], "resblock_stage": ["resblock_stage"], "conv1d_f16": ["conv1d_f16"],
+                "add_inplace": ["add_inplace_f16"]}),
 }
 for what, (cmd, names) in WHAT.items():
+    if ONLY and what not in ONLY:
+        continue
     try:
         f = json.load(open(os.path.join(ROOT, "gpurun_out", f"pmc2_{what}_FETCH_SIZE.json")))
         w = json.load(open(os.path.join(ROOT, "gpurun_out", f"pmc2_{what}_WRITE_SIZE.json")))
@@ -40,5 +45,5 @@ for what, (cmd, names) in WHAT.items():
         out["kernels"][name] = per
         out[name + "_hbm_bytes_per_launch"] = sum(p["hbm_bytes_per_launch"] * p["dispatches"] for p in per) / max(n, 1)
         out[name + "_hbm_bytes_total"] = sum(p["hbm_bytes_per_launch"] * p["dispatches"] for p in per)
-    json.dump(out, open(os.path.join(ROOT, "profiles", f"r02_pmc_{what}.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", f"{RND}_pmc_{what}.json"), "w"), indent=1)
     print(what, json.dumps({k: round(v) for k, v in out.items() if k.endswith("per_launch")}))
