@@ -18,6 +18,7 @@
 // CBHG runs on the MFMA conv kernel (conv1d.hip) with ReLU->BatchNorm, max-pool and highway
 // gates fused; the bidirectional GRU is a scan of EPI_GRU launches over precomputed W_ih.x.
 #include "taco_fast.h"
+#include "gru_scan.h"
 
 namespace mb {
 
@@ -583,6 +584,8 @@ struct Cbhg {
   std::vector<ConvL> bank, hw1, hw2;
   ConvL proj1, proj2, pre_highway, gru_ih_f, gru_ih_b;
   DevBuf gru_hh_f, gru_hh_b, gru_bhh_f, gru_bhh_b;
+  DevBuf gru_raw_f, gru_raw_b;  // torch weight_hh as is: the resident scan (gru_scan.h) splits it into its registers
+  int gru_sexp[2] = {0, 0};     // 2^s of that split, per direction
   bool has_pre = false;
   void release() {
     for (auto& c : bank) c.release();
@@ -590,6 +593,7 @@ struct Cbhg {
     for (auto& c : hw2) c.release();
     proj1.release(); proj2.release(); pre_highway.release(); gru_ih_f.release(); gru_ih_b.release();
     gru_hh_f.release(); gru_hh_b.release(); gru_bhh_f.release(); gru_bhh_b.release();
+    gru_raw_f.release(); gru_raw_b.release();
   }
 };
 
@@ -627,6 +631,8 @@ int make_cbhg(Cbhg* c, const float* const* hw, int* pix, int cin, int ch, int p0
     pack_rowtile(rows.data(), 3 * Hg, Hg, 3, &packed);
     RC((d ? c->gru_hh_b : c->gru_hh_f).upload(packed.data(), packed.size()));
     RC((d ? c->gru_bhh_b : c->gru_bhh_f).upload(hw[ix + 3], 3 * Hg));
+    RC((d ? c->gru_raw_b : c->gru_raw_f).upload(hw[ix + 1], (size_t)3 * Hg * Hg));
+    c->gru_sexp[d] = gru_scan_scale_exp(hw[ix + 1], (size_t)3 * Hg * Hg);
     ix += 4;
   }
 #undef RC
@@ -634,7 +640,8 @@ int make_cbhg(Cbhg* c, const float* const* hw, int* pix, int cin, int ch, int p0
   return rc;
 }
 
-struct CbhgWs { float *bank, *pj1, *pj2, *hwa, *hwb, *gate, *ihf, *ihb, *gh, *seq; };
+struct CbhgWs { float *bank, *pj1, *pj2, *hwa, *hwb, *gate, *ihf, *ihb, *gh, *seq, *seq_tm; unsigned long long* gsx; };
+constexpr size_t GSX_WORDS = (size_t)2 * 2 * 32 * 256 + 32;  // granules of the resident GRU scan (gru_scan.h) + its abort word
 
 void cbhg_take(Arena& ar, const Cbhg& c, size_t B, size_t F, CbhgWs* w) {
   const size_t ch = c.ch;
@@ -645,6 +652,8 @@ void cbhg_take(Arena& ar, const Cbhg& c, size_t B, size_t F, CbhgWs* w) {
   w->ihf = ar.take<float>(B * F * 3 * (ch / 2)); w->ihb = ar.take<float>(B * F * 3 * (ch / 2));
   w->gh = ar.take<float>(4 * B * (ch / 2));
   w->seq = ar.take<float>(B * ch * F);
+  w->gsx = ar.take<unsigned long long>(GSX_WORDS);
+  w->seq_tm = ar.take<float>(B * ch * F);
 }
 
 int run_conv(const ConvL& c, const float* x, int batch, int t, float* y, long long y_bstride, int in_act,
@@ -681,7 +690,41 @@ int cbhg_forward(const Cbhg& c, const float* x, int B, int F, const CbhgWs& L, h
   // bidirectional GRU (cbhg.py:76-77): W_ih.x + b_ih for every t as one GEMM per direction (time-major table)
   RC(run_conv(c.gru_ih_f, hin, B, F, L.ihf, (long long)F * 3 * Hg, 0, 0, nullptr, nullptr, 1, s));
   RC(run_conv(c.gru_ih_b, hin, B, F, L.ihb, (long long)F * 3 * Hg, 0, 0, nullptr, nullptr, 1, s));
-  if (!rc) {
+  // the scan: one resident launch for both directions (gru_scan.h); a lost hand-off (never seen: 4..8 workgroups) or
+  // MBHIP_GRU_SCAN=0 or a shape it has no instance for -> one launch per step
+  bool scanned = false;
+  {
+    const char* e = getenv("MBHIP_GRU_SCAN");
+    if (!rc && !(e && atoi(e) == 0) && gru_scan_shape_ok(B, Hg) && c.gru_raw_f.p && c.gru_raw_b.p) {
+      GruScanK k;
+      memset(&k, 0, sizeof(k));
+      k.whh[0] = c.gru_raw_f.p; k.whh[1] = c.gru_raw_b.p; k.bhh[0] = c.gru_bhh_f.p; k.bhh[1] = c.gru_bhh_b.p;
+      k.ih[0] = L.ihf; k.ih[1] = L.ihb; k.seq_tm = L.seq_tm; k.ex = L.gsx; k.abort_word = reinterpret_cast<int*>(L.gsx + GSX_WORDS - 32);
+      k.B = B; k.F = F; k.Hg = Hg;
+      for (int d = 0; d < 2; ++d) {
+        k.wscale[d] = std::ldexp(1.f, c.gru_sexp[d]);
+        k.unscale[d] = std::ldexp(1.f, -c.gru_sexp[d] - 10);
+      }
+      if (const char* de = getenv("MBHIP_GS_DBG")) k.dbg = atoi(de);
+      MB_HIP(hipMemsetAsync(L.gsx, 0, GSX_WORDS * sizeof(unsigned long long), s));
+      if (getenv("MBHIP_GRU_SCAN_TEST_ABORT")) {  // tests: the fallback path
+        const int one = 1;
+        MB_HIP(hipMemcpyAsync(k.abort_word, &one, sizeof(int), hipMemcpyHostToDevice, s));
+      }
+      rc = gru_scan_launch(k, s);
+      if (!rc) {
+        hipLaunchKernelGGL(gru_scan_transpose_kernel, dim3(cdiv(C, 32), cdiv(F, 32), B), dim3(256), 0, s, L.seq_tm, L.seq, F, B, C);
+        MB_HIP(hipGetLastError());
+      }
+      int aborted = 0;
+      if (!rc) {
+        MB_HIP(hipMemcpyAsync(&aborted, k.abort_word, sizeof(int), hipMemcpyDeviceToHost, s));
+        MB_HIP(hipStreamSynchronize(s));
+      }
+      scanned = !rc && !aborted;
+    }
+  }
+  if (!rc && !scanned) {
     MB_HIP(hipMemsetAsync(L.gh, 0, sizeof(float) * 4 * B * Hg, s));
     for (int st = 0; st < F && !rc; ++st) {
       RnnK kd[2];

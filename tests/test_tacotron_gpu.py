@@ -268,3 +268,37 @@ def test_non_default_checkpoint_dims_match_oracle(cuda, lib, B, r):
     for b in range(B):  # ragged padding (chars == 0 masks the logits, lsa.py:34)
         chars[b, T - (b % 5):] = 0
     _decode_vs_oracle(dev, dec, hp, r, mem, memp, chars, 8 * r, mask_seed=31, width=2 * D)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Resident bidirectional GRU scan of the two CBHGs (gru_scan.h): the encoder memory and the postnet output of the
+# default path against the launch-per-step scan (MBHIP_GRU_SCAN=0) and through the fallback after a lost hand-off.
+# (Every oracle test above runs the resident scan: it is the default.)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["off", "abort"])
+def test_resident_gru_scan_equals_launch_per_step_scan(model, monkeypatch, mode):
+    """cbhg.py:76-77 both ways: error-compensated fp16 products with W_hh in registers (one launch) against the fp32 MFMA
+    launch per step -- 2^-22-grade agreement; `abort`: the resident launch finds the abort word raised and the same call
+    computes the launch-per-step scan (bit-identical to MBHIP_GRU_SCAN=0)."""
+    dev, w = model
+    B = 18  # two column tiles, the second one partly dead
+    chars, spk, _, _ = _batch(B, 33, 47, seed=77)
+    T = chars.shape[1]
+    g = torch.Generator().manual_seed(6)
+    enc_masks = torch.stack([torch.empty(B, T, 256).bernoulli_(0.5, generator=g) for _ in range(2)])
+    hm, hp = dev.encode(chars.cuda(), spk.cuda(), -1, enc_masks)
+    steps = 24
+    masks = synth.decoder_dropout_masks(3, (steps + 1) // 2, B, 256)
+    mel, lin, _ = dev.decode(hm, hp, chars.cuda(), steps, 11.0, dropout=masks)
+    monkeypatch.setenv("MBHIP_GRU_SCAN_TEST_ABORT" if mode == "abort" else "MBHIP_GRU_SCAN", "1" if mode == "abort" else "0")
+    hm2, hp2 = dev.encode(chars.cuda(), spk.cuda(), -1, enc_masks)
+    mel2, lin2, _ = dev.decode(hm, hp, chars.cuda(), steps, 11.0, dropout=masks)
+    for name, a, b in (("memory", hm, hm2), ("memory_proj", hp, hp2), ("linear", lin, lin2)):
+        e = hiputil.relerr(a, b)
+        assert e["nan"] == 0 and e["max_abs"] <= 2e-5, (name, e)
+    assert torch.equal(mel.cpu(), mel2.cpu())  # the decoder loop itself is untouched
+    if mode == "abort":
+        monkeypatch.delenv("MBHIP_GRU_SCAN_TEST_ABORT")
+        monkeypatch.setenv("MBHIP_GRU_SCAN", "0")
+        hm3, _ = dev.encode(chars.cuda(), spk.cuda(), -1, enc_masks)
+        assert torch.equal(hm2.cpu(), hm3.cpu())
