@@ -652,12 +652,26 @@ def main():
             mol.generate_samples(mel[:, :60], True, 2000, 200, seed=1)
             sm = mol.generate_samples(mel, True, target, overlap, seed=2)
             torch.cuda.synchronize()
+            resident_m = mol.last_loop_launches == 1
             result["wavernn_mol"] = {
-                "workload": f"MOL-mode WaveRNN, mel 80x{F}, batched: {mol.last_plan.n_folds} folds x {mol.last_plan.seq_len} steps; 5-launch chain "
-                            "with fc3 + sample_from_discretized_mix_logistic fused in one launch (wf_fc3_mol_kernel)",
+                "workload": f"MOL-mode WaveRNN, mel 80x{F}, batched: {mol.last_plan.n_folds} folds x {mol.last_plan.seq_len} steps; "
+                            + ("ONE resident launch (wavernn_pipe.h: the F3 role is one workgroup that computes the 30 mixture parameters "
+                               "and samples sample_from_discretized_mix_logistic itself)" if resident_m else
+                               "5-launch chain with fc3 + sample_from_discretized_mix_logistic fused in one launch (wf_fc3_mol_kernel)"),
                 "sample_loop_ms": mol.last_loop_ms, "us_per_time_step": mol.last_loop_ms * 1e3 / mol.last_plan.seq_len,
                 "loop_launches": mol.last_loop_launches,
                 "value": sm.numel() / (mol.last_loop_ms * 1e-3), "unit": "fold samples/s (loop only)"}
+            if resident_m:  # A/B partner: the launch chain, same utterance and seed -- bit-identical stream
+                os.environ["MBHIP_WAVERNN_PIPE"] = "0"
+                try:
+                    sc = mol.generate_samples(mel, True, target, overlap, seed=2)
+                    torch.cuda.synchronize()
+                    result["wavernn_mol"]["chain_reference"] = {
+                        "us_per_time_step": mol.last_loop_ms * 1e3 / mol.last_plan.seq_len, "loop_launches": mol.last_loop_launches,
+                        "identical_stream": bool(torch.equal(sc, sm))}
+                    del sc
+                finally:
+                    os.environ.pop("MBHIP_WAVERNN_PIPE", None)
             del mol, sm
         # ---- secondary: WaveRNN throughput mode -- north_star's "batch-32 synthetic input": 32 utterances of
         # mel 80x{F} share ONE sample loop (736 fold columns instead of 23 per launch)

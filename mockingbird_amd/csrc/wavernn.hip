@@ -776,10 +776,11 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
   // NOTE: a resident launch makes this call host-blocking (the abort word has to be looked at before returning).
   const char* penv = getenv("MBHIP_WAVERNN_PERSIST");
   const char* qenv = getenv("MBHIP_WAVERNN_PIPE");
-  const bool resident_ok = fastk && c.mode == 0 && C <= 512 && !w->bench_which && !w->bench_chain && !getenv("MBHIP_TRACE_FILE") && !getenv("MBHIP_WF_DBG_WHICH");
+  const bool resident_ok = fastk && C <= 512 && !w->bench_which && !w->bench_chain && !getenv("MBHIP_TRACE_FILE") && !getenv("MBHIP_WF_DBG_WHICH");
   const bool persist_asked = penv && atoi(penv) == 1 && N <= WP_NCOL;  // MBHIP_WAVERNN_PERSIST=1 keeps meaning wavernn_persist.h
+  // (MOL models: the pipelined kernel only -- its F3 role carries the mixture sampler; one column runs the chain)
   bool pipe = resident_ok && N >= 2 && N <= WQ_G * WQ_GC && (qenv ? atoi(qenv) != 0 : (WQ_DEFAULT_ON != 0 && !persist_asked));
-  bool persist = resident_ok && !pipe && N <= WP_NCOL && (penv ? atoi(penv) != 0 : N == 1);
+  bool persist = resident_ok && c.mode == 0 && !pipe && N <= WP_NCOL && (penv ? atoi(penv) != 0 : N == 1);
   if ((pipe || persist) && !rc) {
     int dev = 0;
     MB_HIP(hipGetDevice(&dev));
@@ -818,6 +819,7 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
       qk.cond = cond; qk.G2 = L.G2; qk.F1 = L.F1; qk.F2 = L.F2;
       qk.g = wg; qk.ex = L.px; qk.abort_word = abort_word;
       qk.samples = d_samples; qk.progress = h_progress; qk.seed = seed; qk.R = R; qk.FC = FC; qk.C = C; qk.S = S; qk.N = N;
+      qk.mol = c.mode == 1 ? 1 : 0; qk.nr_mix = C / 3;
       qk.gn0[0] = 0; qk.gn0[1] = (N + 1) / 2; qk.gn0[2] = N;  // two groups of ceil / floor (N / 2) columns
       if (const char* ge = getenv("MBHIP_WQ_GROUPS")) { if (atoi(ge) == 1 && N <= WQ_GC) qk.gn0[1] = N; }  // A/B: one group, no pipelining
       qk.flags = getenv("MBHIP_WQ_FLAGS") ? atoi(getenv("MBHIP_WQ_FLAGS")) : 1;  // A/B switches of wavernn_pipe.h

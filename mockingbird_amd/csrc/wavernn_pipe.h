@@ -53,6 +53,8 @@ struct WqK {
   float* samples; volatile int* progress;
   unsigned long long seed; int R, FC, C, S, N;
   int gn0[WQ_G + 1];          // group g owns fold columns [gn0[g], gn0[g + 1])
+  int mol, nr_mix;            // MOL mode (fatchord_version.py:213-220): fc3 has 3 nr_mix rows, F3 is ONE workgroup that samples the
+                              // mixture of logistics itself (wf_fc3_mol_kernel's draws) and hands the SAMPLE to R1
   int flags;                  // A/B switches (MBHIP_WQ_FLAGS): 1 = exchange rows padded to 16 columns (default), 2 = R2's residual x1 by a global load
   unsigned long long* trace;  // diagnostics (MBHIP_WP_TRACE): wall-clock marks of one workgroup per role, steps 1000..1003
 };
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int du = lane >> 4, i = lane & 15;
   const int H = a.R, S = a.S;
-  const int n_t3 = a.C / 16;
+  const int n_t3 = a.mol ? 1 : a.C / 16;  // fc3 workgroups (MOL: one, holding both row tiles of the <= 32 mixture parameters)
   int rb = 0;  // red buffer of the next GEMM
   auto EX = [&](int what, int g, unsigned tag) { return a.ex + ((size_t)g * 2 + (tag & 1)) * WQX_PER + what; };
 #define WQ_MARK(role, k)                                                                                   \
@@ -138,7 +140,20 @@ __global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
         if (Ng <= 0) continue;
         WQ_MARK(0, 0);
         // ---- keys of step s-1 -> sample x of every column of the group ----
-        if (s > 0) {
+        if (s > 0 && a.mol) {  // MOL: the key word IS the sample (one granule per column, written by the one F3 workgroup)
+          if (tid < Ng) {
+            unsigned xv[1];
+            if (!wp_wait<1>(EX(WQX_KEY, g, tag_prev) + tid, 1, tag_prev, xv, a.abort_word)) return;
+            const float x = __uint_as_float(xv[0]);
+            s_x[tid] = x;
+            if (blk == 0) {
+              a.samples[(size_t)(n0 + tid) * S + (s - 1)] = x;
+              if (a.progress && n0 + tid == 0 && (s - 1) % 100 == 0) *a.progress = s;
+            }
+          }
+          __syncthreads();
+          WQ_MARK(0, 1);
+        } else if (s > 0) {
           const unsigned long long* K = EX(WQX_KEY, g, tag_prev);  // key halves of a tile: rows of LD granules (whole lines per store)
           wp_watch<1>(K + (size_t)((n_t3 - 1) * 2 + 1) * LD + (Ng - 1), tag_prev, a.abort_word);
           if (tid < 32 * Ng && (tid & 31) < n_t3) {
@@ -269,8 +284,17 @@ __global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
   const int fr = (blk - WQ_R1 - WQ_R2) / WQ_F, ft = (blk - WQ_R1 - WQ_R2) % WQ_F;  // role 0 / 1 / 2, row tile
   const bool mark_wg = ft == 0;
   if (fr == 2 && ft >= n_t3) return;
-  wp_copy_tile(lw, (fr == 0 ? a.w_fc1 : fr == 1 ? a.w_fc2 : a.w_fc3) + (size_t)ft * 8192, 8192);
-  const float4 b3q = fr == 2 ? *reinterpret_cast<const float4*>(a.b_fc3 + ft * 16 + du * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool f3mol = fr == 2 && a.mol;
+  wp_copy_tile(lw, (fr == 0 ? a.w_fc1 : fr == 1 ? a.w_fc2 : a.w_fc3) + (size_t)ft * 8192, f3mol ? 16384 : 8192);
+  const float4 b3q = fr == 2 && !a.mol ? *reinterpret_cast<const float4*>(a.b_fc3 + ft * 16 + du * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float bmol[4] = {0.f, 0.f, 0.f, 0.f};  // MOL: bias of rows wave * 16 + du * 4 + r (waves 0 / 1 = the two row tiles)
+  if (f3mol && wave < 2) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wave * 16 + du * 4 + r;
+      bmol[r] = row < a.C ? a.b_fc3[row] : 0.f;
+    }
+  }
   float4 fpre[WQ_G];
   int f_row[WQ_G];
 #pragma unroll
@@ -291,7 +315,7 @@ __global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
           fpre[g] = *reinterpret_cast<const float4*>((fr == 0 ? a.F1 : a.F2) + (size_t)frow * a.FC + ft * 16 + du * 4);
           f_row[g] = frow;
         }
-      } else if (wave == 0) {  // the step's Gumbel noise does not depend on the data: drawn before the wait
+      } else if (wave == 0 && !a.mol) {  // the step's Gumbel noise does not depend on the data: drawn before the wait
         uint32_t grn[4];
         philox4x32((uint32_t)s, (uint32_t)ncl, (uint32_t)((ft * 16 + du * 4) >> 2), 0x57415645u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), grn);
 #pragma unroll
@@ -302,6 +326,46 @@ __global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
       if (!wq_gather<1>(EX(src, g, tag), tag, Ng, LD, b, a.abort_word)) return;
       WQ_MARK(2 + fr, 1);
       float sx[4];
+      if (f3mol) {
+        // ---- MOL: both row tiles against the gathered y2 (the per-tile sums of fm_gemm), the mixture parameters of the group's
+        //      columns through LDS (the red half the NEXT product will use: free until the barrier of its gather), then
+        //      wf_fc3_mol_kernel's sampler per column -- same Philox words, same expressions -- and the sample as the key ----
+        const bool epi2 = wp_gemm2<4>(lw, 8192, b, red + rb * 4096, sx);
+        rb ^= 1;
+        float* lg = red + rb * 4096;  // [16 columns][33]
+        if (epi2) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lg[i * 33 + wave * 16 + du * 4 + r] = sx[r] + bmol[r];
+        }
+        __syncthreads();
+        WQ_MARK(2 + fr, 3);
+        if (tid < Ng) {
+          const float* l = lg + tid * 33;
+          const int M = a.nr_mix, n = n0 + tid;
+          float best = -INFINITY, uu = 0.5f;
+          int bidx = 0;
+          for (int q = 0; q <= M / 4; ++q) {  // draws 0 .. M: M mixture-indicator uniforms, then the logistic one
+            uint32_t rr[4];
+            philox4x32((uint32_t)s, (uint32_t)n, (uint32_t)q, 0x4d4f4c21u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), rr);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int m = q * 4 + e;
+              const float u = 1e-5f + (1.0f - 2e-5f) * u32_to_unit(rr[e]);  // uniform_(1e-5, 1 - 1e-5)
+              if (m < M) {
+                const float v = l[m] - logf(-logf(u));
+                if (v > best) { best = v; bidx = m; }  // first maximum on ties
+              } else if (m == M) uu = u;
+            }
+          }
+          const float mean = l[M + bidx];
+          const float ls = fmaxf(l[2 * M + bidx], -32.23619130191664f);  // log(1e-14)
+          float x = mean + expf(ls) * (logf(uu) - logf(1.f - uu));
+          x = fminf(fmaxf(x, -1.f), 1.f);
+          wp_put(EX(WQX_KEY, g, tag) + tid, x, tag);
+        }
+        WQ_MARK(2 + fr, 2);
+        continue;
+      }
       const bool epi = wp_gemm<4>(lw, b, red + rb * 4096, sx);
       rb ^= 1;
       WQ_MARK(2 + fr, 3);

@@ -401,8 +401,16 @@ def test_mol_free_running_facade(mol_model):
     not on the RAW class grid, mu-law decoding is skipped in MOL mode (fatchord_version.py:154) even when asked for."""
     dev, w = mol_model
     m = torch.from_numpy(synth.wavernn_mel(30, seed=4) / 4.0).cuda()
+    import os
     a = dev.generate_samples(m, True, 600, 100, seed=5)
-    assert dev.last_loop_launches == 5 * dev.last_plan.seq_len  # production chain: fc3 + mixture sampler fused (wf_fc3_mol_kernel)
+    assert dev.last_loop_launches == 1  # production path: the resident pipelined kernel, its F3 role samples the mixture (wavernn_pipe.h)
+    os.environ["MBHIP_WAVERNN_PIPE"] = "0"
+    try:
+        chain = dev.generate_samples(m, True, 600, 100, seed=5)
+        assert dev.last_loop_launches == 5 * dev.last_plan.seq_len  # the launch chain: fc3 + mixture sampler fused (wf_fc3_mol_kernel)
+    finally:
+        del os.environ["MBHIP_WAVERNN_PIPE"]
+    assert torch.equal(a, chain)  # same per-tile sums, same Philox words, same expressions: bit-identical streams
     b = dev.generate_samples(m, True, 600, 100, seed=5)
     c = dev.generate_samples(m, True, 600, 100, seed=6)
     assert torch.equal(a, b) and not torch.equal(a, c)
@@ -422,7 +430,6 @@ def test_mol_free_running_facade(mol_model):
     assert float(d[~near_tie].max()) <= 1e-4 and int(near_tie.sum()) < steps, (float(d[~near_tie].max()), int(near_tie.sum()))
     # the exact 6-launch chain (stand-alone sampler, both GRU halves on the chain) draws the same words; continuous samples feed
     # roundings back, so the two streams agree to 1e-4 over the first steps and drift apart later
-    import os
     os.environ["MBHIP_WAVERNN_NOFUSE"] = "1"
     try:
         exact = dev.generate_samples(m, True, 600, 100, seed=5)
