@@ -134,6 +134,50 @@ def test_resblock_pair_weight_stream_layout(lib):
     assert L.mb_resblock_pair_f16_supported(64, 4, 1) == 0  # even kernel sizes have no "same" padding
 
 
+def test_resblock_stage_weight_stream_layout(lib):
+    """mb_resblock_stage_f16_pack / _supported (host code): ONE circular fp16 stream in the kernel's consumption order
+    [ResBlock j][unit u][conv1 | conv2][tap][k-block][lane][8] (one 32-row output tile, rows >= C zero), the
+    v_mfma_f32_32x32x16_f16 A-fragment lane map; the supported() rule follows LDS (window + halo of the widest ResBlock)."""
+    import ctypes as C_
+    from mockingbird_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(1)
+    for Cc, ks, nd in ((32, (3, 7, 11), 3), (16, (3, 5), 4), (32, (7,), 2)):
+        nk = len(ks)
+        w1 = [rng.standard_normal((Cc, Cc, ks[j])).astype(np.float32) for j in range(nk) for _ in range(nd)]
+        w2 = [rng.standard_normal((Cc, Cc, ks[j])).astype(np.float32) for j in range(nk) for _ in range(nd)]
+        karr = (C_.c_int * nk)(*ks)
+        n = L.mb_resblock_stage_f16_packed_halves(Cc, nk, karr, nd)
+        KB = Cc // 16
+        assert n == sum(2 * nd * k for k in ks) * KB * 512
+        img = np.empty(n, np.float16)
+        p1 = (C_.c_void_p * len(w1))(*[w.ctypes.data for w in w1])
+        p2 = (C_.c_void_p * len(w2))(*[w.ctypes.data for w in w2])
+        _lib.check(L.mb_resblock_stage_f16_pack(p1, p2, Cc, nk, karr, nd, img.ctypes.data), "mb_resblock_stage_f16_pack")
+        o = 0
+        for j in range(nk):
+            for u in range(nd):
+                for ph, ws in ((0, w1), (1, w2)):
+                    w = ws[j * nd + u]
+                    blk = img[o:o + ks[j] * KB * 512].reshape(ks[j], KB, 64, 8)
+                    o += ks[j] * KB * 512
+                    for tap, kb, lane in ((0, 0, 0), (ks[j] - 1, KB - 1, 63), (ks[j] // 2, 0, 37)):
+                        co, ci0 = lane & 31, kb * 16 + (lane >> 5) * 8
+                        want = w[co, ci0:ci0 + 8, tap].astype(np.float16) if co < Cc else np.zeros(8, np.float16)
+                        assert np.array_equal(blk[tap, kb, lane], want), (Cc, j, u, ph, tap, kb, lane)
+        assert o == n
+    k3 = (C_.c_int * 3)(3, 7, 11)
+    d135 = (C_.c_int * 9)(*([1, 3, 5] * 3))
+    d1357 = (C_.c_int * 12)(*([1, 3, 5, 7] * 3))
+    assert L.mb_resblock_stage_f16_supported(32, 3, k3, 3, d135) == 1 and L.mb_resblock_stage_f16_supported(32, 3, k3, 4, d1357) == 1
+    assert L.mb_resblock_stage_f16_supported(16, 3, k3, 4, d1357) == 1
+    assert L.mb_resblock_stage_f16_supported(64, 3, k3, 3, d135) == 0   # wider stages: one launch per unit (mb_resblock_pair_f16)
+    k4 = (C_.c_int * 3)(3, 4, 11)
+    assert L.mb_resblock_stage_f16_supported(32, 3, k4, 3, d135) == 0   # even kernel sizes have no "same" padding
+    big = (C_.c_int * 9)(*([1, 9, 27] * 3))
+    assert L.mb_resblock_stage_f16_supported(32, 3, k3, 3, big) == 0    # the halo of the widest ResBlock leaves no rows in the tile
+
+
 def test_wavernn_finish_workspace_and_shape_errors(lib):
     """Host-side checks of mb_wavernn_finish: workspace formula, argument validation before any launch."""
     from mockingbird_amd import _lib
