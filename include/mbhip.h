@@ -172,10 +172,14 @@ int mb_resblock_pair_f16(const mb_resblock_pair_f16_args* a, mb_stream_t stream)
  *   models/vocoder/hifigan/models.py:139-145, models/vocoder/fregan/generator.py:150-157
  * with ResBlock1.forward (hifigan/models.py:39-46, fregan/generator.py:43-50), the activations of a tile LDS-resident across
  * all units of all chains (resblock_stage_f16.hip): x is read once and y written once per stage.
- * Supported: channels in {16, 32}, 1..4 kernels (k odd >= 3), 1..4 dilations, the tile must fit LDS
- * (mb_resblock_stage_f16_supported); wider stages run mb_resblock_pair_f16 per unit. */
+ * Supported: channels in {16, 32, 64, 128}, 1..4 kernels (k odd >= 3), 1..4 dilations, the tile must fit LDS
+ * (mb_resblock_stage_f16_supported).  At 16 / 32 channels the whole group is one launch; at 64 / 128 channels LDS holds short
+ * windows (256 / 128 rows), so it pays for single ResBlocks with a small reach only (mb_resblock_stage_f16_efficiency = useful
+ * rows / window rows): the others run mb_resblock_pair_f16 per unit, every launch accumulating into y. */
 int mb_resblock_stage_f16_supported(int channels, int num_kernels, const int* ksizes, int num_dilations,
                                     const int* dilations /* [num_kernels][num_dilations] */);
+float mb_resblock_stage_f16_efficiency(int channels, int num_kernels, const int* ksizes, int num_dilations,
+                                       const int* dilations);
 size_t mb_resblock_stage_f16_packed_halves(int channels, int num_kernels, const int* ksizes, int num_dilations);
 /* h_w1[j * num_dilations + u], h_w2[...]: fp32 torch Conv1d weights [C][C][k_j] of convs1[u] / convs2[u] of ResBlock j */
 int mb_resblock_stage_f16_pack(const float* const* h_w1, const float* const* h_w2, int channels, int num_kernels,
@@ -191,6 +195,7 @@ typedef struct mb_resblock_stage_f16_args {
   int dilation[4][4];     /* [kernel][unit]: dilation of convs1[unit]; convs2 have dilation 1 */
   float slope;            /* leaky_relu slope in (0,1)                                      */
   float out_scale;        /* 0 = 1 / num_kernels                                            */
+  int accumulate;         /* y += result (a stage run as one launch per ResBlock)           */
   const int* d_valid; int valid_mul;  /* ragged batches, as mb_resblock_pair_f16_args */
 } mb_resblock_stage_f16_args;
 int mb_resblock_stage_f16(const mb_resblock_stage_f16_args* a, mb_stream_t stream);

@@ -65,7 +65,7 @@ class ResStageF16Args(C.Structure):
         ("d_x", C.c_void_p), ("d_y", C.c_void_p), ("d_wpacked", C.c_void_p), ("d_bias", C.c_void_p),
         ("batch", C.c_int), ("channels", C.c_int), ("t", C.c_int), ("num_kernels", C.c_int), ("num_dilations", C.c_int),
         ("ksize", C.c_int * 4), ("dilation", (C.c_int * 4) * 4),
-        ("slope", C.c_float), ("out_scale", C.c_float),
+        ("slope", C.c_float), ("out_scale", C.c_float), ("accumulate", C.c_int),
         ("d_valid", C.c_void_p), ("valid_mul", C.c_int),
     ]
 
@@ -156,6 +156,7 @@ SIGNATURES = {
     "mb_resblock_pair_f16_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "mb_resblock_pair_f16": (C.c_int, [C.POINTER(ResPairF16Args), C.c_void_p]),
     "mb_resblock_stage_f16_supported": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "mb_resblock_stage_f16_efficiency": (C.c_float, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "mb_resblock_stage_f16_packed_halves": (C.c_size_t, [C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "mb_resblock_stage_f16_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "mb_resblock_stage_f16": (C.c_int, [C.POINTER(ResStageF16Args), C.c_void_p]),

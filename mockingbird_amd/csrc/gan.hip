@@ -143,6 +143,9 @@ struct mb_gan {
   // fp16 path, narrow stages (C <= 32): the whole ResBlock group of a stage as ONE launch (resblock_stage_f16.hip); per stage the
   // weight stream and the [kernel][unit][2][C] bias block; empty = the stage runs its units one by one
   std::vector<DevBuf> stage_w, stage_b;
+  // fp16 path, wider stages (64 / 128 channels): single ResBlocks whose reach is small against the rows LDS holds (k = 3, 7 at 64
+  // channels, k = 3 at 128) as ONE launch each, accumulating into the stage output; indexed (stage * num_kernels + kernel)
+  std::vector<DevBuf> chain_w, chain_b;
   int hop;
   // indices into convs
   int i_pre, i_ups, i_cond, i_resout, i_rb, i_post;
@@ -272,6 +275,42 @@ extern "C" int mb_gan_create_ex(const mb_gan_config* cfg, const float* const* h_
       if (!rc) rc = g->stage_b[i].upload(bias.data(), bias.size());
       if (rc) { mb_gan_destroy(g); return rc; }
     }
+    if (!getenv("MBHIP_GAN_NOCHAIN")) {
+      g->chain_w.resize((size_t)cfg->num_upsamples * nk);
+      g->chain_b.resize((size_t)cfg->num_upsamples * nk);
+      for (int i = 0; i < cfg->num_upsamples; ++i) {
+        const int ch = cfg->upsample_initial_channel >> (i + 1);
+        if (ch != 64 && ch != 128) continue;
+        for (int j = 0; j < nk; ++j) {
+          const int base = g->i_rb + ((i * nk + j) * nd) * 2;
+          int kj = 0, dil[4];
+          const float *w1[4], *w2[4];
+          bool ok = !g->pairs.empty();
+          bias.assign((size_t)nd * 2 * ch, 0.f);
+          for (int d = 0; d < nd && ok; ++d) {
+            const ConvSpec& s1 = v[base + d];
+            const ConvSpec& s2 = v[base + nd + d];
+            ok = g->pairs[(size_t)(i * nk + j) * nd + d].p != nullptr && s1.c_in == ch && (d == 0 || s1.k == kj);  // (pairs: shapes checked above)
+            kj = s1.k; dil[d] = s1.dil;
+            w1[d] = h_weights[2 * (base + d)]; w2[d] = h_weights[2 * (base + nd + d)];
+            if (ok) {
+              memcpy(&bias[((size_t)d * 2) * ch], h_weights[2 * (base + d) + 1], ch * sizeof(float));
+              memcpy(&bias[((size_t)d * 2 + 1) * ch], h_weights[2 * (base + nd + d) + 1], ch * sizeof(float));
+            }
+          }
+          // useful rows per window row: measured on HiFi-GAN 32 x 200 (same box): no chain launches 3.667 ms, k = 3 at 64 channels
+          // (0.91) 3.616, + k = 3 at 128 channels (0.81) 3.569, + k = 7 at 64 channels (0.72) 3.579 -- below ~0.75 the halo
+          // recompute costs what the per-unit launches' tensor passes do
+          const char* ee = getenv("MBHIP_GAN_CHAIN_EFF");  // A/B: another threshold
+          if (!ok || mb_resblock_stage_f16_efficiency(ch, 1, &kj, nd, dil) < (ee ? (float)atof(ee) : 0.75f)) continue;
+          img.assign(mb_resblock_stage_f16_packed_halves(ch, 1, &kj, nd) / 2, 0.f);
+          rc = mb_resblock_stage_f16_pack(w1, w2, ch, 1, &kj, nd, reinterpret_cast<uint16_t*>(img.data()));
+          if (!rc) rc = g->chain_w[(size_t)i * nk + j].upload(img.data(), img.size());
+          if (!rc) rc = g->chain_b[(size_t)i * nk + j].upload(bias.data(), bias.size());
+          if (rc) { mb_gan_destroy(g); return rc; }
+        }
+      }
+    }
   }
   *out = g;
   return MB_OK;
@@ -283,6 +322,8 @@ extern "C" void mb_gan_destroy(mb_gan* g) {
   for (auto& p : g->pairs) p.release();
   for (auto& p : g->stage_w) p.release();
   for (auto& p : g->stage_b) p.release();
+  for (auto& p : g->chain_w) p.release();
+  for (auto& p : g->chain_b) p.release();
   delete g;
 }
 
@@ -516,6 +557,18 @@ static int gan_forward_impl(const mb_gan* g, const float* d_mel, int batch, int 
       bool all_fused = f16 && !g->pairs.empty();
       for (int d = 0; d < c.num_dilations && all_fused; ++d)
         all_fused = g->pairs[(size_t)(i * c.num_kernels + j) * c.num_dilations + d].p != nullptr;
+      if (all_fused && !g->chain_w.empty() && g->chain_w[(size_t)i * c.num_kernels + j].p) {  // the whole ResBlock in one launch
+        mb_resblock_stage_f16_args a;
+        memset(&a, 0, sizeof(a));
+        a.d_x = X; a.d_y = XS; a.d_wpacked = g->chain_w[(size_t)i * c.num_kernels + j].p; a.d_bias = g->chain_b[(size_t)i * c.num_kernels + j].p;
+        a.batch = batch; a.channels = ch; a.t = t; a.num_kernels = 1; a.num_dilations = c.num_dilations;
+        a.ksize[0] = g->convs[base].s.k;
+        for (int d = 0; d < c.num_dilations; ++d) a.dilation[0][d] = g->convs[base + d].s.dil;
+        a.slope = LRELU; a.out_scale = inv_nk; a.accumulate = j > 0;
+        a.d_valid = L.valid; a.valid_mul = t / L.frames_max;
+        if (!L.rc) L.rc = mb_resblock_stage_f16(&a, stream);
+        continue;
+      }
       if (all_fused) {  // one launch per (convs1[d], convs2[d]); never in place: X -> XR -> T -> XR ... -> XS
         for (int d = 0; d < c.num_dilations; ++d) {
           const bool last = d == c.num_dilations - 1;

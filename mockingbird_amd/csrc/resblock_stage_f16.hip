@@ -46,6 +46,7 @@ struct ResStageK {
   int dil[STAGE_MAX_CHAINS][STAGE_MAX_UNITS];
   int Hh, PAD, NB, tiles_per_item, n_tiles, NFT;
   float slope, out_scale;
+  int accumulate;  // y += (the wider stages run one ResBlock per launch: the mean over the ResBlocks accumulates in y)
   const int* valid; int valid_mul;
   unsigned long long* trace;  // diagnostics only (-DMB_STAGE_TRACE_BUILD + MBHIP_STAGE_TRACE): shader-clock marks of workgroup 0, tile 1
 };
@@ -68,15 +69,19 @@ __device__ __forceinline__ int stage_valid_len(const ResStageK& a, int b) {  // 
   return min(a.T, v * a.valid_mul);
 }
 
-template <int C, int NTW>
+// C channels = WM x MT 32-row output tiles (WM waves along the channels, MT tiles per wave), WN = 4 / WM waves along the rows with
+// NTW 32-row tiles each: <16 | 32, 1, 4, NTW> for the narrow stages (one launch = the whole ResBlock group), <64, 2, 4, 2> and
+// <128, 2, 2, 2> for single ResBlocks of the wider stages whose halo is small against what LDS holds (k = 3, 7 at 64 channels,
+// k = 3 at 128).  TD = taps of weight prefetch in flight, BD = k-steps the B fragments (LDS) run ahead of the MFMAs.
+template <int C, int MT, int WN, int NTW, int TD, int BD>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void resblock_stage_f16_kernel(ResStageK a) {
-  static_assert(C == 16 || C == 32, "one M tile, one chunk");
-  constexpr int KB = C / 16;         // k-steps per tap
-  constexpr int CP = C + 8;          // LDS row stride in halves (48 / 80 bytes: odd multiples of 16 B)
-  constexpr int N1 = 128 * NTW;
-  constexpr int TD = 2;              // taps of weight prefetch in flight
-  constexpr int BD = C >= 32 ? 2 : 1;  // k-steps the B fragments (LDS) run ahead of the MFMAs
+  constexpr int WM = 4 / WN;
+  static_assert(C == 16 || WM * MT * 32 == C, "the four MMA waves cover all channels");
+  constexpr int KB = C / 16;         // k-steps per tap (the whole window lives in LDS: no channel chunks)
+  constexpr int CP = C + 8;          // LDS row stride in halves (odd multiples of 16 B)
+  constexpr int N1 = WN * NTW * 32;
+  constexpr int CG = C >= 32 ? 4 : 2;  // 8-channel groups of a 32-row output tile that exist (C = 16: half a tile)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int R = N1 + 2 * a.PAD;
   h16* As = reinterpret_cast<h16*>(lds_raw);
@@ -142,7 +147,8 @@ void resblock_stage_f16_kernel(ResStageK a) {
           const int idx = base + i * 256 + ltid;
           const int idc = idx < ytotal ? idx : ytotal - 1;
           const int row = idc / PPR, pc = idc - row * PPR;
-          const h16x8 o = *reinterpret_cast<const h16x8*>(Os + row * CP + pc * 8);
+          h16x8 o = *reinterpret_cast<const h16x8*>(Os + row * CP + pc * 8);
+          if (a.accumulate) o += *reinterpret_cast<const h16x8*>(yb + (long long)idc * 8);  // the fp16 running sum of the per-unit path
           if (idx < ytotal) *reinterpret_cast<h16x8*>(yb + (long long)idx * 8) = o;
         }
       }
@@ -174,22 +180,26 @@ void resblock_stage_f16_kernel(ResStageK a) {
   }
 
   // ------------------------------ MMA waves ------------------------------
-  const int wn = wave;  // WN = 4, WM = 1
-  const h16x8* wp = reinterpret_cast<const h16x8*>(a.w) + lane;
+  const int wm = wave / WN, wn = wave % WN;
+  const int mt0 = wm * MT;  // first 32-row output tile of this wave
   const int NFT = a.NFT;
+  const h16x8* wp[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) wp[i] = reinterpret_cast<const h16x8*>(a.w) + (size_t)(mt0 + i) * NFT * KB * 64 + lane;
 
-  h16x8 ring[TD][KB];
+  h16x8 ring[TD][KB][MT];
 #pragma unroll
   for (int s = 0; s < TD; ++s)
 #pragma unroll
-    for (int u = 0; u < KB; ++u) ring[s][u] = wp[(size_t)(s * KB + u) * 64];
+    for (int u = 0; u < KB; ++u)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) ring[s][u][i] = wp[i][(size_t)(s * KB + u) * 64];
   int ftn = TD;  // next flat tap to prefetch
 
-  f32x16 acc[NTW];
+  f32x16 acc[MT][NTW];
   // one tap: KB k-steps from ring slot S, refilled with flat tap ftn AFTER the MFMAs that read it (resblock_f16.hip).
-  // The B fragments (LDS) run TWO k-steps ahead of the MFMAs (bf_[0] = this step, bf_[BD] = loaded here): with
-  // four MMA waves bursting 5 ds_read_b128 each, a burst takes ~80 LDS cycles + latency, more than the 160 cycles of one k-step.
-  // (BD = 2 at C = 32; reads past the conv's last tap wrap to its first taps and are discarded).
+  // The B fragments (LDS) run BD k-steps ahead of the MFMAs (bf_[0] = this step, bf_[BD] = loaded here; reads past the conv's
+  // last tap wrap to its first taps and are discarded).
   // FIRST: the conv's first tap -- its first k-step takes the bias vector as the C operand (no accumulator initialisation).
 #define MB_TAPROW(J) (cb_ + (size_t)((J) < ntaps ? (J) : (J) - ntaps) * ts_)
 #define MB_STEPPTR(J, STEP) (MB_TAPROW((J) + (STEP) / KB) + ((STEP) % KB) * 16)
@@ -200,16 +210,17 @@ void resblock_stage_f16_kernel(ResStageK a) {
       const h16* rp_ = MB_STEPPTR(J, u + BD);                                                      \
       _Pragma("unroll") for (int n = 0; n < NTW; ++n)                                              \
         bf_[BD][n] = *reinterpret_cast<const h16x8*>(rp_ + n * 32 * CP);                           \
-      _Pragma("unroll") for (int n = 0; n < NTW; ++n)                                              \
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[S][u], bf_[0][n], (FIRST) && u == 0 ? bv_ : acc[n], 0, 0, 0); \
-      ring[S][u] = wp[(nf_ + u) * 64];                                                             \
-      /* issue order: one LDS read behind every MFMA (a burst of NTW reads from four waves at once backs the LDS queue up */ \
-      /* into the issuing wave), the ring refill behind the last MFMA that reads its registers */   \
-      _Pragma("unroll") for (int n = 0; n < NTW; ++n) {                                            \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i)                                               \
+        _Pragma("unroll") for (int n = 0; n < NTW; ++n)                                            \
+          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[S][u][i], bf_[0][n], (FIRST) && u == 0 ? bv_[i] : acc[i][n], 0, 0, 0); \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i) ring[S][u][i] = wp[i][(nf_ + u) * 64];        \
+      /* issue order: one LDS read behind each of the first NTW MFMAs (a burst of reads from four waves at once backs the LDS */ \
+      /* queue up into the issuing wave), the ring refills behind the last MFMA that reads their registers */ \
+      _Pragma("unroll") for (int m = 0; m < MT * NTW; ++m) {                                       \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                         \
+        if (m < NTW) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
       }                                                                                            \
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                           \
+      __builtin_amdgcn_sched_group_barrier(0x020, MT, 0);                                          \
       __builtin_amdgcn_sched_barrier(0);                                                           \
       _Pragma("unroll") for (int q = 0; q < BD; ++q)                                               \
         _Pragma("unroll") for (int n = 0; n < NTW; ++n) bf_[q][n] = bf_[q + 1][n];                 \
@@ -217,30 +228,37 @@ void resblock_stage_f16_kernel(ResStageK a) {
     ftn = ftn + 1 == NFT ? 0 : ftn + 1;                                                            \
   } while (0)
   // a conv = ntaps taps (odd): the first one from ring slot S0 (0 for conv1, 1 for conv2: every conv has an odd tap count, the
-  // slots alternate), then (ntaps - 1) / 2 pairs.  BIAS: fp32 [C] in LDS.
+  // slots alternate; TD = 1: one slot), then (ntaps - 1) / 2 pairs.  BIAS: fp32 [C] in LDS.
 #define MB_CONV(S0, BASE, TAPSTEP, BIAS)                                                           \
   do {                                                                                             \
     const h16* cb_ = (BASE);                                                                       \
     const size_t ts_ = (size_t)(TAPSTEP);                                                          \
-    f32x16 bv_;  /* accumulator layout: channel 8 g + ch4 + e at element 4 g + e */                \
-    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                \
-      const f32x4 q_ = g < C / 8 ? *reinterpret_cast<const f32x4*>((BIAS) + 8 * g + ch4) : (f32x4)0.f; \
-      bv_[4 * g] = q_[0]; bv_[4 * g + 1] = q_[1]; bv_[4 * g + 2] = q_[2]; bv_[4 * g + 3] = q_[3]; \
-    }                                                                                              \
+    f32x16 bv_[MT];  /* accumulator layout: channel 32 mt + 8 g + ch4 + e at element 4 g + e */    \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                 \
+      _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                              \
+        const f32x4 q_ = g < CG ? *reinterpret_cast<const f32x4*>((BIAS) + (mt0 + i) * 32 + 8 * g + ch4) : (f32x4)0.f; \
+        bv_[i][4 * g] = q_[0]; bv_[i][4 * g + 1] = q_[1]; bv_[i][4 * g + 2] = q_[2]; bv_[i][4 * g + 3] = q_[3]; \
+      }                                                                                            \
     h16x8 bf_[BD + 1][NTW];                                                                        \
     _Pragma("unroll") for (int q = 0; q < BD; ++q)                                                 \
       _Pragma("unroll") for (int n = 0; n < NTW; ++n)                                              \
         bf_[q][n] = *reinterpret_cast<const h16x8*>(MB_STEPPTR(0, q) + n * 32 * CP);               \
-    MB_TAPJ(S0, 0, true);                                                                          \
-    for (int j_ = 1; j_ + 1 < ntaps; j_ += 2) {                                                    \
-      MB_TAPJ(1 - S0, j_, false);                                                                  \
-      MB_TAPJ(S0, j_ + 1, false);                                                                  \
+    if (TD == 1) {                                                                                 \
+      MB_TAPJ(0, 0, true);                                                                         \
+      for (int j_ = 1; j_ < ntaps; ++j_) MB_TAPJ(0, j_, false);                                    \
+    } else {                                                                                       \
+      constexpr int sa_ = (S0) * (TD - 1), sb_ = (1 - (S0)) * (TD - 1);  /* (index 1 only exists for TD = 2) */ \
+      MB_TAPJ(sa_, 0, true);                                                                       \
+      for (int j_ = 1; j_ + 1 < ntaps; j_ += 2) {                                                  \
+        MB_TAPJ(sb_, j_, false);                                                                   \
+        MB_TAPJ(sa_, j_ + 1, false);                                                               \
+      }                                                                                            \
     }                                                                                              \
   } while (0)
 
   const int lrow = wn * (NTW * 32) + (lane & 31);  // this lane's row inside a 32-row group of its wave
   const int lcol = (lane >> 5) * 8;
-  const int ch4 = 4 * (lane >> 5);                 // accumulator layout: channels 8 g + ch4 .. + 3, position = lane & 31
+  const int ch4 = 4 * (lane >> 5);                 // accumulator layout: channels 32 mt + 8 g + ch4 .. + 3, position = lane & 31
   for (int it = 0; it < my_tiles; ++it) {
     const int tile = (int)blockIdx.x + it * (int)gridDim.x;
     const int t0 = (tile % a.tiles_per_item) * a.NB;
@@ -250,12 +268,15 @@ void resblock_stage_f16_kernel(ResStageK a) {
       const int p2 = (ntaps - 1) >> 1;
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): one ring drain per chain keeps the compiler's counts in the tap loops exact
       __syncthreads();  // X: the window is down (raw in H, lrelu in A)
-      h16x4 xres[NTW][C / 8];
+      h16x4 xres[MT][NTW][CG];  // the residual x of this wave's cells (its rows x its channels), for the whole chain
 #pragma unroll
-      for (int n = 0; n < NTW; ++n)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int g = 0; g < C / 8; ++g)
-          xres[n][g] = *reinterpret_cast<const h16x4*>(Hs + (a.PAD + lrow + n * 32) * CP + 8 * g + ch4);
+        for (int n = 0; n < NTW; ++n)
+#pragma unroll
+          for (int g = 0; g < CG; ++g)
+            xres[i][n][g] = *reinterpret_cast<const h16x4*>(Hs + (a.PAD + lrow + n * 32) * CP + (mt0 + i) * 32 + 8 * g + ch4);
+      // (the cells of the four waves -- rows x channels -- are disjoint: reading H here and overwriting it in epilogue 1 needs no barrier)
       // rows of this wave that are positions outside [0, Tb) exist only in the first and last tiles of an item: everywhere else
       // the zero-padding selects of the epilogues are skipped (wave-uniform branch)
       const int tw0 = t0 - a.Hh + wn * (NTW * 32);
@@ -271,32 +292,22 @@ void resblock_stage_f16_kernel(ResStageK a) {
         // ---------------- conv1 (dilation d) on A -> h ----------------
         MB_CONV(0, As + (a.PAD + lrow - p2 * d) * CP + lcol, d * CP, b1);
         MB_SMARK(1);
-        if (interior) {
 #pragma unroll
-          for (int n = 0; n < NTW; ++n)
-#pragma unroll
-            for (int g = 0; g < C / 8; ++g) {
-              const f32x4 v = {acc[n][4 * g], acc[n][4 * g + 1], acc[n][4 * g + 2], acc[n][4 * g + 3]};
-              h16x4 hv = __builtin_convertvector(v, h16x4);
-              hv = __builtin_elementwise_max(hv, hv * slope);
-              *reinterpret_cast<h16x4*>(Hs + (a.PAD + lrow + n * 32) * CP + 8 * g + ch4) = hv;
-            }
-        } else {
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int n = 0; n < NTW; ++n) {
             const int row = lrow + n * 32;
             const int t = t0 - a.Hh + row;
-            const bool inside = t >= 0 && t < Tb;
+            const bool inside = interior || (t >= 0 && t < Tb);
 #pragma unroll
-            for (int g = 0; g < C / 8; ++g) {
-              const f32x4 v = {acc[n][4 * g], acc[n][4 * g + 1], acc[n][4 * g + 2], acc[n][4 * g + 3]};
+            for (int g = 0; g < CG; ++g) {
+              const f32x4 v = {acc[i][n][4 * g], acc[i][n][4 * g + 1], acc[i][n][4 * g + 2], acc[i][n][4 * g + 3]};
               h16x4 hv = __builtin_convertvector(v, h16x4);
               hv = __builtin_elementwise_max(hv, hv * slope);
-              if (!inside) hv = (h16x4)(h16)0.f;  // conv2's zero padding
-              *reinterpret_cast<h16x4*>(Hs + (a.PAD + row) * CP + 8 * g + ch4) = hv;
+              if (!interior && !inside) hv = (h16x4)(h16)0.f;  // conv2's zero padding
+              *reinterpret_cast<h16x4*>(Hs + (a.PAD + row) * CP + (mt0 + i) * 32 + 8 * g + ch4) = hv;
             }
           }
-        }
         MB_SMARK(2);
         __syncthreads();  // E1: h is complete, nobody reads A any more
         MB_SMARK(3);
@@ -305,33 +316,23 @@ void resblock_stage_f16_kernel(ResStageK a) {
         MB_SMARK(4);
         // x <- x + (conv2 + b2): the conv result rounded to fp16, then a packed fp16 add (the two roundings of the per-unit path)
         if (!last) {
-          if (interior) {
 #pragma unroll
-            for (int n = 0; n < NTW; ++n)
-#pragma unroll
-              for (int g = 0; g < C / 8; ++g) {
-                const f32x4 v = {acc[n][4 * g], acc[n][4 * g + 1], acc[n][4 * g + 2], acc[n][4 * g + 3]};
-                const h16x4 xn = __builtin_convertvector(v, h16x4) + xres[n][g];
-                xres[n][g] = xn;
-                *reinterpret_cast<h16x4*>(As + (a.PAD + lrow + n * 32) * CP + 8 * g + ch4) = __builtin_elementwise_max(xn, xn * slope);
-              }
-          } else {
+          for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int n = 0; n < NTW; ++n) {
               const int row = lrow + n * 32;
               const int t = t0 - a.Hh + row;
-              const bool inside = t >= 0 && t < Tb;
+              const bool inside = interior || (t >= 0 && t < Tb);
 #pragma unroll
-              for (int g = 0; g < C / 8; ++g) {
-                const f32x4 v = {acc[n][4 * g], acc[n][4 * g + 1], acc[n][4 * g + 2], acc[n][4 * g + 3]};
-                const h16x4 xn = __builtin_convertvector(v, h16x4) + xres[n][g];
-                xres[n][g] = xn;
+              for (int g = 0; g < CG; ++g) {
+                const f32x4 v = {acc[i][n][4 * g], acc[i][n][4 * g + 1], acc[i][n][4 * g + 2], acc[i][n][4 * g + 3]};
+                const h16x4 xn = __builtin_convertvector(v, h16x4) + xres[i][n][g];
+                xres[i][n][g] = xn;
                 h16x4 av = __builtin_elementwise_max(xn, xn * slope);
-                if (!inside) av = (h16x4)(h16)0.f;  // conv1's zero padding
-                *reinterpret_cast<h16x4*>(As + (a.PAD + row) * CP + 8 * g + ch4) = av;
+                if (!interior && !inside) av = (h16x4)(h16)0.f;  // conv1's zero padding
+                *reinterpret_cast<h16x4*>(As + (a.PAD + row) * CP + (mt0 + i) * 32 + 8 * g + ch4) = av;
               }
             }
-          }
           MB_SMARK(5);
           __syncthreads();  // E2: lrelu(x) of the next unit is complete
           MB_SMARK(6);
@@ -340,7 +341,7 @@ void resblock_stage_f16_kernel(ResStageK a) {
           MB_SMARK(5);
           const h16 osc = (h16)a.out_scale;
           // running sum of the chains' results: every read of O in flight before the first add (one LDS round trip, not twenty)
-          h16x4 prev[NTW][C / 8];
+          h16x4 prev[MT][NTW][CG];
           bool mine[NTW];
 #pragma unroll
           for (int n = 0; n < NTW; ++n) {
@@ -348,20 +349,24 @@ void resblock_stage_f16_kernel(ResStageK a) {
             mine[n] = orow >= 0 && orow < a.NB;
             const int orc = min(max(orow, 0), a.NB - 1);
 #pragma unroll
-            for (int g = 0; g < C / 8; ++g)
-              prev[n][g] = c > 0 ? *reinterpret_cast<const h16x4*>(Os + orc * CP + 8 * g + ch4) : (h16x4)(h16)0.f;
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+              for (int g = 0; g < CG; ++g)
+                prev[i][n][g] = c > 0 ? *reinterpret_cast<const h16x4*>(Os + orc * CP + (mt0 + i) * 32 + 8 * g + ch4) : (h16x4)(h16)0.f;
           }
 #pragma unroll
-          for (int n = 0; n < NTW; ++n) {
-            const int orc = min(max(lrow + n * 32 - a.Hh, 0), a.NB - 1);
+          for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int g = 0; g < C / 8; ++g) {
-              const f32x4 v = {acc[n][4 * g], acc[n][4 * g + 1], acc[n][4 * g + 2], acc[n][4 * g + 3]};
-              const h16x4 xn = __builtin_convertvector(v, h16x4) + xres[n][g];
-              // fp16(x / num_kernels), then the fp16 running sum: the roundings of the per-unit path
-              if (mine[n]) *reinterpret_cast<h16x4*>(Os + orc * CP + 8 * g + ch4) = xn * osc + prev[n][g];
+            for (int n = 0; n < NTW; ++n) {
+              const int orc = min(max(lrow + n * 32 - a.Hh, 0), a.NB - 1);
+#pragma unroll
+              for (int g = 0; g < CG; ++g) {
+                const f32x4 v = {acc[i][n][4 * g], acc[i][n][4 * g + 1], acc[i][n][4 * g + 2], acc[i][n][4 * g + 3]};
+                const h16x4 xn = __builtin_convertvector(v, h16x4) + xres[i][n][g];
+                // fp16(x / num_kernels), then the fp16 running sum: the roundings of the per-unit path
+                if (mine[n]) *reinterpret_cast<h16x4*>(Os + orc * CP + (mt0 + i) * 32 + 8 * g + ch4) = xn * osc + prev[i][n][g];
+              }
             }
-          }
           MB_SMARK(6);
         }
       }
@@ -376,9 +381,9 @@ void resblock_stage_f16_kernel(ResStageK a) {
 
 struct StageGeom { int Hh, PAD, NB, NFT; size_t lds; };
 
-template <int C, int NTW>
+template <int C, int N1>
 static bool stage_geom(int nk, const int* ksizes, int nd, const int* dil /*[nk][nd]*/, StageGeom* g) {
-  const int N1 = 128 * NTW, CP = C + 8;
+  const int CP = C + 8;
   int Hh = 0, PAD = 0, NFT = 0;
   for (int c = 0; c < nk; ++c) {
     const int p2 = (ksizes[c] - 1) / 2;
@@ -393,14 +398,14 @@ static bool stage_geom(int nk, const int* ksizes, int nd, const int* dil /*[nk][
   return g->lds <= 160 * 1024;
 }
 
-template <int C, int NTW>
+template <int C, int MT, int WN, int NTW, int TD, int BD>
 static int launch_stage(ResStageK k, const StageGeom& g, int batch, hipStream_t s) {
   k.Hh = g.Hh; k.PAD = g.PAD; k.NB = g.NB; k.NFT = g.NFT;
   k.tiles_per_item = cdiv(k.T, k.NB);
   k.n_tiles = k.tiles_per_item * batch;
   static bool attr_done = false;
   if (!attr_done) {
-    MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_stage_f16_kernel<C, NTW>),
+    MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_stage_f16_kernel<C, MT, WN, NTW, TD, BD>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
@@ -421,7 +426,7 @@ static int launch_stage(ResStageK k, const StageGeom& g, int batch, hipStream_t 
     k.trace = d_trace;
   }
 #endif
-  hipLaunchKernelGGL((resblock_stage_f16_kernel<C, NTW>), dim3(std::min(k.n_tiles, n_cu)), dim3(512), g.lds, s, k);
+  hipLaunchKernelGGL((resblock_stage_f16_kernel<C, MT, WN, NTW, TD, BD>), dim3(std::min(k.n_tiles, n_cu)), dim3(512), g.lds, s, k);
   MB_HIP(hipGetLastError());
 #ifdef MB_STAGE_TRACE_BUILD
   if (trace_path) {  // diagnostics: "C NTW chains units tiles : marks[chain][unit][8]" per launch
@@ -440,7 +445,8 @@ static int launch_stage(ResStageK k, const StageGeom& g, int batch, hipStream_t 
 }
 
 static bool stage_shape_ok(int channels, int nk, const int* ksizes, int nd, const int* dil) {
-  if (!(channels == 16 || channels == 32) || nk < 1 || nk > STAGE_MAX_CHAINS || nd < 1 || nd > STAGE_MAX_UNITS || !ksizes || !dil)
+  if (!(channels == 16 || channels == 32 || channels == 64 || channels == 128) || nk < 1 || nk > STAGE_MAX_CHAINS || nd < 1 ||
+      nd > STAGE_MAX_UNITS || !ksizes || !dil)
     return false;
   for (int c = 0; c < nk; ++c) {
     if (ksizes[c] < 3 || (ksizes[c] & 1) == 0) return false;
@@ -448,6 +454,16 @@ static bool stage_shape_ok(int channels, int nk, const int* ksizes, int nd, cons
       if (dil[c * nd + u] < 1) return false;
   }
   return true;
+}
+
+// the instance of a channel count: window rows N1 (LDS holds two windows + the result rows)
+static bool stage_geom_c(int channels, int nk, const int* ksizes, int nd, const int* dil, StageGeom* g) {
+  switch (channels) {
+    case 16: return stage_geom<16, 768>(nk, ksizes, nd, dil, g);
+    case 32: return stage_geom<32, 640>(nk, ksizes, nd, dil, g);
+    case 64: return stage_geom<64, 256>(nk, ksizes, nd, dil, g);
+    default: return stage_geom<128, 128>(nk, ksizes, nd, dil, g);
+  }
 }
 
 }  // namespace mb
@@ -458,41 +474,50 @@ extern "C" int mb_resblock_stage_f16_supported(int channels, int num_kernels, co
                                                const int* dilations) {
   if (!stage_shape_ok(channels, num_kernels, ksizes, num_dilations, dilations)) return 0;
   StageGeom g;
-  return channels == 32 ? stage_geom<32, 5>(num_kernels, ksizes, num_dilations, dilations, &g)
-                        : stage_geom<16, 6>(num_kernels, ksizes, num_dilations, dilations, &g);
+  return stage_geom_c(channels, num_kernels, ksizes, num_dilations, dilations, &g) ? 1 : 0;
+}
+
+// useful rows of a tile / window rows of the instance (0 = unsupported): what a caller weighs against the per-unit launches
+extern "C" float mb_resblock_stage_f16_efficiency(int channels, int num_kernels, const int* ksizes, int num_dilations,
+                                                  const int* dilations) {
+  if (!stage_shape_ok(channels, num_kernels, ksizes, num_dilations, dilations)) return 0.f;
+  StageGeom g;
+  if (!stage_geom_c(channels, num_kernels, ksizes, num_dilations, dilations, &g)) return 0.f;
+  return (float)g.NB / (float)(g.NB + 2 * g.Hh);
 }
 
 extern "C" size_t mb_resblock_stage_f16_packed_halves(int channels, int num_kernels, const int* ksizes, int num_dilations) {
-  if (!(channels == 16 || channels == 32) || !ksizes || num_kernels < 1 || num_dilations < 1) return 0;
+  if (!(channels == 16 || channels == 32 || channels == 64 || channels == 128) || !ksizes || num_kernels < 1 || num_dilations < 1) return 0;
   size_t taps = 0;
   for (int c = 0; c < num_kernels; ++c) taps += (size_t)2 * num_dilations * ksizes[c];
-  return taps * (channels / 16) * 512;  // one 32-row output tile: 512 halves per (tap, k-step) fragment
+  return (size_t)((channels + 31) / 32) * taps * (channels / 16) * 512;  // per 32-row output tile: 512 halves per (tap, k-step) fragment
 }
 
 // h_w1[c * nd + u], h_w2[c * nd + u]: fp32 torch Conv1d weights [C][C][k_c] (weight norm folded) of chain c, unit u.
 extern "C" int mb_resblock_stage_f16_pack(const float* const* h_w1, const float* const* h_w2, int channels, int num_kernels,
                                           const int* ksizes, int num_dilations, uint16_t* h_packed) {
   MB_REQUIRE(h_w1 && h_w2 && h_packed && ksizes, "resblock_stage_f16_pack: null pointer");
-  MB_REQUIRE(channels == 16 || channels == 32, "resblock_stage_f16_pack: C=%d unsupported", channels);
-  const int C = channels, KB = C / 16;
+  MB_REQUIRE(channels == 16 || channels == 32 || channels == 64 || channels == 128, "resblock_stage_f16_pack: C=%d unsupported", channels);
+  const int C = channels, KB = C / 16, MTT = (C + 31) / 32;
   h16* out = reinterpret_cast<h16*>(h_packed);
   size_t o = 0;
-  for (int c = 0; c < num_kernels; ++c)
-    for (int u = 0; u < num_dilations; ++u)
-      for (int ph = 0; ph < 2; ++ph) {
-        const float* w = ph ? h_w2[c * num_dilations + u] : h_w1[c * num_dilations + u];
-        MB_REQUIRE(w, "resblock_stage_f16_pack: null weight (chain %d unit %d)", c, u);
-        const int k = ksizes[c];
-        for (int j = 0; j < k; ++j)
-          for (int kb = 0; kb < KB; ++kb)
-            for (int lane = 0; lane < 64; ++lane)
-              for (int e = 0; e < 8; ++e) {
-                // A fragment of v_mfma_f32_32x32x16_f16: lane l holds A[m = l&31][k = 8*(l>>5) + e]
-                const int co = lane & 31;
-                const int ci = kb * 16 + (lane >> 5) * 8 + e;
-                out[o++] = co < C ? (h16)w[((size_t)co * C + ci) * k + j] : (h16)0.f;
-              }
-      }
+  for (int mt = 0; mt < MTT; ++mt)  // one stream per 32-row output tile, each in consumption order
+    for (int c = 0; c < num_kernels; ++c)
+      for (int u = 0; u < num_dilations; ++u)
+        for (int ph = 0; ph < 2; ++ph) {
+          const float* w = ph ? h_w2[c * num_dilations + u] : h_w1[c * num_dilations + u];
+          MB_REQUIRE(w, "resblock_stage_f16_pack: null weight (chain %d unit %d)", c, u);
+          const int k = ksizes[c];
+          for (int j = 0; j < k; ++j)
+            for (int kb = 0; kb < KB; ++kb)
+              for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                  // A fragment of v_mfma_f32_32x32x16_f16: lane l holds A[m = l&31][k = 8*(l>>5) + e]
+                  const int co = mt * 32 + (lane & 31);
+                  const int ci = kb * 16 + (lane >> 5) * 8 + e;
+                  out[o++] = co < C ? (h16)w[((size_t)co * C + ci) * k + j] : (h16)0.f;
+                }
+        }
   return MB_OK;
 }
 
@@ -520,12 +545,14 @@ extern "C" int mb_resblock_stage_f16(const mb_resblock_stage_f16_args* a, mb_str
   }
   k.slope = a->slope; k.out_scale = a->out_scale == 0.f ? 1.f / (float)a->num_kernels : a->out_scale;
   k.valid = a->d_valid; k.valid_mul = a->valid_mul > 0 ? a->valid_mul : 1;
+  k.accumulate = a->accumulate;
   StageGeom g;
   hipStream_t s = (hipStream_t)stream;
-  if (a->channels == 32) {
-    MB_REQUIRE((stage_geom<32, 5>(a->num_kernels, a->ksize, a->num_dilations, dil, &g)), "resblock_stage_f16: the tile does not fit LDS");
-    return launch_stage<32, 5>(k, g, a->batch, s);
+  MB_REQUIRE(stage_geom_c(a->channels, a->num_kernels, a->ksize, a->num_dilations, dil, &g), "resblock_stage_f16: the tile does not fit LDS");
+  switch (a->channels) {
+    case 16: return launch_stage<16, 1, 4, 6, 2, 1>(k, g, a->batch, s);
+    case 32: return launch_stage<32, 1, 4, 5, 2, 2>(k, g, a->batch, s);
+    case 64: return launch_stage<64, 2, 4, 2, 2, 2>(k, g, a->batch, s);
+    default: return launch_stage<128, 2, 2, 2, 1, 1>(k, g, a->batch, s);
   }
-  MB_REQUIRE((stage_geom<16, 6>(a->num_kernels, a->ksize, a->num_dilations, dil, &g)), "resblock_stage_f16: the tile does not fit LDS");
-  return launch_stage<16, 6>(k, g, a->batch, s);
 }

@@ -162,7 +162,7 @@ def resblock_pair_f16_hip(x, w1, b1, w2, b2, *, dilation=1, slope=0.1, out_scale
     return y.float().transpose(1, 2).contiguous().cpu()
 
 
-def resblock_stage_f16_hip(x, chains, *, slope=0.1, out_scale=0.0, valid=None, valid_mul=1, device="cuda"):
+def resblock_stage_f16_hip(x, chains, *, slope=0.1, out_scale=0.0, valid=None, valid_mul=1, accumulate_into=None, device="cuda"):
     """One stage's ResBlock group in one launch (mb_resblock_stage_f16).  x: [B, C, T] float; chains: list (one per ResBlock)
     of lists (one per unit) of (w1, b1, w2, b2, dilation); returns [B, C, T] float32 (rows beyond `valid` are left NaN)."""
     L = _lib.lib()
@@ -185,8 +185,14 @@ def resblock_stage_f16_hip(x, chains, *, slope=0.1, out_scale=0.0, valid=None, v
     B, _, T = xt.shape
     xh = torch.empty(B, T, Cc, dtype=torch.float16, device=dev)
     _lib.check(L.mb_f32_to_f16_tm(xt.data_ptr(), xh.data_ptr(), B, Cc, T, _lib.stream_ptr()), "mb_f32_to_f16_tm")
-    y = torch.full((B, T, Cc), float("nan"), dtype=torch.float16, device=dev)
+    if accumulate_into is not None:
+        at = accumulate_into.float().contiguous().to(dev)
+        y = torch.empty(B, T, Cc, dtype=torch.float16, device=dev)
+        _lib.check(L.mb_f32_to_f16_tm(at.data_ptr(), y.data_ptr(), B, Cc, T, _lib.stream_ptr()), "mb_f32_to_f16_tm")
+    else:
+        y = torch.full((B, T, Cc), float("nan"), dtype=torch.float16, device=dev)
     a = _lib.ResStageF16Args()
+    a.accumulate = int(accumulate_into is not None)
     a.d_x, a.d_y, a.d_wpacked, a.d_bias = xh.data_ptr(), y.data_ptr(), pw.data_ptr(), bias.data_ptr()
     a.batch, a.channels, a.t, a.num_kernels, a.num_dilations = B, Cc, T, nk, nd
     for j, ch in enumerate(chains):

@@ -171,7 +171,11 @@ def test_resblock_stage_weight_stream_layout(lib):
     d1357 = (C_.c_int * 12)(*([1, 3, 5, 7] * 3))
     assert L.mb_resblock_stage_f16_supported(32, 3, k3, 3, d135) == 1 and L.mb_resblock_stage_f16_supported(32, 3, k3, 4, d1357) == 1
     assert L.mb_resblock_stage_f16_supported(16, 3, k3, 4, d1357) == 1
-    assert L.mb_resblock_stage_f16_supported(64, 3, k3, 3, d135) == 0   # wider stages: one launch per unit (mb_resblock_pair_f16)
+    assert L.mb_resblock_stage_f16_supported(64, 3, k3, 3, d135) == 1 and L.mb_resblock_stage_f16_supported(128, 3, k3, 3, d135) == 0
+    k1 = (C_.c_int * 1)(3)
+    d1 = (C_.c_int * 3)(1, 3, 5)
+    assert L.mb_resblock_stage_f16_supported(128, 1, k1, 3, d1) == 1 and abs(L.mb_resblock_stage_f16_efficiency(128, 1, k1, 3, d1) - 104 / 128) < 1e-6
+    assert L.mb_resblock_stage_f16_supported(48, 1, k1, 3, d1) == 0
     k4 = (C_.c_int * 3)(3, 4, 11)
     assert L.mb_resblock_stage_f16_supported(32, 3, k4, 3, d135) == 0   # even kernel sizes have no "same" padding
     big = (C_.c_int * 9)(*([1, 9, 27] * 3))

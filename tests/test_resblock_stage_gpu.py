@@ -66,6 +66,9 @@ CASES = [
     (1, 16, 77, (3, 7, 11), ((1, 3, 5),) * 3),
     (1, 32, 700, (7,), ((1, 2),)),
     (1, 32, 900, (5, 3), ((2, 1, 1), (1, 1, 4))),
+    # the wider stages' single ResBlocks (two 32-row output tiles per wave; at 128 channels two waves along the channels)
+    (2, 64, 1000, (3,), ((1, 3, 5),)), (1, 64, 700, (7,), ((1, 3, 5),)), (1, 64, 200, (3,), ((1, 3, 5, 7),)),
+    (2, 128, 500, (3,), ((1, 3, 5),)), (1, 128, 90, (3,), ((1, 3, 5),)),
 ]
 
 
@@ -120,8 +123,24 @@ def test_resblock_stage_equals_unit_launches(cuda, lib):
     assert int((dlt > tol).sum()) == 0, float(dlt.max())
 
 
+def test_resblock_stage_accumulates_into_the_stage_output(cuda, lib):
+    """A wider stage runs one launch per ResBlock: y = y + ResBlock_j(x) / num_kernels (models.py:141-145)."""
+    B, C, T = 2, 64, 900
+    x = _rand(B, C, T, seed=4)
+    chains = _make(C, (7,), ((1, 3, 5),), seed=13)
+    acc = _rand(B, C, T, seed=5)
+    y = hiputil.resblock_stage_f16_hip(x, chains, slope=0.1, out_scale=1.0 / 3.0, accumulate_into=acc)
+    ref = _h(_h(acc) + _h(_ref(x, chains, 0.1) * 1.0 / 3.0 * 1.0))  # _ref divides by len(chains) = 1: scale 1/3 here
+    dlt = (y.double() - ref.double()).abs()
+    tol = 2e-3 + 2.0 ** -8 * ref.double().abs().clamp(min=1.0)
+    assert int(torch.isnan(y).sum()) == 0 and int((dlt > tol).sum()) == 0, float(dlt.max())
+
+
 def test_resblock_stage_rejects_bad_shapes(cuda, lib):
     from mockingbird_amd._lib import MbHipError
-    x = _rand(1, 64, 100, seed=1)
+    x = _rand(1, 48, 100, seed=1)
     with pytest.raises(MbHipError, match="unsupported"):
-        hiputil.resblock_stage_f16_hip(x, _make(64, (3,), ((1,),)))
+        hiputil.resblock_stage_f16_hip(x, _make(48, (3,), ((1,),)))
+    x = _rand(1, 128, 300, seed=1)
+    with pytest.raises(MbHipError, match="unsupported"):  # the reach of k = 11 leaves no rows in a 128-row window
+        hiputil.resblock_stage_f16_hip(x, _make(128, (11,), ((1, 3, 5),)))
