@@ -29,6 +29,7 @@
 // work ahead), which runs seamlessly across chunk, phase and tile boundaries.  k is odd, so the ring
 // slot of a chunk's first tap alternates 0,1,0,1,...: the chunk body exists in two statically
 // scheduled variants (the compiler's s_waitcnt placement stays exact, no dynamic ring indexing).
+#include <type_traits>
 #include "common.h"
 
 namespace mb {
@@ -384,24 +385,29 @@ void resblock_pair_f16_kernel(ResPairK a) {
       const h16 hslope = (h16)a.slope;
       const int tw0 = t0 - p2 + wn * (NTW * 32);
       const bool interior = tw0 >= 0 && tw0 + NTW * 32 <= Tb;  // wave-uniform
+      auto epi1 = [&](auto INTERIOR) {  // two instances: a merged one keeps the selects (the compiler folds the predicate in)
+        constexpr bool interior_ = decltype(INTERIOR)::value;
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int n = 0; n < NTW; ++n) {
-          const int row = lrow + n * 32;
-          const int th = t0 - p2 + row;
-          const bool inside = interior || (th >= 0 && th < Tb);
+          for (int n = 0; n < NTW; ++n) {
+            const int row = lrow + n * 32;
+            const int th = t0 - p2 + row;
+            const bool inside = th >= 0 && th < Tb;
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int co0 = (mt0 + i) * 32 + 8 * g + 4 * (lane >> 5);
-            if (co0 >= C) continue;  // only C = 16: rows 16..31 of the tile are padding
-            const f32x4 v = {acc[i][n][4 * g], acc[i][n][4 * g + 1], acc[i][n][4 * g + 2], acc[i][n][4 * g + 3]};
-            h16x4 hv = __builtin_convertvector(v, h16x4);
-            hv = __builtin_elementwise_max(hv, hv * hslope);  // leaky_relu in fp16, as the unfused path applies it
-            if (!interior && !inside) hv = (h16x4)(h16)0.f;
-            *reinterpret_cast<h16x4*>(hs + row * CP + co0) = hv;
+            for (int g = 0; g < 4; ++g) {
+              const int co0 = (mt0 + i) * 32 + 8 * g + 4 * (lane >> 5);
+              if (co0 >= C) continue;  // only C = 16: rows 16..31 of the tile are padding
+              const f32x4 v = {acc[i][n][4 * g], acc[i][n][4 * g + 1], acc[i][n][4 * g + 2], acc[i][n][4 * g + 3]};
+              h16x4 hv = __builtin_convertvector(v, h16x4);
+              hv = __builtin_elementwise_max(hv, hv * hslope);  // leaky_relu in fp16, as the unfused path applies it
+              if (!interior_ && !inside) hv = (h16x4)(h16)0.f;
+              *reinterpret_cast<h16x4*>(hs + row * CP + co0) = hv;
+            }
           }
-        }
+      };
+      if (interior) epi1(std::true_type{});
+      else epi1(std::false_type{});
     }
     MB_PMARK(0, it, 4);
     __syncthreads();  // E1

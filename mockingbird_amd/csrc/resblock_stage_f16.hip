@@ -28,6 +28,7 @@
 // ([chain][unit][conv][tap][k-step], packed on the host), which runs seamlessly across conv, unit, chain and tile boundaries.
 // Waves 4-7 (support) own all HBM traffic: they hold the tile's window in registers and lay it down at every chain start
 // (raw -> H, lrelu -> A), fetch the next tile's window during the first chain, and write the previous tile's O out.
+#include <type_traits>
 #include "common.h"
 
 namespace mb {
@@ -292,22 +293,27 @@ void resblock_stage_f16_kernel(ResStageK a) {
         // ---------------- conv1 (dilation d) on A -> h ----------------
         MB_CONV(0, As + (a.PAD + lrow - p2 * d) * CP + lcol, d * CP, b1);
         MB_SMARK(1);
+        auto epi1 = [&](auto INTERIOR) {  // two instances: interior waves carry no zero-padding selects at all
+          constexpr bool interior_ = decltype(INTERIOR)::value;
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+          for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int n = 0; n < NTW; ++n) {
-            const int row = lrow + n * 32;
-            const int t = t0 - a.Hh + row;
-            const bool inside = interior || (t >= 0 && t < Tb);
+            for (int n = 0; n < NTW; ++n) {
+              const int row = lrow + n * 32;
+              const int t = t0 - a.Hh + row;
+              const bool inside = t >= 0 && t < Tb;
 #pragma unroll
-            for (int g = 0; g < CG; ++g) {
-              const f32x4 v = {acc[i][n][4 * g], acc[i][n][4 * g + 1], acc[i][n][4 * g + 2], acc[i][n][4 * g + 3]};
-              h16x4 hv = __builtin_convertvector(v, h16x4);
-              hv = __builtin_elementwise_max(hv, hv * slope);
-              if (!interior && !inside) hv = (h16x4)(h16)0.f;  // conv2's zero padding
-              *reinterpret_cast<h16x4*>(Hs + (a.PAD + row) * CP + (mt0 + i) * 32 + 8 * g + ch4) = hv;
+              for (int g = 0; g < CG; ++g) {
+                const f32x4 v = {acc[i][n][4 * g], acc[i][n][4 * g + 1], acc[i][n][4 * g + 2], acc[i][n][4 * g + 3]};
+                h16x4 hv = __builtin_convertvector(v, h16x4);
+                hv = __builtin_elementwise_max(hv, hv * slope);
+                if (!interior_ && !inside) hv = (h16x4)(h16)0.f;  // conv2's zero padding
+                *reinterpret_cast<h16x4*>(Hs + (a.PAD + row) * CP + (mt0 + i) * 32 + 8 * g + ch4) = hv;
+              }
             }
-          }
+        };
+        if (interior) epi1(std::true_type{});
+        else epi1(std::false_type{});
         MB_SMARK(2);
         __syncthreads();  // E1: h is complete, nobody reads A any more
         MB_SMARK(3);
@@ -316,23 +322,28 @@ void resblock_stage_f16_kernel(ResStageK a) {
         MB_SMARK(4);
         // x <- x + (conv2 + b2): the conv result rounded to fp16, then a packed fp16 add (the two roundings of the per-unit path)
         if (!last) {
+          auto epi2 = [&](auto INTERIOR) {
+            constexpr bool interior_ = decltype(INTERIOR)::value;
 #pragma unroll
-          for (int i = 0; i < MT; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int n = 0; n < NTW; ++n) {
-              const int row = lrow + n * 32;
-              const int t = t0 - a.Hh + row;
-              const bool inside = interior || (t >= 0 && t < Tb);
+              for (int n = 0; n < NTW; ++n) {
+                const int row = lrow + n * 32;
+                const int t = t0 - a.Hh + row;
+                const bool inside = t >= 0 && t < Tb;
 #pragma unroll
-              for (int g = 0; g < CG; ++g) {
-                const f32x4 v = {acc[i][n][4 * g], acc[i][n][4 * g + 1], acc[i][n][4 * g + 2], acc[i][n][4 * g + 3]};
-                const h16x4 xn = __builtin_convertvector(v, h16x4) + xres[i][n][g];
-                xres[i][n][g] = xn;
-                h16x4 av = __builtin_elementwise_max(xn, xn * slope);
-                if (!interior && !inside) av = (h16x4)(h16)0.f;  // conv1's zero padding
-                *reinterpret_cast<h16x4*>(As + (a.PAD + row) * CP + (mt0 + i) * 32 + 8 * g + ch4) = av;
+                for (int g = 0; g < CG; ++g) {
+                  const f32x4 v = {acc[i][n][4 * g], acc[i][n][4 * g + 1], acc[i][n][4 * g + 2], acc[i][n][4 * g + 3]};
+                  const h16x4 xn = __builtin_convertvector(v, h16x4) + xres[i][n][g];
+                  xres[i][n][g] = xn;
+                  h16x4 av = __builtin_elementwise_max(xn, xn * slope);
+                  if (!interior_ && !inside) av = (h16x4)(h16)0.f;  // conv1's zero padding
+                  *reinterpret_cast<h16x4*>(As + (a.PAD + row) * CP + (mt0 + i) * 32 + 8 * g + ch4) = av;
+                }
               }
-            }
+          };
+          if (interior) epi2(std::true_type{});
+          else epi2(std::false_type{});
           MB_SMARK(5);
           __syncthreads();  // E2: lrelu(x) of the next unit is complete
           MB_SMARK(6);
