@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-ppg2mel", action="store_true")
     ap.add_argument("--no-wavernn-batch", action="store_true")
     ap.add_argument("--no-wavernn-unbatched", action="store_true")
+    ap.add_argument("--no-wavernn-mol", action="store_true",
+                    help="skip the MOL object (the rocprofv3 pass behind frac_rocprof: its launches share the headline's kernel name)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the configs[3] / configs[4] sharded objects")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -642,8 +644,8 @@ def main():
                          if model.last_loop_launches == 1 else "5-launch chain, hipGraph replays"),
             }
             del su, wu
-        # ---- secondary: MOL mode (hparams voc_mode = 'MOL': 30 fc3 outputs, mixture-of-logistics sampler) on the production chain
-        if not args.no_wavernn_unbatched:
+        # ---- secondary: MOL mode (hparams voc_mode = 'MOL': 30 fc3 outputs, mixture-of-logistics sampler) on the production path
+        if not args.no_wavernn_unbatched and not args.no_wavernn_mol:
             import types
             from mockingbird_amd.vocoder.wavernn import hparams as whp
             hpm = types.SimpleNamespace(**{k_: getattr(whp, k_) for k_ in dir(whp) if not k_.startswith("_")})

@@ -10,6 +10,7 @@ timeout 900 python bench.py > gpurun_out/bench_f.log 2>&1; echo "bench rc=$?"
 tail -c 600 gpurun_out/bench_f.log
 if [ "${1:-}" = "prof" ]; then
 rm -rf gpurun_out/prof_bench_f
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench_f -o b -- python bench.py > gpurun_out/prof_bench_f.log 2>&1; echo "prof rc=$?"
+# (without the MOL object: its launches carry the headline kernel's name, the per-kernel average would mix the two)
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench_f -o b -- python bench.py --no-wavernn-mol > gpurun_out/prof_bench_f.log 2>&1; echo "prof rc=$?"
 find gpurun_out/prof_bench_f -type f ! -name '*kernel_stats*' -delete
 fi
