@@ -8,6 +8,6 @@ for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" "SQ_INSTS_VALU_MFMA_MOPS
   rm -rf gpurun_out/pmc_gan_tmp
   timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d gpurun_out/pmc_gan_tmp -o p -- python tools/gan_run.py hifigan f16 32 200 3 > gpurun_out/pmc_gan.log 2>&1
   echo "$tag rc=$?"
-  python tools/pmc_summary.py gpurun_out/pmc_gan_tmp gpurun_out/pmc_gan_$tag.json | grep -E "resblock_pair|conv1d_f16" | head -12
+  python tools/pmc_summary.py gpurun_out/pmc_gan_tmp gpurun_out/pmc_gan_$tag.json | grep -E "resblock_pair|resblock_stage|conv1d_f16" | head -12
 done
 rm -rf gpurun_out/pmc_gan_tmp
