@@ -336,7 +336,8 @@ def gan_floor_bytes(h, batch, frames):
     """Read-x + write-y floor of one fp16 generator forward AS LAUNCHED (every launch reads its input and writes its output
     once, 2 B per element): conv_pre, per stage the upsampler and either num_kernels x len(dilations) fused pair units (the mean
     over the parallel ResBlocks adds a read of the accumulator for all but the first) or, for the narrow stages (<= 32 channels),
-    ONE launch for the whole ResBlock group (resblock_stage_f16.hip: one read, one write), conv_post."""
+    ONE launch for the whole ResBlock group (resblock_stage_f16.hip: one read, one write); at 64 / 128 channels the k = 3 ResBlocks
+    of HiFi-GAN are one launch each; conv_post."""
     B, T, C = batch, frames, h["upsample_initial_channel"]
     b = B * T * (h["num_mels"] + C) * 2.0
     nk, nd = len(h["resblock_kernel_sizes"]), len(h["resblock_dilation_sizes"][0])
@@ -347,7 +348,10 @@ def gan_floor_bytes(h, batch, frames):
         if C <= 32:
             b += 2 * B * T * C * 2.0
         else:
-            b += nk * nd * 2 * B * T * C * 2.0 + (nk - 1) * B * T * C * 2.0
+            for j, ks in enumerate(h["resblock_kernel_sizes"]):
+                # 64 / 128 channels: a ResBlock with k = 3 is one launch (gan.hip: mb_resblock_stage_f16_efficiency >= 0.75), the others one per unit
+                chain = C in (64, 128) and ks == 3 and nd <= 3
+                b += (2 if chain else nd * 2) * B * T * C * 2.0 + (B * T * C * 2.0 if j > 0 else 0.0)
     return b + B * T * C * 2.0 + B * T * 4.0
 
 
