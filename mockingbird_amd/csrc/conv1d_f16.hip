@@ -235,6 +235,104 @@ __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void conv1d_f16_kernel(ConvHK
   }
 }
 
+// ConvTranspose1d upsamplers (ksize = taps x stride) as ONE workgroup per (NQ input positions, batch item): the x window with
+// ALL input channels is staged once (the general kernel above runs one workgroup per polyphase and re-stages the window per
+// 32- / 64-channel chunk), the `up` polyphase outputs of the tile are computed back to back -- each of the 8 waves owns one
+// 32 x 32 (output channels x positions) tile per phase -- and staged in LDS in OUTPUT order, so that the tile leaves as whole
+// rows (the general kernel's 8-byte stores land `up` rows apart: partial lines, written by `up` different workgroups).
+// A wave's A fragments (its output-channel tile, all phases: one contiguous walk through the packed image per phase) come
+// through an EIGHT-deep register ring, refilled behind the MFMA that read the slot: with the one-step prefetch of the general
+// kernel every k-step waited an L2 round trip for 32 cycles of MFMA work (a first version of this kernel: 18 us per tile).
+__global__ __launch_bounds__(512) void convt_f16_kernel(ConvHK a, const int n_mt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NQ = 32 * (8 / n_mt);
+  const int b = blockIdx.y, q0 = blockIdx.x * NQ;
+  const int t_lim = a.valid ? min(a.t_in, a.valid[b] * a.valid_mul) : a.t_in;  // ragged batch: this item's input rows
+  const int t_out_b = a.valid ? min(a.t_out, t_lim * a.up) : a.t_out;
+  if (q0 * a.up >= t_out_b) return;
+  const int cinp = a.c_in + 8, coutp = a.c_out + 8;
+  const int rowlen = NQ + a.span;
+  h16* xs = reinterpret_cast<h16*>(lds_raw);  // [rowlen][c_in + 8]
+  h16* os = xs + rowlen * cinp;               // [NQ * up][c_out + 8]
+  const int mt = wave % n_mt, nt = wave / n_mt;
+  const int nst = a.ntaps * a.n_cb;           // k-steps per phase (a multiple of 8: checked on the host)
+  const h16x8* wbase = reinterpret_cast<const h16x8*>(a.w) + lane;
+  // the wave's fragments in consumption order: nst contiguous ones per phase, phases n_mt * nst apart; the walk stops at the
+  // last fragment (re-reads, discarded)
+  const h16x8* wnext = wbase + (size_t)mt * nst * 64;
+  int pf_left = nst, pf_phases = a.up - 1;
+  auto next_frag = [&]() {
+    const h16x8 v = *wnext;
+    if (--pf_left > 0) wnext += 64;
+    else if (pf_phases > 0) { --pf_phases; pf_left = nst; wnext += (size_t)((n_mt - 1) * nst + 1) * 64; }
+    else pf_left = 1;
+    return v;
+  };
+  h16x8 ring[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) ring[r] = next_frag();  // in flight under the window fill
+  const h16* xb = a.x + (long long)b * a.x_bstride;
+  {  // the window, input activation applied
+    const int ppr = a.c_in >> 3;
+    const h16 slope = (h16)a.in_slope;
+    for (int idx = tid; idx < rowlen * ppr; idx += 512) {
+      const int row = idx / ppr, pc = idx - row * ppr;
+      const int ti = q0 + a.min_off + row;
+      h16x8 v = (h16x8)(h16)0.f;
+      if (ti >= 0 && ti < t_lim) {
+        v = *reinterpret_cast<const h16x8*>(xb + (long long)ti * a.c_in + pc * 8);
+        if (a.in_act == 1) v = lrelu8(v, slope);
+      }
+      *reinterpret_cast<h16x8*>(xs + row * cinp + pc * 8) = v;
+    }
+  }
+  __syncthreads();
+  const int qrow = nt * 32 + (lane & 31);
+  for (int p = 0; p < a.up; ++p) {
+    const h16* lb = xs + (qrow + a.off0[p] - a.min_off) * cinp + (lane >> 5) * 8;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    int j = 0, cb = 0;
+    h16x8 bf = *reinterpret_cast<const h16x8*>(lb);  // the B fragment runs one k-step ahead of its MFMA
+    for (int st = 0; st < nst; st += 8) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        if (++cb == a.n_cb) { cb = 0; ++j; }
+        const int jn = j < a.ntaps ? j : 0;  // (past the phase's last step: any valid row, discarded)
+        const h16x8 bn = *reinterpret_cast<const h16x8*>(lb + jn * a.step * cinp + cb * 16);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[r], bf, acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        ring[r] = next_frag();
+        bf = bn;
+      }
+    }
+    // D fragment: col = lane & 31 (position), rows 8 g + 4 (lane >> 5) + e (channel): + bias -> fp16 -> output order in LDS
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int co0 = mt * 32 + 8 * g + 4 * (lane >> 5);
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.bias) bv = *reinterpret_cast<const float4*>(a.bias + co0);
+      h16x4 hv;
+      hv[0] = (h16)(acc[4 * g] + bv.x); hv[1] = (h16)(acc[4 * g + 1] + bv.y);
+      hv[2] = (h16)(acc[4 * g + 2] + bv.z); hv[3] = (h16)(acc[4 * g + 3] + bv.w);
+      *reinterpret_cast<h16x4*>(os + (qrow * a.up + p) * coutp + co0) = hv;
+    }
+  }
+  __syncthreads();
+  {  // the tile's rows, whole 16-byte pieces, consecutive lanes -> consecutive bytes of y
+    const int ppr = a.c_out >> 3;
+    const int rows = min(NQ * a.up, t_out_b - q0 * a.up);
+    h16* yb = reinterpret_cast<h16*>(a.y) + (long long)b * a.y_bstride + (long long)q0 * a.up * a.c_out;
+    for (int idx = tid; idx < rows * ppr; idx += 512) {
+      const int row = idx / ppr, pc = idx - row * ppr;
+      *reinterpret_cast<h16x8*>(yb + (long long)idx * 8) = *reinterpret_cast<const h16x8*>(os + row * coutp + pc * 8);
+    }
+  }
+}
+
 // [B][C][T] fp32 (the reference's layout) -> [B][T][C] fp16, 32x32 tiles through LDS so both
 // sides are coalesced.
 __global__ __launch_bounds__(256) void cm_f32_to_tm_f16_kernel(const float* __restrict__ x,
@@ -369,6 +467,23 @@ extern "C" int mb_conv1d_f16(const mb_conv1d_f16_args* a, mb_stream_t stream) {
   const int n_mt = (a->c_out + 31) / 32;
   const int tq = cdiv(a->t_out, a->up);
   hipStream_t s = (hipStream_t)stream;
+  // ---- upsamplers: one workgroup per tile of input positions, all polyphases, coalesced output (convt_f16_kernel) ----
+  if (a->up > 1 && !getenv("MBHIP_CONVT_GENERAL") && (a->c_out == 32 || a->c_out == 64 || a->c_out == 128 || a->c_out == 256) &&
+      a->c_in % 16 == 0 && (k.ntaps * k.n_cb) % 8 == 0 && !a->d_res && !a->accumulate && a->out_act == 0 && !a->y_f32 &&
+      k.in_repeat == 1 && k.out_scale == 1.f && a->t_out == a->t_in * a->up) {
+    const int NQ = 32 * (8 / n_mt);
+    const size_t lds = ((size_t)(NQ + k.span) * (a->c_in + 8) + (size_t)NQ * a->up * (a->c_out + 8)) * sizeof(h16);
+    if (lds <= 160 * 1024) {
+      static bool attr_done = false;
+      if (!attr_done) {
+        MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convt_f16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+      }
+      hipLaunchKernelGGL(convt_f16_kernel, dim3(cdiv(a->t_in, NQ), a->batch), dim3(512), lds, s, k, n_mt);
+      MB_HIP(hipGetLastError());
+      return MB_OK;
+    }
+  }
   // wave arrangement: >= 4 channel tiles -> 2x2 waves of 2 tiles; else all waves along time.
   // Packed 8-byte epilogue needs c_out % 4 == 0 and fp16 output; anything else (conv_post with
   // c_out = 1, fp32 output) takes the per-element epilogue with one channel tile per wave.
