@@ -243,8 +243,21 @@ __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void conv1d_f16_kernel(ConvHK
 // A wave's A fragments (its output-channel tile, all phases: one contiguous walk through the packed image per phase) come
 // through an EIGHT-deep register ring, refilled behind the MFMA that read the slot: with the one-step prefetch of the general
 // kernel every k-step waited an L2 round trip for 32 cycles of MFMA work (a first version of this kernel: 18 us per tile).
-__global__ __launch_bounds__(512) void convt_f16_kernel(ConvHK a, const int n_mt) {
+// Also the form for SHORT plain convs (up = 1: conv_pre, 80 -> 512 channels over a few thousand frames: 35 dependent k-steps of
+// latency in the general kernel): more than 8 channel tiles are dealt over blockIdx.z in groups of 8.
+// The k-steps of a phase run in GROUPS of RD (= the ring depth, a template parameter): a group is RD channel blocks of one tap
+// (TPG = 1, n_cb a multiple of RD) or TPG whole taps (n_cb * TPG = RD), so every address inside a group is the group's base plus
+// a compile-time offset and the bookkeeping (next group's bases, with selects) happens once per group.  A version that walked
+// (tap, channel block) per step spent ~40 scalar instructions per MFMA -- the scalar unit is shared by the CU's four SIMDs, the
+// 8 waves queued on it and the upsamplers got slower.
+// The B fragment of a step is read from LDS TWO steps ahead (b_cur / b_nxt / the new one): with one step the wait in front of
+// an MFMA was for the read issued just before the previous one -- LDS latency on every step of the dependent MFMA chain.
+// Every MFMA takes a fresh 1 KB A fragment from L2, so this shape is L2-bound at a quarter of the matrix rate: right for the
+// upsamplers and conv_pre (a few GFLOP), wrong for anything large (the host keeps those on the general kernel).
+template <int RD, int TPG>
+__global__ __launch_bounds__(512) void convt_f16_kernel(ConvHK a, const int n_mt_tot, const int n_mt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  constexpr int CBG = RD / TPG;               // channel blocks of one tap inside a group
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int NQ = 32 * (8 / n_mt);
@@ -252,27 +265,26 @@ __global__ __launch_bounds__(512) void convt_f16_kernel(ConvHK a, const int n_mt
   const int t_lim = a.valid ? min(a.t_in, a.valid[b] * a.valid_mul) : a.t_in;  // ragged batch: this item's input rows
   const int t_out_b = a.valid ? min(a.t_out, t_lim * a.up) : a.t_out;
   if (q0 * a.up >= t_out_b) return;
-  const int cinp = a.c_in + 8, coutp = a.c_out + 8;
+  const int c_wg = n_mt * 32;                 // output channels of this workgroup
+  const int cinp = a.c_in + 8, coutp = c_wg + 8;
   const int rowlen = NQ + a.span;
   h16* xs = reinterpret_cast<h16*>(lds_raw);  // [rowlen][c_in + 8]
-  h16* os = xs + rowlen * cinp;               // [NQ * up][c_out + 8]
-  const int mt = wave % n_mt, nt = wave / n_mt;
-  const int nst = a.ntaps * a.n_cb;           // k-steps per phase (a multiple of 8: checked on the host)
-  const h16x8* wbase = reinterpret_cast<const h16x8*>(a.w) + lane;
-  // the wave's fragments in consumption order: nst contiguous ones per phase, phases n_mt * nst apart; the walk stops at the
-  // last fragment (re-reads, discarded)
-  const h16x8* wnext = wbase + (size_t)mt * nst * 64;
-  int pf_left = nst, pf_phases = a.up - 1;
-  auto next_frag = [&]() {
-    const h16x8 v = *wnext;
-    if (--pf_left > 0) wnext += 64;
-    else if (pf_phases > 0) { --pf_phases; pf_left = nst; wnext += (size_t)((n_mt - 1) * nst + 1) * 64; }
-    else pf_left = 1;
-    return v;
-  };
-  h16x8 ring[8];
+  h16* os = xs + rowlen * cinp;               // [NQ * up][c_wg + 8]
+  const int mtl = wave % n_mt, nt = wave / n_mt;
+  const int mt = blockIdx.z * 8 + mtl;
+  const int nst = a.ntaps * a.n_cb;           // k-steps per phase, a multiple of RD
+  const int ngroups = nst / RD;
+  // the wave's A fragments: nst contiguous ones per phase (consumption order), phases n_mt_tot * nst apart
+  const h16x8* wphase = reinterpret_cast<const h16x8*>(a.w) + (size_t)mt * nst * 64;
+  const size_t wpstride = (size_t)n_mt_tot * nst * 64;
+  h16x8 ring[RD];
 #pragma unroll
-  for (int r = 0; r < 8; ++r) ring[r] = next_frag();  // in flight under the window fill
+  for (int r = 0; r < RD; ++r) {  // phase 0, group 0: in flight under the window fill
+    ring[r] = wphase[r * 64 + lane];
+    // in slot order: issued out of order, the youngest-but-one slot being the first one consumed, the compiler's wait in
+    // front of that MFMA is vmcnt(1) in EVERY iteration (loop-entry and back-edge states are merged)
+    __builtin_amdgcn_sched_barrier(0);
+  }
   const h16* xb = a.x + (long long)b * a.x_bstride;
   {  // the window, input activation applied
     const int ppr = a.c_in >> 3;
@@ -290,46 +302,149 @@ __global__ __launch_bounds__(512) void convt_f16_kernel(ConvHK a, const int n_mt
   }
   __syncthreads();
   const int qrow = nt * 32 + (lane & 31);
+  const int tapstride = a.step * cinp;        // halves between the rows of consecutive taps
   for (int p = 0; p < a.up; ++p) {
     const h16* lb = xs + (qrow + a.off0[p] - a.min_off) * cinp + (lane >> 5) * 8;
+    // where the ring refills of this phase's LAST group come from: the next phase's first group (after the last phase: this
+    // phase's own first group again, discarded)
+    const h16x8* wnextphase = p + 1 < a.up ? wphase + wpstride : wphase;
+    const h16x8* wref = wphase;               // + RD * 64 per group
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    int j = 0, cb = 0;
-    h16x8 bf = *reinterpret_cast<const h16x8*>(lb);  // the B fragment runs one k-step ahead of its MFMA
-    for (int st = 0; st < nst; st += 8) {
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        if (++cb == a.n_cb) { cb = 0; ++j; }
-        const int jn = j < a.ntaps ? j : 0;  // (past the phase's last step: any valid row, discarded)
-        const h16x8 bn = *reinterpret_cast<const h16x8*>(lb + jn * a.step * cinp + cb * 16);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[r], bf, acc, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        ring[r] = next_frag();
-        bf = bn;
+    // B fragment of step r of the group at (tap jg, channel block cg): lb + jg * tapstride + cg * 16 + a compile-time part
+    auto bfrag = [&](const h16* gb, const int r) {
+      return *reinterpret_cast<const h16x8*>(gb + (r / CBG) * tapstride + (r % CBG) * 16);
+    };
+    int jg = 0, cg = 0;
+    const h16* gb = lb;
+    h16x8 b_cur = bfrag(gb, 0), b_nxt = bfrag(gb, 1 % RD);
+    for (int g = 0; g < ngroups; ++g) {
+      const bool lastg = g == ngroups - 1;
+      wref = lastg ? wnextphase : wref + RD * 64;
+      // next group's base (the last group re-reads its own first two fragments, discarded)
+      if (TPG > 1) jg += lastg ? 0 : TPG;
+      else {
+        const bool wrap = cg + RD == a.n_cb;
+        cg = lastg ? cg : (wrap ? 0 : cg + RD);
+        jg += (wrap && !lastg) ? 1 : 0;
       }
+      const h16* gbn = lb + jg * tapstride + cg * 16;
+#pragma unroll
+      for (int r = 0; r < RD; ++r) {
+        const h16x8 b_new = r + 2 < RD ? bfrag(gb, r + 2) : bfrag(gbn, r + 2 - RD);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[r], b_cur, acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        ring[r] = wref[r * 64 + lane];
+        b_cur = b_nxt;
+        b_nxt = b_new;
+      }
+      gb = gbn;
     }
+    wphase = wnextphase;
     // D fragment: col = lane & 31 (position), rows 8 g + 4 (lane >> 5) + e (channel): + bias -> fp16 -> output order in LDS
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int co0 = mt * 32 + 8 * g + 4 * (lane >> 5);
+      const int cl = mtl * 32 + 8 * g + 4 * (lane >> 5);
       float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (a.bias) bv = *reinterpret_cast<const float4*>(a.bias + co0);
+      if (a.bias) bv = *reinterpret_cast<const float4*>(a.bias + blockIdx.z * 256 + cl);
       h16x4 hv;
       hv[0] = (h16)(acc[4 * g] + bv.x); hv[1] = (h16)(acc[4 * g + 1] + bv.y);
       hv[2] = (h16)(acc[4 * g + 2] + bv.z); hv[3] = (h16)(acc[4 * g + 3] + bv.w);
-      *reinterpret_cast<h16x4*>(os + (qrow * a.up + p) * coutp + co0) = hv;
+      *reinterpret_cast<h16x4*>(os + (qrow * a.up + p) * coutp + cl) = hv;
     }
   }
   __syncthreads();
-  {  // the tile's rows, whole 16-byte pieces, consecutive lanes -> consecutive bytes of y
-    const int ppr = a.c_out >> 3;
+  {  // the tile's rows, whole 16-byte pieces, consecutive lanes -> consecutive bytes of y (c_wg channels of each row)
+    const int ppr = c_wg >> 3;
     const int rows = min(NQ * a.up, t_out_b - q0 * a.up);
-    h16* yb = reinterpret_cast<h16*>(a.y) + (long long)b * a.y_bstride + (long long)q0 * a.up * a.c_out;
+    h16* yb = reinterpret_cast<h16*>(a.y) + (long long)b * a.y_bstride + (long long)q0 * a.up * a.c_out + blockIdx.z * 256;
     for (int idx = tid; idx < rows * ppr; idx += 512) {
       const int row = idx / ppr, pc = idx - row * ppr;
-      *reinterpret_cast<h16x8*>(yb + (long long)idx * 8) = *reinterpret_cast<const h16x8*>(os + row * coutp + pc * 8);
+      *reinterpret_cast<h16x8*>(yb + (long long)row * a.c_out + pc * 8) = *reinterpret_cast<const h16x8*>(os + row * coutp + pc * 8);
     }
+  }
+}
+
+// One output channel (conv_post: 32 -> 1 channels, k = 7, tanh): a dot product per output position on the packed-fp16 dot unit
+// (v_dot2_f32_f16, fp32 accumulate) instead of a 32-row MFMA tile with one live row.  256 positions per workgroup, the window
+// staged once with the input activation, the 224 weights of the channel in registers (read out of the A-fragment image: row
+// co = 0 lives in lanes 0 / 32 of every fragment).  Bound by the one read of x.
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+static constexpr int C1_TPW = 4;  // 256-position tiles per workgroup
+template <int CIN, int KS>
+__global__ __launch_bounds__(256, 3) void conv_c1_f16_kernel(ConvHK a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  constexpr int NB = 256, CP = CIN + 8, PPR = CIN / 8, TPW = C1_TPW;
+  h16* xs = reinterpret_cast<h16*>(lds_raw);  // [NB + span][CIN + 8]
+  const int tid = threadIdx.x, b = blockIdx.y, qbase = blockIdx.x * NB * TPW;
+  const int t_lim = a.valid ? min(a.t_in, a.valid[b] * a.valid_mul) : a.t_in;
+  const int q_end = a.valid ? min(a.t_out, t_lim + (a.t_out - a.t_in)) : a.t_out;  // tiles from here on are never consumed
+  if (qbase >= q_end) return;
+  h16x8 w[KS][PPR];
+  // vector loads through an opaque zero lane offset: as provably uniform loads the 112 weight words went to SGPRs, 47 of them
+  // spilled to VGPR lanes (a v_readlane in front of every other dot product)
+  int vz;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+  const h16x8* wp = reinterpret_cast<const h16x8*>(a.w) + vz;
+#pragma unroll
+  for (int j = 0; j < KS; ++j)
+#pragma unroll
+    for (int pc = 0; pc < PPR; ++pc) w[j][pc] = wp[(j * (CIN / 16) + (pc >> 1)) * 64 + (pc & 1) * 32];
+  const h16* xb = a.x + (long long)b * a.x_bstride;
+  const int rowlen = NB + a.span;
+  const h16 slope = (h16)a.in_slope;
+  const float bias = a.bias ? a.bias[0] : 0.f;
+  // a tile's window: every 16-byte piece of a thread requested before the first is used, and the NEXT tile's pieces while this
+  // one is computed (the first version -- one tile per workgroup, load -> store per piece -- was latency-bound at 2 TB/s);
+  // loads from clamped rows, the zero padding is a select on the value
+  constexpr int NIT = (NB + 64) * PPR / 256;  // span <= 64 (host)
+  h16x8 xv[NIT];
+  auto issue = [&](const int q0) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + 256 * it, row = idx / PPR, pc = idx % PPR;
+      const int tc = min(max(q0 + a.min_off + row, 0), a.t_in - 1);
+      xv[it] = *reinterpret_cast<const h16x8*>(xb + (long long)tc * CIN + pc * 8);
+    }
+  };
+  issue(qbase);
+  for (int tt = 0; tt < TPW; ++tt) {
+    const int q0 = qbase + tt * NB;
+    if (q0 >= q_end) break;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + 256 * it, row = idx / PPR, pc = idx % PPR;
+      const int ti = q0 + a.min_off + row;
+      h16x8 v = (ti >= 0 && ti < t_lim) ? xv[it] : (h16x8)(h16)0.f;
+      if (a.in_act == 1) v = lrelu8(v, slope);
+      if (row < rowlen) *reinterpret_cast<h16x8*>(xs + row * CP + pc * 8) = v;
+    }
+    __syncthreads();
+    if (tt + 1 < TPW && q0 + NB < q_end) issue(q0 + NB);
+    const int q = q0 + tid;
+    float acc = bias;
+    const h16* lb = xs + tid * CP;
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+#pragma unroll
+      for (int pc = 0; pc < PPR; ++pc) {
+        const h16x8 xr = *reinterpret_cast<const h16x8*>(lb + j * a.step * CP + pc * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const h16x2 x2 = {xr[2 * e], xr[2 * e + 1]}, w2 = {w[j][pc][2 * e], w[j][pc][2 * e + 1]};
+          acc = __builtin_amdgcn_fdot2(x2, w2, acc, false);
+        }
+      }
+    }
+    if (a.out_act == 1) acc = fmaxf(acc, 0.f);
+    else if (a.out_act == 2) acc = tanhf(acc);
+    acc *= a.out_scale;
+    if (q < a.t_out) {
+      if (a.y_f32) reinterpret_cast<float*>(a.y)[(long long)b * a.y_bstride + q] = acc;
+      else reinterpret_cast<h16*>(a.y)[(long long)b * a.y_bstride + q] = (h16)acc;
+    }
+    __syncthreads();  // every wave is done with the window
   }
 }
 
@@ -467,19 +582,51 @@ extern "C" int mb_conv1d_f16(const mb_conv1d_f16_args* a, mb_stream_t stream) {
   const int n_mt = (a->c_out + 31) / 32;
   const int tq = cdiv(a->t_out, a->up);
   hipStream_t s = (hipStream_t)stream;
-  // ---- upsamplers: one workgroup per tile of input positions, all polyphases, coalesced output (convt_f16_kernel) ----
-  if (a->up > 1 && !getenv("MBHIP_CONVT_GENERAL") && (a->c_out == 32 || a->c_out == 64 || a->c_out == 128 || a->c_out == 256) &&
-      a->c_in % 16 == 0 && (k.ntaps * k.n_cb) % 8 == 0 && !a->d_res && !a->accumulate && a->out_act == 0 && !a->y_f32 &&
-      k.in_repeat == 1 && k.out_scale == 1.f && a->t_out == a->t_in * a->up) {
-    const int NQ = 32 * (8 / n_mt);
-    const size_t lds = ((size_t)(NQ + k.span) * (a->c_in + 8) + (size_t)NQ * a->up * (a->c_out + 8)) * sizeof(h16);
+  // ---- upsamplers and short plain convs: one workgroup per tile of input positions, all polyphases, eight-deep weight ring,
+  //      coalesced output (convt_f16_kernel) ----
+  const bool plain = !a->d_res && !a->accumulate && k.in_repeat == 1;
+  const bool tiles8 = a->c_out % 32 == 0 && (n_mt == 1 || n_mt == 2 || n_mt == 4 || n_mt % 8 == 0);
+  // group shape: RD k-steps = RD channel blocks of one tap (n_cb % RD == 0) or TPG whole taps (n_cb * TPG == RD)
+  const int nst = k.ntaps * k.n_cb;
+  int rd = 0, tpg = 1;
+  for (int d = 8; d >= 5 && !rd; --d)
+    if (k.n_cb % d == 0) rd = d;
+  if (!rd)
+    for (int d = 8; d >= 4 && !rd; d -= 2)
+      if (d % k.n_cb == 0 && k.ntaps % (d / k.n_cb) == 0) { rd = d; tpg = d / k.n_cb; }
+  if (rd == 6 && tpg != 1 && tpg != 2) rd = 0;  // instances below
+  if (rd == 4 && tpg != 1 && tpg != 2) rd = 0;
+  // (the choice must not depend on the batch: an item of a ragged batch and its single run take the same kernel -- same sums)
+  const bool small = a->up > 1 || (a->t_out <= 8192 && nst >= 8 && n_mt >= 8);
+  if (!getenv("MBHIP_CONVT_GENERAL") && plain && tiles8 && small && rd && a->c_in % 16 == 0 && a->out_act == 0 && !a->y_f32 &&
+      k.out_scale == 1.f && a->t_out == a->t_in * a->up) {
+    const int n_wg = std::min(n_mt, 8);
+    const int NQ = 32 * (8 / n_wg);
+    const size_t lds = ((size_t)(NQ + k.span) * (a->c_in + 8) + (size_t)NQ * a->up * (n_wg * 32 + 8)) * sizeof(h16);
     if (lds <= 160 * 1024) {
-      static bool attr_done = false;
-      if (!attr_done) {
-        MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convt_f16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-      }
-      hipLaunchKernelGGL(convt_f16_kernel, dim3(cdiv(a->t_in, NQ), a->batch), dim3(512), lds, s, k, n_mt);
+      const dim3 grid(cdiv(a->t_in, NQ), a->batch, cdiv(n_mt, 8));
+#define MB_CONVT(RD_, TPG_)                                                                                                  \
+  if (rd == RD_ && tpg == TPG_) {                                                                                            \
+    static bool attr_done = false;                                                                                           \
+    if (!attr_done) {                                                                                                        \
+      MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&convt_f16_kernel<RD_, TPG_>),                                \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                                  \
+      attr_done = true;                                                                                                      \
+    }                                                                                                                        \
+    hipLaunchKernelGGL((convt_f16_kernel<RD_, TPG_>), grid, dim3(512), lds, s, k, n_mt, n_wg);                               \
+  }
+      MB_CONVT(8, 1) MB_CONVT(7, 1) MB_CONVT(6, 1) MB_CONVT(5, 1)
+      MB_CONVT(8, 2) MB_CONVT(8, 4) MB_CONVT(8, 8) MB_CONVT(6, 2) MB_CONVT(4, 2) MB_CONVT(4, 1)
+#undef MB_CONVT
+      MB_HIP(hipGetLastError());
+      return MB_OK;
+    }
+  }
+  // ---- one output channel (conv_post): dot products, no matrix tile with one live row ----
+  if (!getenv("MBHIP_CONVT_GENERAL") && plain && a->up == 1 && a->c_out == 1 && a->c_in == 32 && a->ksize == 7 && a->t_out == a->t_in) {
+    const size_t lds = (size_t)(256 + k.span) * (32 + 8) * sizeof(h16);
+    if (k.span <= 64) {
+      hipLaunchKernelGGL((conv_c1_f16_kernel<32, 7>), dim3(cdiv(a->t_out, 256 * C1_TPW), a->batch), dim3(256), lds, s, k);
       MB_HIP(hipGetLastError());
       return MB_OK;
     }

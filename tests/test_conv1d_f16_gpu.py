@@ -40,6 +40,9 @@ CONV_CASES = [
     (1, 128, 128, 37, 1, 1),     # 1x1
     (1, 48, 96, 50, 3, 1),       # Cin = 3 x 16 (ragged chunk), Cout = 3 tiles (inactive 4th)
     (1, 24, 40, 77, 5, 2),       # Cin % 16 = 8 (zero-filled half block), Cout % 32 = 8
+    (3, 80, 512, 201, 7, 1),     # conv_pre on the short-conv kernel: two groups of 8 channel tiles, 35 k-steps padded to 40
+    (2, 192, 512, 100, 7, 1),    # VITS conv_pre (84 k-steps -> 88)
+    (2, 64, 256, 90, 3, 1),      # 8 channel tiles, 12 k-steps -> 16
 ]
 
 
@@ -115,3 +118,18 @@ def test_layout_converters_roundtrip(cuda, lib):
     torch.cuda.synchronize()
     assert torch.equal(h, x.transpose(1, 2).contiguous().half())
     assert torch.equal(back, x.half().float())
+
+
+def test_short_conv_and_conv_post_kernels_equal_general_kernel(cuda, lib, monkeypatch):
+    # convt_f16_kernel (up = 1) / conv_c1_f16_kernel against the general MFMA kernel (MBHIP_CONVT_GENERAL=1, read per call)
+    x = _rand(2, 80, 333, seed=31)
+    w, b = _rand(512, 80, 7, seed=32) / 23.7, _rand(512, seed=33)
+    xp = _rand(3, 32, 2049, seed=34)
+    wp, bp = _rand(1, 32, 7, seed=35) / 15.0, _rand(1, seed=36)
+    y_new = hiputil.conv1d_f16_hip(x, w, b, pad=3)
+    p_new = hiputil.conv1d_f16_hip(xp, wp, bp, pad=3, in_act=1, in_slope=0.01, out_act=2, y_f32=True)
+    monkeypatch.setenv("MBHIP_CONVT_GENERAL", "1")
+    y_old = hiputil.conv1d_f16_hip(x, w, b, pad=3)
+    p_old = hiputil.conv1d_f16_hip(xp, wp, bp, pad=3, in_act=1, in_slope=0.01, out_act=2, y_f32=True)
+    assert float((y_new.float() - y_old.float()).abs().max()) <= 4e-3   # one fp16 ulp at |y| < 4 (summation order)
+    assert float((p_new - p_old).abs().max()) <= 2e-6
