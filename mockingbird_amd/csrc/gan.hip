@@ -520,15 +520,15 @@ static int gan_forward_impl(const mb_gan* g, const float* d_mel, int batch, int 
       mel_cur = mel_next; mel_t *= cu.s.stride;
       L.add(XS, mel_cur, (size_t)batch * cu.s.c_out * mel_t);
     }
-    if (fre && i > lvl) {
-      // output = res_output[i-lvl-1](x or output): nearest x u then 1x1 conv (generator.py:145-149)
+    const bool ro_deferred = fre && i > lvl && out_cur;  // res_output of `output`: runs behind the stage with "+ x" as its residual
+    if (fre && i > lvl && !ro_deferred) {
+      // output = res_output[i-lvl-1](x): nearest x u then 1x1 conv (generator.py:145-149); x is overwritten by this stage, so
+      // this one runs here and "+ x" is a launch of its own below
       const ConvW& ro = g->convs[g->i_resout + (i - lvl - 1)];
       const int u = c.upsample_rates[i];
-      const char* src = out_cur ? out_cur : XS;
-      const int src_t = out_cur ? out_t : t;
-      char* dst = (out_cur == OUTA) ? OUTB : OUTA;
-      L.conv(ro, src, src_t, dst, 0, 0.f, nullptr, 1.f, 0, 0, u);
-      pending_out = dst; out_t = src_t * u;
+      char* dst = OUTA;
+      L.conv(ro, XS, t, dst, 0, 0.f, nullptr, 1.f, 0, 0, u);
+      pending_out = dst; out_t = t * u;
     }
     // x = ups[i](leaky_relu(x))
     const ConvW& up = g->convs[g->i_ups + i];
@@ -591,6 +591,12 @@ static int gan_forward_impl(const mb_gan* g, const float* d_mel, int batch, int 
     if (pending_out) {  // output = output + x (generator.py:158-159)
       L.add(pending_out, XS, (size_t)batch * ch * t);
       out_cur = pending_out;
+    } else if (ro_deferred) {  // output = res_output[i-lvl-1](output) + x in one launch (x = this stage's result)
+      const ConvW& ro = g->convs[g->i_resout + (i - lvl - 1)];
+      const int u = c.upsample_rates[i];
+      char* dst = (out_cur == OUTA) ? OUTB : OUTA;
+      L.conv(ro, out_cur, out_t, dst, 0, 0.f, XS, 1.f, 0, 0, u);
+      out_cur = dst; out_t *= u;
     }
   }
   // x = leaky_relu(x) [default slope 0.01, models.py:146]; conv_post; tanh
