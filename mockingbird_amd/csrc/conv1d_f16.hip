@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256, 3) void conv_c1_f16_kernel(ConvHK a) {
   // a tile's window: every 16-byte piece of a thread requested before the first is used, and the NEXT tile's pieces while this
   // one is computed (the first version -- one tile per workgroup, load -> store per piece -- was latency-bound at 2 TB/s);
   // loads from clamped rows, the zero padding is a select on the value
-  constexpr int NIT = (NB + 64) * PPR / 256;  // span <= 64 (host)
+  constexpr int NIT = ((NB + 64) * PPR + 255) / 256;  // span <= 64 (host)
   h16x8 xv[NIT];
   auto issue = [&](const int q0) {
 #pragma unroll
@@ -445,6 +445,89 @@ __global__ __launch_bounds__(256, 3) void conv_c1_f16_kernel(ConvHK a) {
       else reinterpret_cast<h16*>(a.y)[(long long)b * a.y_bstride + q] = (h16)acc;
     }
     __syncthreads();  // every wave is done with the window
+  }
+}
+
+// 1x1 conv over a nearest-repeated input (+ residual): Fre-GAN's res_output (generator.py:104-110, 145-159).  Bandwidth work
+// with a few MFMAs in it: the general kernel staged chunks through LDS behind barriers and fetched its (4 KB of) weights one
+// k-step ahead per tile -- 3 to 4 x the time of the bytes.  Here a wave keeps ALL A fragments in registers, takes its B
+// fragments straight from HBM (lane = source position, 16 bytes = 8 channels; the next tile's are in flight during this
+// one's products), computes each SOURCE position once, and writes the `in_repeat` output rows that share it -- residual added
+// per row -- as whole rows from a wave-private LDS tile.  No barrier anywhere.
+template <int NMT, int NCB>
+__global__ __launch_bounds__(256) void conv_pw_f16_kernel(ConvHK a, const int tiles_per_wave) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  constexpr int CP = 32 * NMT + 8;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  h16* os = reinterpret_cast<h16*>(lds_raw) + wave * 32 * CP;  // [32 source positions][32 NMT + 8]
+  const int b = blockIdx.y, u = a.in_repeat;
+  const int t_lim = a.valid ? min(a.t_in, a.valid[b] * a.valid_mul * u) : a.t_in;  // output rows of this item
+  const int src_lim = t_lim / u, src_all = a.t_in / u;
+  const int tile0 = (blockIdx.x * 4 + wave) * tiles_per_wave;
+  if (tile0 * 32 >= src_all) return;
+  h16x8 af[NMT][NCB];
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) af[mt][cb] = reinterpret_cast<const h16x8*>(a.w)[(mt * NCB + cb) * 64 + lane];
+  float4 bv[NMT][4];
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int co0 = mt * 32 + 8 * g + 4 * (lane >> 5);
+      bv[mt][g] = (a.bias && co0 < a.c_out) ? *reinterpret_cast<const float4*>(a.bias + co0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  const h16* xb = a.x + (long long)b * a.x_bstride + (lane >> 5) * 8;
+  const h16* rb = a.res ? a.res + (long long)b * a.res_bstride : nullptr;
+  h16* yb = reinterpret_cast<h16*>(a.y) + (long long)b * a.y_bstride;
+  const h16 slope = (h16)a.in_slope;
+  h16x8 bnext[NCB];
+  auto issue = [&](const int tile) {
+    const int q = min(tile * 32 + (lane & 31), src_all - 1);
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) bnext[cb] = *reinterpret_cast<const h16x8*>(xb + (long long)q * a.c_in + cb * 16);
+  };
+  issue(tile0);
+  const int ppr = a.c_out >> 3;            // 16-byte pieces per output row
+  for (int tt = 0; tt < tiles_per_wave; ++tt) {
+    const int tile = tile0 + tt, q0 = tile * 32;
+    if (q0 >= src_all) break;
+    h16x8 bf[NCB];
+    const bool live = q0 + (lane & 31) < src_lim;  // beyond the item's length: its zero padding
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      bf[cb] = live ? bnext[cb] : (h16x8)(h16)0.f;
+      if (a.in_act == 1) bf[cb] = lrelu8(bf[cb], slope);
+    }
+    if (tt + 1 < tiles_per_wave && q0 + 32 < src_all) issue(tile + 1);
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt][cb], bf[cb], acc, 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        h16x4 hv;
+        hv[0] = (h16)(acc[4 * g] + bv[mt][g].x); hv[1] = (h16)(acc[4 * g + 1] + bv[mt][g].y);
+        hv[2] = (h16)(acc[4 * g + 2] + bv[mt][g].z); hv[3] = (h16)(acc[4 * g + 3] + bv[mt][g].w);
+        *reinterpret_cast<h16x4*>(os + (lane & 31) * CP + mt * 32 + 8 * g + 4 * (lane >> 5)) = hv;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // the tile is this wave's own: LDS operations of a wave complete in order
+    // the tile's 32 u output rows, contiguous in y: consecutive lanes -> consecutive 16-byte pieces
+    const int rows = min(32 * u, a.t_out - q0 * u);
+    const long long o0 = (long long)q0 * u * a.c_out;
+    for (int idx = lane; idx < rows * ppr; idx += 64) {
+      const int orow = idx / ppr, pc = idx - orow * ppr;
+      h16x8 v = *reinterpret_cast<const h16x8*>(os + (orow / u) * CP + pc * 8);
+      if (rb) v += *reinterpret_cast<const h16x8*>(rb + o0 + (long long)idx * 8);
+      *reinterpret_cast<h16x8*>(yb + o0 + (long long)idx * 8) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -622,14 +705,29 @@ extern "C" int mb_conv1d_f16(const mb_conv1d_f16_args* a, mb_stream_t stream) {
       return MB_OK;
     }
   }
+  // ---- 1x1 conv over a nearest-repeated input, optional residual (Fre-GAN res_output): streaming kernel, no LDS staging of x ----
+  if (!getenv("MBHIP_CONVT_GENERAL") && a->up == 1 && a->ksize == 1 && !a->accumulate && a->out_act == 0 && !a->y_f32 &&
+      k.out_scale == 1.f && a->c_in % 16 == 0 && (a->c_out % 32 == 0 || a->c_out == 16) && a->t_out == a->t_in) {
+    const int tpw = 4;  // 32-position tiles per wave
+    const dim3 grid(cdiv(cdiv(a->t_in / k.in_repeat, 32), 4 * tpw), a->batch);
+#define MB_PW(NMT_, NCB_)                                                                                                   \
+  if (n_mt == NMT_ && k.n_cb == NCB_) {                                                                                     \
+    hipLaunchKernelGGL((conv_pw_f16_kernel<NMT_, NCB_>), grid, dim3(256), 4 * 32 * (32 * NMT_ + 8) * sizeof(h16), s, k, tpw); \
+    MB_HIP(hipGetLastError());                                                                                              \
+    return MB_OK;                                                                                                           \
+  }
+    MB_PW(2, 8) MB_PW(1, 4) MB_PW(1, 2)
+#undef MB_PW
+  }
   // ---- one output channel (conv_post): dot products, no matrix tile with one live row ----
-  if (!getenv("MBHIP_CONVT_GENERAL") && plain && a->up == 1 && a->c_out == 1 && a->c_in == 32 && a->ksize == 7 && a->t_out == a->t_in) {
-    const size_t lds = (size_t)(256 + k.span) * (32 + 8) * sizeof(h16);
-    if (k.span <= 64) {
-      hipLaunchKernelGGL((conv_c1_f16_kernel<32, 7>), dim3(cdiv(a->t_out, 256 * C1_TPW), a->batch), dim3(256), lds, s, k);
-      MB_HIP(hipGetLastError());
-      return MB_OK;
-    }
+  if (!getenv("MBHIP_CONVT_GENERAL") && plain && a->up == 1 && a->c_out == 1 && (a->c_in == 32 || a->c_in == 16) && a->ksize == 7 &&
+      a->t_out == a->t_in && k.span <= 64) {
+    const size_t lds = (size_t)(256 + k.span) * (a->c_in + 8) * sizeof(h16);
+    const dim3 grid(cdiv(a->t_out, 256 * C1_TPW), a->batch);
+    if (a->c_in == 32) hipLaunchKernelGGL((conv_c1_f16_kernel<32, 7>), grid, dim3(256), lds, s, k);
+    else hipLaunchKernelGGL((conv_c1_f16_kernel<16, 7>), grid, dim3(256), lds, s, k);
+    MB_HIP(hipGetLastError());
+    return MB_OK;
   }
   // wave arrangement: >= 4 channel tiles -> 2x2 waves of 2 tiles; else all waves along time.
   // Packed 8-byte epilogue needs c_out % 4 == 0 and fp16 output; anything else (conv_post with

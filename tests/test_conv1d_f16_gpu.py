@@ -133,3 +133,32 @@ def test_short_conv_and_conv_post_kernels_equal_general_kernel(cuda, lib, monkey
     p_old = hiputil.conv1d_f16_hip(xp, wp, bp, pad=3, in_act=1, in_slope=0.01, out_act=2, y_f32=True)
     assert float((y_new.float() - y_old.float()).abs().max()) <= 4e-3   # one fp16 ulp at |y| < 4 (summation order)
     assert float((p_new - p_old).abs().max()) <= 2e-6
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T,u,with_res", [(2, 128, 64, 301, 2, True), (3, 64, 32, 1000, 2, True), (2, 32, 16, 777, 2, True),
+                                                     (1, 32, 16, 130, 1, False), (2, 64, 32, 95, 3, False)])
+def test_pointwise_repeat_residual_kernel(cuda, lib, monkeypatch, B, Cin, Cout, T, u, with_res):
+    # conv_pw_f16_kernel: 1x1 conv over the nearest-repeated input + residual (fregan/generator.py:104-110,145-159)
+    x = _rand(B, Cin, T, seed=41)
+    w, b = _rand(Cout, Cin, 1, seed=42) / Cin ** 0.5, _rand(Cout, seed=43)
+    res = _rand(B, Cout, T * u, seed=44) if with_res else None
+    xr = F.interpolate(_h(x), scale_factor=u, mode="nearest") if u > 1 else _h(x)
+    ref = F.conv1d(xr, _h(w), b)
+    if with_res:
+        ref = _h(ref) + _h(res)   # the conv result is rounded to fp16 before the (fp16) residual add
+    y = hiputil.conv1d_f16_hip(x, w, b, in_repeat=u, res=res)
+    assert y.shape == ref.shape
+    _check(y, ref, "pointwise")
+    monkeypatch.setenv("MBHIP_CONVT_GENERAL", "1")
+    y_old = hiputil.conv1d_f16_hip(x, w, b, in_repeat=u, res=res)
+    assert float((y.float() - y_old.float()).abs().max()) <= 8e-3
+
+
+def test_conv_post_16_channels(cuda, lib):
+    # Fre-GAN's conv_post (16 -> 1 channels) on the dot-product kernel
+    x = _rand(2, 16, 3001, seed=51)
+    w, b = _rand(1, 16, 7, seed=52) / (16 * 7) ** 0.5, _rand(1, seed=53)
+    xa = torch.maximum(_h(x), _h(_h(x) * float(torch.tensor(0.01).half())))
+    ref = torch.tanh(F.conv1d(xa, _h(w), b, padding=3))
+    y = hiputil.conv1d_f16_hip(x, w, b, pad=3, in_act=1, in_slope=0.01, out_act=2, y_f32=True)
+    _check(y, ref, "conv_post16", out_fp16=False)
