@@ -349,8 +349,9 @@ def gan_floor_bytes(h, batch, frames):
             b += 2 * B * T * C * 2.0
         else:
             for j, ks in enumerate(h["resblock_kernel_sizes"]):
-                # 64 / 128 channels: a ResBlock with k = 3 is one launch (gan.hip: mb_resblock_stage_f16_efficiency >= 0.75), the others one per unit
-                chain = C in (64, 128) and ks == 3 and nd <= 3
+                # 64 / 128 channels: a ResBlock with k = 3 is one launch (gan.hip: mb_resblock_stage_f16_efficiency >= 0.65 for k = 3, which
+                # holds for both benchmarked dilation sets), the others one per unit
+                chain = C in (64, 128) and ks == 3
                 b += (2 if chain else nd * 2) * B * T * C * 2.0 + (B * T * C * 2.0 if j > 0 else 0.0)
     return b + B * T * C * 2.0 + B * T * 4.0
 

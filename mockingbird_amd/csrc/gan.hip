@@ -301,8 +301,10 @@ extern "C" int mb_gan_create_ex(const mb_gan_config* cfg, const float* const* h_
           // useful rows per window row: measured on HiFi-GAN 32 x 200 (same box): no chain launches 3.667 ms, k = 3 at 64 channels
           // (0.91) 3.616, + k = 3 at 128 channels (0.81) 3.569, + k = 7 at 64 channels (0.72) 3.579 -- below ~0.75 the halo
           // recompute costs what the per-unit launches' tensor passes do
+          // do.  k = 3 units are the least efficient per-unit launches (21 % of the matrix peak at 128 channels), so their chain
+          // pays from 0.65: Fre-GAN 8 x 3000 with dilations (1, 3, 5, 7), k = 3 at 128 channels (0.69): 12.97 -> 12.78 ms same box.
           const char* ee = getenv("MBHIP_GAN_CHAIN_EFF");  // A/B: another threshold
-          if (!ok || mb_resblock_stage_f16_efficiency(ch, 1, &kj, nd, dil) < (ee ? (float)atof(ee) : 0.75f)) continue;
+          if (!ok || mb_resblock_stage_f16_efficiency(ch, 1, &kj, nd, dil) < (ee ? (float)atof(ee) : (kj <= 3 ? 0.65f : 0.75f))) continue;
           img.assign(mb_resblock_stage_f16_packed_halves(ch, 1, &kj, nd) / 2, 0.f);
           rc = mb_resblock_stage_f16_pack(w1, w2, ch, 1, &kj, nd, reinterpret_cast<uint16_t*>(img.data()));
           if (!rc) rc = g->chain_w[(size_t)i * nk + j].upload(img.data(), img.size());
