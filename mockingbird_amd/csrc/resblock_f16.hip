@@ -129,7 +129,11 @@ void resblock_pair_f16_kernel(ResPairK a) {
   const int my_tiles = (a.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int njobs = my_tiles * NCH;
 
-  for (int i = tid; i < 2 * C; i += 64 * (4 + PAIR_NL)) bs[i] = i < C ? a.b1[i] : a.b2[i - C];  // visible after the first barrier
+  for (int i = tid; i < 2 * C; i += 64 * (4 + PAIR_NL)) bs[i] = i < C ? a.b1[i] : a.b2[i - C];
+  // Z: the MMA waves start their accumulators from bs BEFORE the first barrier of the tile loop.  Without this one the first
+  // tile of a workgroup raced with the fill and took whatever the LDS held (mostly the previous launch's bias block: one tile of
+  // a launch now and then off by a bias difference -- found by test_resblock_stage_equals_unit_launches failing once in five runs)
+  __syncthreads();
 
   if (wave >= 4) {
     // ------------------------------ loader waves ------------------------------

@@ -75,3 +75,22 @@ def test_resblock_pair_rejects_bad_shapes(cuda, lib):
     w = _rand(48, 48, 3, seed=2)
     with pytest.raises(MbHipError, match="unsupported"):
         hiputil.resblock_pair_f16_hip(x, w, torch.zeros(48), w, torch.zeros(48))
+
+
+@pytest.mark.parametrize("C", [32, 64, 128])
+def test_bias_block_of_the_previous_launch_is_never_used(cuda, lib, C):
+    """The kernel stages (b1, b2) in LDS and starts its accumulators from them.  Alternate launches with very different
+    biases: a first tile that read the LDS before the fill was fenced (a race this kernel once had: one tile of a launch now
+    and then took the previous launch's bias block) shows up as an error of the bias difference."""
+    T, k, d = 3000, 7, 3
+    x = _rand(1, C, T, seed=1)
+    w1 = _rand(C, C, k, seed=2) / (C * k) ** 0.5
+    w2 = _rand(C, C, k, seed=3) / (C * k) ** 0.5
+    biases = [(0.1 * _rand(C, seed=4) + 3.0, 0.1 * _rand(C, seed=5) - 2.0), (0.1 * _rand(C, seed=6) - 3.0, 0.1 * _rand(C, seed=7) + 2.0)]
+    refs = [_ref(x, w1, b1, w2, b2, d, 0.1) for b1, b2 in biases]
+    for rep in range(6):
+        b1, b2 = biases[rep & 1]
+        y = hiputil.resblock_pair_f16_hip(x, w1, b1, w2, b2, dilation=d, slope=0.1)
+        dlt = (y.double() - refs[rep & 1].double()).abs()
+        tol = 4e-3 + 2.0 ** -8 * refs[rep & 1].double().abs().clamp(min=1.0)
+        assert int((dlt > tol).sum()) == 0, (rep, float(dlt.max()))
