@@ -332,16 +332,25 @@ def sharded_objects(args, rank, world, dev, use_dist, timed, total_over_ranks):
     return out
 
 
-def gan_floor_bytes(h, batch, frames):
+def gan_floor_bytes(h, batch, frames, fregan=False, top_k=4):
     """Read-x + write-y floor of one fp16 generator forward AS LAUNCHED (every launch reads its input and writes its output
     once, 2 B per element): conv_pre, per stage the upsampler and either num_kernels x len(dilations) fused pair units (the mean
     over the parallel ResBlocks adds a read of the accumulator for all but the first) or, for the narrow stages (<= 32 channels),
     ONE launch for the whole ResBlock group (resblock_stage_f16.hip: one read, one write); at 64 / 128 channels the k = 3 ResBlocks
-    of HiFi-GAN are one launch each; conv_post."""
+    are one launch each; conv_post.  fregan=True adds that generator's own launches: the cond_up chain, `x += mel`, res_output and
+    `output + x` (fused into the res_output launch except at the first level)."""
     B, T, C = batch, frames, h["upsample_initial_channel"]
     b = B * T * (h["num_mels"] + C) * 2.0
     nk, nd = len(h["resblock_kernel_sizes"]), len(h["resblock_dilation_sizes"][0])
-    for u in h["upsample_rates"]:
+    lvl = len(h["upsample_rates"]) - top_k if fregan else 1 << 30
+    mel_c = h["num_mels"]
+    for i, u in enumerate(h["upsample_rates"]):
+        if i >= lvl:      # Fre-GAN: mel = cond_up(mel) (read + write), x += mel (two reads, one write)  generator.py:142-144
+            b += B * (T // h["upsample_rates"][i - 1]) * mel_c * 2.0 + B * T * C * 2.0 + 3 * B * T * C * 2.0
+            mel_c = C
+        if i > lvl:       # output = res_output(x or output) + x (generator.py:145-159): the source at 1/u of the rows, the result
+            dst = B * T * u * (C // 2) * 2.0                                     # written once, x read once as the residual; at the
+            b += B * T * C * 2.0 + (4 if i == lvl + 1 else 2) * dst              # first level "+ x" is a launch of its own
         b += B * T * C * 2.0
         T, C = T * u, C // 2
         b += B * T * C * 2.0
@@ -782,7 +791,7 @@ def main():
             }
             tr, src = pmc_traffic("fregan")
             result["fregan_f16"]["roofline"].update({"traffic": tr, "traffic_source": src,
-                                                     "traffic_floor_bytes": gan_floor_bytes(hf, 8, 3000)})
+                                                     "traffic_floor_bytes": gan_floor_bytes(hf, 8, 3000, fregan=True)})
             del gen, y, gmf
         # ---- secondary: Tacotron synthesize (BASELINE configs[2]): B=32, ~100 tokens, r=2, 400 frames forced
         if not args.no_tacotron:
