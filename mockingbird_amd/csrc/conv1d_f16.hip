@@ -29,6 +29,9 @@ namespace mb {
 typedef _Float16 h16;
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+#ifndef MB_CONVT_FB
+#define MB_CONVT_FB 6  // window pieces per thread in flight (convt_f16_kernel); 1 = diagnostics: one round trip per piece
+#endif
 
 struct ConvHK {
   const h16* x; const h16* w; const float* bias; const h16* res; void* y;
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(512) void convt_f16_kernel(ConvHK a, const int n_mt
   const int t_lim = a.valid ? min(a.t_in, a.valid[b] * a.valid_mul) : a.t_in;  // ragged batch: this item's input rows
   const int t_out_b = a.valid ? min(a.t_out, t_lim * a.up) : a.t_out;
   if (q0 * a.up >= t_out_b) return;
-  const int c_wg = n_mt * 32;                 // output channels of this workgroup
+  const int c_wg = min(n_mt * 32, a.c_out);   // output channels of this workgroup (16: half a tile, the other rows are padding)
   const int cinp = a.c_in + 8, coutp = c_wg + 8;
   const int rowlen = NQ + a.span;
   h16* xs = reinterpret_cast<h16*>(lds_raw);  // [rowlen][c_in + 8]
@@ -286,18 +289,30 @@ __global__ __launch_bounds__(512) void convt_f16_kernel(ConvHK a, const int n_mt
     __builtin_amdgcn_sched_barrier(0);
   }
   const h16* xb = a.x + (long long)b * a.x_bstride;
-  {  // the window, input activation applied
+  {  // the window, input activation applied.  Six pieces per thread are requested before the first is used (clamped rows, the
+     // zero padding is a select on the value): a load -> store loop made every workgroup wait five HBM round trips in a row
     const int ppr = a.c_in >> 3;
     const h16 slope = (h16)a.in_slope;
-    for (int idx = tid; idx < rowlen * ppr; idx += 512) {
-      const int row = idx / ppr, pc = idx - row * ppr;
-      const int ti = q0 + a.min_off + row;
-      h16x8 v = (h16x8)(h16)0.f;
-      if (ti >= 0 && ti < t_lim) {
-        v = *reinterpret_cast<const h16x8*>(xb + (long long)ti * a.c_in + pc * 8);
-        if (a.in_act == 1) v = lrelu8(v, slope);
+    const int total = rowlen * ppr;
+    constexpr int FB = MB_CONVT_FB;
+    for (int base = 0; base < total; base += 512 * FB) {
+      h16x8 v[FB];
+#pragma unroll
+      for (int i = 0; i < FB; ++i) {
+        const int idx = min(base + i * 512 + tid, total - 1);
+        const int row = idx / ppr, pc = idx - row * ppr;
+        const int tc = min(max(q0 + a.min_off + row, 0), a.t_in - 1);
+        v[i] = *reinterpret_cast<const h16x8*>(xb + (long long)tc * a.c_in + pc * 8);
       }
-      *reinterpret_cast<h16x8*>(xs + row * cinp + pc * 8) = v;
+#pragma unroll
+      for (int i = 0; i < FB; ++i) {
+        const int idx = base + i * 512 + tid;
+        const int row = idx / ppr, pc = idx - row * ppr;
+        const int ti = q0 + a.min_off + row;
+        h16x8 w = (ti >= 0 && ti < t_lim) ? v[i] : (h16x8)(h16)0.f;
+        if (a.in_act == 1) w = lrelu8(w, slope);
+        if (idx < total) *reinterpret_cast<h16x8*>(xs + row * cinp + pc * 8) = w;
+      }
     }
   }
   __syncthreads();
@@ -346,6 +361,7 @@ __global__ __launch_bounds__(512) void convt_f16_kernel(ConvHK a, const int n_mt
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int cl = mtl * 32 + 8 * g + 4 * (lane >> 5);
+      if (cl >= c_wg) continue;
       float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
       if (a.bias) bv = *reinterpret_cast<const float4*>(a.bias + blockIdx.z * 256 + cl);
       h16x4 hv;
@@ -668,7 +684,7 @@ extern "C" int mb_conv1d_f16(const mb_conv1d_f16_args* a, mb_stream_t stream) {
   // ---- upsamplers and short plain convs: one workgroup per tile of input positions, all polyphases, eight-deep weight ring,
   //      coalesced output (convt_f16_kernel) ----
   const bool plain = !a->d_res && !a->accumulate && k.in_repeat == 1;
-  const bool tiles8 = a->c_out % 32 == 0 && (n_mt == 1 || n_mt == 2 || n_mt == 4 || n_mt % 8 == 0);
+  const bool tiles8 = (a->c_out % 32 == 0 || a->c_out == 16) && (n_mt == 1 || n_mt == 2 || n_mt == 4 || n_mt % 8 == 0);
   // group shape: RD k-steps = RD channel blocks of one tap (n_cb % RD == 0) or TPG whole taps (n_cb * TPG == RD)
   const int nst = k.ntaps * k.n_cb;
   int rd = 0, tpg = 1;
@@ -685,7 +701,7 @@ extern "C" int mb_conv1d_f16(const mb_conv1d_f16_args* a, mb_stream_t stream) {
       k.out_scale == 1.f && a->t_out == a->t_in * a->up) {
     const int n_wg = std::min(n_mt, 8);
     const int NQ = 32 * (8 / n_wg);
-    const size_t lds = ((size_t)(NQ + k.span) * (a->c_in + 8) + (size_t)NQ * a->up * (n_wg * 32 + 8)) * sizeof(h16);
+    const size_t lds = ((size_t)(NQ + k.span) * (a->c_in + 8) + (size_t)NQ * a->up * (std::min(n_wg * 32, a->c_out) + 8)) * sizeof(h16);
     if (lds <= 160 * 1024) {
       const dim3 grid(cdiv(a->t_in, NQ), a->batch, cdiv(n_mt, 8));
 #define MB_CONVT(RD_, TPG_)                                                                                                  \
