@@ -52,11 +52,14 @@ __device__ __forceinline__ float row16_sum(float v) {
 // (wave w owns k-blocks w, w+8, ...), first PS steps from seg0, the rest from seg1 (both FM).  NPART = 2 keeps the
 // seg1 sums apart (GRU hidden part).  All loads are issued before the first MFMA.  Returns true for the NT
 // epilogue waves (wave w finishes column tile nt0 + w) with the reduced sums in sx / sh (k order: waves 0..7).
-template <int NT, int PW, int PS, int RL, int NPART>
+// WaitB: called between the weight loads and the activation loads (taco_lstm2_kernel: the second cell's workgroups have their
+// weights in flight while they wait for the first cell's output); the default keeps the interleaved issue order.
+struct FmNoWait { __device__ __forceinline__ void operator()() const {} };
+template <int NT, int PW, int PS, int RL, int NPART, class WaitB = FmNoWait>
 __device__ __forceinline__ bool fm_gemm(const float* __restrict__ w, const int mt, const float* __restrict__ seg0,
                                         const float* __restrict__ seg1, const int nta, const int nt0, float* red,
                                         float (&sx)[4], float (&sh)[4], unsigned long long* tr = nullptr, int slot = 0,
-                                        bool pick = false) {
+                                        bool pick = false, WaitB wait_b = WaitB()) {
   constexpr int BLK = 4 * RL * 16, NKB = 8 * PW;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -67,10 +70,17 @@ __device__ __forceinline__ bool fm_gemm(const float* __restrict__ w, const int m
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) ntc[nt] = (nt0 + nt < nta) ? nt0 + nt : nta - 1;  // odd tile count: duplicate, never stored
   float4 a[PW], b[PW][NT];
+  constexpr bool SPLIT = !__is_same(WaitB, FmNoWait);
+  if (SPLIT) {
+#pragma unroll
+    for (int p = 0; p < PW; ++p) a[p] = *reinterpret_cast<const float4*>(wl + (size_t)(wave + 8 * p) * BLK);
+    __builtin_amdgcn_sched_barrier(0);
+    wait_b();
+  }
 #pragma unroll
   for (int p = 0; p < PW; ++p) {
     const int kb = wave + 8 * p;
-    a[p] = *reinterpret_cast<const float4*>(wl + (size_t)kb * BLK);
+    if (!SPLIT) a[p] = *reinterpret_cast<const float4*>(wl + (size_t)kb * BLK);
     const float4* sp = reinterpret_cast<const float4*>(p < PS ? seg0 : seg1);
     const int kl = p < PS ? kb : kb - 8 * PS;
 #pragma unroll
@@ -125,7 +135,7 @@ template <int NT, int NPART> struct FmRed { static constexpr int floats = 8 * NT
 
 // flags block in the workspace (ints): [0] done, [1] n_frames, [2] arrival ticket, [3] utterances below the stop
 // threshold, [4] iteration index of the first launch of the current graph replay, [6..7] 64-bit dropout seed
-enum { TF_DONE = 0, TF_NFRAMES = 1, TF_ARRIVE = 2, TF_NOTREADY = 3, TF_ITER = 4, TF_SEED = 6 };
+enum { TF_DONE = 0, TF_NFRAMES = 1, TF_ARRIVE = 2, TF_NOTREADY = 3, TF_ITER = 4, TF_LOST = 5, TF_SEED = 6, TF_LSTM_SYNC = 8 };  // [8..15]: taco_lstm2_kernel's hand-off counters, one per blockIdx.y; [5]: a hand-off timed out
 
 // ---- always-on PreNet dropout (pre_net.py:23,26) of a relu'd row quad; same masks / same Philox stream as the
 //      general paths (rnn_body.h): Philox(iter, layer, n, row/4); masks [iteration][column][row] per layer ----
