@@ -228,6 +228,25 @@ def test_gan_f16_unfused_path_matches_oracle(cuda, lib, monkeypatch, kind, cfg, 
     assert d["rel_rms"] <= F16_REL_TOL, d
 
 
+@pytest.mark.parametrize("kind,cfg,uic,frames,batch", [("hifigan", synth.HIFIGAN_16K, 512, 23, 2),
+                                                       ("fregan", synth.FREGAN_16K, 512, 12, 1)])
+def test_gan_f16_per_unit_launches_match_group_launches(cuda, lib, monkeypatch, kind, cfg, uic, frames, batch):
+    """MBHIP_GAN_NOSTAGE=1 + MBHIP_GAN_NOCHAIN=1 (read at create time): every ResBlock unit as its own mb_resblock_pair_f16
+    launch -- the production path of round 2, and today's path for any shape the one-launch stage / chain kernels do not take
+    -- against the oracle and against the default (narrow stages and k = 3 ResBlocks as one launch each).  Run twice: the unit
+    kernel keeps a bias block in LDS, consecutive launches carry different ones (see test_resblock_pair_gpu.py)."""
+    h = synth.small(cfg, uic)
+    grouped, ref = _run(kind, h, frames, batch, seed=5, dtype="f16")
+    monkeypatch.setenv("MBHIP_GAN_NOSTAGE", "1")
+    monkeypatch.setenv("MBHIP_GAN_NOCHAIN", "1")
+    for _ in range(2):
+        units, _ = _run(kind, h, frames, batch, seed=5, dtype="f16")
+        e = hiputil.relerr(units, ref)
+        assert e["nan"] == 0 and e["rel_rms"] <= F16_REL_TOL, e
+        d = hiputil.relerr(units, grouped)
+        assert d["rel_rms"] <= F16_REL_TOL, d
+
+
 @pytest.mark.parametrize("kind,cfg,uic,dtype", [("hifigan", synth.HIFIGAN_16K, 64, "f32"), ("fregan", synth.FREGAN_16K, 64, "f32"),
                                                 ("hifigan", synth.HIFIGAN_16K, 256, "f16"), ("fregan", synth.FREGAN_16K, 256, "f16")])
 def test_ragged_batch_equals_single_runs(cuda, lib, kind, cfg, uic, dtype):
