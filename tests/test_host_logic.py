@@ -217,3 +217,30 @@ def test_gan_out_samples_rule_24k():
     import numpy as np, os
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "gan24k.npz"))
     assert g["hifigan24k_uic64_f16_b2_s5"].shape[-1] == t == 4785
+
+
+def test_bench_traffic_floor_counts_every_launch_once():
+    """bench.gan_floor_bytes (the denominator of `traffic / floor` in DESIGN 4b'): read-x + write-y of every launch of an fp16
+    generator forward as the launcher in gan.hip issues them.  Hand count for HiFi-GAN V1 at 1 x 1 frame, and the Fre-GAN-only
+    launches (cond_up, x += mel, res_output (+ x)) on top of the shared structure."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(__file__), "..", "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    h = synth.HIFIGAN_16K
+    # conv_pre: 80 -> 512; stages (u, C): (5, 256) (5, 128) (4, 64) (2, 32); per stage: upsampler read + write, then
+    # 256 ch: 3 ResBlocks x 3 units x (read + write) + 2 accumulator reads; 128 / 64 ch: k = 3 is ONE launch (2) + 2 x 3 units x 2
+    # + 2 accumulator reads; 32 ch: one launch for the group (2); conv_post: read 32 ch, write fp32
+    T, el = 1, 2.0
+    want = (80 + 512) * el
+    C = 512
+    for u, per_elem in ((5, 18 + 2), (5, 2 + 12 + 2), (4, 2 + 12 + 2), (2, 2)):
+        want += T * C * el
+        T, C = T * u, C // 2
+        want += T * C * el + per_elem * T * C * el
+    want += T * C * el + T * 4.0
+    assert bench.gan_floor_bytes(h, 1, 1) == want
+    hf = synth.FREGAN_16K
+    base = bench.gan_floor_bytes(hf, 2, 7)
+    assert bench.gan_floor_bytes(hf, 2, 7, fregan=True) > base               # that generator's own launches
+    assert bench.gan_floor_bytes(hf, 4, 7, fregan=True) == 2 * bench.gan_floor_bytes(hf, 2, 7, fregan=True)  # linear in the batch
