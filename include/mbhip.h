@@ -42,6 +42,14 @@ extern "C" {
 typedef void* mb_stream_t;
 
 const char* mb_last_error(void);
+/* Version of this header's contract; bumped whenever the MEANING of an existing argument or the layout of a packed image
+ * changes (new symbols alone do not bump it).  Callers compare mb_abi_version() with the MB_ABI_VERSION they were built
+ * against (mockingbird_amd/_lib.py refuses a library that answers something else).
+ *   1: rounds 1-2.
+ *   2: mb_taco_config.dropout = 0 means the reference's 0.5 and a negative value disables dropout (was: 0 disables);
+ *      mb_conv1d_pack images carry the fp16 hi / lo fragments behind the fp32 ones; the uniform draws of the on-device RNGs
+ *      are centres of 2^23 cells (the same seed gives other dropout masks / samples than version 1). */
+#define MB_ABI_VERSION 2
 int mb_abi_version(void);
 
 /* ------------------------------------------------------------------------
@@ -101,6 +109,13 @@ typedef struct mb_conv1d_args {
 } mb_conv1d_args;
 
 int mb_conv1d(const mb_conv1d_args* a, mb_stream_t stream);
+
+/* Range diagnostics of the error-compensated path (no reference counterpart: the reference's fp32 Conv1d of
+ * models/vocoder/hifigan/models.py:11-48 has no such limit).  With MBHIP_CONV_RANGE_CHECK=1 in the environment every launch
+ * of that path counts the input values it stages with |x| > 131008 (both fp16 halves saturate there) or NaN / Inf into one
+ * word per device.  Returns the count of the current device (0 if the check never ran there), < 0 on a HIP error;
+ * reset != 0 clears it.  Synchronises the device. */
+long long mb_conv1d_range_events(int reset);
 
 /* ------------------------------------------------------------------------
  * 1b. fp16 Conv1d / ConvTranspose1d primitive (fp16 storage, fp32 accumulate on
@@ -334,7 +349,12 @@ int mb_wavernn_plan_generate(const mb_wavernn* w, int frames, int batched, int t
  * d_forced: optional teacher forcing: [n_folds][seq_len] samples fed back
  *        instead of the drawn ones (tests).
  * h_progress: optional host-visible (pinned/host-coherent) int32 the kernels
- *        update with the number of completed steps (progress_callback support). */
+ *        update with the number of completed steps (progress_callback support).
+ * HOST-BLOCKING on the default path: for 1..32 fold columns the loop is ONE resident launch (wavernn_persist.h /
+ *        wavernn_pipe.h) whose 192 / 224 workgroups must be co-resident; the call waits for the launch and reads its
+ *        abort word (a lost hand-off -> the launch chain recomputes the same samples, and the device is remembered as
+ *        unsuitable), so it returns with the samples complete on `stream`.  Wider calls (the launch chain, hipGraph replays)
+ *        are stream-asynchronous as before; MBHIP_WAVERNN_PIPE=0 MBHIP_WAVERNN_PERSIST=0 selects the chain for every width. */
 int mb_wavernn_generate(const mb_wavernn* w, const mb_wavernn_plan* plan,
                         const float* d_mel, const float* d_noise, uint64_t seed,
                         float* d_samples, float* d_logits_out, const float* d_forced,
@@ -503,6 +523,9 @@ size_t mb_ppg2mel_workspace_bytes(const mb_ppg2mel* p, int batch);
  * [max_steps][batch][prenet_dims[l]] inside; NULL -> Philox(seed).  Outputs are per step, untruncated:
  * d_mel [batch][max_steps][frames_per_step*num_mels], d_align [batch][max_steps][t_enc],
  * d_stop [batch][max_steps] (logits); *h_n_steps = steps produced. */
+/* mb_ppg2mel_decode is HOST-BLOCKING (it returns *h_n_steps): batch 1 runs the resident launch of ppg_resident.h and reads its
+ * abort word behind it (a lost hand-off -> the 6-launch chain redoes the utterance), wider batches poll the stop flag.
+ * The same holds for mb_taco_encode / mb_taco_decode's CBHG GRU scans (gru_scan.h): one stream synchronisation per CBHG. */
 /* Duration of the decoder loop of the last mb_ppg2mel_decode call (HIP events on the loop's stream) and the steps it
  * produced; production-dims handles only (the graph-replayed step of ppg_fast.h), MB_ESTATE otherwise. */
 int mb_ppg2mel_last_loop_ms(const mb_ppg2mel* p, float* ms, int* steps);

@@ -147,6 +147,7 @@ SIGNATURES = {
     "mb_conv1d_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_void_p]),
     "mb_conv1d": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "mb_conv1d_range_events": (C.c_longlong, [C.c_int]),
     "mb_conv1d_f16_packed_halves": (C.c_size_t, [C.c_int] * 4),
     "mb_conv1d_f16_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_void_p]),
@@ -244,6 +245,9 @@ SIGNATURES = {
 _lib = None
 
 
+ABI_VERSION = 2  # include/mbhip.h: MB_ABI_VERSION
+
+
 def lib():
     """Load (once) and return the ctypes library; raises if it is not built."""
     global _lib
@@ -261,6 +265,9 @@ def lib():
             fn = getattr(l, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
+        if l.mb_abi_version() != ABI_VERSION:  # a stale .so: argument meanings / packed images differ (include/mbhip.h)
+            raise MbHipError(f"{LIB_PATH} answers ABI version {l.mb_abi_version()}, this package needs {ABI_VERSION}: rebuild it "
+                             "(python -m mockingbird_amd.build --force)")
         _lib = l
     return _lib
 

@@ -41,4 +41,4 @@ void DevBuf::release() {
 }  // namespace mb
 
 extern "C" const char* mb_last_error(void) { return mb::g_err; }
-extern "C" int mb_abi_version(void) { return 1; }
+extern "C" int mb_abi_version(void) { return MB_ABI_VERSION; }

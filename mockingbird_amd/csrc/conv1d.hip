@@ -39,6 +39,7 @@ struct ConvK {
   int out_act, accumulate, in_repeat;
   float out_scale, out_slope;
   const int* valid; int valid_mul;  // ragged batches (mb_conv1d_args.d_valid)
+  unsigned* range_events;           // diagnostics (MBHIP_CONV_RANGE_CHECK=1): staged values beyond the split path's range are counted here
 };
 
 template <int WM, int WN, bool TR>
@@ -203,6 +204,7 @@ static constexpr int SROW = SCK * 4 + 16;  // bytes per staged position
 // dealt evenly over the 256 threads, every stride is hoisted, and the epilogue has a straight-line path for interior tiles.
 static constexpr int SNT = 128;    // output positions per workgroup
 static constexpr int SITEMS = 4;   // (position, 8-channel group) items per thread and chunk: rowlen <= 256
+static constexpr float SPLIT_RANGE = 131008.f;  // |x| beyond this saturates both fp16 halves (the clamp of split_store2)
 
 __device__ __forceinline__ void split_store2(char* row, const int grp, const float (&v)[8]) {
   h16x8 hi, lo;
@@ -292,6 +294,12 @@ __global__ __launch_bounds__(256) void conv1d_split_kernel(ConvK a, const uint4*
           x = x > 0.f ? x : x * slope_eff;        // leaky_relu, slope_eff = 1 when there is no input activation: exact
         }
         v[e] = x;
+      }
+      if (a.range_events) {  // diagnostics only (uniform branch): the hi / lo halves saturate beyond 2 x 65504
+        int n_out = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) n_out += !(fabsf(v[e]) <= SPLIT_RANGE) ? 1 : 0;  // counts NaN / Inf as well
+        if (n_out) atomicAdd(a.range_events, (unsigned)n_out);
       }
       split_store2(slds + boff + lds_off[it], 0, v);
     }
@@ -541,6 +549,35 @@ extern "C" int mb_conv1d_pack(const float* h_w, int c_out, int c_in, int ksize, 
   return MB_OK;
 }
 
+// Range diagnostics of the split path: with MBHIP_CONV_RANGE_CHECK=1 every conv1d_split_kernel launch
+// counts the staged input values with |x| > 131008 (or NaN / Inf) -- values the fp32 reference would carry and the hi / lo
+// clamp saturates silently -- into one device word per device; mb_conv1d_range_events reads (and optionally clears) it.
+static unsigned* g_range_word[16] = {};
+static unsigned* range_word() {
+  const char* e = getenv("MBHIP_CONV_RANGE_CHECK");
+  if (!e || atoi(e) == 0) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!g_range_word[dev]) {
+    unsigned* p = nullptr;
+    if (hipMalloc(&p, sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, sizeof(unsigned)) != hipSuccess) { (void)hipFree(p); return nullptr; }
+    g_range_word[dev] = p;
+  }
+  return g_range_word[dev];
+}
+
+extern "C" long long mb_conv1d_range_events(int reset) {
+  int dev = 0;
+  MB_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16 || !g_range_word[dev]) return 0;  // the check never ran on this device
+  unsigned v = 0;
+  MB_HIP(hipDeviceSynchronize());
+  MB_HIP(hipMemcpy(&v, g_range_word[dev], sizeof(unsigned), hipMemcpyDeviceToHost));
+  if (reset) MB_HIP(hipMemset(g_range_word[dev], 0, sizeof(unsigned)));
+  return (long long)v;
+}
+
 extern "C" int mb_conv1d(const mb_conv1d_args* a, mb_stream_t stream) {
   MB_REQUIRE(a && a->d_x && a->d_wpacked && a->d_y, "conv1d: null pointer");
   MB_REQUIRE(!a->transpose_out || a->up == 1, "conv1d: transpose_out needs up==1");
@@ -560,6 +597,7 @@ extern "C" int mb_conv1d(const mb_conv1d_args* a, mb_stream_t stream) {
   k.out_scale = a->out_scale == 0.f ? 1.f : a->out_scale;
   k.out_slope = a->out_slope;
   k.valid = a->d_valid; k.valid_mul = a->valid_mul > 0 ? a->valid_mul : 1;
+  k.range_events = range_word();
   MB_REQUIRE(k.in_repeat == 1 || a->t_in % k.in_repeat == 0, "conv1d: t_in %% in_repeat != 0");
   if (a->batch <= 0 || a->t_out <= 0) return MB_OK;
 
@@ -578,8 +616,9 @@ extern "C" int mb_conv1d(const mb_conv1d_args* a, mb_stream_t stream) {
     dim3 grid(cdiv(tq, SNT), cdiv(n_mt, wm), a->batch * a->up);
     const int rowlen = SNT * k.down + k.span;
     const char* l2env = getenv("MBHIP_CONV_SPLIT_LDS2");  // A/B: force one (0) or two (1) x-tile buffers
-    const int nbuf = l2env ? (atoi(l2env) == 1 && k.c_in > SCK ? 2 : 1) : (k.c_in >= 512 ? 2 : 1);
-    const size_t lds = (size_t)nbuf * rowlen * SROW;
+    int nbuf = l2env ? (atoi(l2env) == 1 && k.c_in > SCK ? 2 : 1) : (k.c_in >= 512 ? 2 : 1);
+    if ((size_t)nbuf * rowlen * SROW > 64 * 1024) nbuf = 1;  // two buffers of a long window (rowlen > 227) would pass the 64 KB a
+    const size_t lds = (size_t)nbuf * rowlen * SROW;          // launch gets without hipFuncSetAttribute; one always fits (<= 36 KB)
     const bool fits32 = (long long)a->c_in * a->t_in < (1ll << 31) && (long long)a->c_out * a->t_out < (1ll << 31);  // 32-bit offsets inside an item
     if (rowlen <= 256 && fits32) {  // (strided convs with long halos, giant items: the fp32-input kernel below)
       const bool pool = a->in_act == 2;

@@ -18,6 +18,7 @@
 // after consuming every tag t.  Every spin has the wall-clock bail-out of granule.h: a lost hand-off raises the abort word, the
 // launch drains, and the host runs the launch-per-step scan instead (MBHIP_GRU_SCAN=0 selects that one outright).
 #pragma once
+#include <atomic>
 #include <type_traits>
 #include "granule.h"
 
@@ -296,18 +297,36 @@ static inline int gru_scan_scale_exp(const float* w, size_t n) {
   if (!(wmax > 0.f) || !std::isfinite(wmax)) return 0;
   int e2;
   (void)std::frexp(wmax, &e2);  // wmax = m 2^e2, m in [0.5, 1)
-  return 14 - e2;
+  return std::max(-24, std::min(40, 14 - e2));  // clamped like mb_conv1d_pack's: a degenerate (denormal) W_hh must not scale to inf
 }
 
 static inline bool gru_scan_shape_ok(int B, int Hg) { return B >= 1 && B <= 32 && (Hg == 128 || Hg == 256); }
 
+// Devices on which a resident scan lost a hand-off (or failed to launch): later calls go straight to the launch-per-step scan
+// instead of spinning 0.2 s again (the memo wavernn.hip / ppg2mel.hip keep for their resident loops).  Bit d = device d.
+static std::atomic<unsigned long long> g_gru_scan_failed{0};
+static inline bool gru_scan_device_failed() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  return (g_gru_scan_failed.load(std::memory_order_relaxed) >> dev) & 1ull;
+}
+static inline void gru_scan_mark_failed() {
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) g_gru_scan_failed.fetch_or(1ull << dev, std::memory_order_relaxed);
+}
+
 template <int KS, int NT, int NW>
 static int gru_scan_launch_inst(const GruScanK& k, hipStream_t s) {
   const size_t lds = (size_t)2 * 2 * (NT * 16) * (KS * 32 + 8) * sizeof(gs_h16);
-  static bool attr_done = false;
-  if (!attr_done) {
+  // the attribute belongs to the function ON THE CURRENT DEVICE: tracked per device (a process-wide flag left a second
+  // device's first launch without it), atomically (two host threads may encode at once; setting it twice is harmless)
+  static std::atomic<unsigned long long> attr_done{0};  // bit d = set on device d
+  int dev = 0;
+  MB_HIP(hipGetDevice(&dev));
+  const unsigned long long bit = dev >= 0 && dev < 64 ? 1ull << dev : 0ull;
+  if (!bit || !(attr_done.load(std::memory_order_acquire) & bit)) {
     MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_scan_kernel<KS, NT, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    attr_done = true;
+    attr_done.fetch_or(bit, std::memory_order_release);
   }
   hipLaunchKernelGGL((gru_scan_kernel<KS, NT, NW>), dim3(2 * (KS * 32) / (NW * 16)), dim3(NW * 64), lds, s, k);
   MB_HIP(hipGetLastError());

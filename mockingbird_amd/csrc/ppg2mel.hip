@@ -12,6 +12,7 @@
 //   -> decoder LSTMCell(s) [att_h, context, h] -> projection (+ stop row) -> ppg_finalize_kernel
 // (frames / stop logits to the outputs, batch-wide stop rule).  The next step's prenet reads the last
 // frame straight out of the projection buffer.  fp32 throughout.
+#include <atomic>
 #include "rnn.h"
 #include "ppg_fast.h"
 #include "ppg_resident.h"
@@ -167,7 +168,7 @@ struct mb_ppg2mel {
 };
 
 // a resident launch (ppg_resident.h) once lost a hand-off on this device: stop defaulting to it there
-static bool g_ppg_resident_failed[64] = {};
+static std::atomic<bool> g_ppg_resident_failed[64] = {};  // written by whichever host thread sees the abort word: atomic
 
 static int ppg_shapes(const mb_ppg2mel_config* c, std::vector<size_t>* numel) {
   MB_REQUIRE(c, "ppg2mel: null config");

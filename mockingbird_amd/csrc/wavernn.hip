@@ -24,6 +24,7 @@
 //     T1[pos] + x*(W_ih1.W_I[:,0]) with T1 one more per-position table, so once the sample x is
 //     known rnn1 is ELEMENTWISE (wavernn_gru1_finish_kernel) and rnn2 only multiplies its input
 //     half (K = 512 instead of 1024).  Still 5 launches per step, about half the bytes on the chain.
+#include <atomic>
 #include "rnn.h"
 #include "wavernn_fast.h"
 #include "wavernn_persist.h"
@@ -293,7 +294,7 @@ struct mb_wavernn {
 };
 
 // a resident launch (wavernn_persist.h / wavernn_pipe.h) once lost a hand-off on this device: stop defaulting to them there
-static bool g_resident_failed[64] = {};
+static std::atomic<bool> g_resident_failed[64] = {};  // written by whichever host thread sees the abort word: atomic
 
 static int wavernn_shapes(const mb_wavernn_config* c, std::vector<size_t>* numel) {
   MB_REQUIRE(c, "wavernn: null config");

@@ -174,7 +174,8 @@ class GanFacade:
                       sample rate, which differs from this vocoder's for the 24 kHz generator (default: this
                       vocoder's output rate);
           normalize = 0.97 -> wav / abs(wav).max() * 0.97 (gen_voice.py:41);
-          pcm16 = 'sndfile' | 'encode_16bits' | 'save_wav' -> int16 PCM (run.py:91).
+          pcm16 = 'encode_16bits' | 'save_wav' (both pinned by goldens of the reference functions) | 'sndfile' (libsndfile's
+                  PCM_16 of run.py:91, restated WITHOUT a pin: by name only) -> int16 PCM.
         device_out=True returns the device tensors themselves (for a device-to-device gather) instead of numpy."""
         if self.generator is None:
             raise Exception(f"Please load {self.name} in memory before using it")

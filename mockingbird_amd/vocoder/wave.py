@@ -42,10 +42,12 @@ def peak_normalize_(wav: torch.Tensor, target: float = 0.97) -> torch.Tensor:
     return wav
 
 
-def pack_pcm16(wav: torch.Tensor, mode: str = "sndfile") -> torch.Tensor:
-    """float waveform -> int16 tensor of the same shape.  mode: 'sndfile' (PCM_16 as libsndfile writes it,
-    run.py:91), 'encode_16bits' (wavernn/audio.py:38-39), 'save_wav' (synthesizer/audio.py:12-15, rescales
-    the peak to 32767)."""
+def pack_pcm16(wav: torch.Tensor, mode: str = "encode_16bits") -> torch.Tensor:
+    """float waveform -> int16 tensor of the same shape.  mode: 'encode_16bits' (wavernn/audio.py:38-39; the default),
+    'save_wav' (synthesizer/audio.py:12-15, rescales the peak to 32767) -- both pinned bit-exactly by goldens from the
+    reference functions -- or 'sndfile' (PCM_16 as libsndfile writes it, run.py:91): a restatement WITHOUT a pin
+    (libsndfile is neither vendored by the reference nor installed here), so it is never a default and has to be asked
+    for by name."""
     if mode not in _MODES:
         raise ValueError(f"mode must be one of {sorted(_MODES)}, got {mode!r}")
     dt = _dtype(wav)

@@ -300,7 +300,7 @@ def infer_waveform_batch(mels, normalize=True, target=8000, overlap=800, seeds=N
       breaks[i] = frames per sentence of item i, cut at frames * break_hop samples + break_seconds of silence
                   (gen_voice.py:30-34; gap length from break_sample_rate, default this vocoder's rate);
       peak_normalize = 0.97 -> wav / abs(wav).max() * 0.97 (gen_voice.py:41);
-      pcm16 = 'encode_16bits' | 'save_wav' | 'sndfile' -> int16 PCM;
+      pcm16 = 'encode_16bits' | 'save_wav' (pinned by goldens) | 'sndfile' (unpinned restatement of libsndfile, by name only) -> int16 PCM;
       device_out=True keeps the results in HBM (device-to-device gather)."""
     if _model is None:
         raise Exception("Please load Wave-RNN in memory before using it")

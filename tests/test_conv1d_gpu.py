@@ -65,6 +65,61 @@ def test_split_kernel_is_fp32_grade(cuda, lib, monkeypatch):
         assert e_split <= max(4 * e_f32, 2e-6), (name, e_split, e_f32)
 
 
+def test_split_kernel_small_activation_stage(cuda, lib, monkeypatch, capsys):
+    """a stage whose activations are SMALL (|x| ~ 1e-3, what the narrow late stages of a trained
+    generator can carry) -- there the low halves xl = fp16(x - xh) are fp16 subnormals (an absolute 3e-8 per value, i.e.
+    ~2^-15 relative instead of 2^-22).  The error-compensated kernel is measured against float64 beside the exact
+    fp32-input kernel; its error must stay below 1e-4 of the output RMS (the audio gate's size) and is reported, so the
+    cost of the un-scaled activations is on record.  Also |x| ~ 3e-2 (lo halves partly normal)."""
+    g = torch.Generator().manual_seed(11)
+    out = {}
+    for name, xs in (("1e-3", 1e-3), ("3e-2", 3e-2)):
+        x = torch.randn(2, 128, 400, generator=g) * xs
+        w = torch.randn(128, 128, 7, generator=g) / (128 * 7) ** 0.5
+        ref = F.conv1d(F.leaky_relu(x.double(), 0.1), w.double(), None, padding=3)
+        scale = float(ref.abs().pow(2).mean().sqrt())
+        monkeypatch.delenv("MBHIP_CONV_SPLIT", raising=False)
+        e_split = float((hiputil.conv1d_hip(x, w, None, pad=3, in_act=1, in_slope=0.1).cpu().double() - ref).abs().max()) / scale
+        monkeypatch.setenv("MBHIP_CONV_SPLIT", "0")
+        e_f32 = float((hiputil.conv1d_hip(x, w, None, pad=3, in_act=1, in_slope=0.1).cpu().double() - ref).abs().max()) / scale
+        out[name] = (e_split, e_f32)
+        assert e_split <= 1e-4, (name, e_split, e_f32)
+    with capsys.disabled():
+        print("\n[split conv, small activations] max err / output rms (split, fp32-input kernel):", out)
+
+
+def test_split_kernel_range_counter(cuda, lib, monkeypatch):
+    """The hi / lo halves saturate at fp16's 65504 each: |x| > 131008 is silently clamped where the reference's fp32 conv is
+    not.  MBHIP_CONV_RANGE_CHECK=1 counts such values (and NaN / Inf) as they are staged; in-range data counts nothing."""
+    L = lib
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 32, 200, generator=g)
+    w = torch.randn(32, 32, 3, generator=g) / 10.0
+    monkeypatch.delenv("MBHIP_CONV_SPLIT", raising=False)
+    monkeypatch.setenv("MBHIP_CONV_RANGE_CHECK", "1")
+    hiputil.conv1d_hip(x, w, None, pad=1)
+    assert L.mb_conv1d_range_events(1) == 0
+    x2 = x.clone()
+    x2[0, 3, 50] = 2.0e5
+    x2[0, 7, 120] = -1.5e5
+    x2[0, 9, 10] = 1.3e5  # inside the range: hi = 65504, lo = 64496
+    y = hiputil.conv1d_hip(x2, w, None, pad=1)
+    n = L.mb_conv1d_range_events(1)
+    assert 2 <= n <= 4, n  # each bad value is staged once per workgroup whose window holds it (128 positions + halo each)
+    assert L.mb_conv1d_range_events(0) == 0  # cleared
+    ref = F.conv1d(x2, w, None, padding=1)
+    good = torch.ones(200, dtype=torch.bool)
+    for t in (10, 50, 120):
+        good[t - 1:t + 2] = False
+    d = (y.cpu() - ref).abs()
+    assert float(d[:, :, good].max()) < 1e-4   # untouched positions
+    assert float(d[:, :, 9:12].max()) < 8.0    # 1.3e5 is in range: hi = 65504, lo = 64496 rounded to fp16 (ulp 32) -> ~16 x |w|
+    assert float(d[:, :, 49:52].max()) > 100.0  # 2e5 was clamped to 131008: this is the silent saturation the counter reports
+    monkeypatch.setenv("MBHIP_CONV_RANGE_CHECK", "0")
+    hiputil.conv1d_hip(x2, w, None, pad=1)
+    assert L.mb_conv1d_range_events(0) == 0  # off: nothing counted
+
+
 @pytest.mark.parametrize("B,Cin,Cout,T,k,dil", CONV_CASES)
 def test_conv1d_same(cuda, lib, conv_path, B, Cin, Cout, T, k, dil):
     x = _rand(B, Cin, T, seed=1)

@@ -207,6 +207,9 @@ def test_wave_wire_format_has_no_cpu_path(lib):
     with pytest.raises(ValueError, match="mode must be one of"):
         wave.pack_pcm16(torch.zeros(8), "pcm24")
     assert lib.mb_wave_workspace_bytes() >= 8
+    # the default encoding is one pinned by a golden of the reference function; the unpinned libsndfile restatement is by name only
+    import inspect
+    assert inspect.signature(wave.pack_pcm16).parameters["mode"].default == "encode_16bits"
 
 
 def test_gan_out_samples_rule_24k():

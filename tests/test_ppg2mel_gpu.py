@@ -62,6 +62,37 @@ def test_decode_matches_oracle_at_the_benchmarked_shape(cuda, lib):
         assert float((al - oal).abs().max()) <= ALIGN_TOL and float((stop - ostop).abs().max()) <= 1e-2
 
 
+@pytest.mark.parametrize("B", [1, 32])
+def test_all_400_steps_at_the_benchmarked_shape_vs_oracle(cuda, lib, capsys, B):
+    """bench.py's ppg2mel object over its WHOLE length: T_enc = 200, 400 decoder steps (stop bias -8:
+    the oracle runs to max_step = T * encoder_down_factor / r = 400 as well), the default path -- batch 1 = ONE resident
+    launch (ppg_resident.h), batch 32 = the default batch loop -- against rnn_decoder_mol.py:318-360 restated in
+    oracle/ppg2mel.py with the same injected prenet masks.  The loop feeds its own frames back: the error over the first
+    48 / 200 / 400 steps is reported so growth is visible."""
+    from mockingbird_amd.ppg2mel import Ppg2MelDecoder
+    w = synth.ppg2mel_decoder_state(synth.PPG2MEL_HP, seed=6, stop_bias=-8.0)
+    dec = Ppg2MelDecoder(w, synth.PPG2MEL_HP)
+    T, steps = 200, 400
+    mem = torch.from_numpy(synth.ppg2mel_memory(B, T, seed=7 + B))
+    masks = synth.ppg2mel_dropout_masks(5, steps, B)
+    with torch.no_grad():
+        omel, oal, ostop = op.inference_batched(w, dict(op.HP), mem, masks=op.MaskSource(list(masks)))
+    assert oal.shape[1] == steps, oal.shape  # never stopped early
+    mel, al, stop = dec.decode(mem.cuda(), dropout=masks)
+    if B == 1:
+        assert dec.last_loop_launches == 1  # the resident launch is what ran
+    mel, al, stop = mel.cpu().reshape(B, -1, 80), al.cpu(), stop.cpu()
+    assert mel.shape == omel.shape and al.shape == oal.shape and stop.shape == ostop.shape, (mel.shape, omel.shape, al.shape, oal.shape)
+    d = (mel - omel).abs()
+    r = mel.shape[1] // steps
+    g = {n: float(d[:, :n * r].max()) for n in (48, 200, 400)}
+    ea, es = float((al - oal).abs().max()), float((stop - ostop).abs().max())
+    with capsys.disabled():
+        print(f"\n[ppg2mel B={B}, 400 steps] mel max|d| @48/200/400 = {g[48]:.2e} / {g[200]:.2e} / {g[400]:.2e}; alignment {ea:.2e}; stop {es:.2e}")
+    assert torch.isfinite(mel).all() and g[400] <= MEL_TOL and ea <= ALIGN_TOL and es <= 1e-2, (g, ea, es)
+    assert float(omel.abs().mean()) > 0.05
+
+
 @pytest.mark.parametrize("T,wseed,sb,mseed", [(30, 3, -2.0, 1), (26, 4, 0.0, 2), (200, 6, -8.0, 8), (301, 5, -1.0, 9)])
 def test_resident_loop_matches_oracle_and_the_chain(cuda, lib, monkeypatch, T, wseed, sb, mseed):
     """ppg_resident.h: one utterance = ONE launch (217 resident workgroups, weights in LDS, granule hand-offs) against the

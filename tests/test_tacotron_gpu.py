@@ -221,6 +221,73 @@ def test_baseline_config2_b32_decode_matches_oracle(model):
     _decode_vs_oracle(dev, w, ot.HP, 2, mem, memp, chars, 40, mask_seed=17)
 
 
+def _growth(a, b, frames):
+    """max |a - b| over the frames up to each mark (the loop is autoregressive: growth of the error must be visible)."""
+    d = (a.detach().cpu().float() - b.detach().cpu().float()).abs()
+    return {f: float(d[:, :, :f].max()) for f in frames}
+
+
+def test_baseline_config2_full_length_vs_oracle(model, capsys):
+    """BASELINE configs[2] at the size bench.py times: B = 32, T in [90, 110], r = 2, steps = 400,
+    min_stop_token = 11 -> all 200 decoder iterations (hipGraph replays of the 7-launch iteration, taco_fast.h) and the CBHG
+    postnet with the resident gru_scan_kernel<8, 2, 4> over 400 frames, through the DEFAULT path, against
+    oracle.tacotron.decode + postnet (tacotron.py:264-283, sublayer/cbhg.py:76-77) on the same injected masks.
+    Gates: mel / linear max|delta| <= 1e-3 over ALL 400 frames, attention <= 1e-4; the error at frames 40 / 200 / 400 is
+    reported and may not grow by more than 8x from frame 40 to frame 400 (the loop feeds its own output back)."""
+    dev, w = model
+    chars, spk, _, _ = _batch(32, 90, 110, seed=2)
+    torch.manual_seed(1)
+    with torch.no_grad():
+        mem, memp = ot.encoder_memory(w, ot.HP, chars, spk, -1)
+    steps, B = 400, 32
+    masks = synth.decoder_dropout_masks(17, steps // 2, B)
+    src = ot.MaskSource([masks[i, l] for i in range(steps // 2) for l in range(2)])
+    with torch.no_grad():
+        omel, oattn = ot.decode(w, ot.HP, 2, mem, memp, chars, steps, 11.0, src)
+        olin = ot.postnet(w, ot.HP, omel)
+    mel, lin, attn = dev.decode(mem.cuda(), memp.cuda(), chars.cuda(), steps, 11.0, dropout=masks)
+    assert mel.shape == omel.shape == (B, 80, steps) and lin.shape == olin.shape and attn.shape == oattn.shape == (B, steps // 2, chars.shape[1])
+    gm, gl = _growth(mel, omel, (40, 200, 400)), _growth(lin, olin, (40, 200, 400))
+    ga = float((attn.cpu() - oattn).abs().max())
+    with capsys.disabled():
+        print(f"\n[taco full length] mel max|d| @40/200/400 = {gm[40]:.2e} / {gm[200]:.2e} / {gm[400]:.2e}; "
+              f"linear = {gl[40]:.2e} / {gl[200]:.2e} / {gl[400]:.2e}; attention = {ga:.2e}")
+    for name, a, b, tol in (("mel", mel, omel, MEL_TOL), ("linear", lin, olin, MEL_TOL), ("attn", attn, oattn, 1e-4)):
+        e = hiputil.relerr(a, b)
+        assert e["nan"] == 0 and e["max_abs"] <= tol, (name, e, gm, gl)
+    assert gm[400] <= 8 * max(gm[40], 2e-5), gm  # no runaway feedback error
+    assert float(omel.abs().mean()) > 0.1
+
+
+def test_baseline_config2_full_length_facade_chunk32_vs_oracle(model, tmp_path, capsys):
+    """The same 32 utterances x 400 frames through the FACADE with chunk_size=32 (one padded batch, one decoder loop;
+    inference.py:104-142 with hparams.synthesis_batch_size raised): encoder (resident gru_scan_kernel<4, 2, 8>) + GST + 200
+    iterations + postnet + tail trim against oracle.synthesize_spectrograms with synthesis_batch_size = 32, every mask injected."""
+    from mockingbird_amd.synthesizer.inference import Synthesizer
+    dev, w = model
+    torch.save(synth.tacotron_state(seed=3), tmp_path / "taco.pt")
+    syn = Synthesizer(tmp_path / "taco.pt", verbose=False)
+    chars, spk, seqs, emb = _batch(32, 90, 110, seed=2)
+    T, B, steps = chars.shape[1], 32, 400
+    g = torch.Generator().manual_seed(5)
+    enc_masks = [torch.empty(B, T, 256).bernoulli_(0.5, generator=g) for _ in range(2)]
+    masks = synth.decoder_dropout_masks(13, steps // 2, B)
+    src = ot.MaskSource(enc_masks + [masks[i, l] for i in range(steps // 2) for l in range(2)])
+    hp32 = dict(ot.HP, synthesis_batch_size=32)
+    ospecs, oal = ot.synthesize_spectrograms(w, hp32, 2, seqs, emb, style_idx=-1, min_stop_token=11, steps=steps, masks=src)
+    specs, al = syn.synthesize_from_tokens(seqs, emb, style_idx=-1, min_stop_token=11, steps=steps,
+                                           enc_masks=torch.stack(enc_masks), dropout=masks, chunk_size=32)
+    assert len(specs) == len(ospecs) == B and tuple(al.shape) == tuple(oal.shape) == (B, steps // 2, T)
+    worst = 0.0
+    for a, b in zip(specs, ospecs):
+        assert a.shape == b.shape and a.dtype == np.float32 and a.shape[1] > 300
+        worst = max(worst, float(np.abs(a - b).max()))
+    ea = float((torch.as_tensor(al).cpu() - oal).abs().max())
+    with capsys.disabled():
+        print(f"\n[taco full length, facade chunk_size=32] mel max|d| = {worst:.2e}, attention = {ea:.2e}")
+    assert worst <= MEL_TOL and ea <= 1e-4, (worst, ea)
+
+
 @pytest.mark.parametrize("B,tmin,tmax", [(2, 140, 150), (3, 200, 220), (2, 290, 300), (1, 640, 640)])
 def test_long_text_attention_kernels_match_oracle(model, B, tmin, tmax):
     """T = 150 -> lsa_fast_kernel<48>; T = 220 / 300 / 640 -> the general lsa_kernel (location window in dynamic LDS,

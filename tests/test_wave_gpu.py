@@ -76,5 +76,8 @@ def test_errors(cuda, lib):
     with pytest.raises(ValueError, match="zero-size"):
         wave.peak_normalize_(torch.zeros(0, device="cuda"))
     assert wave.pack_pcm16(torch.zeros(0, device="cuda")).numel() == 0
+    # default mode = the pinned encode_16bits (wavernn/audio.py:38-39), not the unpinned libsndfile restatement
+    y = torch.linspace(-1.2, 1.2, 4097, device="cuda")
+    assert torch.equal(wave.pack_pcm16(y), wave.pack_pcm16(y, "encode_16bits"))
     # all-zero waveform: the reference's 0/0 -> NaN
     assert bool(torch.isnan(wave.peak_normalize_(torch.zeros(8, device="cuda"))).all())
