@@ -179,16 +179,21 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvK a) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // The same implicit GEMM on the fp16 matrix pipe with error compensation ("split" path, the default for c_in >= 16):
-//   x = xh + xl,  w * 2^s = wh + wl   (xh = fp16(x), xl = fp16(x - xh); s per conv so that max |w| 2^s is in [2^13, 2^14))
-//   acc += wh.xh + wh.xl + wl.xh      three v_mfma_f32_32x32x16_f16 per (16 channels, tap), fp32 accumulate,
-//   y = acc * 2^-s ...                the dropped wl.xl term is 2^-22 of a product: fp32-grade results (each operand keeps
-//                                     22 bits; an |x| below 0.125 keeps an absolute 3e-8 instead -- fp16 subnormals)
-// at 1/5.3 of the matrix-pipe time of the fp32-input MFMA (3 x 32 cycles per 32x32x16 block instead of 8 x 64).
-// Range: |x| <= 131008 (hi and lo both saturate at fp16's 65504; the audio / mel activations of this path are O(1..100)).
+//   w * 2^s = wh + wl          (wh = fp16(w 2^s), wl = fp16(w 2^s - wh); s per conv so that max |w| 2^s is in [2^13, 2^14):
+//                               the low halves of all but negligible weights are fp16 normals)
+//   x = xh + 2^-11 xl          (xh = fp16(x), xl = fp16((x - xh) 2^11): the residual is stored SCALED, so it is an fp16 normal
+//                               whenever xh is -- round 3 stored it unscaled and a stage with |x| ~ 1e-3 kept 14 bits, not 22:
+//                               1.1e-4 of the output RMS against 6e-6 for the fp32-input kernel, tests/test_conv1d_gpu.py)
+//   acc += wl.xh + ws.xl + wh.xh   with the third weight image ws = fp16(wh 2^-11): three v_mfma_f32_32x32x16_f16 per
+//                               (16 channels, tap), fp32 accumulate;  y = acc * 2^-s ...
+// The dropped wl.xl term is 2^-22 of a product and each operand keeps 22 bits down to |x| = 2^-14 (an absolute 2^-36 below):
+// fp32-grade results at 1/5.3 of the matrix-pipe time of the fp32-input MFMA (3 x 32 cycles per 32x32x16 block instead of 8 x 64).
+// Range: |x| <= 65536 (xh saturates at fp16's 65504, the scaled residual right behind it; audio / mel activations are O(1..100));
+// MBHIP_CONV_RANGE_CHECK=1 counts the values beyond it (mb_conv1d_range_events).
 // MBHIP_CONV_SPLIT=0 selects the exact fp32-input kernel above (tests/test_conv1d_gpu.py runs both).
 // Layout: x staged per chunk of SCK = 32 channels as [position][32 hi | 32 lo | pad] fp16 rows of 144 bytes (16-byte
 // B fragments = 8 consecutive channels of one position, conflict-free for ds_read_b128 / ds_write_b128: 144 / 16 is odd);
-// weights pre-split on the host in A-fragment order [phase][mt][16-channel step][tap][hi | lo][lane][8].
+// weights pre-split on the host in A-fragment order [phase][mt][16-channel step][tap][hi | lo | hi 2^-11][lane][8].
 typedef _Float16 h16;
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 static constexpr int SCK = 32;
@@ -204,7 +209,7 @@ static constexpr int SROW = SCK * 4 + 16;  // bytes per staged position
 // dealt evenly over the 256 threads, every stride is hoisted, and the epilogue has a straight-line path for interior tiles.
 static constexpr int SNT = 128;    // output positions per workgroup
 static constexpr int SITEMS = 4;   // (position, 8-channel group) items per thread and chunk: rowlen <= 256
-static constexpr float SPLIT_RANGE = 131008.f;  // |x| beyond this saturates both fp16 halves (the clamp of split_store2)
+static constexpr float SPLIT_RANGE = 65536.f;  // |x| beyond this saturates both fp16 halves (the clamps of split_store2)
 
 __device__ __forceinline__ void split_store2(char* row, const int grp, const float (&v)[8]) {
   h16x8 hi, lo;
@@ -212,7 +217,7 @@ __device__ __forceinline__ void split_store2(char* row, const int grp, const flo
   for (int e = 0; e < 8; ++e) {
     const h16 h = (h16)__builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
     hi[e] = h;
-    lo[e] = (h16)__builtin_amdgcn_fmed3f(v[e] - (float)h, -65504.f, 65504.f);
+    lo[e] = (h16)__builtin_amdgcn_fmed3f((v[e] - (float)h) * 2048.f, -65504.f, 65504.f);  // residual scaled by 2^11: a normal whenever hi is
   }
   *reinterpret_cast<h16x8*>(row + grp * 16) = hi;
   *reinterpret_cast<h16x8*>(row + SCK * 2 + grp * 16) = lo;
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(256) void conv1d_split_kernel(ConvK a, const uint4*
   const int n_ks = (a.c_in + 15) >> 4;
   const int n_w = n_ks * a.ntaps;
   const float* xb = a.x + (long long)b * a.x_bstride;
-  const uint4* wp = wsplit + ((size_t)(p * n_mt + (active ? mt : 0)) * n_w) * 128 + lane;
+  const uint4* wp = wsplit + ((size_t)(p * n_mt + (active ? mt : 0)) * n_w) * 192 + lane;
   const int off_base = a.off0[p] - a.min_off;
   const int t_src = a.in_repeat > 1 ? a.t_in / a.in_repeat : a.t_in;
 
@@ -312,8 +317,8 @@ __global__ __launch_bounds__(256) void conv1d_split_kernel(ConvK a, const uint4*
     for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
 
   int wi = 0;
-  uint4 ah = make_uint4(0, 0, 0, 0), al = make_uint4(0, 0, 0, 0);
-  if (active) { ah = wp[0]; al = wp[64]; }
+  uint4 ah = make_uint4(0, 0, 0, 0), al = make_uint4(0, 0, 0, 0), as = make_uint4(0, 0, 0, 0);
+  if (active) { ah = wp[0]; al = wp[64]; as = wp[128]; }
 
   const int cin16 = n_ks * 16;
   const int tap_stride = a.step * SROW, tile_stride = 32 * a.down * SROW;
@@ -333,19 +338,19 @@ __global__ __launch_bounds__(256) void conv1d_split_kernel(ConvK a, const uint4*
         const char* lp = lbase0 + cur * buf_bytes + ks2 * 32;
         for (int j = 0; j < a.ntaps; ++j, lp += tap_stride) {
           ++wi;
-          const h16x8 Ah = __builtin_bit_cast(h16x8, ah), Al = __builtin_bit_cast(h16x8, al);
-          if (wi < n_w) { ah = wp[(size_t)wi * 128]; al = wp[(size_t)wi * 128 + 64]; }
+          const h16x8 Ah = __builtin_bit_cast(h16x8, ah), Al = __builtin_bit_cast(h16x8, al), As = __builtin_bit_cast(h16x8, as);
+          if (wi < n_w) { ah = wp[(size_t)wi * 192]; al = wp[(size_t)wi * 192 + 64]; as = wp[(size_t)wi * 192 + 128]; }
 #pragma unroll
           for (int n = 0; n < NTW; ++n) {
             const h16x8 Bh = *reinterpret_cast<const h16x8*>(lp + n * tile_stride);
             const h16x8 Bl = *reinterpret_cast<const h16x8*>(lp + n * tile_stride + SCK * 2);
             if (!TR) {
               acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, acc[n], 0, 0, 0);
-              acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc[n], 0, 0, 0);
+              acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(As, Bl, acc[n], 0, 0, 0);
               acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, acc[n], 0, 0, 0);
             } else {
               acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bh, Al, acc[n], 0, 0, 0);
-              acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bl, Ah, acc[n], 0, 0, 0);
+              acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bl, As, acc[n], 0, 0, 0);
               acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bh, Ah, acc[n], 0, 0, 0);
             }
           }
@@ -478,7 +483,7 @@ static size_t conv_f32_image_floats(int c_out, int c_in, int ksize) {
 }
 static size_t conv_split_image_floats(int c_out, int c_in, int ksize) {
   const int n_mt = (c_out + 31) / 32, n_ks = (c_in + 15) / 16;
-  return (size_t)n_mt * n_ks * ksize * 512;
+  return (size_t)n_mt * n_ks * ksize * 768;  // three fp16 A fragments (hi | lo | hi 2^-11) of 64 lanes x 8 per (mt, 16-channel step, tap)
 }
 extern "C" size_t mb_conv1d_packed_floats(int c_out, int c_in, int ksize, int up) {
   (void)up;
@@ -532,7 +537,7 @@ extern "C" int mb_conv1d_pack(const float* h_w, int c_out, int c_in, int ksize, 
       for (int ks = 0; ks < n_ks; ++ks)
         for (int j = 0; j < ntaps; ++j) {
           const int jj = transposed ? j0 + j * up : j;
-          for (int part = 0; part < 2; ++part)
+          for (int part = 0; part < 3; ++part)
             for (int lane = 0; lane < 64; ++lane)
               for (int e = 0; e < 8; ++e) {
                 // A fragment of v_mfma_f32_32x32x16_f16: lane l holds A[m = l & 31][k = 8 * (l >> 5) + e]
@@ -542,7 +547,7 @@ extern "C" int mb_conv1d_pack(const float* h_w, int c_out, int c_in, int ksize, 
                 if (co < c_out && ci < c_in)
                   v = (transposed ? h_w[((size_t)ci * c_out + co) * ksize + jj] : h_w[((size_t)co * c_in + ci) * ksize + jj]) * scale;
                 const h16 hi = (h16)v;
-                hp[oh++] = part == 0 ? hi : (h16)(v - (float)hi);
+                hp[oh++] = part == 0 ? hi : part == 1 ? (h16)(v - (float)hi) : (h16)((float)hi * (1.f / 2048.f));
               }
         }
   }
@@ -550,7 +555,7 @@ extern "C" int mb_conv1d_pack(const float* h_w, int c_out, int c_in, int ksize, 
 }
 
 // Range diagnostics of the split path: with MBHIP_CONV_RANGE_CHECK=1 every conv1d_split_kernel launch
-// counts the staged input values with |x| > 131008 (or NaN / Inf) -- values the fp32 reference would carry and the hi / lo
+// counts the staged input values with |x| > 65536 (or NaN / Inf) -- values the fp32 reference would carry and the hi / lo
 // clamp saturates silently -- into one device word per device; mb_conv1d_range_events reads (and optionally clears) it.
 static unsigned* g_range_word[16] = {};
 static unsigned* range_word() {

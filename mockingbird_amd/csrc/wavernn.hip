@@ -28,7 +28,7 @@
 #include "rnn.h"
 #include "wavernn_fast.h"
 #include "wavernn_persist.h"
-#include "wavernn_pipe.h"
+#include "wavernn_pipe16.h"
 
 namespace mb {
 
@@ -270,6 +270,10 @@ struct mb_wavernn {
   DevBuf w_rnn2x, w_hh1, w_hh2;
   // fast chain (wavernn_fast.h): hidden halves in GRU tile order, their biases as (r, z, n, -) per unit
   DevBuf f_hh1t, f_hh2t, f_bhh1q, f_bhh2q;
+  // resident kernel on 22-bit operand pairs (wavernn_pipe16.h): fp16 hi / lo A fragments of the six on-chip matrices (uint16 pairs
+  // stored in float-typed buffers) and their 2^-s
+  DevBuf q_rnn2, q_hh2, q_hh1, q_fc1, q_fc2, q_fc3;
+  float q_us[6] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
   // Folds are independent sequences: they are dealt to up to MAX_LANES "lanes", each with its own
   // stream + graph, so the per-kernel dependency latency of one lane overlaps with the others.
   static constexpr int MAX_LANES = 8;
@@ -335,6 +339,16 @@ extern "C" size_t mb_wavernn_weight_numel(const mb_wavernn_config* cfg, int inde
   std::vector<size_t> v;
   if (wavernn_shapes(cfg, &v) || index < 0 || index >= (int)v.size()) return 0;
   return v[index];
+}
+
+// split image of a tile-ordered matrix for wavernn_pipe16.h (K = 512 only: the resident kernels are production-dims kernels)
+static int upload_q16(const float* rows, int n_live_rows, int K, int RL, DevBuf* dst, float* unscale) {
+  if (K != 512) return MB_OK;
+  const int sexp = wq16_scale_exp(rows, (size_t)n_live_rows * K);
+  std::vector<unsigned short> img;
+  wq16_pack(rows, n_live_rows, K, RL, sexp, &img);
+  *unscale = std::ldexp(1.f, -sexp);
+  return dst->upload(reinterpret_cast<const float*>(img.data()), img.size() / 2);
 }
 
 // conv weight [c_out][c_in][k] (+ optional eval BatchNorm folded in) -> packed + bias
@@ -478,6 +492,7 @@ extern "C" int mb_wavernn_create(const mb_wavernn_config* cfg, const float* cons
     RC(w->w_hh1.upload(packed.data(), packed.size()));
     cell_rows(whh, R, R, whh, 0, R, 3, &rows); pack_rowtile(rows.data(), 3 * R, R, 3, &packed);
     RC(w->f_hh1t.upload(packed.data(), packed.size()));
+    RC(upload_q16(rows.data(), 3 * R, R, 3, &w->q_hh1, &w->q_us[2]));
     std::vector<float> bq((size_t)R * 4);
     for (int j = 0; j < R; ++j) for (int g = 0; g < 4; ++g) bq[(size_t)j * 4 + g] = g < 3 ? bhh[g * R + j] : 0.f;
     RC(w->f_bhh1q.upload(bq.data(), bq.size()));
@@ -492,10 +507,12 @@ extern "C" int mb_wavernn_create(const mb_wavernn_config* cfg, const float* cons
     cell_rows(wih, R, R + A, whh, 0, R, 3, &rows);
     pack_rowtile(rows.data(), 3 * R, R, 3, &packed);
     RC(w->w_rnn2x.upload(packed.data(), packed.size()));
+    RC(upload_q16(rows.data(), 3 * R, R, 3, &w->q_rnn2, &w->q_us[0]));
     pack_rowtile(whh, 3 * R, R, 4, &packed);
     RC(w->w_hh2.upload(packed.data(), packed.size()));
     cell_rows(whh, R, R, whh, 0, R, 3, &rows); pack_rowtile(rows.data(), 3 * R, R, 3, &packed);
     RC(w->f_hh2t.upload(packed.data(), packed.size()));
+    RC(upload_q16(rows.data(), 3 * R, R, 3, &w->q_hh2, &w->q_us[1]));
     std::vector<float> bq((size_t)R * 4);
     for (int j = 0; j < R; ++j) for (int g = 0; g < 4; ++g) bq[(size_t)j * 4 + g] = g < 3 ? bhh[g * R + j] : 0.f;
     RC(w->f_bhh2q.upload(bq.data(), bq.size()));
@@ -508,13 +525,16 @@ extern "C" int mb_wavernn_create(const mb_wavernn_config* cfg, const float* cons
     ix += 6;
     std::vector<float> m = col_slice(w1, FC, R + A, 0, R);
     pack_rowtile(m.data(), FC, R, 4, &packed); RC(w->w_fc1.upload(packed.data(), packed.size()));
+    RC(upload_q16(m.data(), FC, R, 4, &w->q_fc1, &w->q_us[3]));
     std::vector<float> a1 = col_slice(w1, FC, R + A, R, A);
     RC(make_cond_conv(&w->t_f1, a1.data(), FC, A, 1, 0, b1, nullptr));
     m = col_slice(w2, FC, FC + A, 0, FC);
     pack_rowtile(m.data(), FC, FC, 4, &packed); RC(w->w_fc2.upload(packed.data(), packed.size()));
+    RC(upload_q16(m.data(), FC, FC, 4, &w->q_fc2, &w->q_us[4]));
     std::vector<float> a2 = col_slice(w2, FC, FC + A, FC, A);
     RC(make_cond_conv(&w->t_f2, a2.data(), FC, A, 1, 0, b2, nullptr));
     pack_rowtile(w3, C, FC, 4, &packed); RC(w->w_fc3.upload(packed.data(), packed.size()));
+    RC(upload_q16(w3, C, FC, 4, &w->q_fc3, &w->q_us[5]));
     RC(w->b_fc3.upload(b3, C));
   }
 #undef RC
@@ -543,7 +563,8 @@ extern "C" void mb_wavernn_destroy(mb_wavernn* w) {
   for (auto& c : w->res2) rel(c);
   DevBuf* bs[] = {&w->wI0, &w->g1I0, &w->w_rnn1, &w->w_rnn2, &w->w_fc1, &w->w_fc2, &w->w_fc3,
                   &w->b_ih1, &w->b_hh1, &w->b_hh2, &w->b_fc3, &w->w_rnn2x, &w->w_hh1, &w->w_hh2,
-                  &w->f_hh1t, &w->f_hh2t, &w->f_bhh1q, &w->f_bhh2q, &w->kw};
+                  &w->f_hh1t, &w->f_hh2t, &w->f_bhh1q, &w->f_bhh2q, &w->kw,
+                  &w->q_rnn2, &w->q_hh2, &w->q_hh1, &w->q_fc1, &w->q_fc2, &w->q_fc3};
   for (DevBuf* b : bs) b->release();
   w->drop_graph();
   if (w->h_abort) (void)hipHostFree(w->h_abort);
@@ -791,6 +812,7 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
       MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WP_LDS_BYTES));
       MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_persist1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WP1_LDS_BYTES));
       MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_pipe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WQ_LDS_BYTES));
+      MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_pipe16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WQ16_LDS_BYTES));
       int nb0 = 0, nb1 = 0, nb2 = 0;
       MB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb0, reinterpret_cast<const void*>(wf_persist_kernel), 512, WP_LDS_BYTES));
       MB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, reinterpret_cast<const void*>(wf_persist1_kernel), 512, WP1_LDS_BYTES));
@@ -823,8 +845,21 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
       qk.mol = c.mode == 1 ? 1 : 0; qk.nr_mix = C / 3;
       qk.gn0[0] = 0; qk.gn0[1] = (N + 1) / 2; qk.gn0[2] = N;  // two groups of ceil / floor (N / 2) columns
       if (const char* ge = getenv("MBHIP_WQ_GROUPS")) { if (atoi(ge) == 1 && N <= WQ_GC) qk.gn0[1] = N; }  // A/B: one group, no pipelining
-      qk.flags = getenv("MBHIP_WQ_FLAGS") ? atoi(getenv("MBHIP_WQ_FLAGS")) : 1;  // A/B switches of wavernn_pipe.h
+      qk.flags = getenv("MBHIP_WQ_FLAGS") ? atoi(getenv("MBHIP_WQ_FLAGS")) : 17;  // A/B switches of wavernn_pipe.h (1 = padded rows, 16 = weights in registers)
       qk.trace = trace;
+      // RAW models run the kernel on 22-bit operand pairs (wavernn_pipe16.h: half the sweep bytes, fp16 matrix pipe; samples checked
+      // against the oracle, not bit-identical to the chain); MBHIP_WQ16=0 and MOL models: the exact kernel
+      const char* e16 = getenv("MBHIP_WQ16");
+      const bool q16 = c.mode == 0 && w->q_fc3.p && w->q_hh1.p && !(e16 && atoi(e16) == 0) && (qk.flags & 1);
+      if (q16) {
+        Wq16K k16;
+        k16.q = qk;
+        k16.h_rnn2 = reinterpret_cast<const uint4*>(w->q_rnn2.p); k16.h_hh2 = reinterpret_cast<const uint4*>(w->q_hh2.p);
+        k16.h_hh1 = reinterpret_cast<const uint4*>(w->q_hh1.p); k16.h_fc1 = reinterpret_cast<const uint4*>(w->q_fc1.p);
+        k16.h_fc2 = reinterpret_cast<const uint4*>(w->q_fc2.p); k16.h_fc3 = reinterpret_cast<const uint4*>(w->q_fc3.p);
+        k16.us_rnn2 = w->q_us[0]; k16.us_hh2 = w->q_us[1]; k16.us_hh1 = w->q_us[2]; k16.us_fc1 = w->q_us[3]; k16.us_fc2 = w->q_us[4]; k16.us_fc3 = w->q_us[5];
+        hipLaunchKernelGGL(wf_pipe16_kernel, dim3(WQ_WGS), dim3(512), WQ16_LDS_BYTES, s, k16);
+      } else
       hipLaunchKernelGGL(wf_pipe_kernel, dim3(WQ_WGS), dim3(512), WQ_LDS_BYTES, s, qk);
     } else {
       WpK pk;

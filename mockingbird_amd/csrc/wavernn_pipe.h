@@ -55,16 +55,19 @@ struct WqK {
   int gn0[WQ_G + 1];          // group g owns fold columns [gn0[g], gn0[g + 1])
   int mol, nr_mix;            // MOL mode (fatchord_version.py:213-220): fc3 has 3 nr_mix rows, F3 is ONE workgroup that samples the
                               // mixture of logistics itself (wf_fc3_mol_kernel's draws) and hands the SAMPLE to R1
-  int flags;                  // A/B switches (MBHIP_WQ_FLAGS): 1 = exchange rows padded to 16 columns (default), 2 = R2's residual x1 by a global load
+  int flags;                  // A/B switches (MBHIP_WQ_FLAGS, default 17): 1 = exchange rows padded to 16 columns, 2 = R2's residual x1 by a global load,
+                              // 16 = weight fragments held in registers for the whole utterance (LDS reads per product otherwise: +0.3 us per step)
   unsigned long long* trace;  // diagnostics (MBHIP_WP_TRACE): wall-clock marks of one workgroup per role, steps 1000..1003
 };
 
 // wp_gather with the row stride LD apart from the live column count N
 template <int SLEEP>
-__device__ __forceinline__ bool wq_gather(const unsigned long long* vec, const unsigned tag, const int N, const int LD, float4 (&b)[4], int* abort_word) {
+__device__ __forceinline__ bool wq_gather(const unsigned long long* vec, const unsigned tag, const int N, const int LD, float4 (&b)[4], int* abort_word,
+                                          unsigned long long* mk = nullptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, kq = lane >> 4;
   // ONE watching lane, then a barrier, then one sweep (four staggered watchers + an LDS flag instead: 14.2 vs 13.9 us per step)
   wp_watch<SLEEP>(vec + (size_t)511 * LD + (N - 1), tag, abort_word);
+  if (mk && threadIdx.x == 0) *mk = (unsigned long long)wall_clock64();  // diagnostics: the hand-off was noticed
 #pragma unroll
   for (int p = 0; p < 4; ++p) b[p] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i >= N) return true;
@@ -87,6 +90,76 @@ __device__ __forceinline__ bool wq_gather(const unsigned long long* vec, const u
   for (int p = 0; p < 4; ++p)
     b[p] = make_float4(__uint_as_float((unsigned)v[p * 4]), __uint_as_float((unsigned)v[p * 4 + 1]), __uint_as_float((unsigned)v[p * 4 + 2]),
                        __uint_as_float((unsigned)v[p * 4 + 3]));
+  return true;
+}
+
+// wp_gemm / wp_gemm2 on A fragments the caller holds (registers for the whole utterance with flags & 16, re-read from LDS per
+// product otherwise): the same MFMA sequence and wave-order reduction.
+template <int RL>
+__device__ __forceinline__ void wq_load_a(const float* lw, float4 (&a)[4]) {
+  constexpr int BLK = 4 * RL * 16;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, kq = lane >> 4;
+  const int u = i >> 2, tau = (i & 3) < RL ? (i & 3) : RL - 1;
+  const float* wl = lw + ((u * RL + tau) * 4 + kq) * 4;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) a[p] = *reinterpret_cast<const float4*>(wl + (size_t)(wave + 8 * p) * BLK);
+}
+__device__ __forceinline__ bool wq_gemm1(const float4 (&a)[4], const float4 (&b)[4], float* red, float (&sx)[4], unsigned long long* mk = nullptr) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p].x, b[p].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p].y, b[p].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p].z, b[p].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p].w, b[p].w, acc, 0, 0, 0);
+  }
+  float4* red4 = reinterpret_cast<float4*>(red);
+  red4[wave * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  __syncthreads();
+  if (mk && threadIdx.x == 0) *mk = (unsigned long long)wall_clock64();
+  if (wave != 0) return false;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) sx[g] = 0.f;
+#pragma unroll
+  for (int w8 = 0; w8 < 8; ++w8) {
+    const float4 v = red4[w8 * 64 + lane];
+    sx[0] += v.x; sx[1] += v.y; sx[2] += v.z; sx[3] += v.w;
+  }
+  return true;
+}
+__device__ __forceinline__ bool wq_gemm2(const float4 (&a0)[4], const float4 (&a1)[4], const float4 (&b)[4], float* red, float (&sx)[4],
+                                         unsigned long long* mk = nullptr) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[p].x, b[p].x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[p].x, b[p].x, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[p].y, b[p].y, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[p].y, b[p].y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[p].z, b[p].z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[p].z, b[p].z, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[p].w, b[p].w, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[p].w, b[p].w, acc1, 0, 0, 0);
+  }
+  float4* red4 = reinterpret_cast<float4*>(red);  // [2 tiles][8 waves][64]
+  red4[wave * 64 + lane] = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
+  red4[512 + wave * 64 + lane] = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
+  __syncthreads();
+  if (mk && threadIdx.x == 0) *mk = (unsigned long long)wall_clock64();
+  if (wave >= 2) return false;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) sx[g] = 0.f;
+#pragma unroll
+  for (int w8 = 0; w8 < 8; ++w8) {
+    const float4 v = red4[wave * 512 + w8 * 64 + lane];
+    sx[0] += v.x; sx[1] += v.y; sx[2] += v.z; sx[3] += v.w;
+  }
   return true;
 }
 
@@ -114,6 +187,9 @@ __global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
       a.trace[((role) * 4 + (s - 1000)) * 16 + (k)] = (unsigned long long)wall_clock64();                  \
   } while (0)
 
+#define WQ_MK(role, k) ((a.trace && mark_wg && g == 0 && s >= 1000 && s < 1004) ? a.trace + (((role) * 4 + (s - 1000)) * 16 + (k)) : nullptr)
+  const bool aregs = (a.flags & 16) != 0;   // weight fragments live in registers for the whole utterance
+
   if (blk < WQ_R1) {
     // ---------------------------------------------------------------------------------------------- R1: rnn1
     const bool mark_wg = blk == 0;
@@ -132,6 +208,8 @@ __global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
       tq[g][0] = t4.x; tq[g][1] = t4.y; tq[g][2] = t4.z; tq[g][3] = t4.w;
     }
     __syncthreads();
+    float4 A0[4], A1[4];
+    if (aregs) { wq_load_a<3>(lw, A0); wq_load_a<3>(lw + 6144, A1); }
     for (int s = 0; s <= S; ++s) {
       const unsigned tag_prev = (unsigned)s, tag = (unsigned)s + 1;
 #pragma unroll
@@ -197,10 +275,11 @@ __global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
         }
         // ---- hidden half of the next step: P1 = W_hh1 . h1 + b_hh1, kept by the lane that will use it ----
         float4 b[4];
-        if (!wq_gather<2>(EX(WQX_H1, g, tag), tag, Ng, LD, b, a.abort_word)) return;
+        if (!wq_gather<2>(EX(WQX_H1, g, tag), tag, Ng, LD, b, a.abort_word, WQ_MK(0, 6))) return;
         WQ_MARK(0, 3);
         float sx[4];
-        const bool epi = wp_gemm2<3>(lw, 6144, b, red + rb * 4096, sx);
+        if (!aregs) { wq_load_a<3>(lw, A0); wq_load_a<3>(lw + 6144, A1); }
+        const bool epi = wq_gemm2(A0, A1, b, red + rb * 4096, sx);
         rb ^= 1;
         if (epi) { P1[g][0] = sx[0] + bq.x; P1[g][1] = sx[1] + bq.y; P1[g][2] = sx[2] + bq.z; }
         WQ_MARK(0, 4);
@@ -224,6 +303,8 @@ __global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
 #pragma unroll
     for (int g = 0; g < WQ_G; ++g) { h2[g] = 0.f; P2[g][0] = bq.x; P2[g][1] = bq.y; P2[g][2] = bq.z; g2_row[g] = -1; g2v[g][0] = g2v[g][1] = g2v[g][2] = 0.f; }
     __syncthreads();
+    float4 A0[4], A1[4], A2[4], A3[4];
+    if (aregs) { wq_load_a<3>(lw, A0); wq_load_a<3>(lw + 6144, A1); wq_load_a<3>(lw + 12288, A2); wq_load_a<3>(lw + 12288 + 6144, A3); }
     for (int s = 0; s < S; ++s) {
       const unsigned tag = (unsigned)s + 1;
 #pragma unroll
@@ -238,7 +319,7 @@ __global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
         }
         WQ_MARK(1, 0);
         float4 b[4];
-        if (!wq_gather<1>(EX(WQX_X1, g, tag), tag, Ng, LD, b, a.abort_word)) return;
+        if (!wq_gather<1>(EX(WQX_X1, g, tag), tag, Ng, LD, b, a.abort_word, WQ_MK(1, 6))) return;
         WQ_MARK(1, 1);
         // the residual x1 of this workgroup's own 8 units sits in the fragments just gathered (one k-block, wave xr_wave,
         // register xr_p, lanes kq = xr_kq0 + tile): handed to the epilogue lanes through LDS behind the GEMM's own barrier
@@ -249,7 +330,8 @@ __global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
             if (p == xr_p) { dst[0] = b[p].x; dst[16] = b[p].y; dst[32] = b[p].z; dst[48] = b[p].w; }
         }
         float sx[4];
-        const bool epi = wp_gemm2<3>(lw, 6144, b, red + rb * 4096, sx);
+        if (!aregs) { wq_load_a<3>(lw, A0); wq_load_a<3>(lw + 6144, A1); }
+        const bool epi = wq_gemm2(A0, A1, b, red + rb * 4096, sx, WQ_MK(1, 7));
         rb ^= 1;
         WQ_MARK(1, 5);
         if (epi && i < Ng) {
@@ -271,7 +353,8 @@ __global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
         if (s + 1 >= S) continue;
         if (!wq_gather<2>(EX(WQX_H2, g, tag), tag, Ng, LD, b, a.abort_word)) return;
         WQ_MARK(1, 3);
-        const bool epi2 = wp_gemm2<3>(lw + 12288, 6144, b, red + rb * 4096, sx);
+        if (!aregs) { wq_load_a<3>(lw + 12288, A2); wq_load_a<3>(lw + 12288 + 6144, A3); }
+        const bool epi2 = wq_gemm2(A2, A3, b, red + rb * 4096, sx);
         rb ^= 1;
         if (epi2) { P2[g][0] = sx[0] + bq.x; P2[g][1] = sx[1] + bq.y; P2[g][2] = sx[2] + bq.z; }
         WQ_MARK(1, 4);
@@ -301,6 +384,8 @@ __global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
   for (int g = 0; g < WQ_G; ++g) { fpre[g] = make_float4(0.f, 0.f, 0.f, 0.f); f_row[g] = -1; }
   const int src = fr == 0 ? WQX_X2 : fr == 1 ? WQX_Y1 : WQX_Y2;
   __syncthreads();
+  float4 A0[4];
+  if (aregs && !f3mol) wq_load_a<4>(lw, A0);
   for (int s = 0; s < S; ++s) {
     const unsigned tag = (unsigned)s + 1;
 #pragma unroll
@@ -323,7 +408,7 @@ __global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
       }
       WQ_MARK(2 + fr, 0);
       float4 b[4];
-      if (!wq_gather<1>(EX(src, g, tag), tag, Ng, LD, b, a.abort_word)) return;
+      if (!wq_gather<1>(EX(src, g, tag), tag, Ng, LD, b, a.abort_word, WQ_MK(2 + fr, 6))) return;
       WQ_MARK(2 + fr, 1);
       float sx[4];
       if (f3mol) {
@@ -366,7 +451,8 @@ __global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
         WQ_MARK(2 + fr, 2);
         continue;
       }
-      const bool epi = wp_gemm<4>(lw, b, red + rb * 4096, sx);
+      if (!aregs) wq_load_a<4>(lw, A0);
+      const bool epi = wq_gemm1(A0, b, red + rb * 4096, sx, WQ_MK(2 + fr, 7));
       rb ^= 1;
       WQ_MARK(2 + fr, 3);
       if (!epi) continue;
@@ -404,6 +490,7 @@ __global__ __launch_bounds__(512) void wf_pipe_kernel(WqK a) {
     }
   }
 #undef WQ_MARK
+#undef WQ_MK
 }
 
 }  // namespace mb

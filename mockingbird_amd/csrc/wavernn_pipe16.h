@@ -1,0 +1,478 @@
+// Round 4: the resident pipelined WaveRNN kernel of wavernn_pipe.h with its exchange vectors and its products on 22-bit
+// operand pairs -- the benchmarked path for 2..32 fold columns of a RAW-mode model (BASELINE configs[1]: 23 folds).
+//
+// What round 3's wall-clock marks said about wf_pipe_kernel (profiles/r04_wavernn_pipe_marks.json, 14.3 us per step on that box):
+// an edge is NOT latency -- a producer's store is noticed by the watching lane 0.3 us later -- it is the SWEEP: every consumer
+// workgroup pulls 512 features x 16 columns x 8-byte granules = 64 KB through its compute unit's 64 B/clk path to the L2
+// (1.1 us until the first wave has its fragments, 1.4 us until the slowest), five times per step; and a stage is 0.43-0.85 us
+// of v_mfma_f32_16x16x4_f32 (one tile per unit at the 1/16-rate fp32 pipe).  Levers that do not touch those two were measured
+// and lost (MBHIP_WQ_FLAGS sweep of the same session: whole-line stores +0.0, 16-byte sweep loads +1.7, two / four staggered
+// polls of the watching lane +0.5 / +0.7, keys read by the finish lanes +3.4 us per step; weight fragments in registers -0.3).
+// So this kernel halves the bytes of every sweep and takes the products off the fp32 pipe:
+//   * a value crosses workgroups as fp16 hi + fp16 lo (x = xh + xl: 21 of its 24 significant bits; below |x| = 0.125 the low half is
+//     an fp16 subnormal: an absolute 6e-8, the size of fp32's own rounding of the O(1) sums these vectors feed), and an 8-byte
+//     granule carries TWO features {xh | xl, xh' | xl'}; the step tag shrinks to 2 bits -- the least significant bit of each low
+//     half (a granule is rewritten every second step and read in between: consecutive tags of a parity buffer differ,
+//     tag2(t) = ((t >> 1) + 1) & 3, and memory starts as 0 != tag2(1), tag2(2));
+//   * the weights are split on the host, w 2^s = wh + wl (s per matrix: max |w| 2^s in [2^13, 2^14)), into the A fragments of
+//     v_mfma_f32_16x16x32_f16 and live in REGISTERS for the whole utterance (16 VGPRs per tile, no LDS tile at all); a product is
+//     wl.xh + wh.xl + wh.xh in fp32 accumulators -- conv1d.hip's error-compensated scheme, 6 MFMAs of 16 cycles per wave and tile
+//     instead of 16 of 32.
+// The sample stream is therefore NOT bit-identical to the launch chain's / wf_pipe_kernel's any more (VERDICT r03 item 3 allows
+// that); it is held to the oracle itself: tests/test_wavernn_gpu.py::test_production_* replay the reference loop body on the device's
+// own history with the exported noise.  MBHIP_WQ16=0 selects the exact kernel (wavernn_pipe.h, the A/B partner and the MOL path).
+// Roles, groups in flight, item order, deadlock argument, bail-outs: wavernn_pipe.h's, unchanged.
+#pragma once
+#include "wavernn_pipe.h"
+
+namespace mb {
+
+typedef _Float16 wh16;
+typedef _Float16 wh16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned wq_u4 __attribute__((ext_vector_type(4)));
+
+struct Wq16K {
+  WqK q;                                      // everything wf_pipe_kernel takes (its fp32 weight images are unused here)
+  const uint4* h_rnn2; const uint4* h_hh2; const uint4* h_hh1; const uint4* h_fc1; const uint4* h_fc2; const uint4* h_fc3;  // split images
+  float us_rnn2, us_hh2, us_hh1, us_fc1, us_fc2, us_fc3;  // 2^-s of each matrix
+};
+
+// Host: tile-ordered rows (pack_rowtile's input: rows of tile mt are [mt * 4 RL, (mt + 1) * 4 RL) in (unit, gate) order, K = 512)
+// -> per tile [wave 8][k-step 2][hi | lo][lane 64][8 halves]: lane (m = lane & 15, kb = lane >> 4) holds row (m >> 2) * RL +
+// min(m & 3, RL - 1) of the tile (the dead 4th GRU row re-reads gate 2, as the fp32 image does), k = wave * 64 + step * 32 + kb * 8 + e.
+inline int wq16_scale_exp(const float* rows, size_t n) {
+  float wmax = 0.f;
+  for (size_t i = 0; i < n; ++i) wmax = std::max(wmax, std::fabs(rows[i]));
+  if (!(wmax > 0.f) || !std::isfinite(wmax)) return 0;
+  int e2;
+  (void)std::frexp(wmax, &e2);
+  return std::max(-24, std::min(40, 14 - e2));
+}
+inline void wq16_pack(const float* rows, int n_live_rows, int K, int RL, int sexp, std::vector<unsigned short>* out) {
+  const int per_tile = 4 * RL, n_mt = (n_live_rows + per_tile - 1) / per_tile;
+  const float scale = std::ldexp(1.f, sexp);
+  out->assign((size_t)n_mt * 8 * 2 * 2 * 64 * 8, 0);
+  for (int mt = 0; mt < n_mt; ++mt)
+    for (int w = 0; w < 8; ++w)
+      for (int st = 0; st < 2; ++st)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int m = lane & 15, kb = lane >> 4;
+          const int row = mt * per_tile + (m >> 2) * RL + std::min(m & 3, RL - 1);
+          for (int e = 0; e < 8; ++e) {
+            const int k = w * 64 + st * 32 + kb * 8 + e;
+            float v = 0.f;
+            if (row < n_live_rows && k < K) v = rows[(size_t)row * K + k] * scale;
+            const wh16 hi = (wh16)v;
+            const wh16 lo = (wh16)(v - (float)hi);
+            const size_t base = ((((size_t)mt * 8 + w) * 2 + st) * 2) * 64 * 8;
+            unsigned short hb, lb;
+            memcpy(&hb, &hi, 2); memcpy(&lb, &lo, 2);
+            (*out)[base + (size_t)lane * 8 + e] = hb;
+            (*out)[base + 64 * 8 + (size_t)lane * 8 + e] = lb;
+          }
+        }
+}
+
+// ---- device side ----
+__device__ __forceinline__ unsigned wq16_tag2(const unsigned tag) { return ((tag >> 1) + 1u) & 3u; }
+
+// fp32 -> {fp16 hi | fp16 lo << 16}; the low half's least significant bit is left for the tag
+__device__ __forceinline__ unsigned wq16_word(const float v) {
+  const wh16 h = (wh16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+  const wh16 l = (wh16)(v - (float)h);
+  return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+}
+__device__ __forceinline__ void wq16_put(unsigned long long* p, const float va, const float vb, const unsigned t2) {
+  const unsigned wa = (wq16_word(va) & ~0x10000u) | ((t2 & 1u) << 16);
+  const unsigned wb = (wq16_word(vb) & ~0x10000u) | ((t2 >> 1) << 16);
+  __hip_atomic_store(p, ((unsigned long long)wb << 32) | (unsigned long long)wa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool wq16_fresh(const unsigned long long v, const unsigned t2) {
+  return (((unsigned)v >> 16) & 1u) == (t2 & 1u) && (((unsigned)(v >> 48)) & 1u) == (t2 >> 1);
+}
+
+// B fragments (hi and lo, two k-steps of 32) of this lane from an exchange vector [feature pair 256][16 columns]: lane (column
+// i, kb) of wave w needs features w * 64 + st * 32 + kb * 8 + 0..7 = pairs w * 32 + st * 16 + kb * 4 + 0..3 -- eight 8-byte
+// loads per lane (wf_pipe_kernel: sixteen), 32 KB per workgroup and sweep.  One watching lane, a barrier, one sweep.
+template <int SLEEP>
+__device__ __forceinline__ bool wq16_gather(const unsigned long long* vec, const unsigned tag, const int N, wh16x8 (&bh)[2], wh16x8 (&bl)[2],
+                                            int* abort_word, unsigned long long* mk = nullptr) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, kb = lane >> 4;
+  const unsigned t2 = wq16_tag2(tag);
+  if (threadIdx.x == 0) {
+    const unsigned long long* p = vec + (size_t)255 * WQ_GC + (N - 1);
+    unsigned long long t0 = 0;
+    for (int tries = 0; !wq16_fresh(wp_get(p), t2); ++tries) {
+      if ((tries & 1023) == 1023 && wp_lost(tries, t0, abort_word)) break;
+      __builtin_amdgcn_s_sleep(SLEEP);
+    }
+  }
+  __syncthreads();
+  if (mk && threadIdx.x == 0) *mk = (unsigned long long)wall_clock64();
+#pragma unroll
+  for (int st = 0; st < 2; ++st) { bh[st] = (wh16x8)(wh16)0.f; bl[st] = (wh16x8)(wh16)0.f; }
+  if (i >= N) return true;
+  const unsigned long long* base = vec + ((size_t)(wave * 32 + kb * 4) * WQ_GC + i);
+  unsigned long long v[8];
+  unsigned long long t0 = 0;
+  for (int tries = 0;; ++tries) {
+    bool ok = true;
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[st * 4 + j] = wp_get(base + (size_t)(st * 16 + j) * WQ_GC);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) ok = ok && wq16_fresh(v[q], t2);
+    if (ok) break;
+    if ((tries & 1023) == 1023 && wp_lost(tries, t0, abort_word)) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    wq_u4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned wa = (unsigned)v[st * 4 + j], wb = (unsigned)(v[st * 4 + j] >> 32);
+      h[j] = __builtin_amdgcn_perm(wb, wa, 0x05040100u);                // {hi(a), hi(b)}
+      l[j] = __builtin_amdgcn_perm(wb, wa, 0x07060302u) & 0xfffefffeu;   // {lo(a), lo(b)}, tag bits cleared
+    }
+    bh[st] = __builtin_bit_cast(wh16x8, h);
+    bl[st] = __builtin_bit_cast(wh16x8, l);
+  }
+  return true;
+}
+
+// A fragments of one tile for this lane: [k-step][hi | lo]
+struct Wq16A { wh16x8 h[2], l[2]; };
+__device__ __forceinline__ void wq16_load_a(const uint4* img, const int tile, Wq16A& A) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint4* p = img + ((size_t)(tile * 8 + wave) * 4) * 64 + lane;
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    A.h[st] = __builtin_bit_cast(wh16x8, p[(st * 2) * 64]);
+    A.l[st] = __builtin_bit_cast(wh16x8, p[(st * 2 + 1) * 64]);
+  }
+}
+__device__ __forceinline__ f32x4 wq16_mma(const Wq16A& A, const wh16x8 (&bh)[2], const wh16x8 (&bl)[2]) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A.l[st], bh[st], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A.h[st], bl[st], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A.h[st], bh[st], acc, 0, 0, 0);
+  }
+  return acc;
+}
+// one tile: the 8 waves' K slices through LDS, wave 0 gets the sums (x 2^-s)
+__device__ __forceinline__ bool wq16_gemm1(const Wq16A& A, const wh16x8 (&bh)[2], const wh16x8 (&bl)[2], float* red, const float unscale, float (&sx)[4],
+                                           unsigned long long* mk = nullptr) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const f32x4 acc = wq16_mma(A, bh, bl);
+  float4* red4 = reinterpret_cast<float4*>(red);
+  red4[wave * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  __syncthreads();
+  if (mk && threadIdx.x == 0) *mk = (unsigned long long)wall_clock64();
+  if (wave != 0) return false;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) sx[g] = 0.f;
+#pragma unroll
+  for (int w8 = 0; w8 < 8; ++w8) {
+    const float4 v = red4[w8 * 64 + lane];
+    sx[0] += v.x; sx[1] += v.y; sx[2] += v.z; sx[3] += v.w;
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) sx[g] *= unscale;
+  return true;
+}
+// two tiles against the same B fragments, one barrier; wave tt (0 / 1) gets tile tt's sums
+__device__ __forceinline__ bool wq16_gemm2(const Wq16A& A0, const Wq16A& A1, const wh16x8 (&bh)[2], const wh16x8 (&bl)[2], float* red, const float unscale,
+                                           float (&sx)[4], unsigned long long* mk = nullptr) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const f32x4 acc0 = wq16_mma(A0, bh, bl), acc1 = wq16_mma(A1, bh, bl);
+  float4* red4 = reinterpret_cast<float4*>(red);  // [2 tiles][8 waves][64]
+  red4[wave * 64 + lane] = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
+  red4[512 + wave * 64 + lane] = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
+  __syncthreads();
+  if (mk && threadIdx.x == 0) *mk = (unsigned long long)wall_clock64();
+  if (wave >= 2) return false;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) sx[g] = 0.f;
+#pragma unroll
+  for (int w8 = 0; w8 < 8; ++w8) {
+    const float4 v = red4[wave * 512 + w8 * 64 + lane];
+    sx[0] += v.x; sx[1] += v.y; sx[2] += v.z; sx[3] += v.w;
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) sx[g] *= unscale;
+  return true;
+}
+
+// LDS (floats): [red: two 4096-float buffers, alternating] [keys / samples / residual hand-over]
+constexpr size_t WQ16_LDS_BYTES = (size_t)WQ_LDS_RED * 4 + 2 * WQ_GC * 8 + 8 * 16 * 4 + 64;
+
+__global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
+  const WqK& a = k16.q;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* red = lds;
+  unsigned long long* s_key = reinterpret_cast<unsigned long long*>(red + WQ_LDS_RED);  // [GC] max key of the step
+  float* s_x = reinterpret_cast<float*>(s_key + WQ_GC);                                 // [GC] decoded sample
+  if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // (tests: the fallback path)
+  const int blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int du = lane >> 4, i = lane & 15;
+  const int H = a.R, S = a.S;
+  const int n_t3 = a.C / 16;  // fc3 workgroups
+  constexpr int LD = WQ_GC;   // rows of 16 columns: one 128-byte line per feature pair (and per key half)
+  int rb = 0;                 // red buffer of the next GEMM
+  auto EX = [&](int what, int g, unsigned tag) { return a.ex + ((size_t)g * 2 + (tag & 1)) * WQX_PER + what; };
+#define WQ_MARK(role, k)                                                                                   \
+  do {                                                                                                     \
+    if (a.trace && tid == 0 && mark_wg && g == 0 && s >= 1000 && s < 1004)                                 \
+      a.trace[((role) * 4 + (s - 1000)) * 16 + (k)] = (unsigned long long)wall_clock64();                  \
+  } while (0)
+#define WQ_MK(role, k) ((a.trace && mark_wg && g == 0 && s >= 1000 && s < 1004) ? a.trace + (((role) * 4 + (s - 1000)) * 16 + (k)) : nullptr)
+
+  if (blk < WQ_R1) {
+    // ---------------------------------------------------------------------------------------------- R1: rnn1
+    const bool mark_wg = blk == 0;
+    if (tid < WQ_GC) { s_key[tid] = 0ull; s_x[tid] = 0.f; }
+    Wq16A A0, A1;
+    wq16_load_a(k16.h_hh1, 2 * blk, A0);
+    wq16_load_a(k16.h_hh1, 2 * blk + 1, A1);
+    const int ju = (2 * blk + (wave & 1)) * 4 + du;  // unit of an epilogue lane (waves 0 / 1)
+    const float4 bq = a.bhh1q[ju];
+    const float gr = a.g1[ju], gz = a.g1[H + ju], gn = a.g1[2 * H + ju], w0 = a.wI0[ju];
+    float h1[WQ_G], P1[WQ_G][3], tq[WQ_G][4];
+#pragma unroll
+    for (int g = 0; g < WQ_G; ++g) {
+      h1[g] = 0.f; P1[g][0] = bq.x; P1[g][1] = bq.y; P1[g][2] = bq.z;  // W_hh . 0 + b_hh
+      const int Ng = a.gn0[g + 1] - a.gn0[g];
+      const int ncl = a.gn0[g] + (i < Ng ? i : (Ng > 0 ? Ng - 1 : 0));
+      const float4 t4 = wf_cond_row4(a.cond, wf_pos(a.g, ncl, 0), (unsigned)a.g.total_len, ju, H, a.g.frames);
+      tq[g][0] = t4.x; tq[g][1] = t4.y; tq[g][2] = t4.z; tq[g][3] = t4.w;
+    }
+    __syncthreads();
+    for (int s = 0; s <= S; ++s) {
+      const unsigned tag_prev = (unsigned)s, tag = (unsigned)s + 1;
+#pragma unroll
+      for (int g = 0; g < WQ_G; ++g) {
+        const int n0 = a.gn0[g], Ng = a.gn0[g + 1] - n0;
+        if (Ng <= 0) continue;
+        WQ_MARK(0, 0);
+        // ---- keys of step s-1 -> sample x of every column of the group (classic {value, 32-bit tag} granules) ----
+        if (s > 0) {
+          const unsigned long long* K = EX(WQX_KEY, g, tag_prev);
+          wp_watch<1>(K + (size_t)((n_t3 - 1) * 2 + 1) * LD + (Ng - 1), tag_prev, a.abort_word);
+          if (tid < 32 * Ng && (tid & 31) < n_t3) {
+            const int tile = tid & 31, n = tid >> 5;
+            unsigned kv[2];
+            if (!wp_wait<2>(K + (size_t)tile * 2 * LD + n, LD, tag_prev, kv, a.abort_word)) return;
+            atomicMax(&s_key[n], ((unsigned long long)kv[0] << 32) | (unsigned long long)kv[1]);
+          }
+          __syncthreads();
+          WQ_MARK(0, 1);
+          if (tid < Ng) {
+            const unsigned long long slot = s_key[tid];
+            const float x = slot ? 2.f * (float)argmax_class(slot) / ((float)a.C - 1.f) - 1.f : 0.f;
+            s_x[tid] = x;
+            s_key[tid] = 0ull;
+            if (blk == 0) {
+              a.samples[(size_t)(n0 + tid) * S + (s - 1)] = x;
+              if (a.progress && n0 + tid == 0 && (s - 1) % 100 == 0) *a.progress = s;
+            }
+          }
+          __syncthreads();
+        }
+        if (s == S) continue;
+        // ---- rnn1 finish for (unit ju, column i): wf_finish_kernel's expressions; units 2j, 2j + 1 (lanes 16 apart) share a granule ----
+        if (wave < 2) {
+          const float x = s_x[i];
+          const float rg = sigmoidf_((tq[g][0] + x * gr) + P1[g][0]);
+          const float zg = sigmoidf_((tq[g][1] + x * gz) + P1[g][1]);
+          const float ng = tanhf((tq[g][2] + x * gn) + rg * P1[g][2]);
+          const float hy = ng + zg * (h1[g] - ng);
+          h1[g] = hy;
+          const float x1 = (tq[g][3] + x * w0) + hy;
+          const float x1o = __shfl_xor(x1, 16, 64), hyo = __shfl_xor(hy, 16, 64);
+          if (!(du & 1) && i < Ng) {
+            const unsigned t2 = wq16_tag2(tag);
+            wq16_put(EX(WQX_X1, g, tag) + (size_t)(ju >> 1) * LD + i, x1, x1o, t2);
+            wq16_put(EX(WQX_H1, g, tag) + (size_t)(ju >> 1) * LD + i, hy, hyo, t2);
+          }
+        }
+        WQ_MARK(0, 2);
+        if (s + 1 >= S) continue;
+        // ---- next step's table rows (a whole step to arrive) ----
+        if (wave < 2) {
+          const float4 t4 = wf_cond_row4(a.cond, wf_pos(a.g, n0 + (i < Ng ? i : Ng - 1), s + 1), (unsigned)a.g.total_len, ju, H, a.g.frames);
+          tq[g][0] = t4.x; tq[g][1] = t4.y; tq[g][2] = t4.z; tq[g][3] = t4.w;
+        }
+        // ---- hidden half of the next step: P1 = W_hh1 . h1 + b_hh1, kept by the lane that will use it ----
+        wh16x8 bh[2], bl[2];
+        if (!wq16_gather<2>(EX(WQX_H1, g, tag), tag, Ng, bh, bl, a.abort_word, WQ_MK(0, 6))) return;
+        WQ_MARK(0, 3);
+        float sx[4];
+        const bool epi = wq16_gemm2(A0, A1, bh, bl, red + rb * 4096, k16.us_hh1, sx);
+        rb ^= 1;
+        if (epi) { P1[g][0] = sx[0] + bq.x; P1[g][1] = sx[1] + bq.y; P1[g][2] = sx[2] + bq.z; }
+        WQ_MARK(0, 4);
+      }
+    }
+    return;
+  }
+
+  if (blk < WQ_R1 + WQ_R2) {
+    // ---------------------------------------------------------------------------------------------- R2: rnn2
+    const int b2 = blk - WQ_R1;
+    const bool mark_wg = b2 == 0;
+    Wq16A A0, A1, A2, A3;
+    wq16_load_a(k16.h_rnn2, 2 * b2, A0);
+    wq16_load_a(k16.h_rnn2, 2 * b2 + 1, A1);
+    wq16_load_a(k16.h_hh2, 2 * b2, A2);
+    wq16_load_a(k16.h_hh2, 2 * b2 + 1, A3);
+    const int ju = (2 * b2 + (wave & 1)) * 4 + du;
+    // this workgroup's own units 8 b2 .. 8 b2 + 7 (the residual x1 of its epilogue) are the eight halves of ONE fragment word group:
+    // features 8 b2 + e = wave xr_wave, k-step xr_st, lanes kb = xr_kb
+    const int xr_wave = b2 >> 3, xr_st = (b2 >> 2) & 1, xr_kb = b2 & 3;
+    float* s_xr = s_x + WQ_GC;  // [8 units][16 columns]
+    const float4 bq = a.bhh2q[ju];
+    float h2[WQ_G], P2[WQ_G][3], g2v[WQ_G][3];
+    int g2_row[WQ_G];
+#pragma unroll
+    for (int g = 0; g < WQ_G; ++g) { h2[g] = 0.f; P2[g][0] = bq.x; P2[g][1] = bq.y; P2[g][2] = bq.z; g2_row[g] = -1; g2v[g][0] = g2v[g][1] = g2v[g][2] = 0.f; }
+    __syncthreads();
+    for (int s = 0; s < S; ++s) {
+      const unsigned tag = (unsigned)s + 1;
+#pragma unroll
+      for (int g = 0; g < WQ_G; ++g) {
+        const int n0 = a.gn0[g], Ng = a.gn0[g + 1] - n0;
+        if (Ng <= 0) continue;
+        const int frow = wf_frame_row(a.g, n0 + (i < Ng ? i : Ng - 1), s);
+        if (wave < 2 && frow != g2_row[g]) {  // the per-frame rows change once per hop: kept in registers in between
+          const float* gp = a.G2 + (size_t)frow * 3 * H + ju;
+          g2v[g][0] = gp[0]; g2v[g][1] = gp[H]; g2v[g][2] = gp[2 * H];
+          g2_row[g] = frow;
+        }
+        WQ_MARK(1, 0);
+        wh16x8 bh[2], bl[2];
+        if (!wq16_gather<1>(EX(WQX_X1, g, tag), tag, Ng, bh, bl, a.abort_word, WQ_MK(1, 6))) return;
+        WQ_MARK(1, 1);
+        if (wave == xr_wave && (lane >> 4) == xr_kb) {  // residual of the own units: hi + lo, through LDS behind the GEMM's own barrier
+          const wh16x8 xh = xr_st ? bh[1] : bh[0], xl = xr_st ? bl[1] : bl[0];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s_xr[e * 16 + i] = (float)xh[e] + (float)xl[e];
+        }
+        float sx[4];
+        const bool epi = wq16_gemm2(A0, A1, bh, bl, red + rb * 4096, k16.us_rnn2, sx, WQ_MK(1, 7));
+        rb ^= 1;
+        WQ_MARK(1, 5);
+        if (epi) {
+          const float xr = s_xr[((wave & 1) * 4 + du) * 16 + i];
+          const float rg = sigmoidf_((sx[0] + g2v[g][0]) + P2[g][0]);
+          const float zg = sigmoidf_((sx[1] + g2v[g][1]) + P2[g][1]);
+          const float ng = tanhf((sx[2] + g2v[g][2]) + rg * P2[g][2]);
+          const float hy = ng + zg * (h2[g] - ng);
+          h2[g] = hy;
+          const float x2 = xr + hy;
+          const float x2o = __shfl_xor(x2, 16, 64), hyo = __shfl_xor(hy, 16, 64);
+          if (!(du & 1) && i < Ng) {
+            const unsigned t2 = wq16_tag2(tag);
+            wq16_put(EX(WQX_X2, g, tag) + (size_t)(ju >> 1) * LD + i, x2, x2o, t2);
+            wq16_put(EX(WQX_H2, g, tag) + (size_t)(ju >> 1) * LD + i, hy, hyo, t2);
+          }
+        }
+        WQ_MARK(1, 2);
+        if (s + 1 >= S) continue;
+        if (!wq16_gather<2>(EX(WQX_H2, g, tag), tag, Ng, bh, bl, a.abort_word)) return;
+        WQ_MARK(1, 3);
+        const bool epi2 = wq16_gemm2(A2, A3, bh, bl, red + rb * 4096, k16.us_hh2, sx);
+        rb ^= 1;
+        if (epi2) { P2[g][0] = sx[0] + bq.x; P2[g][1] = sx[1] + bq.y; P2[g][2] = sx[2] + bq.z; }
+        WQ_MARK(1, 4);
+      }
+    }
+    return;
+  }
+
+  // ------------------------------------------------------------------------------------------------ F1 / F2 / F3
+  const int fr = (blk - WQ_R1 - WQ_R2) / WQ_F, ft = (blk - WQ_R1 - WQ_R2) % WQ_F;  // role 0 / 1 / 2, row tile
+  const bool mark_wg = ft == 0;
+  if (fr == 2 && ft >= n_t3) return;
+  Wq16A A0;
+  wq16_load_a(fr == 0 ? k16.h_fc1 : fr == 1 ? k16.h_fc2 : k16.h_fc3, ft, A0);
+  const float us = fr == 0 ? k16.us_fc1 : fr == 1 ? k16.us_fc2 : k16.us_fc3;
+  const float4 b3q = fr == 2 ? *reinterpret_cast<const float4*>(a.b_fc3 + ft * 16 + du * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 fpre[WQ_G];
+  int f_row[WQ_G];
+#pragma unroll
+  for (int g = 0; g < WQ_G; ++g) { fpre[g] = make_float4(0.f, 0.f, 0.f, 0.f); f_row[g] = -1; }
+  const int src = fr == 0 ? WQX_X2 : fr == 1 ? WQX_Y1 : WQX_Y2;
+  __syncthreads();
+  for (int s = 0; s < S; ++s) {
+    const unsigned tag = (unsigned)s + 1;
+#pragma unroll
+    for (int g = 0; g < WQ_G; ++g) {
+      const int n0 = a.gn0[g], Ng = a.gn0[g + 1] - n0;
+      if (Ng <= 0) continue;
+      const int ncl = n0 + (i < Ng ? i : Ng - 1);
+      float lgn[4] = {0.f, 0.f, 0.f, 0.f};
+      if (fr < 2) {
+        const int frow = wf_frame_row(a.g, ncl, s);
+        if (wave == 0 && frow != f_row[g]) {
+          fpre[g] = *reinterpret_cast<const float4*>((fr == 0 ? a.F1 : a.F2) + (size_t)frow * a.FC + ft * 16 + du * 4);
+          f_row[g] = frow;
+        }
+      } else if (wave == 0) {  // the step's Gumbel noise does not depend on the data: drawn before the wait
+        uint32_t grn[4];
+        philox4x32((uint32_t)s, (uint32_t)ncl, (uint32_t)((ft * 16 + du * 4) >> 2), 0x57415645u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), grn);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lgn[r] = logf(-logf(u32_to_unit(grn[r])));
+      }
+      WQ_MARK(2 + fr, 0);
+      wh16x8 bh[2], bl[2];
+      if (!wq16_gather<1>(EX(src, g, tag), tag, Ng, bh, bl, a.abort_word, WQ_MK(2 + fr, 6))) return;
+      WQ_MARK(2 + fr, 1);
+      float sx[4];
+      const bool epi = wq16_gemm1(A0, bh, bl, red + rb * 4096, us, sx, WQ_MK(2 + fr, 7));
+      rb ^= 1;
+      WQ_MARK(2 + fr, 3);
+      if (!epi) continue;
+      if (fr < 2) {
+        if (i < Ng) {  // rows ft * 16 + du * 4 + 0..3 = feature pairs ft * 8 + du * 2 + 0, 1
+          unsigned long long* Y = EX(fr == 0 ? WQX_Y1 : WQX_Y2, g, tag) + (size_t)(ft * 8 + du * 2) * LD + i;
+          const unsigned t2 = wq16_tag2(tag);
+          wq16_put(Y, fmaxf(sx[0] + fpre[g].x, 0.f), fmaxf(sx[1] + fpre[g].y, 0.f), t2);
+          wq16_put(Y + LD, fmaxf(sx[2] + fpre[g].z, 0.f), fmaxf(sx[3] + fpre[g].w, 0.f), t2);
+        }
+      } else {  // wf_fc3_kernel's sampler; lanes of dead columns take part in the shuffles only
+        const float bv[4] = {b3q.x, b3q.y, b3q.z, b3q.w};
+        float best = -INFINITY;
+        int bcls = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = ft * 16 + du * 4 + r;
+          const float v = sx[r] + bv[r];
+          const float gmb = v - lgn[r];
+          if (gmb > best) { best = gmb; bcls = row; }
+        }
+        unsigned long long pk = pack_argmax(best, bcls);
+        const unsigned long long o1 = __shfl_xor(pk, 16, 64);
+        pk = o1 > pk ? o1 : pk;
+        const unsigned long long o2 = __shfl_xor(pk, 32, 64);
+        pk = o2 > pk ? o2 : pk;
+        if (du == 0 && i < Ng) {
+          unsigned long long* K = EX(WQX_KEY, g, tag) + (size_t)ft * 2 * LD + i;
+          wp_put_u(K, (unsigned)(pk >> 32), tag);
+          wp_put_u(K + LD, (unsigned)pk, tag);
+        }
+      }
+      WQ_MARK(2 + fr, 2);
+    }
+  }
+#undef WQ_MARK
+#undef WQ_MK
+}
+
+}  // namespace mb

@@ -67,13 +67,14 @@ def test_split_kernel_is_fp32_grade(cuda, lib, monkeypatch):
 
 def test_split_kernel_small_activation_stage(cuda, lib, monkeypatch, capsys):
     """a stage whose activations are SMALL (|x| ~ 1e-3, what the narrow late stages of a trained
-    generator can carry) -- there the low halves xl = fp16(x - xh) are fp16 subnormals (an absolute 3e-8 per value, i.e.
-    ~2^-15 relative instead of 2^-22).  The error-compensated kernel is measured against float64 beside the exact
-    fp32-input kernel; its error must stay below 1e-4 of the output RMS (the audio gate's size) and is reported, so the
-    cost of the un-scaled activations is on record.  Also |x| ~ 3e-2 (lo halves partly normal)."""
+    generator can carry).  Round 3 stored the residual xl = fp16(x - xh) unscaled: an fp16 subnormal there (an absolute 3e-8
+    per value, ~2^-15 relative instead of 2^-22) -- measured 1.1e-4 of the output RMS against 5.9e-6 for the exact fp32-input
+    kernel (this test's first run).  The residual is now stored scaled by 2^11 with a third weight image wh 2^-11
+    (conv1d.hip): each value keeps max(2^-22 |x|, 2^-36), i.e. the error is fp32-grade down to |x| ~ 1e-4; at |x| ~ 1e-6 the
+    absolute floor (1.5e-11) shows: measured 6e-5 of the output RMS there, gated at 2e-4 (no audio / mel stage lives there)."""
     g = torch.Generator().manual_seed(11)
     out = {}
-    for name, xs in (("1e-3", 1e-3), ("3e-2", 3e-2)):
+    for name, xs in (("1e-3", 1e-3), ("3e-2", 3e-2), ("1e-4", 1e-4), ("1e-6", 1e-6)):
         x = torch.randn(2, 128, 400, generator=g) * xs
         w = torch.randn(128, 128, 7, generator=g) / (128 * 7) ** 0.5
         ref = F.conv1d(F.leaky_relu(x.double(), 0.1), w.double(), None, padding=3)
@@ -83,14 +84,14 @@ def test_split_kernel_small_activation_stage(cuda, lib, monkeypatch, capsys):
         monkeypatch.setenv("MBHIP_CONV_SPLIT", "0")
         e_f32 = float((hiputil.conv1d_hip(x, w, None, pad=3, in_act=1, in_slope=0.1).cpu().double() - ref).abs().max()) / scale
         out[name] = (e_split, e_f32)
-        assert e_split <= 1e-4, (name, e_split, e_f32)
+        assert e_split <= (2e-4 if name == "1e-6" else max(4 * e_f32, 2e-6)), (name, e_split, e_f32)
     with capsys.disabled():
         print("\n[split conv, small activations] max err / output rms (split, fp32-input kernel):", out)
 
 
 def test_split_kernel_range_counter(cuda, lib, monkeypatch):
-    """The hi / lo halves saturate at fp16's 65504 each: |x| > 131008 is silently clamped where the reference's fp32 conv is
-    not.  MBHIP_CONV_RANGE_CHECK=1 counts such values (and NaN / Inf) as they are staged; in-range data counts nothing."""
+    """The hi half saturates at fp16's 65504 and the scaled residual right behind it: |x| > 65536 is silently clamped where the
+    reference's fp32 conv is not.  MBHIP_CONV_RANGE_CHECK=1 counts such values (and NaN / Inf) as they are staged; in-range data counts nothing."""
     L = lib
     g = torch.Generator().manual_seed(5)
     x = torch.randn(1, 32, 200, generator=g)
@@ -102,7 +103,7 @@ def test_split_kernel_range_counter(cuda, lib, monkeypatch):
     x2 = x.clone()
     x2[0, 3, 50] = 2.0e5
     x2[0, 7, 120] = -1.5e5
-    x2[0, 9, 10] = 1.3e5  # inside the range: hi = 65504, lo = 64496
+    x2[0, 9, 10] = 60011.0  # inside the range: hi = 60000, residual 11 (x 2^11 = 22528, exact)
     y = hiputil.conv1d_hip(x2, w, None, pad=1)
     n = L.mb_conv1d_range_events(1)
     assert 2 <= n <= 4, n  # each bad value is staged once per workgroup whose window holds it (128 positions + halo each)
@@ -113,8 +114,8 @@ def test_split_kernel_range_counter(cuda, lib, monkeypatch):
         good[t - 1:t + 2] = False
     d = (y.cpu() - ref).abs()
     assert float(d[:, :, good].max()) < 1e-4   # untouched positions
-    assert float(d[:, :, 9:12].max()) < 8.0    # 1.3e5 is in range: hi = 65504, lo = 64496 rounded to fp16 (ulp 32) -> ~16 x |w|
-    assert float(d[:, :, 49:52].max()) > 100.0  # 2e5 was clamped to 131008: this is the silent saturation the counter reports
+    assert float(d[:, :, 9:12].max()) < 5e-2   # 60011 is in range and exact in hi + 2^-11 lo (fp32 rounding of ~6e3-sized sums only)
+    assert float(d[:, :, 49:52].max()) > 100.0  # 2e5 was clamped to ~65536: this is the silent saturation the counter reports
     monkeypatch.setenv("MBHIP_CONV_RANGE_CHECK", "0")
     hiputil.conv1d_hip(x2, w, None, pad=1)
     assert L.mb_conv1d_range_events(0) == 0  # off: nothing counted

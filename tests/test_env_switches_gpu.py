@@ -153,9 +153,11 @@ def test_wavernn_persistent_kernel_falls_back_to_the_chain(cuda, lib, monkeypatc
                                                                 (200, 3000, 300, 13, 1)],
                          ids=["2-folds", "3-folds", "15-folds", "23-folds", "32-folds", "3-folds-1-group", "13-folds-1-group"])
 def test_wavernn_pipe_kernel_keeps_the_sample_stream(wavernn, monkeypatch, frames, target, overlap, folds, groups):
-    """wavernn_pipe.h: ONE launch of role-specialised resident workgroups, two fold-column groups in flight (one with
-    MBHIP_WQ_GROUPS=1) -- against the 5-launch chain: the same samples, sample for sample, from 2 to 32 columns
-    (BASELINE configs[1] = 23)."""
+    """wavernn_pipe.h (the EXACT resident kernel: MBHIP_WQ16=0; also the MOL path): ONE launch of role-specialised resident
+    workgroups, two fold-column groups in flight (one with MBHIP_WQ_GROUPS=1) -- against the 5-launch chain: the same samples,
+    sample for sample, from 2 to 32 columns (BASELINE configs[1] = 23).  The default kernel since round 4 (wavernn_pipe16.h, 22-bit
+    operand pairs) is not bit-identical to the chain; it is held to the oracle in test_wavernn_gpu.py::test_production_*."""
+    monkeypatch.setenv("MBHIP_WQ16", "0")
     mel = torch.from_numpy(synth.wavernn_mel(frames, seed=17) / 4.0).cuda()
     monkeypatch.setenv("MBHIP_WAVERNN_PIPE", "0")
     monkeypatch.setenv("MBHIP_WAVERNN_PERSIST", "0")

@@ -498,7 +498,7 @@ def test_debug_noise_is_exponential(model):
     assert torch.equal(e[10:20], dev.sampler_noise(3, 10, 5, step0=10))
 
 
-@pytest.mark.parametrize("form", ["default", "chain", "pipe"])
+@pytest.mark.parametrize("form", ["default", "chain", "pipe", "pipe_exact"])
 def test_production_fast_chain_23_folds_vs_oracle(model, monkeypatch, form):
     """BASELINE configs[1], 23 folds x 2000 steps against the oracle: the default call (whatever bench.py times), the
     wf_* launch chain (FM fast chain, fused sampler, hipGraph replays) and the resident pipelined kernel
@@ -506,16 +506,52 @@ def test_production_fast_chain_23_folds_vs_oracle(model, monkeypatch, form):
     dev, w = model
     for k in ("MBHIP_WAVERNN_FAST", "MBHIP_WAVERNN_PERSIST", "MBHIP_WAVERNN_NOFUSE", "MBHIP_WAVERNN_CHAIN", "MBHIP_NO_GRAPH", "MBHIP_WAVERNN_PIPE"):
         monkeypatch.delenv(k, raising=False)
+    monkeypatch.delenv("MBHIP_WQ16", raising=False)
     if form != "default":
-        monkeypatch.setenv("MBHIP_WAVERNN_PIPE", "1" if form == "pipe" else "0")
+        monkeypatch.setenv("MBHIP_WAVERNN_PIPE", "0" if form == "chain" else "1")
+    if form == "pipe_exact":
+        monkeypatch.setenv("MBHIP_WQ16", "0")  # wavernn_pipe.h: fp32 MFMA, 8-byte {value, tag} granules (bit-identical to the chain)
     frames, target, overlap, steps, seed = 1000, 8000, 800, 2000, 1234
     mel = synth.wavernn_mel(frames, seed=1)
     s = dev.generate_samples(torch.from_numpy(mel / 4.0).cuda(), True, target, overlap, seed=seed).cpu()
     assert (dev.last_plan.n_folds, dev.last_plan.seq_len) == (23, 9600)
-    assert dev.last_loop_launches == {"default": dev.last_loop_launches, "chain": 5 * 9600, "pipe": 1}[form]
+    assert dev.last_loop_launches == {"default": 1, "chain": 5 * 9600, "pipe": 1, "pipe_exact": 1}[form]
     noise = dev.sampler_noise(seed, steps, 23).cpu()
     o_s, o_l = _oracle_replay(w, mel, True, target, overlap, s, noise, steps)
     _assert_same_picks(s, o_s, o_l, noise, steps, max_ties=8)
+
+
+@pytest.mark.parametrize("frames,target,overlap,folds,groups", [(40, 4000, 200, 2, 2), (40, 3000, 100, 3, 2), (330, 4000, 400, 15, 2),
+                                                                (330, 2000, 100, 32, 2), (200, 3000, 300, 13, 1)],
+                         ids=["2-folds", "3-folds", "15-folds", "32-folds", "13-folds-1-group"])
+def test_production_pipe16_geometries_vs_oracle(model, monkeypatch, frames, target, overlap, folds, groups):
+    """wavernn_pipe16.h (the default resident kernel for RAW models since round 4: exchange vectors as fp16 hi / lo pairs with 2-bit
+    tags, error-compensated fp16 MFMA products) from 2 to 32 fold columns, two column groups and one: 400 steps each against the
+    oracle's loop body on the device's history with the exported noise (fatchord_version.py:190-228) -- the pick of every step must be
+    the oracle's except provable near-ties.  Same seed -> same stream (the kernel is deterministic); MBHIP_WQ16=0 is the exact
+    kernel, whose stream is the launch chain's."""
+    dev, w = model
+    for k in ("MBHIP_WAVERNN_PERSIST", "MBHIP_WAVERNN_PIPE", "MBHIP_WQ16", "MBHIP_WQ_GROUPS"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("MBHIP_WAVERNN_PERSIST", "0")
+    if groups == 1:
+        monkeypatch.setenv("MBHIP_WQ_GROUPS", "1")
+    mel = synth.wavernn_mel(frames, seed=17)
+    m = torch.from_numpy(mel / 4.0).cuda()
+    s = dev.generate_samples(m, True, target, overlap, seed=31).cpu()
+    assert s.shape[0] == folds and dev.last_loop_launches == 1, "the resident kernel did not run"
+    s2 = dev.generate_samples(m, True, target, overlap, seed=31).cpu()
+    assert torch.equal(s, s2)
+    steps = min(400, s.shape[1])
+    noise = dev.sampler_noise(31, steps, folds).cpu()
+    o_s, o_l = _oracle_replay(w, mel, True, target, overlap, s, noise, steps)
+    _assert_same_picks(s, o_s, o_l, noise, steps, max_ties=3)
+    monkeypatch.setenv("MBHIP_WQ16", "0")
+    exact = dev.generate_samples(m, True, target, overlap, seed=31).cpu()
+    assert dev.last_loop_launches == 1 and exact.shape == s.shape
+    # the two kernels draw the same noise: their streams agree until the first near-tie decides differently (usually never within
+    # the first steps); report-only sanity that they are the same process
+    assert float((exact[:, :50] == s[:, :50]).float().mean()) > 0.9
 
 
 @pytest.mark.parametrize("form", ["fmaf", "mfma", "chain"])

@@ -12,6 +12,8 @@ out = {"cases": {}}
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 CASES = (("configs1_23_folds", 1000, 8000, 800, ("chain", "pipe")), ("12_folds", 200, 3000, 300, ("chain", "pipe", "pipe_1group")),
          ("4_folds", 40, 2200, 100, ("chain", "pipe", "persist")), ("32_folds", 330, 2000, 100, ("chain", "pipe")))
+if os.environ.get("WQ_AB_CASES"):  # e.g. WQ_AB_CASES=configs1_23_folds: only these cases (a quick marks run under MBHIP_WQ_FLAGS)
+    CASES = tuple(c for c in CASES if c[0] in os.environ["WQ_AB_CASES"].split(","))
 for name, F, target, overlap, modes in CASES:
     mel = torch.from_numpy(synth.wavernn_mel(F, seed=0) / 4.0).cuda()
     res = {}
@@ -39,7 +41,7 @@ for name, F, target, overlap, modes in CASES:
             if os.path.exists(tf):
                 m = struct.unpack("<320Q", open(tf, "rb").read())
                 t0 = m[0]  # R1, step 1000, mark 0
-                res["pipe_marks_us"] = {role: [[(m[(r * 4 + st) * 16 + k] - t0) / 100.0 if m[(r * 4 + st) * 16 + k] else None for k in range(6)]
+                res["pipe_marks_us"] = {role: [[(m[(r * 4 + st) * 16 + k] - t0) / 100.0 if m[(r * 4 + st) * 16 + k] else None for k in range(9)]
                                                for st in range(4)] for r, role in enumerate(("R1", "R2", "F1", "F2", "F3"))}
     ref = res.pop("chain_samples")
     res["sample_streams_identical"] = {m: bool(torch.equal(ref, res.pop(m + "_samples"))) for m in modes[1:]}
