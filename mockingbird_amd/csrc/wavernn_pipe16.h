@@ -74,6 +74,9 @@ inline void wq16_pack(const float* rows, int n_live_rows, int K, int RL, int sex
 }
 
 // ---- device side ----
+// gate functions on the hardware exp2 / reciprocal (1 ulp each): this kernel has no bit-identical partner to keep (gru_scan.h's rule)
+__device__ __forceinline__ float wq16_sigmoid(const float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float wq16_tanh(const float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * x)); }
 __device__ __forceinline__ unsigned wq16_tag2(const unsigned tag) { return ((tag >> 1) + 1u) & 3u; }
 
 // fp32 -> {fp16 hi | fp16 lo << 16}; the low half's least significant bit is left for the tag
@@ -210,14 +213,14 @@ __device__ __forceinline__ bool wq16_gemm2(const Wq16A& A0, const Wq16A& A1, con
 }
 
 // LDS (floats): [red: two 4096-float buffers, alternating] [keys / samples / residual hand-over]
-constexpr size_t WQ16_LDS_BYTES = (size_t)WQ_LDS_RED * 4 + 2 * WQ_GC * 8 + 8 * 16 * 4 + 64;
+constexpr size_t WQ16_LDS_BYTES = (size_t)WQ_LDS_RED * 4 + WQ_G * WQ_GC * 8 + WQ_GC * 4 + 8 * 16 * 4 + 64;
 
 __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
   const WqK& a = k16.q;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* red = lds;
-  unsigned long long* s_key = reinterpret_cast<unsigned long long*>(red + WQ_LDS_RED);  // [GC] max key of the step
-  float* s_x = reinterpret_cast<float*>(s_key + WQ_GC);                                 // [GC] decoded sample
+  unsigned long long* s_key = reinterpret_cast<unsigned long long*>(red + WQ_LDS_RED);  // [group][GC] max key of the step
+  float* s_x = reinterpret_cast<float*>(s_key + WQ_G * WQ_GC);                          // (R2: residual hand-over behind it)
   if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // (tests: the fallback path)
   const int blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
   if (blk < WQ_R1) {
     // ---------------------------------------------------------------------------------------------- R1: rnn1
     const bool mark_wg = blk == 0;
-    if (tid < WQ_GC) { s_key[tid] = 0ull; s_x[tid] = 0.f; }
+    if (tid < WQ_G * WQ_GC) s_key[tid] = 0ull;
     Wq16A A0, A1;
     wq16_load_a(k16.h_hh1, 2 * blk, A0);
     wq16_load_a(k16.h_hh1, 2 * blk + 1, A1);
@@ -261,7 +264,10 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
         const int n0 = a.gn0[g], Ng = a.gn0[g + 1] - n0;
         if (Ng <= 0) continue;
         WQ_MARK(0, 0);
-        // ---- keys of step s-1 -> sample x of every column of the group (classic {value, 32-bit tag} granules) ----
+        // ---- keys of step s-1 -> sample x of every column of the group (classic {value, 32-bit tag} granules): 32 tiles x Ng lanes
+        //      fetch and max them into LDS, ONE barrier, and every finish lane decodes its column's sample itself; the slots are cleared
+        //      behind the next barrier of this item (the h1 gather's), which every reader has passed by then ----
+        float x = 0.f;
         if (s > 0) {
           const unsigned long long* K = EX(WQX_KEY, g, tag_prev);
           wp_watch<1>(K + (size_t)((n_t3 - 1) * 2 + 1) * LD + (Ng - 1), tag_prev, a.abort_word);
@@ -269,29 +275,25 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
             const int tile = tid & 31, n = tid >> 5;
             unsigned kv[2];
             if (!wp_wait<2>(K + (size_t)tile * 2 * LD + n, LD, tag_prev, kv, a.abort_word)) return;
-            atomicMax(&s_key[n], ((unsigned long long)kv[0] << 32) | (unsigned long long)kv[1]);
+            atomicMax(&s_key[g * WQ_GC + n], ((unsigned long long)kv[0] << 32) | (unsigned long long)kv[1]);
           }
           __syncthreads();
           WQ_MARK(0, 1);
-          if (tid < Ng) {
-            const unsigned long long slot = s_key[tid];
-            const float x = slot ? 2.f * (float)argmax_class(slot) / ((float)a.C - 1.f) - 1.f : 0.f;
-            s_x[tid] = x;
-            s_key[tid] = 0ull;
-            if (blk == 0) {
-              a.samples[(size_t)(n0 + tid) * S + (s - 1)] = x;
-              if (a.progress && n0 + tid == 0 && (s - 1) % 100 == 0) *a.progress = s;
+          if (wave < 2) {
+            const unsigned long long slot = s_key[g * WQ_GC + i];
+            x = (slot && i < Ng) ? 2.f * (float)argmax_class(slot) / ((float)a.C - 1.f) - 1.f : 0.f;
+            if (blk == 0 && wave == 0 && du == 0 && i < Ng) {
+              a.samples[(size_t)(n0 + i) * S + (s - 1)] = x;
+              if (a.progress && n0 + i == 0 && (s - 1) % 100 == 0) *a.progress = s;
             }
           }
-          __syncthreads();
         }
         if (s == S) continue;
         // ---- rnn1 finish for (unit ju, column i): wf_finish_kernel's expressions; units 2j, 2j + 1 (lanes 16 apart) share a granule ----
         if (wave < 2) {
-          const float x = s_x[i];
-          const float rg = sigmoidf_((tq[g][0] + x * gr) + P1[g][0]);
-          const float zg = sigmoidf_((tq[g][1] + x * gz) + P1[g][1]);
-          const float ng = tanhf((tq[g][2] + x * gn) + rg * P1[g][2]);
+          const float rg = wq16_sigmoid((tq[g][0] + x * gr) + P1[g][0]);
+          const float zg = wq16_sigmoid((tq[g][1] + x * gz) + P1[g][1]);
+          const float ng = wq16_tanh((tq[g][2] + x * gn) + rg * P1[g][2]);
           const float hy = ng + zg * (h1[g] - ng);
           h1[g] = hy;
           const float x1 = (tq[g][3] + x * w0) + hy;
@@ -303,7 +305,11 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
           }
         }
         WQ_MARK(0, 2);
-        if (s + 1 >= S) continue;
+        if (s + 1 >= S) {  // last step: no hidden half to prepare; the key slots are still cleared behind a barrier
+          __syncthreads();
+          if (tid < WQ_GC) s_key[g * WQ_GC + tid] = 0ull;
+          continue;
+        }
         // ---- next step's table rows (a whole step to arrive) ----
         if (wave < 2) {
           const float4 t4 = wf_cond_row4(a.cond, wf_pos(a.g, n0 + (i < Ng ? i : Ng - 1), s + 1), (unsigned)a.g.total_len, ju, H, a.g.frames);
@@ -312,6 +318,7 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
         // ---- hidden half of the next step: P1 = W_hh1 . h1 + b_hh1, kept by the lane that will use it ----
         wh16x8 bh[2], bl[2];
         if (!wq16_gather<2>(EX(WQX_H1, g, tag), tag, Ng, bh, bl, a.abort_word, WQ_MK(0, 6))) return;
+        if (tid < WQ_GC) s_key[g * WQ_GC + tid] = 0ull;  // every finish lane has read the step's keys (the gather's barrier is behind us)
         WQ_MARK(0, 3);
         float sx[4];
         const bool epi = wq16_gemm2(A0, A1, bh, bl, red + rb * 4096, k16.us_hh1, sx);
@@ -370,9 +377,9 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
         WQ_MARK(1, 5);
         if (epi) {
           const float xr = s_xr[((wave & 1) * 4 + du) * 16 + i];
-          const float rg = sigmoidf_((sx[0] + g2v[g][0]) + P2[g][0]);
-          const float zg = sigmoidf_((sx[1] + g2v[g][1]) + P2[g][1]);
-          const float ng = tanhf((sx[2] + g2v[g][2]) + rg * P2[g][2]);
+          const float rg = wq16_sigmoid((sx[0] + g2v[g][0]) + P2[g][0]);
+          const float zg = wq16_sigmoid((sx[1] + g2v[g][1]) + P2[g][1]);
+          const float ng = wq16_tanh((sx[2] + g2v[g][2]) + rg * P2[g][2]);
           const float hy = ng + zg * (h2[g] - ng);
           h2[g] = hy;
           const float x2 = xr + hy;
