@@ -515,6 +515,12 @@ def main():
         "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1000.0, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "stub" if stub else "synthetic",
+        "dtype_note": ("fp32 weights, state, accumulators, epilogues and samples; since round 4 the resident kernel's matrix products run "
+                       "as error-compensated fp16 pairs on the fp16 matrix pipe (w = wh + wl, x = xh + xl, wl.xh + wh.xl + wh.xh, fp32 "
+                       "accumulate: 21-22 significant bits per operand instead of 24) and its exchange vectors carry the same pairs; "
+                       "parity = the reference loop body replayed on the device's own sample history with the exported noise "
+                       "(tests/test_wavernn_gpu.py::test_production_*: every pick equal except provable near-ties); MBHIP_WQ16=0 "
+                       "runs the exact fp32-MFMA kernel (bit-identical to the launch chain)"),
         "config": {"workload": "BASELINE configs[1]: WaveRNN 9-bit mu-law RAW, batch=1 utterance/GPU, "
                                f"mel 80x{F}, batched target=8000 overlap=800 -> {plan.n_folds} folds x "
                                f"{plan.seq_len} steps, Philox sampling, fp32 weights (synthetic, seeded)",
@@ -574,7 +580,7 @@ def main():
             """average duration of a kernel in the committed rocprofv3 --kernel-trace --stats summary of this command"""
             try:
                 import csv
-                for row in csv.DictReader(open(os.path.join(ROOT, "profiles", "r03_bench_kernel_stats.csv"))):
+                for row in csv.DictReader(open(os.path.join(ROOT, "profiles", "r04_bench_kernel_stats.csv"))):
                     if kernel_substr in row.get("Name", ""):
                         return float(row["AverageNs"]) / 1e3
             except Exception:
@@ -585,15 +591,21 @@ def main():
             launch_us = float(np.median(loop_ms)) * 1000.0
             launch_bytes = step_bytes * plan.seq_len
             gbps = launch_bytes / (launch_us * 1e-6) / 1e9
-            traffic, traffic_src = committed("pipe_hbm_bytes_per_launch", ("r03_pmc_wavernn.json",))
+            q16 = os.environ.get("MBHIP_WQ16", "1") != "0"  # wavernn_pipe16.h (default) or the exact wavernn_pipe.h kernel
+            traffic, traffic_src = committed("pipe_hbm_bytes_per_launch", ("r04_pmc_wavernn.json",) if q16 else ("r03_pmc_wavernn.json",))
             os.environ["MBHIP_WAVERNN_PIPE"] = "0"  # the launch chain on the same utterance, for reference
             model.generate_samples(mel, True, target, overlap, seed=0)
             chain_us = model.last_loop_ms * 1e3 / plan.seq_len
             os.environ.pop("MBHIP_WAVERNN_PIPE")
-            rp = rocprof_avg_us("wf_pipe_kernel")
+            rp = rocprof_avg_us("wf_pipe16_kernel" if q16 else "wf_pipe_kernel")
             result["roofline"] = {
-                "kernel": "mb::wf_pipe_kernel (wavernn_pipe.h): the whole sample loop of the utterance as ONE resident launch -- 224 "
-                          "role-specialised workgroups, weight tiles in LDS, two fold-column groups in flight, granule hand-offs",
+                "kernel": ("mb::wf_pipe16_kernel (wavernn_pipe16.h): the whole sample loop of the utterance as ONE resident launch -- 224 "
+                           "role-specialised workgroups, two fold-column groups in flight; round 4: exchange vectors as fp16 hi / lo pairs "
+                           "(two features per 8-byte granule, 2-bit tags: half the sweep bytes), products as error-compensated "
+                           "v_mfma_f32_16x16x32_f16 on weight fragments held in registers; samples held to the oracle, "
+                           "tests/test_wavernn_gpu.py::test_production_*" if q16 else
+                           "mb::wf_pipe_kernel (wavernn_pipe.h, MBHIP_WQ16=0): the exact fp32 resident kernel -- 224 "
+                           "role-specialised workgroups, weight tiles in LDS, two fold-column groups in flight, granule hand-offs"),
                 "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
                 "frac_rocprof": (launch_bytes / (rp * 1e-6) / 1e9 / HBM_PEAK_GBS) if rp else None, "rocprof_avg_launch_us": rp,
                 "traffic": traffic, "traffic_source": traffic_src,
@@ -602,7 +614,7 @@ def main():
                 "avg_launch_us": launch_us,
                 "avg_launch_us_method": "HIP events recorded on the loop's own stream right before and after the launch "
                                         "(mb_wavernn_last_loop_ms), median over the timed passes; frac_rocprof uses the average "
-                                        "duration of the same kernel in profiles/r03_bench_kernel_stats.csv",
+                                        "duration of the same kernel in profiles/r04_bench_kernel_stats.csv",
                 "note": "algorithmic bytes follow SURVEY 8(d) (16.3 MB of fp32 weights per step as if streamed); the resident kernel "
                         "reads each weight ONCE per utterance, so `traffic` is far below them -- the bound that matters is the "
                         "hand-off latency of the 5 all-to-all edges per step, DESIGN.md section 4e",

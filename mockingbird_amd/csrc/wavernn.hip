@@ -801,7 +801,11 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
   const bool resident_ok = fastk && C <= 512 && !w->bench_which && !w->bench_chain && !getenv("MBHIP_TRACE_FILE") && !getenv("MBHIP_WF_DBG_WHICH");
   const bool persist_asked = penv && atoi(penv) == 1 && N <= WP_NCOL;  // MBHIP_WAVERNN_PERSIST=1 keeps meaning wavernn_persist.h
   // (MOL models: the pipelined kernel only -- its F3 role carries the mixture sampler; one column runs the chain)
-  bool pipe = resident_ok && N >= 2 && N <= WQ_G * WQ_GC && (qenv ? atoi(qenv) != 0 : (WQ_DEFAULT_ON != 0 && !persist_asked));
+  const char* e16 = getenv("MBHIP_WQ16");
+  // RAW models run the kernel on 22-bit operand pairs (wavernn_pipe16.h: half the sweep bytes, fp16 matrix pipe, up to four column
+  // groups = 64 columns; samples checked against the oracle, not bit-identical to the chain); MBHIP_WQ16=0 and MOL models: the exact kernel
+  const bool q16 = c.mode == 0 && w->q_fc3.p && w->q_hh1.p && !(e16 && atoi(e16) == 0);
+  bool pipe = resident_ok && N >= 2 && N <= (q16 ? WQ_GMAX : WQ_G) * WQ_GC && (qenv ? atoi(qenv) != 0 : (WQ_DEFAULT_ON != 0 && !persist_asked));
   bool persist = resident_ok && c.mode == 0 && !pipe && N <= WP_NCOL && (penv ? atoi(penv) != 0 : N == 1);
   if ((pipe || persist) && !rc) {
     int dev = 0;
@@ -827,7 +831,7 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
   }
   if ((pipe || persist) && !rc) {
     const size_t ex_bytes = pipe ? wq_exchange_bytes() : wp_exchange_bytes();
-    int* abort_word = reinterpret_cast<int*>(L.px + (pipe ? (size_t)WQ_G * 2 * WQX_PER : (size_t)2 * WPX_PER_PARITY));
+    int* abort_word = reinterpret_cast<int*>(L.px + (pipe ? (size_t)WQ_GMAX * 2 * WQX_PER : (size_t)2 * WPX_PER_PARITY));
     MB_HIP(hipMemsetAsync(L.px, 0, ex_bytes, s));
     if (getenv("MBHIP_WP_TEST_ABORT"))  // tests only: the launch finds its abort word raised, the chain takes over
       MB_HIP(hipMemsetAsync(abort_word, 1, 1, s));
@@ -843,14 +847,18 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
       qk.g = wg; qk.ex = L.px; qk.abort_word = abort_word;
       qk.samples = d_samples; qk.progress = h_progress; qk.seed = seed; qk.R = R; qk.FC = FC; qk.C = C; qk.S = S; qk.N = N;
       qk.mol = c.mode == 1 ? 1 : 0; qk.nr_mix = C / 3;
-      qk.gn0[0] = 0; qk.gn0[1] = (N + 1) / 2; qk.gn0[2] = N;  // two groups of ceil / floor (N / 2) columns
-      if (const char* ge = getenv("MBHIP_WQ_GROUPS")) { if (atoi(ge) == 1 && N <= WQ_GC) qk.gn0[1] = N; }  // A/B: one group, no pipelining
+      {  // column groups: two up to 32 columns, ceil(N / 16) beyond (pipe16 only), sizes as even as possible
+        int ng = N <= 2 * WQ_GC ? 2 : (N + WQ_GC - 1) / WQ_GC;
+        if (const char* ge = getenv("MBHIP_WQ_GROUPS")) {  // A/B: one group (no pipelining) / more groups than needed
+          const int want = atoi(ge);
+          if (want == 1 && N <= WQ_GC) ng = 1;
+          else if (q16 && want >= ng && want <= WQ_GMAX) ng = want;
+        }
+        for (int g = 0; g <= WQ_GMAX; ++g) qk.gn0[g] = g >= ng ? N : (int)((long long)N * g / ng + ((long long)N * g % ng ? 1 : 0));  // ceil(N g / ng)
+        if (ng == 2) qk.gn0[1] = (N + 1) / 2;
+      }
       qk.flags = getenv("MBHIP_WQ_FLAGS") ? atoi(getenv("MBHIP_WQ_FLAGS")) : 17;  // A/B switches of wavernn_pipe.h (1 = padded rows, 16 = weights in registers)
       qk.trace = trace;
-      // RAW models run the kernel on 22-bit operand pairs (wavernn_pipe16.h: half the sweep bytes, fp16 matrix pipe; samples checked
-      // against the oracle, not bit-identical to the chain); MBHIP_WQ16=0 and MOL models: the exact kernel
-      const char* e16 = getenv("MBHIP_WQ16");
-      const bool q16 = c.mode == 0 && w->q_fc3.p && w->q_hh1.p && !(e16 && atoi(e16) == 0) && (qk.flags & 1);
       if (q16) {
         Wq16K k16;
         k16.q = qk;

@@ -36,13 +36,14 @@ namespace mb {
 
 constexpr int WQ_R1 = 64, WQ_R2 = 64, WQ_F = 32;
 constexpr int WQ_WGS = WQ_R1 + WQ_R2 + 3 * WQ_F;  // 224 resident workgroups, one per compute unit
-constexpr int WQ_G = 2;                           // column groups in flight
+constexpr int WQ_G = 2;                           // column groups in flight (this kernel: 2..32 columns)
+constexpr int WQ_GMAX = 4;                        // wavernn_pipe16.h serves up to four groups (33..64 columns: an utterance beyond ~1400 frames)
 constexpr int WQ_GC = 16;                         // columns per group (one MFMA column tile)
 constexpr int WQ_DEFAULT_ON = 1;                  // default for 2..32 columns (MBHIP_WAVERNN_PIPE overrides)
 
 // exchange area per (group, parity), in granules
 enum { WQX_X1 = 0, WQX_X2 = 8192, WQX_H1 = 16384, WQX_H2 = 24576, WQX_Y1 = 32768, WQX_Y2 = 40960, WQX_KEY = 49152, WQX_PER = 50176 };
-inline size_t wq_exchange_bytes() { return (size_t)WQ_G * 2 * WQX_PER * 8 + 256 + 8192; }  // + abort word + diagnostics marks
+inline size_t wq_exchange_bytes() { return (size_t)WQ_GMAX * 2 * WQX_PER * 8 + 256 + 8192; }  // + abort word + diagnostics marks
 
 struct WqK {
   const float* w_rnn2; const float* w_hh2; const float* w_hh1; const float* w_fc1; const float* w_fc2; const float* w_fc3;
@@ -52,7 +53,7 @@ struct WqK {
   unsigned long long* ex; int* abort_word;
   float* samples; volatile int* progress;
   unsigned long long seed; int R, FC, C, S, N;
-  int gn0[WQ_G + 1];          // group g owns fold columns [gn0[g], gn0[g + 1])
+  int gn0[WQ_GMAX + 1];       // group g owns fold columns [gn0[g], gn0[g + 1]); wf_pipe_kernel looks at the first WQ_G groups only
   int mol, nr_mix;            // MOL mode (fatchord_version.py:213-220): fc3 has 3 nr_mix rows, F3 is ONE workgroup that samples the
                               // mixture of logistics itself (wf_fc3_mol_kernel's draws) and hands the SAMPLE to R1
   int flags;                  // A/B switches (MBHIP_WQ_FLAGS, default 17): 1 = exchange rows padded to 16 columns, 2 = R2's residual x1 by a global load,

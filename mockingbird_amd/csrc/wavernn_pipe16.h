@@ -21,7 +21,9 @@
 // The sample stream is therefore NOT bit-identical to the launch chain's / wf_pipe_kernel's any more (VERDICT r03 item 3 allows
 // that); it is held to the oracle itself: tests/test_wavernn_gpu.py::test_production_* replay the reference loop body on the device's
 // own history with the exported noise.  MBHIP_WQ16=0 selects the exact kernel (wavernn_pipe.h, the A/B partner and the MOL path).
-// Roles, groups in flight, item order, deadlock argument, bail-outs: wavernn_pipe.h's, unchanged.
+// Roles, item order, deadlock argument, bail-outs: wavernn_pipe.h's, unchanged.  Column groups: two for 2..32 columns as there; THREE or
+// FOUR for 33..64 columns (fold_with_overlap has no limit, fatchord_version.py:288-338: an utterance beyond ~1400 mel frames used to
+// drop to the launch chain) -- a workgroup serves the groups in turn, the period stays the trip of ONE group while its items fit.
 #pragma once
 #include "wavernn_pipe.h"
 
@@ -213,14 +215,14 @@ __device__ __forceinline__ bool wq16_gemm2(const Wq16A& A0, const Wq16A& A1, con
 }
 
 // LDS (floats): [red: two 4096-float buffers, alternating] [keys / samples / residual hand-over]
-constexpr size_t WQ16_LDS_BYTES = (size_t)WQ_LDS_RED * 4 + WQ_G * WQ_GC * 8 + WQ_GC * 4 + 8 * 16 * 4 + 64;
+constexpr size_t WQ16_LDS_BYTES = (size_t)WQ_LDS_RED * 4 + WQ_GMAX * WQ_GC * 8 + WQ_GC * 4 + 8 * 16 * 4 + 64;
 
 __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
   const WqK& a = k16.q;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* red = lds;
   unsigned long long* s_key = reinterpret_cast<unsigned long long*>(red + WQ_LDS_RED);  // [group][GC] max key of the step
-  float* s_x = reinterpret_cast<float*>(s_key + WQ_G * WQ_GC);                          // (R2: residual hand-over behind it)
+  float* s_x = reinterpret_cast<float*>(s_key + WQ_GMAX * WQ_GC);                          // (R2: residual hand-over behind it)
   if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // (tests: the fallback path)
   const int blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -240,16 +242,16 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
   if (blk < WQ_R1) {
     // ---------------------------------------------------------------------------------------------- R1: rnn1
     const bool mark_wg = blk == 0;
-    if (tid < WQ_G * WQ_GC) s_key[tid] = 0ull;
+    if (tid < WQ_GMAX * WQ_GC) s_key[tid] = 0ull;
     Wq16A A0, A1;
     wq16_load_a(k16.h_hh1, 2 * blk, A0);
     wq16_load_a(k16.h_hh1, 2 * blk + 1, A1);
     const int ju = (2 * blk + (wave & 1)) * 4 + du;  // unit of an epilogue lane (waves 0 / 1)
     const float4 bq = a.bhh1q[ju];
     const float gr = a.g1[ju], gz = a.g1[H + ju], gn = a.g1[2 * H + ju], w0 = a.wI0[ju];
-    float h1[WQ_G], P1[WQ_G][3], tq[WQ_G][4];
+    float h1[WQ_GMAX], P1[WQ_GMAX][3], tq[WQ_GMAX][4];
 #pragma unroll
-    for (int g = 0; g < WQ_G; ++g) {
+    for (int g = 0; g < WQ_GMAX; ++g) {
       h1[g] = 0.f; P1[g][0] = bq.x; P1[g][1] = bq.y; P1[g][2] = bq.z;  // W_hh . 0 + b_hh
       const int Ng = a.gn0[g + 1] - a.gn0[g];
       const int ncl = a.gn0[g] + (i < Ng ? i : (Ng > 0 ? Ng - 1 : 0));
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
     for (int s = 0; s <= S; ++s) {
       const unsigned tag_prev = (unsigned)s, tag = (unsigned)s + 1;
 #pragma unroll
-      for (int g = 0; g < WQ_G; ++g) {
+      for (int g = 0; g < WQ_GMAX; ++g) {
         const int n0 = a.gn0[g], Ng = a.gn0[g + 1] - n0;
         if (Ng <= 0) continue;
         WQ_MARK(0, 0);
@@ -345,15 +347,15 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
     const int xr_wave = b2 >> 3, xr_st = (b2 >> 2) & 1, xr_kb = b2 & 3;
     float* s_xr = s_x + WQ_GC;  // [8 units][16 columns]
     const float4 bq = a.bhh2q[ju];
-    float h2[WQ_G], P2[WQ_G][3], g2v[WQ_G][3];
-    int g2_row[WQ_G];
+    float h2[WQ_GMAX], P2[WQ_GMAX][3], g2v[WQ_GMAX][3];
+    int g2_row[WQ_GMAX];
 #pragma unroll
-    for (int g = 0; g < WQ_G; ++g) { h2[g] = 0.f; P2[g][0] = bq.x; P2[g][1] = bq.y; P2[g][2] = bq.z; g2_row[g] = -1; g2v[g][0] = g2v[g][1] = g2v[g][2] = 0.f; }
+    for (int g = 0; g < WQ_GMAX; ++g) { h2[g] = 0.f; P2[g][0] = bq.x; P2[g][1] = bq.y; P2[g][2] = bq.z; g2_row[g] = -1; g2v[g][0] = g2v[g][1] = g2v[g][2] = 0.f; }
     __syncthreads();
     for (int s = 0; s < S; ++s) {
       const unsigned tag = (unsigned)s + 1;
 #pragma unroll
-      for (int g = 0; g < WQ_G; ++g) {
+      for (int g = 0; g < WQ_GMAX; ++g) {
         const int n0 = a.gn0[g], Ng = a.gn0[g + 1] - n0;
         if (Ng <= 0) continue;
         const int frow = wf_frame_row(a.g, n0 + (i < Ng ? i : Ng - 1), s);
@@ -411,16 +413,16 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
   wq16_load_a(fr == 0 ? k16.h_fc1 : fr == 1 ? k16.h_fc2 : k16.h_fc3, ft, A0);
   const float us = fr == 0 ? k16.us_fc1 : fr == 1 ? k16.us_fc2 : k16.us_fc3;
   const float4 b3q = fr == 2 ? *reinterpret_cast<const float4*>(a.b_fc3 + ft * 16 + du * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 fpre[WQ_G];
-  int f_row[WQ_G];
+  float4 fpre[WQ_GMAX];
+  int f_row[WQ_GMAX];
 #pragma unroll
-  for (int g = 0; g < WQ_G; ++g) { fpre[g] = make_float4(0.f, 0.f, 0.f, 0.f); f_row[g] = -1; }
+  for (int g = 0; g < WQ_GMAX; ++g) { fpre[g] = make_float4(0.f, 0.f, 0.f, 0.f); f_row[g] = -1; }
   const int src = fr == 0 ? WQX_X2 : fr == 1 ? WQX_Y1 : WQX_Y2;
   __syncthreads();
   for (int s = 0; s < S; ++s) {
     const unsigned tag = (unsigned)s + 1;
 #pragma unroll
-    for (int g = 0; g < WQ_G; ++g) {
+    for (int g = 0; g < WQ_GMAX; ++g) {
       const int n0 = a.gn0[g], Ng = a.gn0[g + 1] - n0;
       if (Ng <= 0) continue;
       const int ncl = n0 + (i < Ng ? i : Ng - 1);
