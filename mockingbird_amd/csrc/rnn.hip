@@ -11,7 +11,7 @@
 // Hence: (1) the kernel is specialised at compile time on the feature set the caller uses (F), so a
 // launch executes straight-line code with no dead branches; (2) every load is issued before the
 // first wait; (3) nothing the previous launch wrote is read except the activations themselves.
-#include "rnn_ts2_body.h"
+#include "rnn_ts3_body.h"
 
 namespace mb {
 
@@ -132,6 +132,22 @@ __global__ __launch_bounds__(256) void rnn_dual_linear_ts2_kernel(RnnDev d0, Rnn
   if ((int)blockIdx.x < nx0) rnn_ts2_body<EPI_LINEAR, F0, MT, NT>(d0, blockIdx.x, blockIdx.y);
   else rnn_ts2_body<EPI_LINEAR, F1, MT, NT>(d1, blockIdx.x - nx0, blockIdx.y);
 }
+// The same wave tiling on the fp16 matrix pipe (rnn_ts3_body.h: error-compensated products, activations split once per workgroup in LDS)
+template <int EPI, unsigned F, int MT, int NT>
+__global__ __launch_bounds__(256) void rnn_ts3_kernel(RnnDev d) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ts3_lds[];
+  rnn_ts3_body<EPI, F, MT, NT>(d, blockIdx.x, blockIdx.y, reinterpret_cast<t3h*>(ts3_lds));
+}
+template <unsigned F0, unsigned F1, int MT, int NT>
+__global__ __launch_bounds__(256) void rnn_dual_linear_ts3_kernel(RnnDev d0, RnnDev d1, int nx0) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ts3_lds[];
+  if ((int)blockIdx.x < nx0) rnn_ts3_body<EPI_LINEAR, F0, MT, NT>(d0, blockIdx.x, blockIdx.y, reinterpret_cast<t3h*>(ts3_lds));
+  else rnn_ts3_body<EPI_LINEAR, F1, MT, NT>(d1, blockIdx.x - nx0, blockIdx.y, reinterpret_cast<t3h*>(ts3_lds));
+}
+static bool rnn_ts3_enabled() {
+  const char* e = getenv("MBHIP_RNN_TS3");
+  return !(e && atoi(e) == 0);
+}
 // Column tiles per wave of the register-tiled wide form, 0 = use the first wide form (rnn_body.h TS).
 // 128 row tiles in pieces of 2 make 16 workgroup rows, so the piece must be narrow enough for >= 256 workgroups:
 // 3 column tiles from 44 column tiles up (736 columns: exactly one piece per SIMD), 2 from 28, 1 from 14; narrower
@@ -243,6 +259,13 @@ int rnn_launch_dual_linear(const RnnK& k0, const RnnK& k1, hipStream_t s) {
     dim3 g2(cdiv(nx0, MT * TS2_WAVES) + cdiv(nx1, MT * TS2_WAVES), cdiv(cdiv(k0.N, 16), nt2));
     MB_REQUIRE(k0.nkb_total == k1.nkb_total, "rnn_launch_dual(ts2): jobs must share K");
     const int nxw = cdiv(nx0, MT * TS2_WAVES);
+    if (k0.w16 && k1.w16 && rnn_ts3_enabled()) {  // fp16 matrix pipe, error-compensated (rnn_ts3_body.h)
+      if (nt2 == 3) hipLaunchKernelGGL((rnn_dual_linear_ts3_kernel<F0 | RF_FOLDTAB, F1, MT, 3>), g2, dim3(256), ts3_lds_bytes<3>(), s, d0, d1, nxw);
+      else if (nt2 == 2) hipLaunchKernelGGL((rnn_dual_linear_ts3_kernel<F0 | RF_FOLDTAB, F1, MT, 2>), g2, dim3(256), ts3_lds_bytes<2>(), s, d0, d1, nxw);
+      else hipLaunchKernelGGL((rnn_dual_linear_ts3_kernel<F0 | RF_FOLDTAB, F1, MT, 1>), g2, dim3(256), ts3_lds_bytes<1>(), s, d0, d1, nxw);
+      MB_HIP(hipGetLastError());
+      return MB_OK;
+    }
     if (nt2 == 3) hipLaunchKernelGGL((rnn_dual_linear_ts2_kernel<F0 | RF_FOLDTAB, F1, MT, 3>), g2, dim3(256), 0, s, d0, d1, nxw);
     else if (nt2 == 2) hipLaunchKernelGGL((rnn_dual_linear_ts2_kernel<F0 | RF_FOLDTAB, F1, MT, 2>), g2, dim3(256), 0, s, d0, d1, nxw);
     else hipLaunchKernelGGL((rnn_dual_linear_ts2_kernel<F0 | RF_FOLDTAB, F1, MT, 1>), g2, dim3(256), 0, s, d0, d1, nxw);
@@ -344,6 +367,17 @@ int rnn_launch(int epi, const RnnK& k, hipStream_t s) {
     constexpr unsigned FL = RF_BIASX | RF_FRAME | RF_GUMBEL | RF_FOLDTAB;
     dim3 gts(cdiv(n_mt, 2), cdiv(cdiv(k.N, 16), 4));
     if (const int nt2 = rnn_ts2_nt(k.N)) {
+      const bool ts3 = k.w16 && rnn_ts3_enabled();  // fp16 matrix pipe, error-compensated (rnn_ts3_body.h)
+      if (epi == EPI_GRU && feat == FG && ts3) {
+        dim3 g2(cdiv(n_mt, 2 * TS2_WAVES), cdiv(cdiv(k.N, 16), nt2));
+        if (nt2 == 3) hipLaunchKernelGGL((rnn_ts3_kernel<EPI_GRU, FG, 2, 3>), g2, dim3(256), ts3_lds_bytes<3>(), s, d);
+        else if (nt2 == 2) hipLaunchKernelGGL((rnn_ts3_kernel<EPI_GRU, FG, 2, 2>), g2, dim3(256), ts3_lds_bytes<2>(), s, d);
+        else hipLaunchKernelGGL((rnn_ts3_kernel<EPI_GRU, FG, 2, 1>), g2, dim3(256), ts3_lds_bytes<1>(), s, d);
+        done = true;
+      } else if (epi == EPI_LINEAR && feat == FL && ts3) {
+        dim3 g2(cdiv(n_mt, MB_TS2_FC3_MT * TS2_WAVES), cdiv(cdiv(k.N, 16), MB_TS2_FC3_NT));
+        hipLaunchKernelGGL((rnn_ts3_kernel<EPI_LINEAR, FL, MB_TS2_FC3_MT, MB_TS2_FC3_NT>), g2, dim3(256), ts3_lds_bytes<MB_TS2_FC3_NT>(), s, d); done = true;
+      } else
       if (epi == EPI_GRU && feat == FG) {  // rnn2: 128 row tiles -> 2 x nt2 tiles per wave
         dim3 g2(cdiv(n_mt, 2 * TS2_WAVES), cdiv(cdiv(k.N, 16), nt2));
         if (nt2 == 3) hipLaunchKernelGGL((rnn_ts2_kernel<EPI_GRU, FG, 2, 3>), g2, dim3(256), 0, s, d);

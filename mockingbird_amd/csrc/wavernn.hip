@@ -273,7 +273,8 @@ struct mb_wavernn {
   // resident kernel on 22-bit operand pairs (wavernn_pipe16.h): fp16 hi / lo A fragments of the six on-chip matrices (uint16 pairs
   // stored in float-typed buffers) and their 2^-s
   DevBuf q_rnn2, q_hh2, q_hh1, q_fc1, q_fc2, q_fc3;
-  float q_us[6] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+  DevBuf q_hh1l, q_hh2l;  // the hidden halves as plain gate-major linears (the batch loop's hh jobs, rnn_ts3_body.h)
+  float q_us[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
   // Folds are independent sequences: they are dealt to up to MAX_LANES "lanes", each with its own
   // stream + graph, so the per-kernel dependency latency of one lane overlaps with the others.
   static constexpr int MAX_LANES = 8;
@@ -490,6 +491,7 @@ extern "C" int mb_wavernn_create(const mb_wavernn_config* cfg, const float* cons
     }
     pack_rowtile(whh, 3 * R, R, 4, &packed);
     RC(w->w_hh1.upload(packed.data(), packed.size()));
+    RC(upload_q16(whh, 3 * R, R, 4, &w->q_hh1l, &w->q_us[6]));
     cell_rows(whh, R, R, whh, 0, R, 3, &rows); pack_rowtile(rows.data(), 3 * R, R, 3, &packed);
     RC(w->f_hh1t.upload(packed.data(), packed.size()));
     RC(upload_q16(rows.data(), 3 * R, R, 3, &w->q_hh1, &w->q_us[2]));
@@ -510,6 +512,7 @@ extern "C" int mb_wavernn_create(const mb_wavernn_config* cfg, const float* cons
     RC(upload_q16(rows.data(), 3 * R, R, 3, &w->q_rnn2, &w->q_us[0]));
     pack_rowtile(whh, 3 * R, R, 4, &packed);
     RC(w->w_hh2.upload(packed.data(), packed.size()));
+    RC(upload_q16(whh, 3 * R, R, 4, &w->q_hh2l, &w->q_us[7]));
     cell_rows(whh, R, R, whh, 0, R, 3, &rows); pack_rowtile(rows.data(), 3 * R, R, 3, &packed);
     RC(w->f_hh2t.upload(packed.data(), packed.size()));
     RC(upload_q16(rows.data(), 3 * R, R, 3, &w->q_hh2, &w->q_us[1]));
@@ -564,7 +567,7 @@ extern "C" void mb_wavernn_destroy(mb_wavernn* w) {
   DevBuf* bs[] = {&w->wI0, &w->g1I0, &w->w_rnn1, &w->w_rnn2, &w->w_fc1, &w->w_fc2, &w->w_fc3,
                   &w->b_ih1, &w->b_hh1, &w->b_hh2, &w->b_fc3, &w->w_rnn2x, &w->w_hh1, &w->w_hh2,
                   &w->f_hh1t, &w->f_hh2t, &w->f_bhh1q, &w->f_bhh2q, &w->kw,
-                  &w->q_rnn2, &w->q_hh2, &w->q_hh1, &w->q_fc1, &w->q_fc2, &w->q_fc3};
+                  &w->q_rnn2, &w->q_hh2, &w->q_hh1, &w->q_fc1, &w->q_fc2, &w->q_fc3, &w->q_hh1l, &w->q_hh2l};
   for (DevBuf* b : bs) b->release();
   w->drop_graph();
   if (w->h_abort) (void)hipHostFree(w->h_abort);
@@ -1404,6 +1407,7 @@ static int wavernn_generate_batch_impl(const mb_wavernn* wc, const mb_wavernn_ba
     RnnK k;
     memset(&k, 0, sizeof(k));
     k.w = w->w_rnn2x.p; k.nseg = 1; k.nkb_total = R / 16; k.seg[0] = {L.x1, R, R / 16, 0};
+    k.w16 = w->q_rnn2.p; k.w16_unscale = w->q_us[0];
     k.N = N; k.units = R; k.h_pre = L.P2; k.pre_table = L.G2; frame_rows(k); k.pre_stride = 3 * R;
     k.h_prev = h2p; k.x_res = L.x1; k.h_out = h2n; k.x_out = L.x2; k.zero_slot = slot_prev;
     if ((r = rnn_launch(EPI_GRU, k, s))) return r;
@@ -1411,16 +1415,19 @@ static int wavernn_generate_batch_impl(const mb_wavernn* wc, const mb_wavernn_ba
       RnnK k1;
       memset(&k, 0, sizeof(k)); memset(&k1, 0, sizeof(k1));
       k.w = g ? w->w_fc2.p : w->w_fc1.p; k.nseg = 1;
+      k.w16 = g ? w->q_fc2.p : w->q_fc1.p; k.w16_unscale = w->q_us[g ? 4 : 3];
       k.seg[0] = {g ? L.y1 : L.x2, g ? FC : R, (g ? FC : R) / 16, 0};
       k.nkb_total = k.seg[0].nkb;
       k.N = N; k.units = FC; k.pre_table = g ? L.F2 : L.F1; frame_rows(k); k.pre_stride = FC;
       k.y = g ? L.y2 : L.y1; k.ldy = FC; k.act = 1;
       k1.w = g ? w->w_hh2.p : w->w_hh1.p; k1.nseg = 1; k1.nkb_total = R / 16; k1.seg[0] = {g ? h2n : h1n, R, R / 16, 0};
+      k1.w16 = g ? w->q_hh2l.p : w->q_hh1l.p; k1.w16_unscale = w->q_us[g ? 7 : 6];
       k1.N = N; k1.units = 3 * R; k1.biasX = g ? w->b_hh2.p : w->b_hh1.p; k1.y = g ? L.P2 : L.P1; k1.ldy = 3 * R;
       if ((r = rnn_launch_dual_linear(k, k1, s))) return r;
     }
     memset(&k, 0, sizeof(k));
     k.w = w->w_fc3.p; k.nseg = 1; k.nkb_total = FC / 16; k.seg[0] = {L.y2, FC, FC / 16, 0};
+    k.w16 = w->q_fc3.p; k.w16_unscale = w->q_us[5];
     k.N = N; k.units = C; k.biasX = w->b_fc3.p; k.ldy = C; frame_rows(k);
     k.gum_slot = slot_cur; k.gum_seed = 0;
     return rnn_launch(EPI_LINEAR, k, s);

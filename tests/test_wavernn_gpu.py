@@ -281,11 +281,13 @@ def test_two_column_tiles_per_workgroup_is_bit_identical(model, monkeypatch):
     assert torch.equal(a, b), int((a != b).sum())
 
 
-def test_batch_loop_equals_single_utterance_runs(model):
+def test_batch_loop_equals_single_utterance_runs(model, monkeypatch):
     """mb_wavernn_generate_batch: three utterances of different lengths in ONE sample loop.  Fold n carries a
     descriptor with its utterance's table offsets and noise identity, so utterance u must reproduce
     generate_samples(mel_u, seed=seeds[u]) sample for sample (columns of the MFMA GEMMs are independent and the
-    Philox counter is (step, local fold, class) under the utterance's own seed)."""
+    Philox counter is (step, local fold, class) under the utterance's own seed).  The single runs use the exact
+    resident kernel (MBHIP_WQ16=0: the fp32-MFMA sums of the chain and of the narrow batch loop)."""
+    monkeypatch.setenv("MBHIP_WQ16", "0")
     dev, w = model
     frames = [41, 30, 57]
     mels = [torch.from_numpy(synth.wavernn_mel(f, seed=20 + i) / 4.0).cuda() for i, f in enumerate(frames)]
@@ -334,6 +336,8 @@ def test_wide_batch_tile_split_equals_single_runs(model, monkeypatch, form):
     instantiated piece width is exercised at 76 columns).  All of them walk the same 8 accumulation chains as
     the K-split form, so each utterance must still equal its own single-utterance run bit for bit."""
     dev, w = model
+    monkeypatch.setenv("MBHIP_RNN_TS3", "0")  # the fp32 forms (the default since round 4 is rnn_ts3_body.h: next test)
+    monkeypatch.setenv("MBHIP_WQ16", "0")     # single runs on the exact resident kernel
     if form == "ts":
         monkeypatch.setenv("MBHIP_RNN_TS2", "0")
     elif form.startswith("ts2_nt"):
@@ -350,6 +354,38 @@ def test_wide_batch_tile_split_equals_single_runs(model, monkeypatch, form):
         assert torch.equal(outs[u], single), (form, u, int((outs[u] != single).sum()))
     # utterances 0 and 2 have different mels but equal length; 1 and 3 share a seed but not a mel
     assert not torch.equal(outs[0], outs[2])
+
+
+def test_wide_batch_fp16_forms_agree_and_match_oracle(model, monkeypatch):
+    """rnn_ts3_body.h, the default wide form since round 4: the recurrent GEMMs as error-compensated fp16 MFMA products with the
+    activations split once per workgroup in LDS.  A column's sums must not depend on the batch it is in nor on the piece width:
+    the three instantiated widths (forced at 76 columns) give identical streams, equal lengths / equal seeds do not collide, and
+    every compared utterance follows the oracle's loop body (fatchord_version.py:190-228) on its own history with its seed's
+    noise.  (Not bit-identical to the fp32 forms / single runs any more: see the docstring of rnn_ts3_body.h.)"""
+    dev, w = model
+    monkeypatch.delenv("MBHIP_RNN_TS3", raising=False)
+    frames = [100, 93, 100, 77]
+    mels_np = [synth.wavernn_mel(f, seed=40 + i) for i, f in enumerate(frames)]
+    mels = [torch.from_numpy(m / 4.0).cuda() for m in mels_np]
+    seeds = [3, 1, 4, 1]
+    outs = {}
+    for nt in ("1", "2", "3"):
+        monkeypatch.setenv("MBHIP_TS2_NT", nt)
+        outs[nt] = [o.cpu() for o in dev.generate_samples_batch(mels, 1000, 100, seeds)]
+        assert dev.last_batch_plan.n_folds > 64
+    monkeypatch.delenv("MBHIP_TS2_NT")
+    for u in range(4):
+        assert torch.equal(outs["1"][u], outs["2"][u]) and torch.equal(outs["1"][u], outs["3"][u]), u
+    assert not torch.equal(outs["1"][0], outs["1"][2])
+    steps = 300
+    for u in (0, 3):
+        s = outs["3"][u]
+        noise = dev.sampler_noise(seeds[u], steps, s.shape[0]).cpu()
+        o_s, o_l = _oracle_replay(w, mels_np[u], True, 1000, 100, s, noise, steps)
+        _assert_same_picks(s, o_s, o_l, noise, steps, max_ties=3)
+    monkeypatch.setenv("MBHIP_RNN_TS3", "0")  # the fp32 form draws the same noise: same process, almost always the same picks early on
+    ref = dev.generate_samples_batch(mels, 1000, 100, seeds)[0].cpu()
+    assert float((ref[:, :50] == outs["3"][0][:, :50]).float().mean()) > 0.9
 
 
 # ---------------------------------------------------------------------------------------------------------
