@@ -91,6 +91,7 @@ struct RnnK {
   // wide batches (rnn_ts3_body.h): the same matrix as fp16 hi / lo A fragments of v_mfma_f32_16x16x32_f16
   // ([row tile][k-step of 32][hi | lo][lane][8], wavernn_pipe16.h wq16_pack) scaled by 2^s, and 2^-s; null -> the fp32 forms
   const void* w16; float w16_unscale;
+  int dbg;  // diagnostics (MBHIP_TS3_DBG, results are WRONG on purpose): 1 = rnn_ts3_body skips its k loop, 2 = skips its epilogues
 };
 
 // order-preserving float -> uint key and the packed (key, lowest-class-wins) argmax word

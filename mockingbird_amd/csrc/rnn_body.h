@@ -406,6 +406,7 @@ __device__ __forceinline__ void rnn_rowtile_body(const RnnDev& d, const int bx, 
 // fill the flat-segment argument block; returns MB_EINVAL if the segments do not cover nkb_total
 static inline int make_rnn_dev(const RnnK& k, RnnDev* d) {
   d->k = k;
+  if (const char* e = getenv("MBHIP_TS3_DBG")) d->k.dbg = atoi(e);  // diagnostics of rnn_ts3_body.h (wrong results on purpose)
   int start = 0;
   for (int t = 0; t < 4; ++t) {
     if (t < k.nseg) {

@@ -49,7 +49,7 @@ __device__ __forceinline__ void rnn_ts3_body(const RnnDev& d, const int bx, cons
   const int edu = lane >> 4;  // epilogue unit (or row quad) within the tile
   const int H = a.units;
   const int nks = a.nkb_total >> 1;   // k-steps of 32
-  const int NST = a.nkb_total >> 2;   // stages of 64 (launches require nkb_total % 8 == 0)
+  const int NST = (a.dbg & 1) ? 2 : a.nkb_total >> 2;   // stages of 64 (launches require nkb_total % 8 == 0); diagnostics: two stages only
 
   int mt_raw[MT], mt[MT], en_raw[NT], en[NT];
   const uint4* wA[MT];
@@ -201,7 +201,7 @@ __device__ __forceinline__ void rnn_ts3_body(const RnnDev& d, const int bx, cons
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       l_bx[m][r] = 0.f;
-      if (EPI == EPI_LINEAR && f_biasx) l_bx[m][r] = a.biasX[erow + r < H ? erow + r : H - 1];
+      if (EPI == EPI_LINEAR && f_biasx) l_bx[m][r] = a.biasX[erow + r < H ? erow + r : H - 1];  // (stable data: the compiler merges the four)
       if (EPI != EPI_LINEAR && f_biasx && r < RL) l_bx[m][r] = a.biasX[r * H + ej[m]];
     }
 #pragma unroll
@@ -209,6 +209,11 @@ __device__ __forceinline__ void rnn_ts3_body(const RnnDev& d, const int bx, cons
       const float* prp = a.pre_table + (size_t)prow[n] * a.pre_stride;
       const size_t so = (size_t)en[n] * H + ej[m];
       l_hp[m][n] = 0.f; l_xr[m][n] = 0.f;
+      if (EPI == EPI_LINEAR && f_pre && (H & 15) == 0) {  // the lane's four rows are one aligned 16-byte piece of the table row
+        const float4 p4 = *reinterpret_cast<const float4*>(prp + erow);
+        l_pre[m][n][0] = p4.x; l_pre[m][n][1] = p4.y; l_pre[m][n][2] = p4.z; l_pre[m][n][3] = p4.w;
+        l_hs[m][n][0] = l_hs[m][n][1] = l_hs[m][n][2] = l_hs[m][n][3] = 0.f;
+      } else
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         l_pre[m][n][r] = 0.f; l_hs[m][n][r] = 0.f;
@@ -235,6 +240,15 @@ __device__ __forceinline__ void rnn_ts3_body(const RnnDev& d, const int bx, cons
         for (int e = 0; e < 4; ++e) sum[m][n][e] *= us;
   }
 
+  if (a.dbg & 2) {  // diagnostics: no epilogue (the sums still have to be computed)
+    float t = 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) t += sum[m][n][0] + sum[m][n][1] + sum[m][n][2] + sum[m][n][3];
+    if (t == 12345.678f) a.h_out[0] = t;
+    return;
+  }
   // ---- the MT x NT epilogues: rnn_rowtile_body's, per tile ----
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
@@ -259,6 +273,8 @@ __device__ __forceinline__ void rnn_ts3_body(const RnnDev& d, const int bx, cons
                                         dsc_slo[nn], dsc_shi[nn], gr);
         else if (f_gum) philox4x32((uint32_t)fr_s, (uint32_t)(a.fr_n_off + n), (uint32_t)((mtt * 16 + du * 4) >> 2), 0x57415645u,
                                    (uint32_t)a.gum_seed, (uint32_t)(a.gum_seed >> 32), gr);
+        float yv[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool yvec = a.y && (a.units & 15) == 0 && (a.ldy & 3) == 0;  // four consecutive rows of a column: one 16-byte store
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = mtt * 16 + du * 4 + r;
@@ -267,13 +283,15 @@ __device__ __forceinline__ void rnn_ts3_body(const RnnDev& d, const int bx, cons
             if (act == 1) v = fmaxf(v, 0.f);
             else if (act == 2) v = sigmoidf_(v);
             else if (act == 3) v = tanhf(v);
-            if (a.y) a.y[(size_t)n * a.ldy + row] = v;
+            yv[r] = v;
+            if (a.y && !yvec) a.y[(size_t)n * a.ldy + row] = v;
             if (f_gum) {
               const float g = v - logf(-logf(u32_to_unit(gr[r])));
               if (g > best) { best = g; bcls = row; }  // ascending rows: first maximum kept
             }
           }
         }
+        if (yvec) *reinterpret_cast<float4*>(a.y + (size_t)n * a.ldy + mtt * 16 + du * 4) = make_float4(yv[0], yv[1], yv[2], yv[3]);
         if (f_gum) {  // the 4 row quads of this column sit in lanes l, l+16, l+32, l+48
           unsigned long long pk = pack_argmax(best, bcls);
           const unsigned long long o1 = __shfl_xor(pk, 16, 64);
@@ -290,9 +308,10 @@ __device__ __forceinline__ void rnn_ts3_body(const RnnDev& d, const int bx, cons
       const float e_xr = l_xr[m][nn];
       if (EPI == EPI_GRU) {  // torch GRUCell, as rnn_rowtile_body (absent biases are the same literal zeros there)
         const float zero = 0.f;
-        const float rg = sigmoidf_((sx[0] + (l_bx[m][0] + l_pre[m][nn][0])) + (sh[0] + zero));
-        const float zg = sigmoidf_((sx[1] + (l_bx[m][1] + l_pre[m][nn][1])) + (sh[1] + zero));
-        const float ng = tanhf((sx[2] + (l_bx[m][2] + l_pre[m][nn][2])) + rg * (sh[2] + zero));
+        // gates on the hardware exp2 / reciprocal (1 ulp): this form has no bit-identical partner to keep
+        const float rg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * ((sx[0] + (l_bx[m][0] + l_pre[m][nn][0])) + (sh[0] + zero))));
+        const float zg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * ((sx[1] + (l_bx[m][1] + l_pre[m][nn][1])) + (sh[1] + zero))));
+        const float ng = 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * ((sx[2] + (l_bx[m][2] + l_pre[m][nn][2])) + rg * (sh[2] + zero))));
         const float hy = ng + zg * (l_hp[m][nn] - ng);
         a.h_out[so] = hy;
         if (f_xout) a.x_out[so] = e_xr + hy;
