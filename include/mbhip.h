@@ -392,6 +392,19 @@ int mb_wavernn_finish(const float* d_samples, int n_folds, int seq_len, int batc
                       int n_classes, int mu_law, int apply_preemphasis, double preemphasis,
                       int wave_len, int fade_len, double* d_wav, int* out_len, void* d_workspace,
                       size_t workspace_bytes, mb_stream_t stream);
+/* Host-logic hook (no GPU needed; tests/test_host_logic.py): which form of the sample loop mb_wavernn_generate runs -- the one table
+ * the library itself consults (csrc/wavernn.hip wavernn_pick_path).  No reference counterpart: WaveRNN.generate
+ * (models/vocoder/wavernn/models/fatchord_version.py:153-235) is a Python loop.
+ *   columns: fold columns (1 = batched=False); mode: 0 RAW / 1 MOL; production: 1 = production-dims model sampling on the device
+ *   (no injected noise, forced samples, logits dump, trace); have_q16: the K = 512 split weight images exist; resident_cus: compute
+ *   units a resident launch may count on; dev_failed: a resident launch lost a hand-off on this device before;
+ *   env_pipe / env_persist / env_q16: MBHIP_WAVERNN_PIPE / MBHIP_WAVERNN_PERSIST / MBHIP_WQ16, -1 = unset. */
+#define MB_WRN_PATH_CHAIN 0     /* the 5-launch chain (csrc/wavernn_fast.h), hipGraph replays                          */
+#define MB_WRN_PATH_PERSIST1 1  /* one column: wf_persist1_kernel (csrc/wavernn_persist.h)                             */
+#define MB_WRN_PATH_PIPE 2      /* 2..32 columns, exact fp32 MFMA: wf_pipe_kernel (csrc/wavernn_pipe.h); MOL models     */
+#define MB_WRN_PATH_PIPE16 3    /* 2..64 columns, 22-bit operand pairs: wf_pipe16_kernel (csrc/wavernn_pipe16.h); RAW  */
+int mb_wavernn_loop_path(int columns, int mode, int production, int have_q16, int resident_cus, int dev_failed,
+                         int env_pipe, int env_persist, int env_q16);
 /* Test hook: the Exp(1) noise the on-device sampler of the production paths draws for `seed`:
  * d_out [steps][folds][n_classes] = E for steps step0 .. step0+steps-1, i.e. exactly the tensor which, passed as d_noise
  * to the oracle's sample loop (argmax(softmax(l) / E), torch.multinomial's rule), reproduces what

@@ -135,7 +135,7 @@ template <int NT, int NPART> struct FmRed { static constexpr int floats = 8 * NT
 
 // flags block in the workspace (ints): [0] done, [1] n_frames, [2] arrival ticket, [3] utterances below the stop
 // threshold, [4] iteration index of the first launch of the current graph replay, [6..7] 64-bit dropout seed
-enum { TF_DONE = 0, TF_NFRAMES = 1, TF_ARRIVE = 2, TF_NOTREADY = 3, TF_ITER = 4, TF_LOST = 5, TF_SEED = 6, TF_LSTM_SYNC = 8 };  // [8..15]: taco_lstm2_kernel's hand-off counters, one per blockIdx.y; [5]: a hand-off timed out
+enum { TF_DONE = 0, TF_NFRAMES = 1, TF_ARRIVE = 2, TF_NOTREADY = 3, TF_ITER = 4, TF_LOST = 5, TF_SEED = 6 };
 
 // ---- always-on PreNet dropout (pre_net.py:23,26) of a relu'd row quad; same masks / same Philox stream as the
 //      general paths (rnn_body.h): Philox(iter, layer, n, row/4); masks [iteration][column][row] per layer ----

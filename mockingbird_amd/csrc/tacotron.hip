@@ -1358,10 +1358,7 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
   MB_HIP(hipGetLastError());
 
   int hh1_split = H / 8;  // row tiles of W_hh1 . h1 taken by the mel launch (the rest: next rnn_input launch)
-  // MBHIP_TACO_LSTM_MERGED=1: both LSTM cells in one launch (taco_lstm2_kernel).  Measured and left off: 100.7 against 48.7 us
-  // per iteration -- the agent-scope release / acquire fences of the hand-off cost 23 + 14 us, polling and shared bandwidth 15 more
-  const bool lstm_merged = getenv("MBHIP_TACO_LSTM_MERGED") != nullptr;
-  if (const char* he = getenv("MBHIP_TACO_HH1_SPLIT")) hh1_split = std::max(0, std::min(H / 4, atoi(he)));
+  // (MBHIP_TACO_HH1_SPLIT sweep, round 2: flat between 128 and 224 rows -- the switch is gone, the value stays)
   auto iteration = [&](int pp, int it_off) -> int {
     // (the LSTM state needs no ping-pong: h is read only by the hh jobs, which have finished before the next LSTM launch)
     const dim3 blk(512);
@@ -1428,13 +1425,8 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
     lk2.w = t->l2_wx.p; lk2.b4 = reinterpret_cast<const float4*>(t->f_l2_b4.p); lk2.x = L.f_x1; lk2.h_out = L.f_h2;
     lk2.hpre = reinterpret_cast<const float4*>(L.f_hp2);
     lk2.c = L.f_c2; lk2.x_out = L.f_x2; lk2.trace_slot = TS_LSTM2;
-    if (lstm_merged && gy <= 8) {  // both cells in one launch: the second cell's weights stream while it waits for the first
-      TfLstm2K l2k{lk1, lk2, flags + TF_LSTM_SYNC, it_off, getenv("MBHIP_TACO_L2_DBG") ? atoi(getenv("MBHIP_TACO_L2_DBG")) : 0};
-      TF_LAUNCH(taco_lstm2_kernel, 2 * (H / 4), l2k);
-    } else {
-      TF_LAUNCH(taco_lstm_kernel, H / 4, lk1);
-      TF_LAUNCH(taco_lstm_kernel, H / 4, lk2);
-    }
+    TF_LAUNCH(taco_lstm_kernel, H / 4, lk1);
+    TF_LAUNCH(taco_lstm_kernel, H / 4, lk2);
     // 7. mel frames, next prenet layer 1, stop token + stop rule
     TfMelK mk;
     mk.w_mel = t->mel_w.p; mk.w_fc1 = t->f_fc1_w.p; mk.b_fc1 = t->pre1_b.p; mk.w_stop = t->f_stop_w.p; mk.b_stop = t->stop_b.p;
@@ -1455,7 +1447,7 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
   int it_done = 0, rc = MB_OK;
   bool stopped = false;
   if (use_graph) {
-    mb_taco::GraphKey key = {d_memory, d_memory_proj, d_chars, d_dropout, d_mel, d_attn, d_workspace, B, T, max_steps, G, min_stop_token, (lstm_merged ? 1 : 0) | (getenv("MBHIP_TACO_L2_DBG") ? atoi(getenv("MBHIP_TACO_L2_DBG")) << 1 : 0)};
+    mb_taco::GraphKey key = {d_memory, d_memory_proj, d_chars, d_dropout, d_mel, d_attn, d_workspace, B, T, max_steps, G, min_stop_token, 0};
     if (!t->graph_exec || !(key == t->gkey)) {
       t->drop_graph();
       MB_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
@@ -1492,7 +1484,6 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
   MB_HIP(hipMemcpyAsync(t->h_flags, flags, sizeof(int) * 8, hipMemcpyDeviceToHost, s));
   MB_HIP(hipStreamSynchronize(s));
   *frames_out = t->h_flags[TF_NFRAMES];
-  MB_REQUIRE(!t->h_flags[TF_LOST], "taco_decode: a hand-off between the LSTM cells timed out (MBHIP_TACO_LSTM_MERGED diagnostics path)");
   t->last_iters = cdiv(*frames_out, r); t->timed = true;
   if (tr) {
     std::vector<unsigned long long> host((size_t)16 * TS_SLOTS);
@@ -1557,7 +1548,7 @@ extern "C" int mb_taco_decode(const mb_taco* t, const float* d_memory, const flo
   MB_HIP(hipMemsetAsync(L.h2, 0, sizeof(float) * 2 * B * H, s)); MB_HIP(hipMemsetAsync(L.c2, 0, sizeof(float) * 2 * B * H, s));
   MB_HIP(hipMemsetAsync(L.melstep, 0, sizeof(float) * B * r * M, s));  // <GO> frame
   MB_HIP(hipMemsetAsync(L.cumulative, 0, sizeof(float) * 2 * B * T, s));
-  MB_HIP(hipMemsetAsync(L.flags, 0, sizeof(int) * 16, s));  // (incl. the hand-off counters of taco_lstm2_kernel)
+  MB_HIP(hipMemsetAsync(L.flags, 0, sizeof(int) * 16, s));
   MB_HIP(hipMemsetAsync(d_mel, 0, sizeof(float) * (size_t)B * M * max_steps, s));
   if (d_attn) MB_HIP(hipMemsetAsync(d_attn, 0, sizeof(float) * (size_t)B * n_iter_max * T, s));
   int* done = L.flags;

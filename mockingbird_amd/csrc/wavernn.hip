@@ -301,6 +301,42 @@ struct mb_wavernn {
 // a resident launch (wavernn_persist.h / wavernn_pipe.h) once lost a hand-off on this device: stop defaulting to them there
 static std::atomic<bool> g_resident_failed[64] = {};  // written by whichever host thread sees the abort word: atomic
 
+// ---- which form of the sample loop a call runs: ONE function (the host code below and tests/test_host_logic.py both go through it) ----
+//   columns      fold columns of the call (1 = batched=False)
+//   mode         0 RAW, 1 MOL
+//   production   1: production-dims model (rnn 512 / fc 512, classes <= 512), sampling on the device, no logits dump / teacher forcing /
+//                trace / per-kernel bench -- the only calls a resident launch serves
+//   have_q16     the fp16 hi / lo weight images of wavernn_pipe16.h exist (K = 512 models)
+//   resident_cus co-resident 512-thread workgroups the device offers (its CU count if the kernels fit one per unit, else 0)
+//   dev_failed   a resident launch lost a hand-off on this device before
+//   env_*        MBHIP_WAVERNN_PIPE / MBHIP_WAVERNN_PERSIST / MBHIP_WQ16: -1 unset, else the value
+// | columns | RAW                                   | MOL                         |
+// | 1       | wf_persist1_kernel (PERSIST != 0)     | launch chain                |
+// | 2..32   | wf_pipe16_kernel; WQ16=0: wf_pipe     | wf_pipe_kernel              |
+// | 33..64  | wf_pipe16_kernel; WQ16=0: chain       | launch chain                |
+// | > 64    | launch chain (mb_wavernn_generate_batch's wide GEMMs serve several utterances)   |
+// and the launch chain whenever production == 0, the device offers fewer units than the kernel has workgroups (224 / 192), PIPE / PERSIST
+// = 0, or the device failed before and no switch asks explicitly.
+int wavernn_pick_path(int columns, int mode, int production, int have_q16, int resident_cus, int dev_failed, int env_pipe, int env_persist,
+                      int env_q16) {
+  if (!production || columns < 1) return MB_WRN_PATH_CHAIN;
+  const bool q16 = mode == 0 && have_q16 && env_q16 != 0;
+  if (columns >= 2) {
+    if (columns > (q16 ? WQ_GMAX : WQ_G) * WQ_GC || env_pipe == 0) return MB_WRN_PATH_CHAIN;
+    if (dev_failed && env_pipe < 0) return MB_WRN_PATH_CHAIN;
+    if (resident_cus < WQ_WGS) return MB_WRN_PATH_CHAIN;
+    return q16 ? MB_WRN_PATH_PIPE16 : MB_WRN_PATH_PIPE;
+  }
+  if (mode != 0 || env_persist == 0) return MB_WRN_PATH_CHAIN;  // one column: the fmaf-chain kernel (RAW only)
+  if (dev_failed && env_persist < 0) return MB_WRN_PATH_CHAIN;
+  if (resident_cus < WP_ON + WP_OFF) return MB_WRN_PATH_CHAIN;
+  return MB_WRN_PATH_PERSIST1;
+}
+extern "C" int mb_wavernn_loop_path(int columns, int mode, int production, int have_q16, int resident_cus, int dev_failed, int env_pipe,
+                                    int env_persist, int env_q16) {
+  return wavernn_pick_path(columns, mode, production, have_q16, resident_cus, dev_failed, env_pipe, env_persist, env_q16);
+}
+
 static int wavernn_shapes(const mb_wavernn_config* c, std::vector<size_t>* numel) {
   MB_REQUIRE(c, "wavernn: null config");
   MB_REQUIRE(c->mode == 0 || c->mode == 1, "wavernn: mode must be 0 (RAW) or 1 (MOL)");
@@ -792,46 +828,41 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
   };
   // Resident forms of the loop: ONE launch for the whole utterance, every weight tile in LDS, granule hand-offs between
   // the layers, same sample stream as the chain.
-  //   * wf_pipe_kernel (wavernn_pipe.h), 2..32 fold columns: role-specialised workgroups, two column groups in flight.
-  //     MBHIP_WAVERNN_PIPE=0 keeps the chain, =1 forces it wherever it is legal.
-  //   * wf_persist1_kernel / wf_persist_kernel (wavernn_persist.h), 1 (default) .. 4 columns (MBHIP_WAVERNN_PERSIST=1).
+  //   * wf_pipe16_kernel (wavernn_pipe16.h, RAW models) / wf_pipe_kernel (wavernn_pipe.h, MOL models and MBHIP_WQ16=0), 2..64 / 2..32 fold
+  //     columns: role-specialised workgroups, column groups in flight.  MBHIP_WAVERNN_PIPE=0 keeps the chain.
+  //   * wf_persist1_kernel (wavernn_persist.h): one column (batched=False), MBHIP_WAVERNN_PERSIST=0 keeps the chain.
+  //   The choice is wavernn_pick_path's table (above).
   // Both need their workgroups co-resident, one per compute unit: checked here against the device (CU count, occupancy
   // of the kernel, a per-device "it failed before" flag); a launch that still loses a hand-off (another process holds
   // compute units) times out after 0.2 s, raises its abort word and the chain below computes the same samples.
   // NOTE: a resident launch makes this call host-blocking (the abort word has to be looked at before returning).
   const char* penv = getenv("MBHIP_WAVERNN_PERSIST");
   const char* qenv = getenv("MBHIP_WAVERNN_PIPE");
-  const bool resident_ok = fastk && C <= 512 && !w->bench_which && !w->bench_chain && !getenv("MBHIP_TRACE_FILE") && !getenv("MBHIP_WF_DBG_WHICH");
-  const bool persist_asked = penv && atoi(penv) == 1 && N <= WP_NCOL;  // MBHIP_WAVERNN_PERSIST=1 keeps meaning wavernn_persist.h
-  // (MOL models: the pipelined kernel only -- its F3 role carries the mixture sampler; one column runs the chain)
   const char* e16 = getenv("MBHIP_WQ16");
-  // RAW models run the kernel on 22-bit operand pairs (wavernn_pipe16.h: half the sweep bytes, fp16 matrix pipe, up to four column
-  // groups = 64 columns; samples checked against the oracle, not bit-identical to the chain); MBHIP_WQ16=0 and MOL models: the exact kernel
-  const bool q16 = c.mode == 0 && w->q_fc3.p && w->q_hh1.p && !(e16 && atoi(e16) == 0);
-  bool pipe = resident_ok && N >= 2 && N <= (q16 ? WQ_GMAX : WQ_G) * WQ_GC && (qenv ? atoi(qenv) != 0 : (WQ_DEFAULT_ON != 0 && !persist_asked));
-  bool persist = resident_ok && c.mode == 0 && !pipe && N <= WP_NCOL && (penv ? atoi(penv) != 0 : N == 1);
-  if ((pipe || persist) && !rc) {
+  const bool resident_ok = fastk && C <= 512 && !w->bench_which && !w->bench_chain && !getenv("MBHIP_TRACE_FILE") && !getenv("MBHIP_WF_DBG_WHICH");
+  int path = MB_WRN_PATH_CHAIN;
+  if (resident_ok && !rc) {
     int dev = 0;
     MB_HIP(hipGetDevice(&dev));
     if (w->resident_cus < 0) {  // once per handle = per device
       hipDeviceProp_t prop;
       MB_HIP(hipGetDeviceProperties(&prop, dev));
-      MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WP_LDS_BYTES));
       MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_persist1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WP1_LDS_BYTES));
       MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_pipe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WQ_LDS_BYTES));
       MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_pipe16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WQ16_LDS_BYTES));
-      int nb0 = 0, nb1 = 0, nb2 = 0;
-      MB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb0, reinterpret_cast<const void*>(wf_persist_kernel), 512, WP_LDS_BYTES));
+      int nb1 = 0, nb2 = 0, nb3 = 0;
       MB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, reinterpret_cast<const void*>(wf_persist1_kernel), 512, WP1_LDS_BYTES));
       MB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, reinterpret_cast<const void*>(wf_pipe_kernel), 512, WQ_LDS_BYTES));
-      w->resident_cus = (nb0 >= 1 && nb1 >= 1 && nb2 >= 1) ? prop.multiProcessorCount : 0;
+      MB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb3, reinterpret_cast<const void*>(wf_pipe16_kernel), 512, WQ16_LDS_BYTES));
+      w->resident_cus = (nb1 >= 1 && nb2 >= 1 && nb3 >= 1) ? prop.multiProcessorCount : 0;
       if (!w->h_abort) MB_HIP(hipHostMalloc((void**)&w->h_abort, sizeof(int), hipHostMallocDefault));
     }
     const bool dev_failed = dev >= 0 && dev < 64 && g_resident_failed[dev];
-    if (dev_failed && !(pipe ? qenv : penv)) { pipe = false; persist = false; }  // (an explicit switch still tries)
-    if (pipe && w->resident_cus < WQ_WGS) pipe = false;
-    if (persist && w->resident_cus < WP_ON + WP_OFF) persist = false;
+    path = wavernn_pick_path(N, c.mode, 1, w->q_fc3.p && w->q_hh1.p ? 1 : 0, w->resident_cus, dev_failed ? 1 : 0, qenv ? atoi(qenv) : -1,
+                             penv ? atoi(penv) : -1, e16 ? atoi(e16) : -1);
   }
+  const bool pipe = path == MB_WRN_PATH_PIPE || path == MB_WRN_PATH_PIPE16, persist = path == MB_WRN_PATH_PERSIST1;
+  const bool q16 = path == MB_WRN_PATH_PIPE16;
   if ((pipe || persist) && !rc) {
     const size_t ex_bytes = pipe ? wq_exchange_bytes() : wp_exchange_bytes();
     int* abort_word = reinterpret_cast<int*>(L.px + (pipe ? (size_t)WQ_GMAX * 2 * WQX_PER : (size_t)2 * WPX_PER_PARITY));
@@ -881,8 +912,7 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
       pk.g = wg; pk.ex = L.px; pk.abort_word = abort_word;
       pk.samples = d_samples; pk.progress = h_progress; pk.seed = seed; pk.R = R; pk.FC = FC; pk.C = C; pk.S = S; pk.N = N;
       pk.trace = trace;
-      if (N == 1 && !getenv("MBHIP_WP_MFMA")) hipLaunchKernelGGL(wf_persist1_kernel, dim3(WP_ON + WP_OFF), dim3(512), WP1_LDS_BYTES, s, pk);
-      else hipLaunchKernelGGL(wf_persist_kernel, dim3(WP_ON + WP_OFF), dim3(512), WP_LDS_BYTES, s, pk);
+      hipLaunchKernelGGL(wf_persist1_kernel, dim3(WP_ON + WP_OFF), dim3(512), WP1_LDS_BYTES, s, pk);  // (one column)
     }
     MB_HIP(hipGetLastError());
     MB_HIP(hipEventRecord(w->ev_t1, s));

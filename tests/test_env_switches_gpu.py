@@ -57,11 +57,10 @@ def taco(cuda, lib):
     return dev, mem, memp, chars
 
 
-@pytest.mark.parametrize("env", [{"MBHIP_TACO_HH1_SPLIT": "64"}, {"MBHIP_TACO_HH1_SPLIT": "240"}, {"MBHIP_TACO_GRAPH_ITERS": "4"},
-                                 {"MBHIP_NO_GRAPH": "1"}], ids=lambda e: ",".join(f"{k[6:]}={v}" for k, v in e.items()))
+@pytest.mark.parametrize("env", [{"MBHIP_TACO_GRAPH_ITERS": "4"}, {"MBHIP_NO_GRAPH": "1"}],
+                         ids=lambda e: ",".join(f"{k[6:]}={v}" for k, v in e.items()))
 def test_tacotron_fast_loop_switches_are_bit_identical(taco, monkeypatch, env):
-    """Where the LSTM-1 hidden half rides (mel vs rnn_input launch), how many iterations a graph holds, eager launches:
-    the same kernels on the same operands."""
+    """How many iterations a graph holds, eager launches: the same kernels on the same operands."""
     dev, mem, memp, chars = taco
     for k in list(env):
         monkeypatch.delenv(k, raising=False)
@@ -98,28 +97,18 @@ def test_ppg2mel_switches(cuda, lib, monkeypatch, env, exact, B):
             assert e["nan"] == 0 and e["max_abs"] <= 2e-4, e
 
 
-@pytest.mark.parametrize("frames,batched,target,overlap", [(9, False, 0, 0), (40, True, 3000, 100), (40, True, 2200, 100)],
-                         ids=["unbatched", "3-folds", "4-folds"])
-def test_wavernn_persistent_kernel_keeps_the_sample_stream(wavernn, monkeypatch, frames, batched, target, overlap):
-    """wavernn_persist.h: ONE launch for the whole utterance, weights resident in LDS, layers handing their vectors over
-    through tagged granules -- against the 5-launch chain: the same samples, sample for sample (<= 4 fold columns)."""
-    mel = torch.from_numpy(synth.wavernn_mel(frames, seed=13) / 4.0).cuda()
+def test_wavernn_persistent_kernel_keeps_the_sample_stream(wavernn, monkeypatch):
+    """wavernn_persist.h (one fold column, batched=False): ONE launch for the whole utterance, weights resident in LDS, layers handing
+    their vectors over through tagged granules, products as fmaf chains in the fp32 MFMA's own order -- against the 5-launch chain:
+    the same samples, sample for sample."""
+    mel = torch.from_numpy(synth.wavernn_mel(9, seed=13) / 4.0).cuda()
     monkeypatch.setenv("MBHIP_WAVERNN_PERSIST", "0")
-    monkeypatch.setenv("MBHIP_WAVERNN_PIPE", "0")
-    base = wavernn.generate_samples(mel, batched, target, overlap, seed=21)
+    base = wavernn.generate_samples(mel, False, 0, 0, seed=21)
     assert wavernn.last_loop_launches > 1
-    monkeypatch.delenv("MBHIP_WAVERNN_PIPE")
-    if batched:
-        monkeypatch.setenv("MBHIP_WAVERNN_PERSIST", "1")   # 2..4 columns: opt-in (MFMA tiles, at parity with the chain)
-    else:
-        monkeypatch.delenv("MBHIP_WAVERNN_PERSIST")        # one column: the default (fmaf chains in the MFMA's order)
-    alt = wavernn.generate_samples(mel, batched, target, overlap, seed=21)
+    monkeypatch.delenv("MBHIP_WAVERNN_PERSIST")
+    alt = wavernn.generate_samples(mel, False, 0, 0, seed=21)
     assert wavernn.last_loop_launches == 1, "the persistent kernel did not run"
-    if not batched:
-        monkeypatch.setenv("MBHIP_WP_MFMA", "1")           # the MFMA form of the one-column kernel
-        alt2 = wavernn.generate_samples(mel, batched, target, overlap, seed=21)
-        assert wavernn.last_loop_launches == 1 and torch.equal(base, alt2)
-    assert base.shape == alt.shape and base.shape[0] <= 4
+    assert base.shape == alt.shape and base.shape[0] == 1
     assert torch.equal(base, alt), (int((base != alt).sum()), int((base != alt).any(0).nonzero()[0]) if (base != alt).any() else -1)
 
 

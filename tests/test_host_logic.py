@@ -46,23 +46,25 @@ def test_wavernn_weight_list_matches_abi_counts(lib):
 
 
 def test_conv_pack_is_a_permutation_with_zero_padding(lib):
-    """mb_conv1d_pack: the image is [fp32 A fragments | 64-float header | fp16 hi / lo A fragments].  Every weight appears
+    """mb_conv1d_pack: the image is [fp32 A fragments | 64-float header | fp16 hi / lo / hi 2^-11 A fragments].  Every weight appears
     exactly once in the fp32 part (conv and all polyphase taps of the transposed conv), padding is zero; the split part
-    holds w * 2^s as hi + lo halves (header word 0 = 2^-s) that add back to the weight to 22 bits."""
+    holds w * 2^s as hi + lo halves (header word 0 = 2^-s) that add back to the weight to 22 bits, and the third image is
+    hi * 2^-11 (the partner of the scaled activation residual, conv1d.hip)."""
     import hiputil
     for (shape, transposed, up, pad) in (((40, 20, 3), False, 1, 1), ((24, 16, 10), True, 5, 3), ((64, 32, 4), True, 2, 1)):
         w = torch.arange(1, int(np.prod(shape)) + 1, dtype=torch.float32).reshape(shape) / 1000.0
         packed, (c_out, c_in, k) = hiputil.pack_conv(w, transposed, up, pad)
         n_mt, n_cb, n_ks = (c_out + 31) // 32, (c_in + 7) // 8, (c_in + 15) // 16
         n_f32 = n_mt * n_cb * k * 256
-        assert packed.numel() == n_f32 + 64 + n_mt * n_ks * k * 512
+        assert packed.numel() == n_f32 + 64 + n_mt * n_ks * k * 768
         f32 = packed[:n_f32]
         nz = f32[f32 != 0]
         assert nz.numel() == w.numel() and torch.equal(nz.sort().values, w.flatten().sort().values)
         unscale = float(packed[n_f32])
         assert unscale > 0 and np.log2(unscale) == round(np.log2(unscale)) and float(packed[n_f32 + 1:n_f32 + 64].abs().max()) == 0
         assert 2 ** 13 <= float(w.abs().max()) / unscale < 2 ** 14
-        halves = packed[n_f32 + 64:].view(torch.float16).reshape(-1, 2, 512).double()  # [(p, mt, ks, tap)][hi | lo][lane * 8 + e]
+        halves = packed[n_f32 + 64:].view(torch.float16).reshape(-1, 3, 512).double()  # [(p, mt, ks, tap)][hi | lo | hi 2^-11][lane * 8 + e]
+        assert torch.equal(halves[:, 2] * 2048.0, halves[:, 0])  # exact: hi is a normal fp16 here (max |w| 2^s >= 2^13)
         rec = ((halves[:, 0] + halves[:, 1]) * unscale).flatten()
         rnz = rec[rec != 0]
         assert rnz.numel() == w.numel()
@@ -247,3 +249,28 @@ def test_bench_traffic_floor_counts_every_launch_once():
     base = bench.gan_floor_bytes(hf, 2, 7)
     assert bench.gan_floor_bytes(hf, 2, 7, fregan=True) > base               # that generator's own launches
     assert bench.gan_floor_bytes(hf, 4, 7, fregan=True) == 2 * bench.gan_floor_bytes(hf, 2, 7, fregan=True)  # linear in the batch
+
+
+def test_wavernn_loop_path_table(lib):
+    """The ONE selection function of the WaveRNN sample loop (csrc/wavernn.hip wavernn_pick_path, exported as
+    mb_wavernn_loop_path): (columns, mode, production, images, residency, failure memo, switches) -> path.  VERDICT r03 item 8."""
+    CHAIN, P1, PIPE, PIPE16 = 0, 1, 2, 3
+    f = lib.mb_wavernn_loop_path
+    U = -1  # switch unset
+    #        columns mode prod q16 cus failed pipe persist wq16 -> path
+    table = [
+        (1, 0, 1, 1, 256, 0, U, U, U, P1), (1, 0, 1, 1, 256, 0, U, 0, U, CHAIN), (1, 1, 1, 0, 256, 0, U, U, U, CHAIN),   # one column: RAW only
+        (1, 0, 1, 1, 191, 0, U, U, U, CHAIN), (1, 0, 1, 1, 192, 0, U, U, U, P1),                                     # 192 workgroups
+        (1, 0, 1, 1, 256, 1, U, U, U, CHAIN), (1, 0, 1, 1, 256, 1, U, 1, U, P1),                                     # failure memo / explicit switch
+        (2, 0, 1, 1, 256, 0, U, U, U, PIPE16), (23, 0, 1, 1, 256, 0, U, U, U, PIPE16), (32, 0, 1, 1, 256, 0, U, U, U, PIPE16),
+        (33, 0, 1, 1, 256, 0, U, U, U, PIPE16), (64, 0, 1, 1, 256, 0, U, U, U, PIPE16), (65, 0, 1, 1, 256, 0, U, U, U, CHAIN),
+        (23, 0, 1, 1, 256, 0, U, U, 0, PIPE), (33, 0, 1, 1, 256, 0, U, U, 0, CHAIN),                                 # MBHIP_WQ16=0: the exact kernel, 32 columns
+        (23, 0, 1, 0, 256, 0, U, U, U, PIPE), (23, 1, 1, 1, 256, 0, U, U, U, PIPE), (40, 1, 1, 1, 256, 0, U, U, U, CHAIN),   # no images / MOL
+        (23, 0, 1, 1, 256, 0, 0, U, U, CHAIN), (23, 0, 1, 1, 256, 0, 1, U, U, PIPE16),                               # MBHIP_WAVERNN_PIPE
+        (23, 0, 1, 1, 223, 0, U, U, U, CHAIN), (23, 0, 1, 1, 224, 0, U, U, U, PIPE16), (23, 0, 1, 1, 0, 0, 1, U, U, CHAIN),   # 224 workgroups
+        (23, 0, 1, 1, 256, 1, U, U, U, CHAIN), (23, 0, 1, 1, 256, 1, 1, U, U, PIPE16),                               # failure memo
+        (23, 0, 0, 1, 256, 0, 1, 1, 1, CHAIN), (0, 0, 1, 1, 256, 0, U, U, U, CHAIN),                                 # not a production call
+        (3, 0, 1, 1, 256, 0, U, 1, U, PIPE16),                                                                       # PERSIST=1 no longer claims 2..4 columns
+    ]
+    for row in table:
+        assert f(*row[:9]) == row[9], row

@@ -369,19 +369,3 @@ def test_resident_gru_scan_equals_launch_per_step_scan(model, monkeypatch, mode)
         monkeypatch.setenv("MBHIP_GRU_SCAN", "0")
         hm3, _ = dev.encode(chars.cuda(), spk.cuda(), -1, enc_masks)
         assert torch.equal(hm2.cpu(), hm3.cpu())
-
-
-@pytest.mark.parametrize("B,steps", [(32, 40), (18, 24), (5, 12)])
-def test_merged_lstm_launch_equals_two_launches(model, monkeypatch, B, steps):
-    """taco_lstm2_kernel (both residual LSTM cells of an iteration in one launch, fence + counter hand-off between the cells'
-    workgroups; tacotron.py:112-125; a measured-and-rejected form kept behind MBHIP_TACO_LSTM_MERGED=1) against the two launches
-    of the default path: the same products in the same order -- bit-identical mel, linear and alignments, through graph replays
-    (B = 32: two replays of 16) and the eager tail."""
-    dev, w = model
-    chars, spk, _, _ = _batch(B, 33, 47, seed=91)
-    hm, hp = dev.encode(chars.cuda(), spk.cuda(), -1)
-    masks = synth.decoder_dropout_masks(5, (steps + 1) // 2, B, 256)
-    mel, lin, att = dev.decode(hm, hp, chars.cuda(), steps, 11.0, dropout=masks)
-    monkeypatch.setenv("MBHIP_TACO_LSTM_MERGED", "1")
-    mel2, lin2, att2 = dev.decode(hm, hp, chars.cuda(), steps, 11.0, dropout=masks)
-    assert torch.equal(mel.cpu(), mel2.cpu()) and torch.equal(lin.cpu(), lin2.cpu()) and torch.equal(att.cpu(), att2.cpu())

@@ -597,15 +597,12 @@ def test_production_pipe16_geometries_vs_oracle(model, monkeypatch, frames, targ
     assert float((exact[:, :50] == s[:, :50]).float().mean()) > 0.9
 
 
-@pytest.mark.parametrize("form", ["fmaf", "mfma", "chain"])
+@pytest.mark.parametrize("form", ["fmaf", "chain"])
 def test_production_one_column_vs_oracle(model, monkeypatch, form):
-    """batched=False (one fold column): the persistent kernel (default: fmaf chains; MBHIP_WP_MFMA=1: MFMA tiles) and the
-    launch chain it replaces, 2000 steps each against the oracle."""
+    """batched=False (one fold column): the persistent kernel (fmaf chains in the MFMA's order) and the launch chain it replaces,
+    2000 steps each against the oracle."""
     dev, w = model
     monkeypatch.delenv("MBHIP_WAVERNN_PERSIST", raising=False)
-    monkeypatch.delenv("MBHIP_WP_MFMA", raising=False)
-    if form == "mfma":
-        monkeypatch.setenv("MBHIP_WP_MFMA", "1")
     if form == "chain":
         monkeypatch.setenv("MBHIP_WAVERNN_PERSIST", "0")
     frames, steps, seed = 30, 2000, 77
@@ -615,19 +612,6 @@ def test_production_one_column_vs_oracle(model, monkeypatch, form):
     assert dev.last_loop_launches == (5 * 6000 if form == "chain" else 1)
     noise = dev.sampler_noise(seed, steps, 1).cpu()
     o_s, o_l = _oracle_replay(w, mel, False, 0, 0, s, noise, steps)
-    _assert_same_picks(s, o_s, o_l, noise, steps, max_ties=2)
-
-
-def test_production_three_columns_persistent_vs_oracle(model, monkeypatch):
-    """MBHIP_WAVERNN_PERSIST=1 at three fold columns (wf_persist_kernel, MFMA tiles, column-dense exchange vectors)."""
-    dev, w = model
-    monkeypatch.setenv("MBHIP_WAVERNN_PERSIST", "1")
-    frames, target, overlap, steps, seed = 40, 2400, 200, 2000, 5
-    mel = synth.wavernn_mel(frames, seed=14)
-    s = dev.generate_samples(torch.from_numpy(mel / 4.0).cuda(), True, target, overlap, seed=seed).cpu()
-    assert s.shape == (3, 2800) and dev.last_loop_launches == 1
-    noise = dev.sampler_noise(seed, steps, 3).cpu()
-    o_s, o_l = _oracle_replay(w, mel, True, target, overlap, s, noise, steps)
     _assert_same_picks(s, o_s, o_l, noise, steps, max_ties=2)
 
 
