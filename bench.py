@@ -498,6 +498,7 @@ def main():
     elapsed, res = timed(headline, args.steps, args.warmup)
     loop_ms = loop_ms[args.warmup:]
     my_phase = [float(np.median([p[k] for p in phase_s[args.warmup:]])) * 1e3 for k in (0, 1)]
+    my_phase.append(float(local_rank if stub else torch.cuda.current_device()))  # the device this rank ran on (LOCAL_RANK -> cuda:LOCAL_RANK)
     if use_dist:  # per-rank medians, in rank order
         tp = torch.tensor(my_phase, device=dev, dtype=torch.float64)
         parts = [torch.zeros_like(tp) for _ in range(world)]
@@ -527,7 +528,7 @@ def main():
                    "samples_per_utterance": int(len(wav)), "utterances": world,
                    "sample_loop_ms": float(np.median(loop_ms)),
                    "us_per_time_step": float(np.median(loop_ms)) * 1000.0 / plan.seq_len},
-        "per_rank_ms": {"compute": [p[0] for p in per_rank], "gather": [p[1] for p in per_rank],
+        "per_rank_ms": {"compute": [p[0] for p in per_rank], "gather": [p[1] for p in per_rank], "device": [int(p[2]) for p in per_rank],
                         "what": "median over the timed passes of each rank: compute = conditioning + sample loop + float64 tail "
                                 "(+ D2H at 1 GPU); gather = the device-to-device gather of the finished waveforms to rank 0 "
                                 "(0 at 1 GPU)"},

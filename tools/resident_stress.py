@@ -1,0 +1,67 @@
+"""Stress of the resident (one-launch) loops' hand-offs -- wf_pipe16_kernel (23 fold columns), wf_pipe_kernel (the exact kernel),
+wf_persist1_kernel (one column), ppg_resident_kernel (ppg2mel, one utterance): the same call many times, alone and while another
+stream keeps the GPU busy with GEMMs of varying size (uneven load, workgroups competing for compute units).  Every run must either
+reproduce the quiet resident run bit for bit (the kernels are deterministic) or -- if the launch lost a hand-off and drained -- equal
+the launch chain's result (the fallback); anything else is a FAILURE.  VERDICT r03 item 8.
+usage: python tools/resident_stress.py [reps]   (prints one line per run, then 'ok' or 'FAILED')"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import torch, synth
+from mockingbird_amd.vocoder.wavernn.inference import WaveRNNDevice
+from mockingbird_amd.ppg2mel import Ppg2MelDecoder
+REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 9
+dev = WaveRNNDevice(synth.wavernn_state(seed=1)["model_state"])
+dec = Ppg2MelDecoder(synth.ppg2mel_decoder_state(synth.PPG2MEL_HP, seed=3, stop_bias=-6.0), synth.PPG2MEL_HP)
+mel23 = torch.from_numpy(synth.wavernn_mel(120, seed=0) / 4.0).cuda()   # 23 x 1100-step folds at target 1000 / overlap 50? (see columns below)
+mel1 = torch.from_numpy(synth.wavernn_mel(12, seed=0) / 4.0).cuda()
+mem = torch.from_numpy(synth.ppg2mel_memory(1, 60, seed=2)).cuda()
+
+
+def wrn(mel, batched, env):
+    for k in ("MBHIP_WAVERNN_PIPE", "MBHIP_WAVERNN_PERSIST", "MBHIP_WQ16"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    out = dev.generate_samples(mel, batched, 1000, 50, seed=9)
+    torch.cuda.synchronize()
+    return out.clone(), dev.last_loop_launches
+
+
+def ppg(env):
+    os.environ.pop("MBHIP_PPG_RESIDENT", None)
+    os.environ.update(env)
+    out = dec.decode(mem, seed=5, max_steps=100)
+    torch.cuda.synchronize()
+    return out[0].clone(), dec.last_loop_launches
+
+
+CASES = {
+    "wavernn_pipe16": (lambda env: wrn(mel23, True, env), {}, {"MBHIP_WAVERNN_PIPE": "0"}),
+    "wavernn_pipe_exact": (lambda env: wrn(mel23, True, env), {"MBHIP_WQ16": "0"}, {"MBHIP_WAVERNN_PIPE": "0"}),
+    "wavernn_one_column": (lambda env: wrn(mel1, False, env), {}, {"MBHIP_WAVERNN_PERSIST": "0"}),
+    "ppg2mel_resident": (ppg, {"MBHIP_PPG_RESIDENT": "1"}, {"MBHIP_PPG_RESIDENT": "0"}),
+}
+side = torch.cuda.Stream()
+bad = 0
+for name, (run, env_res, env_chain) in CASES.items():
+    chain, nl = run(env_chain)
+    assert nl > 1, (name, "chain reference ran", nl)
+    quiet, nl = run(env_res)
+    assert nl == 1, (name, "the resident launch did not run on the quiet GPU", nl)
+    for rep in range(REPS):
+        load = rep % 3  # 0: idle, 1: small GEMMs, 2: large GEMMs on the side stream
+        if load:
+            n = 512 if load == 1 else 4096
+            a = torch.randn(n, n, device="cuda"); b = torch.randn(n, n, device="cuda")
+            with torch.cuda.stream(side):
+                for _ in range(1500 if load == 1 else 120):
+                    a = (a @ b) * 1e-3
+        t0 = time.perf_counter()
+        # explicit switches: a device that fell back once is tried again (the memo only changes the DEFAULT)
+        out, nl = run(dict(env_res, **({"MBHIP_WAVERNN_PIPE": "1"} if name.startswith("wavernn_pipe") else {})))
+        verdict = "resident" if (nl == 1 and torch.equal(out, quiet)) else "fallback" if (nl > 1 and torch.equal(out, chain)) else "WRONG"
+        bad += verdict == "WRONG"
+        print(f"{name} rep {rep} load {load}: {verdict} (launches {nl}, wall {time.perf_counter() - t0:.3f} s)", flush=True)
+        torch.cuda.synchronize()
+print("FAILED" if bad else "ok")
+sys.exit(1 if bad else 0)
