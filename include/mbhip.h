@@ -215,6 +215,21 @@ typedef struct mb_resblock_stage_f16_args {
 } mb_resblock_stage_f16_args;
 int mb_resblock_stage_f16(const mb_resblock_stage_f16_args* a, mb_stream_t stream);
 
+/* The same ResBlock group at the reference's precision (round 4, resblock_stage_f32.hip): fp32 [B][channels][t] tensors in and out (the
+ * reference's layout), fp32-grade results from error-compensated fp16 MFMA products on LDS-resident hi / lo operands (section 1's scheme),
+ * residual chain and the kernels' mean in fp32 registers.  Replaces, on the fp32 path, the 2 x num_dilations x num_kernels Conv1d calls of
+ * one stage of Generator.forward (models/vocoder/hifigan/models.py:139-145 with ResBlock1.forward :39-46; fregan/generator.py:150-157,
+ * :43-50).  channels = 32: the whole group in one launch (384-row windows); channels = 64: one ResBlock or one unit per launch (192-row
+ * windows), accumulating into y.  Same argument struct as mb_resblock_stage_f16 with d_x / d_y = fp32 [B][channels][t] and d_bias =
+ * [num_kernels][num_dilations][2][channels] biases followed by the [num_kernels][num_dilations][2] unscale factors mb_resblock_stage_f32_pack
+ * returns in h_unscale. */
+int mb_resblock_stage_f32_supported(int channels, int num_kernels, const int* ksizes, int num_dilations, const int* dilations);
+float mb_resblock_stage_f32_efficiency(int channels, int num_kernels, const int* ksizes, int num_dilations, const int* dilations);
+size_t mb_resblock_stage_f32_packed_halves(int channels, int num_kernels, const int* ksizes, int num_dilations);
+int mb_resblock_stage_f32_pack(const float* const* h_w1, const float* const* h_w2, int channels, int num_kernels, const int* ksizes,
+                               int num_dilations, uint16_t* h_packed, float* h_unscale);
+int mb_resblock_stage_f32(const mb_resblock_stage_f16_args* a, mb_stream_t stream);
+
 /* Layout/precision converters between the reference's [B][C][T] fp32 tensors and the
  * time-major fp16 activations above (mel upload; tests). */
 int mb_f32_to_f16_tm(const float* d_x, void* d_y, int batch, int channels, int t, mb_stream_t stream);

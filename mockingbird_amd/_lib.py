@@ -161,6 +161,11 @@ SIGNATURES = {
     "mb_resblock_stage_f16_packed_halves": (C.c_size_t, [C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "mb_resblock_stage_f16_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "mb_resblock_stage_f16": (C.c_int, [C.POINTER(ResStageF16Args), C.c_void_p]),
+    "mb_resblock_stage_f32_supported": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "mb_resblock_stage_f32_efficiency": (C.c_float, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "mb_resblock_stage_f32_packed_halves": (C.c_size_t, [C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "mb_resblock_stage_f32_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "mb_resblock_stage_f32": (C.c_int, [C.POINTER(ResStageF16Args), C.c_void_p]),
     "mb_f32_to_f16_tm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mb_f16_tm_to_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mb_gan_num_weights": (C.c_int, [C.POINTER(GanConfig)]),

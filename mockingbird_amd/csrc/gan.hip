@@ -146,6 +146,12 @@ struct mb_gan {
   // fp16 path, wider stages (64 / 128 channels): single ResBlocks whose reach is small against the rows LDS holds (k = 3, 7 at 64
   // channels, k = 3 at 128) as ONE launch each, accumulating into the stage output; indexed (stage * num_kernels + kernel)
   std::vector<DevBuf> chain_w, chain_b;
+  // fp32 path (round 4, resblock_stage_f32.hip): 32-channel stages as ONE launch per stage (s32_w / s32_b, indexed by stage); 64-channel
+  // stages as one launch per ResBlock where the reach leaves >= 60 % of a 192-row window useful, else one launch per unit -- the
+  // launches of ResBlock (stage, kernel) in order: first unit, unit count, weight stream, bias + unscale block
+  struct S32Launch { int u0, nu; DevBuf w, b; };
+  std::vector<DevBuf> s32_w, s32_b;
+  std::vector<std::vector<S32Launch>> r32;  // [stage * num_kernels + kernel]
   int hop;
   // indices into convs
   int i_pre, i_ups, i_cond, i_resout, i_rb, i_post;
@@ -314,6 +320,65 @@ extern "C" int mb_gan_create_ex(const mb_gan_config* cfg, const float* const* h_
       }
     }
   }
+  if (dtype == MB_F32 && !getenv("MBHIP_GAN_NOFUSE") && !getenv("MBHIP_GAN_NOSTAGE") && cfg->num_kernels <= 4 && cfg->num_dilations <= 4) {
+    // fp32 path: fused ResBlock groups on error-compensated operands (resblock_stage_f32.hip)
+    const int nd = cfg->num_dilations, nk = cfg->num_kernels;
+    g->s32_w.resize(cfg->num_upsamples);
+    g->s32_b.resize(cfg->num_upsamples);
+    g->r32.resize((size_t)cfg->num_upsamples * nk);
+    // one launch's image: ResBlocks [j0, j0 + nkl) x units [u0, u0 + nul) of stage i
+    auto make = [&](int i, int ch, int j0, int nkl, int u0, int nul, DevBuf* wout, DevBuf* bout) -> int {
+      int ks[4], dil[16];
+      std::vector<const float*> w1((size_t)nkl * nul), w2((size_t)nkl * nul);
+      std::vector<float> bias((size_t)nkl * nul * 2 * (ch + 1), 0.f);
+      for (int j = 0; j < nkl; ++j)
+        for (int u = 0; u < nul; ++u) {
+          const int base = g->i_rb + ((i * nk + j0 + j) * nd) * 2;
+          const ConvSpec& s1 = v[base + u0 + u];
+          const ConvSpec& s2 = v[base + nd + u0 + u];
+          const bool ok = s1.c_in == ch && s1.c_out == ch && s2.c_in == ch && s2.c_out == ch && s1.k == s2.k && s2.dil == 1 && !s1.transposed &&
+                          !s2.transposed && s1.pad == s1.dil * (s1.k - 1) / 2 && s2.pad == (s2.k - 1) / 2 && (u == 0 || s1.k == ks[j]);
+          if (!ok) return 1;  // not a ResBlock1 unit: the per-conv launches run
+          ks[j] = s1.k; dil[j * nul + u] = s1.dil;
+          w1[(size_t)j * nul + u] = h_weights[2 * (base + u0 + u)];
+          w2[(size_t)j * nul + u] = h_weights[2 * (base + nd + u0 + u)];
+          memcpy(&bias[(((size_t)j * nul + u) * 2) * ch], h_weights[2 * (base + u0 + u) + 1], ch * sizeof(float));
+          memcpy(&bias[(((size_t)j * nul + u) * 2 + 1) * ch], h_weights[2 * (base + nd + u0 + u) + 1], ch * sizeof(float));
+        }
+      if (!mb_resblock_stage_f32_supported(ch, nkl, ks, nul, dil)) return 1;
+      std::vector<float> img(mb_resblock_stage_f32_packed_halves(ch, nkl, ks, nul) / 2, 0.f);
+      int r = mb_resblock_stage_f32_pack(w1.data(), w2.data(), ch, nkl, ks, nul, reinterpret_cast<uint16_t*>(img.data()),
+                                         &bias[(size_t)nkl * nul * 2 * ch]);
+      if (!r) r = wout->upload(img.data(), img.size());
+      if (!r) r = bout->upload(bias.data(), bias.size());
+      return r ? r : 0;
+    };
+    for (int i = 0; i < cfg->num_upsamples && !rc; ++i) {
+      const int ch = cfg->upsample_initial_channel >> (i + 1);
+      if (ch == 32) {
+        const int r = make(i, ch, 0, nk, 0, nd, &g->s32_w[i], &g->s32_b[i]);
+        if (r < 0) rc = r;
+        if (r) { g->s32_w[i].release(); g->s32_b[i].release(); }
+      } else if (ch == 64) {
+        for (int j = 0; j < nk && !rc; ++j) {
+          std::vector<mb_gan::S32Launch>& plan = g->r32[(size_t)i * nk + j];
+          // whole ResBlock in one launch if >= 60 % of the window rows are useful, else unit by unit
+          int kj = v[g->i_rb + ((i * nk + j) * nd) * 2].k, dl[4];
+          for (int u = 0; u < nd; ++u) dl[u] = v[g->i_rb + ((i * nk + j) * nd) * 2 + u].dil;
+          const bool whole = mb_resblock_stage_f32_efficiency(ch, 1, &kj, nd, dl) >= 0.6f;
+          const int nl = whole ? 1 : nd;
+          plan.resize(nl);
+          for (int l = 0; l < nl && !rc; ++l) {
+            plan[l].u0 = whole ? 0 : l; plan[l].nu = whole ? nd : 1;
+            const int r = make(i, ch, j, 1, plan[l].u0, plan[l].nu, &plan[l].w, &plan[l].b);
+            if (r < 0) rc = r;
+            if (r) { for (auto& q : plan) { q.w.release(); q.b.release(); } plan.clear(); break; }
+          }
+        }
+      }
+    }
+    if (rc) { mb_gan_destroy(g); return rc; }
+  }
   *out = g;
   return MB_OK;
 }
@@ -324,6 +389,10 @@ extern "C" void mb_gan_destroy(mb_gan* g) {
   for (auto& p : g->pairs) p.release();
   for (auto& p : g->stage_w) p.release();
   for (auto& p : g->stage_b) p.release();
+  for (auto& p : g->s32_w) p.release();
+  for (auto& p : g->s32_b) p.release();
+  for (auto& pl : g->r32)
+    for (auto& q : pl) { q.w.release(); q.b.release(); }
   for (auto& p : g->chain_w) p.release();
   for (auto& p : g->chain_b) p.release();
   delete g;
@@ -552,10 +621,41 @@ static int gan_forward_impl(const mb_gan* g, const float* d_mel, int batch, int 
       a.slope = LRELU; a.out_scale = inv_nk;
       a.d_valid = L.valid; a.valid_mul = t / L.frames_max;
       if (!L.rc) L.rc = mb_resblock_stage_f16(&a, stream);
+    } else if (!f16 && !g->s32_w.empty() && g->s32_w[i].p) {  // fp32 path, 32 channels: the whole group in one launch, X -> XS
+      mb_resblock_stage_f16_args a;
+      memset(&a, 0, sizeof(a));
+      a.d_x = X; a.d_y = XS; a.d_wpacked = g->s32_w[i].p; a.d_bias = g->s32_b[i].p;
+      a.batch = batch; a.channels = ch; a.t = t; a.num_kernels = c.num_kernels; a.num_dilations = c.num_dilations;
+      for (int j = 0; j < c.num_kernels; ++j) {
+        const int base = g->i_rb + ((i * c.num_kernels + j) * c.num_dilations) * 2;
+        a.ksize[j] = g->convs[base].s.k;
+        for (int d = 0; d < c.num_dilations; ++d) a.dilation[j][d] = g->convs[base + d].s.dil;
+      }
+      a.slope = LRELU; a.out_scale = inv_nk;
+      a.d_valid = L.valid; a.valid_mul = t / L.frames_max;
+      if (!L.rc) L.rc = mb_resblock_stage_f32(&a, stream);
     } else
     for (int j = 0; j < c.num_kernels; ++j) {
       const int base = g->i_rb + ((i * c.num_kernels + j) * c.num_dilations) * 2;
       const char* xr = X;
+      if (!f16 && !g->r32.empty() && !g->r32[(size_t)i * c.num_kernels + j].empty()) {  // fp32 path, 64 channels: one launch per ResBlock / unit
+        const std::vector<mb_gan::S32Launch>& plan = g->r32[(size_t)i * c.num_kernels + j];
+        for (size_t l = 0; l < plan.size(); ++l) {
+          const bool last = l + 1 == plan.size();
+          char* dst = last ? XS : ((l & 1) ? T : XR);  // never in place: X -> XR -> T -> ... -> XS
+          mb_resblock_stage_f16_args a;
+          memset(&a, 0, sizeof(a));
+          a.d_x = xr; a.d_y = dst; a.d_wpacked = plan[l].w.p; a.d_bias = plan[l].b.p;
+          a.batch = batch; a.channels = ch; a.t = t; a.num_kernels = 1; a.num_dilations = plan[l].nu;
+          a.ksize[0] = g->convs[base].s.k;
+          for (int u = 0; u < plan[l].nu; ++u) a.dilation[0][u] = g->convs[base + plan[l].u0 + u].s.dil;
+          a.slope = LRELU; a.out_scale = last ? inv_nk : 1.f; a.accumulate = last && j > 0;
+          a.d_valid = L.valid; a.valid_mul = t / L.frames_max;
+          if (!L.rc) L.rc = mb_resblock_stage_f32(&a, stream);
+          xr = dst;
+        }
+        continue;
+      }
       bool all_fused = f16 && !g->pairs.empty();
       for (int d = 0; d < c.num_dilations && all_fused; ++d)
         all_fused = g->pairs[(size_t)(i * c.num_kernels + j) * c.num_dilations + d].p != nullptr;

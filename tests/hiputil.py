@@ -207,3 +207,45 @@ def resblock_stage_f16_hip(x, chains, *, slope=0.1, out_scale=0.0, valid=None, v
     _lib.check(L.mb_resblock_stage_f16(C.byref(a), _lib.stream_ptr()), "mb_resblock_stage_f16")
     torch.cuda.synchronize()
     return y.float().transpose(1, 2).contiguous().cpu()
+
+
+def resblock_stage_f32_hip(x, chains, *, slope=0.1, out_scale=0.0, valid=None, valid_mul=1, accumulate_into=None, device="cuda"):
+    """One stage's ResBlock group (or one ResBlock / one unit of it) in one launch at the reference's precision (mb_resblock_stage_f32:
+    fp32 [B, C, T] in and out).  chains: list (one per ResBlock) of lists (one per unit) of (w1, b1, w2, b2, dilation); returns
+    [B, C, T] float32 (positions beyond `valid` are left NaN)."""
+    L = _lib.lib()
+    dev = torch.device(device)
+    nk, nd = len(chains), len(chains[0])
+    Cc = chains[0][0][0].shape[0]
+    ks = (C.c_int * nk)(*[ch[0][0].shape[-1] for ch in chains])
+    dil = (C.c_int * (nk * nd))(*[u[4] for ch in chains for u in ch])
+    if not L.mb_resblock_stage_f32_supported(Cc, nk, ks, nd, dil):
+        raise _lib.MbHipError("mb_resblock_stage_f32: unsupported shape")
+    w1 = [u[0].detach().float().contiguous().cpu() for ch in chains for u in ch]
+    w2 = [u[2].detach().float().contiguous().cpu() for ch in chains for u in ch]
+    p1 = (C.c_void_p * len(w1))(*[w.data_ptr() for w in w1])
+    p2 = (C.c_void_p * len(w2))(*[w.data_ptr() for w in w2])
+    packed = torch.empty(L.mb_resblock_stage_f32_packed_halves(Cc, nk, ks, nd), dtype=torch.float16)
+    unscale = torch.empty(nk * nd * 2, dtype=torch.float32)
+    _lib.check(L.mb_resblock_stage_f32_pack(p1, p2, Cc, nk, ks, nd, packed.data_ptr(), unscale.data_ptr()), "mb_resblock_stage_f32_pack")
+    pw = packed.to(dev)
+    bias = torch.cat([torch.stack([torch.stack([u[1].float(), u[3].float()]) for ch in chains for u in ch]).flatten(), unscale]).contiguous().to(dev)
+    xt = x.float().contiguous().to(dev)
+    B, _, T = xt.shape
+    y = accumulate_into.float().contiguous().to(dev) if accumulate_into is not None else torch.full((B, Cc, T), float("nan"), device=dev)
+    a = _lib.ResStageF16Args()
+    a.accumulate = int(accumulate_into is not None)
+    a.d_x, a.d_y, a.d_wpacked, a.d_bias = xt.data_ptr(), y.data_ptr(), pw.data_ptr(), bias.data_ptr()
+    a.batch, a.channels, a.t, a.num_kernels, a.num_dilations = B, Cc, T, nk, nd
+    for j, ch in enumerate(chains):
+        a.ksize[j] = ch[0][0].shape[-1]
+        for u, unit in enumerate(ch):
+            a.dilation[j][u] = unit[4]
+    a.slope, a.out_scale = slope, out_scale
+    vd = None
+    if valid is not None:
+        vd = torch.tensor(valid, dtype=torch.int32, device=dev)
+        a.d_valid, a.valid_mul = vd.data_ptr(), valid_mul
+    _lib.check(L.mb_resblock_stage_f32(C.byref(a), _lib.stream_ptr()), "mb_resblock_stage_f32")
+    torch.cuda.synchronize()
+    return y.cpu()
