@@ -19,11 +19,17 @@
 // Layout: fp32 [B][C][T] in and out.  LDS (halves): Ah | Al [PAD + N1 + PAD][C + 8]  lrelu(x) of the running unit, zero outside [0, T);
 //                                                   Hh | Hl                          h = lrelu(conv1 + b1)
 // A tile = N1 = 32 * WN * NTW window rows; row i <-> position t0 - Hh + i (Hh = the widest chain's reach per side); the NB = N1 - 2 Hh rows
-// in the middle are the tile's result (resblock_stage_f16.hip).  Four arrays instead of two: C = 32 takes N1 = 384 (the whole group of
-// HiFi-GAN's last stage: NB = 264), C = 64 takes N1 = 192 (single ResBlocks / single units, accumulating into y).
-// 8 waves, two roles: waves 0-3 run the MFMA loops (B operands from LDS, weights through a register ring over ONE circular stream in
-// consumption order), waves 4-7 own the window: they fetch the next tile's fp32 window while the first chain runs and lay lrelu(x) down
-// (hi / lo) at every chain start.
+// in the middle are the tile's result (resblock_stage_f16.hip).  C = 32 takes N1 = 256 (the whole group of HiFi-GAN's last stage: NB = 136),
+// C = 64 takes N1 = 128 (single ResBlocks / single units, accumulating into y): two 32-row tiles per wave -- with three (N1 = 384 / 192, which
+// LDS would hold) the kernel needs more than the 512 registers a wave can have and reloads its residual from scratch one word per round trip.
+// FOUR waves, one per SIMD, each with the whole 512-register budget of its SIMD: the fp32 residual of a wave's cells (48 VGPRs), its
+// accumulators (48), two taps of weight fragments (48-96), a k-step of B fragments ahead (48) and the fp32 window of the current and the
+// next tile (2 x 48) do not fit the 256 registers an 8-wave workgroup leaves a wave -- the first version (resblock_stage_f16.hip's two
+// roles of four waves) spilled 200-350 VGPRs around every chain start, its 48 residual loads and 48 result read-modify-writes serialised
+// behind the spill traffic (vmcnt(0) after every load), and ran SLOWER than the per-conv launches (15.8 against 13.6 ms).  Every wave
+// runs the MFMA loops on its rows (B operands from LDS, weights through a register ring over ONE circular stream in consumption order) and
+// lays its quarter of the window down (lrelu, hi / lo) at every chain start; the next tile's fp32 window is requested at the start of the
+// tile and arrives under the first chain.
 #include <atomic>
 #include <cmath>
 #include <type_traits>
@@ -55,6 +61,15 @@ __device__ __forceinline__ int s32_valid_len(const ResStage32K& a, int b) {
   return min(a.T, a.valid[b] * a.valid_mul);
 }
 
+// uniform base + 32-bit BYTE offset of the lane: the address form global_load / global_store take as (SGPR pair, one VGPR) -- element
+// offsets made the compiler build a 64-bit address per access (zext(off) << 2), two VGPRs each, 48 of them live at once
+__device__ __forceinline__ float s32_ld(const float* base, const unsigned byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void s32_st(float* base, const unsigned byte_off, const float v) {
+  *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
 // fp32 x 8 -> fp16 hi and scaled fp16 residual (conv1d.hip split_store2)
 __device__ __forceinline__ void s32_split8(const float (&v)[8], h16x8& hi, h16x8& lo) {
 #pragma unroll
@@ -78,7 +93,7 @@ __device__ __forceinline__ void s32_split4(const float (&v)[4], h16x4& hi, h16x4
 // accumulate into y one after the other (the owner lane re-reads what it wrote: a running sum in registers next to the accumulators and
 // the fp32 residual spilled 350 VGPRs -- the extra tensor passes are 0.15 ms of the 32-channel stage).
 template <int C, int MT, int WN, int NTW, int TD>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void resblock_stage_f32_kernel(ResStage32K a) {
   constexpr int WM = 4 / WN;
   static_assert(WM * MT * 32 == C, "the four MMA waves cover all channels");
@@ -102,87 +117,61 @@ void resblock_stage_f32_kernel(ResStage32K a) {
   {  // zero the four arrays once (the PAD rows are never written again), stage biases and unscale factors
     h16x8* z = reinterpret_cast<h16x8*>(lds_raw);
     const int n16 = 4 * ARR / 8;
-    for (int i = tid; i < n16; i += 512) z[i] = (h16x8)(h16)0.f;
+    for (int i = tid; i < n16; i += 256) z[i] = (h16x8)(h16)0.f;
     const int nb = a.nchains * a.nunits * 2 * (C + 1);
-    for (int i = tid; i < nb; i += 512) bs[i] = a.bias[i];
+    for (int i = tid; i < nb; i += 256) bs[i] = a.bias[i];
   }
   __syncthreads();  // Z
 
-  if (wave >= 4) {
-    // ------------------------------ support waves: the window ------------------------------
-    constexpr int PPR = C / 8;              // 8-channel pieces per row
-    constexpr int LB = N1 * PPR / 256;      // pieces per lane of one window
-    static_assert(N1 * PPR % 256 == 0 && N1 % 64 == 0, "window pieces divide over the support lanes");
-    const int ltid = tid - 256;
-    float cur[LB][8], nxt[LB][8];
-    // (addresses = a uniform base per channel-in-piece (SGPR pair) + ONE 32-bit lane offset per piece: 48 loads in flight with their own
-    //  64-bit addresses spilled 112 VGPRs)
-    auto load_window = [&](int it, float (&v)[LB][8]) {
-      const int tile = (int)blockIdx.x + it * (int)gridDim.x;
-      const int b = tile / a.tiles_per_item, t0 = (tile - b * a.tiles_per_item) * a.NB;
-      const int Tb = s32_valid_len(a, b);
-      const float* xb = a.x + (long long)b * a.bstride;
-      unsigned off[LB];
-      bool inside[LB];
+  // ------------------------------ the window (all four waves) ------------------------------
+  constexpr int PPR = C / 8;              // 8-channel pieces per row
+  constexpr int LB = N1 * PPR / 256;      // pieces per lane of one window
+  static_assert(N1 * PPR % 256 == 0 && N1 % 64 == 0, "window pieces divide over the support lanes");
+  const int ltid = tid;  // all four waves lay the window down
+  // (addresses = a uniform base per channel-in-piece (SGPR pair) + ONE 32-bit lane offset per piece: 48 loads in flight with their own
+  //  64-bit addresses spilled 112 VGPRs)
+  auto load_window = [&](int it, float (&v)[LB][8]) __attribute__((always_inline)) {
+    const int tile = (int)blockIdx.x + it * (int)gridDim.x;
+    const int b = tile / a.tiles_per_item, t0 = (tile - b * a.tiles_per_item) * a.NB;
+    const int Tb = s32_valid_len(a, b);
+    const float* xb = a.x + (long long)b * a.bstride;
+    unsigned off[LB];
+    bool inside[LB];
 #pragma unroll
-      for (int i = 0; i < LB; ++i) {
-        const int idx = i * 256 + ltid;
-        const int pc = idx / N1, row = idx - pc * N1;  // consecutive lanes = consecutive positions of one channel: coalesced rows
-        const int t = t0 - a.Hh + row;
-        const int tc = min(max(t, 0), a.T - 1);  // clamped: the load is always legal, the value is selected
-        inside[i] = t >= 0 && t < Tb;
-        off[i] = (unsigned)(pc * 8) * (unsigned)a.T + (unsigned)tc;
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float* xe = xb + (size_t)e * a.T;  // uniform
-#pragma unroll
-        for (int i = 0; i < LB; ++i) {
-          const float ld = xe[off[i]];
-          v[i][e] = inside[i] ? ld : 0.f;
-        }
-      }
-    };
-    auto store_window = [&](const float (&v)[LB][8]) {  // lrelu(x) -> Ah / Al
-#pragma unroll
-      for (int i = 0; i < LB; ++i) {
-        const int idx = i * 256 + ltid;
-        const int pc = idx / N1, row = idx - pc * N1;
-        float l[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) l[e] = v[i][e] > 0.f ? v[i][e] : v[i][e] * slope;
-        h16x8 hi, lo;
-        s32_split8(l, hi, lo);
-        const int o = (a.PAD + row) * CP + pc * 8;
-        *reinterpret_cast<h16x8*>(Ah + o) = hi;
-        *reinterpret_cast<h16x8*>(Al + o) = lo;
-      }
-    };
-    // Barrier schedule per tile (mirrors the MMA waves'): per chain X, then per unit E1 and (E2 | P); Y after the last chain.
-    if (my_tiles > 0) { load_window(0, cur); store_window(cur); }
-    for (int it = 0; it < my_tiles; ++it) {
-      for (int c = 0; c < a.nchains; ++c) {
-        if (c > 0) store_window(cur);  // chain c starts from x again (A is free behind the previous chain's last E1)
-        __syncthreads();  // X
-        if (c == 0 && it + 1 < my_tiles) load_window(it + 1, nxt);
-        for (int u = 0; u < a.nunits; ++u) {
-          __syncthreads();  // E1
-          __syncthreads();  // E2 (u < last) | P (last)
-        }
-      }
-      if (it + 1 < my_tiles) {  // the next tile's window goes down while the MMA waves store this tile's result
-#pragma unroll
-        for (int i = 0; i < LB; ++i)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) cur[i][e] = nxt[i][e];
-        store_window(cur);
-      }
-      __syncthreads();  // Y
+    for (int i = 0; i < LB; ++i) {
+      const int idx = i * 256 + ltid;
+      const int pc = idx / N1, row = idx - pc * N1;  // consecutive lanes = consecutive positions of one channel: coalesced rows
+      const int t = t0 - a.Hh + row;
+      const int tc = min(max(t, 0), a.T - 1);  // clamped: the load is always legal, the value is selected
+      inside[i] = t >= 0 && t < Tb;
+      off[i] = ((unsigned)(pc * 8) * (unsigned)a.T + (unsigned)tc) * 4u;
     }
-    return;
-  }
-
-  // ------------------------------ MMA waves ------------------------------
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float* xe = xb + (size_t)e * a.T;  // uniform
+#pragma unroll
+      for (int i = 0; i < LB; ++i) {
+        const float ld = s32_ld(xe, off[i]);
+        v[i][e] = inside[i] ? ld : 0.f;
+      }
+    }
+  };
+  auto store_window = [&](const float (&v)[LB][8]) __attribute__((always_inline)) {  // lrelu(x) -> Ah / Al
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+      const int idx = i * 256 + ltid;
+      const int pc = idx / N1, row = idx - pc * N1;
+      float l[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) l[e] = v[i][e] > 0.f ? v[i][e] : v[i][e] * slope;
+      h16x8 hi, lo;
+      s32_split8(l, hi, lo);
+      const int o = (a.PAD + row) * CP + pc * 8;
+      *reinterpret_cast<h16x8*>(Ah + o) = hi;
+      *reinterpret_cast<h16x8*>(Al + o) = lo;
+    }
+  };
+  // ------------------------------ the MFMA loops ------------------------------
   const int wm = wave / WN, wn = wave % WN;
   const int mt0 = wm * MT;  // first 32-row output tile of this wave
   const int NFT = a.NFT;
@@ -267,11 +256,17 @@ void resblock_stage_f32_kernel(ResStage32K a) {
     for (int c = 0; c < a.nchains; ++c) {
       const int ntaps = a.ntaps[c];
       const int p2 = (ntaps - 1) >> 1;
-      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): one ring drain per chain keeps the compiler's counts in the tap loops exact
+      {  // every chain starts from x: the tile's fp32 window (L2-hot after the first chain) -> lrelu -> hi / lo rows.  A is free behind the
+         // previous chain's (tile's) last barrier.  (Keeping the window -- and the next tile's -- in registers across the chains cost 96
+         // VGPRs that the allocator spilled to scratch and reloaded one word per round trip: 50-100 us per chain start.)
+        float win[LB][8];
+        load_window(it, win);
+        store_window(win);
+      }
       __syncthreads();  // X: lrelu(x) is down (Ah / Al)
       // the residual x of this wave's cells (its rows x its channels), fp32, for the whole chain: 32 consecutive positions of a channel
       // per half wave and load
-      f32x16 xres[MT][NTW];
+      float xres[MT][NTW][16];  // (scalars, not f32x16: element-wise updates of vector values kept several copies alive)
       unsigned xoff[MT][NTW];  // lane offset of (first channel of the lane's group, its position); element q adds a uniform (8 (q >> 2) + (q & 3)) T
 #pragma unroll
       for (int i = 0; i < MT; ++i)
@@ -279,7 +274,7 @@ void resblock_stage_f32_kernel(ResStage32K a) {
         for (int n = 0; n < NTW; ++n) {
           const int t = t0 - a.Hh + lrow + n * 32;
           const int tc = min(max(t, 0), a.T - 1);
-          xoff[i][n] = (unsigned)((mt0 + i) * 32 + ch4) * (unsigned)a.T + (unsigned)tc;
+          xoff[i][n] = ((unsigned)((mt0 + i) * 32 + ch4) * (unsigned)a.T + (unsigned)tc) * 4u;
         }
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
@@ -289,7 +284,7 @@ void resblock_stage_f32_kernel(ResStage32K a) {
 #pragma unroll
           for (int n = 0; n < NTW; ++n) {
             const int t = t0 - a.Hh + lrow + n * 32;
-            const float ld = xq[xoff[i][n]];
+            const float ld = s32_ld(xq, xoff[i][n]);
             xres[i][n][q] = (t >= 0 && t < Tb) ? ld : 0.f;
           }
       }
@@ -324,6 +319,7 @@ void resblock_stage_f32_kernel(ResStage32K a) {
               *reinterpret_cast<h16x4*>(Hhi + o) = hi;
               *reinterpret_cast<h16x4*>(Hlo + o) = lo;
             }
+            __builtin_amdgcn_sched_barrier(0);  // one 32-row tile at a time: interleaved, the epilogues of three tiles held > 512 values
           }
         __syncthreads();  // E1: h is complete, nobody reads A any more
         // ---------------- conv2 (dilation 1) on h; x <- x + conv2 2^-s + b2 ----------------
@@ -354,11 +350,24 @@ void resblock_stage_f32_kernel(ResStage32K a) {
                 *reinterpret_cast<h16x4*>(Al + o) = lo;
               }
             }
+            __builtin_amdgcn_sched_barrier(0);
           }
         __syncthreads();  // E2: lrelu(x) of the next unit is complete | P (last): nobody reads H or A any more
       }
-      {  // this chain's share of the tile's result: rows [Hh, Hh + NB) of the window that are positions of the item
+      {  // this chain's share of the tile's result: rows [Hh, Hh + NB) of the window that are positions of the item.  Chains after the
+         // first (and launches that accumulate) add to what y holds: every read is in flight before the first add.
         const bool acc_y = a.accumulate || c > 0;
+        unsigned yoff[MT][NTW];
+        bool mine[MT][NTW];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int n = 0; n < NTW; ++n) {
+            const int orow = lrow + n * 32 - a.Hh;
+            const int t = t0 + orow;
+            mine[i][n] = orow >= 0 && orow < a.NB && t < Tb;
+            yoff[i][n] = ((unsigned)((mt0 + i) * 32 + ch4) * (unsigned)a.T + (unsigned)min(max(t, 0), a.T - 1)) * 4u;
+          }
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           float* yq = yb + (size_t)(8 * (q >> 2) + (q & 3)) * a.T;  // uniform
@@ -366,19 +375,19 @@ void resblock_stage_f32_kernel(ResStage32K a) {
           for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int n = 0; n < NTW; ++n) {
-              const int orow = lrow + n * 32 - a.Hh;
-              const int t = t0 + orow;
-              if (orow >= 0 && orow < a.NB && t < Tb) {
-                float* yp = yq + ((unsigned)((mt0 + i) * 32 + ch4) * (unsigned)a.T + (unsigned)t);
-                float v = xres[i][n][q] * a.out_scale;
-                if (acc_y) v += *yp;
-                *yp = v;
+              const float v = xres[i][n][q] * a.out_scale;
+              float* yp = reinterpret_cast<float*>(reinterpret_cast<char*>(yq) + yoff[i][n]);
+              if (mine[i][n]) {
+                // later chains (and accumulating launches) ADD: a returnless fp32 atomic -- one lane per element, so the sum is the
+                // sequential one, and nothing has to come back (a read-modify-write held 48 more registers and a round trip per chain)
+                if (acc_y) unsafeAtomicAdd(yp, v);
+                else *yp = v;
               }
             }
         }
       }
     }
-    __syncthreads();  // Y: the next tile's window is down
+    // (no barrier here: the next tile's first window store sits behind this tile's last E2 / P barrier)
   }
 #undef S32_CONV
 #undef S32_TAPJ
@@ -424,7 +433,7 @@ static int launch_stage32(ResStage32K k, const Stage32Geom& g, int batch, hipStr
     attr_done.fetch_or(bit, std::memory_order_release);
   }
   const int cus = bit && n_cu[dev] ? n_cu[dev] : 256;
-  hipLaunchKernelGGL((resblock_stage_f32_kernel<C, MT, WN, NTW, TD>), dim3(std::min(k.n_tiles, cus)), dim3(512), g.lds, s, k);
+  hipLaunchKernelGGL((resblock_stage_f32_kernel<C, MT, WN, NTW, TD>), dim3(std::min(k.n_tiles, cus)), dim3(256), g.lds, s, k);
   MB_HIP(hipGetLastError());
   return MB_OK;
 }
@@ -439,7 +448,7 @@ static bool stage32_shape_ok(int channels, int nk, const int* ksizes, int nd, co
   return true;
 }
 static bool stage32_geom_c(int channels, int nk, const int* ksizes, int nd, const int* dil, Stage32Geom* g) {
-  return channels == 32 ? stage32_geom<32, 384>(nk, ksizes, nd, dil, g) : stage32_geom<64, 192>(nk, ksizes, nd, dil, g);
+  return channels == 32 ? stage32_geom<32, 256>(nk, ksizes, nd, dil, g) : stage32_geom<64, 128>(nk, ksizes, nd, dil, g);
 }
 
 }  // namespace mb
@@ -522,6 +531,7 @@ extern "C" int mb_resblock_stage_f32(const mb_resblock_stage_f16_args* a, mb_str
              "resblock_stage_f32: C=%d kernels=%d dilations=%d unsupported", a->channels, a->num_kernels, a->num_dilations);
   MB_REQUIRE(a->slope > 0.f && a->slope < 1.f, "resblock_stage_f32: leaky_relu slope must be in (0,1)");
   if (a->batch <= 0 || a->t <= 0) return MB_OK;
+  MB_REQUIRE((long long)a->channels * a->t * 4 < (1ll << 31), "resblock_stage_f32: an item of %d x %d floats is beyond the 32-bit byte offsets", a->channels, a->t);
   ResStage32K k;
   memset(&k, 0, sizeof(k));
   k.x = reinterpret_cast<const float*>(a->d_x); k.y = reinterpret_cast<float*>(a->d_y);
@@ -538,6 +548,6 @@ extern "C" int mb_resblock_stage_f32(const mb_resblock_stage_f16_args* a, mb_str
   Stage32Geom g;
   hipStream_t s = (hipStream_t)stream;
   MB_REQUIRE(stage32_geom_c(a->channels, a->num_kernels, a->ksize, a->num_dilations, dil, &g), "resblock_stage_f32: the tile does not fit LDS");
-  if (a->channels == 32) return launch_stage32<32, 1, 4, 3, 1>(k, g, a->batch, s);
-  return launch_stage32<64, 1, 2, 3, 1>(k, g, a->batch, s);
+  if (a->channels == 32) return launch_stage32<32, 1, 4, 2, 2>(k, g, a->batch, s);
+  return launch_stage32<64, 1, 2, 2, 2>(k, g, a->batch, s);
 }

@@ -54,7 +54,7 @@ CASES = [
     # (B, C, T, kernel sizes, dilations per ResBlock)
     (2, 32, 1500, (3, 7, 11), ((1, 3, 5),) * 3),      # HiFi-GAN V1's 32-channel group, several tiles per item
     (1, 32, 100, (3, 7, 11), ((1, 3, 5),) * 3),       # shorter than one tile
-    (1, 32, 264 * 3, (3, 7, 11), ((1, 3, 5),) * 3),   # exactly three tiles
+    (1, 32, 136 * 3, (3, 7, 11), ((1, 3, 5),) * 3),   # exactly three tiles
     (1, 32, 2000, (3, 7, 11), ((1, 3, 5, 7),) * 3),   # Fre-GAN's four dilations
     (1, 32, 700, (7,), ((1, 2),)), (1, 32, 900, (5, 3), ((2, 1, 1), (1, 1, 4))),
     (2, 64, 1000, (3,), ((1, 3, 5),)), (1, 64, 700, (7,), ((1, 3, 5),)),   # 64 channels: a ResBlock per launch
