@@ -355,11 +355,13 @@ extern "C" int mb_gan_create_ex(const mb_gan_config* cfg, const float* const* h_
     };
     for (int i = 0; i < cfg->num_upsamples && !rc; ++i) {
       const int ch = cfg->upsample_initial_channel >> (i + 1);
-      if (ch == 32) {
+      // (32 channels: the whole group in ONE launch -- s32_w -- works, tests/test_resblock_stage_f32_gpu.py, but every chain then pays the
+      //  widest chain's halo: 136 useful rows of 256; a launch per ResBlock / unit lets k = 3 keep 232 and k = 11's units 196-236)
+      if (ch == 32 && getenv("MBHIP_GAN_S32_GROUP")) {
         const int r = make(i, ch, 0, nk, 0, nd, &g->s32_w[i], &g->s32_b[i]);
         if (r < 0) rc = r;
         if (r) { g->s32_w[i].release(); g->s32_b[i].release(); }
-      } else if (ch == 64) {
+      } else if (ch == 64 || ch == 32) {
         for (int j = 0; j < nk && !rc; ++j) {
           std::vector<mb_gan::S32Launch>& plan = g->r32[(size_t)i * nk + j];
           // whole ResBlock in one launch if >= 60 % of the window rows are useful, else unit by unit
