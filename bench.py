@@ -718,7 +718,8 @@ def main():
             nsmp = sum(len(x) for x in bw)
             result["wavernn_batch32"] = {
                 "workload": f"{nb} utterances x mel 80x{F} in one sample loop: {bp.n_folds} folds x {bp.seq_len} steps, "
-                            "conditioning + loop + float64 tail + D2H, Philox sampling, fp32",
+                            "conditioning + loop + float64 tail + D2H, Philox sampling, fp32 state / results "
+                            "(products on the fp16 matrix pipe with error compensation since round 4)",
                 "value": nsmp / tb, "unit": "samples/s", "x_realtime": nsmp / tb / 16000.0, "s_total": tb,
                 "sample_loop_ms": model.last_loop_ms, "us_per_time_step": model.last_loop_ms * 1e3 / bp.seq_len,
                 "us_per_fold_step": model.last_loop_ms * 1e3 / bp.seq_len / bp.n_folds,
@@ -730,10 +731,17 @@ def main():
             R_, FC_, C_ = model.cfg.rnn_dims, model.cfg.fc_dims, model.n_classes
             fl = 2.0 * (3 * (3 * R_ * R_) + FC_ * R_ + FC_ * FC_ + C_ * FC_) * bp.n_folds
             tf = fl / (result["wavernn_batch32"]["us_per_time_step"] * 1e-6) / 1e12
+            ts3 = os.environ.get("MBHIP_RNN_TS3", "1") != "0"  # rnn_ts3_body.h (default since round 4) or the fp32 form
+            peak = (2500.0 / 3.0) if ts3 else MFMA_F32_PEAK_TFLOPS
             result["wavernn_batch32"]["roofline"] = {
-                "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                "kernel": "mb::rnn_ts2_kernel / rnn_dual_linear_ts2_kernel (whole step: 4 GEMM launches + finish)",
+                "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
+                "frac": tf / peak, "frac_of_fp32_mfma_peak": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                "kernel": ("mb::rnn_ts3_kernel / rnn_dual_linear_ts3_kernel (rnn_ts3_body.h; whole step: 4 GEMM launches + finish): the "
+                           "recurrent GEMMs as error-compensated fp16 MFMA products (three per algorithmic product: ceiling 2500 / 3 TFLOP/s), "
+                           "activations split once per workgroup in LDS; samples held to the oracle (test_production_batch*)" if ts3 else
+                           "mb::rnn_ts2_kernel / rnn_dual_linear_ts2_kernel (whole step: 4 GEMM launches + finish), fp32 MFMA"),
+                "note": "MBHIP_TS3_DBG diagnostics (tools/wrn_batch32_dbg.py): of 65 us per step the k loops are 27 (L2 -> L1 operand traffic: "
+                        "88 MB per big launch), the epilogues 10, launch ramps + prologues + the elementwise rnn1 launch 28",
                 "algorithmic_flops_per_step": fl}
             del outs, bw, bm
             model._ws = None
@@ -771,8 +779,10 @@ def main():
                 entry = {
                     "workload": f"HiFi-GAN V1 16k generator forward, batch 32 x mel (80,200), {dt}"
                                 + (" (fp16 storage, fp16 MFMA, fp32 accumulate)" if dt == "f16" else
-                                   " storage, fp32-grade results: error-compensated fp16 MFMA (x = xh + xl, w = wh + wl, 3 products), "
-                                   "peak = 2500 / 3 TFLOP/s" if split else " storage, fp32-input MFMA"),
+                                   " storage, fp32-grade results: error-compensated fp16 MFMA (x = xh + 2^-11 xl, w = wh + wl, 3 products), "
+                                   "peak = 2500 / 3 TFLOP/s; round 4: the 32- and 64-channel stages as fused ResBlock launches "
+                                   "(resblock_stage_f32.hip: LDS-resident hi / lo operands, fp32 residual in registers)"
+                                   if split else " storage, fp32-input MFMA"),
                     "dtype": dt, "value": 32 * 200 * 200 / (ms * 1e-3), "unit": "samples/s",
                     "x_realtime": 32 * 200 * 200 / (ms * 1e-3) / 16000.0, "ms_per_batch": ms,
                     "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": peak,
