@@ -20,6 +20,11 @@
 
 namespace mb {
 
+// gate functions on the hardware exp2 / reciprocal (1 ulp), as ppg_resident.h / gru_scan.h / taco_fast.h use them
+__device__ __forceinline__ float pf_sigmoid(const float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float pf_tanh(const float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * x)); }
+
+
 __device__ __forceinline__ float pf_softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }  // F.softplus(beta=1, threshold=20)
 
 // LSTM-tile-order product -> CM4 gate quads (a hidden / context part computed one launch or one step ahead)
@@ -73,13 +78,13 @@ __global__ __launch_bounds__(512) void ppg_lstm_kernel(PfLstmK a) {
   float sx[4], sh[4];
   if (!fm_gemm<NT, PW, PS, 4, 1>(a.w, mt, a.x0, a.x1, a.nta, nt0, red, sx, sh)) return;
   if (nt0 + wv >= a.nta || done) return;
-  const float gi = sigmoidf_(((sx[0] + pa.x) + pb.x) + bq.x);
-  const float gf = sigmoidf_(((sx[1] + pa.y) + pb.y) + bq.y);
-  const float gg = tanhf(((sx[2] + pa.z) + pb.z) + bq.z);
-  const float go = sigmoidf_(((sx[3] + pa.w) + pb.w) + bq.w);
+  const float gi = pf_sigmoid(((sx[0] + pa.x) + pb.x) + bq.x);
+  const float gf = pf_sigmoid(((sx[1] + pa.y) + pb.y) + bq.y);
+  const float gg = pf_tanh(((sx[2] + pa.z) + pb.z) + bq.z);
+  const float go = pf_sigmoid(((sx[3] + pa.w) + pb.w) + bq.w);
   const float cy = gf * cprev + gi * gg;
   *cp = cy;
-  a.h[((size_t)(mt >> 2) * a.nta + ntE) * 256 + (mt & 3) * 64 + i * 4 + du] = go * tanhf(cy);
+  a.h[((size_t)(mt >> 2) * a.nta + ntE) * 256 + (mt & 3) * 64 + i * 4 + du] = go * pf_tanh(cy);
 }
 
 // ---------------------------------------------------------------------------------------------- 3: query layer 0 (+ att hh)

@@ -31,6 +31,13 @@
 
 namespace mb {
 
+// Gate functions of the production loop on the hardware exp2 / reciprocal (1 ulp each; gru_scan.h's forms).  Round 3 measured them
+// (48.6 -> 47.5 us per iteration) and dropped them together with the WaveRNN ones because the MOL chain / resident pair stopped being
+// bit-identical; the Tacotron loops have no bit-identical partner (fast vs general loop: 2e-4), so the production loop takes them.
+__device__ __forceinline__ float tf_sigmoid(const float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float tf_tanh(const float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * x)); }
+
+
 // ------------------------------------------------------------------------------------------------ fc2
 // p2 = dropout(relu(fc2 . p1 + b2))   (pre_net.py:24-26).  K = 2D = 256 -> PW = 2.
 struct TfFcK {
@@ -81,9 +88,9 @@ __global__ __launch_bounds__(512) void taco_gru_kernel(TfGruK a) {
   if (!fm_gemm<NT, 2, 2, 3, 1>(a.w, mt, a.xin, a.xin, a.nta, nt0, red, sx, sh, a.trace, TS_GRU, pick)) return;
   if (nt0 + wv >= a.nta || done) return;
   // torch GRUCell, gate order (r, z, n)
-  const float rg = sigmoidf_((sx[0] + xp.x) + hp.x);
-  const float zg = sigmoidf_((sx[1] + xp.y) + hp.y);
-  const float ng = tanhf((sx[2] + xp.z) + rg * hp.z);
+  const float rg = tf_sigmoid((sx[0] + xp.x) + hp.x);
+  const float zg = tf_sigmoid((sx[1] + xp.y) + hp.y);
+  const float ng = tf_tanh((sx[2] + xp.z) + rg * hp.z);
   *hpt = ng + zg * (hprev - ng);
   tf_mark_end(a.trace, TS_GRU, 4, pick);
 }
@@ -188,12 +195,12 @@ __global__ __launch_bounds__(512) void taco_lstm_kernel(TfLstmK a) {
   if (!fm_gemm<NT, 8, 8, 4, 1>(a.w, mt, a.x, a.x, a.nta, nt0, red, sx, sh, a.trace, a.trace_slot, pick)) return;
   if (nt0 + wv >= a.nta || done) return;
   // torch LSTMCell, gate order (i, f, g, o)
-  const float gi = sigmoidf_((sx[0] + hq.x) + bq.x);
-  const float gf = sigmoidf_((sx[1] + hq.y) + bq.y);
-  const float gg = tanhf((sx[2] + hq.z) + bq.z);
-  const float go = sigmoidf_((sx[3] + hq.w) + bq.w);
+  const float gi = tf_sigmoid((sx[0] + hq.x) + bq.x);
+  const float gf = tf_sigmoid((sx[1] + hq.y) + bq.y);
+  const float gg = tf_tanh((sx[2] + hq.z) + bq.z);
+  const float go = tf_sigmoid((sx[3] + hq.w) + bq.w);
   const float cy = gf * cprev + gi * gg;
-  const float hy = go * tanhf(cy);
+  const float hy = go * tf_tanh(cy);
   *cp = cy;
   a.h_out[fo] = hy;
   a.x_out[fo] = xr + hy;

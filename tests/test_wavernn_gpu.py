@@ -597,6 +597,43 @@ def test_production_pipe16_geometries_vs_oracle(model, monkeypatch, frames, targ
     assert float((exact[:, :50] == s[:, :50]).float().mean()) > 0.9
 
 
+@pytest.mark.parametrize("q16", ["1", "0"])
+def test_production_8_bit_model_vs_oracle(cuda, lib, monkeypatch, q16):
+    """A bits = 8 checkpoint (256 classes: 16 fc3 row tiles, the F3 role of the resident kernels has 16 workgroups instead of 32;
+    fatchord_version.py:95-98) through the default resident kernel and the exact one, 400 steps against the oracle."""
+    import types
+    from mockingbird_amd.vocoder.wavernn import hparams as hp
+    from mockingbird_amd.vocoder.wavernn.inference import WaveRNNDevice
+    hp8 = dict(synth.WAVERNN_HP, bits=8)
+    st = synth.wavernn_state(hp8, seed=9)
+    hpm = types.SimpleNamespace(**{k: getattr(hp, k) for k in dir(hp) if not k.startswith("_")})
+    hpm.bits = 8
+    dev = WaveRNNDevice(st["model_state"], hpm)
+    w = dict(st["model_state"])
+    assert dev.n_classes == 256
+    for k in ("MBHIP_WAVERNN_PERSIST", "MBHIP_WAVERNN_PIPE", "MBHIP_WQ_GROUPS"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("MBHIP_WQ16", q16)
+    frames, target, overlap, steps, seed = 120, 1000, 50, 400, 21
+    mel = synth.wavernn_mel(frames, seed=3)
+    s = dev.generate_samples(torch.from_numpy(mel / 4.0).cuda(), True, target, overlap, seed=seed).cpu()
+    assert s.shape[0] == 23 and dev.last_loop_launches == 1
+    noise = dev.sampler_noise(seed, steps, 23).cpu()
+    hpo = dict(ow.HP, bits=8)
+    with torch.no_grad():
+        mels, aux = ow.conditioning(w, hpo, torch.from_numpy(mel[None] / 4.0), True, target, overlap)
+        o_s, o_l = ow.sample_loop(w, hpo, mels, aux, noise=noise, forced=s, return_logits=True, max_steps=steps)
+    k_dev = torch.round((s[:, :steps] + 1) * 255 / 2).long()
+    k_or = torch.round((o_s + 1) * 255 / 2).long()
+    mism = k_dev != k_or
+    if int(mism.sum()):
+        post = torch.softmax(o_l, dim=2) / noise[:steps]
+        top2 = post.topk(2, dim=2).values
+        ratio = ((top2[..., 0] - top2[..., 1]) / top2[..., 0]).t()
+        assert not (mism & (ratio > 1e-4)).any()
+    assert int(mism.sum()) <= 3
+
+
 @pytest.mark.parametrize("form", ["fmaf", "chain"])
 def test_production_one_column_vs_oracle(model, monkeypatch, form):
     """batched=False (one fold column): the persistent kernel (fmaf chains in the MFMA's order) and the launch chain it replaces,
