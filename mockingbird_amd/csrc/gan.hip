@@ -295,7 +295,6 @@ extern "C" int mb_gan_create_ex(const mb_gan_config* cfg, const float* const* h_
           bias.assign((size_t)nd * 2 * ch, 0.f);
           for (int d = 0; d < nd && ok; ++d) {
             const ConvSpec& s1 = v[base + d];
-            const ConvSpec& s2 = v[base + nd + d];
             ok = g->pairs[(size_t)(i * nk + j) * nd + d].p != nullptr && s1.c_in == ch && (d == 0 || s1.k == kj);  // (pairs: shapes checked above)
             kj = s1.k; dil[d] = s1.dil;
             w1[d] = h_weights[2 * (base + d)]; w2[d] = h_weights[2 * (base + nd + d)];
