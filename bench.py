@@ -377,11 +377,11 @@ def gan_floor_bytes(h, batch, frames, fregan=False, top_k=4):
 
 
 def pmc_traffic(what, keys=None):
-    """HBM bytes from the committed rocprofv3 PMC passes of the benchmarked configuration (profiles/r02_pmc_<what>.json,
+    """HBM bytes from the committed rocprofv3 PMC passes of the benchmarked configuration (profiles/r0N_pmc_<what>.json,
     tools/pmc_r02.sh: 2 x FETCH_SIZE + WRITE_SIZE per launch; counters cannot be read in-process).  keys = kernels to
     sum per launch; None = all bytes of the profiled command.  Returns (bytes, source) or (None, None)."""
     pm = name = None
-    for rnd in ("r03", "r02"):  # the newest committed pass of this object
+    for rnd in ("r04", "r03", "r02"):  # the newest committed pass of this object
         try:
             name = f"profiles/{rnd}_pmc_{what}.json"
             pm = json.load(open(os.path.join(ROOT, name)))

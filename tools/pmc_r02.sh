@@ -3,6 +3,7 @@
 # BENCHMARKED configurations (WaveRNN: tools/pmc_wavernn_r02.sh): Tacotron configs[2] (B=32, 400 steps),
 # HiFi-GAN f16 32x200 and Fre-GAN f16 8x3000.  Counter mode crashes on hipGraph replays, so the loops run
 # eagerly (MBHIP_NO_GRAPH=1): same kernels, same arguments.  Summaries -> gpurun_out/pmc2_<what>_<counter>.json
+exec < /dev/null
 export TMPDIR=/tmp MBHIP_NO_GRAPH=1
 mkdir -p gpurun_out
 run() {  # name, command...
