@@ -531,7 +531,7 @@ def main():
                        "as error-compensated fp16 pairs on the fp16 matrix pipe (w = wh + wl, x = xh + xl, wl.xh + wh.xl + wh.xh, fp32 "
                        "accumulate: 21-22 significant bits per operand instead of 24) and its exchange vectors carry the same pairs; "
                        "parity = the reference loop body replayed on the device's own sample history with the exported noise "
-                       "(tests/test_wavernn_gpu.py::test_production_*: every pick equal except provable near-ties); MBHIP_WQ16=0 "
+                       "(tests/test_wavernn_gpu.py::test_production_*: every pick equal except provable near-ties); MBHIP_WAVERNN_RESIDENT=exact "
                        "runs the exact fp32-MFMA kernel (bit-identical to the launch chain)"),
         "config": {"workload": "BASELINE configs[1]: WaveRNN 9-bit mu-law RAW, batch=1 utterance/GPU, "
                                f"mel 80x{F}, batched target=8000 overlap=800 -> {plan.n_folds} folds x "
@@ -562,7 +562,7 @@ def main():
         resident = model.last_loop_launches == 1  # wavernn_pipe.h: the whole sample loop is ONE resident launch
         step_bytes = 16.3e6 + 452.0 * plan.n_folds  # fp32 weights + conditioning per step per fold-batch
         per_kernel = {}
-        split = os.environ.get("MBHIP_WAVERNN_CHAIN", "") != "classic"
+        split = "classic" not in os.environ.get("MBHIP_WAVERNN_CHAIN", "").split(",")
         names = (("gru1_finish", "rnn2_input_half", "fc1+hh1", "fc2+hh2", "fc3_sampler") if split
                  else ("rnn1_gru", "rnn2_gru", "fc1", "fc2", "fc3_sampler"))
         for which, name in enumerate(names):  # (mb_wavernn_bench_kernel always times the launch chain)
@@ -603,12 +603,16 @@ def main():
             launch_us = float(np.median(loop_ms)) * 1000.0
             launch_bytes = step_bytes * plan.seq_len
             gbps = launch_bytes / (launch_us * 1e-6) / 1e9
-            q16 = os.environ.get("MBHIP_WQ16", "1") != "0"  # wavernn_pipe16.h (default) or the exact wavernn_pipe.h kernel
+            q16 = os.environ.get("MBHIP_WAVERNN_RESIDENT", "auto") != "exact"  # wavernn_pipe16.h (default) or the exact wavernn_pipe.h kernel
             traffic, traffic_src = committed("pipe_hbm_bytes_per_launch", ("r04_pmc_wavernn.json",) if q16 else ("r03_pmc_wavernn.json",))
-            os.environ["MBHIP_WAVERNN_PIPE"] = "0"  # the launch chain on the same utterance, for reference
+            resident_env = os.environ.get("MBHIP_WAVERNN_RESIDENT")
+            os.environ["MBHIP_WAVERNN_RESIDENT"] = "0"  # the launch chain on the same utterance, for reference
             model.generate_samples(mel, True, target, overlap, seed=0)
             chain_us = model.last_loop_ms * 1e3 / plan.seq_len
-            os.environ.pop("MBHIP_WAVERNN_PIPE")
+            if resident_env is None:
+                os.environ.pop("MBHIP_WAVERNN_RESIDENT")
+            else:
+                os.environ["MBHIP_WAVERNN_RESIDENT"] = resident_env
             rp = rocprof_avg_us("wf_pipe16_kernel" if q16 else "wf_pipe_kernel")
             result["roofline"] = {
                 "kernel": ("mb::wf_pipe16_kernel (wavernn_pipe16.h): the whole sample loop of the utterance as ONE resident launch -- 224 "
@@ -616,7 +620,7 @@ def main():
                            "(two features per 8-byte granule, 2-bit tags: half the sweep bytes), products as error-compensated "
                            "v_mfma_f32_16x16x32_f16 on weight fragments held in registers; samples held to the oracle, "
                            "tests/test_wavernn_gpu.py::test_production_*" if q16 else
-                           "mb::wf_pipe_kernel (wavernn_pipe.h, MBHIP_WQ16=0): the exact fp32 resident kernel -- 224 "
+                           "mb::wf_pipe_kernel (wavernn_pipe.h, MBHIP_WAVERNN_RESIDENT=exact): the exact fp32 resident kernel -- 224 "
                            "role-specialised workgroups, weight tiles in LDS, two fold-column groups in flight, granule hand-offs"),
                 "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
                 "frac_rocprof": (launch_bytes / (rp * 1e-6) / 1e9 / HBM_PEAK_GBS) if rp else None, "rocprof_avg_launch_us": rp,
@@ -702,7 +706,7 @@ def main():
                 "loop_launches": mol.last_loop_launches,
                 "value": sm.numel() / (mol.last_loop_ms * 1e-3), "unit": "fold samples/s (loop only)"}
             if resident_m:  # A/B partner: the launch chain, same utterance and seed -- bit-identical stream
-                os.environ["MBHIP_WAVERNN_PIPE"] = "0"
+                os.environ["MBHIP_WAVERNN_RESIDENT"] = "0"
                 try:
                     sc = mol.generate_samples(mel, True, target, overlap, seed=2)
                     torch.cuda.synchronize()
@@ -711,7 +715,7 @@ def main():
                         "identical_stream": bool(torch.equal(sc, sm))}
                     del sc
                 finally:
-                    os.environ.pop("MBHIP_WAVERNN_PIPE", None)
+                    os.environ.pop("MBHIP_WAVERNN_RESIDENT", None)
             del mol, sm
         # ---- secondary: WaveRNN throughput mode -- north_star's "batch-32 synthetic input": 32 utterances of
         # mel 80x{F} share ONE sample loop (736 fold columns instead of 23 per launch)
@@ -742,7 +746,7 @@ def main():
             R_, FC_, C_ = model.cfg.rnn_dims, model.cfg.fc_dims, model.n_classes
             fl = 2.0 * (3 * (3 * R_ * R_) + FC_ * R_ + FC_ * FC_ + C_ * FC_) * bp.n_folds
             tf = fl / (result["wavernn_batch32"]["us_per_time_step"] * 1e-6) / 1e12
-            ts3 = os.environ.get("MBHIP_RNN_TS3", "1") != "0"  # rnn_ts3_body.h (default since round 4) or the fp32 form
+            ts3 = os.environ.get("MBHIP_RNN_WIDE", "ts3").startswith("ts3")  # rnn_ts3_body.h (default since round 4) or the fp32 form
             peak = (2500.0 / 3.0) if ts3 else MFMA_F32_PEAK_TFLOPS
             result["wavernn_batch32"]["roofline"] = {
                 "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
@@ -751,7 +755,7 @@ def main():
                            "recurrent GEMMs as error-compensated fp16 MFMA products (three per algorithmic product: ceiling 2500 / 3 TFLOP/s), "
                            "activations split once per workgroup in LDS; samples held to the oracle (test_production_batch*)" if ts3 else
                            "mb::rnn_ts2_kernel / rnn_dual_linear_ts2_kernel (whole step: 4 GEMM launches + finish), fp32 MFMA"),
-                "note": "MBHIP_TS3_DBG diagnostics (tools/wrn_batch32_dbg.py): of 65 us per step the k loops are 27 (L2 -> L1 operand traffic: "
+                "note": "MBHIP_DIAG=ts3_dbg diagnostics (tools/wrn_batch32_dbg.py): of 65 us per step the k loops are 27 (L2 -> L1 operand traffic: "
                         "88 MB per big launch), the epilogues 10, launch ramps + prologues + the elementwise rnn1 launch 28",
                 "algorithmic_flops_per_step": fl}
             del outs, bw, bm

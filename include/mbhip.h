@@ -48,8 +48,10 @@ const char* mb_last_error(void);
  *   1: rounds 1-2.
  *   2: mb_taco_config.dropout = 0 means the reference's 0.5 and a negative value disables dropout (was: 0 disables);
  *      mb_conv1d_pack images carry the fp16 hi / lo fragments behind the fp32 ones; the uniform draws of the on-device RNGs
- *      are centres of 2^23 cells (the same seed gives other dropout masks / samples than version 1). */
-#define MB_ABI_VERSION 2
+ *      are centres of 2^23 cells (the same seed gives other dropout masks / samples than version 1).
+ *   3: mb_wavernn_loop_path takes one `resident` argument (MBHIP_WAVERNN_RESIDENT) in place of the three env_* ones; the library reads
+ *      19 environment switches instead of 52 (DESIGN.md "Run-time switches": renamed / merged / moved under MBHIP_DIAG). */
+#define MB_ABI_VERSION 3
 int mb_abi_version(void);
 
 /* ------------------------------------------------------------------------
@@ -369,7 +371,7 @@ int mb_wavernn_plan_generate(const mb_wavernn* w, int frames, int batched, int t
  *        wavernn_pipe.h) whose 192 / 224 workgroups must be co-resident; the call waits for the launch and reads its
  *        abort word (a lost hand-off -> the launch chain recomputes the same samples, and the device is remembered as
  *        unsuitable), so it returns with the samples complete on `stream`.  Wider calls (the launch chain, hipGraph replays)
- *        are stream-asynchronous as before; MBHIP_WAVERNN_PIPE=0 MBHIP_WAVERNN_PERSIST=0 selects the chain for every width. */
+ *        are stream-asynchronous as before; MBHIP_WAVERNN_RESIDENT=0 selects the chain for every width. */
 int mb_wavernn_generate(const mb_wavernn* w, const mb_wavernn_plan* plan,
                         const float* d_mel, const float* d_noise, uint64_t seed,
                         float* d_samples, float* d_logits_out, const float* d_forced,
@@ -413,13 +415,13 @@ int mb_wavernn_finish(const float* d_samples, int n_folds, int seq_len, int batc
  *   columns: fold columns (1 = batched=False); mode: 0 RAW / 1 MOL; production: 1 = production-dims model sampling on the device
  *   (no injected noise, forced samples, logits dump, trace); have_q16: the K = 512 split weight images exist; resident_cus: compute
  *   units a resident launch may count on; dev_failed: a resident launch lost a hand-off on this device before;
- *   env_pipe / env_persist / env_q16: MBHIP_WAVERNN_PIPE / MBHIP_WAVERNN_PERSIST / MBHIP_WQ16, -1 = unset. */
+ *   resident: MBHIP_WAVERNN_RESIDENT as an int: -1 unset / "auto", 0 = no resident launch, 1 = resident wherever legal (also on a
+ *   device that failed before), 2 = "exact": like 1 with the exact fp32 kernel instead of the operand-pair one. */
 #define MB_WRN_PATH_CHAIN 0     /* the 5-launch chain (csrc/wavernn_fast.h), hipGraph replays                          */
 #define MB_WRN_PATH_PERSIST1 1  /* one column: wf_persist1_kernel (csrc/wavernn_persist.h)                             */
 #define MB_WRN_PATH_PIPE 2      /* 2..32 columns, exact fp32 MFMA: wf_pipe_kernel (csrc/wavernn_pipe.h); MOL models     */
 #define MB_WRN_PATH_PIPE16 3    /* 2..64 columns, 22-bit operand pairs: wf_pipe16_kernel (csrc/wavernn_pipe16.h); RAW  */
-int mb_wavernn_loop_path(int columns, int mode, int production, int have_q16, int resident_cus, int dev_failed,
-                         int env_pipe, int env_persist, int env_q16);
+int mb_wavernn_loop_path(int columns, int mode, int production, int have_q16, int resident_cus, int dev_failed, int resident);
 /* Test hook: the Exp(1) noise the on-device sampler of the production paths draws for `seed`:
  * d_out [steps][folds][n_classes] = E for steps step0 .. step0+steps-1, i.e. exactly the tensor which, passed as d_noise
  * to the oracle's sample loop (argmax(softmax(l) / E), torch.multinomial's rule), reproduces what

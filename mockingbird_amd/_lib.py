@@ -205,7 +205,7 @@ SIGNATURES = {
     "mb_wavernn_generate": (C.c_int, [C.c_void_p, C.POINTER(WaveRNNPlan), C.c_void_p, C.c_void_p,
                                       C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_size_t, C.c_void_p]),
-    "mb_wavernn_loop_path": (C.c_int, [C.c_int] * 9),
+    "mb_wavernn_loop_path": (C.c_int, [C.c_int] * 7),
     "mb_wavernn_debug_noise": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mb_wavernn_debug_noise_mol": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mb_wavernn_last_loop_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
@@ -251,7 +251,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 2  # include/mbhip.h: MB_ABI_VERSION
+ABI_VERSION = 3  # include/mbhip.h: MB_ABI_VERSION
 
 
 def lib():

@@ -30,6 +30,14 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
     }                                    \
   } while (0)
 
+// Diagnostics, A/B knobs and test hooks share ONE environment variable so that they cannot be mistaken for supported switches:
+//   MBHIP_DIAG="key=value,key,key=value"   (read at call time; a bare key reads as "1")
+// diag_str returns false when the key is absent; diag_int returns `absent` then.  The keys are listed in DESIGN.md ("Run-time switches").
+bool diag_str(const char* key, std::string* value);
+int diag_int(const char* key, int absent = 0);
+// value of a documented path switch (plain MBHIP_* variable) as an int; `absent` when unset
+int env_int(const char* name, int absent);
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -1,5 +1,6 @@
 // Error reporting, device buffers and ABI version for libmbhip.
 #include "common.h"
+#include <cstdlib>
 
 namespace mb {
 
@@ -15,6 +16,32 @@ void set_error(const char* fmt, ...) {
 int hip_fail(hipError_t e, const char* what, const char* file, int line) {
   set_error("HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
   return MB_EHIP;
+}
+
+bool diag_str(const char* key, std::string* value) {
+  const char* e = getenv("MBHIP_DIAG");
+  if (!e) return false;
+  const size_t kl = strlen(key);
+  for (const char* p = e; *p;) {
+    const char* end = strchr(p, ',');
+    const size_t len = end ? (size_t)(end - p) : strlen(p);
+    if (len >= kl && strncmp(p, key, kl) == 0 && (len == kl || p[kl] == '=')) {
+      if (value) *value = len == kl ? std::string("1") : std::string(p + kl + 1, len - kl - 1);
+      return true;
+    }
+    p += len + (end ? 1 : 0);
+  }
+  return false;
+}
+
+int diag_int(const char* key, int absent) {
+  std::string v;
+  return diag_str(key, &v) ? atoi(v.c_str()) : absent;
+}
+
+int env_int(const char* name, int absent) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : absent;
 }
 
 int DevBuf::alloc(size_t count) {

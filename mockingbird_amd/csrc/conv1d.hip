@@ -620,8 +620,8 @@ extern "C" int mb_conv1d(const mb_conv1d_args* a, mb_stream_t stream) {
     const int wm = n_mt >= 4 ? 4 : (n_mt >= 2 ? 2 : 1);
     dim3 grid(cdiv(tq, SNT), cdiv(n_mt, wm), a->batch * a->up);
     const int rowlen = SNT * k.down + k.span;
-    const char* l2env = getenv("MBHIP_CONV_SPLIT_LDS2");  // A/B: force one (0) or two (1) x-tile buffers
-    int nbuf = l2env ? (atoi(l2env) == 1 && k.c_in > SCK ? 2 : 1) : (k.c_in >= 512 ? 2 : 1);
+    const int l2 = diag_int("conv_lds2", -1);  // A/B: force one (0) or two (1) x-tile buffers
+    int nbuf = l2 >= 0 ? (l2 == 1 && k.c_in > SCK ? 2 : 1) : (k.c_in >= 512 ? 2 : 1);
     if ((size_t)nbuf * rowlen * SROW > 64 * 1024) nbuf = 1;  // two buffers of a long window (rowlen > 227) would pass the 64 KB a
     const size_t lds = (size_t)nbuf * rowlen * SROW;          // launch gets without hipFuncSetAttribute; one always fits (<= 36 KB)
     const bool fits32 = (long long)a->c_in * a->t_in < (1ll << 31) && (long long)a->c_out * a->t_out < (1ll << 31);  // 32-bit offsets inside an item

@@ -226,7 +226,17 @@ extern "C" int mb_gan_create_ex(const mb_gan_config* cfg, const float* const* h_
   }
   g->i_rb = idx; idx += cfg->num_upsamples * cfg->num_kernels * cfg->num_dilations * 2;
   g->i_post = idx;
-  if (dtype == MB_F16 && !getenv("MBHIP_GAN_NOFUSE")) {
+  // MBHIP_GAN_FUSE = all (default) | nochain (no one-launch ResBlock chains) | units (fused units only: no stage / chain launches) |
+  // none (one launch per conv): the fallbacks the parity tests compare the fused launches with
+  const char* fenv = getenv("MBHIP_GAN_FUSE");
+  const std::string fuse = fenv ? fenv : "all";
+  if (!(fuse == "all" || fuse == "nochain" || fuse == "units" || fuse == "none")) {
+    set_error("MBHIP_GAN_FUSE: unknown value '%s' (all | nochain | units | none)", fuse.c_str());
+    mb_gan_destroy(g);
+    return MB_EINVAL;
+  }
+  const bool no_fuse = fuse == "none", no_stage = no_fuse || fuse == "units", no_chain = no_stage || fuse == "nochain";
+  if (dtype == MB_F16 && !no_fuse) {
     const int nd = cfg->num_dilations;
     g->pairs.resize((size_t)cfg->num_upsamples * cfg->num_kernels * nd);
     std::vector<float> img;
@@ -247,7 +257,7 @@ extern "C" int mb_gan_create_ex(const mb_gan_config* cfg, const float* const* h_
           if (rc) { mb_gan_destroy(g); return rc; }
         }
   }
-  if (dtype == MB_F16 && !getenv("MBHIP_GAN_NOFUSE") && !getenv("MBHIP_GAN_NOSTAGE") && cfg->num_kernels <= 4 &&
+  if (dtype == MB_F16 && !no_stage && cfg->num_kernels <= 4 &&
       cfg->num_dilations <= 4) {
     const int nd = cfg->num_dilations, nk = cfg->num_kernels;
     g->stage_w.resize(cfg->num_upsamples);
@@ -281,7 +291,7 @@ extern "C" int mb_gan_create_ex(const mb_gan_config* cfg, const float* const* h_
       if (!rc) rc = g->stage_b[i].upload(bias.data(), bias.size());
       if (rc) { mb_gan_destroy(g); return rc; }
     }
-    if (!getenv("MBHIP_GAN_NOCHAIN")) {
+    if (!no_chain) {
       g->chain_w.resize((size_t)cfg->num_upsamples * nk);
       g->chain_b.resize((size_t)cfg->num_upsamples * nk);
       for (int i = 0; i < cfg->num_upsamples; ++i) {
@@ -308,8 +318,9 @@ extern "C" int mb_gan_create_ex(const mb_gan_config* cfg, const float* const* h_
           // recompute costs what the per-unit launches' tensor passes do
           // do.  k = 3 units are the least efficient per-unit launches (21 % of the matrix peak at 128 channels), so their chain
           // pays from 0.65: Fre-GAN 8 x 3000 with dilations (1, 3, 5, 7), k = 3 at 128 channels (0.69): 12.97 -> 12.78 ms same box.
-          const char* ee = getenv("MBHIP_GAN_CHAIN_EFF");  // A/B: another threshold
-          if (!ok || mb_resblock_stage_f16_efficiency(ch, 1, &kj, nd, dil) < (ee ? (float)atof(ee) : (kj <= 3 ? 0.65f : 0.75f))) continue;
+          std::string ee;  // A/B (MBHIP_DIAG=gan_chain_eff=<x>): another threshold
+          const bool have_ee = diag_str("gan_chain_eff", &ee);
+          if (!ok || mb_resblock_stage_f16_efficiency(ch, 1, &kj, nd, dil) < (have_ee ? (float)atof(ee.c_str()) : (kj <= 3 ? 0.65f : 0.75f))) continue;
           img.assign(mb_resblock_stage_f16_packed_halves(ch, 1, &kj, nd) / 2, 0.f);
           rc = mb_resblock_stage_f16_pack(w1, w2, ch, 1, &kj, nd, reinterpret_cast<uint16_t*>(img.data()));
           if (!rc) rc = g->chain_w[(size_t)i * nk + j].upload(img.data(), img.size());
@@ -319,7 +330,7 @@ extern "C" int mb_gan_create_ex(const mb_gan_config* cfg, const float* const* h_
       }
     }
   }
-  if (dtype == MB_F32 && !getenv("MBHIP_GAN_NOFUSE") && !getenv("MBHIP_GAN_NOSTAGE") && cfg->num_kernels <= 4 && cfg->num_dilations <= 4) {
+  if (dtype == MB_F32 && !no_stage && cfg->num_kernels <= 4 && cfg->num_dilations <= 4) {
     // fp32 path: fused ResBlock groups on error-compensated operands (resblock_stage_f32.hip)
     const int nd = cfg->num_dilations, nk = cfg->num_kernels;
     g->s32_w.resize(cfg->num_upsamples);
@@ -356,7 +367,7 @@ extern "C" int mb_gan_create_ex(const mb_gan_config* cfg, const float* const* h_
       const int ch = cfg->upsample_initial_channel >> (i + 1);
       // (32 channels: the whole group in ONE launch -- s32_w -- works, tests/test_resblock_stage_f32_gpu.py, but every chain then pays the
       //  widest chain's halo: 136 useful rows of 256; a launch per ResBlock / unit lets k = 3 keep 232 and k = 11's units 196-236)
-      if (ch == 32 && getenv("MBHIP_GAN_S32_GROUP")) {
+      if (ch == 32 && diag_int("gan_s32_group")) {
         const int r = make(i, ch, 0, nk, 0, nd, &g->s32_w[i], &g->s32_b[i]);
         if (r < 0) rc = r;
         if (r) { g->s32_w[i].release(); g->s32_b[i].release(); }

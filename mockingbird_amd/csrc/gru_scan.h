@@ -38,7 +38,7 @@ struct GruScanK {
   int B, F, Hg;
   float unscale[2];         // 2^-(s + 10) per direction
   float wscale[2];          // 2^s
-  int dbg;                  // diagnostics (MBHIP_GS_DBG, wrong results): 1 = no hand-off, 2 = no sequence stores, 4 = no products, 8 = no x loads
+  int dbg;                  // diagnostics (MBHIP_DIAG=gs_dbg=<bits>, wrong results): 1 = no hand-off, 2 = no sequence stores, 4 = no products, 8 = no x loads
 };
 
 constexpr float GS_HSCALE = 1024.f;

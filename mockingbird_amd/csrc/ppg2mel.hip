@@ -507,7 +507,7 @@ static int ppg_fast_loop_body(mb_ppg2mel* p, const PpgLayout& L, const float* d_
   };
   MB_HIP(hipEventRecord(p->ev_t0, s));
   int G = 16;
-  if (const char* ge = getenv("MBHIP_PPG_GRAPH_STEPS")) G = std::max(1, atoi(ge));
+  if (const char* ge = getenv("MBHIP_GRAPH_STEPS")) G = std::max(1, atoi(ge));
   const bool use_graph = getenv("MBHIP_NO_GRAPH") == nullptr && max_steps >= G;
   int done_steps = 0, eager_steps = 0, rc = MB_OK;
   bool stopped = false;
@@ -630,8 +630,10 @@ extern "C" int mb_ppg2mel_decode(const mb_ppg2mel* p, const float* d_memory, int
       hipStream_t ls = pm->loop_stream;
       int* abort_word = reinterpret_cast<int*>(L.px + (size_t)2 * PRX_PER);
       MB_HIP(hipMemsetAsync(L.px, 0, pr_exchange_bytes(), ls));
-      if (getenv("MBHIP_PR_TEST_ABORT")) MB_HIP(hipMemsetAsync(abort_word, 1, 1, ls));  // tests only: the chain takes over
-      const char* rtrace = getenv("MBHIP_PR_TRACE");  // diagnostics: dump the wall-clock marks of the kernel to this file
+      const bool test_abort = diag_int("abort_pr") != 0;  // tests only (MBHIP_DIAG=abort_pr): the chain takes over
+      if (test_abort) MB_HIP(hipMemsetAsync(abort_word, 1, 1, ls));
+      std::string rtrace_file;  // diagnostics (MBHIP_DIAG=pr_trace=<file>): dump the wall-clock marks of the kernel to this file
+      const char* rtrace = diag_str("pr_trace", &rtrace_file) ? rtrace_file.c_str() : nullptr;
       PrK k;
       k.img_att = pm->r_att.p; k.img_w1 = pm->r_w1.p; k.img_dec = pm->r_dec.p; k.img_q0 = pm->r_q0.p; k.img_out = pm->r_out.p;
       k.att_b4 = reinterpret_cast<const float4*>(pm->f_att_b4.p); k.dec_b4 = reinterpret_cast<const float4*>(pm->f_dec_b4.p);
@@ -639,7 +641,7 @@ extern "C" int mb_ppg2mel_decode(const mb_ppg2mel* p, const float* d_memory, int
       k.memory = d_memory; k.mel_out = d_mel; k.align_out = d_align; k.stop_out = d_stop; k.drop_mask = d_dropout;
       k.ex = L.px; k.abort_word = abort_word; k.flags = L.flags; k.seed = seed;
       k.T = T; k.M = M; k.RM = RM; k.S = max_steps; k.min_steps = min_steps; k.thr = stop_threshold; k.eps = 1e-5f;
-      k.variant = getenv("MBHIP_PR_VARIANT") ? atoi(getenv("MBHIP_PR_VARIANT")) : 0;
+      k.variant = diag_int("pr_variant", 0);
       k.trace = rtrace ? reinterpret_cast<unsigned long long*>(abort_word) + 32 : nullptr;
       MB_HIP(hipEventRecord(pm->ev_t0, ls));
       hipLaunchKernelGGL(ppg_resident_kernel, dim3(PR_WGS), dim3(512), PR_LDS_BYTES, ls, k);
@@ -664,7 +666,7 @@ extern "C" int mb_ppg2mel_decode(const mb_ppg2mel* p, const float* d_memory, int
         fprintf(stderr, "[mbhip] ppg2mel: resident kernel could not keep its workgroups co-resident; using the launch chain\n");
         warned = true;
       }
-      if (dev >= 0 && dev < 64 && !getenv("MBHIP_PR_TEST_ABORT")) g_ppg_resident_failed[dev] = true;
+      if (dev >= 0 && dev < 64 && !test_abort) g_ppg_resident_failed[dev] = true;
       // whatever the drained launch left behind: outputs and flags back to zero, then the chain from step 0
       MB_HIP(hipMemsetAsync(L.mu, 0, sizeof(float) * B * M, ls));
       MB_HIP(hipMemsetAsync(L.flags, 0, sizeof(int) * 8, ls));

@@ -59,8 +59,8 @@ struct PrK {
   unsigned long long seed;
   int T, M, RM, S, min_steps;
   float thr, eps;
-  int variant;                                     // A/B switches (MBHIP_PR_VARIANT): 1 = DEC polls the context as a whole vector, 2 = ATT polls p0 as a whole vector
-  unsigned long long* trace;                       // diagnostics (MBHIP_PR_TRACE): wall-clock marks, steps 100..103
+  int variant;                                     // A/B switches (MBHIP_DIAG=pr_variant=<bits>): 1 = DEC polls the context as a whole vector, 2 = ATT polls p0 as a whole vector
+  unsigned long long* trace;                       // diagnostics (MBHIP_DIAG=pr_trace=<file>): wall-clock marks, steps 100..103
 };
 
 __device__ __forceinline__ float pr_dpp(const float v, const int ctrl_sel) {

@@ -43,8 +43,8 @@ struct ResPairK {
   long long bstride;  // elements per batch item (T*C)
   int T, ntaps, dil;
   int NB, tiles_per_item, n_tiles, x_rows;
-  unsigned long long* trace;  // diagnostics only (MBHIP_PAIR_TRACE): shader-clock marks of workgroup 0
-  int dbg;   // diagnostics only (MBHIP_PAIR_DBG): 1 = weight stream folded onto its first taps (L1-resident),
+  unsigned long long* trace;  // diagnostics only (MBHIP_DIAG=pair_trace=<file>): shader-clock marks of workgroup 0
+  int dbg;   // diagnostics only (MBHIP_DIAG=pair_dbg=<bits>): 1 = weight stream folded onto its first taps (L1-resident),
              // 2 = no residual read, 4 = no output store -- results are wrong, timings isolate one cost each
   int nbuf;  // LDS buffers of the x window (1 = single buffer, refilled while phase 2 runs; C <= 64 only)
   float slope, out_scale;
@@ -62,7 +62,7 @@ constexpr int PAIR_LB = 80 / PAIR_NL;  // x-window loads in flight per support l
 #ifndef MB_PAIR_NT
 #define MB_PAIR_NT 0
 #endif
-// The MBHIP_PAIR_DBG bits exist only in diagnostics builds (-DMB_PAIR_DBG_BUILD): a run-time test around the weight
+// The MBHIP_DIAG=pair_dbg=<bits> bits exist only in diagnostics builds (-DMB_PAIR_DBG_BUILD): a run-time test around the weight
 // prefetch made every ring refill a conditional load, and the compiler then drained vmcnt to 0 at every tap pair.
 #ifdef MB_PAIR_DBG_BUILD
 #define MB_PDBG(a_, bit) ((a_).dbg & (bit))
@@ -488,9 +488,10 @@ static int launch_pair(ResPairK k, int batch, hipStream_t s) {
   int nbuf = pair_min_nbuf<C>(NTW, k.ntaps, k.dil);
   while (nbuf < 4 && pair_lds_bytes<C>(NTW, k.ntaps, k.dil, nbuf + 1, YS) <= PAIR_LDS_CAP) ++nbuf;
   k.nbuf = nbuf;
-  if (const char* e = getenv("MBHIP_PAIR_DBG")) k.dbg = atoi(e);
+  k.dbg = diag_int("pair_dbg", k.dbg);
   static unsigned long long* d_trace = nullptr;
-  const char* trace_path = getenv("MBHIP_PAIR_TRACE");
+  std::string trace_file;
+  const char* trace_path = diag_str("pair_trace", &trace_file) ? trace_file.c_str() : nullptr;
   if (trace_path) {
     if (!d_trace) MB_HIP(hipMalloc((void**)&d_trace, 256 * sizeof(unsigned long long)));
     MB_HIP(hipMemsetAsync(d_trace, 0, 256 * sizeof(unsigned long long), s));

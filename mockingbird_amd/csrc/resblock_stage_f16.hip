@@ -49,7 +49,7 @@ struct ResStageK {
   float slope, out_scale;
   int accumulate;  // y += (the wider stages run one ResBlock per launch: the mean over the ResBlocks accumulates in y)
   const int* valid; int valid_mul;
-  unsigned long long* trace;  // diagnostics only (-DMB_STAGE_TRACE_BUILD + MBHIP_STAGE_TRACE): shader-clock marks of workgroup 0, tile 1
+  unsigned long long* trace;  // diagnostics only (-DMB_STAGE_TRACE_BUILD + MBHIP_DIAG=stage_trace=<file>): shader-clock marks of workgroup 0, tile 1
 };
 
 #ifdef MB_STAGE_TRACE_BUILD
@@ -428,9 +428,10 @@ static int launch_stage(ResStageK k, const StageGeom& g, int batch, hipStream_t 
                ? prop.multiProcessorCount : 256;
   }
 #ifdef MB_STAGE_TRACE_BUILD
-  if (getenv("MBHIP_STAGE_DBG_FOLD")) k.NFT = 4;  // diagnostics: the weight stream folded onto its first four taps (L1-resident; wrong results)
+  if (diag_int("stage_fold")) k.NFT = 4;  // diagnostics: the weight stream folded onto its first four taps (L1-resident; wrong results)
   static unsigned long long* d_trace = nullptr;
-  const char* trace_path = getenv("MBHIP_STAGE_TRACE");
+  std::string trace_file;
+  const char* trace_path = diag_str("stage_trace", &trace_file) ? trace_file.c_str() : nullptr;
   if (trace_path) {
     if (!d_trace) MB_HIP(hipMalloc((void**)&d_trace, 128 * sizeof(unsigned long long)));
     MB_HIP(hipMemsetAsync(d_trace, 0, 128 * sizeof(unsigned long long), s));

@@ -83,15 +83,12 @@ struct RnnK {
   unsigned long long* gum_slot; unsigned long long gum_seed;
   // zero_slot != null: workgroup (0,0) clears zero_slot[0..N) (the argmax words of the NEXT step)
   unsigned long long* zero_slot;
-  // arrive != null (with gum_slot): once this workgroup's argmax atomics have been performed, one lane adds 1
-  // to *arrive (agent scope) -- the in-launch hand-off to the gru1-finish job of rnn_fc3_finish_kernel
-  unsigned int* arrive;
-  // diagnostics (MBHIP_TRACE_FILE): per-workgroup (start, end) wall_clock64 ticks, TRACE_SLOTS pairs
+  // diagnostics (MBHIP_DIAG=trace_file=<file>): per-workgroup (start, end) wall_clock64 ticks, TRACE_SLOTS pairs
   unsigned long long* trace;
   // wide batches (rnn_ts3_body.h): the same matrix as fp16 hi / lo A fragments of v_mfma_f32_16x16x32_f16
   // ([row tile][k-step of 32][hi | lo][lane][8], wavernn_pipe16.h wq16_pack) scaled by 2^s, and 2^-s; null -> the fp32 forms
   const void* w16; float w16_unscale;
-  int dbg;  // diagnostics (MBHIP_TS3_DBG, results are WRONG on purpose): 1 = rnn_ts3_body skips its k loop, 2 = skips its epilogues
+  int dbg;  // diagnostics (MBHIP_DIAG=ts3_dbg=<bits>, results are WRONG on purpose): 1 = rnn_ts3_body skips its k loop, 2 = skips its epilogues
 };
 
 // order-preserving float -> uint key and the packed (key, lowest-class-wins) argmax word
@@ -201,19 +198,14 @@ struct Fin1K {
   float* h_out; float* x_out; float* samples; volatile int* progress;
   const int* step_base; int step_off, n_off, nl, R, C, S, fold_stride, total_len;
   const int* desc;  // optional per-fold descriptors (RnnK::fr_desc layout)
-  // in-launch variant: wait until *arrive >= (step index) * arrive_per_step before reading the slots
-  const unsigned int* arrive; unsigned int arrive_per_step;
   unsigned long long* trace;
 };
 int rnn_launch(int epi, const RnnK& k, hipStream_t s);
 // Forward and backward step of a bidirectional GRU scan in one launch (falls back to two launches for
 // shapes outside the instantiated scan instance)
 int rnn_launch_dual_gru(const RnnK& k0, const RnnK& k1, hipStream_t s);
-// stand-alone gru1-finish launch (first step of a generate call, or MBHIP_WAVERNN_MERGE=0)
+// gru1-finish launch (the elementwise rnn1 of the split-hidden chains)
 int rnn_launch_finish(const Fin1K& f, hipStream_t s);
-// fc3 + Gumbel-argmax sampler AND the gru1-finish job of the NEXT step in one launch: the finish
-// workgroups prefetch their sample-independent operands, then wait on the arrival counter (rnn.hip)
-int rnn_launch_fc3_finish(const RnnK& k, const Fin1K& f, hipStream_t s);
 // Two LINEAR jobs in one launch (job 0 on the critical path gets the first workgroups); see rnn.hip.
 int rnn_launch_dual_linear(const RnnK& k0, const RnnK& k1, hipStream_t s);
 

@@ -21,7 +21,6 @@ __global__ __launch_bounds__(512) void rnn_rowtile_kernel(RnnDev d) {
 }
 
 // ---- gru1-finish job (Fin1K, rnn.h): one thread per (fold, unit), all loads issued before first use ----
-template <bool WAIT>
 __device__ __forceinline__ void gru1_finish_body(const Fin1K& a, const int block, const int nthreads) {
   const int idx = block * nthreads + threadIdx.x;
   const int H = a.R;
@@ -43,20 +42,7 @@ __device__ __forceinline__ void gru1_finish_body(const Fin1K& a, const int block
   }
   const float tr = tq.x, tz = tq.y, tn = tq.z, ip = tq.w;
   const float gr = a.g1[j], gz = a.g1[H + j], gn = a.g1[2 * H + j], w0 = a.wI0[j];
-  unsigned long long slot;
-  if (WAIT) {
-    // every fc3 workgroup of this launch has added 1 to *arrive after its argmax atomics were performed
-    if (threadIdx.x == 0) {
-      const unsigned int target = (unsigned int)s * a.arrive_per_step;  // s = index of the step being prepared
-      int spins = 0;
-      while (__hip_atomic_load(a.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1 << 17))
-        __builtin_amdgcn_s_sleep(1);  // bounded: a lost arrival costs wrong samples, never a hung GPU
-    }
-    __syncthreads();
-    slot = __hip_atomic_load(a.slot + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  } else {
-    slot = a.slot[n];
-  }
+  const unsigned long long slot = a.slot[n];
   if (!live) return;
   const float x = slot ? 2.f * (float)argmax_class(slot) / ((float)a.C - 1.f) - 1.f : 0.f;
   // torch GRUCell, gate order (r, z, n)
@@ -74,39 +60,24 @@ __device__ __forceinline__ void gru1_finish_body(const Fin1K& a, const int block
 
 __global__ __launch_bounds__(256) void wavernn_gru1_finish_kernel(Fin1K a) {
   trace_begin(a.trace);
-  gru1_finish_body<false>(a, blockIdx.x, 256);
+  gru1_finish_body(a, blockIdx.x, 256);
   trace_end(a.trace);
 }
 
-// fc3 + sampler (job 0, first workgroups) and the NEXT step's gru1-finish (job 1) in one launch.
-// Job 1 needs every job-0 workgroup's argmax: job 0 arrives on a device-scope counter (RF_ARRIVE),
-// job 1 prefetches everything that does not depend on the sample and then polls the counter.  All
-// nx0*gridDim.y + finish workgroups are co-resident (far fewer than CUs), job 0 is dispatched first.
-template <unsigned F0>
-__global__ __launch_bounds__(512) void rnn_fc3_finish_kernel(RnnDev d0, Fin1K f, int nx0) {
-  if ((int)blockIdx.x < nx0) { rnn_rowtile_body<EPI_LINEAR, 1, 4, F0>(d0, blockIdx.x, blockIdx.y); return; }
-  if (blockIdx.y != 0) return;
-  gru1_finish_body<true>(f, blockIdx.x - nx0, 512);
-}
+// (fc3 + the NEXT step's gru1-finish in one launch through an arrival counter was measured in rounds 1 and 4 -- 26.4 against 25.7 us per
+//  step at 23 columns, 73-94 against 62 at 736 -- and is not part of the library: DESIGN 4i, tools/rejected/.)
 
 // Two independent LINEAR jobs in ONE launch: workgroups with blockIdx.x < nx0 run job 0 (the one on
 // the critical path: they are dispatched first), the rest run job 1 on the CUs job 0 leaves idle.
 // The WaveRNN loop uses it to compute the hidden halves W_hh.h + b_hh of the NEXT step's GRUs beside
 // fc1 / fc2 (wavernn.hip), which takes them off the dependent chain.
-template <int UB0, unsigned F0, int UB1, unsigned F1, int NT = 1>
+template <int UB0, unsigned F0, int UB1, unsigned F1>
 __global__ __launch_bounds__(512) void rnn_dual_linear_kernel(RnnDev d0, RnnDev d1, int nx0) {
-  if ((int)blockIdx.x < nx0) rnn_rowtile_body<EPI_LINEAR, NT, UB0, F0>(d0, blockIdx.x, blockIdx.y);
-  else rnn_rowtile_body<EPI_LINEAR, NT, UB1, F1>(d1, blockIdx.x - nx0, blockIdx.y);
+  if ((int)blockIdx.x < nx0) rnn_rowtile_body<EPI_LINEAR, 1, UB0, F0>(d0, blockIdx.x, blockIdx.y);
+  else rnn_rowtile_body<EPI_LINEAR, 1, UB1, F1>(d1, blockIdx.x - nx0, blockIdx.y);
 }
-// 17..64 fold columns (BASELINE configs[1]: 23): two 16-column tiles per workgroup share one weight fetch, half the
-// workgroups per launch.  Measured and NOT adopted: 29.1 us per step against 26.0 with one tile per workgroup (each
-// launch +0.2..1.0 us: the second tile's loads, MFMAs and reduction are serial inside the workgroup, while a second
-// workgroup runs beside the first) -- the loop is latency-bound, not bound by the weight stream.  Kept behind
-// MBHIP_WAVERNN_NT2=1, bit-identical sample stream (tests/test_wavernn_gpu.py).
-static bool rnn_wavernn_nt2(int N) {
-  const char* e = getenv("MBHIP_WAVERNN_NT2");
-  return e && atoi(e) != 0 && N > 16 && N <= 64;
-}
+// (17..64 fold columns with two 16-column tiles per workgroup -- one weight fetch for both -- was measured in round 1 and not adopted:
+//  29.1 us per step against 26.0; the loop is latency-bound, not bound by the weight stream.  Removed from the library in round 4.)
 
 // Tile-split launches (rnn_body.h, TS): wide batches (several utterances per WaveRNN loop)
 template <int EPI, unsigned F>
@@ -144,20 +115,25 @@ __global__ __launch_bounds__(256) void rnn_dual_linear_ts3_kernel(RnnDev d0, Rnn
   if ((int)blockIdx.x < nx0) rnn_ts3_body<EPI_LINEAR, F0, MT, NT>(d0, blockIdx.x, blockIdx.y, reinterpret_cast<t3h*>(ts3_lds));
   else rnn_ts3_body<EPI_LINEAR, F1, MT, NT>(d1, blockIdx.x - nx0, blockIdx.y, reinterpret_cast<t3h*>(ts3_lds));
 }
-static bool rnn_ts3_enabled() {
-  const char* e = getenv("MBHIP_RNN_TS3");
-  return !(e && atoi(e) == 0);
+// Wide batches (> 64 fold columns): MBHIP_RNN_WIDE = ts3 (default: fp16 pipe, rnn_ts3_body.h) | ts2 (fp32 register-tiled form,
+// rnn_ts2_body.h) | ts (first wide form, rnn_body.h TS), optionally ":<column tiles per wave>" (1..3) for the parity tests
+static int rnn_wide_form(int* nt_forced = nullptr) {  // 3 / 2 / 1
+  if (nt_forced) *nt_forced = 0;
+  const char* e = getenv("MBHIP_RNN_WIDE");
+  if (!e) return 3;
+  if (nt_forced) if (const char* c = strchr(e, ':')) *nt_forced = atoi(c + 1);
+  return strncmp(e, "ts2", 3) == 0 ? 2 : (strncmp(e, "ts3", 3) == 0 ? 3 : (strncmp(e, "ts", 2) == 0 ? 1 : 3));
 }
+static bool rnn_ts3_enabled() { return rnn_wide_form() == 3; }
 // Column tiles per wave of the register-tiled wide form, 0 = use the first wide form (rnn_body.h TS).
 // 128 row tiles in pieces of 2 make 16 workgroup rows, so the piece must be narrow enough for >= 256 workgroups:
 // 3 column tiles from 44 column tiles up (736 columns: exactly one piece per SIMD), 2 from 28, 1 from 14; narrower
 // batches keep the 8-wave one-tile-per-wave form, which cuts the same work into four times as many workgroups.
-// MBHIP_RNN_TS2=0 forces that form, MBHIP_TS2_NT=1|2|3 forces a piece width (parity tests, A/B runs).
+// MBHIP_RNN_WIDE=ts forces that form, "ts3:2" / "ts2:1" force a piece width (parity tests, A/B runs).
 static int rnn_ts2_nt(int N) {
-  const char* e = getenv("MBHIP_RNN_TS2");
-  if (e && atoi(e) == 0) return 0;
-  const char* f = getenv("MBHIP_TS2_NT");
-  if (f && atoi(f) >= 1 && atoi(f) <= 3) return atoi(f);
+  int nt_forced = 0;
+  if (rnn_wide_form(&nt_forced) == 1) return 0;
+  if (nt_forced >= 1 && nt_forced <= 3) return nt_forced;
   const int ct = cdiv(N, 16);
   return ct >= 44 ? 3 : ct >= 28 ? 2 : ct >= 14 ? 1 : 0;
 }
@@ -216,11 +192,6 @@ void cell_rows(const float* w_ih, int kx, int ldx, const float* w_hh, int kh, in
   /* ... and with per-fold descriptors (several utterances per loop) */                                   \
   X(EPI_GRU, 1, 4, RF_PRE | RF_FRAME | RF_HPRE | RF_XRES | RF_XOUT | RF_ZERO | RF_FOLDTAB)                \
   X(EPI_LINEAR, 1, 4, RF_BIASX | RF_FRAME | RF_GUMBEL | RF_FOLDTAB)                                       \
-  /* ... with two column tiles per workgroup (MBHIP_WAVERNN_NT2) */                                        \
-  X(EPI_GRU, 2, 4, RF_PRE | RF_FRAME | RF_HPRE | RF_XRES | RF_XOUT | RF_ZERO)                             \
-  X(EPI_GRU, 2, 4, RF_PRE | RF_FRAME | RF_HPRE | RF_XRES | RF_XOUT | RF_ZERO | RF_FOLDTAB)                \
-  X(EPI_LINEAR, 2, 4, RF_BIASX | RF_FRAME | RF_GUMBEL)                                                    \
-  X(EPI_LINEAR, 2, 4, RF_BIASX | RF_FRAME | RF_GUMBEL | RF_FOLDTAB)                                       \
   /* Tacotron decoder: prenet fc1/fc2 (mask / on-device dropout), attention GRU, rnn_input, LSTMs, mel */ \
   X(EPI_LINEAR, 1, 2, RF_BIASX | RF_SKIP | RF_MASK | ACT(1))                                              \
   X(EPI_LINEAR, 1, 2, RF_BIASX | RF_SKIP | RF_DROP | ACT(1))                                              \
@@ -279,13 +250,6 @@ int rnn_launch_dual_linear(const RnnK& k0, const RnnK& k1, hipStream_t s) {
     MB_HIP(hipGetLastError());
     return MB_OK;
   }
-  if (rnn_wavernn_nt2(k0.N)) {
-    dim3 grid2(nx0 + nx1, cdiv(k0.N, 32));
-    if (f0 == F0) hipLaunchKernelGGL((rnn_dual_linear_kernel<4, F0, 4, F1, 2>), grid2, dim3(NW * 64), 0, s, d0, d1, nx0);
-    else hipLaunchKernelGGL((rnn_dual_linear_kernel<4, F0 | RF_FOLDTAB, 4, F1, 2>), grid2, dim3(NW * 64), 0, s, d0, d1, nx0);
-    MB_HIP(hipGetLastError());
-    return MB_OK;
-  }
   dim3 grid(nx0 + nx1, cdiv(k0.N, 16));
   if (f0 == F0) hipLaunchKernelGGL((rnn_dual_linear_kernel<4, F0, 4, F1>), grid, dim3(NW * 64), 0, s, d0, d1, nx0);
   else hipLaunchKernelGGL((rnn_dual_linear_kernel<4, F0 | RF_FOLDTAB, 4, F1>), grid, dim3(NW * 64), 0, s, d0, d1, nx0);
@@ -321,22 +285,6 @@ int rnn_launch_finish(const Fin1K& f, hipStream_t s) {
   return MB_OK;
 }
 
-int rnn_launch_fc3_finish(const RnnK& k, const Fin1K& f, hipStream_t s) {
-  constexpr int NW = 8;
-  constexpr unsigned F0 = RF_BIASX | RF_FRAME | RF_GUMBEL | RF_ARRIVE;
-  RnnDev d0;
-  int rc = make_rnn_dev(k, &d0);
-  if (rc) return rc;
-  MB_REQUIRE(rnn_features(EPI_LINEAR, k) == F0 && cdiv(k.nkb_total, NW) == 4 && k.nseg == 1 && f.arrive == k.arrive,
-             "rnn_launch_fc3_finish: needs the fused-sampler fc3 instance with K = 512 (features %x)", rnn_features(EPI_LINEAR, k));
-  const int nx0 = cdiv(k.units, 16), ny = cdiv(k.N, 16);
-  MB_REQUIRE(f.arrive_per_step == (unsigned)(nx0 * ny), "rnn_launch_fc3_finish: arrive_per_step must be %d", nx0 * ny);
-  dim3 grid(nx0 + cdiv(f.nl * f.R, NW * 64), ny);
-  hipLaunchKernelGGL((rnn_fc3_finish_kernel<F0>), grid, dim3(NW * 64), 0, s, d0, f, nx0);
-  MB_HIP(hipGetLastError());
-  return MB_OK;
-}
-
 int rnn_launch(int epi, const RnnK& k, hipStream_t s) {
   MB_REQUIRE(k.N >= 1 && k.units >= 1 && k.nseg >= 1 && k.nseg <= 4, "rnn_launch: bad shape");
   MB_REQUIRE(!k.aff_slot || (k.fr_base && k.nseg >= 1 && epi == EPI_GRU), "rnn_launch: rebuilt segment needs the fold geometry");
@@ -351,10 +299,7 @@ int rnn_launch(int epi, const RnnK& k, hipStream_t s) {
   const int rl = (epi == EPI_GRU) ? 3 : 4;
   const size_t wbytes = (size_t)n_mt * k.nkb_total * 4 * rl * 16 * sizeof(float);
   const unsigned feat = rnn_features(epi, k);
-  constexpr unsigned FW_G = RF_PRE | RF_FRAME | RF_HPRE | RF_XRES | RF_XOUT | RF_ZERO, FW_L = RF_BIASX | RF_FRAME | RF_GUMBEL;
-  const bool wavernn_nt2 = rnn_wavernn_nt2(k.N) && ((epi == EPI_GRU && (feat & ~RF_FOLDTAB) == FW_G) ||
-                                                    (epi == EPI_LINEAR && (feat & ~RF_FOLDTAB) == FW_L));
-  const int nt = ((k.N > 16 && wbytes >= ((size_t)12 << 20)) || wavernn_nt2) ? 2 : 1;
+  const int nt = (k.N > 16 && wbytes >= ((size_t)12 << 20)) ? 2 : 1;
   RnnDev d;
   int rcd = make_rnn_dev(k, &d);
   if (rcd) return rcd;

@@ -10,7 +10,7 @@ enum : unsigned {
   RF_BIASX = 1u << 0, RF_BIASH = 1u << 1, RF_PRE = 1u << 2, RF_PREIDX = 1u << 3, RF_FRAME = 1u << 4,
   RF_XRES = 1u << 5, RF_SKIP = 1u << 6, RF_MASK = 1u << 7, RF_DROP = 1u << 8, RF_SEQ = 1u << 9,
   RF_XOUT = 1u << 10, RF_AFFINE = 1u << 11, RF_GUMBEL = 1u << 12, RF_ZERO = 1u << 13, RF_MULTISEG = 1u << 14,
-  RF_HPRE = 1u << 15, RF_ARRIVE = 1u << 20, RF_FOLDTAB = 1u << 21,
+  RF_HPRE = 1u << 15, RF_FOLDTAB = 1u << 21,
   RF_ACT_SHIFT = 16,  // 2 bits
   RF_GENERIC = 1u << 31
 };
@@ -33,7 +33,6 @@ static inline unsigned rnn_features(int epi, const RnnK& k) {
   if (k.zero_slot) f |= RF_ZERO;
   if (k.nseg > 1) f |= RF_MULTISEG;
   if (k.h_pre) f |= RF_HPRE;
-  if (k.arrive) f |= RF_ARRIVE;
   if (k.fr_desc) f |= RF_FOLDTAB;
   if (epi == EPI_LINEAR) f |= (unsigned)(k.act & 3) << RF_ACT_SHIFT;
   return f;
@@ -77,7 +76,6 @@ __device__ __forceinline__ void rnn_rowtile_body(const RnnDev& d, const int bx, 
   const bool f_gum = RHAS(RF_GUMBEL, a.gum_slot != nullptr), f_zero = RHAS(RF_ZERO, a.zero_slot != nullptr);
   const bool f_mseg = RHAS(RF_MULTISEG, a.nseg > 1);
   const bool f_hpre = RHAS(RF_HPRE, a.h_pre != nullptr);
-  const bool f_arrive = RHAS(RF_ARRIVE, a.arrive != nullptr);
   const bool f_ftab = RHAS(RF_FOLDTAB, a.fr_desc != nullptr);
   const int act = (F & RF_GENERIC) ? a.act : (int)((F >> RF_ACT_SHIFT) & 3);
 
@@ -354,14 +352,7 @@ __device__ __forceinline__ void rnn_rowtile_body(const RnnDev& d, const int bx, 
       pk = o1 > pk ? o1 : pk;
       const unsigned long long o2 = __shfl_xor(pk, 32, 64);
       pk = o2 > pk ? o2 : pk;
-      if (f_arrive) {
-        // the returned value proves the atomic was performed at the device coherence point; only then
-        // does this workgroup count as arrived (relaxed agent-scope add, nothing else to publish)
-        unsigned int lo = 0;
-        if (du == 0) lo = (unsigned int)atomicMax(a.gum_slot + n, pk);
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(lo) : : "memory");
-        if (lane == 0) __hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else if (du == 0) atomicMax(a.gum_slot + n, pk);
+      if (du == 0) atomicMax(a.gum_slot + n, pk);
     }
     MB_MARK(a.trace, 6, 0);
     trace_end(a.trace);
@@ -406,7 +397,7 @@ __device__ __forceinline__ void rnn_rowtile_body(const RnnDev& d, const int bx, 
 // fill the flat-segment argument block; returns MB_EINVAL if the segments do not cover nkb_total
 static inline int make_rnn_dev(const RnnK& k, RnnDev* d) {
   d->k = k;
-  if (const char* e = getenv("MBHIP_TS3_DBG")) d->k.dbg = atoi(e);  // diagnostics of rnn_ts3_body.h (wrong results on purpose)
+  d->k.dbg = diag_int("ts3_dbg", d->k.dbg);  // diagnostics of rnn_ts3_body.h (wrong results on purpose)
   int start = 0;
   for (int t = 0; t < 4; ++t) {
     if (t < k.nseg) {

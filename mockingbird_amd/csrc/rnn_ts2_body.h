@@ -40,7 +40,7 @@ constexpr int TS2_WAVES = 4;  // waves per workgroup, stacked along the rows
 template <int EPI, unsigned F, int MT, int NT>
 __device__ __forceinline__ void rnn_ts2_body(const RnnDev& d, const int bx, const int by) {
   static_assert(!(F & RF_GENERIC), "ts2: specialised instances only");
-  static_assert(!(F & (RF_AFFINE | RF_MASK | RF_DROP | RF_SEQ | RF_SKIP | RF_PREIDX | RF_ARRIVE | RF_MULTISEG | RF_BIASH)),
+  static_assert(!(F & (RF_AFFINE | RF_MASK | RF_DROP | RF_SEQ | RF_SKIP | RF_PREIDX | RF_MULTISEG | RF_BIASH)),
                 "ts2: feature not wired");
   static_assert(EPI != EPI_GRU || (F & RF_HPRE), "ts2: GRU instances take the hidden half precomputed");
   static_assert(EPI != EPI_LSTM, "ts2: no LSTM instance");

@@ -14,7 +14,7 @@
 //   acc += wl.xh + wh.xl + wh.xh   in fp32, y = acc 2^-s: 18 MFMAs of 16 cycles per k-step and wave (2 x 3 tiles) against 48 of 32.
 // Results are fp32-grade (21-22 bits per operand), NOT bit-identical to the fp32 forms any more: a column's sums still do not
 // depend on the batch it is in (same order for every column), and the batch loop is held to the oracle with the exported noise
-// (tests/test_wavernn_gpu.py::test_production_batch*).  MBHIP_RNN_TS3=0 selects rnn_ts2_body.
+// (tests/test_wavernn_gpu.py::test_production_batch*).  MBHIP_RNN_WIDE=ts2 selects rnn_ts2_body.
 #pragma once
 #include "rnn_ts2_body.h"
 
@@ -30,7 +30,7 @@ template <int NT> constexpr size_t ts3_lds_bytes() { return (size_t)2 * 2 * NT *
 template <int EPI, unsigned F, int MT, int NT>
 __device__ __forceinline__ void rnn_ts3_body(const RnnDev& d, const int bx, const int by, t3h* lds) {
   static_assert(!(F & RF_GENERIC), "ts3: specialised instances only");
-  static_assert(!(F & (RF_AFFINE | RF_MASK | RF_DROP | RF_SEQ | RF_SKIP | RF_PREIDX | RF_ARRIVE | RF_MULTISEG | RF_BIASH)),
+  static_assert(!(F & (RF_AFFINE | RF_MASK | RF_DROP | RF_SEQ | RF_SKIP | RF_PREIDX | RF_MULTISEG | RF_BIASH)),
                 "ts3: feature not wired");
   static_assert(EPI != EPI_GRU || (F & RF_HPRE), "ts3: GRU instances take the hidden half precomputed");
   static_assert(EPI != EPI_LSTM, "ts3: no LSTM instance");

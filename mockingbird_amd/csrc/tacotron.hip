@@ -706,9 +706,10 @@ int cbhg_forward(const Cbhg& c, const float* x, int B, int F, const CbhgWs& L, h
         k.wscale[d] = std::ldexp(1.f, c.gru_sexp[d]);
         k.unscale[d] = std::ldexp(1.f, -c.gru_sexp[d] - 10);
       }
-      if (const char* de = getenv("MBHIP_GS_DBG")) k.dbg = atoi(de);
+      k.dbg = diag_int("gs_dbg", 0);
       MB_HIP(hipMemsetAsync(L.gsx, 0, GSX_WORDS * sizeof(unsigned long long), s));
-      if (getenv("MBHIP_GRU_SCAN_TEST_ABORT")) {  // tests: the fallback path
+      const bool test_abort = diag_int("abort_gru_scan") != 0;  // tests (MBHIP_DIAG=abort_gru_scan): the fallback path
+      if (test_abort) {
         const int one = 1;
         MB_HIP(hipMemcpyAsync(k.abort_word, &one, sizeof(int), hipMemcpyHostToDevice, s));
       }
@@ -723,7 +724,7 @@ int cbhg_forward(const Cbhg& c, const float* x, int B, int F, const CbhgWs& L, h
         MB_HIP(hipStreamSynchronize(s));
       }
       scanned = !lrc && !aborted;
-      if (!scanned && !getenv("MBHIP_GRU_SCAN_TEST_ABORT")) gru_scan_mark_failed();
+      if (!scanned && !test_abort) gru_scan_mark_failed();
     }
   }
   if (!rc && !scanned) {
@@ -895,7 +896,7 @@ struct mb_taco {
   hipGraphExec_t graph_exec = nullptr;
   int* h_flags = nullptr;  // pinned: [2][8] flag snapshots
   hipEvent_t ev_flags[2] = {nullptr, nullptr};
-  unsigned long long* d_trace = nullptr;  // MBHIP_TACO_TRACE
+  unsigned long long* d_trace = nullptr;  // MBHIP_DIAG=taco_trace=<file>
   hipStream_t loop_stream = nullptr;  // the loop runs (and is captured) on its own stream: the caller's may be the
   hipEvent_t ev_in = nullptr;         // legacy default stream, which cannot be captured
   void drop_graph() {
@@ -1333,7 +1334,8 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
   dk.thresh = drop_enabled ? (unsigned)std::min(4294967295.0, (double)c.dropout * 4294967296.0) : 0u;
   dk.scale = drop_enabled ? 1.f / (1.f - c.dropout) : 1.f; dk.enabled = drop_enabled ? 1 : 0;
   int* flags = L.flags;
-  const char* trace_path = getenv("MBHIP_TACO_TRACE");
+  std::string trace_file;  // diagnostics (MBHIP_DIAG=taco_trace=<file>)
+  const char* trace_path = diag_str("taco_trace", &trace_file) ? trace_file.c_str() : nullptr;
   if (trace_path && !t->d_trace) MB_HIP(hipMalloc((void**)&t->d_trace, sizeof(unsigned long long) * 16 * TS_SLOTS));
   unsigned long long* tr = trace_path ? t->d_trace : nullptr;
   if (tr) MB_HIP(hipMemsetAsync(tr, 0, sizeof(unsigned long long) * 16 * TS_SLOTS, s));
@@ -1358,7 +1360,7 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
   MB_HIP(hipGetLastError());
 
   int hh1_split = H / 8;  // row tiles of W_hh1 . h1 taken by the mel launch (the rest: next rnn_input launch)
-  // (MBHIP_TACO_HH1_SPLIT sweep, round 2: flat between 128 and 224 rows -- the switch is gone, the value stays)
+  // (an hh1-split sweep, round 2: flat between 128 and 224 rows -- the switch is gone, the value stays)
   auto iteration = [&](int pp, int it_off) -> int {
     // (the LSTM state needs no ping-pong: h is read only by the hh jobs, which have finished before the next LSTM launch)
     const dim3 blk(512);
@@ -1442,7 +1444,7 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
 
   MB_HIP(hipEventRecord(t->ev_t0, s));
   int G = 16;  // iterations per graph replay (even: the LSTM state / cumulative-attention parity returns to 0)
-  if (const char* ge = getenv("MBHIP_TACO_GRAPH_ITERS")) G = atoi(ge) & ~1;
+  if (const char* ge = getenv("MBHIP_GRAPH_STEPS")) G = atoi(ge) & ~1;  // (steps of this loop = decoder iterations)
   const bool use_graph = getenv("MBHIP_NO_GRAPH") == nullptr && G >= 2 && n_iter_max >= G;
   int it_done = 0, rc = MB_OK;
   bool stopped = false;

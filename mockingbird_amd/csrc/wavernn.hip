@@ -309,32 +309,37 @@ static std::atomic<bool> g_resident_failed[64] = {};  // written by whichever ho
 //   have_q16     the fp16 hi / lo weight images of wavernn_pipe16.h exist (K = 512 models)
 //   resident_cus co-resident 512-thread workgroups the device offers (its CU count if the kernels fit one per unit, else 0)
 //   dev_failed   a resident launch lost a hand-off on this device before
-//   env_*        MBHIP_WAVERNN_PIPE / MBHIP_WAVERNN_PERSIST / MBHIP_WQ16: -1 unset, else the value
+//   resident     MBHIP_WAVERNN_RESIDENT: -1 unset (auto), 0 = no resident launch, 1 = resident launch wherever legal (also on a device
+//                that failed before), 2 ("exact") = like 1 with the exact fp32 kernel (wavernn_pipe.h) instead of wavernn_pipe16.h
 // | columns | RAW                                   | MOL                         |
-// | 1       | wf_persist1_kernel (PERSIST != 0)     | launch chain                |
-// | 2..32   | wf_pipe16_kernel; WQ16=0: wf_pipe     | wf_pipe_kernel              |
-// | 33..64  | wf_pipe16_kernel; WQ16=0: chain       | launch chain                |
+// | 1       | wf_persist1_kernel                    | launch chain                |
+// | 2..32   | wf_pipe16_kernel; exact: wf_pipe      | wf_pipe_kernel              |
+// | 33..64  | wf_pipe16_kernel; exact: chain        | launch chain                |
 // | > 64    | launch chain (mb_wavernn_generate_batch's wide GEMMs serve several utterances)   |
-// and the launch chain whenever production == 0, the device offers fewer units than the kernel has workgroups (224 / 192), PIPE / PERSIST
-// = 0, or the device failed before and no switch asks explicitly.
-int wavernn_pick_path(int columns, int mode, int production, int have_q16, int resident_cus, int dev_failed, int env_pipe, int env_persist,
-                      int env_q16) {
-  if (!production || columns < 1) return MB_WRN_PATH_CHAIN;
-  const bool q16 = mode == 0 && have_q16 && env_q16 != 0;
+// and the launch chain whenever production == 0, the device offers fewer units than the kernel has workgroups (224 / 192), resident
+// = 0, or the device failed before and the switch does not ask explicitly.
+int wavernn_pick_path(int columns, int mode, int production, int have_q16, int resident_cus, int dev_failed, int resident) {
+  if (!production || columns < 1 || resident == 0) return MB_WRN_PATH_CHAIN;
+  if (dev_failed && resident < 0) return MB_WRN_PATH_CHAIN;
+  const bool q16 = mode == 0 && have_q16 && resident != 2;
   if (columns >= 2) {
-    if (columns > (q16 ? WQ_GMAX : WQ_G) * WQ_GC || env_pipe == 0) return MB_WRN_PATH_CHAIN;
-    if (dev_failed && env_pipe < 0) return MB_WRN_PATH_CHAIN;
+    if (columns > (q16 ? WQ_GMAX : WQ_G) * WQ_GC) return MB_WRN_PATH_CHAIN;
     if (resident_cus < WQ_WGS) return MB_WRN_PATH_CHAIN;
     return q16 ? MB_WRN_PATH_PIPE16 : MB_WRN_PATH_PIPE;
   }
-  if (mode != 0 || env_persist == 0) return MB_WRN_PATH_CHAIN;  // one column: the fmaf-chain kernel (RAW only)
-  if (dev_failed && env_persist < 0) return MB_WRN_PATH_CHAIN;
+  if (mode != 0) return MB_WRN_PATH_CHAIN;  // one column: the fmaf-chain kernel (RAW only)
   if (resident_cus < WP_ON + WP_OFF) return MB_WRN_PATH_CHAIN;
   return MB_WRN_PATH_PERSIST1;
 }
-extern "C" int mb_wavernn_loop_path(int columns, int mode, int production, int have_q16, int resident_cus, int dev_failed, int env_pipe,
-                                    int env_persist, int env_q16) {
-  return wavernn_pick_path(columns, mode, production, have_q16, resident_cus, dev_failed, env_pipe, env_persist, env_q16);
+extern "C" int mb_wavernn_loop_path(int columns, int mode, int production, int have_q16, int resident_cus, int dev_failed, int resident) {
+  return wavernn_pick_path(columns, mode, production, have_q16, resident_cus, dev_failed, resident);
+}
+// MBHIP_WAVERNN_RESIDENT as wavernn_pick_path's `resident`
+static int wavernn_resident_env() {
+  const char* e = getenv("MBHIP_WAVERNN_RESIDENT");
+  if (!e || strcmp(e, "auto") == 0) return -1;
+  if (strcmp(e, "exact") == 0) return 2;
+  return atoi(e) != 0 ? 1 : 0;
 }
 
 static int wavernn_shapes(const mb_wavernn_config* c, std::vector<size_t>* numel) {
@@ -634,12 +639,25 @@ struct WrnLayout {
 inline long long floordiv(long long a, long long b) { long long q = a / b; if ((a % b != 0) && ((a < 0) != (b < 0))) --q; return q; }
 }  // namespace
 
-// MBHIP_WAVERNN_CHAIN=classic keeps the 5-launch chain with both GRU halves on the dependent path
-// (no T1 table: 6 KB less workspace per conditioning position)
-static bool wavernn_split_chain() {
+// MBHIP_WAVERNN_CHAIN selects the launch chain behind (or instead of) the resident kernels -- a comma list of
+//   fast     (default) the split-hidden chain on fragment-major activations (wavernn_fast.h)
+//   split    the split-hidden chain on the rnn_rowtile_body instances (round 1)
+//   classic  the 5-launch chain with both GRU halves on the dependent path (no T1 table: 6 KB less workspace per conditioning position)
+//   nofuse   stand-alone sampler launch (6 launches per step) under any of them
+// The exact / teacher-forced / logits-dump test paths build on split / classic + nofuse whatever the variable says.
+static bool wavernn_chain_has(const char* word) {
   const char* e = getenv("MBHIP_WAVERNN_CHAIN");
-  return !(e && strcmp(e, "classic") == 0);
+  if (!e) return false;
+  const size_t wl = strlen(word);
+  for (const char* p = e; *p;) {
+    const char* end = strchr(p, ',');
+    const size_t len = end ? (size_t)(end - p) : strlen(p);
+    if (len == wl && strncmp(p, word, wl) == 0) return true;
+    p += len + (end ? 1 : 0);
+  }
+  return false;
 }
+static bool wavernn_split_chain() { return !wavernn_chain_has("classic"); }
 
 static void wavernn_layout(const mb_wavernn* w, const mb_wavernn_plan* p, void* base, WrnLayout* L) {
   const mb_wavernn_config& c = w->cfg;
@@ -774,27 +792,17 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
   // fc3 launch and the next step's input is rebuilt from the argmax word -> 5 launches per step.
   // MOL mode: the fused form exists on the fragment-major chain only (wf_fc3_mol_kernel: fc3 + the mixture sampler in one launch,
   // the sample itself in the slot word); every other configuration of a MOL model keeps the exact 6-launch chain.
-  const bool mol_fast = c.mode == 1 && R == 512 && FC == 512 && C <= 32 && N <= 64 && wavernn_split_chain() &&
-                        !(getenv("MBHIP_WAVERNN_FAST") && atoi(getenv("MBHIP_WAVERNN_FAST")) == 0) &&
-                        !(getenv("MBHIP_WAVERNN_LANES") && atoi(getenv("MBHIP_WAVERNN_LANES")) > 1) && !getenv("MBHIP_WAVERNN_MERGE") &&
-                        !getenv("MBHIP_WAVERNN_NT2");
-  const bool fused = !d_noise && !d_forced && !d_logits_out && getenv("MBHIP_WAVERNN_NOFUSE") == nullptr && (c.mode == 0 || mol_fast);
+  const bool fast_ok = wavernn_split_chain() && !wavernn_chain_has("split");
+  const bool mol_fast = c.mode == 1 && R == 512 && FC == 512 && C <= 32 && N <= 64 && fast_ok;
+  const bool fused = !d_noise && !d_forced && !d_logits_out && !wavernn_chain_has("nofuse") && (c.mode == 0 || mol_fast);
   const bool split = fused && wavernn_split_chain();
-  // MBHIP_WAVERNN_MERGE=1 (experiment, off): fc3 + the next step's elementwise rnn1 in ONE launch (4 per
-  // step) through an in-launch arrival counter.  Measured on MI355X (profiles/r01_wavernn_chain_ab.json):
-  // 26.4 us/step against 25.7 with the kernel boundary -- the 64-arrival fan-in + poll + fresh slot
-  // read costs more than the 1.7 us boundary it removes, so the boundary stays.
-  const bool merged = split && getenv("MBHIP_WAVERNN_MERGE") && atoi(getenv("MBHIP_WAVERNN_MERGE")) == 1;
   // Production shape (rnn 512 / fc 512, <= 64 fold columns): the same chain on fragment-major activations
-  // (wavernn_fast.h), bit-identical sample stream.  MBHIP_WAVERNN_FAST=0 keeps the rnn_rowtile_body instances.
-  const char* fenv = getenv("MBHIP_WAVERNN_FAST");
-  const char* lenv = getenv("MBHIP_WAVERNN_LANES");
-  const bool fastk = split && !merged && R == 512 && FC == 512 && (C % 16 == 0 || c.mode == 1) && N <= 64 && !(fenv && atoi(fenv) == 0) &&
-                     !(lenv && atoi(lenv) > 1) && getenv("MBHIP_WAVERNN_NT2") == nullptr;
+  // (wavernn_fast.h), bit-identical sample stream.  MBHIP_WAVERNN_CHAIN=split keeps the rnn_rowtile_body instances.
+  // (fc3 + the next step's rnn1 in one launch, two column tiles per row-tile workgroup and several stream "lanes" of columns were
+  //  measured in round 1 -- 26.4 / 29.1 against 25.7 / 26.0 us per step, lanes do not overlap -- and left the library in round 4.)
+  const bool fastk = split && R == 512 && FC == 512 && (C % 16 == 0 || c.mode == 1) && N <= 64 && fast_ok;
   const int nta = cdiv(N, 16);
-  int fnt = 2;  // fold-column tiles per workgroup of the fast chain
-  if (const char* te = getenv("MBHIP_WAVERNN_FAST_NT")) fnt = atoi(te) == 1 ? 1 : 2;
-  if (nta < 2) fnt = 1;
+  const int fnt = nta < 2 ? 1 : 2;  // fold-column tiles per workgroup of the fast chain
   // ---- per-frame tables of the aux columns (time-major) + the zero-conditioning row = bias ----
   RC(run_cond_conv(w->t_g2, L.aux + (size_t)1 * A * F, F, L.G2, nullptr, 0, 1, s));
   RC(run_cond_conv(w->t_f1, L.aux + (size_t)2 * A * F, F, L.F1, nullptr, 0, 1, s));
@@ -828,18 +836,18 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
   };
   // Resident forms of the loop: ONE launch for the whole utterance, every weight tile in LDS, granule hand-offs between
   // the layers, same sample stream as the chain.
-  //   * wf_pipe16_kernel (wavernn_pipe16.h, RAW models) / wf_pipe_kernel (wavernn_pipe.h, MOL models and MBHIP_WQ16=0), 2..64 / 2..32 fold
-  //     columns: role-specialised workgroups, column groups in flight.  MBHIP_WAVERNN_PIPE=0 keeps the chain.
-  //   * wf_persist1_kernel (wavernn_persist.h): one column (batched=False), MBHIP_WAVERNN_PERSIST=0 keeps the chain.
+  //   * wf_pipe16_kernel (wavernn_pipe16.h, RAW models) / wf_pipe_kernel (wavernn_pipe.h, MOL models and MBHIP_WAVERNN_RESIDENT=exact), 2..64 / 2..32 fold
+  //     columns: role-specialised workgroups, column groups in flight.
+  //   * wf_persist1_kernel (wavernn_persist.h): one column (batched=False).  MBHIP_WAVERNN_RESIDENT=0 keeps the chain for both.
   //   The choice is wavernn_pick_path's table (above).
   // Both need their workgroups co-resident, one per compute unit: checked here against the device (CU count, occupancy
   // of the kernel, a per-device "it failed before" flag); a launch that still loses a hand-off (another process holds
   // compute units) times out after 0.2 s, raises its abort word and the chain below computes the same samples.
   // NOTE: a resident launch makes this call host-blocking (the abort word has to be looked at before returning).
-  const char* penv = getenv("MBHIP_WAVERNN_PERSIST");
-  const char* qenv = getenv("MBHIP_WAVERNN_PIPE");
-  const char* e16 = getenv("MBHIP_WQ16");
-  const bool resident_ok = fastk && C <= 512 && !w->bench_which && !w->bench_chain && !getenv("MBHIP_TRACE_FILE") && !getenv("MBHIP_WF_DBG_WHICH");
+  std::string trace_file;  // diagnostics (MBHIP_DIAG=trace_file=<path>, wf_which=<bits>): the chain, launch by launch
+  const char* trace_path = diag_str("trace_file", &trace_file) ? trace_file.c_str() : nullptr;
+  const int dbg_which = diag_int("wf_which", -1);
+  const bool resident_ok = fastk && C <= 512 && !w->bench_which && !w->bench_chain && !trace_path && dbg_which < 0;
   int path = MB_WRN_PATH_CHAIN;
   if (resident_ok && !rc) {
     int dev = 0;
@@ -858,8 +866,7 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
       if (!w->h_abort) MB_HIP(hipHostMalloc((void**)&w->h_abort, sizeof(int), hipHostMallocDefault));
     }
     const bool dev_failed = dev >= 0 && dev < 64 && g_resident_failed[dev];
-    path = wavernn_pick_path(N, c.mode, 1, w->q_fc3.p && w->q_hh1.p ? 1 : 0, w->resident_cus, dev_failed ? 1 : 0, qenv ? atoi(qenv) : -1,
-                             penv ? atoi(penv) : -1, e16 ? atoi(e16) : -1);
+    path = wavernn_pick_path(N, c.mode, 1, w->q_fc3.p && w->q_hh1.p ? 1 : 0, w->resident_cus, dev_failed ? 1 : 0, wavernn_resident_env());
   }
   const bool pipe = path == MB_WRN_PATH_PIPE || path == MB_WRN_PATH_PIPE16, persist = path == MB_WRN_PATH_PERSIST1;
   const bool q16 = path == MB_WRN_PATH_PIPE16;
@@ -867,9 +874,10 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
     const size_t ex_bytes = pipe ? wq_exchange_bytes() : wp_exchange_bytes();
     int* abort_word = reinterpret_cast<int*>(L.px + (pipe ? (size_t)WQ_GMAX * 2 * WQX_PER : (size_t)2 * WPX_PER_PARITY));
     MB_HIP(hipMemsetAsync(L.px, 0, ex_bytes, s));
-    if (getenv("MBHIP_WP_TEST_ABORT"))  // tests only: the launch finds its abort word raised, the chain takes over
-      MB_HIP(hipMemsetAsync(abort_word, 1, 1, s));
-    const char* wtrace = getenv("MBHIP_WP_TRACE");  // diagnostics: dump the wall-clock marks of the kernel to this file
+    const bool test_abort = diag_int("abort_wp") != 0;  // tests only (MBHIP_DIAG=abort_wp): the launch finds its abort word raised, the chain takes over
+    if (test_abort) MB_HIP(hipMemsetAsync(abort_word, 1, 1, s));
+    std::string wtrace_file;  // diagnostics (MBHIP_DIAG=wp_trace=<file>): dump the wall-clock marks of the kernel to this file
+    const char* wtrace = diag_str("wp_trace", &wtrace_file) ? wtrace_file.c_str() : nullptr;
     unsigned long long* trace = wtrace ? reinterpret_cast<unsigned long long*>(abort_word) + 32 : nullptr;
     MB_HIP(hipEventRecord(w->ev_t0, s));
     if (pipe) {
@@ -891,7 +899,7 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
         for (int g = 0; g <= WQ_GMAX; ++g) qk.gn0[g] = g >= ng ? N : (int)((long long)N * g / ng + ((long long)N * g % ng ? 1 : 0));  // ceil(N g / ng)
         if (ng == 2) qk.gn0[1] = (N + 1) / 2;
       }
-      qk.flags = getenv("MBHIP_WQ_FLAGS") ? atoi(getenv("MBHIP_WQ_FLAGS")) : 17;  // A/B switches of wavernn_pipe.h (1 = padded rows, 16 = weights in registers)
+      qk.flags = diag_int("wq_flags", 17);  // A/B switches of wavernn_pipe.h (1 = padded rows, 16 = weights in registers)
       qk.trace = trace;
       if (q16) {
         Wq16K k16;
@@ -938,7 +946,7 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
       warned = true;
     }
     int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !getenv("MBHIP_WP_TEST_ABORT")) g_resident_failed[dev] = true;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !diag_int("abort_wp")) g_resident_failed[dev] = true;
   }
   if (fastk && !rc) {  // zero state; P = W_hh.0 + b_hh for the first step by the loop's own hidden-half jobs
     MB_HIP(hipMemsetAsync(L.f_x1, 0, L.f_bytes, s));
@@ -963,12 +971,10 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
   }
   if (rc) return rc;
 
-  // ---- lanes: contiguous fold ranges, one stream each ----
-  // Measured on MI355X (profiles/r01_wavernn_lane_sweep.json): extra lanes do NOT overlap -- kernel
-  // submission serialises on the host/CP at ~3-4 us per launch -- so the default is one lane.
-  int lanes = 1;
-  if (const char* le = getenv("MBHIP_WAVERNN_LANES")) { if (atoi(le) >= 1) lanes = atoi(le); }
-  lanes = std::max(1, std::min(std::min(lanes, (int)mb_wavernn::MAX_LANES), N));
+  // ---- one lane = one stream for all fold columns.  (Several lanes of contiguous fold ranges were measured in round 1,
+  // profiles/r01_wavernn_lane_sweep.json: they do NOT overlap -- kernel submission serialises on the host / CP at ~3-4 us per
+  // launch; the switch is gone, the loops below keep the lane index.) ----
+  const int lanes = 1;
   int lane_n0[mb_wavernn::MAX_LANES + 1];
   for (int l = 0; l <= lanes; ++l) lane_n0[l] = (int)((long long)N * l / lanes);
   MB_HIP(hipEventRecord(w->ev_cond, s));  // conditioning tables + zeroed state are ready
@@ -1004,7 +1010,7 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
     if (fastk) {  // wavernn_fast.h: A | B | C | D | E on FM activations (one lane: n0 = 0, nl = N)
       // diagnostics only (tools/pmc_wavernn_r02.sh): run just the launches whose bit is set -- rocprofv3 counter mode
       // cannot survive the interleaved chain, one launch type at a time it can.  Results are garbage.
-      if (const char* dbg = getenv("MBHIP_WF_DBG_WHICH")) which &= atoi(dbg);
+      if (dbg_which >= 0) which &= dbg_which;
       if (which & 1) {
         WfFinK f;
         f.g = wg; f.g.step_off = soff; f.slot = slot_prev; f.P1 = reinterpret_cast<const float4*>(L.f_P1);
@@ -1042,8 +1048,6 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
     if (split) {
       float* P1 = L.P1 + (size_t)n0 * 3 * R; float* P2 = L.P2 + (size_t)n0 * 3 * R;
       // (A) rnn1, elementwise: every product is precomputed (T1 table, P1 from the previous step).
-      //     merged: A of step s+1 rides in the fc3 launch of step s (below); A of step 0 is launched
-      //     once before the loop.
       auto fin = [&](int parity, int off) {
         Fin1K f;
         memset(&f, 0, sizeof(f));
@@ -1055,8 +1059,7 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
         f.fold_stride = plan->fold_stride; f.total_len = T;
         return f;
       };
-      if (which == 0x100) return rnn_launch_finish(fin(pp, soff), ls);  // prologue: A of the first step only
-      if ((which & 1) && !merged) {
+      if (which & 1) {
         Fin1K f = fin(pp, soff);
         f.trace = tr ? tr + 0 : nullptr;
         if ((r = rnn_launch_finish(f, ls))) return r;
@@ -1092,13 +1095,7 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
       frame_rows(k);
       k.gum_slot = slot_cur; k.gum_seed = seed;
       k.trace = tr ? tr + 8 * TRACE_SLOTS : nullptr;
-      if (merged && (which & 1)) {  // + A of step s+1 in the same launch
-        Fin1K f = fin(pp ^ 1, soff + 1);
-        k.arrive = reinterpret_cast<unsigned int*>(L.step + 8 + l);
-        f.arrive = k.arrive;
-        f.arrive_per_step = (unsigned)(cdiv(C, 16) * cdiv(nl, 16));
-        if ((which & 16) && (r = rnn_launch_fc3_finish(k, f, ls))) return r;
-      } else if ((which & 16) && (r = rnn_launch(EPI_LINEAR, k, ls))) return r;
+      if ((which & 16) && (r = rnn_launch(EPI_LINEAR, k, ls))) return r;
       return MB_OK;
     }
     memset(&k, 0, sizeof(k));
@@ -1167,13 +1164,8 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
     MB_HIP(hipGetLastError());
   }
 
-  if (merged)
-    for (int l = 0; l < lanes && !rc; ++l) rc = step(l, 0, 0, 0x100);
-  if (rc) return rc;
-
-  // diagnostics: MBHIP_TRACE_FILE=<path> records per-kernel first-wave-start / last-store-end device
+  // diagnostics: MBHIP_DIAG=trace_file=<path> records per-kernel first-wave-start / last-store-end device
   // timestamps (wall_clock64, 100 MHz) of the LAST graph replay and dumps them after a sync.
-  const char* trace_path = getenv("MBHIP_TRACE_FILE");
   unsigned long long* d_trace = nullptr;
   int trace_steps = 0;
   MB_HIP(hipEventRecord(w->ev_t0, s));
@@ -1239,7 +1231,7 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
     (void)hipFree(d_trace);
     if (FILE* f = fopen(trace_path, "wb")) { fwrite(host.data(), sizeof(unsigned long long), host.size(), f); fclose(f); }
   }
-  w->last_launches = (merged ? 4 : fused ? 5 : 6) * S * lanes;
+  w->last_launches = (fused ? 5 : 6) * S * lanes;
   w->last_lanes = lanes;
   w->timed = true;
   MB_HIP(hipEventRecord(w->ev_out, s));

@@ -50,7 +50,7 @@ struct WpK {
   unsigned long long* ex; int* abort_word;
   float* samples; volatile int* progress;
   unsigned long long seed; int R, FC, C, S, N;
-  unsigned long long* trace;  // diagnostics (MBHIP_WP_TRACE): wall-clock marks of workgroups 0 and 32, steps 1000..1003
+  unsigned long long* trace;  // diagnostics (MBHIP_DIAG=wp_trace=<file>): wall-clock marks of workgroups 0 and 32, steps 1000..1003
 };
 
 // spin until the NQ granules p[q * stride] all carry `tag`; false = aborted

@@ -39,7 +39,7 @@ constexpr int WQ_WGS = WQ_R1 + WQ_R2 + 3 * WQ_F;  // 224 resident workgroups, on
 constexpr int WQ_G = 2;                           // column groups in flight (this kernel: 2..32 columns)
 constexpr int WQ_GMAX = 4;                        // wavernn_pipe16.h serves up to four groups (33..64 columns: an utterance beyond ~1400 frames)
 constexpr int WQ_GC = 16;                         // columns per group (one MFMA column tile)
-constexpr int WQ_DEFAULT_ON = 1;                  // default for 2..32 columns (MBHIP_WAVERNN_PIPE overrides)
+constexpr int WQ_DEFAULT_ON = 1;                  // default for 2..32 columns (MBHIP_WAVERNN_RESIDENT overrides)
 
 // exchange area per (group, parity), in granules
 enum { WQX_X1 = 0, WQX_X2 = 8192, WQX_H1 = 16384, WQX_H2 = 24576, WQX_Y1 = 32768, WQX_Y2 = 40960, WQX_KEY = 49152, WQX_PER = 50176 };
@@ -56,9 +56,9 @@ struct WqK {
   int gn0[WQ_GMAX + 1];       // group g owns fold columns [gn0[g], gn0[g + 1]); wf_pipe_kernel looks at the first WQ_G groups only
   int mol, nr_mix;            // MOL mode (fatchord_version.py:213-220): fc3 has 3 nr_mix rows, F3 is ONE workgroup that samples the
                               // mixture of logistics itself (wf_fc3_mol_kernel's draws) and hands the SAMPLE to R1
-  int flags;                  // A/B switches (MBHIP_WQ_FLAGS, default 17): 1 = exchange rows padded to 16 columns, 2 = R2's residual x1 by a global load,
+  int flags;                  // A/B switches (MBHIP_DIAG=wq_flags=<bits>, default 17): 1 = exchange rows padded to 16 columns, 2 = R2's residual x1 by a global load,
                               // 16 = weight fragments held in registers for the whole utterance (LDS reads per product otherwise: +0.3 us per step)
-  unsigned long long* trace;  // diagnostics (MBHIP_WP_TRACE): wall-clock marks of one workgroup per role, steps 1000..1003
+  unsigned long long* trace;  // diagnostics (MBHIP_DIAG=wp_trace=<file>): wall-clock marks of one workgroup per role, steps 1000..1003
 };
 
 // wp_gather with the row stride LD apart from the live column count N

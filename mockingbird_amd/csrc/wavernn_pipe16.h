@@ -6,7 +6,7 @@
 // workgroup pulls 512 features x 16 columns x 8-byte granules = 64 KB through its compute unit's 64 B/clk path to the L2
 // (1.1 us until the first wave has its fragments, 1.4 us until the slowest), five times per step; and a stage is 0.43-0.85 us
 // of v_mfma_f32_16x16x4_f32 (one tile per unit at the 1/16-rate fp32 pipe).  Levers that do not touch those two were measured
-// and lost (MBHIP_WQ_FLAGS sweep of the same session: whole-line stores +0.0, 16-byte sweep loads +1.7, two / four staggered
+// and lost (wq_flags sweep of the same session: whole-line stores +0.0, 16-byte sweep loads +1.7, two / four staggered
 // polls of the watching lane +0.5 / +0.7, keys read by the finish lanes +3.4 us per step; weight fragments in registers -0.3).
 // So this kernel halves the bytes of every sweep and takes the products off the fp32 pipe:
 //   * a value crosses workgroups as fp16 hi + fp16 lo (x = xh + xl: 21 of its 24 significant bits; below |x| = 0.125 the low half is
@@ -20,7 +20,7 @@
 //     instead of 16 of 32.
 // The sample stream is therefore NOT bit-identical to the launch chain's / wf_pipe_kernel's any more (VERDICT r03 item 3 allows
 // that); it is held to the oracle itself: tests/test_wavernn_gpu.py::test_production_* replay the reference loop body on the device's
-// own history with the exported noise.  MBHIP_WQ16=0 selects the exact kernel (wavernn_pipe.h, the A/B partner and the MOL path).
+// own history with the exported noise.  MBHIP_WAVERNN_RESIDENT=exact selects the exact kernel (wavernn_pipe.h, the A/B partner and the MOL path).
 // Roles, item order, deadlock argument, bail-outs: wavernn_pipe.h's, unchanged.  Column groups: two for 2..32 columns as there; THREE or
 // FOUR for 33..64 columns (fold_with_overlap has no limit, fatchord_version.py:288-338: an utterance beyond ~1400 mel frames used to
 // drop to the launch chain) -- a workgroup serves the groups in turn, the period stays the trip of ONE group while its items fit.

@@ -16,15 +16,15 @@ def wavernn(cuda, lib):
     return WaveRNNDevice(synth.wavernn_state(seed=5)["model_state"])
 
 
-@pytest.mark.parametrize("env", [{"MBHIP_WAVERNN_FAST": "0"}, {"MBHIP_WAVERNN_FAST_NT": "1"}, {"MBHIP_GRAPH_STEPS": "32"},
-                                 {"MBHIP_NO_GRAPH": "1"}, {"MBHIP_WAVERNN_LANES": "2"},
-                                 {"MBHIP_WAVERNN_FAST": "0", "MBHIP_WAVERNN_CHAIN": "classic"}],
+@pytest.mark.parametrize("env", [{"MBHIP_WAVERNN_CHAIN": "split"}, {"MBHIP_GRAPH_STEPS": "32"}, {"MBHIP_NO_GRAPH": "1"},
+                                 {"MBHIP_WAVERNN_CHAIN": "classic"}],
                          ids=lambda e: ",".join(f"{k[6:]}={v}" for k, v in e.items()))
 def test_wavernn_switches_keep_the_sample_stream(wavernn, monkeypatch, env):
-    """FM fast chain (default) == round-1 row-tile chain == classic chain, one or two column tiles per workgroup,
-    any graph length, eager launches, two lanes: the same Philox stream and bit-identical sums -> identical samples."""
+    """The launch chains behind the resident kernels (MBHIP_WAVERNN_RESIDENT=0): FM fast chain (default) == round-1 row-tile chain
+    == classic chain, any graph length, eager launches: the same Philox stream and bit-identical sums -> identical samples."""
     mel = torch.from_numpy(synth.wavernn_mel(45, seed=8) / 4.0).cuda()  # 3 folds of 4400: > 16 columns never; nta = 1
     mel2 = torch.from_numpy(synth.wavernn_mel(330, seed=9) / 4.0).cuda()  # 18 folds -> two column tiles
+    monkeypatch.setenv("MBHIP_WAVERNN_RESIDENT", "0")
     for k in list(env):
         monkeypatch.delenv(k, raising=False)
     base = [wavernn.generate_samples(mel, True, 4000, 200, seed=11), wavernn.generate_samples(mel2, True, 4000, 400, seed=12)]
@@ -57,7 +57,7 @@ def taco(cuda, lib):
     return dev, mem, memp, chars
 
 
-@pytest.mark.parametrize("env", [{"MBHIP_TACO_GRAPH_ITERS": "4"}, {"MBHIP_NO_GRAPH": "1"}],
+@pytest.mark.parametrize("env", [{"MBHIP_GRAPH_STEPS": "4"}, {"MBHIP_NO_GRAPH": "1"}],
                          ids=lambda e: ",".join(f"{k[6:]}={v}" for k, v in e.items()))
 def test_tacotron_fast_loop_switches_are_bit_identical(taco, monkeypatch, env):
     """How many iterations a graph holds, eager launches: the same kernels on the same operands."""
@@ -72,8 +72,8 @@ def test_tacotron_fast_loop_switches_are_bit_identical(taco, monkeypatch, env):
         assert a.shape == b.shape and torch.equal(a, b)
 
 
-@pytest.mark.parametrize("env,exact", [({"MBHIP_PPG_FAST": "0"}, False), ({"MBHIP_PPG_GRAPH_STEPS": "4"}, True),
-                                       ({"MBHIP_NO_GRAPH": "1"}, True)], ids=["PPG_FAST=0", "PPG_GRAPH_STEPS=4", "NO_GRAPH"])
+@pytest.mark.parametrize("env,exact", [({"MBHIP_PPG_FAST": "0"}, False), ({"MBHIP_GRAPH_STEPS": "4"}, True),
+                                       ({"MBHIP_NO_GRAPH": "1"}, True)], ids=["PPG_FAST=0", "GRAPH_STEPS=4", "NO_GRAPH"])
 @pytest.mark.parametrize("B", [1, 19])
 def test_ppg2mel_switches(cuda, lib, monkeypatch, env, exact, B):
     """The 6-launch FM step against the 8-launch general step (different summation orders: tolerance) and against
@@ -102,10 +102,10 @@ def test_wavernn_persistent_kernel_keeps_the_sample_stream(wavernn, monkeypatch)
     their vectors over through tagged granules, products as fmaf chains in the fp32 MFMA's own order -- against the 5-launch chain:
     the same samples, sample for sample."""
     mel = torch.from_numpy(synth.wavernn_mel(9, seed=13) / 4.0).cuda()
-    monkeypatch.setenv("MBHIP_WAVERNN_PERSIST", "0")
+    monkeypatch.setenv("MBHIP_WAVERNN_RESIDENT", "0")
     base = wavernn.generate_samples(mel, False, 0, 0, seed=21)
     assert wavernn.last_loop_launches > 1
-    monkeypatch.delenv("MBHIP_WAVERNN_PERSIST")
+    monkeypatch.delenv("MBHIP_WAVERNN_RESIDENT")
     alt = wavernn.generate_samples(mel, False, 0, 0, seed=21)
     assert wavernn.last_loop_launches == 1, "the persistent kernel did not run"
     assert base.shape == alt.shape and base.shape[0] == 1
@@ -118,21 +118,21 @@ def test_wavernn_persistent_kernel_falls_back_to_the_chain(cuda, lib, monkeypatc
     from mockingbird_amd.vocoder.wavernn.inference import WaveRNNDevice
     dev = WaveRNNDevice(synth.wavernn_state(seed=5)["model_state"])
     mel = torch.from_numpy(synth.wavernn_mel(9, seed=13) / 4.0).cuda()
-    monkeypatch.setenv("MBHIP_WAVERNN_PERSIST", "0")
+    monkeypatch.setenv("MBHIP_WAVERNN_RESIDENT", "0")
     base = dev.generate_samples(mel, False, 0, 0, seed=4)
-    monkeypatch.delenv("MBHIP_WAVERNN_PERSIST")
-    monkeypatch.setenv("MBHIP_WP_TEST_ABORT", "1")
+    monkeypatch.delenv("MBHIP_WAVERNN_RESIDENT")
+    monkeypatch.setenv("MBHIP_DIAG", "abort_wp")
     alt = dev.generate_samples(mel, False, 0, 0, seed=4)
     assert dev.last_loop_launches > 1 and torch.equal(base, alt)
-    monkeypatch.delenv("MBHIP_WP_TEST_ABORT")
+    monkeypatch.delenv("MBHIP_DIAG")
     again = dev.generate_samples(mel, False, 0, 0, seed=4)  # (the test switch does not mark the device as failed)
     assert dev.last_loop_launches == 1 and torch.equal(base, again)
     # the pipelined resident kernel (wavernn_pipe.h) takes the same way out
     mel3 = torch.from_numpy(synth.wavernn_mel(40, seed=13) / 4.0).cuda()
-    monkeypatch.setenv("MBHIP_WAVERNN_PIPE", "0")
+    monkeypatch.setenv("MBHIP_WAVERNN_RESIDENT", "0")
     base3 = dev.generate_samples(mel3, True, 3000, 100, seed=4)
-    monkeypatch.setenv("MBHIP_WAVERNN_PIPE", "1")
-    monkeypatch.setenv("MBHIP_WP_TEST_ABORT", "1")
+    monkeypatch.setenv("MBHIP_WAVERNN_RESIDENT", "1")
+    monkeypatch.setenv("MBHIP_DIAG", "abort_wp")
     alt3 = dev.generate_samples(mel3, True, 3000, 100, seed=4)
     assert dev.last_loop_launches > 1 and torch.equal(base3, alt3)
 
@@ -142,17 +142,15 @@ def test_wavernn_persistent_kernel_falls_back_to_the_chain(cuda, lib, monkeypatc
                                                                 (200, 3000, 300, 13, 1)],
                          ids=["2-folds", "3-folds", "15-folds", "23-folds", "32-folds", "3-folds-1-group", "13-folds-1-group"])
 def test_wavernn_pipe_kernel_keeps_the_sample_stream(wavernn, monkeypatch, frames, target, overlap, folds, groups):
-    """wavernn_pipe.h (the EXACT resident kernel: MBHIP_WQ16=0; also the MOL path): ONE launch of role-specialised resident
+    """wavernn_pipe.h (the EXACT resident kernel: MBHIP_WAVERNN_RESIDENT=exact; also the MOL path): ONE launch of role-specialised resident
     workgroups, two fold-column groups in flight (one with MBHIP_WQ_GROUPS=1) -- against the 5-launch chain: the same samples,
     sample for sample, from 2 to 32 columns (BASELINE configs[1] = 23).  The default kernel since round 4 (wavernn_pipe16.h, 22-bit
     operand pairs) is not bit-identical to the chain; it is held to the oracle in test_wavernn_gpu.py::test_production_*."""
-    monkeypatch.setenv("MBHIP_WQ16", "0")
     mel = torch.from_numpy(synth.wavernn_mel(frames, seed=17) / 4.0).cuda()
-    monkeypatch.setenv("MBHIP_WAVERNN_PIPE", "0")
-    monkeypatch.setenv("MBHIP_WAVERNN_PERSIST", "0")
+    monkeypatch.setenv("MBHIP_WAVERNN_RESIDENT", "0")
     base = wavernn.generate_samples(mel, True, target, overlap, seed=31)
     assert base.shape[0] == folds and wavernn.last_loop_launches == 5 * base.shape[1]
-    monkeypatch.setenv("MBHIP_WAVERNN_PIPE", "1")
+    monkeypatch.setenv("MBHIP_WAVERNN_RESIDENT", "exact")
     if groups == 1:
         monkeypatch.setenv("MBHIP_WQ_GROUPS", "1")
     alt = wavernn.generate_samples(mel, True, target, overlap, seed=31)

@@ -216,11 +216,11 @@ def test_fregan_f16_config4_share_vs_oracle(cuda, lib):
 @pytest.mark.parametrize("kind,cfg,uic,frames,batch", [("hifigan", synth.HIFIGAN_16K, 256, 23, 2),
                                                        ("fregan", synth.FREGAN_16K, 512, 12, 1)])
 def test_gan_f16_unfused_path_matches_oracle(cuda, lib, monkeypatch, kind, cfg, uic, frames, batch):
-    """MBHIP_GAN_NOFUSE=1 (read at create time): every ResBlock conv as its own conv1d_f16 launch -- the path
+    """MBHIP_GAN_FUSE=none (read at create time): every ResBlock conv as its own conv1d_f16 launch -- the path
     shapes without a fused ResBlock-unit instance take -- against the fp32 oracle, and against the fused path."""
     h = synth.small(cfg, uic)
     fused, ref = _run(kind, h, frames, batch, seed=5, dtype="f16")
-    monkeypatch.setenv("MBHIP_GAN_NOFUSE", "1")
+    monkeypatch.setenv("MBHIP_GAN_FUSE", "none")
     unfused, _ = _run(kind, h, frames, batch, seed=5, dtype="f16")
     e = hiputil.relerr(unfused, ref)
     assert e["nan"] == 0 and e["rel_rms"] <= F16_REL_TOL, e
@@ -231,14 +231,13 @@ def test_gan_f16_unfused_path_matches_oracle(cuda, lib, monkeypatch, kind, cfg, 
 @pytest.mark.parametrize("kind,cfg,uic,frames,batch", [("hifigan", synth.HIFIGAN_16K, 512, 23, 2),
                                                        ("fregan", synth.FREGAN_16K, 512, 12, 1)])
 def test_gan_f16_per_unit_launches_match_group_launches(cuda, lib, monkeypatch, kind, cfg, uic, frames, batch):
-    """MBHIP_GAN_NOSTAGE=1 + MBHIP_GAN_NOCHAIN=1 (read at create time): every ResBlock unit as its own mb_resblock_pair_f16
+    """MBHIP_GAN_FUSE=units (read at create time): every ResBlock unit as its own mb_resblock_pair_f16
     launch -- the production path of round 2, and today's path for any shape the one-launch stage / chain kernels do not take
     -- against the oracle and against the default (narrow stages and k = 3 ResBlocks as one launch each).  Run twice: the unit
     kernel keeps a bias block in LDS, consecutive launches carry different ones (see test_resblock_pair_gpu.py)."""
     h = synth.small(cfg, uic)
     grouped, ref = _run(kind, h, frames, batch, seed=5, dtype="f16")
-    monkeypatch.setenv("MBHIP_GAN_NOSTAGE", "1")
-    monkeypatch.setenv("MBHIP_GAN_NOCHAIN", "1")
+    monkeypatch.setenv("MBHIP_GAN_FUSE", "units")
     for _ in range(2):
         units, _ = _run(kind, h, frames, batch, seed=5, dtype="f16")
         e = hiputil.relerr(units, ref)

@@ -141,7 +141,7 @@ def test_resident_loop_falls_back_to_the_chain(cuda, lib, monkeypatch):
     monkeypatch.setenv("MBHIP_PPG_RESIDENT", "0")
     base = dec.decode(mem, dropout=masks)
     monkeypatch.setenv("MBHIP_PPG_RESIDENT", "1")
-    monkeypatch.setenv("MBHIP_PR_TEST_ABORT", "1")
+    monkeypatch.setenv("MBHIP_DIAG", "abort_pr")
     alt = dec.decode(mem, dropout=masks)
     assert dec.last_loop_launches > 1
     for x, y in zip(base, alt):

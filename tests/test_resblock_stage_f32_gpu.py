@@ -112,7 +112,7 @@ def test_resblock_stage_f32_ragged_accumulate_and_scale(cuda, lib):
 
 
 def test_generator_uses_the_fused_stages_and_matches_the_per_conv_path(cuda, lib, monkeypatch):
-    """GanGenerator (fp32) with the fused stages (default) against MBHIP_GAN_NOSTAGE=1 (one conv1d_split_kernel launch per conv): the
+    """GanGenerator (fp32) with the fused stages (default) against MBHIP_GAN_FUSE=units (one conv1d_split_kernel launch per conv): the
     same generator, the same weights -- RMS of the difference <= 2e-6 of the waveform's RMS (both are fp32-grade)."""
     import numpy as np
     import synth
@@ -120,9 +120,9 @@ def test_generator_uses_the_fused_stages_and_matches_the_per_conv_path(cuda, lib
     h = synth.HIFIGAN_16K
     st = synth.gan_state(h, "hifigan", seed=3)["generator"]
     mel = torch.from_numpy(synth.mel_input(37, 2, seed=1)).cuda()
-    monkeypatch.delenv("MBHIP_GAN_NOSTAGE", raising=False)
+    monkeypatch.delenv("MBHIP_GAN_FUSE", raising=False)
     y = GanGenerator(h, st, 0)(mel).cpu().double()
-    monkeypatch.setenv("MBHIP_GAN_NOSTAGE", "1")
+    monkeypatch.setenv("MBHIP_GAN_FUSE", "units")
     y0 = GanGenerator(h, st, 0)(mel).cpu().double()
     assert y.shape == y0.shape and int(torch.isnan(y).sum()) == 0
     rms = float(y0.pow(2).mean().sqrt())

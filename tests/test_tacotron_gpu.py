@@ -357,7 +357,7 @@ def test_resident_gru_scan_equals_launch_per_step_scan(model, monkeypatch, mode)
     steps = 24
     masks = synth.decoder_dropout_masks(3, (steps + 1) // 2, B, 256)
     mel, lin, _ = dev.decode(hm, hp, chars.cuda(), steps, 11.0, dropout=masks)
-    monkeypatch.setenv("MBHIP_GRU_SCAN_TEST_ABORT" if mode == "abort" else "MBHIP_GRU_SCAN", "1" if mode == "abort" else "0")
+    monkeypatch.setenv("MBHIP_DIAG" if mode == "abort" else "MBHIP_GRU_SCAN", "abort_gru_scan" if mode == "abort" else "0")
     hm2, hp2 = dev.encode(chars.cuda(), spk.cuda(), -1, enc_masks)
     mel2, lin2, _ = dev.decode(hm, hp, chars.cuda(), steps, 11.0, dropout=masks)
     for name, a, b in (("memory", hm, hm2), ("memory_proj", hp, hp2), ("linear", lin, lin2)):
@@ -365,7 +365,7 @@ def test_resident_gru_scan_equals_launch_per_step_scan(model, monkeypatch, mode)
         assert e["nan"] == 0 and e["max_abs"] <= 2e-5, (name, e)
     assert torch.equal(mel.cpu(), mel2.cpu())  # the decoder loop itself is untouched
     if mode == "abort":
-        monkeypatch.delenv("MBHIP_GRU_SCAN_TEST_ABORT")
+        monkeypatch.delenv("MBHIP_DIAG")
         monkeypatch.setenv("MBHIP_GRU_SCAN", "0")
         hm3, _ = dev.encode(chars.cuda(), spk.cuda(), -1, enc_masks)
         assert torch.equal(hm2.cpu(), hm3.cpu())

@@ -25,15 +25,11 @@ def _oracle_cond(w, mel, batched, target, overlap):
         return ow.conditioning(w, ow.HP, torch.from_numpy(mel[None] / 4.0), batched, target, overlap)
 
 
-@pytest.mark.parametrize("frames,batched,target,overlap,nt2", [(30, True, 600, 100, 0), (27, False, 0, 0, 0),
-                                                               (40, True, 1100, 50, 0), (70, True, 600, 100, 0),
-                                                               (70, True, 600, 100, 1)])
-def test_teacher_forced_logits(model, monkeypatch, frames, batched, target, overlap, nt2):
-    """(70, 600, 100) gives 26 folds: two 16-column MFMA tiles, as BASELINE configs[1]'s 23; nt2 = the launch form
-    with both tiles in one workgroup (MBHIP_WAVERNN_NT2)."""
+@pytest.mark.parametrize("frames,batched,target,overlap", [(30, True, 600, 100), (27, False, 0, 0), (40, True, 1100, 50),
+                                                           (70, True, 600, 100)])
+def test_teacher_forced_logits(model, monkeypatch, frames, batched, target, overlap):
+    """(70, 600, 100) gives 26 folds: two 16-column MFMA tiles, as BASELINE configs[1]'s 23."""
     dev, w = model
-    if nt2:
-        monkeypatch.setenv("MBHIP_WAVERNN_NT2", "1")
     mel = synth.wavernn_mel(frames, seed=2)
     mels, aux = _oracle_cond(w, mel, batched, target, overlap)
     steps = 96
@@ -154,14 +150,12 @@ def test_fused_sampler_matches_exact_sampler(model, monkeypatch):
     diverges, it is autoregressive)."""
     dev, w = model
     m = torch.from_numpy(synth.wavernn_mel(30, seed=11) / 4.0).cuda()
-    monkeypatch.delenv("MBHIP_WAVERNN_NOFUSE", raising=False)
     monkeypatch.delenv("MBHIP_WAVERNN_CHAIN", raising=False)
-    monkeypatch.delenv("MBHIP_WAVERNN_MERGE", raising=False)
-    monkeypatch.setenv("MBHIP_WAVERNN_PIPE", "0")  # the launch chains (the resident kernel is tested against them elsewhere)
+    monkeypatch.setenv("MBHIP_WAVERNN_RESIDENT", "0")  # the launch chains (the resident kernels are tested against them elsewhere)
     fused = dev.generate_samples(m, True, 600, 100, seed=77).cpu()
     assert dev.last_loop_launches == 5 * dev.last_plan.seq_len  # split-hidden chain
     # the other production chains draw the same Philox noise: identical streams up to a near-tie flip
-    for env, per_step in (({"MBHIP_WAVERNN_MERGE": "1"}, 4), ({"MBHIP_WAVERNN_CHAIN": "classic"}, 5)):
+    for env, per_step in (({"MBHIP_WAVERNN_CHAIN": "split"}, 5), ({"MBHIP_WAVERNN_CHAIN": "classic"}, 5)):
         for k_, v_ in env.items():
             monkeypatch.setenv(k_, v_)
         other = dev.generate_samples(m, True, 600, 100, seed=77).cpu()
@@ -170,7 +164,7 @@ def test_fused_sampler_matches_exact_sampler(model, monkeypatch):
             monkeypatch.delenv(k_)
         same = [bool((fused[i] == other[i]).all()) for i in range(fused.shape[0])]
         assert sum(same) >= fused.shape[0] - 1, (env, same)
-    monkeypatch.setenv("MBHIP_WAVERNN_NOFUSE", "1")
+    monkeypatch.setenv("MBHIP_WAVERNN_CHAIN", "nofuse")
     exact = dev.generate_samples(m, True, 600, 100, seed=77).cpu()
     assert dev.last_loop_launches == 6 * dev.last_plan.seq_len
     n, S = fused.shape
@@ -180,10 +174,9 @@ def test_fused_sampler_matches_exact_sampler(model, monkeypatch):
     assert min(first_bad) >= 50, first_bad
     assert sum(fb == S for fb in first_bad) >= n - 2, first_bad
     # unbatched (one sequence, eager tail after the graph replays) exercises the flush of the last sample
-    monkeypatch.delenv("MBHIP_WAVERNN_NOFUSE", raising=False)
-    monkeypatch.setenv("MBHIP_WAVERNN_PERSIST", "0")  # the chain (one column defaults to the persistent kernel, tested elsewhere)
+    monkeypatch.delenv("MBHIP_WAVERNN_CHAIN", raising=False)  # (MBHIP_WAVERNN_RESIDENT=0 still holds: one column defaults to the persistent kernel)
     f1 = dev.generate_samples(m[:, :27], False, 0, 0, seed=5).cpu()
-    monkeypatch.setenv("MBHIP_WAVERNN_NOFUSE", "1")
+    monkeypatch.setenv("MBHIP_WAVERNN_CHAIN", "nofuse")
     e1 = dev.generate_samples(m[:, :27], False, 0, 0, seed=5).cpu()
     a1 = (f1 == e1)[0]
     assert (int((~a1).nonzero()[0]) if (~a1).any() else f1.shape[1]) >= 200
@@ -269,25 +262,13 @@ def test_baseline_config1_full_size_properties(model):
     assert abs(wav[-1]) == 0.0 and np.abs(wav).max() > 0  # linear fade reaches exactly zero
 
 
-def test_two_column_tiles_per_workgroup_is_bit_identical(model, monkeypatch):
-    """MBHIP_WAVERNN_NT2: 17..64 folds with two column tiles per workgroup (one weight fetch for both) must give
-    the sample stream of the one-tile-per-workgroup launches bit for bit (same K split, same reduction order)."""
-    dev, w = model
-    mel = torch.from_numpy(synth.wavernn_mel(90, seed=12) / 4.0).cuda()
-    a = dev.generate_samples(mel, True, 800, 80, seed=9)
-    assert 16 < dev.last_plan.n_folds <= 32
-    monkeypatch.setenv("MBHIP_WAVERNN_NT2", "1")
-    b = dev.generate_samples(mel, True, 800, 80, seed=9)
-    assert torch.equal(a, b), int((a != b).sum())
-
-
 def test_batch_loop_equals_single_utterance_runs(model, monkeypatch):
     """mb_wavernn_generate_batch: three utterances of different lengths in ONE sample loop.  Fold n carries a
     descriptor with its utterance's table offsets and noise identity, so utterance u must reproduce
     generate_samples(mel_u, seed=seeds[u]) sample for sample (columns of the MFMA GEMMs are independent and the
     Philox counter is (step, local fold, class) under the utterance's own seed).  The single runs use the exact
-    resident kernel (MBHIP_WQ16=0: the fp32-MFMA sums of the chain and of the narrow batch loop)."""
-    monkeypatch.setenv("MBHIP_WQ16", "0")
+    resident kernel (MBHIP_WAVERNN_RESIDENT=exact: the fp32-MFMA sums of the chain and of the narrow batch loop)."""
+    monkeypatch.setenv("MBHIP_WAVERNN_RESIDENT", "exact")
     dev, w = model
     frames = [41, 30, 57]
     mels = [torch.from_numpy(synth.wavernn_mel(f, seed=20 + i) / 4.0).cuda() for i, f in enumerate(frames)]
@@ -336,19 +317,14 @@ def test_wide_batch_tile_split_equals_single_runs(model, monkeypatch, form):
     instantiated piece width is exercised at 76 columns).  All of them walk the same 8 accumulation chains as
     the K-split form, so each utterance must still equal its own single-utterance run bit for bit."""
     dev, w = model
-    monkeypatch.setenv("MBHIP_RNN_TS3", "0")  # the fp32 forms (the default since round 4 is rnn_ts3_body.h: next test)
-    monkeypatch.setenv("MBHIP_WQ16", "0")     # single runs on the exact resident kernel
-    if form == "ts":
-        monkeypatch.setenv("MBHIP_RNN_TS2", "0")
-    elif form.startswith("ts2_nt"):
-        monkeypatch.setenv("MBHIP_TS2_NT", form[-1])
+    # the fp32 forms (the default since round 4 is rnn_ts3_body.h: next test); MBHIP_RNN_WIDE = form[:columns tiles per wave]
+    monkeypatch.setenv("MBHIP_RNN_WIDE", {"auto": "ts2", "ts": "ts"}.get(form, "ts2:" + form[-1]))
+    monkeypatch.setenv("MBHIP_WAVERNN_RESIDENT", "exact")  # single runs on the exact resident kernel
     frames = [100, 93, 100, 77]
     mels = [torch.from_numpy(synth.wavernn_mel(f, seed=40 + i) / 4.0).cuda() for i, f in enumerate(frames)]
     seeds = [3, 1, 4, 1]
     outs = dev.generate_samples_batch(mels, 1000, 100, seeds)
     assert dev.last_batch_plan.n_folds > 64
-    monkeypatch.delenv("MBHIP_RNN_TS2", raising=False)
-    monkeypatch.delenv("MBHIP_TS2_NT", raising=False)
     for u in (0, 1, 3):
         single = dev.generate_samples(mels[u], True, 1000, 100, seed=seeds[u])
         assert torch.equal(outs[u], single), (form, u, int((outs[u] != single).sum()))
@@ -363,17 +339,17 @@ def test_wide_batch_fp16_forms_agree_and_match_oracle(model, monkeypatch):
     every compared utterance follows the oracle's loop body (fatchord_version.py:190-228) on its own history with its seed's
     noise.  (Not bit-identical to the fp32 forms / single runs any more: see the docstring of rnn_ts3_body.h.)"""
     dev, w = model
-    monkeypatch.delenv("MBHIP_RNN_TS3", raising=False)
+    monkeypatch.delenv("MBHIP_RNN_WIDE", raising=False)
     frames = [100, 93, 100, 77]
     mels_np = [synth.wavernn_mel(f, seed=40 + i) for i, f in enumerate(frames)]
     mels = [torch.from_numpy(m / 4.0).cuda() for m in mels_np]
     seeds = [3, 1, 4, 1]
     outs = {}
     for nt in ("1", "2", "3"):
-        monkeypatch.setenv("MBHIP_TS2_NT", nt)
+        monkeypatch.setenv("MBHIP_RNN_WIDE", "ts3:" + nt)
         outs[nt] = [o.cpu() for o in dev.generate_samples_batch(mels, 1000, 100, seeds)]
         assert dev.last_batch_plan.n_folds > 64
-    monkeypatch.delenv("MBHIP_TS2_NT")
+    monkeypatch.delenv("MBHIP_RNN_WIDE")
     for u in range(4):
         assert torch.equal(outs["1"][u], outs["2"][u]) and torch.equal(outs["1"][u], outs["3"][u]), u
     assert not torch.equal(outs["1"][0], outs["1"][2])
@@ -383,7 +359,7 @@ def test_wide_batch_fp16_forms_agree_and_match_oracle(model, monkeypatch):
         noise = dev.sampler_noise(seeds[u], steps, s.shape[0]).cpu()
         o_s, o_l = _oracle_replay(w, mels_np[u], True, 1000, 100, s, noise, steps)
         _assert_same_picks(s, o_s, o_l, noise, steps, max_ties=3)
-    monkeypatch.setenv("MBHIP_RNN_TS3", "0")  # the fp32 form draws the same noise: same process, almost always the same picks early on
+    monkeypatch.setenv("MBHIP_RNN_WIDE", "ts2")  # the fp32 form draws the same noise: same process, almost always the same picks early on
     ref = dev.generate_samples_batch(mels, 1000, 100, seeds)[0].cpu()
     assert float((ref[:, :50] == outs["3"][0][:, :50]).float().mean()) > 0.9
 
@@ -440,12 +416,12 @@ def test_mol_free_running_facade(mol_model):
     import os
     a = dev.generate_samples(m, True, 600, 100, seed=5)
     assert dev.last_loop_launches == 1  # production path: the resident pipelined kernel, its F3 role samples the mixture (wavernn_pipe.h)
-    os.environ["MBHIP_WAVERNN_PIPE"] = "0"
+    os.environ["MBHIP_WAVERNN_RESIDENT"] = "0"
     try:
         chain = dev.generate_samples(m, True, 600, 100, seed=5)
         assert dev.last_loop_launches == 5 * dev.last_plan.seq_len  # the launch chain: fc3 + mixture sampler fused (wf_fc3_mol_kernel)
     finally:
-        del os.environ["MBHIP_WAVERNN_PIPE"]
+        del os.environ["MBHIP_WAVERNN_RESIDENT"]
     assert torch.equal(a, chain)  # same per-tile sums, same Philox words, same expressions: bit-identical streams
     b = dev.generate_samples(m, True, 600, 100, seed=5)
     c = dev.generate_samples(m, True, 600, 100, seed=6)
@@ -466,12 +442,12 @@ def test_mol_free_running_facade(mol_model):
     assert float(d[~near_tie].max()) <= 1e-4 and int(near_tie.sum()) < steps, (float(d[~near_tie].max()), int(near_tie.sum()))
     # the exact 6-launch chain (stand-alone sampler, both GRU halves on the chain) draws the same words; continuous samples feed
     # roundings back, so the two streams agree to 1e-4 over the first steps and drift apart later
-    os.environ["MBHIP_WAVERNN_NOFUSE"] = "1"
+    os.environ["MBHIP_WAVERNN_CHAIN"] = "nofuse"
     try:
         exact = dev.generate_samples(m, True, 600, 100, seed=5)
         assert dev.last_loop_launches == 6 * dev.last_plan.seq_len
     finally:
-        del os.environ["MBHIP_WAVERNN_NOFUSE"]
+        del os.environ["MBHIP_WAVERNN_CHAIN"]
     assert float((a[:, :12] - exact[:, :12]).abs().max()) <= 1e-4
     one = dev.generate_samples(m[:, :27], False, 0, 0, seed=8)   # one column, eager tail + flush of the last sample
     assert dev.last_plan.seq_len == 5400 and torch.isfinite(one).all() and float(one.abs().max()) <= 1
@@ -540,13 +516,10 @@ def test_production_fast_chain_23_folds_vs_oracle(model, monkeypatch, form):
     wf_* launch chain (FM fast chain, fused sampler, hipGraph replays) and the resident pipelined kernel
     (wavernn_pipe.h), each forced in turn."""
     dev, w = model
-    for k in ("MBHIP_WAVERNN_FAST", "MBHIP_WAVERNN_PERSIST", "MBHIP_WAVERNN_NOFUSE", "MBHIP_WAVERNN_CHAIN", "MBHIP_NO_GRAPH", "MBHIP_WAVERNN_PIPE"):
+    for k in ("MBHIP_WAVERNN_RESIDENT", "MBHIP_WAVERNN_CHAIN", "MBHIP_NO_GRAPH", "MBHIP_WQ_GROUPS"):
         monkeypatch.delenv(k, raising=False)
-    monkeypatch.delenv("MBHIP_WQ16", raising=False)
-    if form != "default":
-        monkeypatch.setenv("MBHIP_WAVERNN_PIPE", "0" if form == "chain" else "1")
-    if form == "pipe_exact":
-        monkeypatch.setenv("MBHIP_WQ16", "0")  # wavernn_pipe.h: fp32 MFMA, 8-byte {value, tag} granules (bit-identical to the chain)
+    if form != "default":  # pipe_exact = wavernn_pipe.h: fp32 MFMA, 8-byte {value, tag} granules (bit-identical to the chain)
+        monkeypatch.setenv("MBHIP_WAVERNN_RESIDENT", {"chain": "0", "pipe": "1", "pipe_exact": "exact"}[form])
     frames, target, overlap, steps, seed = 1000, 8000, 800, 2000, 1234
     mel = synth.wavernn_mel(frames, seed=1)
     s = dev.generate_samples(torch.from_numpy(mel / 4.0).cuda(), True, target, overlap, seed=seed).cpu()
@@ -566,12 +539,11 @@ def test_production_pipe16_geometries_vs_oracle(model, monkeypatch, frames, targ
     """wavernn_pipe16.h (the default resident kernel for RAW models since round 4: exchange vectors as fp16 hi / lo pairs with 2-bit
     tags, error-compensated fp16 MFMA products) from 2 to 32 fold columns, two column groups and one: 400 steps each against the
     oracle's loop body on the device's history with the exported noise (fatchord_version.py:190-228) -- the pick of every step must be
-    the oracle's except provable near-ties.  Same seed -> same stream (the kernel is deterministic); MBHIP_WQ16=0 is the exact
+    the oracle's except provable near-ties.  Same seed -> same stream (the kernel is deterministic); MBHIP_WAVERNN_RESIDENT=exact is the exact
     kernel, whose stream is the launch chain's."""
     dev, w = model
-    for k in ("MBHIP_WAVERNN_PERSIST", "MBHIP_WAVERNN_PIPE", "MBHIP_WQ16", "MBHIP_WQ_GROUPS"):
+    for k in ("MBHIP_WAVERNN_RESIDENT", "MBHIP_WQ_GROUPS"):
         monkeypatch.delenv(k, raising=False)
-    monkeypatch.setenv("MBHIP_WAVERNN_PERSIST", "0")
     if groups != 2:
         monkeypatch.setenv("MBHIP_WQ_GROUPS", str(groups))  # 1: no pipelining; 3 / 4: what 33..64 columns get by themselves (forced at 15)
     mel = synth.wavernn_mel(frames, seed=17)
@@ -579,17 +551,17 @@ def test_production_pipe16_geometries_vs_oracle(model, monkeypatch, frames, targ
     s = dev.generate_samples(m, True, target, overlap, seed=31).cpu()
     assert s.shape[0] == folds and dev.last_loop_launches == 1, "the resident kernel did not run"
     if folds > 32:  # beyond the exact kernel's two groups: it drops to the launch chain there (and the stream is the chain's)
-        monkeypatch.setenv("MBHIP_WQ16", "0")
+        monkeypatch.setenv("MBHIP_WAVERNN_RESIDENT", "exact")
         dev.generate_samples(m, True, target, overlap, seed=31)
         assert dev.last_loop_launches > 1
-        monkeypatch.delenv("MBHIP_WQ16")
+        monkeypatch.delenv("MBHIP_WAVERNN_RESIDENT")
     s2 = dev.generate_samples(m, True, target, overlap, seed=31).cpu()
     assert torch.equal(s, s2)
     steps = min(400, s.shape[1])
     noise = dev.sampler_noise(31, steps, folds).cpu()
     o_s, o_l = _oracle_replay(w, mel, True, target, overlap, s, noise, steps)
     _assert_same_picks(s, o_s, o_l, noise, steps, max_ties=3)
-    monkeypatch.setenv("MBHIP_WQ16", "0")
+    monkeypatch.setenv("MBHIP_WAVERNN_RESIDENT", "exact")
     exact = dev.generate_samples(m, True, target, overlap, seed=31).cpu()
     assert (dev.last_loop_launches == 1) == (folds <= 32) and exact.shape == s.shape
     # the two kernels draw the same noise: their streams agree until the first near-tie decides differently (usually never within
@@ -597,8 +569,8 @@ def test_production_pipe16_geometries_vs_oracle(model, monkeypatch, frames, targ
     assert float((exact[:, :50] == s[:, :50]).float().mean()) > 0.9
 
 
-@pytest.mark.parametrize("q16", ["1", "0"])
-def test_production_8_bit_model_vs_oracle(cuda, lib, monkeypatch, q16):
+@pytest.mark.parametrize("resident", ["1", "exact"])
+def test_production_8_bit_model_vs_oracle(cuda, lib, monkeypatch, resident):
     """A bits = 8 checkpoint (256 classes: 16 fc3 row tiles, the F3 role of the resident kernels has 16 workgroups instead of 32;
     fatchord_version.py:95-98) through the default resident kernel and the exact one, 400 steps against the oracle."""
     import types
@@ -611,9 +583,8 @@ def test_production_8_bit_model_vs_oracle(cuda, lib, monkeypatch, q16):
     dev = WaveRNNDevice(st["model_state"], hpm)
     w = dict(st["model_state"])
     assert dev.n_classes == 256
-    for k in ("MBHIP_WAVERNN_PERSIST", "MBHIP_WAVERNN_PIPE", "MBHIP_WQ_GROUPS"):
-        monkeypatch.delenv(k, raising=False)
-    monkeypatch.setenv("MBHIP_WQ16", q16)
+    monkeypatch.delenv("MBHIP_WQ_GROUPS", raising=False)
+    monkeypatch.setenv("MBHIP_WAVERNN_RESIDENT", resident)
     frames, target, overlap, steps, seed = 120, 1000, 50, 400, 21
     mel = synth.wavernn_mel(frames, seed=3)
     s = dev.generate_samples(torch.from_numpy(mel / 4.0).cuda(), True, target, overlap, seed=seed).cpu()
@@ -639,9 +610,9 @@ def test_production_one_column_vs_oracle(model, monkeypatch, form):
     """batched=False (one fold column): the persistent kernel (fmaf chains in the MFMA's order) and the launch chain it replaces,
     2000 steps each against the oracle."""
     dev, w = model
-    monkeypatch.delenv("MBHIP_WAVERNN_PERSIST", raising=False)
+    monkeypatch.delenv("MBHIP_WAVERNN_RESIDENT", raising=False)
     if form == "chain":
-        monkeypatch.setenv("MBHIP_WAVERNN_PERSIST", "0")
+        monkeypatch.setenv("MBHIP_WAVERNN_RESIDENT", "0")
     frames, steps, seed = 30, 2000, 77
     mel = synth.wavernn_mel(frames, seed=13)
     s = dev.generate_samples(torch.from_numpy(mel / 4.0).cuda(), False, 0, 0, seed=seed).cpu()

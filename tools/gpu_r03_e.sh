@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_ppg2mel_gpu.py tests/test_wavernn_gpu.py tests/test_env_switches_gpu.py -m gpu -q -x --timeout=300 > gpurun_out/pytest_e.log 2>&1; echo "pytest rc=$?"
 tail -5 gpurun_out/pytest_e.log
-MBHIP_PR_TRACE=/tmp/pr_trace.bin timeout 300 python tools/ppg_resident_ab.py > gpurun_out/ppg_resident_ab.log 2>&1; echo "ab rc=$?"
+MBHIP_DIAG=pr_trace=/tmp/pr_trace.bin timeout 300 python tools/ppg_resident_ab.py > gpurun_out/ppg_resident_ab.log 2>&1; echo "ab rc=$?"
 grep T_enc gpurun_out/ppg_resident_ab.log
 timeout 600 python tools/wrn_pipe_ab.py > gpurun_out/pipe_ab.log 2>&1; echo "pipe_ab rc=$?"
 tail -c 1500 gpurun_out/pipe_ab.log

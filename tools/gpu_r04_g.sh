@@ -15,7 +15,7 @@ torch.cuda.synchronize()
 print(dev.last_batch_plan.n_folds, outs[0].shape, dev.last_loop_ms * 1e3 / outs[0].shape[1])
 PY
 for d in ts3 ts2; do
-  if [ $d = ts2 ]; then export MBHIP_RNN_TS3=0; fi
+  if [ $d = ts2 ]; then export MBHIP_RNN_WIDE=ts2; fi
   MBHIP_NO_GRAPH=1 timeout -k 5 120 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r04g/prof_$d -o p -- python /tmp/b32.py > gpurun_out/r04g/prof_$d.log 2>&1
   grep -v "^W2\|^E2\|^I2" gpurun_out/r04g/prof_$d.log | tail -2
   f=$(find gpurun_out/r04g/prof_$d -name "*kernel_stats.csv" | head -1)

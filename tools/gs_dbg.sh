@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 for dbg in ${@:-0 1 2 4 8 15}; do
   rm -rf gpurun_out/prof_gs
-  MBHIP_GS_DBG=$dbg timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_gs -o t -- python tools/taco_gen_time.py > gpurun_out/prof_gs.log 2>&1
+  MBHIP_DIAG=gs_dbg=$dbg timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_gs -o t -- python tools/taco_gen_time.py > gpurun_out/prof_gs.log 2>&1
   f=$(find gpurun_out/prof_gs -name '*kernel_stats*' | head -1)
   python - "$f" $dbg <<'PY'
 import csv, sys

@@ -1,9 +1,10 @@
-"""Phase timeline of the fused ResBlock-pair kernel (MBHIP_PAIR_TRACE marks of workgroup 0):
+"""Phase timeline of the fused ResBlock-pair kernel (MBHIP_DIAG=pair_trace=<file> marks of workgroup 0):
 python tools/pair_trace.py  -> runs one HiFi-GAN f16 forward (B=32, F=200) and prints, per distinct
 kernel configuration, the median shader-clock cycles between marks of tiles 1..4."""
 import os, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+from _diag import diag_set, diag_get
 import numpy as np
 path = os.path.join(ROOT, "gpurun_out", "pair_trace.txt")
 os.makedirs(os.path.dirname(path), exist_ok=True)
@@ -15,9 +16,9 @@ h = synth.HIFIGAN_16K
 gen = GanGenerator(h, synth.gan_state(h, "hifigan", seed=3)["generator"], 0, dtype="f16")
 mel = torch.from_numpy(synth.mel_input(200, 32, seed=0)).cuda()
 gen(mel); torch.cuda.synchronize()
-os.environ["MBHIP_PAIR_TRACE"] = path
+diag_set("pair_trace", path)
 gen(mel); torch.cuda.synchronize()
-os.environ.pop("MBHIP_PAIR_TRACE")
+diag_set("pair_trace")
 rows = collections.OrderedDict()
 for line in open(path):
     head, marks = line.split(":")

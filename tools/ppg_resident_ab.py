@@ -1,7 +1,9 @@
 """A/B of the ppg2mel decoder loop at one utterance: resident launch (csrc/ppg_resident.h) against the 6-launch
 graph-replayed step (csrc/ppg_fast.h) on bench.py's ppg2mel object (T_enc = 200, 400 steps forced, device RNG).
-Prints one JSON line; with MBHIP_PR_TRACE set, also the per-role wall-clock marks of steps 100..103."""
+Prints one JSON line; with MBHIP_DIAG=pr_trace=<file> set, also the per-role wall-clock marks of steps 100..103."""
 import json
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _diag import diag_set, diag_get
 import os
 import struct
 import sys
@@ -37,7 +39,7 @@ for mode in ("0", "1"):
 out["mel_max_abs_diff"] = hiputil.relerr(res["1"][0], res["0"][0])["max_abs"]
 out["align_max_abs_diff"] = float((res["1"][1] - res["0"][1]).abs().max())
 print(json.dumps(out))
-tr = os.environ.get("MBHIP_PR_TRACE")
+tr = diag_get("pr_trace")
 if tr and os.path.exists(tr):
     raw = open(tr, "rb").read()
     marks = struct.unpack("<%dQ" % (len(raw) // 8), raw)

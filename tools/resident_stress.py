@@ -19,7 +19,7 @@ mem = torch.from_numpy(synth.ppg2mel_memory(1, 60, seed=2)).cuda()
 
 
 def wrn(mel, batched, env):
-    for k in ("MBHIP_WAVERNN_PIPE", "MBHIP_WAVERNN_PERSIST", "MBHIP_WQ16"):
+    for k in ("MBHIP_WAVERNN_RESIDENT",):
         os.environ.pop(k, None)
     os.environ.update(env)
     out = dev.generate_samples(mel, batched, 1000, 50, seed=9)
@@ -36,9 +36,9 @@ def ppg(env):
 
 
 CASES = {
-    "wavernn_pipe16": (lambda env: wrn(mel23, True, env), {}, {"MBHIP_WAVERNN_PIPE": "0"}),
-    "wavernn_pipe_exact": (lambda env: wrn(mel23, True, env), {"MBHIP_WQ16": "0"}, {"MBHIP_WAVERNN_PIPE": "0"}),
-    "wavernn_one_column": (lambda env: wrn(mel1, False, env), {}, {"MBHIP_WAVERNN_PERSIST": "0"}),
+    "wavernn_pipe16": (lambda env: wrn(mel23, True, env), {"MBHIP_WAVERNN_RESIDENT": "1"}, {"MBHIP_WAVERNN_RESIDENT": "0"}),
+    "wavernn_pipe_exact": (lambda env: wrn(mel23, True, env), {"MBHIP_WAVERNN_RESIDENT": "exact"}, {"MBHIP_WAVERNN_RESIDENT": "0"}),
+    "wavernn_one_column": (lambda env: wrn(mel1, False, env), {"MBHIP_WAVERNN_RESIDENT": "1"}, {"MBHIP_WAVERNN_RESIDENT": "0"}),
     "ppg2mel_resident": (ppg, {"MBHIP_PPG_RESIDENT": "1"}, {"MBHIP_PPG_RESIDENT": "0"}),
 }
 side = torch.cuda.Stream()
@@ -58,7 +58,7 @@ for name, (run, env_res, env_chain) in CASES.items():
                     a = (a @ b) * 1e-3
         t0 = time.perf_counter()
         # explicit switches: a device that fell back once is tried again (the memo only changes the DEFAULT)
-        out, nl = run(dict(env_res, **({"MBHIP_WAVERNN_PIPE": "1"} if name.startswith("wavernn_pipe") else {})))
+        out, nl = run(env_res)
         verdict = "resident" if (nl == 1 and torch.equal(out, quiet)) else "fallback" if (nl > 1 and torch.equal(out, chain)) else "WRONG"
         bad += verdict == "WRONG"
         print(f"{name} rep {rep} load {load}: {verdict} (launches {nl}, wall {time.perf_counter() - t0:.3f} s)", flush=True)

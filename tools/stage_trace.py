@@ -1,9 +1,10 @@
-"""Phase timeline of the one-launch ResBlock group kernel (resblock_stage_f16.hip; MBHIP_STAGE_TRACE marks of thread 0 of
+"""Phase timeline of the one-launch ResBlock group kernel (resblock_stage_f16.hip; MBHIP_DIAG=stage_trace=<file> marks of thread 0 of
 workgroup 0, tile 1).  Needs the trace build:  MODULE=resblock_stage_f16 tools/build_variant.sh stagetrace -DMB_STAGE_TRACE_BUILD
 and MBHIP_LIB=build_variants/libmbhip_stagetrace.so.  Prints shader-clock cycles per chain / unit."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+from _diag import diag_set, diag_get
 import numpy as np
 path = os.path.join(ROOT, "gpurun_out", "stage_trace.txt")
 os.makedirs(os.path.dirname(path), exist_ok=True)
@@ -17,9 +18,9 @@ gen = GanGenerator(h, synth.gan_state(h, kind, seed=3)["generator"], 0 if kind =
 B, F = (32, 200) if kind == "hifigan" else (8, 3000)
 mel = torch.from_numpy(synth.mel_input(F, B, seed=0)).cuda()
 gen(mel); torch.cuda.synchronize()
-os.environ["MBHIP_STAGE_TRACE"] = path
+diag_set("stage_trace", path)
 gen(mel); torch.cuda.synchronize()
-os.environ.pop("MBHIP_STAGE_TRACE")
+diag_set("stage_trace")
 names = ["conv1", "epi1", "wait E1", "conv2", "epi2|wait P", "wait E2|epi O"]
 for line in open(path):
     head, marks = line.split(":")

@@ -1,11 +1,12 @@
-"""Phase timeline of one decoder iteration of the fast loop (taco_fast.h tf_mark stamps, MBHIP_TACO_TRACE).
+"""Phase timeline of one decoder iteration of the fast loop (taco_fast.h tf_mark stamps, MBHIP_DIAG=taco_trace=<file>).
 Per kernel: shader-clock deltas between marks of ONE workgroup (cycles and us at the measured clock), and the
 100 MHz wall clock of kernel start / end to see the gaps between the launches of the last iteration."""
 import json, os, struct, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+from _diag import diag_set, diag_get
 out_path = os.path.join(ROOT, "gpurun_out", "taco_trace.bin")
-os.environ["MBHIP_TACO_TRACE"] = out_path
+diag_set("taco_trace", out_path)
 import numpy as np, torch, synth
 from mockingbird_amd.synthesizer.inference import TacotronDevice
 st = synth.tacotron_state(seed=3)["model_state"]

@@ -1,8 +1,9 @@
-"""Per-kernel device timeline of the WaveRNN sample loop (MBHIP_TRACE_FILE diagnostics):
+"""Per-kernel device timeline of the WaveRNN sample loop (MBHIP_DIAG=trace_file=<file> diagnostics):
 first-wave start / last-store end of each of the 6 launches of a step, 100 MHz wall clock."""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+from _diag import diag_set, diag_get
 import numpy as np, torch
 import synth
 from mockingbird_amd.vocoder.wavernn.inference import WaveRNNDevice
@@ -13,9 +14,9 @@ path = os.path.join(ROOT, "gpurun_out", "wavernn_trace.bin")
 model = WaveRNNDevice(synth.wavernn_state(seed=5)["model_state"])
 mel = torch.from_numpy(synth.wavernn_mel(frames, seed=1) / 4.0).cuda()
 model.generate_samples(mel, bool(batched), 8000, 800, seed=0)
-os.environ["MBHIP_TRACE_FILE"] = path
+diag_set("trace_file", path)
 model.generate_samples(mel, bool(batched), 8000, 800, seed=1)
-os.environ.pop("MBHIP_TRACE_FILE")
+diag_set("trace_file")
 p = model.last_plan
 print("folds", p.n_folds, "seq", p.seq_len, "us/step", model.last_loop_ms * 1e3 / p.seq_len)
 raw = np.fromfile(path, dtype=np.uint64).reshape(-1, 6, 512, 2)

@@ -1,5 +1,5 @@
 """bench.py's wavernn_batch32 object (32 utterances x mel 80x1000 = 736 fold columns x 9600 steps in ONE sample loop): the wide
-recurrent GEMM on the fp16 matrix pipe (rnn_ts3_body.h, default) against the fp32 form (rnn_ts2_body.h, MBHIP_RNN_TS3=0).
+recurrent GEMM on the fp16 matrix pipe (rnn_ts3_body.h, default) against the fp32 form (rnn_ts2_body.h, MBHIP_RNN_WIDE=ts2).
 usage: python tools/wrn_batch32_ab.py [modes, e.g. ts3,ts3nt6,ts2] -> gpurun_out/wrn_batch32_ab.json"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,9 +12,7 @@ seeds = list(range(500, 532))
 out = {}
 modes = sys.argv[1].split(",") if len(sys.argv) > 1 else ["ts3", "ts2", "ts3"]   # e.g. ts3,ts3nt6,ts2,ts3nt6,ts3
 for mode in modes:
-    os.environ["MBHIP_RNN_TS3"] = "0" if mode == "ts2" else "1"
-    os.environ.pop("MBHIP_TS2_NT", None)
-    if "nt" in mode: os.environ["MBHIP_TS2_NT"] = mode.split("nt")[1]
+    os.environ["MBHIP_RNN_WIDE"] = ("ts2" if mode.startswith("ts2") else "ts3") + (":" + mode.split("nt")[1] if "nt" in mode else "")
     outs = dev.generate_samples_batch(mels, 8000, 800, seeds)
     torch.cuda.synchronize()
     us = dev.last_loop_ms * 1e3 / outs[0].shape[1]

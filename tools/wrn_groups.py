@@ -11,11 +11,11 @@ for name, F, target, overlap, groups in (("23_folds", 1000, 8000, 800, (2, 3, 4)
                                          ("63_folds", 330, 1000, 50, (4,))):
     mel = torch.from_numpy(synth.wavernn_mel(F, seed=0) / 4.0).cuda()
     res = {}
-    os.environ["MBHIP_WAVERNN_PIPE"] = "0"
+    os.environ["MBHIP_WAVERNN_RESIDENT"] = "0"
     dev.generate_samples(mel, True, target, overlap, seed=5)
     s = dev.generate_samples(mel, True, target, overlap, seed=5)
     res["chain"] = {"us_per_step": dev.last_loop_ms * 1e3 / s.shape[1], "columns": int(s.shape[0]), "steps": int(s.shape[1])}
-    os.environ["MBHIP_WAVERNN_PIPE"] = "1"
+    os.environ["MBHIP_WAVERNN_RESIDENT"] = "1"
     for g in groups:
         os.environ["MBHIP_WQ_GROUPS"] = str(g)
         best = 1e9

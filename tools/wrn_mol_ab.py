@@ -14,7 +14,7 @@ mel = torch.from_numpy(synth.wavernn_mel(1000, seed=0) / 4.0).cuda()
 dev.generate_samples(mel[:, :60], True, 2000, 200, seed=1)
 a = dev.generate_samples(mel, True, 8000, 800, seed=2); torch.cuda.synchronize()
 print("pipe : launches", dev.last_loop_launches, "us/step %.2f" % (dev.last_loop_ms * 1e3 / a.shape[1]))
-os.environ["MBHIP_WAVERNN_PIPE"] = "0"
+os.environ["MBHIP_WAVERNN_RESIDENT"] = "0"
 c = dev.generate_samples(mel, True, 8000, 800, seed=2); torch.cuda.synchronize()
 print("chain: launches", dev.last_loop_launches, "us/step %.2f" % (dev.last_loop_ms * 1e3 / c.shape[1]), "identical", bool(torch.equal(a, c)),
       "max |diff| %.3g" % float((a - c).abs().max()), "first differing step", int(((a != c).any(0)).float().argmax()) if not torch.equal(a, c) else -1)

@@ -2,8 +2,9 @@
 import os, sys, struct
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
-os.environ["MBHIP_WAVERNN_PERSIST"] = "1"
-os.environ["MBHIP_WP_TRACE"] = "/tmp/wp_trace.bin"
+from _diag import diag_set, diag_get
+os.environ["MBHIP_WAVERNN_RESIDENT"] = "1"
+diag_set("wp_trace", "/tmp/wp_trace.bin")
 import torch, synth
 from mockingbird_amd.vocoder.wavernn.inference import WaveRNNDevice
 dev = WaveRNNDevice(synth.wavernn_state(seed=1)["model_state"])

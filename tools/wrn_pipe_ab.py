@@ -5,6 +5,7 @@ usage: python tools/wrn_pipe_ab.py [out.json] -> gpurun_out/wavernn_pipe_ab.json
 import json, os, struct, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+from _diag import diag_set, diag_get
 import torch, synth
 from mockingbird_amd.vocoder.wavernn.inference import WaveRNNDevice
 dev = WaveRNNDevice(synth.wavernn_state(seed=1)["model_state"])
@@ -12,16 +13,17 @@ out = {"cases": {}}
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 CASES = (("configs1_23_folds", 1000, 8000, 800, ("chain", "pipe")), ("12_folds", 200, 3000, 300, ("chain", "pipe", "pipe_1group")),
          ("4_folds", 40, 2200, 100, ("chain", "pipe", "persist")), ("32_folds", 330, 2000, 100, ("chain", "pipe")))
-if os.environ.get("WQ_AB_CASES"):  # e.g. WQ_AB_CASES=configs1_23_folds: only these cases (a quick marks run under MBHIP_WQ_FLAGS)
+if os.environ.get("WQ_AB_CASES"):  # e.g. WQ_AB_CASES=configs1_23_folds: only these cases (a quick marks run under MBHIP_DIAG=wq_flags=<bits>)
     CASES = tuple(c for c in CASES if c[0] in os.environ["WQ_AB_CASES"].split(","))
 for name, F, target, overlap, modes in CASES:
     mel = torch.from_numpy(synth.wavernn_mel(F, seed=0) / 4.0).cuda()
     res = {}
     for mode in modes:
-        for k in ("MBHIP_WAVERNN_PIPE", "MBHIP_WAVERNN_PERSIST", "MBHIP_WQ_GROUPS", "MBHIP_WP_TRACE"):
-            os.environ.pop(k, None)
-        os.environ["MBHIP_WAVERNN_PIPE"] = "1" if mode.startswith("pipe") else "0"
-        os.environ["MBHIP_WAVERNN_PERSIST"] = "1" if mode == "persist" else "0"
+        os.environ.pop("MBHIP_WQ_GROUPS", None)
+        diag_set("wp_trace")
+        # (WQ_AB_EXACT=1: the exact fp32 resident kernel instead of the operand-pair one; "persist": the 4-column persist kernel of
+        #  round 3 is gone, the mode now times the default resident kernel)
+        os.environ["MBHIP_WAVERNN_RESIDENT"] = ("exact" if os.environ.get("WQ_AB_EXACT") == "1" else "1") if mode != "chain" else "0"
         if mode == "pipe_1group":
             os.environ["MBHIP_WQ_GROUPS"] = "1"
         dev.generate_samples(mel[:, :40], True, 2200, 100, seed=2)  # warm-up
@@ -35,9 +37,9 @@ for name, F, target, overlap, modes in CASES:
         res[mode + "_samples"] = smp
         if mode == "pipe" and smp.shape[1] > 1100:  # wall-clock marks (100 MHz) of one workgroup per role, group 0, steps 1000..1003
             tf = os.path.join(ROOT, "gpurun_out", f"wq_trace_{name}.bin")
-            os.environ["MBHIP_WP_TRACE"] = tf
+            diag_set("wp_trace", tf)
             dev.generate_samples(mel, True, target, overlap, seed=5)
-            os.environ.pop("MBHIP_WP_TRACE")
+            diag_set("wp_trace")
             if os.path.exists(tf):
                 m = struct.unpack("<320Q", open(tf, "rb").read())
                 t0 = m[0]  # R1, step 1000, mark 0

@@ -1,19 +1,21 @@
-"""Sweep of wavernn_pipe.h's A/B switches at BASELINE configs[1] (23 folds): us per step per MBHIP_WQ_FLAGS / MBHIP_WQ_GROUPS value.
+"""Sweep of wavernn_pipe.h's A/B switches at BASELINE configs[1] (23 folds): us per step per MBHIP_DIAG=wq_flags / MBHIP_WQ_GROUPS value.
 usage: python tools/wrn_pipe_sweep.py FLAGS[,FLAGS...]"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+from _diag import diag_set, diag_get
 import torch, synth
 from mockingbird_amd.vocoder.wavernn.inference import WaveRNNDevice
 dev = WaveRNNDevice(synth.wavernn_state(seed=1)["model_state"])
 mel = torch.from_numpy(synth.wavernn_mel(1000, seed=0) / 4.0).cuda()
-os.environ["MBHIP_WAVERNN_PIPE"] = "0"
+_res = os.environ.get("MBHIP_WAVERNN_RESIDENT", "1")
+os.environ["MBHIP_WAVERNN_RESIDENT"] = "0"
 ref = dev.generate_samples(mel, True, 8000, 800, seed=5)
 print("chain", dev.last_loop_ms * 1e3 / ref.shape[1], flush=True)
-os.environ["MBHIP_WAVERNN_PIPE"] = "1"
+os.environ["MBHIP_WAVERNN_RESIDENT"] = _res  # "exact": the fp32 kernel
 out = {}
 for fl in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0"]):
-    os.environ["MBHIP_WQ_FLAGS"] = fl
+    diag_set("wq_flags", fl)
     best = 1e9
     for rep in range(3):
         s = dev.generate_samples(mel, True, 8000, 800, seed=5)
