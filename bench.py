@@ -806,6 +806,10 @@ def main():
                 if dt == "f16":  # PMC pass of this object: HBM bytes of one forward against the read-x + write-y floor
                     tr, src = pmc_traffic("hifigan")
                     entry["roofline"].update({"traffic": tr, "traffic_source": src, "traffic_floor_bytes": gan_floor_bytes(h, 32, 200)})
+                elif split:  # the fp32-result object's own pass (round 4: profiles/r04_pmc_hifigan_f32.json), when it has been committed
+                    tr, src = pmc_traffic("hifigan_f32")
+                    if tr is not None:
+                        entry["roofline"].update({"traffic": tr, "traffic_source": src})
                 if dt == "f32":
                     y32 = y
                 else:

@@ -25,5 +25,5 @@ done
 rm -rf gpurun_out/pmc4_tmp
 timeout 60 python tools/pmc_wavernn_r04_json.py
 # the Tacotron iteration's kernels (hardware gate functions since round 4): profiles/r04_pmc_tacotron.json
-MB_PMC_ROUND=r04 timeout 900 bash tools/pmc_r02.sh tacotron
+MB_PMC_ROUND=r04 timeout 1200 bash tools/pmc_r02.sh tacotron hifigan_f32
 fi

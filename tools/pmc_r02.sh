@@ -20,6 +20,7 @@ for what in ${@:-tacotron hifigan fregan}; do
   case $what in
     tacotron) run tacotron python tools/taco_run.py 1 ;;
     hifigan) run hifigan python tools/gan_run.py hifigan f16 32 200 2 ;;
+    hifigan_f32) run hifigan_f32 python tools/gan_run.py hifigan f32 32 200 2 ;;
     fregan) run fregan python tools/gan_run.py fregan f16 8 3000 2 ;;
   esac
 done

@@ -15,6 +15,8 @@ WHAT = {
                   "rnn_input": ["taco_rin_kernel"], "lstm": ["taco_lstm_kernel"], "mel_proj": ["taco_mel_kernel"]}),
     "hifigan": ("tools/gan_run.py hifigan f16 32 200 (bench object hifigan_f16)",
                 {"resblock_pair": ["resblock_pair"], "resblock_stage": ["resblock_stage"], "conv1d_f16": ["conv1d_f16"]}),
+    "hifigan_f32": ("tools/gan_run.py hifigan f32 32 200 (bench object hifigan: fp32 storage, error-compensated fp16 MFMA)",
+                    {"resblock_stage_f32": ["resblock_stage_f32"], "conv1d_split": ["conv1d_split"], "conv1d_mfma": ["conv1d_mfma"]}),
     "fregan": ("tools/gan_run.py fregan f16 8 3000 (bench object fregan_f16)",
                {"resblock_pair": ["resblock_pair"], "resblock_stage": ["resblock_stage"], "conv1d_f16": ["conv1d_f16"],
                 "add_inplace": ["add_inplace_f16"]}),
@@ -29,7 +31,7 @@ for what, (cmd, names) in WHAT.items():
         print(what, "skipped:", e)
         continue
     out = {"source": SRC % cmd, "kernels": {}}
-    if what in ("hifigan", "fregan"):
+    if what in ("hifigan", "hifigan_f32", "fregan"):
         out["forwards"] = 3  # tools/gan_run.py: one warm-up + two timed forwards
     for name, subs in names.items():
         # every instance (template arguments differ per layer shape): aggregate all kernels matching the substrings
