@@ -202,7 +202,10 @@ static constexpr int SROW = SCK * 4 + 16;  // bytes per staged position
 // One workgroup = 4 waves on 128 output positions (WM x WN waves, NTW 32-position tiles per wave: 4x1x4, 2x2x2 or 1x4x1).
 // Pipeline per 32-channel chunk: the NEXT chunk's x values are already in flight to registers (SITEMS x 8 floats per
 // thread, issued before this chunk's MFMAs), the chunk itself is computed from LDS, then the registers are split into
-// hi / lo halves and stored: global latency sits behind the MFMAs, five workgroups per CU hide the rest.
+// hi / lo halves and stored: global latency sits behind the MFMAs, three workgroups per CU hide the rest (the register budget is
+// capped for three waves per SIMD: 158 VGPRs for 4x1x4, accumulators included -- 172 us against 185 at two for the 128-channel k = 7
+// conv of HiFi-GAN 32 x 200; a 4x1x8 form with 256 positions per workgroup -- half the weight stream per output -- needs 384
+// registers or spills: 342 us).
 // The first version of this kernel was VALU-bound, not matrix-bound: ~5500 vector instructions per wave next to 168 MFMAs
 // (rocprofv3 SQ_INSTS_VALU; the do-nothing skeleton alone cost half the kernel).  Hence: loads are unconditional from
 // clamped 32-bit offsets (one add per element, the select happens on the value), work items (position, 8-channel group) are
@@ -224,7 +227,7 @@ __device__ __forceinline__ void split_store2(char* row, const int grp, const flo
 }
 
 template <int WM, int WN, int NTW, bool TR, bool POOL>
-__global__ __launch_bounds__(256) void conv1d_split_kernel(ConvK a, const uint4* __restrict__ wsplit, const float* __restrict__ whdr, const int nbuf) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv1d_split_kernel(ConvK a, const uint4* __restrict__ wsplit, const float* __restrict__ whdr, const int nbuf) {
   extern __shared__ __attribute__((aligned(16))) char slds[];
   static_assert(32 * NTW * WN == SNT, "tile shape");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
