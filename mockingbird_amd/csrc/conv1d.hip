@@ -212,15 +212,17 @@ static constexpr int SROW = SCK * 4 + 16;  // bytes per staged position
 // dealt evenly over the 256 threads, every stride is hoisted, and the epilogue has a straight-line path for interior tiles.
 static constexpr int SNT = 128;    // output positions per workgroup
 static constexpr int SITEMS = 4;   // (position, 8-channel group) items per thread and chunk: rowlen <= 256
-static constexpr float SPLIT_RANGE = 65536.f;  // |x| beyond this saturates both fp16 halves (the clamps of split_store2)
+static constexpr float SPLIT_RANGE = 65504.f;  // |x| beyond this saturates (the clamp of split_store2)
 
 __device__ __forceinline__ void split_store2(char* row, const int grp, const float (&v)[8]) {
   h16x8 hi, lo;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const h16 h = (h16)__builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
+    // one clamp: a finite hi leaves a residual of at most half an fp16 ulp (<= 16), x 2^11 <= 32768 -- the low half needs none
+    const float x = __builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
+    const h16 h = (h16)x;
     hi[e] = h;
-    lo[e] = (h16)__builtin_amdgcn_fmed3f((v[e] - (float)h) * 2048.f, -65504.f, 65504.f);  // residual scaled by 2^11: a normal whenever hi is
+    lo[e] = (h16)((x - (float)h) * 2048.f);  // residual scaled by 2^11: a normal whenever hi is
   }
   *reinterpret_cast<h16x8*>(row + grp * 16) = hi;
   *reinterpret_cast<h16x8*>(row + SCK * 2 + grp * 16) = lo;
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
         if (POOL) x = fmaxf(x, pre2[it][e]);  // MaxPool1d(2, stride 1, pad 1)[:T] (cbhg.py:20,61)
         else {
           x *= a.in_scale;                        // (1.0 when unused: exact)
-          x = x > 0.f ? x : x * slope_eff;        // leaky_relu, slope_eff = 1 when there is no input activation: exact
+          x = fmaxf(x, x * slope_eff);            // leaky_relu for slopes in (0, 1]: x > 0 ? x : slope x, bit for bit; slope_eff = 1 = no activation
         }
         v[e] = x;
       }
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
           const h16x8 Ah = __builtin_bit_cast(h16x8, ah), Al = __builtin_bit_cast(h16x8, al), As = __builtin_bit_cast(h16x8, as);
           if (wi < n_w) { ah = wp[(size_t)wi * 192]; al = wp[(size_t)wi * 192 + 64]; as = wp[(size_t)wi * 192 + 128]; }
 #pragma unroll
-          for (int n = 0; n < NTW; ++n) {
+          for (int n = 0; n < NTW; ++n) {  // (three products per accumulator in a row: interleaving two tiles' chains measured no faster)
             const h16x8 Bh = *reinterpret_cast<const h16x8*>(lp + n * tile_stride);
             const h16x8 Bl = *reinterpret_cast<const h16x8*>(lp + n * tile_stride + SCK * 2);
             if (!TR) {
@@ -615,7 +617,8 @@ extern "C" int mb_conv1d(const mb_conv1d_args* a, mb_stream_t stream) {
   // ---- split path (error-compensated fp16 MFMA), the default from 16 input channels up ----
   const char* senv = getenv("MBHIP_CONV_SPLIT");
   const bool split_off = senv && atoi(senv) == 0;
-  if (!split_off && a->c_in >= 16) {
+  const bool slope_ok = a->in_act != 1 || (a->in_slope >= 0.f && a->in_slope <= 1.f);  // the split kernel's max-form leaky_relu
+  if (!split_off && a->c_in >= 16 && slope_ok) {
     const float* hdr = a->d_wpacked + conv_f32_image_floats(a->c_out, a->c_in, a->ksize);
     const uint4* wsplit = reinterpret_cast<const uint4*>(hdr + 64);
     // 128 output positions per workgroup; waves along the output channels when there are enough of them (A fragments are
