@@ -114,7 +114,7 @@ int mb_conv1d(const mb_conv1d_args* a, mb_stream_t stream);
 
 /* Range diagnostics of the error-compensated path (no reference counterpart: the reference's fp32 Conv1d of
  * models/vocoder/hifigan/models.py:11-48 has no such limit).  With MBHIP_CONV_RANGE_CHECK=1 in the environment every launch
- * of that path counts the input values it stages with |x| > 65536 (both fp16 halves saturate there) or NaN / Inf into one
+ * of that path counts the input values it stages with |x| > 65504 (the fp16 hi half saturates there) or NaN / Inf into one
  * word per device.  Returns the count of the current device (0 if the check never ran there), < 0 on a HIP error;
  * reset != 0 clears it.  Synchronises the device. */
 long long mb_conv1d_range_events(int reset);

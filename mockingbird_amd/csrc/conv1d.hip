@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvK a) {
 //                               (16 channels, tap), fp32 accumulate;  y = acc * 2^-s ...
 // The dropped wl.xl term is 2^-22 of a product and each operand keeps 22 bits down to |x| = 2^-14 (an absolute 2^-36 below):
 // fp32-grade results at 1/5.3 of the matrix-pipe time of the fp32-input MFMA (3 x 32 cycles per 32x32x16 block instead of 8 x 64).
-// Range: |x| <= 65536 (xh saturates at fp16's 65504, the scaled residual right behind it; audio / mel activations are O(1..100));
+// Range: |x| <= 65504 (x is clamped to fp16's largest value before it is split; audio / mel activations are O(1..100));
 // MBHIP_CONV_RANGE_CHECK=1 counts the values beyond it (mb_conv1d_range_events).
 // MBHIP_CONV_SPLIT=0 selects the exact fp32-input kernel above (tests/test_conv1d_gpu.py runs both).
 // Layout: x staged per chunk of SCK = 32 channels as [position][32 hi | 32 lo | pad] fp16 rows of 144 bytes (16-byte
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
         }
         v[e] = x;
       }
-      if (a.range_events) {  // diagnostics only (uniform branch): the hi / lo halves saturate beyond 2 x 65504
+      if (a.range_events) {  // diagnostics only (uniform branch): x saturates beyond 65504
         int n_out = 0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) n_out += !(fabsf(v[e]) <= SPLIT_RANGE) ? 1 : 0;  // counts NaN / Inf as well
@@ -560,7 +560,7 @@ extern "C" int mb_conv1d_pack(const float* h_w, int c_out, int c_in, int ksize, 
 }
 
 // Range diagnostics of the split path: with MBHIP_CONV_RANGE_CHECK=1 every conv1d_split_kernel launch
-// counts the staged input values with |x| > 65536 (or NaN / Inf) -- values the fp32 reference would carry and the hi / lo
+// counts the staged input values with |x| > 65504 (or NaN / Inf) -- values the fp32 reference would carry and the hi / lo
 // clamp saturates silently -- into one device word per device; mb_conv1d_range_events reads (and optionally clears) it.
 static unsigned* g_range_word[16] = {};
 static unsigned* range_word() {
