@@ -53,6 +53,10 @@ const char* mb_last_error(void);
  *      19 environment switches instead of 52 (DESIGN.md "Run-time switches": renamed / merged / moved under MBHIP_DIAG). */
 #define MB_ABI_VERSION 3
 int mb_abi_version(void);
+/* Host-logic hook (tests/test_host_logic.py): the library's view of MBHIP_DIAG="key=value,key,..." -- the one variable behind every
+ * diagnostic, A/B knob and test hook (DESIGN.md "Run-time switches").  Copies the value of `key` (a bare key reads as "1") into
+ * out[0..n) and returns its length, or -1 when the key is absent.  No reference counterpart. */
+int mb_diag_lookup(const char* key, char* out, int n);
 
 /* ------------------------------------------------------------------------
  * 1. Conv1d / ConvTranspose1d primitive (fp32 MFMA implicit GEMM).

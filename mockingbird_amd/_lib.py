@@ -206,6 +206,7 @@ SIGNATURES = {
                                       C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_size_t, C.c_void_p]),
     "mb_wavernn_loop_path": (C.c_int, [C.c_int] * 7),
+    "mb_diag_lookup": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int]),
     "mb_wavernn_debug_noise": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mb_wavernn_debug_noise_mol": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mb_wavernn_last_loop_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),

@@ -69,3 +69,9 @@ void DevBuf::release() {
 
 extern "C" const char* mb_last_error(void) { return mb::g_err; }
 extern "C" int mb_abi_version(void) { return MB_ABI_VERSION; }
+extern "C" int mb_diag_lookup(const char* key, char* out, int n) {
+  std::string v;
+  if (!key || !mb::diag_str(key, &v)) return -1;
+  if (out && n > 0) { strncpy(out, v.c_str(), (size_t)n - 1); out[n - 1] = 0; }
+  return (int)v.size();
+}

@@ -299,3 +299,20 @@ def test_switch_inventory_is_small_and_documented():
             mentioned |= set(re.findall(r"MBHIP_[A-Z0-9_]+", open(path, errors="replace").read()))
     mentioned.discard("MBHIP_H")  # the header's include guard
     assert mentioned <= names, sorted(mentioned - names)
+
+
+def test_diag_variable_parsing(lib, monkeypatch):
+    """MBHIP_DIAG="key=value,key,...": exact key match (no prefix hits), bare keys read as 1, values may contain '=' and '/'."""
+    def get(key):
+        buf = C.create_string_buffer(64)
+        n = lib.mb_diag_lookup(key.encode(), buf, 64)
+        return None if n < 0 else buf.value.decode()
+    monkeypatch.delenv("MBHIP_DIAG", raising=False)
+    assert get("wq_flags") is None
+    monkeypatch.setenv("MBHIP_DIAG", "wq_flags=17,abort_wp,wp_trace=/tmp/a=b.bin,ts3_dbg=3")
+    assert get("wq_flags") == "17" and get("abort_wp") == "1" and get("wp_trace") == "/tmp/a=b.bin" and get("ts3_dbg") == "3"
+    assert get("wq") is None and get("abort") is None and get("trace") is None
+    monkeypatch.setenv("MBHIP_DIAG", "abort_pr")
+    assert get("abort_pr") == "1" and get("abort_wp") is None
+    monkeypatch.setenv("MBHIP_DIAG", "")
+    assert get("abort_pr") is None
