@@ -229,8 +229,7 @@ __device__ __forceinline__ void split_store2(char* row, const int grp, const flo
 }
 
 template <int WM, int WN, int NTW, bool TR, bool POOL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv1d_split_kernel(ConvK a, const uint4* __restrict__ wsplit, const float* __restrict__ whdr, const int nbuf) {
-  extern __shared__ __attribute__((aligned(16))) char slds[];
+__device__ __forceinline__ void conv1d_split_body(const ConvK& a, const uint4* __restrict__ wsplit, const float* __restrict__ whdr, const int nbuf, char* slds) {
   static_assert(32 * NTW * WN == SNT, "tile shape");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -446,6 +445,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
   }
 }
 
+// The register budget is capped for three waves per SIMD (see above); the max-pool instances hold a second value per staged element
+// (32 more registers) and would spill under that cap: they keep the allocator's own choice (two waves).
+template <int WM, int WN, int NTW, bool TR, bool POOL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv1d_split_kernel(ConvK a, const uint4* __restrict__ wsplit, const float* __restrict__ whdr, const int nbuf) {
+  extern __shared__ __attribute__((aligned(16))) char slds[];
+  static_assert(!POOL, "the pooled instances are conv1d_split_pool_kernel");
+  conv1d_split_body<WM, WN, NTW, TR, false>(a, wsplit, whdr, nbuf, slds);
+}
+template <int WM, int WN, int NTW, bool TR>
+__global__ __launch_bounds__(256) void conv1d_split_pool_kernel(ConvK a, const uint4* __restrict__ wsplit, const float* __restrict__ whdr, const int nbuf) {
+  extern __shared__ __attribute__((aligned(16))) char slds[];
+  conv1d_split_body<WM, WN, NTW, TR, true>(a, wsplit, whdr, nbuf, slds);
+}
+
 static int conv_geometry(const mb_conv1d_args* a, ConvK* k) {
   MB_REQUIRE(a->up >= 1 && a->up <= 8, "conv1d: up=%d out of range", a->up);
   MB_REQUIRE(a->ksize >= 1 && a->c_in >= 1 && a->c_out >= 1, "conv1d: bad shape");
@@ -635,7 +648,7 @@ extern "C" int mb_conv1d(const mb_conv1d_args* a, mb_stream_t stream) {
       const bool pool = a->in_act == 2;
 #define MB_SLAUNCH2(WM_, WN_, NTW_, TR_)                                                                                          \
   do {                                                                                                                            \
-    if (pool) hipLaunchKernelGGL((conv1d_split_kernel<WM_, WN_, NTW_, TR_, true>), grid, dim3(256), lds, s, k, wsplit, hdr, nbuf);      \
+    if (pool) hipLaunchKernelGGL((conv1d_split_pool_kernel<WM_, WN_, NTW_, TR_>), grid, dim3(256), lds, s, k, wsplit, hdr, nbuf);       \
     else hipLaunchKernelGGL((conv1d_split_kernel<WM_, WN_, NTW_, TR_, false>), grid, dim3(256), lds, s, k, wsplit, hdr, nbuf);          \
   } while (0)
 #define MB_SLAUNCH(WM_, WN_, NTW_)                                          \

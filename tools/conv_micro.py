@@ -16,7 +16,7 @@ a.d_x, a.d_wpacked, a.d_y = x.data_ptr(), pw.data_ptr(), y.data_ptr()
 a.x_bstride, a.y_bstride, a.res_bstride = Cin * T, Cout * T, Cout * T
 a.batch, a.c_in, a.c_out, a.t_in, a.t_out = B, Cin, Cout, T, T
 a.ksize, a.dilation, a.pad, a.up = k, dil, (k - 1) * dil // 2, 1
-a.in_act, a.in_slope, a.in_scale, a.out_scale, a.in_repeat = 1, 0.1, 1.0, 1.0, 1
+a.in_act, a.in_slope, a.in_scale, a.out_scale, a.in_repeat = (2 if os.environ.get("POOL") == "1" else 1), 0.1, 1.0, 1.0, 1  # POOL=1: MaxPool1d(2, 1, 1)[:T] fused into the input (the CBHG projections)
 for dbg in os.environ.get("DBGS", "0").split(","):
     os.environ["MBHIP_CONV_SPLIT_DBG"] = dbg
     for _ in range(3):
