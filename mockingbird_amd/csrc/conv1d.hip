@@ -230,7 +230,8 @@ __device__ __forceinline__ void split_store2(char* row, const int grp, const flo
 
 template <int WM, int WN, int NTW, bool TR, bool POOL>
 __device__ __forceinline__ void conv1d_split_body(const ConvK& a, const uint4* __restrict__ wsplit, const float* __restrict__ whdr, const int nbuf, char* slds) {
-  static_assert(32 * NTW * WN == SNT, "tile shape");
+  constexpr int SNT = 32 * NTW * WN;  // output positions of this instance's workgroup: 128, or 32 for short rows (shadows the default)
+  static_assert(SNT == 128 || SNT == 32, "tile shape");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int p = blockIdx.z % a.up, b = blockIdx.z / a.up;
@@ -637,8 +638,13 @@ extern "C" int mb_conv1d(const mb_conv1d_args* a, mb_stream_t stream) {
     // 128 output positions per workgroup; waves along the output channels when there are enough of them (A fragments are
     // then reused over 4 position tiles), else along time
     const int wm = n_mt >= 4 ? 4 : (n_mt >= 2 ? 2 : 1);
-    dim3 grid(cdiv(tq, SNT), cdiv(n_mt, wm), a->batch * a->up);
-    const int rowlen = SNT * k.down + k.span;
+    // Short rows (the Tacotron encoder's 100-odd text positions, 32 utterances: 32 workgroups of 128 positions on 256 compute
+    // units): 32 positions per workgroup instead -- the same sums in the same order, four times the workgroups.
+    const int wgs128 = cdiv(tq, SNT) * cdiv(n_mt, wm) * a->batch * a->up;
+    const bool narrow = wm == 4 && wgs128 < diag_int("conv_narrow_below", 256);
+    const int snt = narrow ? 32 : SNT;
+    dim3 grid(cdiv(tq, snt), cdiv(n_mt, wm), a->batch * a->up);
+    const int rowlen = snt * k.down + k.span;
     const int l2 = diag_int("conv_lds2", -1);  // A/B: force one (0) or two (1) x-tile buffers
     int nbuf = l2 >= 0 ? (l2 == 1 && k.c_in > SCK ? 2 : 1) : (k.c_in >= 512 ? 2 : 1);
     if ((size_t)nbuf * rowlen * SROW > 64 * 1024) nbuf = 1;  // two buffers of a long window (rowlen > 227) would pass the 64 KB a
@@ -656,7 +662,8 @@ extern "C" int mb_conv1d(const mb_conv1d_args* a, mb_stream_t stream) {
     if (a->transpose_out) MB_SLAUNCH2(WM_, WN_, NTW_, true);                \
     else MB_SLAUNCH2(WM_, WN_, NTW_, false);                                \
   } while (0)
-      if (wm == 4) MB_SLAUNCH(4, 1, 4);
+      if (narrow) MB_SLAUNCH(4, 1, 1);
+      else if (wm == 4) MB_SLAUNCH(4, 1, 4);
       else if (wm == 2) MB_SLAUNCH(2, 2, 2);
       else MB_SLAUNCH(1, 4, 1);
 #undef MB_SLAUNCH

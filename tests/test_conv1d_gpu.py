@@ -35,14 +35,31 @@ CONV_CASES = [
 ]
 
 
-@pytest.fixture(params=["split", "f32"])
+@pytest.fixture(params=["split", "split_wide_tiles", "f32"])
 def conv_path(request, monkeypatch):
-    """Both conv kernels behind mb_conv1d: the error-compensated fp16 MFMA kernel (default) and the exact fp32-input one."""
+    """The conv kernels behind mb_conv1d: the error-compensated fp16 MFMA kernel (default: 32-position workgroups when 128-position
+    ones would not fill the GPU -- most shapes here -- and, forced, its 128-position form) and the exact fp32-input one."""
+    monkeypatch.delenv("MBHIP_CONV_SPLIT", raising=False)
+    monkeypatch.delenv("MBHIP_DIAG", raising=False)
     if request.param == "f32":
         monkeypatch.setenv("MBHIP_CONV_SPLIT", "0")
-    else:
-        monkeypatch.delenv("MBHIP_CONV_SPLIT", raising=False)
+    elif request.param == "split_wide_tiles":
+        monkeypatch.setenv("MBHIP_DIAG", "conv_narrow_below=0")
     return request.param
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T,k,dil,kw", [(3, 128, 128, 111, 5, 1, {}), (2, 256, 512, 300, 3, 2, {"in_act": 1, "in_slope": 0.1}),
+                                                     (1, 2048, 128, 97, 3, 1, {"in_act": 2}), (2, 128, 256, 70, 16, 1, {"transpose_out": True})])
+def test_short_row_tiles_are_bit_identical(cuda, lib, monkeypatch, B, Cin, Cout, T, k, dil, kw):
+    """Short rows (the Tacotron encoder: 100-odd positions x 32 utterances = 32 workgroups of 128 positions on 256 compute units)
+    run 32-position workgroups: the same sums in the same order -- bit-identical to the 128-position form."""
+    x, w, b = _rand(B, Cin, T, seed=3), _rand(Cout, Cin, k, seed=4) / (Cin * k) ** 0.5, _rand(Cout, seed=5)
+    pad = dil * (k - 1) // 2
+    monkeypatch.delenv("MBHIP_DIAG", raising=False)
+    y_narrow = hiputil.conv1d_hip(x, w, b, dilation=dil, pad=pad, **kw).cpu()
+    monkeypatch.setenv("MBHIP_DIAG", "conv_narrow_below=0")
+    y_wide = hiputil.conv1d_hip(x, w, b, dilation=dil, pad=pad, **kw).cpu()
+    assert not torch.isnan(y_narrow).any() and torch.equal(y_narrow, y_wide)
 
 
 def test_split_kernel_is_fp32_grade(cuda, lib, monkeypatch):
