@@ -188,6 +188,17 @@ def test_fused_prologue_epilogue(cuda, lib):
     assert e["nan"] == 0 and e["max_abs"] < 1e-4, e
 
 
+@pytest.mark.parametrize("slope", [0.0, 1.0, 1.5, -0.2])
+def test_input_leaky_relu_slopes(cuda, lib, slope):
+    """The split kernel applies the input leaky_relu as max(x, slope x) -- exact for slopes in [0, 1] (0 = ReLU, 1 = none); a slope
+    outside that interval must take the exact fp32-input kernel (x > 0 ? x : slope x) instead of returning max's answer."""
+    x, w = _rand(2, 64, 150, seed=21), _rand(64, 64, 3, seed=22) / 14.0
+    ref = F.conv1d(torch.where(x > 0, x, x * slope), w, None, padding=1)
+    y = hiputil.conv1d_hip(x, w, None, pad=1, in_act=1, in_slope=slope)
+    e = hiputil.relerr(y, ref)
+    assert e["nan"] == 0 and e["max_abs"] < 1e-4, (slope, e)
+
+
 def test_relu_bn_and_tanh(cuda, lib):
     x = _rand(1, 80, 90, seed=14)
     w = _rand(96, 80, 3, seed=15) / 15.0
