@@ -40,6 +40,33 @@ def test_gan_forward_matches_oracle(cuda, lib, kind, cfg, uic, frames, batch):
 F16_REL_TOL = 5e-3  # fp16 gate, relative RMS, reported separately
 
 
+@pytest.mark.parametrize("fuse", ["nochain", "units", "none"])
+def test_gan_f32_fuse_levels_agree(cuda, lib, monkeypatch, fuse):
+    """MBHIP_GAN_FUSE (read at create time) on the fp32-result path: every level of fusion is the same generator -- against the
+    oracle at the fp32 gates and within 2e-6 of the default's waveform RMS."""
+    h = synth.small(synth.HIFIGAN_16K, 128)
+    monkeypatch.delenv("MBHIP_GAN_FUSE", raising=False)
+    y0, ref = _run("hifigan", h, 31, 2, seed=7)
+    monkeypatch.setenv("MBHIP_GAN_FUSE", fuse)
+    y1, _ = _run("hifigan", h, 31, 2, seed=7)
+    e = hiputil.relerr(y1, ref)
+    assert e["nan"] == 0 and e["rms"] <= RMS_TOL and e["rel_rms"] <= REL_TOL, e
+    d = (y1.double() - y0.double()).pow(2).mean().sqrt()
+    assert float(d) <= 2e-6 * max(float(y0.double().pow(2).mean().sqrt()), 1e-3), float(d)
+
+
+def test_gan_fuse_switch_rejects_unknown_values(cuda, lib, monkeypatch):
+    """A misspelt MBHIP_GAN_FUSE must fail the create call loudly, not silently run the default."""
+    from mockingbird_amd.vocoder.gan import GanGenerator
+    from mockingbird_amd import _lib
+    h = synth.small(synth.HIFIGAN_16K, 64)
+    st = synth.gan_state(h, "hifigan", seed=1)
+    monkeypatch.setenv("MBHIP_GAN_FUSE", "unit")
+    with pytest.raises(_lib.MbHipError) as ei:
+        GanGenerator(h, st["generator"], 0)
+    assert "MBHIP_GAN_FUSE" in str(ei.value)
+
+
 # the fp16 path stores activations as 16-byte rows of 8 channels: every conv needs c_in % 8 == 0,
 # i.e. upsample_initial_channel >= 128 (HiFi-GAN, 4 halvings) / 256 (Fre-GAN, 5 halvings)
 @pytest.mark.parametrize("kind,cfg,uic,frames,batch", [
