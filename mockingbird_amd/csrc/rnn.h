@@ -208,5 +208,7 @@ int rnn_launch_dual_gru(const RnnK& k0, const RnnK& k1, hipStream_t s);
 int rnn_launch_finish(const Fin1K& f, hipStream_t s);
 // Two LINEAR jobs in one launch (job 0 on the critical path gets the first workgroups); see rnn.hip.
 int rnn_launch_dual_linear(const RnnK& k0, const RnnK& k1, hipStream_t s);
+// MBHIP_RNN_WIDE is unset or one of ts3 | ts2 | ts, optionally :1..3 (callers reject anything else up front)
+bool rnn_wide_switch_valid();
 
 }  // namespace mb

@@ -125,6 +125,15 @@ static int rnn_wide_form(int* nt_forced = nullptr) {  // 3 / 2 / 1
   return strncmp(e, "ts2", 3) == 0 ? 2 : (strncmp(e, "ts3", 3) == 0 ? 3 : (strncmp(e, "ts", 2) == 0 ? 1 : 3));
 }
 static bool rnn_ts3_enabled() { return rnn_wide_form() == 3; }
+bool rnn_wide_switch_valid() {
+  const char* e = getenv("MBHIP_RNN_WIDE");
+  if (!e) return true;
+  std::string form(e), nt;
+  const size_t c = form.find(':');
+  if (c != std::string::npos) { nt = form.substr(c + 1); form = form.substr(0, c); }
+  if (form != "ts3" && form != "ts2" && form != "ts") return false;
+  return c == std::string::npos || nt == "1" || nt == "2" || nt == "3";
+}
 // Column tiles per wave of the register-tiled wide form, 0 = use the first wide form (rnn_body.h TS).
 // 128 row tiles in pieces of 2 make 16 workgroup rows, so the piece must be narrow enough for >= 256 workgroups:
 // 3 column tiles from 44 column tiles up (736 columns: exactly one piece per SIMD), 2 from 28, 1 from 14; narrower

@@ -335,11 +335,13 @@ extern "C" int mb_wavernn_loop_path(int columns, int mode, int production, int h
   return wavernn_pick_path(columns, mode, production, have_q16, resident_cus, dev_failed, resident);
 }
 // MBHIP_WAVERNN_RESIDENT as wavernn_pick_path's `resident`
-static int wavernn_resident_env() {
+static int wavernn_resident_env() {  // -2 = a value that is none of auto | 0 | 1 | exact
   const char* e = getenv("MBHIP_WAVERNN_RESIDENT");
   if (!e || strcmp(e, "auto") == 0) return -1;
   if (strcmp(e, "exact") == 0) return 2;
-  return atoi(e) != 0 ? 1 : 0;
+  if (strcmp(e, "0") == 0) return 0;
+  if (strcmp(e, "1") == 0) return 1;
+  return -2;
 }
 
 static int wavernn_shapes(const mb_wavernn_config* c, std::vector<size_t>* numel) {
@@ -658,6 +660,19 @@ static bool wavernn_chain_has(const char* word) {
   return false;
 }
 static bool wavernn_split_chain() { return !wavernn_chain_has("classic"); }
+// every word of MBHIP_WAVERNN_CHAIN is one of the four (a misspelt switch must not silently run the default)
+static bool wavernn_chain_valid() {
+  const char* e = getenv("MBHIP_WAVERNN_CHAIN");
+  if (!e) return true;
+  for (const char* p = e; *p;) {
+    const char* end = strchr(p, ',');
+    const size_t len = end ? (size_t)(end - p) : strlen(p);
+    const std::string word(p, len);
+    if (word != "fast" && word != "split" && word != "classic" && word != "nofuse") return false;
+    p += len + (end ? 1 : 0);
+  }
+  return true;
+}
 
 static void wavernn_layout(const mb_wavernn* w, const mb_wavernn_plan* p, void* base, WrnLayout* L) {
   const mb_wavernn_config& c = w->cfg;
@@ -792,6 +807,7 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
   // fc3 launch and the next step's input is rebuilt from the argmax word -> 5 launches per step.
   // MOL mode: the fused form exists on the fragment-major chain only (wf_fc3_mol_kernel: fc3 + the mixture sampler in one launch,
   // the sample itself in the slot word); every other configuration of a MOL model keeps the exact 6-launch chain.
+  MB_REQUIRE(wavernn_chain_valid(), "MBHIP_WAVERNN_CHAIN: unknown word in '%s' (fast | split | classic, optionally ,nofuse)", getenv("MBHIP_WAVERNN_CHAIN"));
   const bool fast_ok = wavernn_split_chain() && !wavernn_chain_has("split");
   const bool mol_fast = c.mode == 1 && R == 512 && FC == 512 && C <= 32 && N <= 64 && fast_ok;
   const bool fused = !d_noise && !d_forced && !d_logits_out && !wavernn_chain_has("nofuse") && (c.mode == 0 || mol_fast);
@@ -866,7 +882,9 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
       if (!w->h_abort) MB_HIP(hipHostMalloc((void**)&w->h_abort, sizeof(int), hipHostMallocDefault));
     }
     const bool dev_failed = dev >= 0 && dev < 64 && g_resident_failed[dev];
-    path = wavernn_pick_path(N, c.mode, 1, w->q_fc3.p && w->q_hh1.p ? 1 : 0, w->resident_cus, dev_failed ? 1 : 0, wavernn_resident_env());
+    const int resident_sw = wavernn_resident_env();
+    MB_REQUIRE(resident_sw != -2, "MBHIP_WAVERNN_RESIDENT: unknown value '%s' (auto | 0 | 1 | exact)", getenv("MBHIP_WAVERNN_RESIDENT"));
+    path = wavernn_pick_path(N, c.mode, 1, w->q_fc3.p && w->q_hh1.p ? 1 : 0, w->resident_cus, dev_failed ? 1 : 0, resident_sw);
   }
   const bool pipe = path == MB_WRN_PATH_PIPE || path == MB_WRN_PATH_PIPE16, persist = path == MB_WRN_PATH_PERSIST1;
   const bool q16 = path == MB_WRN_PATH_PIPE16;
@@ -1324,6 +1342,7 @@ static int wavernn_generate_batch_impl(const mb_wavernn* wc, const mb_wavernn_ba
                                        void* d_workspace, size_t workspace_bytes, mb_stream_t stream) {
   mb_wavernn* w = const_cast<mb_wavernn*>(wc);
   MB_REQUIRE(w && plan && h_frames && h_d_mels && h_seeds && d_samples, "wavernn_generate_batch: null pointer");
+  MB_REQUIRE(rnn_wide_switch_valid(), "MBHIP_RNN_WIDE: unknown value '%s' (ts3 | ts2 | ts, optionally :1..3)", getenv("MBHIP_RNN_WIDE"));
   MB_REQUIRE(w->cfg.mode == 0, "wavernn_generate_batch: RAW mode only (the shared loop is the fused-sampler chain); run MOL utterances one by one");
   const int n_utt = plan->n_utt, N = plan->n_folds, S = plan->seq_len;
   WrnBatchLayout L;

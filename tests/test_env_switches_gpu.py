@@ -157,3 +157,28 @@ def test_wavernn_pipe_kernel_keeps_the_sample_stream(wavernn, monkeypatch, frame
     assert wavernn.last_loop_launches == 1, "the resident kernel did not run"
     bad = (base != alt)
     assert torch.equal(base, alt), (int(bad.sum()), int(bad.any(0).nonzero()[0]) if bad.any() else -1, bad.any(1).nonzero().flatten().tolist())
+
+
+@pytest.mark.parametrize("name,value", [("MBHIP_WAVERNN_RESIDENT", "on"), ("MBHIP_WAVERNN_CHAIN", "clasic"), ("MBHIP_WAVERNN_CHAIN", "split,nofused")])
+def test_misspelt_switch_values_fail_loudly(wavernn, monkeypatch, name, value):
+    """A path switch with a value outside its documented set fails the call (MB_EINVAL with the variable's name in the message)
+    instead of silently running the default path."""
+    from mockingbird_amd import _lib
+    mel = torch.from_numpy(synth.wavernn_mel(40, seed=1) / 4.0).cuda()
+    monkeypatch.setenv(name, value)
+    with pytest.raises(_lib.MbHipError) as ei:
+        wavernn.generate_samples(mel, True, 3000, 100, seed=1)
+    assert name in str(ei.value)
+    monkeypatch.delenv(name)
+    assert wavernn.generate_samples(mel, True, 3000, 100, seed=1).shape[0] == 3  # the handle is usable afterwards
+
+
+def test_misspelt_wide_form_fails_loudly(wavernn, monkeypatch):
+    from mockingbird_amd import _lib
+    mels = [torch.from_numpy(synth.wavernn_mel(30, seed=u) / 4.0).cuda() for u in range(2)]
+    monkeypatch.setenv("MBHIP_RNN_WIDE", "ts4")
+    with pytest.raises(_lib.MbHipError) as ei:
+        wavernn.generate_samples_batch(mels, 2000, 200, [1, 2])
+    assert "MBHIP_RNN_WIDE" in str(ei.value)
+    monkeypatch.setenv("MBHIP_RNN_WIDE", "ts2:2")
+    assert len(wavernn.generate_samples_batch(mels, 2000, 200, [1, 2])) == 2
