@@ -699,8 +699,10 @@ def main():
             resident_m = mol.last_loop_launches == 1
             result["wavernn_mol"] = {
                 "workload": f"MOL-mode WaveRNN, mel 80x{F}, batched: {mol.last_plan.n_folds} folds x {mol.last_plan.seq_len} steps; "
-                            + ("ONE resident launch (wavernn_pipe.h: the F3 role is one workgroup that computes the 30 mixture parameters "
-                               "and samples sample_from_discretized_mix_logistic itself)" if resident_m else
+                            + ("ONE resident launch (wavernn_pipe16.h since round 4 -- operand pairs on the fp16 pipe, as the RAW "
+                               "headline: the F3 role is one workgroup that computes the 30 mixture parameters and samples "
+                               "sample_from_discretized_mix_logistic itself; MBHIP_WAVERNN_RESIDENT=exact: wavernn_pipe.h, bit-identical to the chain)"
+                               if resident_m else
                                "5-launch chain with fc3 + sample_from_discretized_mix_logistic fused in one launch (wf_fc3_mol_kernel)"),
                 "sample_loop_ms": mol.last_loop_ms, "us_per_time_step": mol.last_loop_ms * 1e3 / mol.last_plan.seq_len,
                 "loop_launches": mol.last_loop_launches,
@@ -712,7 +714,8 @@ def main():
                     torch.cuda.synchronize()
                     result["wavernn_mol"]["chain_reference"] = {
                         "us_per_time_step": mol.last_loop_ms * 1e3 / mol.last_plan.seq_len, "loop_launches": mol.last_loop_launches,
-                        "identical_stream": bool(torch.equal(sc, sm))}
+                        "identical_stream": bool(torch.equal(sc, sm)),
+                        "max_abs_diff_first_40_steps": float((sc[:, :40] - sm[:, :40]).abs().max())}
                     del sc
                 finally:
                     os.environ.pop("MBHIP_WAVERNN_RESIDENT", None)

@@ -423,8 +423,8 @@ int mb_wavernn_finish(const float* d_samples, int n_folds, int seq_len, int batc
  *   device that failed before), 2 = "exact": like 1 with the exact fp32 kernel instead of the operand-pair one. */
 #define MB_WRN_PATH_CHAIN 0     /* the 5-launch chain (csrc/wavernn_fast.h), hipGraph replays                          */
 #define MB_WRN_PATH_PERSIST1 1  /* one column: wf_persist1_kernel (csrc/wavernn_persist.h)                             */
-#define MB_WRN_PATH_PIPE 2      /* 2..32 columns, exact fp32 MFMA: wf_pipe_kernel (csrc/wavernn_pipe.h); MOL models     */
-#define MB_WRN_PATH_PIPE16 3    /* 2..64 columns, 22-bit operand pairs: wf_pipe16_kernel (csrc/wavernn_pipe16.h); RAW  */
+#define MB_WRN_PATH_PIPE 2      /* 2..32 columns, exact fp32 MFMA: wf_pipe_kernel (csrc/wavernn_pipe.h); resident = "exact" */
+#define MB_WRN_PATH_PIPE16 3    /* 2..64 columns, 22-bit operand pairs: wf_pipe16_kernel (csrc/wavernn_pipe16.h); RAW + MOL */
 int mb_wavernn_loop_path(int columns, int mode, int production, int have_q16, int resident_cus, int dev_failed, int resident);
 /* Test hook: the Exp(1) noise the on-device sampler of the production paths draws for `seed`:
  * d_out [steps][folds][n_classes] = E for steps step0 .. step0+steps-1, i.e. exactly the tensor which, passed as d_noise

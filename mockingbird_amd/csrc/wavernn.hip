@@ -311,17 +311,17 @@ static std::atomic<bool> g_resident_failed[64] = {};  // written by whichever ho
 //   dev_failed   a resident launch lost a hand-off on this device before
 //   resident     MBHIP_WAVERNN_RESIDENT: -1 unset (auto), 0 = no resident launch, 1 = resident launch wherever legal (also on a device
 //                that failed before), 2 ("exact") = like 1 with the exact fp32 kernel (wavernn_pipe.h) instead of wavernn_pipe16.h
-// | columns | RAW                                   | MOL                         |
-// | 1       | wf_persist1_kernel                    | launch chain                |
-// | 2..32   | wf_pipe16_kernel; exact: wf_pipe      | wf_pipe_kernel              |
-// | 33..64  | wf_pipe16_kernel; exact: chain        | launch chain                |
+// | columns | RAW                                   | MOL                                   |
+// | 1       | wf_persist1_kernel                    | launch chain                          |
+// | 2..32   | wf_pipe16_kernel; exact: wf_pipe      | wf_pipe16_kernel; exact: wf_pipe      |
+// | 33..64  | wf_pipe16_kernel; exact: chain        | wf_pipe16_kernel; exact: chain        |
 // | > 64    | launch chain (mb_wavernn_generate_batch's wide GEMMs serve several utterances)   |
 // and the launch chain whenever production == 0, the device offers fewer units than the kernel has workgroups (224 / 192), resident
 // = 0, or the device failed before and the switch does not ask explicitly.
 int wavernn_pick_path(int columns, int mode, int production, int have_q16, int resident_cus, int dev_failed, int resident) {
   if (!production || columns < 1 || resident == 0) return MB_WRN_PATH_CHAIN;
   if (dev_failed && resident < 0) return MB_WRN_PATH_CHAIN;
-  const bool q16 = mode == 0 && have_q16 && resident != 2;
+  const bool q16 = have_q16 && resident != 2;  // (both sampler modes: the MOL F3 role exists on both resident kernels)
   if (columns >= 2) {
     if (columns > (q16 ? WQ_GMAX : WQ_G) * WQ_GC) return MB_WRN_PATH_CHAIN;
     if (resident_cus < WQ_WGS) return MB_WRN_PATH_CHAIN;
@@ -852,7 +852,7 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
   };
   // Resident forms of the loop: ONE launch for the whole utterance, every weight tile in LDS, granule hand-offs between
   // the layers, same sample stream as the chain.
-  //   * wf_pipe16_kernel (wavernn_pipe16.h, RAW models) / wf_pipe_kernel (wavernn_pipe.h, MOL models and MBHIP_WAVERNN_RESIDENT=exact), 2..64 / 2..32 fold
+  //   * wf_pipe16_kernel (wavernn_pipe16.h, RAW and MOL models) / wf_pipe_kernel (wavernn_pipe.h, MBHIP_WAVERNN_RESIDENT=exact or no fp16 images), 2..64 / 2..32 fold
   //     columns: role-specialised workgroups, column groups in flight.
   //   * wf_persist1_kernel (wavernn_persist.h): one column (batched=False).  MBHIP_WAVERNN_RESIDENT=0 keeps the chain for both.
   //   The choice is wavernn_pick_path's table (above).

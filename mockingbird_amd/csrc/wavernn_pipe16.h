@@ -1,5 +1,5 @@
 // Round 4: the resident pipelined WaveRNN kernel of wavernn_pipe.h with its exchange vectors and its products on 22-bit
-// operand pairs -- the benchmarked path for 2..32 fold columns of a RAW-mode model (BASELINE configs[1]: 23 folds).
+// operand pairs -- the benchmarked path for 2..64 fold columns (BASELINE configs[1]: 23 folds of a RAW-mode model; MOL-mode models run it too).
 //
 // What round 3's wall-clock marks said about wf_pipe_kernel (profiles/r04_wavernn_pipe_marks.json, 14.3 us per step on that box):
 // an edge is NOT latency -- a producer's store is noticed by the watching lane 0.3 us later -- it is the SWEEP: every consumer
@@ -20,7 +20,7 @@
 //     instead of 16 of 32.
 // The sample stream is therefore NOT bit-identical to the launch chain's / wf_pipe_kernel's any more (VERDICT r03 item 3 allows
 // that); it is held to the oracle itself: tests/test_wavernn_gpu.py::test_production_* replay the reference loop body on the device's
-// own history with the exported noise.  MBHIP_WAVERNN_RESIDENT=exact selects the exact kernel (wavernn_pipe.h, the A/B partner and the MOL path).
+// own history with the exported noise.  MBHIP_WAVERNN_RESIDENT=exact selects the exact kernel (wavernn_pipe.h, the A/B partner).
 // Roles, item order, deadlock argument, bail-outs: wavernn_pipe.h's, unchanged.  Column groups: two for 2..32 columns as there; THREE or
 // FOUR for 33..64 columns (fold_with_overlap has no limit, fatchord_version.py:288-338: an utterance beyond ~1400 mel frames used to
 // drop to the launch chain) -- a workgroup serves the groups in turn, the period stays the trip of ONE group while its items fit.
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int du = lane >> 4, i = lane & 15;
   const int H = a.R, S = a.S;
-  const int n_t3 = a.C / 16;  // fc3 workgroups
+  const int n_t3 = a.mol ? 1 : a.C / 16;  // fc3 workgroups (MOL: one, holding both row tiles of the <= 32 mixture parameters)
   constexpr int LD = WQ_GC;   // rows of 16 columns: one 128-byte line per feature pair (and per key half)
   int rb = 0;                 // red buffer of the next GEMM
   auto EX = [&](int what, int g, unsigned tag) { return a.ex + ((size_t)g * 2 + (tag & 1)) * WQX_PER + what; };
@@ -270,7 +270,20 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
         //      fetch and max them into LDS, ONE barrier, and every finish lane decodes its column's sample itself; the slots are cleared
         //      behind the next barrier of this item (the h1 gather's), which every reader has passed by then ----
         float x = 0.f;
-        if (s > 0) {
+        if (s > 0 && a.mol) {  // MOL (fatchord_version.py:213-220): the key word IS the sample -- one classic granule per column from the one F3 workgroup
+          if (tid < Ng) {
+            unsigned xv[1];
+            if (!wp_wait<1>(EX(WQX_KEY, g, tag_prev) + tid, 1, tag_prev, xv, a.abort_word)) return;
+            s_x[g * WQ_GC + tid] = __uint_as_float(xv[0]);
+            if (blk == 0) {
+              a.samples[(size_t)(n0 + tid) * S + (s - 1)] = __uint_as_float(xv[0]);
+              if (a.progress && n0 + tid == 0 && (s - 1) % 100 == 0) *a.progress = s;
+            }
+          }
+          __syncthreads();
+          WQ_MARK(0, 1);
+          if (wave < 2) x = i < Ng ? s_x[g * WQ_GC + i] : 0.f;
+        } else if (s > 0) {
           const unsigned long long* K = EX(WQX_KEY, g, tag_prev);
           wp_watch<1>(K + (size_t)((n_t3 - 1) * 2 + 1) * LD + (Ng - 1), tag_prev, a.abort_word);
           if (tid < 32 * Ng && (tid & 31) < n_t3) {
@@ -409,10 +422,20 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
   const int fr = (blk - WQ_R1 - WQ_R2) / WQ_F, ft = (blk - WQ_R1 - WQ_R2) % WQ_F;  // role 0 / 1 / 2, row tile
   const bool mark_wg = ft == 0;
   if (fr == 2 && ft >= n_t3) return;
-  Wq16A A0;
+  const bool f3mol = fr == 2 && a.mol;
+  Wq16A A0, A1;
   wq16_load_a(fr == 0 ? k16.h_fc1 : fr == 1 ? k16.h_fc2 : k16.h_fc3, ft, A0);
+  wq16_load_a(k16.h_fc3, f3mol ? 1 : 0, A1);  // (MOL: the second row tile of the mixture parameters; unused otherwise)
   const float us = fr == 0 ? k16.us_fc1 : fr == 1 ? k16.us_fc2 : k16.us_fc3;
-  const float4 b3q = fr == 2 ? *reinterpret_cast<const float4*>(a.b_fc3 + ft * 16 + du * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 b3q = fr == 2 && !a.mol ? *reinterpret_cast<const float4*>(a.b_fc3 + ft * 16 + du * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float bmol[4] = {0.f, 0.f, 0.f, 0.f};  // MOL: bias of rows wave * 16 + du * 4 + r (waves 0 / 1 = the two row tiles)
+  if (f3mol && wave < 2) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wave * 16 + du * 4 + r;
+      bmol[r] = row < a.C ? a.b_fc3[row] : 0.f;
+    }
+  }
   float4 fpre[WQ_GMAX];
   int f_row[WQ_GMAX];
 #pragma unroll
@@ -433,7 +456,7 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
           fpre[g] = *reinterpret_cast<const float4*>((fr == 0 ? a.F1 : a.F2) + (size_t)frow * a.FC + ft * 16 + du * 4);
           f_row[g] = frow;
         }
-      } else if (wave == 0) {  // the step's Gumbel noise does not depend on the data: drawn before the wait
+      } else if (wave == 0 && !a.mol) {  // the step's Gumbel noise does not depend on the data: drawn before the wait
         uint32_t grn[4];
         philox4x32((uint32_t)s, (uint32_t)ncl, (uint32_t)((ft * 16 + du * 4) >> 2), 0x57415645u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), grn);
 #pragma unroll
@@ -444,6 +467,46 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
       if (!wq16_gather<1>(EX(src, g, tag), tag, Ng, bh, bl, a.abort_word, WQ_MK(2 + fr, 6))) return;
       WQ_MARK(2 + fr, 1);
       float sx[4];
+      if (f3mol) {
+        // ---- MOL: both row tiles against the gathered y2, the mixture parameters of the group's columns through LDS (the red half the
+        //      NEXT product will use: free until the barrier of its gather), then wf_fc3_mol_kernel's sampler per column -- same
+        //      Philox words, same expressions -- and the sample itself as the key (wavernn_pipe.h's F3, on this kernel's products) ----
+        const bool epi2 = wq16_gemm2(A0, A1, bh, bl, red + rb * 4096, us, sx);
+        rb ^= 1;
+        float* lg = red + rb * 4096;  // [16 columns][33]
+        if (epi2) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lg[i * 33 + wave * 16 + du * 4 + r] = sx[r] + bmol[r];
+        }
+        __syncthreads();
+        WQ_MARK(2 + fr, 3);
+        if (tid < Ng) {
+          const float* l = lg + tid * 33;
+          const int M = a.nr_mix, n = n0 + tid;
+          float best = -INFINITY, uu = 0.5f;
+          int bidx = 0;
+          for (int q = 0; q <= M / 4; ++q) {  // draws 0 .. M: M mixture-indicator uniforms, then the logistic one
+            uint32_t rr[4];
+            philox4x32((uint32_t)s, (uint32_t)n, (uint32_t)q, 0x4d4f4c21u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), rr);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int m = q * 4 + e;
+              const float u = 1e-5f + (1.0f - 2e-5f) * u32_to_unit(rr[e]);  // uniform_(1e-5, 1 - 1e-5)
+              if (m < M) {
+                const float v = l[m] - logf(-logf(u));
+                if (v > best) { best = v; bidx = m; }  // first maximum on ties
+              } else if (m == M) uu = u;
+            }
+          }
+          const float mean = l[M + bidx];
+          const float ls = fmaxf(l[2 * M + bidx], -32.23619130191664f);  // log(1e-14)
+          float x = mean + expf(ls) * (logf(uu) - logf(1.f - uu));
+          x = fminf(fmaxf(x, -1.f), 1.f);
+          wp_put(EX(WQX_KEY, g, tag) + tid, x, tag);
+        }
+        WQ_MARK(2 + fr, 2);
+        continue;
+      }
       const bool epi = wq16_gemm1(A0, bh, bl, red + rb * 4096, us, sx, WQ_MK(2 + fr, 7));
       rb ^= 1;
       WQ_MARK(2 + fr, 3);

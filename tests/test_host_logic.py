@@ -265,7 +265,8 @@ def test_wavernn_loop_path_table(lib):
         (2, 0, 1, 1, 256, 0, U, PIPE16), (23, 0, 1, 1, 256, 0, U, PIPE16), (32, 0, 1, 1, 256, 0, U, PIPE16),
         (33, 0, 1, 1, 256, 0, U, PIPE16), (64, 0, 1, 1, 256, 0, U, PIPE16), (65, 0, 1, 1, 256, 0, U, CHAIN), (65, 0, 1, 1, 256, 0, ON, CHAIN),
         (23, 0, 1, 1, 256, 0, EXACT, PIPE), (33, 0, 1, 1, 256, 0, EXACT, CHAIN),                                      # the exact kernel: 32 columns
-        (23, 0, 1, 0, 256, 0, U, PIPE), (23, 1, 1, 1, 256, 0, U, PIPE), (40, 1, 1, 1, 256, 0, U, CHAIN),              # no images / MOL
+        (23, 0, 1, 0, 256, 0, U, PIPE), (23, 1, 1, 1, 256, 0, U, PIPE16), (40, 1, 1, 1, 256, 0, U, PIPE16),           # no images / MOL
+        (23, 1, 1, 1, 256, 0, EXACT, PIPE), (40, 1, 1, 1, 256, 0, EXACT, CHAIN), (23, 1, 1, 0, 256, 0, U, PIPE),
         (23, 0, 1, 1, 256, 0, OFF, CHAIN), (23, 0, 1, 1, 256, 0, ON, PIPE16),
         (23, 0, 1, 1, 223, 0, U, CHAIN), (23, 0, 1, 1, 224, 0, U, PIPE16), (23, 0, 1, 1, 0, 0, ON, CHAIN),            # 224 workgroups
         (23, 0, 1, 1, 256, 1, U, CHAIN), (23, 0, 1, 1, 256, 1, ON, PIPE16),                                           # failure memo
