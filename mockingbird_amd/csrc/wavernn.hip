@@ -873,11 +873,15 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
       MB_HIP(hipGetDeviceProperties(&prop, dev));
       MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_persist1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WP1_LDS_BYTES));
       MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_pipe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WQ_LDS_BYTES));
-      MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_pipe16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WQ16_LDS_BYTES));
+      MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_pipe16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WQ16_LDS_BYTES));
+      MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_pipe16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WQ16_LDS_BYTES));
       int nb1 = 0, nb2 = 0, nb3 = 0;
       MB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, reinterpret_cast<const void*>(wf_persist1_kernel), 512, WP1_LDS_BYTES));
       MB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, reinterpret_cast<const void*>(wf_pipe_kernel), 512, WQ_LDS_BYTES));
-      MB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb3, reinterpret_cast<const void*>(wf_pipe16_kernel), 512, WQ16_LDS_BYTES));
+      int nb3m = 0;
+      MB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb3, reinterpret_cast<const void*>(wf_pipe16_kernel<false>), 512, WQ16_LDS_BYTES));
+      MB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb3m, reinterpret_cast<const void*>(wf_pipe16_kernel<true>), 512, WQ16_LDS_BYTES));
+      nb3 = std::min(nb3, nb3m);
       w->resident_cus = (nb1 >= 1 && nb2 >= 1 && nb3 >= 1) ? prop.multiProcessorCount : 0;
       if (!w->h_abort) MB_HIP(hipHostMalloc((void**)&w->h_abort, sizeof(int), hipHostMallocDefault));
     }
@@ -926,7 +930,8 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
         k16.h_hh1 = reinterpret_cast<const uint4*>(w->q_hh1.p); k16.h_fc1 = reinterpret_cast<const uint4*>(w->q_fc1.p);
         k16.h_fc2 = reinterpret_cast<const uint4*>(w->q_fc2.p); k16.h_fc3 = reinterpret_cast<const uint4*>(w->q_fc3.p);
         k16.us_rnn2 = w->q_us[0]; k16.us_hh2 = w->q_us[1]; k16.us_hh1 = w->q_us[2]; k16.us_fc1 = w->q_us[3]; k16.us_fc2 = w->q_us[4]; k16.us_fc3 = w->q_us[5];
-        hipLaunchKernelGGL(wf_pipe16_kernel, dim3(WQ_WGS), dim3(512), WQ16_LDS_BYTES, s, k16);
+        if (c.mode == 1) hipLaunchKernelGGL(wf_pipe16_kernel<true>, dim3(WQ_WGS), dim3(512), WQ16_LDS_BYTES, s, k16);
+        else hipLaunchKernelGGL(wf_pipe16_kernel<false>, dim3(WQ_WGS), dim3(512), WQ16_LDS_BYTES, s, k16);
       } else
       hipLaunchKernelGGL(wf_pipe_kernel, dim3(WQ_WGS), dim3(512), WQ_LDS_BYTES, s, qk);
     } else {

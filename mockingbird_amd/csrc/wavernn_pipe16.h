@@ -217,6 +217,9 @@ __device__ __forceinline__ bool wq16_gemm2(const Wq16A& A0, const Wq16A& A1, con
 // LDS (floats): [red: two 4096-float buffers, alternating] [keys / samples / residual hand-over]
 constexpr size_t WQ16_LDS_BYTES = (size_t)WQ_LDS_RED * 4 + WQ_GMAX * WQ_GC * 8 + WQ_GC * 4 + 8 * 16 * 4 + 64;
 
+// MOL: the sampler mode is a compile-time property (a run-time `a.mol` next to the RAW path cost the headline 0.27 us per step: one
+// more fragment set live in the F roles, a branch per item)
+template <bool MOL>
 __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
   const WqK& a = k16.q;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int du = lane >> 4, i = lane & 15;
   const int H = a.R, S = a.S;
-  const int n_t3 = a.mol ? 1 : a.C / 16;  // fc3 workgroups (MOL: one, holding both row tiles of the <= 32 mixture parameters)
+  const int n_t3 = MOL ? 1 : a.C / 16;  // fc3 workgroups (MOL: one, holding both row tiles of the <= 32 mixture parameters)
   constexpr int LD = WQ_GC;   // rows of 16 columns: one 128-byte line per feature pair (and per key half)
   int rb = 0;                 // red buffer of the next GEMM
   auto EX = [&](int what, int g, unsigned tag) { return a.ex + ((size_t)g * 2 + (tag & 1)) * WQX_PER + what; };
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
         //      fetch and max them into LDS, ONE barrier, and every finish lane decodes its column's sample itself; the slots are cleared
         //      behind the next barrier of this item (the h1 gather's), which every reader has passed by then ----
         float x = 0.f;
-        if (s > 0 && a.mol) {  // MOL (fatchord_version.py:213-220): the key word IS the sample -- one classic granule per column from the one F3 workgroup
+        if (MOL && s > 0) {  // MOL (fatchord_version.py:213-220): the key word IS the sample -- one classic granule per column from the one F3 workgroup
           if (tid < Ng) {
             unsigned xv[1];
             if (!wp_wait<1>(EX(WQX_KEY, g, tag_prev) + tid, 1, tag_prev, xv, a.abort_word)) return;
@@ -422,12 +425,13 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
   const int fr = (blk - WQ_R1 - WQ_R2) / WQ_F, ft = (blk - WQ_R1 - WQ_R2) % WQ_F;  // role 0 / 1 / 2, row tile
   const bool mark_wg = ft == 0;
   if (fr == 2 && ft >= n_t3) return;
-  const bool f3mol = fr == 2 && a.mol;
+  const bool f3mol = MOL && fr == 2;
   Wq16A A0, A1;
   wq16_load_a(fr == 0 ? k16.h_fc1 : fr == 1 ? k16.h_fc2 : k16.h_fc3, ft, A0);
-  wq16_load_a(k16.h_fc3, f3mol ? 1 : 0, A1);  // (MOL: the second row tile of the mixture parameters; unused otherwise)
+  if (MOL) wq16_load_a(k16.h_fc3, f3mol ? 1 : 0, A1);  // (MOL: the second row tile of the mixture parameters)
+  else A1 = A0;
   const float us = fr == 0 ? k16.us_fc1 : fr == 1 ? k16.us_fc2 : k16.us_fc3;
-  const float4 b3q = fr == 2 && !a.mol ? *reinterpret_cast<const float4*>(a.b_fc3 + ft * 16 + du * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 b3q = fr == 2 && !MOL ? *reinterpret_cast<const float4*>(a.b_fc3 + ft * 16 + du * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
   float bmol[4] = {0.f, 0.f, 0.f, 0.f};  // MOL: bias of rows wave * 16 + du * 4 + r (waves 0 / 1 = the two row tiles)
   if (f3mol && wave < 2) {
 #pragma unroll
@@ -456,7 +460,7 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
           fpre[g] = *reinterpret_cast<const float4*>((fr == 0 ? a.F1 : a.F2) + (size_t)frow * a.FC + ft * 16 + du * 4);
           f_row[g] = frow;
         }
-      } else if (wave == 0 && !a.mol) {  // the step's Gumbel noise does not depend on the data: drawn before the wait
+      } else if (wave == 0 && !MOL) {  // the step's Gumbel noise does not depend on the data: drawn before the wait
         uint32_t grn[4];
         philox4x32((uint32_t)s, (uint32_t)ncl, (uint32_t)((ft * 16 + du * 4) >> 2), 0x57415645u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), grn);
 #pragma unroll
