@@ -60,6 +60,43 @@ def test_gather_waveforms_world2():
     assert sorted(res) == [(0, True), (1, True)]
 
 
+def _idle_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mockingbird_amd.sharding import gather_waveforms, shard_indices
+    lens = [300, 20, 77]  # fewer utterances than ranks: at least one rank has nothing to do and still has to take part in the gather
+    mine = shard_indices(lens, world, rank)
+    order = [i for r in range(world) for i in shard_indices(lens, world, r)]
+    ok = sorted(order) == [0, 1, 2]
+    local = [np.full(lens[i], float(i + 1), np.float32) for i in mine]
+    out = gather_waveforms(local, device="cpu")
+    if rank == 0:
+        ok = ok and len(out) == 3 and all(len(w) == lens[i] and (w == i + 1).all() for w, i in zip(out, order))
+    else:
+        ok = ok and out == []
+    allr = gather_waveforms([np.full(lens[i], i + 1, np.int16) for i in mine], device="cpu", dst=None)
+    ok = ok and len(allr) == 3 and all(w.dtype == np.int16 and len(w) == lens[i] and (w == i + 1).all() for w, i in zip(allr, order))
+    q.put((rank, ok, len(mine)))
+    dist.destroy_process_group()
+
+
+def test_gather_waveforms_world4_with_idle_ranks():
+    """8 GPUs and 5 requests is an ordinary serving state: ranks without an utterance still enter every collective."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_idle_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert sorted((r, ok) for r, ok, _ in res) == [(0, True), (1, True), (2, True), (3, True)]
+    assert sorted(n for _, _, n in res) == [0, 1, 1, 1]
+
+
 class _StubSynth:
     """Deterministic stand-in for the Synthesizer facade: sentence -> (80, 2*len(text)) spectrogram."""
     sample_rate = 16000
