@@ -172,3 +172,33 @@ def test_pipeline_gen_wavs_world2_matches_single_process(kw):
         assert np.array_equal(np.asarray(a, want_dtype), b)
     if kw:
         assert max(int(np.abs(b).max()) for b in ref) in (32766, 32767)  # save_wav rescales the peak to 32767 and truncates (synthesizer/audio.py:13-15)
+
+
+def _pipeline_worker_few(rank, world, port, q):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mockingbird_amd import pipeline
+    out = pipeline.gen_wavs(_StubSynth(), _StubVocoder(), _requests()[:1], pcm16="save_wav", normalize=0.97)  # ONE request, three sentences at most
+    q.put((rank, [w.tolist() for w in out]))
+    dist.destroy_process_group()
+
+
+def test_pipeline_gen_wavs_more_ranks_than_sentences():
+    """One request on four ranks: ranks without a sentence synthesise nothing, take part in the gather, and rank 0 still gets the
+    request's waveform equal to the single-process result."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from mockingbird_amd import pipeline
+    ref = pipeline.gen_wavs(_StubSynth(), _StubVocoder(), _requests()[:1], pcm16="save_wav", normalize=0.97)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker_few, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(30)
+    assert all(res[r] == [] for r in (1, 2, 3))
+    assert len(res[0]) == 1 and np.array_equal(np.asarray(res[0][0], np.int16), ref[0])
