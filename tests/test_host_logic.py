@@ -317,3 +317,49 @@ def test_diag_variable_parsing(lib, monkeypatch):
     assert get("abort_pr") == "1" and get("abort_wp") is None
     monkeypatch.setenv("MBHIP_DIAG", "")
     assert get("abort_pr") is None
+
+
+def test_resblock_stage_f32_weight_stream_layout(lib):
+    """mb_resblock_stage_f32_pack (CPU only): one stream per 32-row output tile in consumption order [chain][unit][conv1 | conv2][tap]
+    [16-channel k-step][hi | lo | hi 2^-11][lane][8]; (hi + lo) x 2^-s gives the weight back to 2^-21 of the conv's largest weight,
+    the third image is hi 2^-11, the scale puts that largest weight into [2^13, 2^14)."""
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    for ch, ks, nd in ((32, [3, 7], 2), (64, [3], 3), (64, [11], 1)):
+        nk = len(ks)
+        w1 = [rng.standard_normal((ch, ch, ks[c])).astype(np.float32) * (0.02 + 0.3 * c) for c in range(nk) for _ in range(nd)]
+        w2 = [rng.standard_normal((ch, ch, ks[c])).astype(np.float32) * 0.05 for c in range(nk) for _ in range(nd)]
+        ksa = (C.c_int * nk)(*ks)
+        dil = (C.c_int * (nk * nd))(*([1, 3, 5][:nd] * nk))
+        assert lib.mb_resblock_stage_f32_supported(ch, nk, ksa, nd, dil) == 1
+        assert lib.mb_resblock_stage_f32_supported(128, nk, ksa, nd, dil) == 0
+        eff = lib.mb_resblock_stage_f32_efficiency(ch, nk, ksa, nd, dil)
+        assert 0.2 < eff <= 1.0
+        n = lib.mb_resblock_stage_f32_packed_halves(ch, nk, ksa, nd)
+        assert n == (ch // 32) * sum(2 * nd * k for k in ks) * (ch // 16) * 3 * 512
+        packed = np.zeros(n, np.float16)
+        unscale = np.zeros(nk * nd * 2, np.float32)
+        p1 = (C.c_void_p * (nk * nd))(*[w.ctypes.data for w in w1])
+        p2 = (C.c_void_p * (nk * nd))(*[w.ctypes.data for w in w2])
+        assert lib.mb_resblock_stage_f32_pack(p1, p2, ch, nk, ksa, nd, packed.ctypes.data, unscale.ctypes.data) == 0
+        o = 0
+        for mt in range(ch // 32):
+            for c in range(nk):
+                for u in range(nd):
+                    for ph in range(2):
+                        w = (w2 if ph else w1)[c * nd + u]
+                        us = float(unscale[(c * nd + u) * 2 + ph])
+                        wmax = float(np.abs(w).max())
+                        assert 2.0 ** 13 <= wmax / us < 2.0 ** 14 and np.log2(us) == round(np.log2(us))
+                        for j in range(ks[c]):
+                            for kb in range(ch // 16):
+                                blk = packed[o:o + 1536].astype(np.float64).reshape(3, 64, 8)
+                                o += 1536
+                                lane = np.arange(64)[:, None]
+                                e = np.arange(8)[None, :]
+                                co = mt * 32 + (lane & 31)
+                                ci = kb * 16 + (lane >> 5) * 8 + e
+                                ref = w[co, ci, j].astype(np.float64)
+                                assert np.abs((blk[0] + blk[1]) * us - ref).max() <= wmax * 2.0 ** -21
+                                assert np.array_equal(blk[2], (blk[0] / 2048.0).astype(np.float16).astype(np.float64))
+        assert o == n
