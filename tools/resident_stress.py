@@ -1,4 +1,4 @@
-"""Stress of the resident (one-launch) loops' hand-offs -- wf_pipe16_kernel (23 fold columns), wf_pipe_kernel (the exact kernel),
+"""Stress of the resident (one-launch) loops' hand-offs -- wf_pipe16_kernel (23 fold columns, RAW and MOL models), wf_pipe_kernel (the exact kernel),
 wf_persist1_kernel (one column), ppg_resident_kernel (ppg2mel, one utterance): the same call many times, alone and while another
 stream keeps the GPU busy with GEMMs of varying size (uneven load, workgroups competing for compute units).  Every run must either
 reproduce the quiet resident run bit for bit (the kernels are deterministic) or -- if the launch lost a hand-off and drained -- equal
@@ -12,19 +12,25 @@ from mockingbird_amd.vocoder.wavernn.inference import WaveRNNDevice
 from mockingbird_amd.ppg2mel import Ppg2MelDecoder
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 9
 dev = WaveRNNDevice(synth.wavernn_state(seed=1)["model_state"])
+import types
+from mockingbird_amd.vocoder.wavernn import hparams as _whp
+_hpm = types.SimpleNamespace(**{k: getattr(_whp, k) for k in dir(_whp) if not k.startswith("_")})
+_hpm.voc_mode = "MOL"
+dev_mol = WaveRNNDevice(synth.wavernn_state(synth.WAVERNN_HP_MOL, seed=6)["model_state"], _hpm)
 dec = Ppg2MelDecoder(synth.ppg2mel_decoder_state(synth.PPG2MEL_HP, seed=3, stop_bias=-6.0), synth.PPG2MEL_HP)
 mel23 = torch.from_numpy(synth.wavernn_mel(120, seed=0) / 4.0).cuda()   # 23 x 1100-step folds at target 1000 / overlap 50? (see columns below)
 mel1 = torch.from_numpy(synth.wavernn_mel(12, seed=0) / 4.0).cuda()
 mem = torch.from_numpy(synth.ppg2mel_memory(1, 60, seed=2)).cuda()
 
 
-def wrn(mel, batched, env):
+def wrn(mel, batched, env, d=None):
+    d = d or dev
     for k in ("MBHIP_WAVERNN_RESIDENT",):
         os.environ.pop(k, None)
     os.environ.update(env)
-    out = dev.generate_samples(mel, batched, 1000, 50, seed=9)
+    out = d.generate_samples(mel, batched, 1000, 50, seed=9)
     torch.cuda.synchronize()
-    return out.clone(), dev.last_loop_launches
+    return out.clone(), d.last_loop_launches
 
 
 def ppg(env):
@@ -38,6 +44,7 @@ def ppg(env):
 CASES = {
     "wavernn_pipe16": (lambda env: wrn(mel23, True, env), {"MBHIP_WAVERNN_RESIDENT": "1"}, {"MBHIP_WAVERNN_RESIDENT": "0"}),
     "wavernn_pipe_exact": (lambda env: wrn(mel23, True, env), {"MBHIP_WAVERNN_RESIDENT": "exact"}, {"MBHIP_WAVERNN_RESIDENT": "0"}),
+    "wavernn_pipe16_mol": (lambda env: wrn(mel23, True, env, dev_mol), {"MBHIP_WAVERNN_RESIDENT": "1"}, {"MBHIP_WAVERNN_RESIDENT": "0"}),
     "wavernn_one_column": (lambda env: wrn(mel1, False, env), {"MBHIP_WAVERNN_RESIDENT": "1"}, {"MBHIP_WAVERNN_RESIDENT": "0"}),
     "ppg2mel_resident": (ppg, {"MBHIP_PPG_RESIDENT": "1"}, {"MBHIP_PPG_RESIDENT": "0"}),
 }
