@@ -118,16 +118,20 @@ __device__ __forceinline__ bool wq16_gather(const unsigned long long* vec, const
   for (int st = 0; st < 2; ++st) { bh[st] = (wh16x8)(wh16)0.f; bl[st] = (wh16x8)(wh16)0.f; }
   if (i >= N) return true;
   const unsigned long long* base = vec + ((size_t)(wave * 32 + kb * 4) * WQ_GC + i);
+  const unsigned e_lo = (t2 & 1u) << 16, e_hi = (t2 >> 1) << 16;  // the tag's two bits where the granule's halves carry them
   unsigned long long v[8];
   unsigned long long t0 = 0;
   for (int tries = 0;; ++tries) {
-    bool ok = true;
 #pragma unroll
     for (int st = 0; st < 2; ++st)
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[st * 4 + j] = wp_get(base + (size_t)(st * 16 + j) * WQ_GC);
+    // all eight tags in one xor / or chain (bit 16 of either half differs from the expected tag bit -> stale): eight short-circuit
+    // tests compiled to eight nested exec-mask branches, ~ 80 instructions per lane and sweep
+    unsigned stale = 0u;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) ok = ok && wq16_fresh(v[q], t2);
+    for (int q = 0; q < 8; ++q) stale |= ((unsigned)v[q] ^ e_lo) | ((unsigned)(v[q] >> 32) ^ e_hi);
+    const bool ok = (stale & 0x10000u) == 0u;
     if (ok) break;
     if ((tries & 1023) == 1023 && wp_lost(tries, t0, abort_word)) return false;
     __builtin_amdgcn_s_sleep(1);
