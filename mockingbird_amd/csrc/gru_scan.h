@@ -176,8 +176,12 @@ __global__ __launch_bounds__(NW * 64) void gru_scan_kernel(GruScanK a) {
           }
       };
       bool ok = true;
+      {  // all tags in one xor / or chain (a chain of && compiled to nested exec-mask branches, wavernn_pipe16.h)
+        unsigned stale_ = 0u;
 #pragma unroll
-      for (int q = 0; q < RQ; ++q) ok = ok && (unsigned)(vq[q] >> 32) == tag;
+        for (int q = 0; q < RQ; ++q) stale_ |= (unsigned)(vq[q] >> 32) ^ tag;
+        ok = ok && stale_ == 0u;
+      }
       if (ok) to_lds();  // (the use of the loaded values stays on the straight-line path too: behind the join the compiler waits for everything again)
       else {
         unsigned long long t0 = 0;
@@ -185,8 +189,12 @@ __global__ __launch_bounds__(NW * 64) void gru_scan_kernel(GruScanK a) {
           __builtin_amdgcn_s_sleep(1);
           poll_issue(nt, s);
           ok = true;
+          {  // all tags in one xor / or chain (a chain of && compiled to nested exec-mask branches, wavernn_pipe16.h)
+            unsigned stale_ = 0u;
 #pragma unroll
-          for (int q = 0; q < RQ; ++q) ok = ok && (unsigned)(vq[q] >> 32) == tag;
+            for (int q = 0; q < RQ; ++q) stale_ |= (unsigned)(vq[q] >> 32) ^ tag;
+            ok = ok && stale_ == 0u;
+          }
           if (ok) break;
           if ((tries & 1023) == 1023 && wp_lost(tries, t0, a.abort_word)) return false;
         }

@@ -172,8 +172,12 @@ __device__ __forceinline__ bool pr_poll(const unsigned long long* vec, const uns
 #pragma unroll
         for (int i = 0; i < NG; ++i) v[i] = wp_get(vec + i * 64 + lane);
         bool ok = true;
+        {  // all tags in one xor / or chain (a chain of && compiled to nested exec-mask branches, wavernn_pipe16.h)
+          unsigned stale_ = 0u;
 #pragma unroll
-        for (int i = 0; i < NG; ++i) ok = ok && (unsigned)(v[i] >> 32) == tag;
+          for (int i = 0; i < NG; ++i) stale_ |= (unsigned)(v[i] >> 32) ^ tag;
+          ok = ok && stale_ == 0u;
+        }
         if (__all(ok)) break;
         if ((tries & 7) == 7 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { if (lane == 0) *s_flag = 1; break; }
         if ((tries & 1023) == 1023 && wp_lost(tries, t0, abort_word)) { if (lane == 0) *s_flag = 1; break; }

@@ -62,8 +62,12 @@ __device__ __forceinline__ bool wp_wait(const unsigned long long* p, const size_
     bool ok = true;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) v[q] = wp_get(p + q * stride);
+    {  // all tags in one xor / or chain (a chain of && compiled to nested exec-mask branches, wavernn_pipe16.h)
+      unsigned stale_ = 0u;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) ok = ok && (unsigned)(v[q] >> 32) == tag;
+      for (int q = 0; q < NQ; ++q) stale_ |= (unsigned)(v[q] >> 32) ^ tag;
+      ok = ok && stale_ == 0u;
+    }
     if (ok) break;
     if ((tries & 1023) == 1023 && wp_lost(tries, t0, abort_word)) return false;
     __builtin_amdgcn_s_sleep(1);
@@ -83,8 +87,12 @@ template <int NQ>
 __device__ __forceinline__ bool wp_take(const unsigned long long* p, const size_t stride, const unsigned tag, const unsigned long long (&v)[NQ],
                                         unsigned (&out)[NQ], int* abort_word) {
   bool ok = true;
+  {  // all tags in one xor / or chain (a chain of && compiled to nested exec-mask branches, wavernn_pipe16.h)
+    unsigned stale_ = 0u;
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) ok = ok && (unsigned)(v[q] >> 32) == tag;
+    for (int q = 0; q < NQ; ++q) stale_ |= (unsigned)(v[q] >> 32) ^ tag;
+    ok = ok && stale_ == 0u;
+  }
   if (!ok) return wp_wait<NQ>(p, stride, tag, out, abort_word);
 #pragma unroll
   for (int q = 0; q < NQ; ++q) out[q] = (unsigned)v[q];
@@ -127,8 +135,12 @@ __device__ __forceinline__ bool wp_gather(const unsigned long long* vec, const u
     for (int p = 0; p < 4; ++p)
 #pragma unroll
       for (int c = 0; c < 4; ++c) v[p * 4 + c] = wp_get(base + ((size_t)p * 128 + c) * N);
+    {  // all tags in one xor / or chain (a chain of && compiled to nested exec-mask branches, wavernn_pipe16.h)
+      unsigned stale_ = 0u;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) ok = ok && (unsigned)(v[q] >> 32) == tag;
+      for (int q = 0; q < 16; ++q) stale_ |= (unsigned)(v[q] >> 32) ^ tag;
+      ok = ok && stale_ == 0u;
+    }
     if (ok) break;
     if ((tries & 1023) == 1023 && wp_lost(tries, t0, abort_word)) return false;
     __builtin_amdgcn_s_sleep(1);

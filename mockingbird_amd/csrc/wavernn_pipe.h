@@ -81,8 +81,12 @@ __device__ __forceinline__ bool wq_gather(const unsigned long long* vec, const u
     for (int p = 0; p < 4; ++p)
 #pragma unroll
       for (int c = 0; c < 4; ++c) v[p * 4 + c] = wp_get(base + ((size_t)p * 128 + c) * LD);
+    {  // all tags in one xor / or chain (a chain of && compiled to nested exec-mask branches, wavernn_pipe16.h)
+      unsigned stale_ = 0u;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) ok = ok && (unsigned)(v[q] >> 32) == tag;
+      for (int q = 0; q < 16; ++q) stale_ |= (unsigned)(v[q] >> 32) ^ tag;
+      ok = ok && stale_ == 0u;
+    }
     if (ok) break;
     if ((tries & 1023) == 1023 && wp_lost(tries, t0, abort_word)) return false;
     __builtin_amdgcn_s_sleep(1);
