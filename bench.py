@@ -106,6 +106,24 @@ def _median(xs):
     return xs[len(xs) // 2]
 
 
+KERNEL_STATS_CSV = "r05_bench_kernel_stats.csv"   # rocprofv3 --kernel-trace --stats summary of this command, committed per round
+CPU_BASELINE_THREADS = 8   # one policy for every cpu_baseline leg: min(host threads, 8) -- the reference's eager ops on small batches get
+                           # SLOWER beyond that (WaveRNN's 23-row GEMVs 3x at 128 threads, HiFi-GAN 1 x (80,200) 4.5x); `cores` states it
+
+
+class _cpu_threads:
+    """with _cpu_threads() as n: torch runs on n = min(default, CPU_BASELINE_THREADS) threads inside, the default again outside"""
+    def __enter__(self):
+        self.default = torch.get_num_threads()
+        self.n = min(self.default, CPU_BASELINE_THREADS)
+        torch.set_num_threads(self.n)
+        return self.n
+
+    def __exit__(self, *exc):
+        torch.set_num_threads(self.default)
+        return False
+
+
 def _reference_available():
     try:
         import refimport
@@ -120,14 +138,9 @@ def cpu_baseline_wavernn(state, F, target, overlap, n_useful, plan, cpu_seconds)
     9600 steps).  kind "port": oracle/wavernn.py (the same ATen-CPU ops in the same order) for ~cpu_seconds of the
     same workload.  Threads: min(torch's default, 8) -- the loop is 512-wide GEMVs on 23 rows, which 128 threads make three times
     SLOWER than 8 (VERDICT r03 weak #11: 1 909 samples/s on 128 threads against 5 817 on 8); `cores` says what was used."""
-    import synth
-    default_threads = torch.get_num_threads()
-    threads = min(default_threads, 8)
-    torch.set_num_threads(threads)
-    try:
-        return _cpu_baseline_wavernn(state, F, target, overlap, n_useful, plan, cpu_seconds, threads, default_threads)
-    finally:
-        torch.set_num_threads(default_threads)
+    ct = _cpu_threads()
+    with ct as threads:
+        return _cpu_baseline_wavernn(state, F, target, overlap, n_useful, plan, cpu_seconds, threads, ct.default)
 
 
 def _cpu_baseline_wavernn(state, F, target, overlap, n_useful, plan, cpu_seconds, threads, default_threads):
@@ -207,15 +220,15 @@ def cpu_baseline_hifigan():
         w = og.fold_weight_norm_state(st)
         fwd = lambda: og.hifigan_forward(w, h, mel)  # noqa: E731
     ts = []
-    with torch.no_grad():
+    with torch.no_grad(), _cpu_threads() as threads:
         fwd()
         for _ in range(3):
             t0 = time.perf_counter()
             y = fwd()
             ts.append(time.perf_counter() - t0)
     t = _median(ts)
-    return {"value": y.numel() / t, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": kind,
-            "sample": f"BASELINE configs[0]: generator forward on 1 x (80,200), median of 3 = {t * 1e3:.1f} ms "
+    return {"value": y.numel() / t, "unit": "samples/s", "cores": threads, "kind": kind,
+            "sample": f"BASELINE configs[0]: generator forward on 1 x (80,200), median of 3 = {t * 1e3:.1f} ms on {threads} threads "
                       f"({'the reference Generator' if kind == 'reference' else 'oracle/gan.py, the same ATen-CPU ops'})"}
 
 
@@ -257,15 +270,15 @@ def cpu_baseline_tacotron():
     if fwd is None:
         fwd = lambda: ot.generate(tst, ot.HP, 2, chars, spk, steps=400, style_idx=-1, min_stop_token=11)  # noqa: E731
     ts = []
-    with torch.no_grad():
+    with torch.no_grad(), _cpu_threads() as threads:
         for _ in range(3):
             t0 = time.perf_counter()
             out = fwd()
             ts.append(time.perf_counter() - t0)
     t = _median(ts)
     frames = int(out[1].shape[-1]) * 32
-    return {"value": frames / t, "unit": "mel frames/s", "cores": torch.get_num_threads(), "kind": kind,
-            "sample": f"BASELINE configs[2]: generate, B=32, T={Tt}, {frames // 32} frames forced, median of 3 = {t:.2f} s "
+    return {"value": frames / t, "unit": "mel frames/s", "cores": threads, "kind": kind,
+            "sample": f"BASELINE configs[2]: generate, B=32, T={Tt}, {frames // 32} frames forced, median of 3 = {t:.2f} s on {threads} threads "
                       f"({'the reference Tacotron' if kind == 'reference' else 'oracle/tacotron.py, the same ATen-CPU ops'})"}
 
 
@@ -300,9 +313,12 @@ def sharded_objects(args, rank, world, dev, use_dist, timed, total_over_ranks):
     import contextlib
     import io
 
+    e2e_t = {}
+
     def e2e(_):
         with contextlib.redirect_stdout(io.StringIO()):  # the facade prints the prompts, like the reference
-            wavs = pipeline.gen_wavs(syn, voc, requests, steps=400, min_stop_token=11, normalize=0.97, pcm16="save_wav", chunk_size=32)
+            wavs = pipeline.gen_wavs(syn, voc, requests, steps=400, min_stop_token=11, normalize=0.97, pcm16="save_wav", chunk_size=32,
+                                     timings=e2e_t)
         return sum(len(w) for w in wavs)  # rank 0 holds everything after the gather; other ranks 0
 
     el, res = timed(e2e, 1, 1)
@@ -312,7 +328,12 @@ def sharded_objects(args, rank, world, dev, use_dist, timed, total_over_ranks):
                     "= 32 per rank: Synthesizer.synthesize_spectrograms (ONE decoder loop per rank: additive chunk_size=32 instead of the default 2 x 16; 400 frames forced) -> HiFi-GAN V1 fp32 -> "
                     "0.15 s breaks, peak normalise, int16 PCM on the device -> device-to-device gather to rank 0",
         "value": n_samples / el, "unit": "samples/s", "x_realtime": n_samples / el / 16000.0, "s_total": el,
-        "requests": n_req, "n_gpus": world, "scaling": "weak"}
+        "requests": n_req, "n_gpus": world, "scaling": "weak",
+        "shares_rank0": {"synthesizer_s": e2e_t.get("synthesizer"), "vocoder_s": e2e_t.get("vocoder"), "gather_s": e2e_t.get("gather"),
+                         "vocoder_share": (e2e_t["vocoder"] / el) if e2e_t.get("vocoder") is not None else None,
+                         "what": "this rank's seconds of the timed pass: Synthesizer facade (Tacotron encoder + decoder loop + postnet + "
+                                 "D2H of the mels + trimming), vocoder facade (H2D of the mels, HiFi-GAN fp32-result forward, breaks, peak "
+                                 "normalisation, PCM16; device-synchronised), gather"}}
     del syn, voc
     # ---- configs[4] ----
     hf = synth.FREGAN_16K
@@ -381,7 +402,7 @@ def pmc_traffic(what, keys=None):
     tools/pmc_r02.sh: 2 x FETCH_SIZE + WRITE_SIZE per launch; counters cannot be read in-process).  keys = kernels to
     sum per launch; None = all bytes of the profiled command.  Returns (bytes, source) or (None, None)."""
     pm = name = None
-    for rnd in ("r04", "r03", "r02"):  # the newest committed pass of this object
+    for rnd in ("r05", "r04", "r03", "r02"):  # the newest committed pass of this object (round 5 refreshed every one of them)
         try:
             name = f"profiles/{rnd}_pmc_{what}.json"
             pm = json.load(open(os.path.join(ROOT, name)))
@@ -452,9 +473,9 @@ def main():
 
     phase_s = []  # (compute, gather) seconds of every pass of this rank: a 1 -> 8 run must show which of the two grows
 
-    def one_pass(seed):
+    def one_pass(seed, mel_in=None):
         tc0 = time.perf_counter()
-        samples = model.generate_samples(mel, True, target, overlap, seed=seed)
+        samples = model.generate_samples(mel if mel_in is None else mel_in, True, target, overlap, seed=seed)
         if use_dist and not stub:
             # float64 tail on the device; the finished waveform goes device-to-device to rank 0 (the only exchange
             # of the whole path), which copies the gathered set to the host once
@@ -508,6 +529,42 @@ def main():
 
     elapsed, res = timed(headline, args.steps, args.warmup)
     loop_ms = loop_ms[args.warmup:]
+    side = {}
+    if not stub and not use_dist:
+        # ---- the same pass with the mel handed over as a HOST buffer (H2D of the mel inside the timed region, as the
+        #      facade's callers do).  Reported beside `value`, never as `value` (the task's contract: inputs resident in HBM).
+        mel_host = torch.from_numpy((synth.wavernn_mel(F, seed=1 + rank) / 4.0).astype(np.float32)).pin_memory()
+        el_h, res_h = timed(lambda i: one_pass(i, mel_host.to(dev, non_blocking=True)), args.steps, 1)
+        n_h = sum(n for _, n in res_h)
+        side["pcie_inclusive"] = {"value": n_h / el_h, "unit": "samples/s", "ms_per_step": el_h / args.steps * 1e3,
+                                  "what": f"the headline pass with the {mel_host.numel() * 4} B mel uploaded from pinned host memory inside "
+                                          "the timed region (the D2H of the waveform is inside both)"}
+        # ---- the strict-fp32 kernel in the same run: MBHIP_WAVERNN_RESIDENT=exact = wf_pipe_kernel, fp32-input MFMA,
+        #      bit-identical to the launch chain
+        prev = os.environ.get("MBHIP_WAVERNN_RESIDENT")
+        os.environ["MBHIP_WAVERNN_RESIDENT"] = "exact"
+        try:
+            x_ms = []
+
+            def exact_pass(i):
+                r_ = one_pass(i)
+                x_ms.append(model.last_loop_ms)
+                return r_
+            el_x, res_x = timed(exact_pass, args.steps, 1)
+            n_x = sum(n for _, n in res_x)
+            side["exact_f32"] = {"value": n_x / el_x, "unit": "samples/s", "x_realtime": n_x / el_x / 16000.0, "ms_per_step": el_x / args.steps * 1e3,
+                                 "dtype": "f32 (fp32-input MFMA v_mfma_f32_16x16x4_f32, fp32 everywhere)",
+                                 "sample_loop_ms": float(np.median(x_ms[1:])), "us_per_time_step": float(np.median(x_ms[1:])) * 1e3 / model.last_plan.seq_len,
+                                 "loop_launches": model.last_loop_launches, "path": model.last_path,
+                                 "kernel": "mb::wf_pipe_kernel (wavernn_pipe.h): the same roles and hand-offs on 8-byte {fp32 value, tag} granules; "
+                                           "sample stream bit-identical to the 5-launch chain"}
+        finally:
+            if prev is None:
+                os.environ.pop("MBHIP_WAVERNN_RESIDENT", None)
+            else:
+                os.environ["MBHIP_WAVERNN_RESIDENT"] = prev
+        model.generate_samples(mel, True, target, overlap, seed=0)  # (last_plan / last_loop_launches of the default path again)
+        torch.cuda.synchronize()
     my_phase = [float(np.median([p[k] for p in phase_s[args.warmup:]])) * 1e3 for k in (0, 1)]
     my_phase.append(float(local_rank if stub else torch.cuda.current_device()))  # the device this rank ran on (LOCAL_RANK -> cuda:LOCAL_RANK)
     if use_dist:  # per-rank medians, in rank order
@@ -526,13 +583,15 @@ def main():
         "value": value, "unit": "samples/s", "x_realtime": value / 16000.0,
         "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1000.0, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "stub" if stub else "synthetic",
-        "dtype_note": ("fp32 weights, state, accumulators, epilogues and samples; since round 4 the resident kernel's matrix products run "
-                       "as error-compensated fp16 pairs on the fp16 matrix pipe (w = wh + wl, x = xh + xl, wl.xh + wh.xl + wh.xh, fp32 "
-                       "accumulate: 21-22 significant bits per operand instead of 24) and its exchange vectors carry the same pairs; "
-                       "parity = the reference loop body replayed on the device's own sample history with the exported noise "
-                       "(tests/test_wavernn_gpu.py::test_production_*: every pick equal except provable near-ties); MBHIP_WAVERNN_RESIDENT=exact "
-                       "runs the exact fp32-MFMA kernel (bit-identical to the launch chain)"),
+        "vs_baseline": None, "dtype": "split-f16 products (two fp16 halves per operand, 21-22 bits), f32 accumulate / state / epilogues",
+        "data": "stub" if stub else "synthetic",
+        "dtype_note": ("what MULTIPLIES on the headline path is the fp16 matrix pipe: w 2^s = wh + wl, x = xh + 2^-11 xl (scaled residual since "
+                       "round 5), products wl.xh + wh.xh + 2^-11 wh.xl in fp32 accumulators (wavernn_pipe16.h); weights, GRU state, sums, gate "
+                       "functions, sampler and samples are fp32.  Parity = the reference loop body replayed on the device's own sample "
+                       "history with the exported noise over ALL 9600 steps x 23 folds (tests/test_wavernn_gpu.py::"
+                       "test_production_default_full_length_vs_oracle: every pick equal except provable near-ties).  The strict-fp32 "
+                       "kernel (MBHIP_WAVERNN_RESIDENT=exact: fp32-input MFMA, bit-identical to the launch chain) is timed in the same run: "
+                       "`exact_f32` below"),
         "config": {"workload": "BASELINE configs[1]: WaveRNN 9-bit mu-law RAW, batch=1 utterance/GPU, "
                                f"mel 80x{F}, batched target=8000 overlap=800 -> {plan.n_folds} folds x "
                                f"{plan.seq_len} steps, Philox sampling, fp32 weights (synthetic, seeded)",
@@ -545,6 +604,9 @@ def main():
                                 "(0 at 1 GPU)"},
     }
 
+    result.update(side)
+    if not stub:
+        result["config"]["loop_path"] = {"path": model.last_path, "fallback": model.last_fallback}
     if stub:
         if rank == 0:
             print(json.dumps(result))
@@ -592,7 +654,7 @@ def main():
             """average duration of a kernel in the committed rocprofv3 --kernel-trace --stats summary of this command"""
             try:
                 import csv
-                for row in csv.DictReader(open(os.path.join(ROOT, "profiles", "r04_bench_kernel_stats.csv"))):
+                for row in csv.DictReader(open(os.path.join(ROOT, "profiles", KERNEL_STATS_CSV))):
                     if kernel_substr in row.get("Name", ""):
                         return float(row["AverageNs"]) / 1e3
             except Exception:
@@ -604,7 +666,7 @@ def main():
             launch_bytes = step_bytes * plan.seq_len
             gbps = launch_bytes / (launch_us * 1e-6) / 1e9
             q16 = os.environ.get("MBHIP_WAVERNN_RESIDENT", "auto") != "exact"  # wavernn_pipe16.h (default) or the exact wavernn_pipe.h kernel
-            traffic, traffic_src = committed("pipe_hbm_bytes_per_launch", ("r04_pmc_wavernn.json",) if q16 else ("r03_pmc_wavernn.json",))
+            traffic, traffic_src = committed("pipe_hbm_bytes_per_launch", ("r05_pmc_wavernn.json", "r04_pmc_wavernn.json") if q16 else ("r03_pmc_wavernn.json",))
             resident_env = os.environ.get("MBHIP_WAVERNN_RESIDENT")
             os.environ["MBHIP_WAVERNN_RESIDENT"] = "0"  # the launch chain on the same utterance, for reference
             model.generate_samples(mel, True, target, overlap, seed=0)
@@ -622,15 +684,21 @@ def main():
                            "tests/test_wavernn_gpu.py::test_production_*" if q16 else
                            "mb::wf_pipe_kernel (wavernn_pipe.h, MBHIP_WAVERNN_RESIDENT=exact): the exact fp32 resident kernel -- 224 "
                            "role-specialised workgroups, weight tiles in LDS, two fold-column groups in flight, granule hand-offs"),
-                "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
+                "bound": "latency",
+                "bound_note": "nominal roofline = HBM on the weights AS IF streamed every step (SURVEY 8(d)): `achieved` / `frac` price the launch "
+                              "that way.  The kernel keeps every weight in registers and reads it once per utterance; what bounds a step is "
+                              "the latency of its five dependent all-to-all hand-offs (MI355X_MICROARCH.md handoff-1to1: 0.8-1.0 us each) plus "
+                              "the stages between them -- `counter_GBps` is the HBM rate the PMC counters actually see",
+                "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
                 "frac_rocprof": (launch_bytes / (rp * 1e-6) / 1e9 / HBM_PEAK_GBS) if rp else None, "rocprof_avg_launch_us": rp,
                 "traffic": traffic, "traffic_source": traffic_src,
+                "counter_GBps": (traffic / (launch_us * 1e-6) / 1e9) if traffic else None,
                 "algorithmic_bytes_per_launch": launch_bytes,
                 "algorithmic_bytes_per_step": step_bytes, "steps_per_launch": plan.seq_len,
                 "avg_launch_us": launch_us,
                 "avg_launch_us_method": "HIP events recorded on the loop's own stream right before and after the launch "
                                         "(mb_wavernn_last_loop_ms), median over the timed passes; frac_rocprof uses the average "
-                                        "duration of the same kernel in profiles/r04_bench_kernel_stats.csv",
+                                        "duration of the same kernel in profiles/" + KERNEL_STATS_CSV,
                 "note": "algorithmic bytes follow SURVEY 8(d) (16.3 MB of fp32 weights per step as if streamed); the resident kernel "
                         "reads each weight ONCE per utterance, so `traffic` is far below them -- the bound that matters is the "
                         "hand-off latency of the 5 all-to-all edges per step, DESIGN.md section 4e",
@@ -753,7 +821,7 @@ def main():
             peak = (2500.0 / 3.0) if ts3 else MFMA_F32_PEAK_TFLOPS
             result["wavernn_batch32"]["roofline"] = {
                 "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
-                "frac": tf / peak, "frac_of_fp32_mfma_peak": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                "frac": tf / peak, "frac_of_fp32_mfma_peak": tf / MFMA_F32_PEAK_TFLOPS, "frac_of_fp16_mfma_peak": tf / 2500.0, "traffic": None,
                 "kernel": ("mb::rnn_ts3_kernel / rnn_dual_linear_ts3_kernel (rnn_ts3_body.h; whole step: 4 GEMM launches + finish): the "
                            "recurrent GEMMs as error-compensated fp16 MFMA products (three per algorithmic product: ceiling 2500 / 3 TFLOP/s), "
                            "activations split once per workgroup in LDS; samples held to the oracle (test_production_batch*)" if ts3 else
@@ -926,9 +994,10 @@ def main():
                                  "unit": "GB/s", "frac": wbytes / (entry["batch1"]["us_per_step"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                  "traffic": None, "algorithmic_bytes_per_step": wbytes}
             try:  # HBM bytes of one step (all six launches) from the committed PMC passes (tools/pmc_r03_ppg.sh)
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_ppg2mel.json")))
+                ppg_pmc = "r05_pmc_ppg2mel.json" if os.path.exists(os.path.join(ROOT, "profiles", "r05_pmc_ppg2mel.json")) else "r03_pmc_ppg2mel.json"
+                pm = json.load(open(os.path.join(ROOT, "profiles", ppg_pmc)))
                 entry["roofline"]["traffic_chain_step"] = pm["step_hbm_bytes_per_launch"]  # measured on the 6-launch chain
-                entry["roofline"]["traffic_source"] = "profiles/r03_pmc_ppg2mel.json: " + pm.get("source", "")[:200]
+                entry["roofline"]["traffic_source"] = f"profiles/{ppg_pmc}: " + pm.get("source", "")[:200]
                 if not resident_p:
                     entry["roofline"]["traffic"] = pm["step_hbm_bytes_per_launch"]
             except Exception:

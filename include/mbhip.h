@@ -225,8 +225,9 @@ int mb_resblock_stage_f16(const mb_resblock_stage_f16_args* a, mb_stream_t strea
  * reference's layout), fp32-grade results from error-compensated fp16 MFMA products on LDS-resident hi / lo operands (section 1's scheme),
  * residual chain and the kernels' mean in fp32 registers.  Replaces, on the fp32 path, the 2 x num_dilations x num_kernels Conv1d calls of
  * one stage of Generator.forward (models/vocoder/hifigan/models.py:139-145 with ResBlock1.forward :39-46; fregan/generator.py:150-157,
- * :43-50).  channels = 32: the whole group in one launch (384-row windows); channels = 64: one ResBlock or one unit per launch (192-row
- * windows), accumulating into y.  Same argument struct as mb_resblock_stage_f16 with d_x / d_y = fp32 [B][channels][t] and d_bias =
+ * :43-50).  One launch covers the kernels / dilations the arguments name: gan.hip's default plan calls it once per ResBlock (k = 3, 7)
+ * or per unit (k = 11) at 32 channels (256-row windows; the whole group in one launch only under MBHIP_DIAG=gan_s32_group), once per
+ * ResBlock or unit at 64 channels (192-row windows), accumulating into y.  Same argument struct as mb_resblock_stage_f16 with d_x / d_y = fp32 [B][channels][t] and d_bias =
  * [num_kernels][num_dilations][2][channels] biases followed by the [num_kernels][num_dilations][2] unscale factors mb_resblock_stage_f32_pack
  * returns in h_unscale. */
 int mb_resblock_stage_f32_supported(int channels, int num_kernels, const int* ksizes, int num_dilations, const int* dilations);
@@ -371,11 +372,15 @@ int mb_wavernn_plan_generate(const mb_wavernn* w, int frames, int batched, int t
  *        instead of the drawn ones (tests).
  * h_progress: optional host-visible (pinned/host-coherent) int32 the kernels
  *        update with the number of completed steps (progress_callback support).
- * HOST-BLOCKING on the default path: for 1..32 fold columns the loop is ONE resident launch (wavernn_persist.h /
- *        wavernn_pipe.h) whose 192 / 224 workgroups must be co-resident; the call waits for the launch and reads its
- *        abort word (a lost hand-off -> the launch chain recomputes the same samples, and the device is remembered as
- *        unsuitable), so it returns with the samples complete on `stream`.  Wider calls (the launch chain, hipGraph replays)
- *        are stream-asynchronous as before; MBHIP_WAVERNN_RESIDENT=0 selects the chain for every width. */
+ * HOST-BLOCKING on the default path: for 1..96 fold columns the loop is ONE resident launch (wavernn_persist.h /
+ *        wavernn_pipe16.h / wavernn_pipe.h) whose 192 / 224 workgroups must be co-resident; the call waits for the launch and
+ *        reads its abort word (a lost hand-off -> the launch chain computes the utterance instead, and the device is remembered
+ *        as unsuitable) and, for wf_pipe16_kernel, its range word (an activation beyond the operand pairs' |x| <= 65504 -> the
+ *        fp32 launch chain computes the utterance), so it returns with the samples complete on `stream`.  The chain's stream
+ *        equals the exact resident kernels' bit for bit but NOT wf_pipe16_kernel's (same noise, fp32 instead of fp32-grade sums:
+ *        the two may pick differently at near-ties): mb_wavernn_last_path tells which form produced a call's samples.  Wider
+ *        calls (the launch chain, hipGraph replays) are stream-asynchronous as before; MBHIP_WAVERNN_RESIDENT=0 selects the
+ *        chain for every width. */
 int mb_wavernn_generate(const mb_wavernn* w, const mb_wavernn_plan* plan,
                         const float* d_mel, const float* d_noise, uint64_t seed,
                         float* d_samples, float* d_logits_out, const float* d_forced,
@@ -424,8 +429,15 @@ int mb_wavernn_finish(const float* d_samples, int n_folds, int seq_len, int batc
 #define MB_WRN_PATH_CHAIN 0     /* the 5-launch chain (csrc/wavernn_fast.h), hipGraph replays                          */
 #define MB_WRN_PATH_PERSIST1 1  /* one column: wf_persist1_kernel (csrc/wavernn_persist.h)                             */
 #define MB_WRN_PATH_PIPE 2      /* 2..32 columns, exact fp32 MFMA: wf_pipe_kernel (csrc/wavernn_pipe.h); resident = "exact" */
-#define MB_WRN_PATH_PIPE16 3    /* 2..64 columns, 22-bit operand pairs: wf_pipe16_kernel (csrc/wavernn_pipe16.h); RAW + MOL */
+#define MB_WRN_PATH_PIPE16 3    /* 2..96 columns (MOL: 2..64), 22-bit operand pairs: wf_pipe16_kernel (csrc/wavernn_pipe16.h) */
 int mb_wavernn_loop_path(int columns, int mode, int production, int have_q16, int resident_cus, int dev_failed, int resident);
+/* Which form of the loop produced the samples of the LAST mb_wavernn_generate call on this handle (*path: MB_WRN_PATH_*), and
+ * whether a resident launch was discarded on the way (*fallback): a caller that needs a reproducible stream per (mel, seed) checks
+ * that the path is the one it expects (the chain's stream differs from wf_pipe16_kernel's at near-ties).  No reference counterpart. */
+#define MB_WRN_FALLBACK_NONE 0   /* the planned form ran                                                                  */
+#define MB_WRN_FALLBACK_ABORT 1  /* a resident launch lost a hand-off (workgroups not co-resident): the chain ran instead    */
+#define MB_WRN_FALLBACK_RANGE 2  /* wf_pipe16_kernel met |x| > 65504 or a NaN in an exchange vector: the fp32 chain ran instead */
+int mb_wavernn_last_path(const mb_wavernn* w, int* path, int* fallback);
 /* Test hook: the Exp(1) noise the on-device sampler of the production paths draws for `seed`:
  * d_out [steps][folds][n_classes] = E for steps step0 .. step0+steps-1, i.e. exactly the tensor which, passed as d_noise
  * to the oracle's sample loop (argmax(softmax(l) / E), torch.multinomial's rule), reproduces what

@@ -210,6 +210,7 @@ SIGNATURES = {
     "mb_wavernn_debug_noise": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mb_wavernn_debug_noise_mol": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mb_wavernn_last_loop_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "mb_wavernn_last_path": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mb_wavernn_bench_kernel": (C.c_int, [C.c_void_p, C.POINTER(WaveRNNPlan), C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_float),
                                           C.POINTER(C.c_double), C.c_void_p]),

@@ -88,6 +88,7 @@ struct RnnK {
   // wide batches (rnn_ts3_body.h): the same matrix as fp16 hi / lo A fragments of v_mfma_f32_16x16x32_f16
   // ([row tile][k-step of 32][hi | lo][lane][8], wavernn_pipe16.h wq16_pack) scaled by 2^s, and 2^-s; null -> the fp32 forms
   const void* w16; float w16_unscale;
+  int* range_word;  // rnn_ts3_body: raised when a staged activation is beyond the operand pairs' range (|x| > 65504 or NaN); may be null
   int dbg;  // diagnostics (MBHIP_DIAG=ts3_dbg=<bits>, results are WRONG on purpose): 1 = rnn_ts3_body skips its k loop, 2 = skips its epilogues
 };
 
@@ -152,11 +153,11 @@ struct WfCond {
 };
 // (T1[pos][r, z, n], Ipre[pos]) of unit j; pos >= total_len = zero conditioning.  u_row0 / a_row0: first row of this utterance's
 // block in concatenated tables (batch loop).
-__device__ __forceinline__ float4 wf_cond_row4(const WfCond& c, const unsigned pos, const unsigned total_len, const int j, const int H,
-                                               const int frames, const long long u_row0 = 0, const long long a_row0 = 0) {
-  const bool live = pos < total_len;
-  const unsigned f = live ? pos / (unsigned)c.hop : (unsigned)frames + 4u;   // dead: five zero rows
-  const unsigned p = live ? pos - f * (unsigned)c.hop : 0u;
+// the same from (frame f, phase p) of a live position (resident kernels advance them step by step instead of dividing by the hop)
+__device__ __forceinline__ float4 wf_cond_row4_fp(const WfCond& c, const unsigned f_live, const unsigned p_live, const bool live, const int j, const int H,
+                                                  const int frames, const long long u_row0 = 0, const long long a_row0 = 0) {
+  const unsigned f = live ? f_live : (unsigned)frames + 4u;   // dead: five zero rows
+  const unsigned p = live ? p_live : 0u;
   const long long fa = a_row0 + (live ? (long long)f : (long long)frames);
   const float* kw = c.Kw + p * 5;
   const float* at = c.AT + fa * 3 * H + j;
@@ -172,6 +173,12 @@ __device__ __forceinline__ float4 wf_cond_row4(const WfCond& c, const unsigned p
     acc.w = fmaf(k, ui[(size_t)o * H], acc.w);
   }
   return acc;
+}
+__device__ __forceinline__ float4 wf_cond_row4(const WfCond& c, const unsigned pos, const unsigned total_len, const int j, const int H,
+                                               const int frames, const long long u_row0 = 0, const long long a_row0 = 0) {
+  const bool live = pos < total_len;
+  const unsigned f = live ? pos / (unsigned)c.hop : 0u;
+  return wf_cond_row4_fp(c, f, live ? pos - f * (unsigned)c.hop : 0u, live, j, H, frames, u_row0, a_row0);
 }
 // Ipre[pos][j] alone (the exact 6-launch chain feeds I(..) itself to rnn1)
 __device__ __forceinline__ float wf_cond_ipre(const WfCond& c, const unsigned pos, const unsigned total_len, const int j, const int H,

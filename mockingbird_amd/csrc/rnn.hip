@@ -240,6 +240,7 @@ int rnn_launch_dual_linear(const RnnK& k0, const RnnK& k1, hipStream_t s) {
     MB_REQUIRE(k0.nkb_total == k1.nkb_total, "rnn_launch_dual(ts2): jobs must share K");
     const int nxw = cdiv(nx0, MT * TS2_WAVES);
     if (k0.w16 && k1.w16 && rnn_ts3_enabled()) {  // fp16 matrix pipe, error-compensated (rnn_ts3_body.h)
+      d0.k.dbg = d1.k.dbg = diag_int("ts3_dbg", 0);  // diagnostics of rnn_ts3_body.h (wrong results on purpose); read on this path only
       if (nt2 == 3) hipLaunchKernelGGL((rnn_dual_linear_ts3_kernel<F0 | RF_FOLDTAB, F1, MT, 3>), g2, dim3(256), ts3_lds_bytes<3>(), s, d0, d1, nxw);
       else if (nt2 == 2) hipLaunchKernelGGL((rnn_dual_linear_ts3_kernel<F0 | RF_FOLDTAB, F1, MT, 2>), g2, dim3(256), ts3_lds_bytes<2>(), s, d0, d1, nxw);
       else hipLaunchKernelGGL((rnn_dual_linear_ts3_kernel<F0 | RF_FOLDTAB, F1, MT, 1>), g2, dim3(256), ts3_lds_bytes<1>(), s, d0, d1, nxw);
@@ -322,6 +323,7 @@ int rnn_launch(int epi, const RnnK& k, hipStream_t s) {
     dim3 gts(cdiv(n_mt, 2), cdiv(cdiv(k.N, 16), 4));
     if (const int nt2 = rnn_ts2_nt(k.N)) {
       const bool ts3 = k.w16 && rnn_ts3_enabled();  // fp16 matrix pipe, error-compensated (rnn_ts3_body.h)
+      if (ts3) d.k.dbg = diag_int("ts3_dbg", 0);  // diagnostics of rnn_ts3_body.h (wrong results on purpose); read on this path only
       if (epi == EPI_GRU && feat == FG && ts3) {
         dim3 g2(cdiv(n_mt, 2 * TS2_WAVES), cdiv(cdiv(k.N, 16), nt2));
         if (nt2 == 3) hipLaunchKernelGGL((rnn_ts3_kernel<EPI_GRU, FG, 2, 3>), g2, dim3(256), ts3_lds_bytes<3>(), s, d);

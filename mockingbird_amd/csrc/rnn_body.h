@@ -397,7 +397,6 @@ __device__ __forceinline__ void rnn_rowtile_body(const RnnDev& d, const int bx, 
 // fill the flat-segment argument block; returns MB_EINVAL if the segments do not cover nkb_total
 static inline int make_rnn_dev(const RnnK& k, RnnDev* d) {
   d->k = k;
-  d->k.dbg = diag_int("ts3_dbg", d->k.dbg);  // diagnostics of rnn_ts3_body.h (wrong results on purpose)
   int start = 0;
   for (int t = 0; t < 4; ++t) {
     if (t < k.nseg) {

@@ -11,7 +11,12 @@
 //                    (NT x 16 columns x 64 k) are loaded cooperatively, split into fp16 hi / lo rows in LDS (144-byte rows: conflict-free
 //                    16-byte fragment reads), double-buffered, one barrier per stage.  Fetched per wave straight from memory the B
 //                    fragments would be 142 B/clk per compute unit -- the fp16 pipe is 5.3x faster, the L1 is not;
-//   acc += wl.xh + wh.xl + wh.xh   in fp32, y = acc 2^-s: 18 MFMAs of 16 cycles per k-step and wave (2 x 3 tiles) against 48 of 32.
+//   acc += wl.xh + wh.xh, acl += wh.xl   in fp32, y = (acc + 2^-11 acl) 2^-s: 18 MFMAs of 16 cycles per k-step and wave (2 x 3 tiles)
+//                    against 48 of 32.  Round 5: the residual is stored SCALED, xl = fp16((x - xh) 2^11) (conv1d.hip's fix: unscaled it
+//                    is an fp16 subnormal below |x| = 0.125 -- 14 bits at |x| = 1e-3, which relu(fc1 ..) of a real checkpoint may be), at
+//                    the price of a second accumulator set; the split itself is two packed conversions per pair.
+// Range: |x| <= 65504.  A staged value beyond it (or a NaN) raises RnnK::range_word; mb_wavernn_generate_batch then discards the loop's
+// samples and reruns it on rnn_ts2_body (fp32 MFMA) -- no silent clamp.
 // Results are fp32-grade (21-22 bits per operand), NOT bit-identical to the fp32 forms any more: a column's sums still do not
 // depend on the batch it is in (same order for every column), and the batch loop is held to the oracle with the exported noise
 // (tests/test_wavernn_gpu.py::test_production_batch*).  MBHIP_RNN_WIDE=ts2 selects rnn_ts2_body.
@@ -23,6 +28,8 @@ namespace mb {
 typedef _Float16 t3h;
 typedef _Float16 t3h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 t3h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 t3h2 __attribute__((ext_vector_type(2)));
+typedef float t3f2 __attribute__((ext_vector_type(2)));
 constexpr int TS3_KS = 64;          // K per stage (two k-steps of 32)
 constexpr int TS3_ROW = TS3_KS + 8;  // halves per staged column row (144 bytes)
 template <int NT> constexpr size_t ts3_lds_bytes() { return (size_t)2 * 2 * NT * 16 * TS3_ROW * sizeof(t3h); }  // [buffer][hi | lo][column][k]
@@ -105,24 +112,23 @@ __device__ __forceinline__ void rnn_ts3_body(const RnnDev& d, const int bx, cons
     t3h* lb = hb + (size_t)NT * 16 * TS3_ROW;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-      const float v[4] = {xs[n].x, xs[n].y, xs[n].z, xs[n].w};
-      t3h4 h, l;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const t3h hh = (t3h)__builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
-        h[e] = hh;
-        l[e] = (t3h)(v[e] - (float)hh);
-      }
+      const t3f2 va = {xs[n].x, xs[n].y}, vb = {xs[n].z, xs[n].w};
+      const t3h2 ha = __builtin_convertvector(va, t3h2), hb2 = __builtin_convertvector(vb, t3h2);
+      const t3h2 la = __builtin_convertvector((va - __builtin_convertvector(ha, t3f2)) * 2048.f, t3h2);   // exact differences, scaled residual
+      const t3h2 lb2 = __builtin_convertvector((vb - __builtin_convertvector(hb2, t3f2)) * 2048.f, t3h2);
+      if (a.range_word && !((__builtin_fabsf(va[0]) + __builtin_fabsf(va[1])) + (__builtin_fabsf(vb[0]) + __builtin_fabsf(vb[1])) <= 65504.f))
+        __hip_atomic_store(a.range_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const t3h4 h = {ha[0], ha[1], hb2[0], hb2[1]}, l = {la[0], la[1], lb2[0], lb2[1]};
       const int o = (n * 16 + c16) * TS3_ROW + k4 * 4;
       *reinterpret_cast<t3h4*>(hb + o) = h;
       *reinterpret_cast<t3h4*>(lb + o) = l;
     }
   };
-  f32x4 sum[MT][NT];
+  f32x4 sum[MT][NT], sul[MT][NT];  // wl.xh + wh.xh | wh.xl (scaled residual)
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int n = 0; n < NT; ++n) sum[m][n] = {0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < NT; ++n) { sum[m][n] = {0.f, 0.f, 0.f, 0.f}; sul[m][n] = {0.f, 0.f, 0.f, 0.f}; }
   auto compute = [&](const FragA& f, const int buf) {
     const t3h* hb = lds + (size_t)buf * 2 * NT * 16 * TS3_ROW;
     const t3h* lb = hb + (size_t)NT * 16 * TS3_ROW;
@@ -141,7 +147,7 @@ __device__ __forceinline__ void rnn_ts3_body(const RnnDev& d, const int bx, cons
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           sum[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[n], sum[m][n], 0, 0, 0);
-          sum[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[n], sum[m][n], 0, 0, 0);
+          sul[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[n], sul[m][n], 0, 0, 0);
           sum[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[n], sum[m][n], 0, 0, 0);
         }
       }
@@ -237,7 +243,7 @@ __device__ __forceinline__ void rnn_ts3_body(const RnnDev& d, const int bx, cons
 #pragma unroll
       for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sum[m][n][e] *= us;
+        for (int e = 0; e < 4; ++e) sum[m][n][e] = (sum[m][n][e] + sul[m][n][e] * 4.8828125e-4f) * us;
   }
 
   if (a.dbg & 2) {  // diagnostics: no epilogue (the sums still have to be computed)

@@ -279,7 +279,11 @@ struct mb_wavernn {
   // stream + graph, so the per-kernel dependency latency of one lane overlaps with the others.
   static constexpr int MAX_LANES = 8;
   int resident_cus = -1;                      // compute units a resident launch may count on (-1: not probed yet, 0: none)
-  int* h_abort = nullptr;                     // pinned host copy of the resident launch's abort word
+  int* d_range = nullptr;                     // device word the wide-batch fp16 GEMMs (rnn_ts3_body.h) raise for an activation beyond their range
+  int* h_range = nullptr;                     // its pinned host copy
+  int* h_abort = nullptr;                     // pinned host copy of the resident launch's abort word [0] and range word [1]
+  int last_path = MB_WRN_PATH_CHAIN;          // what computed the samples of the last generate call (mb_wavernn_last_path)
+  int last_fallback = MB_WRN_FALLBACK_NONE;   // and whether a resident launch was discarded on the way
   hipStream_t loop_stream = nullptr;          // lane 0 (also runs the conditioning networks)
   hipStream_t lane_stream[MAX_LANES] = {};
   hipEvent_t lane_ev[MAX_LANES] = {};
@@ -315,7 +319,8 @@ static std::atomic<bool> g_resident_failed[64] = {};  // written by whichever ho
 // | 1       | wf_persist1_kernel                    | launch chain                          |
 // | 2..32   | wf_pipe16_kernel; exact: wf_pipe      | wf_pipe16_kernel; exact: wf_pipe      |
 // | 33..64  | wf_pipe16_kernel; exact: chain        | wf_pipe16_kernel; exact: chain        |
-// | > 64    | launch chain (mb_wavernn_generate_batch's wide GEMMs serve several utterances)   |
+// | 65..96  | wf_pipe16_kernel; exact: chain        | launch chain                          |
+// | > 96    | launch chain (mb_wavernn_generate_batch's wide GEMMs serve several utterances)   |
 // and the launch chain whenever production == 0, the device offers fewer units than the kernel has workgroups (224 / 192), resident
 // = 0, or the device failed before and the switch does not ask explicitly.
 int wavernn_pick_path(int columns, int mode, int production, int have_q16, int resident_cus, int dev_failed, int resident) {
@@ -324,6 +329,7 @@ int wavernn_pick_path(int columns, int mode, int production, int have_q16, int r
   const bool q16 = have_q16 && resident != 2;  // (both sampler modes: the MOL F3 role exists on both resident kernels)
   if (columns >= 2) {
     if (columns > (q16 ? WQ_GMAX : WQ_G) * WQ_GC) return MB_WRN_PATH_CHAIN;
+    if (mode != 0 && columns > 64) return MB_WRN_PATH_CHAIN;  // the MOL launch chain's fused sampler stops at 64 columns, and with it `production`
     if (resident_cus < WQ_WGS) return MB_WRN_PATH_CHAIN;
     return q16 ? MB_WRN_PATH_PIPE16 : MB_WRN_PATH_PIPE;
   }
@@ -386,11 +392,11 @@ extern "C" size_t mb_wavernn_weight_numel(const mb_wavernn_config* cfg, int inde
 }
 
 // split image of a tile-ordered matrix for wavernn_pipe16.h (K = 512 only: the resident kernels are production-dims kernels)
-static int upload_q16(const float* rows, int n_live_rows, int K, int RL, DevBuf* dst, float* unscale) {
+static int upload_q16(const float* rows, int n_live_rows, int K, int RL, DevBuf* dst, float* unscale, int min_tiles = 0) {
   if (K != 512) return MB_OK;
   const int sexp = wq16_scale_exp(rows, (size_t)n_live_rows * K);
   std::vector<unsigned short> img;
-  wq16_pack(rows, n_live_rows, K, RL, sexp, &img);
+  wq16_pack(rows, n_live_rows, K, RL, sexp, &img, min_tiles);
   *unscale = std::ldexp(1.f, -sexp);
   return dst->upload(reinterpret_cast<const float*>(img.data()), img.size() / 2);
 }
@@ -580,7 +586,7 @@ extern "C" int mb_wavernn_create(const mb_wavernn_config* cfg, const float* cons
     std::vector<float> a2 = col_slice(w2, FC, FC + A, FC, A);
     RC(make_cond_conv(&w->t_f2, a2.data(), FC, A, 1, 0, b2, nullptr));
     pack_rowtile(w3, C, FC, 4, &packed); RC(w->w_fc3.upload(packed.data(), packed.size()));
-    RC(upload_q16(w3, C, FC, 4, &w->q_fc3, &w->q_us[5]));
+    RC(upload_q16(w3, C, FC, 4, &w->q_fc3, &w->q_us[5], cfg->mode == 1 ? 2 : 0));  // MOL: the F3 role reads two row tiles whatever nr_mix is
     RC(w->b_fc3.upload(b3, C));
   }
 #undef RC
@@ -614,6 +620,8 @@ extern "C" void mb_wavernn_destroy(mb_wavernn* w) {
   for (DevBuf* b : bs) b->release();
   w->drop_graph();
   if (w->h_abort) (void)hipHostFree(w->h_abort);
+  if (w->h_range) (void)hipHostFree(w->h_range);
+  if (w->d_range) (void)hipFree(w->d_range);
   if (w->ev_in) (void)hipEventDestroy(w->ev_in);
   if (w->ev_out) (void)hipEventDestroy(w->ev_out);
   if (w->ev_t0) (void)hipEventDestroy(w->ev_t0);
@@ -852,19 +860,25 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
   };
   // Resident forms of the loop: ONE launch for the whole utterance, every weight tile in LDS, granule hand-offs between
   // the layers, same sample stream as the chain.
-  //   * wf_pipe16_kernel (wavernn_pipe16.h, RAW and MOL models) / wf_pipe_kernel (wavernn_pipe.h, MBHIP_WAVERNN_RESIDENT=exact or no fp16 images), 2..64 / 2..32 fold
+  //   * wf_pipe16_kernel (wavernn_pipe16.h, RAW and MOL models) / wf_pipe_kernel (wavernn_pipe.h, MBHIP_WAVERNN_RESIDENT=exact or no fp16 images), 2..96 / 2..32 fold
   //     columns: role-specialised workgroups, column groups in flight.
   //   * wf_persist1_kernel (wavernn_persist.h): one column (batched=False).  MBHIP_WAVERNN_RESIDENT=0 keeps the chain for both.
   //   The choice is wavernn_pick_path's table (above).
   // Both need their workgroups co-resident, one per compute unit: checked here against the device (CU count, occupancy
   // of the kernel, a per-device "it failed before" flag); a launch that still loses a hand-off (another process holds
-  // compute units) times out after 0.2 s, raises its abort word and the chain below computes the same samples.
+  // compute units) times out after 0.2 s, raises its abort word and the chain below computes the utterance instead; so does a
+  // wf_pipe16_kernel launch that met a value beyond its operand range (range word).  The chain's stream is wf_pipe_kernel's and
+  // wf_persist1_kernel's bit for bit, but NOT wf_pipe16_kernel's (same noise, fp32-grade instead of fp32 sums: the two differ at
+  // near-ties) -- mb_wavernn_last_path says which form produced the samples of a call.
   // NOTE: a resident launch makes this call host-blocking (the abort word has to be looked at before returning).
   std::string trace_file;  // diagnostics (MBHIP_DIAG=trace_file=<path>, wf_which=<bits>): the chain, launch by launch
   const char* trace_path = diag_str("trace_file", &trace_file) ? trace_file.c_str() : nullptr;
   const int dbg_which = diag_int("wf_which", -1);
-  const bool resident_ok = fastk && C <= 512 && !w->bench_which && !w->bench_chain && !trace_path && dbg_which < 0;
+  // (the resident kernels go beyond the fast chain's 64 columns: up to WQ_GMAX groups of 16; a MOL model's F3 role reads two fc3 row tiles)
+  const bool resident_dims = split && R == 512 && FC == 512 && (C % 16 == 0 || c.mode == 1) && fast_ok && (c.mode == 0 || C > 16);
+  const bool resident_ok = resident_dims && C <= 512 && !w->bench_which && !w->bench_chain && !trace_path && dbg_which < 0;
   int path = MB_WRN_PATH_CHAIN;
+  w->last_path = MB_WRN_PATH_CHAIN; w->last_fallback = MB_WRN_FALLBACK_NONE;
   if (resident_ok && !rc) {
     int dev = 0;
     MB_HIP(hipGetDevice(&dev));
@@ -873,17 +887,21 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
       MB_HIP(hipGetDeviceProperties(&prop, dev));
       MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_persist1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WP1_LDS_BYTES));
       MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_pipe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WQ_LDS_BYTES));
-      MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_pipe16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WQ16_LDS_BYTES));
-      MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_pipe16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WQ16_LDS_BYTES));
-      int nb1 = 0, nb2 = 0, nb3 = 0;
+      int nb1 = 0, nb2 = 0, nb3 = 1 << 30;
       MB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, reinterpret_cast<const void*>(wf_persist1_kernel), 512, WP1_LDS_BYTES));
       MB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, reinterpret_cast<const void*>(wf_pipe_kernel), 512, WQ_LDS_BYTES));
-      int nb3m = 0;
-      MB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb3, reinterpret_cast<const void*>(wf_pipe16_kernel<false>), 512, WQ16_LDS_BYTES));
-      MB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb3m, reinterpret_cast<const void*>(wf_pipe16_kernel<true>), 512, WQ16_LDS_BYTES));
-      nb3 = std::min(nb3, nb3m);
+      const void* p16[7] = {reinterpret_cast<const void*>(wf_pipe16_kernel<false, 2, false>), reinterpret_cast<const void*>(wf_pipe16_kernel<false, 4, false>),
+                            reinterpret_cast<const void*>(wf_pipe16_kernel<false, 6, false>), reinterpret_cast<const void*>(wf_pipe16_kernel<true, 2, false>),
+                            reinterpret_cast<const void*>(wf_pipe16_kernel<true, 4, false>), reinterpret_cast<const void*>(wf_pipe16_kernel<true, 6, false>),
+                            reinterpret_cast<const void*>(wf_pipe16_kernel<false, 2, true>)};
+      for (const void* f : p16) {
+        int nb = 0;
+        MB_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WQ16_LDS_BYTES));
+        MB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f, 512, WQ16_LDS_BYTES));
+        nb3 = std::min(nb3, nb);
+      }
       w->resident_cus = (nb1 >= 1 && nb2 >= 1 && nb3 >= 1) ? prop.multiProcessorCount : 0;
-      if (!w->h_abort) MB_HIP(hipHostMalloc((void**)&w->h_abort, sizeof(int), hipHostMallocDefault));
+      if (!w->h_abort) MB_HIP(hipHostMalloc((void**)&w->h_abort, 2 * sizeof(int), hipHostMallocDefault));
     }
     const bool dev_failed = dev >= 0 && dev < 64 && g_resident_failed[dev];
     const int resident_sw = wavernn_resident_env();
@@ -895,6 +913,7 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
   if ((pipe || persist) && !rc) {
     const size_t ex_bytes = pipe ? wq_exchange_bytes() : wp_exchange_bytes();
     int* abort_word = reinterpret_cast<int*>(L.px + (pipe ? (size_t)WQ_GMAX * 2 * WQX_PER : (size_t)2 * WPX_PER_PARITY));
+    int* range_word = abort_word + 1;
     MB_HIP(hipMemsetAsync(L.px, 0, ex_bytes, s));
     const bool test_abort = diag_int("abort_wp") != 0;  // tests only (MBHIP_DIAG=abort_wp): the launch finds its abort word raised, the chain takes over
     if (test_abort) MB_HIP(hipMemsetAsync(abort_word, 1, 1, s));
@@ -902,6 +921,7 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
     const char* wtrace = diag_str("wp_trace", &wtrace_file) ? wtrace_file.c_str() : nullptr;
     unsigned long long* trace = wtrace ? reinterpret_cast<unsigned long long*>(abort_word) + 32 : nullptr;
     MB_HIP(hipEventRecord(w->ev_t0, s));
+    int n_groups = 2;
     if (pipe) {
       WqK qk;
       qk.w_rnn2 = w->w_rnn2x.p; qk.w_hh2 = w->f_hh2t.p; qk.w_hh1 = w->f_hh1t.p; qk.w_fc1 = w->w_fc1.p; qk.w_fc2 = w->w_fc2.p; qk.w_fc3 = w->w_fc3.p;
@@ -913,11 +933,11 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
       qk.mol = c.mode == 1 ? 1 : 0; qk.nr_mix = C / 3;
       {  // column groups: two up to 32 columns, ceil(N / 16) beyond (pipe16 only), sizes as even as possible
         int ng = N <= 2 * WQ_GC ? 2 : (N + WQ_GC - 1) / WQ_GC;
-        if (const char* ge = getenv("MBHIP_WQ_GROUPS")) {  // A/B: one group (no pipelining) / more groups than needed
-          const int want = atoi(ge);
+        if (const int want = diag_int("wq_groups", 0)) {  // A/B (MBHIP_DIAG=wq_groups=<n>): one group (no pipelining) / more groups than needed
           if (want == 1 && N <= WQ_GC) ng = 1;
           else if (q16 && want >= ng && want <= WQ_GMAX) ng = want;
         }
+        n_groups = ng;
         for (int g = 0; g <= WQ_GMAX; ++g) qk.gn0[g] = g >= ng ? N : (int)((long long)N * g / ng + ((long long)N * g % ng ? 1 : 0));  // ceil(N g / ng)
         if (ng == 2) qk.gn0[1] = (N + 1) / 2;
       }
@@ -930,8 +950,14 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
         k16.h_hh1 = reinterpret_cast<const uint4*>(w->q_hh1.p); k16.h_fc1 = reinterpret_cast<const uint4*>(w->q_fc1.p);
         k16.h_fc2 = reinterpret_cast<const uint4*>(w->q_fc2.p); k16.h_fc3 = reinterpret_cast<const uint4*>(w->q_fc3.p);
         k16.us_rnn2 = w->q_us[0]; k16.us_hh2 = w->q_us[1]; k16.us_hh1 = w->q_us[2]; k16.us_fc1 = w->q_us[3]; k16.us_fc2 = w->q_us[4]; k16.us_fc3 = w->q_us[5];
-        if (c.mode == 1) hipLaunchKernelGGL(wf_pipe16_kernel<true>, dim3(WQ_WGS), dim3(512), WQ16_LDS_BYTES, s, k16);
-        else hipLaunchKernelGGL(wf_pipe16_kernel<false>, dim3(WQ_WGS), dim3(512), WQ16_LDS_BYTES, s, k16);
+        k16.range_word = range_word;
+        // the instance with the fewest group slots that holds the launch's groups (per-group state is register arrays of that size)
+#define MB_WQ16(MOL_, NG_, TR_) hipLaunchKernelGGL((wf_pipe16_kernel<MOL_, NG_, TR_>), dim3(WQ_WGS), dim3(512), WQ16_LDS_BYTES, s, k16)
+        if (c.mode == 1) { if (n_groups <= 2) MB_WQ16(true, 2, false); else if (n_groups <= 4) MB_WQ16(true, 4, false); else MB_WQ16(true, 6, false); }
+        else if (n_groups <= 2) { if (trace) MB_WQ16(false, 2, true); else MB_WQ16(false, 2, false); }  // (marks: the RAW two-group instance only)
+        else if (n_groups <= 4) MB_WQ16(false, 4, false);
+        else MB_WQ16(false, 6, false);
+#undef MB_WQ16
       } else
       hipLaunchKernelGGL(wf_pipe_kernel, dim3(WQ_WGS), dim3(512), WQ_LDS_BYTES, s, qk);
     } else {
@@ -949,27 +975,40 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
     MB_HIP(hipEventRecord(w->ev_t1, s));
     w->last_launches = 1; w->last_lanes = 1; w->timed = true;
     // the abort word is the only way a broken hand-off shows: one D2H copy into pinned memory behind the launch, one wait
-    MB_HIP(hipMemcpyAsync(w->h_abort, abort_word, sizeof(int), hipMemcpyDeviceToHost, s));
+    MB_HIP(hipMemcpyAsync(w->h_abort, abort_word, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     MB_HIP(hipEventRecord(w->ev_out, s));
     MB_HIP(hipStreamWaitEvent(cs, w->ev_out, 0));
     MB_HIP(hipEventSynchronize(w->ev_out));
-    const int aborted = *w->h_abort;
+    const int aborted = w->h_abort[0], out_of_range = q16 ? w->h_abort[1] : 0;
     if (wtrace && !aborted) {
       unsigned long long marks[5 * 4 * 16];
       MB_HIP(hipMemcpy(marks, trace, sizeof(marks), hipMemcpyDeviceToHost));
       if (FILE* f = fopen(wtrace, "wb")) { fwrite(marks, sizeof(marks), 1, f); fclose(f); }
     }
-    if (!aborted) return MB_OK;
-    // A hand-off never arrived within the time limit: the workgroups were not all resident (something else holds
-    // compute units -- another stream or process) and the launch drained itself.  The chain below computes the same
-    // samples bit for bit without needing co-residency; say so once and stop defaulting to resident launches here.
-    static bool warned = false;
-    if (!warned) {
-      fprintf(stderr, "[mbhip] wavernn: resident kernel could not keep its workgroups co-resident; using the launch chain\n");
-      warned = true;
+    if (!aborted && !out_of_range) { w->last_path = path; return MB_OK; }
+    if (aborted) {
+      // A hand-off never arrived within the time limit: the workgroups were not all resident (something else holds
+      // compute units -- another stream or process) and the launch drained itself.  The chain below computes the utterance
+      // without needing co-residency (the exact kernels' stream bit for bit; wf_pipe16_kernel's up to near-ties: same noise,
+      // fp32 sums); say so once and stop defaulting to resident launches here.
+      static bool warned = false;
+      if (!warned) {
+        fprintf(stderr, "[mbhip] wavernn: resident kernel could not keep its workgroups co-resident; using the launch chain\n");
+        warned = true;
+      }
+      int dev = 0;
+      if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !diag_int("abort_wp")) g_resident_failed[dev] = true;
+      w->last_fallback = MB_WRN_FALLBACK_ABORT;
+    } else {
+      // wf_pipe16_kernel published a value beyond fp16's range (or a NaN): its operand pairs cannot carry this utterance.  The
+      // launch's samples are discarded and the fp32 chain computes it; nothing is remembered (the next utterance tries again).
+      static bool warned_range = false;
+      if (!warned_range) {
+        fprintf(stderr, "[mbhip] wavernn: an activation left the operand-pair kernel's range (|x| > 65504 or NaN); using the fp32 launch chain\n");
+        warned_range = true;
+      }
+      w->last_fallback = MB_WRN_FALLBACK_RANGE;
     }
-    int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !diag_int("abort_wp")) g_resident_failed[dev] = true;
   }
   if (fastk && !rc) {  // zero state; P = W_hh.0 + b_hh for the first step by the loop's own hidden-half jobs
     MB_HIP(hipMemsetAsync(L.f_x1, 0, L.f_bytes, s));
@@ -1344,7 +1383,7 @@ extern "C" int mb_wavernn_generate(const mb_wavernn* wc, const mb_wavernn_plan* 
 
 static int wavernn_generate_batch_impl(const mb_wavernn* wc, const mb_wavernn_batch_plan* plan, const int* h_frames,
                                        const float* const* h_d_mels, const uint64_t* h_seeds, float* d_samples,
-                                       void* d_workspace, size_t workspace_bytes, mb_stream_t stream) {
+                                       void* d_workspace, size_t workspace_bytes, mb_stream_t stream, const bool allow_w16) {
   mb_wavernn* w = const_cast<mb_wavernn*>(wc);
   MB_REQUIRE(w && plan && h_frames && h_d_mels && h_seeds && d_samples, "wavernn_generate_batch: null pointer");
   MB_REQUIRE(rnn_wide_switch_valid(), "MBHIP_RNN_WIDE: unknown value '%s' (ts3 | ts2 | ts, optionally :1..3)", getenv("MBHIP_RNN_WIDE"));
@@ -1453,7 +1492,7 @@ static int wavernn_generate_batch_impl(const mb_wavernn* wc, const mb_wavernn_ba
     RnnK k;
     memset(&k, 0, sizeof(k));
     k.w = w->w_rnn2x.p; k.nseg = 1; k.nkb_total = R / 16; k.seg[0] = {L.x1, R, R / 16, 0};
-    k.w16 = w->q_rnn2.p; k.w16_unscale = w->q_us[0];
+    k.w16 = allow_w16 ? w->q_rnn2.p : nullptr; k.w16_unscale = w->q_us[0]; k.range_word = w->d_range;
     k.N = N; k.units = R; k.h_pre = L.P2; k.pre_table = L.G2; frame_rows(k); k.pre_stride = 3 * R;
     k.h_prev = h2p; k.x_res = L.x1; k.h_out = h2n; k.x_out = L.x2; k.zero_slot = slot_prev;
     if ((r = rnn_launch(EPI_GRU, k, s))) return r;
@@ -1461,19 +1500,19 @@ static int wavernn_generate_batch_impl(const mb_wavernn* wc, const mb_wavernn_ba
       RnnK k1;
       memset(&k, 0, sizeof(k)); memset(&k1, 0, sizeof(k1));
       k.w = g ? w->w_fc2.p : w->w_fc1.p; k.nseg = 1;
-      k.w16 = g ? w->q_fc2.p : w->q_fc1.p; k.w16_unscale = w->q_us[g ? 4 : 3];
+      k.w16 = !allow_w16 ? nullptr : g ? w->q_fc2.p : w->q_fc1.p; k.w16_unscale = w->q_us[g ? 4 : 3]; k.range_word = w->d_range;
       k.seg[0] = {g ? L.y1 : L.x2, g ? FC : R, (g ? FC : R) / 16, 0};
       k.nkb_total = k.seg[0].nkb;
       k.N = N; k.units = FC; k.pre_table = g ? L.F2 : L.F1; frame_rows(k); k.pre_stride = FC;
       k.y = g ? L.y2 : L.y1; k.ldy = FC; k.act = 1;
       k1.w = g ? w->w_hh2.p : w->w_hh1.p; k1.nseg = 1; k1.nkb_total = R / 16; k1.seg[0] = {g ? h2n : h1n, R, R / 16, 0};
-      k1.w16 = g ? w->q_hh2l.p : w->q_hh1l.p; k1.w16_unscale = w->q_us[g ? 7 : 6];
+      k1.w16 = !allow_w16 ? nullptr : g ? w->q_hh2l.p : w->q_hh1l.p; k1.w16_unscale = w->q_us[g ? 7 : 6];  // (|h| < 1: no range word)
       k1.N = N; k1.units = 3 * R; k1.biasX = g ? w->b_hh2.p : w->b_hh1.p; k1.y = g ? L.P2 : L.P1; k1.ldy = 3 * R;
       if ((r = rnn_launch_dual_linear(k, k1, s))) return r;
     }
     memset(&k, 0, sizeof(k));
     k.w = w->w_fc3.p; k.nseg = 1; k.nkb_total = FC / 16; k.seg[0] = {L.y2, FC, FC / 16, 0};
-    k.w16 = w->q_fc3.p; k.w16_unscale = w->q_us[5];
+    k.w16 = allow_w16 ? w->q_fc3.p : nullptr; k.w16_unscale = w->q_us[5]; k.range_word = w->d_range;
     k.N = N; k.units = C; k.biasX = w->b_fc3.p; k.ldy = C; frame_rows(k);
     k.gum_slot = slot_cur; k.gum_seed = 0;
     return rnn_launch(EPI_LINEAR, k, s);
@@ -1515,9 +1554,31 @@ static int wavernn_generate_batch_impl(const mb_wavernn* wc, const mb_wavernn_ba
 extern "C" int mb_wavernn_generate_batch(const mb_wavernn* wc, const mb_wavernn_batch_plan* plan, const int* h_frames,
                                          const float* const* h_d_mels, const uint64_t* h_seeds, float* d_samples,
                                          void* d_workspace, size_t workspace_bytes, mb_stream_t stream) {
-  return wavernn_join_on_error(const_cast<mb_wavernn*>(wc),
-                               wavernn_generate_batch_impl(wc, plan, h_frames, h_d_mels, h_seeds, d_samples, d_workspace,
-                                                           workspace_bytes, stream));
+  mb_wavernn* w = const_cast<mb_wavernn*>(wc);
+  MB_REQUIRE(w && plan, "wavernn_generate_batch: null pointer");
+  if (!w->d_range) {
+    MB_HIP(hipMalloc((void**)&w->d_range, sizeof(int)));
+    MB_HIP(hipHostMalloc((void**)&w->h_range, sizeof(int), hipHostMallocDefault));
+  }
+  w->last_path = MB_WRN_PATH_CHAIN; w->last_fallback = MB_WRN_FALLBACK_NONE;
+  // > 64 columns: the GEMMs of the loop are rnn_ts3_body's operand pairs (|x| <= 65504).  Their range word is read behind the loop --
+  // the call is HOST-BLOCKING there -- and a raised word reruns the whole loop on the fp32 instances (rnn_ts2_body.h): no silent clamp.
+  const bool pairs = plan->n_folds > 64;
+  if (pairs) MB_HIP(hipMemsetAsync(w->d_range, 0, sizeof(int), w->loop_stream));  // (ordered before the loop: same stream)
+  int rc = wavernn_join_on_error(w, wavernn_generate_batch_impl(wc, plan, h_frames, h_d_mels, h_seeds, d_samples, d_workspace,
+                                                                workspace_bytes, stream, true));
+  if (rc || !pairs) return rc;
+  MB_HIP(hipMemcpyAsync(w->h_range, w->d_range, sizeof(int), hipMemcpyDeviceToHost, w->loop_stream));
+  MB_HIP(hipStreamSynchronize(w->loop_stream));
+  if (!*w->h_range) return MB_OK;
+  static bool warned = false;
+  if (!warned) {
+    fprintf(stderr, "[mbhip] wavernn batch: an activation left the operand-pair GEMMs' range (|x| > 65504 or NaN); rerunning on the fp32 instances\n");
+    warned = true;
+  }
+  w->last_fallback = MB_WRN_FALLBACK_RANGE;
+  return wavernn_join_on_error(w, wavernn_generate_batch_impl(wc, plan, h_frames, h_d_mels, h_seeds, d_samples, d_workspace,
+                                                              workspace_bytes, stream, false));
 }
 
 // Test hook (tests/test_wavernn_gpu.py): the Exp(1) draws E[step][fold][class] = -log u that every fused Gumbel-argmax
@@ -1567,6 +1628,12 @@ extern "C" int mb_wavernn_debug_noise_mol(uint64_t seed, int step0, int steps, i
   hipLaunchKernelGGL(wavernn_debug_noise_mol_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (unsigned long long)seed, step0, steps, folds,
                      nr_mix, d_out);
   MB_HIP(hipGetLastError());
+  return MB_OK;
+}
+extern "C" int mb_wavernn_last_path(const mb_wavernn* w, int* path, int* fallback) {
+  MB_REQUIRE(w, "wavernn_last_path: null handle");
+  if (path) *path = w->last_path;
+  if (fallback) *fallback = w->last_fallback;
   return MB_OK;
 }
 extern "C" int mb_wavernn_last_loop_ms(const mb_wavernn* w, float* ms, int* launches) {

@@ -37,7 +37,7 @@ namespace mb {
 constexpr int WQ_R1 = 64, WQ_R2 = 64, WQ_F = 32;
 constexpr int WQ_WGS = WQ_R1 + WQ_R2 + 3 * WQ_F;  // 224 resident workgroups, one per compute unit
 constexpr int WQ_G = 2;                           // column groups in flight (this kernel: 2..32 columns)
-constexpr int WQ_GMAX = 4;                        // wavernn_pipe16.h serves up to four groups (33..64 columns: an utterance beyond ~1400 frames)
+constexpr int WQ_GMAX = 6;                        // wavernn_pipe16.h serves up to six groups (33..96 columns: a 3000-frame utterance is 68 folds)
 constexpr int WQ_GC = 16;                         // columns per group (one MFMA column tile)
 constexpr int WQ_DEFAULT_ON = 1;                  // default for 2..32 columns (MBHIP_WAVERNN_RESIDENT overrides)
 

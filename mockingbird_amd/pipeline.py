@@ -35,7 +35,7 @@ def insert_breaks(wav: np.ndarray, frames_per_sentence: Sequence[int], hop_size:
 
 
 def gen_wavs(synthesizer, vocoder, requests: List[Tuple[List[str], np.ndarray]], *, style_idx=-1, min_stop_token=4,
-             steps=400, group=None, normalize=None, pcm16=None, dst=0, chunk_size=None) -> List[np.ndarray]:
+             steps=400, group=None, normalize=None, pcm16=None, dst=0, chunk_size=None, timings=None) -> List[np.ndarray]:
     """requests: [(texts, embed)] -> one waveform per request, in request order, on rank `dst` (every other rank
     returns []; dst=None: on every rank).
 
@@ -49,7 +49,11 @@ def gen_wavs(synthesizer, vocoder, requests: List[Tuple[List[str], np.ndarray]],
     synthesizer: object with synthesize_spectrograms / hparams.hop_size / sample_rate (the Synthesizer facade);
     vocoder: module or object with infer_waveform_batch(mels, normalize= | peak_normalize=, pcm16=, breaks=, break_hop=,
     break_sample_rate=, device_out=) -> (wavs, sample_rate): the hifigan / fregan facades (`normalize` = peak
-    normalisation) or the wavernn facade (`peak_normalize`; its `normalize` keeps meaning the mel scaling)."""
+    normalisation) or the wavernn facade (`peak_normalize`; its `normalize` keeps meaning the mel scaling).
+    timings: optional dict (measurement only, bench.py): receives this rank's seconds in "synthesizer", "vocoder" (device-synchronised)
+    and "gather"."""
+    import time
+    t_syn = t_voc = 0.0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     lengths = [sum(len(t) for t in texts) for texts, _ in requests]
@@ -63,8 +67,10 @@ def gen_wavs(synthesizer, vocoder, requests: List[Tuple[List[str], np.ndarray]],
             flat_embeds += [embed] * len(texts)
             owner += [i] * len(texts)
         skw = {"chunk_size": chunk_size} if chunk_size else {}  # additive keyword of the Synthesizer facade (utterances per decoder loop)
+        t0 = time.perf_counter()
         specs = synthesizer.synthesize_spectrograms(flat_texts, flat_embeds, style_idx=style_idx,
                                                     min_stop_token=min_stop_token, steps=steps, **skw)
+        t_syn = time.perf_counter() - t0
         per_req = {i: [s for s, o in zip(specs, owner) if o == i] for i in mine}
         mels = [np.concatenate(per_req[i], axis=1) for i in mine]
         kw = dict(pcm16=pcm16, breaks=[[s.shape[1] for s in per_req[i]] for i in mine],
@@ -76,8 +82,17 @@ def gen_wavs(synthesizer, vocoder, requests: List[Tuple[List[str], np.ndarray]],
             kw["peak_normalize"] = normalize
         else:
             kw["normalize"] = normalize
+        t0 = time.perf_counter()
         local, _sr = vocoder.infer_waveform_batch(mels, **kw)
+        if timings is not None:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            t_voc = time.perf_counter() - t0
+    t0 = time.perf_counter()
     gathered = sharding.gather_waveforms(local, group=group, dst=dst)
+    if timings is not None:
+        timings.update(synthesizer=t_syn, vocoder=t_voc, gather=time.perf_counter() - t0)
     if dst is not None and rank != dst:
         return []
     # gather_waveforms returns rank-major order; put the requests back in their own order

@@ -121,6 +121,12 @@ class WaveRNNDevice:
         ms, nl = C.c_float(), C.c_int()
         _lib.check(L.mb_wavernn_last_loop_ms(self._h, C.byref(ms), C.byref(nl)), "mb_wavernn_last_loop_ms")
         self.last_loop_ms, self.last_loop_launches, self.last_plan = ms.value, nl.value, p
+        path, fb = C.c_int(), C.c_int()
+        _lib.check(L.mb_wavernn_last_path(self._h, C.byref(path), C.byref(fb)), "mb_wavernn_last_path")
+        # which form of the loop produced these samples ("chain" | "persist1" | "pipe" | "pipe16") and whether a resident launch was
+        # discarded on the way (None | "abort" | "range"): the chain's stream differs from pipe16's at near-ties
+        self.last_path = ("chain", "persist1", "pipe", "pipe16")[path.value]
+        self.last_fallback = (None, "abort", "range")[fb.value]
         return (samples, logits) if want_logits else samples
 
     def sampler_noise(self, seed, steps, folds, step0=0):
@@ -219,6 +225,10 @@ class WaveRNNDevice:
         ms, nl = C.c_float(), C.c_int()
         _lib.check(L.mb_wavernn_last_loop_ms(self._h, C.byref(ms), C.byref(nl)), "mb_wavernn_last_loop_ms")
         self.last_loop_ms, self.last_loop_launches, self.last_batch_plan = ms.value, nl.value, plan
+        path, fb = C.c_int(), C.c_int()
+        _lib.check(L.mb_wavernn_last_path(self._h, C.byref(path), C.byref(fb)), "mb_wavernn_last_path")
+        self.last_path = ("chain", "persist1", "pipe", "pipe16")[path.value]
+        self.last_fallback = (None, "abort", "range")[fb.value]  # "range": the loop was rerun on the fp32 GEMMs (rnn_ts2_body.h)
         return [samples[offs[u]:offs[u + 1]] for u in range(n)]
 
     def generate_batch(self, mels, target, overlap, mu_law, seeds=None):

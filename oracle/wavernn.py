@@ -153,8 +153,11 @@ def n_classes_of(hp):  # fatchord_version.py:95-98
     return 30 if hp["mode"] == "MOL" else 2 ** hp["bits"]
 
 
-def sample_loop(w, hp, mels, aux, noise=None, forced=None, return_logits=False, max_steps=None):
+def sample_loop(w, hp, mels, aux, noise=None, forced=None, return_logits=False, max_steps=None, state=None, return_state=False):
     """Loop body :176-234.  mels [b, T, 80], aux [b, T, 128].
+    state / return_state (test infrastructure, no counterpart in the reference): (h1, h2, x) carried from a previous
+    call over the steps before mels[:, 0] -- a long replay runs as consecutive windows with bounded memory; state=None
+    is the reference's zero initialisation (:179-181).
     RAW mode -- noise: None -> Categorical(p).sample() on the global torch RNG (the reference's call);
            else [T, b, C] Exp(1) draws, sample = argmax(p / noise) (the same arithmetic
            torch.multinomial(p, 1) performs on CPU).
@@ -164,9 +167,12 @@ def sample_loop(w, hp, mels, aux, noise=None, forced=None, return_logits=False, 
     b_size, seq_len, _ = mels.size()
     if max_steps is not None:
         seq_len = min(seq_len, max_steps)
-    h1 = torch.zeros(b_size, hp["rnn_dims"])
-    h2 = torch.zeros(b_size, hp["rnn_dims"])
-    x = torch.zeros(b_size, 1)
+    if state is None:
+        h1 = torch.zeros(b_size, hp["rnn_dims"])
+        h2 = torch.zeros(b_size, hp["rnn_dims"])
+        x = torch.zeros(b_size, 1)
+    else:
+        h1, h2, x = state
     d = hp["res_out_dims"] // 4
     aux_split = [aux[:, :, d * i:d * (i + 1)] for i in range(4)]
     output, logits_all = [], []
@@ -199,7 +205,10 @@ def sample_loop(w, hp, mels, aux, noise=None, forced=None, return_logits=False, 
         output.append(sample)
         x = (forced[:, i] if forced is not None else sample).unsqueeze(-1)
     out = torch.stack(output).transpose(0, 1)
-    return (out, torch.stack(logits_all)) if return_logits else out
+    res = (out, torch.stack(logits_all)) if return_logits else out
+    if return_state:
+        return (*res, (h1, h2, x)) if return_logits else (res, (h1, h2, x))
+    return res
 
 
 def conditioning(w, hp, mel, batched, target, overlap):

@@ -143,7 +143,7 @@ def test_wavernn_persistent_kernel_falls_back_to_the_chain(cuda, lib, monkeypatc
                          ids=["2-folds", "3-folds", "15-folds", "23-folds", "32-folds", "3-folds-1-group", "13-folds-1-group"])
 def test_wavernn_pipe_kernel_keeps_the_sample_stream(wavernn, monkeypatch, frames, target, overlap, folds, groups):
     """wavernn_pipe.h (the EXACT resident kernel: MBHIP_WAVERNN_RESIDENT=exact; also the MOL path): ONE launch of role-specialised resident
-    workgroups, two fold-column groups in flight (one with MBHIP_WQ_GROUPS=1) -- against the 5-launch chain: the same samples,
+    workgroups, two fold-column groups in flight (one with MBHIP_DIAG=wq_groups=1) -- against the 5-launch chain: the same samples,
     sample for sample, from 2 to 32 columns (BASELINE configs[1] = 23).  The default kernel since round 4 (wavernn_pipe16.h, 22-bit
     operand pairs) is not bit-identical to the chain; it is held to the oracle in test_wavernn_gpu.py::test_production_*."""
     mel = torch.from_numpy(synth.wavernn_mel(frames, seed=17) / 4.0).cuda()
@@ -152,7 +152,7 @@ def test_wavernn_pipe_kernel_keeps_the_sample_stream(wavernn, monkeypatch, frame
     assert base.shape[0] == folds and wavernn.last_loop_launches == 5 * base.shape[1]
     monkeypatch.setenv("MBHIP_WAVERNN_RESIDENT", "exact")
     if groups == 1:
-        monkeypatch.setenv("MBHIP_WQ_GROUPS", "1")
+        monkeypatch.setenv("MBHIP_DIAG", "wq_groups=1")
     alt = wavernn.generate_samples(mel, True, target, overlap, seed=31)
     assert wavernn.last_loop_launches == 1, "the resident kernel did not run"
     bad = (base != alt)

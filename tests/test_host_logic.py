@@ -263,7 +263,9 @@ def test_wavernn_loop_path_table(lib):
         (1, 0, 1, 1, 191, 0, U, CHAIN), (1, 0, 1, 1, 192, 0, U, P1),                                                  # 192 workgroups
         (1, 0, 1, 1, 256, 1, U, CHAIN), (1, 0, 1, 1, 256, 1, ON, P1), (1, 0, 1, 1, 256, 1, EXACT, P1),                # failure memo / explicit switch
         (2, 0, 1, 1, 256, 0, U, PIPE16), (23, 0, 1, 1, 256, 0, U, PIPE16), (32, 0, 1, 1, 256, 0, U, PIPE16),
-        (33, 0, 1, 1, 256, 0, U, PIPE16), (64, 0, 1, 1, 256, 0, U, PIPE16), (65, 0, 1, 1, 256, 0, U, CHAIN), (65, 0, 1, 1, 256, 0, ON, CHAIN),
+        (33, 0, 1, 1, 256, 0, U, PIPE16), (64, 0, 1, 1, 256, 0, U, PIPE16), (65, 0, 1, 1, 256, 0, U, PIPE16), (96, 0, 1, 1, 256, 0, U, PIPE16),
+        (97, 0, 1, 1, 256, 0, U, CHAIN), (97, 0, 1, 1, 256, 0, ON, CHAIN), (65, 0, 1, 1, 256, 0, EXACT, CHAIN),       # six groups of 16
+        (64, 1, 1, 1, 256, 0, U, PIPE16), (65, 1, 1, 1, 256, 0, U, CHAIN), (65, 1, 1, 1, 256, 0, ON, CHAIN),          # MOL: the fused chain's 64 columns
         (23, 0, 1, 1, 256, 0, EXACT, PIPE), (33, 0, 1, 1, 256, 0, EXACT, CHAIN),                                      # the exact kernel: 32 columns
         (23, 0, 1, 0, 256, 0, U, PIPE), (23, 1, 1, 1, 256, 0, U, PIPE16), (40, 1, 1, 1, 256, 0, U, PIPE16),           # no images / MOL
         (23, 1, 1, 1, 256, 0, EXACT, PIPE), (40, 1, 1, 1, 256, 0, EXACT, CHAIN), (23, 1, 1, 0, 256, 0, U, PIPE),

@@ -19,13 +19,13 @@ for name, F, target, overlap, modes in CASES:
     mel = torch.from_numpy(synth.wavernn_mel(F, seed=0) / 4.0).cuda()
     res = {}
     for mode in modes:
-        os.environ.pop("MBHIP_WQ_GROUPS", None)
+        diag_set("wq_groups")
         diag_set("wp_trace")
         # (WQ_AB_EXACT=1: the exact fp32 resident kernel instead of the operand-pair one; "persist": the 4-column persist kernel of
         #  round 3 is gone, the mode now times the default resident kernel)
         os.environ["MBHIP_WAVERNN_RESIDENT"] = ("exact" if os.environ.get("WQ_AB_EXACT") == "1" else "1") if mode != "chain" else "0"
         if mode == "pipe_1group":
-            os.environ["MBHIP_WQ_GROUPS"] = "1"
+            diag_set("wq_groups", "1")
         dev.generate_samples(mel[:, :40], True, 2200, 100, seed=2)  # warm-up
         best = None
         for rep in range(3):

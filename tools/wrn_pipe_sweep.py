@@ -1,4 +1,4 @@
-"""Sweep of wavernn_pipe.h's A/B switches at BASELINE configs[1] (23 folds): us per step per MBHIP_DIAG=wq_flags / MBHIP_WQ_GROUPS value.
+"""Sweep of wavernn_pipe.h's A/B switches at BASELINE configs[1] (23 folds): us per step per MBHIP_DIAG=wq_flags / wq_groups value.
 usage: python tools/wrn_pipe_sweep.py FLAGS[,FLAGS...]"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
