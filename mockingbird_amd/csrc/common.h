@@ -13,6 +13,18 @@ namespace mb {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// fp32 -> fp16 hi + fp16 residual scaled by 2^11 (the operand split of every error-compensated fp16 MFMA path: conv1d.hip,
+// resblock_stage_f32.hip), two values at a time: v_cvt_pk_f16_f32, v_pk_add_f32, v_pk_mul_f32 -- 4 instructions per value instead
+// of 6-7.  The value is clamped to fp16's range first (a finite hi leaves a residual of at most half an fp16 ulp, <= 16, x 2^11 <=
+// 32768: the low half needs no clamp); results are bit for bit those of the scalar form (same roundings in the same order).
+typedef _Float16 mb_h2 __attribute__((ext_vector_type(2)));
+typedef float mb_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair(const float a, const float b, mb_h2& hi, mb_h2& lo) {
+  const mb_f2 v = {__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f)};
+  hi = __builtin_convertvector(v, mb_h2);
+  lo = __builtin_convertvector((v - __builtin_convertvector(hi, mb_f2)) * 2048.f, mb_h2);
+}
+
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what, const char* file, int line);
 

@@ -217,12 +217,10 @@ static constexpr float SPLIT_RANGE = 65504.f;  // |x| beyond this saturates (the
 __device__ __forceinline__ void split_store2(char* row, const int grp, const float (&v)[8]) {
   h16x8 hi, lo;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    // one clamp: a finite hi leaves a residual of at most half an fp16 ulp (<= 16), x 2^11 <= 32768 -- the low half needs none
-    const float x = __builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
-    const h16 h = (h16)x;
-    hi[e] = h;
-    lo[e] = (h16)((x - (float)h) * 2048.f);  // residual scaled by 2^11: a normal whenever hi is
+  for (int e = 0; e < 8; e += 2) {  // (packed: common.h split_pair)
+    mb_h2 h, l;
+    split_pair(v[e], v[e + 1], h, l);
+    hi[e] = h[0]; hi[e + 1] = h[1]; lo[e] = l[0]; lo[e + 1] = l[1];
   }
   *reinterpret_cast<h16x8*>(row + grp * 16) = hi;
   *reinterpret_cast<h16x8*>(row + SCK * 2 + grp * 16) = lo;

@@ -73,18 +73,18 @@ __device__ __forceinline__ void s32_st(float* base, const unsigned byte_off, con
 // fp32 x 8 -> fp16 hi and scaled fp16 residual (conv1d.hip split_store2)
 __device__ __forceinline__ void s32_split8(const float (&v)[8], h16x8& hi, h16x8& lo) {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const h16 h = (h16)__builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
-    hi[e] = h;
-    lo[e] = (h16)__builtin_amdgcn_fmed3f((v[e] - (float)h) * 2048.f, -65504.f, 65504.f);
+  for (int e = 0; e < 8; e += 2) {  // (packed, one clamp per value: common.h split_pair; bit for bit the scalar form's halves)
+    mb_h2 h, l;
+    split_pair(v[e], v[e + 1], h, l);
+    hi[e] = h[0]; hi[e + 1] = h[1]; lo[e] = l[0]; lo[e + 1] = l[1];
   }
 }
 __device__ __forceinline__ void s32_split4(const float (&v)[4], h16x4& hi, h16x4& lo) {
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const h16 h = (h16)__builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
-    hi[e] = h;
-    lo[e] = (h16)__builtin_amdgcn_fmed3f((v[e] - (float)h) * 2048.f, -65504.f, 65504.f);
+  for (int e = 0; e < 4; e += 2) {
+    mb_h2 h, l;
+    split_pair(v[e], v[e + 1], h, l);
+    hi[e] = h[0]; hi[e + 1] = h[1]; lo[e] = l[0]; lo[e + 1] = l[1];
   }
 }
 

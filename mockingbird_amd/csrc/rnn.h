@@ -174,6 +174,37 @@ __device__ __forceinline__ float4 wf_cond_row4_fp(const WfCond& c, const unsigne
   }
   return acc;
 }
+// ... and in two halves: the 29 loads now, the fmaf chain later (a resident workgroup has other work to put in between); same
+// expression, same bits
+struct WfCondRaw { float at[3], ai, kw[5], ut[5][3], ui[5]; };
+__device__ __forceinline__ void wf_cond_load(const WfCond& c, const unsigned f_live, const unsigned p_live, const bool live, const int j, const int H,
+                                             const int frames, WfCondRaw& r) {
+  const unsigned f = live ? f_live : (unsigned)frames + 4u;
+  const unsigned p = live ? p_live : 0u;
+  const long long fa = live ? (long long)f : (long long)frames;
+  const float* kw = c.Kw + p * 5;
+  const float* at = c.AT + fa * 3 * H + j;
+  r.at[0] = at[0]; r.at[1] = at[H]; r.at[2] = at[2 * H]; r.ai = c.AI[fa * H + j];
+  const float* ut = c.UT + (long long)f * 3 * H + j;
+  const float* ui = c.UI + (long long)f * H + j;
+#pragma unroll
+  for (int o = 0; o < 5; ++o) {
+    r.kw[o] = kw[o];
+    r.ut[o][0] = ut[(size_t)o * 3 * H]; r.ut[o][1] = ut[(size_t)o * 3 * H + H]; r.ut[o][2] = ut[(size_t)o * 3 * H + 2 * H];
+    r.ui[o] = ui[(size_t)o * H];
+  }
+}
+__device__ __forceinline__ float4 wf_cond_fma(const WfCondRaw& r) {
+  float4 acc = make_float4(r.at[0], r.at[1], r.at[2], r.ai);
+#pragma unroll
+  for (int o = 0; o < 5; ++o) {
+    acc.x = fmaf(r.kw[o], r.ut[o][0], acc.x);
+    acc.y = fmaf(r.kw[o], r.ut[o][1], acc.y);
+    acc.z = fmaf(r.kw[o], r.ut[o][2], acc.z);
+    acc.w = fmaf(r.kw[o], r.ui[o], acc.w);
+  }
+  return acc;
+}
 __device__ __forceinline__ float4 wf_cond_row4(const WfCond& c, const unsigned pos, const unsigned total_len, const int j, const int H,
                                                const int frames, const long long u_row0 = 0, const long long a_row0 = 0) {
   const bool live = pos < total_len;

@@ -103,6 +103,7 @@ __device__ __forceinline__ void rnn_ts3_body(const RnnDev& d, const int bx, cons
         for (int part = 0; part < 2; ++part) f.v[ks][m][part] = wA[m][((size_t)(st * 2 + ks) * 2 + part) * 64];
   };
   float4 xs[NT];
+  float rmax = 0.f;  // largest |a| + |b| this thread staged (NaN sticks)
   auto issueB = [&](const int st) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) xs[n] = *reinterpret_cast<const float4*>(pS[n] + st * TS3_KS);
@@ -116,8 +117,10 @@ __device__ __forceinline__ void rnn_ts3_body(const RnnDev& d, const int bx, cons
       const t3h2 ha = __builtin_convertvector(va, t3h2), hb2 = __builtin_convertvector(vb, t3h2);
       const t3h2 la = __builtin_convertvector((va - __builtin_convertvector(ha, t3f2)) * 2048.f, t3h2);   // exact differences, scaled residual
       const t3h2 lb2 = __builtin_convertvector((vb - __builtin_convertvector(hb2, t3f2)) * 2048.f, t3h2);
-      if (a.range_word && !((__builtin_fabsf(va[0]) + __builtin_fabsf(va[1])) + (__builtin_fabsf(vb[0]) + __builtin_fabsf(vb[1])) <= 65504.f))
-        __hip_atomic_store(a.range_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // range: a running NaN-propagating maximum of |a| + |b| (v_maximum3_f32: three instructions per four values, no branch -- a
+      // compare-and-branch per float4 cost the 736-column step 4 us of 63), looked at once behind the k loop
+      rmax = __builtin_elementwise_maximum(__builtin_elementwise_maximum(rmax, __builtin_fabsf(va[0]) + __builtin_fabsf(va[1])),
+                                           __builtin_fabsf(vb[0]) + __builtin_fabsf(vb[1]));
       const t3h4 h = {ha[0], ha[1], hb2[0], hb2[1]}, l = {la[0], la[1], lb2[0], lb2[1]};
       const int o = (n * 16 + c16) * TS3_ROW + k4 * 4;
       *reinterpret_cast<t3h4*>(hb + o) = h;
@@ -236,6 +239,7 @@ __device__ __forceinline__ void rnn_ts3_body(const RnnDev& d, const int bx, cons
   }
   __builtin_amdgcn_sched_barrier(0);
   compute(fb, 1);  // the last stage, in the shadow of the operand loads
+  if (a.range_word && !(rmax <= 65504.f)) __hip_atomic_store(a.range_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   {
     const float us = a.w16_unscale;
 #pragma unroll

@@ -981,7 +981,7 @@ static int wavernn_generate_impl(const mb_wavernn* wc, const mb_wavernn_plan* pl
     MB_HIP(hipEventSynchronize(w->ev_out));
     const int aborted = w->h_abort[0], out_of_range = q16 ? w->h_abort[1] : 0;
     if (wtrace && !aborted) {
-      unsigned long long marks[5 * 4 * 16];
+      unsigned long long marks[1024];  // [role 5][step 4][mark 16], then from word 512 every workgroup's publish time at step 1001
       MB_HIP(hipMemcpy(marks, trace, sizeof(marks), hipMemcpyDeviceToHost));
       if (FILE* f = fopen(wtrace, "wb")) { fwrite(marks, sizeof(marks), 1, f); fclose(f); }
     }

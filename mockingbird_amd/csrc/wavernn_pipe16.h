@@ -105,14 +105,17 @@ __device__ __forceinline__ void wq16_put(unsigned long long* p, const float va, 
   const unsigned w0 = __builtin_bit_cast(unsigned, h), w1 = (__builtin_bit_cast(unsigned, l) & ~1u) | tb;
   __hip_atomic_store(p, ((unsigned long long)w1 << 32) | (unsigned long long)w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// a published value beyond fp16's range (or a NaN): sum of magnitudes above 65504 or unordered.  (A sum that trips although every
-// term is in range only sends the utterance to the exact chain.)
-__device__ __forceinline__ void wq16_range2(int* range_word, const float a, const float b) {
-  if (!(__builtin_fabsf(a) + __builtin_fabsf(b) <= 65504.f)) __hip_atomic_store(range_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// Range bookkeeping of a publishing lane: a running NaN-propagating maximum (v_maximum3_f32) of |a| + |b| over everything it published,
+// looked at ONCE when its role's loop ends -- no compare-and-branch on the critical path of an item.  (A pair sum that trips although both
+// terms are in range only sends the utterance to the exact chain.)
+__device__ __forceinline__ float wq16_track2(const float rmax, const float a, const float b) {
+  return __builtin_elementwise_maximum(rmax, __builtin_fabsf(a) + __builtin_fabsf(b));
 }
-__device__ __forceinline__ void wq16_range4(int* range_word, const float a, const float b, const float c, const float d) {
-  if (!((__builtin_fabsf(a) + __builtin_fabsf(b)) + (__builtin_fabsf(c) + __builtin_fabsf(d)) <= 65504.f))
-    __hip_atomic_store(range_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ float wq16_track4(const float rmax, const float a, const float b, const float c, const float d) {
+  return __builtin_elementwise_maximum(__builtin_elementwise_maximum(rmax, __builtin_fabsf(a) + __builtin_fabsf(b)), __builtin_fabsf(c) + __builtin_fabsf(d));
+}
+__device__ __forceinline__ void wq16_range_report(int* range_word, const float rmax) {
+  if (!(rmax <= 65504.f)) __hip_atomic_store(range_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ bool wq16_fresh(const unsigned long long v, const unsigned tb) { return (((unsigned)(v >> 32)) & 1u) == tb; }
 
@@ -260,6 +263,7 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
   unsigned long long* s_key = reinterpret_cast<unsigned long long*>(red + WQ_LDS_RED);  // [group][GC] max key of the step
   float* s_x = reinterpret_cast<float*>(s_key + WQ_GMAX * WQ_GC);                          // [group][GC] (MOL) decoded samples
   float* s_xr = s_x + WQ_GMAX * WQ_GC;                                                     // R2: [8 units][16 columns] residual hand-over
+  int* s_stale = reinterpret_cast<int*>(s_xr + 8 * 16);                                    // R1: a key lane found a stale granule in its direct fetch
   if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // (tests: the fallback path)
   const int blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -275,6 +279,7 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
     g_off[g] = (unsigned)((wave * 32 + (lane >> 4) * 4) * WQ_GC + (i < Ng ? i : (Ng > 0 ? Ng - 1 : 0)));
   }
   int rb = 0;                 // red buffer of the next GEMM
+  float rmax = 0.f;           // range bookkeeping of this lane's publications (wq16_track*)
   auto EX = [&](int what, int g, unsigned tag) { return a.ex + ((size_t)g * 2 + (tag & 1)) * WQX_PER + what; };
 #define WQ_MARK(role, k)                                                                                   \
   do {                                                                                                     \
@@ -287,6 +292,7 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
     // ---------------------------------------------------------------------------------------------- R1: rnn1
     const bool mark_wg = blk == 0;
     if (tid < WQ_GMAX * WQ_GC) s_key[tid] = 0ull;
+    if (tid == 0) *s_stale = 0;
     Wq16A A0, A1;
     wq16_load_a(k16.h_hh1, 2 * blk, A0);
     wq16_load_a(k16.h_hh1, 2 * blk + 1, A1);
@@ -333,14 +339,29 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
           if (wave < 2) x = i < Ng ? s_x[g * WQ_GC + i] : 0.f;
         } else if (s > 0) {
           const unsigned long long* K = EX(WQX_KEY, g, tag_prev);
-          wp_watch<1>(K + (size_t)((n_t3 - 1) * 2 + 1) * LD + (Ng - 1), tag_prev, a.abort_word);
-          if (tid < 32 * Ng && (tid & 31) < n_t3) {
-            const int tile = tid & 31, n = tid >> 5;
-            unsigned kv[2];
-            if (!wp_wait<2>(K + (size_t)tile * 2 * LD + n, LD, tag_prev, kv, a.abort_word)) return;
-            atomicMax(&s_key[g * WQ_GC + n], ((unsigned long long)kv[0] << 32) | (unsigned long long)kv[1]);
+          // ONE direct fetch first: when this workgroup is late (it serves the other group's item while the keys arrive) they are all
+          // there and the watch would be a second round trip for nothing; a lane that finds a stale granule says so and the
+          // workgroup falls back to watch + fetch (every lane polling by itself while the keys are NOT there yet cost 0.7 us per
+          // step in round 3)
+          const bool key_lane = tid < 32 * Ng && (tid & 31) < n_t3;
+          const int tile = tid & 31, n = tid >> 5;
+          bool have = false;
+          if (key_lane) {
+            const unsigned long long k0 = wp_get(K + (size_t)tile * 2 * LD + n), k1 = wp_get(K + (size_t)tile * 2 * LD + LD + n);
+            have = (unsigned)(k0 >> 32) == tag_prev && (unsigned)(k1 >> 32) == tag_prev;
+            if (have) atomicMax(&s_key[g * WQ_GC + n], ((unsigned long long)(unsigned)k0 << 32) | (unsigned long long)(unsigned)k1);
+            else *s_stale = 1;
           }
           __syncthreads();
+          if (*s_stale) {  // (uniform; cleared behind the h1 gather's barrier with the key slots)
+            wp_watch<1>(K + (size_t)((n_t3 - 1) * 2 + 1) * LD + (Ng - 1), tag_prev, a.abort_word);
+            if (key_lane && !have) {
+              unsigned kv[2];
+              if (!wp_wait<2>(K + (size_t)tile * 2 * LD + n, LD, tag_prev, kv, a.abort_word)) return;
+              atomicMax(&s_key[g * WQ_GC + n], ((unsigned long long)kv[0] << 32) | (unsigned long long)kv[1]);
+            }
+            __syncthreads();
+          }
           WQ_MARK(0, 1);
           if (wave < 2) {
             const unsigned long long slot = s_key[g * WQ_GC + i];
@@ -365,33 +386,43 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
             const unsigned tb = wq16_tbit(tag);
             wq16_put(EX(WQX_X1, g, tag) + p_off, x1, x1o, tb);
             wq16_put(EX(WQX_H1, g, tag) + p_off, hy, hyo, tb);   // |h| < 1: in range by construction
-            wq16_range2(k16.range_word, x1, x1o);
+            rmax = wq16_track2(rmax, x1, x1o);
           }
         }
         WQ_MARK(0, 2);
+        if (TRACE && a.trace && tid == 0 && g == 0 && s == 1001) a.trace[512 + blk] = (unsigned long long)wall_clock64();  // every workgroup's publish time
         if (s + 1 >= S) {  // last step: no hidden half to prepare; the key slots are still cleared behind a barrier
           __syncthreads();
           if (tid < WQ_GC) s_key[g * WQ_GC + tid] = 0ull;
+          if (tid == 0) *s_stale = 0;
           continue;
         }
-        // ---- next step's table rows (a whole step to arrive) ----
-        if (wave < 2) {
-          const float4 t4 = wf_cond_row4_fp(a.cond, pq[g].f, pq[g].p, pq[g].pos < total_len, ju, H, a.g.frames);
-          tq[g][0] = t4.x; tq[g][1] = t4.y; tq[g][2] = t4.z; tq[g][3] = t4.w;
-        }
+        // ---- next step's table rows: the 29 loads are REQUESTED here and combined at the end of the item (round 5's marks: R1 is the
+        //      busiest role -- its item, not the ring, set the period -- and waves 0 / 1, the watching lane among them, sat in
+        //      these loads' round trip between the publication and the h1 sweep) ----
+        WfCondRaw craw;
+        if (wave < 2) wf_cond_load(a.cond, pq[g].f, pq[g].p, pq[g].pos < total_len, ju, H, a.g.frames, craw);
         pq[g].step(hop);
+        WQ_MARK(0, 5);
         // ---- hidden half of the next step: P1 = W_hh1 . h1 + b_hh1, kept by the lane that will use it ----
         wh16x8 bh[2], bl[2];
         if (!wq16_gather<2>(EX(WQX_H1, g, tag), g_off[g], tag, Ng, bh, bl, a.abort_word, WQ_MK(0, 6))) return;
         if (tid < WQ_GC) s_key[g * WQ_GC + tid] = 0ull;  // every finish lane has read the step's keys (the gather's barrier is behind us)
+        if (tid == 0) *s_stale = 0;
         WQ_MARK(0, 3);
         float sx[4];
         const bool epi = wq16_gemm2(A0, A1, bh, bl, red + rb * 4096, k16.us_hh1, sx);
         rb ^= 1;
         if (epi) { P1[g][0] = sx[0] + bq.x; P1[g][1] = sx[1] + bq.y; P1[g][2] = sx[2] + bq.z; }
         WQ_MARK(0, 4);
+        // ---- ... and the fmaf chains of the rows requested above (their loads have long arrived) ----
+        if (wave < 2) {
+          const float4 t4 = wf_cond_fma(craw);
+          tq[g][0] = t4.x; tq[g][1] = t4.y; tq[g][2] = t4.z; tq[g][3] = t4.w;
+        }
       }
     }
+    wq16_range_report(k16.range_word, rmax);
     return;
   }
 
@@ -459,10 +490,11 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
             const unsigned tb = wq16_tbit(tag);
             wq16_put(EX(WQX_X2, g, tag) + p_off, x2, x2o, tb);
             wq16_put(EX(WQX_H2, g, tag) + p_off, hy, hyo, tb);
-            wq16_range2(k16.range_word, x2, x2o);
+            rmax = wq16_track2(rmax, x2, x2o);
           }
         }
         WQ_MARK(1, 2);
+        if (TRACE && a.trace && tid == 0 && g == 0 && s == 1001) a.trace[512 + blk] = (unsigned long long)wall_clock64();
         if (s + 1 >= S) continue;
         if (!wq16_gather<2>(EX(WQX_H2, g, tag), g_off[g], tag, Ng, bh, bl, a.abort_word)) return;
         WQ_MARK(1, 3);
@@ -472,6 +504,7 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
         WQ_MARK(1, 4);
       }
     }
+    wq16_range_report(k16.range_word, rmax);
     return;
   }
 
@@ -584,7 +617,7 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
           const float y2 = fmaxf(sx[2] + fpre[g].z, 0.f), y3 = fmaxf(sx[3] + fpre[g].w, 0.f);
           wq16_put(Y, y0, y1, tb);
           wq16_put(Y + LD, y2, y3, tb);
-          wq16_range4(k16.range_word, y0, y1, y2, y3);
+          rmax = wq16_track4(rmax, y0, y1, y2, y3);
         }
       } else {  // wf_fc3_kernel's sampler; lanes of dead columns take part in the shuffles only
         const float bv[4] = {b3q.x, b3q.y, b3q.z, b3q.w};
@@ -609,8 +642,10 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
         }
       }
       WQ_MARK(2 + fr, 2);
+      if (TRACE && a.trace && tid == 0 && g == 0 && s == 1001) a.trace[512 + blk] = (unsigned long long)wall_clock64();
     }
   }
+  wq16_range_report(k16.range_word, rmax);
 #undef WQ_MARK
 #undef WQ_MK
 }

@@ -534,13 +534,12 @@ def test_production_activation_range_models_vs_oracle(cuda, lib, monkeypatch, ki
     else:
         assert dev.last_path == "chain" and dev.last_fallback == "range" and dev.last_loop_launches > 1
     _replay_all_steps(dev, w, ow.HP, mel, True, target, overlap, s, seed, steps, max_ties=4, window=600)
-    # the wide-batch GEMMs (> 64 columns: rnn_ts3_body.h)
-    fr = [100, 93, 100, 77]
-    mels_np = [synth.wavernn_mel(f, seed=60 + i) for i, f in enumerate(fr)]
-    seeds = [11, 12, 13, 14]
+    # the wide-batch GEMMs (rnn_ts3_body.h serves batches of >= 14 column tiles: twelve utterances of 19 folds = 228 columns)
+    mels_np = [synth.wavernn_mel(100, seed=60 + i) for i in range(12)]
+    seeds = list(range(11, 23))
     outs = dev.generate_samples_batch([torch.from_numpy(m / 4.0).cuda() for m in mels_np], 1000, 100, seeds)
-    assert dev.last_batch_plan.n_folds > 64 and dev.last_fallback == (None if kind == "small" else "range")
-    for u in (0, 3):
+    assert dev.last_batch_plan.n_folds == 228 and dev.last_fallback == (None if kind == "small" else "range")
+    for u in (0, 7, 11):
         _replay_all_steps(dev, w, ow.HP, mels_np[u], True, 1000, 100, outs[u].cpu(), seeds[u], 300, max_ties=3, window=300)
 
 

@@ -41,7 +41,12 @@ for name, F, target, overlap, modes in CASES:
             dev.generate_samples(mel, True, target, overlap, seed=5)
             diag_set("wp_trace")
             if os.path.exists(tf):
-                m = struct.unpack("<320Q", open(tf, "rb").read())
+                raw = open(tf, "rb").read()
+                m = struct.unpack("<320Q", raw[:2560])
+                if len(raw) >= 8192:  # round 5: every workgroup's publish time at step 1001 (R1 0..63, R2 64..127, F1 / F2 / F3 32 each)
+                    pw = struct.unpack("<224Q", raw[4096:4096 + 224 * 8])
+                    res["publish_us_step1001"] = {role: [round((x - m[0]) / 100.0, 2) if x else None for x in pw[lo:hi]]
+                                                  for role, lo, hi in (("R1", 0, 64), ("R2", 64, 128), ("F1", 128, 160), ("F2", 160, 192), ("F3", 192, 224))}
                 t0 = m[0]  # R1, step 1000, mark 0
                 res["pipe_marks_us"] = {role: [[(m[(r * 4 + st) * 16 + k] - t0) / 100.0 if m[(r * 4 + st) * 16 + k] else None for k in range(9)]
                                                for st in range(4)] for r, role in enumerate(("R1", "R2", "F1", "F2", "F3"))}
