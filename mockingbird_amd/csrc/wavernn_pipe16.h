@@ -119,6 +119,9 @@ __device__ __forceinline__ void wq16_range_report(int* range_word, const float r
 }
 __device__ __forceinline__ bool wq16_fresh(const unsigned long long v, const unsigned tb) { return (((unsigned)(v >> 32)) & 1u) == tb; }
 
+#ifndef WQ16_RETRY_SLEEP
+#define WQ16_RETRY_SLEEP 1  // s_sleep between two sweeps of a lane that found a stale granule (A/B)
+#endif
 // B fragments (hi and lo, two k-steps of 32) of this lane from an exchange vector [feature pair 256][16 columns]: lane (column
 // i, kb) of wave w needs features w * 64 + st * 32 + kb * 8 + 0..7 = pairs w * 32 + st * 16 + kb * 4 + 0..3 -- eight 8-byte
 // loads per lane (wf_pipe_kernel: sixteen), 32 KB per workgroup and sweep; word 0 / word 1 of granule j ARE register j of the
@@ -129,7 +132,10 @@ template <int SLEEP>
 __device__ __forceinline__ bool wq16_gather(const unsigned long long* vec, const unsigned lane_off, const unsigned tag, const int N, wh16x8 (&bh)[2], wh16x8 (&bl)[2],
                                             int* abort_word, unsigned long long* mk = nullptr) {
   const unsigned tb = wq16_tbit(tag);
-  if (threadIdx.x == 0) {
+  // SLEEP == 2 marks the hidden-state sweeps of R1 / R2 (h1, h2: published about a sweep's round trip before the workgroup asks for
+  // them, and off the chain): no watching lane there, every lane polls its own granules -- the watch was a second round trip for
+  // data that is almost always in place, and it kept the two busiest roles away from the chain's items (8.75 -> 8.53 us per step)
+  if (threadIdx.x == 0 && SLEEP != 2) {
     const unsigned long long* p = vec + (size_t)255 * WQ_GC + (N - 1);
     unsigned long long t0 = 0;
     for (int tries = 0; !wq16_fresh(wp_get(p), tb); ++tries) {
@@ -153,7 +159,7 @@ __device__ __forceinline__ bool wq16_gather(const unsigned long long* vec, const
     for (int q = 0; q < 8; ++q) stale = __builtin_amdgcn_bitop3_b32(stale, (unsigned)(v[q] >> 32), tb, 0xf6);
     if ((stale & 1u) == 0u) break;
     if ((tries & 1023) == 1023 && wp_lost(tries, t0, abort_word)) return false;
-    __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_s_sleep(WQ16_RETRY_SLEEP);
   }
 #pragma unroll
   for (int st = 0; st < 2; ++st) {
@@ -254,6 +260,9 @@ constexpr size_t WQ16_LDS_BYTES = (size_t)WQ_LDS_RED * 4 + WQ_GMAX * WQ_GC * 8 +
 // more fragment set live in the F roles, a branch per item).  NG: column groups the instance serves (its per-group state is
 // register arrays of that size; groups the launch does not use have Ng = 0).  TRACE: the diagnostics marks (MBHIP_DIAG=wp_trace=<file>)
 // exist in the <false, 2, true> instance only -- each mark is an exec-mask branch on the critical path of every item otherwise.
+#ifndef WQ16_CRIT_SLEEP
+#define WQ16_CRIT_SLEEP 1   // s_sleep between the polls of the watching lane on the chain's edges (A/B: 0 / 2)
+#endif
 template <bool MOL, int NG, bool TRACE>
 __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
   static_assert(NG >= 1 && NG <= WQ_GMAX, "column groups");
@@ -346,12 +355,16 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
           const bool key_lane = tid < 32 * Ng && (tid & 31) < n_t3;
           const int tile = tid & 31, n = tid >> 5;
           bool have = false;
+#ifdef WQ16_AB_KEYS_WATCH_ONLY
+          if (tid == 0) *s_stale = 1;
+#else
           if (key_lane) {
             const unsigned long long k0 = wp_get(K + (size_t)tile * 2 * LD + n), k1 = wp_get(K + (size_t)tile * 2 * LD + LD + n);
             have = (unsigned)(k0 >> 32) == tag_prev && (unsigned)(k1 >> 32) == tag_prev;
             if (have) atomicMax(&s_key[g * WQ_GC + n], ((unsigned long long)(unsigned)k0 << 32) | (unsigned long long)(unsigned)k1);
             else *s_stale = 1;
           }
+#endif
           __syncthreads();
           if (*s_stale) {  // (uniform; cleared behind the h1 gather's barrier with the key slots)
             wp_watch<1>(K + (size_t)((n_t3 - 1) * 2 + 1) * LD + (Ng - 1), tag_prev, a.abort_word);
@@ -466,7 +479,7 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
         }
         WQ_MARK(1, 0);
         wh16x8 bh[2], bl[2];
-        if (!wq16_gather<1>(EX(WQX_X1, g, tag), g_off[g], tag, Ng, bh, bl, a.abort_word, WQ_MK(1, 6))) return;
+        if (!wq16_gather<WQ16_CRIT_SLEEP>(EX(WQX_X1, g, tag), g_off[g], tag, Ng, bh, bl, a.abort_word, WQ_MK(1, 6))) return;
         WQ_MARK(1, 1);
         if (wave == xr_wave && (lane >> 4) == xr_kb) {  // residual of the own units: hi + 2^-11 lo, through LDS behind the GEMM's own barrier
           const wh16x8 xh = xr_st ? bh[1] : bh[0], xl = xr_st ? bl[1] : bl[0];
@@ -562,7 +575,7 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
       }
       WQ_MARK(2 + fr, 0);
       wh16x8 bh[2], bl[2];
-      if (!wq16_gather<1>(EX(src, g, tag), g_off[g], tag, Ng, bh, bl, a.abort_word, WQ_MK(2 + fr, 6))) return;
+      if (!wq16_gather<WQ16_CRIT_SLEEP>(EX(src, g, tag), g_off[g], tag, Ng, bh, bl, a.abort_word, WQ_MK(2 + fr, 6))) return;
       WQ_MARK(2 + fr, 1);
       float sx[4];
       if (f3mol) {
