@@ -996,9 +996,10 @@ def main():
             try:  # HBM bytes of one step (all six launches) from the committed PMC passes (tools/pmc_r03_ppg.sh)
                 ppg_pmc = "r05_pmc_ppg2mel.json" if os.path.exists(os.path.join(ROOT, "profiles", "r05_pmc_ppg2mel.json")) else "r03_pmc_ppg2mel.json"
                 pm = json.load(open(os.path.join(ROOT, "profiles", ppg_pmc)))
-                entry["roofline"]["traffic_chain_step"] = pm["step_hbm_bytes_per_launch"]  # measured on the 6-launch chain
+                pmc_resident = any("ppg_resident_kernel" in k for k in pm.get("kernels", {}))  # round 5 profiled the resident launch, round 3 the chain
+                entry["roofline"]["traffic_resident_step" if pmc_resident else "traffic_chain_step"] = pm["step_hbm_bytes_per_launch"]
                 entry["roofline"]["traffic_source"] = f"profiles/{ppg_pmc}: " + pm.get("source", "")[:200]
-                if not resident_p:
+                if resident_p == pmc_resident:  # the counters describe the form that was timed
                     entry["roofline"]["traffic"] = pm["step_hbm_bytes_per_launch"]
             except Exception:
                 pass
