@@ -970,6 +970,22 @@ def main():
                 entry[f"batch{pb}"] = {"ms": tp * 1e3, "steps": int(steps_p), "us_per_step": (lm * 1e3 if lm else tp * 1e6) / steps_p,
                                        "wall_us_per_step": tp * 1e6 / steps_p, "mel_frames_per_s": pb * steps_p * 2 / tp,
                                        "loop_launches": getattr(pdec, "last_loop_launches", None)}
+                if getattr(pdec, "last_loop_launches", 0) == 1:
+                    entry[f"batch{pb}"]["loop"] = ("ONE resident launch, fp32 fmaf chains on LDS-resident weights (ppg_resident.h)" if pb == 1 else
+                                                   "ONE resident launch (ppg_batch.h, round 5): 160 role workgroups + one attention workgroup per utterance, "
+                                                   "weights as split fp16 fragments in registers, error-compensated v_mfma_f32_16x16x32_f16, pair-granule "
+                                                   "hand-offs, two column groups of 16 in flight")
+                if pb == 32 and getattr(pdec, "last_loop_launches", 0) == 1:  # A/B partner: the 6-launch chain on the same batch
+                    os.environ["MBHIP_PPG_RESIDENT"] = "0"
+                    try:
+                        pdec.decode(pmem, seed=1)
+                        cm, _, _ = pdec.decode(pmem, seed=4)
+                        torch.cuda.synchronize()
+                        entry["batch32"]["chain_reference"] = {"us_per_step": pdec.last_loop_ms * 1e3 / cm.shape[1], "loop_launches": pdec.last_loop_launches,
+                                                               "loop": "6-launch step (ppg_fast.h), hipGraph replays, same batch",
+                                                               "mel_max_abs_diff_vs_resident": float((cm - pm).abs().max())}
+                    finally:
+                        os.environ.pop("MBHIP_PPG_RESIDENT", None)
                 if pb == 1 and getattr(pdec, "last_loop_launches", 0) == 1:  # A/B partner of the resident loop: the 6-launch chain
                     os.environ["MBHIP_PPG_RESIDENT"] = "0"
                     try:

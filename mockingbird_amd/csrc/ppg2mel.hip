@@ -16,6 +16,7 @@
 #include "rnn.h"
 #include "ppg_fast.h"
 #include "ppg_resident.h"
+#include "ppg_batch.h"
 
 namespace mb {
 
@@ -145,6 +146,12 @@ struct mb_ppg2mel {
   // resident loop at batch 1 (ppg_resident.h): per-workgroup LDS images of the same weights
   bool resident = false;
   DevBuf r_att, r_w1, r_dec, r_q0, r_out;
+  // resident loop for a batch of 2..32 (ppg_batch.h): split fp16 images (A fragments of v_mfma_f32_16x16x32_f16) + 2^-s per role
+  bool batch_resident = false;
+  DevBuf b_att_w1, b_att_wx, b_att_wc, b_att_wh, b_q0, b_dec_wa, b_dec_wc, b_dec_wh, b_out_wh, b_out_wc;
+  float b_us[5] = {1.f, 1.f, 1.f, 1.f, 1.f};  // prenet.1, attention LSTM, query_layer.0, decoder LSTM, output rows
+  int batch_cus = -1;
+  int last_batch_fallback = 0;  // 0 none, 1 lost hand-off, 2 operand range
   int resident_cus = -1;  // compute units a resident launch may count on (-1: not probed yet, 0: none)
   int* h_abort = nullptr;
   hipEvent_t ev_res = nullptr;
@@ -213,7 +220,8 @@ extern "C" void mb_ppg2mel_destroy(mb_ppg2mel* p) {
   for (auto& b : p->dec_bhh) b.release();
   DevBuf* bs[] = {&p->zero_bias, &p->att_w, &p->att_bih, &p->att_bhh, &p->q0_w, &p->q0_b, &p->q2_w, &p->q2_b, &p->out_w, &p->out_b,
                   &p->f_att_p, &p->f_att_c, &p->f_att_h, &p->f_att_b4, &p->f_dec_x, &p->f_dec_h, &p->f_dec_b4, &p->f_fc0_w, &p->f_fc0_b,
-                  &p->r_att, &p->r_w1, &p->r_dec, &p->r_q0, &p->r_out};
+                  &p->r_att, &p->r_w1, &p->r_dec, &p->r_q0, &p->r_out,
+                  &p->b_att_w1, &p->b_att_wx, &p->b_att_wc, &p->b_att_wh, &p->b_q0, &p->b_dec_wa, &p->b_dec_wc, &p->b_dec_wh, &p->b_out_wh, &p->b_out_wc};
   for (DevBuf* b : bs) b->release();
   p->drop_graph();
   if (p->h_flags) (void)hipHostFree(p->h_flags);
@@ -370,6 +378,61 @@ extern "C" int mb_ppg2mel_create(const mb_ppg2mel_config* cfg, const float* cons
           }
         RC(p->r_out.upload(img.data(), img.size()));
       }
+      // resident loop for 2..32 utterances (ppg_batch.h): the same matrices as split fp16 A fragments, row tiles in the roles' order
+      if (RMr % 16 == 0 && RMr / 16 <= 16 && M <= 5) {
+        auto cols = [](const float* w, int rows_n, int ld, int c0, int nc, auto row_of) {  // rows_n rows (tile order via row_of) x columns [c0, c0 + nc)
+          std::vector<float> o((size_t)rows_n * nc);
+          for (int r2 = 0; r2 < rows_n; ++r2) {
+            const int src = row_of(r2);
+            if (src < 0) { std::fill(o.begin() + (size_t)r2 * nc, o.begin() + (size_t)(r2 + 1) * nc, 0.f); continue; }
+            memcpy(&o[(size_t)r2 * nc], w + (size_t)src * ld + c0, sizeof(float) * nc);
+          }
+          return o;
+        };
+        auto natural = [](int r2) { return r2; };
+        auto lstm_a = [A](int r2) { return (r2 & 3) * A + (r2 >> 2); };  // unit-major tile rows: row 4 u + gate <- gate-major source row gate A + u
+        auto lstm_d = [D](int r2) { return (r2 & 3) * D + (r2 >> 2); };
+        auto up = [&](const std::vector<float>& m, int n_tiles, int K, int nwv, int sexp, DevBuf* dst) {
+          std::vector<unsigned short> img16;
+          pb_pack(m, n_tiles, K, nwv, sexp, &img16);
+          return dst->upload(reinterpret_cast<const float*>(img16.data()), img16.size() / 2);
+        };
+        const float *q0w = hw[6], *w1 = hw[1], *w_stop = hw[16];
+        {  // prenet.1 [128][256]
+          std::vector<float> m = cols(w1, Pn, P0, 0, P0, natural);
+          const int e = pb_scale_exp({&m});
+          RC(up(m, Pn / 16, P0, 8, e, &p->b_att_w1)); p->b_us[0] = std::ldexp(1.f, -e);
+        }
+        {  // attention LSTM: [prenet 128 | context 256] of w_ih, w_hh 512; one scale for the three parts of a gate sum
+          std::vector<float> mx = cols(a_wih, 4 * A, Pn + E, 0, Pn, lstm_a), mc = cols(a_wih, 4 * A, Pn + E, Pn, E, lstm_a), mh = cols(a_whh, 4 * A, A, 0, A, lstm_a);
+          const int e = pb_scale_exp({&mx, &mc, &mh});
+          RC(up(mx, A / 4, Pn, 4, e, &p->b_att_wx)); RC(up(mc, A / 4, E, 8, e, &p->b_att_wc)); RC(up(mh, A / 4, A, 8, e, &p->b_att_wh));
+          p->b_us[1] = std::ldexp(1.f, -e);
+        }
+        {  // query_layer.0 [256][512]
+          std::vector<float> m = cols(q0w, Q, A, 0, A, natural);
+          const int e = pb_scale_exp({&m});
+          RC(up(m, Q / 16, A, 8, e, &p->b_q0)); p->b_us[2] = std::ldexp(1.f, -e);
+        }
+        {  // decoder LSTM: [attention_hidden 512 | context 256] of w_ih, w_hh 512
+          std::vector<float> ma = cols(d_wih, 4 * D, A + E, 0, A, lstm_d), mc = cols(d_wih, 4 * D, A + E, A, E, lstm_d), mh = cols(d_whh, 4 * D, D, 0, D, lstm_d);
+          const int e = pb_scale_exp({&ma, &mc, &mh});
+          RC(up(ma, D / 4, A, 8, e, &p->b_dec_wa)); RC(up(mc, D / 4, E, 8, e, &p->b_dec_wc)); RC(up(mh, D / 4, D, 8, e, &p->b_dec_wh));
+          p->b_us[3] = std::ldexp(1.f, -e);
+        }
+        {  // output rows over [h 512 | context 256]: 16 tiles of prenet.0', RM / 16 projection tiles, the stop row (row 0 of its tile)
+          const int n_tiles = P0 / 16 + RMr / 16 + 1;
+          std::vector<float> all((size_t)n_tiles * 16 * kout, 0.f);
+          memcpy(all.data(), wf.data(), sizeof(float) * (size_t)P0 * kout);
+          memcpy(all.data() + (size_t)P0 * kout, w_proj, sizeof(float) * (size_t)RMr * kout);
+          memcpy(all.data() + (size_t)(P0 + RMr) * kout, w_stop, sizeof(float) * kout);
+          std::vector<float> mh = cols(all.data(), n_tiles * 16, kout, 0, D, natural), mc = cols(all.data(), n_tiles * 16, kout, D, E, natural);
+          const int e = pb_scale_exp({&mh, &mc});
+          RC(up(mh, n_tiles, D, 8, e, &p->b_out_wh)); RC(up(mc, n_tiles, E, 8, e, &p->b_out_wc));
+          p->b_us[4] = std::ldexp(1.f, -e);
+        }
+        p->batch_resident = !rc;
+      }
     }
     if (!rc && (hipHostMalloc((void**)&p->h_flags, sizeof(int) * 16) != hipSuccess ||
                 hipStreamCreateWithFlags(&p->loop_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -378,7 +441,7 @@ extern "C" int mb_ppg2mel_create(const mb_ppg2mel_config* cfg, const float* cons
                 hipEventCreateWithFlags(&p->ev_flags[0], hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&p->ev_flags[1], hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&p->ev_res, hipEventDisableTiming) != hipSuccess ||
-                hipHostMalloc((void**)&p->h_abort, sizeof(int), hipHostMallocDefault) != hipSuccess)) {
+                hipHostMalloc((void**)&p->h_abort, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess)) {
       set_error("ppg2mel_create: stream / events / pinned flags");
       rc = MB_EHIP;
     }
@@ -427,7 +490,7 @@ void ppg_layout(const mb_ppg2mel* p, int B, void* base, PpgLayout* L) {
     L->f_bytes = ar.off - start;
   }
   L->flags = ar.take<int>(16);
-  L->px = ar.take<unsigned long long>(pr_exchange_bytes() / 8);
+  L->px = ar.take<unsigned long long>(std::max(pr_exchange_bytes(), pb_exchange_bytes()) / 8);
   L->bytes = ar.off + 256;
 }
 }  // namespace
@@ -613,6 +676,89 @@ extern "C" int mb_ppg2mel_decode(const mb_ppg2mel* p, const float* d_memory, int
     const char* renv = getenv("MBHIP_PPG_RESIDENT");
     bool resident = pm->resident && B == 1 && T <= PR_T_MAX && !(renv && atoi(renv) == 0);
     int dev = 0;
+    // 2..32 utterances: the whole loop as ONE resident launch on MFMA tiles (ppg_batch.h): 160 role workgroups + one per utterance,
+    // co-resident; the same switch, the same fallbacks (lost hand-off -> abort word 1, operand range -> range word: the chain reruns the batch)
+    pm->last_batch_fallback = 0;
+    bool batch_res = pm->batch_resident && B >= 2 && B <= PB_BMAX && T <= PB_T_MAX && !(renv && atoi(renv) == 0);
+    if (batch_res) {
+      MB_HIP(hipGetDevice(&dev));
+      if (pm->batch_cus < 0) {
+        hipDeviceProp_t prop;
+        MB_HIP(hipGetDeviceProperties(&prop, dev));
+        MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ppg_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PB_LDS_BYTES));
+        int nb = 0;
+        MB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(ppg_batch_kernel), 512, PB_LDS_BYTES));
+        pm->batch_cus = nb >= 1 ? prop.multiProcessorCount : 0;
+      }
+      if (pm->batch_cus < PB_G_MOL + B) batch_res = false;
+      if (dev >= 0 && dev < 64 && g_ppg_resident_failed[dev] && !renv) batch_res = false;
+    }
+    if (batch_res) {
+      hipStream_t ls = pm->loop_stream;
+      int* abort_word = reinterpret_cast<int*>(L.px + (size_t)PB_NG * 2 * PBX_PER);
+      MB_HIP(hipMemsetAsync(L.px, 0, pb_exchange_bytes(), ls));
+      const bool test_abort = diag_int("abort_pr") != 0;
+      if (test_abort) MB_HIP(hipMemsetAsync(abort_word, 1, 1, ls));
+      MB_HIP(hipMemcpyAsync(L.flags + TF_SEED, &seed, sizeof(seed), hipMemcpyHostToDevice, ls));
+      const int P0 = c.prenet_dims[0], P1 = c.prenet_dims[1];
+      PbK k;
+      k.att_w1 = {reinterpret_cast<const uint4*>(pm->b_att_w1.p), pm->b_us[0]};
+      k.att_wx = {reinterpret_cast<const uint4*>(pm->b_att_wx.p), pm->b_us[1]};
+      k.att_wc = {reinterpret_cast<const uint4*>(pm->b_att_wc.p), pm->b_us[1]};
+      k.att_wh = {reinterpret_cast<const uint4*>(pm->b_att_wh.p), pm->b_us[1]};
+      k.q0_w = {reinterpret_cast<const uint4*>(pm->b_q0.p), pm->b_us[2]};
+      k.dec_wa = {reinterpret_cast<const uint4*>(pm->b_dec_wa.p), pm->b_us[3]};
+      k.dec_wc = {reinterpret_cast<const uint4*>(pm->b_dec_wc.p), pm->b_us[3]};
+      k.dec_wh = {reinterpret_cast<const uint4*>(pm->b_dec_wh.p), pm->b_us[3]};
+      k.out_wh = {reinterpret_cast<const uint4*>(pm->b_out_wh.p), pm->b_us[4]};
+      k.out_wc = {reinterpret_cast<const uint4*>(pm->b_out_wc.p), pm->b_us[4]};
+      k.att_b4 = reinterpret_cast<const float4*>(pm->f_att_b4.p); k.dec_b4 = reinterpret_cast<const float4*>(pm->f_dec_b4.p);
+      k.q0_b = pm->q0_b.p; k.out_b = pm->out_b.p; k.fc0_b = pm->f_fc0_b.p; k.w2 = pm->q2_w.p; k.b2 = pm->q2_b.p;
+      k.memory = d_memory; k.mel_out = d_mel; k.align_out = d_align; k.stop_out = d_stop;
+      DropK dk;
+      dk.thresh = 0x80000000u; dk.scale = 2.f; dk.enabled = 1; dk.it_add = 0; dk.it_limit = max_steps;  // F.dropout(p = 0.5, training = True)   DecoderPrenet :18-21
+      k.drop1 = dk; k.drop1.layer = 1; k.drop1.ld = P1; k.drop1.it_stride = (long long)B * P1;
+      k.drop1.mask = d_dropout ? d_dropout + (size_t)max_steps * B * P0 : nullptr;
+      k.drop0 = dk; k.drop0.layer = 0; k.drop0.it_add = 1; k.drop0.ld = P0; k.drop0.it_stride = (long long)B * P0; k.drop0.mask = d_dropout;
+      k.ex = L.px; k.abort_word = abort_word; k.range_word = abort_word + 1; k.flags = L.flags;
+      k.B = B; k.T = T; k.M = M; k.RM = RM; k.S = max_steps; k.min_steps = min_steps; k.thr = stop_threshold; k.eps = 1e-5f;
+      const int ng = (B <= PB_GC && !(B >= 2 && diag_int("pb_groups") == 2)) ? 1 : 2;  // (A/B: MBHIP_DIAG=pb_groups=2 splits a small batch too)
+      k.gn0[0] = 0; k.gn0[1] = ng == 1 ? B : (B + 1) / 2; k.gn0[2] = B;
+      MB_HIP(hipEventRecord(pm->ev_t0, ls));
+      hipLaunchKernelGGL(ppg_batch_kernel, dim3(PB_G_MOL + B), dim3(512), PB_LDS_BYTES, ls, k);
+      MB_HIP(hipGetLastError());
+      MB_HIP(hipEventRecord(pm->ev_t1, ls));
+      MB_HIP(hipMemcpyAsync(pm->h_abort, abort_word, 2 * sizeof(int), hipMemcpyDeviceToHost, ls));
+      MB_HIP(hipMemcpyAsync(pm->h_flags, L.flags, sizeof(int) * 8, hipMemcpyDeviceToHost, ls));
+      MB_HIP(hipEventRecord(pm->ev_res, ls));
+      MB_HIP(hipEventSynchronize(pm->ev_res));
+      if (pm->h_abort[0] != 1 && pm->h_abort[1] == 0) {
+        *h_n_steps = pm->h_flags[TF_NFRAMES];
+        pm->last_steps = *h_n_steps; pm->timed = true; pm->last_resident = true;
+        return MB_OK;
+      }
+      if (pm->h_abort[0] == 1) {
+        static bool warned_b = false;
+        if (!warned_b) {
+          fprintf(stderr, "[mbhip] ppg2mel: the batch resident kernel could not keep its workgroups co-resident; using the launch chain\n");
+          warned_b = true;
+        }
+        if (dev >= 0 && dev < 64 && !test_abort) g_ppg_resident_failed[dev] = true;
+        pm->last_batch_fallback = 1;
+      } else {
+        static bool warned_r = false;
+        if (!warned_r) {
+          fprintf(stderr, "[mbhip] ppg2mel: an activation left the operand-pair kernel's range (|x| > 65504 or NaN); using the fp32 launch chain\n");
+          warned_r = true;
+        }
+        pm->last_batch_fallback = 2;
+      }
+      MB_HIP(hipMemsetAsync(L.mu, 0, sizeof(float) * B * M, ls));
+      MB_HIP(hipMemsetAsync(L.flags, 0, sizeof(int) * 8, ls));
+      MB_HIP(hipMemsetAsync(d_mel, 0, sizeof(float) * (size_t)B * max_steps * RM, ls));
+      MB_HIP(hipMemsetAsync(d_align, 0, sizeof(float) * (size_t)B * max_steps * T, ls));
+      MB_HIP(hipMemsetAsync(d_stop, 0, sizeof(float) * (size_t)B * max_steps, ls));
+    }
     if (resident) {
       MB_HIP(hipGetDevice(&dev));
       if (pm->resident_cus < 0) {

@@ -1,0 +1,659 @@
+// ppg2mel decoder loop for a BATCH of 2..32 utterances (Decoder.inference_batched, models/ppg2mel/rnn_decoder_mol.py:317-374; attend
+// :187-198, decode :200-209, DecoderPrenet :10-22; utils/mol_attention.py:67-122) as ONE resident launch: VERDICT r02 item 5 / r03 item 7 /
+// r04 missing #1.  At batch 32 the 6-launch step of ppg_fast.h is 30 us of launch latency around 1.2 GFLOP; ppg_resident.h (one
+// utterance: lane-private fmaf chains) does not scale to columns.  This is wavernn_pipe16.h's machine on ppg2mel's layers:
+//
+//   role  workgroups  weight tiles (split fp16 images in REGISTERS)      on the chain (per step and column group)                 in its shadow
+//   ATT   64          prenet.1 (8 tiles, its K slice) | attention LSTM    W_ctx ctx(s-1) while waiting; p0 -> p1 = drop(relu(prenet.1   W_hh att_h of the next
+//                     units 8g..8g+7: W_x, W_ctx, W_hh (2 tiles)          p0)) (every workgroup, its K slice of all 8 tiles, reduced  step (lane-private sums)
+//                                                                         in LDS) -> W_x p1 + parts -> LSTMCell -> att_h
+//   Q0    16          query_layer.0 tile j                                att_h -> q = relu(.. + b)
+//   MOL   one per     (memory rows in registers, ppg_resident.h's code)   q of ITS column -> mixture parameters -> alpha -> context
+//         utterance
+//   DEC   64          decoder LSTM units 8d..8d+7: W_att, W_ctx, W_hh     W_hh h(s-1), W_att att_h early; + W_ctx ctx -> LSTMCell -> h
+//   OUT   16          prenet.0' tile j | projection tile j | stop row     W_ctx ctx early; + W_h h -> frames, stop logit, p0(s + 1)
+//
+// Five hand-offs per step (p0 -> att_h -> q -> ctx -> h -> p0) on pair granules (pair_granule.h: two features per 8-byte granule, fp16
+// hi + scaled lo, 1-bit tags), utterance columns in groups of 16 that travel through the roles in turn (B <= 16: one group).  Products are
+// error-compensated v_mfma_f32_16x16x32_f16 (w 2^s = wh + wl on the host, one s per role so that the parts of a gate sum share a
+// scale); sums, cell states, gates, the attention window and the outputs are fp32.  Results are fp32-grade, not bit-identical to
+// ppg_fast.h's (other summation orders): the tests hold both to the oracle at the same tolerance.
+// Stop rule (:349-354): every OUT workgroup carries the stop row; when no utterance of any group is below the threshold at step s (and
+// s + 1 >= min_steps) the OUT workgroups hold back what they had not published yet, workgroup 0 of the role writes the frame count
+// and raises the abort word to 2 = "finished"; every waiting loop looks at that word.  (A group that was served before the last vote
+// of the step was in has its p0(s + 1) out already: the roles run that group's step s + 1 up to the point where they wait for a
+// vector that never comes -- its outputs lie beyond the frame count the host reports.)
+// A lost hand-off raises the word to 1 after 0.2 s (granule.h), a published value beyond the operand pairs' range raises the range
+// word: either way the host reruns the batch on the launch chain.
+#pragma once
+#include "ppg_resident.h"
+#include "pair_granule.h"
+
+namespace mb {
+
+constexpr int PB_ATT = 64, PB_DEC = 64, PB_Q0 = 16, PB_OUT = 16, PB_GC = 16, PB_NG = 2, PB_BMAX = PB_GC * PB_NG;
+constexpr int PB_G_DEC = PB_ATT, PB_G_Q0 = PB_ATT + PB_DEC, PB_G_OUT = PB_G_Q0 + PB_Q0, PB_G_MOL = PB_G_OUT + PB_OUT;  // + one MOL workgroup per utterance
+// exchange area per (group, parity), in granules: vectors of [feature pair][16 columns]
+enum { PBX_P0 = 0, PBX_AH = 128 * PB_GC, PBX_Q = (128 + 256) * PB_GC, PBX_CTX = (128 + 256 + 128) * PB_GC, PBX_DH = (128 + 256 + 128 + 128) * PB_GC,
+       PBX_PER = (128 + 256 + 128 + 128 + 256) * PB_GC };
+inline size_t pb_exchange_bytes() { return (size_t)PB_NG * 2 * PBX_PER * 8 + 256 + 8192; }  // + abort / range words + diagnostics marks
+constexpr int PB_T_MAX = 4096;
+// LDS (bytes): [red A: 8 tiles x 8 waves x 1 KB] [red B: 3 tiles x 8 waves x 1 KB] [p1 hi | lo: 16 columns x 136 halves each] [small]
+constexpr int PB_LDS_REDA = 64 * 1024, PB_LDS_REDB = 24 * 1024, PB_P1_ROW = 136;
+constexpr size_t PB_LDS_BYTES = (size_t)PB_LDS_REDA + PB_LDS_REDB + 2 * PB_GC * PB_P1_ROW * 2 + 1024;
+
+struct PbImg { const uint4* w; float us; };  // split image [tile][wave][k-step][hi | lo][lane] (16 bytes each) and its 2^-s
+struct PbK {
+  PbImg att_w1, att_wx, att_wc, att_wh;  // prenet.1 [8 tiles] K = 256 | attention LSTM [128 unit-major tiles] K = 128 (4 waves) / 256 / 512
+  PbImg q0_w;                            // query_layer.0 [16 tiles] K = 512
+  PbImg dec_wa, dec_wc, dec_wh;          // decoder LSTM [128 unit-major tiles] K = 512 / 256 / 512
+  PbImg out_wh, out_wc;                  // [16 prenet.0' | RM / 16 projection | 1 stop] tiles, K = 512 / 256
+  const float4* att_b4; const float4* dec_b4;  // (b_ih + b_hh) as (i, f, g, o) per unit
+  const float* q0_b; const float* out_b; const float* fc0_b;  // out_b: projection bias [RM] then the stop bias
+  const float* w2; const float* b2;      // query_layer.2 [3M][256], [3M]
+  const float* memory;                   // [B][T][256]
+  float* mel_out; float* align_out; float* stop_out;  // [B][S][RM], [B][S][T], [B][S]
+  DropK drop0, drop1;                    // prenet layer 0 (prepared for step + 1: it_add = 1) and layer 1
+  unsigned long long* ex; int* abort_word; int* range_word; int* flags;
+  int B, T, M, RM, S, min_steps;
+  float thr, eps;
+  int gn0[PB_NG + 1];                    // group g owns utterance columns [gn0[g], gn0[g + 1])
+};
+
+// ---- host: rows [n_tiles * 16][K] in tile order -> [tile][wave NWV][k-step KS][hi | lo][lane 64][8 halves], k = (wave KS + st) 32 + kb 8 + e ----
+inline int pb_scale_exp(const std::vector<const std::vector<float>*>& mats) {
+  float wmax = 0.f;
+  for (const auto* m : mats) for (float v : *m) wmax = std::max(wmax, std::fabs(v));
+  if (!(wmax > 0.f) || !std::isfinite(wmax)) return 0;
+  int e2;
+  (void)std::frexp(wmax, &e2);
+  return std::max(-24, std::min(40, 14 - e2));
+}
+inline void pb_pack(const std::vector<float>& rows, int n_tiles, int K, int NWV, int sexp, std::vector<unsigned short>* out) {
+  const int KS = K / (32 * NWV);
+  const float scale = std::ldexp(1.f, sexp);
+  out->assign((size_t)n_tiles * NWV * KS * 2 * 64 * 8, 0);
+  for (int t = 0; t < n_tiles; ++t)
+    for (int w = 0; w < NWV; ++w)
+      for (int st = 0; st < KS; ++st)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int m = lane & 15, kb = lane >> 4;
+          for (int e = 0; e < 8; ++e) {
+            const int k = (w * KS + st) * 32 + kb * 8 + e;
+            const float v = rows[((size_t)t * 16 + m) * K + k] * scale;
+            const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+            unsigned short hb, lb;
+            memcpy(&hb, &hi, 2); memcpy(&lb, &lo, 2);
+            const size_t base = ((((size_t)t * NWV + w) * KS + st) * 2) * 64 * 8;
+            (*out)[base + (size_t)lane * 8 + e] = hb;
+            (*out)[base + 64 * 8 + (size_t)lane * 8 + e] = lb;
+          }
+        }
+}
+
+// ---- device ----
+template <int KS> struct PbA { wh16x8 h[KS], l[KS]; };
+template <int KS, int NWV>
+__device__ __forceinline__ void pb_load_a(const PbImg& img, const int tile, PbA<KS>& A) {
+  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) % NWV;
+  const uint4* p = img.w + ((size_t)(tile * NWV + wave) * KS) * 2 * 64 + lane;
+#pragma unroll
+  for (int st = 0; st < KS; ++st) {
+    A.h[st] = __builtin_bit_cast(wh16x8, p[(st * 2) * 64]);
+    A.l[st] = __builtin_bit_cast(wh16x8, p[(st * 2 + 1) * 64]);
+  }
+}
+// acc += wl.xh + wh.xh, acl += wh.xl' (scaled residual): two chains per tile
+template <int KS>
+__device__ __forceinline__ void pb_mma(const PbA<KS>& A, const wh16x8 (&bh)[KS], const wh16x8 (&bl)[KS], f32x4& acc, f32x4& acl) {
+#pragma unroll
+  for (int st = 0; st < KS; ++st) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A.l[st], bh[st], acc, 0, 0, 0);
+    acl = __builtin_amdgcn_mfma_f32_16x16x32_f16(A.h[st], bl[st], acl, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A.h[st], bh[st], acc, 0, 0, 0);
+  }
+}
+__device__ __forceinline__ float4 pb_fold(const f32x4& acc, const f32x4& acl) {
+  const f32x4 v = acc + acl * WQ16_LO_UNSCALE;
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ bool pb_over(const int* abort_word) { return __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; }
+
+// B fragments of this lane from an exchange vector [pair][16 columns]: wave w takes k-steps w KS .. w KS + KS - 1 (k-step = 16 pairs);
+// lane (column, kb) reads pairs kstep 16 + kb 4 + 0..3.  WATCH: one lane polls the last granule first (a vector the workgroup is
+// waiting for); else every lane polls its own granules (a vector that is normally in place).  Ends behind a barrier; false = the
+// launch is over (finished or aborted).  col = min(column of the lane, N - 1).
+template <int KS, bool WATCH, int SLEEP>
+__device__ __forceinline__ bool pb_gather(const unsigned long long* vec, const int npairs, const unsigned col, const int N, const unsigned tag,
+                                          wh16x8 (&bh)[KS], wh16x8 (&bl)[KS], int* abort_word, int* s_flag) {
+  const unsigned tb = wq16_tbit(tag);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (WATCH && threadIdx.x == 0) {
+    const unsigned long long* p = vec + (size_t)(npairs - 1) * PB_GC + (N - 1);
+    unsigned long long t0 = 0;
+    for (int tries = 0; !wq16_fresh(wp_get(p), tb); ++tries) {
+      if ((tries & 7) == 7 && pb_over(abort_word)) { *s_flag = 1; break; }
+      if ((tries & 1023) == 1023 && wp_lost(tries, t0, abort_word)) { *s_flag = 1; break; }
+      __builtin_amdgcn_s_sleep(SLEEP);
+    }
+  }
+  __syncthreads();
+  if (*s_flag) return false;
+  const unsigned long long* base = vec + ((size_t)(wave * KS) * 16 + (lane >> 4) * 4) * PB_GC + col;
+  unsigned long long v[KS * 4];
+  unsigned long long t0 = 0;
+  bool ok = true;
+  for (int tries = 0;; ++tries) {
+#pragma unroll
+    for (int st = 0; st < KS; ++st)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[st * 4 + j] = wp_get(base + (size_t)(st * 16 + j) * PB_GC);
+    unsigned stale = 0u;
+#pragma unroll
+    for (int q = 0; q < KS * 4; ++q) stale = __builtin_amdgcn_bitop3_b32(stale, (unsigned)(v[q] >> 32), tb, 0xf6);
+    if ((stale & 1u) == 0u) break;
+    if ((tries & 7) == 7 && pb_over(abort_word)) { ok = false; break; }
+    if ((tries & 1023) == 1023 && wp_lost(tries, t0, abort_word)) { ok = false; break; }
+    __builtin_amdgcn_s_sleep(WATCH ? 1 : 4);
+  }
+  if (!ok) *s_flag = 1;  // (every wave meets the next barrier; the flag is looked at behind it)
+#pragma unroll
+  for (int st = 0; st < KS; ++st) {
+    wq_u4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { h[j] = (unsigned)v[st * 4 + j]; l[j] = (unsigned)(v[st * 4 + j] >> 32); }
+    bh[st] = __builtin_bit_cast(wh16x8, h);
+    bl[st] = __builtin_bit_cast(wh16x8, l);
+  }
+  return true;
+}
+// sum of the NWV partial float4s of tile `tile` for this lane (red: [tile][wave][lane])
+template <int NWV>
+__device__ __forceinline__ float4 pb_sum(const float4* red, const int tile, const int lane) {
+  float4 s = red[(tile * NWV) * 64 + lane];
+#pragma unroll
+  for (int w = 1; w < NWV; ++w) {
+    const float4 v = red[(tile * NWV + w) * 64 + lane];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  return s;
+}
+
+__global__ __launch_bounds__(512) void ppg_batch_kernel(PbK a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char pb_lds[];
+  float4* redA = reinterpret_cast<float4*>(pb_lds);
+  float4* redB = reinterpret_cast<float4*>(pb_lds + PB_LDS_REDA);
+  wh16* s_p1h = reinterpret_cast<wh16*>(pb_lds + PB_LDS_REDA + PB_LDS_REDB);
+  wh16* s_p1l = s_p1h + PB_GC * PB_P1_ROW;
+  int* s_flag = reinterpret_cast<int*>(s_p1l + PB_GC * PB_P1_ROW);
+  if (pb_over(a.abort_word)) return;  // (tests: the fallback path)
+  const int blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, du = lane >> 4;
+  const int S = a.S;
+  if (tid == 0) *s_flag = 0;
+  auto EX = [&](int what, int g, unsigned tag) { return a.ex + ((size_t)g * 2 + (tag & 1)) * PBX_PER + what; };
+  int Ng[PB_NG];
+  unsigned colg[PB_NG];  // this lane's column inside group g (dead columns: the last live one)
+#pragma unroll
+  for (int g = 0; g < PB_NG; ++g) {
+    Ng[g] = a.gn0[g + 1] - a.gn0[g];
+    colg[g] = (unsigned)(i < Ng[g] ? i : (Ng[g] > 0 ? Ng[g] - 1 : 0));
+  }
+  float rmax = 0.f;
+  __syncthreads();
+
+  if (blk < PB_ATT) {
+    // ================================================================ ATT: prenet.1 + attention LSTMCell, units 8 blk .. 8 blk + 7
+    PbA<1> W1[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) pb_load_a<1, 8>(a.att_w1, t, W1[t]);
+    PbA<1> Wx[2], Wc[2];
+    PbA<2> Wh[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      pb_load_a<1, 4>(a.att_wx, 2 * blk + t, Wx[t]);  // (waves 4..7 hold copies of waves 0..3's: unused)
+      pb_load_a<1, 8>(a.att_wc, 2 * blk + t, Wc[t]);
+      pb_load_a<2, 8>(a.att_wh, 2 * blk + t, Wh[t]);
+    }
+    const int u = blk * 8 + (wave & 1) * 4 + du;  // unit of an epilogue lane (waves 0 / 1)
+    const float4 bq = a.att_b4[u];
+    float cst[PB_NG], P[PB_NG][4];
+#pragma unroll
+    for (int g = 0; g < PB_NG; ++g) { cst[g] = 0.f; P[g][0] = P[g][1] = P[g][2] = P[g][3] = 0.f; }
+    for (int s = 0; s < S; ++s) {
+      const unsigned tag = (unsigned)s + 1;
+#pragma unroll
+      for (int g = 0; g < PB_NG; ++g) {
+        if (Ng[g] <= 0) continue;
+        float vx[4] = {0.f, 0.f, 0.f, 0.f};
+        if (s > 0) {  // p0(0) = 0 and context(-1) = 0: the go frame through a bias-free prenet, zero initial context
+          f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, acl[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+          {  // the context part of the gates, W_ctx . context(s - 1): in place since the OUT role consumed it, fetched while this workgroup
+             // would only wait for p0 (as the tail of the previous item it made the workgroup sit through Q0 and MOL before it could
+             // serve the other group's chain item: 19 us per step at two groups against 11 at one)
+            wh16x8 bh[1], bl[1];
+            if (!pb_gather<1, false, 4>(EX(PBX_CTX, g, tag - 1), 128, colg[g], Ng[g], tag - 1, bh, bl, a.abort_word, s_flag)) return;
+            pb_mma<1>(Wc[0], bh, bl, acc[0], acl[0]);
+            pb_mma<1>(Wc[1], bh, bl, acc[1], acl[1]);
+          }
+          wh16x8 bh[1], bl[1];
+          // (p0 of step s carries the tag of the step that produced it, s - 1: the FIRST write of either parity buffer must be
+          //  tag 1 / tag 2 -- tbit 1 -- or zero-initialised memory would read as fresh)
+          if (!pb_gather<1, true, 1>(EX(PBX_P0, g, tag - 1), 128, colg[g], Ng[g], tag - 1, bh, bl, a.abort_word, s_flag)) return;
+          // prenet.1: this wave's K slice of all 8 tiles -> LDS, tile `wave` summed by wave `wave`
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            f32x4 pa = {0.f, 0.f, 0.f, 0.f}, pl = {0.f, 0.f, 0.f, 0.f};
+            pb_mma<1>(W1[t], bh, bl, pa, pl);
+            redA[(t * 8 + wave) * 64 + lane] = pb_fold(pa, pl);
+          }
+          __syncthreads();
+          if (*s_flag) return;
+          {
+            const float4 sm = pb_sum<8>(redA, wave, lane);
+            float v[4] = {sm.x * a.att_w1.us, sm.y * a.att_w1.us, sm.z * a.att_w1.us, sm.w * a.att_w1.us};
+            relu_drop_quad(a.drop1, a.flags, s, a.gn0[g] + (int)colg[g], wave * 16 + du * 4, v);
+            const wq_f2 va = {v[0], v[1]}, vb = {v[2], v[3]};
+            const wh16x2 ha = __builtin_convertvector(va, wh16x2), hb = __builtin_convertvector(vb, wh16x2);
+            const wh16x2 la = __builtin_convertvector((va - __builtin_convertvector(ha, wq_f2)) * WQ16_LO_SCALE, wh16x2);
+            const wh16x2 lb = __builtin_convertvector((vb - __builtin_convertvector(hb, wq_f2)) * WQ16_LO_SCALE, wh16x2);
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            const h4 hq = {ha[0], ha[1], hb[0], hb[1]}, lq = {la[0], la[1], lb[0], lb[1]};
+            *reinterpret_cast<h4*>(s_p1h + i * PB_P1_ROW + wave * 16 + du * 4) = hq;
+            *reinterpret_cast<h4*>(s_p1l + i * PB_P1_ROW + wave * 16 + du * 4) = lq;
+            rmax = wq16_track4(rmax, v[0], v[1], v[2], v[3]);
+          }
+          __syncthreads();
+          if (wave < 4) {  // W_x . p1: K = 128 = one k-step per wave, on top of the wave's context part
+            wh16x8 ph[1], pl[1];
+            ph[0] = *reinterpret_cast<const wh16x8*>(s_p1h + i * PB_P1_ROW + wave * 32 + du * 8);
+            pl[0] = *reinterpret_cast<const wh16x8*>(s_p1l + i * PB_P1_ROW + wave * 32 + du * 8);
+            pb_mma<1>(Wx[0], ph, pl, acc[0], acl[0]);
+            pb_mma<1>(Wx[1], ph, pl, acc[1], acl[1]);
+          }
+          redB[(0 * 8 + wave) * 64 + lane] = pb_fold(acc[0], acl[0]);
+          redB[(1 * 8 + wave) * 64 + lane] = pb_fold(acc[1], acl[1]);
+          __syncthreads();
+          if (wave < 2) {
+            const float4 sm = pb_sum<8>(redB, wave, lane);
+            vx[0] = sm.x * a.att_wx.us; vx[1] = sm.y * a.att_wx.us; vx[2] = sm.z * a.att_wx.us; vx[3] = sm.w * a.att_wx.us;
+          }
+        }
+        if (wave < 2) {  // torch LSTMCell, gate order (i, f, g, o)
+          const float gi = wq16_sigmoid((vx[0] + P[g][0]) + bq.x), gf = wq16_sigmoid((vx[1] + P[g][1]) + bq.y);
+          const float gg = wq16_tanh((vx[2] + P[g][2]) + bq.z), go = wq16_sigmoid((vx[3] + P[g][3]) + bq.w);
+          cst[g] = gf * cst[g] + gi * gg;
+          const float h = go * wq16_tanh(cst[g]);
+          const float ho = __shfl_xor(h, 16, 64);
+          if (!(du & 1) && i < Ng[g]) wq16_put(EX(PBX_AH, g, tag) + (size_t)(u >> 1) * PB_GC + i, h, ho, wq16_tbit(tag));
+        }
+        if (s + 1 == S) continue;
+        // ---- in the shadow: the hidden part of the next step's gates, W_hh . att_h(s) ----
+        {
+          f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, acl[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+          wh16x8 bh[2], bl[2];
+          if (!pb_gather<2, true, 2>(EX(PBX_AH, g, tag), 256, colg[g], Ng[g], tag, bh, bl, a.abort_word, s_flag)) return;
+          pb_mma<2>(Wh[0], bh, bl, acc[0], acl[0]);
+          pb_mma<2>(Wh[1], bh, bl, acc[1], acl[1]);
+          redB[(0 * 8 + wave) * 64 + lane] = pb_fold(acc[0], acl[0]);
+          redB[(1 * 8 + wave) * 64 + lane] = pb_fold(acc[1], acl[1]);
+        }
+        __syncthreads();
+        if (*s_flag) return;
+        if (wave < 2) {
+          const float4 sm = pb_sum<8>(redB, wave, lane);
+          P[g][0] = sm.x * a.att_wh.us; P[g][1] = sm.y * a.att_wh.us; P[g][2] = sm.z * a.att_wh.us; P[g][3] = sm.w * a.att_wh.us;
+        }
+        __syncthreads();  // redB is rewritten by the next item
+      }
+    }
+    wq16_range_report(a.range_word, rmax);
+    return;
+  }
+
+  if (blk < PB_G_Q0) {
+    // ================================================================ DEC: decoder LSTMCell, units 8 d .. 8 d + 7
+    const int d = blk - PB_G_DEC;
+    PbA<2> Wa[2], Wh[2];
+    PbA<1> Wc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      pb_load_a<2, 8>(a.dec_wa, 2 * d + t, Wa[t]);
+      pb_load_a<1, 8>(a.dec_wc, 2 * d + t, Wc[t]);
+      pb_load_a<2, 8>(a.dec_wh, 2 * d + t, Wh[t]);
+    }
+    const int u = d * 8 + (wave & 1) * 4 + du;
+    const float4 bq = a.dec_b4[u];
+    float cst[PB_NG];
+#pragma unroll
+    for (int g = 0; g < PB_NG; ++g) cst[g] = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const unsigned tag = (unsigned)s + 1;
+#pragma unroll
+      for (int g = 0; g < PB_NG; ++g) {
+        if (Ng[g] <= 0) continue;
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, acl[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if (s > 0) {  // h of the previous step: in place long ago
+          wh16x8 bh[2], bl[2];
+          if (!pb_gather<2, false, 4>(EX(PBX_DH, g, tag - 1), 256, colg[g], Ng[g], tag - 1, bh, bl, a.abort_word, s_flag)) return;
+          pb_mma<2>(Wh[0], bh, bl, acc[0], acl[0]);
+          pb_mma<2>(Wh[1], bh, bl, acc[1], acl[1]);
+        }
+        {
+          wh16x8 bh[2], bl[2];
+          if (!pb_gather<2, true, 1>(EX(PBX_AH, g, tag), 256, colg[g], Ng[g], tag, bh, bl, a.abort_word, s_flag)) return;
+          pb_mma<2>(Wa[0], bh, bl, acc[0], acl[0]);
+          pb_mma<2>(Wa[1], bh, bl, acc[1], acl[1]);
+        }
+        {
+          wh16x8 bh[1], bl[1];
+          if (!pb_gather<1, true, 1>(EX(PBX_CTX, g, tag), 128, colg[g], Ng[g], tag, bh, bl, a.abort_word, s_flag)) return;
+          pb_mma<1>(Wc[0], bh, bl, acc[0], acl[0]);
+          pb_mma<1>(Wc[1], bh, bl, acc[1], acl[1]);
+        }
+        redB[(0 * 8 + wave) * 64 + lane] = pb_fold(acc[0], acl[0]);
+        redB[(1 * 8 + wave) * 64 + lane] = pb_fold(acc[1], acl[1]);
+        __syncthreads();
+        if (*s_flag) return;
+        if (wave < 2) {
+          const float4 sm = pb_sum<8>(redB, wave, lane);
+          const float us = a.dec_wa.us;
+          const float gi = wq16_sigmoid(sm.x * us + bq.x), gf = wq16_sigmoid(sm.y * us + bq.y);
+          const float gg = wq16_tanh(sm.z * us + bq.z), go = wq16_sigmoid(sm.w * us + bq.w);
+          cst[g] = gf * cst[g] + gi * gg;
+          const float h = go * wq16_tanh(cst[g]);
+          const float ho = __shfl_xor(h, 16, 64);
+          if (!(du & 1) && i < Ng[g]) wq16_put(EX(PBX_DH, g, tag) + (size_t)(u >> 1) * PB_GC + i, h, ho, wq16_tbit(tag));
+        }
+        __syncthreads();  // redB is rewritten by the next item
+      }
+    }
+    return;
+  }
+
+  if (blk < PB_G_OUT) {
+    // ================================================================ Q0: q = relu(query_layer.0 . att_h + b)   mol_attention.py:75
+    const int j = blk - PB_G_Q0;
+    PbA<2> W;
+    pb_load_a<2, 8>(a.q0_w, j, W);
+    const float4 bq = *reinterpret_cast<const float4*>(a.q0_b + j * 16 + du * 4);
+    for (int s = 0; s < S; ++s) {
+      const unsigned tag = (unsigned)s + 1;
+#pragma unroll
+      for (int g = 0; g < PB_NG; ++g) {
+        if (Ng[g] <= 0) continue;
+        wh16x8 bh[2], bl[2];
+        if (!pb_gather<2, true, 1>(EX(PBX_AH, g, tag), 256, colg[g], Ng[g], tag, bh, bl, a.abort_word, s_flag)) return;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acl = {0.f, 0.f, 0.f, 0.f};
+        pb_mma<2>(W, bh, bl, acc, acl);
+        redB[wave * 64 + lane] = pb_fold(acc, acl);
+        __syncthreads();
+        if (*s_flag) return;
+        if (wave == 0) {
+          const float4 sm = pb_sum<8>(redB, 0, lane);
+          const float us = a.q0_w.us;
+          const float q0 = fmaxf(sm.x * us + bq.x, 0.f), q1 = fmaxf(sm.y * us + bq.y, 0.f), q2 = fmaxf(sm.z * us + bq.z, 0.f), q3 = fmaxf(sm.w * us + bq.w, 0.f);
+          if (i < Ng[g]) {
+            unsigned long long* Y = EX(PBX_Q, g, tag) + (size_t)(j * 8 + du * 2) * PB_GC + i;
+            wq16_put(Y, q0, q1, wq16_tbit(tag));
+            wq16_put(Y + PB_GC, q2, q3, wq16_tbit(tag));
+            rmax = wq16_track4(rmax, q0, q1, q2, q3);
+          }
+        }
+        __syncthreads();
+      }
+    }
+    wq16_range_report(a.range_word, rmax);
+    return;
+  }
+
+  if (blk < PB_G_MOL) {
+    // ================================================================ OUT: prenet.0' tile j | projection tile j | stop row
+    const int j = blk - PB_G_OUT;
+    const int nproj = a.RM / 16;
+    const bool has_proj = j < nproj;
+    PbA<2> Wh[3];
+    PbA<1> Wc[3];
+    const int tiles[3] = {j, has_proj ? 16 + j : 16 + nproj, 16 + nproj};  // (no projection tile: the stop tile twice, its copy unused)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { pb_load_a<2, 8>(a.out_wh, tiles[t], Wh[t]); pb_load_a<1, 8>(a.out_wc, tiles[t], Wc[t]); }
+    const float4 b_fc0 = *reinterpret_cast<const float4*>(a.fc0_b + j * 16 + du * 4);
+    const float4 b_proj = has_proj ? *reinterpret_cast<const float4*>(a.out_b + j * 16 + du * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float b_stop = a.out_b[a.RM];
+    int n_groups = 0;
+#pragma unroll
+    for (int g = 0; g < PB_NG; ++g) n_groups += Ng[g] > 0 ? 1 : 0;
+    for (int s = 0; s < S; ++s) {
+      const unsigned tag = (unsigned)s + 1;
+      int below_step = 0, served = 0;  // (uniform over the workgroup: every wave evaluates the votes)
+#pragma unroll
+      for (int g = 0; g < PB_NG; ++g) {
+        if (Ng[g] <= 0) continue;
+        f32x4 acc[3], acl[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { acc[t] = {0.f, 0.f, 0.f, 0.f}; acl[t] = {0.f, 0.f, 0.f, 0.f}; }
+        {
+          wh16x8 bh[1], bl[1];
+          if (!pb_gather<1, true, 2>(EX(PBX_CTX, g, tag), 128, colg[g], Ng[g], tag, bh, bl, a.abort_word, s_flag)) return;
+#pragma unroll
+          for (int t = 0; t < 3; ++t) pb_mma<1>(Wc[t], bh, bl, acc[t], acl[t]);
+        }
+        {
+          wh16x8 bh[2], bl[2];
+          if (!pb_gather<2, true, 1>(EX(PBX_DH, g, tag), 256, colg[g], Ng[g], tag, bh, bl, a.abort_word, s_flag)) return;
+#pragma unroll
+          for (int t = 0; t < 3; ++t) pb_mma<2>(Wh[t], bh, bl, acc[t], acl[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) redB[(t * 8 + wave) * 64 + lane] = pb_fold(acc[t], acl[t]);
+        __syncthreads();
+        if (*s_flag) return;
+        // stop_output = stop_layer([h, context]) (:288); every wave works the group's votes out (row 0 of the stop tile: lanes du == 0)
+        const float us = a.out_wh.us;
+        const int n = a.gn0[g] + i;
+        int below = 0;
+        {
+          const float4 ss = pb_sum<8>(redB, 2, lane);
+          const float lg = ss.x * us + b_stop;
+          if (du == 0 && i < Ng[g]) {
+            below = !(1.f / (1.f + expf(-lg)) > a.thr);
+            if (j == 0 && wave == 2) a.stop_out[(size_t)n * S + s] = lg;
+          }
+        }
+        below_step += __popcll(__ballot(below)) ? 1 : 0;
+        ++served;
+        const bool finished = served == n_groups && below_step == 0 && s + 1 >= a.min_steps;  // stop rule :349-354 (batch-wide)
+        if (wave == 1 && has_proj && i < Ng[g]) {  // mel_output = linear_projection([h, context])   :281-287
+          const float4 sm = pb_sum<8>(redB, 1, lane);
+          *reinterpret_cast<float4*>(a.mel_out + ((size_t)n * S + s) * a.RM + j * 16 + du * 4) =
+              make_float4(sm.x * us + b_proj.x, sm.y * us + b_proj.y, sm.z * us + b_proj.z, sm.w * us + b_proj.w);
+        }
+        if (wave == 0 && !finished) {  // next step's prenet layer 0 through the projection's last frame, relu, dropout of step s + 1
+          const float4 sm = pb_sum<8>(redB, 0, lane);
+          float v[4] = {sm.x * us + b_fc0.x, sm.y * us + b_fc0.y, sm.z * us + b_fc0.z, sm.w * us + b_fc0.w};
+          relu_drop_quad(a.drop0, a.flags, s, a.gn0[g] + (int)colg[g], j * 16 + du * 4, v);
+          if (i < Ng[g]) {
+            unsigned long long* Y = EX(PBX_P0, g, tag) + (size_t)(j * 8 + du * 2) * PB_GC + i;
+            wq16_put(Y, v[0], v[1], wq16_tbit(tag));
+            wq16_put(Y + PB_GC, v[2], v[3], wq16_tbit(tag));
+            rmax = wq16_track4(rmax, v[0], v[1], v[2], v[3]);
+          }
+        }
+        if (served == n_groups && j == 0 && tid == 0) {
+          a.flags[TF_NFRAMES] = s + 1;
+          if (finished) {
+            a.flags[TF_DONE] = 1;
+            __hip_atomic_store(a.abort_word, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        if (finished) { wq16_range_report(a.range_word, rmax); return; }
+        __syncthreads();
+      }
+    }
+    wq16_range_report(a.range_word, rmax);
+    return;
+  }
+
+  // ================================================================== MOL: mixture-of-logistics attention of ONE utterance   mol_attention.py:67-122
+  // (ppg_resident.h's role: the first wave works the mixture parameters out, every wave evaluates the window at its 33 positions and
+  //  accumulates its share of context = alpha . memory from registers; here the query arrives as operand pairs of column `col` and the
+  //  context leaves the same way)
+  {
+    const int b = blk - PB_G_MOL;
+    if (b >= a.B) return;
+    int g = 0;
+#pragma unroll
+    for (int q = 1; q < PB_NG; ++q) if (b >= a.gn0[q]) g = q;
+    const int col = b - a.gn0[g];
+    const int T = a.T, M = a.M;
+    float* s_q = reinterpret_cast<float*>(pb_lds);  // [256]
+    float* s_mpw = s_q + 256;                       // [16] raw mixture parameters
+    float* s_mix = s_mpw + 16;                      // [3][16]: w, 1 / sigma, mu of this step
+    float* s_part = s_mpw + 128;                    // [8][256]
+    float4* s_w2 = reinterpret_cast<float4*>(s_part + 2048 + 4);
+    const int sl = tid & 15, rr = lane >> 4;
+    const float* mem = a.memory + (size_t)b * T * 256 + lane * 4;
+    constexpr int NR = 32;
+    float4 mv[NR];
+#pragma unroll
+    for (int jj = 0; jj < NR; ++jj) {
+      const int t = wave * NR + jj;
+      mv[jj] = t < T ? *reinterpret_cast<const float4*>(mem + (size_t)t * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int o = gq * 4 + rr;
+        if (wave == 0)
+          s_w2[(gq * 4 + c) * 64 + lane] = o < 3 * M ? *reinterpret_cast<const float4*>(a.w2 + (size_t)o * 256 + (c * 16 + sl) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    const int r3 = lane >> 4, m16 = lane & 15;
+    const bool live = m16 < M && r3 < 3;
+    const float b_l = live ? a.b2[r3 * M + m16] : 0.f;
+    float mu_prev = 0.f;
+    __syncthreads();
+    for (int s = 0; s < S; ++s) {
+      const unsigned tag = (unsigned)s + 1, tb = wq16_tbit(tag);
+      // ---- q of this utterance: 128 pair granules of column `col` ----
+      const unsigned long long* Q = EX(PBX_Q, g, tag) + col;
+      if (tid == 0) {
+        unsigned long long t0 = 0;
+        for (int tries = 0; !wq16_fresh(wp_get(Q + (size_t)127 * PB_GC), tb); ++tries) {
+          if ((tries & 7) == 7 && pb_over(a.abort_word)) { *s_flag = 1; break; }
+          if ((tries & 1023) == 1023 && wp_lost(tries, t0, a.abort_word)) { *s_flag = 1; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      __syncthreads();
+      if (*s_flag) return;
+      if (tid < 128) {
+        unsigned long long v, t0 = 0;
+        for (int tries = 0;; ++tries) {
+          v = wp_get(Q + (size_t)tid * PB_GC);
+          if (wq16_fresh(v, tb)) break;
+          if ((tries & 7) == 7 && pb_over(a.abort_word)) { *s_flag = 1; break; }
+          if ((tries & 1023) == 1023 && wp_lost(tries, t0, a.abort_word)) { *s_flag = 1; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        const wh16x2 h = __builtin_bit_cast(wh16x2, (unsigned)v), l = __builtin_bit_cast(wh16x2, (unsigned)(v >> 32));
+        s_q[2 * tid] = (float)h[0] + (float)l[0] * WQ16_LO_UNSCALE;
+        s_q[2 * tid + 1] = (float)h[1] + (float)l[1] * WQ16_LO_UNSCALE;
+      }
+      __syncthreads();
+      if (*s_flag) return;
+      // mixture_params = query_layer.2(q)  :75 -- waves 0..3 take four rows each
+      if (wave < 4) {
+        const float4* q4 = reinterpret_cast<const float4*>(s_q) + sl;
+        float4 qv[4], wv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { qv[c] = q4[c * 16]; wv[c] = s_w2[(wave * 4 + c) * 64 + lane]; }
+        __builtin_amdgcn_sched_barrier(0);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          s0 = fmaf(wv[c].x, qv[c].x, s0); s1 = fmaf(wv[c].y, qv[c].y, s1); s2 = fmaf(wv[c].z, qv[c].z, s2); s3 = fmaf(wv[c].w, qv[c].w, s3);
+        }
+        const float acc = pr_sum16((s0 + s1) + (s2 + s3));
+        if (sl == 0) s_mpw[wave * 4 + rr] = acc;
+      }
+      __syncthreads();
+      // w = softmax(w_hat) + eps; sigma = softplus(sigma_hat) + eps; mu = mu_prev + softplus(Delta_hat)   :92-96
+      if (wave == 0) {
+        const float x = live ? s_mpw[r3 * M + m16] + b_l : (r3 == 0 ? -INFINITY : 0.f);
+        float mx = x;
+        mx = fmaxf(mx, pr_dpp(mx, 0)); mx = fmaxf(mx, pr_dpp(mx, 1)); mx = fmaxf(mx, pr_dpp(mx, 2)); mx = fmaxf(mx, pr_dpp(mx, 3));
+        const float e = expf(r3 == 0 ? x - mx : x);
+        const float ew = (live && r3 == 0) ? e : 0.f;
+        float se = 0.f;
+#pragma unroll
+        for (int mm = 0; mm < 5; ++mm) se += pr_lane(ew, mm);
+        const float sp = pr_softplus(x, e);
+        float val = ew * __builtin_amdgcn_rcpf(se) + a.eps;
+        if (r3 == 1) val = __builtin_amdgcn_rcpf(sp + a.eps);
+        if (r3 == 2) { val = mu_prev + sp; if (live) mu_prev = val; }
+        if (lane < 48) s_mix[lane] = val;
+      }
+      __syncthreads();
+      float wm[5], isg[5], mum[5];
+#pragma unroll
+      for (int mm = 0; mm < 5; ++mm) { wm[mm] = s_mix[mm]; isg[mm] = s_mix[16 + mm]; mum[mm] = s_mix[32 + mm]; }
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      f32x2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
+      float* al = a.align_out + ((size_t)b * S + s) * T;
+      for (int t0 = wave * NR; t0 < T; t0 += 8 * NR) {
+        float af = 0.f;
+        const float pos = (float)(t0 + lane) + 0.5f;
+#pragma unroll
+        for (int mm = 0; mm < 5; ++mm)
+          if (mm < M) {
+            const float e = __expf((pos - mum[mm]) * isg[mm]);
+            af += wm[mm] * (1.f - __builtin_amdgcn_rcpf(2.f + e));
+          }
+        float v = __shfl_down(af, 1, 64) - af;
+        if (v == 0.f) v = a.eps;
+        const int t = t0 + lane;
+        if (lane >= NR || t >= T) v = 0.f;
+        else al[t] = v;
+        if (t0 == wave * NR) {
+#pragma unroll
+          for (int jj = 0; jj < NR; ++jj) {
+            const float sc = pr_lane(v, jj);
+            const f32x2 sc2 = {sc, sc}, m01 = {mv[jj].x, mv[jj].y}, m23 = {mv[jj].z, mv[jj].w};
+            acc01 = __builtin_elementwise_fma(sc2, m01, acc01); acc23 = __builtin_elementwise_fma(sc2, m23, acc23);
+          }
+        } else {
+#pragma unroll 1
+          for (int j8 = 0; j8 < NR; j8 += 4) {
+            float4 vv[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const int tr_ = t0 + j8 + jj;
+              vv[jj] = tr_ < T ? *reinterpret_cast<const float4*>(mem + (size_t)tr_ * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const float sc = __shfl(v, j8 + jj, 64);
+              const f32x2 sc2 = {sc, sc}, m01 = {vv[jj].x, vv[jj].y}, m23 = {vv[jj].z, vv[jj].w};
+              acc01 = __builtin_elementwise_fma(sc2, m01, acc01); acc23 = __builtin_elementwise_fma(sc2, m23, acc23);
+            }
+          }
+        }
+      }
+      *reinterpret_cast<float4*>(s_part + wave * 256 + lane * 4) = make_float4(acc01.x, acc01.y, acc23.x, acc23.y);
+      __syncthreads();
+      if (tid < 128) {  // context pair tid = features 2 tid, 2 tid + 1
+        float r0 = s_part[2 * tid], r1 = s_part[2 * tid + 1];
+#pragma unroll
+        for (int w8 = 1; w8 < 8; ++w8) { r0 += s_part[w8 * 256 + 2 * tid]; r1 += s_part[w8 * 256 + 2 * tid + 1]; }
+        wq16_put(EX(PBX_CTX, g, tag) + (size_t)tid * PB_GC + col, r0, r1, tb);
+        rmax = wq16_track2(rmax, r0, r1);
+      }
+      __syncthreads();
+    }
+    wq16_range_report(a.range_word, rmax);
+  }
+}
+
+}  // namespace mb
