@@ -1,5 +1,5 @@
 """Stress of the resident (one-launch) loops' hand-offs -- wf_pipe16_kernel (23 fold columns, RAW and MOL models), wf_pipe_kernel (the exact kernel),
-wf_persist1_kernel (one column), ppg_resident_kernel (ppg2mel, one utterance): the same call many times, alone and while another
+wf_persist1_kernel (one column), ppg_resident_kernel (ppg2mel, one utterance), ppg_batch_kernel (ppg2mel, 32 utterances): the same call many times, alone and while another
 stream keeps the GPU busy with GEMMs of varying size (uneven load, workgroups competing for compute units).  Every run must either
 reproduce the quiet resident run bit for bit (the kernels are deterministic) or -- if the launch lost a hand-off and drained -- equal
 the launch chain's result (the fallback); anything else is a FAILURE.  VERDICT r03 item 8.
@@ -21,6 +21,7 @@ dec = Ppg2MelDecoder(synth.ppg2mel_decoder_state(synth.PPG2MEL_HP, seed=3, stop_
 mel23 = torch.from_numpy(synth.wavernn_mel(120, seed=0) / 4.0).cuda()   # 23 x 1100-step folds at target 1000 / overlap 50? (see columns below)
 mel1 = torch.from_numpy(synth.wavernn_mel(12, seed=0) / 4.0).cuda()
 mem = torch.from_numpy(synth.ppg2mel_memory(1, 60, seed=2)).cuda()
+mem32 = torch.from_numpy(synth.ppg2mel_memory(32, 60, seed=3)).cuda()   # ppg_batch.h: 160 role workgroups + 32 attention workgroups
 
 
 def wrn(mel, batched, env, d=None):
@@ -33,10 +34,10 @@ def wrn(mel, batched, env, d=None):
     return out.clone(), d.last_loop_launches
 
 
-def ppg(env):
+def ppg(env, m=None):
     os.environ.pop("MBHIP_PPG_RESIDENT", None)
     os.environ.update(env)
-    out = dec.decode(mem, seed=5, max_steps=100)
+    out = dec.decode(mem if m is None else m, seed=5, max_steps=100)
     torch.cuda.synchronize()
     return out[0].clone(), dec.last_loop_launches
 
@@ -47,6 +48,7 @@ CASES = {
     "wavernn_pipe16_mol": (lambda env: wrn(mel23, True, env, dev_mol), {"MBHIP_WAVERNN_RESIDENT": "1"}, {"MBHIP_WAVERNN_RESIDENT": "0"}),
     "wavernn_one_column": (lambda env: wrn(mel1, False, env), {"MBHIP_WAVERNN_RESIDENT": "1"}, {"MBHIP_WAVERNN_RESIDENT": "0"}),
     "ppg2mel_resident": (ppg, {"MBHIP_PPG_RESIDENT": "1"}, {"MBHIP_PPG_RESIDENT": "0"}),
+    "ppg2mel_batch32_resident": (lambda env: ppg(env, mem32), {"MBHIP_PPG_RESIDENT": "1"}, {"MBHIP_PPG_RESIDENT": "0"}),
 }
 side = torch.cuda.Stream()
 bad = 0
