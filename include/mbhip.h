@@ -569,14 +569,16 @@ size_t mb_ppg2mel_workspace_bytes(const mb_ppg2mel* p, int batch);
  * [max_steps][batch][prenet_dims[l]] inside; NULL -> Philox(seed).  Outputs are per step, untruncated:
  * d_mel [batch][max_steps][frames_per_step*num_mels], d_align [batch][max_steps][t_enc],
  * d_stop [batch][max_steps] (logits); *h_n_steps = steps produced. */
-/* mb_ppg2mel_decode is HOST-BLOCKING (it returns *h_n_steps): batch 1 runs the resident launch of ppg_resident.h and reads its
- * abort word behind it (a lost hand-off -> the 6-launch chain redoes the utterance), wider batches poll the stop flag.
+/* mb_ppg2mel_decode is HOST-BLOCKING (it returns *h_n_steps): batch 1 runs the resident launch of ppg_resident.h, a batch of 2..32 the
+ * resident launch of ppg_batch.h (round 5: Decoder.inference_batched, rnn_decoder_mol.py:317-374, on MFMA tiles; fp32-grade results, not
+ * bit-identical to the chain's), and reads its abort / range words behind it (a lost hand-off or an activation beyond the operand
+ * pairs' |x| <= 65504 -> the 6-launch chain redoes the batch); wider batches poll the stop flag.
  * The same holds for mb_taco_encode / mb_taco_decode's CBHG GRU scans (gru_scan.h): one stream synchronisation per CBHG. */
 /* Duration of the decoder loop of the last mb_ppg2mel_decode call (HIP events on the loop's stream) and the steps it
  * produced; production-dims handles only (the graph-replayed step of ppg_fast.h), MB_ESTATE otherwise. */
 int mb_ppg2mel_last_loop_ms(const mb_ppg2mel* p, float* ms, int* steps);
-/* Kernel launches the decoder loop of the last mb_ppg2mel_decode call took: 1 = the resident loop (one utterance,
- * csrc/ppg_resident.h: the whole Decoder.inference loop, rnn_decoder_mol.py:267-316, as one launch), 6 per step on the
+/* Kernel launches the decoder loop of the last mb_ppg2mel_decode call took: 1 = a resident loop (one utterance:
+ * csrc/ppg_resident.h, the whole Decoder.inference loop, rnn_decoder_mol.py:267-316, as one launch; 2..32 utterances: csrc/ppg_batch.h), 6 per step on the
  * graph-replayed chain (csrc/ppg_fast.h).  Production-dims handles only, MB_ESTATE otherwise. */
 int mb_ppg2mel_last_loop_launches(const mb_ppg2mel* p, int* launches);
 int mb_ppg2mel_decode(const mb_ppg2mel* p, const float* d_memory, int batch, int t_enc, int max_steps,
