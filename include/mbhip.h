@@ -427,9 +427,9 @@ int mb_wavernn_finish(const float* d_samples, int n_folds, int seq_len, int batc
  *   resident: MBHIP_WAVERNN_RESIDENT as an int: -1 unset / "auto", 0 = no resident launch, 1 = resident wherever legal (also on a
  *   device that failed before), 2 = "exact": like 1 with the exact fp32 kernel instead of the operand-pair one. */
 #define MB_WRN_PATH_CHAIN 0     /* the 5-launch chain (csrc/wavernn_fast.h), hipGraph replays                          */
-#define MB_WRN_PATH_PERSIST1 1  /* one column: wf_persist1_kernel (csrc/wavernn_persist.h)                             */
+#define MB_WRN_PATH_PERSIST1 1  /* one column, resident = "exact" (RAW): wf_persist1_kernel (csrc/wavernn_persist.h)     */
 #define MB_WRN_PATH_PIPE 2      /* 2..32 columns, exact fp32 MFMA: wf_pipe_kernel (csrc/wavernn_pipe.h); resident = "exact" */
-#define MB_WRN_PATH_PIPE16 3    /* 2..96 columns (MOL: 2..64), 22-bit operand pairs: wf_pipe16_kernel (csrc/wavernn_pipe16.h) */
+#define MB_WRN_PATH_PIPE16 3    /* 1..96 columns (MOL: 1..64), 22-bit operand pairs: wf_pipe16_kernel (csrc/wavernn_pipe16.h) */
 int mb_wavernn_loop_path(int columns, int mode, int production, int have_q16, int resident_cus, int dev_failed, int resident);
 /* Which form of the loop produced the samples of the LAST mb_wavernn_generate call on this handle (*path: MB_WRN_PATH_*), and
  * whether a resident launch was discarded on the way (*fallback): a caller that needs a reproducible stream per (mel, seed) checks

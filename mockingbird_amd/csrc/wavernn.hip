@@ -316,7 +316,7 @@ static std::atomic<bool> g_resident_failed[64] = {};  // written by whichever ho
 //   resident     MBHIP_WAVERNN_RESIDENT: -1 unset (auto), 0 = no resident launch, 1 = resident launch wherever legal (also on a device
 //                that failed before), 2 ("exact") = like 1 with the exact fp32 kernel (wavernn_pipe.h) instead of wavernn_pipe16.h
 // | columns | RAW                                   | MOL                                   |
-// | 1       | wf_persist1_kernel                    | launch chain                          |
+// | 1       | wf_pipe16_kernel; exact: wf_persist1  | wf_pipe16_kernel; exact: chain        |
 // | 2..32   | wf_pipe16_kernel; exact: wf_pipe      | wf_pipe16_kernel; exact: wf_pipe      |
 // | 33..64  | wf_pipe16_kernel; exact: chain        | wf_pipe16_kernel; exact: chain        |
 // | 65..96  | wf_pipe16_kernel; exact: chain        | launch chain                          |
@@ -333,7 +333,10 @@ int wavernn_pick_path(int columns, int mode, int production, int have_q16, int r
     if (resident_cus < WQ_WGS) return MB_WRN_PATH_CHAIN;
     return q16 ? MB_WRN_PATH_PIPE16 : MB_WRN_PATH_PIPE;
   }
-  if (mode != 0) return MB_WRN_PATH_CHAIN;  // one column: the fmaf-chain kernel (RAW only)
+  // one column (batched=False): the operand-pair kernel serves it as one group of one column (round 5: 8.4 us per step against 9.4 on
+  // wf_persist1_kernel, and MOL models leave the launch chain); "exact" keeps the fmaf-chain kernel (RAW only)
+  if (q16 && resident_cus >= WQ_WGS) return MB_WRN_PATH_PIPE16;
+  if (mode != 0) return MB_WRN_PATH_CHAIN;
   if (resident_cus < WP_ON + WP_OFF) return MB_WRN_PATH_CHAIN;
   return MB_WRN_PATH_PERSIST1;
 }

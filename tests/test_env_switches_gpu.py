@@ -105,11 +105,15 @@ def test_wavernn_persistent_kernel_keeps_the_sample_stream(wavernn, monkeypatch)
     monkeypatch.setenv("MBHIP_WAVERNN_RESIDENT", "0")
     base = wavernn.generate_samples(mel, False, 0, 0, seed=21)
     assert wavernn.last_loop_launches > 1
-    monkeypatch.delenv("MBHIP_WAVERNN_RESIDENT")
+    monkeypatch.setenv("MBHIP_WAVERNN_RESIDENT", "exact")  # (the default for one column is the operand-pair kernel since round 5: one group of one column)
     alt = wavernn.generate_samples(mel, False, 0, 0, seed=21)
-    assert wavernn.last_loop_launches == 1, "the persistent kernel did not run"
+    assert wavernn.last_loop_launches == 1 and wavernn.last_path == "persist1", "the persistent kernel did not run"
     assert base.shape == alt.shape and base.shape[0] == 1
     assert torch.equal(base, alt), (int((base != alt).sum()), int((base != alt).any(0).nonzero()[0]) if (base != alt).any() else -1)
+    monkeypatch.delenv("MBHIP_WAVERNN_RESIDENT")
+    dflt = wavernn.generate_samples(mel, False, 0, 0, seed=21)
+    assert wavernn.last_loop_launches == 1 and wavernn.last_path == "pipe16" and dflt.shape == base.shape
+    assert float((dflt == base).float().mean()) > 0.99  # same noise, fp32-grade sums: equal up to near-ties (held to the oracle in test_wavernn_gpu.py)
 
 
 def test_wavernn_persistent_kernel_falls_back_to_the_chain(cuda, lib, monkeypatch):
@@ -120,13 +124,13 @@ def test_wavernn_persistent_kernel_falls_back_to_the_chain(cuda, lib, monkeypatc
     mel = torch.from_numpy(synth.wavernn_mel(9, seed=13) / 4.0).cuda()
     monkeypatch.setenv("MBHIP_WAVERNN_RESIDENT", "0")
     base = dev.generate_samples(mel, False, 0, 0, seed=4)
-    monkeypatch.delenv("MBHIP_WAVERNN_RESIDENT")
+    monkeypatch.setenv("MBHIP_WAVERNN_RESIDENT", "exact")
     monkeypatch.setenv("MBHIP_DIAG", "abort_wp")
     alt = dev.generate_samples(mel, False, 0, 0, seed=4)
-    assert dev.last_loop_launches > 1 and torch.equal(base, alt)
+    assert dev.last_loop_launches > 1 and torch.equal(base, alt) and dev.last_path == "chain" and dev.last_fallback == "abort"
     monkeypatch.delenv("MBHIP_DIAG")
     again = dev.generate_samples(mel, False, 0, 0, seed=4)  # (the test switch does not mark the device as failed)
-    assert dev.last_loop_launches == 1 and torch.equal(base, again)
+    assert dev.last_loop_launches == 1 and torch.equal(base, again) and dev.last_fallback is None
     # the pipelined resident kernel (wavernn_pipe.h) takes the same way out
     mel3 = torch.from_numpy(synth.wavernn_mel(40, seed=13) / 4.0).cuda()
     monkeypatch.setenv("MBHIP_WAVERNN_RESIDENT", "0")

@@ -259,9 +259,10 @@ def test_wavernn_loop_path_table(lib):
     U, OFF, ON, EXACT = -1, 0, 1, 2  # MBHIP_WAVERNN_RESIDENT: unset / 0 / 1 / exact
     #        columns mode prod q16 cus failed resident -> path
     table = [
-        (1, 0, 1, 1, 256, 0, U, P1), (1, 0, 1, 1, 256, 0, OFF, CHAIN), (1, 1, 1, 0, 256, 0, U, CHAIN),                # one column: RAW only
-        (1, 0, 1, 1, 191, 0, U, CHAIN), (1, 0, 1, 1, 192, 0, U, P1),                                                  # 192 workgroups
-        (1, 0, 1, 1, 256, 1, U, CHAIN), (1, 0, 1, 1, 256, 1, ON, P1), (1, 0, 1, 1, 256, 1, EXACT, P1),                # failure memo / explicit switch
+        (1, 0, 1, 1, 256, 0, U, PIPE16), (1, 1, 1, 1, 256, 0, U, PIPE16), (1, 0, 1, 1, 256, 0, OFF, CHAIN),           # one column: the operand-pair kernel (round 5)
+        (1, 0, 1, 0, 256, 0, U, P1), (1, 1, 1, 0, 256, 0, U, CHAIN), (1, 0, 1, 1, 256, 0, EXACT, P1), (1, 1, 1, 1, 256, 0, EXACT, CHAIN),  # no images / exact: fmaf-chain kernel, RAW only
+        (1, 0, 1, 1, 191, 0, U, CHAIN), (1, 0, 1, 1, 192, 0, U, P1), (1, 0, 1, 1, 223, 0, U, P1), (1, 0, 1, 1, 224, 0, U, PIPE16),  # 192 / 224 workgroups
+        (1, 0, 1, 1, 256, 1, U, CHAIN), (1, 0, 1, 1, 256, 1, ON, PIPE16), (1, 0, 1, 1, 256, 1, EXACT, P1),            # failure memo / explicit switch
         (2, 0, 1, 1, 256, 0, U, PIPE16), (23, 0, 1, 1, 256, 0, U, PIPE16), (32, 0, 1, 1, 256, 0, U, PIPE16),
         (33, 0, 1, 1, 256, 0, U, PIPE16), (64, 0, 1, 1, 256, 0, U, PIPE16), (65, 0, 1, 1, 256, 0, U, PIPE16), (96, 0, 1, 1, 256, 0, U, PIPE16),
         (97, 0, 1, 1, 256, 0, U, CHAIN), (97, 0, 1, 1, 256, 0, ON, CHAIN), (65, 0, 1, 1, 256, 0, EXACT, CHAIN),       # six groups of 16

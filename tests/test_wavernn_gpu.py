@@ -731,19 +731,21 @@ def test_production_8_bit_model_vs_oracle(cuda, lib, monkeypatch, resident):
     assert int(mism.sum()) <= 3
 
 
-@pytest.mark.parametrize("form", ["fmaf", "chain"])
+@pytest.mark.parametrize("form", ["default", "fmaf", "chain"])
 def test_production_one_column_vs_oracle(model, monkeypatch, form):
-    """batched=False (one fold column): the persistent kernel (fmaf chains in the MFMA's order) and the launch chain it replaces,
-    2000 steps each against the oracle."""
+    """batched=False (one fold column): the default (round 5: wf_pipe16_kernel as one group of one column), the persistent fmaf-chain
+    kernel (MBHIP_WAVERNN_RESIDENT=exact) and the launch chain, 2000 steps each against the oracle."""
     dev, w = model
     monkeypatch.delenv("MBHIP_WAVERNN_RESIDENT", raising=False)
-    if form == "chain":
-        monkeypatch.setenv("MBHIP_WAVERNN_RESIDENT", "0")
+    monkeypatch.delenv("MBHIP_DIAG", raising=False)
+    if form != "default":
+        monkeypatch.setenv("MBHIP_WAVERNN_RESIDENT", "0" if form == "chain" else "exact")
     frames, steps, seed = 30, 2000, 77
     mel = synth.wavernn_mel(frames, seed=13)
     s = dev.generate_samples(torch.from_numpy(mel / 4.0).cuda(), False, 0, 0, seed=seed).cpu()
     assert s.shape == (1, 6000)
     assert dev.last_loop_launches == (5 * 6000 if form == "chain" else 1)
+    assert dev.last_path == {"default": "pipe16", "fmaf": "persist1", "chain": "chain"}[form]
     noise = dev.sampler_noise(seed, steps, 1).cpu()
     o_s, o_l = _oracle_replay(w, mel, False, 0, 0, s, noise, steps)
     _assert_same_picks(s, o_s, o_l, noise, steps, max_ties=2)
