@@ -509,6 +509,12 @@ int mb_taco_decode(const mb_taco* t, const float* d_memory, const float* d_memor
  * iterations it ran.  Production-dims handles only (the hipGraph-replayed loop); MB_ESTATE otherwise. */
 int mb_taco_last_loop_ms(const mb_taco* t, float* ms, int* iterations);
 
+/* Launches per decoder iteration of the last mb_taco_decode call on the hipGraph-replayed loop: 5 = prenet fc2, attention GRU and
+ * attention as ROLES of one launch with tagged-granule hand-offs (taco_front_kernel: batch <= 32, text <= 192 symbols, 48 + 4 batch
+ * compute units), 7 = one launch each (same bits; also what a call falls back to when a hand-off of the fused launch times out, and
+ * with MBHIP_DIAG=taco_front=0); -1 = no decode on that loop yet. */
+int mb_taco_last_loop_form(const mb_taco* t);
+
 /* Text encoder + global style token + attention-memory assembly (the once-per-chunk front
  * half of Tacotron.forward, tacotron.py:234-255):
  *  d_chars   [B][T] int32, d_speaker [B][speaker_dims],

@@ -147,6 +147,24 @@ struct DropK {
   int it_limit;            // iterations covered by `mask`: the job that prepares iteration it_limit (never run) reads nothing
   unsigned thresh; float scale; int enabled;
 };
+// the factors alone (1 = keep unscaled): what relu_drop_quad multiplies by, computable before the sums exist
+__device__ __forceinline__ void drop_quad_factors(const DropK& d, const int* flags, int it, int n, int row0, float (&f)[4]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) f[r] = 1.f;
+  if (!d.enabled) return;
+  const int iter = it + d.it_add;
+  if (d.mask) {
+    if (iter >= d.it_limit) return;
+    const float4 m = *reinterpret_cast<const float4*>(d.mask + (long long)iter * d.it_stride + (size_t)n * d.ld + row0);
+    f[0] = m.x * d.scale; f[1] = m.y * d.scale; f[2] = m.z * d.scale; f[3] = m.w * d.scale;
+  } else {
+    const unsigned long long seed = *reinterpret_cast<const unsigned long long*>(flags + TF_SEED);
+    uint32_t rr[4];
+    philox4x32((uint32_t)iter, (uint32_t)d.layer, (uint32_t)n, (uint32_t)(row0 >> 2), (uint32_t)seed, (uint32_t)(seed >> 32), rr);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) f[r] = (rr[r] >= d.thresh) ? d.scale : 0.f;
+  }
+}
 __device__ __forceinline__ void relu_drop_quad(const DropK& d, const int* flags, int it, int n, int row0, float (&v)[4]) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);

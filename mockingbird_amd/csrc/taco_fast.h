@@ -219,10 +219,12 @@ __global__ __launch_bounds__(512) void taco_lstm_kernel(TfLstmK a) {
 // job 2 (1 tile):      stop = sigmoid(stop_proj([x, context])) (:133-136) -- x half here, context half from the rnn_input
 //        launch -- and the batch-wide stop rule (:275)
 // job 3 (hh.n_tiles row tiles): W_hh1 . h1 for the next iteration (fm_hh_job)
+// job 4 (hh2.n_tiles row tiles): W_hh2 . h2 for the next iteration, the tiles taco_front_kernel has no room for
 struct TfMelK {
   const float* w_mel; const float* w_fc1; const float* b_fc1; const float* w_stop; const float* b_stop;
   const float* x2; const float* stop_part; float* p1; float* mel_out; float* stop_out;
   TfHhK hh;  // job 3: hidden half of the NEXT iteration's first LSTM (h1 of this iteration is final)
+  TfHhK hh2; // job 4 (fused front only): the first row tiles of the next iteration's W_hh2 . h2 (h2 is final as well)
   int nta, B, n_mel, M, r, max_steps, it_off; float min_stop_token; int* flags; DropK drop; unsigned long long* trace;
 };
 template <int NT>
@@ -265,7 +267,9 @@ __global__ __launch_bounds__(512) void taco_mel_kernel(TfMelK a) {
     return;
   }
   if (bx > a.n_mel + 16) {
-    fm_hh_job<NT>(a.hh, bx - (a.n_mel + 17), nt0, a.nta, done, red);
+    const int j = bx - (a.n_mel + 17);
+    if (j < a.hh.n_tiles) fm_hh_job<NT>(a.hh, j, nt0, a.nta, done, red);
+    else fm_hh_job<NT>(a.hh2, j - a.hh.n_tiles, nt0, a.nta, done, red);
     return;
   }
   // stop tile: one live row (row 0) over K = x2; the context half of the logit comes from the rnn_input launch

@@ -75,6 +75,37 @@ def test_fast_loop_equals_general_loop(model, monkeypatch):
         assert a.shape == b.shape and e["nan"] == 0 and e["max_abs"] <= 2e-4, (name, e)
 
 
+@pytest.mark.parametrize("B,tmin,tmax", [(32, 60, 100), (7, 20, 30), (17, 130, 150), (1, 12, 12)])
+def test_fused_front_equals_one_launch_each(model, monkeypatch, B, tmin, tmax):
+    """taco_front_kernel (prenet fc2, attention GRU and attention as roles of ONE launch with tagged-granule hand-offs: 5 launches
+    per iteration) against the same three kernels as launches of their own (MBHIP_DIAG=taco_front=0: 7): the same bits, graph
+    replays and eager tail, injected masks and the on-device Philox stream; a lost hand-off (MBHIP_DIAG=taco_front_lost=1: every
+    wait bails out) makes the call run again with 7 launches and return the same frames."""
+    dev, w = model
+    chars, spk, _, _ = _batch(B, tmin, tmax, seed=40 + B)
+    with torch.no_grad():
+        mem, memp = ot.encoder_memory(w, ot.HP, chars, spk, 0)
+    steps = 74  # 37 iterations: two graph replays of 16 + 5 eager
+    masks = synth.decoder_dropout_masks(5, steps // 2, B)
+    monkeypatch.delenv("MBHIP_DIAG", raising=False)
+    a = dev.decode(mem.cuda(), memp.cuda(), chars.cuda(), steps, 11.0, dropout=masks)
+    assert dev.last_loop_launches_per_iteration == 5
+    ar = dev.decode(mem.cuda(), memp.cuda(), chars.cuda(), steps, 11.0, seed=123)
+    monkeypatch.setenv("MBHIP_DIAG", "taco_front=0")
+    b = dev.decode(mem.cuda(), memp.cuda(), chars.cuda(), steps, 11.0, dropout=masks)
+    assert dev.last_loop_launches_per_iteration == 7
+    br = dev.decode(mem.cuda(), memp.cuda(), chars.cuda(), steps, 11.0, seed=123)
+    monkeypatch.setenv("MBHIP_DIAG", "taco_front_lost=1")
+    c = dev.decode(mem.cuda(), memp.cuda(), chars.cuda(), steps, 11.0, dropout=masks)
+    assert dev.last_loop_launches_per_iteration == 7
+    monkeypatch.delenv("MBHIP_DIAG")
+    d = dev.decode(mem.cuda(), memp.cuda(), chars.cuda(), steps, 11.0, dropout=masks)
+    assert dev.last_loop_launches_per_iteration == 5  # the provoked loss is not remembered
+    for x, y in list(zip(a, b)) + list(zip(ar, br)) + list(zip(a, c)) + list(zip(a, d)):
+        assert torch.equal(x, y)
+    assert float(a[0].abs().mean()) > 0.1
+
+
 def test_stop_rule_matches_oracle(model):
     """Batch-wide stop (tacotron.py:275): (stop*10 > min_stop_token).all() and t > 10, frames of the
     stopping iteration are kept."""

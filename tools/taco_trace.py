@@ -7,6 +7,9 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 from _diag import diag_set, diag_get
 out_path = os.path.join(ROOT, "gpurun_out", "taco_trace.bin")
 diag_set("taco_trace", out_path)
+SEVEN = "seven" in sys.argv[1:]  # one launch each for fc2 / GRU / attention instead of taco_front_kernel
+if SEVEN:
+    diag_set("taco_front", "0")
 import numpy as np, torch, synth
 from mockingbird_amd.synthesizer.inference import TacotronDevice
 st = synth.tacotron_state(seed=3)["model_state"]
@@ -36,4 +39,8 @@ for name, r in zip(names, raw):
                  "phases_cycles": {marks[i + 1][0]: marks[i + 1][1] - marks[i][1] for i in range(len(marks) - 1)}}
     print(f"{name:9s} wall {wall[0]*0.01:8.2f} -> {wall[1]*0.01:8.2f} us ({us_wall:5.2f} us, {cyc} cyc, {ghz:.2f} GHz)  " +
           "  ".join(f"{k}: {v}" for k, v in res[name]["phases_cycles"].items()))
-json.dump(res, open(os.path.join(ROOT, "gpurun_out", "taco_trace.json"), "w"), indent=1)
+if not SEVEN:
+    res["front_extra_us"] = {"last_attention_workgroup": (int(raw[2][13]) - wall0) * 0.01, "first_hh2_tile_done": (int(raw[0][12]) - wall0) * 0.01,
+                             "hh2_tile_200_done": (int(raw[0][11]) - wall0) * 0.01, "last_hh2_tile_done": (int(raw[0][13]) - wall0) * 0.01}
+    print(res["front_extra_us"])
+json.dump(res, open(os.path.join(ROOT, "gpurun_out", "taco_trace_seven.json" if SEVEN else "taco_trace.json"), "w"), indent=1)
