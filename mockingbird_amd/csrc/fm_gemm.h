@@ -48,6 +48,25 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+// wave-wide sum / max on DPP row operations and four v_readlane (every lane receives the result): ~15 VALU ops where the
+// __shfl_xor butterfly (common.h wave_sum) makes six trips through the LDS crossbar -- the attention's softmax is ONE wave on the chain
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  v = fmaxf(v, dpp_mov<0x140>(v));
+  return v;
+}
+__device__ __forceinline__ float lane_bcast(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+__device__ __forceinline__ float wave64_sum(float v) {
+  v = row16_sum(v);
+  return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
+}
+__device__ __forceinline__ float wave64_max(float v) {
+  v = row16_max(v);
+  return fmaxf(fmaxf(lane_bcast(v, 0), lane_bcast(v, 16)), fmaxf(lane_bcast(v, 32), lane_bcast(v, 48)));
+}
+
 // Skinny GEMM core: one 16-row weight tile (mt) x NT column tiles, K = 8 * PW k-blocks split over the 8 waves
 // (wave w owns k-blocks w, w+8, ...), first PS steps from seg0, the rest from seg1 (both FM).  NPART = 2 keeps the
 // seg1 sums apart (GRU hidden part).  All loads are issued before the first MFMA.  Returns true for the NT

@@ -27,4 +27,17 @@ __device__ __forceinline__ unsigned long long wp_get(const unsigned long long* p
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Wait for one granule with TWO loads in flight: the next poll is on its way while the last one is looked at, so a fresh value is seen
+// half a round trip sooner on average than with load / test / sleep (the chain edges of taco_front_kernel: ~0.2 us each).
+// Returns the granule (stale if the wait was lost: the caller's launch is aborting anyway).
+__device__ __forceinline__ unsigned long long wp_wait2(const unsigned long long* p, const unsigned tag, int* abort_word) {
+  unsigned long long cur = wp_get(p), t0 = 0;
+  for (int tries = 0;; ++tries) {
+    const unsigned long long nxt = wp_get(p);
+    if ((unsigned)(cur >> 32) == tag) return cur;
+    if ((tries & 1023) == 1023 && wp_lost(tries, t0, abort_word)) return cur;
+    cur = nxt;
+  }
+}
+
 }  // namespace mb

@@ -108,6 +108,66 @@ __device__ __forceinline__ void fm_hh_job(const TfHhK& a, const int mt_local, co
   if (nt >= nta || done) return;
   a.hpre[((size_t)mt * nta + nt) * 64 + lane] = make_float4(sx[0], sx[1], sx[2], sx[3]);
 }
+// Two row tiles per workgroup against ONE set of activation fragments (taco_front_kernel: every workgroup of that launch has a compute
+// unit to itself, so the tile COUNT is what the launch's tail is made of; the 128 KB of h fragments are read once per pair).  Per tile
+// the products, their order and the reduction are fm_gemm's: same bits as two fm_hh_job calls.  red: 2 * FmRed<NT, 1>::floats.
+template <int NT>
+__device__ __forceinline__ void fm_hh_pair_job(const TfHhK& a, const int pair, const int nta, const int done, float* red) {
+  constexpr int PW = 8, BLK = 4 * 4 * 16, NKB = 8 * PW;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, kq = lane >> 4, u = i >> 2, tau = i & 3;
+  const int mtl0 = 2 * pair, mtl1 = (2 * pair + 1 < a.n_tiles) ? 2 * pair + 1 : 2 * pair;  // odd count: the last pair repeats its tile
+  const float* wl0 = a.w + (size_t)(a.tile0 + mtl0) * NKB * BLK + ((u * 4 + tau) * 4 + kq) * 4;
+  const float* wl1 = a.w + (size_t)(a.tile0 + mtl1) * NKB * BLK + ((u * 4 + tau) * 4 + kq) * 4;
+  int ntc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) ntc[nt] = nt < nta ? nt : nta - 1;
+  float4 w0[PW], w1[PW], b[PW][NT];
+  const float4* sp = reinterpret_cast<const float4*>(a.h);
+#pragma unroll
+  for (int p = 0; p < PW; ++p) {
+    const int kb = wave + 8 * p;
+    w0[p] = *reinterpret_cast<const float4*>(wl0 + (size_t)kb * BLK);
+    w1[p] = *reinterpret_cast<const float4*>(wl1 + (size_t)kb * BLK);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[p][nt] = sp[((size_t)kb * nta + ntc[nt]) * 64 + lane];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 acc0[NT], acc1[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) { acc0[nt] = {0.f, 0.f, 0.f, 0.f}; acc1[nt] = {0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int p = 0; p < PW; ++p)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float a0 = c == 0 ? w0[p].x : c == 1 ? w0[p].y : c == 2 ? w0[p].z : w0[p].w;
+      const float a1 = c == 0 ? w1[p].x : c == 1 ? w1[p].y : c == 2 ? w1[p].z : w1[p].w;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float bv = c == 0 ? b[p][nt].x : c == 1 ? b[p][nt].y : c == 2 ? b[p][nt].z : b[p][nt].w;
+        acc0[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv, acc0[nt], 0, 0, 0);
+        acc1[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv, acc1[nt], 0, 0, 0);
+      }
+    }
+  float4* red4 = reinterpret_cast<float4*>(red);  // [2 tiles][8][NT][64]
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    red4[(wave * NT + nt) * 64 + lane] = make_float4(acc0[nt][0], acc0[nt][1], acc0[nt][2], acc0[nt][3]);
+    red4[((8 + wave) * NT + nt) * 64 + lane] = make_float4(acc1[nt][0], acc1[nt][1], acc1[nt][2], acc1[nt][3]);
+  }
+  __syncthreads();
+  if (wave >= 2 * NT) return;
+  const int ts = wave / NT, nt = wave - ts * NT;
+  float sx[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int w8 = 0; w8 < 8; ++w8) {
+    const float4 v = red4[((ts * 8 + w8) * NT + nt) * 64 + lane];
+    sx[0] += v.x; sx[1] += v.y; sx[2] += v.z; sx[3] += v.w;
+  }
+  if (nt >= nta || done || (ts == 1 && mtl1 == mtl0)) return;
+  a.hpre[((size_t)(a.tile0 + (ts ? mtl1 : mtl0)) * nta + nt) * 64 + lane] = make_float4(sx[0], sx[1], sx[2], sx[3]);
+}
 // stand-alone form (general LSA kernel in use, or diagnostics)
 template <int NT>
 __global__ __launch_bounds__(512) void taco_hh_kernel(TfHhK a, int nta, const int* flags) {

@@ -58,6 +58,7 @@ struct LsaK {
   // attention-GRU workgroups; `lost` = the word a timed-out wait raises (flags + TF_LOST)
   const unsigned long long* q_gran = nullptr; int* lost = nullptr;
   unsigned long long* e_gran = nullptr;  // [B][128] energies exchanged between the four workgroups of an utterance (T <= 128)
+  int dma_early = 0;  // fused launch: waves 2..7 queue the memory rows' LDS-DMA in front of the query wait (waves 0 / 1 poll)
 };
 __device__ __forceinline__ size_t lsa_qidx(const LsaK& a, int b, int k) { return a.fm_nta ? fm_index(a.fm_nta, b, k) : (size_t)b * a.D + k; }
 // float4 slot of context columns [p, p+4) of utterance b (p % 4 == 0)
@@ -297,6 +298,27 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
   f32x4 accs[FUSED ? NPASS : 1][ND];
   if (FUSED) {
     __syncthreads();  // B1a: window staged
+    if (ES && dma && a.dma_early) {
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) {
+        asm volatile("" : "+v"(mf[dt][0].x), "+v"(mf[dt][0].y), "+v"(mf[dt][0].z), "+v"(mf[dt][0].w));
+        asm volatile("" : "+v"(mf[dt][1].x), "+v"(mf[dt][1].y), "+v"(mf[dt][1].z), "+v"(mf[dt][1].w));
+        asm volatile("" : "+v"(mpf[0][dt].x), "+v"(mpf[0][dt].y), "+v"(mpf[0][dt].z), "+v"(mpf[0][dt].w));
+      }
+#pragma unroll
+      for (int k4 = 0; k4 < 8; ++k4) asm volatile("" : "+v"(wq4[k4].x), "+v"(wq4[k4].y), "+v"(wq4[k4].z), "+v"(wq4[k4].w));
+#pragma unroll
+      for (int m = 0; m < (TMAX + 63) / 64; ++m) asm volatile("" : "+v"(chv[m]));
+      if (wave >= 2) {
+#pragma unroll
+        for (int j = 0; j < (TMAX + 5) / 6; ++j) {
+          const int t = (wave - 2) + 6 * j;  // wave-uniform
+          if (t < T)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(mem + (size_t)t * P),
+                                             (__attribute__((address_space(3))) void*)(s_mem + t * PW), 16, 0, 0);
+        }
+      }
+    }
     // location term on the matrix pipe (phase 2's MFMAs, same order per accumulator)
     {
       const int i = lane & 15, kq = lane >> 4;
@@ -321,14 +343,7 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
       }
     }
     if (tid < D && !skip) {  // now wait for this utterance's attention-GRU output
-      const unsigned long long* gp = a.q_gran + (size_t)b * D + tid;
-      const unsigned tag = (unsigned)iter + 1u;
-      unsigned long long g, t0 = 0;
-      for (int tries = 0; (unsigned)((g = wp_get(gp)) >> 32) != tag; ++tries) {
-        if ((tries & 1023) == 1023 && wp_lost(tries, t0, a.lost)) break;
-        __builtin_amdgcn_s_sleep(1);
-      }
-      qv = __uint_as_float((unsigned)g);
+      qv = __uint_as_float((unsigned)wp_wait2(a.q_gran + (size_t)b * D + tid, (unsigned)iter + 1u, a.lost));
     }
     if (tid < D) s_q[tid] = qv;
   }
@@ -369,7 +384,7 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
   }
   __syncthreads();  // B2
   tf_mark(a.trace, TS_LSA, 3, pick);
-  if (dma) {  // queued behind B2: a barrier drains the DMA queue (hipcc emits vmcnt(0) in front of s_barrier)
+  if (dma && !(ES && a.dma_early)) {  // queued behind B2: a barrier drains the DMA queue (hipcc emits vmcnt(0) in front of s_barrier)
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
       const int t = wave + 8 * j;  // wave-uniform: row t lands at s_mem[t][0..255], lane l -> floats [4 l, 4 l + 4)
@@ -425,13 +440,7 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
       }
       // the sibling workgroups' 96 energies
       if (tid < T && (tid >> 5) != pg && !skip) {
-        const unsigned long long* gp = a.e_gran + (size_t)b * TMAX + tid;
-        unsigned long long g, t0 = 0;
-        for (int tries = 0; (unsigned)((g = wp_get(gp)) >> 32) != tag; ++tries) {
-          if ((tries & 1023) == 1023 && wp_lost(tries, t0, a.lost)) break;
-          __builtin_amdgcn_s_sleep(1);
-        }
-        s_e[tid] = __uint_as_float((unsigned)g);
+        s_e[tid] = __uint_as_float((unsigned)wp_wait2(a.e_gran + (size_t)b * TMAX + tid, tag, a.lost));
       }
     }
   } else {
@@ -511,7 +520,7 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
       uv[q] = u;
       m = fmaxf(m, u);
     }
-    m = wave_max(m);
+    m = wave64_max(m);
     float ssum = 0.f;
 #pragma unroll
     for (int q = 0; q < (TMAX + 63) / 64; ++q) {
@@ -519,7 +528,7 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
       uv[q] = (t < T) ? expf(uv[q] - m) : 0.f;
       ssum += uv[q];
     }
-    ssum = wave_sum(ssum);
+    ssum = wave64_sum(ssum);
     float* ao = (a.attn_out && pg == 0) ? a.attn_out + ((size_t)b * a.n_iter_max + iter) * T : nullptr;
 #pragma unroll
     for (int q = 0; q < (TMAX + 63) / 64; ++q) {
@@ -620,6 +629,7 @@ __global__ __launch_bounds__(512) void lsa_hh_kernel(LsaK a, TfHhK hh, int n_lsa
 struct TfFrontX {
   unsigned long long* p2g; unsigned long long* ahg; int* lost;
   int n_fc2, n_gru, watch;
+  int hh_pairs;  // the hh2 workgroups take two row tiles each (fm_hh_pair_job)
 };
 template <int NT>
 __device__ __forceinline__ void front_fc2_job(const TfFcK& a, const TfFrontX& x, const int mt, float* red) {
@@ -671,12 +681,13 @@ __device__ __forceinline__ void front_gru_job(const TfGruK& a, const TfFrontX& x
   if (x.watch) {
     const int j = lane < PW * NT ? lane : 0, p = j / NT, nt = j - p * NT;
     const unsigned long long* wp = x.p2g + ((size_t)((wave + 8 * p) * a.nta + (nt < a.nta ? nt : a.nta - 1)) * 4 + 3) * 64 + 63;
-    unsigned long long t0 = 0;
-    for (int tries = 0;; ++tries) {
-      const bool fresh = (unsigned)(wp_get(wp) >> 32) == tag;
+    unsigned long long t0 = 0, cur = wp_get(wp);
+    for (int tries = 0;; ++tries) {  // two polls in flight (granule.h wp_wait2)
+      const unsigned long long nxt = wp_get(wp);
+      const bool fresh = (unsigned)(cur >> 32) == tag;
       if (__builtin_amdgcn_ballot_w64(!fresh) == 0ull) break;
       if ((tries & 1023) == 1023 && wp_lost(tries, t0, x.lost)) break;
-      __builtin_amdgcn_s_sleep(1);
+      cur = nxt;
     }
   }
   tf_mark(a.trace, TS_GRU, 1, pick);
@@ -740,7 +751,7 @@ __device__ __forceinline__ void front_gru_job(const TfGruK& a, const TfFrontX& x
 }
 template <int TJ, int NT>
 __global__ __launch_bounds__(512) void taco_front_kernel(TfFcK fk, TfGruK gk, LsaK a, TfHhK hh, TfFrontX x, int n_lsa, int B, int gy, int nta) {
-  __shared__ __attribute__((aligned(16))) float s_big[TJ == 32 ? 32 * 4 * 256 : FmRed<NT, 1>::floats];
+  __shared__ __attribute__((aligned(16))) float s_big[TJ == 32 ? 32 * 4 * 256 : 2 * FmRed<NT, 1>::floats];
   const int id = blockIdx.x;
   if (id < x.n_fc2) { front_fc2_job<NT>(fk, x, id, s_big); return; }
   if (id < x.n_fc2 + x.n_gru) { front_gru_job<NT>(gk, x, id - x.n_fc2, fk.flags[TF_ITER] + fk.it_off, s_big); return; }
@@ -750,12 +761,12 @@ __global__ __launch_bounds__(512) void taco_front_kernel(TfFcK fk, TfGruK gk, Ls
     if (a.trace && threadIdx.x == 0) atomicMax(a.trace + TS_LSA * 16 + 13, (unsigned long long)wall_clock64());  // last attention workgroup
     return;
   }
-  const int j = l - n_lsa, mt = j / gy;
-  fm_hh_job<NT>(hh, mt, (j - mt * gy) * NT, nta, a.skip_flag ? *a.skip_flag : 0, s_big);
+  const int j = l - n_lsa;  // (gy == 1: the fused launch serves at most NT column tiles)
+  if (x.hh_pairs) fm_hh_pair_job<NT>(hh, j, nta, a.skip_flag ? *a.skip_flag : 0, s_big);
+  else fm_hh_job<NT>(hh, j, 0, nta, a.skip_flag ? *a.skip_flag : 0, s_big);
   if (a.trace && threadIdx.x == 0) {
     atomicMax(a.trace + TS_FC2 * 16 + 13, (unsigned long long)wall_clock64());  // last hh2 tile
     if (j == 0) a.trace[TS_FC2 * 16 + 12] = (unsigned long long)wall_clock64();  // first hh2 tile done
-    if (j == 200) a.trace[TS_FC2 * 16 + 11] = (unsigned long long)wall_clock64();
   }
 }
 
@@ -1692,9 +1703,11 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
     if (front) {  // 1..3 as one launch (taco_front_kernel): fc2 tiles | GRU tiles | attention workgroups | hh2 tiles
       TfFrontX fx;
       fx.p2g = L.f_p2g; fx.ahg = L.f_ahg; fx.lost = flags + TF_LOST; fx.n_fc2 = 2 * D / 16; fx.n_gru = D / 4; fx.watch = diag_int("taco_gru_watch", 1);
+      fx.hh_pairs = diag_int("taco_hh_pairs", 1);
+      lk.dma_early = diag_int("taco_dma_early", 1);
       lk.q_gran = L.f_ahg; lk.lost = flags + TF_LOST; lk.e_gran = L.f_eg;
       hh2.tile0 = hh2_mel; hh2.n_tiles = H / 4 - hh2_mel;
-      const dim3 g1(fx.n_fc2 + fx.n_gru + n_lsa + hh2.n_tiles * gy);
+      const dim3 g1(fx.n_fc2 + fx.n_gru + n_lsa + (fx.hh_pairs ? cdiv(hh2.n_tiles, 2) : hh2.n_tiles));
       if (T <= 128 && nta >= 2) hipLaunchKernelGGL((taco_front_kernel<32, 2>), g1, blk, 0, s, fk, gk, lk, hh2, fx, n_lsa, B, gy, nta);
       else if (T <= 128) hipLaunchKernelGGL((taco_front_kernel<32, 1>), g1, blk, 0, s, fk, gk, lk, hh2, fx, n_lsa, B, gy, nta);
       else if (nta >= 2) hipLaunchKernelGGL((taco_front_kernel<48, 2>), g1, blk, 0, s, fk, gk, lk, hh2, fx, n_lsa, B, gy, nta);
@@ -1754,7 +1767,7 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
   int it_done = 0, rc = MB_OK;
   bool stopped = false;
   if (use_graph) {
-    mb_taco::GraphKey key = {d_memory, d_memory_proj, d_chars, d_dropout, d_mel, d_attn, d_workspace, B, T, max_steps, G, min_stop_token, front ? 1 + hh2_mel + 1024 * diag_int("taco_gru_watch", 1) : 0};
+    mb_taco::GraphKey key = {d_memory, d_memory_proj, d_chars, d_dropout, d_mel, d_attn, d_workspace, B, T, max_steps, G, min_stop_token, front ? 1 + hh2_mel + 1024 * diag_int("taco_gru_watch", 1) + 2048 * diag_int("taco_dma_early", 1) + 4096 * diag_int("taco_hh_pairs", 1) : 0};
     if (!t->graph_exec || !(key == t->gkey)) {
       t->drop_graph();
       MB_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));

@@ -11,7 +11,8 @@ SRC = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two separate pas
        "doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B)")
 WHAT = {
     "tacotron": ("tools/taco_run.py (BASELINE configs[2]: B=32, ~100 tokens, 400 decoder iterations)",
-                 {"prenet_fc2": ["taco_fc2_kernel"], "attn_gru": ["taco_gru_kernel"], "lsa": ["lsa_hh_kernel"],
+                 {"front": ["taco_front_kernel"],  # round 5: fc2 | attention GRU | attention as roles of one launch
+                  "prenet_fc2": ["taco_fc2_kernel"], "attn_gru": ["taco_gru_kernel"], "lsa": ["lsa_hh_kernel"],
                   "rnn_input": ["taco_rin_kernel"], "lstm": ["taco_lstm_kernel"], "mel_proj": ["taco_mel_kernel"]}),
     "hifigan": ("tools/gan_run.py hifigan f16 32 200 (bench object hifigan_f16)",
                 {"resblock_pair": ["resblock_pair"], "resblock_stage": ["resblock_stage"], "conv1d_f16": ["conv1d_f16"]}),

@@ -1,5 +1,6 @@
 """Stress of the resident (one-launch) loops' hand-offs -- wf_pipe16_kernel (23 fold columns, RAW and MOL models), wf_pipe_kernel (the exact kernel),
-wf_persist1_kernel (one column), ppg_resident_kernel (ppg2mel, one utterance), ppg_batch_kernel (ppg2mel, 32 utterances): the same call many times, alone and while another
+wf_persist1_kernel (one column), ppg_resident_kernel (ppg2mel, one utterance), ppg_batch_kernel (ppg2mel, 32 utterances), taco_front_kernel (the
+Tacotron iteration's fused front: a launch with two in-launch hand-offs per iteration, counted as "1" here against the 7-launch iteration): the same call many times, alone and while another
 stream keeps the GPU busy with GEMMs of varying size (uneven load, workgroups competing for compute units).  Every run must either
 reproduce the quiet resident run bit for bit (the kernels are deterministic) or -- if the launch lost a hand-off and drained -- equal
 the launch chain's result (the fallback); anything else is a FAILURE.  VERDICT r03 item 8.
@@ -34,6 +35,25 @@ def wrn(mel, batched, env, d=None):
     return out.clone(), d.last_loop_launches
 
 
+from mockingbird_amd.synthesizer.inference import TacotronDevice
+import numpy as np
+_tst = synth.tacotron_state(seed=3)["model_state"]
+tdev = TacotronDevice(_tst, torch.device("cuda"))
+_seqs, _emb = synth.tacotron_inputs(32, 60, 100, seed=4)
+_T = max(len(q) for q in _seqs)
+t_chars = torch.tensor(np.stack([np.pad(q, (0, _T - len(q))) for q in _seqs])).long().cuda()
+t_mem, t_memp = tdev.encode(t_chars, torch.tensor(np.stack(_emb)).cuda(), -1, None, 1)
+
+
+def taco(env):
+    os.environ.pop("MBHIP_DIAG", None)
+    os.environ.update(env)
+    mel, _, _ = tdev.decode(t_mem, t_memp, t_chars, 120, 11.0, seed=3)
+    torch.cuda.synchronize()
+    os.environ.pop("MBHIP_DIAG", None)
+    return mel.clone(), (1 if tdev.last_loop_launches_per_iteration == 5 else 7)
+
+
 def ppg(env, m=None):
     os.environ.pop("MBHIP_PPG_RESIDENT", None)
     os.environ.update(env)
@@ -49,6 +69,7 @@ CASES = {
     "wavernn_one_column": (lambda env: wrn(mel1, False, env), {"MBHIP_WAVERNN_RESIDENT": "1"}, {"MBHIP_WAVERNN_RESIDENT": "0"}),
     "ppg2mel_resident": (ppg, {"MBHIP_PPG_RESIDENT": "1"}, {"MBHIP_PPG_RESIDENT": "0"}),
     "ppg2mel_batch32_resident": (lambda env: ppg(env, mem32), {"MBHIP_PPG_RESIDENT": "1"}, {"MBHIP_PPG_RESIDENT": "0"}),
+    "tacotron_fused_front_b32": (taco, {}, {"MBHIP_DIAG": "taco_front=0"}),
 }
 side = torch.cuda.Stream()
 bad = 0
@@ -69,6 +90,8 @@ for name, (run, env_res, env_chain) in CASES.items():
         # explicit switches: a device that fell back once is tried again (the memo only changes the DEFAULT)
         out, nl = run(env_res)
         verdict = "resident" if (nl == 1 and torch.equal(out, quiet)) else "fallback" if (nl > 1 and torch.equal(out, chain)) else "WRONG"
+        if name.startswith("tacotron") and not torch.equal(quiet, chain):
+            verdict = "WRONG"  # the fused and the 7-launch iteration are the same arithmetic
         bad += verdict == "WRONG"
         print(f"{name} rep {rep} load {load}: {verdict} (launches {nl}, wall {time.perf_counter() - t0:.3f} s)", flush=True)
         torch.cuda.synchronize()

@@ -41,6 +41,6 @@ for name, r in zip(names, raw):
           "  ".join(f"{k}: {v}" for k, v in res[name]["phases_cycles"].items()))
 if not SEVEN:
     res["front_extra_us"] = {"last_attention_workgroup": (int(raw[2][13]) - wall0) * 0.01, "first_hh2_tile_done": (int(raw[0][12]) - wall0) * 0.01,
-                             "hh2_tile_200_done": (int(raw[0][11]) - wall0) * 0.01, "last_hh2_tile_done": (int(raw[0][13]) - wall0) * 0.01}
+                             "last_hh2_tile_done": (int(raw[0][13]) - wall0) * 0.01}
     print(res["front_extra_us"])
 json.dump(res, open(os.path.join(ROOT, "gpurun_out", "taco_trace_seven.json" if SEVEN else "taco_trace.json"), "w"), indent=1)
