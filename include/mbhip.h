@@ -515,6 +515,12 @@ int mb_taco_last_loop_ms(const mb_taco* t, float* ms, int* iterations);
  * with MBHIP_DIAG=taco_front=0); -1 = no decode on that loop yet. */
 int mb_taco_last_loop_form(const mb_taco* t);
 
+/* 1 when the last mb_taco_decode call on that loop multiplied its K >= 1024 tiles (LSTM input halves, rnn_input, mel_proj / prenet fc1' /
+ * stop rows, hidden halves) on the fp16 matrix pipe with error-compensated split operands (w 2^s = wh + wl, x = xh + 2^-11 xl: 22-bit
+ * operands, fp32 accumulate -- the 5-launch form with more than 16 utterances; a value beyond fp16's range makes the call run again on
+ * the exact fp32 loop), 0 when every product ran on the fp32 pipe, -1 = no decode on that loop yet.  MBHIP_DIAG=taco_f16=0|1 overrides. */
+int mb_taco_last_loop_f16(const mb_taco* t);
+
 /* Text encoder + global style token + attention-memory assembly (the once-per-chunk front
  * half of Tacotron.forward, tacotron.py:234-255):
  *  d_chars   [B][T] int32, d_speaker [B][speaker_dims],

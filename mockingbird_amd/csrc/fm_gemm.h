@@ -9,6 +9,7 @@
 //     lane writes is what the consuming epilogue lane reads (gate pre-activations, cell state).
 #pragma once
 #include "rnn_body.h"
+#include "pair_granule.h"
 
 namespace mb {
 
@@ -148,6 +149,107 @@ __device__ __forceinline__ bool fm_gemm(const float* __restrict__ w, const int m
     }
   }
   return true;
+}
+
+// The same tile product on the fp16 matrix pipe, fp32-grade (conv1d.hip's error-compensated scheme, as in wavernn_pipe16.h):
+// w 2^s = wh + wl (host-split image), x = xh + 2^-11 xl' (split in registers from the fp32 FM fragments), three
+// v_mfma_f32_16x16x32_f16 per 32 k in two accumulator chains -- 24 matrix instructions per wave where the fp32 form issues 64 four-pass
+// ones (2048 of a launch's ~11 000 cycles per wave, twice that per SIMD).  A 32-k step of wave w pairs k-blocks w + 16 s and
+// w + 16 s + 8: lane (i, kq) holds features 4 kq .. + 3 of both -- the matrix instruction does not care which k a lane's eight values
+// are as long as A and B agree, so the B operand stays the FM float4 pair it is.  Image (pack_rowtile16, tacotron.hip):
+// [tile][g = 8 s + w][hi | lo][64 lanes] x 8 halves, K padded to a multiple of 256 with zero columns (the B loads of a padded
+// k-block re-read a valid one).  PS2 = steps taken from seg0 (k-blocks < kb0), the rest from seg1; NPART = 2 keeps the seg1 sums apart.
+// A value beyond fp16's range (|x| > 65504) turns the sums into inf / NaN: the callers test their sums and raise flags[TF_LOST],
+// the host reruns the call on the exact fp32 loop.
+typedef float fm_f8 __attribute__((ext_vector_type(8)));
+template <int NT, int PW2, int PS2, int NPART>
+__device__ __forceinline__ bool fm_gemm16(const uint4* __restrict__ w16, const int mt, const float* __restrict__ seg0, const int kb0,
+                                          const float* __restrict__ seg1, const int kb1, const int nta, const int nt0, float* red,
+                                          const float unscale, float (&sx)[4], float (&sh)[4], unsigned long long* tr = nullptr, int slot = 0,
+                                          bool pick = false) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint4* wl = w16 + (size_t)mt * (PW2 * 8) * 2 * 64 + lane;
+  int ntc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) ntc[nt] = (nt0 + nt < nta) ? nt0 + nt : nta - 1;
+  uint4 ah[PW2], al[PW2];
+  float4 b0[PW2][NT], b1[PW2][NT];
+#pragma unroll
+  for (int s = 0; s < PW2; ++s) {
+    const int g = s * 8 + wave;
+    ah[s] = wl[(size_t)(g * 2) * 64];
+    al[s] = wl[(size_t)(g * 2 + 1) * 64];
+    const int kbA = wave + 16 * s, kbB = kbA + 8;
+    const float4* sp = reinterpret_cast<const float4*>(s < PS2 ? seg0 : seg1);
+    const int nk = s < PS2 ? kb0 : kb1, base = s < PS2 ? 0 : PS2 * 16;
+    const int ka = kbA - base, kb = (kbB - base < nk) ? kbB - base : ka;  // (padded k-block: its weights are zero)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      b0[s][nt] = sp[((size_t)ka * nta + ntc[nt]) * 64 + lane];
+      b1[s][nt] = sp[((size_t)kb * nta + ntc[nt]) * 64 + lane];
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  tf_mark(tr, slot, 1, pick);
+  f32x4 accX[NT], aclX[NT], accH[NT], aclH[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    accX[nt] = {0.f, 0.f, 0.f, 0.f}; aclX[nt] = {0.f, 0.f, 0.f, 0.f};
+    accH[nt] = {0.f, 0.f, 0.f, 0.f}; aclH[nt] = {0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int s = 0; s < PW2; ++s) {
+    const bool hpart = NPART == 2 && s >= PS2;
+    const wh16x8 wh = __builtin_bit_cast(wh16x8, ah[s]), wlo = __builtin_bit_cast(wh16x8, al[s]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const fm_f8 v = {b0[s][nt].x, b0[s][nt].y, b0[s][nt].z, b0[s][nt].w, b1[s][nt].x, b1[s][nt].y, b1[s][nt].z, b1[s][nt].w};
+      const wh16x8 xh = __builtin_convertvector(v, wh16x8);
+      const fm_f8 d = (v - __builtin_convertvector(xh, fm_f8)) * WQ16_LO_SCALE;
+      const wh16x8 xl = __builtin_convertvector(d, wh16x8);
+      if (hpart) {
+        accH[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, xh, accH[nt], 0, 0, 0);
+        aclH[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, aclH[nt], 0, 0, 0);
+        accH[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, accH[nt], 0, 0, 0);
+      } else {
+        accX[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, xh, accX[nt], 0, 0, 0);
+        aclX[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, aclX[nt], 0, 0, 0);
+        accX[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, accX[nt], 0, 0, 0);
+      }
+    }
+  }
+  float4* red4 = reinterpret_cast<float4*>(red);  // [8][NT][NPART][64]
+  tf_mark(tr, slot, 2, pick);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const f32x4 x = (accX[nt] + aclX[nt] * WQ16_LO_UNSCALE) * unscale;
+    red4[((wave * NT + nt) * NPART + 0) * 64 + lane] = make_float4(x[0], x[1], x[2], x[3]);
+    if (NPART == 2) {
+      const f32x4 h = (accH[nt] + aclH[nt] * WQ16_LO_UNSCALE) * unscale;
+      red4[((wave * NT + nt) * NPART + 1) * 64 + lane] = make_float4(h[0], h[1], h[2], h[3]);
+    }
+  }
+  __syncthreads();
+  tf_mark(tr, slot, 3, pick);
+  if (wave >= NT) return false;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) { sx[g] = 0.f; sh[g] = 0.f; }
+#pragma unroll
+  for (int w8 = 0; w8 < 8; ++w8) {
+    const float4 v = red4[((w8 * NT + wave) * NPART + 0) * 64 + lane];
+    sx[0] += v.x; sx[1] += v.y; sx[2] += v.z; sx[3] += v.w;
+    if (NPART == 2) {
+      const float4 h = red4[((w8 * NT + wave) * NPART + 1) * 64 + lane];
+      sh[0] += h.x; sh[1] += h.y; sh[2] += h.z; sh[3] += h.w;
+    }
+  }
+  return true;
+}
+// non-finite sums = an operand left fp16's range (see above): the launch flags the call for the exact loop
+__device__ __forceinline__ void fm_range_check(const float (&sx)[4], int* lost) {
+  const float m = fmaxf(fmaxf(__builtin_fabsf(sx[0]), __builtin_fabsf(sx[1])), fmaxf(__builtin_fabsf(sx[2]), __builtin_fabsf(sx[3])));
+  if (!(m <= 3.0e38f) || !(sx[0] == sx[0]) || !(sx[1] == sx[1]) || !(sx[2] == sx[2]) || !(sx[3] == sx[3])) atomicExch(lost, 1);
 }
 
 template <int NT, int NPART> struct FmRed { static constexpr int floats = 8 * NT * NPART * 256; };

@@ -98,14 +98,24 @@ __global__ __launch_bounds__(512) void taco_gru_kernel(TfGruK a) {
 // ------------------------------------------------------------------------------------------------ LSTM hidden halves
 // hh job: hpre = W_hh . h (LSTM tile order: the 16 rows of tile mt are the 4 gates of units 4 mt .. 4 mt + 3), one
 // CM4 quad per (unit, column).  Rides as extra workgroups behind the jobs of a latency-bound launch.
-struct TfHhK { const float* w; const float* h; float4* hpre; int n_tiles, tile0; };  // row tiles [tile0, tile0 + n_tiles)
-template <int NT>
-__device__ __forceinline__ void fm_hh_job(const TfHhK& a, const int mt_local, const int nt0, const int nta, const int done, float* red) {
+// w16: the split fp16 image for the F16 form (fm_gemm16).  (No pointer behind `unscale`: a {float, pointer} tail of this struct inside a
+// kernel argument is loaded as one vector, parked in a private array and promoted to LDS -- and a kernel with a promoted array reads
+// its workgroup size from the dispatch packet in host memory at the start of EVERY workgroup: 80 ns per workgroup, 20 us per launch.)
+struct TfHhK { const float* w; const float* h; float4* hpre; int n_tiles, tile0; const uint4* w16 = nullptr; float unscale = 1.f; };  // row tiles [tile0, tile0 + n_tiles)
+// (F16 is a compile-time choice: with both products behind a run-time test the register allocator gave up the all-loads-in-flight
+//  schedule of either -- taco_rin / taco_mel went from 8 / 7 to 19 / 18 us)
+template <int NT, bool F16 = false>
+__device__ __forceinline__ void fm_hh_job(const TfHhK& a, const int mt_local, const int nt0, const int nta, const int done, float* red, int* lost = nullptr) {
   const int mt = a.tile0 + mt_local;
   float sx[4], sh[4];
-  if (!fm_gemm<NT, 8, 8, 4, 1>(a.w, mt, a.h, a.h, nta, nt0, red, sx, sh)) return;
+  if constexpr (F16) {
+    if (!fm_gemm16<NT, 4, 4, 1>(a.w16, mt, a.h, 64, a.h, 0, nta, nt0, red, a.unscale, sx, sh)) return;
+  } else {
+    if (!fm_gemm<NT, 8, 8, 4, 1>(a.w, mt, a.h, a.h, nta, nt0, red, sx, sh)) return;
+  }
   const int lane = threadIdx.x & 63, nt = nt0 + (threadIdx.x >> 6);
   if (nt >= nta || done) return;
+  if (F16) fm_range_check(sx, lost);
   a.hpre[((size_t)mt * nta + nt) * 64 + lane] = make_float4(sx[0], sx[1], sx[2], sx[3]);
 }
 // Two row tiles per workgroup against ONE set of activation fragments (taco_front_kernel: every workgroup of that launch has a compute
@@ -187,8 +197,11 @@ struct TfRinK {
   TfHhK hh;  // job 3: second half of the row tiles of W_hh1 . h1 (the first half rode in the previous mel launch)
   const float* ctx; const float* ah; float* x; float4* xpre; float4* hpre;
   int nta, n_rin; const int* flags; unsigned long long* trace;
+  // split fp16 images of the three chain jobs (fm_gemm16; K = P + D padded to 1280) -- null: the fp32 pipe
+  const uint4* rin16 = nullptr; const uint4* pre16 = nullptr; const uint4* stopc16 = nullptr;
+  float us_rin = 1.f, us_pre = 1.f, us_stopc = 1.f; int* lost = nullptr;
 };
-template <int NT>
+template <int NT, bool F16 = false>
 __global__ __launch_bounds__(512) void taco_rin_kernel(TfRinK a) {
   __shared__ __attribute__((aligned(16))) float red[FmRed<NT, 2>::floats];
   const int nt0 = blockIdx.y * NT;
@@ -199,9 +212,14 @@ __global__ __launch_bounds__(512) void taco_rin_kernel(TfRinK a) {
     const int mt = blockIdx.x;
     const bool pick = blockIdx.x == 3 && blockIdx.y == 0;
     tf_mark(a.trace, TS_RIN, 0, pick);
-    if (!fm_gemm<NT, 9, 8, 4, 1>(a.w_rin, mt, a.ctx, a.ah, a.nta, nt0, red, sx, sh, a.trace, TS_RIN, pick)) return;
+    if constexpr (F16) {
+      if (!fm_gemm16<NT, 5, 4, 1>(a.rin16, mt, a.ctx, 64, a.ah, 8, a.nta, nt0, red, a.us_rin, sx, sh, a.trace, TS_RIN, pick)) return;
+    } else {
+      if (!fm_gemm<NT, 9, 8, 4, 1>(a.w_rin, mt, a.ctx, a.ah, a.nta, nt0, red, sx, sh, a.trace, TS_RIN, pick)) return;
+    }
     const int nt = nt0 + wv;
     if (nt >= a.nta || done) return;
+    if (F16) fm_range_check(sx, a.lost);
     const float4 bq = *reinterpret_cast<const float4*>(a.b_rin + mt * 16 + du * 4);
     reinterpret_cast<float4*>(a.x)[((size_t)mt * a.nta + nt) * 64 + lane] =
         make_float4(sx[0] + bq.x, sx[1] + bq.y, sx[2] + bq.z, sx[3] + bq.w);
@@ -209,21 +227,36 @@ __global__ __launch_bounds__(512) void taco_rin_kernel(TfRinK a) {
     return;
   }
   const int mt = blockIdx.x - a.n_rin;
-  if (mt > 32) { fm_hh_job<NT>(a.hh, mt - 33, nt0, a.nta, done, red); return; }
+  if (mt > 32) {
+    fm_hh_job<NT, F16>(a.hh, mt - 33, nt0, a.nta, done, red, a.lost);
+    if (a.trace && threadIdx.x == 0) atomicMax(a.trace + TS_RIN * 16 + 13, (unsigned long long)wall_clock64());  // last rider
+    return;
+  }
   if (mt == 32) {  // stop token, context half
-    if (!fm_gemm<NT, 9, 8, 4, 1>(a.w_stopc, 0, a.ctx, a.ah, a.nta, nt0, red, sx, sh)) return;
+    if constexpr (F16) {
+      if (!fm_gemm16<NT, 5, 4, 1>(a.stopc16, 0, a.ctx, 64, a.ah, 8, a.nta, nt0, red, a.us_stopc, sx, sh)) return;
+    } else {
+      if (!fm_gemm<NT, 9, 8, 4, 1>(a.w_stopc, 0, a.ctx, a.ah, a.nta, nt0, red, sx, sh)) return;
+    }
     const int nt = nt0 + wv;
     if (nt >= a.nta || done || du != 0) return;
     a.stop_part[nt * 16 + (lane & 15)] = sx[0];
+    if (a.trace && lane == 0) atomicMax(a.trace + TS_RIN * 16 + 11, (unsigned long long)wall_clock64());  // stop tile
     return;
   }
-  if (!fm_gemm<NT, 9, 8, 3, 2>(a.w_pre, mt, a.ctx, a.ah, a.nta, nt0, red, sx, sh)) return;
+  if constexpr (F16) {
+    if (!fm_gemm16<NT, 5, 4, 2>(a.pre16, mt, a.ctx, 64, a.ah, 8, a.nta, nt0, red, a.us_pre, sx, sh)) return;
+  } else {
+    if (!fm_gemm<NT, 9, 8, 3, 2>(a.w_pre, mt, a.ctx, a.ah, a.nta, nt0, red, sx, sh)) return;
+  }
   const int nt = nt0 + wv;
   if (nt >= a.nta || done) return;
+  if (F16) { fm_range_check(sx, a.lost); fm_range_check(sh, a.lost); }
   const float4 bi = a.bih4[mt * 4 + du], bh = a.bhh4[mt * 4 + du];
   const size_t cm = ((size_t)mt * a.nta + nt) * 64 + lane;
   a.xpre[cm] = make_float4(sx[0] + bi.x, sx[1] + bi.y, sx[2] + bi.z, 0.f);
   a.hpre[cm] = make_float4(sh[0] + bh.x, sh[1] + bh.y, sh[2] + bh.z, 0.f);
+  if (a.trace && lane == 0) atomicMax(a.trace + TS_RIN * 16 + 12, (unsigned long long)wall_clock64());  // last GRU-pre tile
 }
 
 // ------------------------------------------------------------------------------------------------ residual LSTM
@@ -235,8 +268,9 @@ struct TfLstmK {
   const float4* hpre;                // W_hh . h_prev (CM4)
   const float* x; float* h_out; float* c; float* x_out;  // FM, FM, CM1 (in place), FM
   int nta; const int* flags; unsigned long long* trace; int trace_slot;
+  const uint4* w16 = nullptr; float unscale = 1.f; int* lost = nullptr;  // F16: W_ih as a split fp16 image (fm_gemm16)
 };
-template <int NT>
+template <int NT, bool F16 = false>
 __global__ __launch_bounds__(512) void taco_lstm_kernel(TfLstmK a) {
   __shared__ __attribute__((aligned(16))) float red[FmRed<NT, 1>::floats];
   const int mt = blockIdx.x, nt0 = blockIdx.y * NT;
@@ -252,8 +286,11 @@ __global__ __launch_bounds__(512) void taco_lstm_kernel(TfLstmK a) {
   float sx[4], sh[4];
   const bool pick = blockIdx.x == 100 && blockIdx.y == 0;
   tf_mark(a.trace, a.trace_slot, 0, pick);
-  if (!fm_gemm<NT, 8, 8, 4, 1>(a.w, mt, a.x, a.x, a.nta, nt0, red, sx, sh, a.trace, a.trace_slot, pick)) return;
+  if (F16) {
+    if (!fm_gemm16<NT, 4, 4, 1>(a.w16, mt, a.x, 64, a.x, 0, a.nta, nt0, red, a.unscale, sx, sh, a.trace, a.trace_slot, pick)) return;
+  } else if (!fm_gemm<NT, 8, 8, 4, 1>(a.w, mt, a.x, a.x, a.nta, nt0, red, sx, sh, a.trace, a.trace_slot, pick)) return;
   if (nt0 + wv >= a.nta || done) return;
+  if (F16) fm_range_check(sx, a.lost);
   // torch LSTMCell, gate order (i, f, g, o)
   const float gi = tf_sigmoid((sx[0] + hq.x) + bq.x);
   const float gf = tf_sigmoid((sx[1] + hq.y) + bq.y);
@@ -286,8 +323,11 @@ struct TfMelK {
   TfHhK hh;  // job 3: hidden half of the NEXT iteration's first LSTM (h1 of this iteration is final)
   TfHhK hh2; // job 4 (fused front only): the first row tiles of the next iteration's W_hh2 . h2 (h2 is final as well)
   int nta, B, n_mel, M, r, max_steps, it_off; float min_stop_token; int* flags; DropK drop; unsigned long long* trace;
+  // split fp16 images of the three chain jobs (fm_gemm16, K = H) -- null: the fp32 pipe
+  const uint4* mel16 = nullptr; const uint4* fc116 = nullptr; const uint4* stop16 = nullptr;
+  float us_mel = 1.f, us_fc1 = 1.f, us_stop = 1.f;
 };
-template <int NT>
+template <int NT, bool F16 = false>
 __global__ __launch_bounds__(512) void taco_mel_kernel(TfMelK a) {
   __shared__ __attribute__((aligned(16))) float red[FmRed<NT, 1>::floats];
   const int nt0 = blockIdx.y * NT;
@@ -298,9 +338,14 @@ __global__ __launch_bounds__(512) void taco_mel_kernel(TfMelK a) {
   if (bx < a.n_mel) {
     const bool pick = bx == 3 && blockIdx.y == 0;
     tf_mark(a.trace, TS_MEL, 0, pick);
-    if (!fm_gemm<NT, 8, 8, 4, 1>(a.w_mel, bx, a.x2, a.x2, a.nta, nt0, red, sx, sh, a.trace, TS_MEL, pick)) return;
+    if constexpr (F16) {
+      if (!fm_gemm16<NT, 4, 4, 1>(a.mel16, bx, a.x2, 64, a.x2, 0, a.nta, nt0, red, a.us_mel, sx, sh, a.trace, TS_MEL, pick)) return;
+    } else {
+      if (!fm_gemm<NT, 8, 8, 4, 1>(a.w_mel, bx, a.x2, a.x2, a.nta, nt0, red, sx, sh, a.trace, TS_MEL, pick)) return;
+    }
     const int nt = nt0 + wv, n = nt * 16 + i, t0 = it * a.r;
     if (nt >= a.nta || n >= a.B || done) return;
+    if (F16) fm_range_check(sx, a.flags + TF_LOST);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int row = bx * 16 + du * 4 + q;
@@ -316,7 +361,11 @@ __global__ __launch_bounds__(512) void taco_mel_kernel(TfMelK a) {
     const int mt = bx - a.n_mel;
     const bool pick = mt == 3 && blockIdx.y == 0;
     tf_mark(a.trace, TS_MEL_FC1, 0, pick);
-    if (!fm_gemm<NT, 8, 8, 4, 1>(a.w_fc1, mt, a.x2, a.x2, a.nta, nt0, red, sx, sh, a.trace, TS_MEL_FC1, pick)) return;
+    if constexpr (F16) {
+      if (!fm_gemm16<NT, 4, 4, 1>(a.fc116, mt, a.x2, 64, a.x2, 0, a.nta, nt0, red, a.us_fc1, sx, sh, a.trace, TS_MEL_FC1, pick)) return;
+    } else {
+      if (!fm_gemm<NT, 8, 8, 4, 1>(a.w_fc1, mt, a.x2, a.x2, a.nta, nt0, red, sx, sh, a.trace, TS_MEL_FC1, pick)) return;
+    }
     const int nt = nt0 + wv, n = nt * 16 + i, row0 = mt * 16 + du * 4;
     if (nt >= a.nta || done) return;
     const float4 bq = *reinterpret_cast<const float4*>(a.b_fc1 + row0);
@@ -328,8 +377,9 @@ __global__ __launch_bounds__(512) void taco_mel_kernel(TfMelK a) {
   }
   if (bx > a.n_mel + 16) {
     const int j = bx - (a.n_mel + 17);
-    if (j < a.hh.n_tiles) fm_hh_job<NT>(a.hh, j, nt0, a.nta, done, red);
-    else fm_hh_job<NT>(a.hh2, j - a.hh.n_tiles, nt0, a.nta, done, red);
+    if (j < a.hh.n_tiles) fm_hh_job<NT, F16>(a.hh, j, nt0, a.nta, done, red, a.flags + TF_LOST);
+    else fm_hh_job<NT, F16>(a.hh2, j - a.hh.n_tiles, nt0, a.nta, done, red, a.flags + TF_LOST);
+    if (a.trace && threadIdx.x == 0) atomicMax(a.trace + TS_MEL * 16 + 13, (unsigned long long)wall_clock64());  // last rider
     return;
   }
   // stop tile: one live row (row 0) over K = x2; the context half of the logit comes from the rnn_input launch
@@ -337,7 +387,11 @@ __global__ __launch_bounds__(512) void taco_mel_kernel(TfMelK a) {
   tf_mark(a.trace, TS_MEL_STOP, 0, pickS);
   const int ntS = (nt0 + (wv < NT ? wv : 0) < a.nta) ? nt0 + (wv < NT ? wv : 0) : a.nta - 1;
   const float spart = a.stop_part[ntS * 16 + i];
-  if (!fm_gemm<NT, 8, 8, 4, 1>(a.w_stop, 0, a.x2, a.x2, a.nta, nt0, red, sx, sh, a.trace, TS_MEL_STOP, pickS)) return;
+  if constexpr (F16) {
+    if (!fm_gemm16<NT, 4, 4, 1>(a.stop16, 0, a.x2, 64, a.x2, 0, a.nta, nt0, red, a.us_stop, sx, sh, a.trace, TS_MEL_STOP, pickS)) return;
+  } else {
+    if (!fm_gemm<NT, 8, 8, 4, 1>(a.w_stop, 0, a.x2, a.x2, a.nta, nt0, red, sx, sh, a.trace, TS_MEL_STOP, pickS)) return;
+  }
   const int nt = nt0 + wv, n = nt * 16 + i;
   if (nt >= a.nta || done) return;
   int below = 0;

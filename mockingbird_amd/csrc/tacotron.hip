@@ -749,7 +749,7 @@ __device__ __forceinline__ void front_gru_job(const TfGruK& a, const TfFrontX& x
   *hpt = hn;                                                               // rnn_input / next iteration: after the launch
   tf_mark_end(a.trace, TS_GRU, 4, pick);
 }
-template <int TJ, int NT>
+template <int TJ, int NT, bool F16>
 __global__ __launch_bounds__(512) void taco_front_kernel(TfFcK fk, TfGruK gk, LsaK a, TfHhK hh, TfFrontX x, int n_lsa, int B, int gy, int nta) {
   __shared__ __attribute__((aligned(16))) float s_big[TJ == 32 ? 32 * 4 * 256 : 2 * FmRed<NT, 1>::floats];
   const int id = blockIdx.x;
@@ -763,7 +763,7 @@ __global__ __launch_bounds__(512) void taco_front_kernel(TfFcK fk, TfGruK gk, Ls
   }
   const int j = l - n_lsa;  // (gy == 1: the fused launch serves at most NT column tiles)
   if (x.hh_pairs) fm_hh_pair_job<NT>(hh, j, nta, a.skip_flag ? *a.skip_flag : 0, s_big);
-  else fm_hh_job<NT>(hh, j, 0, nta, a.skip_flag ? *a.skip_flag : 0, s_big);
+  else fm_hh_job<NT, F16>(hh, j, 0, nta, a.skip_flag ? *a.skip_flag : 0, s_big, x.lost);
   if (a.trace && threadIdx.x == 0) {
     atomicMax(a.trace + TS_FC2 * 16 + 13, (unsigned long long)wall_clock64());  // last hh2 tile
     if (j == 0) a.trace[TS_FC2 * 16 + 12] = (unsigned long long)wall_clock64();  // first hh2 tile done
@@ -1176,6 +1176,10 @@ struct mb_taco {
   // fast decoder loop (taco_fast.h), packed when the checkpoint has the production dims
   bool fast = false;
   int n_cus = -1; bool front_failed = false; int last_front = 0;  // fused front of the fast loop (taco_front_kernel)
+  // split fp16 images (pack_rowtile16) of the fast loop's big tiles, for the 5-launch form's products on the fp16 matrix pipe
+  struct Img16 { DevBuf w; float unscale = 1.f; };
+  Img16 i_l1x, i_l2x, i_l1hh, i_l2hh, i_rin, i_pre, i_stopc, i_mel, i_fc1, i_stop;
+  bool last_f16 = false;
   DevBuf f_gru_w, f_pre_w, f_bih4, f_bhh4, f_l1_b4, f_l2_b4, f_fc1_w, f_stop_w, f_stopc_w, f_l1_hh, f_l2_hh;
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // loop timing (mb_taco_last_loop_ms)
   int last_iters = 0; bool timed = false;
@@ -1204,6 +1208,37 @@ struct mb_taco {
 // this is weight preprocessing like BatchNorm folding, not part of the per-request path).
 // global_style_token.py:31-76 (6 x [Conv2d 3x3 s2 p1, BN, ReLU], GRU) on the all-zero input the
 // inference branch feeds (tacotron.py:250); :79-145 (STL + multi-head attention).
+// Split fp16 image of row tiles for fm_gemm16 (fm_gemm.h): rows as pack_rowtile takes them (tile mt = rows [mt * 4 RL, +4 RL), unit-major),
+// K padded to a multiple of 256 with zero columns, values scaled by 2^sexp (chosen so that max |w| 2^s ~ 2^14: both halves fp16 normals).
+// out: [tile][g = 8 s + w][hi | lo][64 lanes][8 halves]; lane (i, kq): features 4 kq .. + 3 of k-blocks w + 16 s and w + 16 s + 8.
+static int pack_rowtile16(const float* rows, int n_live_rows, int K, int RL, mb_taco::Img16* img) {
+  const int per_tile = 4 * RL, n_mt = (n_live_rows + per_tile - 1) / per_tile;
+  const int Kp = (K + 255) / 256 * 256, PW2 = Kp / 256;
+  float wmax = 0.f;
+  for (size_t i = 0; i < (size_t)n_live_rows * K; ++i) wmax = std::max(wmax, std::fabs(rows[i]));
+  int e2 = 0, sexp = 0;
+  if (wmax > 0.f && std::isfinite(wmax)) { (void)std::frexp(wmax, &e2); sexp = std::max(-24, std::min(40, 14 - e2)); }
+  const float scale = std::ldexp(1.f, sexp);
+  std::vector<unsigned short> out((size_t)n_mt * PW2 * 8 * 2 * 64 * 8, 0);
+  for (int mt = 0; mt < n_mt; ++mt)
+    for (int s = 0; s < PW2; ++s)
+      for (int w = 0; w < 8; ++w)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int i = lane & 15, kq = lane >> 4, u = i >> 2, tau = i & 3;
+          const int row = mt * per_tile + u * RL + tau;
+          const size_t base = ((((size_t)mt * PW2 * 8 + (s * 8 + w)) * 2) * 64 + lane) * 8;
+          for (int e = 0; e < 8; ++e) {
+            const int kb = (e < 4) ? w + 16 * s : w + 16 * s + 8, k = kb * 16 + kq * 4 + (e & 3);
+            const float v = (tau < RL && row < n_live_rows && k < K) ? rows[(size_t)row * K + k] * scale : 0.f;
+            const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+            memcpy(&out[base + e], &hi, 2);
+            memcpy(&out[base + (size_t)64 * 8 + e], &lo, 2);
+          }
+        }
+  img->unscale = std::ldexp(1.f, -sexp);
+  return img->w.upload(reinterpret_cast<const float*>(out.data()), out.size() / 2);
+}
+
 static int fold_gst(mb_taco* t, const float* const* hw, int* pix) {
   const mb_taco_config& c = t->cfg;
   int ix = *pix;
@@ -1444,6 +1479,8 @@ extern "C" int mb_taco_create(const mb_taco_config* cfg, const float* const* hw,
     // ... and its context / hidden parts over K = [context | attn_hidden], two accumulators
     cell_rows(a_wih, P, P + 2 * D, a_whh, D, D, 3, &rows);
     pack_rowtile(rows.data(), 3 * D, P + D, 3, &packed); RC(t->f_pre_w.upload(packed.data(), packed.size()));
+    RC(pack_rowtile16(rows.data(), 3 * D, P + D, 3, &t->i_pre));
+    RC(pack_rowtile16(hw[14], H, P + D, 4, &t->i_rin));  // rnn_input.weight [H][P + D]
     std::vector<float> q4((size_t)D * 4), h4((size_t)D * 4);
     for (int j = 0; j < D; ++j)
       for (int g = 0; g < 4; ++g) {
@@ -1471,18 +1508,30 @@ extern "C" int mb_taco_create(const mb_taco_config* cfg, const float* const* hw,
         for (int k = 0; k < H; ++k) wf[(size_t)o * H + k] = (float)acc[k];
       }
       pack_rowtile(wf.data(), 2 * D, H, 4, &packed); RC(t->f_fc1_w.upload(packed.data(), packed.size()));
+      RC(pack_rowtile16(wf.data(), 2 * D, H, 4, &t->i_fc1));
     }
     // stop_proj as two one-live-row tiles: x half (K = H) for the mel launch, context half (K = [P | 0 x D]) for rnn_input's
     pack_rowtile(stop_w, 1, H, 4, &packed); RC(t->f_stop_w.upload(packed.data(), packed.size()));
+    RC(pack_rowtile16(stop_w, 1, H, 4, &t->i_stop));
+    {  // mel_proj's live rows, frame-major (as packed for mel_w above)
+      std::vector<float> sel((size_t)cfg->r * M * H);
+      for (int j = 0; j < cfg->r; ++j)
+        for (int m = 0; m < M; ++m) memcpy(&sel[((size_t)j * M + m) * H], mel_w + ((size_t)m * cfg->max_r + j) * H, sizeof(float) * H);
+      RC(pack_rowtile16(sel.data(), cfg->r * M, H, 4, &t->i_mel));
+    }
     {
       std::vector<float> sc((size_t)P + D, 0.f);
       memcpy(sc.data(), stop_w + H, sizeof(float) * P);
       pack_rowtile(sc.data(), 1, P + D, 4, &packed); RC(t->f_stopc_w.upload(packed.data(), packed.size()));
+      RC(pack_rowtile16(sc.data(), 1, P + D, 4, &t->i_stopc));
     }
     for (int l = 0; l < 2; ++l) {  // hidden halves W_hh in LSTM tile order (K = H)
       cell_rows(hw[16 + 4 * l + 1], H, H, hw[16 + 4 * l + 1], 0, H, 4, &rows);
       pack_rowtile(rows.data(), 4 * H, H, 4, &packed);
       RC((l ? t->f_l2_hh : t->f_l1_hh).upload(packed.data(), packed.size()));
+      RC(pack_rowtile16(rows.data(), 4 * H, H, 4, l ? &t->i_l2hh : &t->i_l1hh));
+      cell_rows(hw[16 + 4 * l], H, H, hw[16 + 4 * l + 1], 0, H, 4, &rows);  // input halves W_ih (LSTM tile order)
+      RC(pack_rowtile16(rows.data(), 4 * H, H, 4, l ? &t->i_l2x : &t->i_l1x));
     }
     if (!rc && (hipHostMalloc((void**)&t->h_flags, sizeof(int) * 16) != hipSuccess ||
                 hipStreamCreateWithFlags(&t->loop_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -1537,6 +1586,7 @@ extern "C" void mb_taco_destroy(mb_taco* t) {
   if (t->loop_stream) (void)hipStreamDestroy(t->loop_stream);
   t->post.release(); t->post_proj.release(); t->enc.release();
   t->enc_fc1.release(); t->enc_fc2.release(); t->enc_proj.release();
+  for (mb_taco::Img16* im : {&t->i_l1x, &t->i_l2x, &t->i_l1hh, &t->i_l2hh, &t->i_rin, &t->i_pre, &t->i_stopc, &t->i_mel, &t->i_fc1, &t->i_stop}) im->w.release();
   delete t;
 }
 
@@ -1661,15 +1711,30 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
   // fused front: the attention workgroups hold 128 KB of LDS each, so every workgroup of that launch has a compute unit to itself and
   // the W_hh2 . h2 tiles behind them come in rounds of (256 - 48 - B psplit): the first hh2_mel row tiles ride in the previous
   // iteration's mel launch instead (h2 is final there), the rest stay (sweep: profiles/r05_taco_front_ab.json)
+  // 5-launch form, more than 16 utterances: the K >= 1024 tile products (LSTM input halves, rnn_input, mel / fc1' / stop rows, the
+  // hidden-half riders) on the fp16 matrix pipe from split images (fm_gemm16: fp32-grade, not the 7-launch loop's bits; a value beyond
+  // fp16's range raises flags[TF_LOST] -> the call reruns on the exact loop).  With one column tile the fp32 products are half as
+  // many and the operand conversions cost what is saved (31.6 against 32.1 us at batch 16, 30.8 against 31.8 at batch 1).
+  const int f16_sw = diag_int("taco_f16", -1);
+  const bool f16 = front && t->i_l1x.w.p && (f16_sw < 0 ? nta >= 2 : f16_sw != 0);
   const int front_free = t->n_cus - (2 * D / 16 + D / 4 + B * psplit);  // compute units the hh2 tiles of the fused launch start on
-  const int hh2_auto = std::min(std::max(H / 4 - 2 * front_free, 0), 96);  // (96: the mel launch stays within one round of 256 workgroups)
+  // (96: the mel launch stays within one round of 256 workgroups; the fp16-pipe riders are short enough for the front launch to keep all)
+  const int hh2_auto = f16 ? 0 : std::min(std::max(H / 4 - 2 * front_free, 0), 96);
   const int hh2_mel = front ? std::min(std::max(diag_int("taco_hh2_mel", hh2_auto), 0), H / 4) : 0;
+  auto img16 = [&](TfHhK& h, const mb_taco::Img16& im) {
+    if (f16) { h.w16 = reinterpret_cast<const uint4*>(im.w.p); h.unscale = im.unscale; }
+  };
   int hh1_split = H / 8;  // row tiles of W_hh1 . h1 taken by the mel launch (the rest: next rnn_input launch)
   // (an hh1-split sweep, round 2: flat between 128 and 224 rows -- the switch is gone, the value stays)
   auto iteration = [&](int pp, int it_off) -> int {
     // (the LSTM state needs no ping-pong: h is read only by the hh jobs, which have finished before the next LSTM launch)
     const dim3 blk(512);
     const int gy = nta >= 2 ? cdiv(nta, 2) : nta;
+#define TF_LAUNCH16(KERNEL, GX, ARG)                                                         \
+    do {                                                                                     \
+      if (nta >= 2) hipLaunchKernelGGL((KERNEL<2, true>), dim3(GX, gy), blk, 0, s, ARG);     \
+      else hipLaunchKernelGGL((KERNEL<1, true>), dim3(GX, gy), blk, 0, s, ARG);              \
+    } while (0)
 #define TF_LAUNCH(KERNEL, GX, ARG)                                                     \
     do {                                                                               \
       if (nta >= 2) hipLaunchKernelGGL(KERNEL<2>, dim3(GX, gy), blk, 0, s, ARG);       \
@@ -1699,19 +1764,26 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
     // ... with the hidden half of THIS iteration's second LSTM (W_hh2 . h2 of the previous iteration) on the idle CUs
     TfHhK hh2;
     hh2.w = t->f_l2_hh.p; hh2.h = L.f_h2; hh2.hpre = reinterpret_cast<float4*>(L.f_hp2); hh2.n_tiles = H / 4; hh2.tile0 = 0;
+    img16(hh2, t->i_l2hh);
     const int n_lsa = B * psplit;
     if (front) {  // 1..3 as one launch (taco_front_kernel): fc2 tiles | GRU tiles | attention workgroups | hh2 tiles
       TfFrontX fx;
       fx.p2g = L.f_p2g; fx.ahg = L.f_ahg; fx.lost = flags + TF_LOST; fx.n_fc2 = 2 * D / 16; fx.n_gru = D / 4; fx.watch = diag_int("taco_gru_watch", 1);
-      fx.hh_pairs = diag_int("taco_hh_pairs", 1);
+      fx.hh_pairs = f16 ? 0 : diag_int("taco_hh_pairs", 1);  // (fp16-pipe riders are short enough to come one tile per workgroup)
       lk.dma_early = diag_int("taco_dma_early", 1);
       lk.q_gran = L.f_ahg; lk.lost = flags + TF_LOST; lk.e_gran = L.f_eg;
       hh2.tile0 = hh2_mel; hh2.n_tiles = H / 4 - hh2_mel;
       const dim3 g1(fx.n_fc2 + fx.n_gru + n_lsa + (fx.hh_pairs ? cdiv(hh2.n_tiles, 2) : hh2.n_tiles));
-      if (T <= 128 && nta >= 2) hipLaunchKernelGGL((taco_front_kernel<32, 2>), g1, blk, 0, s, fk, gk, lk, hh2, fx, n_lsa, B, gy, nta);
-      else if (T <= 128) hipLaunchKernelGGL((taco_front_kernel<32, 1>), g1, blk, 0, s, fk, gk, lk, hh2, fx, n_lsa, B, gy, nta);
-      else if (nta >= 2) hipLaunchKernelGGL((taco_front_kernel<48, 2>), g1, blk, 0, s, fk, gk, lk, hh2, fx, n_lsa, B, gy, nta);
-      else hipLaunchKernelGGL((taco_front_kernel<48, 1>), g1, blk, 0, s, fk, gk, lk, hh2, fx, n_lsa, B, gy, nta);
+#define TF_FRONT(TJ_, NT_)                                                                                                      \
+      do {                                                                                                                       \
+        if (f16) hipLaunchKernelGGL((taco_front_kernel<TJ_, NT_, true>), g1, blk, 0, s, fk, gk, lk, hh2, fx, n_lsa, B, gy, nta);  \
+        else hipLaunchKernelGGL((taco_front_kernel<TJ_, NT_, false>), g1, blk, 0, s, fk, gk, lk, hh2, fx, n_lsa, B, gy, nta);     \
+      } while (0)
+      if (T <= 128 && nta >= 2) TF_FRONT(32, 2);
+      else if (T <= 128) TF_FRONT(32, 1);
+      else if (nta >= 2) TF_FRONT(48, 2);
+      else TF_FRONT(48, 1);
+#undef TF_FRONT
     } else if (lsa_fast) {
       const dim3 g1(n_lsa + (H / 4) * gy);
       if (T <= 128 && nta >= 2) hipLaunchKernelGGL((lsa_hh_kernel<32, 2>), g1, blk, 0, s, lk, hh2, n_lsa, B, gy, nta);
@@ -1734,7 +1806,14 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
     // iteration's mel launch (both launches leave most CUs idle; one launch taking all 256 tiles slowed its chain jobs)
     rk.hh.w = t->f_l1_hh.p; rk.hh.h = L.f_h1; rk.hh.hpre = reinterpret_cast<float4*>(L.f_hp1);
     rk.hh.tile0 = hh1_split; rk.hh.n_tiles = H / 4 - hh1_split;
-    TF_LAUNCH(taco_rin_kernel, H / 16 + D / 4 + 1 + rk.hh.n_tiles, rk);
+    img16(rk.hh, t->i_l1hh);
+    if (f16) {
+      rk.rin16 = reinterpret_cast<const uint4*>(t->i_rin.w.p); rk.us_rin = t->i_rin.unscale;
+      rk.pre16 = reinterpret_cast<const uint4*>(t->i_pre.w.p); rk.us_pre = t->i_pre.unscale;
+      rk.stopc16 = reinterpret_cast<const uint4*>(t->i_stopc.w.p); rk.us_stopc = t->i_stopc.unscale; rk.lost = flags + TF_LOST;
+    }
+    if (f16) TF_LAUNCH16(taco_rin_kernel, H / 16 + D / 4 + 1 + rk.hh.n_tiles, rk);
+    else TF_LAUNCH(taco_rin_kernel, H / 16 + D / 4 + 1 + rk.hh.n_tiles, rk);
     // 5./6. residual LSTMs
     TfLstmK lk1;
     lk1.w = t->l1_wx.p; lk1.b4 = reinterpret_cast<const float4*>(t->f_l1_b4.p); lk1.x = L.f_x; lk1.h_out = L.f_h1;
@@ -1744,18 +1823,33 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
     lk2.w = t->l2_wx.p; lk2.b4 = reinterpret_cast<const float4*>(t->f_l2_b4.p); lk2.x = L.f_x1; lk2.h_out = L.f_h2;
     lk2.hpre = reinterpret_cast<const float4*>(L.f_hp2);
     lk2.c = L.f_c2; lk2.x_out = L.f_x2; lk2.trace_slot = TS_LSTM2;
-    TF_LAUNCH(taco_lstm_kernel, H / 4, lk1);
-    TF_LAUNCH(taco_lstm_kernel, H / 4, lk2);
+    if (f16) {
+      lk1.w16 = reinterpret_cast<const uint4*>(t->i_l1x.w.p); lk1.unscale = t->i_l1x.unscale; lk1.lost = flags + TF_LOST;
+      lk2.w16 = reinterpret_cast<const uint4*>(t->i_l2x.w.p); lk2.unscale = t->i_l2x.unscale; lk2.lost = flags + TF_LOST;
+      TF_LAUNCH16(taco_lstm_kernel, H / 4, lk1);
+      TF_LAUNCH16(taco_lstm_kernel, H / 4, lk2);
+    } else {
+      TF_LAUNCH(taco_lstm_kernel, H / 4, lk1);
+      TF_LAUNCH(taco_lstm_kernel, H / 4, lk2);
+    }
     // 7. mel frames, next prenet layer 1, stop token + stop rule
     TfMelK mk;
     mk.w_mel = t->mel_w.p; mk.w_fc1 = t->f_fc1_w.p; mk.b_fc1 = t->pre1_b.p; mk.w_stop = t->f_stop_w.p; mk.b_stop = t->stop_b.p;
     mk.x2 = L.f_x2; mk.stop_part = L.f_stop_part; mk.p1 = L.f_p1; mk.mel_out = d_mel; mk.stop_out = L.stop;
     mk.hh.w = t->f_l1_hh.p; mk.hh.h = L.f_h1; mk.hh.hpre = reinterpret_cast<float4*>(L.f_hp1); mk.hh.n_tiles = hh1_split; mk.hh.tile0 = 0;
+    img16(mk.hh, t->i_l1hh);
+    if (f16) {
+      mk.mel16 = reinterpret_cast<const uint4*>(t->i_mel.w.p); mk.us_mel = t->i_mel.unscale;
+      mk.fc116 = reinterpret_cast<const uint4*>(t->i_fc1.w.p); mk.us_fc1 = t->i_fc1.unscale;
+      mk.stop16 = reinterpret_cast<const uint4*>(t->i_stop.w.p); mk.us_stop = t->i_stop.unscale;
+    }
     mk.nta = nta; mk.B = B; mk.n_mel = r * M / 16; mk.M = M; mk.r = r; mk.max_steps = max_steps; mk.it_off = it_off;
     mk.min_stop_token = min_stop_token; mk.flags = flags; mk.drop = dk; mk.drop.layer = 0; mk.drop.it_add = 1; mk.trace = tr;
     mk.hh2 = hh2; mk.hh2.tile0 = 0; mk.hh2.n_tiles = hh2_mel;
-    TF_LAUNCH(taco_mel_kernel, r * M / 16 + 2 * D / 16 + 1 + hh1_split + hh2_mel, mk);
+    if (f16) TF_LAUNCH16(taco_mel_kernel, r * M / 16 + 2 * D / 16 + 1 + hh1_split + hh2_mel, mk);
+    else TF_LAUNCH(taco_mel_kernel, r * M / 16 + 2 * D / 16 + 1 + hh1_split + hh2_mel, mk);
 #undef TF_LAUNCH
+#undef TF_LAUNCH16
     MB_HIP(hipGetLastError());
     return MB_OK;
   };
@@ -1767,7 +1861,7 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
   int it_done = 0, rc = MB_OK;
   bool stopped = false;
   if (use_graph) {
-    mb_taco::GraphKey key = {d_memory, d_memory_proj, d_chars, d_dropout, d_mel, d_attn, d_workspace, B, T, max_steps, G, min_stop_token, front ? 1 + hh2_mel + 1024 * diag_int("taco_gru_watch", 1) + 2048 * diag_int("taco_dma_early", 1) + 4096 * diag_int("taco_hh_pairs", 1) : 0};
+    mb_taco::GraphKey key = {d_memory, d_memory_proj, d_chars, d_dropout, d_mel, d_attn, d_workspace, B, T, max_steps, G, min_stop_token, front ? 1 + hh2_mel + 1024 * diag_int("taco_gru_watch", 1) + 2048 * diag_int("taco_dma_early", 1) + 4096 * diag_int("taco_hh_pairs", 1) + (f16 ? 8192 : 0) : 0};
     if (!t->graph_exec || !(key == t->gkey)) {
       t->drop_graph();
       MB_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
@@ -1805,6 +1899,7 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
   MB_HIP(hipStreamSynchronize(s));
   *frames_out = t->h_flags[TF_NFRAMES];
   *lost_out = t->h_flags[TF_LOST] != 0;
+  t->last_f16 = f16;
   t->last_iters = cdiv(*frames_out, r); t->timed = true;
   if (tr) {
     std::vector<unsigned long long> host((size_t)16 * TS_SLOTS);
@@ -2033,6 +2128,11 @@ void enc_layout(const mb_taco* t, int B, int T, void* base, EncLayout* L) {
   L->bytes = ar.off + 256;
 }
 }  // namespace
+
+extern "C" int mb_taco_last_loop_f16(const mb_taco* t) {
+  if (!t || !t->timed) return -1;
+  return t->last_f16 ? 1 : 0;
+}
 
 extern "C" int mb_taco_last_loop_form(const mb_taco* t) {
   if (!t || !t->timed) return -1;

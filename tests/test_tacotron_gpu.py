@@ -78,22 +78,30 @@ def test_fast_loop_equals_general_loop(model, monkeypatch):
 @pytest.mark.parametrize("B,tmin,tmax", [(32, 60, 100), (7, 20, 30), (17, 130, 150), (1, 12, 12)])
 def test_fused_front_equals_one_launch_each(model, monkeypatch, B, tmin, tmax):
     """taco_front_kernel (prenet fc2, attention GRU and attention as roles of ONE launch with tagged-granule hand-offs: 5 launches
-    per iteration) against the same three kernels as launches of their own (MBHIP_DIAG=taco_front=0: 7): the same bits, graph
-    replays and eager tail, injected masks and the on-device Philox stream; a lost hand-off (MBHIP_DIAG=taco_front_lost=1: every
-    wait bails out) makes the call run again with 7 launches and return the same frames."""
+    per iteration) against the same three kernels as launches of their own (MBHIP_DIAG=taco_front=0: 7):
+      * MBHIP_DIAG=taco_f16=0 (every product on the fp32 pipe, as in the 7-launch loop) -- the same bits, graph replays and eager
+        tail, injected masks and the on-device Philox stream;
+      * the default (the K = 1024 tile products of the LSTM / rnn_input / mel launches and the hidden-half riders on the fp16 matrix
+        pipe from split images, fm_gemm16) -- the same frames to 1e-4; the oracle bar is checked by the other tests of this file,
+        which run on this form;
+      * a lost hand-off (MBHIP_DIAG=taco_front_lost=1: every wait bails out) makes the call run again with 7 launches."""
     dev, w = model
     chars, spk, _, _ = _batch(B, tmin, tmax, seed=40 + B)
     with torch.no_grad():
         mem, memp = ot.encoder_memory(w, ot.HP, chars, spk, 0)
     steps = 74  # 37 iterations: two graph replays of 16 + 5 eager
     masks = synth.decoder_dropout_masks(5, steps // 2, B)
-    monkeypatch.delenv("MBHIP_DIAG", raising=False)
+    monkeypatch.setenv("MBHIP_DIAG", "taco_f16=1")  # (the default for more than 16 utterances; forced here for the one-tile kernels too)
+    f = dev.decode(mem.cuda(), memp.cuda(), chars.cuda(), steps, 11.0, dropout=masks)
+    assert dev.last_loop_launches_per_iteration == 5 and dev.last_loop_f16_products
+    fr = dev.decode(mem.cuda(), memp.cuda(), chars.cuda(), steps, 11.0, seed=123)
+    monkeypatch.setenv("MBHIP_DIAG", "taco_f16=0")
     a = dev.decode(mem.cuda(), memp.cuda(), chars.cuda(), steps, 11.0, dropout=masks)
-    assert dev.last_loop_launches_per_iteration == 5
+    assert dev.last_loop_launches_per_iteration == 5 and not dev.last_loop_f16_products
     ar = dev.decode(mem.cuda(), memp.cuda(), chars.cuda(), steps, 11.0, seed=123)
     monkeypatch.setenv("MBHIP_DIAG", "taco_front=0")
     b = dev.decode(mem.cuda(), memp.cuda(), chars.cuda(), steps, 11.0, dropout=masks)
-    assert dev.last_loop_launches_per_iteration == 7
+    assert dev.last_loop_launches_per_iteration == 7 and not dev.last_loop_f16_products
     br = dev.decode(mem.cuda(), memp.cuda(), chars.cuda(), steps, 11.0, seed=123)
     monkeypatch.setenv("MBHIP_DIAG", "taco_front_lost=1")
     c = dev.decode(mem.cuda(), memp.cuda(), chars.cuda(), steps, 11.0, dropout=masks)
@@ -101,9 +109,34 @@ def test_fused_front_equals_one_launch_each(model, monkeypatch, B, tmin, tmax):
     monkeypatch.delenv("MBHIP_DIAG")
     d = dev.decode(mem.cuda(), memp.cuda(), chars.cuda(), steps, 11.0, dropout=masks)
     assert dev.last_loop_launches_per_iteration == 5  # the provoked loss is not remembered
-    for x, y in list(zip(a, b)) + list(zip(ar, br)) + list(zip(a, c)) + list(zip(a, d)):
+    assert dev.last_loop_f16_products == (B > 16)
+    for x, y in list(zip(a, b)) + list(zip(ar, br)) + list(zip(b, c)) + list(zip(f if B > 16 else a, d)):
         assert torch.equal(x, y)
+    for name, x, y in (("mel", f[0], b[0]), ("linear", f[1], b[1]), ("attn", f[2], b[2]), ("mel_rng", fr[0], br[0])):
+        e = hiputil.relerr(x, y)
+        assert x.shape == y.shape and e["nan"] == 0 and e["max_abs"] <= 1e-4, (name, e)
     assert float(a[0].abs().mean()) > 0.1
+
+
+def test_f16_products_out_of_range_rerun_on_the_exact_loop(cuda, lib, monkeypatch):
+    """The 5-launch loop multiplies on the fp16 pipe with split operands: an activation beyond fp16's range (here rnn_input's bias
+    = 1e5, i.e. |x| ~ 1e5 at the LSTMs' input) turns a tile's sums into inf / NaN, the launch raises flags[TF_LOST] and the call runs
+    again on the exact 7-launch loop -- the same bits as asking for that loop outright, and mb_taco_last_loop_* say so."""
+    from mockingbird_amd.synthesizer.inference import TacotronDevice
+    st = {k: v.clone() for k, v in synth.tacotron_state(seed=3)["model_state"].items()}
+    st["decoder.rnn_input.bias"] = torch.full_like(st["decoder.rnn_input.bias"], 1.0e5)
+    dev = TacotronDevice(st, torch.device("cuda"))
+    chars, spk, _, _ = _batch(32, 40, 60, seed=5)
+    with torch.no_grad():
+        mem, memp = ot.encoder_memory(st, ot.HP, chars, spk, 0)
+    monkeypatch.setenv("MBHIP_DIAG", "taco_front=0")
+    ref = dev.decode(mem.cuda(), memp.cuda(), chars.cuda(), 40, 11.0, seed=9)
+    monkeypatch.delenv("MBHIP_DIAG")
+    out = dev.decode(mem.cuda(), memp.cuda(), chars.cuda(), 40, 11.0, seed=9)
+    assert dev.last_loop_launches_per_iteration == 7 and not dev.last_loop_f16_products
+    for x, y in zip(out, ref):
+        assert torch.equal(x, y) and bool(torch.isfinite(x).all())
+    assert float(out[0].abs().max()) > 1.0e3  # the large activations really went through
 
 
 def test_stop_rule_matches_oracle(model):

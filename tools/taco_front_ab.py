@@ -12,8 +12,7 @@ from mockingbird_amd.synthesizer.inference import TacotronDevice
 st = synth.tacotron_state(seed=3)["model_state"]
 dev = TacotronDevice(st, torch.device("cuda"))
 out = {}
-VARIANTS = [("fused", ""), ("seven", "taco_front=0"), ("dma_late", "taco_dma_early=0"), ("hh_single", "taco_hh_pairs=0"),
-            ("hh2_mel_64", "taco_hh2_mel=64"), ("hh2_mel_80", "taco_hh2_mel=80"), ("no_watch", "taco_gru_watch=0"), ("fused_again", "")]
+VARIANTS = [("default", ""), ("f16", "taco_f16=1"), ("five_f32", "taco_f16=0"), ("seven", "taco_front=0"), ("f16_hh2_mel_64", "taco_f16=1,taco_hh2_mel=64"), ("default_again", "")]
 SHAPES = ((32, 60, 100), (16, 60, 100), (1, 60, 60), (32, 150, 180))
 if "quick" in sys.argv[2:]:
     SHAPES = SHAPES[:1]

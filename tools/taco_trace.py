@@ -39,6 +39,9 @@ for name, r in zip(names, raw):
                  "phases_cycles": {marks[i + 1][0]: marks[i + 1][1] - marks[i][1] for i in range(len(marks) - 1)}}
     print(f"{name:9s} wall {wall[0]*0.01:8.2f} -> {wall[1]*0.01:8.2f} us ({us_wall:5.2f} us, {cyc} cyc, {ghz:.2f} GHz)  " +
           "  ".join(f"{k}: {v}" for k, v in res[name]["phases_cycles"].items()))
+res["rider_marks_us"] = {"rin_last_rider": (int(raw[3][13]) - wall0) * 0.01, "rin_last_pre_tile": (int(raw[3][12]) - wall0) * 0.01,
+                         "rin_stop_tile": (int(raw[3][11]) - wall0) * 0.01, "mel_last_rider": (int(raw[6][13]) - wall0) * 0.01}
+print(res["rider_marks_us"])
 if not SEVEN:
     res["front_extra_us"] = {"last_attention_workgroup": (int(raw[2][13]) - wall0) * 0.01, "first_hh2_tile_done": (int(raw[0][12]) - wall0) * 0.01,
                              "last_hh2_tile_done": (int(raw[0][13]) - wall0) * 0.01}
