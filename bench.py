@@ -936,18 +936,38 @@ def main():
             bytes_it = 81.06e6 + 32 * Tt * (1024 + 128) * 4  # decoder weights + attention memory, per iteration
             # PMC pass of this configuration: the launches of one iteration (lstm runs twice)
             t_launches = getattr(tdev, "last_loop_launches_per_iteration", 7)
+            t_f16 = bool(getattr(tdev, "last_loop_f16_products", False))
+            # the exact fp32 loop (7 launches, every product on the fp32 pipe) timed in the same run
+            _old_diag = os.environ.get("MBHIP_DIAG")
+            os.environ["MBHIP_DIAG"] = (_old_diag + "," if _old_diag else "") + "taco_front=0"
+            try:
+                tdev.decode(mem, memp, chars, 400, 11, seed=1)
+                tdev.decode(mem, memp, chars, 400, 11, seed=2)
+                torch.cuda.synchronize()
+                x_loop_ms, x_launches = getattr(tdev, "last_loop_ms", None), getattr(tdev, "last_loop_launches_per_iteration", None)
+            finally:
+                if _old_diag is None:
+                    os.environ.pop("MBHIP_DIAG", None)
+                else:
+                    os.environ["MBHIP_DIAG"] = _old_diag
             t_traffic, t_src = (pmc_traffic("tacotron", ["front", "rnn_input", "lstm", "lstm", "mel_proj"]) if t_launches == 5 else (None, None))
             if t_traffic is None:  # the seven-launch loop (or a PMC pass older than the fused front: same bytes, other kernel names)
                 t_traffic, t_src = pmc_traffic("tacotron", ["prenet_fc2", "attn_gru", "lsa", "rnn_input", "lstm", "lstm", "mel_proj"])
             result["tacotron"] = {
                 "workload": "Tacotron generate (text encoder + GST + 200 decoder iterations r=2 + CBHG postnet), "
-                            f"batch 32 x ~100 tokens (T={Tt}), 400 mel frames forced, fp32, on-device dropout RNG",
+                            f"batch 32 x ~100 tokens (T={Tt}), 400 mel frames forced, fp32 state / accumulate / epilogues, on-device dropout RNG",
+                "dtype": ("split-f16 products (22-bit operands: w 2^s = wh + wl, x = xh + 2^-11 xl; three v_mfma_f32_16x16x32_f16 per 32 k) on the K >= 1024 "
+                          "tiles of the decoder loop, f32 accumulate / state / epilogues; fc2, attention GRU and attention on the f32 pipe" if t_f16 else
+                          "f32 (every product of the decoder loop on the fp32 matrix pipe)"),
+                "exact_f32": {"decoder_loop_ms": x_loop_ms, "us_per_decoder_iteration": (x_loop_ms * 1e3 / iters) if x_loop_ms else None,
+                              "launches_per_iteration": x_launches, "how": "MBHIP_DIAG=taco_front=0: the 7-launch loop, fp32 MFMA only (also the loop a range event or a lost hand-off falls back to)"},
                 "value": 32 * 400 / tt, "unit": "mel frames/s", "x_realtime_at_200_samples_per_frame": 32 * 400 * 200 / tt / 16000.0,
                 "ms_per_batch": tt * 1e3, "decode_plus_postnet_ms": td * 1e3, "decoder_loop_ms": loop_ms,
                 "us_per_decoder_iteration": it_us, "launches_per_iteration": t_launches,
                 "roofline": {"bound": "hbm", "kernel": f"decoder iteration (taco_fast.h: {t_launches} launches per iteration"
                                                        + (" -- prenet fc2, attention GRU and attention are roles of one launch with tagged-granule "
                                                           "hand-offs, taco_front_kernel" if t_launches == 5 else "") +
+                                                       ("; rnn_input / LSTM / mel launches and the hidden-half riders on fm_gemm16" if t_f16 else "") +
                                                        ", hipGraph replays; 81.06 MB fp32 weights + attention memory per iteration)",
                              "achieved": bytes_it / (it_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": bytes_it / (it_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": t_traffic,
