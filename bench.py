@@ -950,7 +950,8 @@ def main():
                     os.environ.pop("MBHIP_DIAG", None)
                 else:
                     os.environ["MBHIP_DIAG"] = _old_diag
-            t_traffic, t_src = (pmc_traffic("tacotron", ["front", "rnn_input", "lstm", "lstm", "mel_proj"]) if t_launches == 5 else (None, None))
+            t_traffic, t_src = (pmc_traffic("tacotron", ["front", "lstm", "lstm", "mel_proj"]) if t_launches == 4 else
+                                pmc_traffic("tacotron", ["front", "rnn_input", "lstm", "lstm", "mel_proj"]) if t_launches == 5 else (None, None))
             if t_traffic is None:  # the seven-launch loop (or a PMC pass older than the fused front: same bytes, other kernel names)
                 t_traffic, t_src = pmc_traffic("tacotron", ["prenet_fc2", "attn_gru", "lsa", "rnn_input", "lstm", "lstm", "mel_proj"])
             result["tacotron"] = {
@@ -966,8 +967,9 @@ def main():
                 "us_per_decoder_iteration": it_us, "launches_per_iteration": t_launches,
                 "roofline": {"bound": "hbm", "kernel": f"decoder iteration (taco_fast.h: {t_launches} launches per iteration"
                                                        + (" -- prenet fc2, attention GRU and attention are roles of one launch with tagged-granule "
-                                                          "hand-offs, taco_front_kernel" if t_launches == 5 else "") +
-                                                       ("; rnn_input / LSTM / mel launches and the hidden-half riders on fm_gemm16" if t_f16 else "") +
+                                                          "hand-offs, taco_front_kernel" if t_launches in (4, 5) else "") +
+                                                       ("; rnn_input folded into the attention role through a memory projected once per call" if t_launches == 4 else "") +
+                                                       ("; LSTM / mel launches and the hidden-half riders on fm_gemm16" if t_f16 else "") +
                                                        ", hipGraph replays; 81.06 MB fp32 weights + attention memory per iteration)",
                              "achieved": bytes_it / (it_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": bytes_it / (it_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": t_traffic,

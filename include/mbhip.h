@@ -509,16 +509,21 @@ int mb_taco_decode(const mb_taco* t, const float* d_memory, const float* d_memor
  * iterations it ran.  Production-dims handles only (the hipGraph-replayed loop); MB_ESTATE otherwise. */
 int mb_taco_last_loop_ms(const mb_taco* t, float* ms, int* iterations);
 
-/* Launches per decoder iteration of the last mb_taco_decode call on the hipGraph-replayed loop: 5 = prenet fc2, attention GRU and
- * attention as ROLES of one launch with tagged-granule hand-offs (taco_front_kernel: batch <= 32, text <= 192 symbols, 48 + 4 batch
- * compute units), 7 = one launch each (same bits; also what a call falls back to when a hand-off of the fused launch times out, and
- * with MBHIP_DIAG=taco_front=0); -1 = no decode on that loop yet. */
+/* Launches per decoder iteration of the last mb_taco_decode call on the hipGraph-replayed loop:
+ *   7 = one launch per stage, every product on the fp32 matrix pipe (also what a call falls back to when a hand-off of the fused launch
+ *       times out or an operand leaves fp16's range, and what MBHIP_DIAG=taco_front=0 selects);
+ *   5 = prenet fc2, attention GRU and attention as ROLES of one launch with tagged-granule hand-offs (taco_front_kernel: batch <= 32,
+ *       text <= 192 symbols, 48 + 4 batch compute units) -- with fp32 products the 7-launch loop's bits;
+ *   4 = additionally without the rnn_input launch (text <= 128 symbols): rnn_input, the next attention-GRU pre-activation and the stop
+ *       logit's context half are linear in the context, so they are formed by the attention workgroups from a memory projected once per
+ *       call (the workspace holds the projection); always with the fp16-pipe products below;
+ *  -1 = no decode on that loop yet. */
 int mb_taco_last_loop_form(const mb_taco* t);
 
 /* 1 when the last mb_taco_decode call on that loop multiplied its K >= 1024 tiles (LSTM input halves, rnn_input, mel_proj / prenet fc1' /
  * stop rows, hidden halves) on the fp16 matrix pipe with error-compensated split operands (w 2^s = wh + wl, x = xh + 2^-11 xl: 22-bit
- * operands, fp32 accumulate -- the 5-launch form with more than 16 utterances; a value beyond fp16's range makes the call run again on
- * the exact fp32 loop), 0 when every product ran on the fp32 pipe, -1 = no decode on that loop yet.  MBHIP_DIAG=taco_f16=0|1 overrides. */
+ * operands, fp32 accumulate -- the 4-launch form, and the 5-launch form with more than 16 utterances; a value beyond fp16's range makes
+ * the call run again on the exact fp32 loop), 0 when every product ran on the fp32 pipe, -1 = no decode on that loop yet.  MBHIP_DIAG=taco_f16=0|1 overrides. */
 int mb_taco_last_loop_f16(const mb_taco* t);
 
 /* Text encoder + global style token + attention-memory assembly (the once-per-chunk front

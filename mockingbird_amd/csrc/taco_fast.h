@@ -69,6 +69,10 @@ __global__ __launch_bounds__(512) void taco_fc2_kernel(TfFcK a) {
 struct TfGruK {
   const float* w; const float* xin; const float4* xpre; const float4* hpre; float* ah;  // ah FM [D], updated in place
   int nta, B; const int* flags; unsigned long long* trace;
+  // folded form (taco_front_kernel without an rnn_input launch): the role multiplies W_hh . attn_hidden itself, in front of its wait
+  // (the k-blocks P / 16 .. of w_pre's tiles, rnn_input job 1's products in their order), and attn_hidden ping-pongs between two FM
+  // buffers (the other tiles' epilogues would otherwise write into the fragments this one is still reading)
+  const float* w_pre = nullptr; const float4* bhh4 = nullptr; float* ah_out = nullptr;
 };
 template <int NT>
 __global__ __launch_bounds__(512) void taco_gru_kernel(TfGruK a) {

@@ -59,6 +59,17 @@ struct LsaK {
   const unsigned long long* q_gran = nullptr; int* lost = nullptr;
   unsigned long long* e_gran = nullptr;  // [B][128] energies exchanged between the four workgroups of an utterance (T <= 128)
   int dma_early = 0;  // fused launch: waves 2..7 queue the memory rows' LDS-DMA in front of the query wait (waves 0 / 1 poll)
+  // folded form (taco_front_kernel, no rnn_input launch): `memory` holds the PROJECTED memory rows [B][T][mem_ld] = W . memory_t with
+  // W = [rnn_input's context columns (H rows) | attention GRU's W_ih context columns as (r, z, n, 0) quads per unit (4 D rows) | stop_proj's
+  // context columns (1 row)], so that sum_t score_t row_t IS rnn_input's context part / the next GRU pre-activation / the stop logit's
+  // context part (the context vector itself is no longer formed).  `context` then receives x = rnn_input([context, attn_hidden]).
+  int mem_ld = 0;              // floats per memory row (0: P)
+  int fold = 0;
+  const float4* rin_a4 = nullptr;  // [psplit][D][64]: rnn_input's attn_hidden columns, W[p0 + 4 lane .. +3][P + k]
+  const float* rin_b = nullptr;    // [H]
+  const float4* bih4 = nullptr;    // [D] (b_r, b_z, b_n, 0) of the attention GRU's W_ih
+  float4* xpre_out = nullptr;      // CM4 [D / 4][nta][64]: next iteration's W_ih[:, :P] . context + b_ih
+  float* stop_part = nullptr;      // [nta * 16]: stop_proj's context half
 };
 __device__ __forceinline__ size_t lsa_qidx(const LsaK& a, int b, int k) { return a.fm_nta ? fm_index(a.fm_nta, b, k) : (size_t)b * a.D + k; }
 // float4 slot of context columns [p, p+4) of utterance b (p % 4 == 0)
@@ -218,7 +229,7 @@ __global__ __launch_bounds__(512) void lsa_kernel(LsaK a) {
 // v-weighting, softmax and context are what is left behind it.  (The LDS-DMA of the memory rows stays behind B2: queued early it
 // competes with the W_hh2 tiles of the same launch and, loads returning in order, holds the query poll back by a microsecond.)  Same operations on the same operands in the
 // same order per accumulator: the two forms give the same bits.
-template <int TJ, bool FUSED = false>
+template <int TJ, bool FUSED = false, bool FOLD = false>
 __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const int pg, float* s_mem = nullptr) {
   constexpr int D = 128, TMAX = 4 * TJ, TM = TMAX / 8, PW = 256, NTILE = TMAX / 16, NPASS = (NTILE + 7) / 8;
   // ES (fused launch, T <= 128): the four workgroups of an utterance (one per 256 context columns) need the same T energies -- 32 tanh
@@ -236,6 +247,9 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
   __shared__ __attribute__((aligned(16))) float s_e[TMAX];          // energies
   __shared__ __attribute__((aligned(16))) float s_u[TMAX];          // scores
   __shared__ __attribute__((aligned(16))) float4 s_part[8][64];
+  // folded form: partial sums of the next GRU pre-activation (32 unit quads per wave); ES: in the tanh exchange buffer, dead by then
+  __shared__ __attribute__((aligned(16))) float4 s_part2s[(FUSED && FOLD && !ES) ? 8 : 1][64];
+  float4 (*s_part2)[64] = ES ? reinterpret_cast<float4 (*)[64]>(&s_th[0][0][0]) : s_part2s;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int d = tid & (D - 1), tq = __builtin_amdgcn_readfirstlane(tid >> 7);
@@ -285,8 +299,37 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
     }
   }
   const int p0 = pg * PW;
-  const float* mem = a.memory + (size_t)b * T * P + p0 + lane * 4;
+  const int ld = a.mem_ld ? a.mem_ld : P;
+  const float* mem = a.memory + (size_t)b * T * ld + p0 + lane * 4;
   const bool dma = TJ == 32 && s_mem != nullptr;
+  constexpr bool fold = FUSED && FOLD;
+  // folded form: wave 0 runs the softmax alone, so the rows of the score-weighted sums belong to waves 1..7 (their operands arrive
+  // while they wait for it) -- wave 0 would meet its own loads at the barrier behind the softmax
+  constexpr int TMF = fold ? (TMAX + 6) / 7 : TM;  // rows per wave
+  // GRU pre-activation rows: waves 2..7 (the ones without a poll in the energy exchange: loads return in order), requested right behind
+  // that exchange's first barrier -- the hop and the softmax are their time to arrive (requested in front of the query wait instead:
+  // 44 more registers held for 8 us, the same 32.5 us per iteration); lanes 0..31 take the even rows of the wave, 32..63 the odd ones
+  constexpr int TM6 = fold ? (TMAX + 5) / 6 : 1, TMH = (TM6 + 1) / 2;
+  static_assert(!fold || ES, "the folded form is the LDS-window form (T <= 128)");
+  float4 pm2v[fold ? TMH : 1];
+  // rnn_input's attn_hidden columns for this wave's 16 k: requested with everything else, multiplied as soon as the query is staged
+  float4 ra4[fold ? 16 : 1];
+  if (fold) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) ra4[k] = a.rin_a4[((size_t)pg * D + wave * 16 + k) * 64 + lane];
+  }
+
+  // folded form: the stop logit's context part of this thread's softmax positions, rnn_input's bias for this lane's four columns
+  float pm3[(TMAX + 63) / 64];
+  float4 brin = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (fold) {
+#pragma unroll
+    for (int m = 0; m < (TMAX + 63) / 64; ++m) {
+      const int t = lane + 64 * m;
+      pm3[m] = (t < T && pg == 0 && wave == 0) ? a.memory[((size_t)b * T + t) * ld + P + 4 * D] : 0.f;
+    }
+    if (wave == 0) brin = *reinterpret_cast<const float4*>(a.rin_b + p0 + lane * 4);
+  }
   // staging
   if (!FUSED && tid < D) s_q[tid] = qv;
   if (tid < 2 * D) s_vc[tid >> 7][tid & (D - 1)] = vc;
@@ -314,7 +357,7 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
         for (int j = 0; j < (TMAX + 5) / 6; ++j) {
           const int t = (wave - 2) + 6 * j;  // wave-uniform
           if (t < T)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(mem + (size_t)t * P),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(mem + (size_t)t * ld),
                                              (__attribute__((address_space(3))) void*)(s_mem + t * PW), 16, 0, 0);
         }
       }
@@ -360,6 +403,14 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
     }
     s_pq[tq][d] = acc;
   }
+  float4 acc_ra = make_float4(0.f, 0.f, 0.f, 0.f);  // folded form: this wave's k slice of W_rin[:, P:] . attn_hidden for the lane's four columns
+  if (fold) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float qk = s_q[wave * 16 + k];
+      acc_ra.x += ra4[k].x * qk; acc_ra.y += ra4[k].y * qk; acc_ra.z += ra4[k].z * qk; acc_ra.w += ra4[k].w * qk;
+    }
+  }
   // chars of this thread's softmax positions (mask), requested early as well
   if (!FUSED) {
 #pragma unroll
@@ -389,7 +440,7 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
     for (int j = 0; j < TM; ++j) {
       const int t = wave + 8 * j;  // wave-uniform: row t lands at s_mem[t][0..255], lane l -> floats [4 l, 4 l + 4)
       if (t < T)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(mem + (size_t)t * P),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(mem + (size_t)t * ld),
                                          (__attribute__((address_space(3))) void*)(s_mem + t * PW), 16, 0, 0);
     }
   }
@@ -415,6 +466,14 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
       s_th[tl][dt0 + 1][lane] = th4[1];
     }
     __syncthreads();  // B2a: the tanh values of this workgroup's two tiles
+    if (fold && wave >= 2) {  // next GRU pre-activation rows of this workgroup's 32 units: lane (l & 31) holds unit 32 pg + (l & 31)'s (r, z, n, 0) quad
+      const float* p2 = a.memory + (size_t)b * T * ld + P + 128 * pg + 4 * (lane & 31);
+#pragma unroll
+      for (int j = 0; j < TMH; ++j) {
+        const int rr = 2 * j + (lane >> 5), t = (wave - 2) + 6 * rr;
+        pm2v[j] = (t < T && rr < TM6) ? *reinterpret_cast<const float4*>(p2 + (size_t)t * ld) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
     if (wave < 2) {
       const int tg = 2 * pg + wave;
       const unsigned tag = (unsigned)iter + 1u;
@@ -501,11 +560,11 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
   tf_mark(a.trace, TS_LSA, 5, pick);
   // context rows (stable data) of the register path (no LDS window): requested now, they arrive while wave 0 runs the softmax
   float4 memv[TM];
-  if (!dma) {
+  if (!dma && !fold) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
       const int t = wave + 8 * j;
-      memv[j] = (t < T) ? *reinterpret_cast<const float4*>(mem + (size_t)t * P) : make_float4(0.f, 0.f, 0.f, 0.f);
+      memv[j] = (t < T) ? *reinterpret_cast<const float4*>(mem + (size_t)t * ld) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
   // ---- phase 4: mask, softmax over T (lsa.py:34-38) by wave 0, cumulative update ----
@@ -530,23 +589,51 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
     }
     ssum = wave64_sum(ssum);
     float* ao = (a.attn_out && pg == 0) ? a.attn_out + ((size_t)b * a.n_iter_max + iter) * T : nullptr;
+    float sp = 0.f;
 #pragma unroll
     for (int q = 0; q < (TMAX + 63) / 64; ++q) {
       const int t = lane + 64 * q;
       if (t < T) {
         const float sc = uv[q] / ssum;
         s_u[t] = sc;
+        if (fold) sp += sc * pm3[q];
         if (pg == 0 && !skip) {
           a.cum_out[(size_t)b * T + t] = s_cum[t + half] + sc;  // cumulative += attention (lsa.py:40)
           if (ao) ao[t] = sc;
         }
       }
     }
+    if (fold && pg == 0) {  // stop_proj's context half (tacotron.py:133-135): sum_t score_t (w_stop[H:] . memory_t)
+      sp = wave64_sum(sp);
+      if (lane == 0 && !skip) a.stop_part[b] = sp;
+    }
   }
   __syncthreads();  // B4
   tf_mark(a.trace, TS_LSA, 6, pick);
   // ---- phase 5: context = scores @ encoder_seq (tacotron.py:104), this group's 256 columns ----
-  {
+  if constexpr (fold) {
+    float4 acc = acc_ra, acc2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (wave > 0) {
+#pragma unroll
+      for (int j = 0; j < TMF; ++j) {
+        const int t = (wave - 1) + 7 * j;
+        const float sc = (t < T) ? s_u[t] : 0.f;
+        float4 mv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < T) mv = *reinterpret_cast<const float4*>(s_mem + t * PW + lane * 4);
+        acc.x += sc * mv.x; acc.y += sc * mv.y; acc.z += sc * mv.z; acc.w += sc * mv.w;
+      }
+      if (wave >= 2) {
+#pragma unroll
+        for (int j = 0; j < TMH; ++j) {
+          const int rr = 2 * j + (lane >> 5), t = (wave - 2) + 6 * rr;
+          const float sc = (t < T && rr < TM6) ? s_u[t] : 0.f;
+          acc2.x += sc * pm2v[j].x; acc2.y += sc * pm2v[j].y; acc2.z += sc * pm2v[j].z; acc2.w += sc * pm2v[j].w;
+        }
+      }
+    }
+    s_part2[wave][lane] = acc2;
+    s_part[wave][lane] = acc;
+  } else {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
@@ -568,7 +655,19 @@ __device__ __forceinline__ void lsa_fast_body(const LsaK& a, const int b, const 
       const float4 o = s_part[w][lane];
       r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
     }
+    if (fold) { r.x += brin.x; r.y += brin.y; r.z += brin.z; r.w += brin.w; }  // x = rnn_input([context, attn_hidden])
     *lsa_ctx4(a, b, p0 + lane * 4) = r;
+  }
+  if (fold && wave == 1 && lane < 32 && !skip) {  // W_ih[:, :P] . context + b_ih of unit 32 pg + lane: the next iteration's GRU reads it
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int w = 2; w < 8; ++w) {  // (waves 0 / 1 hold no rows)
+      const float4 o = s_part2[w][lane], o2 = s_part2[w][lane + 32];
+      r.x += o.x + o2.x; r.y += o.y + o2.y; r.z += o.z + o2.z; r.w += o.w + o2.w;
+    }
+    const int u = 32 * pg + lane;
+    const float4 bi = a.bih4[u];
+    a.xpre_out[((size_t)(u >> 2) * a.fm_nta + (b >> 4)) * 64 + (u & 3) * 16 + (b & 15)] = make_float4(r.x + bi.x, r.y + bi.y, r.z + bi.z, 0.f);
   }
   tf_mark_end(a.trace, TS_LSA, 8, pick);
 }
@@ -609,6 +708,25 @@ __global__ __launch_bounds__(512) void lsa_hh_kernel(LsaK a, TfHhK hh, int n_lsa
   if (id < n_lsa) { lsa_fast_body<TJ>(a, id % B, id / B, TJ == 32 ? s_big : nullptr); return; }
   const int j = id - n_lsa, mt = j / gy;
   fm_hh_job<NT>(hh, mt, (j - mt * gy) * NT, nta, a.skip_flag ? *a.skip_flag : 0, red);
+}
+
+constexpr int TACO_PM_LD = 1664;  // floats per projected-memory row: H + 4 D + 1 = 1537 rows of W, padded to 13 x 128 output channels
+// [B][T][C] -> [B][C][T] (the attention memory as the 1 x 1 conv's channel-major input), 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void btc_to_bct_kernel(const float* __restrict__ x, float* __restrict__ y, int T, int C) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, c0 = blockIdx.x * 32, t0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t = t0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = (t < T && c < C) ? x[((size_t)b * T + t) * C + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, t = t0 + tx;
+    if (c < C && t < T) y[((size_t)b * C + c) * T + t] = tile[tx][ty + 8 * i];
+  }
 }
 
 // ---------------------------------------------------------------- fused front of the fast decoder loop
@@ -670,12 +788,34 @@ __device__ __forceinline__ void front_gru_job(const TfGruK& a, const TfFrontX& x
   for (int p = 0; p < PW; ++p) wa[p] = *reinterpret_cast<const float4*>(wl + (size_t)(wave + 8 * p) * BLK);
   const int ntE = (wave < NT && wave < a.nta) ? wave : a.nta - 1;
   const size_t cm = ((size_t)mt * a.nta + ntE) * 64 + lane;
-  const float4 xp = a.xpre[cm], hp = a.hpre[cm];
-  float* hpt = a.ah + ((size_t)(mt >> 2) * a.nta + ntE) * 256 + (mt & 3) * 64 + i * 4 + du;
-  const float hprev = *hpt;
+  const bool own_h = a.w_pre != nullptr;
+  const float4 xp = a.xpre[cm];
+  float4 hp = own_h ? a.bhh4[mt * 4 + du] : a.hpre[cm];
+  const size_t ho = ((size_t)(mt >> 2) * a.nta + ntE) * 256 + (mt & 3) * 64 + i * 4 + du;
+  float* hpt = (own_h ? a.ah_out : a.ah) + ho;
+  const float hprev = a.ah[ho];
   int ntc[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) ntc[nt] = nt < a.nta ? nt : a.nta - 1;
+  // folded form: W_hh . attn_hidden(t-1) for this tile, k-block `wave` of the hidden part (fm_gemm<NT, 9, 8, 3, 2>'s accH)
+  f32x4 accH[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) accH[nt] = {0.f, 0.f, 0.f, 0.f};
+  if (own_h) {
+    const float4 wh = *reinterpret_cast<const float4*>(a.w_pre + (size_t)mt * 72 * BLK + (size_t)(64 + wave) * BLK + ((u * RL + tau) * 4 + kq) * 4);
+    float4 bh[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bh[nt] = reinterpret_cast<const float4*>(a.ah)[((size_t)wave * a.nta + ntc[nt]) * 64 + lane];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float av = c == 0 ? wh.x : c == 1 ? wh.y : c == 2 ? wh.z : wh.w;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float bv = c == 0 ? bh[nt].x : c == 1 ? bh[nt].y : c == 2 ? bh[nt].z : bh[nt].w;
+        accH[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, accH[nt], 0, 0, 0);
+      }
+    }
+  }
   const unsigned tag = (unsigned)it + 1u;
   // watch: lane j < PW * NT of every wave polls the last granule of one of the wave's fragments, then one sweep (re-read while stale)
   if (x.watch) {
@@ -728,17 +868,29 @@ __device__ __forceinline__ void front_gru_job(const TfGruK& a, const TfFrontX& x
       for (int nt = 0; nt < NT; ++nt)
         acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, __uint_as_float((unsigned)g[p][nt][c]), acc[nt], 0, 0, 0);
     }
-  float4* red4 = reinterpret_cast<float4*>(red);  // [8][NT][64]
+  float4* red4 = reinterpret_cast<float4*>(red);  // [8][NT][2][64]
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) red4[(wave * NT + nt) * 64 + lane] = make_float4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]);
+  for (int nt = 0; nt < NT; ++nt) {
+    red4[((wave * NT + nt) * 2 + 0) * 64 + lane] = make_float4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]);
+    if (own_h) red4[((wave * NT + nt) * 2 + 1) * 64 + lane] = make_float4(accH[nt][0], accH[nt][1], accH[nt][2], accH[nt][3]);
+  }
   __syncthreads();
   tf_mark(a.trace, TS_GRU, 3, pick);
   if (wave >= NT || wave >= a.nta) return;
   float sx[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int w8 = 0; w8 < 8; ++w8) {
-    const float4 v = red4[(w8 * NT + wave) * 64 + lane];
+    const float4 v = red4[((w8 * NT + wave) * 2 + 0) * 64 + lane];
     sx[0] += v.x; sx[1] += v.y; sx[2] += v.z; sx[3] += v.w;
+  }
+  if (own_h) {
+    float sh[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w8 = 0; w8 < 8; ++w8) {
+      const float4 v = red4[((w8 * NT + wave) * 2 + 1) * 64 + lane];
+      sh[0] += v.x; sh[1] += v.y; sh[2] += v.z; sh[3] += v.w;
+    }
+    hp = make_float4(sh[0] + hp.x, sh[1] + hp.y, sh[2] + hp.z, 0.f);
   }
   // torch GRUCell, gate order (r, z, n)  (taco_gru_kernel's epilogue)
   const float rg = tf_sigmoid((sx[0] + xp.x) + hp.x);
@@ -749,21 +901,22 @@ __device__ __forceinline__ void front_gru_job(const TfGruK& a, const TfFrontX& x
   *hpt = hn;                                                               // rnn_input / next iteration: after the launch
   tf_mark_end(a.trace, TS_GRU, 4, pick);
 }
-template <int TJ, int NT, bool F16>
-__global__ __launch_bounds__(512) void taco_front_kernel(TfFcK fk, TfGruK gk, LsaK a, TfHhK hh, TfFrontX x, int n_lsa, int B, int gy, int nta) {
+template <int TJ, int NT, bool F16, bool FOLD>
+__global__ __launch_bounds__(512) void taco_front_kernel(TfFcK fk, TfGruK gk, LsaK a, TfHhK hh, TfHhK hhb, TfFrontX x, int n_lsa, int B, int gy, int nta) {
   __shared__ __attribute__((aligned(16))) float s_big[TJ == 32 ? 32 * 4 * 256 : 2 * FmRed<NT, 1>::floats];
   const int id = blockIdx.x;
   if (id < x.n_fc2) { front_fc2_job<NT>(fk, x, id, s_big); return; }
   if (id < x.n_fc2 + x.n_gru) { front_gru_job<NT>(gk, x, id - x.n_fc2, fk.flags[TF_ITER] + fk.it_off, s_big); return; }
   const int l = id - x.n_fc2 - x.n_gru;
   if (l < n_lsa) {
-    lsa_fast_body<TJ, true>(a, l % B, l / B, TJ == 32 ? s_big : nullptr);
+    lsa_fast_body<TJ, true, FOLD>(a, l % B, l / B, TJ == 32 ? s_big : nullptr);
     if (a.trace && threadIdx.x == 0) atomicMax(a.trace + TS_LSA * 16 + 13, (unsigned long long)wall_clock64());  // last attention workgroup
     return;
   }
   const int j = l - n_lsa;  // (gy == 1: the fused launch serves at most NT column tiles)
   if (x.hh_pairs) fm_hh_pair_job<NT>(hh, j, nta, a.skip_flag ? *a.skip_flag : 0, s_big);
-  else fm_hh_job<NT, F16>(hh, j, 0, nta, a.skip_flag ? *a.skip_flag : 0, s_big, x.lost);
+  else if (j < hh.n_tiles) fm_hh_job<NT, F16>(hh, j, 0, nta, a.skip_flag ? *a.skip_flag : 0, s_big, x.lost);
+  else fm_hh_job<NT, F16>(hhb, j - hh.n_tiles, 0, nta, a.skip_flag ? *a.skip_flag : 0, s_big, x.lost);  // folded form: the W_hh1 tiles the mel launch has no room for
   if (a.trace && threadIdx.x == 0) {
     atomicMax(a.trace + TS_FC2 * 16 + 13, (unsigned long long)wall_clock64());  // last hh2 tile
     if (j == 0) a.trace[TS_FC2 * 16 + 12] = (unsigned long long)wall_clock64();  // first hh2 tile done
@@ -1180,6 +1333,10 @@ struct mb_taco {
   struct Img16 { DevBuf w; float unscale = 1.f; };
   Img16 i_l1x, i_l2x, i_l1hh, i_l2hh, i_rin, i_pre, i_stopc, i_mel, i_fc1, i_stop;
   bool last_f16 = false;
+  // folded form of the fast loop (4 launches per iteration): the 1 x 1 conv that projects the attention memory once per decode call
+  // (rows: rnn_input's context columns | attention GRU W_ih context columns as unit quads | stop_proj's context columns), and
+  // rnn_input's attn_hidden columns in the attention workgroups' lane order
+  ConvL pm_conv; DevBuf rin_a4; int last_form = 7;
   DevBuf f_gru_w, f_pre_w, f_bih4, f_bhh4, f_l1_b4, f_l2_b4, f_fc1_w, f_stop_w, f_stopc_w, f_l1_hh, f_l2_hh;
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // loop timing (mb_taco_last_loop_ms)
   int last_iters = 0; bool timed = false;
@@ -1525,6 +1682,21 @@ extern "C" int mb_taco_create(const mb_taco_config* cfg, const float* const* hw,
       pack_rowtile(sc.data(), 1, P + D, 4, &packed); RC(t->f_stopc_w.upload(packed.data(), packed.size()));
       RC(pack_rowtile16(sc.data(), 1, P + D, 4, &t->i_stopc));
     }
+    {  // folded form: projected-memory weights [TACO_PM_LD][P] and rnn_input's attn_hidden columns [4][D][64] x 4
+      const float* rin = hw[14];  // rnn_input.weight [H][P + D], input order [context, attn_hidden] (tacotron.py:108-109)
+      std::vector<float> wpm((size_t)TACO_PM_LD * P, 0.f);
+      for (int r = 0; r < H; ++r) memcpy(&wpm[(size_t)r * P], rin + (size_t)r * (P + D), sizeof(float) * P);
+      for (int u = 0; u < D; ++u)
+        for (int g = 0; g < 3; ++g) memcpy(&wpm[(size_t)(H + 4 * u + g) * P], a_wih + (size_t)(g * D + u) * (P + 2 * D), sizeof(float) * P);
+      memcpy(&wpm[(size_t)(H + 4 * D) * P], stop_w + H, sizeof(float) * P);
+      RC(make_linear_conv(&t->pm_conv, wpm.data(), TACO_PM_LD, P, nullptr));
+      std::vector<float> ra((size_t)4 * D * 64 * 4);
+      for (int pg = 0; pg < 4; ++pg)
+        for (int k = 0; k < D; ++k)
+          for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 4; ++j) ra[(((size_t)pg * D + k) * 64 + l) * 4 + j] = rin[(size_t)(256 * pg + 4 * l + j) * (P + D) + P + k];
+      RC(t->rin_a4.upload(ra.data(), ra.size()));
+    }
     for (int l = 0; l < 2; ++l) {  // hidden halves W_hh in LSTM tile order (K = H)
       cell_rows(hw[16 + 4 * l + 1], H, H, hw[16 + 4 * l + 1], 0, H, 4, &rows);
       pack_rowtile(rows.data(), 4 * H, H, 4, &packed);
@@ -1574,7 +1746,7 @@ extern "C" void mb_taco_destroy(mb_taco* t) {
                   &t->lsa_Wb, &t->lsa_v, &t->attn_w, &t->attn_bih, &t->attn_bhh, &t->rin_w, &t->rin_b, &t->l1_w,
                   &t->l1_bih, &t->l1_bhh, &t->l2_w, &t->l2_bih, &t->l2_bhh, &t->l1_wx, &t->l1_whh, &t->l2_wx, &t->l2_whh, &t->mel_w, &t->stop_w, &t->stop_b,
                   &t->emb, &t->enc_proj_full, &t->lsa_Mt, &t->lsa_c0, &t->lsa_Wt, &t->gst_qconst, &t->gst_WqS, &t->gst_K, &t->gst_V,
-                  &t->f_gru_w, &t->f_pre_w, &t->f_bih4, &t->f_bhh4, &t->f_l1_b4, &t->f_l2_b4, &t->f_fc1_w, &t->f_stop_w, &t->f_stopc_w, &t->f_l1_hh, &t->f_l2_hh, &t->lsa_Wq4, &t->lsa_Mq4};
+                  &t->f_gru_w, &t->f_pre_w, &t->f_bih4, &t->f_bhh4, &t->f_l1_b4, &t->f_l2_b4, &t->f_fc1_w, &t->f_stop_w, &t->f_stopc_w, &t->f_l1_hh, &t->f_l2_hh, &t->lsa_Wq4, &t->lsa_Mq4, &t->rin_a4};
   for (DevBuf* b : bs) b->release();
   t->drop_graph();
   if (t->h_flags) (void)hipHostFree(t->h_flags);
@@ -1587,6 +1759,7 @@ extern "C" void mb_taco_destroy(mb_taco* t) {
   t->post.release(); t->post_proj.release(); t->enc.release();
   t->enc_fc1.release(); t->enc_fc2.release(); t->enc_proj.release();
   for (mb_taco::Img16* im : {&t->i_l1x, &t->i_l2x, &t->i_l1hh, &t->i_l2hh, &t->i_rin, &t->i_pre, &t->i_stopc, &t->i_mel, &t->i_fc1, &t->i_stop}) im->w.release();
+  t->pm_conv.release();
   delete t;
 }
 
@@ -1595,6 +1768,8 @@ struct TacoLayout {
   float *p1, *p2, *attn_h, *context, *x, *x1, *x2, *h1, *c1, *h2, *c2, *melstep, *cumulative, *stop;
   // fast loop (taco_fast.h): FM activations, CM cell state / gate pre-activations
   float *f_p1, *f_p2, *f_ah, *f_ctx, *f_x, *f_x1, *f_x2, *f_h1, *f_h2, *f_c1, *f_c2, *f_xpre, *f_hpre, *f_hp1, *f_hp2, *f_stop_part;
+  float *f_ah2;       // folded form: the second attn_hidden buffer (ping-pong)
+  float *memT, *pm;   // folded form: the memory channel-major [B][P][T], the projected memory [B][T][TACO_PM_LD]
   unsigned long long *f_p2g, *f_ahg, *f_eg;  // fused front (taco_front_kernel): tagged granules of p2 / attn_hidden / energies
   size_t f_state_bytes;  // the region above, zeroed per call
   float* mpq4;  // mem_proj in MFMA D-fragment order for lsa_fast_body: [B][4 TJ / 16][8][64] float4 = B * 4 TJ * D floats, TJ = 32 | 48
@@ -1630,12 +1805,18 @@ static void taco_layout(const mb_taco* t, int B, int T, int max_steps, void* bas
     L->f_xpre = ar.take<float>(4 * cm_items(D, nta)); L->f_hpre = ar.take<float>(4 * cm_items(D, nta));
     L->f_p2g = ar.take<unsigned long long>(fm_floats(2 * D, nta)); L->f_ahg = ar.take<unsigned long long>((size_t)nta * 16 * D);
     L->f_eg = ar.take<unsigned long long>((size_t)nta * 16 * 128);
+    L->f_ah2 = ar.take<float>(fm_floats(D, nta));
     L->f_state_bytes = ar.off - start;
   }
   L->melstep = ar.take<float>((size_t)B * c.r * M);
   L->cumulative = ar.take<float>((size_t)2 * B * T);
   L->stop = ar.take<float>(B);
   L->mpq4 = ar.take<float>(T <= 192 ? (size_t)B * 4 * (T <= 128 ? 32 : 48) * 128 : 1);
+  {
+    const bool foldable = t->fast && T <= 192 && B <= 32;  // (the shapes taco_front_kernel serves)
+    L->memT = ar.take<float>(foldable ? (size_t)B * P * T : 1);
+    L->pm = ar.take<float>(foldable ? (size_t)B * T * 1664 : 1);
+  }
   L->flags = ar.take<int>(16);
   L->melc = ar.take<float>(B * M * F);
   L->linc = ar.take<float>(B * M * F);
@@ -1690,6 +1871,20 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
   if (tr) MB_HIP(hipMemsetAsync(tr, 0, sizeof(unsigned long long) * 16 * TS_SLOTS, s));
   MB_HIP(hipMemsetAsync(L.f_p1, 0, L.f_state_bytes, s));
   MB_HIP(hipMemcpyAsync(flags + TF_SEED, &seed, sizeof(seed), hipMemcpyHostToDevice, s));  // pageable source: staged before return
+  // folded form (4 launches per iteration): rnn_input, the next GRU pre-activation and the stop logit's context half are linear in the
+  // context = sum_t score_t memory_t, so with the memory rows projected ONCE per call (a 1 x 1 conv on the split-fp16 path,
+  // conv1d.hip) the attention workgroups produce them directly and the rnn_input launch is gone
+  const int f16_sw = diag_int("taco_f16", -1), fold_sw = diag_int("taco_fold", -1);
+  const bool f16 = front && t->i_l1x.w.p && (f16_sw < 0 ? (nta >= 2 || (T <= 128 && t->pm_conv.w.p && fold_sw != 0)) : f16_sw != 0);  // (below)
+  // (T <= 128: the attention's LDS window form.  By default only together with the fp16-pipe riders: the rnn_input launch is also
+  //  where 128 hidden-half tiles rode, and only the short riders fit the front / mel launches without a second round)
+  const bool fold = front && T <= 128 && t->pm_conv.w.p && (fold_sw < 0 ? f16 : fold_sw != 0);
+  if (fold) {
+    hipLaunchKernelGGL(btc_to_bct_kernel, dim3(cdiv(P, 32), cdiv(T, 32), B), dim3(256), 0, s, d_memory, L.memT, T, P);
+    MB_HIP(hipGetLastError());
+    const int rcv = run_conv(t->pm_conv, L.memT, B, T, L.pm, (long long)T * TACO_PM_LD, 0, 0, nullptr, nullptr, 1, s);
+    if (rcv) return rcv;
+  }
   {
     TfP1K pk;
     pk.b_fc1 = t->pre1_b.p; pk.p1 = L.f_p1; pk.nta = nta; pk.B = B; pk.rows = 2 * D; pk.flags = flags; pk.drop = dk;
@@ -1711,12 +1906,10 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
   // fused front: the attention workgroups hold 128 KB of LDS each, so every workgroup of that launch has a compute unit to itself and
   // the W_hh2 . h2 tiles behind them come in rounds of (256 - 48 - B psplit): the first hh2_mel row tiles ride in the previous
   // iteration's mel launch instead (h2 is final there), the rest stay (sweep: profiles/r05_taco_front_ab.json)
-  // 5-launch form, more than 16 utterances: the K >= 1024 tile products (LSTM input halves, rnn_input, mel / fc1' / stop rows, the
-  // hidden-half riders) on the fp16 matrix pipe from split images (fm_gemm16: fp32-grade, not the 7-launch loop's bits; a value beyond
-  // fp16's range raises flags[TF_LOST] -> the call reruns on the exact loop).  With one column tile the fp32 products are half as
-  // many and the operand conversions cost what is saved (31.6 against 32.1 us at batch 16, 30.8 against 31.8 at batch 1).
-  const int f16_sw = diag_int("taco_f16", -1);
-  const bool f16 = front && t->i_l1x.w.p && (f16_sw < 0 ? nta >= 2 : f16_sw != 0);
+  // (f16, decided above: the K >= 1024 tile products -- LSTM input halves, rnn_input, mel / fc1' / stop rows, the hidden-half riders -- on
+  //  the fp16 matrix pipe from split images, fm_gemm16: fp32-grade, not the 7-launch loop's bits; a value beyond fp16's range raises
+  //  flags[TF_LOST] -> the call reruns on the exact loop.  On its own it pays with two column tiles only -- with one the fp32 products
+  //  are half as many and the conversions cost what is saved, 31.6 against 32.1 us at batch 16 -- but the folded form needs its short riders)
   const int front_free = t->n_cus - (2 * D / 16 + D / 4 + B * psplit);  // compute units the hh2 tiles of the fused launch start on
   // (96: the mel launch stays within one round of 256 workgroups; the fp16-pipe riders are short enough for the front launch to keep all)
   const int hh2_auto = f16 ? 0 : std::min(std::max(H / 4 - 2 * front_free, 0), 96);
@@ -1724,6 +1917,8 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
   auto img16 = [&](TfHhK& h, const mb_taco::Img16& im) {
     if (f16) { h.w16 = reinterpret_cast<const uint4*>(im.w.p); h.unscale = im.unscale; }
   };
+  // folded form: W_hh1 row tiles [0, m1) ride in the mel launch (one round with its 27 chain tiles), the rest behind the W_hh2 tiles of the front launch
+  const int m1 = fold ? std::min(std::max(diag_int("taco_m1", 200), 0), H / 4) : 0;
   int hh1_split = H / 8;  // row tiles of W_hh1 . h1 taken by the mel launch (the rest: next rnn_input launch)
   // (an hh1-split sweep, round 2: flat between 128 and 224 rows -- the switch is gone, the value stays)
   auto iteration = [&](int pp, int it_off) -> int {
@@ -1750,6 +1945,10 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
     TfGruK gk;
     gk.w = t->f_gru_w.p; gk.xin = L.f_p2; gk.xpre = reinterpret_cast<const float4*>(L.f_xpre);
     gk.hpre = reinterpret_cast<const float4*>(L.f_hpre); gk.ah = L.f_ah; gk.nta = nta; gk.B = B; gk.flags = flags; gk.trace = tr;
+    if (fold) {  // attn_hidden ping-pongs (pp: this iteration's input buffer); the role multiplies W_hh . attn_hidden itself
+      gk.ah = pp ? L.f_ah2 : L.f_ah; gk.ah_out = pp ? L.f_ah : L.f_ah2;
+      gk.w_pre = t->f_pre_w.p; gk.bhh4 = reinterpret_cast<const float4*>(t->f_bhh4.p);
+    }
     if (!front) TF_LAUNCH(taco_gru_kernel, D / 4, gk);
     // 3. location-sensitive attention + context
     LsaK lk;
@@ -1772,17 +1971,26 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
       fx.hh_pairs = f16 ? 0 : diag_int("taco_hh_pairs", 1);  // (fp16-pipe riders are short enough to come one tile per workgroup)
       lk.dma_early = diag_int("taco_dma_early", 1);
       lk.q_gran = L.f_ahg; lk.lost = flags + TF_LOST; lk.e_gran = L.f_eg;
-      hh2.tile0 = hh2_mel; hh2.n_tiles = H / 4 - hh2_mel;
-      const dim3 g1(fx.n_fc2 + fx.n_gru + n_lsa + (fx.hh_pairs ? cdiv(hh2.n_tiles, 2) : hh2.n_tiles));
-#define TF_FRONT(TJ_, NT_)                                                                                                      \
-      do {                                                                                                                       \
-        if (f16) hipLaunchKernelGGL((taco_front_kernel<TJ_, NT_, true>), g1, blk, 0, s, fk, gk, lk, hh2, fx, n_lsa, B, gy, nta);  \
-        else hipLaunchKernelGGL((taco_front_kernel<TJ_, NT_, false>), g1, blk, 0, s, fk, gk, lk, hh2, fx, n_lsa, B, gy, nta);     \
+      if (fold) {
+        lk.fold = 1; lk.memory = L.pm; lk.mem_ld = TACO_PM_LD; lk.context = L.f_x;
+        lk.rin_a4 = reinterpret_cast<const float4*>(t->rin_a4.p); lk.rin_b = t->rin_b.p;
+        lk.bih4 = reinterpret_cast<const float4*>(t->f_bih4.p); lk.xpre_out = reinterpret_cast<float4*>(L.f_xpre); lk.stop_part = L.f_stop_part;
+      }
+      hh2.tile0 = fold ? 0 : hh2_mel; hh2.n_tiles = H / 4 - hh2.tile0;
+      TfHhK hh1b;  // folded form: W_hh1 row tiles [m1, H / 4) (h1 of the previous iteration: final since its LSTM-1 launch)
+      hh1b.w = t->f_l1_hh.p; hh1b.h = L.f_h1; hh1b.hpre = reinterpret_cast<float4*>(L.f_hp1); hh1b.tile0 = m1; hh1b.n_tiles = fold ? H / 4 - m1 : 0;
+      img16(hh1b, t->i_l1hh);
+      if (fold) fx.hh_pairs = 0;
+      const dim3 g1(fx.n_fc2 + fx.n_gru + n_lsa + (fx.hh_pairs ? cdiv(hh2.n_tiles, 2) : hh2.n_tiles + hh1b.n_tiles));
+#define TF_FRONT(TJ_, NT_, FOLD_)                                                                                                      \
+      do {                                                                                                                              \
+        if (f16) hipLaunchKernelGGL((taco_front_kernel<TJ_, NT_, true, FOLD_>), g1, blk, 0, s, fk, gk, lk, hh2, hh1b, fx, n_lsa, B, gy, nta);  \
+        else hipLaunchKernelGGL((taco_front_kernel<TJ_, NT_, false, FOLD_>), g1, blk, 0, s, fk, gk, lk, hh2, hh1b, fx, n_lsa, B, gy, nta);     \
       } while (0)
-      if (T <= 128 && nta >= 2) TF_FRONT(32, 2);
-      else if (T <= 128) TF_FRONT(32, 1);
-      else if (nta >= 2) TF_FRONT(48, 2);
-      else TF_FRONT(48, 1);
+      if (T <= 128 && nta >= 2) { if (fold) TF_FRONT(32, 2, true); else TF_FRONT(32, 2, false); }
+      else if (T <= 128) { if (fold) TF_FRONT(32, 1, true); else TF_FRONT(32, 1, false); }
+      else if (nta >= 2) TF_FRONT(48, 2, false);
+      else TF_FRONT(48, 1, false);
 #undef TF_FRONT
     } else if (lsa_fast) {
       const dim3 g1(n_lsa + (H / 4) * gy);
@@ -1806,14 +2014,16 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
     // iteration's mel launch (both launches leave most CUs idle; one launch taking all 256 tiles slowed its chain jobs)
     rk.hh.w = t->f_l1_hh.p; rk.hh.h = L.f_h1; rk.hh.hpre = reinterpret_cast<float4*>(L.f_hp1);
     rk.hh.tile0 = hh1_split; rk.hh.n_tiles = H / 4 - hh1_split;
-    img16(rk.hh, t->i_l1hh);
-    if (f16) {
-      rk.rin16 = reinterpret_cast<const uint4*>(t->i_rin.w.p); rk.us_rin = t->i_rin.unscale;
-      rk.pre16 = reinterpret_cast<const uint4*>(t->i_pre.w.p); rk.us_pre = t->i_pre.unscale;
-      rk.stopc16 = reinterpret_cast<const uint4*>(t->i_stopc.w.p); rk.us_stopc = t->i_stopc.unscale; rk.lost = flags + TF_LOST;
+    if (!fold) {
+      img16(rk.hh, t->i_l1hh);
+      if (f16) {
+        rk.rin16 = reinterpret_cast<const uint4*>(t->i_rin.w.p); rk.us_rin = t->i_rin.unscale;
+        rk.pre16 = reinterpret_cast<const uint4*>(t->i_pre.w.p); rk.us_pre = t->i_pre.unscale;
+        rk.stopc16 = reinterpret_cast<const uint4*>(t->i_stopc.w.p); rk.us_stopc = t->i_stopc.unscale; rk.lost = flags + TF_LOST;
+      }
+      if (f16) TF_LAUNCH16(taco_rin_kernel, H / 16 + D / 4 + 1 + rk.hh.n_tiles, rk);
+      else TF_LAUNCH(taco_rin_kernel, H / 16 + D / 4 + 1 + rk.hh.n_tiles, rk);
     }
-    if (f16) TF_LAUNCH16(taco_rin_kernel, H / 16 + D / 4 + 1 + rk.hh.n_tiles, rk);
-    else TF_LAUNCH(taco_rin_kernel, H / 16 + D / 4 + 1 + rk.hh.n_tiles, rk);
     // 5./6. residual LSTMs
     TfLstmK lk1;
     lk1.w = t->l1_wx.p; lk1.b4 = reinterpret_cast<const float4*>(t->f_l1_b4.p); lk1.x = L.f_x; lk1.h_out = L.f_h1;
@@ -1846,8 +2056,10 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
     mk.nta = nta; mk.B = B; mk.n_mel = r * M / 16; mk.M = M; mk.r = r; mk.max_steps = max_steps; mk.it_off = it_off;
     mk.min_stop_token = min_stop_token; mk.flags = flags; mk.drop = dk; mk.drop.layer = 0; mk.drop.it_add = 1; mk.trace = tr;
     mk.hh2 = hh2; mk.hh2.tile0 = 0; mk.hh2.n_tiles = hh2_mel;
-    if (f16) TF_LAUNCH16(taco_mel_kernel, r * M / 16 + 2 * D / 16 + 1 + hh1_split + hh2_mel, mk);
-    else TF_LAUNCH(taco_mel_kernel, r * M / 16 + 2 * D / 16 + 1 + hh1_split + hh2_mel, mk);
+    if (fold) { mk.hh.tile0 = 0; mk.hh.n_tiles = m1; mk.hh2.n_tiles = 0; }  // W_hh1 row tiles [0, m1); every W_hh2 tile rides in the front launch
+    const int mel_riders = fold ? m1 : hh1_split + hh2_mel;
+    if (f16) TF_LAUNCH16(taco_mel_kernel, r * M / 16 + 2 * D / 16 + 1 + mel_riders, mk);
+    else TF_LAUNCH(taco_mel_kernel, r * M / 16 + 2 * D / 16 + 1 + mel_riders, mk);
 #undef TF_LAUNCH
 #undef TF_LAUNCH16
     MB_HIP(hipGetLastError());
@@ -1861,7 +2073,9 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
   int it_done = 0, rc = MB_OK;
   bool stopped = false;
   if (use_graph) {
-    mb_taco::GraphKey key = {d_memory, d_memory_proj, d_chars, d_dropout, d_mel, d_attn, d_workspace, B, T, max_steps, G, min_stop_token, front ? 1 + hh2_mel + 1024 * diag_int("taco_gru_watch", 1) + 2048 * diag_int("taco_dma_early", 1) + 4096 * diag_int("taco_hh_pairs", 1) + (f16 ? 8192 : 0) : 0};
+    const unsigned variant = !front ? 0u : 1u | (unsigned)hh2_mel << 1 | (unsigned)diag_int("taco_gru_watch", 1) << 10 | (unsigned)diag_int("taco_dma_early", 1) << 11 |
+                                          (unsigned)diag_int("taco_hh_pairs", 1) << 12 | (fold ? 1u : 0u) << 13 | (f16 ? 1u : 0u) << 14 | (unsigned)m1 << 15;
+    mb_taco::GraphKey key = {d_memory, d_memory_proj, d_chars, d_dropout, d_mel, d_attn, d_workspace, B, T, max_steps, G, min_stop_token, (int)variant};
     if (!t->graph_exec || !(key == t->gkey)) {
       t->drop_graph();
       MB_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
@@ -1900,6 +2114,7 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
   *frames_out = t->h_flags[TF_NFRAMES];
   *lost_out = t->h_flags[TF_LOST] != 0;
   t->last_f16 = f16;
+  t->last_form = fold ? 4 : front ? 5 : 7;
   t->last_iters = cdiv(*frames_out, r); t->timed = true;
   if (tr) {
     std::vector<unsigned long long> host((size_t)16 * TS_SLOTS);
@@ -2136,7 +2351,7 @@ extern "C" int mb_taco_last_loop_f16(const mb_taco* t) {
 
 extern "C" int mb_taco_last_loop_form(const mb_taco* t) {
   if (!t || !t->timed) return -1;
-  return t->last_front ? 5 : 7;
+  return t->last_form;
 }
 
 extern "C" int mb_taco_last_loop_ms(const mb_taco* t, float* ms, int* iterations) {

@@ -80,7 +80,7 @@ class TacotronDevice:
         ms, its = C.c_float(), C.c_int()
         if L.mb_taco_last_loop_ms(self._h, C.byref(ms), C.byref(its)) == 0:  # production-dims loop only
             self.last_loop_ms, self.last_loop_iterations = ms.value, its.value
-            self.last_loop_launches_per_iteration = L.mb_taco_last_loop_form(self._h)  # 5: fused front, 7: one launch each
+            self.last_loop_launches_per_iteration = L.mb_taco_last_loop_form(self._h)  # 4: fused front + folded rnn_input, 5: fused front, 7: one launch each
             self.last_loop_f16_products = bool(L.mb_taco_last_loop_f16(self._h) == 1)  # split-f16 products on the K >= 1024 tiles
         return mel[:, :, :F], lin[:, :, :F], attn[:, :F // r]
 

@@ -77,42 +77,51 @@ def test_fast_loop_equals_general_loop(model, monkeypatch):
 
 @pytest.mark.parametrize("B,tmin,tmax", [(32, 60, 100), (7, 20, 30), (17, 130, 150), (1, 12, 12)])
 def test_fused_front_equals_one_launch_each(model, monkeypatch, B, tmin, tmax):
-    """taco_front_kernel (prenet fc2, attention GRU and attention as roles of ONE launch with tagged-granule hand-offs: 5 launches
-    per iteration) against the same three kernels as launches of their own (MBHIP_DIAG=taco_front=0: 7):
-      * MBHIP_DIAG=taco_f16=0 (every product on the fp32 pipe, as in the 7-launch loop) -- the same bits, graph replays and eager
-        tail, injected masks and the on-device Philox stream;
-      * the default (the K = 1024 tile products of the LSTM / rnn_input / mel launches and the hidden-half riders on the fp16 matrix
-        pipe from split images, fm_gemm16) -- the same frames to 1e-4; the oracle bar is checked by the other tests of this file,
-        which run on this form;
+    """The forms of the production-dims decoder loop against the 7-launch loop (MBHIP_DIAG=taco_front=0: one launch per stage, every
+    product on the fp32 pipe):
+      * MBHIP_DIAG=taco_f16=0 -- 5 launches: prenet fc2, attention GRU and attention as roles of ONE launch (taco_front_kernel) with
+        tagged-granule hand-offs, the same arithmetic: the same bits, graph replays and eager tail, injected masks and the Philox stream;
+      * taco_f16=1,taco_fold=0 -- 5 launches with the K >= 1024 tile products on the fp16 matrix pipe (fm_gemm16): the same frames to 1e-4;
+      * taco_f16=1 -- for texts <= 128 symbols additionally WITHOUT the rnn_input launch (4 launches: rnn_input, the next GRU pre-activation
+        and the stop logit's context half folded through a memory projected once per call): the same frames to 1e-4;
+      * the default is the last form wherever it exists (texts <= 128 symbols), the fp16-pipe 5-launch form for longer texts with more
+        than 16 utterances and the fp32 one otherwise; the oracle bar itself is checked by the other tests of this file on the default;
       * a lost hand-off (MBHIP_DIAG=taco_front_lost=1: every wait bails out) makes the call run again with 7 launches."""
     dev, w = model
     chars, spk, _, _ = _batch(B, tmin, tmax, seed=40 + B)
+    T = chars.shape[1]
     with torch.no_grad():
         mem, memp = ot.encoder_memory(w, ot.HP, chars, spk, 0)
     steps = 74  # 37 iterations: two graph replays of 16 + 5 eager
     masks = synth.decoder_dropout_masks(5, steps // 2, B)
-    monkeypatch.setenv("MBHIP_DIAG", "taco_f16=1")  # (the default for more than 16 utterances; forced here for the one-tile kernels too)
-    f = dev.decode(mem.cuda(), memp.cuda(), chars.cuda(), steps, 11.0, dropout=masks)
-    assert dev.last_loop_launches_per_iteration == 5 and dev.last_loop_f16_products
-    fr = dev.decode(mem.cuda(), memp.cuda(), chars.cuda(), steps, 11.0, seed=123)
-    monkeypatch.setenv("MBHIP_DIAG", "taco_f16=0")
-    a = dev.decode(mem.cuda(), memp.cuda(), chars.cuda(), steps, 11.0, dropout=masks)
-    assert dev.last_loop_launches_per_iteration == 5 and not dev.last_loop_f16_products
-    ar = dev.decode(mem.cuda(), memp.cuda(), chars.cuda(), steps, 11.0, seed=123)
-    monkeypatch.setenv("MBHIP_DIAG", "taco_front=0")
-    b = dev.decode(mem.cuda(), memp.cuda(), chars.cuda(), steps, 11.0, dropout=masks)
-    assert dev.last_loop_launches_per_iteration == 7 and not dev.last_loop_f16_products
-    br = dev.decode(mem.cuda(), memp.cuda(), chars.cuda(), steps, 11.0, seed=123)
-    monkeypatch.setenv("MBHIP_DIAG", "taco_front_lost=1")
-    c = dev.decode(mem.cuda(), memp.cuda(), chars.cuda(), steps, 11.0, dropout=masks)
-    assert dev.last_loop_launches_per_iteration == 7
-    monkeypatch.delenv("MBHIP_DIAG")
-    d = dev.decode(mem.cuda(), memp.cuda(), chars.cuda(), steps, 11.0, dropout=masks)
-    assert dev.last_loop_launches_per_iteration == 5  # the provoked loss is not remembered
-    assert dev.last_loop_f16_products == (B > 16)
-    for x, y in list(zip(a, b)) + list(zip(ar, br)) + list(zip(b, c)) + list(zip(f if B > 16 else a, d)):
+
+    def run(diag, **kw):
+        if diag is None:
+            monkeypatch.delenv("MBHIP_DIAG", raising=False)
+        else:
+            monkeypatch.setenv("MBHIP_DIAG", diag)
+        out = dev.decode(mem.cuda(), memp.cuda(), chars.cuda(), steps, 11.0, **kw)
+        return out, dev.last_loop_launches_per_iteration, dev.last_loop_f16_products
+
+    g, ng, hg = run("taco_f16=1", dropout=masks)
+    gr, _, _ = run("taco_f16=1", seed=123)
+    assert ng == (4 if T <= 128 else 5) and hg
+    f, nf, hf = run("taco_f16=1,taco_fold=0", dropout=masks)
+    assert nf == 5 and hf
+    a, na, ha = run("taco_f16=0", dropout=masks)
+    ar, _, _ = run("taco_f16=0", seed=123)
+    assert na == 5 and not ha
+    b, nb, hb = run("taco_front=0", dropout=masks)
+    br, _, _ = run("taco_front=0", seed=123)
+    assert nb == 7 and not hb
+    c, nc, _ = run("taco_front_lost=1", dropout=masks)
+    assert nc == 7
+    d, nd, hd = run(None, dropout=masks)  # the provoked loss is not remembered
+    assert hd == (B > 16 or T <= 128) and nd == (4 if T <= 128 else 5)
+    for x, y in list(zip(a, b)) + list(zip(ar, br)) + list(zip(b, c)) + list(zip(g if hd else a, d)):
         assert torch.equal(x, y)
-    for name, x, y in (("mel", f[0], b[0]), ("linear", f[1], b[1]), ("attn", f[2], b[2]), ("mel_rng", fr[0], br[0])):
+    for name, x, y in (("mel", g[0], b[0]), ("linear", g[1], b[1]), ("attn", g[2], b[2]), ("mel_rng", gr[0], br[0]),
+                       ("mel_5", f[0], b[0]), ("attn_5", f[2], b[2])):
         e = hiputil.relerr(x, y)
         assert x.shape == y.shape and e["nan"] == 0 and e["max_abs"] <= 1e-4, (name, e)
     assert float(a[0].abs().mean()) > 0.1

@@ -12,7 +12,8 @@ from mockingbird_amd.synthesizer.inference import TacotronDevice
 st = synth.tacotron_state(seed=3)["model_state"]
 dev = TacotronDevice(st, torch.device("cuda"))
 out = {}
-VARIANTS = [("default", ""), ("f16", "taco_f16=1"), ("five_f32", "taco_f16=0"), ("seven", "taco_front=0"), ("f16_hh2_mel_64", "taco_f16=1,taco_hh2_mel=64"), ("default_again", "")]
+VARIANTS = [("default", ""), ("five_f16", "taco_f16=1,taco_fold=0"), ("five_f32", "taco_f16=0"), ("seven", "taco_front=0"),
+            ("fold_m1_160", "taco_m1=160"), ("fold_m1_229", "taco_m1=229"), ("default_again", "")]
 SHAPES = ((32, 60, 100), (16, 60, 100), (1, 60, 60), (32, 150, 180))
 if "quick" in sys.argv[2:]:
     SHAPES = SHAPES[:1]

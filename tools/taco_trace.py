@@ -10,6 +10,9 @@ diag_set("taco_trace", out_path)
 SEVEN = "seven" in sys.argv[1:]  # one launch each for fc2 / GRU / attention instead of taco_front_kernel
 if SEVEN:
     diag_set("taco_front", "0")
+FIVE = "five" in sys.argv[1:]   # the fused front without the folded rnn_input (5 launches)
+if FIVE:
+    diag_set("taco_fold", "0")
 import numpy as np, torch, synth
 from mockingbird_amd.synthesizer.inference import TacotronDevice
 st = synth.tacotron_state(seed=3)["model_state"]
@@ -29,6 +32,8 @@ labels = {"lsa": ["start", "loads issued", "B1 (query+cum staged)", "B2 (pq)", "
 res = {}
 wall0 = min(int(r[14]) for r in raw if r[14] > 0)
 for name, r in zip(names, raw):
+    if r[14] == 0:
+        continue  # a launch this form does not have
     lab = labels.get(name, labels["*"])
     marks = [(lab[k], int(r[k])) for k in range(len(lab)) if lab[k] != "-" and r[k] > 0]
     wall = (int(r[14]) - wall0, int(r[15]) - wall0)  # 10 ns ticks
@@ -46,4 +51,4 @@ if not SEVEN:
     res["front_extra_us"] = {"last_attention_workgroup": (int(raw[2][13]) - wall0) * 0.01, "first_hh2_tile_done": (int(raw[0][12]) - wall0) * 0.01,
                              "last_hh2_tile_done": (int(raw[0][13]) - wall0) * 0.01}
     print(res["front_extra_us"])
-json.dump(res, open(os.path.join(ROOT, "gpurun_out", "taco_trace_seven.json" if SEVEN else "taco_trace.json"), "w"), indent=1)
+json.dump(res, open(os.path.join(ROOT, "gpurun_out", "taco_trace_seven.json" if SEVEN else "taco_trace_five.json" if FIVE else "taco_trace.json"), "w"), indent=1)
