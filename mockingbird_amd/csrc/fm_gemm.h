@@ -249,7 +249,7 @@ __device__ __forceinline__ bool fm_gemm16(const uint4* __restrict__ w16, const i
 // non-finite sums = an operand left fp16's range (see above): the launch flags the call for the exact loop
 __device__ __forceinline__ void fm_range_check(const float (&sx)[4], int* lost) {
   const float m = fmaxf(fmaxf(__builtin_fabsf(sx[0]), __builtin_fabsf(sx[1])), fmaxf(__builtin_fabsf(sx[2]), __builtin_fabsf(sx[3])));
-  if (!(m <= 3.0e38f) || !(sx[0] == sx[0]) || !(sx[1] == sx[1]) || !(sx[2] == sx[2]) || !(sx[3] == sx[3])) atomicExch(lost, 1);
+  if (!(m <= 3.0e38f) || !(sx[0] == sx[0]) || !(sx[1] == sx[1]) || !(sx[2] == sx[2]) || !(sx[3] == sx[3])) atomicCAS(lost, 0, 2);  // (2: range event; a timed-out wait's 1 stays)
 }
 
 template <int NT, int NPART> struct FmRed { static constexpr int floats = 8 * NT * NPART * 256; };

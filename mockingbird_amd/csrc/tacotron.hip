@@ -1852,7 +1852,7 @@ int run_conv(const ConvL& c, const float* x, int batch, int t, float* y, long lo
 static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_memory, const float* d_memory_proj, const int32_t* d_chars,
                                int B, int T, int max_steps, float min_stop_token, const float* d_dropout, uint64_t seed, float* d_mel,
                                float* d_attn, bool lsa_fast, size_t lds_lsa, int psplit, void* d_workspace, hipStream_t s, int* frames_out,
-                               bool front, bool* lost_out) {
+                               bool front, int* lost_out) {
   const mb_taco_config& c = t->cfg;
   const int D = c.decoder_dims, P = c.project_dims, H = c.lstm_dims, M = c.n_mels, r = c.r;
   const int nta = cdiv(B, 16), n_iter_max = cdiv(max_steps, r);
@@ -2112,7 +2112,7 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
   MB_HIP(hipMemcpyAsync(t->h_flags, flags, sizeof(int) * 8, hipMemcpyDeviceToHost, s));
   MB_HIP(hipStreamSynchronize(s));
   *frames_out = t->h_flags[TF_NFRAMES];
-  *lost_out = t->h_flags[TF_LOST] != 0;
+  *lost_out = t->h_flags[TF_LOST];  // 0 | 1 (a hand-off timed out) | 2 (an operand left fp16's range)
   t->last_f16 = f16;
   t->last_form = fold ? 4 : front ? 5 : 7;
   t->last_iters = cdiv(*frames_out, r); t->timed = true;
@@ -2127,7 +2127,7 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
 static int taco_fast_loop(mb_taco* t, const TacoLayout& L, const float* d_memory, const float* d_memory_proj, const int32_t* d_chars,
                           int B, int T, int max_steps, float min_stop_token, const float* d_dropout, uint64_t seed, float* d_mel,
                           float* d_attn, bool lsa_fast, size_t lds_lsa, int psplit, void* d_workspace, hipStream_t caller, int* frames_out,
-                          bool front, bool* lost_out) {
+                          bool front, int* lost_out) {
   hipStream_t ls = t->loop_stream;
   MB_HIP(hipEventRecord(t->ev_in, caller));  // the caller's memsets / producers of memory first
   MB_HIP(hipStreamWaitEvent(ls, t->ev_in, 0));
@@ -2211,7 +2211,7 @@ extern "C" int mb_taco_decode(const mb_taco* t, const float* d_memory, const flo
     }
     bool front = lsa_fast && B <= 32 && 2 * D / 16 + D / 4 + B * psplit <= tm->n_cus && !tm->front_failed && diag_int("taco_front", 1) != 0;
     for (;;) {
-      bool lost = false;
+      int lost = 0;
       if (front && diag_int("taco_front_lost")) {  // tests: every wait of the fused launch bails out at its first clock check
         const int one = 1;
         MB_HIP(hipMemcpyAsync(L.flags + TF_LOST, &one, sizeof(int), hipMemcpyHostToDevice, s));
@@ -2221,9 +2221,10 @@ extern "C" int mb_taco_decode(const mb_taco* t, const float* d_memory, const flo
       if (rcf) return rcf;
       tm->last_front = front ? 1 : 0;
       if (!lost) break;
-      // a hand-off inside the fused launch timed out (its workgroups were not co-resident): the call again with three launches
+      // a hand-off inside the fused launch timed out (its workgroups were not co-resident: remembered, the handle stays on the 7-launch
+      // loop) or an operand of the fp16-pipe products left fp16's range (this call only): the call again on the exact loop
       MB_REQUIRE(front, "taco_decode: lost hand-off flag without a fused launch");
-      if (!diag_int("taco_front_lost")) tm->front_failed = true;
+      if (lost == 1 && !diag_int("taco_front_lost")) tm->front_failed = true;
       front = false;
       const int rz = zero_state();
       if (rz) return rz;
