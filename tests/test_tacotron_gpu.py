@@ -28,7 +28,9 @@ def _batch(n, tmin, tmax, seed):
 
 
 @pytest.mark.parametrize("B,tmin,tmax,steps,style", [(3, 20, 30, 40, -1), (5, 33, 47, 60, 0), (1, 12, 12, 24, 3),
-                                                     (20, 20, 30, 36, -1), (40, 15, 25, 24, 0)])
+                                                     (20, 20, 30, 36, -1), (40, 15, 25, 24, 0),
+                                                     # the edges of the 4-launch form: a full 128-symbol window, one symbol more (5 launches)
+                                                     (9, 127, 127, 40, 0), (18, 128, 128, 40, -1), (32, 96, 112, 40, 0)])  # (+ EOS: T = 128, 129, <= 113)
 def test_decode_and_postnet_match_oracle(model, B, tmin, tmax, steps, style):
     dev, w = model
     chars, spk, _, _ = _batch(B, tmin, tmax, seed=B)
