@@ -22,7 +22,8 @@ __host__ __device__ __forceinline__ size_t fm_index(int nta, int n, int k) {
 
 // diagnostics (MBHIP_DIAG=taco_trace=<file>): shader-clock stamps of one workgroup per kernel, 16 marks per kernel slot;
 // mark 14 / 15 = 100 MHz wall clock at kernel start / end (aligns the kernels of an iteration with each other)
-enum { TS_FC2 = 0, TS_GRU = 1, TS_LSA = 2, TS_RIN = 3, TS_LSTM1 = 4, TS_LSTM2 = 5, TS_MEL = 6, TS_MEL_FC1 = 7, TS_MEL_STOP = 8, TS_SLOTS = 9 };
+enum { TS_FC2 = 0, TS_GRU = 1, TS_LSA = 2, TS_RIN = 3, TS_LSTM1 = 4, TS_LSTM2 = 5, TS_MEL = 6, TS_MEL_FC1 = 7, TS_MEL_STOP = 8, TS_SLOTS = 9,
+       TS_WG = 16 * TS_SLOTS, TS_WORDS = TS_WG + 2 * 128 };  // [TS_WG + 2 l], [.. + 1]: query-arrival and end wall clock of attention workgroup l of the fused launch
 __device__ __forceinline__ void tf_mark(unsigned long long* tr, int slot, int k, bool pick) {
   if (tr && pick && threadIdx.x == 0) {
     tr[slot * 16 + k] = (unsigned long long)clock64();

@@ -25,7 +25,9 @@ mem, memp = dev.encode(chars, spk, -1, None, 1)
 for _ in range(3):
     dev.decode(mem, memp, chars, 400, 11, seed=1)
 torch.cuda.synchronize()
-raw = np.fromfile(out_path, dtype=np.uint64).reshape(-1, 16).astype(np.int64)
+flat = np.fromfile(out_path, dtype=np.uint64).astype(np.int64)
+raw = flat[:16 * 9].reshape(-1, 16)
+wg = flat[16 * 9:].reshape(-1, 2) if flat.size > 16 * 9 else None
 names = ["fc2", "gru", "lsa", "rin", "lstm1", "lstm2", "mel", "mel_fc1", "mel_stop"]
 labels = {"lsa": ["start", "loads issued", "B1 (query+cum staged)", "B2 (pq)", "-", "B3 (energies)", "B4 (softmax)", "B5 (context partials)", "end"],
           "*": ["start", "loads issued", "wave0 MFMAs done", "reduction barrier", "end"]}
@@ -47,6 +49,13 @@ for name, r in zip(names, raw):
 res["rider_marks_us"] = {"rin_last_rider": (int(raw[3][13]) - wall0) * 0.01, "rin_last_pre_tile": (int(raw[3][12]) - wall0) * 0.01,
                          "rin_stop_tile": (int(raw[3][11]) - wall0) * 0.01, "mel_last_rider": (int(raw[6][13]) - wall0) * 0.01}
 print(res["rider_marks_us"])
+if not SEVEN and wg is not None:
+    q = [(int(x[0]) - wall0) * 0.01 for x in wg if x[0] > 0]; e = [(int(x[1]) - wall0) * 0.01 for x in wg if x[1] > 0]
+    if q and e:
+        res["attention_workgroups_us"] = {"query_arrival_min_max": [min(q), max(q)], "end_min_max": [min(e), max(e)],
+                                          "end_by_group_of_32": [round(float(np.mean(e[i:i + 32])), 2) for i in range(0, len(e), 32)],
+                                          "latest_8": sorted(range(len(e)), key=lambda i: -e[i])[:8]}
+        print(res["attention_workgroups_us"])
 if not SEVEN:
     res["front_extra_us"] = {"last_attention_workgroup": (int(raw[2][13]) - wall0) * 0.01, "first_hh2_tile_done": (int(raw[0][12]) - wall0) * 0.01,
                              "last_hh2_tile_done": (int(raw[0][13]) - wall0) * 0.01}
