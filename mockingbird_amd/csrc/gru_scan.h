@@ -83,6 +83,7 @@ __global__ __launch_bounds__(NW * 64) void gru_scan_kernel(GruScanK a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int dir = blockIdx.x / G, g = blockIdx.x - dir * G;
+  const int c0 = blockIdx.y * NC;  // column group (round 5: a batch of 32 as two groups of one tile each, side by side -- see gru_scan_launch)
   const int u0 = g * UW + wave * 16;
   const int row = lane & 15, kq = lane >> 4;
   if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(NW * 64) void gru_scan_kernel(GruScanK a) {
   // (unconditional) stores rewrite what column B - 1 writes.
   int cl[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) cl[nt] = min(nt * 16 + col, a.B - 1);
+  for (int nt = 0; nt < NT; ++nt) cl[nt] = min(c0 + nt * 16 + col, a.B - 1);
   // x half of a (step, column tile), with b_ih: three gate quads
   auto load_x = [&](float4 (&x)[3], const int nt, const int s) {
     const int sc = min(s, a.F - 1);
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(NW * 64) void gru_scan_kernel(GruScanK a) {
   constexpr int RQ = G > 1 ? (G - 1) * 16 / CPI : 1;  // granules per lane and phase
   unsigned long long vq[RQ];                          // the poll's loads: issued a phase ahead (below), consumed at the phase start
   auto poll_issue = [&](const int nt, const int s) {  // remote units of h(s-1) of tile nt: parity (s-1) & 1
-    const unsigned long long* ep = exd + ((size_t)((s - 1) & 1) * 32 + nt * 16 + tid / UW) * Hg + (tid % UW);
+    const unsigned long long* ep = exd + ((size_t)((s - 1) & 1) * 32 + c0 + nt * 16 + tid / UW) * Hg + (tid % UW);
 #pragma unroll
     for (int rw = 0; rw < G - 1; ++rw)
 #pragma unroll
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(NW * 64) void gru_scan_kernel(GruScanK a) {
       // ---- publish: the wave reads its 16 units x 16 columns back from LDS (its own writes: program order) so that ONE store
       //      instruction covers whole 128-byte lines (16 consecutive lanes = the wave's 16 units of a column); pieces of a line
       //      written by several instructions become visible one after the other (ppg_resident.h) ----
-      unsigned long long* ew = exd + ((size_t)par * 32 + nt * 16) * Hg + u0 + (lane & 15);
+      unsigned long long* ew = exd + ((size_t)par * 32 + c0 + nt * 16) * Hg + u0 + (lane & 15);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int cc = q * 4 + (lane >> 4);
@@ -324,7 +325,7 @@ static inline void gru_scan_mark_failed() {
 }
 
 template <int KS, int NT, int NW>
-static int gru_scan_launch_inst(const GruScanK& k, hipStream_t s) {
+static int gru_scan_launch_inst(const GruScanK& k, hipStream_t s, int groups = 1) {
   const size_t lds = (size_t)2 * 2 * (NT * 16) * (KS * 32 + 8) * sizeof(gs_h16);
   // the attribute belongs to the function ON THE CURRENT DEVICE: tracked per device (a process-wide flag left a second
   // device's first launch without it), atomically (two host threads may encode at once; setting it twice is harmless)
@@ -336,15 +337,19 @@ static int gru_scan_launch_inst(const GruScanK& k, hipStream_t s) {
     MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_scan_kernel<KS, NT, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     attr_done.fetch_or(bit, std::memory_order_release);
   }
-  hipLaunchKernelGGL((gru_scan_kernel<KS, NT, NW>), dim3(2 * (KS * 32) / (NW * 16)), dim3(NW * 64), lds, s, k);
+  hipLaunchKernelGGL((gru_scan_kernel<KS, NT, NW>), dim3(2 * (KS * 32) / (NW * 16), groups), dim3(NW * 64), lds, s, k);
   MB_HIP(hipGetLastError());
   return MB_OK;
 }
 
 static int gru_scan_launch(const GruScanK& k, hipStream_t s) {
   const int nt = (k.B + 15) / 16;
-  if (k.Hg == 128) return nt == 1 ? gru_scan_launch_inst<4, 1, 8>(k, s) : gru_scan_launch_inst<4, 2, 8>(k, s);
-  return nt == 1 ? gru_scan_launch_inst<8, 1, 4>(k, s) : gru_scan_launch_inst<8, 2, 4>(k, s);
+  // 17..32 utterances: two column tiles.  As two PHASES of one workgroup set (NT = 2: a tile's hand-off rides under the other tile's
+  // products) or as two workgroup sets side by side (NT = 1, grid.y = 2: the scan uses 4 / 16 of 256 compute units instead of 2 / 8;
+  // MBHIP_DIAG=gs_split=0 keeps the phases) -- the sequences of different utterances never meet
+  const bool split = nt == 2 && diag_int("gs_split", 1) != 0;
+  if (k.Hg == 128) return nt == 1 ? gru_scan_launch_inst<4, 1, 8>(k, s) : split ? gru_scan_launch_inst<4, 1, 8>(k, s, 2) : gru_scan_launch_inst<4, 2, 8>(k, s);
+  return nt == 1 ? gru_scan_launch_inst<8, 1, 4>(k, s) : split ? gru_scan_launch_inst<8, 1, 4>(k, s, 2) : gru_scan_launch_inst<8, 2, 4>(k, s);
 }
 
 }  // namespace mb
