@@ -106,8 +106,7 @@ __global__ __launch_bounds__(512) void taco_gru_kernel(TfGruK a) {
 // kernel argument is loaded as one vector, parked in a private array and promoted to LDS -- and a kernel with a promoted array reads
 // its workgroup size from the dispatch packet in host memory at the start of EVERY workgroup: 80 ns per workgroup, 20 us per launch.)
 struct TfHhK { const float* w; const float* h; float4* hpre; int n_tiles, tile0; const uint4* w16 = nullptr; float unscale = 1.f; };  // row tiles [tile0, tile0 + n_tiles)
-// (F16 is a compile-time choice: with both products behind a run-time test the register allocator gave up the all-loads-in-flight
-//  schedule of either -- taco_rin / taco_mel went from 8 / 7 to 19 / 18 us)
+// (F16 is a compile-time choice: the fp32 kernels stay the code they were)
 template <int NT, bool F16 = false>
 __device__ __forceinline__ void fm_hh_job(const TfHhK& a, const int mt_local, const int nt0, const int nta, const int done, float* red, int* lost = nullptr) {
   const int mt = a.tile0 + mt_local;
