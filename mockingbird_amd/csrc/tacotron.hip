@@ -1974,7 +1974,7 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
       TfFrontX fx;
       fx.p2g = L.f_p2g; fx.ahg = L.f_ahg; fx.lost = flags + TF_LOST; fx.n_fc2 = 2 * D / 16; fx.n_gru = D / 4; fx.watch = diag_int("taco_gru_watch", 1);
       fx.hh_pairs = f16 ? 0 : diag_int("taco_hh_pairs", 1);  // (fp16-pipe riders are short enough to come one tile per workgroup)
-      lk.dma_early = diag_int("taco_dma_early", 1);
+      lk.dma_early = diag_int("taco_dma_early", nta >= 2 ? 1 : 0);  // (one column tile: 29.2 against 30.0 us per iteration with the DMA behind B2)
       lk.q_gran = L.f_ahg; lk.lost = flags + TF_LOST; lk.e_gran = L.f_eg;
       if (fold) {
         lk.fold = 1; lk.memory = L.pm; lk.mem_ld = TACO_PM_LD; lk.context = L.f_x;
@@ -2078,7 +2078,7 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
   int it_done = 0, rc = MB_OK;
   bool stopped = false;
   if (use_graph) {
-    const unsigned variant = !front ? 0u : 1u | (unsigned)hh2_mel << 1 | (unsigned)diag_int("taco_gru_watch", 1) << 10 | (unsigned)diag_int("taco_dma_early", 1) << 11 |
+    const unsigned variant = !front ? 0u : 1u | (unsigned)hh2_mel << 1 | (unsigned)diag_int("taco_gru_watch", 1) << 10 | (unsigned)diag_int("taco_dma_early", nta >= 2 ? 1 : 0) << 11 |
                                           (unsigned)diag_int("taco_hh_pairs", 1) << 12 | (fold ? 1u : 0u) << 13 | (f16 ? 1u : 0u) << 14 | (unsigned)m1 << 15;
     mb_taco::GraphKey key = {d_memory, d_memory_proj, d_chars, d_dropout, d_mel, d_attn, d_workspace, B, T, max_steps, G, min_stop_token, (int)variant};
     if (!t->graph_exec || !(key == t->gkey)) {

@@ -12,8 +12,8 @@ from mockingbird_amd.synthesizer.inference import TacotronDevice
 st = synth.tacotron_state(seed=3)["model_state"]
 dev = TacotronDevice(st, torch.device("cuda"))
 out = {}
-VARIANTS = [("default", ""), ("five_f16", "taco_f16=1,taco_fold=0"), ("five_f32", "taco_f16=0"), ("seven", "taco_front=0"),
-            ("fold_m1_160", "taco_m1=160"), ("fold_m1_229", "taco_m1=229"), ("default_again", "")]
+VARIANTS = [("default", ""), ("no_gru_watch", "taco_gru_watch=0"), ("dma_late", "taco_dma_early=0"), ("five_f16", "taco_f16=1,taco_fold=0"), ("five_f32", "taco_f16=0"),
+            ("seven", "taco_front=0"), ("fold_m1_160", "taco_m1=160"), ("fold_m1_229", "taco_m1=229"), ("default_again", "")]
 SHAPES = ((32, 60, 100), (16, 60, 100), (1, 60, 60), (32, 150, 180))
 if "quick" in sys.argv[2:]:
     SHAPES = SHAPES[:1]
