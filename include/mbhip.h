@@ -520,6 +520,13 @@ int mb_taco_last_loop_ms(const mb_taco* t, float* ms, int* iterations);
  *  -1 = no decode on that loop yet. */
 int mb_taco_last_loop_form(const mb_taco* t);
 
+/* Host logic only (no device access): THE selection of that loop's form -- (batch, text length, whether the fast attention kernel serves
+ * the call (production dims, <= 192 symbols), compute units of the device, whether the handle has its fp16 images / projection weights,
+ * the handle's lost-hand-off memo, MBHIP_DIAG taco_front / taco_f16 / taco_fold as -1 (unset) | 0 | 1) -> 4 | 5 | 7 launches per iteration,
+ * *f16_out (may be null) = the fp16-pipe products.  mb_taco_decode calls the same function (csrc/tacotron.hip taco_pick_form; the table is
+ * its header comment and tests/test_host_logic.py::test_taco_loop_form_table). */
+int mb_taco_loop_form(int batch, int t_text, int lsa_fast, int n_cus, int images, int front_failed, int front_sw, int f16_sw, int fold_sw, int* f16_out);
+
 /* 1 when the last mb_taco_decode call on that loop multiplied its K >= 1024 tiles (LSTM input halves, rnn_input, mel_proj / prenet fc1' /
  * stop rows, hidden halves) on the fp16 matrix pipe with error-compensated split operands (w 2^s = wh + wl, x = xh + 2^-11 xl: 22-bit
  * operands, fp32 accumulate -- the 4-launch form, and the 5-launch form with more than 16 utterances; a value beyond fp16's range makes

@@ -245,6 +245,7 @@ SIGNATURES = {
     "mb_taco_last_loop_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "mb_taco_last_loop_form": (C.c_int, [C.c_void_p]),
     "mb_taco_last_loop_f16": (C.c_int, [C.c_void_p]),
+    "mb_taco_loop_form": (C.c_int, [C.c_int] * 9 + [C.POINTER(C.c_int)]),
     "mb_taco_encode_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "mb_taco_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                  C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

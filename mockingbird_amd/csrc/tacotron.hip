@@ -1853,6 +1853,30 @@ int run_conv(const ConvL& c, const float* x, int batch, int t, float* y, long lo
 }
 }  // namespace
 
+// THE selection of the production-dims decoder loop's form (exported as mb_taco_loop_form for the host-logic test):
+//   batch, t_text   the call;  lsa_fast: the fast attention kernel serves it (production dims, t_text <= 192, no MBHIP_LSA_GENERIC)
+//   n_cus           compute units of the device;  images: the fp16 images / projection weights exist (production handles: yes)
+//   front_failed    a hand-off of the fused launch timed out on this handle before
+//   front_sw / f16_sw / fold_sw   MBHIP_DIAG taco_front / taco_f16 / taco_fold: -1 = unset, 0, 1
+// -> launches per iteration: 7 (one launch per stage, fp32 pipe) | 5 (taco_front_kernel) | 4 (+ rnn_input folded into the attention role);
+//    *f16 = the K >= 1024 tile products run on the fp16 matrix pipe (fm_gemm16).
+// | t_text     | batch <= 16                  | 17..32                       | > 32 (or too few compute units, or front_failed) |
+// | <= 128     | 4 launches, fp16 products    | 4 launches, fp16 products    | 7 launches, fp32                                 |
+// | 129..192   | 5 launches, fp32 products    | 5 launches, fp16 products    | 7 launches, fp32                                 |
+// | > 192      | 7 launches, fp32 (general attention kernel)                                                                    |
+static int taco_pick_form(int batch, int t_text, int lsa_fast, int n_cus, int images, int front_failed, int front_sw, int f16_sw, int fold_sw, int* f16_out) {
+  const int nta = (batch + 15) / 16;
+  const bool front = lsa_fast && batch >= 1 && batch <= 32 && 16 + 32 + 4 * batch <= n_cus && !front_failed && front_sw != 0;
+  const bool foldable = front && t_text <= 128 && images;
+  const bool f16 = front && images && (f16_sw < 0 ? (nta >= 2 || (foldable && fold_sw != 0)) : f16_sw != 0);
+  const bool fold = foldable && (fold_sw < 0 ? f16 : fold_sw != 0);
+  if (f16_out) *f16_out = f16 ? 1 : 0;
+  return fold ? 4 : front ? 5 : 7;
+}
+extern "C" int mb_taco_loop_form(int batch, int t_text, int lsa_fast, int n_cus, int images, int front_failed, int front_sw, int f16_sw, int fold_sw, int* f16_out) {
+  return taco_pick_form(batch, t_text, lsa_fast, n_cus, images, front_failed, front_sw, f16_sw, fold_sw, f16_out);
+}
+
 // ---- fast decoder loop (taco_fast.h): 7 launches per iteration, hipGraph-captured, stop flag polled one replay behind ----
 static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_memory, const float* d_memory_proj, const int32_t* d_chars,
                                int B, int T, int max_steps, float min_stop_token, const float* d_dropout, uint64_t seed, float* d_mel,
@@ -1879,11 +1903,11 @@ static int taco_fast_loop_body(mb_taco* t, const TacoLayout& L, const float* d_m
   // folded form (4 launches per iteration): rnn_input, the next GRU pre-activation and the stop logit's context half are linear in the
   // context = sum_t score_t memory_t, so with the memory rows projected ONCE per call (a 1 x 1 conv on the split-fp16 path,
   // conv1d.hip) the attention workgroups produce them directly and the rnn_input launch is gone
-  const int f16_sw = diag_int("taco_f16", -1), fold_sw = diag_int("taco_fold", -1);
-  const bool f16 = front && t->i_l1x.w.p && (f16_sw < 0 ? (nta >= 2 || (T <= 128 && t->pm_conv.w.p && fold_sw != 0)) : f16_sw != 0);  // (below)
-  // (T <= 128: the attention's LDS window form.  By default only together with the fp16-pipe riders: the rnn_input launch is also
-  //  where 128 hidden-half tiles rode, and only the short riders fit the front / mel launches without a second round)
-  const bool fold = front && T <= 128 && t->pm_conv.w.p && (fold_sw < 0 ? f16 : fold_sw != 0);
+  // (taco_pick_form.  T <= 128: the attention's LDS window form; by default only together with the fp16-pipe riders: the rnn_input
+  //  launch is also where 128 hidden-half tiles rode, and only the short riders fit the front / mel launches without a second round)
+  int f16_i = 0;
+  const int form = !front ? 7 : taco_pick_form(B, T, 1, t->n_cus, t->i_l1x.w.p && t->pm_conv.w.p ? 1 : 0, 0, 1, diag_int("taco_f16", -1), diag_int("taco_fold", -1), &f16_i);
+  const bool f16 = front && f16_i != 0, fold = form == 4;
   if (fold) {
     hipLaunchKernelGGL(btc_to_bct_kernel, dim3(cdiv(P, 32), cdiv(T, 32), B), dim3(256), 0, s, d_memory, L.memT, T, P);
     MB_HIP(hipGetLastError());
@@ -2214,7 +2238,7 @@ extern "C" int mb_taco_decode(const mb_taco* t, const float* d_memory, const flo
       MB_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
       tm->n_cus = ncu;
     }
-    bool front = lsa_fast && B <= 32 && 2 * D / 16 + D / 4 + B * psplit <= tm->n_cus && !tm->front_failed && diag_int("taco_front", 1) != 0;
+    bool front = taco_pick_form(B, T, lsa_fast ? 1 : 0, tm->n_cus, 1, tm->front_failed ? 1 : 0, diag_int("taco_front", -1), 0, 0, nullptr) != 7;
     for (;;) {
       int lost = 0;
       if (front && diag_int("taco_front_lost")) {  // tests: every wait of the fused launch bails out at its first clock check

@@ -279,6 +279,34 @@ def test_wavernn_loop_path_table(lib):
         assert f(*row[:7]) == row[7], row
 
 
+def test_taco_loop_form_table(lib):
+    """The ONE selection function of the production-dims Tacotron decoder loop (csrc/tacotron.hip taco_pick_form, exported as
+    mb_taco_loop_form): (batch, text length, fast attention kernel, compute units, images, lost-hand-off memo, MBHIP_DIAG taco_front /
+    taco_f16 / taco_fold) -> launches per iteration and whether the K >= 1024 tiles multiply on the fp16 pipe."""
+    import ctypes as C
+    U = -1
+    #        batch T   lsa cus img failed front f16 fold -> (launches, f16)
+    table = [
+        (32, 101, 1, 256, 1, 0, U, U, U, (4, 1)), (16, 96, 1, 256, 1, 0, U, U, U, (4, 1)), (1, 12, 1, 256, 1, 0, U, U, U, (4, 1)),      # <= 128 symbols: the folded form
+        (32, 128, 1, 256, 1, 0, U, U, U, (4, 1)), (32, 129, 1, 256, 1, 0, U, U, U, (5, 1)), (17, 192, 1, 256, 1, 0, U, U, U, (5, 1)),   # 129..192: the LDS window is gone
+        (16, 129, 1, 256, 1, 0, U, U, U, (5, 0)), (1, 192, 1, 256, 1, 0, U, U, U, (5, 0)),                                              # ... and one column tile stays on the fp32 pipe
+        (32, 193, 0, 256, 1, 0, U, U, U, (7, 0)), (32, 640, 0, 256, 1, 0, U, U, U, (7, 0)),                                             # the general attention kernel
+        (33, 101, 1, 256, 1, 0, U, U, U, (7, 0)), (64, 101, 1, 256, 1, 0, U, U, U, (7, 0)), (0, 101, 1, 256, 1, 0, U, U, U, (7, 0)),    # more than two column tiles
+        (32, 101, 1, 175, 1, 0, U, U, U, (7, 0)), (32, 101, 1, 176, 1, 0, U, U, U, (4, 1)), (8, 101, 1, 80, 1, 0, U, U, U, (4, 1)),     # 48 + 4 batch co-resident workgroups
+        (32, 101, 1, 256, 1, 1, U, U, U, (7, 0)), (32, 101, 1, 256, 1, 1, 1, U, U, (7, 0)),                                             # a lost hand-off is remembered
+        (32, 101, 1, 256, 1, 0, 0, U, U, (7, 0)), (32, 101, 1, 256, 1, 0, 0, 1, 1, (7, 0)),                                             # taco_front=0
+        (32, 101, 1, 256, 1, 0, U, 0, U, (5, 0)), (16, 101, 1, 256, 1, 0, U, 0, U, (5, 0)),                                             # taco_f16=0: no short riders, no fold
+        (32, 101, 1, 256, 1, 0, U, U, 0, (5, 1)), (16, 101, 1, 256, 1, 0, U, U, 0, (5, 0)),                                             # taco_fold=0
+        (32, 101, 1, 256, 1, 0, U, 0, 1, (4, 0)), (16, 150, 1, 256, 1, 0, U, 1, U, (5, 1)), (16, 150, 1, 256, 1, 0, U, 1, 1, (5, 1)),   # forced combinations (A/B only)
+        (32, 101, 1, 256, 0, 0, U, U, U, (5, 0)), (32, 101, 1, 256, 0, 0, U, 1, 1, (5, 0)),                                             # a handle without the images
+    ]
+    for row in table:
+        f16 = C.c_int(-1)
+        got = lib.mb_taco_loop_form(*row[:9], C.byref(f16))
+        assert (got, f16.value) == row[9], row
+    assert lib.mb_taco_loop_form(32, 101, 1, 256, 1, 0, U, U, U, None) == 4  # the flag is optional
+
+
 def test_switch_inventory_is_small_and_documented():
     """the library reads at most 20 environment switches and DESIGN.md's table names every one of them (a switch
     that is not documented -- or not tested: tests/test_env_switches_gpu.py and the tests named in the table -- does not stay)."""
