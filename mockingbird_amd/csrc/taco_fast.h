@@ -23,6 +23,10 @@
 //     GRU context/hidden pre-activations | LSTM1 | LSTM2 | mel_proj beside the next iteration's prenet fc1 (folded
 //     through mel_proj: fc1 . mel_proj[last frame], exact algebra) and the stop token + batch-wide stop rule.
 //     7 launches, captured in a hipGraph (iteration index, seed and flags live in device memory).
+//   * round 5 (tacotron.hip taco_front_kernel, fm_gemm.h fm_gemm16): launches 1..3 as ROLES of one launch with tagged-granule
+//     hand-offs, rnn_input folded into the attention role through a memory projected once per call (texts <= 128 symbols), the K >= 1024
+//     tile products of what remains -- LSTM 1 | LSTM 2 | mel_proj + fc1' + stop, and the hidden-half riders -- on the fp16 matrix pipe
+//     with split operands: 4 launches per iteration (taco_pick_form chooses among 4 / 5 / 7); the kernels below are the jobs of all forms.
 // Reference arithmetic: models/synthesizer/models/tacotron.py:71-138, sublayer/pre_net.py:21-26, torch GRUCell /
 // LSTMCell gate orders as in rnn_body.h.
 #pragma once
