@@ -237,6 +237,38 @@ int mb_resblock_stage_f32_pack(const float* const* h_w1, const float* const* h_w
                                int num_dilations, uint16_t* h_packed, float* h_unscale);
 int mb_resblock_stage_f32(const mb_resblock_stage_f16_args* a, mb_stream_t stream);
 
+/* Round 6 -- the fused ResBlock unit at the REFERENCE's precision on TIME-major fp32 tensors (resblock_pair_split.hip):
+ *   y = (accumulate ? y : 0) + out_scale * (x + conv2(lrelu(conv1(lrelu(x)) + b1)) + b2)
+ * = one (convs1[i], convs2[i]) iteration of ResBlock1.forward (models/vocoder/hifigan/models.py:39-46,
+ * models/vocoder/fregan/generator.py:43-50; vits.py:251 builds the same block) in ONE launch: d_x / d_y are fp32 [B][t][channels]
+ * (every staged load 16 bytes, no transposition), the intermediate h stays in LDS, the products are the error-compensated fp16 MFMA
+ * triple of section 1 (w 2^s = wh + wl, a = ah + 2^-11 al: fp32-grade sums), the residual chain stays fp32.  This is what the fp32
+ * generators' ResBlocks run on since round 6 (gan.hip: channel-major tensors are turned once per stage, mb_f32_cm_to_tm / _tm_to_cm).
+ * Supported: channels in {16,32,64,128,256}, k odd >= 3, the tile must fit LDS (mb_resblock_pair_split_supported). */
+int mb_resblock_pair_split_supported(int channels, int ksize, int dilation);
+size_t mb_resblock_pair_split_packed_halves(int channels, int ksize);
+/* h_w1, h_w2: fp32 torch Conv1d weights [C][C][k], weight norm folded -> one stream of {hi, lo} fp16 A fragments per 32-row output
+ * tile in consumption order; h_unscale[2] = 2^-s of conv1 / conv2 (pass them back as unscale1 / unscale2) */
+int mb_resblock_pair_split_pack(const float* h_w1, const float* h_w2, int channels, int ksize, uint16_t* h_packed, float* h_unscale);
+typedef struct mb_resblock_pair_split_args {
+  const float* d_x;       /* fp32 [B][t][channels]                                */
+  float* d_y;             /* fp32 [B][t][channels], must not alias d_x            */
+  const void* d_wpacked;  /* image from mb_resblock_pair_split_pack               */
+  const float* d_b1;      /* fp32 [channels] bias of conv1                        */
+  const float* d_b2;      /* fp32 [channels] bias of conv2                        */
+  int batch, channels, t;
+  int ksize, dilation;    /* conv1 dilation; conv2 has dilation 1                 */
+  float slope;            /* leaky_relu slope in (0,1), applied before both convs */
+  float out_scale;        /* 0 = 1.0                                              */
+  float unscale1, unscale2; /* h_unscale[0], h_unscale[1] of the pack             */
+  int accumulate;
+  const int* d_valid; int valid_mul;  /* ragged batches: item b has d_valid[b] * valid_mul positions (NULL = t) */
+} mb_resblock_pair_split_args;
+int mb_resblock_pair_split(const mb_resblock_pair_split_args* a, mb_stream_t stream);
+/* fp32 [B][channels][t] (the reference's layout) <-> fp32 [B][t][channels] (the layout above), out of place */
+int mb_f32_cm_to_tm(const float* d_x, float* d_y, int batch, int channels, int t, mb_stream_t stream);
+int mb_f32_tm_to_cm(const float* d_x, float* d_y, int batch, int channels, int t, mb_stream_t stream);
+
 /* Layout/precision converters between the reference's [B][C][T] fp32 tensors and the
  * time-major fp16 activations above (mel upload; tests). */
 int mb_f32_to_f16_tm(const float* d_x, void* d_y, int batch, int channels, int t, mb_stream_t stream);

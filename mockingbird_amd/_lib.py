@@ -103,6 +103,15 @@ class GanConfig(C.Structure):
     ]
 
 
+class ResPairSplitArgs(C.Structure):
+    _fields_ = [
+        ("d_x", C.c_void_p), ("d_y", C.c_void_p), ("d_wpacked", C.c_void_p), ("d_b1", C.c_void_p), ("d_b2", C.c_void_p),
+        ("batch", C.c_int), ("channels", C.c_int), ("t", C.c_int), ("ksize", C.c_int), ("dilation", C.c_int),
+        ("slope", C.c_float), ("out_scale", C.c_float), ("unscale1", C.c_float), ("unscale2", C.c_float),
+        ("accumulate", C.c_int), ("d_valid", C.c_void_p), ("valid_mul", C.c_int),
+    ]
+
+
 class WaveRNNConfig(C.Structure):
     _fields_ = [
         ("rnn_dims", C.c_int), ("fc_dims", C.c_int), ("bits", C.c_int), ("pad", C.c_int),
@@ -156,6 +165,12 @@ SIGNATURES = {
     "mb_resblock_pair_f16_packed_halves": (C.c_size_t, [C.c_int] * 2),
     "mb_resblock_pair_f16_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "mb_resblock_pair_f16": (C.c_int, [C.POINTER(ResPairF16Args), C.c_void_p]),
+    "mb_resblock_pair_split_supported": (C.c_int, [C.c_int] * 3),
+    "mb_resblock_pair_split_packed_halves": (C.c_size_t, [C.c_int] * 2),
+    "mb_resblock_pair_split_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "mb_resblock_pair_split": (C.c_int, [C.POINTER(ResPairSplitArgs), C.c_void_p]),
+    "mb_f32_cm_to_tm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mb_f32_tm_to_cm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mb_resblock_stage_f16_supported": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "mb_resblock_stage_f16_efficiency": (C.c_float, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "mb_resblock_stage_f16_packed_halves": (C.c_size_t, [C.c_int, C.c_int, C.c_void_p, C.c_int]),

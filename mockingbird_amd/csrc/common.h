@@ -50,6 +50,9 @@ int diag_int(const char* key, int absent = 0);
 // value of a documented path switch (plain MBHIP_* variable) as an int; `absent` when unset
 int env_int(const char* name, int absent);
 
+// the device word MBHIP_CONV_RANGE_CHECK=1 counts out-of-range staged values in (conv1d.hip; null when the check is off)
+unsigned* conv_range_word();
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -589,6 +589,8 @@ static unsigned* range_word() {
   return g_range_word[dev];
 }
 
+namespace mb { unsigned* conv_range_word() { return range_word(); } }
+
 extern "C" long long mb_conv1d_range_events(int reset) {
   int dev = 0;
   MB_HIP(hipGetDevice(&dev));

@@ -152,6 +152,10 @@ struct mb_gan {
   struct S32Launch { int u0, nu; DevBuf w, b; };
   std::vector<DevBuf> s32_w, s32_b;
   std::vector<std::vector<S32Launch>> r32;  // [stage * num_kernels + kernel]
+  // fp32 path (round 6, resblock_pair_split.hip): the ResBlock units on TIME-major fp32 tensors, one launch per (convs1[d], convs2[d]);
+  // indexed as `pairs`; a stage whose units all have an image runs time-major (turned once in, once out), the others keep the plan above
+  struct SPair { DevBuf w; float us1 = 0.f, us2 = 0.f; };
+  std::vector<SPair> spairs;
   int hop;
   // indices into convs
   int i_pre, i_ups, i_cond, i_resout, i_rb, i_post;
@@ -230,12 +234,39 @@ extern "C" int mb_gan_create_ex(const mb_gan_config* cfg, const float* const* h_
   // none (one launch per conv): the fallbacks the parity tests compare the fused launches with
   const char* fenv = getenv("MBHIP_GAN_FUSE");
   const std::string fuse = fenv ? fenv : "all";
-  if (!(fuse == "all" || fuse == "nochain" || fuse == "units" || fuse == "none")) {
-    set_error("MBHIP_GAN_FUSE: unknown value '%s' (all | nochain | units | none)", fuse.c_str());
+  if (!(fuse == "all" || fuse == "nochain" || fuse == "units" || fuse == "none" || fuse == "cm")) {
+    set_error("MBHIP_GAN_FUSE: unknown value '%s' (all | nochain | units | none | cm)", fuse.c_str());
     mb_gan_destroy(g);
     return MB_EINVAL;
   }
+  // (cm: the fp32 path's channel-major plan of rounds 4-5 -- resblock_stage_f32 launches + one launch per wide conv -- instead of the
+  //  time-major split pairs; on the fp16 path it reads as "all")
   const bool no_fuse = fuse == "none", no_stage = no_fuse || fuse == "units", no_chain = no_stage || fuse == "nochain";
+  const bool f32_cm = fuse == "cm";
+  if (dtype == MB_F32 && !no_fuse && !f32_cm) {
+    const int nd = cfg->num_dilations;
+    g->spairs.resize((size_t)cfg->num_upsamples * cfg->num_kernels * nd);
+    std::vector<float> img;
+    for (int i = 0; i < cfg->num_upsamples; ++i)
+      for (int j = 0; j < cfg->num_kernels; ++j)
+        for (int d = 0; d < nd; ++d) {
+          const int base = g->i_rb + ((i * cfg->num_kernels + j) * nd) * 2;
+          const ConvSpec& s1 = v[base + d];
+          const ConvSpec& s2 = v[base + nd + d];
+          if (s1.c_in != s1.c_out || s2.c_in != s1.c_in || s2.c_out != s1.c_in || s1.k != s2.k || s2.dil != 1 ||
+              s1.transposed || s2.transposed || s1.pad != s1.dil * (s1.k - 1) / 2 || s2.pad != (s2.k - 1) / 2 ||
+              !mb_resblock_pair_split_supported(s1.c_in, s1.k, s1.dil))
+            continue;
+          img.assign(mb_resblock_pair_split_packed_halves(s1.c_in, s1.k) / 2, 0.f);
+          float us[2] = {0.f, 0.f};
+          mb_gan::SPair& sp = g->spairs[(size_t)(i * cfg->num_kernels + j) * nd + d];
+          rc = mb_resblock_pair_split_pack(h_weights[2 * (base + d)], h_weights[2 * (base + nd + d)], s1.c_in, s1.k,
+                                           reinterpret_cast<uint16_t*>(img.data()), us);
+          if (!rc) rc = sp.w.upload(img.data(), img.size());
+          sp.us1 = us[0]; sp.us2 = us[1];
+          if (rc) { mb_gan_destroy(g); return rc; }
+        }
+  }
   if (dtype == MB_F16 && !no_fuse) {
     const int nd = cfg->num_dilations;
     g->pairs.resize((size_t)cfg->num_upsamples * cfg->num_kernels * nd);
@@ -331,7 +362,8 @@ extern "C" int mb_gan_create_ex(const mb_gan_config* cfg, const float* const* h_
     }
   }
   if (dtype == MB_F32 && !no_stage && cfg->num_kernels <= 4 && cfg->num_dilations <= 4) {
-    // fp32 path: fused ResBlock groups on error-compensated operands (resblock_stage_f32.hip)
+    // fp32 path: fused ResBlock groups on error-compensated operands (resblock_stage_f32.hip) -- the plan of MBHIP_GAN_FUSE=cm, and
+    // of every stage the time-major pairs above do not cover
     const int nd = cfg->num_dilations, nk = cfg->num_kernels;
     g->s32_w.resize(cfg->num_upsamples);
     g->s32_b.resize(cfg->num_upsamples);
@@ -399,6 +431,7 @@ extern "C" void mb_gan_destroy(mb_gan* g) {
   if (!g) return;
   for (auto& c : g->convs) { c.w.release(); c.b.release(); }
   for (auto& p : g->pairs) p.release();
+  for (auto& p : g->spairs) p.w.release();
   for (auto& p : g->stage_w) p.release();
   for (auto& p : g->stage_b) p.release();
   for (auto& p : g->s32_w) p.release();
@@ -490,6 +523,20 @@ struct Launcher {
     a.d_valid = valid; a.valid_mul = t / frames_max;
     rc = mb_resblock_pair_f16(&a, (mb_stream_t)s);
   }
+  // fp32 fused ResBlock unit on time-major tensors: y = (acc ? y : 0) + scale * (x + c2(lrelu(c1(lrelu(x)))))
+  void pair_split(const mb_gan::SPair& w, const ConvW& c1, const ConvW& c2, const void* x, int t, void* y, float slope,
+                  float out_scale, int accumulate) {
+    if (rc) return;
+    mb_resblock_pair_split_args a;
+    memset(&a, 0, sizeof(a));
+    a.d_x = (const float*)x; a.d_y = (float*)y; a.d_wpacked = w.w.p; a.d_b1 = c1.b.p; a.d_b2 = c2.b.p;
+    a.batch = batch; a.channels = c1.s.c_in; a.t = t; a.ksize = c1.s.k; a.dilation = c1.s.dil;
+    a.slope = slope; a.out_scale = out_scale; a.unscale1 = w.us1; a.unscale2 = w.us2; a.accumulate = accumulate;
+    a.d_valid = valid; a.valid_mul = t / frames_max;
+    rc = mb_resblock_pair_split(&a, (mb_stream_t)s);
+  }
+  void to_tm(const void* x, void* y, int ch, int t) { if (!rc) rc = mb_f32_cm_to_tm((const float*)x, (float*)y, batch, ch, t, (mb_stream_t)s); }
+  void to_cm(const void* x, void* y, int ch, int t) { if (!rc) rc = mb_f32_tm_to_cm((const float*)x, (float*)y, batch, ch, t, (mb_stream_t)s); }
   // y = conv(x) with fused pro/epilogue; lengths are per batch item.  `last` = conv_post (fp32 out).
   void conv(const ConvW& c, const void* xv, int t_in, void* yv, int in_act, float in_slope,
             const void* resv, float out_scale, int accumulate, int out_act, int in_repeat = 1,
@@ -620,7 +667,27 @@ static int gan_forward_impl(const mb_gan* g, const float* d_mel, int batch, int 
     t = (int)gan_up_len(c, i, t);
     MB_REQUIRE(t > 0, "gan_forward: %d frames vanish in upsample stage %d", frames, i);
     // xs = mean_j resblock_j(x)
-    if (f16 && !g->stage_w.empty() && g->stage_w[i].p) {  // narrow stage: every unit of every ResBlock in one launch, X -> XS
+    bool tm_stage = !f16 && !g->spairs.empty();  // fp32 path, round 6: every unit of the stage as a time-major split pair
+    for (int q = 0; q < c.num_kernels * c.num_dilations && tm_stage; ++q)
+      tm_stage = g->spairs[(size_t)i * c.num_kernels * c.num_dilations + q].w.p != nullptr;
+    if (tm_stage) {
+      // X (channel-major, from ups[i]) -> XR time-major = the input of every ResBlock; chains ping-pong X / T; the mean accumulates
+      // in XS (time-major) and is turned back into X, which becomes the stage's result
+      L.to_tm(X, XR, ch, t);
+      for (int j = 0; j < c.num_kernels; ++j) {
+        const int base = g->i_rb + ((i * c.num_kernels + j) * c.num_dilations) * 2;
+        const char* xr = XR;
+        for (int d = 0; d < c.num_dilations; ++d) {
+          const bool last = d == c.num_dilations - 1;
+          char* dst = last ? XS : ((d & 1) ? T : X);
+          L.pair_split(g->spairs[(size_t)(i * c.num_kernels + j) * c.num_dilations + d], g->convs[base + d],
+                       g->convs[base + c.num_dilations + d], xr, t, dst, LRELU, last ? inv_nk : 1.f, last && j > 0);
+          xr = dst;
+        }
+      }
+      L.to_cm(XS, X, ch, t);
+      std::swap(X, XS);
+    } else if (f16 && !g->stage_w.empty() && g->stage_w[i].p) {  // narrow stage: every unit of every ResBlock in one launch, X -> XS
       mb_resblock_stage_f16_args a;
       memset(&a, 0, sizeof(a));
       a.d_x = X; a.d_y = XS; a.d_wpacked = g->stage_w[i].p; a.d_bias = g->stage_b[i].p;

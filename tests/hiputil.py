@@ -162,6 +162,65 @@ def resblock_pair_f16_hip(x, w1, b1, w2, b2, *, dilation=1, slope=0.1, out_scale
     return y.float().transpose(1, 2).contiguous().cpu()
 
 
+def f32_cm_to_tm(t, device="cuda"):
+    """[B, C, T] float -> device fp32 [B, T, C] through mb_f32_cm_to_tm."""
+    L = _lib.lib()
+    t = t.float().contiguous().to(torch.device(device))
+    B, C_, Tt = t.shape
+    out = torch.empty(B, Tt, C_, dtype=torch.float32, device=t.device)
+    _lib.check(L.mb_f32_cm_to_tm(t.data_ptr(), out.data_ptr(), B, C_, Tt, _lib.stream_ptr()), "mb_f32_cm_to_tm")
+    return out
+
+
+def f32_tm_to_cm(t):
+    """device fp32 [B, T, C] -> device fp32 [B, C, T] through mb_f32_tm_to_cm."""
+    L = _lib.lib()
+    B, Tt, C_ = t.shape
+    out = torch.empty(B, C_, Tt, dtype=torch.float32, device=t.device)
+    _lib.check(L.mb_f32_tm_to_cm(t.data_ptr(), out.data_ptr(), B, C_, Tt, _lib.stream_ptr()), "mb_f32_tm_to_cm")
+    return out
+
+
+def pack_pair_split(w1, w2, device="cuda"):
+    """(packed fp16 image on the device, unscale1, unscale2) of mb_resblock_pair_split_pack."""
+    L = _lib.lib()
+    w1 = w1.detach().float().contiguous().cpu()
+    w2 = w2.detach().float().contiguous().cpu()
+    Cc, _, k = w1.shape
+    packed = torch.empty(L.mb_resblock_pair_split_packed_halves(Cc, k), dtype=torch.float16)
+    us = torch.zeros(2, dtype=torch.float32)
+    _lib.check(L.mb_resblock_pair_split_pack(w1.data_ptr(), w2.data_ptr(), Cc, k, packed.data_ptr(), us.data_ptr()),
+               "mb_resblock_pair_split_pack")
+    return packed.to(torch.device(device)), float(us[0]), float(us[1])
+
+
+def resblock_pair_split_hip(x, w1, b1, w2, b2, *, dilation=1, slope=0.1, out_scale=1.0, accumulate_into=None, valid=None,
+                            valid_mul=1, device="cuda"):
+    """Fused ResBlock unit at fp32-grade precision (mb_resblock_pair_split).  x / accumulate_into are [B, C, T] float tensors
+    (reference layout, turned time-major on the device); returns [B, C, T] float32 (rows beyond `valid` keep their NaN fill)."""
+    L = _lib.lib()
+    dev = torch.device(device)
+    Cc, _, k = w1.shape
+    if not L.mb_resblock_pair_split_supported(Cc, k, dilation):
+        raise _lib.MbHipError("mb_resblock_pair_split: unsupported shape")
+    pw, us1, us2 = pack_pair_split(w1, w2, device)
+    xt = f32_cm_to_tm(x, device)
+    B, T, _ = xt.shape
+    y = f32_cm_to_tm(accumulate_into, device) if accumulate_into is not None else \
+        torch.full((B, T, Cc), float("nan"), dtype=torch.float32, device=dev)
+    pb1, pb2 = b1.float().contiguous().to(dev), b2.float().contiguous().to(dev)
+    vt = torch.tensor(valid, dtype=torch.int32, device=dev) if valid is not None else None
+    a = _lib.ResPairSplitArgs()
+    a.d_x, a.d_y, a.d_wpacked, a.d_b1, a.d_b2 = xt.data_ptr(), y.data_ptr(), pw.data_ptr(), pb1.data_ptr(), pb2.data_ptr()
+    a.batch, a.channels, a.t, a.ksize, a.dilation = B, Cc, T, k, dilation
+    a.slope, a.out_scale, a.unscale1, a.unscale2 = slope, out_scale, us1, us2
+    a.accumulate = int(accumulate_into is not None)
+    a.d_valid, a.valid_mul = (vt.data_ptr() if vt is not None else None), valid_mul
+    _lib.check(L.mb_resblock_pair_split(C.byref(a), _lib.stream_ptr()), "mb_resblock_pair_split")
+    torch.cuda.synchronize()
+    return f32_tm_to_cm(y).cpu()
+
+
 def resblock_stage_f16_hip(x, chains, *, slope=0.1, out_scale=0.0, valid=None, valid_mul=1, accumulate_into=None, device="cuda"):
     """One stage's ResBlock group in one launch (mb_resblock_stage_f16).  x: [B, C, T] float; chains: list (one per ResBlock)
     of lists (one per unit) of (w1, b1, w2, b2, dilation); returns [B, C, T] float32 (rows beyond `valid` are left NaN)."""
