@@ -27,12 +27,9 @@
 #include <cmath>
 #include <type_traits>
 #include "common.h"
+#include "split_tm.h"
 
 namespace mb {
-
-typedef _Float16 h16;
-typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 
 struct ResPairSK {
   const float* x; float* y; const h16* w; const float* b1; const float* b2;
@@ -45,13 +42,23 @@ struct ResPairSK {
   int accumulate;
   const int* valid; int valid_mul;  // ragged batches: item b has valid[b] * valid_mul positions (null: T)
   unsigned* range_events;           // MBHIP_CONV_RANGE_CHECK=1: staged values beyond fp16's range are counted here (conv1d.hip)
+  unsigned long long* trace;        // diagnostics builds only (-DSPAIR_TRACE_BUILD, MBHIP_DIAG=spair_trace=<file>): shader-clock marks of workgroup 0
 };
 
-constexpr int SPAIR_NL = 4;  // support waves per workgroup (beside the 4 MMA waves)
+// NL = support waves per workgroup (beside the 4 MMA waves): 4 (one per SIMD, 256 registers each) or, where the MMA waves need <= 168
+// registers (<= 64 channels), 8 (two per SIMD) -- at those widths the support waves' instruction stream, not the MFMAs, sets the pace
+constexpr int SPAIR_MAX_HALO = 80;  // (ksize - 1) * dilation the support waves' window registers are sized for (k = 11, d = 7: 70)
 // diagnostics builds only (tools/build_variant.sh ... -DSPAIR_DBG=<bits>; results are wrong, timings isolate one cost each):
 // 1 = weight ring never refilled, 2 = B fragments read once per chunk, 4 = no epilogues, 8 = no window fill, 16 = no write-out, 32 = no MFMAs
-#ifndef SPAIR_DBG
-#define SPAIR_DBG 0
+// mark k of tile `it`, role 0 = MMA wave 0, 1 = support wave 4 (workgroup 0, first 4 tiles, 64 marks each)
+#ifdef SPAIR_TRACE_BUILD
+#define SP_MARK(role, it, k)                                                                    \
+  do {                                                                                          \
+    if (a.trace && blockIdx.x == 0 && (it) < 4 && (tid & 63) == 0 && wave == ((role) ? 4 : 0))  \
+      a.trace[((role) * 4 + (it)) * 64 + (k)] = (unsigned long long)clock64();                  \
+  } while (0)
+#else  // (a conditional global store in front of an MFMA loop makes the compiler's vmcnt bookkeeping give up: never in the product)
+#define SP_MARK(role, it, k) do { } while (0)
 #endif
 
 // valid length of batch item b: a SCALAR load with its own wait (resblock_f16.hip pair_valid_len: a vector-memory load at the head
@@ -80,8 +87,8 @@ template <int C, int MT_, int WN_, int NTW_> struct SPairGeom {
 
 // YS = y staged in its own fp32 LDS tile (the support waves then have the whole tile time for the x prefetch and the write-out);
 // without it y is staged over the h planes and must leave before the next h is written.
-template <int C, int MT_, int WN_, int NTW_, bool YS>
-__global__ __launch_bounds__(64 * (4 + SPAIR_NL)) __attribute__((amdgpu_waves_per_eu(2, 2)))
+template <int C, int MT_, int WN_, int NTW_, bool YS, int NL>
+__global__ __launch_bounds__(64 * (4 + NL)) __attribute__((amdgpu_waves_per_eu(1 + NL / 4, 1 + NL / 4)))
 void resblock_pair_split_kernel(ResPairSK a) {
   using G = SPairGeom<C, MT_, WN_, NTW_>;
   constexpr int CK = G::CK, KB = G::KB, NCH = G::NCH, MT = G::MT, WN = G::WN, NTW = G::NTW;
@@ -102,137 +109,206 @@ void resblock_pair_split_kernel(ResPairSK a) {
   const int my_tiles = (a.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int njobs = my_tiles * NCH;
 
-  for (int i = tid; i < 2 * C; i += 64 * (4 + SPAIR_NL)) bs[i] = i < C ? a.b1[i] : a.b2[i - C];
+  for (int i = tid; i < 2 * C; i += 64 * (4 + NL)) bs[i] = i < C ? a.b1[i] : a.b2[i - C];
   __syncthreads();  // Z (resblock_f16.hip: the epilogues read bs behind their own barriers, the fill must be fenced once)
 
   if (wave >= 4) {
     // ------------------------------ support waves ------------------------------
-    constexpr int PPR = CK / 4;  // 16-byte pieces (4 floats) per row of a chunk
-    constexpr int LB = 8;        // loads in flight per lane per batch
+    // A software pipeline across the tile's barriers: every HBM load is ISSUED at the head of one barrier interval and its result used
+    // in the NEXT interval (two register sets alternate), so an interval costs the support waves their vector / LDS work only,
+    // never a memory round trip.  Measured on the way (256 channels, k = 3, shader-clock marks of workgroup 0): load -> wait -> store
+    // inside one interval made the support waves the pole of phase 1 (7.1 k cycles per chunk interval against 4.3 k of MFMAs: the MMA
+    // waves waited 25 k of a tile's 102 k cycles at the chunk barriers); issuing the loads at the END of the previous interval
+    // changed nothing (the support waves arrive last, so "one interval ahead" was a few cycles ahead).
+#ifndef SPAIR_SUPPORT_PRIO
+#define SPAIR_SUPPORT_PRIO 2
+#endif
+    // the support wave of a SIMD is the YOUNGER of its two waves and loses every vector-issue arbitration to the MMA wave
+    // (MI355X_MICROARCH.md "Two waves per SIMD": priority, then age); its ~250 instructions per interval then took 6 k cycles.  An MFMA needs
+    // one issue slot per 32 cycles, so the static priority costs the MMA wave next to nothing.
+    __builtin_amdgcn_s_setprio(SPAIR_SUPPORT_PRIO);
+    constexpr int PPR = CK / 4;                            // 16-byte pieces (4 floats) per row of a chunk
+    constexpr int NSL = 64 * NL;                           // support lanes
+    constexpr int LBX = ((N1 + SPAIR_MAX_HALO) * PPR + NSL - 1) / NSL;  // window pieces per lane (one chunk)
+    constexpr int YPR = C / 4;                             // 16-byte pieces per output row
+    constexpr int NP = NCH == 1 ? 2 : NCH;                 // write-out parts per tile
+    constexpr int WB = (N1 * YPR / NP + NSL - 1) / NSL;    // output pieces per lane per part
     const float slope = a.slope;
     const int total = a.x_rows * PPR;
     const int ltid = tid - 256;
-    f32x4 v[LB];
-    auto load_batch = [&](int q, int base) {
+    // per-lane constants of the window pieces: piece i of a lane is (row, 4-channel group) = fixed for every job
+    int xrow[LBX];
+    unsigned xcol[LBX], xlds[LBX];
+#pragma unroll
+    for (int i = 0; i < LBX; ++i) {
+      const int idx = min(i * NSL + ltid, total - 1);
+      xrow[i] = idx / PPR;
+      xcol[i] = (unsigned)(idx - xrow[i] * PPR) * 4u;
+      xlds[i] = (unsigned)xrow[i] * CKP + xcol[i];
+    }
+    // window of job q (tile q / NCH, chunk q % NCH): clamped addresses (the load is always legal), the value selected
+    auto issue_x = [&](int q, f32x4 (&vx)[LBX]) __attribute__((always_inline)) {
+      if (SPAIR_DBG & 8) return;
       const int tile = (int)blockIdx.x + (q / NCH) * (int)gridDim.x, c = q % NCH;
       const int b = tile / a.tiles_per_item, t0 = (tile - b * a.tiles_per_item) * a.NB;
       const int Tb = spair_valid_len(a, b);  // beyond: this item's zero padding
       const int tx0 = t0 - p2 - p1;
       const float* xb = a.x + (long long)b * a.bstride + c * CK;
 #pragma unroll
-      for (int i = 0; i < LB; ++i) {
-        const int idx = base + i * (64 * SPAIR_NL) + ltid;
-        const int row = idx / PPR, pc = idx - row * PPR;
-        const int tx = tx0 + row;
-        v[i] = (f32x4)0.f;
-        if (idx < total && tx >= 0 && tx < Tb) v[i] = *reinterpret_cast<const f32x4*>(xb + (long long)tx * C + pc * 4);
+      for (int i = 0; i < LBX; ++i) {
+        const int tx = tx0 + xrow[i];
+        const unsigned off = (unsigned)min(max(tx, 0), a.T - 1) * (unsigned)C + xcol[i];
+        const f32x4 ld = *reinterpret_cast<const f32x4*>(xb + off);
+        vx[i] = (tx >= 0 && tx < Tb) ? ld : (f32x4)0.f;
       }
     };
-    auto store_batch = [&](int q, int base) {
+    auto commit_x = [&](int q, const f32x4 (&vx)[LBX]) __attribute__((always_inline)) {  // lrelu -> hi / scaled lo planes of buffer q % nbuf
+      if (SPAIR_DBG & 8) return;
       h16* buf = xs + (q % a.nbuf) * 2 * XPL;
 #pragma unroll
-      for (int i = 0; i < LB; ++i) {
-        const int idx = base + i * (64 * SPAIR_NL) + ltid;
-        const int row = idx / PPR, pc = idx - row * PPR;
+      for (int i = 0; i < LBX; ++i) {
         float l[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) l[e] = fmaxf(v[i][e], v[i][e] * slope);  // leaky_relu, 0 < slope < 1 (bit for bit x > 0 ? x : slope x)
-        if (a.range_events) {  // diagnostics only (uniform branch): the split saturates beyond 65504
-          int n_out = 0;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) n_out += !(fabsf(l[e]) <= 65504.f) ? 1 : 0;  // counts NaN / Inf as well
-          if (n_out && idx < total) atomicAdd(a.range_events, (unsigned)n_out);
-        }
+        for (int e = 0; e < 4; ++e) l[e] = fmaxf(vx[i][e], vx[i][e] * slope);  // leaky_relu, 0 < slope < 1 (bit for bit x > 0 ? x : slope x)
         mb_h2 h0, l0, h1, l1;
         split_pair(l[0], l[1], h0, l0);
         split_pair(l[2], l[3], h1, l1);
         const h16x4 hi = {h0[0], h0[1], h1[0], h1[1]}, lo = {l0[0], l0[1], l1[0], l1[1]};
-        if (idx < total) {
-          *reinterpret_cast<h16x4*>(buf + row * CKP + pc * 4) = hi;
-          *reinterpret_cast<h16x4*>(buf + XPL + row * CKP + pc * 4) = lo;
-        }
+        // (pieces past the window repeat its last piece: the same halves to the same place, no predicate)
+        *reinterpret_cast<h16x4*>(buf + xlds[i]) = hi;
+        *reinterpret_cast<h16x4*>(buf + XPL + xlds[i]) = lo;
+      }
+      if (a.range_events) {  // diagnostics only (MBHIP_CONV_RANGE_CHECK=1, uniform branch): values the split saturates (NaN / Inf too)
+        int n_out = 0;
+#pragma unroll
+        for (int i = 0; i < LBX; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) n_out += (i * NSL + ltid < total && !(fabsf(vx[i][e]) <= 65504.f)) ? 1 : 0;  // (|lrelu(x)| <= |x|: x beyond the range <=> flagged; slope x is not)
+        if (n_out) atomicAdd(a.range_events, (unsigned)n_out);
       }
     };
-    auto fill = [&](int q) {
-      if (SPAIR_DBG & 8) return;
-      for (int base = 0; base < total; base += 64 * SPAIR_NL * LB) { load_batch(q, base); store_batch(q, base); }
-    };
-    // y write-out of a finished tile: the MMA waves leave conv2 2^-s + b2 in ys (fp32); here the residual x (and the running sum when
-    // accumulating) is added and the rows leave as coalesced 16-byte stores.  Runs while the MMA waves are in the next tile.
-    constexpr int WB = 4;         // pieces per lane per batch
-    constexpr int YPR = C / 4;    // 16-byte pieces per output row
-    auto write_out = [&](int it, int lo, int hi, int den) {  // batches [nbt*lo/den, nbt*hi/den) of tile `it`
-      if (SPAIR_DBG & 16) return;
+    // y write-out of a finished tile in NP parts: the MMA waves leave conv2 2^-s + b2 in ys (fp32); the residual x (and the running sum
+    // when accumulating) is requested a barrier interval ahead (issue_w), added here and the rows leave as coalesced 16-byte stores
+    struct WTile { const float* xb; float* yb; int ytotal; };
+    auto wtile = [&](int it) __attribute__((always_inline)) {
       const int tile = (int)blockIdx.x + it * (int)gridDim.x;
       const int b = tile / a.tiles_per_item, t0 = (tile - b * a.tiles_per_item) * a.NB;
       const int Tb = spair_valid_len(a, b);
       const int rows = max(0, min(a.NB, Tb - t0));
-      const int ytotal = rows * YPR;
-      const float* xb = a.x + (long long)b * a.bstride + (long long)t0 * C;
-      float* yb = a.y + (long long)b * a.bstride + (long long)t0 * C;
-      constexpr int BSZ = 64 * SPAIR_NL * WB;
-      const int nbt = (ytotal + BSZ - 1) / BSZ;
-      const int b_lo = nbt * lo / den, b_hi = nbt * hi / den;
-      for (int base = b_lo * BSZ; base < b_hi * BSZ && base < ytotal; base += BSZ) {
-        f32x4 rx[WB], ry[WB];
+      return WTile{a.x + (long long)b * a.bstride + (long long)t0 * C, a.y + (long long)b * a.bstride + (long long)t0 * C, rows * YPR};
+    };
+    auto issue_w = [&](int it, int part, f32x4 (&rx)[WB], f32x4 (&ry)[WB]) __attribute__((always_inline)) {
+      if (SPAIR_DBG & 16) return;
+      const WTile w = wtile(it);
+      if (w.ytotal <= 0) return;  // (uniform: a tile beyond its item's valid length)
 #pragma unroll
-        for (int i = 0; i < WB; ++i) {
-          int idx = base + i * (64 * SPAIR_NL) + ltid;
-          idx = idx < ytotal ? idx : ytotal - 1;  // clamped: loads legal, store predicated
-          rx[i] = *reinterpret_cast<const f32x4*>(xb + (long long)idx * 4);
-          if (a.accumulate) ry[i] = *reinterpret_cast<const f32x4*>(yb + (long long)idx * 4);
-        }
-#pragma unroll
-        for (int i = 0; i < WB; ++i) {
-          const int idx = base + i * (64 * SPAIR_NL) + ltid;
-          const int idc = idx < ytotal ? idx : ytotal - 1;
-          const int row = idc / YPR, pc = idc - row * YPR;
-          const f32x4 hv = *reinterpret_cast<const f32x4*>(ys + row * CPF + pc * 4);
-          f32x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float f = (rx[i][e] + hv[e]) * a.out_scale;
-            if (a.accumulate) f += ry[i][e];
-            o[e] = f;
-          }
-          if (idx < ytotal) *reinterpret_cast<f32x4*>(yb + (long long)idx * 4) = o;
-        }
+      for (int i = 0; i < WB; ++i) {
+        const unsigned idx = (unsigned)min(part * (WB * NSL) + i * NSL + ltid, w.ytotal - 1);  // pieces past the tile repeat its last piece
+        rx[i] = *reinterpret_cast<const f32x4*>(w.xb + idx * 4u);
+        if (a.accumulate) ry[i] = *reinterpret_cast<const f32x4*>(w.yb + idx * 4u);
       }
     };
+    auto commit_w = [&](int it, int part, const f32x4 (&rx)[WB], const f32x4 (&ry)[WB]) __attribute__((always_inline)) {
+      if (SPAIR_DBG & 16) return;
+      const WTile w = wtile(it);
+      if (w.ytotal <= 0) return;
+#pragma unroll
+      for (int i = 0; i < WB; ++i) {
+        const int idx = part * (WB * NSL) + i * NSL + ltid;
+        const unsigned idc = (unsigned)min(idx, w.ytotal - 1);
+        const unsigned row = idc / YPR, pc = idc - row * YPR;
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(ys + row * CPF + pc * 4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float f = (rx[i][e] + hv[e]) * a.out_scale;
+          if (a.accumulate) f += ry[i][e];
+          o[e] = f;
+        }
+        if (idx < w.ytotal) *reinterpret_cast<f32x4*>(w.yb + idc * 4u) = o;  // (a repeated piece would accumulate twice)
+      }
+    };
+    f32x4 vxA[LBX], rxA[WB], ryA[WB], rxB[WB], ryB[WB];
     // Barrier schedule per tile (must mirror the MMA waves'): B per chunk, [W], E1, P|YF, Y.
-    if (a.nbuf == 1) {
-      // single buffer (NCH == 1): the next tile's first batch flies during phase 1 and the window is laid down while the MMA waves run
-      // phase 2, which reads only h
-      if (my_tiles > 0) fill(0);
+    if (NCH == 1) {
+      // one chunk per tile, one buffer: the next tile's window is requested at the head of phase 1 and laid down while the MMA waves
+      // run phase 2, which reads only h.  The previous tile's y leaves in two parts (register sets A, B).  With its own y tile: part
+      // 0 in phase 1, part 1 in phase 2, each requested one interval earlier; over the h planes both parts leave before W and are
+      // requested at the head of the previous tile's phase 2.
+      if (my_tiles > 0) { issue_x(0, vxA); commit_x(0, vxA); }
       for (int it = 0; it < my_tiles; ++it) {
+        SP_MARK(1, it, 0);
         __syncthreads();  // B
-        if (it > 0) write_out(it - 1, 0, YS ? 3 : 8, 8);  // with its own y tile: 3/8 now, the rest during phase 2
-        if (!YS) __syncthreads();  // W: hs is free for h of this tile
+        SP_MARK(1, it, 1);
+        if (it + 1 < my_tiles) issue_x(it + 1, vxA);
+        if (it > 0) {
+          if (YS) issue_w(it - 1, 1, rxB, ryB);
+          commit_w(it - 1, 0, rxA, ryA);
+          if (!YS) commit_w(it - 1, 1, rxB, ryB);
+        }
+        SP_MARK(1, it, 32);
+        if (!YS) __syncthreads();  // W: the h planes are free for h of this tile
         __syncthreads();  // E1: phase 1 has finished reading xs
-        if (it + 1 < my_tiles) fill(it + 1);
-        if (YS && it > 0) write_out(it - 1, 3, 8, 8);
+        SP_MARK(1, it, 33);
+        issue_w(it, 0, rxA, ryA);
+        if (!YS) issue_w(it, 1, rxB, ryB);
+        if (it + 1 < my_tiles) commit_x(it + 1, vxA);
+        if (YS && it > 0) commit_w(it - 1, 1, rxB, ryB);
+        SP_MARK(1, it, 34);
         __syncthreads();  // P (all MMA waves done with h) | YF (ys is free for y of this tile)
+        SP_MARK(1, it, 35);
         __syncthreads();  // Y: y of this tile is staged
+        SP_MARK(1, it, 36);
+      }
+      if (my_tiles > 0) {
+        if (YS) issue_w(my_tiles - 1, 1, rxB, ryB);
+        commit_w(my_tiles - 1, 0, rxA, ryA);
+        commit_w(my_tiles - 1, 1, rxB, ryB);
       }
     } else {
-      for (int q = 0; q < a.nbuf - 1 && q < njobs; ++q) fill(q);
+      // chunk ring: at the head of interval q (behind B_q) job q + nbuf is requested into the register set of q's parity; the job
+      // requested an interval earlier (q + nbuf - 1, the other set) is laid down into the buffer job q - 1 just left.  The previous
+      // tile's y leaves in NCH parts the same way (part c behind B_c, requested behind B_{c-1}; part 0 behind E1 of its own tile).
+      f32x4 vxB[LBX];
+      for (int q = 0; q < a.nbuf - 1 && q < njobs; ++q) { issue_x(q, vxA); commit_x(q, vxA); }
+      if (a.nbuf - 1 < njobs) issue_x(a.nbuf - 1, vxB);
       for (int it = 0; it < my_tiles; ++it) {
-        for (int c = 0; c < NCH; ++c) {
+        for (int c = 0; c < NCH; c += 2) {
           const int q = it * NCH + c;
+          SP_MARK(1, it, 2 * c);
           __syncthreads();  // B_q: job q is staged, the buffer of job q-1 is free
-          if (q + a.nbuf - 1 < njobs) fill(q + a.nbuf - 1);
-          if (!YS && it > 0) write_out(it - 1, c, c + 1, NCH);  // spread over the chunks: no B barrier waits long
+          SP_MARK(1, it, 2 * c + 1);
+          if (q + a.nbuf < njobs) issue_x(q + a.nbuf, vxA);
+          if (it > 0) issue_w(it - 1, c + 1, rxA, ryA);
+          if (q + a.nbuf - 1 < njobs) commit_x(q + a.nbuf - 1, vxB);
+          if (it > 0) commit_w(it - 1, c, rxB, ryB);
+          SP_MARK(1, it, 2 * c + 2);
+          __syncthreads();  // B_{q+1}
+          SP_MARK(1, it, 2 * c + 3);
+          if (q + 1 + a.nbuf < njobs) issue_x(q + 1 + a.nbuf, vxB);
+          if (it > 0 && c + 2 < NCH) issue_w(it - 1, c + 2, rxB, ryB);
+          if (q + a.nbuf < njobs) commit_x(q + a.nbuf, vxA);
+          if (it > 0) commit_w(it - 1, c + 1, rxA, ryA);
         }
+        SP_MARK(1, it, 32);
         if (!YS) __syncthreads();  // W
+        SP_MARK(1, it, 33);
         __syncthreads();  // E1
-        if (YS && it > 0) write_out(it - 1, 0, 1, 1);
+        SP_MARK(1, it, 34);
+        issue_w(it, 0, rxB, ryB);
         __syncthreads();  // P | YF
+        SP_MARK(1, it, 35);
         __syncthreads();  // Y
+        SP_MARK(1, it, 36);
+      }
+      if (my_tiles > 0) {
+        commit_w(my_tiles - 1, 0, rxB, ryB);
+        for (int c = 1; c < NCH; ++c) { issue_w(my_tiles - 1, c, rxA, ryA); commit_w(my_tiles - 1, c, rxA, ryA); }
       }
     }
-    if (my_tiles > 0) write_out(my_tiles - 1, 0, 1, 1);
     return;
   }
+
 
   // ------------------------------ MMA waves ------------------------------
   const int wm = wave / WN, wn = wave % WN;
@@ -265,73 +341,6 @@ void resblock_pair_split_kernel(ResPairSK a) {
   };
   const h16 k2m11 = (h16)(1.f / 2048.f);
 
-  // one tap: KB k-steps from ring slot S; refills the slot with flat tap ftn AFTER the MFMAs that read it.  The B fragments (LDS, hi and
-  // lo planes LO_ halves apart) run one k-step ahead of the MFMAs (bhc_ / blc_ = current); NEXT = first row of the next tap (or any
-  // valid row after the chunk's last tap: that read is discarded).  The three products of a k-step run product-major over the wave's
-  // MT x NTW accumulators: consecutive MFMAs never wait on each other's result.
-#define SP_TAP(S, BPTR, NEXT, RS, LO_)                                                             \
-  do {                                                                                             \
-    const h16* bp_ = (BPTR);                                                                       \
-    const h16* np_ = (NEXT);                                                                       \
-    const size_t nf_ = (size_t)ftn * KB;                                                           \
-    _Pragma("unroll") for (int u = 0; u < KB; ++u) {                                               \
-      h16x8 bhn_[NTW], bln_[NTW], ws_[MT];                                                         \
-      const h16* rp_ = u + 1 < KB ? bp_ + (u + 1) * 16 : np_;                                      \
-      _Pragma("unroll") for (int n = 0; n < NTW; ++n) {                                            \
-        if (SPAIR_DBG & 2) { bhn_[n] = bhc_[n]; bln_[n] = blc_[n]; continue; }                     \
-        bhn_[n] = *reinterpret_cast<const h16x8*>(rp_ + n * 32 * (RS));                            \
-        bln_[n] = *reinterpret_cast<const h16x8*>(rp_ + (LO_) + n * 32 * (RS));                    \
-      }                                                                                            \
-      _Pragma("unroll") for (int i = 0; i < MT; ++i) ws_[i] = ring[S][u][i][0] * k2m11;            \
-      if (SPAIR_DBG & 32) {                                                                        \
-        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                             \
-          _Pragma("unroll") for (int n = 0; n < NTW; ++n) {                                        \
-            acc[i][n][0] += (float)ring[S][u][i][1][0] * (float)bhc_[n][0] + (float)ws_[i][0] * (float)blc_[n][0]; \
-            acc[i][n][1] += (float)ring[S][u][i][0][0];                                            \
-          }                                                                                        \
-      } else {                                                                                     \
-      _Pragma("unroll") for (int i = 0; i < MT; ++i)                                               \
-        _Pragma("unroll") for (int n = 0; n < NTW; ++n)                                            \
-          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[S][u][i][1], bhc_[n], acc[i][n], 0, 0, 0); \
-      _Pragma("unroll") for (int i = 0; i < MT; ++i)                                               \
-        _Pragma("unroll") for (int n = 0; n < NTW; ++n)                                            \
-          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ws_[i], blc_[n], acc[i][n], 0, 0, 0); \
-      _Pragma("unroll") for (int i = 0; i < MT; ++i)                                               \
-        _Pragma("unroll") for (int n = 0; n < NTW; ++n)                                            \
-          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[S][u][i][0], bhc_[n], acc[i][n], 0, 0, 0); \
-      }                                                                                            \
-      if (!(SPAIR_DBG & 1)) {                                                                      \
-        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                             \
-          _Pragma("unroll") for (int p = 0; p < 2; ++p) ring[S][u][i][p] = wp[i][((nf_ + u) * 2 + p) * 64]; \
-      }                                                                                            \
-      __builtin_amdgcn_sched_barrier(0);                                                           \
-      _Pragma("unroll") for (int n = 0; n < NTW; ++n) { bhc_[n] = bhn_[n]; blc_[n] = bln_[n]; }    \
-    }                                                                                              \
-    ftn = ftn + 1 == NFT ? 0 : ftn + 1;                                                            \
-  } while (0)
-
-  // a chunk = ntaps taps (ntaps odd); S0 = ring slot of its first tap
-#define SP_TAPJ(S, J)                                                                              \
-  SP_TAP(S, cb_ + (size_t)(J) * ts_, cb_ + (size_t)((J) + 1 < ntaps ? (J) + 1 : 0) * ts_, rs_, lo_)
-#define SP_CHUNK(S0, BASE, RS, TAPSTEP, LOFF)                                                      \
-  do {                                                                                             \
-    const h16* cb_ = (BASE);                                                                       \
-    const int rs_ = (RS);                                                                          \
-    const size_t ts_ = (size_t)(TAPSTEP);                                                          \
-    const int lo_ = (LOFF);                                                                        \
-    h16x8 bhc_[NTW], blc_[NTW];                                                                    \
-    _Pragma("unroll") for (int n = 0; n < NTW; ++n) {                                              \
-      bhc_[n] = *reinterpret_cast<const h16x8*>(cb_ + n * 32 * rs_);                               \
-      blc_[n] = *reinterpret_cast<const h16x8*>(cb_ + lo_ + n * 32 * rs_);                         \
-    }                                                                                              \
-    int j_ = 0;                                                                                    \
-    if (S0 == 1) { SP_TAPJ(TD - 1, 0); j_ = 1; }                                                   \
-    for (; j_ + 1 < ntaps; j_ += 2) {                                                              \
-      SP_TAPJ(0, j_);                                                                              \
-      SP_TAPJ(TD - 1, j_ + 1);                                                                     \
-    }                                                                                              \
-    if (S0 == 0) SP_TAPJ(0, ntaps - 1);                                                            \
-  } while (0)
 
   const int lrow = wn * (NTW * 32) + (lane & 31);  // this lane's row inside an N tile group
   const int lcol = (lane >> 5) * 8;
@@ -342,20 +351,31 @@ void resblock_pair_split_kernel(ResPairSK a) {
     const int t0 = (tile % a.tiles_per_item) * a.NB;
     const int Tb = spair_valid_len(a, tile / a.tiles_per_item);
     // ---------------- phase 1: h = lrelu(conv1(lrelu(x)) 2^-s + b1) ----------------
+#ifdef SPAIR_TRACE_BUILD
+    if (a.trace && blockIdx.x == 0 && it < 4 && tid == 0) a.trace[(0 * 4 + it) * 64 + 62] = (unsigned long long)wall_clock64();
+#endif
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): a known scoreboard at the head of the tile keeps the compiler's counted waits exact
     zero_acc();
     if (NCH == 1) {
+      SP_MARK(0, it, 0);
       __syncthreads();  // B
+      SP_MARK(0, it, 1);
       SP_CHUNK(0, xs + ((it * NCH) % a.nbuf) * 2 * XPL + lrow * CKP + lcol, CKP, x_tapstep, XPL);
     } else {
       for (int c = 0; c < NCH; c += 2) {
+        SP_MARK(0, it, 2 * c);
         __syncthreads();  // B
+        SP_MARK(0, it, 2 * c + 1);
         SP_CHUNK(0, xs + ((it * NCH + c) % a.nbuf) * 2 * XPL + lrow * CKP + lcol, CKP, x_tapstep, XPL);
+        SP_MARK(0, it, 2 * c + 2);
         __syncthreads();  // B
+        SP_MARK(0, it, 2 * c + 3);
         SP_CHUNK(1, xs + ((it * NCH + c + 1) % a.nbuf) * 2 * XPL + lrow * CKP + lcol, CKP, x_tapstep, XPL);
       }
     }
+    SP_MARK(0, it, 32);
     if (!YS) __syncthreads();  // W: the support waves have written out the previous tile's y from the h planes
+    SP_MARK(0, it, 33);
     if (!(SPAIR_DBG & 4)) {  // epilogue 1 -> h planes (hi / scaled lo); rows outside [0, Tb) are conv2's zero padding
 #pragma unroll
       for (int i = 0; i < MT; ++i)
@@ -385,7 +405,9 @@ void resblock_pair_split_kernel(ResPairSK a) {
           }
         }
     }
+    SP_MARK(0, it, 34);
     __syncthreads();  // E1
+    SP_MARK(0, it, 35);
     // ---------------- phase 2: conv2(h) 2^-s + b2 ----------------
     zero_acc();
     if (NCH == 1) {
@@ -396,7 +418,9 @@ void resblock_pair_split_kernel(ResPairSK a) {
         SP_CHUNK(1, hs + lrow * CP + (c + 1) * CK + lcol, CP, CP, HPL);
       }
     }
+    SP_MARK(0, it, 36);
     __syncthreads();  // P: every MMA wave has finished reading h | YF: the previous tile's y has left ys
+    SP_MARK(0, it, 37);
     if (!(SPAIR_DBG & 4)) {  // epilogue 2 -> ys (fp32); the support waves add the residual and write y out
 #pragma unroll
       for (int i = 0; i < MT; ++i)
@@ -415,11 +439,13 @@ void resblock_pair_split_kernel(ResPairSK a) {
           }
         }
     }
+    SP_MARK(0, it, 38);
     __syncthreads();  // Y
+    SP_MARK(0, it, 39);
+#ifdef SPAIR_TRACE_BUILD
+    if (a.trace && blockIdx.x == 0 && it < 4 && tid == 0) a.trace[(0 * 4 + it) * 64 + 63] = (unsigned long long)wall_clock64();
+#endif
   }
-#undef SP_CHUNK
-#undef SP_TAPJ
-#undef SP_TAP
 }
 
 // LDS bytes of an instance for a given conv1 geometry and x-chunk buffer count
@@ -448,7 +474,7 @@ static int spair_cus() {
   return n;
 }
 
-template <int C, int MT, int WN, int NTW, bool YS>
+template <int C, int MT, int WN, int NTW, bool YS, int NL>
 static int launch_spair(ResPairSK k, int batch, hipStream_t s) {
   using G = SPairGeom<C, MT, WN, NTW>;
   k.NB = G::N1 - (k.ntaps - 1);
@@ -465,13 +491,36 @@ static int launch_spair(ResPairSK k, int batch, hipStream_t s) {
   MB_HIP(hipGetDevice(&dev));
   const unsigned long long bit = dev >= 0 && dev < 64 ? 1ull << dev : 0ull;
   if (!bit || !(attr_done.load(std::memory_order_acquire) & bit)) {
-    MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_split_kernel<C, MT, WN, NTW, YS>),
+    MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_split_kernel<C, MT, WN, NTW, YS, NL>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done.fetch_or(bit, std::memory_order_release);
   }
   const int grid = std::min(k.n_tiles, spair_cus());
-  hipLaunchKernelGGL((resblock_pair_split_kernel<C, MT, WN, NTW, YS>), dim3(grid), dim3(64 * (4 + SPAIR_NL)), lds, s, k);
+#ifdef SPAIR_TRACE_BUILD
+  static unsigned long long* d_trace = nullptr;
+  std::string trace_file;
+  const char* trace_path = diag_str("spair_trace", &trace_file) ? trace_file.c_str() : nullptr;
+  if (trace_path) {
+    if (!d_trace) MB_HIP(hipMalloc((void**)&d_trace, 512 * sizeof(unsigned long long)));
+    MB_HIP(hipMemsetAsync(d_trace, 0, 512 * sizeof(unsigned long long), s));
+    k.trace = d_trace;
+  }
+#endif
+  hipLaunchKernelGGL((resblock_pair_split_kernel<C, MT, WN, NTW, YS, NL>), dim3(grid), dim3(64 * (4 + NL)), lds, s, k);
   MB_HIP(hipGetLastError());
+#ifdef SPAIR_TRACE_BUILD
+  if (trace_path) {  // append "C MT WN NTW YS ntaps dil nbuf tiles : marks..." per launch
+    unsigned long long h[512];
+    MB_HIP(hipStreamSynchronize(s));
+    MB_HIP(hipMemcpy(h, d_trace, sizeof(h), hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(trace_path, "a")) {
+      fprintf(f, "%d %d %d %d %d %d %d %d %d :", C, MT, WN, NTW, (int)YS, k.ntaps, k.dil, k.nbuf, k.n_tiles);
+      for (int i = 0; i < 512; ++i) fprintf(f, " %llu", h[i]);
+      fprintf(f, "\n");
+      fclose(f);
+    }
+  }
+#endif
   return MB_OK;
 }
 
@@ -480,8 +529,8 @@ using SG256a = SPairGeom<256, 2, 1, 3>;
 using SG256b = SPairGeom<256, 2, 1, 2>;
 using SG128a = SPairGeom<128, 1, 1, 4>;
 using SG128b = SPairGeom<128, 1, 1, 3>;
-using SG64a = SPairGeom<64, 1, 2, 2>;
-using SG32a = SPairGeom<32, 1, 4, 2>;
+using SG64a = SPairGeom<64, 1, 2, 2>;  // (192-row tiles at 64 channels / 384-row tiles at 32 measured no faster and need > 256 registers
+using SG32a = SPairGeom<32, 1, 4, 2>;  //  in the support waves: two window sets + two residual sets)
 using SG32b = SPairGeom<32, 1, 4, 1>;
 using SG16a = SPairGeom<16, 1, 4, 2>;
 using SG16b = SPairGeom<16, 1, 4, 1>;
@@ -492,7 +541,7 @@ using namespace mb;
 
 extern "C" int mb_resblock_pair_split_supported(int channels, int ksize, int dilation) {
   if (!(channels == 16 || channels == 32 || channels == 64 || channels == 128 || channels == 256)) return 0;
-  if (ksize < 3 || (ksize & 1) == 0 || dilation < 1) return 0;
+  if (ksize < 3 || (ksize & 1) == 0 || dilation < 1 || (ksize - 1) * dilation > SPAIR_MAX_HALO) return 0;
   switch (channels) {
     case 256: return spair_fits<SG256a>(ksize, dilation, false) || spair_fits<SG256b>(ksize, dilation, false);
     case 128: return spair_fits<SG128a>(ksize, dilation, false) || spair_fits<SG128b>(ksize, dilation, false);
@@ -584,8 +633,9 @@ extern "C" int mb_resblock_pair_split(const mb_resblock_pair_split_args* a, mb_s
     const bool fa = spair_fits<GA>(ks, dl, YA), fb = spair_fits<GB>(ks, dl, YB);                          \
     MB_REQUIRE(fa || fb, "resblock_pair_split: no instance fits LDS");                                     \
     const bool pick_b = fb && (!fa || force == 2 || (force != 1 && cost(GB::N1) < cost(GA::N1)));          \
-    if (pick_b) return launch_spair<GB::CH, GB::MT, GB::WN, GB::NTW, YB>(k, a->batch, s);             \
-    return launch_spair<GA::CH, GA::MT, GA::WN, GA::NTW, YA>(k, a->batch, s);                         \
+    constexpr int nl_ = GA::CH <= 64 ? 8 : 4;                                                             \
+    if (pick_b) return launch_spair<GB::CH, GB::MT, GB::WN, GB::NTW, YB, nl_>(k, a->batch, s);        \
+    return launch_spair<GA::CH, GA::MT, GA::WN, GA::NTW, YA, nl_>(k, a->batch, s);                    \
   } while (0)
   switch (a->channels) {
     case 256: SP_PICK2(SG256a, false, SG256b, false);
