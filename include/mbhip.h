@@ -265,6 +265,32 @@ typedef struct mb_resblock_pair_split_args {
   const int* d_valid; int valid_mul;  /* ragged batches: item b has d_valid[b] * valid_mul positions (NULL = t) */
 } mb_resblock_pair_split_args;
 int mb_resblock_pair_split(const mb_resblock_pair_split_args* a, mb_stream_t stream);
+/* Round 6 -- every other conv of the fp32 generators on the same time-major tensors (conv_split_tm.hip): conv_pre, the ConvTranspose1d
+ * upsamplers as three-tap polyphase convs whose [t][u C'] result IS the upsampled [u t][C'] tensor, Fre-GAN's cond_up / res_output,
+ * conv_post (models/vocoder/hifigan/models.py:103-127,134-150; models/vocoder/fregan/generator.py:95-118,137-166):
+ *   y[b][t][m] = act(out_scale * (sum_{ci,j} W[m][ci][j] lrelu(x[b][t - pad + j dilation][ci]) + bias[m] + res[b][t][m])) (+ y)
+ * x fp32 [B][t][c_in], y / res fp32 [B][t][c_out]; error-compensated fp16 MFMA products, fp32-grade sums.  Supported: k odd,
+ * (k - 1) dilation <= 16, c_in a multiple of 4 (mb_conv_split_tm_supported). */
+int mb_conv_split_tm_supported(int c_out, int c_in, int ksize, int dilation);
+size_t mb_conv_split_tm_packed_halves(int c_out, int c_in, int ksize);
+/* h_w: fp32 [c_out][c_in][ksize] (torch Conv1d layout) -> {hi, lo} fp16 A-fragment streams; *h_unscale = 2^-s (pass back as unscale) */
+int mb_conv_split_tm_pack(const float* h_w, int c_out, int c_in, int ksize, uint16_t* h_packed, float* h_unscale);
+typedef struct mb_conv_split_tm_args {
+  const float* d_x;       /* fp32 [B][t][c_in]                                      */
+  float* d_y;             /* fp32 [B][t][c_out], must not alias d_x                 */
+  const void* d_wpacked;  /* image from mb_conv_split_tm_pack                       */
+  const float* d_bias;    /* fp32 [c_out] or NULL                                   */
+  const float* d_res;     /* fp32 [B][t][c_out] added before the activation, or NULL (needs c_out % 4 == 0) */
+  int batch, t, c_in, c_out;
+  int ksize, dilation, pad;
+  float in_slope;         /* leaky_relu slope in (0,1] applied to x; 1 = none       */
+  float unscale;          /* *h_unscale of the pack                                 */
+  float out_scale;        /* 0 = 1.0                                                */
+  int out_act;            /* 0 none, 2 tanh                                         */
+  int accumulate;         /* y += result (needs c_out % 4 == 0)                     */
+  const int* d_valid; int valid_mul;  /* ragged batches: item b has d_valid[b] * valid_mul rows (NULL = t) */
+} mb_conv_split_tm_args;
+int mb_conv_split_tm(const mb_conv_split_tm_args* a, mb_stream_t stream);
 /* fp32 [B][channels][t] (the reference's layout) <-> fp32 [B][t][channels] (the layout above), out of place */
 int mb_f32_cm_to_tm(const float* d_x, float* d_y, int batch, int channels, int t, mb_stream_t stream);
 int mb_f32_tm_to_cm(const float* d_x, float* d_y, int batch, int channels, int t, mb_stream_t stream);

@@ -112,6 +112,16 @@ class ResPairSplitArgs(C.Structure):
     ]
 
 
+class ConvSplitTmArgs(C.Structure):
+    _fields_ = [
+        ("d_x", C.c_void_p), ("d_y", C.c_void_p), ("d_wpacked", C.c_void_p), ("d_bias", C.c_void_p), ("d_res", C.c_void_p),
+        ("batch", C.c_int), ("t", C.c_int), ("c_in", C.c_int), ("c_out", C.c_int),
+        ("ksize", C.c_int), ("dilation", C.c_int), ("pad", C.c_int),
+        ("in_slope", C.c_float), ("unscale", C.c_float), ("out_scale", C.c_float),
+        ("out_act", C.c_int), ("accumulate", C.c_int), ("d_valid", C.c_void_p), ("valid_mul", C.c_int),
+    ]
+
+
 class WaveRNNConfig(C.Structure):
     _fields_ = [
         ("rnn_dims", C.c_int), ("fc_dims", C.c_int), ("bits", C.c_int), ("pad", C.c_int),
@@ -169,6 +179,10 @@ SIGNATURES = {
     "mb_resblock_pair_split_packed_halves": (C.c_size_t, [C.c_int] * 2),
     "mb_resblock_pair_split_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mb_resblock_pair_split": (C.c_int, [C.POINTER(ResPairSplitArgs), C.c_void_p]),
+    "mb_conv_split_tm_supported": (C.c_int, [C.c_int] * 4),
+    "mb_conv_split_tm_packed_halves": (C.c_size_t, [C.c_int] * 3),
+    "mb_conv_split_tm_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "mb_conv_split_tm": (C.c_int, [C.POINTER(ConvSplitTmArgs), C.c_void_p]),
     "mb_f32_cm_to_tm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mb_f32_tm_to_cm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mb_resblock_stage_f16_supported": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),

@@ -12,7 +12,7 @@ ROOT = Path(__file__).resolve().parent
 CSRC = ROOT / "csrc"
 LIB = ROOT / "libmbhip.so"
 ARCH = "gfx950"
-SOURCES = ["common.hip", "conv1d.hip", "conv1d_f16.hip", "resblock_f16.hip", "resblock_stage_f16.hip", "resblock_stage_f32.hip", "resblock_pair_split.hip", "gan.hip", "rnn.hip", "wavernn.hip", "wavernn_post.hip", "wave_post.hip", "tacotron.hip", "ppg2mel.hip", "ppg_net.hip",
+SOURCES = ["common.hip", "conv1d.hip", "conv1d_f16.hip", "resblock_f16.hip", "resblock_stage_f16.hip", "resblock_stage_f32.hip", "resblock_pair_split.hip", "conv_split_tm.hip", "gan.hip", "rnn.hip", "wavernn.hip", "wavernn_post.hip", "wave_post.hip", "tacotron.hip", "ppg2mel.hip", "ppg_net.hip",
            "maximum_path.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]

@@ -129,6 +129,15 @@ __global__ void add_chan_bias_f16_kernel(_Float16* __restrict__ x, const float* 
     xb[i] = (_Float16)((float)xb[i] + bb[i % C]);
 }
 
+// x[b][t][c] += bias[b][c]  (fp32 time-major)
+__global__ void add_chan_bias_tm_kernel(float* __restrict__ x, const float* __restrict__ bias, int C, int T) {
+  const int b = blockIdx.y;
+  const size_t n = (size_t)C * T;
+  float* xb = x + (size_t)b * n;
+  const float* bb = bias + (size_t)b * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) xb[i] += bb[i % C];
+}
+
 }  // namespace mb
 
 using namespace mb;
@@ -156,6 +165,11 @@ struct mb_gan {
   // indexed as `pairs`; a stage whose units all have an image runs time-major (turned once in, once out), the others keep the plan above
   struct SPair { DevBuf w; float us1 = 0.f, us2 = 0.f; };
   std::vector<SPair> spairs;
+  // ... and every other conv as a time-major split conv (conv_split_tm.hip), indexed as `convs` (ResBlock entries stay empty).  When
+  // every conv of the generator has an image (tm_all) the whole forward runs time-major: the mel is turned once, nothing else is.
+  struct TmConv { DevBuf w, bias; float us = 0.f; int c_in = 0, m = 0, k = 0, pad = 0, rep = 1; };
+  std::vector<TmConv> tmc;
+  bool tm_all = false;
   int hop;
   // indices into convs
   int i_pre, i_ups, i_cond, i_resout, i_rb, i_post;
@@ -287,6 +301,72 @@ extern "C" int mb_gan_create_ex(const mb_gan_config* cfg, const float* const* h_
           if (!rc) rc = g->pairs[(size_t)(i * cfg->num_kernels + j) * nd + d].upload(img.data(), img.size());
           if (rc) { mb_gan_destroy(g); return rc; }
         }
+  }
+  if (dtype == MB_F32 && !g->spairs.empty() && !cfg->interp_ups) {
+    // conv_pre / ups / cond_up / res_output / conv_post as time-major split convs.  ConvTranspose1d(C -> C', 2 u taps, stride u, padding
+    // u/2 + u%2) = a three-tap conv to u C' channels: W[r C' + co][ci][j] = w[ci][co][u (1 - j) + r + pad]  (conv_split_tm.hip)
+    bool all = true;
+    for (auto& sp : g->spairs) all = all && sp.w.p != nullptr;
+    g->tmc.resize(v.size());
+    std::vector<float> weff, beff, img;
+    auto make_tm = [&](int idx, int rep) -> int {  // rep > 1: 1x1 conv behind a nearest-repeat x rep (Fre-GAN res_output)
+      const ConvSpec& sp = v[idx];
+      mb_gan::TmConv& t = g->tmc[idx];
+      const float* w = h_weights[2 * idx];
+      const float* b = h_weights[2 * idx + 1];
+      if (sp.transposed) {
+        const int u = sp.stride;
+        if (sp.k != 2 * u || sp.dil != 1) return 1;
+        t.c_in = sp.c_in; t.m = u * sp.c_out; t.k = 3; t.pad = 1; t.rep = u;
+        weff.assign((size_t)t.m * t.c_in * 3, 0.f);
+        for (int r = 0; r < u; ++r)
+          for (int co = 0; co < sp.c_out; ++co)
+            for (int ci = 0; ci < sp.c_in; ++ci)
+              for (int j = 0; j < 3; ++j) {
+                const int kk = u * (1 - j) + r + sp.pad;
+                if (kk >= 0 && kk < sp.k) weff[((size_t)(r * sp.c_out + co) * t.c_in + ci) * 3 + j] = w[((size_t)ci * sp.c_out + co) * sp.k + kk];
+              }
+        beff.resize(t.m);
+        for (int r = 0; r < u; ++r) memcpy(&beff[(size_t)r * sp.c_out], b, sp.c_out * sizeof(float));
+      } else if (rep > 1) {
+        if (sp.k != 1) return 1;
+        t.c_in = sp.c_in; t.m = rep * sp.c_out; t.k = 1; t.pad = 0; t.rep = rep;
+        weff.resize((size_t)t.m * t.c_in);
+        beff.resize(t.m);
+        for (int r = 0; r < rep; ++r) {
+          memcpy(&weff[(size_t)r * sp.c_out * sp.c_in], w, (size_t)sp.c_out * sp.c_in * sizeof(float));
+          memcpy(&beff[(size_t)r * sp.c_out], b, sp.c_out * sizeof(float));
+        }
+      } else {
+        if (sp.stride != 1 || sp.dil != 1) return 1;
+        t.c_in = sp.c_in; t.m = sp.c_out; t.k = sp.k; t.pad = sp.pad; t.rep = 1;
+        weff.assign(w, w + (size_t)sp.c_out * sp.c_in * sp.k);
+        beff.assign(b, b + sp.c_out);
+      }
+      if (!mb_conv_split_tm_supported(t.m, t.c_in, t.k, 1)) return 1;
+      img.assign(mb_conv_split_tm_packed_halves(t.m, t.c_in, t.k) / 2, 0.f);
+      int r = mb_conv_split_tm_pack(weff.data(), t.m, t.c_in, t.k, reinterpret_cast<uint16_t*>(img.data()), &t.us);
+      if (!r) r = t.w.upload(img.data(), img.size());
+      if (!r) r = t.bias.upload(beff.data(), beff.size());
+      return r;
+    };
+    auto want = [&](int idx, int rep) {
+      if (!all || rc) return;
+      const int r = make_tm(idx, rep);
+      if (r < 0) rc = r;
+      else if (r) all = false;
+    };
+    want(g->i_pre, 1);
+    for (int i = 0; i < cfg->num_upsamples; ++i) want(g->i_ups + i, 1);
+    if (cfg->kind == MB_GAN_FREGAN) {
+      const int lvl = cfg->num_upsamples - cfg->top_k;
+      for (int i = lvl; i < cfg->num_upsamples; ++i) want(g->i_cond + (i - lvl), 1);
+      for (int i = lvl + 1; i < cfg->num_upsamples; ++i) want(g->i_resout + (i - lvl - 1), cfg->upsample_rates[i]);
+    }
+    want(g->i_post, 1);
+    if (rc) { mb_gan_destroy(g); return rc; }
+    g->tm_all = all && !diag_int("gan_tm_pairs_only");  // A/B: the ResBlock units time-major, everything else channel-major (first form of the round)
+    if (!g->tm_all) { for (auto& t : g->tmc) { t.w.release(); t.bias.release(); } g->tmc.clear(); }
   }
   if (dtype == MB_F16 && !no_stage && cfg->num_kernels <= 4 &&
       cfg->num_dilations <= 4) {
@@ -432,6 +512,7 @@ extern "C" void mb_gan_destroy(mb_gan* g) {
   for (auto& c : g->convs) { c.w.release(); c.b.release(); }
   for (auto& p : g->pairs) p.release();
   for (auto& p : g->spairs) p.w.release();
+  for (auto& t : g->tmc) { t.w.release(); t.bias.release(); }
   for (auto& p : g->stage_w) p.release();
   for (auto& p : g->stage_b) p.release();
   for (auto& p : g->s32_w) p.release();
@@ -477,7 +558,8 @@ extern "C" size_t mb_gan_workspace_bytes(const mb_gan* g, int batch, int frames)
   const size_t per = align_up(gan_max_act(g, frames) * batch * esz, 256);
   const int nbuf = g->cfg.kind == MB_GAN_FREGAN ? 8 : 4;
   // fp16: + the time-major fp16 copy of the mel
-  const size_t melh = g->dtype == MB_F16 ? align_up((size_t)batch * frames * g->cfg.num_mels * 2, 256) : 0;
+  const size_t melh = g->dtype == MB_F16 ? align_up((size_t)batch * frames * g->cfg.num_mels * 2, 256)
+                                         : (g->tm_all ? align_up((size_t)batch * frames * g->cfg.num_mels * 4, 256) : 0);  // fp32: + its time-major copy
   return per * nbuf + melh + 256;
 }
 
@@ -535,6 +617,17 @@ struct Launcher {
     a.d_valid = valid; a.valid_mul = t / frames_max;
     rc = mb_resblock_pair_split(&a, (mb_stream_t)s);
   }
+  // time-major split conv (conv_split_tm.hip); t = input rows, the result has t rows of tc.m floats (= t * tc.rep rows of the conv's c_out)
+  void conv_tm(const mb_gan::TmConv& tc, const void* x, int t, void* y, float in_slope, const void* res, int out_act) {
+    if (rc) return;
+    mb_conv_split_tm_args a;
+    memset(&a, 0, sizeof(a));
+    a.d_x = (const float*)x; a.d_y = (float*)y; a.d_wpacked = tc.w.p; a.d_bias = tc.bias.p; a.d_res = (const float*)res;
+    a.batch = batch; a.t = t; a.c_in = tc.c_in; a.c_out = tc.m; a.ksize = tc.k; a.dilation = 1; a.pad = tc.pad;
+    a.in_slope = in_slope; a.unscale = tc.us; a.out_scale = 1.f; a.out_act = out_act;
+    a.d_valid = valid; a.valid_mul = t / frames_max;
+    rc = mb_conv_split_tm(&a, (mb_stream_t)s);
+  }
   void to_tm(const void* x, void* y, int ch, int t) { if (!rc) rc = mb_f32_cm_to_tm((const float*)x, (float*)y, batch, ch, t, (mb_stream_t)s); }
   void to_cm(const void* x, void* y, int ch, int t) { if (!rc) rc = mb_f32_tm_to_cm((const float*)x, (float*)y, batch, ch, t, (mb_stream_t)s); }
   // y = conv(x) with fused pro/epilogue; lengths are per batch item.  `last` = conv_post (fp32 out).
@@ -588,6 +681,85 @@ extern "C" int mb_gan_forward_ragged(const mb_gan* g, const float* d_mel, int ba
   return gan_forward_impl(g, d_mel, batch, frames, d_frames, d_wav, d_chan_bias, d_workspace, workspace_bytes, stream);
 }
 
+// The fp32 generators entirely on time-major tensors (round 6): the mel is turned once, every conv is a conv_split_tm / resblock_pair_split
+// launch, the waveform [T][1] comes out as it is stored.  Same dataflow as the general plan below.
+static int gan_forward_tm(const mb_gan* g, const float* d_mel, int batch, int frames, const int32_t* d_frames, float* d_wav,
+                          const float* d_chan_bias, void* d_workspace, size_t workspace_bytes, mb_stream_t stream) {
+  const mb_gan_config& c = g->cfg;
+  const bool fre = c.kind == MB_GAN_FREGAN;
+  const size_t per = gan_max_act(g, frames) * batch * sizeof(float);
+  Arena ar(d_workspace, workspace_bytes);
+  char* X = ar.take<char>(per);   // ups output = resblock input
+  char* XS = ar.take<char>(per);  // stage output (mean of resblocks)
+  char* XR = ar.take<char>(per);  // running x inside a resblock
+  char* T = ar.take<char>(per);
+  char *MELA = nullptr, *MELB = nullptr, *OUTA = nullptr, *OUTB = nullptr;
+  if (fre) {
+    MELA = ar.take<char>(per); MELB = ar.take<char>(per);
+    OUTA = ar.take<char>(per); OUTB = ar.take<char>(per);
+  }
+  char* melt = ar.take<char>((size_t)batch * frames * c.num_mels * sizeof(float));
+  Launcher L{(hipStream_t)stream, batch, MB_F32};
+  L.valid = d_frames; L.frames_max = frames;
+  L.to_tm(d_mel, melt, c.num_mels, frames);
+  const float LRELU = 0.1f;
+  const int lvl = fre ? c.num_upsamples - c.top_k : 1 << 30;
+  const float inv_nk = 1.0f / (float)c.num_kernels;
+  L.conv_tm(g->tmc[g->i_pre], melt, frames, XS, 1.f, nullptr, 0);  // conv_pre
+  if (d_chan_bias && !L.rc) {  // VITS decoder: x = conv_pre(x) + cond(g)   vits.py:274-276
+    const int C0 = c.upsample_initial_channel;
+    hipLaunchKernelGGL(add_chan_bias_tm_kernel, dim3(std::min(cdiv(C0 * frames, 256), 1024), batch), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<float*>(XS), d_chan_bias, C0, frames);
+    MB_HIP(hipGetLastError());
+  }
+  int t = frames;
+  const char* mel_cur = melt;
+  int mel_t = frames;
+  char* out_cur = nullptr;
+  int out_t = 0;
+  for (int i = 0; i < c.num_upsamples && !L.rc; ++i) {
+    const int ch = c.upsample_initial_channel >> (i + 1);
+    const int u = c.upsample_rates[i];
+    char* pending_out = nullptr;
+    if (fre && i >= lvl) {  // mel = cond_up[i-lvl](mel); x += mel (generator.py:142-144)
+      char* mel_next = (mel_cur == MELA) ? MELB : MELA;
+      const mb_gan::TmConv& cu = g->tmc[g->i_cond + (i - lvl)];
+      L.conv_tm(cu, mel_cur, mel_t, mel_next, 1.f, nullptr, 0);
+      mel_cur = mel_next; mel_t *= cu.rep;
+      L.add(XS, mel_cur, (size_t)batch * (c.upsample_initial_channel >> i) * mel_t);
+    }
+    const bool ro_deferred = fre && i > lvl && out_cur;
+    if (fre && i > lvl && !ro_deferred) {  // output = res_output[i-lvl-1](x) (generator.py:145-149): x is overwritten by this stage
+      L.conv_tm(g->tmc[g->i_resout + (i - lvl - 1)], XS, t, OUTA, 1.f, nullptr, 0);
+      pending_out = OUTA; out_t = t * u;
+    }
+    L.conv_tm(g->tmc[g->i_ups + i], XS, t, X, LRELU, nullptr, 0);  // x = ups[i](leaky_relu(x))
+    t *= u;
+    for (int j = 0; j < c.num_kernels; ++j) {  // xs = mean_j resblock_j(x): chains ping-pong XR / T, the mean accumulates in XS
+      const int base = g->i_rb + ((i * c.num_kernels + j) * c.num_dilations) * 2;
+      const char* xr = X;
+      for (int d = 0; d < c.num_dilations; ++d) {
+        const bool last = d == c.num_dilations - 1;
+        char* dst = last ? XS : ((d & 1) ? T : XR);
+        L.pair_split(g->spairs[(size_t)(i * c.num_kernels + j) * c.num_dilations + d], g->convs[base + d],
+                     g->convs[base + c.num_dilations + d], xr, t, dst, LRELU, last ? inv_nk : 1.f, last && j > 0);
+        xr = dst;
+      }
+    }
+    if (pending_out) {  // output = output + x (generator.py:158-159)
+      L.add(pending_out, XS, (size_t)batch * ch * t);
+      out_cur = pending_out;
+    } else if (ro_deferred) {  // output = res_output[i-lvl-1](output) + x in one launch (x = this stage's result)
+      char* dst = (out_cur == OUTA) ? OUTB : OUTA;
+      L.conv_tm(g->tmc[g->i_resout + (i - lvl - 1)], out_cur, out_t, dst, 1.f, XS, 0);
+      out_cur = dst; out_t *= u;
+    }
+  }
+  const char* fin = (fre && out_cur) ? out_cur : XS;
+  L.conv_tm(g->tmc[g->i_post], fin, t, d_wav, 0.01f, nullptr, 2);  // leaky_relu (default slope, models.py:146) -> conv_post -> tanh
+  return L.rc;
+}
+
 static int gan_forward_impl(const mb_gan* g, const float* d_mel, int batch, int frames, const int32_t* d_frames, float* d_wav,
                             const float* d_chan_bias, void* d_workspace, size_t workspace_bytes, mb_stream_t stream) {
   MB_REQUIRE(g && d_mel && d_wav, "gan_forward: null pointer");
@@ -597,6 +769,7 @@ static int gan_forward_impl(const mb_gan* g, const float* d_mel, int batch, int 
     set_error("gan_forward: workspace %zu B < required %zu B", workspace_bytes, need);
     return MB_ENOMEM;
   }
+  if (g->tm_all) return gan_forward_tm(g, d_mel, batch, frames, d_frames, d_wav, d_chan_bias, d_workspace, workspace_bytes, stream);
   const mb_gan_config& c = g->cfg;
   const bool fre = c.kind == MB_GAN_FREGAN;
   const bool f16 = g->dtype == MB_F16;

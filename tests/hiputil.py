@@ -221,6 +221,40 @@ def resblock_pair_split_hip(x, w1, b1, w2, b2, *, dilation=1, slope=0.1, out_sca
     return f32_tm_to_cm(y).cpu()
 
 
+def conv_split_tm_hip(x, w, bias=None, *, pad=0, dilation=1, in_slope=1.0, res=None, out_act=0, out_scale=1.0, accumulate_into=None,
+                      valid=None, valid_mul=1, device="cuda"):
+    """Time-major split conv (mb_conv_split_tm).  x [B, C_in, T] float (reference layout, turned on the device), w [M, C_in, k] (torch
+    Conv1d layout), res / accumulate_into [B, M, T]; returns [B, M, T] float32 (rows beyond `valid` keep their NaN fill)."""
+    L = _lib.lib()
+    dev = torch.device(device)
+    w = w.detach().float().contiguous().cpu()
+    M, Cin, k = w.shape
+    if not L.mb_conv_split_tm_supported(M, Cin, k, dilation):
+        raise _lib.MbHipError("mb_conv_split_tm: unsupported shape")
+    packed = torch.empty(L.mb_conv_split_tm_packed_halves(M, Cin, k), dtype=torch.float16)
+    us = torch.zeros(1, dtype=torch.float32)
+    _lib.check(L.mb_conv_split_tm_pack(w.data_ptr(), M, Cin, k, packed.data_ptr(), us.data_ptr()), "mb_conv_split_tm_pack")
+    pw = packed.to(dev)
+    xt = f32_cm_to_tm(x, device)
+    B, T, _ = xt.shape
+    y = f32_cm_to_tm(accumulate_into, device) if accumulate_into is not None else \
+        torch.full((B, T, M), float("nan"), dtype=torch.float32, device=dev)
+    rt = f32_cm_to_tm(res, device) if res is not None else None
+    pb = bias.float().contiguous().to(dev) if bias is not None else None
+    vt = torch.tensor(valid, dtype=torch.int32, device=dev) if valid is not None else None
+    a = _lib.ConvSplitTmArgs()
+    a.d_x, a.d_y, a.d_wpacked = xt.data_ptr(), y.data_ptr(), pw.data_ptr()
+    a.d_bias = pb.data_ptr() if pb is not None else None
+    a.d_res = rt.data_ptr() if rt is not None else None
+    a.batch, a.t, a.c_in, a.c_out, a.ksize, a.dilation, a.pad = B, T, Cin, M, k, dilation, pad
+    a.in_slope, a.unscale, a.out_scale, a.out_act = in_slope, float(us[0]), out_scale, out_act
+    a.accumulate = int(accumulate_into is not None)
+    a.d_valid, a.valid_mul = (vt.data_ptr() if vt is not None else None), valid_mul
+    _lib.check(L.mb_conv_split_tm(C.byref(a), _lib.stream_ptr()), "mb_conv_split_tm")
+    torch.cuda.synchronize()
+    return f32_tm_to_cm(y).cpu()
+
+
 def resblock_stage_f16_hip(x, chains, *, slope=0.1, out_scale=0.0, valid=None, valid_mul=1, accumulate_into=None, device="cuda"):
     """One stage's ResBlock group in one launch (mb_resblock_stage_f16).  x: [B, C, T] float; chains: list (one per ResBlock)
     of lists (one per unit) of (w1, b1, w2, b2, dilation); returns [B, C, T] float32 (rows beyond `valid` are left NaN)."""

@@ -1,0 +1,93 @@
+"""Parity of the time-major split conv (mb_conv_split_tm, conv_split_tm.hip: conv_pre, the ConvTranspose1d upsamplers as three-tap
+polyphase convs, Fre-GAN's cond_up / res_output, conv_post of the fp32 generators) against float64 ATen.
+Reference: models/vocoder/hifigan/models.py:103-127,134-150; models/vocoder/fregan/generator.py:95-118,137-166.
+Gate: max |delta| <= 1e-5 * max(1, output RMS) (fp32-grade sums from error-compensated fp16 products)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import hiputil
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g)
+
+
+def _check(y, ref, tol=1e-5):
+    rms = float(ref.pow(2).mean().sqrt())
+    err = float((y.double() - ref).abs().max())
+    assert int(torch.isnan(y).sum()) == 0 and err <= tol * max(1.0, rms), (err, rms)
+
+
+CONVS = [
+    # (B, C_in, M, T, k, in_slope): conv_pre (80 -> 512, k 7), small / ragged shapes, conv_post-like (32 -> 1), 16 input channels
+    (2, 80, 512, 200, 7, 1.0), (1, 80, 256, 37, 7, 1.0), (3, 32, 1, 4000, 7, 0.01), (2, 16, 1, 3000, 7, 0.01),
+    (1, 128, 64, 700, 3, 0.1), (2, 256, 640, 300, 3, 0.1), (1, 64, 96, 500, 1, 1.0), (1, 512, 1280, 130, 3, 0.1),
+]
+
+
+@pytest.mark.parametrize("B,Cin,M,T,k,slope", CONVS)
+def test_conv_matches_float64(cuda, lib, B, Cin, M, T, k, slope):
+    x = _rand(B, Cin, T, seed=1)
+    w = _rand(M, Cin, k, seed=2) / (Cin * k) ** 0.5
+    b = 0.1 * _rand(M, seed=3)
+    y = hiputil.conv_split_tm_hip(x, w, b, pad=(k - 1) // 2, in_slope=slope)
+    xin = x.double() if slope == 1.0 else F.leaky_relu(x.double(), slope)
+    _check(y, F.conv1d(xin, w.double(), b.double(), padding=(k - 1) // 2))
+
+
+def _polyphase(wt, u, pad):
+    """ConvTranspose1d weight [C_in][C_out][2u] -> the three-tap conv image [u * C_out][C_in][3] (conv_split_tm.hip's header)."""
+    Cin, Cout, K = wt.shape
+    w = torch.zeros(u * Cout, Cin, 3)
+    for r in range(u):
+        for j in range(3):
+            kk = u * (1 - j) + r + pad
+            if 0 <= kk < K:
+                w[r * Cout:(r + 1) * Cout, :, j] = wt[:, :, kk].t()
+    return w
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T,u", [(2, 512, 256, 100, 5), (1, 128, 64, 777, 4), (3, 64, 32, 1500, 2), (1, 32, 16, 999, 2), (1, 80, 256, 60, 5)])
+def test_conv_transpose_as_three_tap_conv(cuda, lib, B, Cin, Cout, T, u):
+    """ups[i] = ConvTranspose1d(C, C/2, 2u, u, padding=u//2+u%2, output_padding=u%2) (models.py:120-123): the [T][u C'] result of the
+    polyphase conv, read as [u T][C'], is the transposed conv's output."""
+    K, pad = 2 * u, u // 2 + u % 2
+    x = _rand(B, Cin, T, seed=1)
+    wt = _rand(Cin, Cout, K, seed=2) / (Cin * 2) ** 0.5
+    b = 0.1 * _rand(Cout, seed=3)
+    y = hiputil.conv_split_tm_hip(x, _polyphase(wt, u, pad), b.repeat(u), pad=1, in_slope=0.1)  # [B, u*Cout, T]
+    y = y.view(B, u, Cout, T).permute(0, 2, 3, 1).reshape(B, Cout, T * u)
+    ref = F.conv_transpose1d(F.leaky_relu(x.double(), 0.1), wt.double(), b.double(), stride=u, padding=pad, output_padding=u % 2)
+    assert ref.shape[-1] == T * u
+    _check(y, ref)
+
+
+def test_residual_tanh_accumulate_and_ragged(cuda, lib):
+    B, Cin, M, T, k = 3, 64, 128, 900, 3
+    x = _rand(B, Cin, T, seed=1)
+    w = _rand(M, Cin, k, seed=2) / (Cin * k) ** 0.5
+    b = 0.1 * _rand(M, seed=3)
+    res, acc = _rand(B, M, T, seed=4), _rand(B, M, T, seed=5)
+    conv = F.conv1d(x.double(), w.double(), b.double(), padding=1)
+    _check(hiputil.conv_split_tm_hip(x, w, b, pad=1, res=res), conv + res.double())
+    _check(hiputil.conv_split_tm_hip(x, w, b, pad=1, out_act=2), torch.tanh(conv))
+    _check(hiputil.conv_split_tm_hip(x, w, b, pad=1, res=res, out_scale=0.5, accumulate_into=acc), acc.double() + 0.5 * (conv + res.double()))
+    valid, mul = [100, 33, 1], 9
+    y = hiputil.conv_split_tm_hip(x, w, b, pad=1, valid=valid, valid_mul=mul)
+    for i, v in enumerate(valid):
+        n = v * mul
+        xm = x[i:i + 1].double().clone()
+        xm[:, :, n:] = 0
+        ref = F.conv1d(xm, w.double(), b.double(), padding=1)
+        assert float((y[i, :, :n].double() - ref[0, :, :n]).abs().max()) <= 1e-5 * max(1.0, float(ref.pow(2).mean().sqrt()))
+        assert bool(torch.isnan(y[i, :, n:]).all())
+
+
+def test_rejects_bad_shapes(cuda, lib):
+    from mockingbird_amd._lib import MbHipError
+    with pytest.raises(MbHipError, match="unsupported"):
+        hiputil.conv_split_tm_hip(_rand(1, 32, 50), _rand(8, 32, 4), None, pad=1)  # even kernel size
