@@ -607,9 +607,13 @@ def main():
     result.update(side)
     if not stub:
         result["config"]["loop_path"] = {"path": model.last_path, "fallback": model.last_fallback}
+    if "exact_f32" in side:  # the strict-fp32 leg where the driver's `parsed` keeps it whole
+        xf = side["exact_f32"]
+        result["config"].update({"exact_f32_samples_per_s": xf["value"], "exact_f32_us_per_step": xf["us_per_time_step"],
+                                 "exact_f32_x_realtime": xf["x_realtime"]})
     if stub:
         if rank == 0:
-            print(json.dumps(result))
+            print(json.dumps(_ordered(result)))
         if use_dist:
             dist.barrier()
             dist.destroy_process_group()
@@ -931,6 +935,13 @@ def main():
             torch.cuda.synchronize()
             td = (time.perf_counter() - t0t) / reps
             loop_ms = getattr(tdev, "last_loop_ms", None)  # HIP events around the decoder loop alone (mb_taco_last_loop_ms)
+            post_ms = getattr(tdev, "last_postnet_ms", None)  # HIP events around CBHG postnet + post_proj (mb_taco_last_postnet_ms)
+            torch.cuda.synchronize()
+            t0e = time.perf_counter()
+            for i in range(reps):
+                tdev.encode(chars, spk, -1, None, 2 + i)
+            torch.cuda.synchronize()
+            enc_ms = (time.perf_counter() - t0e) / reps * 1e3
             iters = getattr(tdev, "last_loop_iterations", 200) or 200
             it_us = loop_ms * 1e3 / iters if loop_ms else td * 1e6 / 200
             bytes_it = 81.06e6 + 32 * Tt * (1024 + 128) * 4  # decoder weights + attention memory, per iteration
@@ -965,6 +976,17 @@ def main():
                 "value": 32 * 400 / tt, "unit": "mel frames/s", "x_realtime_at_200_samples_per_frame": 32 * 400 * 200 / tt / 16000.0,
                 "ms_per_batch": tt * 1e3, "decode_plus_postnet_ms": td * 1e3, "decoder_loop_ms": loop_ms,
                 "us_per_decoder_iteration": it_us, "launches_per_iteration": t_launches,
+                "encoder_ms": enc_ms, "postnet_ms": post_ms,
+                # SURVEY 8(d) "Tacotron CBHG postnet": MFMA-bound, 16.1 MFLOP per frame; its convs run the error-compensated fp16 products
+                # (three MFMA products per algorithmic one: ceiling 2500 / 3 = 833 TFLOP/s)
+                "postnet_roofline": ({"bound": "mfma", "kernel": "CBHG postnet + post_proj (tacotron.hip cbhg_forward: conv bank, two projections, 4 highways, "
+                                                                  "bidirectional GRU scan gru_scan.h, post_proj) over 32 x 400 frames",
+                                      "achieved": 16.1e6 * 400 * 32 / (post_ms * 1e-3) / 1e12, "peak": MFMA_F16_PEAK_TFLOPS / 3.0, "unit": "TFLOP/s",
+                                      "frac": 16.1e6 * 400 * 32 / (post_ms * 1e-3) / 1e12 / (MFMA_F16_PEAK_TFLOPS / 3.0),
+                                      "frac_of_2500": 16.1e6 * 400 * 32 / (post_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
+                                      "algorithmic_flops": 16.1e6 * 400 * 32, "ms": post_ms,
+                                      "timing": "HIP events on the call's stream around the postnet (mb_taco_last_postnet_ms)", "traffic": None}
+                                     if post_ms else None),
                 "roofline": {"bound": "hbm", "kernel": f"decoder iteration (taco_fast.h: {t_launches} launches per iteration"
                                                        + (" -- prenet fc2, attention GRU and attention are roles of one launch with tagged-granule "
                                                           "hand-offs, taco_front_kernel" if t_launches in (4, 5) else "") +
@@ -1055,10 +1077,36 @@ def main():
                 result["hifigan"]["cpu_baseline"] = cpu_baseline_hifigan()
             if "tacotron" in result:
                 result["tacotron"]["cpu_baseline"] = cpu_baseline_tacotron()
-        print(json.dumps(result))
+        if "exact_f32" in result and "roofline" in result and result["roofline"].get("algorithmic_bytes_per_launch"):
+            xf = result["exact_f32"]
+            xg = result["roofline"]["algorithmic_bytes_per_launch"] / (xf["sample_loop_ms"] * 1e-3) / 1e9
+            result["roofline"].update({"exact_f32_samples_per_s": xf["value"], "exact_f32_us_per_step": xf["us_per_time_step"],
+                                       "exact_f32_frac": xg / HBM_PEAK_GBS})
+        print(json.dumps(_ordered(result)))
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _ordered(result):
+    """The JSON line with numbers first and prose last (the driver keeps `config` / `roofline` whole but cuts the
+    tail of the line): inside every object the strings longer than 100 characters move behind everything else; at the top level the
+    contract's keys, `config`, `roofline`, `cpu_baseline`, then the secondary objects, then the notes."""
+    def tidy(d):
+        if isinstance(d, dict):
+            short = {k: tidy(v) for k, v in d.items() if not (isinstance(v, str) and len(v) > 100)}
+            short.update({k: v for k, v in d.items() if isinstance(v, str) and len(v) > 100})
+            return short
+        if isinstance(d, list):
+            return [tidy(v) for v in d]
+        return d
+    first = ("metric", "value", "unit", "x_realtime", "n_gpus", "ranks_seen", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+             "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "exact_f32", "pcie_inclusive")
+    last = ("per_rank_ms", "dtype_note")
+    out = {k: result[k] for k in first if k in result}
+    out.update({k: v for k, v in result.items() if k not in first and k not in last})
+    out.update({k: result[k] for k in last if k in result})
+    return tidy(out)
 
 
 if __name__ == "__main__":

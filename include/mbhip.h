@@ -51,7 +51,7 @@ const char* mb_last_error(void);
  *      are centres of 2^23 cells (the same seed gives other dropout masks / samples than version 1).
  *   3: mb_wavernn_loop_path takes one `resident` argument (MBHIP_WAVERNN_RESIDENT) in place of the three env_* ones; the library reads
  *      19 environment switches instead of 52 (DESIGN.md "Run-time switches": renamed / merged / moved under MBHIP_DIAG). */
-#define MB_ABI_VERSION 3
+#define MB_ABI_VERSION 4
 int mb_abi_version(void);
 /* Host-logic hook (tests/test_host_logic.py): the library's view of MBHIP_DIAG="key=value,key,..." -- the one variable behind every
  * diagnostic, A/B knob and test hook (DESIGN.md "Run-time switches").  Copies the value of `key` (a bare key reads as "1") into
@@ -270,7 +270,7 @@ int mb_resblock_pair_split(const mb_resblock_pair_split_args* a, mb_stream_t str
  * conv_post (models/vocoder/hifigan/models.py:103-127,134-150; models/vocoder/fregan/generator.py:95-118,137-166):
  *   y[b][t][m] = act(out_scale * (sum_{ci,j} W[m][ci][j] lrelu(x[b][t - pad + j dilation][ci]) + bias[m] + res[b][t][m])) (+ y)
  * x fp32 [B][t][c_in], y / res fp32 [B][t][c_out]; error-compensated fp16 MFMA products, fp32-grade sums.  Supported: k odd,
- * (k - 1) dilation <= 16, c_in a multiple of 4 (mb_conv_split_tm_supported). */
+ * (k - 1) dilation <= 80, c_in a multiple of 4 (mb_conv_split_tm_supported). */
 int mb_conv_split_tm_supported(int c_out, int c_in, int ksize, int dilation);
 size_t mb_conv_split_tm_packed_halves(int c_out, int c_in, int ksize);
 /* h_w: fp32 [c_out][c_in][ksize] (torch Conv1d layout) -> {hi, lo} fp16 A-fragment streams; *h_unscale = 2^-s (pass back as unscale) */
@@ -331,6 +331,9 @@ typedef struct mb_gan_config {
                                [C_out][C_in][k] (state name ups.i.1).  An even k makes the
                                stage one sample short (T*u - 1), as the reference's does:
                                size d_wav with mb_gan_out_samples.                       */
+  int resblock_type;        /* 0 / 1 = ResBlock1 (three (convs1[d], convs2[d]) units per block), 2 = ResBlock2 (h.resblock == '2',
+                               models.py:51-72,100; vits.py:251): two units x <- x + conv_d(lrelu(x)) with the block's first two
+                               dilations; its weights are resblocks[i].convs[0..1] in place of convs1 / convs2 (ABI 4)             */
 } mb_gan_config;
 
 typedef struct mb_gan mb_gan;
@@ -340,7 +343,7 @@ typedef struct mb_gan mb_gan;
  * weight_g/weight_v folded to `weight` (what remove_weight_norm() leaves,
  * hifigan/models.py:152-162), each conv as (weight, bias), in this order:
  *   conv_pre, ups[0..], [fregan: cond_up[0..], res_output[0..].1],
- *   resblocks[0..]: convs1[0..] then convs2[0..], conv_post.
+ *   resblocks[0..]: convs1[0..] then convs2[0..] (resblock_type 2: convs[0], convs[1]), conv_post.
  * See mockingbird_amd/weights.py:gan_weight_list. */
 int mb_gan_num_weights(const mb_gan_config* cfg);
 size_t mb_gan_weight_numel(const mb_gan_config* cfg, int index);
@@ -566,6 +569,9 @@ int mb_taco_decode(const mb_taco* t, const float* d_memory, const float* d_memor
  * only, without the state initialisation in front of it and the postnet behind it) and the number of decoder
  * iterations it ran.  Production-dims handles only (the hipGraph-replayed loop); MB_ESTATE otherwise. */
 int mb_taco_last_loop_ms(const mb_taco* t, float* ms, int* iterations);
+/* Duration of the CBHG postnet + post_proj of the last mb_taco_decode call (tacotron.py:281-283; HIP events on the call's stream) --
+ * what bench.py's tacotron.postnet_roofline prices (16.1 MFLOP per frame, MFMA-bound). */
+int mb_taco_last_postnet_ms(const mb_taco* t, float* ms);
 
 /* Launches per decoder iteration of the last mb_taco_decode call on the hipGraph-replayed loop:
  *   7 = one launch per stage, every product on the fp32 matrix pipe (also what a call falls back to when a hand-off of the fused launch

@@ -100,6 +100,7 @@ class GanConfig(C.Structure):
         ("resblock_dilations", (C.c_int * MB_GAN_MAX_DIL) * MB_GAN_MAX_KERNELS),
         ("top_k", C.c_int),
         ("interp_ups", C.c_int),
+        ("resblock_type", C.c_int),
     ]
 
 
@@ -271,6 +272,7 @@ SIGNATURES = {
     "mb_taco_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                  C.c_int, C.c_float, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mb_taco_last_postnet_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "mb_taco_last_loop_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "mb_taco_last_loop_form": (C.c_int, [C.c_void_p]),
     "mb_taco_last_loop_f16": (C.c_int, [C.c_void_p]),
@@ -285,7 +287,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 3  # include/mbhip.h: MB_ABI_VERSION
+ABI_VERSION = 4  # include/mbhip.h: MB_ABI_VERSION
 
 
 def lib():

@@ -55,7 +55,7 @@ template <int CK_, int MT_, int WN_, int NTW_> struct CtmGeom {
   static constexpr int CKP = CK + 8;        // LDS row stride of the x planes in halves
   static constexpr int MGF = MG + 4;        // fp32 result tile row stride in floats
 };
-constexpr int CTM_MAX_HALO = 16;  // (ntaps - 1) * dil the support waves' window registers are sized for (conv_pre / conv_post: 6)
+constexpr int CTM_MAX_HALO = 80;  // (ntaps - 1) * dil the support waves' window registers are sized for (ResBlock2 units: k = 7, d = 12 -> 72)
 
 template <int CK_, int MT_, int WN_, int NTW_>
 __global__ __launch_bounds__(64 * (4 + CTM_NL)) __attribute__((amdgpu_waves_per_eu(2, 2)))

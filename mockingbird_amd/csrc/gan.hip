@@ -56,10 +56,16 @@ static int gan_specs(const mb_gan_config* c, std::vector<ConvSpec>* out) {
     for (int i = lvl + 1; i < c->num_upsamples; ++i)  // res_output (generator.py:103-110)
       out->push_back({uic >> (i + 1), uic >> i, 1, 1, 0, 1, 0});
   }
+  MB_REQUIRE(c->resblock_type >= 0 && c->resblock_type <= 2, "gan: resblock_type %d", c->resblock_type);
+  MB_REQUIRE(c->resblock_type != 2 || c->num_dilations >= 2, "gan: ResBlock2 needs two dilations per block");
   for (int i = 0; i < c->num_upsamples; ++i) {
     const int ch = uic >> (i + 1);
     for (int j = 0; j < c->num_kernels; ++j) {
       const int k = c->resblock_kernel_sizes[j];
+      if (c->resblock_type == 2) {  // ResBlock2.convs[0..1] (models.py:54-61)
+        for (int d = 0; d < 2; ++d) out->push_back({ch, ch, k, 1, get_padding(k, c->resblock_dilations[j][d]), c->resblock_dilations[j][d], 0});
+        continue;
+      }
       for (int d = 0; d < c->num_dilations; ++d) {
         const int dil = c->resblock_dilations[j][d];
         out->push_back({ch, ch, k, 1, get_padding(k, dil), dil, 0});
@@ -167,7 +173,7 @@ struct mb_gan {
   std::vector<SPair> spairs;
   // ... and every other conv as a time-major split conv (conv_split_tm.hip), indexed as `convs` (ResBlock entries stay empty).  When
   // every conv of the generator has an image (tm_all) the whole forward runs time-major: the mel is turned once, nothing else is.
-  struct TmConv { DevBuf w, bias; float us = 0.f; int c_in = 0, m = 0, k = 0, pad = 0, rep = 1; };
+  struct TmConv { DevBuf w, bias; float us = 0.f; int c_in = 0, m = 0, k = 0, pad = 0, dil = 1, rep = 1; };
   std::vector<TmConv> tmc;
   bool tm_all = false;
   int hop;
@@ -242,7 +248,8 @@ extern "C" int mb_gan_create_ex(const mb_gan_config* cfg, const float* const* h_
     g->i_cond = idx; idx += cfg->num_upsamples - lvl;
     g->i_resout = idx; idx += cfg->num_upsamples - lvl - 1;
   }
-  g->i_rb = idx; idx += cfg->num_upsamples * cfg->num_kernels * cfg->num_dilations * 2;
+  const bool rb2 = cfg->resblock_type == 2;  // two single-conv units per block: none of the fused (convs1, convs2) plans applies
+  g->i_rb = idx; idx += cfg->num_upsamples * cfg->num_kernels * (rb2 ? 2 : cfg->num_dilations * 2);
   g->i_post = idx;
   // MBHIP_GAN_FUSE = all (default) | nochain (no one-launch ResBlock chains) | units (fused units only: no stage / chain launches) |
   // none (one launch per conv): the fallbacks the parity tests compare the fused launches with
@@ -255,7 +262,7 @@ extern "C" int mb_gan_create_ex(const mb_gan_config* cfg, const float* const* h_
   }
   // (cm: the fp32 path's channel-major plan of rounds 4-5 -- resblock_stage_f32 launches + one launch per wide conv -- instead of the
   //  time-major split pairs; on the fp16 path it reads as "all")
-  const bool no_fuse = fuse == "none", no_stage = no_fuse || fuse == "units", no_chain = no_stage || fuse == "nochain";
+  const bool no_fuse = fuse == "none" || rb2, no_stage = no_fuse || fuse == "units", no_chain = no_stage || fuse == "nochain";
   const bool f32_cm = fuse == "cm";
   if (dtype == MB_F32 && !no_fuse && !f32_cm) {
     const int nd = cfg->num_dilations;
@@ -302,7 +309,7 @@ extern "C" int mb_gan_create_ex(const mb_gan_config* cfg, const float* const* h_
           if (rc) { mb_gan_destroy(g); return rc; }
         }
   }
-  if (dtype == MB_F32 && !g->spairs.empty() && !cfg->interp_ups) {
+  if (dtype == MB_F32 && (!g->spairs.empty() || (rb2 && fuse != "none" && !f32_cm)) && !cfg->interp_ups) {
     // conv_pre / ups / cond_up / res_output / conv_post as time-major split convs.  ConvTranspose1d(C -> C', 2 u taps, stride u, padding
     // u/2 + u%2) = a three-tap conv to u C' channels: W[r C' + co][ci][j] = w[ci][co][u (1 - j) + r + pad]  (conv_split_tm.hip)
     bool all = true;
@@ -338,12 +345,12 @@ extern "C" int mb_gan_create_ex(const mb_gan_config* cfg, const float* const* h_
           memcpy(&beff[(size_t)r * sp.c_out], b, sp.c_out * sizeof(float));
         }
       } else {
-        if (sp.stride != 1 || sp.dil != 1) return 1;
-        t.c_in = sp.c_in; t.m = sp.c_out; t.k = sp.k; t.pad = sp.pad; t.rep = 1;
+        if (sp.stride != 1) return 1;
+        t.c_in = sp.c_in; t.m = sp.c_out; t.k = sp.k; t.pad = sp.pad; t.dil = sp.dil; t.rep = 1;
         weff.assign(w, w + (size_t)sp.c_out * sp.c_in * sp.k);
         beff.assign(b, b + sp.c_out);
       }
-      if (!mb_conv_split_tm_supported(t.m, t.c_in, t.k, 1)) return 1;
+      if (!mb_conv_split_tm_supported(t.m, t.c_in, t.k, t.dil)) return 1;
       img.assign(mb_conv_split_tm_packed_halves(t.m, t.c_in, t.k) / 2, 0.f);
       int r = mb_conv_split_tm_pack(weff.data(), t.m, t.c_in, t.k, reinterpret_cast<uint16_t*>(img.data()), &t.us);
       if (!r) r = t.w.upload(img.data(), img.size());
@@ -363,6 +370,8 @@ extern "C" int mb_gan_create_ex(const mb_gan_config* cfg, const float* const* h_
       for (int i = lvl; i < cfg->num_upsamples; ++i) want(g->i_cond + (i - lvl), 1);
       for (int i = lvl + 1; i < cfg->num_upsamples; ++i) want(g->i_resout + (i - lvl - 1), cfg->upsample_rates[i]);
     }
+    if (rb2)
+      for (int q = 0; q < cfg->num_upsamples * cfg->num_kernels * 2; ++q) want(g->i_rb + q, 1);
     want(g->i_post, 1);
     if (rc) { mb_gan_destroy(g); return rc; }
     g->tm_all = all && !diag_int("gan_tm_pairs_only");  // A/B: the ResBlock units time-major, everything else channel-major (first form of the round)
@@ -618,13 +627,14 @@ struct Launcher {
     rc = mb_resblock_pair_split(&a, (mb_stream_t)s);
   }
   // time-major split conv (conv_split_tm.hip); t = input rows, the result has t rows of tc.m floats (= t * tc.rep rows of the conv's c_out)
-  void conv_tm(const mb_gan::TmConv& tc, const void* x, int t, void* y, float in_slope, const void* res, int out_act) {
+  void conv_tm(const mb_gan::TmConv& tc, const void* x, int t, void* y, float in_slope, const void* res, int out_act,
+               float out_scale = 1.f, int accumulate = 0) {
     if (rc) return;
     mb_conv_split_tm_args a;
     memset(&a, 0, sizeof(a));
     a.d_x = (const float*)x; a.d_y = (float*)y; a.d_wpacked = tc.w.p; a.d_bias = tc.bias.p; a.d_res = (const float*)res;
-    a.batch = batch; a.t = t; a.c_in = tc.c_in; a.c_out = tc.m; a.ksize = tc.k; a.dilation = 1; a.pad = tc.pad;
-    a.in_slope = in_slope; a.unscale = tc.us; a.out_scale = 1.f; a.out_act = out_act;
+    a.batch = batch; a.t = t; a.c_in = tc.c_in; a.c_out = tc.m; a.ksize = tc.k; a.dilation = tc.dil; a.pad = tc.pad;
+    a.in_slope = in_slope; a.unscale = tc.us; a.out_scale = out_scale; a.out_act = out_act; a.accumulate = accumulate;
     a.d_valid = valid; a.valid_mul = t / frames_max;
     rc = mb_conv_split_tm(&a, (mb_stream_t)s);
   }
@@ -736,6 +746,12 @@ static int gan_forward_tm(const mb_gan* g, const float* d_mel, int batch, int fr
     L.conv_tm(g->tmc[g->i_ups + i], XS, t, X, LRELU, nullptr, 0);  // x = ups[i](leaky_relu(x))
     t *= u;
     for (int j = 0; j < c.num_kernels; ++j) {  // xs = mean_j resblock_j(x): chains ping-pong XR / T, the mean accumulates in XS
+      if (c.resblock_type == 2) {  // ResBlock2 (models.py:63-68): x <- x + conv_d(lrelu(x)), twice
+        const int b2 = g->i_rb + (i * c.num_kernels + j) * 2;
+        L.conv_tm(g->tmc[b2], X, t, XR, LRELU, X, 0);
+        L.conv_tm(g->tmc[b2 + 1], XR, t, XS, LRELU, XR, 0, inv_nk, j > 0);
+        continue;
+      }
       const int base = g->i_rb + ((i * c.num_kernels + j) * c.num_dilations) * 2;
       const char* xr = X;
       for (int d = 0; d < c.num_dilations; ++d) {
@@ -888,6 +904,12 @@ static int gan_forward_impl(const mb_gan* g, const float* d_mel, int batch, int 
       if (!L.rc) L.rc = mb_resblock_stage_f32(&a, stream);
     } else
     for (int j = 0; j < c.num_kernels; ++j) {
+      if (c.resblock_type == 2) {  // ResBlock2 (models.py:63-68): x <- x + conv_d(lrelu(x)), twice; one launch per conv
+        const int b2 = g->i_rb + (i * c.num_kernels + j) * 2;
+        L.conv(g->convs[b2], X, t, XR, 1, LRELU, X, 1.f, 0, 0);
+        L.conv(g->convs[b2 + 1], XR, t, XS, 1, LRELU, XR, inv_nk, j > 0, 0);
+        continue;
+      }
       const int base = g->i_rb + ((i * c.num_kernels + j) * c.num_dilations) * 2;
       const char* xr = X;
       if (!f16 && !g->r32.empty() && !g->r32[(size_t)i * c.num_kernels + j].empty()) {  // fp32 path, 64 channels: one launch per ResBlock / unit

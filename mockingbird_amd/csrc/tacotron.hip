@@ -1344,6 +1344,8 @@ struct mb_taco {
   ConvL pm_conv; DevBuf rin_a4; int last_form = 7;
   DevBuf f_gru_w, f_pre_w, f_bih4, f_bhh4, f_l1_b4, f_l2_b4, f_fc1_w, f_stop_w, f_stopc_w, f_l1_hh, f_l2_hh;
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // loop timing (mb_taco_last_loop_ms)
+  hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr;  // postnet timing (mb_taco_last_postnet_ms)
+  mutable bool post_timed = false;
   int last_iters = 0; bool timed = false;
   // captured iterations of the fast loop: reused while the call arguments do not change (handle is single-threaded)
   struct GraphKey {
@@ -1714,6 +1716,7 @@ extern "C" int mb_taco_create(const mb_taco_config* cfg, const float* const* hw,
                 hipStreamCreateWithFlags(&t->loop_stream, hipStreamNonBlocking) != hipSuccess ||
                 hipEventCreateWithFlags(&t->ev_in, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreate(&t->ev_t0) != hipSuccess || hipEventCreate(&t->ev_t1) != hipSuccess ||
+                hipEventCreate(&t->ev_p0) != hipSuccess || hipEventCreate(&t->ev_p1) != hipSuccess ||
                 hipEventCreateWithFlags(&t->ev_flags[0], hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&t->ev_flags[1], hipEventDisableTiming) != hipSuccess)) {
       set_error("taco_create: pinned flag buffer / events");
@@ -1760,6 +1763,8 @@ extern "C" void mb_taco_destroy(mb_taco* t) {
   if (t->ev_in) (void)hipEventDestroy(t->ev_in);
   if (t->ev_t0) (void)hipEventDestroy(t->ev_t0);
   if (t->ev_t1) (void)hipEventDestroy(t->ev_t1);
+  if (t->ev_p0) (void)hipEventDestroy(t->ev_p0);
+  if (t->ev_p1) (void)hipEventDestroy(t->ev_p1);
   if (t->loop_stream) (void)hipStreamDestroy(t->loop_stream);
   t->post.release(); t->post_proj.release(); t->enc.release();
   t->enc_fc1.release(); t->enc_fc2.release(); t->enc_proj.release();
@@ -2348,8 +2353,10 @@ extern "C" int mb_taco_decode(const mb_taco* t, const float* d_memory, const flo
                           hipMemcpyDeviceToDevice, s));
   int rc = MB_OK;
 #define RC(x) do { if (!rc) rc = (x); } while (0)
+  if (t->ev_p0) MB_HIP(hipEventRecord(t->ev_p0, s));
   RC(cbhg_forward(t->post, L.melc, B, F, L.cb, s));
   RC(run_conv(t->post_proj, L.cb.seq, B, F, L.linc, 0, 0, 0, nullptr, nullptr, 0, s));
+  if (t->ev_p1) { MB_HIP(hipEventRecord(t->ev_p1, s)); t->post_timed = true; }
   if (!rc) {
     MB_HIP(hipMemsetAsync(d_linear, 0, sizeof(float) * (size_t)B * M * max_steps, s));
     MB_HIP(hipMemcpy2DAsync(d_linear, sizeof(float) * max_steps, L.linc, sizeof(float) * F, sizeof(float) * F, (size_t)B * M,
@@ -2382,6 +2389,14 @@ extern "C" int mb_taco_last_loop_f16(const mb_taco* t) {
 extern "C" int mb_taco_last_loop_form(const mb_taco* t) {
   if (!t || !t->timed) return -1;
   return t->last_form;
+}
+
+extern "C" int mb_taco_last_postnet_ms(const mb_taco* t, float* ms) {
+  MB_REQUIRE(t && ms, "taco_last_postnet_ms: null pointer");
+  if (!t->post_timed) { set_error("taco_last_postnet_ms: no decode with a postnet pass yet"); return MB_ESTATE; }
+  MB_HIP(hipEventSynchronize(t->ev_p1));
+  MB_HIP(hipEventElapsedTime(ms, t->ev_p0, t->ev_p1));
+  return MB_OK;
 }
 
 extern "C" int mb_taco_last_loop_ms(const mb_taco* t, float* ms, int* iterations) {

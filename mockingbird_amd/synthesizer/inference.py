@@ -82,6 +82,8 @@ class TacotronDevice:
             self.last_loop_ms, self.last_loop_iterations = ms.value, its.value
             self.last_loop_launches_per_iteration = L.mb_taco_last_loop_form(self._h)  # 4: fused front + folded rnn_input, 5: fused front, 7: one launch each
             self.last_loop_f16_products = bool(L.mb_taco_last_loop_f16(self._h) == 1)  # split-f16 products on the K >= 1024 tiles
+        pms = C.c_float()
+        self.last_postnet_ms = pms.value if L.mb_taco_last_postnet_ms(self._h, C.byref(pms)) == 0 else None  # CBHG + post_proj (HIP events)
         return mel[:, :, :F], lin[:, :, :F], attn[:, :F // r]
 
     def encode(self, chars, speaker_embedding, style_idx=0, enc_masks=None, seed=None):

@@ -37,9 +37,9 @@ def fold_weight_norm(state: Dict[str, torch.Tensor], prefix: str) -> torch.Tenso
 # ---------------------------------------------------------------- GAN vocoders
 def gan_config(h: dict, kind: int, top_k: int = 4) -> "_lib.GanConfig":
     """AttrDict/json config (hifigan/config_16k_.json, fregan/config.json) -> mb_gan_config."""
-    if str(h.get("resblock", "1")) != "1":
-        raise _lib.MbHipError("only resblock type '1' is implemented (the shipped configs)")
     c = _lib.GanConfig()
+    # resblock = ResBlock1 if h.resblock == '1' else ResBlock2  (hifigan/models.py:100, vits.py:251)
+    c.resblock_type = 1 if str(h.get("resblock", "1")) == "1" else 2
     c.kind = kind
     # h.sampling_rate == 24000 swaps every ConvTranspose1d for Interpolate(nearest)+Conv1d (models.py:107-118)
     c.interp_ups = int(kind == 0 and int(h.get("sampling_rate", 16000)) == 24000)
@@ -69,6 +69,9 @@ def gan_weight_list(state: Dict[str, torch.Tensor], cfg: "_lib.GanConfig") -> Li
         names += [f"cond_up.{i}" for i in range(cfg.num_upsamples - lvl)]
         names += [f"res_output.{i}.1" for i in range(cfg.num_upsamples - lvl - 1)]
     for i in range(cfg.num_upsamples * cfg.num_kernels):
+        if cfg.resblock_type == 2:  # ResBlock2.convs (models.py:54-61): two convs, the block's first two dilations
+            names += [f"resblocks.{i}.convs.{d}" for d in range(2)]
+            continue
         names += [f"resblocks.{i}.convs1.{d}" for d in range(cfg.num_dilations)]
         names += [f"resblocks.{i}.convs2.{d}" for d in range(cfg.num_dilations)]
     names.append("conv_post")

@@ -42,6 +42,24 @@ def _resblock1(w, prefix, x, kernel_size, dilations):
     return x
 
 
+def _resblock2(w, prefix, x, kernel_size, dilations):
+    # ResBlock2.forward hifigan/models.py:63-68 == fregan/generator.py:67-72 == sublayer/vits_modules.py:236-245 (x_mask=None):
+    # two convs, the first two dilations of the block
+    for d in range(2):
+        xt = F.leaky_relu(x, LRELU_SLOPE)
+        xt = F.conv1d(xt, w[f"{prefix}.convs.{d}.weight"], w[f"{prefix}.convs.{d}.bias"],
+                      dilation=dilations[d], padding=get_padding(kernel_size, dilations[d]))
+        x = xt + x
+    return x
+
+
+def _resblock(w, h, prefix, x, kernel_size, dilations):
+    # resblock = ResBlock1 if h.resblock == '1' else ResBlock2  (hifigan/models.py:100, fregan/generator.py:91, vits.py:251)
+    if str(h.get("resblock", "1")) == "1":
+        return _resblock1(w, prefix, x, kernel_size, dilations)
+    return _resblock2(w, prefix, x, kernel_size, dilations)
+
+
 def _up(w, name, x, u):
     # ConvTranspose1d(k, u, padding=u//2+u%2, output_padding=u%2) models.py:120-123
     return F.conv_transpose1d(x, w[name + ".weight"], w[name + ".bias"], stride=u,
@@ -66,8 +84,8 @@ def hifigan_forward(w, h, mel):
         x = _up_interp(w, f"ups.{i}", x, u, h["upsample_kernel_sizes"][i]) if interp else _up(w, f"ups.{i}", x, u)
         xs = None
         for j in range(nk):
-            r = _resblock1(w, f"resblocks.{i * nk + j}", x, h["resblock_kernel_sizes"][j],
-                           h["resblock_dilation_sizes"][j])
+            r = _resblock(w, h, f"resblocks.{i * nk + j}", x, h["resblock_kernel_sizes"][j],
+                          h["resblock_dilation_sizes"][j])
             xs = r if xs is None else xs + r
         x = xs / nk
     x = F.leaky_relu(x)  # default slope 0.01 (models.py:146)
@@ -96,8 +114,8 @@ def fregan_forward(w, h, mel, top_k=4):
         x = _up(w, f"ups.{i}", x, rates[i])
         xs = None
         for j in range(nk):
-            r = _resblock1(w, f"resblocks.{i * nk + j}", x, h["resblock_kernel_sizes"][j],
-                           h["resblock_dilation_sizes"][j])
+            r = _resblock(w, h, f"resblocks.{i * nk + j}", x, h["resblock_kernel_sizes"][j],
+                          h["resblock_dilation_sizes"][j])
             xs = r if xs is None else xs + r
         x = xs / nk
         if output is not None:
@@ -122,7 +140,7 @@ def vits_generator_forward(w, h, x, g=None):
         x = F.conv_transpose1d(x, w[f"ups.{i}.weight"], w[f"ups.{i}.bias"], stride=u, padding=(k - u) // 2)
         xs = None
         for j in range(nk):
-            r = _resblock1(w, f"resblocks.{i * nk + j}", x, h["resblock_kernel_sizes"][j], h["resblock_dilation_sizes"][j])
+            r = _resblock(w, h, f"resblocks.{i * nk + j}", x, h["resblock_kernel_sizes"][j], h["resblock_dilation_sizes"][j])
             xs = r if xs is None else xs + r
         x = xs / nk
     x = F.leaky_relu(x)

@@ -47,6 +47,45 @@ def gan():
     print("gan.npz", {k: v.shape for k, v in out.items()})
 
 
+def gan_rb2():
+    """h.resblock == '2': ResBlock2 generators (hifigan/models.py:51-72,100) and the VITS decoder built with resblock='2' (vits.py:251)."""
+    import types
+    from utils.util import AttrDict
+    from models.vocoder.hifigan.models import Generator
+    out = {}
+    for uic, frames, batch, seed in synth.GAN_RB2_CASES:
+        h = synth.small(synth.HIFIGAN_RB2, uic)
+        st = synth.gan_state(h, "hifigan", seed=seed)
+        g = Generator(AttrDict(h))
+        g.load_state_dict(st["generator"])
+        g.eval()
+        g.remove_weight_norm()
+        mel = torch.from_numpy(synth.mel_input(frames, batch, seed=seed + 1))
+        with torch.no_grad():
+            y = g(mel)
+        out[f"hifigan_rb2_uic{uic}_f{frames}_b{batch}_s{seed}"] = y.numpy()
+    for name in ("loguru", "monotonic_align"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            if name == "loguru":
+                m.logger = types.SimpleNamespace(info=print, debug=print, warning=print, error=print)
+            sys.modules[name] = m
+    from models.synthesizer.models.vits import Generator as VGen
+    for name, uic, frames, batch, use_g, seed in synth.VITS_RB2_CASES:
+        h = dict(synth.VITS_DEC_RB2)
+        h["upsample_initial_channel"] = uic
+        g = VGen(h["initial_channel"], h["resblock"], h["resblock_kernel_sizes"], h["resblock_dilation_sizes"],
+                 h["upsample_rates"], uic, h["upsample_kernel_sizes"], gin_channels=h["gin_channels"])
+        g.load_state_dict(synth.vits_dec_state(h, seed=seed))
+        g.eval()
+        z, spk = synth.vits_latent(frames, batch, seed=seed + 1)
+        with torch.no_grad():
+            y = g(torch.from_numpy(z), g=torch.from_numpy(spk) if use_g else None)
+        out["vits_" + name] = y.numpy()
+    np.savez_compressed(os.path.join(HERE, "gan_rb2.npz"), torch_version=torch.__version__, **out)
+    print("gan_rb2.npz", {k: (v.shape, float(np.abs(v).mean())) for k, v in out.items()})
+
+
 def gan24k():
     """HiFi-GAN with h.sampling_rate == 24000: Interpolate+Conv1d upsampler (models.py:107-118)."""
     from utils.util import AttrDict
@@ -247,7 +286,7 @@ def wave():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gan", "gan24k", "wavernn", "maximum_path", "tacotron", "ppg2mel", "vits", "wave"]
+    which = sys.argv[1:] or ["gan", "gan_rb2", "gan24k", "wavernn", "maximum_path", "tacotron", "ppg2mel", "vits", "wave"]
     for w in which:
         if w in globals():
             globals()[w]()

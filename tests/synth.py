@@ -23,6 +23,13 @@ HIFIGAN_24K = {
     "resblock_dilation_sizes": [[1, 3, 5], [1, 3, 5], [1, 3, 5]], "num_mels": 80,
     "sampling_rate": 24000, "seed": 1234,
 }
+# h.resblock == '2' (hifigan/models.py:100): the V3-style stack, ResBlock2 units with the first two dilations of every block
+HIFIGAN_RB2 = {
+    "resblock": "2", "upsample_rates": [8, 8, 4], "upsample_kernel_sizes": [16, 16, 8],
+    "upsample_initial_channel": 256, "resblock_kernel_sizes": [3, 5, 7],
+    "resblock_dilation_sizes": [[1, 2], [2, 6], [3, 12]], "num_mels": 80, "sampling_rate": 16000, "seed": 1234,
+}
+GAN_RB2_CASES = ((64, 12, 2, 7), (256, 7, 1, 8))  # (upsample_initial_channel, frames, batch, seed)
 GAN24K_CASES = ((64, 16, 2, 5), (256, 9, 1, 6))  # (upsample_initial_channel, frames, batch, seed)
 FREGAN_16K = {
     "resblock": "1", "upsample_rates": [5, 5, 2, 2, 2], "upsample_kernel_sizes": [10, 10, 4, 4, 4],
@@ -85,6 +92,10 @@ def gan_state(h, kind="hifigan", seed=0, top_k=4):
         ch = uic >> (i + 1)
         for j, k in enumerate(h["resblock_kernel_sizes"]):
             nd = len(h["resblock_dilation_sizes"][j])
+            if str(h.get("resblock", "1")) != "1":  # ResBlock2 (models.py:51-72): convs[0..1]
+                for d in range(2):
+                    conv(f"resblocks.{i * nk + j}.convs.{d}", ch, ch, k, 0.7)
+                continue
             for d in range(nd):
                 conv(f"resblocks.{i * nk + j}.convs1.{d}", ch, ch, k, 1.2)
             for d in range(nd):
@@ -426,6 +437,8 @@ def vits_latent(frames, batch=1, seed=0, channels=192, gin=256):
 
 
 VITS_CASES = [("uic64_t9_b2_g", 64, 9, 2, True, 3), ("uic512_t6_b1_nog", 512, 6, 1, False, 4)]
+VITS_DEC_RB2 = dict(VITS_DEC, resblock="2", resblock_kernel_sizes=[3, 5, 7], resblock_dilation_sizes=[[1, 2], [2, 6], [3, 12]])
+VITS_RB2_CASES = [("rb2_uic64_t9_b2_g", 64, 9, 2, True, 5), ("rb2_uic256_t6_b1_nog", 256, 6, 1, False, 6)]
 
 
 # ---------------------------------------------------------------------------- waveform wire format

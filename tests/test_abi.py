@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert not unbound, f"declared in mbhip.h but not bound in _lib.SIGNATURES: {unbound}"
     extra = [s for s in _lib.SIGNATURES if s not in syms]
     assert not extra, f"bound but not declared in the header: {extra}"
-    assert lib.mb_abi_version() == 3
+    assert lib.mb_abi_version() == 4
 
 
 def test_struct_layouts_match_header_sizes(lib, tmp_path):

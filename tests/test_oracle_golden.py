@@ -49,6 +49,37 @@ def test_hifigan_24k_oracle_vs_golden(case):
     assert np.sqrt((gold ** 2).mean()) > 0.05
 
 
+@pytest.mark.parametrize("case", synth.GAN_RB2_CASES)
+def test_hifigan_resblock2_oracle_vs_golden(case):
+    """h.resblock == '2' -> ResBlock2 (hifigan/models.py:51-72,100): oracle.gan against the reference Generator's own output."""
+    uic, f, b, s = case
+    gold = np.load(os.path.join(G, "gan_rb2.npz"))[f"hifigan_rb2_uic{uic}_f{f}_b{b}_s{s}"]
+    h = synth.small(synth.HIFIGAN_RB2, uic)
+    w = og.fold_weight_norm_state(synth.gan_state(h, "hifigan", seed=s)["generator"])
+    mel = torch.from_numpy(synth.mel_input(f, b, seed=s + 1))
+    with torch.no_grad():
+        y = og.hifigan_forward(w, h, mel).numpy()
+    assert y.shape == gold.shape == (b, 1, f * 256)
+    assert np.abs(y - gold).max() <= 2e-6, np.abs(y - gold).max()
+    assert np.sqrt((gold ** 2).mean()) > 0.05
+
+
+@pytest.mark.parametrize("case", synth.VITS_RB2_CASES)
+def test_vits_generator_resblock2_oracle_vs_golden(case):
+    """vits.Generator(resblock='2') (vits.py:251): oracle.gan.vits_generator_forward against the reference module's output."""
+    name, uic, frames, batch, use_g, seed = case
+    gold = np.load(os.path.join(G, "gan_rb2.npz"))["vits_" + name]
+    h = dict(synth.VITS_DEC_RB2)
+    h["upsample_initial_channel"] = uic
+    w = og.fold_weight_norm_state(synth.vits_dec_state(h, seed=seed))
+    z, spk = synth.vits_latent(frames, batch, seed=seed + 1)
+    torch.set_num_threads(1)
+    with torch.no_grad():
+        y = og.vits_generator_forward(w, h, torch.from_numpy(z), torch.from_numpy(spk) if use_g else None)
+    assert y.shape == gold.shape == (batch, 1, frames * 256)
+    assert float(np.abs(y.numpy() - gold).max()) <= 2e-6
+
+
 def test_wavernn_oracle_vs_golden():
     gold = np.load(os.path.join(G, "wavernn.npz"))
     st = synth.wavernn_state(seed=5)

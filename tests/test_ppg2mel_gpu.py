@@ -131,6 +131,39 @@ def test_resident_loop_matches_oracle_and_the_chain(cuda, lib, monkeypatch, T, w
     assert hiputil.relerr(a[0], b[0])["max_abs"] <= 2e-4
 
 
+@pytest.mark.parametrize("B", [8, 32])
+def test_batch_resident_loop_small_activations(cuda, lib, monkeypatch, capsys, B):
+    """ppg_batch.h's split products on operands of |x| ~ 1e-3 -- the encoder memory (hence the attention context
+    every LSTM and the projection multiply) scaled by 2^-10 and the context columns of their weights by 2^10: the same sums, operands
+    a thousand times smaller.  One resident launch, against the oracle on the same masks."""
+    from mockingbird_amd.ppg2mel import Ppg2MelDecoder
+    hp = synth.PPG2MEL_HP
+    w = {k: v.clone() for k, v in synth.ppg2mel_decoder_state(hp, seed=4, stop_bias=0.0).items()}
+    P, A, E = op.HP["prenet_dims"][-1], op.HP["attention_rnn_dim"], op.HP["enc_dim"]
+    Dd = op.HP["decoder_rnn_dim"]
+    w["attention_rnn.weight_ih"][:, P:P + E] *= 2.0 ** 10
+    w["decoder_rnn_layers.0.weight_ih"][:, A:A + E] *= 2.0 ** 10
+    w["linear_projection.linear_layer.weight"][:, Dd:Dd + E] *= 2.0 ** 10
+    w["stop_layer.linear_layer.weight"][:, Dd:Dd + E] *= 2.0 ** 10
+    dec = Ppg2MelDecoder(w, hp)
+    T = 30
+    mem = torch.from_numpy(synth.ppg2mel_memory(B, T, seed=8)) * 2.0 ** -10
+    masks = synth.ppg2mel_dropout_masks(17, T * 2, B)
+    with torch.no_grad():
+        omel, oal, ostop = op.inference_batched(w, dict(op.HP), mem, masks=op.MaskSource(list(masks)))
+    monkeypatch.delenv("MBHIP_DIAG", raising=False)
+    monkeypatch.setenv("MBHIP_PPG_RESIDENT", "1")
+    mel, al, stop = dec.decode(mem.cuda(), dropout=masks)
+    assert dec.last_loop_launches == 1, "the batch resident kernel did not run"
+    n = oal.shape[1]
+    gm, ga = mel.cpu().reshape(B, -1, 80)[:, :n * 2], al.cpu()[:, :n]
+    e = hiputil.relerr(gm, omel)
+    with capsys.disabled():
+        print(f"\n[ppg_batch small activations, B = {B}] mel max|d| = {e['max_abs']:.2e}, alignment = {float((ga - oal).abs().max()):.2e}")
+    assert e["nan"] == 0 and e["max_abs"] <= MEL_TOL and float((ga - oal).abs().max()) <= ALIGN_TOL, e
+    assert float(omel.abs().mean()) > 0.05
+
+
 @pytest.mark.parametrize("B,T,wseed,sb,mseed", [(2, 24, 3, 0.0, 3), (5, 30, 4, -1.0, 5), (16, 26, 3, 0.0, 6), (17, 40, 5, 0.0, 4), (32, 28, 6, 0.0, 7),
                                                   (3, 301, 5, -1.0, 9)])
 def test_batch_resident_loop_matches_oracle_and_the_chain(cuda, lib, monkeypatch, B, T, wseed, sb, mseed):
