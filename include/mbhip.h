@@ -286,11 +286,25 @@ typedef struct mb_conv_split_tm_args {
   float in_slope;         /* leaky_relu slope in (0,1] applied to x; 1 = none       */
   float unscale;          /* *h_unscale of the pack                                 */
   float out_scale;        /* 0 = 1.0                                                */
-  int out_act;            /* 0 none, 2 tanh                                         */
+  int out_act;            /* 0 none, 1 relu, 2 tanh, 3 sigmoid, 4 highway: y = g relu(v) + (1 - g) res with g = d_gate (common/highway_network.py:12-17) */
   int accumulate;         /* y += result (needs c_out % 4 == 0)                     */
   const int* d_valid; int valid_mul;  /* ragged batches: item b has d_valid[b] * valid_mul rows (NULL = t) */
+  const float* d_gate;    /* fp32 [B][t][c_out], out_act 4 only                     */
+  const float* d_post_scale; const float* d_post_shift;  /* fp32 [c_out] affine behind the activation (BatchNorm after ReLU,
+                                                            common/batch_norm_conv.py:11-14), or NULL */
+  long long x_bstride;    /* floats between batch items of x (0 = t * c_in)         */
+  int x_row_stride;       /* floats between rows of x (0 = c_in): e.g. a [t][B][c] scan output read as B items */
+  int x_split;            /* d_x is a SPLIT tensor -- fp16 [B][t][hi | lo][c_in], hi = fp16(x), lo = fp16((x - hi) 2^11): what d_ysplit of a
+                             producer, mb_maxpool2_tm or mb_highway_tm wrote -- and is staged by copy (c_in % 8 == 0, > 32, in_slope 1) */
+  void* d_ysplit;         /* also write the result as such a split tensor [B][t][hi | lo][c_out], or NULL */
 } mb_conv_split_tm_args;
 int mb_conv_split_tm(const mb_conv_split_tm_args* a, mb_stream_t stream);
+/* MaxPool1d(2, stride 1, padding 1)[:t] over time (sublayer/cbhg.py:20,61-62) on fp32 [B][t][channels]: y[t] = max(x[t-1], x[t]), as
+ * fp32 (d_y) and / or as a split tensor (d_ysplit); one of them may be NULL */
+int mb_maxpool2_tm(const float* d_x, float* d_y, void* d_ysplit, int batch, int t, int channels, mb_stream_t stream);
+/* Highway combine (common/highway_network.py:12-17): d_hg fp32 [rows][2 channels] = (W1 x + b1 | W2 x + b2) of one conv launch, d_x fp32
+ * [rows][channels] -> d_y = g relu(h) + (1 - g) x with g = sigmoid(W2 x + b2), also as a split tensor (d_ysplit, may be NULL) */
+int mb_highway_tm(const float* d_hg, const float* d_x, float* d_y, void* d_ysplit, long long rows, int channels, mb_stream_t stream);
 /* fp32 [B][channels][t] (the reference's layout) <-> fp32 [B][t][channels] (the layout above), out of place */
 int mb_f32_cm_to_tm(const float* d_x, float* d_y, int batch, int channels, int t, mb_stream_t stream);
 int mb_f32_tm_to_cm(const float* d_x, float* d_y, int batch, int channels, int t, mb_stream_t stream);

@@ -120,6 +120,8 @@ class ConvSplitTmArgs(C.Structure):
         ("ksize", C.c_int), ("dilation", C.c_int), ("pad", C.c_int),
         ("in_slope", C.c_float), ("unscale", C.c_float), ("out_scale", C.c_float),
         ("out_act", C.c_int), ("accumulate", C.c_int), ("d_valid", C.c_void_p), ("valid_mul", C.c_int),
+        ("d_gate", C.c_void_p), ("d_post_scale", C.c_void_p), ("d_post_shift", C.c_void_p),
+        ("x_bstride", C.c_longlong), ("x_row_stride", C.c_int), ("x_split", C.c_int), ("d_ysplit", C.c_void_p),
     ]
 
 
@@ -184,6 +186,8 @@ SIGNATURES = {
     "mb_conv_split_tm_packed_halves": (C.c_size_t, [C.c_int] * 3),
     "mb_conv_split_tm_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mb_conv_split_tm": (C.c_int, [C.POINTER(ConvSplitTmArgs), C.c_void_p]),
+    "mb_maxpool2_tm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mb_highway_tm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]),
     "mb_f32_cm_to_tm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mb_f32_tm_to_cm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mb_resblock_stage_f16_supported": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),

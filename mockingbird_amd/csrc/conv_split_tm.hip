@@ -25,7 +25,12 @@ namespace mb {
 
 struct ConvTmK {
   const float* x; float* y; const h16* w; const float* bias; const float* res;
+  const float* gate;               // highway epilogue (out_act 4): y = g relu(v) + (1 - g) res
+  const float* post_scale; const float* post_shift;  // per-channel affine behind the activation (BatchNorm after ReLU), or null
   long long x_bstride, y_bstride;  // floats per batch item
+  int x_row_stride;                // floats between consecutive rows of x (c_in when dense)
+  int x_split;                     // x is a SPLIT tensor: fp16 [B][T][hi | lo][c_in] (what a producer's y_split / mb_maxpool2_tm wrote): staged by copy
+  h16* ysplit;                     // also write the result as such a split tensor [B][T][hi | lo][c_out] (or null)
   int T;                           // rows per item (input rows = output rows)
   int c_in, c_out;                 // row strides of x and y in floats (c_out = M)
   int ntaps, dil, pad;
@@ -36,9 +41,19 @@ struct ConvTmK {
   int out_act, accumulate;
   const int* valid; int valid_mul;
   unsigned* range_events;
+  unsigned long long* trace;       // diagnostics builds only (-DCTM_TRACE_BUILD, MBHIP_DIAG=ctm_trace=<file>): shader-clock marks of workgroup 0
 };
 
 constexpr int CTM_NL = 4;  // support waves
+#ifdef CTM_TRACE_BUILD
+#define CT_MARK(role, it, k)                                                                    \
+  do {                                                                                          \
+    if (a.trace && blockIdx.x == 0 && (it) < 4 && (tid & 63) == 0 && wave == ((role) ? 4 : 0))  \
+      a.trace[((role) * 4 + (it)) * 64 + (k)] = (unsigned long long)clock64();                  \
+  } while (0)
+#else
+#define CT_MARK(role, it, k) do { } while (0)
+#endif
 
 __device__ __forceinline__ int ctm_valid_len(const ConvTmK& a, int b) {
   if (!a.valid) return a.T;
@@ -57,16 +72,19 @@ template <int CK_, int MT_, int WN_, int NTW_> struct CtmGeom {
 };
 constexpr int CTM_MAX_HALO = 80;  // (ntaps - 1) * dil the support waves' window registers are sized for (ResBlock2 units: k = 7, d = 12 -> 72)
 
-template <int CK_, int MT_, int WN_, int NTW_>
+// JC = chunks per JOB (1 or 2): a job is what one chunk barrier publishes.  Two chunks per barrier double the MFMAs between barriers for
+// the convs whose chunk is short against the round trip of the window loads (pointwise convs, 3-tap convs on split inputs).
+template <int CK_, int MT_, int WN_, int NTW_, int JC_>
 __global__ __launch_bounds__(64 * (4 + CTM_NL)) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_split_tm_kernel(ConvTmK a) {
   using G = CtmGeom<CK_, MT_, WN_, NTW_>;
+  constexpr int JC = JC_;
   constexpr int CK = G::CK, KB = G::KB, MT = G::MT, WN = G::WN, NTW = G::NTW, MG = G::MG, N1 = G::N1, CKP = G::CKP, MGF = G::MGF;
-  constexpr int TD = 2;
+  constexpr int TD = CK == 64 ? 1 : 2;        // taps of weight fragments in flight (64-channel chunks: one tap = 4 k-steps = the same cover)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int XPL = a.x_rows * CKP;             // halves per plane of an x chunk buffer
-  h16* xs = reinterpret_cast<h16*>(lds_raw);  // [nbuf][hi | lo][x_rows][CKP]
-  float* ys = reinterpret_cast<float*>(xs + a.nbuf * 2 * XPL);  // [N1][MGF]
+  h16* xs = reinterpret_cast<h16*>(lds_raw);  // [nbuf][JC chunks][hi | lo][x_rows][CKP]
+  float* ys = reinterpret_cast<float*>(xs + a.nbuf * JC * 2 * XPL);  // [N1][MGF]
   float* bs = ys + N1 * MGF;                  // [MG]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -74,7 +92,8 @@ void conv_split_tm_kernel(ConvTmK a) {
   // workgroup -> (channel group, its share of the position tiles)
   const int mg = (int)blockIdx.x % a.n_mg, wslot = (int)blockIdx.x / a.n_mg, nslots = (int)gridDim.x / a.n_mg;
   const int my_tiles = (a.n_ntiles - wslot + nslots - 1) / nslots;
-  const int njobs = my_tiles * NCH;
+  const int NJT = NCH / JC;          // jobs per tile (even)
+  const int njobs = my_tiles * NJT;
   const int m0 = mg * MG;
 
   for (int i = tid; i < MG; i += 64 * (4 + CTM_NL)) bs[i] = (a.bias && m0 + i < a.c_out) ? a.bias[m0 + i] : 0.f;
@@ -82,23 +101,33 @@ void conv_split_tm_kernel(ConvTmK a) {
 
   if (wave >= 4) {
     // ------------------------------ support waves (resblock_pair_split.hip's ring schedule) ------------------------------
-    constexpr int PPR = CK / 4;
+    constexpr int PPR = CK / 4;        // pieces per row of a chunk
+    constexpr int PPRJ = JC * PPR;     // ... of a job
     constexpr int NSL = 64 * CTM_NL;
-    constexpr int LBX = ((N1 + CTM_MAX_HALO) * PPR + NSL - 1) / NSL;
+    constexpr int LBX = ((N1 + (CK == 64 ? 0 : (JC == 2 ? 8 : CTM_MAX_HALO))) * PPRJ + NSL - 1) / NSL;  // (64-channel chunks: pointwise convs only; two-chunk jobs: k <= 9)
     constexpr int YPR = MG / 4;                            // 16-byte pieces per result row of this channel group
     constexpr int WB = 4;                                  // result pieces per lane per batch
     const float slope = a.in_slope;
-    const int total = a.x_rows * PPR;
+    const int total = a.x_rows * PPRJ;
     const int ltid = tid - 256;
-    const bool w_loads = a.res != nullptr || a.accumulate;
+    const bool w_loads = a.res != nullptr || a.accumulate || a.gate != nullptr;
+    // per-lane constants of the window pieces.  fp32 x: piece = 4 floats of a row; split x: piece = 8 halves of a row's hi plane
+    // (pieces 0 .. PPR/2-1) or lo plane -- the same PPR pieces per row either way
     int xrow[LBX];
     unsigned xcol[LBX], xlds[LBX];
 #pragma unroll
     for (int i = 0; i < LBX; ++i) {
       const int idx = min(i * NSL + ltid, total - 1);
-      xrow[i] = idx / PPR;
-      xcol[i] = (unsigned)(idx - xrow[i] * PPR) * 4u;
-      xlds[i] = (unsigned)xrow[i] * CKP + xcol[i];
+      xrow[i] = idx / PPRJ;
+      const unsigned pcj = (unsigned)(idx - xrow[i] * PPRJ), cj = pcj / PPR, pc = pcj - cj * PPR;  // chunk of the job, piece of that chunk's row
+      if (a.x_split) {
+        const unsigned plane = pc / (PPR / 2), c8 = (pc % (PPR / 2)) * 8u;
+        xcol[i] = plane * 0x10000u + cj * CK + c8;               // (plane, first channel of the piece inside the job)
+        xlds[i] = (cj * 2u + plane) * (unsigned)XPL + (unsigned)xrow[i] * CKP + c8;
+      } else {
+        xcol[i] = cj * CK + pc * 4u;
+        xlds[i] = cj * 2u * (unsigned)XPL + (unsigned)xrow[i] * CKP + pc * 4u;
+      }
     }
     auto tile_of = [&](int it, int& b, int& t0) __attribute__((always_inline)) {
       const int nt = wslot + it * nslots;
@@ -107,28 +136,46 @@ void conv_split_tm_kernel(ConvTmK a) {
     };
     auto issue_x = [&](int q, f32x4 (&vx)[LBX]) __attribute__((always_inline)) {
       int b, t0;
-      tile_of(q / NCH, b, t0);
-      const int c = q % NCH;
+      tile_of(q / NJT, b, t0);
+      const int c = (q % NJT) * JC;  // first chunk of the job
       const int Tb = ctm_valid_len(a, b);
       const int tx0 = t0 - a.pad;
       const float* xb = a.x + (long long)b * a.x_bstride;
+      if (a.x_split) {  // (uniform) 16-byte pieces of the hi / lo planes, copied as they are
+        const h16* xh = reinterpret_cast<const h16*>(a.x) + (long long)b * a.T * 2 * a.c_in;
+#pragma unroll
+        for (int i = 0; i < LBX; ++i) {
+          const int tx = tx0 + xrow[i];
+          const unsigned plane = xcol[i] >> 16, ch = (unsigned)c * CK + (xcol[i] & 0xffffu);
+          const bool in = tx >= 0 && tx < Tb && ch < (unsigned)a.c_in;
+          const unsigned off = ((unsigned)min(max(tx, 0), a.T - 1) * 2u + plane) * (unsigned)a.c_in + min(ch, (unsigned)a.c_in - 8u);
+          const f32x4 ld = *reinterpret_cast<const f32x4*>(xh + off);
+          vx[i] = in ? ld : (f32x4)0.f;
+        }
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < LBX; ++i) {
         const int tx = tx0 + xrow[i];
         const unsigned ch = (unsigned)c * CK + xcol[i];
         const bool in = tx >= 0 && tx < Tb && ch < (unsigned)a.c_in;  // rows beyond the item / channels beyond c_in: zeros
-        const unsigned off = (unsigned)min(max(tx, 0), a.T - 1) * (unsigned)a.c_in + min(ch, (unsigned)a.c_in - 4u);
+        const unsigned off = (unsigned)min(max(tx, 0), a.T - 1) * (unsigned)a.x_row_stride + min(ch, (unsigned)a.c_in - 4u);
         const f32x4 ld = *reinterpret_cast<const f32x4*>(xb + off);
         vx[i] = in ? ld : (f32x4)0.f;
       }
     };
     auto commit_x = [&](int q, const f32x4 (&vx)[LBX]) __attribute__((always_inline)) {
-      h16* buf = xs + (q % a.nbuf) * 2 * XPL;
+      h16* buf = xs + (q % a.nbuf) * JC * 2 * XPL;
+      if (a.x_split) {
+#pragma unroll
+        for (int i = 0; i < LBX; ++i) *reinterpret_cast<f32x4*>(buf + xlds[i]) = vx[i];
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < LBX; ++i) {
         float l[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) l[e] = fmaxf(vx[i][e], vx[i][e] * slope);  // leaky_relu for slopes in (0, 1]; slope 1 = no activation
+        for (int e = 0; e < 4; ++e) l[e] = slope == 1.f ? vx[i][e] : fmaxf(vx[i][e], vx[i][e] * slope);  // leaky_relu for slopes in (0, 1); 1 = no activation
         mb_h2 h0, l0, h1, l1;
         split_pair(l[0], l[1], h0, l0);
         split_pair(l[2], l[3], h1, l1);
@@ -147,14 +194,15 @@ void conv_split_tm_kernel(ConvTmK a) {
     };
     // result rows of a finished tile: ys (conv 2^-s + bias, fp32) [+ res] -> scale -> [tanh] [+ y] -> HBM, in parts over the next tile's
     // chunk intervals.  Only residual / accumulating launches load anything here (requested one part ahead).
-    struct WTile { const float* rb; float* yb; int ytotal, mcols; };
+    struct WTile { const float* rb; const float* gb; float* yb; h16* sb; int ytotal, mcols; };
     auto wtile = [&](int it) __attribute__((always_inline)) {
       int b, t0;
       tile_of(it, b, t0);
       const int Tb = ctm_valid_len(a, b);
       const int rows = max(0, min(N1, Tb - t0));
       const long long o = (long long)b * a.y_bstride + (long long)t0 * a.c_out + m0;
-      return WTile{a.res ? a.res + o : nullptr, a.y + o, rows * YPR, min(MG, a.c_out - m0)};
+      return WTile{a.res ? a.res + o : nullptr, a.gate ? a.gate + o : nullptr, a.y + o,
+                   a.ysplit ? a.ysplit + ((long long)b * a.T + t0) * 2 * a.c_out + m0 : nullptr, rows * YPR, min(MG, a.c_out - m0)};
     };
     auto write_part = [&](int it, int lo, int hi, int den) __attribute__((always_inline)) {  // batches [nbt lo / den, nbt hi / den)
       const WTile w = wtile(it);
@@ -162,7 +210,7 @@ void conv_split_tm_kernel(ConvTmK a) {
       constexpr int BSZ = NSL * WB;
       const int nbt = (w.ytotal + BSZ - 1) / BSZ;
       for (int base = (nbt * lo / den) * BSZ; base < (nbt * hi / den) * BSZ && base < w.ytotal; base += BSZ) {
-        f32x4 rx[WB], ry[WB];
+        f32x4 rx[WB], ry[WB], rg[WB];
         unsigned goff[WB];
         bool ok[WB];
 #pragma unroll
@@ -175,6 +223,7 @@ void conv_split_tm_kernel(ConvTmK a) {
           if (w_loads) {
             rx[i] = w.rb ? *reinterpret_cast<const f32x4*>(w.rb + goff[i]) : (f32x4)0.f;
             ry[i] = a.accumulate ? *reinterpret_cast<const f32x4*>(w.yb + goff[i]) : (f32x4)0.f;
+            rg[i] = w.gb ? *reinterpret_cast<const f32x4*>(w.gb + goff[i]) : (f32x4)0.f;
           }
         }
 #pragma unroll
@@ -183,15 +232,35 @@ void conv_split_tm_kernel(ConvTmK a) {
           const unsigned idc = (unsigned)min(idx, w.ytotal - 1);
           const unsigned row = idc / YPR, pc = idc - row * YPR;
           const f32x4 hv = *reinterpret_cast<const f32x4*>(ys + row * MGF + pc * 4);
+          const unsigned mc = (unsigned)m0 + min(pc * 4u, (unsigned)max(w.mcols - 4, 0));
+          f32x4 psc = (f32x4)1.f, psh = (f32x4)0.f;
+          if (a.post_scale) { psc = *reinterpret_cast<const f32x4*>(a.post_scale + mc); psh = *reinterpret_cast<const f32x4*>(a.post_shift + mc); }
           f32x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float f = hv[e];
-            if (w_loads) f += rx[i][e];
-            f *= a.out_scale;
-            if (a.out_act == 2) f = tanhf(f);
-            if (w_loads) f += ry[i][e];
+            if (a.out_act == 4) {  // highway (common/highway_network.py:12-17): g relu(W1 x) + (1 - g) x, g = sigmoid(W2 x) from the gate launch
+              const float g = rg[i][e];
+              f = g * fmaxf(f, 0.f) + (1.f - g) * rx[i][e];
+            } else {
+              if (w_loads) f += rx[i][e];
+              f *= a.out_scale;
+              if (a.out_act == 1) f = fmaxf(f, 0.f);
+              else if (a.out_act == 2) f = tanhf(f);
+              else if (a.out_act == 3) f = sigmoidf_(f);
+              if (a.post_scale) f = fmaf(f, psc[e], psh[e]);  // BatchNorm behind the ReLU (common/batch_norm_conv.py:11-14)
+              if (w_loads) f += ry[i][e];
+            }
             o[e] = f;
+          }
+          if (ok[i] && a.ysplit) {  // the same values as fp16 hi / scaled-lo rows for a consumer that stages by copy (mcols >= 4)
+            mb_h2 h0, l0, h1, l1;
+            split_pair(o[0], o[1], h0, l0);
+            split_pair(o[2], o[3], h1, l1);
+            const h16x4 hi = {h0[0], h0[1], h1[0], h1[1]}, lo = {l0[0], l0[1], l1[0], l1[1]};
+            h16* sp = w.sb + (size_t)row * 2 * a.c_out + min(pc * 4u, (unsigned)max(w.mcols - 4, 0));
+            *reinterpret_cast<h16x4*>(sp) = hi;
+            *reinterpret_cast<h16x4*>(sp + a.c_out) = lo;
           }
           if (ok[i]) {
             if (w.mcols >= 4) *reinterpret_cast<f32x4*>(w.yb + goff[i]) = o;
@@ -202,20 +271,27 @@ void conv_split_tm_kernel(ConvTmK a) {
       }
     };
     f32x4 vxA[LBX], vxB[LBX];
+    // (Measured and dropped: with three or more buffers, laying a register set down and requesting it again behind the same barrier lets
+    // the loads fly for two intervals on the same registers -- no faster here, 5-10 % slower in resblock_pair_split.hip.)
     for (int q = 0; q < a.nbuf - 1 && q < njobs; ++q) { issue_x(q, vxA); commit_x(q, vxA); }
     if (a.nbuf - 1 < njobs) issue_x(a.nbuf - 1, vxB);
     for (int it = 0; it < my_tiles; ++it) {
-      for (int c = 0; c < NCH; c += 2) {
-        const int q = it * NCH + c;
+      for (int c = 0; c < NJT; c += 2) {  // two jobs per turn: the register sets alternate
+        const int q = it * NJT + c;
+        if (c < 8) CT_MARK(1, it, 4 * c);
         __syncthreads();  // B_q: job q is staged, the buffer of job q-1 is free
+        if (c < 8) CT_MARK(1, it, 4 * c + 1);
         if (q + a.nbuf < njobs) issue_x(q + a.nbuf, vxA);
         if (q + a.nbuf - 1 < njobs) commit_x(q + a.nbuf - 1, vxB);
-        if (it > 0) write_part(it - 1, c, c + 1, NCH);
+        if (c < 8) CT_MARK(1, it, 4 * c + 2);
+        if (it > 0) write_part(it - 1, c, c + 1, NJT);
+        if (c < 8) CT_MARK(1, it, 4 * c + 3);
         __syncthreads();  // B_{q+1}
         if (q + 1 + a.nbuf < njobs) issue_x(q + 1 + a.nbuf, vxB);
         if (q + a.nbuf < njobs) commit_x(q + a.nbuf, vxA);
-        if (it > 0) write_part(it - 1, c + 1, c + 2, NCH);
+        if (it > 0) write_part(it - 1, c + 1, c + 2, NJT);
       }
+      CT_MARK(1, it, 60);
       __syncthreads();  // YF: the previous tile's result has left ys
       __syncthreads();  // Y: this tile's result is staged
     }
@@ -256,13 +332,32 @@ void conv_split_tm_kernel(ConvTmK a) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[i][n][q] = 0.f;
     // NCH is even and ntaps odd: the ring slot of a chunk's first tap alternates 0, 1 and a tile always starts on slot 0
-    for (int c = 0; c < NCH; c += 2) {
-      __syncthreads();  // B
-      SP_CHUNK(0, xs + ((it * NCH + c) % a.nbuf) * 2 * XPL + lrow * CKP + lcol, CKP, x_tapstep, XPL);
-      __syncthreads();  // B
-      SP_CHUNK(1, xs + ((it * NCH + c + 1) % a.nbuf) * 2 * XPL + lrow * CKP + lcol, CKP, x_tapstep, XPL);
+#define CT_XB(JOB, CJ) (xs + (((JOB)) % a.nbuf) * JC * 2 * XPL + (CJ) * 2 * XPL + lrow * CKP + lcol)
+    for (int c = 0; c < NJT; c += 2) {
+      const int q = it * NJT + c;
+      if (c < 8) CT_MARK(0, it, 4 * c);
+      __syncthreads();  // B_q
+      if (c < 8) CT_MARK(0, it, 4 * c + 1);
+      if (JC == 1) {
+        SP_CHUNK(0, CT_XB(q, 0), CKP, x_tapstep, XPL);
+      } else {
+        SP_CHUNK(0, CT_XB(q, 0), CKP, x_tapstep, XPL);
+        SP_CHUNK(1, CT_XB(q, JC - 1), CKP, x_tapstep, XPL);
+      }
+      if (c < 8) CT_MARK(0, it, 4 * c + 2);
+      __syncthreads();  // B_{q+1}
+      if (c < 8) CT_MARK(0, it, 4 * c + 3);
+      if (JC == 1) {
+        SP_CHUNK(1, CT_XB(q + 1, 0), CKP, x_tapstep, XPL);
+      } else {
+        SP_CHUNK(0, CT_XB(q + 1, 0), CKP, x_tapstep, XPL);
+        SP_CHUNK(1, CT_XB(q + 1, JC - 1), CKP, x_tapstep, XPL);
+      }
     }
+#undef CT_XB
+    CT_MARK(0, it, 60);
     __syncthreads();  // YF
+    CT_MARK(0, it, 61);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -278,14 +373,16 @@ void conv_split_tm_kernel(ConvTmK a) {
           *reinterpret_cast<f32x4*>(ys + row * MGF + co0) = v;
         }
       }
+    CT_MARK(0, it, 62);
     __syncthreads();  // Y
+    CT_MARK(0, it, 63);
   }
 }
 
-template <class G>
+template <class G, int JC>
 static size_t ctm_lds_bytes(int ntaps, int dil, int nbuf) {
   const int x_rows = G::N1 + (ntaps - 1) * dil;
-  return (size_t)nbuf * 2 * x_rows * G::CKP * sizeof(h16) + (size_t)G::N1 * G::MGF * sizeof(float) + G::MG * sizeof(float);
+  return (size_t)nbuf * JC * 2 * x_rows * G::CKP * sizeof(h16) + (size_t)G::N1 * G::MGF * sizeof(float) + G::MG * sizeof(float);
 }
 
 static int ctm_cus() {
@@ -300,7 +397,7 @@ static int ctm_cus() {
   return n;
 }
 
-template <int CK, int MT, int WN, int NTW>
+template <int CK, int MT, int WN, int NTW, int JC = 1>
 static int launch_ctm(ConvTmK k, int batch, hipStream_t s) {
   using G = CtmGeom<CK, MT, WN, NTW>;
   k.x_rows = G::N1 + (k.ntaps - 1) * k.dil;
@@ -308,20 +405,44 @@ static int launch_ctm(ConvTmK k, int batch, hipStream_t s) {
   k.n_ntiles = k.tiles_per_item * batch;
   k.n_mg = cdiv(k.c_out, G::MG);
   int nbuf = 2;
-  while (nbuf < 4 && ctm_lds_bytes<G>(k.ntaps, k.dil, nbuf + 1) <= (size_t)160 * 1024) ++nbuf;
-  MB_REQUIRE(ctm_lds_bytes<G>(k.ntaps, k.dil, nbuf) <= (size_t)160 * 1024, "conv_split_tm: the window does not fit LDS");
+  while (nbuf < 4 && ctm_lds_bytes<G, JC>(k.ntaps, k.dil, nbuf + 1) <= (size_t)160 * 1024) ++nbuf;
+  const size_t lds_bytes = ctm_lds_bytes<G, JC>(k.ntaps, k.dil, nbuf);
+  MB_REQUIRE(lds_bytes <= (size_t)160 * 1024, "conv_split_tm: the window does not fit LDS");
   k.nbuf = nbuf;
   static std::atomic<unsigned long long> attr_done{0};
   int dev = 0;
   MB_HIP(hipGetDevice(&dev));
   const unsigned long long bit = dev >= 0 && dev < 64 ? 1ull << dev : 0ull;
   if (!bit || !(attr_done.load(std::memory_order_acquire) & bit)) {
-    MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_tm_kernel<CK, MT, WN, NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_tm_kernel<CK, MT, WN, NTW, JC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done.fetch_or(bit, std::memory_order_release);
   }
   const int slots = std::max(1, std::min(k.n_ntiles, ctm_cus() / k.n_mg));
-  hipLaunchKernelGGL((conv_split_tm_kernel<CK, MT, WN, NTW>), dim3(slots * k.n_mg), dim3(64 * (4 + CTM_NL)), ctm_lds_bytes<G>(k.ntaps, k.dil, nbuf), s, k);
+#ifdef CTM_TRACE_BUILD
+  static unsigned long long* d_trace = nullptr;
+  std::string trace_file;
+  const char* trace_path = diag_str("ctm_trace", &trace_file) ? trace_file.c_str() : nullptr;
+  if (trace_path) {
+    if (!d_trace) MB_HIP(hipMalloc((void**)&d_trace, 512 * sizeof(unsigned long long)));
+    MB_HIP(hipMemsetAsync(d_trace, 0, 512 * sizeof(unsigned long long), s));
+    k.trace = d_trace;
+  }
+#endif
+  hipLaunchKernelGGL((conv_split_tm_kernel<CK, MT, WN, NTW, JC>), dim3(slots * k.n_mg), dim3(64 * (4 + CTM_NL)), lds_bytes, s, k);
   MB_HIP(hipGetLastError());
+#ifdef CTM_TRACE_BUILD
+  if (trace_path) {
+    unsigned long long h[512];
+    MB_HIP(hipStreamSynchronize(s));
+    MB_HIP(hipMemcpy(h, d_trace, sizeof(h), hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(trace_path, "a")) {
+      fprintf(f, "%d %d %d %d %d %d %d %d %d %d :", CK, MT, WN, NTW, k.c_in, k.c_out, k.ntaps, k.NCH, k.nbuf, k.n_ntiles);
+      for (int i = 0; i < 512; ++i) fprintf(f, " %llu", h[i]);
+      fprintf(f, "\n");
+      fclose(f);
+    }
+  }
+#endif
   return MB_OK;
 }
 
@@ -385,14 +506,23 @@ extern "C" int mb_conv_split_tm(const mb_conv_split_tm_args* a, mb_stream_t stre
              a->c_in, a->c_out, a->ksize, a->dilation);
   MB_REQUIRE(a->in_slope > 0.f && a->in_slope <= 1.f, "conv_split_tm: in_slope must be in (0, 1] (1 = no activation)");
   MB_REQUIRE(a->unscale > 0.f, "conv_split_tm: the unscale factor of mb_conv_split_tm_pack is missing");
-  MB_REQUIRE(a->out_act == 0 || a->out_act == 2, "conv_split_tm: out_act %d (0 = none, 2 = tanh)", a->out_act);
+  MB_REQUIRE(a->out_act >= 0 && a->out_act <= 4, "conv_split_tm: out_act %d (0 none, 1 relu, 2 tanh, 3 sigmoid, 4 highway)", a->out_act);
+  MB_REQUIRE(a->out_act != 4 || (a->d_gate && a->d_res && !a->accumulate), "conv_split_tm: the highway epilogue needs d_gate and d_res");
+  MB_REQUIRE((!a->d_post_scale) == (!a->d_post_shift), "conv_split_tm: d_post_scale and d_post_shift come together");
+  MB_REQUIRE((!a->d_gate && !a->d_post_scale) || a->c_out % 4 == 0, "conv_split_tm: gate / post affine need c_out %% 4 == 0");
   MB_REQUIRE((!a->d_res && !a->accumulate) || a->c_out % 4 == 0, "conv_split_tm: residual / accumulating launches need c_out %% 4 == 0");
   if (a->batch <= 0 || a->t <= 0) return MB_OK;
-  MB_REQUIRE((long long)a->t * std::max(a->c_in, a->c_out) < (1ll << 31), "conv_split_tm: an item of %d rows is beyond the 32-bit offsets", a->t);
+  MB_REQUIRE((long long)a->t * std::max(a->x_row_stride > 0 ? a->x_row_stride : a->c_in, a->c_out) < (1ll << 31), "conv_split_tm: an item of %d rows is beyond the 32-bit offsets", a->t);
   ConvTmK k;
   memset(&k, 0, sizeof(k));
   k.x = a->d_x; k.y = a->d_y; k.w = reinterpret_cast<const h16*>(a->d_wpacked); k.bias = a->d_bias; k.res = a->d_res;
-  k.x_bstride = (long long)a->t * a->c_in; k.y_bstride = (long long)a->t * a->c_out;
+  k.gate = a->d_gate; k.post_scale = a->d_post_scale; k.post_shift = a->d_post_shift;
+  k.x_split = a->x_split ? 1 : 0; k.ysplit = reinterpret_cast<h16*>(a->d_ysplit);
+  MB_REQUIRE(!a->x_split || (a->c_in % 8 == 0 && a->in_slope == 1.f && a->x_row_stride <= 0 && a->x_bstride <= 0),
+             "conv_split_tm: a split x needs c_in %% 8 == 0, no input activation and the dense layout");
+  MB_REQUIRE(!a->d_ysplit || a->c_out % 4 == 0, "conv_split_tm: d_ysplit needs c_out %% 4 == 0");
+  k.x_row_stride = a->x_row_stride > 0 ? a->x_row_stride : a->c_in;
+  k.x_bstride = a->x_bstride > 0 ? a->x_bstride : (long long)a->t * a->c_in; k.y_bstride = (long long)a->t * a->c_out;
   k.T = a->t; k.c_in = a->c_in; k.c_out = a->c_out; k.ntaps = a->ksize; k.dil = a->dilation; k.pad = a->pad;
   k.NCH = ctm_nch(a->c_in);
   k.in_slope = a->in_slope; k.us = a->unscale; k.out_scale = a->out_scale == 0.f ? 1.f : a->out_scale;
@@ -401,6 +531,7 @@ extern "C" int mb_conv_split_tm(const mb_conv_split_tm_args* a, mb_stream_t stre
   k.range_events = conv_range_word();
   hipStream_t s = (hipStream_t)stream;
   const int mg = ctm_mg(a->c_out);
+  MB_REQUIRE(!a->x_split || ctm_ck(a->c_in) == 32, "conv_split_tm: a split x needs more than 32 input channels");
   if (ctm_ck(a->c_in) == 16) {
     switch (mg) {
       case 256: return launch_ctm<16, 2, 1, 3>(k, a->batch, s);
@@ -409,10 +540,114 @@ extern "C" int mb_conv_split_tm(const mb_conv_split_tm_args* a, mb_stream_t stre
       default: return launch_ctm<16, 1, 4, 2>(k, a->batch, s);
     }
   }
+  // tile shape for wide outputs: the candidate with the smallest makespan = rounds of workgroups x (channels x rows) per tile.  (A
+  // 2560 -> 512 projection over 32 x 400 rows: 256 x 96 tiles are 320 tiles = two rounds on 256 compute units, a fifth of the
+  // second-round tiles 16 rows tall; 256 x 64 tiles are 448 = two rounds of two thirds the work each.)
+  const int cus = ctm_cus();
+  auto cost = [&](int mgc, int n1) {
+    const long long tiles = (long long)cdiv(a->c_out, mgc) * cdiv(a->t, n1) * a->batch;
+    return ((tiles + cus - 1) / cus) * (long long)mgc * n1;
+  };
+  // pointwise convs over >= 128 input channels take 64-channel chunks: 36 MFMAs per wave between two chunk barriers (1.1 k cycles) are
+  // less than the round trip of the window loads the support waves wait for (the image is the same: one tap = consecutive k-steps)
+  const bool wide_chunk = a->ksize == 1 && a->c_in % 128 == 0;
+  if (wide_chunk && mg >= 128) k.NCH = a->c_in / 64;
+  const int tile = diag_int("ctm_tile", 0);  // A/B: 1 = 256 x 96, 2 = 256 x 64, 3 = 128 x 128
+  if (mg == 256) {
+    const long long c96 = cost(256, 96), c64 = cost(256, 64), c128 = cost(128, 128);
+    int pick = (c64 < c96 && c64 <= c128) ? 2 : (c128 < c96 && c128 < c64 ? 3 : 1);
+    if (tile >= 1 && tile <= 3) pick = tile;
+    // two chunks per barrier where a chunk's MFMAs are few against the window loads' round trip (measured with shader-clock marks: a
+    // chunk interval never ran below ~3 k cycles, a pointwise chunk has 1.0-1.5 k of MFMAs): pointwise convs, and <= 9-tap convs on
+    // split inputs (copied, so a two-chunk window costs the support waves nothing)
+    const bool jc2 = !diag_int("ctm_jc1") && k.NCH % 4 == 0 && (wide_chunk || (a->x_split && (a->ksize - 1) * a->dilation <= 8));
+    if (wide_chunk) {  // (256 x 96 tiles on 64-channel chunks need more than 256 registers: 256 x 64 or 128 x 128)
+      if (pick == 3 || (pick == 1 && c128 < c64)) return launch_ctm<64, 1, 1, 4>(k, a->batch, s);  // (128-row tiles: one chunk per job, the window registers of two do not fit)
+      return jc2 ? launch_ctm<64, 2, 1, 2, 2>(k, a->batch, s) : launch_ctm<64, 2, 1, 2>(k, a->batch, s);
+    }
+    if (jc2 && pick != 3) return launch_ctm<32, 2, 1, 2, 2>(k, a->batch, s);
+    if (pick == 2) return launch_ctm<32, 2, 1, 2>(k, a->batch, s);
+    if (pick == 3) return launch_ctm<32, 1, 1, 4>(k, a->batch, s);
+    return launch_ctm<32, 2, 1, 3>(k, a->batch, s);
+  }
   switch (mg) {
-    case 256: return launch_ctm<32, 2, 1, 3>(k, a->batch, s);
-    case 128: return launch_ctm<32, 1, 1, 4>(k, a->batch, s);
+    case 128: return wide_chunk ? launch_ctm<64, 1, 1, 4>(k, a->batch, s) : launch_ctm<32, 1, 1, 4>(k, a->batch, s);
     case 64: return launch_ctm<32, 1, 2, 2>(k, a->batch, s);
     default: return launch_ctm<32, 1, 4, 2>(k, a->batch, s);
   }
+}
+
+// MaxPool1d(2, stride 1, padding 1)[:t] over time on a time-major tensor: y[t] = max(x[t - 1], x[t]), y[0] = x[0]  (sublayer/cbhg.py:20,61-62),
+// written as fp32 and / or as the split tensor [B][t][hi | lo][C] the next conv stages by copy
+namespace mb {
+__global__ __launch_bounds__(256) void maxpool2_tm_kernel(const float* __restrict__ x, float* __restrict__ y, h16* __restrict__ ysplit, int T, int C4, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = i / C4;
+    const f32x4 cur = reinterpret_cast<const f32x4*>(x)[i];
+    const f32x4 prev = (row % T) ? reinterpret_cast<const f32x4*>(x)[i - C4] : cur;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = fmaxf(cur[e], prev[e]);
+    if (y) reinterpret_cast<f32x4*>(y)[i] = o;
+    if (ysplit) {
+      mb_h2 h0, l0, h1, l1;
+      split_pair(o[0], o[1], h0, l0);
+      split_pair(o[2], o[3], h1, l1);
+      const h16x4 hi = {h0[0], h0[1], h1[0], h1[1]}, lo = {l0[0], l0[1], l1[0], l1[1]};
+      h16* sp = ysplit + row * 2 * (size_t)(4 * C4) + (i - row * C4) * 4;
+      *reinterpret_cast<h16x4*>(sp) = hi;
+      *reinterpret_cast<h16x4*>(sp + 4 * C4) = lo;
+    }
+  }
+}
+
+// Highway combine (common/highway_network.py:12-17) on time-major tensors: hg [rows][2 C] = (W1 x + b1 | W2 x + b2) from ONE conv launch,
+// x [rows][C]  ->  y = g relu(h) + (1 - g) x, g = sigmoid(W2 x + b2), as fp32 [rows][C] and as a split tensor [rows][hi | lo][C]
+__global__ __launch_bounds__(256) void highway_tm_kernel(const float* __restrict__ hg, const float* __restrict__ x, float* __restrict__ y,
+                                                         h16* __restrict__ ysplit, int C4, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = i / C4, c4 = i - row * C4;
+    const f32x4 h = reinterpret_cast<const f32x4*>(hg)[row * 2 * C4 + c4];
+    const f32x4 gp = reinterpret_cast<const f32x4*>(hg)[row * 2 * C4 + C4 + c4];
+    const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float g = sigmoidf_(gp[e]);
+      o[e] = g * fmaxf(h[e], 0.f) + (1.f - g) * xv[e];
+    }
+    reinterpret_cast<f32x4*>(y)[i] = o;
+    if (ysplit) {
+      mb_h2 h0, l0, h1, l1;
+      split_pair(o[0], o[1], h0, l0);
+      split_pair(o[2], o[3], h1, l1);
+      const h16x4 hi = {h0[0], h0[1], h1[0], h1[1]}, lo = {l0[0], l0[1], l1[0], l1[1]};
+      h16* sp = ysplit + row * 2 * (size_t)(4 * C4) + c4 * 4;
+      *reinterpret_cast<h16x4*>(sp) = hi;
+      *reinterpret_cast<h16x4*>(sp + 4 * C4) = lo;
+    }
+  }
+}
+}  // namespace mb
+
+extern "C" int mb_maxpool2_tm(const float* d_x, float* d_y, void* d_ysplit, int batch, int t, int channels, mb_stream_t stream) {
+  MB_REQUIRE(d_x && (d_y || d_ysplit) && d_x != d_y, "maxpool2_tm: null pointer / in place");
+  MB_REQUIRE(channels % 4 == 0, "maxpool2_tm: channels %% 4 != 0");
+  if (batch <= 0 || t <= 0 || channels <= 0) return MB_OK;
+  const size_t n4 = (size_t)batch * t * (channels / 4);
+  hipLaunchKernelGGL(maxpool2_tm_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, d_x, d_y,
+                     reinterpret_cast<h16*>(d_ysplit), t, channels / 4, n4);
+  MB_HIP(hipGetLastError());
+  return MB_OK;
+}
+
+extern "C" int mb_highway_tm(const float* d_hg, const float* d_x, float* d_y, void* d_ysplit, long long rows, int channels, mb_stream_t stream) {
+  MB_REQUIRE(d_hg && d_x && d_y && d_x != d_y, "highway_tm: null pointer / in place");
+  MB_REQUIRE(channels % 4 == 0, "highway_tm: channels %% 4 != 0");
+  if (rows <= 0 || channels <= 0) return MB_OK;
+  const size_t n4 = (size_t)rows * (channels / 4);
+  hipLaunchKernelGGL(highway_tm_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, d_hg, d_x, d_y,
+                     reinterpret_cast<h16*>(d_ysplit), channels / 4, n4);
+  MB_HIP(hipGetLastError());
+  return MB_OK;
 }

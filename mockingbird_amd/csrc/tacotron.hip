@@ -1028,6 +1028,35 @@ int make_linear_conv(ConvL* c, const float* w, int c_out, int c_in, const float*
   return rc;
 }
 
+// One conv as a time-major split conv (conv_split_tm.hip): round 6, the CBHG postnet on [B][F][C] tensors
+struct TmL {
+  DevBuf w, b, ps, pt;
+  float us = 0.f;
+  int c_in = 0, m = 0, k = 1, pad = 0;
+  void release() { w.release(); b.release(); ps.release(); pt.release(); }
+};
+int make_tml(TmL* t, const float* w_eff, int m, int c_in, int k, int pad, const float* bias, const float* ps, const float* pt) {
+  t->c_in = c_in; t->m = m; t->k = k; t->pad = pad;
+  if (!mb_conv_split_tm_supported(m, c_in, k, 1)) return 1;
+  std::vector<float> img(mb_conv_split_tm_packed_halves(m, c_in, k) / 2, 0.f);
+  int rc = mb_conv_split_tm_pack(w_eff, m, c_in, k, reinterpret_cast<uint16_t*>(img.data()), &t->us);
+  if (!rc) rc = t->w.upload(img.data(), img.size());
+  if (!rc && bias) rc = t->b.upload(bias, m);
+  if (!rc && ps) rc = t->ps.upload(ps, m);
+  if (!rc && pt) rc = t->pt.upload(pt, m);
+  return rc;
+}
+struct CbhgTm {
+  bool ok = false;
+  TmL bank, proj1, proj2, pre, ih_f, ih_b;
+  std::vector<TmL> hwf;  // per highway layer ONE conv to 2 ch channels: (W1 | W2) stacked, the combine is mb_highway_tm
+  void release() {
+    bank.release(); proj1.release(); proj2.release(); pre.release(); ih_f.release(); ih_b.release();
+    for (auto& c : hwf) c.release();
+    ok = false;
+  }
+};
+
 // CBHG (sublayer/cbhg.py:6-84): conv bank K -> maxpool -> 2 projections -> +residual -> [pre_highway]
 // -> highways -> bidirectional GRU.  Shared by the postnet (in 80, ch 512) and the text encoder
 // (in 256, ch 256).  Activations stay channel-major [B][C][T] end to end.
@@ -1039,7 +1068,9 @@ struct Cbhg {
   DevBuf gru_raw_f, gru_raw_b;  // torch weight_hh as is: the resident scan (gru_scan.h) splits it into its registers
   int gru_sexp[2] = {0, 0};     // 2^s of that split, per direction
   bool has_pre = false;
+  CbhgTm tm;                    // the same convs as time-major split convs (make_cbhg_tm; the postnet)
   void release() {
+    tm.release();
     for (auto& c : bank) c.release();
     for (auto& c : hw1) c.release();
     for (auto& c : hw2) c.release();
@@ -1092,7 +1123,66 @@ int make_cbhg(Cbhg* c, const float* const* hw, int* pix, int cin, int ch, int p0
   return rc;
 }
 
-struct CbhgWs { float *bank, *pj1, *pj2, *hwa, *hwb, *gate, *ihf, *ihb, *gh, *seq, *seq_tm; unsigned long long* gsx; };
+// The time-major images of a CBHG's convs (same weight list as make_cbhg).  The conv bank's K convs (kernel sizes 1..K, padding k/2,
+// output cut to T: cbhg.py:53-59) become ONE conv to K ch channels over KT = K | 1 centred taps: conv k's tap j sits at j - k/2 + KT/2.
+int make_cbhg_tm(Cbhg* c, const float* const* hw, int ix, int cin, int ch, int p0, int p1, int K, int nh) {
+  CbhgTm& m = c->tm;
+  int rc = MB_OK;
+#define RC(x) do { if (!rc) rc = (x); } while (0)
+  auto bn_fold = [&](const float* const* bn, int n, std::vector<float>* scale, std::vector<float>* shift, size_t at) {
+    for (int co = 0; co < n; ++co) {
+      const double sc = (double)bn[0][co] / std::sqrt((double)bn[3][co] + 1e-5);
+      (*scale)[at + co] = (float)sc;
+      (*shift)[at + co] = (float)((double)bn[1][co] - (double)bn[2][co] * sc);
+    }
+  };
+  const int KT = K | 1, P = KT / 2;
+  {
+    std::vector<float> w((size_t)K * ch * cin * KT, 0.f), sc((size_t)K * ch), sh((size_t)K * ch);
+    for (int k = 1; k <= K; ++k) {
+      const float* wk = hw[ix];
+      for (int co = 0; co < ch; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+          for (int j = 0; j < k; ++j) w[(((size_t)(k - 1) * ch + co) * cin + ci) * KT + (j - k / 2 + P)] = wk[((size_t)co * cin + ci) * k + j];
+      bn_fold(hw + ix + 1, ch, &sc, &sh, (size_t)(k - 1) * ch);
+      ix += 5;
+    }
+    RC(make_tml(&m.bank, w.data(), K * ch, cin, KT, P, nullptr, sc.data(), sh.data()));
+  }
+  {
+    std::vector<float> sc(p0), sh(p0);
+    bn_fold(hw + ix + 1, p0, &sc, &sh, 0);
+    RC(make_tml(&m.proj1, hw[ix], p0, ch * K, 3, 1, nullptr, sc.data(), sh.data()));
+    ix += 5;
+  }
+  {
+    std::vector<float> sc(p1), sh(p1), wf(hw[ix], hw[ix] + (size_t)p1 * p0 * 3);
+    bn_fold(hw + ix + 1, p1, &sc, &sh, 0);
+    for (int co = 0; co < p1; ++co)
+      for (size_t i = 0; i < (size_t)p0 * 3; ++i) wf[(size_t)co * p0 * 3 + i] *= sc[co];
+    RC(make_tml(&m.proj2, wf.data(), p1, p0, 3, 1, sh.data(), nullptr, nullptr));
+    ix += 5;
+  }
+  if (p1 != ch) { RC(make_tml(&m.pre, hw[ix], ch, p1, 1, 0, nullptr, nullptr, nullptr)); ix += 1; }
+  m.hwf.resize(nh);
+  for (int i = 0; i < nh; ++i) {
+    std::vector<float> w2((size_t)2 * ch * ch), b2((size_t)2 * ch);
+    memcpy(w2.data(), hw[ix], (size_t)ch * ch * sizeof(float)); memcpy(w2.data() + (size_t)ch * ch, hw[ix + 2], (size_t)ch * ch * sizeof(float));
+    memcpy(b2.data(), hw[ix + 1], ch * sizeof(float)); memcpy(b2.data() + ch, hw[ix + 3], ch * sizeof(float));
+    RC(make_tml(&m.hwf[i], w2.data(), 2 * ch, ch, 1, 0, b2.data(), nullptr, nullptr));
+    ix += 4;
+  }
+  if (!rc && (ch % 8 || p0 % 8 || (ch * K) % 8 || ch <= 32 || p0 <= 32)) rc = 1;  // the split tensors between the launches need wide rows
+  const int Hg = ch / 2;
+  RC(make_tml(&m.ih_f, hw[ix], 3 * Hg, ch, 1, 0, hw[ix + 2], nullptr, nullptr)); ix += 4;
+  RC(make_tml(&m.ih_b, hw[ix], 3 * Hg, ch, 1, 0, hw[ix + 2], nullptr, nullptr)); ix += 4;
+#undef RC
+  if (rc > 0) { m.release(); return MB_OK; }  // a shape conv_split_tm has no instance for: the channel-major convs run
+  m.ok = rc == MB_OK;
+  return rc;
+}
+
+struct CbhgWs { float *bank, *pj1, *pj2, *hwa, *hwb, *gate, *ihf, *ihb, *gh, *seq, *seq_tm, *xt, *bank2, *sp1, *spa, *spb, *hg; unsigned long long* gsx; };
 constexpr size_t GSX_WORDS = (size_t)2 * 2 * 32 * 256 + 32;  // granules of the resident GRU scan (gru_scan.h) + its abort word
 
 void cbhg_take(Arena& ar, const Cbhg& c, size_t B, size_t F, CbhgWs* w) {
@@ -1106,10 +1196,67 @@ void cbhg_take(Arena& ar, const Cbhg& c, size_t B, size_t F, CbhgWs* w) {
   w->seq = ar.take<float>(B * ch * F);
   w->gsx = ar.take<unsigned long long>(GSX_WORDS);
   w->seq_tm = ar.take<float>(B * ch * F);
+  w->xt = w->bank2 = w->sp1 = w->spa = w->spb = w->hg = nullptr;
+  if (c.tm.ok) {  // the time-major front: the turned input, the pooled conv bank / projection / highway outputs as split tensors
+    w->xt = ar.take<float>(B * (size_t)c.cin * F);
+    w->bank2 = ar.take<float>(B * ch * c.K * F);   // (a split tensor has the bytes of the fp32 one)
+    w->sp1 = ar.take<float>(B * std::max<size_t>(ch, c.proj1.c_out) * F);
+    w->spa = ar.take<float>(B * ch * F); w->spb = ar.take<float>(B * ch * F);
+    w->hg = ar.take<float>(B * 2 * ch * F);
+  }
 }
 
 int run_conv(const ConvL& c, const float* x, int batch, int t, float* y, long long y_bstride, int in_act,
              int out_act, const float* res, const float* gate, int transpose_out, hipStream_t s);
+
+int cbhg_scan(const Cbhg& c, int B, int F, const CbhgWs& L, hipStream_t s, bool want_cm, bool* tm_valid);
+
+// one conv_split_tm launch of the time-major front (t rows per item)
+static int run_tml(const TmL& c, const float* x, int B, int t, float* y, int out_act, const float* res, const float* gate, hipStream_t s,
+                   long long x_bstride = 0, int x_row_stride = 0, bool x_split = false, float* ysplit = nullptr) {
+  mb_conv_split_tm_args a;
+  memset(&a, 0, sizeof(a));
+  a.d_x = x; a.d_y = y; a.d_wpacked = c.w.p; a.d_bias = c.b.p; a.d_res = res; a.d_gate = gate;
+  a.d_post_scale = c.ps.p; a.d_post_shift = c.pt.p;
+  a.batch = B; a.t = t; a.c_in = c.c_in; a.c_out = c.m; a.ksize = c.k; a.dilation = 1; a.pad = c.pad;
+  a.in_slope = 1.f; a.unscale = c.us; a.out_scale = 1.f; a.out_act = out_act;
+  a.x_bstride = x_bstride; a.x_row_stride = x_row_stride; a.x_split = x_split ? 1 : 0; a.d_ysplit = ysplit;
+  return mb_conv_split_tm(&a, (mb_stream_t)s);
+}
+
+// Round 6: the CBHG on time-major tensors -- x [B][cin][F] is turned once, the conv bank is ONE launch, every
+// conv a conv_split_tm launch (BatchNorm / ReLU / residual / highway in its write-out), the GRU tables come out time-major as the
+// scan reads them.  -> L.seq_tm [F][B][ch] (*tm_valid) or, when the resident scan is not available, L.seq [B][ch][F].
+int cbhg_forward_tm(const Cbhg& c, const float* x, int B, int F, const CbhgWs& L, hipStream_t s, bool* tm_valid) {
+  int rc = MB_OK;
+  const int C = c.ch;
+  const CbhgTm& m = c.tm;
+#define RC(x) do { if (!rc) rc = (x); } while (0)
+  // Tensors a later conv multiplies are ALSO written as split tensors (fp16 hi | scaled lo rows: the bytes of the fp32 tensor) by their
+  // producer, so that the consumer stages them by copy: a 512 -> 512 pointwise conv has 36 MFMAs per wave between two chunk
+  // barriers, and the support waves' fp32 -> split conversion of the chunk (every element once per channel group and consumer)
+  // took four times that (first form of this function: 152 us per highway conv, the whole front no faster than channel-major).
+  RC(mb_f32_cm_to_tm(x, L.xt, B, c.cin, F, (mb_stream_t)s));
+  RC(run_tml(m.bank, L.xt, B, F, L.bank, 1, nullptr, nullptr, s));                       // conv -> ReLU -> BN, all K kernels (cbhg.py:53-59)
+  RC(mb_maxpool2_tm(L.bank, nullptr, L.bank2, B, F, C * c.K, (mb_stream_t)s));           // maxpool(2,1,1)[:F] (cbhg.py:61-62) -> split
+  RC(run_tml(m.proj1, L.bank2, B, F, L.pj1, 1, nullptr, nullptr, s, 0, 0, true, L.sp1)); // conv_project1 -> ReLU -> BN (cbhg.py:65)
+  RC(run_tml(m.proj2, L.sp1, B, F, L.pj2, 0, L.xt, nullptr, s, 0, 0, true, c.has_pre ? nullptr : L.spa));  // conv_project2 (BN folded) + residual (cbhg.py:66-69)
+  const float* hin = L.pj2;
+  float* scur = L.spa;
+  if (c.has_pre) { RC(run_tml(m.pre, L.pj2, B, F, L.hwa, 0, nullptr, nullptr, s, 0, 0, false, L.spa)); hin = L.hwa; }
+  for (int i = 0; i < c.nh; ++i) {  // highway_network.py:12-17: (W1 x + b1 | W2 x + b2) in one launch, then the combine
+    float* dst = (hin == L.hwa) ? L.hwb : L.hwa;
+    float* snext = (scur == L.spa) ? L.spb : L.spa;
+    RC(run_tml(m.hwf[i], scur, B, F, L.hg, 0, nullptr, nullptr, s, 0, 0, true, nullptr));
+    RC(mb_highway_tm(L.hg, hin, dst, snext, (long long)B * F, C, (mb_stream_t)s));
+    hin = dst; scur = snext;
+  }
+  RC(run_tml(m.ih_f, scur, B, F, L.ihf, 0, nullptr, nullptr, s, 0, 0, true, nullptr)); // W_ih x + b_ih for every t (cbhg.py:76-77)
+  RC(run_tml(m.ih_b, scur, B, F, L.ihb, 0, nullptr, nullptr, s, 0, 0, true, nullptr));
+#undef RC
+  if (rc) return rc;
+  return cbhg_scan(c, B, F, L, s, false, tm_valid);
+}
 
 // x [B][cin][F] -> ws.seq [B][ch][F] (forward half in channels [0, ch/2), backward in [ch/2, ch))
 int cbhg_forward(const Cbhg& c, const float* x, int B, int F, const CbhgWs& L, hipStream_t s) {
@@ -1142,6 +1289,17 @@ int cbhg_forward(const Cbhg& c, const float* x, int B, int F, const CbhgWs& L, h
   // bidirectional GRU (cbhg.py:76-77): W_ih.x + b_ih for every t as one GEMM per direction (time-major table)
   RC(run_conv(c.gru_ih_f, hin, B, F, L.ihf, (long long)F * 3 * Hg, 0, 0, nullptr, nullptr, 1, s));
   RC(run_conv(c.gru_ih_b, hin, B, F, L.ihb, (long long)F * 3 * Hg, 0, 0, nullptr, nullptr, 1, s));
+#undef RC
+  if (rc) return rc;
+  return cbhg_scan(c, B, F, L, s, true, nullptr);
+}
+
+// The bidirectional GRU scan over the [B][F][3 Hg] tables L.ihf / L.ihb -> L.seq_tm [F][B][ch] (resident launch; turned into L.seq
+// [B][ch][F] when want_cm) or, on the launch-per-step fallback, L.seq only.  *tm_valid (may be null) = L.seq_tm holds the sequence.
+int cbhg_scan(const Cbhg& c, int B, int F, const CbhgWs& L, hipStream_t s, bool want_cm, bool* tm_valid) {
+  int rc = MB_OK;
+  const int C = c.ch, Hg = C / 2;
+  if (tm_valid) *tm_valid = false;
   // the scan: one resident launch for both directions (gru_scan.h); a lost hand-off (never seen: 4..8 workgroups) or
   // MBHIP_GRU_SCAN=0 or a shape it has no instance for -> one launch per step
   bool scanned = false;
@@ -1167,8 +1325,10 @@ int cbhg_forward(const Cbhg& c, const float* x, int B, int F, const CbhgWs& L, h
       }
       int lrc = gru_scan_launch(k, s);  // a launch that fails (e.g. the LDS attribute on an odd device) is not an error of the
       if (!lrc) {                        // encode: the launch-per-step scan below computes the same sequence
-        hipLaunchKernelGGL(gru_scan_transpose_kernel, dim3(cdiv(C, 32), cdiv(F, 32), B), dim3(256), 0, s, L.seq_tm, L.seq, F, B, C);
-        MB_HIP(hipGetLastError());
+        if (want_cm) {
+          hipLaunchKernelGGL(gru_scan_transpose_kernel, dim3(cdiv(C, 32), cdiv(F, 32), B), dim3(256), 0, s, L.seq_tm, L.seq, F, B, C);
+          MB_HIP(hipGetLastError());
+        }
       } else (void)hipGetLastError();
       int aborted = 0;
       if (!lrc) {
@@ -1176,6 +1336,7 @@ int cbhg_forward(const Cbhg& c, const float* x, int B, int F, const CbhgWs& L, h
         MB_HIP(hipStreamSynchronize(s));
       }
       scanned = !lrc && !aborted;
+      if (scanned && tm_valid) *tm_valid = true;
       if (!scanned && !test_abort) gru_scan_mark_failed();
     }
   }
@@ -1198,7 +1359,6 @@ int cbhg_forward(const Cbhg& c, const float* x, int B, int F, const CbhgWs& L, h
       rc = rnn_launch_dual_gru(kd[0], kd[1], s);  // both directions of step st in one launch
     }
   }
-#undef RC
   return rc;
 }
 
@@ -1324,6 +1484,7 @@ struct mb_taco {
   // postnet
   Cbhg post;
   ConvL post_proj;
+  TmL post_proj_tm;
   // text encoder (optional: cfg.has_encoder)
   DevBuf emb;
   ConvL enc_fc1, enc_fc2, enc_proj;
@@ -1724,8 +1885,18 @@ extern "C" int mb_taco_create(const mb_taco_config* cfg, const float* const* hw,
     }
   }
   // postnet CBHG + post_proj
+  const int ix_post = ix;
   RC(make_cbhg(&t->post, hw, &ix, M, C, C, M, cfg->postnet_K, cfg->num_highways));
-  RC(make_linear_conv(&t->post_proj, hw[ix], M, C, nullptr)); ix += 1;
+  RC(make_linear_conv(&t->post_proj, hw[ix], M, C, nullptr));
+  if (!rc && M % 4 == 0 && !diag_int("taco_post_cm")) {  // round 6: the postnet's convs as time-major split convs too (A/B: MBHIP_DIAG=taco_post_cm at create)
+    RC(make_cbhg_tm(&t->post, hw, ix_post, M, C, C, M, cfg->postnet_K, cfg->num_highways));
+    if (!rc && t->post.tm.ok) {
+      const int r = make_tml(&t->post_proj_tm, hw[ix], M, C, 1, 0, nullptr, nullptr, nullptr);
+      if (r < 0) rc = r;
+      if (r) { t->post.tm.release(); t->post_proj_tm.release(); }
+    }
+  }
+  ix += 1;
   if (cfg->has_encoder && !rc) {
     const int Ce = cfg->encoder_dims, Em = cfg->embed_dims;
     RC(t->emb.upload(hw[ix], (size_t)cfg->num_chars * Em)); ix += 1;
@@ -1766,7 +1937,7 @@ extern "C" void mb_taco_destroy(mb_taco* t) {
   if (t->ev_p0) (void)hipEventDestroy(t->ev_p0);
   if (t->ev_p1) (void)hipEventDestroy(t->ev_p1);
   if (t->loop_stream) (void)hipStreamDestroy(t->loop_stream);
-  t->post.release(); t->post_proj.release(); t->enc.release();
+  t->post.release(); t->post_proj.release(); t->post_proj_tm.release(); t->enc.release();
   t->enc_fc1.release(); t->enc_fc2.release(); t->enc_proj.release();
   for (mb_taco::Img16* im : {&t->i_l1x, &t->i_l2x, &t->i_l1hh, &t->i_l2hh, &t->i_rin, &t->i_pre, &t->i_stopc, &t->i_mel, &t->i_fc1, &t->i_stop}) im->w.release();
   t->pm_conv.release();
@@ -2354,8 +2525,20 @@ extern "C" int mb_taco_decode(const mb_taco* t, const float* d_memory, const flo
   int rc = MB_OK;
 #define RC(x) do { if (!rc) rc = (x); } while (0)
   if (t->ev_p0) MB_HIP(hipEventRecord(t->ev_p0, s));
-  RC(cbhg_forward(t->post, L.melc, B, F, L.cb, s));
-  RC(run_conv(t->post_proj, L.cb.seq, B, F, L.linc, 0, 0, 0, nullptr, nullptr, 0, s));
+  if (t->post.tm.ok && L.cb.xt) {
+    bool seq_tm = false;
+    RC(cbhg_forward_tm(t->post, L.melc, B, F, L.cb, s, &seq_tm));
+    if (seq_tm) {  // post_proj reads the scan's [F][B][C] output as B items of F rows (row stride B C), the result is turned back once
+      const int C = t->post.ch;
+      RC(run_tml(t->post_proj_tm, L.cb.seq_tm, B, F, L.cb.hwa, 0, nullptr, nullptr, s, C, B * C));
+      RC(mb_f32_tm_to_cm(L.cb.hwa, L.linc, B, M, F, (mb_stream_t)s));
+    } else {
+      RC(run_conv(t->post_proj, L.cb.seq, B, F, L.linc, 0, 0, 0, nullptr, nullptr, 0, s));
+    }
+  } else {
+    RC(cbhg_forward(t->post, L.melc, B, F, L.cb, s));
+    RC(run_conv(t->post_proj, L.cb.seq, B, F, L.linc, 0, 0, 0, nullptr, nullptr, 0, s));
+  }
   if (t->ev_p1) { MB_HIP(hipEventRecord(t->ev_p1, s)); t->post_timed = true; }
   if (!rc) {
     MB_HIP(hipMemsetAsync(d_linear, 0, sizeof(float) * (size_t)B * M * max_steps, s));

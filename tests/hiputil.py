@@ -221,8 +221,17 @@ def resblock_pair_split_hip(x, w1, b1, w2, b2, *, dilation=1, slope=0.1, out_sca
     return f32_tm_to_cm(y).cpu()
 
 
+def split_tensor(x_tm):
+    """fp32 [B, T, C] -> the split tensor fp16 [B, T, 2, C] of the error-compensated paths: hi = fp16(x), lo = fp16((x - hi) * 2^11)
+    (values clamped to fp16's range first: common.h split_pair)."""
+    v = x_tm.float().clamp(-65504.0, 65504.0)
+    hi = v.half()
+    lo = ((v - hi.float()) * 2048.0).half()
+    return torch.stack((hi, lo), dim=2).contiguous()
+
+
 def conv_split_tm_hip(x, w, bias=None, *, pad=0, dilation=1, in_slope=1.0, res=None, out_act=0, out_scale=1.0, accumulate_into=None,
-                      valid=None, valid_mul=1, device="cuda"):
+                      valid=None, valid_mul=1, device="cuda", x_split=False, want_split=False, gate=None, post=None):
     """Time-major split conv (mb_conv_split_tm).  x [B, C_in, T] float (reference layout, turned on the device), w [M, C_in, k] (torch
     Conv1d layout), res / accumulate_into [B, M, T]; returns [B, M, T] float32 (rows beyond `valid` keep their NaN fill)."""
     L = _lib.lib()
@@ -237,9 +246,14 @@ def conv_split_tm_hip(x, w, bias=None, *, pad=0, dilation=1, in_slope=1.0, res=N
     pw = packed.to(dev)
     xt = f32_cm_to_tm(x, device)
     B, T, _ = xt.shape
+    if x_split:  # the same values handed over as a split tensor (staged by copy)
+        xt = split_tensor(xt)
     y = f32_cm_to_tm(accumulate_into, device) if accumulate_into is not None else \
         torch.full((B, T, M), float("nan"), dtype=torch.float32, device=dev)
     rt = f32_cm_to_tm(res, device) if res is not None else None
+    gt = f32_cm_to_tm(gate, device) if gate is not None else None
+    ps, pt = (post[0].float().contiguous().to(dev), post[1].float().contiguous().to(dev)) if post is not None else (None, None)
+    ysp = torch.zeros(B, T, 2, M, dtype=torch.float16, device=dev) if want_split else None
     pb = bias.float().contiguous().to(dev) if bias is not None else None
     vt = torch.tensor(valid, dtype=torch.int32, device=dev) if valid is not None else None
     a = _lib.ConvSplitTmArgs()
@@ -250,9 +264,14 @@ def conv_split_tm_hip(x, w, bias=None, *, pad=0, dilation=1, in_slope=1.0, res=N
     a.in_slope, a.unscale, a.out_scale, a.out_act = in_slope, float(us[0]), out_scale, out_act
     a.accumulate = int(accumulate_into is not None)
     a.d_valid, a.valid_mul = (vt.data_ptr() if vt is not None else None), valid_mul
+    a.d_gate = gt.data_ptr() if gt is not None else None
+    a.d_post_scale, a.d_post_shift = (ps.data_ptr(), pt.data_ptr()) if ps is not None else (None, None)
+    a.x_split = int(x_split)
+    a.d_ysplit = ysp.data_ptr() if ysp is not None else None
     _lib.check(L.mb_conv_split_tm(C.byref(a), _lib.stream_ptr()), "mb_conv_split_tm")
     torch.cuda.synchronize()
-    return f32_tm_to_cm(y).cpu()
+    out = f32_tm_to_cm(y).cpu()
+    return (out, ysp.cpu(), y.cpu()) if want_split else out
 
 
 def resblock_stage_f16_hip(x, chains, *, slope=0.1, out_scale=0.0, valid=None, valid_mul=1, accumulate_into=None, device="cuda"):

@@ -87,6 +87,58 @@ def test_residual_tanh_accumulate_and_ragged(cuda, lib):
         assert bool(torch.isnan(y[i, :, n:]).all())
 
 
+def test_epilogues_of_the_cbhg(cuda, lib):
+    """ReLU -> BatchNorm affine (common/batch_norm_conv.py:11-14), sigmoid, and the highway epilogue (common/highway_network.py:12-17)."""
+    B, Cin, M, T = 2, 128, 256, 300
+    x = _rand(B, Cin, T, seed=1)
+    w = _rand(M, Cin, 3, seed=2) / (Cin * 3) ** 0.5
+    b = 0.1 * _rand(M, seed=3)
+    ps, pt = 1.0 + 0.2 * _rand(M, seed=4), 0.3 * _rand(M, seed=5)
+    conv = F.conv1d(x.double(), w.double(), b.double(), padding=1)
+    _check(hiputil.conv_split_tm_hip(x, w, b, pad=1, out_act=1, post=(ps, pt)), torch.relu(conv) * ps.double()[None, :, None] + pt.double()[None, :, None])
+    _check(hiputil.conv_split_tm_hip(x, w, b, pad=1, out_act=3), torch.sigmoid(conv))
+    gate, res = torch.sigmoid(_rand(B, M, T, seed=6)), _rand(B, M, T, seed=7)
+    _check(hiputil.conv_split_tm_hip(x, w, b, pad=1, out_act=4, gate=gate, res=res), gate.double() * torch.relu(conv) + (1 - gate.double()) * res.double())
+
+
+def test_split_tensors_between_launches(cuda, lib):
+    """d_ysplit: the result also as fp16 hi / scaled-lo rows -- bit for bit the split of the fp32 result; x_split: such a tensor as the
+    input, staged by copy -- bit for bit the result of the fp32 input (the same halves reach the matrix pipe)."""
+    B, Cin, M, T, k = 2, 256, 512, 333, 3
+    x = _rand(B, Cin, T, seed=1)
+    w = _rand(M, Cin, k, seed=2) / (Cin * k) ** 0.5
+    b = 0.1 * _rand(M, seed=3)
+    y, ysp, ytm = hiputil.conv_split_tm_hip(x, w, b, pad=1, want_split=True)
+    assert torch.equal(ysp, hiputil.split_tensor(ytm))
+    y2 = hiputil.conv_split_tm_hip(x, w, b, pad=1, x_split=True)
+    assert torch.equal(y2, y)
+    _check(y, F.conv1d(x.double(), w.double(), b.double(), padding=1))
+
+
+def test_maxpool_and_highway_kernels(cuda, lib):
+    """MaxPool1d(2, 1, 1)[:T] (sublayer/cbhg.py:20,61-62) and the highway combine on time-major tensors, fp32 and split outputs."""
+    import ctypes as C
+    from mockingbird_amd import _lib
+    L = _lib.lib()
+    B, Cc, T = 3, 96, 50
+    x = _rand(B, Cc, T, seed=1)
+    xt = hiputil.f32_cm_to_tm(x)
+    y = torch.empty_like(xt); ysp = torch.zeros(B, T, 2, Cc, dtype=torch.float16, device="cuda")
+    _lib.check(L.mb_maxpool2_tm(xt.data_ptr(), y.data_ptr(), ysp.data_ptr(), B, T, Cc, None), "mb_maxpool2_tm")
+    torch.cuda.synchronize()
+    ref = F.max_pool1d(x, 2, 1, 1)[:, :, :T]
+    assert torch.equal(hiputil.f32_tm_to_cm(y).cpu(), ref) and torch.equal(ysp.cpu(), hiputil.split_tensor(y.cpu()))
+    hg = _rand(B * T, 2 * Cc, seed=2).cuda()
+    out = torch.empty(B * T, Cc, device="cuda"); osp = torch.zeros(B * T, 2, Cc, dtype=torch.float16, device="cuda")
+    xr = xt.reshape(B * T, Cc).contiguous()
+    _lib.check(L.mb_highway_tm(hg.data_ptr(), xr.data_ptr(), out.data_ptr(), osp.data_ptr(), B * T, Cc, None), "mb_highway_tm")
+    torch.cuda.synchronize()
+    h, g = hg[:, :Cc].double().cpu(), torch.sigmoid(hg[:, Cc:].double().cpu())
+    refh = g * torch.relu(h) + (1 - g) * xr.double().cpu()
+    assert float((out.double().cpu() - refh).abs().max()) <= 1e-6
+    assert torch.equal(osp.cpu(), hiputil.split_tensor(out.cpu()[None])[0])
+
+
 def test_rejects_bad_shapes(cuda, lib):
     from mockingbird_amd._lib import MbHipError
     with pytest.raises(MbHipError, match="unsupported"):

@@ -1,0 +1,17 @@
+#!/bin/bash
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_p -o taco -- python tools/taco_gen_time.py > /dev/null 2>&1
+f=$(find gpurun_out/prof_p -name "*kernel_trace.csv" | head -1)
+python - "$f" <<'PY'
+import csv, sys
+rows=list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r:int(r['Start_Timestamp']))
+# find the last gru_scan_kernel<8 dispatch (postnet scan) and print the 24 dispatches before it and 4 after
+idx=[i for i,r in enumerate(rows) if 'gru_scan_kernel<8' in r['Kernel_Name']][-1]
+for r in rows[idx-22:idx+5]:
+    d=(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3
+    g=r.get('Grid_Size') or r.get('Grid_Size_X') or '?'
+    print(f"{r['Kernel_Name'][:70]:70s} grid {g:>8s} lds {r.get('LDS_Block_Size','?'):>7s}  {d:8.1f} us")
+PY
+rm -rf gpurun_out/prof_p

@@ -16,3 +16,4 @@ for _ in range(5):
     dev.generate(chars, spk, steps=400, style_idx=-1, min_stop_token=11, seed=5)
 torch.cuda.synchronize()
 print("tacotron generate B=32 ms", (time.perf_counter() - t0) / 5 * 1e3, "env MBHIP_DIAG", os.environ.get("MBHIP_DIAG"))
+print("  decoder loop ms", dev.last_loop_ms, " postnet ms", getattr(dev, "last_postnet_ms", None))
