@@ -402,7 +402,7 @@ def pmc_traffic(what, keys=None):
     tools/pmc_r02.sh: 2 x FETCH_SIZE + WRITE_SIZE per launch; counters cannot be read in-process).  keys = kernels to
     sum per launch; None = all bytes of the profiled command.  Returns (bytes, source) or (None, None)."""
     pm = name = None
-    for rnd in ("r05", "r04", "r03", "r02"):  # the newest committed pass of this object (round 5 refreshed every one of them)
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):  # the newest committed pass of this object
         try:
             name = f"profiles/{rnd}_pmc_{what}.json"
             pm = json.load(open(os.path.join(ROOT, name)))
