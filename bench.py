@@ -1024,6 +1024,13 @@ def main():
                                                    "ONE resident launch (ppg_batch.h, round 5): 160 role workgroups + one attention workgroup per utterance, "
                                                    "weights as split fp16 fragments in registers, error-compensated v_mfma_f32_16x16x32_f16, pair-granule "
                                                    "hand-offs, two column groups of 16 in flight")
+                _ppg_env = os.environ.get("MBHIP_PPG_RESIDENT")  # (a value the caller set is put back behind the A/B legs)
+
+                def _ppg_restore():
+                    if _ppg_env is None:
+                        os.environ.pop("MBHIP_PPG_RESIDENT", None)
+                    else:
+                        os.environ["MBHIP_PPG_RESIDENT"] = _ppg_env
                 if pb == 32 and getattr(pdec, "last_loop_launches", 0) == 1:  # A/B partner: the 6-launch chain on the same batch
                     os.environ["MBHIP_PPG_RESIDENT"] = "0"
                     try:
@@ -1034,7 +1041,7 @@ def main():
                                                                "loop": "6-launch step (ppg_fast.h), hipGraph replays, same batch",
                                                                "mel_max_abs_diff_vs_resident": float((cm - pm).abs().max())}
                     finally:
-                        os.environ.pop("MBHIP_PPG_RESIDENT", None)
+                        _ppg_restore()
                 if pb == 1 and getattr(pdec, "last_loop_launches", 0) == 1:  # A/B partner of the resident loop: the 6-launch chain
                     os.environ["MBHIP_PPG_RESIDENT"] = "0"
                     try:
@@ -1045,7 +1052,7 @@ def main():
                                                               "loop": "6-launch step (ppg_fast.h), hipGraph replays, same utterance",
                                                               "mel_max_abs_diff_vs_resident": float((cm - pm).abs().max())}
                     finally:
-                        os.environ.pop("MBHIP_PPG_RESIDENT", None)
+                        _ppg_restore()
             # 19.1 MB of fp32 weights are touched once per step (attention LSTM 7.3 MB, decoder LSTM 10.5 MB, rest 1.3 MB)
             wbytes = 4.0 * (256 * 80 + 128 * 256 + 2048 * (384 + 512) + 256 * 512 + 15 * 256 + 2048 * (768 + 512) + 161 * 768)
             entry["workload"] = ("ppg2mel Decoder.inference loop (prenet, attention LSTMCell, MoL attention, decoder LSTMCell, "

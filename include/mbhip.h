@@ -468,7 +468,10 @@ int mb_wavernn_generate(const mb_wavernn* w, const mb_wavernn_plan* plan,
  * of all utterances are the columns of the same 5 launches per step, amortising the launch latency that
  * bounds a single utterance.  Production chain only (Philox sampling); batched fold geometry
  * (fold_with_overlap, fatchord_version.py:288-338) per utterance; utterance u draws exactly the noise it
- * would draw alone with seed h_seeds[u], so its samples equal those of mb_wavernn_generate(seed = h_seeds[u]).
+ * would draw alone with seed h_seeds[u]; its samples equal those of mb_wavernn_generate(seed = h_seeds[u]) on the same form of the loop
+ * and, across forms (a wide batch multiplies operand pairs on the fp16 pipe, rnn_ts3_body.h; a single utterance runs wf_pipe16_kernel), up to
+ * picks at provable near-ties.  Above 64 fold columns the call is HOST-BLOCKING: the range word of the operand-pair GEMMs is read behind the
+ * loop (hipStreamSynchronize) and a raised word reruns the loop on the fp32 instances (mb_wavernn_last_path: MB_WRN_FALLBACK_RANGE).
  * h_fold_offsets [n_utt+1] (out of the plan call): utterance u owns rows [off[u], off[u+1]) of
  * d_samples [n_folds][seq_len].  h_d_mels: HOST array of n_utt DEVICE pointers, mel u = fp32 [feat][frames[u]]. */
 typedef struct mb_wavernn_batch_plan {

@@ -1,4 +1,5 @@
 // Error reporting, device buffers and ABI version for libmbhip.
+#include <utility>
 #include "common.h"
 #include <cstdlib>
 
@@ -18,19 +19,30 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
   return MB_EHIP;
 }
 
+// The variable is parsed ONCE per distinct value: a call compares the environment string with the cached one
+// (the common case -- unset -- is one getenv) and looks the key up in the parsed list.  Tests flip the variable between calls, so the
+// string is re-read at every call; threads that mutate the environment while a call runs are not supported (as before).
 bool diag_str(const char* key, std::string* value) {
   const char* e = getenv("MBHIP_DIAG");
-  if (!e) return false;
-  const size_t kl = strlen(key);
-  for (const char* p = e; *p;) {
-    const char* end = strchr(p, ',');
-    const size_t len = end ? (size_t)(end - p) : strlen(p);
-    if (len >= kl && strncmp(p, key, kl) == 0 && (len == kl || p[kl] == '=')) {
-      if (value) *value = len == kl ? std::string("1") : std::string(p + kl + 1, len - kl - 1);
+  if (!e || !*e) return false;
+  static thread_local std::string cached;
+  static thread_local std::vector<std::pair<std::string, std::string>> parsed;
+  if (cached != e) {
+    cached = e;
+    parsed.clear();
+    for (const char* p = e; *p;) {
+      const char* end = strchr(p, ',');
+      const size_t len = end ? (size_t)(end - p) : strlen(p);
+      const char* eq = (const char*)memchr(p, '=', len);
+      if (len) parsed.emplace_back(eq ? std::string(p, eq - p) : std::string(p, len), eq ? std::string(eq + 1, len - (eq - p) - 1) : std::string("1"));
+      p += len + (end ? 1 : 0);
+    }
+  }
+  for (const auto& kv : parsed)
+    if (kv.first == key) {
+      if (value) *value = kv.second;
       return true;
     }
-    p += len + (end ? 1 : 0);
-  }
   return false;
 }
 

@@ -176,6 +176,7 @@ struct mb_ppg2mel {
 
 // a resident launch (ppg_resident.h) once lost a hand-off on this device: stop defaulting to it there
 static std::atomic<bool> g_ppg_resident_failed[64] = {};  // written by whichever host thread sees the abort word: atomic
+static std::atomic<bool> g_ppg_batch_failed[64] = {};     // the batch kernel's own memo (160 + B workgroups against 217: a lost hand-off of one says nothing about the other)
 
 static int ppg_shapes(const mb_ppg2mel_config* c, std::vector<size_t>* numel) {
   MB_REQUIRE(c, "ppg2mel: null config");
@@ -691,7 +692,7 @@ extern "C" int mb_ppg2mel_decode(const mb_ppg2mel* p, const float* d_memory, int
         pm->batch_cus = nb >= 1 ? prop.multiProcessorCount : 0;
       }
       if (pm->batch_cus < PB_G_MOL + B) batch_res = false;
-      if (dev >= 0 && dev < 64 && g_ppg_resident_failed[dev] && !renv) batch_res = false;
+      if (dev >= 0 && dev < 64 && g_ppg_batch_failed[dev] && !renv) batch_res = false;
     }
     if (batch_res) {
       hipStream_t ls = pm->loop_stream;
@@ -743,7 +744,7 @@ extern "C" int mb_ppg2mel_decode(const mb_ppg2mel* p, const float* d_memory, int
           fprintf(stderr, "[mbhip] ppg2mel: the batch resident kernel could not keep its workgroups co-resident; using the launch chain\n");
           warned_b = true;
         }
-        if (dev >= 0 && dev < 64 && !test_abort) g_ppg_resident_failed[dev] = true;
+        if (dev >= 0 && dev < 64 && !test_abort) g_ppg_batch_failed[dev] = true;
         pm->last_batch_fallback = 1;
       } else {
         static bool warned_r = false;

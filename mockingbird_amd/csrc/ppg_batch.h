@@ -233,14 +233,14 @@ __global__ __launch_bounds__(512) void ppg_batch_kernel(PbK a) {
              // would only wait for p0 (as the tail of the previous item it made the workgroup sit through Q0 and MOL before it could
              // serve the other group's chain item: 19 us per step at two groups against 11 at one)
             wh16x8 bh[1], bl[1];
-            if (!pb_gather<1, false, 4>(EX(PBX_CTX, g, tag - 1), 128, colg[g], Ng[g], tag - 1, bh, bl, a.abort_word, s_flag)) return;
+            if (!pb_gather<1, false, 4>(EX(PBX_CTX, g, tag - 1), 128, colg[g], Ng[g], tag - 1, bh, bl, a.abort_word, s_flag)) { wq16_range_report(a.range_word, rmax); return; }
             pb_mma<1>(Wc[0], bh, bl, acc[0], acl[0]);
             pb_mma<1>(Wc[1], bh, bl, acc[1], acl[1]);
           }
           wh16x8 bh[1], bl[1];
           // (p0 of step s carries the tag of the step that produced it, s - 1: the FIRST write of either parity buffer must be
           //  tag 1 / tag 2 -- tbit 1 -- or zero-initialised memory would read as fresh)
-          if (!pb_gather<1, true, 1>(EX(PBX_P0, g, tag - 1), 128, colg[g], Ng[g], tag - 1, bh, bl, a.abort_word, s_flag)) return;
+          if (!pb_gather<1, true, 1>(EX(PBX_P0, g, tag - 1), 128, colg[g], Ng[g], tag - 1, bh, bl, a.abort_word, s_flag)) { wq16_range_report(a.range_word, rmax); return; }
           // prenet.1: this wave's K slice of all 8 tiles -> LDS, tile `wave` summed by wave `wave`
 #pragma unroll
           for (int t = 0; t < 8; ++t) {
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(512) void ppg_batch_kernel(PbK a) {
             redA[(t * 8 + wave) * 64 + lane] = pb_fold(pa, pl);
           }
           __syncthreads();
-          if (*s_flag) return;
+          if (*s_flag) { wq16_range_report(a.range_word, rmax); return; }
           {
             const float4 sm = pb_sum<8>(redA, wave, lane);
             float v[4] = {sm.x * a.att_w1.us, sm.y * a.att_w1.us, sm.z * a.att_w1.us, sm.w * a.att_w1.us};
@@ -293,14 +293,14 @@ __global__ __launch_bounds__(512) void ppg_batch_kernel(PbK a) {
         {
           f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, acl[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
           wh16x8 bh[2], bl[2];
-          if (!pb_gather<2, true, 2>(EX(PBX_AH, g, tag), 256, colg[g], Ng[g], tag, bh, bl, a.abort_word, s_flag)) return;
+          if (!pb_gather<2, true, 2>(EX(PBX_AH, g, tag), 256, colg[g], Ng[g], tag, bh, bl, a.abort_word, s_flag)) { wq16_range_report(a.range_word, rmax); return; }
           pb_mma<2>(Wh[0], bh, bl, acc[0], acl[0]);
           pb_mma<2>(Wh[1], bh, bl, acc[1], acl[1]);
           redB[(0 * 8 + wave) * 64 + lane] = pb_fold(acc[0], acl[0]);
           redB[(1 * 8 + wave) * 64 + lane] = pb_fold(acc[1], acl[1]);
         }
         __syncthreads();
-        if (*s_flag) return;
+        if (*s_flag) { wq16_range_report(a.range_word, rmax); return; }
         if (wave < 2) {
           const float4 sm = pb_sum<8>(redB, wave, lane);
           P[g][0] = sm.x * a.att_wh.us; P[g][1] = sm.y * a.att_wh.us; P[g][2] = sm.z * a.att_wh.us; P[g][3] = sm.w * a.att_wh.us;
@@ -336,26 +336,26 @@ __global__ __launch_bounds__(512) void ppg_batch_kernel(PbK a) {
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, acl[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         if (s > 0) {  // h of the previous step: in place long ago
           wh16x8 bh[2], bl[2];
-          if (!pb_gather<2, false, 4>(EX(PBX_DH, g, tag - 1), 256, colg[g], Ng[g], tag - 1, bh, bl, a.abort_word, s_flag)) return;
+          if (!pb_gather<2, false, 4>(EX(PBX_DH, g, tag - 1), 256, colg[g], Ng[g], tag - 1, bh, bl, a.abort_word, s_flag)) { wq16_range_report(a.range_word, rmax); return; }
           pb_mma<2>(Wh[0], bh, bl, acc[0], acl[0]);
           pb_mma<2>(Wh[1], bh, bl, acc[1], acl[1]);
         }
         {
           wh16x8 bh[2], bl[2];
-          if (!pb_gather<2, true, 1>(EX(PBX_AH, g, tag), 256, colg[g], Ng[g], tag, bh, bl, a.abort_word, s_flag)) return;
+          if (!pb_gather<2, true, 1>(EX(PBX_AH, g, tag), 256, colg[g], Ng[g], tag, bh, bl, a.abort_word, s_flag)) { wq16_range_report(a.range_word, rmax); return; }
           pb_mma<2>(Wa[0], bh, bl, acc[0], acl[0]);
           pb_mma<2>(Wa[1], bh, bl, acc[1], acl[1]);
         }
         {
           wh16x8 bh[1], bl[1];
-          if (!pb_gather<1, true, 1>(EX(PBX_CTX, g, tag), 128, colg[g], Ng[g], tag, bh, bl, a.abort_word, s_flag)) return;
+          if (!pb_gather<1, true, 1>(EX(PBX_CTX, g, tag), 128, colg[g], Ng[g], tag, bh, bl, a.abort_word, s_flag)) { wq16_range_report(a.range_word, rmax); return; }
           pb_mma<1>(Wc[0], bh, bl, acc[0], acl[0]);
           pb_mma<1>(Wc[1], bh, bl, acc[1], acl[1]);
         }
         redB[(0 * 8 + wave) * 64 + lane] = pb_fold(acc[0], acl[0]);
         redB[(1 * 8 + wave) * 64 + lane] = pb_fold(acc[1], acl[1]);
         __syncthreads();
-        if (*s_flag) return;
+        if (*s_flag) { wq16_range_report(a.range_word, rmax); return; }
         if (wave < 2) {
           const float4 sm = pb_sum<8>(redB, wave, lane);
           const float us = a.dec_wa.us;
@@ -384,12 +384,12 @@ __global__ __launch_bounds__(512) void ppg_batch_kernel(PbK a) {
       for (int g = 0; g < PB_NG; ++g) {
         if (Ng[g] <= 0) continue;
         wh16x8 bh[2], bl[2];
-        if (!pb_gather<2, true, 1>(EX(PBX_AH, g, tag), 256, colg[g], Ng[g], tag, bh, bl, a.abort_word, s_flag)) return;
+        if (!pb_gather<2, true, 1>(EX(PBX_AH, g, tag), 256, colg[g], Ng[g], tag, bh, bl, a.abort_word, s_flag)) { wq16_range_report(a.range_word, rmax); return; }
         f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acl = {0.f, 0.f, 0.f, 0.f};
         pb_mma<2>(W, bh, bl, acc, acl);
         redB[wave * 64 + lane] = pb_fold(acc, acl);
         __syncthreads();
-        if (*s_flag) return;
+        if (*s_flag) { wq16_range_report(a.range_word, rmax); return; }
         if (wave == 0) {
           const float4 sm = pb_sum<8>(redB, 0, lane);
           const float us = a.q0_w.us;
@@ -435,20 +435,20 @@ __global__ __launch_bounds__(512) void ppg_batch_kernel(PbK a) {
         for (int t = 0; t < 3; ++t) { acc[t] = {0.f, 0.f, 0.f, 0.f}; acl[t] = {0.f, 0.f, 0.f, 0.f}; }
         {
           wh16x8 bh[1], bl[1];
-          if (!pb_gather<1, true, 2>(EX(PBX_CTX, g, tag), 128, colg[g], Ng[g], tag, bh, bl, a.abort_word, s_flag)) return;
+          if (!pb_gather<1, true, 2>(EX(PBX_CTX, g, tag), 128, colg[g], Ng[g], tag, bh, bl, a.abort_word, s_flag)) { wq16_range_report(a.range_word, rmax); return; }
 #pragma unroll
           for (int t = 0; t < 3; ++t) pb_mma<1>(Wc[t], bh, bl, acc[t], acl[t]);
         }
         {
           wh16x8 bh[2], bl[2];
-          if (!pb_gather<2, true, 1>(EX(PBX_DH, g, tag), 256, colg[g], Ng[g], tag, bh, bl, a.abort_word, s_flag)) return;
+          if (!pb_gather<2, true, 1>(EX(PBX_DH, g, tag), 256, colg[g], Ng[g], tag, bh, bl, a.abort_word, s_flag)) { wq16_range_report(a.range_word, rmax); return; }
 #pragma unroll
           for (int t = 0; t < 3; ++t) pb_mma<2>(Wh[t], bh, bl, acc[t], acl[t]);
         }
 #pragma unroll
         for (int t = 0; t < 3; ++t) redB[(t * 8 + wave) * 64 + lane] = pb_fold(acc[t], acl[t]);
         __syncthreads();
-        if (*s_flag) return;
+        if (*s_flag) { wq16_range_report(a.range_word, rmax); return; }
         // stop_output = stop_layer([h, context]) (:288); every wave works the group's votes out (row 0 of the stop tile: lanes du == 0)
         const float us = a.out_wh.us;
         const int n = a.gn0[g] + i;
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(512) void ppg_batch_kernel(PbK a) {
         }
       }
       __syncthreads();
-      if (*s_flag) return;
+      if (*s_flag) { wq16_range_report(a.range_word, rmax); return; }
       if (tid < 128) {
         unsigned long long v, t0 = 0;
         for (int tries = 0;; ++tries) {
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(512) void ppg_batch_kernel(PbK a) {
         s_q[2 * tid + 1] = (float)h[1] + (float)l[1] * WQ16_LO_UNSCALE;
       }
       __syncthreads();
-      if (*s_flag) return;
+      if (*s_flag) { wq16_range_report(a.range_word, rmax); return; }
       // mixture_params = query_layer.2(q)  :75 -- waves 0..3 take four rows each
       if (wave < 4) {
         const float4* q4 = reinterpret_cast<const float4*>(s_q) + sl;

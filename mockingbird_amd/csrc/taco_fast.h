@@ -245,6 +245,7 @@ __global__ __launch_bounds__(512) void taco_rin_kernel(TfRinK a) {
     } else {
       if (!fm_gemm<NT, 9, 8, 4, 1>(a.w_stopc, 0, a.ctx, a.ah, a.nta, nt0, red, sx, sh)) return;
     }
+    if (F16) fm_range_check(sx, a.lost);  // (every fm_gemm16 result is checked where it is made: no reliance on a sibling tile)
     const int nt = nt0 + wv;
     if (nt >= a.nta || done || du != 0) return;
     a.stop_part[nt * 16 + (lane & 15)] = sx[0];
@@ -373,6 +374,7 @@ __global__ __launch_bounds__(512) void taco_mel_kernel(TfMelK a) {
     } else {
       if (!fm_gemm<NT, 8, 8, 4, 1>(a.w_fc1, mt, a.x2, a.x2, a.nta, nt0, red, sx, sh, a.trace, TS_MEL_FC1, pick)) return;
     }
+    if (F16) fm_range_check(sx, a.flags + TF_LOST);
     const int nt = nt0 + wv, n = nt * 16 + i, row0 = mt * 16 + du * 4;
     if (nt >= a.nta || done) return;
     const float4 bq = *reinterpret_cast<const float4*>(a.b_fc1 + row0);
@@ -399,6 +401,7 @@ __global__ __launch_bounds__(512) void taco_mel_kernel(TfMelK a) {
   } else {
     if (!fm_gemm<NT, 8, 8, 4, 1>(a.w_stop, 0, a.x2, a.x2, a.nta, nt0, red, sx, sh, a.trace, TS_MEL_STOP, pickS)) return;
   }
+  if (F16) fm_range_check(sx, a.flags + TF_LOST);
   const int nt = nt0 + wv, n = nt * 16 + i;
   if (nt >= a.nta || done) return;
   int below = 0;

@@ -2412,7 +2412,17 @@ extern "C" int mb_taco_decode(const mb_taco* t, const float* d_memory, const flo
       int dev = 0, ncu = 0;
       MB_HIP(hipGetDevice(&dev));
       MB_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-      tm->n_cus = ncu;
+      // a compute-unit count alone does not say that an attention workgroup (128 KB of LDS) fits a compute unit of THIS device or
+      // partition: ask the occupancy of the fused launch's instances once per handle (as wavernn.hip does for its resident
+      // kernels) -- a device that cannot hold one workgroup per compute unit runs the 7-launch loop from the start
+      int nb = 1, nb_min = 1 << 30;
+#define TF_OCC(...)                                                                                                                     \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&taco_front_kernel<__VA_ARGS__>), 512, 0) != hipSuccess) nb = 0; \
+      nb_min = std::min(nb_min, nb);
+      TF_OCC(32, 2, true, true) TF_OCC(32, 1, true, true) TF_OCC(32, 2, false, false) TF_OCC(48, 2, true, false) TF_OCC(48, 2, false, false) TF_OCC(48, 1, false, false)
+#undef TF_OCC
+      (void)hipGetLastError();
+      tm->n_cus = nb_min >= 1 ? ncu : 0;
     }
     bool front = taco_pick_form(B, T, lsa_fast ? 1 : 0, tm->n_cus, 1, tm->front_failed ? 1 : 0, diag_int("taco_front", -1), 0, 0, nullptr) != 7;
     for (;;) {

@@ -605,7 +605,11 @@ extern "C" int mb_wavernn_create(const mb_wavernn_config* cfg, const float* cons
         hipEventCreate(&w->ev_t0) != hipSuccess || hipEventCreate(&w->ev_t1) != hipSuccess)
       rc = MB_EHIP;
   }
-  if (rc) { if (rc == MB_EHIP) set_error("wavernn_create: stream/event creation failed"); mb_wavernn_destroy(w); return rc; }
+  // the range word of the wide-batch operand-pair GEMMs and its pinned copy: both here, once (allocated lazily on a const
+  // handle, a failed second allocation left a null host word behind a non-null device word)
+  if (!rc && (hipMalloc((void**)&w->d_range, sizeof(int)) != hipSuccess ||
+              hipHostMalloc((void**)&w->h_range, sizeof(int), hipHostMallocDefault) != hipSuccess)) rc = MB_EHIP;
+  if (rc) { if (rc == MB_EHIP) set_error("wavernn_create: stream / event / range-word creation failed"); mb_wavernn_destroy(w); return rc; }
   *out = w;
   return MB_OK;
 }
@@ -1559,10 +1563,7 @@ extern "C" int mb_wavernn_generate_batch(const mb_wavernn* wc, const mb_wavernn_
                                          void* d_workspace, size_t workspace_bytes, mb_stream_t stream) {
   mb_wavernn* w = const_cast<mb_wavernn*>(wc);
   MB_REQUIRE(w && plan, "wavernn_generate_batch: null pointer");
-  if (!w->d_range) {
-    MB_HIP(hipMalloc((void**)&w->d_range, sizeof(int)));
-    MB_HIP(hipHostMalloc((void**)&w->h_range, sizeof(int), hipHostMallocDefault));
-  }
+  MB_REQUIRE(w->d_range && w->h_range, "wavernn_generate_batch: handle without its range word");
   w->last_path = MB_WRN_PATH_CHAIN; w->last_fallback = MB_WRN_FALLBACK_NONE;
   // > 64 columns: the GEMMs of the loop are rnn_ts3_body's operand pairs (|x| <= 65504).  Their range word is read behind the loop --
   // the call is HOST-BLOCKING there -- and a raised word reruns the whole loop on the fp32 instances (rnn_ts2_body.h): no silent clamp.

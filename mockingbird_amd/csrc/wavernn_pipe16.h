@@ -301,7 +301,7 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
         if (MOL && s > 0) {  // MOL (fatchord_version.py:213-220): the key word IS the sample -- one classic granule per column from the one F3 workgroup
           if (tid < Ng) {
             unsigned xv[1];
-            if (!wp_wait<1>(EX(WQX_KEY, g, tag_prev) + tid, 1, tag_prev, xv, a.abort_word)) return;
+            if (!wp_wait<1>(EX(WQX_KEY, g, tag_prev) + tid, 1, tag_prev, xv, a.abort_word)) { wq16_range_report(k16.range_word, rmax); return; }
             s_x[g * WQ_GC + tid] = __uint_as_float(xv[0]);
             if (blk == 0) {
               a.samples[(size_t)(n0 + tid) * S + (s - 1)] = __uint_as_float(xv[0]);
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
             wp_watch<1>(K + (size_t)((n_t3 - 1) * 2 + 1) * LD + (Ng - 1), tag_prev, a.abort_word);
             if (key_lane && !have) {
               unsigned kv[2];
-              if (!wp_wait<2>(K + (size_t)tile * 2 * LD + n, LD, tag_prev, kv, a.abort_word)) return;
+              if (!wp_wait<2>(K + (size_t)tile * 2 * LD + n, LD, tag_prev, kv, a.abort_word)) { wq16_range_report(k16.range_word, rmax); return; }
               atomicMax(&s_key[g * WQ_GC + n], ((unsigned long long)kv[0] << 32) | (unsigned long long)kv[1]);
             }
             __syncthreads();
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
         WQ_MARK(0, 5);
         // ---- hidden half of the next step: P1 = W_hh1 . h1 + b_hh1, kept by the lane that will use it ----
         wh16x8 bh[2], bl[2];
-        if (!wq16_gather<2>(EX(WQX_H1, g, tag), g_off[g], tag, Ng, bh, bl, a.abort_word, WQ_MK(0, 6))) return;
+        if (!wq16_gather<2>(EX(WQX_H1, g, tag), g_off[g], tag, Ng, bh, bl, a.abort_word, WQ_MK(0, 6))) { wq16_range_report(k16.range_word, rmax); return; }
         if (tid < WQ_GC) s_key[g * WQ_GC + tid] = 0ull;  // every finish lane has read the step's keys (the gather's barrier is behind us)
         if (tid == 0) *s_stale = 0;
         WQ_MARK(0, 3);
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
         }
         WQ_MARK(1, 0);
         wh16x8 bh[2], bl[2];
-        if (!wq16_gather<WQ16_CRIT_SLEEP>(EX(WQX_X1, g, tag), g_off[g], tag, Ng, bh, bl, a.abort_word, WQ_MK(1, 6))) return;
+        if (!wq16_gather<WQ16_CRIT_SLEEP>(EX(WQX_X1, g, tag), g_off[g], tag, Ng, bh, bl, a.abort_word, WQ_MK(1, 6))) { wq16_range_report(k16.range_word, rmax); return; }
         WQ_MARK(1, 1);
         if (wave == xr_wave && (lane >> 4) == xr_kb) {  // residual of the own units: hi + 2^-11 lo, through LDS behind the GEMM's own barrier
           const wh16x8 xh = xr_st ? bh[1] : bh[0], xl = xr_st ? bl[1] : bl[0];
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
         WQ_MARK(1, 2);
         if (TRACE && a.trace && tid == 0 && g == 0 && s == 1001) a.trace[512 + blk] = (unsigned long long)wall_clock64();
         if (s + 1 >= S) continue;
-        if (!wq16_gather<2>(EX(WQX_H2, g, tag), g_off[g], tag, Ng, bh, bl, a.abort_word)) return;
+        if (!wq16_gather<2>(EX(WQX_H2, g, tag), g_off[g], tag, Ng, bh, bl, a.abort_word)) { wq16_range_report(k16.range_word, rmax); return; }
         WQ_MARK(1, 3);
         const bool epi2 = wq16_gemm2(A2, A3, bh, bl, red + rb * 4096, k16.us_hh2, sx);
         rb ^= 1;
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(512) void wf_pipe16_kernel(Wq16K k16) {
       }
       WQ_MARK(2 + fr, 0);
       wh16x8 bh[2], bl[2];
-      if (!wq16_gather<WQ16_CRIT_SLEEP>(EX(src, g, tag), g_off[g], tag, Ng, bh, bl, a.abort_word, WQ_MK(2 + fr, 6))) return;
+      if (!wq16_gather<WQ16_CRIT_SLEEP>(EX(src, g, tag), g_off[g], tag, Ng, bh, bl, a.abort_word, WQ_MK(2 + fr, 6))) { wq16_range_report(k16.range_word, rmax); return; }
       WQ_MARK(2 + fr, 1);
       float sx[4];
       if (f3mol) {

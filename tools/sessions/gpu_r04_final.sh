@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-4 measurement session: every -m gpu test, smoke, the default bench line, rocprofv3 kernel stats of the bench command,
-# PMC traffic passes of the resident WaveRNN kernel.  usage: bash tools/gpu_r04_final.sh [tag] [noprof]
+# PMC traffic passes of the resident WaveRNN kernel.  usage: bash tools/sessions/gpu_r04_final.sh [tag] [noprof]
 exec < /dev/null
 set -u
 TAG=${1:-a}

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-5 measurement session, in stages (usage: bash tools/gpu_r05_final.sh <tag> <stage>...):
+# Round-5 measurement session, in stages (usage: bash tools/sessions/gpu_r05_final.sh <tag> <stage>...):
 #   suite  every -m gpu test, __graft_entry__.smoke(), the default bench line
 #   prof   rocprofv3 --kernel-trace --stats of the bench command -> profiles/r05_bench_kernel_stats.csv
 #   pmcw   HBM traffic + SQ counters of the resident WaveRNN kernel -> profiles/r05_pmc_wavernn.json, r05_wavernn_pipe16_sq_counters.json
