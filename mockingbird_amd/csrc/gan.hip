@@ -8,6 +8,7 @@
 // average and the final tanh are folded into the producing / consuming conv
 // kernel (conv1d.hip), so activations make exactly one HBM round trip per
 // conv.  Activation layout is the reference's [B][C][T] (time contiguous).
+#include <mutex>
 #include "common.h"
 
 namespace mb {
@@ -176,6 +177,16 @@ struct mb_gan {
   struct TmConv { DevBuf w, bias; float us = 0.f; int c_in = 0, m = 0, k = 0, pad = 0, dil = 1, rep = 1; };
   std::vector<TmConv> tmc;
   bool tm_all = false;
+  // tm_all: the parallel ResBlocks of a stage (xs = mean_j resblock_j(x): independent chains) run on streams of their own -- one launch
+  // of 256 persistent workgroups rarely divides its tiles evenly (256 channels, 32 x 1600 rows: 576 tiles = 2.25 rounds), and the
+  // chains' workgroups fill each other's last rounds.  side[j] carries chain j in stages of few rounds (a cross-queue edge costs
+  // ~13 us: stages of many rounds stay on the caller's stream); ev_fork =
+  // the stage input is ready, ev_last[j] = chain j's accumulate into the stage output is enqueued (chain j + 1's accumulate waits for
+  // it: the sum keeps its order, results are bit for bit those of one stream).  Events belong to the handle: enqueue under `mu`.
+  std::vector<hipStream_t> side;
+  std::vector<hipEvent_t> ev_last;
+  hipEvent_t ev_fork = nullptr;
+  std::mutex mu;
   int hop;
   // indices into convs
   int i_pre, i_ups, i_cond, i_resout, i_rb, i_post;
@@ -376,6 +387,25 @@ extern "C" int mb_gan_create_ex(const mb_gan_config* cfg, const float* const* h_
     if (rc) { mb_gan_destroy(g); return rc; }
     g->tm_all = all && !diag_int("gan_tm_pairs_only");  // A/B: the ResBlock units time-major, everything else channel-major (first form of the round)
     if (!g->tm_all) { for (auto& t : g->tmc) { t.w.release(); t.bias.release(); } g->tmc.clear(); }
+    if (g->tm_all && cfg->num_kernels > 1 && !diag_int("gan_one_stream")) {  // (A/B: every launch on the caller's stream)
+      hipError_t e = hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming);
+      for (int j = 0; j < cfg->num_kernels && e == hipSuccess; ++j) {
+        hipEvent_t ev = nullptr;
+        e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e == hipSuccess) g->ev_last.push_back(ev);
+      }
+      // the chains should FINISH in the order of the sum (gan_forward_tm): the first of the side streams gets the highest priority the
+      // device offers, the last the lowest
+      int pr_least = 0, pr_greatest = 0;
+      if (e == hipSuccess) e = hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
+      for (int j = 0; j < cfg->num_kernels && e == hipSuccess; ++j) {
+        hipStream_t st = nullptr;
+        const int pr = j == 0 ? pr_greatest : j + 1 == cfg->num_kernels ? pr_least : (pr_least + pr_greatest) / 2;
+        e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, diag_int("gan_fork_flat") ? 0 : pr);
+        if (e == hipSuccess) g->side.push_back(st);
+      }
+      if (e != hipSuccess) { mb_gan_destroy(g); return hip_fail(e, "gan_create: branch streams", __FILE__, __LINE__); }
+    }
   }
   if (dtype == MB_F16 && !no_stage && cfg->num_kernels <= 4 &&
       cfg->num_dilations <= 4) {
@@ -521,6 +551,9 @@ extern "C" void mb_gan_destroy(mb_gan* g) {
   for (auto& c : g->convs) { c.w.release(); c.b.release(); }
   for (auto& p : g->pairs) p.release();
   for (auto& p : g->spairs) p.w.release();
+  for (auto st : g->side) (void)hipStreamDestroy(st);
+  for (auto ev : g->ev_last) (void)hipEventDestroy(ev);
+  if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
   for (auto& t : g->tmc) { t.w.release(); t.bias.release(); }
   for (auto& p : g->stage_w) p.release();
   for (auto& p : g->stage_b) p.release();
@@ -565,7 +598,7 @@ extern "C" size_t mb_gan_workspace_bytes(const mb_gan* g, int batch, int frames)
   if (!g || batch <= 0 || frames <= 0) return 0;
   const size_t esz = g->dtype == MB_F16 ? 2 : sizeof(float);
   const size_t per = align_up(gan_max_act(g, frames) * batch * esz, 256);
-  const int nbuf = g->cfg.kind == MB_GAN_FREGAN ? 8 : 4;
+  const int nbuf = (g->cfg.kind == MB_GAN_FREGAN ? 8 : 4) + 2 * std::max(0, (int)g->side.size() - 1);  // + the chains' own ping-pong pairs (every chain runs on a side stream)
   // fp16: + the time-major fp16 copy of the mel
   const size_t melh = g->dtype == MB_F16 ? align_up((size_t)batch * frames * g->cfg.num_mels * 2, 256)
                                          : (g->tm_all ? align_up((size_t)batch * frames * g->cfg.num_mels * 4, 256) : 0);  // fp32: + its time-major copy
@@ -709,7 +742,15 @@ static int gan_forward_tm(const mb_gan* g, const float* d_mel, int batch, int fr
     OUTA = ar.take<char>(per); OUTB = ar.take<char>(per);
   }
   char* melt = ar.take<char>((size_t)batch * frames * c.num_mels * sizeof(float));
-  Launcher L{(hipStream_t)stream, batch, MB_F32};
+  const bool can_fork = !g->side.empty();
+  std::vector<char*> XRj(c.num_kernels, XR), Tj(c.num_kernels, T);
+  for (size_t j = 1; j < g->side.size(); ++j) { XRj[j] = ar.take<char>(per); Tj[j] = ar.take<char>(per); }
+  const bool sum_fwd = diag_int("gan_sum_fwd") != 0;  // (A/B: the reference's order of the sum)
+  const int fork_rounds = diag_int("gan_fork_rounds", 8);  // stages whose unit launches have fewer rounds of ~96-row tiles than this fork
+  std::unique_lock<std::mutex> lock(const_cast<mb_gan*>(g)->mu, std::defer_lock);
+  if (can_fork) lock.lock();
+  hipStream_t main_s = (hipStream_t)stream;
+  Launcher L{main_s, batch, MB_F32};
   L.valid = d_frames; L.frames_max = frames;
   L.to_tm(d_mel, melt, c.num_mels, frames);
   const float LRELU = 0.1f;
@@ -745,23 +786,41 @@ static int gan_forward_tm(const mb_gan* g, const float* d_mel, int batch, int fr
     }
     L.conv_tm(g->tmc[g->i_ups + i], XS, t, X, LRELU, nullptr, 0);  // x = ups[i](leaky_relu(x))
     t *= u;
-    for (int j = 0; j < c.num_kernels; ++j) {  // xs = mean_j resblock_j(x): chains ping-pong XR / T, the mean accumulates in XS
+    // xs = mean_j resblock_j(x): chain j ping-pongs XRj / Tj on its own stream, the mean accumulates in XS in the order of j
+    const bool forked = can_fork && (long long)batch * t < (long long)fork_rounds * 96 * 256;
+    if (forked && !L.rc) MB_HIP(hipEventRecord(g->ev_fork, main_s));
+    // The mean is summed from the LAST chain to the first (the widest kernel first: r_{nk-1} + ... + r_0; the reference adds them in
+    // index order, models.py:139-145 -- an fp32 rounding of difference): the chain with the longest launches is the critical path of a
+    // forked stage, it opens the sum on the highest-priority stream and the cheap chains, which fill the gaps, close it.
+    for (int o = 0; o < c.num_kernels && !L.rc; ++o) {
+      const int j = sum_fwd ? o : c.num_kernels - 1 - o;
+      L.s = forked ? g->side[o] : main_s;
+      if (forked) MB_HIP(hipStreamWaitEvent(L.s, g->ev_fork, 0));
+      auto before_last = [&]() -> int {  // the accumulate of the chain before this one is enqueued ahead of this one's
+        if (forked && o > 0) MB_HIP(hipStreamWaitEvent(L.s, g->ev_last[o - 1], 0));
+        return MB_OK;
+      };
       if (c.resblock_type == 2) {  // ResBlock2 (models.py:63-68): x <- x + conv_d(lrelu(x)), twice
         const int b2 = g->i_rb + (i * c.num_kernels + j) * 2;
-        L.conv_tm(g->tmc[b2], X, t, XR, LRELU, X, 0);
-        L.conv_tm(g->tmc[b2 + 1], XR, t, XS, LRELU, XR, 0, inv_nk, j > 0);
-        continue;
+        L.conv_tm(g->tmc[b2], X, t, XRj[j], LRELU, X, 0);
+        if (!L.rc) L.rc = before_last();
+        L.conv_tm(g->tmc[b2 + 1], XRj[j], t, XS, LRELU, XRj[j], 0, inv_nk, o > 0);
+      } else {
+        const int base = g->i_rb + ((i * c.num_kernels + j) * c.num_dilations) * 2;
+        const char* xr = X;
+        for (int d = 0; d < c.num_dilations && !L.rc; ++d) {
+          const bool last = d == c.num_dilations - 1;
+          char* dst = last ? XS : ((d & 1) ? Tj[j] : XRj[j]);
+          if (last) L.rc = before_last();
+          L.pair_split(g->spairs[(size_t)(i * c.num_kernels + j) * c.num_dilations + d], g->convs[base + d],
+                       g->convs[base + c.num_dilations + d], xr, t, dst, LRELU, last ? inv_nk : 1.f, last && o > 0);
+          xr = dst;
+        }
       }
-      const int base = g->i_rb + ((i * c.num_kernels + j) * c.num_dilations) * 2;
-      const char* xr = X;
-      for (int d = 0; d < c.num_dilations; ++d) {
-        const bool last = d == c.num_dilations - 1;
-        char* dst = last ? XS : ((d & 1) ? T : XR);
-        L.pair_split(g->spairs[(size_t)(i * c.num_kernels + j) * c.num_dilations + d], g->convs[base + d],
-                     g->convs[base + c.num_dilations + d], xr, t, dst, LRELU, last ? inv_nk : 1.f, last && j > 0);
-        xr = dst;
-      }
+      if (forked && !L.rc) MB_HIP(hipEventRecord(g->ev_last[o], L.s));
     }
+    L.s = main_s;
+    if (forked && !L.rc) MB_HIP(hipStreamWaitEvent(main_s, g->ev_last[c.num_kernels - 1], 0));  // (follows every chain's last launch)
     if (pending_out) {  // output = output + x (generator.py:158-159)
       L.add(pending_out, XS, (size_t)batch * ch * t);
       out_cur = pending_out;

@@ -1227,7 +1227,7 @@ static int run_tml(const TmL& c, const float* x, int B, int t, float* y, int out
 // Round 6: the CBHG on time-major tensors -- x [B][cin][F] is turned once, the conv bank is ONE launch, every
 // conv a conv_split_tm launch (BatchNorm / ReLU / residual / highway in its write-out), the GRU tables come out time-major as the
 // scan reads them.  -> L.seq_tm [F][B][ch] (*tm_valid) or, when the resident scan is not available, L.seq [B][ch][F].
-int cbhg_forward_tm(const Cbhg& c, const float* x, int B, int F, const CbhgWs& L, hipStream_t s, bool* tm_valid) {
+int cbhg_forward_tm(const Cbhg& c, const float* x, int B, int F, const CbhgWs& L, hipStream_t s, bool* tm_valid, bool want_cm = false) {
   int rc = MB_OK;
   const int C = c.ch;
   const CbhgTm& m = c.tm;
@@ -1255,7 +1255,7 @@ int cbhg_forward_tm(const Cbhg& c, const float* x, int B, int F, const CbhgWs& L
   RC(run_tml(m.ih_b, scur, B, F, L.ihb, 0, nullptr, nullptr, s, 0, 0, true, nullptr));
 #undef RC
   if (rc) return rc;
-  return cbhg_scan(c, B, F, L, s, false, tm_valid);
+  return cbhg_scan(c, B, F, L, s, want_cm, tm_valid);
 }
 
 // x [B][cin][F] -> ws.seq [B][ch][F] (forward half in channels [0, ch/2), backward in [ch/2, ch))
@@ -1903,7 +1903,10 @@ extern "C" int mb_taco_create(const mb_taco_config* cfg, const float* const* hw,
     RC(make_linear_conv(&t->enc_fc1, hw[ix], Ce, Em, hw[ix + 1]));
     RC(make_linear_conv(&t->enc_fc2, hw[ix + 2], Ce, Ce, hw[ix + 3]));
     ix += 4;
+    const int ix_enc = ix;
     RC(make_cbhg(&t->enc, hw, &ix, Ce, Ce, Ce, Ce, cfg->encoder_K, cfg->num_highways));
+    if (!rc && Ce % 4 == 0 && !diag_int("taco_post_cm"))  // the encoder's CBHG on the time-major split convs as well (5 + 8 launches of 37 us -> 1 + 4)
+      RC(make_cbhg_tm(&t->enc, hw, ix_enc, Ce, Ce, Ce, Ce, cfg->encoder_K, cfg->num_highways));
     {  // encoder_proj: columns [0, Ce) as a 1x1 conv over the encoder sequence; the rest per utterance
       std::vector<float> we((size_t)D * Ce);
       for (int d = 0; d < D; ++d) memcpy(&we[(size_t)d * Ce], hw[ix] + (size_t)d * P, sizeof(float) * Ce);
@@ -2639,7 +2642,8 @@ extern "C" int mb_taco_encode(const mb_taco* t, const int32_t* d_chars, const fl
   hipLaunchKernelGGL(dropout_cm_kernel, dim3(std::min(cdiv(Ce * T, 256), 1024), B), dim3(256), 0, s, L.p2,
                      d_dropout ? d_dropout + (size_t)B * T * Ce : nullptr, Ce, T, (unsigned long long)seed, 1, e_thresh, e_scale);
   // x = cbhg(x)  (tacotron.py:43-44)
-  RC(cbhg_forward(t->enc, L.p2, B, T, L.cb, s));
+  if (t->enc.tm.ok) RC(cbhg_forward_tm(t->enc, L.p2, B, T, L.cb, s, nullptr, true));
+  else RC(cbhg_forward(t->enc, L.p2, B, T, L.cb, s));
   // speaker + style concat (tacotron.py:171-197, 253) and encoder_proj (:255)
   if (!rc) {
     const size_t lds = sizeof(float) * (c.speaker_dims + c.style_dims + D);
