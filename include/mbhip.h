@@ -302,6 +302,12 @@ int mb_conv_split_tm(const mb_conv_split_tm_args* a, mb_stream_t stream);
 /* MaxPool1d(2, stride 1, padding 1)[:t] over time (sublayer/cbhg.py:20,61-62) on fp32 [B][t][channels]: y[t] = max(x[t-1], x[t]), as
  * fp32 (d_y) and / or as a split tensor (d_ysplit); one of them may be NULL */
 int mb_maxpool2_tm(const float* d_x, float* d_y, void* d_ysplit, int batch, int t, int channels, mb_stream_t stream);
+/* A Conv1d to ONE output channel on a time-major fp32 tensor (the generators' conv_post: models/vocoder/hifigan/models.py:146-148,
+   fregan/generator.py:161-163, vits.py:296-297): d_y[b][t] = act(bias + sum_{j, c} d_w[j][c] * lrelu(d_x[b][t - pad + j * dilation][c])),
+   'same' padding, exact fp32 FMAs; d_w is [ksize][c_in] fp32 on the device (tap-major), out_act 0 none / 2 tanh, in_slope in (0, 1]
+   (1 = no activation); d_valid / valid_mul as in mb_conv_split_tm (rows beyond an item's length read as zeros and are not written). */
+int mb_conv_c1_tm(const float* d_x, const float* d_w, float bias, float* d_y, int batch, int t, int c_in, int ksize, int dilation,
+                  int pad, float in_slope, int out_act, const int32_t* d_valid, int valid_mul, mb_stream_t stream);
 /* Highway combine (common/highway_network.py:12-17): d_hg fp32 [rows][2 channels] = (W1 x + b1 | W2 x + b2) of one conv launch, d_x fp32
  * [rows][channels] -> d_y = g relu(h) + (1 - g) x with g = sigmoid(W2 x + b2), also as a split tensor (d_ysplit, may be NULL) */
 int mb_highway_tm(const float* d_hg, const float* d_x, float* d_y, void* d_ysplit, long long rows, int channels, mb_stream_t stream);

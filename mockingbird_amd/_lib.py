@@ -187,6 +187,8 @@ SIGNATURES = {
     "mb_conv_split_tm_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mb_conv_split_tm": (C.c_int, [C.POINTER(ConvSplitTmArgs), C.c_void_p]),
     "mb_maxpool2_tm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mb_conv_c1_tm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "mb_highway_tm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]),
     "mb_f32_cm_to_tm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mb_f32_tm_to_cm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

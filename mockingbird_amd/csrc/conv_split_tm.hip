@@ -140,29 +140,21 @@ void conv_split_tm_kernel(ConvTmK a) {
       const int c = (q % NJT) * JC;  // first chunk of the job
       const int Tb = ctm_valid_len(a, b);
       const int tx0 = t0 - a.pad;
-      const float* xb = a.x + (long long)b * a.x_bstride;
+      // rows outside [0, Tb) come back as zeros from the descriptor's range check; channels beyond c_in (a padded last chunk) read
+      // finite neighbours (or zeros past the end) against zero weights
       if (a.x_split) {  // (uniform) 16-byte pieces of the hi / lo planes, copied as they are
         const h16* xh = reinterpret_cast<const h16*>(a.x) + (long long)b * a.T * 2 * a.c_in;
+        const __amdgpu_buffer_rsrc_t rs = tm_rsrc(xh, (long long)Tb * 2 * a.c_in * 2);
 #pragma unroll
         for (int i = 0; i < LBX; ++i) {
-          const int tx = tx0 + xrow[i];
-          const unsigned plane = xcol[i] >> 16, ch = (unsigned)c * CK + (xcol[i] & 0xffffu);
-          const bool in = tx >= 0 && tx < Tb && ch < (unsigned)a.c_in;
-          const unsigned off = ((unsigned)min(max(tx, 0), a.T - 1) * 2u + plane) * (unsigned)a.c_in + min(ch, (unsigned)a.c_in - 8u);
-          const f32x4 ld = *reinterpret_cast<const f32x4*>(xh + off);
-          vx[i] = in ? ld : (f32x4)0.f;
+          const int plane = (int)(xcol[i] >> 16), ch = c * CK + (int)(xcol[i] & 0xffffu);
+          vx[i] = tm_load16(rs, (unsigned)(((tx0 + xrow[i]) * 2 + plane) * a.c_in + ch) * 2u);
         }
         return;
       }
+      const __amdgpu_buffer_rsrc_t rs = tm_rsrc(a.x + (long long)b * a.x_bstride, Tb > 0 ? ((long long)(Tb - 1) * a.x_row_stride + a.c_in) * 4 : 0);
 #pragma unroll
-      for (int i = 0; i < LBX; ++i) {
-        const int tx = tx0 + xrow[i];
-        const unsigned ch = (unsigned)c * CK + xcol[i];
-        const bool in = tx >= 0 && tx < Tb && ch < (unsigned)a.c_in;  // rows beyond the item / channels beyond c_in: zeros
-        const unsigned off = (unsigned)min(max(tx, 0), a.T - 1) * (unsigned)a.x_row_stride + min(ch, (unsigned)a.c_in - 4u);
-        const f32x4 ld = *reinterpret_cast<const f32x4*>(xb + off);
-        vx[i] = in ? ld : (f32x4)0.f;
-      }
+      for (int i = 0; i < LBX; ++i) vx[i] = tm_load16(rs, (unsigned)((tx0 + xrow[i]) * a.x_row_stride + c * CK + (int)xcol[i]) * 4u);
     };
     auto commit_x = [&](int q, const f32x4 (&vx)[LBX]) __attribute__((always_inline)) {
       h16* buf = xs + (q % a.nbuf) * JC * 2 * XPL;
@@ -281,12 +273,14 @@ void conv_split_tm_kernel(ConvTmK a) {
         if (c < 8) CT_MARK(1, it, 4 * c);
         __syncthreads();  // B_q: job q is staged, the buffer of job q-1 is free
         if (c < 8) CT_MARK(1, it, 4 * c + 1);
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // everything outstanding is an interval old: drained here, the next request flies through the interval's processing
         if (q + a.nbuf < njobs) issue_x(q + a.nbuf, vxA);
         if (q + a.nbuf - 1 < njobs) commit_x(q + a.nbuf - 1, vxB);
         if (c < 8) CT_MARK(1, it, 4 * c + 2);
         if (it > 0) write_part(it - 1, c, c + 1, NJT);
         if (c < 8) CT_MARK(1, it, 4 * c + 3);
         __syncthreads();  // B_{q+1}
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         if (q + 1 + a.nbuf < njobs) issue_x(q + 1 + a.nbuf, vxB);
         if (q + a.nbuf < njobs) commit_x(q + a.nbuf, vxA);
         if (it > 0) write_part(it - 1, c + 1, c + 2, NJT);
@@ -628,7 +622,75 @@ __global__ __launch_bounds__(256) void highway_tm_kernel(const float* __restrict
     }
   }
 }
+
+// A Conv1d to ONE output channel on a time-major fp32 tensor (the GANs' conv_post: models/vocoder/hifigan/models.py:146-148,
+// fregan/generator.py:161-163, vits.py:296-297): y[b][t] = act(bias + sum_{j, c} w[j][c] lrelu(x[b][t - pad + j dil][c])).
+// 2 k C flops per 4 C bytes read: an HBM stream.  On the MFMA kernel it was 31 of 32 tile rows of zero weights and a write-out of one
+// float per row (266 us for 164 MB at 32 x 200 frames); here a workgroup lays 256 + halo rows down in LDS (activation applied once)
+// and every thread owns one output row, exact fp32 FMAs (j-major, then c), weights as LDS broadcasts.
+constexpr int C1_ROWS = 256;
+__global__ __launch_bounds__(256) void conv_c1_tm_kernel(const float* __restrict__ x, const float* __restrict__ w, float bias, float* __restrict__ y,
+                                                         int T, int C, int ntaps, int dil, int pad, float slope, int out_act,
+                                                         const int* __restrict__ valid, int valid_mul, int tiles_per_item) {
+  extern __shared__ __attribute__((aligned(16))) float c1_lds[];
+  const int CS = C + 4;                      // row stride in floats (16-byte aligned rows, 4 banks of skew)
+  const int halo = (ntaps - 1) * dil;
+  float* sw = c1_lds;                        // [ntaps][C]
+  float* sx = c1_lds + ntaps * C;            // [C1_ROWS + halo][CS]
+  const int b = blockIdx.x / tiles_per_item, t0 = (blockIdx.x - b * tiles_per_item) * C1_ROWS;
+  const int Tb = valid ? min(T, valid[b] * valid_mul) : T;
+  if (t0 >= Tb) return;  // (uniform)
+  const int tid = threadIdx.x;
+  for (int i = tid; i < ntaps * C; i += 256) sw[i] = w[i];
+  const int c4 = C / 4, rows = C1_ROWS + halo;
+  const __amdgpu_buffer_rsrc_t rs = tm_rsrc(x + (long long)b * T * C, (long long)Tb * C * 4);
+  for (int i = tid; i < rows * c4; i += 256) {
+    const int r = i / c4, q = i - r * c4;
+    f32x4 v = tm_load16(rs, (unsigned)((t0 - pad + r) * C + q * 4) * 4u);  // rows outside [0, Tb): zeros
+    if (slope != 1.f) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * slope);
+    }
+    *reinterpret_cast<f32x4*>(sx + r * CS + q * 4) = v;
+  }
+  __syncthreads();
+  float acc = bias;
+  for (int j = 0; j < ntaps; ++j) {
+    const float* xr = sx + (tid + j * dil) * CS;
+    const float* wr = sw + j * C;
+    for (int q = 0; q < c4; ++q) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + q * 4), wv = *reinterpret_cast<const f32x4*>(wr + q * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = fmaf(wv[e], xv[e], acc);
+    }
+  }
+  if (out_act == 2) acc = tanhf(acc);
+  if (t0 + tid < Tb) y[(long long)b * T + t0 + tid] = acc;
+}
 }  // namespace mb
+
+extern "C" int mb_conv_c1_tm(const float* d_x, const float* d_w, float bias, float* d_y, int batch, int t, int c_in, int ksize, int dilation,
+                             int pad, float in_slope, int out_act, const int32_t* d_valid, int valid_mul, mb_stream_t stream) {
+  MB_REQUIRE(d_x && d_w && d_y, "conv_c1_tm: null pointer");
+  MB_REQUIRE(c_in > 0 && c_in % 4 == 0 && ksize >= 1 && dilation >= 1 && 2 * pad == dilation * (ksize - 1),
+             "conv_c1_tm: c_in=%d ksize=%d dilation=%d pad=%d (c_in %% 4 == 0, 'same' padding)", c_in, ksize, dilation, pad);
+  MB_REQUIRE(out_act == 0 || out_act == 2, "conv_c1_tm: out_act %d (0 none, 2 tanh)", out_act);
+  MB_REQUIRE(in_slope > 0.f && in_slope <= 1.f, "conv_c1_tm: in_slope %g outside (0, 1]", in_slope);
+  if (batch <= 0 || t <= 0) return MB_OK;
+  const size_t lds = sizeof(float) * ((size_t)ksize * c_in + (size_t)(mb::C1_ROWS + (ksize - 1) * dilation) * (c_in + 4));
+  MB_REQUIRE(lds <= 160 * 1024, "conv_c1_tm: window of %zu B does not fit in LDS (c_in=%d ksize=%d dilation=%d)", lds, c_in, ksize, dilation);
+  MB_REQUIRE((long long)t * c_in * 4 < 0xffffffffll, "conv_c1_tm: an item of %d x %d floats is beyond a buffer descriptor's 4 GB", t, c_in);
+  static std::atomic<size_t> attr_bytes{0};
+  if (lds > 64 * 1024 && lds > attr_bytes.load()) {
+    MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mb::conv_c1_tm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_bytes.store(lds);
+  }
+  const int tiles = mb::cdiv(t, mb::C1_ROWS);
+  hipLaunchKernelGGL(mb::conv_c1_tm_kernel, dim3((unsigned)(batch * tiles)), dim3(256), lds, (hipStream_t)stream, d_x, d_w, bias, d_y, t, c_in, ksize,
+                     dilation, pad, in_slope, out_act, d_valid, valid_mul > 0 ? valid_mul : 1, tiles);
+  MB_HIP(hipGetLastError());
+  return MB_OK;
+}
 
 extern "C" int mb_maxpool2_tm(const float* d_x, float* d_y, void* d_ysplit, int batch, int t, int channels, mb_stream_t stream) {
   MB_REQUIRE(d_x && (d_y || d_ysplit) && d_x != d_y, "maxpool2_tm: null pointer / in place");

@@ -174,7 +174,10 @@ struct mb_gan {
   std::vector<SPair> spairs;
   // ... and every other conv as a time-major split conv (conv_split_tm.hip), indexed as `convs` (ResBlock entries stay empty).  When
   // every conv of the generator has an image (tm_all) the whole forward runs time-major: the mel is turned once, nothing else is.
-  struct TmConv { DevBuf w, bias; float us = 0.f; int c_in = 0, m = 0, k = 0, pad = 0, dil = 1, rep = 1; };
+  struct TmConv {
+    DevBuf w, bias; float us = 0.f; int c_in = 0, m = 0, k = 0, pad = 0, dil = 1, rep = 1;
+    DevBuf w1; float bias1 = 0.f;  // a conv to ONE channel (conv_post) also as [k][c_in] fp32 for mb_conv_c1_tm: an HBM stream, no MFMA tile
+  };
   std::vector<TmConv> tmc;
   bool tm_all = false;
   // tm_all: the parallel ResBlocks of a stage (xs = mean_j resblock_j(x): independent chains) run on streams of their own -- one launch
@@ -366,6 +369,13 @@ extern "C" int mb_gan_create_ex(const mb_gan_config* cfg, const float* const* h_
       int r = mb_conv_split_tm_pack(weff.data(), t.m, t.c_in, t.k, reinterpret_cast<uint16_t*>(img.data()), &t.us);
       if (!r) r = t.w.upload(img.data(), img.size());
       if (!r) r = t.bias.upload(beff.data(), beff.size());
+      if (!r && t.m == 1 && t.rep == 1 && t.c_in % 4 == 0 && 2 * t.pad == t.dil * (t.k - 1) && !diag_int("gan_post_mfma")) {  // (A/B: conv_post on the MFMA kernel)
+        std::vector<float> w1((size_t)t.k * t.c_in);
+        for (int ci = 0; ci < t.c_in; ++ci)
+          for (int j = 0; j < t.k; ++j) w1[(size_t)j * t.c_in + ci] = weff[(size_t)ci * t.k + j];
+        r = t.w1.upload(w1.data(), w1.size());
+        t.bias1 = beff[0];
+      }
       return r;
     };
     auto want = [&](int idx, int rep) {
@@ -386,7 +396,7 @@ extern "C" int mb_gan_create_ex(const mb_gan_config* cfg, const float* const* h_
     want(g->i_post, 1);
     if (rc) { mb_gan_destroy(g); return rc; }
     g->tm_all = all && !diag_int("gan_tm_pairs_only");  // A/B: the ResBlock units time-major, everything else channel-major (first form of the round)
-    if (!g->tm_all) { for (auto& t : g->tmc) { t.w.release(); t.bias.release(); } g->tmc.clear(); }
+    if (!g->tm_all) { for (auto& t : g->tmc) { t.w.release(); t.bias.release(); t.w1.release(); } g->tmc.clear(); }
     if (g->tm_all && cfg->num_kernels > 1 && !diag_int("gan_one_stream")) {  // (A/B: every launch on the caller's stream)
       hipError_t e = hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming);
       for (int j = 0; j < cfg->num_kernels && e == hipSuccess; ++j) {
@@ -554,7 +564,7 @@ extern "C" void mb_gan_destroy(mb_gan* g) {
   for (auto st : g->side) (void)hipStreamDestroy(st);
   for (auto ev : g->ev_last) (void)hipEventDestroy(ev);
   if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
-  for (auto& t : g->tmc) { t.w.release(); t.bias.release(); }
+  for (auto& t : g->tmc) { t.w.release(); t.bias.release(); t.w1.release(); }
   for (auto& p : g->stage_w) p.release();
   for (auto& p : g->stage_b) p.release();
   for (auto& p : g->s32_w) p.release();
@@ -663,6 +673,11 @@ struct Launcher {
   void conv_tm(const mb_gan::TmConv& tc, const void* x, int t, void* y, float in_slope, const void* res, int out_act,
                float out_scale = 1.f, int accumulate = 0) {
     if (rc) return;
+    if (tc.w1.p && !res && !accumulate && out_scale == 1.f && (out_act == 0 || out_act == 2)) {  // one output channel: the streaming kernel
+      rc = mb_conv_c1_tm((const float*)x, tc.w1.p, tc.bias1, (float*)y, batch, t, tc.c_in, tc.k, tc.dil, tc.pad, in_slope, out_act, valid,
+                         t / frames_max, (mb_stream_t)s);
+      return;
+    }
     mb_conv_split_tm_args a;
     memset(&a, 0, sizeof(a));
     a.d_x = (const float*)x; a.d_y = (float*)y; a.d_wpacked = tc.w.p; a.d_bias = tc.bias.p; a.d_res = (const float*)res;

@@ -154,13 +154,9 @@ void resblock_pair_split_kernel(ResPairSK a) {
       const int Tb = spair_valid_len(a, b);  // beyond: this item's zero padding
       const int tx0 = t0 - p2 - p1;
       const float* xb = a.x + (long long)b * a.bstride + c * CK;
+      const __amdgpu_buffer_rsrc_t rs = tm_rsrc(xb, (long long)Tb * C * 4 - c * CK * 4);  // rows outside [0, Tb): zeros from the range check
 #pragma unroll
-      for (int i = 0; i < LBX; ++i) {
-        const int tx = tx0 + xrow[i];
-        const unsigned off = (unsigned)min(max(tx, 0), a.T - 1) * (unsigned)C + xcol[i];
-        const f32x4 ld = *reinterpret_cast<const f32x4*>(xb + off);
-        vx[i] = (tx >= 0 && tx < Tb) ? ld : (f32x4)0.f;
-      }
+      for (int i = 0; i < LBX; ++i) vx[i] = tm_load16(rs, (unsigned)((tx0 + xrow[i]) * C + (int)xcol[i]) * 4u);
     };
     auto commit_x = [&](int q, const f32x4 (&vx)[LBX]) __attribute__((always_inline)) {  // lrelu -> hi / scaled lo planes of buffer q % nbuf
       if (SPAIR_DBG & 8) return;
@@ -229,6 +225,10 @@ void resblock_pair_split_kernel(ResPairSK a) {
       }
     };
     f32x4 vxA[LBX], rxA[WB], ryA[WB], rxB[WB], ryB[WB];
+    // Behind a barrier everything a support wave has outstanding is an interval old.  Draining it THERE, explicitly, is free and tells
+    // the compiler that the register set it is about to lay down has landed: the set requested next stays in flight through the whole
+    // interval's processing (left to its own counting, the compiler waited for the newest load at the first use of the oldest).
+#define SP_DRAIN() __builtin_amdgcn_s_waitcnt(0x0F70)
     // Barrier schedule per tile (must mirror the MMA waves'): B per chunk, [W], E1, P|YF, Y.
     if (NCH == 1) {
       // one chunk per tile, one buffer: the next tile's window is requested at the head of phase 1 and laid down while the MMA waves
@@ -240,6 +240,7 @@ void resblock_pair_split_kernel(ResPairSK a) {
         SP_MARK(1, it, 0);
         __syncthreads();  // B
         SP_MARK(1, it, 1);
+        SP_DRAIN();
         if (it + 1 < my_tiles) issue_x(it + 1, vxA);
         if (it > 0) {
           if (YS) issue_w(it - 1, 1, rxB, ryB);
@@ -250,6 +251,7 @@ void resblock_pair_split_kernel(ResPairSK a) {
         if (!YS) __syncthreads();  // W: the h planes are free for h of this tile
         __syncthreads();  // E1: phase 1 has finished reading xs
         SP_MARK(1, it, 33);
+        SP_DRAIN();
         issue_w(it, 0, rxA, ryA);
         if (!YS) issue_w(it, 1, rxB, ryB);
         if (it + 1 < my_tiles) commit_x(it + 1, vxA);
@@ -278,6 +280,7 @@ void resblock_pair_split_kernel(ResPairSK a) {
           SP_MARK(1, it, 2 * c);
           __syncthreads();  // B_q: job q is staged, the buffer of job q-1 is free
           SP_MARK(1, it, 2 * c + 1);
+          SP_DRAIN();
           if (q + a.nbuf < njobs) issue_x(q + a.nbuf, vxA);
           if (it > 0) issue_w(it - 1, c + 1, rxA, ryA);
           if (q + a.nbuf - 1 < njobs) commit_x(q + a.nbuf - 1, vxB);
@@ -285,6 +288,7 @@ void resblock_pair_split_kernel(ResPairSK a) {
           SP_MARK(1, it, 2 * c + 2);
           __syncthreads();  // B_{q+1}
           SP_MARK(1, it, 2 * c + 3);
+          SP_DRAIN();
           if (q + 1 + a.nbuf < njobs) issue_x(q + 1 + a.nbuf, vxB);
           if (it > 0 && c + 2 < NCH) issue_w(it - 1, c + 2, rxB, ryB);
           if (q + a.nbuf < njobs) commit_x(q + a.nbuf, vxA);

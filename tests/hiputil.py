@@ -274,6 +274,23 @@ def conv_split_tm_hip(x, w, bias=None, *, pad=0, dilation=1, in_slope=1.0, res=N
     return (out, ysp.cpu(), y.cpu()) if want_split else out
 
 
+def conv_c1_tm_hip(x, w, bias=0.0, *, dilation=1, in_slope=1.0, out_act=0, valid=None, valid_mul=1, device="cuda"):
+    """One-output-channel conv on a time-major tensor (mb_conv_c1_tm, the generators' conv_post).  x [B, C, T], w [1, C, k] (torch
+    layout); returns [B, T] float32 (rows beyond `valid` keep their NaN fill)."""
+    L = _lib.lib()
+    dev = torch.device(device)
+    _, Cin, k = w.shape
+    w1 = w.detach().float()[0].t().contiguous().to(dev)  # [k][C]
+    xt = f32_cm_to_tm(x, device)
+    B, T, _ = xt.shape
+    y = torch.full((B, T), float("nan"), dtype=torch.float32, device=dev)
+    vt = torch.tensor(valid, dtype=torch.int32, device=dev) if valid is not None else None
+    _lib.check(L.mb_conv_c1_tm(xt.data_ptr(), w1.data_ptr(), float(bias), y.data_ptr(), B, T, Cin, k, dilation, dilation * (k - 1) // 2,
+                               in_slope, out_act, vt.data_ptr() if vt is not None else None, valid_mul, _lib.stream_ptr()), "mb_conv_c1_tm")
+    torch.cuda.synchronize()
+    return y.cpu()
+
+
 def resblock_stage_f16_hip(x, chains, *, slope=0.1, out_scale=0.0, valid=None, valid_mul=1, accumulate_into=None, device="cuda"):
     """One stage's ResBlock group in one launch (mb_resblock_stage_f16).  x: [B, C, T] float; chains: list (one per ResBlock)
     of lists (one per unit) of (w1, b1, w2, b2, dilation); returns [B, C, T] float32 (rows beyond `valid` are left NaN)."""

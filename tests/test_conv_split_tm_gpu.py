@@ -139,6 +139,35 @@ def test_maxpool_and_highway_kernels(cuda, lib):
     assert torch.equal(osp.cpu(), hiputil.split_tensor(out.cpu()[None])[0])
 
 
+@pytest.mark.parametrize("B,Cin,T,k,dil,slope,act", [(3, 32, 1000, 7, 1, 0.01, 2), (2, 64, 517, 7, 1, 0.01, 2), (2, 16, 300, 3, 2, 1.0, 0),
+                                                    (1, 32, 40, 1, 1, 0.1, 0)])
+def test_one_channel_conv_is_exact_fp32(cuda, lib, B, Cin, T, k, dil, slope, act):
+    """mb_conv_c1_tm (conv_post of the generators: leaky_relu -> Conv1d(C, 1, 7) -> tanh, models/vocoder/hifigan/models.py:146-148) against
+    float64; exact fp32 FMAs: the error is fp32 rounding of a k * C term sum."""
+    g = torch.Generator().manual_seed(B * 1000 + Cin + T)
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(1, Cin, k, generator=g) / (Cin * k) ** 0.5
+    bias = 0.25
+    xa = F.leaky_relu(x.double(), slope) if slope != 1.0 else x.double()
+    ref = F.conv1d(xa, w.double(), torch.tensor([bias], dtype=torch.float64), padding=dil * (k - 1) // 2, dilation=dil)[:, 0]
+    if act == 2:
+        ref = torch.tanh(ref)
+    got = hiputil.conv_c1_tm_hip(x, w, bias, dilation=dil, in_slope=slope, out_act=act)
+    assert torch.isfinite(got).all()
+    assert (got.double() - ref).abs().max() < 2e-6
+    # ragged: rows beyond an item's length read as zeros and are not written
+    valid = [max(1, (T // 4) // (b + 1)) for b in range(B)]
+    got = hiputil.conv_c1_tm_hip(x, w, bias, dilation=dil, in_slope=slope, out_act=act, valid=valid, valid_mul=4)
+    for b in range(B):
+        n = min(T, valid[b] * 4)
+        xb = xa[b:b + 1, :, :n]
+        rb = F.conv1d(xb, w.double(), torch.tensor([bias], dtype=torch.float64), padding=dil * (k - 1) // 2, dilation=dil)[0, 0]
+        if act == 2:
+            rb = torch.tanh(rb)
+        assert (got[b, :n].double() - rb).abs().max() < 2e-6
+        assert torch.isnan(got[b, n:]).all()
+
+
 def test_rejects_bad_shapes(cuda, lib):
     from mockingbird_amd._lib import MbHipError
     with pytest.raises(MbHipError, match="unsupported"):
