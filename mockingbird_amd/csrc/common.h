@@ -25,6 +25,20 @@ __device__ __forceinline__ void split_pair(const float a, const float b, mb_h2& 
   lo = __builtin_convertvector((v - __builtin_convertvector(hi, mb_f2)) * 2048.f, mb_h2);
 }
 
+// Window loads of the support waves go through a buffer descriptor per (item, chunk): rows before the item (negative offsets wrap past
+// the end) and rows beyond its valid length come back as zeros from the range check -- no predicate, no select.  (A select on the
+// loaded value inside the REQUEST made the compiler wait for every load where it was issued: the "one interval ahead" pipeline of the
+// support waves never had a load in flight across a barrier -- 7-10 k cycles per interval at 64 channels against 1.7 k of MFMAs.)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tm_rsrc(const void* base, long long bytes) {  // wave-uniform inputs
+  const unsigned long long q = (unsigned long long)base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)q), hi = __builtin_amdgcn_readfirstlane((unsigned)(q >> 32));
+  const unsigned nb = __builtin_amdgcn_readfirstlane((unsigned)(bytes < 0 ? 0 : bytes > 0xffffffffll ? 0xffffffffll : bytes));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, nb, 0x00020000);
+}
+__device__ __forceinline__ f32x4 tm_load16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what, const char* file, int line);
 

@@ -45,6 +45,11 @@ struct ConvTmK {
 };
 
 constexpr int CTM_NL = 4;  // support waves
+// diagnostics builds only (tools/build_variant.sh ... -DCTM_DBG=<bits>; results are wrong, timings isolate one cost each):
+// 1 = no global stores in the write-out, 2 = no LDS read of the result tile, 4 = window pieces not laid down, 8 = no window loads
+#ifndef CTM_DBG
+#define CTM_DBG 0
+#endif
 #ifdef CTM_TRACE_BUILD
 #define CT_MARK(role, it, k)                                                                    \
   do {                                                                                          \
@@ -135,6 +140,7 @@ void conv_split_tm_kernel(ConvTmK a) {
       t0 = (nt - b * a.tiles_per_item) * N1;
     };
     auto issue_x = [&](int q, f32x4 (&vx)[LBX]) __attribute__((always_inline)) {
+      if (CTM_DBG & 8) return;
       int b, t0;
       tile_of(q / NJT, b, t0);
       const int c = (q % NJT) * JC;  // first chunk of the job
@@ -157,6 +163,7 @@ void conv_split_tm_kernel(ConvTmK a) {
       for (int i = 0; i < LBX; ++i) vx[i] = tm_load16(rs, (unsigned)((tx0 + xrow[i]) * a.x_row_stride + c * CK + (int)xcol[i]) * 4u);
     };
     auto commit_x = [&](int q, const f32x4 (&vx)[LBX]) __attribute__((always_inline)) {
+      if (CTM_DBG & 4) return;
       h16* buf = xs + (q % a.nbuf) * JC * 2 * XPL;
       if (a.x_split) {
 #pragma unroll
@@ -223,7 +230,7 @@ void conv_split_tm_kernel(ConvTmK a) {
           const int idx = base + i * NSL + ltid;
           const unsigned idc = (unsigned)min(idx, w.ytotal - 1);
           const unsigned row = idc / YPR, pc = idc - row * YPR;
-          const f32x4 hv = *reinterpret_cast<const f32x4*>(ys + row * MGF + pc * 4);
+          const f32x4 hv = (CTM_DBG & 2) ? (f32x4)1.f : *reinterpret_cast<const f32x4*>(ys + row * MGF + pc * 4);
           const unsigned mc = (unsigned)m0 + min(pc * 4u, (unsigned)max(w.mcols - 4, 0));
           f32x4 psc = (f32x4)1.f, psh = (f32x4)0.f;
           if (a.post_scale) { psc = *reinterpret_cast<const f32x4*>(a.post_scale + mc); psh = *reinterpret_cast<const f32x4*>(a.post_shift + mc); }
@@ -254,7 +261,7 @@ void conv_split_tm_kernel(ConvTmK a) {
             *reinterpret_cast<h16x4*>(sp) = hi;
             *reinterpret_cast<h16x4*>(sp + a.c_out) = lo;
           }
-          if (ok[i]) {
+          if (ok[i] && !((CTM_DBG & 1) && o[0] != 12345.f)) {
             if (w.mcols >= 4) *reinterpret_cast<f32x4*>(w.yb + goff[i]) = o;
             else  // fewer than 4 output channels (conv_post: one): element stores
               for (int e = 0; e < w.mcols; ++e) w.yb[row * (unsigned)a.c_out + e] = o[e];

@@ -47,6 +47,9 @@ struct ResPairSK {
 
 // NL = support waves per workgroup (beside the 4 MMA waves): 4 (one per SIMD, 256 registers each) or, where the MMA waves need <= 168
 // registers (<= 64 channels), 8 (two per SIMD) -- at those widths the support waves' instruction stream, not the MFMAs, sets the pace
+#ifndef SPAIR_NL_NARROW
+#define SPAIR_NL_NARROW 8  // (A/B builds: 4)
+#endif
 constexpr int SPAIR_MAX_HALO = 80;  // (ksize - 1) * dilation the support waves' window registers are sized for (k = 11, d = 7: 70)
 // diagnostics builds only (tools/build_variant.sh ... -DSPAIR_DBG=<bits>; results are wrong, timings isolate one cost each):
 // 1 = weight ring never refilled, 2 = B fragments read once per chunk, 4 = no epilogues, 8 = no window fill, 16 = no write-out, 32 = no MFMAs
@@ -637,7 +640,7 @@ extern "C" int mb_resblock_pair_split(const mb_resblock_pair_split_args* a, mb_s
     const bool fa = spair_fits<GA>(ks, dl, YA), fb = spair_fits<GB>(ks, dl, YB);                          \
     MB_REQUIRE(fa || fb, "resblock_pair_split: no instance fits LDS");                                     \
     const bool pick_b = fb && (!fa || force == 2 || (force != 1 && cost(GB::N1) < cost(GA::N1)));          \
-    constexpr int nl_ = GA::CH <= 64 ? 8 : 4;                                                             \
+    constexpr int nl_ = GA::CH <= 64 ? SPAIR_NL_NARROW : 4;                                               \
     if (pick_b) return launch_spair<GB::CH, GB::MT, GB::WN, GB::NTW, YB, nl_>(k, a->batch, s);        \
     return launch_spair<GA::CH, GA::MT, GA::WN, GA::NTW, YA, nl_>(k, a->batch, s);                    \
   } while (0)

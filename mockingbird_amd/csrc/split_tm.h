@@ -10,20 +10,6 @@ typedef _Float16 h16;
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 
-// Window loads of the support waves go through a buffer descriptor per (item, chunk): rows before the item (negative offsets wrap past
-// the end) and rows beyond its valid length come back as zeros from the range check -- no predicate, no select.  (A select on the
-// loaded value inside the REQUEST made the compiler wait for every load where it was issued: the "one interval ahead" pipeline of the
-// support waves never had a load in flight across a barrier -- 7-10 k cycles per interval at 64 channels against 1.7 k of MFMAs.)
-typedef unsigned tm_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t tm_rsrc(const void* base, long long bytes) {  // wave-uniform inputs
-  const unsigned long long q = (unsigned long long)base;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)q), hi = __builtin_amdgcn_readfirstlane((unsigned)(q >> 32));
-  const unsigned nb = __builtin_amdgcn_readfirstlane((unsigned)(bytes < 0 ? 0 : bytes > 0xffffffffll ? 0xffffffffll : bytes));
-  return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, nb, 0x00020000);
-}
-__device__ __forceinline__ f32x4 tm_load16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
-}
 }  // namespace mb
 
 #ifndef SPAIR_DBG
