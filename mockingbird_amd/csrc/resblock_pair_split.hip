@@ -36,6 +36,7 @@ struct ResPairSK {
   long long bstride;  // floats per batch item (T * C)
   int T, ntaps, dil;
   int NB, tiles_per_item, n_tiles, x_rows;
+  int t_begin, t_end;  // output rows [t_begin, t_end) of every item belong to this launch (the window still reads the whole item)
   int nbuf;           // LDS buffers of the x-window chunk ring (1 = single buffer: one chunk per tile, refilled while phase 2 runs)
   float slope, out_scale;
   float us1, us2;     // 2^-s of conv1 / conv2 (mb_resblock_pair_split_pack)
@@ -153,7 +154,7 @@ void resblock_pair_split_kernel(ResPairSK a) {
     auto issue_x = [&](int q, f32x4 (&vx)[LBX]) __attribute__((always_inline)) {
       if (SPAIR_DBG & 8) return;
       const int tile = (int)blockIdx.x + (q / NCH) * (int)gridDim.x, c = q % NCH;
-      const int b = tile / a.tiles_per_item, t0 = (tile - b * a.tiles_per_item) * a.NB;
+      const int b = tile / a.tiles_per_item, t0 = a.t_begin + (tile - b * a.tiles_per_item) * a.NB;
       const int Tb = spair_valid_len(a, b);  // beyond: this item's zero padding
       const int tx0 = t0 - p2 - p1;
       const float* xb = a.x + (long long)b * a.bstride + c * CK;
@@ -191,9 +192,9 @@ void resblock_pair_split_kernel(ResPairSK a) {
     struct WTile { const float* xb; float* yb; int ytotal; };
     auto wtile = [&](int it) __attribute__((always_inline)) {
       const int tile = (int)blockIdx.x + it * (int)gridDim.x;
-      const int b = tile / a.tiles_per_item, t0 = (tile - b * a.tiles_per_item) * a.NB;
+      const int b = tile / a.tiles_per_item, t0 = a.t_begin + (tile - b * a.tiles_per_item) * a.NB;
       const int Tb = spair_valid_len(a, b);
-      const int rows = max(0, min(a.NB, Tb - t0));
+      const int rows = max(0, min(a.NB, min(Tb, a.t_end) - t0));
       return WTile{a.x + (long long)b * a.bstride + (long long)t0 * C, a.y + (long long)b * a.bstride + (long long)t0 * C, rows * YPR};
     };
     auto issue_w = [&](int it, int part, f32x4 (&rx)[WB], f32x4 (&ry)[WB]) __attribute__((always_inline)) {
@@ -355,7 +356,7 @@ void resblock_pair_split_kernel(ResPairSK a) {
   const float slope = a.slope, us1 = a.us1, us2 = a.us2;
   for (int it = 0; it < my_tiles; ++it) {
     const int tile = (int)blockIdx.x + it * (int)gridDim.x;
-    const int t0 = (tile % a.tiles_per_item) * a.NB;
+    const int t0 = a.t_begin + (tile % a.tiles_per_item) * a.NB;
     const int Tb = spair_valid_len(a, tile / a.tiles_per_item);
     // ---------------- phase 1: h = lrelu(conv1(lrelu(x)) 2^-s + b1) ----------------
 #ifdef SPAIR_TRACE_BUILD
@@ -486,7 +487,8 @@ static int launch_spair(ResPairSK k, int batch, hipStream_t s) {
   using G = SPairGeom<C, MT, WN, NTW>;
   k.NB = G::N1 - (k.ntaps - 1);
   k.x_rows = G::N1 + (k.ntaps - 1) * k.dil;
-  k.tiles_per_item = cdiv(k.T, k.NB);
+  if (k.t_end <= 0) k.t_end = k.T;
+  k.tiles_per_item = cdiv(k.t_end - k.t_begin, k.NB);
   k.n_tiles = k.tiles_per_item * batch;
   int nbuf = spair_min_nbuf<G>();
   if (nbuf > 1)  // as many x-chunk buffers as fit (<= 4): the support waves run nbuf - 1 chunks ahead of the MMA waves
@@ -635,12 +637,35 @@ extern "C" int mb_resblock_pair_split(const mb_resblock_pair_split_args* a, mb_s
     const long long tiles = (long long)cdiv(a->t, nb) * a->batch;
     return ((tiles + cus - 1) / cus) * (long long)n1;
   };
+  // ... or both: when the larger tile leaves a last round mostly empty (32 x 1000 rows at 256 channels: 352 tiles = 1.4 rounds), the
+  // whole rounds run on the larger tile and the remaining rows of every item on the smaller one (a second launch on rows
+  // [j NB_a, T)): 96 + 64 rows of makespan instead of 2 x 96.  OFF by default: measured on the HiFi-GAN forward it loses (8.29 against
+  // 8.16 ms) -- the generator's parallel ResBlock chains already fill each other's last rounds from their branch streams (gan.hip) and
+  // the cut adds six launches of small tiles; a caller that runs one chain at a time can ask for it (MBHIP_DIAG=spair_split=1).
+  const int split_mode = force == 0 ? diag_int("spair_split", 0) : 0;  // 0 = never, 1 = where the makespan says so, 2 = wherever the shapes allow it (tests)
+  const bool may_split = split_mode != 0;
 #define SP_PICK2(GA, YA, GB, YB)                                                                          \
   do {                                                                                                    \
     const bool fa = spair_fits<GA>(ks, dl, YA), fb = spair_fits<GB>(ks, dl, YB);                          \
     MB_REQUIRE(fa || fb, "resblock_pair_split: no instance fits LDS");                                     \
-    const bool pick_b = fb && (!fa || force == 2 || (force != 1 && cost(GB::N1) < cost(GA::N1)));          \
     constexpr int nl_ = GA::CH <= 64 ? SPAIR_NL_NARROW : 4;                                               \
+    if (fa && fb && may_split && GB::N1 < GA::N1) {                                                        \
+      const int nb_a = GA::N1 - (ks - 1), nb_b = GB::N1 - (ks - 1);                                        \
+      const long long tiles_a = (long long)cdiv(a->t, nb_a) * a->batch, full = tiles_a / cus;              \
+      if (full >= 1 && tiles_a % cus != 0 && (full * cus) % a->batch == 0) {                               \
+        const int j = (int)(full * cus / a->batch), rest = a->t - j * nb_a;                                \
+        const long long tiles_b = rest > 0 ? (long long)cdiv(rest, nb_b) * a->batch : 0;                   \
+        const long long c_split = full * GA::N1 + ((tiles_b + cus - 1) / cus) * (GB::N1 + GB::N1 / 8);     \
+        if (rest > 0 && (split_mode == 2 || c_split < std::min(cost(GA::N1), cost(GB::N1)))) {                                  \
+          k.t_begin = 0; k.t_end = j * nb_a;                                                               \
+          const int r = launch_spair<GA::CH, GA::MT, GA::WN, GA::NTW, YA, nl_>(k, a->batch, s);            \
+          if (r) return r;                                                                                 \
+          k.t_begin = j * nb_a; k.t_end = a->t;                                                            \
+          return launch_spair<GB::CH, GB::MT, GB::WN, GB::NTW, YB, nl_>(k, a->batch, s);                   \
+        }                                                                                                  \
+      }                                                                                                    \
+    }                                                                                                      \
+    const bool pick_b = fb && (!fa || force == 2 || (force != 1 && cost(GB::N1) < cost(GA::N1)));          \
     if (pick_b) return launch_spair<GB::CH, GB::MT, GB::WN, GB::NTW, YB, nl_>(k, a->batch, s);        \
     return launch_spair<GA::CH, GA::MT, GA::WN, GA::NTW, YA, nl_>(k, a->batch, s);                    \
   } while (0)

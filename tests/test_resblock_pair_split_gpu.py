@@ -78,6 +78,30 @@ def test_both_tile_candidates(cuda, lib, monkeypatch, tile, C, T, k, d):
     assert torch.equal(y, y0)
 
 
+@pytest.mark.parametrize("B,C,T,k,d", [(32, 128, 1100, 3, 1), (64, 32, 1100, 7, 3), (32, 256, 1000, 11, 5)])
+def test_whole_rounds_on_the_larger_tile_rest_on_the_smaller(cuda, lib, monkeypatch, B, C, T, k, d):
+    """A launch whose tiles leave the last round of persistent workgroups mostly empty is cut in two: rows [0, j NB_a) of every item on the
+    larger tile (whole rounds), the rest on the smaller one (MBHIP_DIAG=spair_split=2 forces the cut wherever the shapes allow it,
+    =0 forbids it).  Same sums per position: bit-identical to the single launch, ragged lengths and an accumulating launch included."""
+    x = _rand(B, C, T, seed=5)
+    w1, b1, w2, b2 = _weights(C, k, seed=21)
+    valid = [T - 7 * (b % 5) for b in range(B)]
+    acc = _rand(B, C, T, seed=6)
+    outs = []
+    for mode in ("2", "0"):
+        monkeypatch.setenv("MBHIP_DIAG", f"spair_split={mode}")
+        y = hiputil.resblock_pair_split_hip(x, w1, b1, w2, b2, dilation=d)
+        yr = hiputil.resblock_pair_split_hip(x, w1, b1, w2, b2, dilation=d, valid=valid, out_scale=0.5, accumulate_into=acc)
+        outs.append((y, yr))
+    monkeypatch.delenv("MBHIP_DIAG")
+    assert torch.equal(outs[0][0], outs[1][0])
+    for b in range(B):
+        assert torch.equal(outs[0][1][b, :, :valid[b]], outs[1][1][b, :, :valid[b]])
+    ref = _ref(x[:4], w1, b1, w2, b2, d, 0.1)
+    rms = float(ref.pow(2).mean().sqrt())
+    assert float((outs[0][0][:4].double() - ref).abs().max()) <= 1e-5 * max(1.0, rms)
+
+
 def test_scale_and_accumulate(cuda, lib):
     """Last unit of a ResBlock: y = acc + (x + conv2(...)) / num_kernels  (models.py:141-145)."""
     B, C, T, k, d = 2, 64, 900, 7, 5
