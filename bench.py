@@ -106,7 +106,7 @@ def _median(xs):
     return xs[len(xs) // 2]
 
 
-KERNEL_STATS_CSV = "r05_bench_kernel_stats.csv"   # rocprofv3 --kernel-trace --stats summary of this command, committed per round
+KERNEL_STATS_CSV = "r06_bench_kernel_stats.csv"   # rocprofv3 --kernel-trace --stats summary of this command, committed per round
 CPU_BASELINE_THREADS = 8   # one policy for every cpu_baseline leg: min(host threads, 8) -- the reference's eager ops on small batches get
                            # SLOWER beyond that (WaveRNN's 23-row GEMVs 3x at 128 threads, HiFi-GAN 1 x (80,200) 4.5x); `cores` states it
 

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 acc = {}
 for f in glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_gan_*.json")):
     for k, cs in json.load(open(f)).items():
-        if any(n in k for n in ("resblock_pair", "resblock_stage", "conv1d_f16", "convt_f16", "conv_c1_f16", "conv_pw_f16", "cm_f32_to_tm_f16", "conv1d_split", "resblock_stage_f32", "conv1d_mfma", "conv_split_tm", "f32_transpose")):
+        if any(n in k for n in ("resblock_pair", "resblock_stage", "conv1d_f16", "convt_f16", "conv_c1_f16", "conv_pw_f16", "cm_f32_to_tm_f16", "conv1d_split", "resblock_stage_f32", "conv1d_mfma", "conv_split_tm", "conv_c1_tm", "f32_transpose")):
             acc.setdefault(k, {}).update({c: v["mean_per_dispatch"] for c, v in cs.items()})
             acc[k]["dispatches"] = max(acc[k].get("dispatches", 0), max(v["dispatches"] for v in cs.values()))
 out = {"source": "rocprofv3 --kernel-trace --pmc <group> (4 separate passes), python tools/gan_run.py hifigan %s 32 200 3; " % DT +

@@ -18,7 +18,7 @@ WHAT = {
                 {"resblock_pair": ["resblock_pair"], "resblock_stage": ["resblock_stage"], "conv1d_f16": ["conv1d_f16"]}),
     "hifigan_f32": ("tools/gan_run.py hifigan f32 32 200 (bench object hifigan: fp32 storage, error-compensated fp16 MFMA)",
                     {"resblock_stage_f32": ["resblock_stage_f32"], "conv1d_split": ["conv1d_split"], "conv1d_mfma": ["conv1d_mfma"],
-                     "resblock_pair_split": ["resblock_pair_split"], "conv_split_tm": ["conv_split_tm"], "f32_transpose": ["f32_transpose"]}),  # round 6: the time-major plan
+                     "resblock_pair_split": ["resblock_pair_split"], "conv_split_tm": ["conv_split_tm"], "conv_c1_tm": ["conv_c1_tm"], "f32_transpose": ["f32_transpose"]}),  # round 6: the time-major plan
     "fregan": ("tools/gan_run.py fregan f16 8 3000 (bench object fregan_f16)",
                {"resblock_pair": ["resblock_pair"], "resblock_stage": ["resblock_stage"], "conv1d_f16": ["conv1d_f16"],
                 "add_inplace": ["add_inplace_f16"]}),
