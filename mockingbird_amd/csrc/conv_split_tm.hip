@@ -47,6 +47,9 @@ struct ConvTmK {
 constexpr int CTM_NL = 4;  // support waves
 // diagnostics builds only (tools/build_variant.sh ... -DCTM_DBG=<bits>; results are wrong, timings isolate one cost each):
 // 1 = no global stores in the write-out, 2 = no LDS read of the result tile, 4 = window pieces not laid down, 8 = no window loads
+#ifndef CTM_DUAL
+#define CTM_DUAL 1
+#endif
 #ifndef CTM_DBG
 #define CTM_DBG 0
 #endif
@@ -318,7 +321,8 @@ void conv_split_tm_kernel(ConvTmK a) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) ring[s][u][i][p] = wp[i][((size_t)((s % NFT) * KB + u) * 2 + p) * 64];
   int ftn = TD % NFT;  // next flat tap to prefetch
-  f32x16 acc[MT][NTW];
+  constexpr bool DUAL = MT == 1 && CTM_DUAL != 0;  // split_tm.h: a second accumulator set instead of the third weight image
+  f32x16 acc[MT][NTW], acl[MT][NTW];
   const h16 k2m11 = (h16)(1.f / 2048.f);
   const int lrow = wn * (NTW * 32) + (lane & 31);
   const int lcol = (lane >> 5) * 8;
@@ -331,7 +335,7 @@ void conv_split_tm_kernel(ConvTmK a) {
 #pragma unroll
       for (int n = 0; n < NTW; ++n)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc[i][n][q] = 0.f;
+        for (int q = 0; q < 16; ++q) { acc[i][n][q] = 0.f; if (DUAL) acl[i][n][q] = 0.f; }
     // NCH is even and ntaps odd: the ring slot of a chunk's first tap alternates 0, 1 and a tile always starts on slot 0
 #define CT_XB(JOB, CJ) (xs + (((JOB)) % a.nbuf) * JC * 2 * XPL + (CJ) * 2 * XPL + lrow * CKP + lcol)
     for (int c = 0; c < NJT; c += 2) {
@@ -370,7 +374,7 @@ void conv_split_tm_kernel(ConvTmK a) {
           const f32x4 bq = *reinterpret_cast<const f32x4*>(bs + co0);
           f32x4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaf(acc[i][n][4 * g + e], us, bq[e]);
+          for (int e = 0; e < 4; ++e) v[e] = fmaf(DUAL ? fmaf(acl[i][n][4 * g + e], 1.f / 2048.f, acc[i][n][4 * g + e]) : acc[i][n][4 * g + e], us, bq[e]);
           *reinterpret_cast<f32x4*>(ys + row * MGF + co0) = v;
         }
       }

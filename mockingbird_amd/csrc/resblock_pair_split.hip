@@ -48,6 +48,9 @@ struct ResPairSK {
 
 // NL = support waves per workgroup (beside the 4 MMA waves): 4 (one per SIMD, 256 registers each) or, where the MMA waves need <= 168
 // registers (<= 64 channels), 8 (two per SIMD) -- at those widths the support waves' instruction stream, not the MFMAs, sets the pace
+#ifndef SPAIR_DUAL
+#define SPAIR_DUAL 1  // (A/B builds: 0 = the third weight image made in registers for every instance)
+#endif
 #ifndef SPAIR_NL_NARROW
 #define SPAIR_NL_NARROW 8  // (A/B builds: 4)
 #endif
@@ -338,15 +341,17 @@ void resblock_pair_split_kernel(ResPairSK a) {
         for (int p = 0; p < 2; ++p) ring[s][u][i][p] = wp[i][((size_t)(s * KB + u) * 2 + p) * 64];
   int ftn = TD;  // next flat tap to prefetch
 
-  f32x16 acc[MT][NTW];
+  constexpr bool DUAL = MT == 1 && SPAIR_DUAL != 0;  // split_tm.h: a second accumulator set instead of the third weight image
+  f32x16 acc[MT][NTW], acl[MT][NTW];
   auto zero_acc = [&]() {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int n = 0; n < NTW; ++n)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc[i][n][q] = 0.f;
+        for (int q = 0; q < 16; ++q) { acc[i][n][q] = 0.f; if (DUAL) acl[i][n][q] = 0.f; }
   };
+  auto acc_at = [&](int i, int n, int q) __attribute__((always_inline)) { return DUAL ? fmaf(acl[i][n][q], 1.f / 2048.f, acc[i][n][q]) : acc[i][n][q]; };
   const h16 k2m11 = (h16)(1.f / 2048.f);
 
 
@@ -400,7 +405,7 @@ void resblock_pair_split_kernel(ResPairSK a) {
             float hv[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              float v = fmaf(acc[i][n][4 * g + e], us1, bq[e]);
+              float v = fmaf(acc_at(i, n, 4 * g + e), us1, bq[e]);
               v = fmaxf(v, v * slope);
               hv[e] = inside ? v : 0.f;
             }
@@ -442,7 +447,7 @@ void resblock_pair_split_kernel(ResPairSK a) {
             const f32x4 bq = *reinterpret_cast<const f32x4*>(bs + C + co0);
             f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaf(acc[i][n][4 * g + e], us2, bq[e]);
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(acc_at(i, n, 4 * g + e), us2, bq[e]);
             *reinterpret_cast<f32x4*>(ys + row * CPF + co0) = v;
           }
         }

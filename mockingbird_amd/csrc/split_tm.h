@@ -1,7 +1,10 @@
 // The product loop shared by the time-major split kernels (resblock_pair_split.hip, conv_split_tm.hip): error-compensated fp16 MFMA
 // products of a tap over LDS-resident hi / scaled-lo B planes and a register ring of {hi, lo} weight fragments.
 // The including kernel defines, with these names: constexpr KB, MT, NTW, TD (= 2); h16x8 ring[TD][KB][MT][2]; const h16x8* wp[MT];
-// int ftn; const int NFT, ntaps; f32x16 acc[MT][NTW]; const h16 k2m11 = 2^-11; and SPAIR_DBG (0 in the product).
+// int ftn; const int NFT, ntaps; f32x16 acc[MT][NTW], acl[MT][NTW]; constexpr bool DUAL; const h16 k2m11 = 2^-11; and SPAIR_DBG (0 in the
+// product).  DUAL (instances with one M tile per wave, where the registers allow a second accumulator set): the product of the scaled
+// low activation half runs on the plain high weight fragment into acl, and the epilogue adds 2^-11 acl -- the wave no longer makes the
+// third weight image (4 v_pk_mul_f16 per k-step beside 6-12 MFMAs).
 #pragma once
 #include "common.h"
 
@@ -33,7 +36,7 @@ typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
         bhn_[n] = *reinterpret_cast<const h16x8*>(rp_ + n * 32 * (RS));                            \
         bln_[n] = *reinterpret_cast<const h16x8*>(rp_ + (LO_) + n * 32 * (RS));                    \
       }                                                                                            \
-      _Pragma("unroll") for (int i = 0; i < MT; ++i) ws_[i] = ring[S][u][i][0] * k2m11;            \
+      if (!DUAL) { _Pragma("unroll") for (int i = 0; i < MT; ++i) ws_[i] = ring[S][u][i][0] * k2m11; } \
       if (SPAIR_DBG & 32) {                                                                        \
         _Pragma("unroll") for (int i = 0; i < MT; ++i)                                             \
           _Pragma("unroll") for (int n = 0; n < NTW; ++n) {                                        \
@@ -45,8 +48,10 @@ typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
         _Pragma("unroll") for (int n = 0; n < NTW; ++n)                                            \
           acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[S][u][i][1], bhc_[n], acc[i][n], 0, 0, 0); \
       _Pragma("unroll") for (int i = 0; i < MT; ++i)                                               \
-        _Pragma("unroll") for (int n = 0; n < NTW; ++n)                                            \
-          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ws_[i], blc_[n], acc[i][n], 0, 0, 0); \
+        _Pragma("unroll") for (int n = 0; n < NTW; ++n) {                                          \
+          if (DUAL) acl[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[S][u][i][0], blc_[n], acl[i][n], 0, 0, 0); \
+          else acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ws_[i], blc_[n], acc[i][n], 0, 0, 0); \
+        }                                                                                          \
       _Pragma("unroll") for (int i = 0; i < MT; ++i)                                               \
         _Pragma("unroll") for (int n = 0; n < NTW; ++n)                                            \
           acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[S][u][i][0], bhc_[n], acc[i][n], 0, 0, 0); \
