@@ -64,6 +64,14 @@ int diag_int(const char* key, int absent = 0);
 // value of a documented path switch (plain MBHIP_* variable) as an int; `absent` when unset
 int env_int(const char* name, int absent);
 
+// Side streams of the library: ONE process-wide pool of three non-blocking streams per device, created on first use and never
+// destroyed.  HIP maps streams onto 4 hardware queues by default; streams beyond that SHARE a queue, and an event wait queued for one of
+// them then holds back every stream behind it in that queue (a WaveRNN handle used to create 8 streams, every loop handle one, a GAN
+// handle three: a GAN forward late in bench.py's process ran 9.4 instead of 8.4 ms).  Handles borrow from the pool: the resident loops
+// run on stream 0, the parallel ResBlock chains of a GAN stage on 0..2; two handles on one pool stream are merely ordered.
+int pool_stream(int i, hipStream_t* out);
+constexpr int POOL_STREAMS = 3;
+
 // the device word MBHIP_CONV_RANGE_CHECK=1 counts out-of-range staged values in (conv1d.hip; null when the check is off)
 unsigned* conv_range_word();
 

@@ -1,5 +1,6 @@
 // Error reporting, device buffers and ABI version for libmbhip.
 #include <utility>
+#include <mutex>
 #include "common.h"
 #include <cstdlib>
 
@@ -54,6 +55,18 @@ int diag_int(const char* key, int absent) {
 int env_int(const char* name, int absent) {
   const char* e = getenv(name);
   return e ? atoi(e) : absent;
+}
+
+int pool_stream(int i, hipStream_t* out) {
+  static std::mutex mu;
+  static hipStream_t pool[64][POOL_STREAMS] = {};
+  int dev = 0;
+  MB_HIP(hipGetDevice(&dev));
+  MB_REQUIRE(out && i >= 0 && i < POOL_STREAMS && dev >= 0 && dev < 64, "pool_stream: stream %d of device %d", i, dev);
+  std::lock_guard<std::mutex> lock(mu);
+  if (!pool[dev][i]) MB_HIP(hipStreamCreateWithFlags(&pool[dev][i], hipStreamNonBlocking));
+  *out = pool[dev][i];
+  return MB_OK;
 }
 
 int DevBuf::alloc(size_t count) {

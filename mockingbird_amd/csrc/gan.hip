@@ -404,15 +404,12 @@ extern "C" int mb_gan_create_ex(const mb_gan_config* cfg, const float* const* h_
         e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
         if (e == hipSuccess) g->ev_last.push_back(ev);
       }
-      // the chains should FINISH in the order of the sum (gan_forward_tm): the first of the side streams gets the highest priority the
-      // device offers, the last the lowest
-      int pr_least = 0, pr_greatest = 0;
-      if (e == hipSuccess) e = hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
+      // the chains borrow the library's pool streams (common.h: a handle with streams of its own oversubscribes the 4 hardware queues
+      // as soon as a process holds a few handles); more ResBlocks than pool streams: the extra chains share
       for (int j = 0; j < cfg->num_kernels && e == hipSuccess; ++j) {
         hipStream_t st = nullptr;
-        const int pr = j == 0 ? pr_greatest : j + 1 == cfg->num_kernels ? pr_least : (pr_least + pr_greatest) / 2;
-        e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, diag_int("gan_fork_flat") ? 0 : pr);
-        if (e == hipSuccess) g->side.push_back(st);
+        if (pool_stream(j % POOL_STREAMS, &st) != MB_OK) e = hipErrorUnknown;
+        else g->side.push_back(st);
       }
       if (e != hipSuccess) { mb_gan_destroy(g); return hip_fail(e, "gan_create: branch streams", __FILE__, __LINE__); }
     }
@@ -561,7 +558,7 @@ extern "C" void mb_gan_destroy(mb_gan* g) {
   for (auto& c : g->convs) { c.w.release(); c.b.release(); }
   for (auto& p : g->pairs) p.release();
   for (auto& p : g->spairs) p.w.release();
-  for (auto st : g->side) (void)hipStreamDestroy(st);
+  g->side.clear();  // (borrowed from the pool)
   for (auto ev : g->ev_last) (void)hipEventDestroy(ev);
   if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
   for (auto& t : g->tmc) { t.w.release(); t.bias.release(); t.w1.release(); }

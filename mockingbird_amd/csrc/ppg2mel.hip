@@ -229,7 +229,7 @@ extern "C" void mb_ppg2mel_destroy(mb_ppg2mel* p) {
   if (p->h_abort) (void)hipHostFree(p->h_abort);
   hipEvent_t evs[] = {p->ev_flags[0], p->ev_flags[1], p->ev_in, p->ev_t0, p->ev_t1, p->ev_res};
   for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
-  if (p->loop_stream) (void)hipStreamDestroy(p->loop_stream);
+  p->loop_stream = nullptr;  // (borrowed from the pool, common.h)
   delete p;
 }
 
@@ -436,7 +436,7 @@ extern "C" int mb_ppg2mel_create(const mb_ppg2mel_config* cfg, const float* cons
       }
     }
     if (!rc && (hipHostMalloc((void**)&p->h_flags, sizeof(int) * 16) != hipSuccess ||
-                hipStreamCreateWithFlags(&p->loop_stream, hipStreamNonBlocking) != hipSuccess ||
+                pool_stream(0, &p->loop_stream) != MB_OK ||
                 hipEventCreateWithFlags(&p->ev_in, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreate(&p->ev_t0) != hipSuccess || hipEventCreate(&p->ev_t1) != hipSuccess ||
                 hipEventCreateWithFlags(&p->ev_flags[0], hipEventDisableTiming) != hipSuccess ||

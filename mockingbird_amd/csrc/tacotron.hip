@@ -1874,7 +1874,7 @@ extern "C" int mb_taco_create(const mb_taco_config* cfg, const float* const* hw,
       RC(pack_rowtile16(rows.data(), 4 * H, H, 4, l ? &t->i_l2x : &t->i_l1x));
     }
     if (!rc && (hipHostMalloc((void**)&t->h_flags, sizeof(int) * 16) != hipSuccess ||
-                hipStreamCreateWithFlags(&t->loop_stream, hipStreamNonBlocking) != hipSuccess ||
+                pool_stream(0, &t->loop_stream) != MB_OK ||
                 hipEventCreateWithFlags(&t->ev_in, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreate(&t->ev_t0) != hipSuccess || hipEventCreate(&t->ev_t1) != hipSuccess ||
                 hipEventCreate(&t->ev_p0) != hipSuccess || hipEventCreate(&t->ev_p1) != hipSuccess ||
@@ -1939,7 +1939,7 @@ extern "C" void mb_taco_destroy(mb_taco* t) {
   if (t->ev_t1) (void)hipEventDestroy(t->ev_t1);
   if (t->ev_p0) (void)hipEventDestroy(t->ev_p0);
   if (t->ev_p1) (void)hipEventDestroy(t->ev_p1);
-  if (t->loop_stream) (void)hipStreamDestroy(t->loop_stream);
+  t->loop_stream = nullptr;  // (borrowed from the pool, common.h)
   t->post.release(); t->post_proj.release(); t->post_proj_tm.release(); t->enc.release();
   t->enc_fc1.release(); t->enc_fc2.release(); t->enc_proj.release();
   for (mb_taco::Img16* im : {&t->i_l1x, &t->i_l2x, &t->i_l1hh, &t->i_l2hh, &t->i_rin, &t->i_pre, &t->i_stopc, &t->i_mel, &t->i_fc1, &t->i_stop}) im->w.release();

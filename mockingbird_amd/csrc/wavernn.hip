@@ -593,10 +593,8 @@ extern "C" int mb_wavernn_create(const mb_wavernn_config* cfg, const float* cons
     RC(w->b_fc3.upload(b3, C));
   }
 #undef RC
-  for (int l = 0; l < mb_wavernn::MAX_LANES && !rc; ++l) {
-    if (hipStreamCreateWithFlags(&w->lane_stream[l], hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&w->lane_ev[l], hipEventDisableTiming) != hipSuccess) rc = MB_EHIP;
-  }
+  if (!rc) rc = pool_stream(0, &w->lane_stream[0]);  // (one lane: the loop runs on the library's pool stream 0, common.h)
+  if (!rc && hipEventCreateWithFlags(&w->lane_ev[0], hipEventDisableTiming) != hipSuccess) rc = MB_EHIP;
   w->loop_stream = w->lane_stream[0];
   if (!rc && hipEventCreateWithFlags(&w->ev_cond, hipEventDisableTiming) != hipSuccess) rc = MB_EHIP;
   if (!rc) {
@@ -636,7 +634,7 @@ extern "C" void mb_wavernn_destroy(mb_wavernn* w) {
   if (w->ev_cond) (void)hipEventDestroy(w->ev_cond);
   for (int l = 0; l < mb_wavernn::MAX_LANES; ++l) {
     if (w->lane_ev[l]) (void)hipEventDestroy(w->lane_ev[l]);
-    if (w->lane_stream[l]) (void)hipStreamDestroy(w->lane_stream[l]);
+    w->lane_stream[l] = nullptr;  // (borrowed from the pool)
   }
   delete w;
 }
