@@ -326,3 +326,47 @@ def test_infer_waveform_batch_ragged_facade(cuda, lib, tmp_path):
     for wv, pc in zip(wavs, pcm):
         ref = owv.encode_16bits(owv.peak_normalize(np.concatenate([wv, np.zeros(2400, np.float32)]), np.float32(0.97)))
         assert pc.dtype == np.int16 and np.array_equal(pc, ref)
+
+
+def test_handles_on_the_shared_pool_streams_from_two_threads(cuda, lib):
+    """Every handle borrows its side streams from ONE pool per device (csrc/common.h pool_stream): two fp32 generators whose forked
+    ResBlock chains land on the same three streams, driven from two host threads on two caller streams at once, and a WaveRNN loop
+    on pool stream 0 between them, must each give exactly what they give alone (sharing a stream only orders the work)."""
+    import threading
+    from mockingbird_amd.vocoder.gan import GanGenerator
+    from mockingbird_amd.vocoder.wavernn.inference import WaveRNNDevice
+    h = synth.small(synth.HIFIGAN_16K, 128)
+    gens = [GanGenerator(h, synth.gan_state(h, "hifigan", seed=s)["generator"], 0, dtype="f32") for s in (3, 4)]
+    mels = [torch.from_numpy(synth.mel_input(40, 3, seed=10 + i)).cuda() for i in range(2)]
+    w = WaveRNNDevice(synth.wavernn_state(seed=1)["model_state"])
+    wmel = torch.from_numpy(synth.wavernn_mel(30, seed=100) / 4.0).cuda()
+    alone = [g(m).cpu() for g, m in zip(gens, mels)]
+    w_alone = w.generate_samples(wmel, True, 2000, 200, seed=7).cpu()
+    torch.cuda.synchronize()
+    outs, errs = [None, None, None], []
+
+    def run_gan(i):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(6):
+                    y = gens[i](mels[i])
+                st.synchronize()
+            outs[i] = y.cpu()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    def run_wrn():
+        try:
+            for _ in range(3):
+                y = w.generate_samples(wmel, True, 2000, 200, seed=7)
+            outs[2] = y.cpu()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=run_gan, args=(0,)), threading.Thread(target=run_gan, args=(1,)), threading.Thread(target=run_wrn)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    assert torch.equal(outs[0], alone[0]) and torch.equal(outs[1], alone[1])
+    assert torch.equal(outs[2], w_alone)
