@@ -753,6 +753,17 @@ size_t mb_wave_workspace_bytes(void);
 int mb_wave_pack_pcm16(const void* d_wav, int dtype, long long n, int mode, int16_t* d_pcm,
                        void* d_workspace, size_t workspace_bytes, mb_stream_t stream);
 
+/* The same tail for a BATCH of fp32 waveforms in two launches (pipeline.gen_wavs: gen_voice.py:30-41 per request -- cut at the sentence
+   boundaries, silence behind every sentence, peak normalisation over the request, PCM).  d_pieces: n_pieces x {source offset in d_wav (< 0: a piece of zeros),
+   destination offset in d_out, length, item} as four int64 each (elements); d_out (out_elems floats, or int16 with a pcm_mode) is zeroed
+   here, so the gaps need no pieces.  normalize_target <= 0 or NaN: no normalisation; pcm_mode -1: float out, else MB_PCM16_SNDFILE /
+   MB_PCM16_ENCODE16 (save_wav needs the peak of the normalised signal: one-waveform calls).  Every item's samples are bit for bit those of
+   mb_wave_peak_normalize + mb_wave_pack_pcm16 on its own waveform. */
+size_t mb_wave_finish_batch_workspace_bytes(int n_items);
+int mb_wave_finish_batch(const float* d_wav, const long long* d_pieces, int n_pieces, int n_items, long long out_elems,
+                         double normalize_target, int pcm_mode, void* d_out, void* d_workspace, size_t workspace_bytes,
+                         mb_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -234,6 +234,9 @@ SIGNATURES = {
                                          C.c_void_p]),
     "mb_wave_pack_pcm16": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_size_t, C.c_void_p]),
+    "mb_wave_finish_batch_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "mb_wave_finish_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_size_t, C.c_void_p]),
     "mb_wavernn_create": (C.c_int, [C.POINTER(WaveRNNConfig), _PP, C.c_int, _PP]),
     "mb_wavernn_destroy": (None, [C.c_void_p]),
     "mb_wavernn_plan_generate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -86,6 +86,52 @@ __global__ __launch_bounds__(256) void wave_pack_pcm16_kernel(const T* __restric
   }
 }
 
+
+// ---- the same tail for a BATCH of waveforms in two launches (gen_voice.py:30-41 per request: sentence breaks, peak normalisation, PCM) ----
+// piece = {source offset (< 0: zeros), destination offset, length, item} in elements; the destination buffer is zeroed by the caller side of the
+// ABI (mb_wave_finish_batch does it), so the gaps behind the sentences need no writes.  One IEEE operation per numpy operation, in
+// the same order as the one-waveform kernels above: an item's result is bit for bit what insert_breaks -> peak_normalize -> pack give.
+struct WavePiece { long long src, dst, len; long long item; };
+
+__global__ __launch_bounds__(256) void wave_batch_absmax_kernel(const float* __restrict__ x, const WavePiece* __restrict__ pieces,
+                                                                int blocks_per_piece, unsigned* __restrict__ slots) {
+  const WavePiece p = pieces[blockIdx.x / blocks_per_piece];
+  const int sub = blockIdx.x % blocks_per_piece;
+  unsigned m = 0;
+  if (p.src < 0) return;  // a gap
+  for (long long i = (long long)sub * 256 + threadIdx.x; i < p.len; i += (long long)blocks_per_piece * 256) {
+    const unsigned b = __builtin_bit_cast(unsigned, x[p.src + i]) & 0x7fffffffu;
+    m = b > m ? b : m;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned o = (unsigned)__shfl_xor((int)m, off);
+    m = o > m ? o : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(slots + p.item, m);
+}
+
+template <int MODE>  // -1: float out
+__global__ __launch_bounds__(256) void wave_batch_write_kernel(const float* __restrict__ x, const WavePiece* __restrict__ pieces,
+                                                               int blocks_per_piece, const unsigned* __restrict__ slots, int normalize,
+                                                               float target, float* __restrict__ yf, short* __restrict__ ys) {
+  const WavePiece p = pieces[blockIdx.x / blocks_per_piece];
+  const int sub = blockIdx.x % blocks_per_piece;
+  const float m = normalize ? __builtin_bit_cast(float, slots[p.item]) : 1.f;
+  for (long long i = (long long)sub * 256 + threadIdx.x; i < p.len; i += (long long)blocks_per_piece * 256) {
+    float v = p.src < 0 ? 0.f : x[p.src + i];  // (src < 0: a gap of zeros -- 0 / max * target, NaN for an all-zero item as in numpy)
+    if (normalize) {
+      const float q = v / m;  // numpy: (wav / max) * 0.97, two roundings
+      v = q * target;
+    }
+    if (MODE < 0) { yf[p.dst + i] = v; continue; }
+    const float w = v * 32768.f;
+    int q;
+    if (MODE == MB_PCM16_SNDFILE) q = w >= 32767.f ? 32767 : (w <= -32768.f ? -32768 : __float2int_rn(w));
+    else { const float c = w < -32768.f ? -32768.f : (w > 32767.f ? 32767.f : w); q = (int)c; }
+    ys[p.dst + i] = (short)q;
+  }
+}
+
 static int wave_grid(long long n) { return (int)std::min<long long>((n + 255) / 256, 256 * 8); }
 
 template <typename T>
@@ -159,4 +205,38 @@ extern "C" int mb_wave_pack_pcm16(const void* d_wav, int dtype, long long n, int
   }
   return dtype == MB_F32 ? pack<float>(d_wav, n, mode, d_pcm, d_workspace, (hipStream_t)stream)
                          : pack<double>(d_wav, n, mode, d_pcm, d_workspace, (hipStream_t)stream);
+}
+
+extern "C" size_t mb_wave_finish_batch_workspace_bytes(int n_items) { return n_items > 0 ? (size_t)n_items * sizeof(unsigned) : 0; }
+
+extern "C" int mb_wave_finish_batch(const float* d_wav, const long long* d_pieces, int n_pieces, int n_items, long long out_elems,
+                                    double normalize_target, int pcm_mode, void* d_out, void* d_workspace, size_t workspace_bytes,
+                                    mb_stream_t stream) {
+  MB_REQUIRE(n_pieces >= 0 && n_items >= 0 && out_elems >= 0, "wave_finish_batch: bad counts");
+  MB_REQUIRE(pcm_mode == -1 || pcm_mode == MB_PCM16_SNDFILE || pcm_mode == MB_PCM16_ENCODE16,
+             "wave_finish_batch: pcm_mode %d (-1 float out, MB_PCM16_SNDFILE, MB_PCM16_ENCODE16; save_wav takes the one-waveform calls)", pcm_mode);
+  if (out_elems == 0) return MB_OK;
+  MB_REQUIRE(d_out, "wave_finish_batch: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  MB_HIP(hipMemsetAsync(d_out, 0, (size_t)out_elems * (pcm_mode < 0 ? sizeof(float) : sizeof(short)), s));  // the gaps
+  if (n_pieces == 0) return MB_OK;
+  MB_REQUIRE(d_wav && d_pieces, "wave_finish_batch: null pointer");
+  const bool norm = normalize_target == normalize_target && normalize_target > 0.0;  // (NaN / <= 0: no normalisation)
+  if (norm) {
+    if (!d_workspace || workspace_bytes < mb_wave_finish_batch_workspace_bytes(n_items)) {
+      set_error("wave_finish_batch: workspace %zu B < required %zu B", workspace_bytes, mb_wave_finish_batch_workspace_bytes(n_items));
+      return MB_ENOMEM;
+    }
+    MB_HIP(hipMemsetAsync(d_workspace, 0, mb_wave_finish_batch_workspace_bytes(n_items), s));
+  }
+  const WavePiece* pieces = reinterpret_cast<const WavePiece*>(d_pieces);
+  const int bpp = std::max(1, std::min(64, 2048 / std::max(1, n_pieces)));  // blocks per piece: ~2048 workgroups in all
+  const dim3 g((unsigned)n_pieces * bpp), b(256);
+  unsigned* slots = reinterpret_cast<unsigned*>(d_workspace);
+  if (norm) hipLaunchKernelGGL(wave_batch_absmax_kernel, g, b, 0, s, d_wav, pieces, bpp, slots);
+  if (pcm_mode < 0) hipLaunchKernelGGL((wave_batch_write_kernel<-1>), g, b, 0, s, d_wav, pieces, bpp, slots, norm ? 1 : 0, (float)normalize_target, (float*)d_out, (short*)nullptr);
+  else if (pcm_mode == MB_PCM16_SNDFILE) hipLaunchKernelGGL((wave_batch_write_kernel<MB_PCM16_SNDFILE>), g, b, 0, s, d_wav, pieces, bpp, slots, norm ? 1 : 0, (float)normalize_target, (float*)nullptr, (short*)d_out);
+  else hipLaunchKernelGGL((wave_batch_write_kernel<MB_PCM16_ENCODE16>), g, b, 0, s, d_wav, pieces, bpp, slots, norm ? 1 : 0, (float)normalize_target, (float*)nullptr, (short*)d_out);
+  MB_HIP(hipGetLastError());
+  return MB_OK;
 }

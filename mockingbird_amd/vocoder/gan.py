@@ -101,12 +101,21 @@ class GanGenerator:
         if min(frames) <= 0:
             raise _lib.MbHipError("forward_ragged: empty mel")
         B, M, Fm = len(mels), self.cfg.num_mels, max(frames)
-        batch = torch.zeros(B, M, Fm, dtype=torch.float32, device=dev)
-        for i, m in enumerate(mels):
-            m = torch.as_tensor(m, dtype=torch.float32)
-            if m.shape[0] != M:
-                raise _lib.MbHipError(f"mel has {m.shape[0]} channels, model expects {M}")
-            batch[i, :, :frames[i]] = m.to(dev)
+        if all(not (torch.is_tensor(m) and m.is_cuda) for m in mels):  # host mels: ONE padded array, one upload
+            hb = np.zeros((B, M, Fm), dtype=np.float32)
+            for i, m in enumerate(mels):
+                m = np.asarray(m, dtype=np.float32)
+                if m.shape[0] != M:
+                    raise _lib.MbHipError(f"mel has {m.shape[0]} channels, model expects {M}")
+                hb[i, :, :frames[i]] = m
+            batch = torch.from_numpy(hb).to(dev)
+        else:
+            batch = torch.zeros(B, M, Fm, dtype=torch.float32, device=dev)
+            for i, m in enumerate(mels):
+                m = torch.as_tensor(m, dtype=torch.float32)
+                if m.shape[0] != M:
+                    raise _lib.MbHipError(f"mel has {m.shape[0]} channels, model expects {M}")
+                batch[i, :, :frames[i]] = m.to(dev)
         d_frames = torch.tensor(frames, dtype=torch.int32, device=dev)
         L = _lib.lib()
         need = L.mb_gan_workspace_bytes(self._h, B, Fm)
@@ -185,7 +194,14 @@ class GanFacade:
         order = sorted(range(len(mels)), key=lambda i: -int(np.shape(mels[i])[1]))  # similar lengths share a batch
         for c0 in range(0, len(order), max_batch):
             idx = order[c0:c0 + max_batch]
-            ys = self.generator.forward_ragged([torch.as_tensor(mels[i], dtype=torch.float32) for i in idx])
+            ys = self.generator.forward_ragged([mels[i] for i in idx])
+            if pcm16 != "save_wav" and (breaks is not None or normalize is not None or pcm16 is not None) and len(idx) > 1:
+                # the tails of the whole batch in two launches (wave.finish_batch); bit for bit the per-item calls below
+                rs = wave.finish_batch(ys, [breaks[i] for i in idx] if breaks is not None else None, break_hop,
+                                       break_sample_rate or self.output_sample_rate, break_seconds, normalize, pcm16)
+                for k, i in enumerate(idx):
+                    out[i] = rs[k] if device_out else rs[k].cpu().numpy()
+                continue
             for k, i in enumerate(idx):
                 r = ys[k].reshape(-1)
                 if breaks is not None:

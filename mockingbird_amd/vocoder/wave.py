@@ -7,6 +7,8 @@ models/vocoder/wavernn/audio.py:38-39 encode_16bits).  Here both run on the voco
 while it is still in HBM, so the D2H copy (and the multi-GPU gather, pipeline.gen_wavs) moves
 2 bytes per sample instead of 4 or 8.  fp32 and float64 tensors are processed in their own type,
 like the numpy arrays they replace.  There is no CPU path."""
+import ctypes as C
+
 import torch
 
 from .. import _lib
@@ -85,3 +87,55 @@ def insert_breaks(wav: torch.Tensor, frames_per_sentence, hop_size: int, sample_
         out[o:o + (t - s)] = wav[s:t]
         o += (t - s) + gap
     return out
+
+
+
+def finish_batch(wavs, breaks, hop_size, sample_rate, seconds=0.15, normalize=None, pcm16=None):
+    """insert_breaks -> peak_normalize_ -> pack_pcm16 for a LIST of fp32 device waveforms (views of one vocoder output are the usual
+    case) in two launches (mb_wave_finish_batch) instead of half a dozen per item; every item's samples are bit for bit those of the
+    one-waveform functions above.  breaks[i] = frames per sentence of item i (None: no breaks); normalize / pcm16 as there
+    ('save_wav' is not offered here: it needs the peak of the normalised signal).  Returns the list of result tensors (views of one
+    flat buffer): float32, or int16 with pcm16."""
+    if pcm16 is not None and pcm16 not in ("encode_16bits", "sndfile"):
+        raise ValueError(f"finish_batch: pcm16 must be 'encode_16bits' or 'sndfile', got {pcm16!r}")
+    if not wavs:
+        return []
+    dev = wavs[0].device
+    if any((not w.is_cuda) or w.dtype != torch.float32 for w in wavs):
+        raise _lib.MbHipError("finish_batch needs fp32 CUDA(HIP) tensors; there is no CPU path")
+    flat = [w.reshape(-1) for w in wavs]
+    if any(not f.is_contiguous() for f in flat):
+        flat = [f.contiguous() for f in flat]
+    base = min(f.data_ptr() for f in flat)
+    gap = int(seconds * sample_rate)
+    table, spans, o = [], [], 0
+    for i, f in enumerate(flat):
+        n, src0 = f.numel(), (f.data_ptr() - base) // 4
+        if breaks is None:
+            pieces = [(0, n)]
+        else:
+            ends, e = [], 0
+            for fr in breaks[i]:
+                e += int(fr) * int(hop_size)
+                ends.append(e)
+            starts = [0] + ends[:-1]
+            pieces = [(min(s, n), min(t, n)) for s, t in zip(starts, ends)]
+        start = o
+        for s, t in pieces:
+            if t > s:
+                table += [src0 + s, o, t - s, i]
+            o += t - s
+            if breaks is not None and gap > 0:  # the silence behind the sentence: a piece of zeros (normalised like the rest)
+                table += [-1, o, gap, i]
+                o += gap
+        spans.append((start, o))
+    out = torch.empty(o, dtype=torch.int16 if pcm16 is not None else torch.float32, device=dev)
+    L = _lib.lib()
+    n_pieces = len(table) // 4
+    d_table = torch.tensor(table if table else [0, 0, 0, 0], dtype=torch.int64).to(dev)
+    ws = torch.empty(max(256, L.mb_wave_finish_batch_workspace_bytes(len(flat))), dtype=torch.uint8, device=dev)
+    _lib.check(L.mb_wave_finish_batch(C.c_void_p(base), _lib.ptr(d_table), n_pieces, len(flat), o,
+                                      float(normalize) if normalize is not None else -1.0, -1 if pcm16 is None else _MODES[pcm16],
+                                      _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "mb_wave_finish_batch")
+    # (the views keep `out` alive; `flat` / the table must outlive the launches: same stream, released by the caching allocator in order)
+    return [out[a:b] for a, b in spans]

@@ -81,3 +81,33 @@ def test_errors(cuda, lib):
     assert torch.equal(wave.pack_pcm16(y), wave.pack_pcm16(y, "encode_16bits"))
     # all-zero waveform: the reference's 0/0 -> NaN
     assert bool(torch.isnan(wave.peak_normalize_(torch.zeros(8, device="cuda"))).all())
+
+
+@pytest.mark.parametrize("normalize,pcm16", [(0.97, "encode_16bits"), (0.97, None), (None, "sndfile"), (None, None)])
+def test_finish_batch_equals_the_one_waveform_calls(cuda, lib, normalize, pcm16):
+    """wave.finish_batch (mb_wave_finish_batch: the tails of a batch of requests in two launches) is bit for bit insert_breaks ->
+    peak_normalize_ -> pack_pcm16 per item: several sentences per item, a boundary past the end (numpy-style clipping), ragged views
+    of one vocoder output, an all-zero item (0 / 0 = NaN like numpy)."""
+    from mockingbird_amd.vocoder import wave
+    g = torch.Generator().manual_seed(11)
+    base = (torch.rand(5, 1, 9000, generator=g) * 2 - 1).cuda() * torch.tensor([0.3, 1.7, 0.01, 0.9, 0.0]).view(5, 1, 1).cuda()
+    lens = [9000, 6400, 7777, 1, 5000]
+    wavs = [base[i, :, :n] for i, n in enumerate(lens)]
+    breaks = [[10, 20, 5], [25], [40, 10], [1], [12, 8]]  # x hop 256: item 2's second boundary lies past its 7777 samples
+    for br in (breaks, None):
+        got = wave.finish_batch(wavs, br, 256, 16000, 0.15, normalize, pcm16)
+        for i, w in enumerate(wavs):
+            r = w.reshape(-1)
+            if br is not None:
+                r = wave.insert_breaks(r, br[i], 256, 16000, 0.15)
+            r = r.contiguous().clone()
+            if normalize is not None:
+                wave.peak_normalize_(r, normalize)
+            if pcm16 is not None:
+                r = wave.pack_pcm16(r, pcm16)
+            a, b = got[i].cpu(), r.cpu()
+            assert a.dtype == b.dtype and a.shape == b.shape
+            assert torch.equal(a, b) or (a.is_floating_point() and torch.equal(torch.isnan(a), torch.isnan(b))
+                                          and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)))
+    with pytest.raises(ValueError):
+        wave.finish_batch(wavs, None, 256, 16000, 0.15, 0.97, "save_wav")
