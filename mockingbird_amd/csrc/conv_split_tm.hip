@@ -321,6 +321,7 @@ void conv_split_tm_kernel(ConvTmK a) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) ring[s][u][i][p] = wp[i][((size_t)((s % NFT) * KB + u) * 2 + p) * 64];
   int ftn = TD % NFT;  // next flat tap to prefetch
+  auto sp_wrap = []() {};
   constexpr bool DUAL = MT == 1 && CTM_DUAL != 0;  // split_tm.h: a second accumulator set instead of the third weight image
   f32x16 acc[MT][NTW], acl[MT][NTW];
   const h16 k2m11 = (h16)(1.f / 2048.f);
@@ -381,6 +382,285 @@ void conv_split_tm_kernel(ConvTmK a) {
     CT_MARK(0, it, 62);
     __syncthreads();  // Y
     CT_MARK(0, it, 63);
+  }
+}
+
+
+// ---- The same conv with the WINDOW RESIDENT in LDS: one workgroup per position tile computes EVERY group of MG output channels ----
+// conv_split_tm_kernel gives a workgroup one channel group, so a conv to n_mg groups stages (loads, activates, splits) every window
+// n_mg times, and its MMA waves wait at a chunk barrier per 1-2 k MFMA cycles for support waves that need 2.4-3.4 k per chunk (a 256 ->
+// 640 upsampler: 60 k cycles per (tile, group) for 11 k of chunk bodies).  Here every chunk of the tile's window is laid down ONCE
+// ([chunk][hi | lo][rows][CKP]); the first channel group runs behind the chunk barriers as before, the others find the window in place:
+// no barriers, no support-wave work beside the write-out of the previous group's result tile.  The weight ring rolls from one group's
+// circular stream into the next one's (split_tm.h sp_wrap).  Per tile: NCH chunk barriers + 2 per group (YF, Y).
+template <int CK_, int MT_, int WN_, int NTW_>
+__global__ __launch_bounds__(64 * (4 + CTM_NL)) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void conv_split_tm_res_kernel(ConvTmK a) {
+  using G = CtmGeom<CK_, MT_, WN_, NTW_>;
+  constexpr int CK = G::CK, KB = G::KB, MT = G::MT, WN = G::WN, NTW = G::NTW, MG = G::MG, N1 = G::N1, CKP = G::CKP, MGF = G::MGF;
+  constexpr int TD = CK == 64 ? 1 : 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int XPL = a.x_rows * CKP;             // halves per plane of a chunk
+  const int NCH = a.NCH, NG = a.n_mg, ntaps = a.ntaps;
+  h16* xs = reinterpret_cast<h16*>(lds_raw);  // [NCH][hi | lo][x_rows][CKP]
+  float* ys = reinterpret_cast<float*>(xs + (size_t)NCH * 2 * XPL);  // [N1][MGF]
+  float* bs = ys + N1 * MGF;                  // [NG * MG]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wslot = (int)blockIdx.x, nslots = (int)gridDim.x;
+  const int my_tiles = (a.n_ntiles - wslot + nslots - 1) / nslots;
+
+  for (int i = tid; i < NG * MG; i += 64 * (4 + CTM_NL)) bs[i] = (a.bias && i < a.c_out) ? a.bias[i] : 0.f;
+  __syncthreads();  // Z
+
+  auto tile_of = [&](int it, int& b, int& t0) __attribute__((always_inline)) {
+    const int nt = wslot + it * nslots;
+    b = nt / a.tiles_per_item;
+    t0 = (nt - b * a.tiles_per_item) * N1;
+  };
+
+  if (wave >= 4) {
+    // ------------------------------ support waves ------------------------------
+    constexpr int PPR = CK / 4;
+    constexpr int NSL = 64 * CTM_NL;
+    constexpr int LBX = ((N1 + (CK == 64 ? 0 : CTM_MAX_HALO)) * PPR + NSL - 1) / NSL;
+    constexpr int YPR = MG / 4;
+    constexpr int WB = 4;
+    const float slope = a.in_slope;
+    const int total = a.x_rows * PPR;
+    const int ltid = tid - 256;
+    const bool w_loads = a.res != nullptr || a.accumulate || a.gate != nullptr;
+    int xrow[LBX];
+    unsigned xcol[LBX], xlds[LBX];
+#pragma unroll
+    for (int i = 0; i < LBX; ++i) {
+      const int idx = min(i * NSL + ltid, total - 1);
+      xrow[i] = idx / PPR;
+      const unsigned pc = (unsigned)(idx - xrow[i] * PPR);
+      if (a.x_split) {
+        const unsigned plane = pc / (PPR / 2), c8 = (pc % (PPR / 2)) * 8u;
+        xcol[i] = plane * 0x10000u + c8;
+        xlds[i] = plane * (unsigned)XPL + (unsigned)xrow[i] * CKP + c8;
+      } else {
+        xcol[i] = pc * 4u;
+        xlds[i] = (unsigned)xrow[i] * CKP + pc * 4u;
+      }
+    }
+    auto issue_x = [&](int it, int c, f32x4 (&vx)[LBX]) __attribute__((always_inline)) {
+      int b, t0;
+      tile_of(it, b, t0);
+      const int Tb = ctm_valid_len(a, b);
+      const int tx0 = t0 - a.pad;
+      if (a.x_split) {
+        const h16* xh = reinterpret_cast<const h16*>(a.x) + (long long)b * a.T * 2 * a.c_in;
+        const __amdgpu_buffer_rsrc_t rs = tm_rsrc(xh, (long long)Tb * 2 * a.c_in * 2);
+#pragma unroll
+        for (int i = 0; i < LBX; ++i) {
+          const int plane = (int)(xcol[i] >> 16), ch = c * CK + (int)(xcol[i] & 0xffffu);
+          vx[i] = tm_load16(rs, (unsigned)(((tx0 + xrow[i]) * 2 + plane) * a.c_in + ch) * 2u);
+        }
+        return;
+      }
+      const __amdgpu_buffer_rsrc_t rs = tm_rsrc(a.x + (long long)b * a.x_bstride, Tb > 0 ? ((long long)(Tb - 1) * a.x_row_stride + a.c_in) * 4 : 0);
+#pragma unroll
+      for (int i = 0; i < LBX; ++i) vx[i] = tm_load16(rs, (unsigned)((tx0 + xrow[i]) * a.x_row_stride + c * CK + (int)xcol[i]) * 4u);
+    };
+    auto commit_x = [&](int c, const f32x4 (&vx)[LBX]) __attribute__((always_inline)) {
+      h16* buf = xs + (size_t)c * 2 * XPL;
+      if (a.x_split) {
+#pragma unroll
+        for (int i = 0; i < LBX; ++i) *reinterpret_cast<f32x4*>(buf + xlds[i]) = vx[i];
+        return;
+      }
+#pragma unroll
+      for (int i = 0; i < LBX; ++i) {
+        float l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) l[e] = slope == 1.f ? vx[i][e] : fmaxf(vx[i][e], vx[i][e] * slope);
+        mb_h2 h0, l0, h1, l1;
+        split_pair(l[0], l[1], h0, l0);
+        split_pair(l[2], l[3], h1, l1);
+        const h16x4 hi = {h0[0], h0[1], h1[0], h1[1]}, lo = {l0[0], l0[1], l1[0], l1[1]};
+        *reinterpret_cast<h16x4*>(buf + xlds[i]) = hi;
+        *reinterpret_cast<h16x4*>(buf + XPL + xlds[i]) = lo;
+      }
+      if (a.range_events) {
+        int n_out = 0;
+#pragma unroll
+        for (int i = 0; i < LBX; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) n_out += (i * NSL + ltid < total && !(fabsf(vx[i][e]) <= 65504.f)) ? 1 : 0;
+        if (n_out) atomicAdd(a.range_events, (unsigned)n_out);
+      }
+    };
+    // the result tile of channel group g of tile `it`: ys -> epilogue -> HBM (conv_split_tm_kernel's write_part, whole tile)
+    auto write_group = [&](int it, int g) __attribute__((always_inline)) {
+      int b, t0;
+      tile_of(it, b, t0);
+      const int Tb = ctm_valid_len(a, b);
+      const int rows = max(0, min(N1, Tb - t0));
+      const int m0 = g * MG;
+      const long long o = (long long)b * a.y_bstride + (long long)t0 * a.c_out + m0;
+      const float* rb = a.res ? a.res + o : nullptr;
+      const float* gb = a.gate ? a.gate + o : nullptr;
+      float* yb = a.y + o;
+      h16* sb = a.ysplit ? a.ysplit + ((long long)b * a.T + t0) * 2 * a.c_out + m0 : nullptr;
+      const int ytotal = rows * YPR, mcols = min(MG, a.c_out - m0);
+      if (ytotal <= 0) return;
+      constexpr int BSZ = NSL * WB;
+      for (int base = 0; base < ytotal; base += BSZ) {
+        f32x4 rx[WB], ry[WB], rg[WB];
+        unsigned goff[WB];
+        bool ok[WB];
+#pragma unroll
+        for (int i = 0; i < WB; ++i) {
+          const int idx = base + i * NSL + ltid;
+          const unsigned idc = (unsigned)min(idx, ytotal - 1);
+          const unsigned row = idc / YPR, pc = idc - row * YPR;
+          ok[i] = idx < ytotal && (int)(pc * 4) < mcols;
+          goff[i] = row * (unsigned)a.c_out + min(pc * 4u, (unsigned)max(mcols - 4, 0));
+          if (w_loads) {
+            rx[i] = rb ? *reinterpret_cast<const f32x4*>(rb + goff[i]) : (f32x4)0.f;
+            ry[i] = a.accumulate ? *reinterpret_cast<const f32x4*>(yb + goff[i]) : (f32x4)0.f;
+            rg[i] = gb ? *reinterpret_cast<const f32x4*>(gb + goff[i]) : (f32x4)0.f;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < WB; ++i) {
+          const int idx = base + i * NSL + ltid;
+          const unsigned idc = (unsigned)min(idx, ytotal - 1);
+          const unsigned row = idc / YPR, pc = idc - row * YPR;
+          const f32x4 hv = *reinterpret_cast<const f32x4*>(ys + row * MGF + pc * 4);
+          const unsigned mc = (unsigned)m0 + min(pc * 4u, (unsigned)max(mcols - 4, 0));
+          f32x4 psc = (f32x4)1.f, psh = (f32x4)0.f;
+          if (a.post_scale) { psc = *reinterpret_cast<const f32x4*>(a.post_scale + mc); psh = *reinterpret_cast<const f32x4*>(a.post_shift + mc); }
+          f32x4 o4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float f = hv[e];
+            if (a.out_act == 4) {
+              const float gt = rg[i][e];
+              f = gt * fmaxf(f, 0.f) + (1.f - gt) * rx[i][e];
+            } else {
+              if (w_loads) f += rx[i][e];
+              f *= a.out_scale;
+              if (a.out_act == 1) f = fmaxf(f, 0.f);
+              else if (a.out_act == 2) f = tanhf(f);
+              else if (a.out_act == 3) f = sigmoidf_(f);
+              if (a.post_scale) f = fmaf(f, psc[e], psh[e]);
+              if (w_loads) f += ry[i][e];
+            }
+            o4[e] = f;
+          }
+          if (ok[i] && a.ysplit) {
+            mb_h2 h0, l0, h1, l1;
+            split_pair(o4[0], o4[1], h0, l0);
+            split_pair(o4[2], o4[3], h1, l1);
+            const h16x4 hi = {h0[0], h0[1], h1[0], h1[1]}, lo = {l0[0], l0[1], l1[0], l1[1]};
+            h16* sp = sb + (size_t)row * 2 * a.c_out + min(pc * 4u, (unsigned)max(mcols - 4, 0));
+            *reinterpret_cast<h16x4*>(sp) = hi;
+            *reinterpret_cast<h16x4*>(sp + a.c_out) = lo;
+          }
+          if (ok[i]) {
+            if (mcols >= 4) *reinterpret_cast<f32x4*>(yb + goff[i]) = o4;
+            else
+              for (int e = 0; e < mcols; ++e) yb[row * (unsigned)a.c_out + e] = o4[e];
+          }
+        }
+      }
+    };
+    f32x4 vxA[LBX], vxB[LBX];
+    if (my_tiles > 0) issue_x(0, 0, vxA);
+    for (int it = 0; it < my_tiles; ++it) {
+      // (the previous tile's last result tile has left ys and every MMA wave is behind its last chunk: the window may be overwritten)
+      for (int c = 0; c < NCH; c += 2) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        issue_x(it, c + 1, vxB);
+        commit_x(c, vxA);
+        __syncthreads();  // B_c: chunk c is in place
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        if (c + 2 < NCH) issue_x(it, c + 2, vxA);
+        else if (it + 1 < my_tiles) issue_x(it + 1, 0, vxA);  // (flies through the other groups; laid down behind the tile's last barrier)
+        commit_x(c + 1, vxB);
+        __syncthreads();  // B_{c+1}
+      }
+      for (int g = 0; g < NG; ++g) {
+        __syncthreads();  // YF_g: ys is free (the write-out of the group before is done: this wave arrives here behind it)
+        __syncthreads();  // Y_g: group g's result tile is staged
+        write_group(it, g);
+      }
+    }
+    return;
+  }
+
+  // ------------------------------ MMA waves ------------------------------
+  const int wm = wave / WN, wn = wave % WN;
+  const int mt0 = wm * MT;
+  const int NFT = NCH * ntaps;  // flat taps of ONE channel group's stream
+  const size_t tile_stride = (size_t)NFT * KB * 2 * 64;  // h16x8 units per 32-row tile
+  const h16x8* wbase = reinterpret_cast<const h16x8*>(a.w) + lane;
+  const h16x8* wp[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) wp[i] = wbase + (size_t)(mt0 + i) * tile_stride;
+  int grp_ring = 0;  // the channel group whose stream the refills read
+  auto sp_wrap = [&]() __attribute__((always_inline)) {
+    grp_ring = grp_ring + 1 == NG ? 0 : grp_ring + 1;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) wp[i] = wbase + (size_t)(grp_ring * (MG / 32) + mt0 + i) * tile_stride;
+  };
+  h16x8 ring[TD][KB][MT][2];
+#pragma unroll
+  for (int s = 0; s < TD; ++s)
+#pragma unroll
+    for (int u = 0; u < KB; ++u)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) ring[s][u][i][p] = wp[i][((size_t)(s * KB + u) * 2 + p) * 64];  // (NFT >= 2: launch_ctm_res)
+  int ftn = TD;
+  if (ftn == NFT) { ftn = 0; sp_wrap(); }
+  constexpr bool DUAL = MT == 1 && CTM_DUAL != 0;
+  f32x16 acc[MT][NTW], acl[MT][NTW];
+  const h16 k2m11 = (h16)(1.f / 2048.f);
+  const int lrow = wn * (NTW * 32) + (lane & 31);
+  const int lcol = (lane >> 5) * 8;
+  const int x_tapstep = a.dil * CKP;
+  const float us = a.us;
+  for (int it = 0; it < my_tiles; ++it) {
+    for (int g = 0; g < NG; ++g) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // a known scoreboard at the head of a group keeps the compiler's counted waits exact
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) { acc[i][n][q] = 0.f; if (DUAL) acl[i][n][q] = 0.f; }
+#define CR_XB(C_) (xs + (size_t)(C_) * 2 * XPL + lrow * CKP + lcol)
+      for (int c = 0; c < NCH; c += 2) {
+        if (g == 0) __syncthreads();  // B_c
+        SP_CHUNK(0, CR_XB(c), CKP, x_tapstep, XPL);
+        if (g == 0) __syncthreads();  // B_{c+1}
+        SP_CHUNK(1, CR_XB(c + 1), CKP, x_tapstep, XPL);
+      }
+#undef CR_XB
+      __syncthreads();  // YF_g
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+          const int row = lrow + n * 32;
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const int co0 = (mt0 + i) * 32 + 8 * q4 + 4 * (lane >> 5);
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(bs + g * MG + co0);
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(DUAL ? fmaf(acl[i][n][4 * q4 + e], 1.f / 2048.f, acc[i][n][4 * q4 + e]) : acc[i][n][4 * q4 + e], us, bq[e]);
+            *reinterpret_cast<f32x4*>(ys + row * MGF + co0) = v;
+          }
+        }
+      __syncthreads();  // Y_g
+    }
   }
 }
 
@@ -448,6 +728,38 @@ static int launch_ctm(ConvTmK k, int batch, hipStream_t s) {
     }
   }
 #endif
+  return MB_OK;
+}
+
+
+template <class G>
+static size_t ctm_res_lds_bytes(int ntaps, int dil, int nch, int n_mg) {
+  const int x_rows = G::N1 + (ntaps - 1) * dil;
+  return (size_t)nch * 2 * x_rows * G::CKP * sizeof(h16) + (size_t)G::N1 * G::MGF * sizeof(float) + (size_t)n_mg * G::MG * sizeof(float);
+}
+
+// -> MB_OK after the launch, or +1 when this instance does not fit (the caller falls back to the ring kernel)
+template <int CK, int MT, int WN, int NTW>
+static int launch_ctm_res(ConvTmK k, int batch, hipStream_t s) {
+  using G = CtmGeom<CK, MT, WN, NTW>;
+  k.x_rows = G::N1 + (k.ntaps - 1) * k.dil;
+  k.tiles_per_item = cdiv(k.T, G::N1);
+  k.n_ntiles = k.tiles_per_item * batch;
+  k.n_mg = cdiv(k.c_out, G::MG);
+  k.nbuf = k.NCH;
+  const size_t lds_bytes = ctm_res_lds_bytes<G>(k.ntaps, k.dil, k.NCH, k.n_mg);
+  if (lds_bytes > (size_t)160 * 1024 || k.NCH * k.ntaps < 2 || (CK != 64 && (k.ntaps - 1) * k.dil > CTM_MAX_HALO) || (CK == 64 && k.ntaps != 1)) return 1;
+  static std::atomic<unsigned long long> attr_done{0};
+  int dev = 0;
+  MB_HIP(hipGetDevice(&dev));
+  const unsigned long long bit = dev >= 0 && dev < 64 ? 1ull << dev : 0ull;
+  if (!bit || !(attr_done.load(std::memory_order_acquire) & bit)) {
+    MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_tm_res_kernel<CK, MT, WN, NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done.fetch_or(bit, std::memory_order_release);
+  }
+  const int grid = std::max(1, std::min(k.n_ntiles, ctm_cus()));
+  hipLaunchKernelGGL((conv_split_tm_res_kernel<CK, MT, WN, NTW>), dim3(grid), dim3(64 * (4 + CTM_NL)), lds_bytes, s, k);
+  MB_HIP(hipGetLastError());
   return MB_OK;
 }
 
@@ -558,6 +870,22 @@ extern "C" int mb_conv_split_tm(const mb_conv_split_tm_args* a, mb_stream_t stre
   const bool wide_chunk = a->ksize == 1 && a->c_in % 128 == 0;
   if (wide_chunk && mg >= 128) k.NCH = a->c_in / 64;
   const int tile = diag_int("ctm_tile", 0);  // A/B: 1 = 256 x 96, 2 = 256 x 64, 3 = 128 x 128
+  // Several channel groups over enough position tiles to fill the chip: the resident-window kernel (the window is staged once per tile
+  // instead of once per (tile, group)); its instances trade rows per tile for the LDS the whole window needs.  (A/B: MBHIP_DIAG=ctm_nores)
+  if (tile == 0 && !diag_int("ctm_nores") && mg >= 128 && cdiv(a->c_out, mg) >= 2) {
+    const long long rows = (long long)a->t * a->batch;
+    int r = 1;
+    if (wide_chunk) {
+      if (mg == 256 && rows >= 32ll * cus / 2) r = launch_ctm_res<64, 2, 1, 1>(k, a->batch, s);
+      if (r == 1 && mg == 128 && rows >= 64ll * cus / 2) r = launch_ctm_res<64, 1, 1, 2>(k, a->batch, s);
+    } else {
+      if (mg == 256 && rows >= 64ll * cus / 2) r = launch_ctm_res<32, 2, 1, 2>(k, a->batch, s);
+      if (r == 1 && mg == 256 && rows >= 32ll * cus / 2) r = launch_ctm_res<32, 2, 1, 1>(k, a->batch, s);
+      if (r == 1 && mg == 128 && rows >= 128ll * cus / 2) r = launch_ctm_res<32, 1, 1, 4>(k, a->batch, s);
+      if (r == 1 && mg == 128 && rows >= 64ll * cus / 2) r = launch_ctm_res<32, 1, 1, 2>(k, a->batch, s);
+    }
+    if (r <= 0) return r;
+  }
   if (mg == 256) {
     const long long c96 = cost(256, 96), c64 = cost(256, 64), c128 = cost(128, 128);
     int pick = (c64 < c96 && c64 <= c128) ? 2 : (c128 < c96 && c128 < c64 ? 3 : 1);

@@ -340,6 +340,7 @@ void resblock_pair_split_kernel(ResPairSK a) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) ring[s][u][i][p] = wp[i][((size_t)(s * KB + u) * 2 + p) * 64];
   int ftn = TD;  // next flat tap to prefetch
+  auto sp_wrap = []() {};
 
   constexpr bool DUAL = MT == 1 && SPAIR_DUAL != 0;  // split_tm.h: a second accumulator set instead of the third weight image
   f32x16 acc[MT][NTW], acl[MT][NTW];

@@ -1,7 +1,8 @@
 // The product loop shared by the time-major split kernels (resblock_pair_split.hip, conv_split_tm.hip): error-compensated fp16 MFMA
 // products of a tap over LDS-resident hi / scaled-lo B planes and a register ring of {hi, lo} weight fragments.
 // The including kernel defines, with these names: constexpr KB, MT, NTW, TD (= 2); h16x8 ring[TD][KB][MT][2]; const h16x8* wp[MT];
-// int ftn; const int NFT, ntaps; f32x16 acc[MT][NTW], acl[MT][NTW]; constexpr bool DUAL; const h16 k2m11 = 2^-11; and SPAIR_DBG (0 in the
+// int ftn; auto sp_wrap (a callable: the stream wrapped -- empty, or the resident conv kernel's switch to the next channel group);
+// const int NFT, ntaps; f32x16 acc[MT][NTW], acl[MT][NTW]; constexpr bool DUAL; const h16 k2m11 = 2^-11; and SPAIR_DBG (0 in the
 // product).  DUAL (instances with one M tile per wave, where the registers allow a second accumulator set): the product of the scaled
 // low activation half runs on the plain high weight fragment into acl, and the epilogue adds 2^-11 acl -- the wave no longer makes the
 // third weight image (4 v_pk_mul_f16 per k-step beside 6-12 MFMAs).
@@ -73,7 +74,7 @@ typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
       __builtin_amdgcn_sched_barrier(0);                                                           \
       _Pragma("unroll") for (int n = 0; n < NTW; ++n) { bhc_[n] = bhn_[n]; blc_[n] = bln_[n]; }    \
     }                                                                                              \
-    ftn = ftn + 1 == NFT ? 0 : ftn + 1;                                                            \
+    if (ftn + 1 == NFT) { ftn = 0; sp_wrap(); } else ++ftn;  /* (sp_wrap: the includer's hook at the end of the circular stream) */ \
   } while (0)
 
 // a chunk = ntaps taps (ntaps odd); S0 = ring slot of its first tap
