@@ -168,6 +168,33 @@ def test_one_channel_conv_is_exact_fp32(cuda, lib, B, Cin, T, k, dil, slope, act
         assert torch.isnan(got[b, n:]).all()
 
 
+@pytest.mark.parametrize("B,Cin,M,T,k,split", [(8, 256, 640, 600, 3, False), (5, 512, 1280, 1000, 3, False), (9, 512, 1024, 500, 1, True),
+                                               (8, 80, 1024, 600, 9, False), (6, 256, 384, 700, 1, False)])
+def test_resident_window_kernel_equals_the_ring_kernel(cuda, lib, monkeypatch, B, Cin, M, T, k, split):
+    """Convs to several channel groups over enough rows run conv_split_tm_res_kernel (the window laid down once per position tile,
+    every group computed from it); MBHIP_DIAG=ctm_nores keeps them on the per-group ring kernel.  Same sums per output: bit-identical,
+    residual / accumulate / tanh epilogue, a ragged batch and a narrower last channel group (384 = 256 + 128) included."""
+    x = _rand(B, Cin, T, seed=1)
+    w = _rand(M, Cin, k, seed=2) / (Cin * k) ** 0.5
+    b = 0.1 * _rand(M, seed=3)
+    res = _rand(B, M, T, seed=4)
+    acc = _rand(B, M, T, seed=5)
+    valid = [T - 11 * (i % 4) for i in range(B)]
+    outs = []
+    for diag in ("", "ctm_nores"):
+        monkeypatch.setenv("MBHIP_DIAG", diag)
+        y0 = hiputil.conv_split_tm_hip(x, w, b, pad=(k - 1) // 2, in_slope=1.0 if split else 0.1, x_split=split)
+        y1 = hiputil.conv_split_tm_hip(x, w, b, pad=(k - 1) // 2, in_slope=1.0 if split else 0.1, x_split=split, res=res, out_act=2,
+                                       out_scale=0.5, accumulate_into=acc, valid=valid)
+        outs.append((y0, y1))
+    monkeypatch.delenv("MBHIP_DIAG")
+    assert torch.equal(outs[0][0], outs[1][0])
+    for i in range(B):
+        assert torch.equal(outs[0][1][i, :, :valid[i]], outs[1][1][i, :, :valid[i]])
+    xin = x.double() if split else F.leaky_relu(x.double(), 0.1)
+    _check(outs[0][0], F.conv1d(xin, w.double(), b.double(), padding=(k - 1) // 2))
+
+
 def test_rejects_bad_shapes(cuda, lib):
     from mockingbird_amd._lib import MbHipError
     with pytest.raises(MbHipError, match="unsupported"):
