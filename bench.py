@@ -870,8 +870,8 @@ def main():
                     "workload": f"HiFi-GAN V1 16k generator forward, batch 32 x mel (80,200), {dt}"
                                 + (" (fp16 storage, fp16 MFMA, fp32 accumulate)" if dt == "f16" else
                                    " storage, fp32-grade results: error-compensated fp16 MFMA (x = xh + 2^-11 xl, w = wh + wl, 3 products), "
-                                   "peak = 2500 / 3 TFLOP/s; round 4: the 32- and 64-channel stages as fused ResBlock launches "
-                                   "(resblock_stage_f32.hip: LDS-resident hi / lo operands, fp32 residual in registers)"
+                                   "peak = 2500 / 3 TFLOP/s; round 6: the whole generator on time-major tensors (resblock_pair_split.hip: one "
+                                   "ResBlock unit per launch, 4 MMA + 4-8 support waves; conv_split_tm.hip: every other conv)"
                                    if split else " storage, fp32-input MFMA"),
                     "dtype": dt, "value": 32 * 200 * 200 / (ms * 1e-3), "unit": "samples/s",
                     "x_realtime": 32 * 200 * 200 / (ms * 1e-3) / 16000.0, "ms_per_batch": ms,
