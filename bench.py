@@ -979,7 +979,7 @@ def main():
                 "encoder_ms": enc_ms, "postnet_ms": post_ms,
                 # SURVEY 8(d) "Tacotron CBHG postnet": MFMA-bound, 16.1 MFLOP per frame; its convs run the error-compensated fp16 products
                 # (three MFMA products per algorithmic one: ceiling 2500 / 3 = 833 TFLOP/s)
-                "postnet_roofline": ({"bound": "mfma", "kernel": "CBHG postnet + post_proj (tacotron.hip cbhg_forward: conv bank, two projections, 4 highways, "
+                "postnet_roofline": ({"bound": "mfma", "kernel": "CBHG postnet + post_proj (tacotron.hip cbhg_forward_tm on conv_split_tm.hip: conv bank as one conv, two projections, 4 highways, "
                                                                   "bidirectional GRU scan gru_scan.h, post_proj) over 32 x 400 frames",
                                       "achieved": 16.1e6 * 400 * 32 / (post_ms * 1e-3) / 1e12, "peak": MFMA_F16_PEAK_TFLOPS / 3.0, "unit": "TFLOP/s",
                                       "frac": 16.1e6 * 400 * 32 / (post_ms * 1e-3) / 1e12 / (MFMA_F16_PEAK_TFLOPS / 3.0),
