@@ -67,12 +67,20 @@ def gen_wavs(synthesizer, vocoder, requests: List[Tuple[List[str], np.ndarray]],
             flat_embeds += [embed] * len(texts)
             owner += [i] * len(texts)
         skw = {"chunk_size": chunk_size} if chunk_size else {}  # additive keyword of the Synthesizer facade (utterances per decoder loop)
+        sparams = inspect.signature(synthesizer.synthesize_spectrograms).parameters
+        on_device = "device_out" in sparams and getattr(vocoder, "accepts_device_mels", False)
+        if on_device:  # the spectrograms stay in HBM between the two facades
+            skw["device_out"] = True
         t0 = time.perf_counter()
         specs = synthesizer.synthesize_spectrograms(flat_texts, flat_embeds, style_idx=style_idx,
                                                     min_stop_token=min_stop_token, steps=steps, **skw)
         t_syn = time.perf_counter() - t0
         per_req = {i: [s for s, o in zip(specs, owner) if o == i] for i in mine}
-        mels = [np.concatenate(per_req[i], axis=1) for i in mine]
+        if on_device:
+            import torch
+            mels = [per_req[i][0] if len(per_req[i]) == 1 else torch.cat(per_req[i], dim=1) for i in mine]
+        else:
+            mels = [np.concatenate(per_req[i], axis=1) for i in mine]
         kw = dict(pcm16=pcm16, breaks=[[s.shape[1] for s in per_req[i]] for i in mine],
                   break_hop=synthesizer.hparams.hop_size, device_out=True)
         params = inspect.signature(vocoder.infer_waveform_batch).parameters

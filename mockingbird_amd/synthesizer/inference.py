@@ -148,8 +148,9 @@ class Synthesizer:
             print("Loaded synthesizer \"%s\" trained to step %d" % (self.model_fpath.name, self._step))
 
     def synthesize_spectrograms(self, texts: List[str], embeddings: Union[np.ndarray, List[np.ndarray]],
-                                return_alignments=False, style_idx=0, min_stop_token=5, steps=2000, chunk_size=None):
-        """Reference signature (inference.py:75) plus one additive keyword: chunk_size = utterances per decoder loop
+                                return_alignments=False, style_idx=0, min_stop_token=5, steps=2000, chunk_size=None, device_out=False):
+        """Reference signature (inference.py:75) plus two additive keywords: device_out = the (trimmed) spectrograms stay in HBM as
+        device tensors for a vocoder facade on the same GPU (pipeline.gen_wavs) instead of going through numpy; chunk_size = utterances per decoder loop
         (default hparams.synthesis_batch_size = 16, hparams.py:56, as the reference chunks).  The encoder runs on the
         device too, so nothing limits a chunk to 16: 32 utterances in ONE loop cost about what 16 do (the loop is
         latency-bound), two chunks of 16 cost twice that.  The batch-wide stop rule (tacotron.py:275) then spans the
@@ -160,13 +161,14 @@ class Synthesizer:
         texts = to_pinyin(texts)
         print("Synthesizing " + str(texts))
         inputs = [text_to_sequence(text, hparams.tts_cleaner_names) for text in texts]
-        specs, alignments = self.synthesize_from_tokens(inputs, embeddings, style_idx, min_stop_token, steps, chunk_size=chunk_size)
+        specs, alignments = self.synthesize_from_tokens(inputs, embeddings, style_idx, min_stop_token, steps, chunk_size=chunk_size,
+                                                        device_out=device_out)
         if self.verbose:
             print("\n\nDone.\n")
         return (specs, alignments) if return_alignments else specs
 
     def synthesize_from_tokens(self, inputs, embeddings, style_idx=0, min_stop_token=5, steps=2000, enc_masks=None,
-                               dropout=None, seed=None, chunk_size=None):
+                               dropout=None, seed=None, chunk_size=None, device_out=False):
         """inference.py:104-139 from token id sequences (benchmarks feed these directly).  seed=None: every
         chunk draws its own RNG key from torch's global generator (fresh_seed); an explicit seed is advanced
         per chunk so that no two chunks share dropout masks."""
@@ -191,6 +193,17 @@ class Synthesizer:
             _, mels, alignments = self._model.generate(chars, speaker_embeddings, style_idx=style_idx,
                                                        min_stop_token=min_stop_token, steps=steps,
                                                        enc_masks=enc_masks, dropout=dropout, seed=chunk_seed)
+            if device_out:  # the same trim from the per-frame maxima (B x T floats cross PCIe instead of B x 80 x T), views of the device tensor
+                mels = mels.detach()
+                fmax = mels.amax(dim=1).cpu().numpy()
+                for b in range(mels.shape[0]):
+                    n = fmax.shape[1]
+                    while fmax[b, n - 1] < hparams.tts_stop_threshold:  # (raises IndexError on an all-silent mel, as the reference does)
+                        n -= 1
+                        if n == 0:
+                            raise IndexError("index -1 is out of bounds for axis 1 with size 0")
+                    specs.append(mels[b, :, :n])
+                continue
             mels = mels.detach().cpu().numpy()
             for m in mels:
                 while np.max(m[:, -1]) < hparams.tts_stop_threshold:  # trim silence (inference.py:136-137)

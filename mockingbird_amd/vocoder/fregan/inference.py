@@ -26,6 +26,9 @@ def infer_waveform(mel, progress_callback=None):
     return _facade.infer_waveform(mel, progress_callback)
 
 
+accepts_device_mels = True  # (pipeline.gen_wavs: mels may be device tensors)
+
+
 def infer_waveform_batch(mels, progress_callback=None, **kw):
     """Additive API: see GanFacade.infer_waveform_batch (normalize / pcm16 / breaks / device_out keywords)."""
     return _facade.infer_waveform_batch(mels, progress_callback, **kw)

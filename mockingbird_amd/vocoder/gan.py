@@ -131,6 +131,8 @@ class GanGenerator:
 class GanFacade:
     """Module-global-singleton semantics of the reference inference modules."""
 
+    accepts_device_mels = True  # infer_waveform_batch takes device tensors as well as numpy mels (pipeline.gen_wavs keeps them in HBM)
+
     def __init__(self, kind: int, default_config: str, name: str):
         self.kind, self.default_config, self.name = kind, default_config, name
         self.generator = None

@@ -255,6 +255,11 @@ def test_chunk_size_keyword_runs_one_loop(model, tmp_path):
     assert len(two) == 20 and np.array_equal(two[0], m0)
     with pytest.raises(ValueError):
         syn.synthesize_from_tokens(seqs, emb, chunk_size=-1)
+    # additive keyword device_out: the same trimmed spectrograms as device tensors (pipeline.gen_wavs hands them to the vocoder in HBM)
+    dev_specs, _ = syn.synthesize_from_tokens(seqs, emb, style_idx=-1, min_stop_token=11, steps=steps, seed=7, chunk_size=32, device_out=True)
+    assert len(dev_specs) == 20 and all(torch.is_tensor(d) and d.is_cuda for d in dev_specs)
+    for a, d in zip(one, dev_specs):
+        assert np.array_equal(a, d.cpu().numpy())
 
 
 def test_baseline_config2_shape_properties(model):
