@@ -1019,10 +1019,15 @@ extern "C" int mb_conv_c1_tm(const float* d_x, const float* d_w, float bias, flo
   const size_t lds = sizeof(float) * ((size_t)ksize * c_in + (size_t)(mb::C1_ROWS + (ksize - 1) * dilation) * (c_in + 4));
   MB_REQUIRE(lds <= 160 * 1024, "conv_c1_tm: window of %zu B does not fit in LDS (c_in=%d ksize=%d dilation=%d)", lds, c_in, ksize, dilation);
   MB_REQUIRE((long long)t * c_in * 4 < 0xffffffffll, "conv_c1_tm: an item of %d x %d floats is beyond a buffer descriptor's 4 GB", t, c_in);
-  static std::atomic<size_t> attr_bytes{0};
-  if (lds > 64 * 1024 && lds > attr_bytes.load()) {
-    MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mb::conv_c1_tm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_bytes.store(lds);
+  if (lds > 64 * 1024) {  // (per device: the attribute belongs to the function on the current device)
+    static std::atomic<unsigned long long> attr_done{0};
+    int dev = 0;
+    MB_HIP(hipGetDevice(&dev));
+    const unsigned long long bit = dev >= 0 && dev < 64 ? 1ull << dev : 0ull;
+    if (!bit || !(attr_done.load(std::memory_order_acquire) & bit)) {
+      MB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mb::conv_c1_tm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_done.fetch_or(bit, std::memory_order_release);
+    }
   }
   const int tiles = mb::cdiv(t, mb::C1_ROWS);
   hipLaunchKernelGGL(mb::conv_c1_tm_kernel, dim3((unsigned)(batch * tiles)), dim3(256), lds, (hipStream_t)stream, d_x, d_w, bias, d_y, t, c_in, ksize,
